@@ -1,0 +1,203 @@
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference (CPU, this container).
+
+Run once here (the reference never travels to the GPU box; only the .npz fixtures do):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Harness-side shims for the transformers 4.39 -> 5.15 skew are those listed in SURVEY.md §8c:
+attn_implementation="eager", and setattr of num_fbanks / conv_padding / context_awareness_type on
+the config.  Reference files are untouched.  Weights come from huggingface_asr_amd.synth (seeded,
+counter-based), so fixtures store only seeds + outputs (+ a weight checksum).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/src")
+
+from huggingface_asr_amd import synth  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+TINY = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+            conv_dim=[32, 32], conv_kernel=[3, 3], conv_stride=[2, 2], vocab_size=50)
+BASE = dict(hidden_size=512, num_hidden_layers=16, num_attention_heads=4, intermediate_size=2048,
+            conv_dim=[256, 256], conv_kernel=[3, 3], conv_stride=[2, 2], vocab_size=5000)
+SMALL = dict(hidden_size=256, num_hidden_layers=12, num_attention_heads=4, intermediate_size=1024,
+             conv_dim=[256, 256], conv_kernel=[3, 3], conv_stride=[2, 2], vocab_size=5000)
+
+
+def build_reference(cfg_kwargs, **extra):
+    from models.encoders.e_branchformer import Wav2Vec2EBranchformerConfig, Wav2Vec2EBranchformerForCTC
+
+    cfg = Wav2Vec2EBranchformerConfig(**cfg_kwargs, attn_implementation="eager", ctc_zero_infinity=True,
+                                      ctc_loss_reduction="mean", layerdrop=0.0, **extra)
+    for k, v in dict(num_fbanks=80, conv_padding=[1, 1], context_awareness_type=None).items():
+        setattr(cfg, k, v)
+    model = Wav2Vec2EBranchformerForCTC(cfg).eval()
+    return cfg, model
+
+
+def load_seeded(model, seed):
+    # parameters only: buffers (e.g. the rotary `embed_positions.inv_freq`) keep their computed values
+    new = {k: torch.from_numpy(synth.init_param(seed, k, tuple(v.shape))) for k, v in model.named_parameters()}
+    missing, unexpected = model.load_state_dict(new, strict=False)
+    assert not unexpected and all("inv_freq" in m for m in missing), (missing, unexpected)
+    return float(sum(v.double().sum() for v in new.values()))
+
+
+def synth_feats(seed, B, T, lengths):
+    x = synth.normal(seed, "feats", (B, T, 80), 1.0)
+    am = np.zeros((B, T), dtype=np.int64)
+    for b, n in enumerate(lengths):
+        am[b, :n] = 1
+        x[b, n:] = 0.0
+    return x, am
+
+
+def synth_labels(seed, B, U, vocab, tgt_lens):
+    lab = synth.labels(seed, B, U, vocab, lo=0)
+    for b, n in enumerate(tgt_lens):
+        lab[b, n:] = -100
+    return lab
+
+
+def run_encoder_case(name, cfg_kwargs, seed, B, T, lengths, U, tgt_lens, full=True, with_bf16=False, **extra):
+    cfg, model = build_reference(cfg_kwargs, **extra)
+    wsum = load_seeded(model, seed)
+    x, am = synth_feats(seed, B, T, lengths)
+    lab = synth_labels(seed, B, U, cfg.vocab_size, tgt_lens)
+    xt, amt, labt = torch.from_numpy(x), torch.from_numpy(am), torch.from_numpy(lab)
+    with torch.no_grad():
+        out = model(xt.clone(), attention_mask=amt, labels=labt, output_hidden_states=True)
+    logits = out.logits.float().numpy()
+    hs = [h.float().numpy() for h in out.hidden_states]
+    rec = dict(seed=seed, weight_sum=wsum, lengths=np.array(lengths), tgt_lens=np.array(tgt_lens),
+               shape=np.array([B, T, U]), loss=float(out.loss),
+               outer_lens=model._get_feat_extract_output_lengths(amt.sum(-1)).numpy(),
+               inner_lens=model.wav2vec2._get_feat_extract_output_lengths(amt.sum(-1)).numpy())
+    if full:
+        rec["logits"] = logits
+        rec["last_hidden"] = hs[-1]
+        for i, h in enumerate(hs[:-1]):
+            rec[f"layer_in_{i}"] = h
+    else:
+        rec["logits_slice"] = logits[:, ::25, :64].copy()
+        rec["logits_blank"] = logits[:, :, -1].copy()
+        rec["logits_absmax"] = float(np.abs(logits).max())
+        rec["logits_std"] = float(logits.std())
+        rec["layer_norms"] = np.array([float(np.linalg.norm(h)) for h in hs])
+        rec["last_hidden_slice"] = hs[-1][:, ::25, :64].copy()
+    if with_bf16:
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            ob = model(xt.clone(), attention_mask=amt, labels=labt)
+        lb = ob.logits.float().numpy()
+        rec["bf16_loss"] = float(ob.loss)
+        rec["bf16_max_dlogit"] = float(np.abs(lb - logits).max())
+        rec["bf16_mean_dlogit"] = float(np.abs(lb - logits).mean())
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
+    print(name, "loss", rec["loss"], "logit std", float(logits.std()), {k: v for k, v in rec.items() if k.startswith("bf16")})
+
+
+def run_fbank_cases():
+    from utilities.feature_extractors import CustomFeatureExtractor
+
+    fe = CustomFeatureExtractor(feature_size=80, norm_type="utterance")
+    fe_raw = CustomFeatureExtractor(feature_size=80, norm_type="utterance", do_ceptral_normalize=False)
+    n = 16000 * 2
+    t = np.arange(n) / 16000.0
+    waves = {
+        "sweep": (0.5 * np.sin(2 * np.pi * (100 + 1800 * t) * t)).astype(np.float32),
+        "noise": synth.normal(0, "fbank_noise", (n,), 0.1),
+        "silence_padded": np.concatenate([np.zeros(3000, np.float32), synth.normal(1, "fbank_sp", (n - 8000,), 0.05),
+                                          np.zeros(5000, np.float32)]),
+    }
+    rec = {}
+    for k, w in waves.items():
+        raw = fe_raw(w, sampling_rate=16000, padding=False, return_attention_mask=False, return_tensors="np")["input_features"][0]
+        nrm = fe(w, sampling_rate=16000, padding=False, return_attention_mask=False, return_tensors="np")["input_features"][0]
+        rec[f"{k}_wave"] = w
+        rec[f"{k}_raw"] = np.asarray(raw, np.float32)
+        rec[f"{k}_cmvn"] = np.asarray(nrm, np.float32)
+        print("fbank", k, raw.shape, float(np.mean(nrm)), float(np.std(nrm)))
+    # global-stat normalisation
+    means = np.linspace(5.0, 9.0, 80).astype(np.float32)
+    stds = np.linspace(2.0, 4.0, 80).astype(np.float32)
+    feg = CustomFeatureExtractor(feature_size=80, norm_type="global", global_means=means.tolist(), global_stds=stds.tolist())
+    rec["noise_global"] = np.asarray(feg(waves["noise"], sampling_rate=16000, padding=False, return_attention_mask=False,
+                                         return_tensors="np")["input_features"][0], np.float32)
+    rec["global_means"], rec["global_stds"] = means, stds
+    np.savez_compressed(os.path.join(HERE, "fbank.npz"), **rec)
+
+
+def run_length_tables():
+    cfg, model = build_reference(TINY)
+    L = torch.arange(50, 3001)
+    rec = dict(L=L.numpy(), inner=model.wav2vec2._get_feat_extract_output_lengths(L).numpy(),
+               outer=model._get_feat_extract_output_lengths(L).numpy())
+    cfgc, modelc = build_reference(TINY, is_causal=True)
+    rec["inner_causal"] = modelc.wav2vec2._get_feat_extract_output_lengths(L).numpy()
+    np.savez_compressed(os.path.join(HERE, "lengths.npz"), **rec)
+    print("lengths 998 ->", int(rec["inner"][998 - 50]), int(rec["outer"][998 - 50]))
+
+
+def run_ctc_known_answers():
+    """torch.nn.functional.ctc_loss as called at e_branchformer.py:480-488 (aten, fp32)."""
+    rec = {}
+    g = torch.Generator().manual_seed(0)
+    cases = {
+        "basic": dict(T=12, V=7, labels=[[1, 2, 3], [4, 4, 0]], in_len=[12, 9], tl=[3, 2]),
+        "repeat": dict(T=8, V=5, labels=[[2, 2, 2], [1, 0, 0]], in_len=[8, 5], tl=[3, 1]),
+        "infeasible": dict(T=6, V=5, labels=[[1, 1, 1, 1], [2, 3, 0, 0]], in_len=[4, 6], tl=[4, 2]),
+        "empty_target": dict(T=5, V=4, labels=[[0, 0], [1, 2]], in_len=[5, 5], tl=[0, 2]),
+    }
+    for name, c in cases.items():
+        B = len(c["labels"])
+        logits = torch.randn(B, c["T"], c["V"] + 1, generator=g)
+        lp = torch.log_softmax(logits, -1)
+        lab = torch.tensor(c["labels"])
+        tl = torch.tensor(c["tl"])
+        flat = torch.cat([lab[b, : tl[b]] for b in range(B)])
+        for zi in (False, True):
+            for red in ("mean", "sum", "none"):
+                v = torch.nn.functional.ctc_loss(lp.transpose(0, 1), flat, torch.tensor(c["in_len"]), tl, blank=c["V"],
+                                                 reduction=red, zero_infinity=zi)
+                rec[f"{name}/{red}/{int(zi)}"] = v.numpy()
+        lab_p = lab.clone()
+        for b in range(B):
+            lab_p[b, tl[b]:] = -100
+        rec[f"{name}/logits"] = logits.numpy()
+        rec[f"{name}/labels"] = lab_p.numpy()
+        rec[f"{name}/in_len"] = np.array(c["in_len"])
+    np.savez_compressed(os.path.join(HERE, "ctc_known.npz"), **rec)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["tiny", "base", "fbank", "lengths", "ctc"]
+    if "tiny" in which:
+        run_encoder_case("tiny_rel", TINY, seed=11, B=2, T=200, lengths=[198, 150], U=7, tgt_lens=[7, 5])
+        run_encoder_case("tiny_rotary", TINY, seed=12, B=2, T=200, lengths=[200, 131], U=6, tgt_lens=[6, 4],
+                         position_embeddings_type="rotary")
+        run_encoder_case("tiny_causal", TINY, seed=13, B=2, T=160, lengths=[160, 97], U=5, tgt_lens=[5, 3], is_causal=True)
+        run_encoder_case("tiny_nomacaron", TINY, seed=14, B=1, T=120, lengths=[120], U=4, tgt_lens=[4], use_macaron_ff=True,
+                         csgu_activation="gelu", csgu_use_linear_after_conv=True)
+    if "base" in which:
+        run_encoder_case("small_rel", SMALL, seed=21, B=2, T=1000, lengths=[998, 700], U=40, tgt_lens=[40, 31], full=False)
+        run_encoder_case("base_rel", BASE, seed=22, B=2, T=1000, lengths=[998, 700], U=40, tgt_lens=[40, 31], full=False,
+                         with_bf16=True)
+        run_encoder_case("base_rotary", BASE, seed=23, B=2, T=1000, lengths=[998, 700], U=40, tgt_lens=[40, 31], full=False,
+                         position_embeddings_type="rotary")
+    if "fbank" in which:
+        run_fbank_cases()
+    if "lengths" in which:
+        run_length_tables()
+    if "ctc" in which:
+        run_ctc_known_answers()

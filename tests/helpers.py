@@ -1,0 +1,46 @@
+"""Shared helpers for the parity tests: rebuild the seeded inputs the golden fixtures were made from."""
+import os
+
+import numpy as np
+import torch
+
+from huggingface_asr_amd import shapes, synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def seeded_state_dict(cfg, seed):
+    sd = synth.state_dict_numpy(shapes.param_shapes(cfg), seed)
+    return {k: torch.from_numpy(v) for k, v in sd.items()}
+
+
+def synth_feats(seed, B, T, lengths):
+    x = synth.normal(seed, "feats", (B, T, 80), 1.0)
+    am = np.zeros((B, T), dtype=np.int64)
+    for b, n in enumerate(lengths):
+        am[b, :n] = 1
+        x[b, n:] = 0.0
+    return torch.from_numpy(x), torch.from_numpy(am)
+
+
+def synth_labels(seed, B, U, vocab, tgt_lens):
+    lab = synth.labels(seed, B, U, vocab, lo=0)
+    for b, n in enumerate(tgt_lens):
+        lab[b, n:] = -100
+    return torch.from_numpy(lab)
+
+
+def case_inputs(g, cfg):
+    """Rebuild (state_dict, feats, attention_mask, labels) for a golden encoder case `g`."""
+    seed = int(g["seed"])
+    B, T, U = [int(v) for v in g["shape"]]
+    sd = seeded_state_dict(cfg, seed)
+    wsum = float(sum(v.double().sum() for v in sd.values()))
+    assert abs(wsum - float(g["weight_sum"])) < 1e-6 * max(1.0, abs(wsum)), "seeded weights drifted from the fixture"
+    x, am = synth_feats(seed, B, T, [int(v) for v in g["lengths"]])
+    lab = synth_labels(seed, B, U, cfg["vocab_size"], [int(v) for v in g["tgt_lens"]])
+    return sd, x, am, lab

@@ -1,0 +1,106 @@
+"""CPU: pin the oracle (oracle/*.py) against golden vectors made by importing the reference
+(tests/golden/make_golden.py).  fp32, tolerance 1e-4 abs on logits (observed ~1e-5)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import case_inputs, load_golden
+from huggingface_asr_amd import shapes
+from oracle import ebranchformer_ref as R
+from oracle import fbank_ref
+
+
+def _cfg(base, **kw):
+    c = dict(base)
+    c.update(ctc_zero_infinity=True, ctc_loss_reduction="mean")
+    c.update(kw)
+    return c
+
+
+TINY_CASES = [
+    ("tiny_rel", _cfg(shapes.TINY)),
+    ("tiny_rotary", _cfg(shapes.TINY, position_embeddings_type="rotary")),
+    ("tiny_causal", _cfg(shapes.TINY, is_causal=True)),
+    ("tiny_nomacaron", _cfg(shapes.TINY, csgu_activation="gelu", csgu_use_linear_after_conv=True)),
+]
+
+
+@pytest.mark.parametrize("name,cfg", TINY_CASES, ids=[c[0] for c in TINY_CASES])
+def test_tiny_full_tensors(name, cfg):
+    g = load_golden(name)
+    sd, x, am, lab = case_inputs(g, cfg)
+    with torch.no_grad():
+        hidden, layers = R.encoder_forward(sd, cfg, x, am, return_layers=True)
+        loss, logits = R.ctc_forward(sd, cfg, x, am, lab)
+    np.testing.assert_allclose(hidden.numpy(), g["last_hidden"], atol=2e-4, rtol=0)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], atol=2e-4, rtol=0)
+    # hidden_states[i] of the reference = input of layer i; layer_in_{i+1} = output of layer i
+    for i in range(1, cfg["num_hidden_layers"]):
+        np.testing.assert_allclose(layers[i - 1].numpy(), g[f"layer_in_{i}"], atol=2e-4, rtol=0)
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    # quirk 8': outer (CTC) lengths differ from inner (mask) lengths
+    np.testing.assert_array_equal(R.conv_out_lengths_outer(am.sum(-1), cfg).numpy(), g["outer_lens"])
+    np.testing.assert_array_equal(R.conv_out_lengths_inner(am.sum(-1), cfg).numpy(), g["inner_lens"])
+
+
+BIG_CASES = [
+    ("small_rel", _cfg(shapes.SMALL)),
+    ("base_rel", _cfg(shapes.BASE)),
+    ("base_rotary", _cfg(shapes.BASE, position_embeddings_type="rotary")),
+]
+
+
+@pytest.mark.parametrize("name,cfg", BIG_CASES, ids=[c[0] for c in BIG_CASES])
+def test_small_base_slices(name, cfg):
+    g = load_golden(name)
+    sd, x, am, lab = case_inputs(g, cfg)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        loss, logits = R.ctc_forward(sd, cfg, x, am, lab)
+    lg = logits.numpy()
+    np.testing.assert_allclose(lg[:, ::25, :64], g["logits_slice"], atol=5e-4, rtol=0)
+    np.testing.assert_allclose(lg[:, :, -1], g["logits_blank"], atol=5e-4, rtol=0)
+    assert abs(float(lg.std()) - float(g["logits_std"])) < 1e-4
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+
+
+def test_lengths_table():
+    g = load_golden("lengths")
+    L = torch.from_numpy(g["L"])
+    cfg = dict(shapes.TINY)
+    np.testing.assert_array_equal(R.conv_out_lengths_inner(L, cfg).numpy(), g["inner"])
+    np.testing.assert_array_equal(R.conv_out_lengths_outer(L, cfg).numpy(), g["outer"])
+    np.testing.assert_array_equal(R.conv_out_lengths_inner(L, dict(cfg, is_causal=True)).numpy(), g["inner_causal"])
+    assert int(R.conv_out_lengths_inner(torch.tensor([998]), cfg)) == 250
+    assert int(R.conv_out_lengths_outer(torch.tensor([998]), cfg)) == 248
+
+
+@pytest.mark.parametrize("wave", ["sweep", "noise", "silence_padded"])
+def test_fbank_matches_reference(wave):
+    g = load_golden("fbank")
+    raw = fbank_ref.fbank(g[f"{wave}_wave"])
+    assert raw.shape == g[f"{wave}_raw"].shape
+    np.testing.assert_allclose(raw, g[f"{wave}_raw"], atol=2e-5, rtol=0)
+    cm = fbank_ref.utterance_cmvn(raw, raw.shape[0])
+    np.testing.assert_allclose(cm, g[f"{wave}_cmvn"], atol=2e-5, rtol=0)
+
+
+def test_fbank_global_norm():
+    g = load_golden("fbank")
+    out = fbank_ref.extract(g["noise_wave"], "global", g["global_means"], g["global_stds"])
+    np.testing.assert_allclose(out, g["noise_global"], atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize("case", ["basic", "repeat", "infeasible", "empty_target"])
+def test_ctc_known_answers(case):
+    g = load_golden("ctc_known")
+    logits = torch.from_numpy(g[f"{case}/logits"])
+    labels = torch.from_numpy(g[f"{case}/labels"])
+    in_len = torch.from_numpy(g[f"{case}/in_len"])
+    tl = (labels >= 0).sum(-1)
+    lp = torch.log_softmax(logits, -1)
+    for zi in (0, 1):
+        for red in ("mean", "sum", "none"):
+            want = g[f"{case}/{red}/{zi}"]
+            got = R.ctc_loss_ref(lp, labels, in_len, tl, blank=logits.shape[-1] - 1, reduction=red, zero_infinity=bool(zi))
+            np.testing.assert_allclose(got.numpy(), want, rtol=1e-5, atol=1e-5)
