@@ -1,0 +1,75 @@
+"""ctypes binding of libhfasr_hip.so (the C ABI declared in include/hfasr_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a symbol cannot be
+resolved, importing/using the ops raises immediately (the GPU box must run the HIP kernels).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhfasr_hip.so")
+
+vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_size_t
+
+
+class EbfConfig(C.Structure):
+    """mirror of mi_ebf_config (include/hfasr_hip.h)"""
+    _fields_ = [(n, i32) for n in ("B", "T", "F", "d", "H", "I", "L", "V", "C1", "C2", "K", "stride", "pad",
+                                   "is_causal", "pos_type", "csgu_kernel", "merge_kernel", "csgu_act", "use_macaron")] + \
+               [("ln_eps", f32), ("logits_f32", i32)]
+
+
+GLOBAL_SLOTS, LAYER_SLOTS = 24, 48
+
+# name -> (argtypes); every function returns int (0 = ok), except mi_ebf_workspace_bytes (size_t)
+SIGNATURES = {
+    "mi_gemm_bf16": [vp, i64, vp, i64, vp, i32, vp, i64, i32, vp, i64, f32, i32, i32, i32, i32, i32, i32, vp],
+    "mi_conv2d_cl_bf16": [vp, vp, vp, vp] + [i32] * 13 + [vp],
+    "mi_conv2d_first_gelu": [vp, vp, vp, vp] + [i32] * 10 + [vp],
+    "mi_layernorm_chain": [vp, i64, vp, i32, vp, vp, f32, vp, i64, vp, vp, f32, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, vp],
+    "mi_rotary_bf16": [vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, vp],
+    "mi_attention_bf16": [vp, i64, vp, i64, vp, i64, i32, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, i32, vp],
+    "mi_row_stats_bf16": [vp, i64, i32, f32, vp, i32, vp],
+    "mi_csgu_bf16": [vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp],
+    "mi_dwconv_residual_bf16": [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp],
+    "mi_fbank_f64": [vp, i64, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, f64, f64, vp],
+    "mi_cmvn_utterance": [vp, vp, i32, i32, i32, i32, i32, f32, vp],
+    "mi_cmvn_global": [vp, i64, i32, vp, vp, vp],
+    "mi_row_lse": [vp, i64, i32, i32, vp, i32, vp],
+    "mi_ctc_loss_fwd": [vp, i64, i64, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp],
+    "mi_ebf_workspace_bytes": [C.POINTER(EbfConfig)],
+    "mi_ebf_forward": [C.POINTER(EbfConfig), vp, vp, vp, vp, vp, i32, vp, sz, vp, vp, vp, vp, vp],
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises HipLibraryError if the .so is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} not found: build it with `python huggingface_asr_amd/csrc/build.py` "
+                "(or __graft_entry__.build()). There is no CPU fallback for the HIP path.")
+        h = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(h, name)          # AttributeError here = header/library mismatch: fail loudly
+            fn.argtypes = args
+            fn.restype = sz if name == "mi_ebf_workspace_bytes" else i32
+        _lib = h
+    return _lib
+
+
+_ERR = {-1: "invalid argument", -2: "kernel launch failed", -3: "unsupported configuration"}
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {_ERR.get(rc, rc)}")

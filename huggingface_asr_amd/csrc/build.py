@@ -1,0 +1,51 @@
+"""Build libhfasr_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python huggingface_asr_amd/csrc/build.py [--force]
+
+One object per .hip (compiled in parallel), linked into huggingface_asr_amd/libhfasr_hip.so (in-tree:
+the .so is git-ignored but travels to the GPU box with the gpurun snapshot).
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OUT = os.path.join(PKG, "libhfasr_hip.so")
+OBJ = os.path.join(HERE, "build")
+SOURCES = ["gemm_bf16.hip", "norm.hip", "conv.hip", "attention.hip", "fbank.hip", "ctc.hip", "encoder.hip"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src):
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    deps = [os.path.join(HERE, src), os.path.join(HERE, "common.hpp"), os.path.join(os.path.dirname(PKG), "include", "hfasr_hip.h")]
+    if _stale(obj, deps):
+        subprocess.run(["hipcc", *FLAGS, "-c", os.path.join(HERE, src), "-o", obj], check=True)
+    return obj
+
+
+def build(force: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    if force or _stale(OUT, objs):
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs], check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build("--force" in sys.argv))

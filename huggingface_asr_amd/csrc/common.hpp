@@ -1,0 +1,48 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of libhfasr_hip.so.
+// Wave = 64 lanes.  bf16 storage, fp32 accumulation everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MI_OK 0
+#define MI_ERR_ARG (-1)
+#define MI_ERR_LAUNCH (-2)
+#define MI_ERR_UNSUPPORTED (-3)
+
+#define MI_CHECK_LAUNCH()                                \
+    do {                                                 \
+        hipError_t e__ = hipGetLastError();              \
+        if (e__ != hipSuccess) return MI_ERR_LAUNCH;     \
+    } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
+
+// exact (erf) GELU, the reference's "gelu" activation (ACT2FN["gelu"] / nn.GELU()).
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,203 @@
+// HBM-bound convolution kernels of the E-Branchformer path (gfx950).
+//
+//  * conv2d_first: Conv2d(1 -> C, KxK, stride s) + GELU over the padded (B,T,F) log-mel layout
+//    (reference extractors.py:71-96 first layer, :111 `input_values[:, None]`), output channels-last
+//    (B, T1, F1, C) bf16 so that the second conv is a K-contiguous implicit GEMM (gemm_bf16.hip).
+//  * dwconv_time: depthwise Conv1d(k<=31) along time on (B,T,C) bf16, two fused forms:
+//      CSGU  (e_branchformer.py:184-204): out = x_r * act(conv(LN(x_g)) + b)   [LN applied on the fly
+//             from per-row mean/rstd, so the normalised gate never round-trips HBM]
+//      MERGE (e_branchformer.py:296-299): out = m + conv(m) + b
+//  * row_stats: per-row mean / rstd of the gate half for the CSGU LayerNorm (fp32).
+#include "common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ conv2d_first
+// one thread = one output position x 8 consecutive channels; 32 threads cover C=256 (generic C%8==0)
+__global__ __launch_bounds__(256) void conv2d_first_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                            int B, int T, int F, int C, int K, int stride, int pad_t, int pad_f,
+                                                            int T1, int F1) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sw = reinterpret_cast<float*>(smem);          // [K*K][C]  (tap-major so 8 channels are contiguous)
+    float* sb = sw + K * K * C;                          // [C]
+    for (int i = threadIdx.x; i < K * K * C; i += blockDim.x) {
+        const int c = i % C, tap = i / C;
+        sw[i] = w[c * K * K + tap];
+    }
+    for (int i = threadIdx.x; i < C; i += blockDim.x) sb[i] = bias[i];
+    __syncthreads();
+    const int cg = C >> 3;                               // channel groups of 8
+    const long total = (long)B * T1 * F1 * cg;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % cg);
+        const long pos = idx / cg;
+        const int f1 = (int)(pos % F1);
+        const int t1 = (int)((pos / F1) % T1);
+        const int b = (int)(pos / ((long)F1 * T1));
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = sb[g * 8 + j];
+        for (int kh = 0; kh < K; ++kh) {
+            const int t = t1 * stride - pad_t + kh;
+            if (t < 0 || t >= T) continue;
+            for (int kw = 0; kw < K; ++kw) {
+                const int f = f1 * stride - pad_f + kw;
+                if (f < 0 || f >= F) continue;
+                const float xv = x[((long)b * T + t) * F + f];
+                const float* wp = sw + (kh * K + kw) * C + g * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, wp[j], acc[j]);
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(gelu_erf(acc[j]));
+        *reinterpret_cast<bf16x8*>(out + pos * C + g * 8) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ row_stats
+__global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict__ x, long ldx, int d, float eps,
+                                                         float* __restrict__ stats, int M) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const bf16x8* xr = reinterpret_cast<const bf16x8*>(x + (long)row * ldx);
+    const int d8 = d >> 3;
+    float s = 0.f, q = 0.f;
+    for (int c = lane; c < d8; c += 64) {
+        const bf16x8 v = xr[c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += bf2f(v[j]);
+    }
+    const float mean = wave_sum(s) / d;
+    for (int c = lane; c < d8; c += 64) {
+        const bf16x8 v = xr[c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float a = bf2f(v[j]) - mean; q += a * a; }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / d + eps);
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
+// ------------------------------------------------------------------------------------------------ dwconv_time
+constexpr int DW_TT = 64;     // output time steps per block
+constexpr int DW_CT = 64;     // channels per block
+constexpr int DW_KMAX = 31;
+
+struct DwArgs {
+    const bf16_t* in; long ld_in;        // conv input rows (gate half for CSGU, m for MERGE)
+    const bf16_t* mul; long ld_mul;      // CSGU: x_r
+    const float* stats;                  // CSGU: (M,2) mean/rstd of the gate rows
+    const float* gamma; const float* beta;   // CSGU LayerNorm affine (C)
+    const float* w; const float* bias;   // (C, K) taps, (C)
+    bf16_t* out; long ld_out;
+    int B, T, C, K, pad_left, dilation, act;    // act: 0 identity, 1 gelu, 2 relu, 3 silu
+};
+
+template <bool CSGU>
+__global__ __launch_bounds__(256) void dwconv_time_kernel(DwArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int halo = (p.K - 1) * p.dilation;
+    const int rows = DW_TT + halo;
+    float* tile = reinterpret_cast<float*>(smem);        // [rows][DW_CT]
+    float* sw = tile + rows * DW_CT;                     // [K][DW_CT]
+    const int c0 = blockIdx.x * DW_CT, t0 = blockIdx.y * DW_TT, b = blockIdx.z;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = c0 + tx;
+    const bool cok = c < p.C;
+    for (int i = threadIdx.x; i < p.K * DW_CT; i += 256) {
+        const int k = i / DW_CT, cc = i % DW_CT;
+        sw[i] = (c0 + cc < p.C) ? p.w[(long)(c0 + cc) * p.K + k] : 0.f;
+    }
+    float g = 1.f, be = 0.f;
+    if (CSGU && cok) { g = p.gamma[c]; be = p.beta[c]; }
+    for (int r = ty; r < rows; r += 4) {
+        const int t = t0 - p.pad_left + r;
+        float v = 0.f;                                   // zero padding is applied to the conv INPUT (post-LN)
+        if (cok && t >= 0 && t < p.T) {
+            const long row = (long)b * p.T + t;
+            v = bf2f(p.in[row * p.ld_in + c]);
+            if (CSGU) v = (v - p.stats[2 * row]) * p.stats[2 * row + 1] * g + be;
+        }
+        tile[r * DW_CT + tx] = v;
+    }
+    __syncthreads();
+    if (!cok) return;
+    const float bias = p.bias ? p.bias[c] : 0.f;
+    // each thread: 16 consecutive outputs of one channel
+#pragma unroll 4
+    for (int j = 0; j < DW_TT / 4; ++j) {
+        const int tl = ty * (DW_TT / 4) + j;
+        const int t = t0 + tl;
+        if (t >= p.T) break;
+        float acc = bias;
+        for (int k = 0; k < p.K; ++k) acc = fmaf(sw[k * DW_CT + tx], tile[(tl + k * p.dilation) * DW_CT + tx], acc);
+        const long row = (long)b * p.T + t;
+        float o;
+        if (CSGU) {
+            if (p.act == 1) acc = gelu_erf(acc);
+            else if (p.act == 2) acc = fmaxf(acc, 0.f);
+            else if (p.act == 3) acc = acc / (1.f + __expf(-acc));
+            o = bf2f(p.mul[row * p.ld_mul + c]) * acc;
+        } else {
+            o = tile[(tl + p.pad_left) * DW_CT + tx] + acc;
+        }
+        p.out[row * p.ld_out + c] = f2bf(o);
+    }
+}
+
+}  // namespace
+
+extern "C" int mi_conv2d_first_gelu(const float* x, const float* w, const float* bias, void* out_cl_bf16,
+                                    int B, int T, int F, int C, int K, int stride, int pad_t, int pad_f,
+                                    int T1, int F1, hipStream_t stream) {
+    if (B <= 0 || T <= 0 || F <= 0 || C <= 0 || (C % 8) != 0 || K <= 0 || K > 7) return MI_ERR_ARG;
+    const long total = (long)B * T1 * F1 * (C / 8);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    const size_t lds = (size_t)(K * K * C + C) * sizeof(float);
+    hipLaunchKernelGGL(conv2d_first_kernel, dim3(grid), dim3(256), lds, stream, x, w, bias, (bf16_t*)out_cl_bf16,
+                       B, T, F, C, K, stride, pad_t, pad_f, T1, F1);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+extern "C" int mi_row_stats_bf16(const void* x, long ldx, int d, float eps, float* stats, int M, hipStream_t stream) {
+    if (M <= 0 || d <= 0 || (d % 8) != 0 || (ldx % 8) != 0) return MI_ERR_ARG;
+    hipLaunchKernelGGL(row_stats_kernel, dim3(cdiv(M, 4)), dim3(256), 0, stream, (const bf16_t*)x, ldx, d, eps, stats, M);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+static int dw_launch(const DwArgs& a, bool csgu, hipStream_t stream) {
+    if (a.B <= 0 || a.T <= 0 || a.C <= 0 || a.K <= 0 || a.K > DW_KMAX || a.dilation < 1) return MI_ERR_ARG;
+    const int halo = (a.K - 1) * a.dilation;
+    const size_t lds = (size_t)((DW_TT + halo) * DW_CT + a.K * DW_CT) * sizeof(float);
+    if (lds > 160 * 1024) return MI_ERR_UNSUPPORTED;
+    dim3 grid(cdiv(a.C, DW_CT), cdiv(a.T, DW_TT), a.B);
+    if (csgu) hipLaunchKernelGGL(dwconv_time_kernel<true>, grid, dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL(dwconv_time_kernel<false>, grid, dim3(256), lds, stream, a);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// CSGU: u (B*T, 2C) bf16 = [x_r | x_g];  out (B*T, C) = x_r * act(dwconv(LN(x_g)) + bias)
+extern "C" int mi_csgu_bf16(const void* u, long ldu, const float* stats, const float* gamma, const float* beta,
+                            const float* w, const float* bias, void* out, long ldo,
+                            int B, int T, int C, int K, int pad_left, int dilation, int act, hipStream_t stream) {
+    DwArgs a{};
+    a.in = (const bf16_t*)u + C; a.ld_in = ldu; a.mul = (const bf16_t*)u; a.ld_mul = ldu; a.stats = stats;
+    a.gamma = gamma; a.beta = beta; a.w = w; a.bias = bias; a.out = (bf16_t*)out; a.ld_out = ldo;
+    a.B = B; a.T = T; a.C = C; a.K = K; a.pad_left = pad_left; a.dilation = dilation; a.act = act;
+    return dw_launch(a, true, stream);
+}
+
+// MERGE: out = m + dwconv(m) + bias on (B*T, C) bf16
+extern "C" int mi_dwconv_residual_bf16(const void* m, long ldm, const float* w, const float* bias, void* out, long ldo,
+                                       int B, int T, int C, int K, int pad_left, hipStream_t stream) {
+    DwArgs a{};
+    a.in = (const bf16_t*)m; a.ld_in = ldm; a.w = w; a.bias = bias; a.out = (bf16_t*)out; a.ld_out = ldo;
+    a.B = B; a.T = T; a.C = C; a.K = K; a.pad_left = pad_left; a.dilation = 1; a.act = 0;
+    return dw_launch(a, false, stream);
+}

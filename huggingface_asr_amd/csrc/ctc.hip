@@ -1,0 +1,135 @@
+// CTC head tail on gfx950: row log-sum-exp + alpha recursion (forward loss).
+//
+// Reference: e_branchformer.py:472-488 — labels >= 0 are the targets, log_softmax in fp32,
+// F.ctc_loss(blank = last class, reduction = config, zero_infinity = config) with input lengths from the
+// UN-padded conv formula (SURVEY.md §8a row 8').  log_softmax is never materialised: the loss only needs
+// lse[b,t] and the logits at the blank / label columns, so the (B,T,V+1) tensor is read exactly once.
+#include "common.hpp"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void row_lse_kernel(const T* __restrict__ x, long ld, int V, float* __restrict__ lse, int M) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const T* xr = x + (long)row * ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < V; c += 64) mx = fmaxf(mx, (float)xr[c]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < V; c += 64) s += __expf((float)xr[c] - mx);
+    s = wave_sum(s);
+    if (lane == 0) lse[row] = mx + __logf(s);
+}
+
+__device__ __forceinline__ double lse3(double a, double b, double c) {
+    const double m = fmax(a, fmax(b, c));
+    if (m == -INFINITY) return -INFINITY;
+    return m + log(exp(a - m) + exp(b - m) + exp(c - m));
+}
+
+// one block per utterance; extended label sequence and alpha (double) in LDS
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_alpha_kernel(const T* __restrict__ logits, long ld_b, long ld_t,
+                                                         const float* __restrict__ lse, int Tmax,
+                                                         const long* __restrict__ labels, int U,
+                                                         const int* __restrict__ in_len, int blank,
+                                                         float* __restrict__ nll, int* __restrict__ tgt_len_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int S_max = 2 * U + 1;
+    int* s_tl_p = reinterpret_cast<int*>(smem);                       // [4] (all LDS in the dynamic region, 16-B carved)
+    int* ext = s_tl_p + 4;                                            // [S_max]
+    int* skip = ext + S_max;                                          // [S_max]
+    double* alpha = reinterpret_cast<double*>(smem + (((4 + 2 * S_max) * sizeof(int) + 15) / 16) * 16);   // [2][S_max]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int n = 0;
+        for (int u = 0; u < U; ++u) {
+            const long v = labels[(long)b * U + u];
+            if (v >= 0) { ext[2 * n + 1] = (int)v; ++n; }
+        }
+        for (int s = 0; s <= 2 * n; s += 2) ext[s] = blank;
+        for (int s = 0; s <= 2 * n; ++s) skip[s] = (s >= 2 && ext[s] != blank && ext[s] != ext[s - 2]) ? 1 : 0;
+        s_tl_p[0] = n;
+    }
+    __syncthreads();
+    const int tl = s_tl_p[0], S = 2 * tl + 1;
+    const int Tb = min(in_len[b], Tmax);
+    if (tid == 0) tgt_len_out[b] = tl;
+    if (Tb <= 0) { if (tid == 0) nll[b] = (tl == 0) ? 0.f : INFINITY; return; }
+    const T* lg = logits + (long)b * ld_b;
+    const float* ls = lse + (long)b * Tmax;
+    for (int s = tid; s < S; s += 256)
+        alpha[s] = (s < 2) ? (double)((float)lg[ext[s]] - ls[0]) : -INFINITY;
+    __syncthreads();
+    int cur = 0;
+    for (int t = 1; t < Tb; ++t) {
+        const double* a = alpha + cur * S_max;
+        double* an = alpha + (cur ^ 1) * S_max;
+        const T* lt = lg + (long)t * ld_t;
+        const float l0 = ls[t];
+        for (int s = tid; s < S; s += 256) {
+            const double a0 = a[s], a1 = s >= 1 ? a[s - 1] : -INFINITY, a2 = skip[s] ? a[s - 2] : -INFINITY;
+            an[s] = lse3(a0, a1, a2) + (double)((float)lt[ext[s]] - l0);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (tid == 0) {
+        const double* a = alpha + cur * S_max;
+        const double a0 = a[S - 1], a1 = S >= 2 ? a[S - 2] : -INFINITY;
+        const double ll = lse3(a0, a1, -INFINITY);
+        nll[b] = (float)(-ll);
+    }
+}
+
+// reduction semantics of torch.nn.functional.ctc_loss: mean = mean_b(nll_b / max(tl_b,1)), sum, zero_infinity
+__global__ void ctc_reduce_kernel(const float* nll, const int* tl, int B, int reduction, int zero_inf, float* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double acc = 0.0;
+    for (int b = 0; b < B; ++b) {
+        float v = nll[b];
+        if (zero_inf && isinf(v)) v = 0.f;
+        acc += (reduction == 1) ? (double)v / (double)max(tl[b], 1) : (double)v;
+    }
+    out[0] = (float)((reduction == 1) ? acc / B : acc);
+}
+
+}  // namespace
+
+// logits (M, ld) f32 (dtype 0) or bf16 (dtype 1) -> lse (M) f32
+extern "C" int mi_row_lse(const void* x, long ld, int dtype, int V, float* lse, int M, hipStream_t stream) {
+    if (M <= 0 || V <= 0) return MI_ERR_ARG;
+    dim3 grid(cdiv(M, 4)), block(256);
+    if (dtype == 0) hipLaunchKernelGGL(row_lse_kernel<float>, grid, block, 0, stream, (const float*)x, ld, V, lse, M);
+    else if (dtype == 1) hipLaunchKernelGGL(row_lse_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)x, ld, V, lse, M);
+    else return MI_ERR_ARG;
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// logits (B, T, V+1) with strides (ld_b, ld_t) elements; lse (B*T); labels (B,U) int64, negatives = padding;
+// in_len (B) int32; out: nll (B) f32, tgt_len (B) int32, loss (1) f32 with reduction 0 sum / 1 mean.
+extern "C" int mi_ctc_loss_fwd(const void* logits, long ld_b, long ld_t, int dtype, const float* lse, int T,
+                               const long* labels, int U, const int* in_len, int blank, int B,
+                               int reduction, int zero_infinity, float* nll, int* tgt_len, float* loss,
+                               hipStream_t stream) {
+    if (B <= 0 || T <= 0 || U < 0) return MI_ERR_ARG;
+    const int S_max = 2 * U + 1;
+    const size_t lds = (((4 + 2 * S_max) * sizeof(int) + 15) / 16) * 16 + 2 * S_max * sizeof(double);
+    if (lds > 150 * 1024) return MI_ERR_UNSUPPORTED;
+    if (dtype == 0)
+        hipLaunchKernelGGL(ctc_alpha_kernel<float>, dim3(B), dim3(256), lds, stream, (const float*)logits, ld_b, ld_t, lse, T,
+                           labels, U, in_len, blank, nll, tgt_len);
+    else if (dtype == 1)
+        hipLaunchKernelGGL(ctc_alpha_kernel<bf16_t>, dim3(B), dim3(256), lds, stream, (const bf16_t*)logits, ld_b, ld_t, lse, T,
+                           labels, U, in_len, blank, nll, tgt_len);
+    else return MI_ERR_ARG;
+    MI_CHECK_LAUNCH();
+    if (loss) {
+        hipLaunchKernelGGL(ctc_reduce_kernel, dim3(1), dim3(64), 0, stream, nll, tgt_len, B, reduction, zero_infinity, loss);
+        MI_CHECK_LAUNCH();
+    }
+    return MI_OK;
+}

@@ -1,0 +1,215 @@
+// Whole-encoder driver: Wav2Vec2EBranchformerForCTC.forward in eval mode as one C call that enqueues
+// every kernel of the path on the caller's stream (no allocation, no sync -> hipGraph-capturable).
+//
+// Reference call stack: e_branchformer.py:422-457 -> wav2vec2_conformer model forward
+// (:1133-1195: conv sub-sampling, mask, feature projection) -> encoder loop (:651-717) with
+// Wav2Vec2EBranchformerEncoderLayer.forward (e_branchformer.py:263-313) -> lm_head ⊕ blank_projection.
+//
+// Data layout in HBM (all row-major, rows = b*T2 + t):
+//   x     fp32 (M, d)     residual stream (the reference's stream is fp32 under bf16 autocast too)
+//   a0/a1/a2 bf16 (M, d)  LayerNorm outputs = GEMM A operands
+//   h     bf16 (M, I)     FFN hidden / cgMLP channel_proj1 output [x_r | x_g]
+//   qk    bf16 (M, 2d)    [Q | K] projections; vt bf16 (d, B*Tp) = V^T, key-contiguous, time padded to 32
+//   cat   bf16 (M, 2d)    [attention branch | cgMLP branch]  (torch.cat at e_branchformer.py:296 is free)
+//   act1  bf16 (B,T1,F1,C1), act2 bf16 (B,T2,F2,C2) channels-last conv activations
+#include "common.hpp"
+#include "../../include/hfasr_hip.h"
+
+namespace {
+
+enum G { G_CONV1_W, G_CONV1_B, G_CONV2_W, G_CONV2_B, G_FEOUT_W, G_FEOUT_B, G_FP_LN_G, G_FP_LN_B, G_FP_W, G_FP_B,
+         G_ENC_LN_G, G_ENC_LN_B, G_HEAD_W, G_HEAD_B };
+enum LS { FF1_LN_G, FF1_LN_B, FF1_W1, FF1_B1, FF1_W2, FF1_B2,
+          ATT_LN_G, ATT_LN_B, ATT_WQK, ATT_BQK, ATT_WV, ATT_BV, ATT_WO, ATT_BO, ATT_WPOS, ATT_U, ATT_V,
+          MLP_LN_G, MLP_LN_B, MLP_W1, MLP_B1, CSGU_LN_G, CSGU_LN_B, CSGU_W, CSGU_B, MLP_W2, MLP_B2,
+          MRG_DW_W, MRG_DW_B, MRG_W, MRG_B, FIN_LN_G, FIN_LN_B,
+          FF2_LN_G, FF2_LN_B, FF2_W1, FF2_B1, FF2_W2, FF2_B2 };
+
+struct Dims { int T1, F1, T2, F2, M, Tp, hd; };
+
+int conv_out(int n, int k, int s, int pad_total) { return (n + pad_total - k) / s + 1; }
+
+Dims dims(const mi_ebf_config& c) {
+    Dims d;
+    const int pt = c.is_causal ? 2 * c.pad : 2 * c.pad;     // causal: all padding on the left (streaming_modules.py:31-55)
+    d.T1 = conv_out(c.T, c.K, c.stride, pt); d.F1 = conv_out(c.F, c.K, c.stride, pt);
+    d.T2 = conv_out(d.T1, c.K, c.stride, pt); d.F2 = conv_out(d.F1, c.K, c.stride, pt);
+    d.M = c.B * d.T2; d.Tp = (d.T2 + 31) / 32 * 32; d.hd = c.d / c.H;
+    return d;
+}
+
+struct Carver {
+    char* base; size_t off;
+    void* take(size_t bytes) { void* p = base ? base + off : nullptr; off += (bytes + 255) / 256 * 256; return p; }
+};
+
+struct Ws {
+    bf16_t *act1, *act2, *a0, *a1, *a2, *a1r, *h, *qk, *vt, *ctx, *cat, *m2, *s, *hid;
+    float *feo, *x, *stats;
+    int* lens;   // [inner(B) | outer(B)]
+    size_t bytes;
+};
+
+Ws carve(const mi_ebf_config& c, void* base) {
+    const Dims d = dims(c);
+    Carver k{(char*)base, 0};
+    Ws w;
+    const size_t M = d.M;
+    w.act1 = (bf16_t*)k.take((size_t)c.B * d.T1 * d.F1 * c.C1 * 2);
+    w.act2 = (bf16_t*)k.take((size_t)c.B * d.T2 * d.F2 * c.C2 * 2);
+    w.feo = (float*)k.take(M * c.d * 4);
+    w.x = (float*)k.take(M * c.d * 4);
+    w.a0 = (bf16_t*)k.take(M * c.d * 2);
+    w.a1 = (bf16_t*)k.take(M * c.d * 2);
+    w.a2 = (bf16_t*)k.take(M * c.d * 2);
+    w.a1r = (bf16_t*)k.take(M * c.d * 2);
+    w.h = (bf16_t*)k.take(M * c.I * 2);
+    w.qk = (bf16_t*)k.take(M * 2 * c.d * 2);
+    w.vt = (bf16_t*)k.take((size_t)c.d * c.B * d.Tp * 2);
+    w.ctx = (bf16_t*)k.take(M * c.d * 2);
+    w.cat = (bf16_t*)k.take(M * 2 * c.d * 2);
+    w.m2 = (bf16_t*)k.take(M * 2 * c.d * 2);
+    w.s = (bf16_t*)k.take(M * (c.I / 2) * 2);
+    w.hid = (bf16_t*)k.take(M * c.d * 2);
+    w.stats = (float*)k.take(M * 2 * 4);
+    w.lens = (int*)k.take((size_t)2 * c.B * 4);
+    w.bytes = k.off;
+    return w;
+}
+
+// lengths: inner = padded conv formula (extractors.py:133-162), outer = un-padded formula
+// (Wav2Vec2ForCTC._get_feat_extract_output_lengths; quirk of SURVEY.md §8a row 8')
+__global__ void lengths_kernel(const int* feat_len, int T, int B, int K, int stride, int pad, int causal, int nconv,
+                               int T2, int* inner, int* outer) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int li = feat_len ? feat_len[b] : T, lo = li;
+    for (int i = 0; i < nconv; ++i) {
+        const int num_i = li + (causal ? K - 1 : 2 * pad) - K;
+        li = (num_i >= 0 ? num_i / stride : -((-num_i + stride - 1) / stride)) + 1;
+        const int num_o = lo - K;
+        lo = (num_o >= 0 ? num_o / stride : -((-num_o + stride - 1) / stride)) + 1;
+    }
+    inner[b] = li < T2 ? li : T2;
+    outer[b] = lo;
+}
+
+#define RUN(expr) do { int rc__ = (expr); if (rc__ != MI_OK) return rc__; } while (0)
+
+}  // namespace
+
+extern "C" size_t mi_ebf_workspace_bytes(const mi_ebf_config* cfg) { return carve(*cfg, nullptr).bytes; }
+
+// posp: (L, 2*T2-1, d) bf16 projected relative positions, (re)computed from pos_table when compute_posp != 0
+extern "C" int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weights, const float* feats,
+                              const int* feat_lengths, const void* pos_table, void* posp, int compute_posp,
+                              void* workspace, size_t workspace_bytes, float* last_hidden, void* logits,
+                              int* inner_len, int* outer_len, hipStream_t st) {
+    const mi_ebf_config& c = *cfg;
+    if (c.B <= 0 || c.T <= 0 || c.L <= 0 || c.d % c.H || c.I % 2) return MI_ERR_ARG;
+    const Dims D = dims(c);
+    if (D.T2 <= 0) return MI_ERR_ARG;
+    Ws w = carve(c, workspace);
+    if (w.bytes > workspace_bytes) return MI_ERR_ARG;
+    auto Gw = [&](int s) { return weights[s]; };
+    auto Lw = [&](int l, int s) { return weights[MI_EBF_GLOBAL_SLOTS + l * MI_EBF_LAYER_SLOTS + s]; };
+    auto Gf = [&](int s) { return (const float*)weights[s]; };
+    auto Lf = [&](int l, int s) { return (const float*)weights[MI_EBF_GLOBAL_SLOTS + l * MI_EBF_LAYER_SLOTS + s]; };
+    const int M = D.M, d = c.d, I = c.I, T2 = D.T2;
+    const float leps = 1e-5f;
+    int* inner = inner_len ? inner_len : w.lens;
+    int* outer = outer_len ? outer_len : w.lens + c.B;
+
+    hipLaunchKernelGGL(lengths_kernel, dim3(cdiv(c.B, 64)), dim3(64), 0, st, feat_lengths, c.T, c.B, c.K, c.stride, c.pad,
+                       c.is_causal, 2, T2, inner, outer);
+    const int* mask_len = feat_lengths ? inner : nullptr;
+
+    // --- Conv2d sub-sampling (extractors.py:110-113)
+    const int pl = c.is_causal ? 2 * c.pad : c.pad;
+    RUN(mi_conv2d_first_gelu(feats, Gf(G_CONV1_W), Gf(G_CONV1_B), w.act1, c.B, c.T, c.F, c.C1, c.K, c.stride, pl, pl, D.T1, D.F1, st));
+    RUN(mi_conv2d_cl_bf16(w.act1, Gw(G_CONV2_W), Gf(G_CONV2_B), w.act2, c.B, D.T1, D.F1, c.C1, c.C2, c.K, c.K, c.stride, pl, pl,
+                          D.T2, D.F2, 1, st));
+    // (B,C,T',F') -> transpose -> flatten -> Linear: act2 is already (B*T', F'*C) with the weight columns permuted to match
+    RUN(mi_gemm_bf16(w.act2, (long)D.F2 * c.C2, Gw(G_FEOUT_W), (long)D.F2 * c.C2, Gf(G_FEOUT_B), 1, w.feo, d, 1, nullptr, 0, 1.f, 0,
+                     M, d, D.F2 * c.C2, 0, 0, st));
+    // --- feature projection: LN -> Linear (extractors.py:130-131; tf:328-333)
+    RUN(mi_layernorm_chain(w.feo, d, nullptr, T2, nullptr, nullptr, 0.f, nullptr, 0, Gf(G_FP_LN_G), Gf(G_FP_LN_B), c.ln_eps,
+                           w.a0, d, nullptr, 0, nullptr, nullptr, nullptr, 0, M, d, st));
+    RUN(mi_gemm_bf16(w.a0, d, Gw(G_FP_W), d, Gf(G_FP_B), 1, w.x, d, 1, nullptr, 0, 1.f, 0, M, d, d, 0, 0, st));
+    // --- zero padded frames once (tf:662-665) + first LayerNorm(s) of layer 0
+    if (c.use_macaron)
+        RUN(mi_layernorm_chain(w.x, d, mask_len, T2, nullptr, nullptr, 0.f, w.x, d, Lf(0, FF1_LN_G), Lf(0, FF1_LN_B), leps,
+                               w.a0, d, nullptr, 0, nullptr, nullptr, nullptr, 0, M, d, st));
+    else
+        RUN(mi_layernorm_chain(w.x, d, mask_len, T2, nullptr, nullptr, 0.f, w.x, d, Lf(0, ATT_LN_G), Lf(0, ATT_LN_B), leps,
+                               w.a1, d, nullptr, 0, Lf(0, MLP_LN_G), Lf(0, MLP_LN_B), w.a2, d, M, d, st));
+    // --- relative positions: p_l = linear_pos_l(table) for every layer (batch independent; tf:531-536)
+    const int P = 2 * T2 - 1;
+    if (c.pos_type == 1 && compute_posp)
+        for (int l = 0; l < c.L; ++l)
+            RUN(mi_gemm_bf16(pos_table, d, Lw(l, ATT_WPOS), d, nullptr, 0, (bf16_t*)posp + (size_t)l * P * d, d, 0, nullptr, 0, 1.f, 0,
+                             P, d, d, 0, 0, st));
+    const float* rot_cos = (const float*)pos_table;
+    const float* rot_sin = rot_cos ? rot_cos + (size_t)T2 * D.hd : nullptr;
+    const float scale = 1.0f / sqrtf((float)D.hd);
+    const int kc = c.csgu_kernel, km = c.merge_kernel;
+
+    for (int l = 0; l < c.L; ++l) {
+        if (c.use_macaron) {   // x += 0.5 * FFN(LN(x))   e_branchformer.py:271-273
+            RUN(mi_gemm_bf16(w.a0, d, Lw(l, FF1_W1), d, Lf(l, FF1_B1), 1, w.h, I, 0, nullptr, 0, 1.f, 1, M, I, d, 0, 0, st));
+            RUN(mi_gemm_bf16(w.h, I, Lw(l, FF1_W2), I, Lf(l, FF1_B2), 1, w.x, d, 1, w.x, d, 0.5f, 0, M, d, I, 0, 0, st));
+            RUN(mi_layernorm_chain(w.x, d, nullptr, T2, nullptr, nullptr, 0.f, nullptr, 0, Lf(l, ATT_LN_G), Lf(l, ATT_LN_B), leps,
+                                   w.a1, d, nullptr, 0, Lf(l, MLP_LN_G), Lf(l, MLP_LN_B), w.a2, d, M, d, st));
+        }
+        // global branch (e_branchformer.py:281-288)
+        const bf16_t* qk_in = w.a1;
+        if (c.pos_type == 2) {
+            RUN(mi_rotary_bf16(w.a1, d, w.a1r, d, rot_cos, rot_sin, M, T2, c.H, D.hd, st));
+            qk_in = w.a1r;
+        }
+        RUN(mi_gemm_bf16(qk_in, d, Lw(l, ATT_WQK), d, Lf(l, ATT_BQK), 1, w.qk, 2 * d, 0, nullptr, 0, 1.f, 0, M, 2 * d, d, 0, 0, st));
+        // V^T = Wv · a1^T (+ bv per row), columns remapped to the time-padded (b*Tp + t) layout
+        RUN(mi_gemm_bf16(Lw(l, ATT_WV), d, w.a1, d, Lf(l, ATT_BV), 2, w.vt, (long)c.B * D.Tp, 0, nullptr, 0, 1.f, 0, d, M, d,
+                         T2, D.Tp, st));
+        RUN(mi_attention_bf16(w.qk, 2 * d, w.qk + d, 2 * d, w.vt, (long)c.B * D.Tp, D.Tp,
+                              c.pos_type == 1 ? (const bf16_t*)posp + (size_t)l * P * d : nullptr, d,
+                              c.pos_type == 1 ? Lf(l, ATT_U) : nullptr, c.pos_type == 1 ? Lf(l, ATT_V) : nullptr,
+                              mask_len, w.ctx, d, c.B, T2, c.H, D.hd, scale, c.is_causal, st));
+        RUN(mi_gemm_bf16(w.ctx, d, Lw(l, ATT_WO), d, Lf(l, ATT_BO), 1, w.cat, 2 * d, 0, nullptr, 0, 1.f, 0, M, d, d, 0, 0, st));
+        // local branch: cgMLP (e_branchformer.py:291-292, 184-222)
+        RUN(mi_gemm_bf16(w.a2, d, Lw(l, MLP_W1), d, Lf(l, MLP_B1), 1, w.h, I, 0, nullptr, 0, 1.f, 1, M, I, d, 0, 0, st));
+        RUN(mi_row_stats_bf16(w.h + I / 2, I, I / 2, leps, w.stats, M, st));
+        // quirk: the causal CSGU conv is dilated by (K-1)/2 (e_branchformer.py:153-160 passes it in the dilation slot)
+        const int dil = c.is_causal ? (kc - 1) / 2 : 1;
+        const int cpad = c.is_causal ? (kc - 1) * dil : (kc - 1) / 2;
+        RUN(mi_csgu_bf16(w.h, I, w.stats, Lf(l, CSGU_LN_G), Lf(l, CSGU_LN_B), Lf(l, CSGU_W), Lf(l, CSGU_B), w.s, I / 2,
+                         c.B, T2, I / 2, kc, cpad, dil, c.csgu_act, st));
+        RUN(mi_gemm_bf16(w.s, I / 2, Lw(l, MLP_W2), I / 2, Lf(l, MLP_B2), 1, w.cat + d, 2 * d, 0, nullptr, 0, 1.f, 0, M, d, I / 2, 0, 0, st));
+        // merge (e_branchformer.py:296-304)
+        RUN(mi_dwconv_residual_bf16(w.cat, 2 * d, Lf(l, MRG_DW_W), Lf(l, MRG_DW_B), w.m2, 2 * d, c.B, T2, 2 * d, km, (km - 1) / 2, st));
+        RUN(mi_gemm_bf16(w.m2, 2 * d, Lw(l, MRG_W), 2 * d, Lf(l, MRG_B), 1, w.x, d, 1, w.x, d, 1.0f, 0, M, d, 2 * d, 0, 0, st));
+        if (c.use_macaron) {   // e_branchformer.py:307-309
+            RUN(mi_layernorm_chain(w.x, d, nullptr, T2, nullptr, nullptr, 0.f, nullptr, 0, Lf(l, FF2_LN_G), Lf(l, FF2_LN_B), leps,
+                                   w.a0, d, nullptr, 0, nullptr, nullptr, nullptr, 0, M, d, st));
+            RUN(mi_gemm_bf16(w.a0, d, Lw(l, FF2_W1), d, Lf(l, FF2_B1), 1, w.h, I, 0, nullptr, 0, 1.f, 1, M, I, d, 0, 0, st));
+            RUN(mi_gemm_bf16(w.h, I, Lw(l, FF2_W2), I, Lf(l, FF2_B2), 1, w.x, d, 1, w.x, d, 0.5f, 0, M, d, I, 0, 0, st));
+        }
+        // final_layer_norm (:312) chained with the next consumer's LayerNorm(s)
+        if (l + 1 == c.L)
+            RUN(mi_layernorm_chain(w.x, d, nullptr, T2, Lf(l, FIN_LN_G), Lf(l, FIN_LN_B), leps, nullptr, 0,
+                                   Gf(G_ENC_LN_G), Gf(G_ENC_LN_B), c.ln_eps, w.hid, d, last_hidden, d, nullptr, nullptr, nullptr, 0, M, d, st));
+        else if (c.use_macaron)
+            RUN(mi_layernorm_chain(w.x, d, nullptr, T2, Lf(l, FIN_LN_G), Lf(l, FIN_LN_B), leps, w.x, d,
+                                   Lf(l + 1, FF1_LN_G), Lf(l + 1, FF1_LN_B), leps, w.a0, d, nullptr, 0, nullptr, nullptr, nullptr, 0, M, d, st));
+        else
+            RUN(mi_layernorm_chain(w.x, d, nullptr, T2, Lf(l, FIN_LN_G), Lf(l, FIN_LN_B), leps, w.x, d,
+                                   Lf(l + 1, ATT_LN_G), Lf(l + 1, ATT_LN_B), leps, w.a1, d, nullptr, 0,
+                                   Lf(l + 1, MLP_LN_G), Lf(l + 1, MLP_LN_B), w.a2, d, M, d, st));
+    }
+    // CTC head: lm_head ⊕ blank_projection, blank LAST (e_branchformer.py:456-457)
+    if (logits)
+        RUN(mi_gemm_bf16(w.hid, d, Gw(G_HEAD_W), d, Gf(G_HEAD_B), 1, logits, c.V + 1, c.logits_f32, nullptr, 0, 1.f, 0,
+                         M, c.V + 1, d, 0, 0, st));
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}

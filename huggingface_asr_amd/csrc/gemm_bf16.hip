@@ -1,0 +1,226 @@
+// bf16 MFMA GEMM with fused epilogues for gfx950:  C[M,N] = epi(A[M,K] · W[N,K]^T)
+//
+// This one kernel carries every nn.Linear of the E-Branchformer path (reference
+// e_branchformer.py:96-98,139,212-216,247 / tf wav2vec2_conformer FFN :350-357 / extractors.py:108,131 /
+// lm_head ⊕ blank_projection e_branchformer.py:456-457) and, with the implicit-im2col A loader,
+// the second Conv2d of the sub-sampling front end (extractors.py:71-96).
+//
+// Tiling (wave64, v_mfma_f32_32x32x16_bf16): block 128x128x64, 4 waves as 2x2, each wave 64x64 =
+// 2x2 MFMA tiles; A and W tiles are K-contiguous in HBM (nn.Linear layout), staged HBM->VGPR->LDS
+// with the next tile's loads in flight under the current tile's MFMAs, LDS double-buffered
+// (one barrier per K tile) and XOR-swizzled so that every ds_read_b128 lane group hits 16 distinct
+// 16-B slots.  blockIdx is remapped so that the blocks of one XCD walk neighbouring N tiles of the
+// same A row panel (A panel + W stay in that XCD's L2).
+#include "common.hpp"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int NT = 256;
+
+struct GemmArgs {
+    const bf16_t* A; long lda;
+    const bf16_t* W; long ldw;
+    const float* bias; int bias_mode;      // 0 none, 1 per output column, 2 per output row
+    void* C; long ldc; int out_f32;
+    const float* resid; long ldr; float alpha;   // if resid: out = resid + alpha * (acc + bias)
+    int act;                                // 0 none, 1 gelu(erf)
+    int col_T, col_Tp;                      // != 0: output column n -> (n / col_T) * col_Tp + n % col_T
+    int M, N, K;
+    // implicit im2col (CONV): A is a channels-last activation (B, Tin, Fin, Cin); row m = (b, to, fo);
+    // k = (kh*KW + kw)*Cin + c
+    int Tin, Fin, Cin, Tout, Fout, KW, stride, pad_t, pad_f;
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+template <bool CONV>
+__global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* sA = reinterpret_cast<bf16_t*>(smem);                 // [2][BM*BK]
+    bf16_t* sB = sA + 2 * BM * BK;                                // [2][BN*BK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware, bijective block remap (8 XCDs, round-robin dispatch): logical id walks N fastest.
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    const int nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / ntn, tn = bid % ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // staging assignment: 4 chunks (16 B) of A and of W per thread; rows (tid>>3)+32*i, chunk tid&7
+    const int srow = tid >> 3, schunk = tid & 7;
+    const bf16_t* aptr[4];
+    bool aval[4];
+    long abase[4];      // CONV: element offset of (b, to*stride - pad, fo*stride - pad, 0)
+    int ati[4], afi[4];
+    const bf16_t* wptr[4];
+    bool wval[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + srow + 32 * i;
+        aval[i] = m < p.M;
+        if (CONV) {
+            const int mm = aval[i] ? m : 0;
+            const int fo = mm % p.Fout, to = (mm / p.Fout) % p.Tout, b = mm / (p.Fout * p.Tout);
+            ati[i] = to * p.stride - p.pad_t;
+            afi[i] = fo * p.stride - p.pad_f;
+            abase[i] = (long)b * p.Tin * p.Fin * p.Cin;
+            aptr[i] = p.A;
+        } else {
+            aptr[i] = p.A + (long)(aval[i] ? m : 0) * p.lda + schunk * 8;
+        }
+        const int n = n0 + srow + 32 * i;
+        wval[i] = n < p.N;
+        wptr[i] = p.W + (long)(wval[i] ? n : 0) * p.ldw + schunk * 8;
+    }
+
+    bf16x8 ra[4], rb[4];
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    auto gload = [&](int kt) {
+        const int k = kt * BK + schunk * 8;          // this thread's K offset (same for its 4 rows)
+        const bool kok = k < p.K;                    // K % 8 == 0: a 16-B chunk never straddles K
+        int kh = 0, kw = 0, c0 = 0;
+        if (CONV) {
+            const int tap = k / p.Cin;               // Cin % 8 == 0: a chunk never straddles a tap
+            c0 = k - tap * p.Cin;
+            kh = tap / p.KW;
+            kw = tap - kh * p.KW;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (CONV) {
+                const int ti = ati[i] + kh, fi = afi[i] + kw;
+                const bool ok = kok && aval[i] && ti >= 0 && ti < p.Tin && fi >= 0 && fi < p.Fin;
+                ra[i] = ok ? *reinterpret_cast<const bf16x8*>(p.A + abase[i] + ((long)ti * p.Fin + fi) * p.Cin + c0)
+                           : zero8;
+            } else {
+                ra[i] = (kok && aval[i]) ? *reinterpret_cast<const bf16x8*>(aptr[i] + kt * BK) : zero8;
+            }
+            rb[i] = (kok && wval[i]) ? *reinterpret_cast<const bf16x8*>(wptr[i] + kt * BK) : zero8;
+        }
+    };
+    auto sstore = [&](int buf) {
+        bf16_t* a = sA + buf * BM * BK;
+        bf16_t* b = sB + buf * BN * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = srow + 32 * i;
+            const int off = row * BK + swz(row, schunk) * 8;
+            *reinterpret_cast<bf16x8*>(a + off) = ra[i];
+            *reinterpret_cast<bf16x8*>(b + off) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+
+    const int lr = lane & 31, lh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const bf16_t* a = sA + buf * BM * BK;
+        const bf16_t* b = sB + buf * BN * BK;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 64 + i * 32 + lr;
+                fa[i] = *reinterpret_cast<const bf16x8*>(a + row * BK + swz(row, ks * 2 + lh) * 8);
+                const int col = wn * 64 + i * 32 + lr;
+                fb[i] = *reinterpret_cast<const bf16x8*>(b + col * BK + swz(col, ks * 2 + lh) * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) sstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + lr;
+        if (n >= p.N) continue;
+        const float bcol = (p.bias_mode == 1) ? p.bias[n] : 0.f;
+        const long nc = p.col_T ? (long)(n / p.col_T) * p.col_Tp + (n % p.col_T) : n;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bcol;
+                if (p.bias_mode == 2) v += p.bias[m];
+                if (p.act == 1) v = gelu_erf(v);
+                if (p.resid) v = p.resid[(long)m * p.ldr + n] + p.alpha * v;
+                if (p.out_f32) reinterpret_cast<float*>(p.C)[(long)m * p.ldc + nc] = v;
+                else reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + nc] = f2bf(v);
+            }
+        }
+    }
+}
+
+int launch(const GemmArgs& a, bool conv, hipStream_t stream) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % 8) != 0) return MI_ERR_ARG;
+    if (!conv && ((a.lda % 8) != 0)) return MI_ERR_ARG;
+    if ((a.ldw % 8) != 0) return MI_ERR_ARG;
+    if (conv && (a.Cin % 8) != 0) return MI_ERR_ARG;
+    const int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
+    const size_t lds = 2 * (BM + BN) * BK * sizeof(bf16_t);
+    if (conv) hipLaunchKernelGGL(gemm_bf16_kernel<true>, dim3(grid), dim3(NT), lds, stream, a);
+    else hipLaunchKernelGGL(gemm_bf16_kernel<false>, dim3(grid), dim3(NT), lds, stream, a);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+}  // namespace
+
+extern "C" int mi_gemm_bf16(const void* A, long lda, const void* W, long ldw, const float* bias, int bias_mode,
+                            void* C, long ldc, int out_f32, const float* resid, long ldr, float alpha, int act,
+                            int M, int N, int K, int col_T, int col_Tp, hipStream_t stream) {
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw;
+    a.bias = bias; a.bias_mode = bias ? bias_mode : 0;
+    a.C = C; a.ldc = ldc; a.out_f32 = out_f32; a.resid = resid; a.ldr = ldr; a.alpha = alpha; a.act = act;
+    a.M = M; a.N = N; a.K = K; a.col_T = col_T; a.col_Tp = col_Tp;
+    return launch(a, false, stream);
+}
+
+// Conv2d (KHxKW, stride s, zero padding) over a channels-last bf16 activation as an implicit GEMM:
+//   in  (B, Tin, Fin, Cin) bf16, weight (Cout, KH*KW*Cin) bf16 with k = (kh*KW + kw)*Cin + c,
+//   out (B, Tout, Fout, Cout) bf16 = act(conv + bias).
+extern "C" int mi_conv2d_cl_bf16(const void* in, const void* weight, const float* bias, void* out,
+                                 int B, int Tin, int Fin, int Cin, int Cout, int KH, int KW, int stride,
+                                 int pad_t, int pad_f, int Tout, int Fout, int act, hipStream_t stream) {
+    GemmArgs a{};
+    a.A = (const bf16_t*)in; a.lda = 0; a.W = (const bf16_t*)weight; a.ldw = (long)KH * KW * Cin;
+    a.bias = bias; a.bias_mode = bias ? 1 : 0;
+    a.C = out; a.ldc = Cout; a.out_f32 = 0; a.resid = nullptr; a.ldr = 0; a.alpha = 1.f; a.act = act;
+    a.M = B * Tout * Fout; a.N = Cout; a.K = KH * KW * Cin;
+    a.Tin = Tin; a.Fin = Fin; a.Cin = Cin; a.Tout = Tout; a.Fout = Fout; a.KW = KW; a.stride = stride;
+    a.pad_t = pad_t; a.pad_f = pad_f;
+    return launch(a, true, stream);
+}

@@ -1,0 +1,173 @@
+"""Thin torch-tensor wrappers over the C ABI (one per entry point in include/hfasr_hip.h).
+
+PyTorch is used for device memory and streams only; every op here runs a hand-written HIP kernel on
+`torch.cuda.current_stream()`.  All tensors must be CUDA(HIP) tensors; there is no CPU path.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, dtype=None):
+    if not t.is_cuda:
+        raise RuntimeError("huggingface_asr_amd ops need device tensors (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    return t
+
+
+def gemm(a, w, bias=None, out=None, *, out_dtype=BF16, act="none", resid=None, alpha=1.0, bias_per_row=False,
+         col_remap=None):
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T); a/w bf16 (last dim contiguous)."""
+    _req(a, BF16); _req(w, BF16)
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=out_dtype)
+    ct, ctp = col_remap if col_remap else (0, 0)
+    rc = _lib.lib().mi_gemm_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _p(bias),
+                                 (2 if bias_per_row else 1) if bias is not None else 0,
+                                 out.data_ptr(), out.stride(0), int(out.dtype == torch.float32),
+                                 _p(resid), resid.stride(0) if resid is not None else 0, float(alpha),
+                                 {"none": 0, "gelu": 1}[act], M, N, K, ct, ctp, _stream())
+    _lib.check(rc, "mi_gemm_bf16")
+    return out
+
+
+def conv2d_first_gelu(x, w, bias, stride=2, pad=1, causal=False):
+    """x (B,T,F) f32, w (C,K*K) f32 -> channels-last (B,T1,F1,C) bf16 = gelu(conv)."""
+    B, T, F = x.shape
+    Cc, KK = w.shape
+    K = int(round(math.sqrt(KK)))
+    T1, F1 = (T + 2 * pad - K) // stride + 1, (F + 2 * pad - K) // stride + 1
+    out = torch.empty((B, T1, F1, Cc), device=x.device, dtype=BF16)
+    pl = 2 * pad if causal else pad
+    rc = _lib.lib().mi_conv2d_first_gelu(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), B, T, F, Cc, K,
+                                         stride, pl, pl, T1, F1, _stream())
+    _lib.check(rc, "mi_conv2d_first_gelu")
+    return out
+
+
+def conv2d_cl(x, w, bias, K=3, stride=2, pad=1, causal=False, act="gelu"):
+    """x (B,T,F,Cin) bf16 channels-last, w (Cout, K*K*Cin) bf16 -> (B,T',F',Cout) bf16."""
+    B, T, F, Cin = x.shape
+    Cout = w.shape[0]
+    T1, F1 = (T + 2 * pad - K) // stride + 1, (F + 2 * pad - K) // stride + 1
+    out = torch.empty((B, T1, F1, Cout), device=x.device, dtype=BF16)
+    pl = 2 * pad if causal else pad
+    rc = _lib.lib().mi_conv2d_cl_bf16(x.data_ptr(), w.data_ptr(), _p(bias), out.data_ptr(), B, T, F, Cin, Cout, K, K, stride,
+                                      pl, pl, T1, F1, {"none": 0, "gelu": 1}[act], _stream())
+    _lib.check(rc, "mi_conv2d_cl_bf16")
+    return out
+
+
+def layernorm_chain(x, *, lengths=None, T=1, ln1=None, eps1=1e-5, store_y=None, lna=None, eps2=1e-5, outa=None,
+                    outa32=None, lnb=None, outb=None):
+    """see csrc/norm.hip; x (M,d) f32; ln* = (gamma, beta) f32."""
+    M, d = x.shape
+    g1, b1 = ln1 if ln1 else (None, None)
+    ga, ba = lna if lna else (None, None)
+    gb, bb = lnb if lnb else (None, None)
+    rc = _lib.lib().mi_layernorm_chain(x.data_ptr(), x.stride(0), _p(lengths), T, _p(g1), _p(b1), eps1,
+                                       _p(store_y), store_y.stride(0) if store_y is not None else 0,
+                                       _p(ga), _p(ba), eps2, _p(outa), outa.stride(0) if outa is not None else 0,
+                                       _p(outa32), outa32.stride(0) if outa32 is not None else 0,
+                                       _p(gb), _p(bb), _p(outb), outb.stride(0) if outb is not None else 0, M, d, _stream())
+    _lib.check(rc, "mi_layernorm_chain")
+
+
+def rotary(x, cos, sin, T, H):
+    M, d = x.shape
+    out = torch.empty_like(x)
+    rc = _lib.lib().mi_rotary_bf16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), cos.data_ptr(), sin.data_ptr(),
+                                   M, T, H, d // H, _stream())
+    _lib.check(rc, "mi_rotary_bf16")
+    return out
+
+
+def attention(q, k, vt, Tp, B, T, H, *, pos=None, bias_u=None, bias_v=None, lengths=None, causal=False):
+    """q,k (B*T, >=d) bf16 views; vt (d, B*Tp) bf16; pos (2T-1, d) bf16 or None -> ctx (B*T, d) bf16."""
+    d = vt.shape[0]
+    hd = d // H
+    out = torch.empty((B * T, d), device=q.device, dtype=BF16)
+    rc = _lib.lib().mi_attention_bf16(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), vt.data_ptr(), vt.stride(0), Tp,
+                                      _p(pos), pos.stride(0) if pos is not None else 0, _p(bias_u), _p(bias_v), _p(lengths),
+                                      out.data_ptr(), out.stride(0), B, T, H, hd, 1.0 / math.sqrt(hd), int(causal), _stream())
+    _lib.check(rc, "mi_attention_bf16")
+    return out
+
+
+def row_stats(x, eps=1e-5):
+    M, d = x.shape
+    st = torch.empty((M, 2), device=x.device, dtype=torch.float32)
+    rc = _lib.lib().mi_row_stats_bf16(x.data_ptr(), x.stride(0), d, eps, st.data_ptr(), M, _stream())
+    _lib.check(rc, "mi_row_stats_bf16")
+    return st
+
+
+def csgu(u, gamma, beta, w, bias, B, T, *, pad_left=None, dilation=1, act=0, eps=1e-5):
+    """u (B*T, 2C) bf16 = [x_r | x_g] -> x_r * act(dwconv(LN(x_g)) + b)  (B*T, C) bf16."""
+    M, C2 = u.shape
+    Cc = C2 // 2
+    K = w.shape[-1]
+    st = row_stats(u[:, Cc:], eps)
+    out = torch.empty((M, Cc), device=u.device, dtype=BF16)
+    rc = _lib.lib().mi_csgu_bf16(u.data_ptr(), u.stride(0), st.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(),
+                                 _p(bias), out.data_ptr(), out.stride(0), B, T, Cc, K,
+                                 (K - 1) // 2 if pad_left is None else pad_left, dilation, act, _stream())
+    _lib.check(rc, "mi_csgu_bf16")
+    return out
+
+
+def dwconv_residual(m, w, bias, B, T):
+    M, Cc = m.shape
+    K = w.shape[-1]
+    out = torch.empty_like(m)
+    rc = _lib.lib().mi_dwconv_residual_bf16(m.data_ptr(), m.stride(0), w.data_ptr(), _p(bias), out.data_ptr(), out.stride(0),
+                                            B, T, Cc, K, (K - 1) // 2, _stream())
+    _lib.check(rc, "mi_dwconv_residual_bf16")
+    return out
+
+
+def row_lse(x):
+    M, V = x.shape
+    out = torch.empty((M,), device=x.device, dtype=torch.float32)
+    rc = _lib.lib().mi_row_lse(x.data_ptr(), x.stride(0), 0 if x.dtype == torch.float32 else 1, V, out.data_ptr(), M, _stream())
+    _lib.check(rc, "mi_row_lse")
+    return out
+
+
+def ctc_loss(logits, labels, in_len, *, reduction="mean", zero_infinity=False, lse=None):
+    """logits (B,T,V+1) f32|bf16 (blank = last class), labels (B,U) int64 (<0 = padding), in_len (B) int32.
+    Returns (loss scalar tensor | per-utterance nll for reduction='none', nll (B), tgt_len (B))."""
+    B, T, V1 = logits.shape
+    labels = labels.contiguous()
+    U = labels.shape[1]
+    if lse is None:
+        lse = row_lse(logits.reshape(B * T, V1))
+    nll = torch.empty((B,), device=logits.device, dtype=torch.float32)
+    tl = torch.empty((B,), device=logits.device, dtype=torch.int32)
+    loss = torch.empty((1,), device=logits.device, dtype=torch.float32)
+    rc = _lib.lib().mi_ctc_loss_fwd(logits.data_ptr(), logits.stride(0), logits.stride(1), 0 if logits.dtype == torch.float32 else 1,
+                                    lse.data_ptr(), T, labels.data_ptr(), U, in_len.data_ptr(), V1 - 1, B,
+                                    1 if reduction == "mean" else 0, int(zero_infinity), nll.data_ptr(), tl.data_ptr(),
+                                    loss.data_ptr(), _stream())
+    _lib.check(rc, "mi_ctc_loss_fwd")
+    if reduction == "none":
+        out = torch.where(torch.isinf(nll), torch.zeros_like(nll), nll) if zero_infinity else nll
+        return out, nll, tl
+    return loss[0], nll, tl

@@ -1,0 +1,126 @@
+/* libhfasr_hip.so — C ABI of the MI355X (gfx950) hot path behind the BUTSpeechFIT/huggingface_asr model surface.
+ *
+ * The reference is 100 % Python and has no FFI of its own: its "plug-in" boundary is
+ * HuggingFace's Auto-class registry (reference src/utilities/bind.py:36-58).  This header is the C boundary
+ * that sits directly below that Python surface: one entry point per tensor op of the hot path, plus one
+ * whole-encoder driver.  Every function
+ *   - takes raw device pointers, element strides and sizes (no torch types), and a hipStream_t,
+ *   - enqueues kernels on that stream and returns immediately (no allocation, no synchronisation,
+ *     no global state; workspaces are passed in, so calls are hipGraph-capturable),
+ *   - returns 0 (MI_OK) or a negative error code (MI_ERR_ARG -1, MI_ERR_LAUNCH -2, MI_ERR_UNSUPPORTED -3).
+ * bf16 buffers are raw 2-byte bfloat16; "ld" arguments are row strides in ELEMENTS.
+ * The reference-side binding is the ctypes loader in huggingface_asr_amd/_lib.py.
+ */
+#ifndef HFASR_HIP_H
+#define HFASR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* mi_stream_t; /* = hipStream_t */
+
+/* ---- nn.Linear / lm_head / projections: C[M,N] = epi(A[M,K] * W[N,K]^T), bf16 in, fp32 accumulate (MFMA).
+ * replaces: every nn.Linear on the path — reference src/models/encoders/e_branchformer.py:96-98,139,212-216,247,456-457;
+ *           src/models/extractors.py:108,131; transformers wav2vec2_conformer FFN (modeling :350-357).
+ * bias_mode 0 none / 1 per column / 2 per row; act 0 none / 1 gelu(erf);
+ * resid != NULL: out = resid[m*ldr+n] + alpha*(acc+bias); out_f32 selects fp32 or bf16 C.
+ * col_T/col_Tp != 0: output column n is remapped to (n / col_T) * col_Tp + n % col_T (time-padded V^T). */
+int mi_gemm_bf16(const void* A, long lda, const void* W, long ldw, const float* bias, int bias_mode,
+                 void* C, long ldc, int out_f32, const float* resid, long ldr, float alpha, int act,
+                 int M, int N, int K, int col_T, int col_Tp, mi_stream_t stream);
+
+/* ---- Conv2d sub-sampling, second layer (C->C, KxK, stride s) as implicit GEMM over a channels-last activation.
+ * replaces: src/models/extractors.py:71-96 (layers >= 1) incl. the causal left-padded form src/models/streaming_modules.py:31-55. */
+int mi_conv2d_cl_bf16(const void* in, const void* weight, const float* bias, void* out,
+                      int B, int Tin, int Fin, int Cin, int Cout, int KH, int KW, int stride,
+                      int pad_t, int pad_f, int Tout, int Fout, int act, mi_stream_t stream);
+
+/* ---- Conv2d sub-sampling, first layer (1->C) + GELU over the padded (B,T,F) fp32 log-mel layout; output channels-last bf16.
+ * replaces: src/models/extractors.py:71-96 (layer 0) and :111. */
+int mi_conv2d_first_gelu(const float* x, const float* w, const float* bias, void* out_cl_bf16,
+                         int B, int T, int F, int C, int K, int stride, int pad_t, int pad_f,
+                         int T1, int F1, mi_stream_t stream);
+
+/* ---- LayerNorm chain on the fp32 residual stream (see csrc/norm.hip).
+ * replaces: nn.LayerNorm at e_branchformer.py:233,236,242,257,261; feature projection LN (extractors.py:130);
+ *           encoder.layer_norm (wav2vec2_conformer :707); zeroing of padded frames (:662-665) via `lengths`. */
+int mi_layernorm_chain(const float* x, long ldx, const int* lengths, int T,
+                       const float* g1, const float* b1, float eps1, float* y32, long ldy,
+                       const float* ga, const float* ba, float eps2, void* outa_bf16, long lda,
+                       float* outa_f32, long lda32,
+                       const float* gb, const float* bb, void* outb_bf16, long ldb,
+                       int M, int d, mi_stream_t stream);
+
+/* ---- rotary embedding of the Q/K projection input. replaces: wav2vec2_conformer _apply_rotary_embedding (:509-526). */
+int mi_rotary_bf16(const void* x, long ldx, void* out, long ldo, const float* cos_t, const float* sin_t,
+                   int M, int T, int H, int hd, mi_stream_t stream);
+
+/* ---- fused self-attention (relative-position / rotary / plain), key-padding + optional causal mask.
+ * replaces: Wav2Vec2EBranchformerSelfAttention.forward e_branchformer.py:100-138 and
+ *           _apply_relative_embeddings wav2vec2_conformer :528-565.  pos == NULL: no relative term. */
+int mi_attention_bf16(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, int Tp,
+                      const void* pos, long ldp, const float* bias_u, const float* bias_v,
+                      const int* lengths, void* out, long ldo, int B, int T, int H, int hd,
+                      float scale, int causal, mi_stream_t stream);
+
+/* ---- cgMLP gate: per-row LN statistics + fused LN -> depthwise conv(time) -> gate.
+ * replaces: ConvolutionalSpatialGatingUnit.forward e_branchformer.py:184-204. */
+int mi_row_stats_bf16(const void* x, long ldx, int d, float eps, float* stats, int M, mi_stream_t stream);
+int mi_csgu_bf16(const void* u, long ldu, const float* stats, const float* gamma, const float* beta,
+                 const float* w, const float* bias, void* out, long ldo,
+                 int B, int T, int C, int K, int pad_left, int dilation, int act, mi_stream_t stream);
+
+/* ---- merge block depthwise conv + residual. replaces: e_branchformer.py:296-299. */
+int mi_dwconv_residual_bf16(const void* m, long ldm, const float* w, const float* bias, void* out, long ldo,
+                            int B, int T, int C, int K, int pad_left, mi_stream_t stream);
+
+/* ---- log-mel front end. replaces: CustomFeatureExtractor.__call__ (src/utilities/feature_extractors.py:51-61) =
+ *      Speech2TextFeatureExtractor._extract_fbank_features / utterance_cmvn (transformers) / global_normalize (:47-49). */
+int mi_fbank_f64(const float* wave, long ldw, const int* num_samples, int N, const double* window,
+                 const double* twiddle, const double* mel_t, const int* mel_lo, const int* mel_hi,
+                 float* out, int T_out, int B, int nmel, double mel_floor, double preemph, mi_stream_t stream);
+int mi_cmvn_utterance(float* x, const int* frames, int B, int T, int nmel, int norm_means, int norm_vars,
+                      float pad, mi_stream_t stream);
+int mi_cmvn_global(float* x, long total, int nmel, const float* means, const float* stds, mi_stream_t stream);
+
+/* ---- CTC tail. replaces: log_softmax + F.ctc_loss at e_branchformer.py:472-488. */
+int mi_row_lse(const void* x, long ld, int dtype, int V, float* lse, int M, mi_stream_t stream);
+int mi_ctc_loss_fwd(const void* logits, long ld_b, long ld_t, int dtype, const float* lse, int T,
+                    const long* labels, int U, const int* in_len, int blank, int B,
+                    int reduction, int zero_infinity, float* nll, int* tgt_len, float* loss, mi_stream_t stream);
+
+/* ---- whole encoder + CTC head: Wav2Vec2EBranchformerForCTC.forward (e_branchformer.py:422-496), eval mode. */
+typedef struct {
+    int B, T, F;                 /* padded log-mel input (B,T,F) fp32 */
+    int d, H, I, L, V;           /* hidden, heads, intermediate, layers, vocab (blank excluded) */
+    int C1, C2, K, stride, pad;  /* Conv2d sub-sampling: 1->C1->C2, KxK, stride, padding */
+    int is_causal;
+    int pos_type;                /* 0 none, 1 relative, 2 rotary */
+    int csgu_kernel, merge_kernel, csgu_act, use_macaron;
+    float ln_eps;                /* feature-projection / encoder LayerNorm eps (layer LNs use 1e-5) */
+    int logits_f32;              /* 1: fp32 logits, 0: bf16 logits */
+} mi_ebf_config;
+
+/* weight-table slot indices: see huggingface_asr_amd/engine.py (SLOTS) — the table is an array of device pointers. */
+enum { MI_EBF_GLOBAL_SLOTS = 24, MI_EBF_LAYER_SLOTS = 48 };
+
+size_t mi_ebf_workspace_bytes(const mi_ebf_config* cfg);
+
+/* feats (B,T,F) fp32; feat_lengths (B) int32 valid frames (attention_mask.sum(-1)) or NULL;
+ * pos_table: relative: (2*T2-1, d) bf16 sinusoid table; rotary: fp32 [cos (T2,hd) | sin (T2,hd)]; none: NULL;
+ * posp: (L, 2*T2-1, d) bf16 scratch for the projected relative positions, recomputed when compute_posp != 0
+ *       (it depends only on the weights and T2, so callers cache it across calls at inference);
+ * workspace: mi_ebf_workspace_bytes(cfg) bytes, ZERO-INITIALISED ONCE by the caller (time padding of V^T);
+ * outputs: last_hidden (B*T2, d) fp32 (nullable), logits (B*T2, V+1) fp32|bf16 (nullable),
+ *          inner_len/outer_len (B) int32 (mask lengths / CTC input lengths, nullable). */
+int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weights, const float* feats, const int* feat_lengths,
+                   const void* pos_table, void* posp, int compute_posp, void* workspace, size_t workspace_bytes,
+                   float* last_hidden, void* logits, int* inner_len, int* outer_len, mi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

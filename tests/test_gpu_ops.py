@@ -1,0 +1,285 @@
+"""GPU parity, op by op: every C-ABI entry point (through huggingface_asr_amd.ops -> ctypes -> libhfasr_hip.so)
+against the oracle's restatement of the same reference op, on identical bf16-rounded inputs.
+
+Tolerances: outputs stored in bf16 are compared at ~1 bf16 ulp (2^-8 relative) of the fp32 oracle value;
+fp32 outputs at 1e-3 abs (accumulation order only)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import load_golden
+from oracle import ebranchformer_ref as R
+from oracle import fbank_ref
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _ops():
+    from huggingface_asr_amd import ops
+    return ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def bfr(x):
+    return x.to(torch.bfloat16).float()
+
+
+def assert_close_bf16(got, want, atol=2e-2, rtol=1.2e-2, what=""):
+    got, want = got.float().cpu(), want.float().cpu()
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    bad = err > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} / {bad.numel()} off, max err {float(err.max()):.4g}"
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (250, 512, 512), (300, 5001, 64), (1000, 192, 1024), (64, 64, 128), (129, 130, 72)])
+def test_gemm_plain(M, N, K):
+    ops = _ops()
+    a, w, b = bfr(rnd(M, K, seed=1)), bfr(rnd(N, K, seed=2, scale=1 / math.sqrt(K))), rnd(N, seed=3)
+    want = a @ w.t() + b
+    got32 = ops.gemm(a.to(DEV, torch.bfloat16), w.to(DEV, torch.bfloat16), b.to(DEV), out_dtype=torch.float32)
+    torch.testing.assert_close(got32.cpu(), want, atol=2e-3, rtol=1e-4)
+    got16 = ops.gemm(a.to(DEV, torch.bfloat16), w.to(DEV, torch.bfloat16), b.to(DEV))
+    assert_close_bf16(got16, want, what="gemm bf16")
+
+
+def test_gemm_identity_asymmetric():
+    """A = I with an asymmetric W catches a transposed C write (guide §3)."""
+    ops = _ops()
+    n = 128
+    a = torch.eye(n)
+    w = bfr(torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 - 100.0)
+    got = ops.gemm(a.to(DEV, torch.bfloat16), w.to(DEV, torch.bfloat16), None, out_dtype=torch.float32)
+    torch.testing.assert_close(got.cpu(), w.t().contiguous(), atol=0, rtol=0)
+
+
+def test_gemm_epilogues():
+    ops = _ops()
+    M, N, K = 257, 384, 256
+    a, w, b = bfr(rnd(M, K, seed=4)), bfr(rnd(N, K, seed=5, scale=1 / 16)), rnd(N, seed=6)
+    res = rnd(M, N, seed=7)
+    ad, wd, bd = a.to(DEV, torch.bfloat16), w.to(DEV, torch.bfloat16), b.to(DEV)
+    lin = a @ w.t() + b
+    assert_close_bf16(ops.gemm(ad, wd, bd, act="gelu"), F.gelu(lin), what="gelu")
+    x = res.to(DEV).clone()
+    ops.gemm(ad, wd, bd, out=x, resid=x, alpha=0.5)            # in-place residual update
+    torch.testing.assert_close(x.cpu(), res + 0.5 * lin, atol=2e-3, rtol=1e-4)
+    # strided output (writes one half of a concat buffer) leaves the other half untouched
+    cat = torch.full((M, 2 * N), 7.0, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(ad, wd, bd, out=cat[:, N:])
+    assert_close_bf16(cat[:, N:], lin, what="strided out")
+    assert bool((cat[:, :N] == 7.0).all())
+    # transposed product with per-row bias and time-padded column remap (the V^T projection)
+    T, Tp, B = 50, 64, 4
+    a2 = bfr(rnd(B * T, K, seed=8))
+    wv, bv = bfr(rnd(96, K, seed=9, scale=1 / 16)), rnd(96, seed=10)
+    vt = torch.zeros((96, B * Tp), device=DEV, dtype=torch.bfloat16)
+    ops.gemm(wv.to(DEV, torch.bfloat16), a2.to(DEV, torch.bfloat16), bv.to(DEV), out=vt, bias_per_row=True, col_remap=(T, Tp))
+    want = (a2 @ wv.t() + bv).t().reshape(96, B, T)
+    got = vt.float().cpu().reshape(96, B, Tp)
+    assert_close_bf16(got[:, :, :T], want, what="V^T")
+    assert bool((got[:, :, T:] == 0).all())
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_conv_subsampling(causal):
+    ops = _ops()
+    B, T, Fd, C1, C2 = 2, 61, 80, 32, 64
+    x = rnd(B, T, Fd, seed=11)
+    w1, b1 = rnd(C1, 1, 3, 3, seed=12, scale=0.3), rnd(C1, seed=13, scale=0.1)
+    w2, b2 = bfr(rnd(C2, C1, 3, 3, seed=14, scale=0.08)), rnd(C2, seed=15, scale=0.1)
+    xin = x[:, None]
+    if causal:
+        h1 = F.gelu(F.conv2d(F.pad(xin, (2, 0, 2, 0)), w1, b1, stride=2))
+    else:
+        h1 = F.gelu(F.conv2d(xin, w1, b1, stride=2, padding=1))
+    g1 = ops.conv2d_first_gelu(x.to(DEV), w1.reshape(C1, 9).to(DEV), b1.to(DEV), causal=causal)
+    assert_close_bf16(g1.permute(0, 3, 1, 2), h1, what="conv1")
+    h1q = g1.float().cpu().permute(0, 3, 1, 2)
+    if causal:
+        h2 = F.gelu(F.conv2d(F.pad(h1q, (2, 0, 2, 0)), w2, b2, stride=2))
+    else:
+        h2 = F.gelu(F.conv2d(h1q, w2, b2, stride=2, padding=1))
+    w2p = w2.permute(0, 2, 3, 1).reshape(C2, 9 * C1).to(DEV, torch.bfloat16)
+    g2 = ops.conv2d_cl(g1, w2p, b2.to(DEV), causal=causal)
+    assert_close_bf16(g2.permute(0, 3, 1, 2), h2, what="conv2")
+
+
+@pytest.mark.parametrize("d", [64, 512, 1024])
+def test_layernorm_chain(d):
+    ops = _ops()
+    M, T = 37, 10
+    x = rnd(M, d, seed=20) * 2 + 0.3
+    gs = [1 + 0.1 * rnd(d, seed=21 + i) for i in range(3)]
+    bs = [0.1 * rnd(d, seed=31 + i) for i in range(3)]
+    dev = lambda t: t.to(DEV)
+    # (a) plain LN -> bf16 ; (b) dual ; (c) chain with fp32 store + masked rows
+    xa = dev(x)
+    oa = torch.empty((M, d), device=DEV, dtype=torch.bfloat16)
+    ob = torch.empty_like(oa)
+    ops.layernorm_chain(xa, lna=(dev(gs[0]), dev(bs[0])), outa=oa, lnb=(dev(gs[1]), dev(bs[1])), outb=ob)
+    assert_close_bf16(oa, F.layer_norm(x, (d,), gs[0], bs[0]), what="ln a")
+    assert_close_bf16(ob, F.layer_norm(x, (d,), gs[1], bs[1]), what="ln b")
+    lens = torch.tensor([7, 10, 3, 9], dtype=torch.int32)
+    M2 = 4 * T
+    x2 = rnd(M2, d, seed=40)
+    xm = x2.clone().reshape(4, T, d)
+    for b in range(4):
+        xm[b, lens[b]:] = 0
+    xm = xm.reshape(M2, d)
+    xd = dev(x2)
+    o32 = torch.empty((M2, d), device=DEV)
+    ops.layernorm_chain(xd, lengths=dev(lens), T=T, ln1=(dev(gs[0]), dev(bs[0])), store_y=xd,
+                        lna=(dev(gs[2]), dev(bs[2])), outa32=o32)
+    y = F.layer_norm(xm, (d,), gs[0], bs[0])
+    torch.testing.assert_close(xd.cpu(), y, atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(o32.cpu(), F.layer_norm(y, (d,), gs[2], bs[2]), atol=5e-5, rtol=1e-5)
+    # mask only (no stage 1): padded rows become exactly zero in the residual stream
+    xd2 = dev(x2)
+    ops.layernorm_chain(xd2, lengths=dev(lens), T=T, store_y=xd2, lna=(dev(gs[0]), dev(bs[0])), outa=torch.empty((M2, d), device=DEV, dtype=torch.bfloat16))
+    torch.testing.assert_close(xd2.cpu(), xm, atol=0, rtol=0)
+
+
+def _attn_ref(q, k, v, B, T, H, pos=None, u=None, vb=None, lengths=None, causal=False):
+    d = q.shape[1]
+    hd = d // H
+    qh = q.view(B, T, H, hd).transpose(1, 2)
+    kh = k.view(B, T, H, hd).transpose(1, 2)
+    vh = v.view(B, T, H, hd).transpose(1, 2)
+    if pos is not None:
+        pp = pos.view(-1, H, hd).transpose(0, 1)
+        scores = R.rel_attention_scores(qh, kh, pp, u, vb, R.bf16_round)
+    else:
+        scores = qh @ kh.transpose(-2, -1) / math.sqrt(hd)
+    if lengths is not None:
+        keymask = torch.arange(T)[None, :] >= lengths[:, None]
+        scores = scores.masked_fill(keymask[:, None, None, :], float("-inf"))
+    if causal:
+        scores = scores.masked_fill(torch.ones(T, T, dtype=torch.bool).triu(1), float("-inf"))
+    return (torch.softmax(scores, -1) @ vh).transpose(1, 2).reshape(B * T, d)
+
+
+@pytest.mark.parametrize("T,H,hd,rel,causal", [(50, 4, 16, True, False), (250, 4, 128, True, False), (75, 2, 64, False, False),
+                                               (97, 4, 32, True, True), (33, 4, 16, False, True), (300, 4, 128, True, False)])
+def test_attention(T, H, hd, rel, causal):
+    ops = _ops()
+    B, d = 3, H * hd
+    Tp = (T + 31) // 32 * 32
+    q, k, v = (bfr(rnd(B * T, d, seed=50 + i, scale=0.8)) for i in range(3))
+    lengths = torch.tensor([T, max(1, T - 13), max(1, T // 2)], dtype=torch.int32)
+    pos = bfr(rnd(2 * T - 1, d, seed=55, scale=0.8)) if rel else None
+    u, vb = (0.2 * rnd(H, hd, seed=56), 0.2 * rnd(H, hd, seed=57)) if rel else (None, None)
+    want = _attn_ref(q, k, v, B, T, H, pos, u, vb, lengths, causal)
+    qk = torch.cat([q, k], 1).to(DEV, torch.bfloat16)
+    vt = torch.zeros((d, B * Tp), dtype=torch.bfloat16, device=DEV)
+    vt.view(d, B, Tp)[:, :, :T] = v.t().reshape(d, B, T).to(DEV, torch.bfloat16)
+    got = ops.attention(qk[:, :d], qk[:, d:], vt, Tp, B, T, H, pos=None if pos is None else pos.to(DEV, torch.bfloat16),
+                        bias_u=None if u is None else u.to(DEV), bias_v=None if vb is None else vb.to(DEV),
+                        lengths=lengths.to(DEV), causal=causal)
+    assert_close_bf16(got, want, atol=1.5e-2, rtol=2e-2, what="attention")
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_csgu_and_merge(causal):
+    ops = _ops()
+    B, T, Cc, K = 2, 150, 128, 31
+    u = bfr(rnd(B * T, 2 * Cc, seed=60))
+    g, b = 1 + 0.1 * rnd(Cc, seed=61), 0.1 * rnd(Cc, seed=62)
+    w, wb = rnd(Cc, 1, K, seed=63, scale=0.2), 0.1 * rnd(Cc, seed=64)
+    r_, g_ = u.view(B, T, 2 * Cc).chunk(2, -1)
+    gn = F.layer_norm(g_, (Cc,), g, b)
+    dil = (K - 1) // 2 if causal else 1
+    conv = R.dwconv1d(gn, w, wb, causal, dil)
+    want = (r_ * conv).reshape(B * T, Cc)
+    got = ops.csgu(u.to(DEV, torch.bfloat16), g.to(DEV), b.to(DEV), w.reshape(Cc, K).to(DEV), wb.to(DEV), B, T,
+                   pad_left=(K - 1) * dil if causal else None, dilation=dil)
+    assert_close_bf16(got, want, what="csgu")
+    m = bfr(rnd(B * T, 2 * Cc, seed=65))
+    w2, wb2 = rnd(2 * Cc, 1, K, seed=66, scale=0.2), 0.1 * rnd(2 * Cc, seed=67)
+    want2 = (m.view(B, T, -1) + R.dwconv1d(m.view(B, T, -1), w2, wb2)).reshape(B * T, -1)
+    got2 = ops.dwconv_residual(m.to(DEV, torch.bfloat16), w2.reshape(2 * Cc, K).to(DEV), wb2.to(DEV), B, T)
+    assert_close_bf16(got2, want2, what="merge dwconv")
+
+
+def test_rotary():
+    ops = _ops()
+    B, T, H, hd = 2, 40, 4, 32
+    x = bfr(rnd(B * T, H * hd, seed=70))
+    cos, sin = R.rotary_table(T, hd)
+    want = R.apply_rotary(x.view(B, T, -1), cos, sin, H).reshape(B * T, -1)
+    got = ops.rotary(x.to(DEV, torch.bfloat16), cos.contiguous().to(DEV), sin.contiguous().to(DEV), T, H)
+    assert_close_bf16(got, want, what="rotary")
+
+
+@pytest.mark.parametrize("wave", ["sweep", "noise", "silence_padded"])
+def test_fbank_golden(wave):
+    """HIP log-mel (+CMVN) against the REFERENCE's own outputs (tests/golden/fbank.npz)."""
+    from huggingface_asr_amd import fbank as FB
+    g = load_golden("fbank")
+    tb = FB.FbankTables(80)
+    w = torch.from_numpy(g[f"{wave}_wave"])[None].to(DEV)
+    raw, frames = FB.fbank_gpu(w, tb, normalize=None)
+    assert int(frames[0]) == g[f"{wave}_raw"].shape[0]
+    np.testing.assert_allclose(raw[0].cpu().numpy(), g[f"{wave}_raw"], atol=2e-5, rtol=0)
+    cm, _ = FB.fbank_gpu(w, tb, normalize="utterance")
+    np.testing.assert_allclose(cm[0].cpu().numpy(), g[f"{wave}_cmvn"], atol=2e-5, rtol=0)
+
+
+def test_fbank_ragged_batch_and_padding():
+    from huggingface_asr_amd import fbank as FB
+    from huggingface_asr_amd import synth
+    tb = FB.FbankTables(80)
+    w = synth.waveforms(3, 3, 16000)
+    ns = torch.tensor([16000, 9000, 12345], dtype=torch.int32)
+    feats, frames = FB.fbank_gpu(torch.from_numpy(w).to(DEV), tb, num_samples=ns.to(DEV), pad_frames_to=100)
+    assert feats.shape == (3, 100, 80)
+    for b in range(3):
+        ref = fbank_ref.extract(w[b, : int(ns[b])])
+        n = ref.shape[0]
+        assert int(frames[b]) == n
+        np.testing.assert_allclose(feats[b, :n].cpu().numpy(), ref, atol=3e-5, rtol=0)
+        assert bool((feats[b, n:] == 0).all())
+    # global normalisation
+    means, stds = torch.linspace(5, 9, 80), torch.linspace(2, 4, 80)
+    fg, _ = FB.fbank_gpu(torch.from_numpy(w[:1]).to(DEV), tb, normalize="global", global_means=means.to(DEV), global_stds=stds.to(DEV))
+    np.testing.assert_allclose(fg[0].cpu().numpy(), fbank_ref.extract(w[0], "global", means.numpy(), stds.numpy()), atol=3e-5, rtol=0)
+
+
+@pytest.mark.parametrize("case", ["basic", "repeat", "infeasible", "empty_target"])
+def test_ctc_known_answers(case):
+    ops = _ops()
+    g = load_golden("ctc_known")
+    logits = torch.from_numpy(g[f"{case}/logits"]).to(DEV)
+    labels = torch.from_numpy(g[f"{case}/labels"]).to(DEV)
+    in_len = torch.from_numpy(g[f"{case}/in_len"]).to(DEV, torch.int32)
+    for zi in (0, 1):
+        for red in ("mean", "sum", "none"):
+            got, _, _ = ops.ctc_loss(logits, labels, in_len, reduction=red, zero_infinity=bool(zi))
+            np.testing.assert_allclose(got.cpu().numpy(), g[f"{case}/{red}/{zi}"], rtol=2e-5, atol=2e-5)
+
+
+def test_ctc_large_vs_oracle():
+    ops = _ops()
+    B, T, V, U = 4, 250, 5000, 40
+    logits = rnd(B, T, V + 1, seed=80)
+    labels = torch.randint(0, V, (B, U), generator=torch.Generator().manual_seed(81))
+    labels[1, 30:] = -100
+    labels[2, 5] = -100          # hole inside: masked_select semantics keep the remaining ids in order
+    in_len = torch.tensor([248, 200, 248, 100], dtype=torch.int32)
+    tl = (labels >= 0).sum(-1)
+    want = R.ctc_loss_ref(torch.log_softmax(logits, -1), labels, in_len, tl, blank=V, reduction="none")
+    got, _, tlg = ops.ctc_loss(logits.to(DEV), labels.to(DEV), in_len.to(DEV), reduction="none")
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-5)
+    assert tlg.cpu().tolist() == tl.tolist()
+    got_bf, _, _ = ops.ctc_loss(logits.to(DEV, torch.bfloat16), labels.to(DEV), in_len.to(DEV), reduction="none")
+    want_bf = R.ctc_loss_ref(torch.log_softmax(bfr(logits), -1), labels, in_len, tl, blank=V, reduction="none")
+    np.testing.assert_allclose(got_bf.cpu().numpy(), want_bf.numpy(), rtol=2e-5)
