@@ -58,11 +58,17 @@ def lib():
             raise HipLibraryError(
                 f"{LIB_PATH} not found: build it with `python huggingface_asr_amd/csrc/build.py` "
                 "(or __graft_entry__.build()). There is no CPU fallback for the HIP path.")
+        # PyTorch-ROCm bundles its own libamdhip64; it must be resident BEFORE our library is dlopen()ed so that
+        # both bind to ONE HIP runtime (same SONAME).  Loaded the other way round, the process holds two runtimes
+        # and kernels launched from here fail with hipErrorNoDevice.
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, args in SIGNATURES.items():
             fn = getattr(h, name)          # AttributeError here = header/library mismatch: fail loudly
             fn.argtypes = args
             fn.restype = sz if name == "mi_ebf_workspace_bytes" else i32
+        h.mi_last_error.argtypes = []
+        h.mi_last_error.restype = C.c_char_p
         _lib = h
     return _lib
 
@@ -72,4 +78,5 @@ _ERR = {-1: "invalid argument", -2: "kernel launch failed", -3: "unsupported con
 
 def check(rc: int, what: str):
     if rc != 0:
-        raise RuntimeError(f"{what} failed: {_ERR.get(rc, rc)}")
+        detail = lib().mi_last_error().decode() if rc == -2 else ""
+        raise RuntimeError(f"{what} failed: {_ERR.get(rc, rc)} {detail}")

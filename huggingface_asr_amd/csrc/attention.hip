@@ -197,6 +197,7 @@ extern "C" int mi_attention_bf16(const void* q, long ldq, const void* k, long ld
                                  const void* pos, long ldp, const float* bias_u, const float* bias_v,
                                  const int* lengths, void* out, long ldo, int B, int T, int H, int hd,
                                  float scale, int causal, hipStream_t stream) {
+    MI_ENTER();
     if (B <= 0 || T <= 0 || H <= 0) return MI_ERR_ARG;
     if ((ldq % 8) || (ldk % 8) || (ldvt % 4) || (Tp % 32) || Tp < T || (ldo % 4)) return MI_ERR_ARG;
     if (pos && ((ldp % 8) || !bias_u || !bias_v)) return MI_ERR_ARG;

@@ -17,10 +17,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MI_ERR_LAUNCH (-2)
 #define MI_ERR_UNSUPPORTED (-3)
 
-#define MI_CHECK_LAUNCH()                                \
-    do {                                                 \
-        hipError_t e__ = hipGetLastError();              \
-        if (e__ != hipSuccess) return MI_ERR_LAUNCH;     \
+// hipGetLastError() is per-thread and sticky across unrelated runtime calls (PyTorch leaves benign errors such as a
+// failed hipPointerGetAttributes behind): clear it on entry, so that MI_CHECK_LAUNCH reports only our own launches.
+#define MI_ENTER() (void)hipGetLastError()
+
+extern "C" void mi_record_hip_error(int code, const char* file, int line);   // encoder.hip (diagnostics only)
+
+#define MI_CHECK_LAUNCH()                                            \
+    do {                                                             \
+        hipError_t e__ = hipGetLastError();                          \
+        if (e__ != hipSuccess) {                                     \
+            mi_record_hip_error((int)e__, __FILE__, __LINE__);       \
+            return MI_ERR_LAUNCH;                                    \
+        }                                                            \
     } while (0)
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }

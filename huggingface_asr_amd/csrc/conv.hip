@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256) void dwconv_time_kernel(DwArgs p) {
 extern "C" int mi_conv2d_first_gelu(const float* x, const float* w, const float* bias, void* out_cl_bf16,
                                     int B, int T, int F, int C, int K, int stride, int pad_t, int pad_f,
                                     int T1, int F1, hipStream_t stream) {
+    MI_ENTER();
     if (B <= 0 || T <= 0 || F <= 0 || C <= 0 || (C % 8) != 0 || K <= 0 || K > 7) return MI_ERR_ARG;
     const long total = (long)B * T1 * F1 * (C / 8);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -164,6 +165,7 @@ extern "C" int mi_conv2d_first_gelu(const float* x, const float* w, const float*
 }
 
 extern "C" int mi_row_stats_bf16(const void* x, long ldx, int d, float eps, float* stats, int M, hipStream_t stream) {
+    MI_ENTER();
     if (M <= 0 || d <= 0 || (d % 8) != 0 || (ldx % 8) != 0) return MI_ERR_ARG;
     hipLaunchKernelGGL(row_stats_kernel, dim3(cdiv(M, 4)), dim3(256), 0, stream, (const bf16_t*)x, ldx, d, eps, stats, M);
     MI_CHECK_LAUNCH();
@@ -186,6 +188,7 @@ static int dw_launch(const DwArgs& a, bool csgu, hipStream_t stream) {
 extern "C" int mi_csgu_bf16(const void* u, long ldu, const float* stats, const float* gamma, const float* beta,
                             const float* w, const float* bias, void* out, long ldo,
                             int B, int T, int C, int K, int pad_left, int dilation, int act, hipStream_t stream) {
+    MI_ENTER();
     DwArgs a{};
     a.in = (const bf16_t*)u + C; a.ld_in = ldu; a.mul = (const bf16_t*)u; a.ld_mul = ldu; a.stats = stats;
     a.gamma = gamma; a.beta = beta; a.w = w; a.bias = bias; a.out = (bf16_t*)out; a.ld_out = ldo;
@@ -196,6 +199,7 @@ extern "C" int mi_csgu_bf16(const void* u, long ldu, const float* stats, const f
 // MERGE: out = m + dwconv(m) + bias on (B*T, C) bf16
 extern "C" int mi_dwconv_residual_bf16(const void* m, long ldm, const float* w, const float* bias, void* out, long ldo,
                                        int B, int T, int C, int K, int pad_left, hipStream_t stream) {
+    MI_ENTER();
     DwArgs a{};
     a.in = (const bf16_t*)m; a.ld_in = ldm; a.w = w; a.bias = bias; a.out = (bf16_t*)out; a.ld_out = ldo;
     a.B = B; a.T = T; a.C = C; a.K = K; a.pad_left = pad_left; a.dilation = 1; a.act = 0;

@@ -100,6 +100,7 @@ __global__ void ctc_reduce_kernel(const float* nll, const int* tl, int B, int re
 
 // logits (M, ld) f32 (dtype 0) or bf16 (dtype 1) -> lse (M) f32
 extern "C" int mi_row_lse(const void* x, long ld, int dtype, int V, float* lse, int M, hipStream_t stream) {
+    MI_ENTER();
     if (M <= 0 || V <= 0) return MI_ERR_ARG;
     dim3 grid(cdiv(M, 4)), block(256);
     if (dtype == 0) hipLaunchKernelGGL(row_lse_kernel<float>, grid, block, 0, stream, (const float*)x, ld, V, lse, M);
@@ -115,6 +116,7 @@ extern "C" int mi_ctc_loss_fwd(const void* logits, long ld_b, long ld_t, int dty
                                const long* labels, int U, const int* in_len, int blank, int B,
                                int reduction, int zero_infinity, float* nll, int* tgt_len, float* loss,
                                hipStream_t stream) {
+    MI_ENTER();
     if (B <= 0 || T <= 0 || U < 0) return MI_ERR_ARG;
     const int S_max = 2 * U + 1;
     const size_t lds = (((4 + 2 * S_max) * sizeof(int) + 15) / 16) * 16 + 2 * S_max * sizeof(double);

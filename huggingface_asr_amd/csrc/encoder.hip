@@ -13,6 +13,7 @@
 //   cat   bf16 (M, 2d)    [attention branch | cgMLP branch]  (torch.cat at e_branchformer.py:296 is free)
 //   act1  bf16 (B,T1,F1,C1), act2 bf16 (B,T2,F2,C2) channels-last conv activations
 #include "common.hpp"
+#include <stdio.h>
 #include "../../include/hfasr_hip.h"
 
 namespace {
@@ -98,6 +99,13 @@ __global__ void lengths_kernel(const int* feat_len, int T, int B, int K, int str
 
 }  // namespace
 
+// diagnostics: text of the last failed launch on this thread ("" if none); not part of the data path
+static thread_local char g_last_error[256] = "";
+extern "C" void mi_record_hip_error(int code, const char* file, int line) {
+    snprintf(g_last_error, sizeof(g_last_error), "%s (hipError %d) at %s:%d", hipGetErrorString((hipError_t)code), code, file, line);
+}
+extern "C" const char* mi_last_error(void) { return g_last_error; }
+
 extern "C" size_t mi_ebf_workspace_bytes(const mi_ebf_config* cfg) { return carve(*cfg, nullptr).bytes; }
 
 // posp: (L, 2*T2-1, d) bf16 projected relative positions, (re)computed from pos_table when compute_posp != 0
@@ -105,6 +113,7 @@ extern "C" int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weigh
                               const int* feat_lengths, const void* pos_table, void* posp, int compute_posp,
                               void* workspace, size_t workspace_bytes, float* last_hidden, void* logits,
                               int* inner_len, int* outer_len, hipStream_t st) {
+    MI_ENTER();
     const mi_ebf_config& c = *cfg;
     if (c.B <= 0 || c.T <= 0 || c.L <= 0 || c.d % c.H || c.I % 2) return MI_ERR_ARG;
     const Dims D = dims(c);

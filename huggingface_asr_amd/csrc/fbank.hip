@@ -154,6 +154,7 @@ __global__ void global_norm_kernel(float* x, long total, int nmel, const float* 
 extern "C" int mi_fbank_f64(const float* wave, long ldw, const int* num_samples, int N, const double* window,
                             const double* twiddle, const double* mel_t, const int* mel_lo, const int* mel_hi,
                             float* out, int T_out, int B, int nmel, double mel_floor, double preemph, hipStream_t stream) {
+    MI_ENTER();
     if (B <= 0 || N < FRAME || T_out <= 0 || nmel <= 0) return MI_ERR_ARG;
     FbankArgs a{wave, ldw, num_samples, N, window, twiddle, mel_t, mel_lo, mel_hi, out, (long)T_out * nmel, T_out,
                 B, nmel, mel_floor, preemph};
@@ -167,6 +168,7 @@ extern "C" int mi_fbank_f64(const float* wave, long ldw, const int* num_samples,
 
 extern "C" int mi_cmvn_utterance(float* x, const int* frames, int B, int T, int nmel, int norm_means, int norm_vars,
                                  float pad, hipStream_t stream) {
+    MI_ENTER();
     if (B <= 0 || T <= 0 || nmel <= 0 || nmel > 128) return MI_ERR_ARG;
     hipLaunchKernelGGL(cmvn_kernel, dim3(B), dim3(128), 0, stream, x, (long)T * nmel, frames, T, nmel, norm_means, norm_vars, pad);
     MI_CHECK_LAUNCH();
@@ -174,6 +176,7 @@ extern "C" int mi_cmvn_utterance(float* x, const int* frames, int B, int T, int 
 }
 
 extern "C" int mi_cmvn_global(float* x, long total, int nmel, const float* means, const float* stds, hipStream_t stream) {
+    MI_ENTER();
     if (total <= 0 || nmel <= 0) return MI_ERR_ARG;
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(global_norm_kernel, dim3(grid), dim3(256), 0, stream, x, total, nmel, means, stds);

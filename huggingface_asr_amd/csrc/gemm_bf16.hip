@@ -201,6 +201,7 @@ int launch(const GemmArgs& a, bool conv, hipStream_t stream) {
 extern "C" int mi_gemm_bf16(const void* A, long lda, const void* W, long ldw, const float* bias, int bias_mode,
                             void* C, long ldc, int out_f32, const float* resid, long ldr, float alpha, int act,
                             int M, int N, int K, int col_T, int col_Tp, hipStream_t stream) {
+    MI_ENTER();
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw;
     a.bias = bias; a.bias_mode = bias ? bias_mode : 0;
@@ -215,6 +216,7 @@ extern "C" int mi_gemm_bf16(const void* A, long lda, const void* W, long ldw, co
 extern "C" int mi_conv2d_cl_bf16(const void* in, const void* weight, const float* bias, void* out,
                                  int B, int Tin, int Fin, int Cin, int Cout, int KH, int KW, int stride,
                                  int pad_t, int pad_f, int Tout, int Fout, int act, hipStream_t stream) {
+    MI_ENTER();
     GemmArgs a{};
     a.A = (const bf16_t*)in; a.lda = 0; a.W = (const bf16_t*)weight; a.ldw = (long)KH * KW * Cin;
     a.bias = bias; a.bias_mode = bias ? 1 : 0;

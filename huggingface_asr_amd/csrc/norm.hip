@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void rotary_kernel(const bf16_t* __restrict__ 
 
 extern "C" int mi_rotary_bf16(const void* x, long ldx, void* out, long ldo, const float* cos_t, const float* sin_t,
                               int M, int T, int H, int hd, hipStream_t stream) {
+    MI_ENTER();
     if (M <= 0 || T <= 0 || H <= 0 || hd <= 0 || (hd & 1)) return MI_ERR_ARG;
     const long total = (long)M * H * (hd / 2);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -143,6 +144,7 @@ extern "C" int mi_layernorm_chain(const float* x, long ldx, const int* lengths, 
                                   float* outa_f32, long lda32,
                                   const float* gb, const float* bb, void* outb_bf16, long ldb,
                                   int M, int d, hipStream_t stream) {
+    MI_ENTER();
     if (M <= 0 || d <= 0 || (d % 4) != 0 || d > 64 * 4 * MAXV) return MI_ERR_ARG;
     if ((ldx % 4) || (y32 && (ldy % 4)) || (outa_bf16 && (lda % 4)) || (outa_f32 && (lda32 % 4)) || (outb_bf16 && (ldb % 4)))
         return MI_ERR_ARG;

@@ -22,6 +22,9 @@ extern "C" {
 
 typedef struct ihipStream_t* mi_stream_t; /* = hipStream_t */
 
+/* diagnostics: text of the last failed kernel launch on the calling thread ("" if none). */
+const char* mi_last_error(void);
+
 /* ---- nn.Linear / lm_head / projections: C[M,N] = epi(A[M,K] * W[N,K]^T), bf16 in, fp32 accumulate (MFMA).
  * replaces: every nn.Linear on the path — reference src/models/encoders/e_branchformer.py:96-98,139,212-216,247,456-457;
  *           src/models/extractors.py:108,131; transformers wav2vec2_conformer FFN (modeling :350-357).

@@ -12,7 +12,7 @@ def _header_functions():
     src = open(os.path.join(ROOT, "include", "hfasr_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(int|size_t)\s+(mi_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"(?<!\*\s)\b(int|size_t)\s+(mi_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = [a for a in m.group(3).split(",") if a.strip()]
         out[m.group(2)] = len(args)
     return out
@@ -34,6 +34,7 @@ def test_header_symbols_exported(built):
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
         assert len(_lib.SIGNATURES[name]) == nargs, f"{name}: header has {nargs} args, binding {len(_lib.SIGNATURES[name])}"
     assert set(_lib.SIGNATURES) == set(decl)
+    assert hasattr(h, "mi_last_error")
 
 
 def test_workspace_query_runs_on_cpu(built):
