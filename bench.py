@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""Headline benchmark: audio-seconds/sec, encoder forward + CTC, E-Branchformer-base (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+  32 x 10 s of 16 kHz audio -> log-mel + utterance CMVN (HIP) -> pad to 1000 frames -> Conv2d sub-sampling ->
+  16 E-Branchformer layers (relative-position attention) -> lm_head ⊕ blank -> logits -> CTC loss (labels U=40).
+The path shards by utterance with no exchange step: every rank runs the same per-GPU batch
+("weak" scaling), value = audio-seconds all ranks processed / max-over-ranks time.  Weights are seeded random
+(no checkpoints offline), data is synthetic.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from huggingface_asr_amd import _lib, fbank as FB, ops, shapes, synth  # noqa: E402
+from huggingface_asr_amd.engine import EBranchformerEngine  # noqa: E402
+
+BATCH, SECONDS, SR, U = 32, 10, 16000, 40
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+
+
+def algorithmic_gflop_per_utt(cfg, T2):
+    """2 x MACs of the GEMM/conv contractions only, per 10 s utterance."""
+    d, I, L, V = cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"], cfg["vocab_size"]
+    C1, C2 = cfg["conv_dim"]
+    T1, F1, F2 = 500, 40, 20
+    mac = T1 * F1 * C1 * 9 + T2 * F2 * C2 * 9 * C1 + T2 * (F2 * C2) * d + T2 * d * d
+    hd = d // cfg["num_attention_heads"]
+    per_layer = 2 * (2 * T2 * d * I) + 4 * T2 * d * d + (T2 * T2 * d) * 2 + T2 * (2 * T2 - 1) * d \
+        + T2 * d * I + T2 * (I // 2) * 31 + T2 * (I // 2) * d + T2 * 2 * d * 31 + T2 * 2 * d * d
+    mac += L * per_layer + T2 * d * (V + 1)
+    return 2.0 * mac / 1e9
+
+
+def cpu_baseline(cfg, sd, seconds_budget=25.0):
+    """Time the ORACLE (CPU restatement; checker only, never the product path) on the host cores:
+    feature extraction + encoder forward + CTC head, fp32, bounded sample."""
+    from oracle import ebranchformer_ref as R
+    from oracle import fbank_ref
+    n_thr = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0))))
+    torch.set_num_threads(n_thr)
+    B = 4
+    wave = synth.waveforms(7, B, SR * SECONDS)
+    cfgd = dict(cfg)
+
+    def one():
+        feats = np.stack([np.pad(fbank_ref.extract(w), ((0, 2), (0, 0))) for w in wave])
+        am = torch.zeros(B, 1000, dtype=torch.long); am[:, :998] = 1
+        with torch.no_grad():
+            h = R.encoder_forward(sd, cfgd, torch.from_numpy(feats), am)
+            R.ctc_head(sd, h)
+    one()
+    t0 = time.perf_counter(); it = 0
+    while True:
+        one(); it += 1
+        if time.perf_counter() - t0 > seconds_budget * 0.6 or it >= 5:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=round(it * B * SECONDS / dt, 2), unit="audio-seconds/sec", cores=n_thr, kind="port",
+                sample=f"{it} x (B={B} x {SECONDS}s clips): numpy float64 fbank+CMVN, torch-CPU fp32 encoder + CTC head")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events on the GEMM kernel")
+    ap.add_argument("--pos", default="relative", choices=["relative", "rotary"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = world > 1
+    if dist:
+        import torch.distributed as td
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    cfg = dict(shapes.BASE, position_embeddings_type=args.pos, ctc_zero_infinity=True, ctc_loss_reduction="mean")
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()}
+    eng = EBranchformerEngine(cfg, dev)
+    eng.load_state_dict(sd)
+    B = args.batch
+    wave = torch.from_numpy(synth.waveforms(100 + rank, B, SR * SECONDS)).to(dev)       # resident in HBM
+    labels = torch.from_numpy(synth.labels(rank, B, U, cfg["vocab_size"])).to(dev)
+    tables = FB.FbankTables(80)
+    tables.device(dev)
+
+    def step():
+        feats, frames = FB.fbank_gpu(wave, tables, pad_frames_to=100)
+        out = eng.forward(feats, frames, want_hidden=False)
+        loss, _, _ = ops.ctc_loss(out["logits"], labels, out["outer_len"], reduction="mean", zero_infinity=True)
+        return loss
+
+    L = _lib.lib()
+    use_events = not args.no_kernel_events
+    n_gemm_per_step = 3 + cfg["num_hidden_layers"] * 10 + 1
+    if use_events:
+        _lib.check(L.mi_profile_create(n_gemm_per_step * args.steps + 64), "mi_profile_create")
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+    torch.cuda.synchronize()
+    if use_events:
+        L.mi_profile_reset(); L.mi_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if use_events:
+        L.mi_profile_enable(0)
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t[0])
+    loss_v = float(loss)
+
+    roof = None
+    if use_events and rank == 0:
+        ms, fl = C.c_double(0), C.c_double(0)
+        _lib.check(L.mi_profile_summary(C.byref(ms), C.byref(fl)), "mi_profile_summary")
+        n = L.mi_profile_count()
+        if n and ms.value > 0:
+            ach = fl.value / (ms.value * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel="gemm_bf16_kernel<false>", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None, launches=n, avg_launch_us=round(ms.value * 1e3 / n, 2),
+                        gflop_per_launch=round(fl.value / n / 1e9, 3))
+
+    if rank == 0:
+        audio_s = world * B * SECONDS * args.steps
+        T2 = eng.out_frames(1000)
+        rec = {
+            "metric": "audio-seconds/sec encoder fwd+CTC, E-Branchformer-base", "value": round(audio_s / dt, 1),
+            "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"E-Branchformer-base enc+CTC ({args.pos}-pos), {B}x{SECONDS}s 16kHz clips/GPU: "
+                                   "fbank+CMVN -> conv2d sub -> 16 layers -> CTC head -> CTC loss",
+                       "per_gpu_batch": B, "frames": 1000, "encoder_frames": T2, "parallelism": f"replicas x{world} (no exchange step)",
+                       "algorithmic_gflop_per_audio_s": round(algorithmic_gflop_per_utt(cfg, T2) / SECONDS, 3),
+                       "ctc_loss": round(loss_v, 4)},
+            "roofline": roof,
+        }
+        rec["model_tflops_per_gpu"] = round(rec["config"]["algorithmic_gflop_per_audio_s"] * rec["value"] / world / 1e3, 2)
+        rec["cpu_baseline"] = None
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(cfg, sd)
+        print(json.dumps(rec), flush=True)
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,17 @@ def lib():
             fn = getattr(h, name)          # AttributeError here = header/library mismatch: fail loudly
             fn.argtypes = args
             fn.restype = sz if name == "mi_ebf_workspace_bytes" else i32
+        h.mi_profile_create.argtypes = [i32]; h.mi_profile_create.restype = i32
+        h.mi_profile_enable.argtypes = [i32]; h.mi_profile_enable.restype = None
+        h.mi_profile_reset.argtypes = []; h.mi_profile_reset.restype = None
+        h.mi_profile_count.argtypes = []; h.mi_profile_count.restype = i32
+        h.mi_profile_summary.argtypes = [C.POINTER(f64), C.POINTER(f64)]; h.mi_profile_summary.restype = i32
+        h.mi_gemm_set_stages.argtypes = [i32]; h.mi_gemm_set_stages.restype = None
+        if os.environ.get("HFASR_GEMM_STAGES"):
+            h.mi_gemm_set_stages(int(os.environ["HFASR_GEMM_STAGES"]))
+        h.mi_gemm_set_krot.argtypes = [i32]; h.mi_gemm_set_krot.restype = None
+        if os.environ.get("HFASR_GEMM_KROT"):
+            h.mi_gemm_set_krot(int(os.environ["HFASR_GEMM_KROT"]))
         h.mi_last_error.argtypes = []
         h.mi_last_error.restype = C.c_char_p
         _lib = h

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libhfasr_hip.so")
 OBJ = os.path.join(HERE, "build")
-SOURCES = ["gemm_bf16.hip", "norm.hip", "conv.hip", "attention.hip", "fbank.hip", "ctc.hip", "encoder.hip"]
+SOURCES = ["gemm_bf16.hip", "gemm_glds.hip", "norm.hip", "conv.hip", "attention.hip", "fbank.hip", "ctc.hip", "encoder.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 
 
@@ -29,7 +29,7 @@ def _stale(target, deps):
 
 def _compile(src):
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-    deps = [os.path.join(HERE, src), os.path.join(HERE, "common.hpp"), os.path.join(os.path.dirname(PKG), "include", "hfasr_hip.h")]
+    deps = [os.path.join(HERE, src), os.path.join(HERE, "common.hpp"), os.path.join(HERE, "gemm_args.hpp"), os.path.join(os.path.dirname(PKG), "include", "hfasr_hip.h")]
     if _stale(obj, deps):
         subprocess.run(["hipcc", *FLAGS, "-c", os.path.join(HERE, src), "-o", obj], check=True)
     return obj

@@ -57,6 +57,47 @@ __global__ __launch_bounds__(256) void conv2d_first_kernel(const float* __restri
     }
 }
 
+// 3x3 fast form: a thread owns 8 output channels (72 taps + 8 biases in registers) and walks output positions.
+__global__ __launch_bounds__(256) void conv2d_first3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                             int B, int T, int F, int C, int stride, int pad_t, int pad_f,
+                                                             int T1, int F1) {
+    const int cg = C >> 3, ppb = 256 / cg;
+    const int g = threadIdx.x % cg, pl = threadIdx.x / cg;
+    float wr[9][8], br[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        br[j] = bias[g * 8 + j];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) wr[tap][j] = w[(g * 8 + j) * 9 + tap];
+    }
+    const long total = (long)B * T1 * F1;
+    for (long pos = (long)blockIdx.x * ppb + pl; pos < total; pos += (long)gridDim.x * ppb) {
+        const int f1 = (int)(pos % F1);
+        const int t1 = (int)((pos / F1) % T1);
+        const int b = (int)(pos / ((long)F1 * T1));
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = br[j];
+        const float* xb = x + (long)b * T * F;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int t = t1 * stride - pad_t + kh;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int f = f1 * stride - pad_f + kw;
+                const float xv = (t >= 0 && t < T && f >= 0 && f < F) ? xb[(long)t * F + f] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, wr[kh * 3 + kw][j], acc[j]);
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(gelu_erf(acc[j]));
+        *reinterpret_cast<bf16x8*>(out + pos * C + g * 8) = o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ row_stats
 __global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict__ x, long ldx, int d, float eps,
                                                          float* __restrict__ stats, int M) {
@@ -148,6 +189,77 @@ __global__ __launch_bounds__(256) void dwconv_time_kernel(DwArgs p) {
     }
 }
 
+// Fast form for the reference's kernel size 31, dilation 1: the (TT+30) x 64 input tile is staged once in LDS (16-B
+// global loads, LayerNorm applied on the way in), then every thread keeps its 46-sample window and the 31 taps of its
+// channel in registers and produces 16 consecutive outputs: 77 LDS reads per 496 FMAs instead of 62 per 31.
+constexpr int DWF_K = 31, DWF_TT = 64, DWF_CT = 64, DWF_ROWS = DWF_TT + DWF_K - 1, DWF_PER = DWF_TT / 4;
+
+template <bool CSGU>
+__global__ __launch_bounds__(256) void dwconv31_kernel(DwArgs p) {
+    __shared__ __attribute__((aligned(16))) float tile[DWF_ROWS * DWF_CT];
+    __shared__ __attribute__((aligned(16))) float sw[DWF_K * DWF_CT];
+    const int c0 = blockIdx.x * DWF_CT, t0 = blockIdx.y * DWF_TT, b = blockIdx.z;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < DWF_K * DWF_CT; i += 256) {
+        const int k = i / DWF_CT, cc = i % DWF_CT;
+        sw[i] = p.w[(long)(c0 + cc) * DWF_K + k];
+    }
+    for (int id = tid; id < DWF_ROWS * (DWF_CT / 8); id += 256) {
+        const int r = id >> 3, ch = id & 7;
+        const int t = t0 - p.pad_left + r;
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+        if (t >= 0 && t < p.T) {
+            const long row = (long)b * p.T + t;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(p.in + row * p.ld_in + c0 + ch * 8);
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = bf2f(v[j]);
+            if (CSGU) {
+                const float mu = p.stats[2 * row], rs = p.stats[2 * row + 1];
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + c0 + ch * 8), g1 = *reinterpret_cast<const f32x4*>(p.gamma + c0 + ch * 8 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + c0 + ch * 8), b1 = *reinterpret_cast<const f32x4*>(p.beta + c0 + ch * 8 + 4);
+                lo = f32x4{(f[0] - mu) * rs * g0.x + b0.x, (f[1] - mu) * rs * g0.y + b0.y, (f[2] - mu) * rs * g0.z + b0.z, (f[3] - mu) * rs * g0.w + b0.w};
+                hi = f32x4{(f[4] - mu) * rs * g1.x + b1.x, (f[5] - mu) * rs * g1.y + b1.y, (f[6] - mu) * rs * g1.z + b1.z, (f[7] - mu) * rs * g1.w + b1.w};
+            } else {
+                lo = f32x4{f[0], f[1], f[2], f[3]};
+                hi = f32x4{f[4], f[5], f[6], f[7]};
+            }
+        }
+        *reinterpret_cast<f32x4*>(tile + r * DWF_CT + ch * 8) = lo;
+        *reinterpret_cast<f32x4*>(tile + r * DWF_CT + ch * 8 + 4) = hi;
+    }
+    __syncthreads();
+    const int tx = tid & 63, ty = tid >> 6;
+    const int c = c0 + tx;
+    float wk[DWF_K];
+#pragma unroll
+    for (int k = 0; k < DWF_K; ++k) wk[k] = sw[k * DWF_CT + tx];
+    float win[DWF_PER + DWF_K - 1];
+#pragma unroll
+    for (int i = 0; i < DWF_PER + DWF_K - 1; ++i) win[i] = tile[(ty * DWF_PER + i) * DWF_CT + tx];
+    const float bias = p.bias ? p.bias[c] : 0.f;
+#pragma unroll
+    for (int j = 0; j < DWF_PER; ++j) {
+        const int t = t0 + ty * DWF_PER + j;
+        if (t < p.T) {
+            float acc = bias;
+#pragma unroll
+            for (int k = 0; k < DWF_K; ++k) acc = fmaf(wk[k], win[j + k], acc);
+            const long row = (long)b * p.T + t;
+            float o;
+            if (CSGU) {
+                if (p.act == 1) acc = gelu_erf(acc);
+                else if (p.act == 2) acc = fmaxf(acc, 0.f);
+                else if (p.act == 3) acc = acc / (1.f + __expf(-acc));
+                o = bf2f(p.mul[row * p.ld_mul + c]) * acc;
+            } else {
+                o = win[j + (DWF_K - 1) / 2] + acc;
+            }
+            p.out[row * p.ld_out + c] = f2bf(o);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int mi_conv2d_first_gelu(const float* x, const float* w, const float* bias, void* out_cl_bf16,
@@ -155,6 +267,16 @@ extern "C" int mi_conv2d_first_gelu(const float* x, const float* w, const float*
                                     int T1, int F1, hipStream_t stream) {
     MI_ENTER();
     if (B <= 0 || T <= 0 || F <= 0 || C <= 0 || (C % 8) != 0 || K <= 0 || K > 7) return MI_ERR_ARG;
+    const int cgs = C / 8;
+    if (K == 3 && cgs <= 256 && (256 % cgs) == 0) {
+        const long npos = (long)B * T1 * F1;
+        const int ppb = 256 / cgs;
+        const long nb = (npos + ppb - 1) / ppb;
+        hipLaunchKernelGGL(conv2d_first3_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, stream, x, w, bias,
+                           (bf16_t*)out_cl_bf16, B, T, F, C, stride, pad_t, pad_f, T1, F1);
+        MI_CHECK_LAUNCH();
+        return MI_OK;
+    }
     const long total = (long)B * T1 * F1 * (C / 8);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     const size_t lds = (size_t)(K * K * C + C) * sizeof(float);
@@ -177,6 +299,15 @@ static int dw_launch(const DwArgs& a, bool csgu, hipStream_t stream) {
     const int halo = (a.K - 1) * a.dilation;
     const size_t lds = (size_t)((DW_TT + halo) * DW_CT + a.K * DW_CT) * sizeof(float);
     if (lds > 160 * 1024) return MI_ERR_UNSUPPORTED;
+    const bool fast = a.K == DWF_K && a.dilation == 1 && a.pad_left == (DWF_K - 1) / 2 && (a.C % DWF_CT) == 0 &&
+                      (a.ld_in % 8) == 0 && (((uintptr_t)a.in) & 15) == 0 && (!csgu || (((uintptr_t)a.gamma | (uintptr_t)a.beta) & 15) == 0);
+    if (fast) {
+        dim3 gridf(a.C / DWF_CT, cdiv(a.T, DWF_TT), a.B);
+        if (csgu) hipLaunchKernelGGL(dwconv31_kernel<true>, gridf, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(dwconv31_kernel<false>, gridf, dim3(256), 0, stream, a);
+        MI_CHECK_LAUNCH();
+        return MI_OK;
+    }
     dim3 grid(cdiv(a.C, DW_CT), cdiv(a.T, DW_TT), a.B);
     if (csgu) hipLaunchKernelGGL(dwconv_time_kernel<true>, grid, dim3(256), lds, stream, a);
     else hipLaunchKernelGGL(dwconv_time_kernel<false>, grid, dim3(256), lds, stream, a);

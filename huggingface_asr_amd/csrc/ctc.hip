@@ -84,6 +84,91 @@ __global__ __launch_bounds__(256) void ctc_alpha_kernel(const T* __restrict__ lo
     }
 }
 
+// Fast form for 2U+1 <= 128 states: the block first gathers every needed log-prob  lp[t][s] = logit[t][ext[s]] - lse[t]
+// into LDS in parallel (the only HBM traffic of the loss), then ONE wave runs the alpha recursion with two states per
+// lane in registers; neighbours come from whole-wave DPP shifts, so a time step costs no barrier and no memory access
+// besides two LDS reads.  fp32 log-space math (as torch's GPU ctc_loss).
+__device__ __forceinline__ float wave_shr1(float v, float fill) {   // lane i <- lane i-1, lane 0 <- fill
+    const int r = __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
+    return __int_as_float(r);
+}
+__device__ __forceinline__ float lse3f(float a, float b, float c) {
+    const float m = fmaxf(a, fmaxf(b, c));
+    if (m == -INFINITY) return -INFINITY;
+    return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_alpha_wave_kernel(const T* __restrict__ logits, long ld_b, long ld_t,
+                                                              const float* __restrict__ lse, int Tmax,
+                                                              const long* __restrict__ labels, int U,
+                                                              const int* __restrict__ in_len, int blank, int tchunk,
+                                                              float* __restrict__ nll, int* __restrict__ tgt_len_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* hdr = reinterpret_cast<int*>(smem);                 // [4]
+    int* ext = hdr + 4;                                      // [128]
+    float* lp = reinterpret_cast<float*>(ext + 128);         // [tchunk][128]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        int n = 0;
+        for (int u = 0; u < U; ++u) {
+            const long v = labels[(long)b * U + u];
+            if (v >= 0) { ext[2 * n + 1] = (int)v; ++n; }
+        }
+        for (int s = 0; s <= 2 * n; s += 2) ext[s] = blank;
+        for (int s = 2 * n + 1; s < 128; ++s) ext[s] = blank;
+        hdr[0] = n;
+    }
+    __syncthreads();
+    const int tl = hdr[0], S = 2 * tl + 1;
+    const int Tb = min(in_len[b], Tmax);
+    if (tid == 0) tgt_len_out[b] = tl;
+    if (Tb <= 0) { if (tid == 0) nll[b] = (tl == 0) ? 0.f : INFINITY; return; }
+    const T* lg = logits + (long)b * ld_b;
+    const float* ls = lse + (long)b * Tmax;
+    const int s0 = lane, s1 = lane + 64;
+    const bool skip0 = s0 >= 2 && s0 < S && ext[s0] != blank && ext[s0] != ext[s0 - 2];
+    const bool skip1 = s1 < S && ext[s1] != blank && ext[s1] != ext[s1 - 2];
+    float a0 = -INFINITY, a1 = -INFINITY;
+    for (int tc = 0; tc < Tb; tc += tchunk) {
+        const int nt = min(tchunk, Tb - tc);
+        for (int i = tid; i < nt * 128; i += 256) {
+            const int t = i >> 7, s = i & 127;
+            lp[i] = (s < S) ? (float)lg[(long)(tc + t) * ld_t + ext[s]] - ls[tc + t] : -INFINITY;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int t = 0; t < nt; ++t) {
+                const float l0 = lp[t * 128 + s0], l1 = lp[t * 128 + s1];
+                if (tc + t == 0) {
+                    a0 = (s0 < 2 && s0 < S) ? l0 : -INFINITY;
+                    a1 = -INFINITY;
+                } else {
+                    const float top = __shfl(a0, 63, 64);                 // state 63 feeds state 64
+                    const float top2 = __shfl(a0, 62, 64);
+                    const float p0 = wave_shr1(a0, -INFINITY);            // alpha[s-1]
+                    const float q0 = wave_shr1(p0, -INFINITY);            // alpha[s-2]
+                    const float p1 = wave_shr1(a1, top);
+                    float q1 = wave_shr1(p1, top2);
+                    if (lane == 1) q1 = top;
+                    const float n0 = lse3f(a0, p0, skip0 ? q0 : -INFINITY) + l0;
+                    const float n1 = lse3f(a1, p1, skip1 ? q1 : -INFINITY) + l1;
+                    a0 = (s0 < S) ? n0 : -INFINITY;
+                    a1 = (s1 < S) ? n1 : -INFINITY;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        // log-likelihood = logsumexp(alpha[S-1], alpha[S-2])
+        const int sa = S - 1, sb = S - 2;
+        const float va = (sa >= 64) ? __shfl(a1, sa - 64, 64) : __shfl(a0, sa, 64);
+        const float vb = (sb < 0) ? -INFINITY : ((sb >= 64) ? __shfl(a1, sb - 64, 64) : __shfl(a0, sb, 64));
+        if (lane == 0) nll[b] = -lse3f(va, vb, -INFINITY);
+    }
+}
+
 // reduction semantics of torch.nn.functional.ctc_loss: mean = mean_b(nll_b / max(tl_b,1)), sum, zero_infinity
 __global__ void ctc_reduce_kernel(const float* nll, const int* tl, int B, int reduction, int zero_inf, float* out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -119,6 +204,23 @@ extern "C" int mi_ctc_loss_fwd(const void* logits, long ld_b, long ld_t, int dty
     MI_ENTER();
     if (B <= 0 || T <= 0 || U < 0) return MI_ERR_ARG;
     const int S_max = 2 * U + 1;
+    if (S_max <= 128) {
+        const int tchunk = T < 256 ? T : 256;                      // 256 steps x 128 states x 4 B = 128 KiB
+        const size_t ldsw = (4 + 128) * sizeof(int) + (size_t)tchunk * 128 * sizeof(float);
+        if (dtype == 0)
+            hipLaunchKernelGGL(ctc_alpha_wave_kernel<float>, dim3(B), dim3(256), ldsw, stream, (const float*)logits, ld_b, ld_t, lse, T,
+                               labels, U, in_len, blank, tchunk, nll, tgt_len);
+        else if (dtype == 1)
+            hipLaunchKernelGGL(ctc_alpha_wave_kernel<bf16_t>, dim3(B), dim3(256), ldsw, stream, (const bf16_t*)logits, ld_b, ld_t, lse, T,
+                               labels, U, in_len, blank, tchunk, nll, tgt_len);
+        else return MI_ERR_ARG;
+        MI_CHECK_LAUNCH();
+        if (loss) {
+            hipLaunchKernelGGL(ctc_reduce_kernel, dim3(1), dim3(64), 0, stream, nll, tgt_len, B, reduction, zero_infinity, loss);
+            MI_CHECK_LAUNCH();
+        }
+        return MI_OK;
+    }
     const size_t lds = (((4 + 2 * S_max) * sizeof(int) + 15) / 16) * 16 + 2 * S_max * sizeof(double);
     if (lds > 150 * 1024) return MI_ERR_UNSUPPORTED;
     if (dtype == 0)

@@ -106,6 +106,44 @@ extern "C" void mi_record_hip_error(int code, const char* file, int line) {
 }
 extern "C" const char* mi_last_error(void) { return g_last_error; }
 
+// ---- profiling facility (diagnostics, off by default): HIP events around every launch of the dense GEMM kernel,
+// recorded on the stream the kernel is launched on.  Used by bench.py for roofline.achieved.
+namespace {
+struct Prof { hipEvent_t* ev = nullptr; double* flops = nullptr; int cap = 0, n = 0; bool on = false; };
+Prof g_prof;
+}
+extern "C" int mi_profile_create(int capacity) {
+    if (g_prof.ev) return MI_ERR_ARG;
+    g_prof.ev = new hipEvent_t[2 * (size_t)capacity];
+    g_prof.flops = new double[capacity];
+    for (int i = 0; i < 2 * capacity; ++i)
+        if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return MI_ERR_LAUNCH;
+    g_prof.cap = capacity; g_prof.n = 0; g_prof.on = false;
+    return MI_OK;
+}
+extern "C" void mi_profile_enable(int on) { g_prof.on = on != 0; }
+extern "C" void mi_profile_reset(void) { g_prof.n = 0; }
+extern "C" int mi_profile_count(void) { return g_prof.n; }
+extern "C" int mi_profile_hook_begin(hipStream_t stream, double flops) {
+    if (!g_prof.on || g_prof.n >= g_prof.cap) return -1;
+    const int slot = g_prof.n++;
+    g_prof.flops[slot] = flops;
+    hipEventRecord(g_prof.ev[2 * slot], stream);
+    return slot;
+}
+extern "C" void mi_profile_hook_end(int slot, hipStream_t stream) { hipEventRecord(g_prof.ev[2 * slot + 1], stream); }
+// after the stream is synchronised: sum of elapsed ms and of algorithmic flops over the recorded launches
+extern "C" int mi_profile_summary(double* total_ms, double* total_flops) {
+    double ms = 0.0, fl = 0.0;
+    for (int i = 0; i < g_prof.n; ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return MI_ERR_LAUNCH;
+        ms += t; fl += g_prof.flops[i];
+    }
+    *total_ms = ms; *total_flops = fl;
+    return MI_OK;
+}
+
 extern "C" size_t mi_ebf_workspace_bytes(const mi_ebf_config* cfg) { return carve(*cfg, nullptr).bytes; }
 
 // posp: (L, 2*T2-1, d) bf16 projected relative positions, (re)computed from pos_table when compute_posp != 0

@@ -141,6 +141,54 @@ __global__ __launch_bounds__(128) void cmvn_kernel(float* x, long ld_b, const in
     for (int t = n; t < T; ++t) xb[(long)t * nmel + f] = pad;
 }
 
+// Fast form of cmvn_kernel: one block per (utterance, group of G mel bins); the (T x G) slab is staged in LDS, G
+// threads run numpy's sequential float32 reductions out of LDS (bit-identical order), everybody writes the result.
+template <int G>
+__global__ __launch_bounds__(256) void cmvn_lds_kernel(float* x, long ld_b, const int* frames, int T, int nmel,
+                                                        int norm_means, int norm_vars, float pad) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* slab = reinterpret_cast<float*>(smem);          // [T][G]
+    float* red = slab + (size_t)T * G;                     // [2][G] : mean, sd
+    const int b = blockIdx.x, f0 = blockIdx.y * G, tid = threadIdx.x;
+    float* xb = x + (long)b * ld_b;
+    const int n = frames ? min(frames[b], T) : T;
+    for (int i = tid; i < T * G; i += 256) {
+        const int t = i / G, g = i % G;
+        slab[i] = (f0 + g < nmel) ? xb[(long)t * nmel + f0 + g] : 0.f;
+    }
+    __syncthreads();
+    if (tid < G) {
+        float mean = 0.f, sd = 1.f;
+        const float fn = (float)max(n, 1);
+        if (n > 0 && norm_means) {
+            float s = 0.f;
+            for (int t = 0; t < n; ++t) s += slab[t * G + tid];
+            mean = s / fn;
+        }
+        if (n > 0 && norm_vars) {
+            float s = 0.f;
+            for (int t = 0; t < n; ++t) s += slab[t * G + tid] - mean;
+            const float m2 = s / fn;
+            float q = 0.f;
+            for (int t = 0; t < n; ++t) { const float d = (slab[t * G + tid] - mean) - m2; q += d * d; }
+            sd = sqrtf(q / fn);
+        }
+        red[tid] = mean; red[G + tid] = sd;
+    }
+    __syncthreads();
+    for (int i = tid; i < T * G; i += 256) {
+        const int t = i / G, g = i % G;
+        if (f0 + g >= nmel) continue;
+        float v = pad;
+        if (t < n) {
+            v = slab[i];
+            if (norm_means) v -= red[g];
+            if (norm_vars) v /= red[G + g];
+        }
+        xb[(long)t * nmel + f0 + g] = v;
+    }
+}
+
 __global__ void global_norm_kernel(float* x, long total, int nmel, const float* means, const float* stds) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int f = (int)(i % nmel);
@@ -170,6 +218,18 @@ extern "C" int mi_cmvn_utterance(float* x, const int* frames, int B, int T, int 
                                  float pad, hipStream_t stream) {
     MI_ENTER();
     if (B <= 0 || T <= 0 || nmel <= 0 || nmel > 128) return MI_ERR_ARG;
+    if ((size_t)T * 16 * 4 + 128 <= 140 * 1024) {
+        hipLaunchKernelGGL(cmvn_lds_kernel<16>, dim3(B, cdiv(nmel, 16)), dim3(256), (size_t)T * 16 * 4 + 128, stream, x, (long)T * nmel,
+                           frames, T, nmel, norm_means, norm_vars, pad);
+        MI_CHECK_LAUNCH();
+        return MI_OK;
+    }
+    if ((size_t)T * 4 * 4 + 32 <= 140 * 1024) {
+        hipLaunchKernelGGL(cmvn_lds_kernel<4>, dim3(B, cdiv(nmel, 4)), dim3(256), (size_t)T * 4 * 4 + 32, stream, x, (long)T * nmel,
+                           frames, T, nmel, norm_means, norm_vars, pad);
+        MI_CHECK_LAUNCH();
+        return MI_OK;
+    }
     hipLaunchKernelGGL(cmvn_kernel, dim3(B), dim3(128), 0, stream, x, (long)T * nmel, frames, T, nmel, norm_means, norm_vars, pad);
     MI_CHECK_LAUNCH();
     return MI_OK;

@@ -1,0 +1,23 @@
+// Argument block shared by the two bf16 GEMM kernels (gemm_bf16.hip: generic register-staged kernel;
+// gemm_glds.hip: LDS-DMA pipelined kernel for K % 64 == 0).
+#pragma once
+#include "common.hpp"
+
+struct GemmArgs {
+    const bf16_t* A; long lda;
+    const bf16_t* W; long ldw;
+    const float* bias; int bias_mode;      // 0 none, 1 per output column, 2 per output row
+    void* C; long ldc; int out_f32;
+    const float* resid; long ldr; float alpha;   // if resid: out = resid + alpha * (acc + bias)
+    int act;                                // 0 none, 1 gelu(erf)
+    int col_T, col_Tp;                      // != 0: output column n -> (n / col_T) * col_Tp + n % col_T
+    int M, N, K;
+    int krot;                               // fast path: rotate the K loop start per block
+    // implicit im2col (CONV): A is a channels-last activation (B, Tin, Fin, Cin); row m = (b, to, fo);
+    // k = (kh*KW + kw)*Cin + c
+    int Tin, Fin, Cin, Tout, Fout, KW, stride, pad_t, pad_f;
+};
+
+// gemm_glds.hip; returns MI_ERR_UNSUPPORTED when the shape/alignment does not fit the fast path
+bool gemm_glds_supported(const GemmArgs& a, bool conv);
+int gemm_glds_launch(const GemmArgs& a, bool conv, hipStream_t stream);

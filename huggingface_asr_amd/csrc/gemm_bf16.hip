@@ -11,26 +11,12 @@
 // (one barrier per K tile) and XOR-swizzled so that every ds_read_b128 lane group hits 16 distinct
 // 16-B slots.  blockIdx is remapped so that the blocks of one XCD walk neighbouring N tiles of the
 // same A row panel (A panel + W stay in that XCD's L2).
-#include "common.hpp"
+#include "gemm_args.hpp"
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int NT = 256;
-
-struct GemmArgs {
-    const bf16_t* A; long lda;
-    const bf16_t* W; long ldw;
-    const float* bias; int bias_mode;      // 0 none, 1 per output column, 2 per output row
-    void* C; long ldc; int out_f32;
-    const float* resid; long ldr; float alpha;   // if resid: out = resid + alpha * (acc + bias)
-    int act;                                // 0 none, 1 gelu(erf)
-    int col_T, col_Tp;                      // != 0: output column n -> (n / col_T) * col_Tp + n % col_T
-    int M, N, K;
-    // implicit im2col (CONV): A is a channels-last activation (B, Tin, Fin, Cin); row m = (b, to, fo);
-    // k = (kh*KW + kw)*Cin + c
-    int Tin, Fin, Cin, Tout, Fout, KW, stride, pad_t, pad_f;
-};
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
@@ -183,15 +169,33 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs p) {
     }
 }
 
+}  // namespace
+// optional per-launch HIP-event timing of the dense GEMM kernel (bench.py's roofline leg); see encoder.hip
+extern "C" int mi_profile_hook_begin(hipStream_t stream, double flops);
+extern "C" void mi_profile_hook_end(int slot, hipStream_t stream);
+namespace {
+
 int launch(const GemmArgs& a, bool conv, hipStream_t stream) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % 8) != 0) return MI_ERR_ARG;
     if (!conv && ((a.lda % 8) != 0)) return MI_ERR_ARG;
     if ((a.ldw % 8) != 0) return MI_ERR_ARG;
     if (conv && (a.Cin % 8) != 0) return MI_ERR_ARG;
+    if (gemm_glds_supported(a, conv)) {   // LDS-DMA pipelined fast path (gemm_glds.hip)
+        const int slot = conv ? -1 : mi_profile_hook_begin(stream, 2.0 * a.M * a.N * a.K);
+        const int rc = gemm_glds_launch(a, conv, stream);
+        if (slot >= 0) mi_profile_hook_end(slot, stream);
+        if (rc != MI_OK) return rc;
+        MI_CHECK_LAUNCH();
+        return MI_OK;
+    }
     const int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
     const size_t lds = 2 * (BM + BN) * BK * sizeof(bf16_t);
     if (conv) hipLaunchKernelGGL(gemm_bf16_kernel<true>, dim3(grid), dim3(NT), lds, stream, a);
-    else hipLaunchKernelGGL(gemm_bf16_kernel<false>, dim3(grid), dim3(NT), lds, stream, a);
+    else {
+        const int slot = mi_profile_hook_begin(stream, 2.0 * a.M * a.N * a.K);
+        hipLaunchKernelGGL(gemm_bf16_kernel<false>, dim3(grid), dim3(NT), lds, stream, a);
+        if (slot >= 0) mi_profile_hook_end(slot, stream);
+    }
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

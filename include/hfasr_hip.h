@@ -25,6 +25,17 @@ typedef struct ihipStream_t* mi_stream_t; /* = hipStream_t */
 /* diagnostics: text of the last failed kernel launch on the calling thread ("" if none). */
 const char* mi_last_error(void);
 
+/* profiling facility (off by default; process-global, not thread-safe, not for production): HIP events recorded on
+ * the launch stream around every launch of the dense GEMM kernel, for bench.py's roofline.achieved. */
+int mi_profile_create(int capacity);
+void mi_profile_enable(int on);
+void mi_profile_reset(void);
+int mi_profile_count(void);
+int mi_profile_summary(double* total_ms, double* total_flops);
+
+/* tuning knob: LDS ring depth of the pipelined GEMM (2: 64 KiB, two blocks per CU; 3: 96 KiB, one block per CU). */
+void mi_gemm_set_stages(int stages);
+
 /* ---- nn.Linear / lm_head / projections: C[M,N] = epi(A[M,K] * W[N,K]^T), bf16 in, fp32 accumulate (MFMA).
  * replaces: every nn.Linear on the path — reference src/models/encoders/e_branchformer.py:96-98,139,212-216,247,456-457;
  *           src/models/extractors.py:108,131; transformers wav2vec2_conformer FFN (modeling :350-357).

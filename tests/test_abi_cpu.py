@@ -12,7 +12,7 @@ def _header_functions():
     src = open(os.path.join(ROOT, "include", "hfasr_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"(?<!\*\s)\b(int|size_t)\s+(mi_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"(?<!\*\s)\b(int|size_t|void)\s+(mi_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = [a for a in m.group(3).split(",") if a.strip()]
         out[m.group(2)] = len(args)
     return out
@@ -31,9 +31,11 @@ def test_header_symbols_exported(built):
     assert len(decl) >= 16
     for name, nargs in decl.items():
         assert hasattr(h, name), f"{name} declared in hfasr_hip.h but not exported"
+        if name.startswith("mi_profile_") or name == "mi_gemm_set_stages":
+            continue
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
         assert len(_lib.SIGNATURES[name]) == nargs, f"{name}: header has {nargs} args, binding {len(_lib.SIGNATURES[name])}"
-    assert set(_lib.SIGNATURES) == set(decl)
+    assert set(_lib.SIGNATURES) == {n for n in decl if not n.startswith("mi_profile_") and n != "mi_gemm_set_stages"}
     assert hasattr(h, "mi_last_error")
 
 
