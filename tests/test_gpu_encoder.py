@@ -113,3 +113,34 @@ def test_engine_requires_device_tensors():
     eng.load_state_dict(sd)
     with pytest.raises(RuntimeError):
         eng.forward(x, None)        # CPU tensor: no fallback
+
+
+def test_hf_model_surface_matches_reference_golden():
+    """The drop-in class (AutoModelForCTC route): state dict in, CausalLMOutput out, same loss/logits as the reference."""
+    from transformers import AutoModelForCTC
+    from huggingface_asr_amd.bind import bind_all
+    from huggingface_asr_amd.configuration_ebranchformer import Wav2Vec2EBranchformerConfig
+    bind_all()
+    cfg = _cfg(shapes.TINY)
+    g = load_golden("tiny_rel")
+    sd, x, am, lab = case_inputs(g, cfg)
+    base = dict(shapes.TINY); base.pop("num_fbanks")
+    hf_cfg = Wav2Vec2EBranchformerConfig(**base, ctc_zero_infinity=True, ctc_loss_reduction="mean")
+    model = AutoModelForCTC.from_config(hf_cfg)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        out = model(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV), output_hidden_states=True)
+    d = np.abs(out.logits.float().cpu().numpy() - g["logits"])
+    assert d.max() < 0.06 and d.mean() < 0.009
+    assert abs(float(out.loss) - float(g["loss"])) < 1e-3 * abs(float(g["loss"]))
+    assert out.hidden_states[-1].shape == (2, 50, 64)
+    # weights edited in place -> engine repacks (version bump)
+    with torch.no_grad():
+        model.lm_head.bias.add_(1.0)
+        out2 = model(x.to(DEV), attention_mask=am.to(DEV))
+    torch.testing.assert_close(out2.logits[..., :-1], out.logits[..., :-1] + 1.0, atol=1e-5, rtol=0)
+    bad = lab.clone(); bad[0, 0] = 50
+    with pytest.raises(ValueError):
+        model(x.to(DEV), attention_mask=am.to(DEV), labels=bad.to(DEV))

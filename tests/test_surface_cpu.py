@@ -1,0 +1,92 @@
+"""CPU: the drop-in HuggingFace surface — registration, state-dict key contract, feature extractor
+parity with the reference's golden log-mel, length helpers.  No GPU calls."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+from huggingface_asr_amd import shapes
+from huggingface_asr_amd.bind import bind_all
+from huggingface_asr_amd.configuration_ebranchformer import Wav2Vec2EBranchformerConfig
+from huggingface_asr_amd.feature_extraction import CustomFeatureExtractor
+from huggingface_asr_amd.modeling_ebranchformer import Wav2Vec2EBranchformerForCTC
+
+
+def _cfg(**kw):
+    base = dict(shapes.TINY)
+    base.pop("num_fbanks")
+    return Wav2Vec2EBranchformerConfig(**base, **kw)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(position_embeddings_type="rotary"), dict(is_causal=True), dict(use_macaron_ff=False)])
+def test_state_dict_keys_match_reference_contract(kw):
+    cfg = _cfg(**kw)
+    model = Wav2Vec2EBranchformerForCTC(cfg)
+    want = shapes.param_shapes(dict(shapes.TINY, **kw))
+    got = {k: tuple(v.shape) for k, v in model.named_parameters()}
+    assert got == {k: tuple(v) for k, v in want.items()}
+    if kw.get("position_embeddings_type") == "rotary":
+        assert "wav2vec2.encoder.embed_positions.inv_freq" in model.state_dict()
+
+
+def test_auto_registration_and_roundtrip(tmp_path):
+    from transformers import AutoConfig, AutoFeatureExtractor, AutoModelForCTC
+    bind_all()
+    cfg = _cfg()
+    model = AutoModelForCTC.from_config(cfg)
+    assert isinstance(model, Wav2Vec2EBranchformerForCTC) and model.main_input_name == "input_values"
+    model.save_pretrained(tmp_path / "m")
+    again = AutoModelForCTC.from_pretrained(tmp_path / "m")
+    assert AutoConfig.from_pretrained(tmp_path / "m").model_type == "wav2vec2-ebranchformer"
+    for (k, a), (_, b) in zip(model.state_dict().items(), again.state_dict().items()):
+        assert torch.equal(a, b), k
+    fe = CustomFeatureExtractor(feature_size=80, norm_type="utterance")
+    fe.save_pretrained(tmp_path / "fe")
+    fe2 = CustomFeatureExtractor.from_pretrained(tmp_path / "fe")
+    assert fe2.norm_type == "utterance" and fe2.num_mel_bins == 80
+
+
+def test_length_helpers_and_errors():
+    model = Wav2Vec2EBranchformerForCTC(_cfg())
+    assert int(model._get_feat_extract_output_lengths(torch.tensor(998))) == 248     # outer (un-padded) formula
+    g = load_golden("lengths")
+    np.testing.assert_array_equal(model._get_feat_extract_output_lengths(torch.from_numpy(g["L"])).numpy(), g["outer"])
+    am = torch.zeros(2, 400, dtype=torch.long); am[0, :400] = 1; am[1, :300] = 1
+    m = model._get_feature_vector_attention_mask(100, am)
+    assert m.sum(-1).tolist() == [99, 74]
+    model.eval()
+    with pytest.raises(RuntimeError):          # CPU tensors: no fallback
+        model(torch.zeros(1, 100, 80))
+    model.train()
+    with pytest.raises(NotImplementedError):
+        model(torch.zeros(1, 100, 80))
+    assert model.get_output_embeddings() is None
+    model.freeze_encoder()
+    assert not any(p.requires_grad for p in model.wav2vec2.encoder.parameters())
+
+
+@pytest.mark.parametrize("wave", ["sweep", "noise", "silence_padded"])
+def test_feature_extractor_matches_reference_golden(wave):
+    g = load_golden("fbank")
+    fe = CustomFeatureExtractor(feature_size=80, norm_type="utterance")
+    out = fe(g[f"{wave}_wave"], sampling_rate=16000, padding=False, return_attention_mask=False, return_tensors="pt")
+    assert out["input_features"].shape == (1,) + g[f"{wave}_cmvn"].shape
+    np.testing.assert_allclose(out["input_features"][0].numpy(), g[f"{wave}_cmvn"], atol=2e-5, rtol=0)
+    raw = CustomFeatureExtractor(feature_size=80, norm_type="utterance", do_ceptral_normalize=False)(
+        g[f"{wave}_wave"], sampling_rate=16000, padding=False, return_tensors="np")["input_features"][0]
+    np.testing.assert_allclose(raw, g[f"{wave}_raw"], atol=2e-5, rtol=0)
+
+
+def test_feature_extractor_global_and_padding():
+    g = load_golden("fbank")
+    fe = CustomFeatureExtractor(feature_size=80, norm_type="global", global_means=g["global_means"].tolist(), global_stds=g["global_stds"].tolist())
+    out = fe(g["noise_wave"], sampling_rate=16000, padding=False, return_attention_mask=False, return_tensors="np")["input_features"][0]
+    np.testing.assert_allclose(out, g["noise_global"], atol=2e-5, rtol=0)
+    fe_u = CustomFeatureExtractor(feature_size=80, norm_type="utterance")
+    a = fe_u(g["noise_wave"], sampling_rate=16000, padding=False, return_tensors="np")
+    b = fe_u(g["sweep_wave"][:20000], sampling_rate=16000, padding=False, return_tensors="np")
+    padded = fe_u.pad([{"input_features": a["input_features"][0]}, {"input_features": b["input_features"][0]}], padding=True,
+                      pad_to_multiple_of=100, return_tensors="pt")
+    assert padded["input_features"].shape == (2, 200, 80) and padded["attention_mask"].sum(-1).tolist() == [198, 123]
+    with pytest.raises(ValueError):
+        CustomFeatureExtractor(norm_type="bogus")
