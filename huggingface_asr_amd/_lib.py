@@ -78,6 +78,12 @@ def lib():
         h.mi_gemm_set_krot.argtypes = [i32]; h.mi_gemm_set_krot.restype = None
         if os.environ.get("HFASR_GEMM_KROT"):
             h.mi_gemm_set_krot(int(os.environ["HFASR_GEMM_KROT"]))
+        h.mi_gemm_set_variant.argtypes = [i32]; h.mi_gemm_set_variant.restype = None
+        if os.environ.get("HFASR_GEMM_VARIANT"):
+            h.mi_gemm_set_variant(int(os.environ["HFASR_GEMM_VARIANT"]))
+        h.mi_gemm_set_debug.argtypes = [i32]; h.mi_gemm_set_debug.restype = None
+        if os.environ.get("HFASR_GEMM_DEBUG"):
+            h.mi_gemm_set_debug(int(os.environ["HFASR_GEMM_DEBUG"]))
         h.mi_last_error.argtypes = []
         h.mi_last_error.restype = C.c_char_p
         _lib = h

@@ -12,6 +12,7 @@ struct GemmArgs {
     int act;                                // 0 none, 1 gelu(erf)
     int col_T, col_Tp;                      // != 0: output column n -> (n / col_T) * col_Tp + n % col_T
     int M, N, K;
+    int dbg;                                // timing experiments only
     int krot;                               // fast path: rotate the K loop start per block
     // implicit im2col (CONV): A is a channels-last activation (B, Tin, Fin, Cin); row m = (b, to, fo);
     // k = (kh*KW + kw)*Cin + c
