@@ -189,15 +189,18 @@ __global__ __launch_bounds__(256) void dwconv_time_kernel(DwArgs p) {
     }
 }
 
-// Fast form for the reference's kernel size 31, dilation 1: the (TT+30) x 64 input tile is staged once in LDS (16-B
-// global loads, LayerNorm applied on the way in), then every thread keeps its 46-sample window and the 31 taps of its
-// channel in registers and produces 16 consecutive outputs: 77 LDS reads per 496 FMAs instead of 62 per 31.
-constexpr int DWF_K = 31, DWF_TT = 64, DWF_CT = 64, DWF_ROWS = DWF_TT + DWF_K - 1, DWF_PER = DWF_TT / 4;
+// Fast form for the reference's kernel size 31, dilation 1.  A block owns 64 channels x 128 time steps: the (128+30) x 64
+// input tile (16-B global loads, LayerNorm applied on the way in), the gate operand x_r and the result tile all live in
+// LDS, every thread keeps a 62-sample window + the 31 taps of its channel in registers and produces 32 consecutive
+// outputs (93 LDS reads per 992 FMAs), and the result leaves as 16-B-per-lane rows.
+constexpr int DWF_K = 31, DWF_TT = 128, DWF_CT = 64, DWF_ROWS = DWF_TT + DWF_K - 1, DWF_PER = DWF_TT / 4;
 
 template <bool CSGU>
 __global__ __launch_bounds__(256) void dwconv31_kernel(DwArgs p) {
-    __shared__ __attribute__((aligned(16))) float tile[DWF_ROWS * DWF_CT];
-    __shared__ __attribute__((aligned(16))) float sw[DWF_K * DWF_CT];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tile = reinterpret_cast<float*>(smem);                          // [DWF_ROWS][64] fp32
+    float* sw = tile + DWF_ROWS * DWF_CT;                                  // [31][64]
+    bf16_t* io = reinterpret_cast<bf16_t*>(sw + DWF_K * DWF_CT);           // [128][64] bf16: x_r in, result out
     const int c0 = blockIdx.x * DWF_CT, t0 = blockIdx.y * DWF_TT, b = blockIdx.z;
     const int tid = threadIdx.x;
     for (int i = tid; i < DWF_K * DWF_CT; i += 256) {
@@ -228,6 +231,15 @@ __global__ __launch_bounds__(256) void dwconv31_kernel(DwArgs p) {
         *reinterpret_cast<f32x4*>(tile + r * DWF_CT + ch * 8) = lo;
         *reinterpret_cast<f32x4*>(tile + r * DWF_CT + ch * 8 + 4) = hi;
     }
+    if (CSGU) {
+        for (int id = tid; id < DWF_TT * (DWF_CT / 8); id += 256) {
+            const int r = id >> 3, ch = id & 7;
+            const int t = t0 + r;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (t < p.T) v = *reinterpret_cast<const bf16x8*>(p.mul + ((long)b * p.T + t) * p.ld_mul + c0 + ch * 8);
+            *reinterpret_cast<bf16x8*>(io + r * DWF_CT + ch * 8) = v;
+        }
+    }
     __syncthreads();
     const int tx = tid & 63, ty = tid >> 6;
     const int c = c0 + tx;
@@ -240,23 +252,27 @@ __global__ __launch_bounds__(256) void dwconv31_kernel(DwArgs p) {
     const float bias = p.bias ? p.bias[c] : 0.f;
 #pragma unroll
     for (int j = 0; j < DWF_PER; ++j) {
-        const int t = t0 + ty * DWF_PER + j;
-        if (t < p.T) {
-            float acc = bias;
+        float acc = bias;
 #pragma unroll
-            for (int k = 0; k < DWF_K; ++k) acc = fmaf(wk[k], win[j + k], acc);
-            const long row = (long)b * p.T + t;
-            float o;
-            if (CSGU) {
-                if (p.act == 1) acc = gelu_erf(acc);
-                else if (p.act == 2) acc = fmaxf(acc, 0.f);
-                else if (p.act == 3) acc = acc / (1.f + __expf(-acc));
-                o = bf2f(p.mul[row * p.ld_mul + c]) * acc;
-            } else {
-                o = win[j + (DWF_K - 1) / 2] + acc;
-            }
-            p.out[row * p.ld_out + c] = f2bf(o);
+        for (int k = 0; k < DWF_K; ++k) acc = fmaf(wk[k], win[j + k], acc);
+        const int rl = ty * DWF_PER + j;
+        float o;
+        if (CSGU) {
+            if (p.act == 1) acc = gelu_erf(acc);
+            else if (p.act == 2) acc = fmaxf(acc, 0.f);
+            else if (p.act == 3) acc = acc / (1.f + __expf(-acc));
+            o = bf2f(io[rl * DWF_CT + tx]) * acc;
+        } else {
+            o = win[j + (DWF_K - 1) / 2] + acc;
         }
+        io[rl * DWF_CT + tx] = f2bf(o);
+    }
+    __syncthreads();
+    for (int id = tid; id < DWF_TT * (DWF_CT / 8); id += 256) {
+        const int r = id >> 3, ch = id & 7;
+        const int t = t0 + r;
+        if (t < p.T)
+            *reinterpret_cast<bf16x8*>(p.out + ((long)b * p.T + t) * p.ld_out + c0 + ch * 8) = *reinterpret_cast<const bf16x8*>(io + r * DWF_CT + ch * 8);
     }
 }
 
@@ -300,11 +316,13 @@ static int dw_launch(const DwArgs& a, bool csgu, hipStream_t stream) {
     const size_t lds = (size_t)((DW_TT + halo) * DW_CT + a.K * DW_CT) * sizeof(float);
     if (lds > 160 * 1024) return MI_ERR_UNSUPPORTED;
     const bool fast = a.K == DWF_K && a.dilation == 1 && a.pad_left == (DWF_K - 1) / 2 && (a.C % DWF_CT) == 0 &&
-                      (a.ld_in % 8) == 0 && (((uintptr_t)a.in) & 15) == 0 && (!csgu || (((uintptr_t)a.gamma | (uintptr_t)a.beta) & 15) == 0);
+                      (a.ld_in % 8) == 0 && (((uintptr_t)a.in) & 15) == 0 && (a.ld_out % 8) == 0 && (((uintptr_t)a.out) & 15) == 0 &&
+                      (!csgu || ((a.ld_mul % 8) == 0 && (((uintptr_t)a.mul) & 15) == 0)) && (!csgu || (((uintptr_t)a.gamma | (uintptr_t)a.beta) & 15) == 0);
     if (fast) {
         dim3 gridf(a.C / DWF_CT, cdiv(a.T, DWF_TT), a.B);
-        if (csgu) hipLaunchKernelGGL(dwconv31_kernel<true>, gridf, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL(dwconv31_kernel<false>, gridf, dim3(256), 0, stream, a);
+        const size_t ldsf = (size_t)(DWF_ROWS * DWF_CT + DWF_K * DWF_CT) * sizeof(float) + (size_t)DWF_TT * DWF_CT * sizeof(bf16_t);
+        if (csgu) hipLaunchKernelGGL(dwconv31_kernel<true>, gridf, dim3(256), ldsf, stream, a);
+        else hipLaunchKernelGGL(dwconv31_kernel<false>, gridf, dim3(256), ldsf, stream, a);
         MI_CHECK_LAUNCH();
         return MI_OK;
     }

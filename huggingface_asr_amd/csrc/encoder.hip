@@ -65,7 +65,7 @@ Ws carve(const mi_ebf_config& c, void* base) {
     w.a2 = (bf16_t*)k.take(M * c.d * 2);
     w.a1r = (bf16_t*)k.take(M * c.d * 2);
     w.h = (bf16_t*)k.take(M * c.I * 2);
-    w.qk = (bf16_t*)k.take(M * 2 * c.d * 2);
+    w.qk = (bf16_t*)k.take(M * 3 * c.d * 2);      // [Q | K | V] (V columns used by the LDS-staged attention only)
     w.vt = (bf16_t*)k.take((size_t)c.d * c.B * d.Tp * 2);
     w.ctx = (bf16_t*)k.take(M * c.d * 2);
     w.cat = (bf16_t*)k.take(M * 2 * c.d * 2);
@@ -214,14 +214,29 @@ extern "C" int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weigh
             RUN(mi_rotary_bf16(w.a1, d, w.a1r, d, rot_cos, rot_sin, M, T2, c.H, D.hd, st));
             qk_in = w.a1r;
         }
-        RUN(mi_gemm_bf16(qk_in, d, Lw(l, ATT_WQK), d, Lf(l, ATT_BQK), 1, w.qk, 2 * d, 0, nullptr, 0, 1.f, 0, M, 2 * d, d, 0, 0, st));
-        // V^T = Wv · a1^T (+ bv per row), columns remapped to the time-padded (b*Tp + t) layout
-        RUN(mi_gemm_bf16(Lw(l, ATT_WV), d, w.a1, d, Lf(l, ATT_BV), 2, w.vt, (long)c.B * D.Tp, 0, nullptr, 0, 1.f, 0, d, M, d,
-                         T2, D.Tp, st));
-        RUN(mi_attention_bf16(w.qk, 2 * d, w.qk + d, 2 * d, w.vt, (long)c.B * D.Tp, D.Tp,
-                              c.pos_type == 1 ? (const bf16_t*)posp + (size_t)l * P * d : nullptr, d,
-                              c.pos_type == 1 ? Lf(l, ATT_U) : nullptr, c.pos_type == 1 ? Lf(l, ATT_V) : nullptr,
-                              mask_len, w.ctx, d, c.B, T2, c.H, D.hd, scale, c.is_causal, st));
+        const bool lds_attn = (D.hd == 64 || D.hd == 128);
+        if (lds_attn) {
+            // fused [Q|K|V] projection (weights are packed [Wq;Wk;Wv]); rotary feeds Q,K from the rotated input only
+            if (c.pos_type == 2) {
+                RUN(mi_gemm_bf16(qk_in, d, Lw(l, ATT_WQK), d, Lf(l, ATT_BQK), 1, w.qk, 3 * d, 0, nullptr, 0, 1.f, 0, M, 2 * d, d, 0, 0, st));
+                RUN(mi_gemm_bf16(w.a1, d, Lw(l, ATT_WV), d, Lf(l, ATT_BV), 1, w.qk + 2 * d, 3 * d, 0, nullptr, 0, 1.f, 0, M, d, d, 0, 0, st));
+            } else {
+                RUN(mi_gemm_bf16(w.a1, d, Lw(l, ATT_WQK), d, Lf(l, ATT_BQK), 1, w.qk, 3 * d, 0, nullptr, 0, 1.f, 0, M, 3 * d, d, 0, 0, st));
+            }
+            RUN(mi_attention_qkv_bf16(w.qk, 3 * d, w.qk + d, 3 * d, w.qk + 2 * d, 3 * d,
+                                      c.pos_type == 1 ? (const bf16_t*)posp + (size_t)l * P * d : nullptr, d,
+                                      c.pos_type == 1 ? Lf(l, ATT_U) : nullptr, c.pos_type == 1 ? Lf(l, ATT_V) : nullptr,
+                                      mask_len, w.ctx, d, c.B, T2, c.H, D.hd, scale, c.is_causal, st));
+        } else {
+            RUN(mi_gemm_bf16(qk_in, d, Lw(l, ATT_WQK), d, Lf(l, ATT_BQK), 1, w.qk, 3 * d, 0, nullptr, 0, 1.f, 0, M, 2 * d, d, 0, 0, st));
+            // V^T = Wv · a1^T (+ bv per row), columns remapped to the time-padded (b*Tp + t) layout
+            RUN(mi_gemm_bf16(Lw(l, ATT_WV), d, w.a1, d, Lf(l, ATT_BV), 2, w.vt, (long)c.B * D.Tp, 0, nullptr, 0, 1.f, 0, d, M, d,
+                             T2, D.Tp, st));
+            RUN(mi_attention_bf16(w.qk, 3 * d, w.qk + d, 3 * d, w.vt, (long)c.B * D.Tp, D.Tp,
+                                  c.pos_type == 1 ? (const bf16_t*)posp + (size_t)l * P * d : nullptr, d,
+                                  c.pos_type == 1 ? Lf(l, ATT_U) : nullptr, c.pos_type == 1 ? Lf(l, ATT_V) : nullptr,
+                                  mask_len, w.ctx, d, c.B, T2, c.H, D.hd, scale, c.is_causal, st));
+        }
         RUN(mi_gemm_bf16(w.ctx, d, Lw(l, ATT_WO), d, Lf(l, ATT_BO), 1, w.cat, 2 * d, 0, nullptr, 0, 1.f, 0, M, d, d, 0, 0, st));
         // local branch: cgMLP (e_branchformer.py:291-292, 184-222)
         RUN(mi_gemm_bf16(w.a2, d, Lw(l, MLP_W1), d, Lf(l, MLP_B1), 1, w.h, I, 0, nullptr, 0, 1.f, 1, M, I, d, 0, 0, st));

@@ -112,9 +112,11 @@ class EBranchformerEngine:
                     lp(pre + "_W2", bf(sd[p + ff + ".1.output_dense.weight"])); lp(pre + "_B2", f32(sd[p + ff + ".1.output_dense.bias"]))
             lp("ATT_LN_G", f32(sd[p + "self_attn_layer_norm.weight"])); lp("ATT_LN_B", f32(sd[p + "self_attn_layer_norm.bias"]))
             a = p + "self_attn."
-            lp("ATT_WQK", bf(torch.cat([sd[a + "linear_q.weight"].detach().to(dev), sd[a + "linear_k.weight"].detach().to(dev)], 0)))
-            lp("ATT_BQK", f32(torch.cat([sd[a + "linear_q.bias"].detach().to(dev), sd[a + "linear_k.bias"].detach().to(dev)], 0)))
-            lp("ATT_WV", bf(sd[a + "linear_v.weight"])); lp("ATT_BV", f32(sd[a + "linear_v.bias"]))
+            # [Wq; Wk; Wv] packed as one (3d, d) matrix: the fused QKV GEMM uses all rows, the Q/K-only and V-only GEMMs views
+            wqkv = bf(torch.cat([sd[a + f"linear_{n}.weight"].detach().to(dev) for n in "qkv"], 0))
+            bqkv = f32(torch.cat([sd[a + f"linear_{n}.bias"].detach().to(dev) for n in "qkv"], 0))
+            lp("ATT_WQK", wqkv); lp("ATT_BQK", bqkv)
+            lp("ATT_WV", wqkv[2 * d:]); lp("ATT_BV", bqkv[2 * d:])
             lp("ATT_WO", bf(sd[a + "linear_out.weight"])); lp("ATT_BO", f32(sd[a + "linear_out.bias"]))
             if rel:
                 lp("ATT_WPOS", bf(sd[a + "linear_pos.weight"]))

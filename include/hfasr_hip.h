@@ -80,6 +80,13 @@ int mi_attention_bf16(const void* q, long ldq, const void* k, long ldk, const vo
                       const int* lengths, void* out, long ldo, int B, int T, int H, int hd,
                       float scale, int causal, mi_stream_t stream);
 
+/* LDS-staged form for head sizes 64 / 128: q, k, v are columns of ONE fused (B*T, 3d) projection (all [row][hd]),
+ * no transposed V copy; the position rows / K / V tiles are shared by the 4 waves of a 128-query block. */
+int mi_attention_qkv_bf16(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                          const void* pos, long ldp, const float* bias_u, const float* bias_v,
+                          const int* lengths, void* out, long ldo, int B, int T, int H, int hd,
+                          float scale, int causal, mi_stream_t stream);
+
 /* ---- cgMLP gate: per-row LN statistics + fused LN -> depthwise conv(time) -> gate.
  * replaces: ConvolutionalSpatialGatingUnit.forward e_branchformer.py:184-204. */
 int mi_row_stats_bf16(const void* x, long ldx, int d, float eps, float* stats, int M, mi_stream_t stream);

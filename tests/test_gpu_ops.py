@@ -188,6 +188,25 @@ def test_attention(T, H, hd, rel, causal):
     assert_close_bf16(got, want, atol=1.5e-2, rtol=2e-2, what="attention")
 
 
+@pytest.mark.parametrize("T,H,hd,rel,causal", [(250, 4, 128, True, False), (75, 2, 64, False, False), (97, 4, 64, True, True),
+                                               (33, 2, 128, False, True), (300, 4, 128, True, False), (129, 1, 128, True, False),
+                                               (500, 2, 64, True, False)])
+def test_attention_lds_staged(T, H, hd, rel, causal):
+    """LDS-staged kernel (fused QKV input, tr-read V, carried G tile) against the same oracle."""
+    ops = _ops()
+    B, d = 3, H * hd
+    q, k, v = (bfr(rnd(B * T, d, seed=150 + i, scale=0.8)) for i in range(3))
+    lengths = torch.tensor([T, max(1, T - 13), max(1, T // 2)], dtype=torch.int32)
+    pos = bfr(rnd(2 * T - 1, d, seed=155, scale=0.8)) if rel else None
+    u, vb = (0.2 * rnd(H, hd, seed=156), 0.2 * rnd(H, hd, seed=157)) if rel else (None, None)
+    want = _attn_ref(q, k, v, B, T, H, pos, u, vb, lengths, causal)
+    qkv = torch.cat([q, k, v], 1).to(DEV, torch.bfloat16)
+    got = ops.attention_qkv(qkv, B, T, H, pos=None if pos is None else pos.to(DEV, torch.bfloat16),
+                            bias_u=None if u is None else u.to(DEV), bias_v=None if vb is None else vb.to(DEV),
+                            lengths=lengths.to(DEV), causal=causal)
+    assert_close_bf16(got, want, atol=1.5e-2, rtol=2e-2, what="attention (lds)")
+
+
 @pytest.mark.parametrize("causal", [False, True])
 def test_csgu_and_merge(causal):
     ops = _ops()
