@@ -109,7 +109,7 @@ extern "C" const char* mi_last_error(void) { return g_last_error; }
 // ---- profiling facility (diagnostics, off by default): HIP events around every launch of the dense GEMM kernel,
 // recorded on the stream the kernel is launched on.  Used by bench.py for roofline.achieved.
 namespace {
-struct Prof { hipEvent_t* ev = nullptr; double* flops = nullptr; int cap = 0, n = 0; bool on = false; };
+struct Prof { hipEvent_t* ev = nullptr; double* flops = nullptr; int cap = 0, n = 0, stride = 1; long seen = 0; bool on = false; };
 Prof g_prof;
 }
 extern "C" int mi_profile_create(int capacity) {
@@ -121,11 +121,13 @@ extern "C" int mi_profile_create(int capacity) {
     g_prof.cap = capacity; g_prof.n = 0; g_prof.on = false;
     return MI_OK;
 }
-extern "C" void mi_profile_enable(int on) { g_prof.on = on != 0; }
+// on = 0: off; on = s > 0: time every s-th launch (s = 1: all).  Sampling keeps the perturbation of the timed region small.
+extern "C" void mi_profile_enable(int on) { g_prof.on = on != 0; g_prof.stride = on > 0 ? on : 1; g_prof.seen = 0; }
 extern "C" void mi_profile_reset(void) { g_prof.n = 0; }
 extern "C" int mi_profile_count(void) { return g_prof.n; }
 extern "C" int mi_profile_hook_begin(hipStream_t stream, double flops) {
     if (!g_prof.on || g_prof.n >= g_prof.cap) return -1;
+    if ((g_prof.seen++ % g_prof.stride) != 0) return -1;
     const int slot = g_prof.n++;
     g_prof.flops[slot] = flops;
     hipEventRecord(g_prof.ev[2 * slot], stream);
@@ -270,7 +272,7 @@ extern "C" int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weigh
     }
     // CTC head: lm_head ⊕ blank_projection, blank LAST (e_branchformer.py:456-457)
     if (logits)
-        RUN(mi_gemm_bf16(w.hid, d, Gw(G_HEAD_W), d, Gf(G_HEAD_B), 1, logits, c.V + 1, c.logits_f32, nullptr, 0, 1.f, 0,
+        RUN(mi_gemm_bf16(w.hid, d, Gw(G_HEAD_W), d, Gf(G_HEAD_B), 1, logits, c.logits_ld > 0 ? c.logits_ld : c.V + 1, c.logits_f32, nullptr, 0, 1.f, 0,
                          M, c.V + 1, d, 0, 0, st));
     MI_CHECK_LAUNCH();
     return MI_OK;

@@ -179,19 +179,23 @@ class EBranchformerEngine:
                               is_causal=int(c.get("is_causal", False)), pos_type=POS[c.get("position_embeddings_type", "relative")],
                               csgu_kernel=c.get("csgu_kernel_size", 31), merge_kernel=c.get("merge_conv_kernel", 31),
                               csgu_act=ACT[c.get("csgu_activation", "identity")], use_macaron=int(c.get("use_macaron_ff", True)),
-                              ln_eps=float(c.get("layer_norm_eps", 1e-5)), logits_f32=int(self.logits_dtype == torch.float32))
+                              ln_eps=float(c.get("layer_norm_eps", 1e-5)), logits_f32=int(self.logits_dtype == torch.float32),
+                              logits_ld=(c["vocab_size"] + 1 + 7) // 8 * 8)
 
-    def _workspace(self, cs):
+    def _workspace(self, cs, slot=0):
         key = (cs.B, cs.T, cs.F)
-        if key not in self._ws:
+        if self._ws.get("key") != key:
+            self._ws = {"key": key}                                                        # keep one shape resident
+        if slot not in self._ws:
             nbytes = _lib.lib().mi_ebf_workspace_bytes(C.byref(cs))
-            self._ws = {key: torch.zeros(nbytes, dtype=torch.uint8, device=self.device)}   # keep one shape resident
-        return self._ws[key]
+            self._ws[slot] = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws[slot]
 
     # ------------------------------------------------------------------ forward
-    def forward(self, feats: torch.Tensor, feat_lengths: torch.Tensor | None = None, *, want_hidden=True, want_logits=True):
+    def forward(self, feats: torch.Tensor, feat_lengths: torch.Tensor | None = None, *, want_hidden=True, want_logits=True, slot=0):
         """feats (B,T,F) fp32 device tensor; feat_lengths (B) int32 (= attention_mask.sum(-1)) or None.
-        Returns dict(logits (B,T2,V+1), last_hidden (B,T2,d) fp32, inner_len, outer_len int32 (B))."""
+        Returns dict(logits (B,T2,V+1), last_hidden (B,T2,d) fp32, inner_len, outer_len int32 (B)).
+        `slot` selects a private workspace: calls issued on different streams must use different slots."""
         if self._table is None:
             raise RuntimeError("EBranchformerEngine: load_state_dict() first")
         if not feats.is_cuda:
@@ -204,7 +208,7 @@ class EBranchformerEngine:
         if T2 <= 0:
             raise ValueError("input too short for the conv sub-sampling")
         d, V1 = c["hidden_size"], c["vocab_size"] + 1
-        ws = self._workspace(cs)
+        ws = self._workspace(cs, slot)
         pos = self._pos_table(T2)
         posp, compute = None, 0
         if cs.pos_type == 1:
@@ -213,15 +217,19 @@ class EBranchformerEngine:
                 self._posp_valid = {}
             posp = self._posp[T2]
             compute = 0 if self._posp_valid.get(T2) == self.weights_version else 1
+            if compute and slot != 0:
+                raise RuntimeError("multi-stream use: run one forward on slot 0 first (it fills the shared position-projection cache)")
             self._posp_valid[T2] = self.weights_version
-        logits = torch.empty((B, T2, V1), dtype=self.logits_dtype, device=self.device) if want_logits else None
+        # rows padded to a multiple of 8 elements (16-B stores in the GEMM epilogue); callers get the (B,T2,V+1) view
+        lbuf = torch.empty((B, T2, cs.logits_ld), dtype=self.logits_dtype, device=self.device) if want_logits else None
+        logits = lbuf[..., :V1] if want_logits else None
         hidden = torch.empty((B, T2, d), dtype=torch.float32, device=self.device) if want_hidden else None
         lens = torch.empty((2, B), dtype=torch.int32, device=self.device)
         if feat_lengths is not None:
             feat_lengths = feat_lengths.to(device=self.device, dtype=torch.int32).contiguous()
         p = lambda t: None if t is None else t.data_ptr()
         rc = _lib.lib().mi_ebf_forward(C.byref(cs), self._table, feats.data_ptr(), p(feat_lengths), p(pos), p(posp), compute,
-                                       ws.data_ptr(), ws.numel(), p(hidden), p(logits), lens[0].data_ptr(), lens[1].data_ptr(),
+                                       ws.data_ptr(), ws.numel(), p(hidden), p(lbuf), lens[0].data_ptr(), lens[1].data_ptr(),
                                        torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "mi_ebf_forward")
         return dict(logits=logits, last_hidden=hidden, inner_len=lens[0], outer_len=lens[1])

@@ -8,7 +8,10 @@ dev = "cuda:0"
 M = 8000
 shapes = [  # (name, M, N, K, kind)
     ("ffn_in   8000x2048x512", M, 2048, 512, "gelu_bf16"),
+    ("ffn_in noact bf16", M, 2048, 512, "bf16"),
+    ("ffn_in f32 out", M, 2048, 512, "f32"),
     ("ffn_out  8000x512x2048", M, 512, 2048, "resid_f32"),
+    ("ffn_out bf16 noresid", M, 512, 2048, "bf16"),
     ("qk       8000x1024x512", M, 1024, 512, "bf16"),
     ("wo       8000x512x512", M, 512, 512, "bf16"),
     ("cp2      8000x512x1024", M, 512, 1024, "bf16"),
