@@ -40,6 +40,9 @@ SIGNATURES = {
     "mi_cmvn_global": [vp, i64, i32, vp, vp, vp],
     "mi_row_lse": [vp, i64, i32, i32, vp, i32, vp],
     "mi_ctc_loss_fwd": [vp, i64, i64, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp],
+    "mi_ctc_prefix_prepare": [vp, i64, i64, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp],
+    "mi_ctc_prefix_score": [vp, i32, i32, i32, i32, i32, vp, vp, i64, i32, vp, vp, vp, vp],
+    "mi_ctc_prefix_select": [vp, i32, i32, i32, i32, i32, vp, vp, i64, i32, vp, vp, i64, i32, vp, vp],
     "mi_ebf_workspace_bytes": [C.POINTER(EbfConfig)],
     "mi_ebf_forward": [C.POINTER(EbfConfig), vp, vp, vp, vp, vp, i32, vp, sz, vp, vp, vp, vp, vp],
 }

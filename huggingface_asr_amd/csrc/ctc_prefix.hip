@@ -1,0 +1,164 @@
+// CTC prefix scorer for joint CTC/attention decoding on gfx950.
+//
+// Replaces the per-token Python loop of the reference's `CTCPrefixScoreTH.__call__` (src/decoding/ctc_scorer.py:58-178:
+// `for t in range(start, end)` over ALL encoder frames on (T, 2, B*W, V) tensors) and `index_select_state` (:180-207).
+// Every (hypothesis i, token c) pair is an independent chain over time
+//     r^n_t = lse(r^n_{t-1}, phi_{t-1}) + x_t[c] ,   r^b_t = lse(r^n_{t-1}, r^b_{t-1}) + x_t[blank] ,
+//     log psi = lse_t(phi_{t-1} + x_t[c])  (+ r^n_{start-1}),      phi_t = (c == last_i) ? r'^b_t : lse(r'^n_t, r'^b_t)
+// so one thread runs one chain with its forward variables in registers: the reference's (T,2,B*W,V) state tensor
+// (50 MB per emitted token at T'=250, W=5, V=5001) is never materialised.  The only state kept between tokens is the
+// previous prefix's (T,2,B*W) forward variables; the chains of the tokens that beam search actually selected are re-run
+// (B*W chains) to advance it — including the reference's quirk that every beam inherits beam 0's variables.
+// HBM traffic per token: the log-posteriors x (B,T,V) read once, coalesced over c (HBM/L2 bound, fp32 math).
+#include "common.hpp"
+
+namespace {
+
+constexpr float LOGZERO = -10000000000.0f;
+
+__device__ __forceinline__ float lse2(float a, float b) {
+    const float m = fmaxf(a, b);
+    return m + log1pf(expf(-fabsf(a - b)));
+}
+
+// x = log_softmax(logits) with the padding rule of ctc_scorer.py:39-42 (frames >= len: logzero, blank = 0)
+template <typename T>
+__global__ __launch_bounds__(256) void prefix_prepare_kernel(const T* __restrict__ logits, long ld_b, long ld_t, const float* __restrict__ lse,
+                                                              const int* __restrict__ lens, int Tn, int O, int blank, float* __restrict__ x) {
+    const int row = blockIdx.x;                 // b*T + t
+    const int b = row / Tn, t = row - b * Tn;
+    const bool pad = t >= lens[b];
+    const T* src = logits + (long)b * ld_b + (long)t * ld_t;
+    const float l = lse[row];
+    for (int c = threadIdx.x; c < O; c += 256)
+        x[(long)row * O + c] = pad ? (c == blank ? 0.f : LOGZERO) : (float)src[c] - l;
+}
+
+// initial forward variables (:74-82): r^n = logzero, r^b_t = cumsum_t x_t[blank] (sequential fp32, as torch.cumsum)
+__global__ void prefix_init_kernel(const float* __restrict__ x, int B, int Tn, int O, int blank, int W, float* __restrict__ r) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // hypothesis
+    if (i >= B * W) return;
+    const int b = i / W;
+    float acc = 0.f;
+    for (int t = 0; t < Tn; ++t) {
+        acc += x[((long)b * Tn + t) * O + blank];
+        r[((long)t * 2 + 0) * B * W + i] = LOGZERO;
+        r[((long)t * 2 + 1) * B * W + i] = acc;
+    }
+}
+
+struct ChainArgs {
+    const float* x; int B, T, O, blank, W;
+    const float* r_prev;            // (T, 2, n_bh)
+    const long* last_ids; long ld_last;   // last token of every hypothesis' prefix (input_ids[:, -1])
+    int out_len;                    // len(prefix) - 1
+    // chain selection: null -> all (i, c); else K chains (hyp[k], tok[k])
+    const int* hyp; const long* tok; long ld_tok; int K;
+    float* r_out;                   // (T, 2, K) or null
+    float* psi_out;                 // (K) / (n_bh, O) or null
+    const float* s_prev;            // (n_bh) or null (= 0)
+    float* scores_out;              // (n_bh, O) or null: psi - s_prev with blank / exact-zero -> logzero
+};
+
+__global__ __launch_bounds__(256) void prefix_chain_kernel(ChainArgs p) {
+    const int n_bh = p.B * p.W;
+    long k = (long)blockIdx.x * 256 + threadIdx.x;
+    int i, c;
+    if (p.hyp) {
+        if (k >= p.K) return;
+        i = p.hyp[k];
+        c = (int)p.tok[k * p.ld_tok];
+    } else {
+        const int cpb = (p.O + 255) / 256;                    // blocks per hypothesis
+        i = blockIdx.x / cpb;
+        c = (blockIdx.x % cpb) * 256 + threadIdx.x;
+        if (i >= n_bh || c >= p.O) return;
+        k = (long)i * p.O + c;
+    }
+    const int b = i / p.W;
+    const float* xb = p.x + (long)b * p.T * p.O;
+    const bool same = (long)c == p.last_ids[(long)i * p.ld_last];
+    const int start = p.out_len > 1 ? p.out_len : 1;
+    const long Kt = p.hyp ? p.K : (long)n_bh * p.O;
+    float r0 = LOGZERO, r1 = LOGZERO;
+    if (p.out_len == 0) r0 = xb[c];
+    if (p.r_out) {
+        for (int t = 0; t < start && t < p.T; ++t) {
+            p.r_out[((long)t * 2 + 0) * Kt + k] = (t == 0 && p.out_len == 0) ? r0 : LOGZERO;
+            p.r_out[((long)t * 2 + 1) * Kt + k] = LOGZERO;
+        }
+    }
+    // r[start-1] : only r[0] can be non-logzero (out_len == 0)
+    if (start - 1 != 0) r0 = LOGZERO;
+    float pm = r0, ps = 1.f;                     // online logsumexp of psi, seeded with r^n_{start-1}
+    for (int t = start; t < p.T; ++t) {
+        const float rp0 = p.r_prev[((long)(t - 1) * 2 + 0) * n_bh + i];
+        const float rp1 = p.r_prev[((long)(t - 1) * 2 + 1) * n_bh + i];
+        const float phi = same ? rp1 : lse2(rp0, rp1);
+        const float xc = xb[(long)t * p.O + c], xbl = xb[(long)t * p.O + p.blank];
+        const float n0 = lse2(r0, phi) + xc;
+        const float n1 = lse2(r0, r1) + xbl;
+        r0 = n0; r1 = n1;
+        if (p.r_out) {
+            p.r_out[((long)t * 2 + 0) * Kt + k] = r0;
+            p.r_out[((long)t * 2 + 1) * Kt + k] = r1;
+        }
+        const float term = phi + xc;
+        if (term > pm) { ps = ps * expf(pm - term) + 1.f; pm = term; }
+        else ps += expf(term - pm);
+    }
+    float psi = pm + logf(ps);
+    if (p.scores_out || !p.hyp) { if (c == p.blank) psi = LOGZERO; }            // :173
+    if (p.psi_out) p.psi_out[k] = psi;
+    if (p.scores_out) {
+        float s = psi - (p.s_prev ? p.s_prev[i] : 0.f);
+        if (s == 0.f) s = LOGZERO;                                              // :176
+        p.scores_out[k] = s;
+    }
+}
+
+}  // namespace
+
+// x_out (B,T,O) fp32 = padded log-posteriors; r0_out (T,2,B*W) initial forward variables. lse: scratch (B*T) fp32.
+extern "C" int mi_row_lse(const void* x, long ld, int dtype, int V, float* lse, int M, hipStream_t stream);
+extern "C" int mi_ctc_prefix_prepare(const void* logits, long ld_b, long ld_t, int dtype, const int* lens, int B, int T, int O,
+                                     int blank, int W, float* lse_scratch, float* x_out, float* r0_out, hipStream_t stream) {
+    MI_ENTER();
+    if (B <= 0 || T <= 0 || O <= 0 || W <= 0 || blank < 0 || blank >= O) return MI_ERR_ARG;
+    // row LSE needs contiguous (B*T) rows with stride ld_t; per-batch stride handled by looping batches when ld_b != T*ld_t
+    for (int b = 0; b < B; ++b) {
+        const char* base = (const char*)logits + (size_t)b * ld_b * (dtype == 0 ? 4 : 2);
+        int rc = mi_row_lse(base, ld_t, dtype, O, lse_scratch + (size_t)b * T, T, stream);
+        if (rc != MI_OK) return rc;
+    }
+    if (dtype == 0)
+        hipLaunchKernelGGL(prefix_prepare_kernel<float>, dim3(B * T), dim3(256), 0, stream, (const float*)logits, ld_b, ld_t, lse_scratch, lens, T, O, blank, x_out);
+    else
+        hipLaunchKernelGGL(prefix_prepare_kernel<bf16_t>, dim3(B * T), dim3(256), 0, stream, (const bf16_t*)logits, ld_b, ld_t, lse_scratch, lens, T, O, blank, x_out);
+    hipLaunchKernelGGL(prefix_init_kernel, dim3(cdiv(B * W, 64)), dim3(64), 0, stream, x_out, B, T, O, blank, W, r0_out);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// score all (hyp, token) pairs: scores_out (n_bh, O), psi_out (n_bh, O)
+extern "C" int mi_ctc_prefix_score(const float* x, int B, int T, int O, int blank, int W, const float* r_prev, const long* last_ids,
+                                   long ld_last, int out_len, const float* s_prev, float* psi_out, float* scores_out, hipStream_t stream) {
+    MI_ENTER();
+    if (B <= 0 || T <= 0 || O <= 0 || W <= 0) return MI_ERR_ARG;
+    ChainArgs a{x, B, T, O, blank, W, r_prev, last_ids, ld_last, out_len, nullptr, nullptr, 0, 0, nullptr, psi_out, s_prev, scores_out};
+    hipLaunchKernelGGL(prefix_chain_kernel, dim3(B * W * cdiv(O, 256)), dim3(256), 0, stream, a);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// advance the state along the selected chains (hyp[k], tok[k]), k < K: r_out (T,2,K)
+extern "C" int mi_ctc_prefix_select(const float* x, int B, int T, int O, int blank, int W, const float* r_prev, const long* last_ids,
+                                    long ld_last, int out_len, const int* hyp, const long* tok, long ld_tok, int K, float* r_out,
+                                    hipStream_t stream) {
+    MI_ENTER();
+    if (B <= 0 || T <= 0 || O <= 0 || W <= 0 || K <= 0) return MI_ERR_ARG;
+    ChainArgs a{x, B, T, O, blank, W, r_prev, last_ids, ld_last, out_len, hyp, tok, ld_tok, K, r_out, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(prefix_chain_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, a);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}

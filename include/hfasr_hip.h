@@ -113,6 +113,17 @@ int mi_ctc_loss_fwd(const void* logits, long ld_b, long ld_t, int dtype, const f
                     const long* labels, int U, const int* in_len, int blank, int B,
                     int reduction, int zero_infinity, float* nll, int* tgt_len, float* loss, mi_stream_t stream);
 
+/* ---- joint CTC/attention decoding: batched CTC prefix scores on device.
+ * replaces: CTCPrefixScoreTH.__call__ / index_select_state (src/decoding/ctc_scorer.py:58-207) as driven by
+ *           CTCRescorerLogitsProcessor.__call__ (:324-354).  x: (B,T,O) padded log-posteriors; r: (T,2,B*W) forward variables. */
+int mi_ctc_prefix_prepare(const void* logits, long ld_b, long ld_t, int dtype, const int* lens, int B, int T, int O,
+                          int blank, int W, float* lse_scratch, float* x_out, float* r0_out, mi_stream_t stream);
+int mi_ctc_prefix_score(const float* x, int B, int T, int O, int blank, int W, const float* r_prev, const long* last_ids,
+                        long ld_last, int out_len, const float* s_prev, float* psi_out, float* scores_out, mi_stream_t stream);
+int mi_ctc_prefix_select(const float* x, int B, int T, int O, int blank, int W, const float* r_prev, const long* last_ids,
+                         long ld_last, int out_len, const int* hyp, const long* tok, long ld_tok, int K, float* r_out,
+                         mi_stream_t stream);
+
 /* ---- whole encoder + CTC head: Wav2Vec2EBranchformerForCTC.forward (e_branchformer.py:422-496), eval mode. */
 typedef struct {
     int B, T, F;                 /* padded log-mel input (B,T,F) fp32 */

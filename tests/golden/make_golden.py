@@ -180,8 +180,49 @@ def run_ctc_known_answers():
     np.savez_compressed(os.path.join(HERE, "ctc_known.npz"), **rec)
 
 
+def run_ctc_prefix_cases():
+    """reference src/decoding/ctc_scorer.py: CTCRescorerLogitsProcessor over 4 decoding steps (B=2, W=3)."""
+    from decoding.ctc_scorer import CTCPrefixScoreTH, CTCRescorerLogitsProcessor, LogSoftmaxProcessor
+
+    class Recorder(CTCPrefixScoreTH):
+        def __call__(self, y, state, scoring_ids=None, att_w=None):
+            out = super().__call__(y, state, scoring_ids, att_w)
+            self.last_scores = out[0].clone()
+            return out
+
+    rec = {}
+    for case, (B, W, T, O, lens, trick) in {"a": (2, 3, 40, 30, [40, 33], False), "b": (1, 5, 75, 51, [75], True),
+                                            "c": (3, 2, 24, 17, [20, 24, 9], False)}.items():
+        g = torch.Generator().manual_seed(7)
+        enc_logits = torch.randn(B, T, O, generator=g) * 2.0
+        blank, eos, space = O - 1, 1, 5
+        proc = CTCRescorerLogitsProcessor(enc_logits.clone(), torch.tensor(lens), blank, eos, 0, 0.3, W, space, trick, 0.8)
+        proc.ctc_prefix_scorer.__class__ = Recorder
+        ids = torch.zeros((B * W, 1), dtype=torch.long) + 2                      # start token
+        rec[f"{case}/enc_logits"] = enc_logits.numpy(); rec[f"{case}/lens"] = np.array(lens)
+        rec[f"{case}/meta"] = np.array([B, W, T, O, blank, eos, space, int(trick)])
+        for step in range(4):
+            att = torch.log_softmax(torch.randn(B * W, O, generator=g) * 1.5, -1)
+            if trick and step == 2:
+                att[:, eos] = 0.0                                                 # provoke the eos/space branch
+            out = proc(ids, att.clone())
+            rec[f"{case}/step{step}/input_ids"] = ids.numpy().copy()
+            rec[f"{case}/step{step}/att"] = att.numpy()
+            rec[f"{case}/step{step}/ctc"] = proc.ctc_prefix_scorer.last_scores.numpy().copy()
+            rec[f"{case}/step{step}/out"] = out.numpy().copy()
+            # beam k of every utterance takes its (k+1)-th best non-blank token -> distinct prefixes per beam
+            order = out.clone(); order[:, blank] = -1e30
+            top = order.topk(W, dim=1).indices
+            nxt = torch.stack([top[i, i % W] for i in range(B * W)])
+            ids = torch.cat([ids, nxt[:, None]], 1)
+        lsm = LogSoftmaxProcessor()(ids, att.clone())
+        rec[f"{case}/logsoftmax"] = lsm.numpy()
+    np.savez_compressed(os.path.join(HERE, "ctc_prefix.npz"), **rec)
+    print("ctc_prefix cases written")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "base", "fbank", "lengths", "ctc"]
+    which = sys.argv[1:] or ["tiny", "base", "fbank", "lengths", "ctc", "prefix"]
     if "tiny" in which:
         run_encoder_case("tiny_rel", TINY, seed=11, B=2, T=200, lengths=[198, 150], U=7, tgt_lens=[7, 5])
         run_encoder_case("tiny_rotary", TINY, seed=12, B=2, T=200, lengths=[200, 131], U=6, tgt_lens=[6, 4],
@@ -201,3 +242,5 @@ if __name__ == "__main__":
         run_length_tables()
     if "ctc" in which:
         run_ctc_known_answers()
+    if "prefix" in which:
+        run_ctc_prefix_cases()

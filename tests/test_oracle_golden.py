@@ -104,3 +104,24 @@ def test_ctc_known_answers(case):
             want = g[f"{case}/{red}/{zi}"]
             got = R.ctc_loss_ref(lp, labels, in_len, tl, blank=logits.shape[-1] - 1, reduction=red, zero_infinity=bool(zi))
             np.testing.assert_allclose(got.numpy(), want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_ctc_prefix_scorer_matches_reference(case):
+    """oracle/ctc_prefix_ref.py against 4 decoding steps of the reference's CTCRescorerLogitsProcessor."""
+    from oracle import ctc_prefix_ref as P
+    g = load_golden("ctc_prefix")
+    B, W, T, O, blank, eos, space, trick = [int(v) for v in g[f"{case}/meta"]]
+    logp = torch.log_softmax(torch.from_numpy(g[f"{case}/enc_logits"]), -1).numpy()
+    sc = P.PrefixScorer(logp, g[f"{case}/lens"], blank, W)
+    for step in range(4):
+        ctc = sc.step(g[f"{case}/step{step}/input_ids"])
+        want = g[f"{case}/step{step}/ctc"]
+        live = want > -1e9
+        np.testing.assert_array_equal(ctc > -1e9, live)
+        np.testing.assert_allclose(ctc[live], want[live], atol=2e-4, rtol=1e-5)
+        if not trick:
+            out = P.rescore(g[f"{case}/step{step}/att"], ctc, blank, 0.3)
+            wo = g[f"{case}/step{step}/out"]
+            ok = wo > -1e9
+            np.testing.assert_allclose(out[ok], wo[ok], atol=2e-4, rtol=1e-5)
