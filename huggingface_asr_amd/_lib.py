@@ -29,9 +29,10 @@ SIGNATURES = {
     "mi_conv2d_cl_bf16": [vp, vp, vp, vp] + [i32] * 13 + [vp],
     "mi_conv2d_first_gelu": [vp, vp, vp, vp] + [i32] * 10 + [vp],
     "mi_layernorm_chain": [vp, i64, vp, i32, vp, vp, f32, vp, i64, vp, vp, f32, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, vp],
+    "mi_cast_f32_bf16": [vp, i64, vp, i64, i32, i32, vp],
     "mi_rotary_bf16": [vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, vp],
     "mi_attention_bf16": [vp, i64, vp, i64, vp, i64, i32, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, i32, vp],
-    "mi_attention_qkv_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, i32, vp],
+    "mi_attention_qkv_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i64, i32, i32, f32, i32, vp],
     "mi_row_stats_bf16": [vp, i64, i32, f32, vp, i32, vp],
     "mi_csgu_bf16": [vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp],
     "mi_dwconv_residual_bf16": [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp],
@@ -43,6 +44,8 @@ SIGNATURES = {
     "mi_ctc_prefix_prepare": [vp, i64, i64, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp],
     "mi_ctc_prefix_score": [vp, i32, i32, i32, i32, i32, vp, vp, i64, i32, vp, vp, vp, vp],
     "mi_ctc_prefix_select": [vp, i32, i32, i32, i32, i32, vp, vp, i64, i32, vp, vp, i64, i32, vp, vp],
+    "mi_embed_tokens": [vp, vp, f32, vp, i32, i32, i32, i32, i32, vp, vp],
+    "mi_ce_label_smoothing": [vp, i64, vp, i32, i32, i32, i32, f32, vp, vp],
     "mi_ebf_workspace_bytes": [C.POINTER(EbfConfig)],
     "mi_ebf_forward": [C.POINTER(EbfConfig), vp, vp, vp, vp, vp, i32, vp, sz, vp, vp, vp, vp, vp],
 }

@@ -27,6 +27,8 @@ struct AttnArgs {
     const int* lengths;                  // (B) number of valid keys, or null
     bf16_t* out; long ldo;               // (B*T, .) context
     int B, T, H; float scale; int causal;
+    int Tk;                              // LDS-staged kernel: number of key/value rows per batch (0 = T); queries are T
+    long kv_bstride;                     // elements between consecutive batches of k / v (0 = Tk * ld): KV caches
 };
 
 constexpr int SKEW_LD = 66;   // words per query row of the skew scratch: reads conflict-free, writes 2-way (free)
@@ -208,11 +210,13 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
     const int head = blockIdx.y, b = blockIdx.z;
     const int ib = blockIdx.x * 128, i0 = ib + wave * 32;
     float* skew = skew_all + wave * 32 * SKEW_LD;
-    const int T = p.T;
-    const int len = p.lengths ? min(p.lengths[b], T) : T;
-    const int kend = p.causal ? min(len, ib + 128) : len;
+    const int T = p.T;                                        // queries per batch
+    const int Tk = p.Tk > 0 ? p.Tk : p.T;                     // keys per batch (cross-attention / KV cache: Tk != T)
+    const int coff = Tk - T;                                  // causal: query i sees keys <= i + coff
+    const int len = p.lengths ? min(p.lengths[b], Tk) : Tk;
+    const int kend = p.causal ? min(len, ib + 128 + coff) : len;
     const int nkt = (kend + 31) / 32;
-    const int rb0 = T - 1 - ib - 31;                          // band base of wave 0 at step 0
+    const int rb0 = T - 1 - ib - 31;                          // band base of wave 0 at step 0 (REL needs Tk == T)
 
     // ---- DMA issue helpers (this wave's PPW pieces of a 32-row tile)
     const int prow = lane / NCH, pc = lane % NCH;
@@ -229,8 +233,8 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
         }
     };
     auto issue_step = [&](int it) {
-        issue_rows(p.k + (long)b * T * p.ldk, p.ldk, 32 * it, T - 1, sK + (it & 1) * TILEB);
-        issue_rows(p.vt + (long)b * T * p.ldvt, p.ldvt, 32 * it, T - 1, sV + (it & 1) * TILEB);     // p.vt = V [key][hd] here
+        issue_rows(p.k + (p.kv_bstride ? (long)b * p.kv_bstride : (long)b * Tk * p.ldk), p.ldk, 32 * it, Tk - 1, sK + (it & 1) * TILEB);
+        issue_rows(p.vt + (p.kv_bstride ? (long)b * p.kv_bstride : (long)b * Tk * p.ldvt), p.ldvt, 32 * it, Tk - 1, sV + (it & 1) * TILEB);   // p.vt = V [key][hd]
         if (REL) issue_rows(p.pos, p.ldp, rb0 + 32 * it + 32, 2 * T - 2, sP + ((it + PRING * 4) % PRING) * TILEB);
     };
 
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int jj = j0 + crow(e, h2);
-            const bool dead = (jj >= len) || (p.causal && jj > i0 + r);
+            const bool dead = (jj >= len) || (p.causal && jj > i0 + r + coff);
             S[e] = dead ? -INFINITY : S[e] * p.scale;
             mx = fmaxf(mx, S[e]);
         }
@@ -439,15 +443,16 @@ extern "C" int mi_attention_bf16(const void* q, long ldq, const void* k, long ld
 // LDS-staged form: q, k, v are all (B*T, ld) bf16 row-major (columns of one fused QKV projection); hd in {64, 128}.
 extern "C" int mi_attention_qkv_bf16(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                                      const void* pos, long ldp, const float* bias_u, const float* bias_v,
-                                     const int* lengths, void* out, long ldo, int B, int T, int H, int hd,
+                                     const int* lengths, void* out, long ldo, int B, int T, int Tk, long kv_bstride, int H, int hd,
                                      float scale, int causal, hipStream_t stream) {
     MI_ENTER();
-    if (B <= 0 || T <= 0 || H <= 0) return MI_ERR_ARG;
+    if (B <= 0 || T <= 0 || H <= 0 || Tk < 0) return MI_ERR_ARG;
+    if (pos && Tk != 0 && Tk != T) return MI_ERR_ARG;                    // the relative term needs a square score matrix
     if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 4)) return MI_ERR_ARG;
-    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return MI_ERR_ARG;
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) || (kv_bstride % 8)) return MI_ERR_ARG;
     if (pos && ((ldp % 8) || ((uintptr_t)pos & 15) || !bias_u || !bias_v)) return MI_ERR_ARG;
     AttnArgs a{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, 0, (const bf16_t*)pos, ldp,
-               bias_u, bias_v, lengths, (bf16_t*)out, ldo, B, T, H, scale, causal};
+               bias_u, bias_v, lengths, (bf16_t*)out, ldo, B, T, H, scale, causal, Tk, kv_bstride};
     const bool rel = pos != nullptr;
     switch (hd) {
         case 64: return launch_lds<64>(a, rel, stream);

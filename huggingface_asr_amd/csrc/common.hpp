@@ -51,6 +51,13 @@ __device__ __forceinline__ float fast_erf(float x) {
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 
+// GPT-2's "gelu_new" (tanh form; transformers activations.NewGELUActivation), used by the decoder MLP
+__device__ __forceinline__ float gelu_tanh(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    const float e = __expf(2.f * u);                       // tanh(u) = 1 - 2/(e^{2u}+1), safe at both ends
+    return 0.5f * x * (2.f - 2.f / (e + 1.f));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

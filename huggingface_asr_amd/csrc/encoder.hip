@@ -228,7 +228,7 @@ extern "C" int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weigh
             RUN(mi_attention_qkv_bf16(w.qk, 3 * d, w.qk + d, 3 * d, w.qk + 2 * d, 3 * d,
                                       c.pos_type == 1 ? (const bf16_t*)posp + (size_t)l * P * d : nullptr, d,
                                       c.pos_type == 1 ? Lf(l, ATT_U) : nullptr, c.pos_type == 1 ? Lf(l, ATT_V) : nullptr,
-                                      mask_len, w.ctx, d, c.B, T2, c.H, D.hd, scale, c.is_causal, st));
+                                      mask_len, w.ctx, d, c.B, T2, 0, 0, c.H, D.hd, scale, c.is_causal, st));
         } else {
             RUN(mi_gemm_bf16(qk_in, d, Lw(l, ATT_WQK), d, Lf(l, ATT_BQK), 1, w.qk, 3 * d, 0, nullptr, 0, 1.f, 0, M, 2 * d, d, 0, 0, st));
             // V^T = Wv · a1^T (+ bv per row), columns remapped to the time-padded (b*Tp + t) layout

@@ -161,6 +161,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs p) {
                 float v = acc[i][j][r] + bcol;
                 if (p.bias_mode == 2) v += p.bias[m];
                 if (p.act == 1) v = gelu_erf(v);
+                else if (p.act == 2) v = gelu_tanh(v);
                 if (p.resid) v = p.resid[(long)m * p.ldr + n] + p.alpha * v;
                 if (p.out_f32) reinterpret_cast<float*>(p.C)[(long)m * p.ldc + nc] = v;
                 else reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + nc] = f2bf(v);

@@ -215,6 +215,7 @@ __global__ __launch_bounds__(CWM * CWN * 64, (TBM == 128 && TBN == 128 && STAGES
                 v[g4] += bcol[SMALL ? j : 0][g4];
                 v[g4] += brow;
                 if (p.act == 1) v[g4] = f32x4{gelu_erf(v[g4].x), gelu_erf(v[g4].y), gelu_erf(v[g4].z), gelu_erf(v[g4].w)};
+                else if (p.act == 2) v[g4] = f32x4{gelu_tanh(v[g4].x), gelu_tanh(v[g4].y), gelu_tanh(v[g4].z), gelu_tanh(v[g4].w)};
                 if (use_res) v[g4] = rcur[g4] + p.alpha * v[g4];
             }
             if (p.out_f32) {
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(CWM * CWN * 64, (TBM == 128 && TBN == 128 && STAGES
                 const long nc = p.col_T ? (long)(n / p.col_T) * p.col_Tp + (n % p.col_T) : n;
                 float vv = acc[i][j][e] + ((p.bias_mode == 1) ? p.bias[n] : brow);
                 if (p.act == 1) vv = gelu_erf(vv);
+                    else if (p.act == 2) vv = gelu_tanh(vv);
                 if (p.resid) vv = p.resid[(long)m * p.ldr + n] + p.alpha * vv;
                 if (p.out_f32) reinterpret_cast<float*>(p.C)[(long)m * p.ldc + nc] = vv;
                 else reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + nc] = f2bf(vv);

@@ -125,7 +125,27 @@ __global__ __launch_bounds__(256) void rotary_kernel(const bf16_t* __restrict__ 
     }
 }
 
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ out, long ldo, int M, int d) {
+    const int d4 = d >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)M * d4; i += (long)gridDim.x * 256) {
+        const long m = i / d4; const int c = (int)(i % d4);
+        const f32x4 v = reinterpret_cast<const f32x4*>(x + m * ldx)[c];
+        reinterpret_cast<bf16x4*>(out + m * ldo)[c] = bf16x4{f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+    }
+}
+
 }  // namespace
+
+// fp32 (M,d) -> bf16 (M,d) round-to-nearest-even (GEMM A operands made from fp32 states: encoder output -> decoder)
+extern "C" int mi_cast_f32_bf16(const float* x, long ldx, void* out, long ldo, int M, int d, hipStream_t stream) {
+    MI_ENTER();
+    if (M <= 0 || d <= 0 || (d % 4) || (ldx % 4) || (ldo % 4)) return MI_ERR_ARG;
+    const long total = (long)M * (d / 4);
+    hipLaunchKernelGGL(cast_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, stream,
+                       x, ldx, (bf16_t*)out, ldo, M, d);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
 
 extern "C" int mi_rotary_bf16(const void* x, long ldx, void* out, long ldo, const float* cos_t, const float* sin_t,
                               int M, int T, int H, int hd, hipStream_t stream) {

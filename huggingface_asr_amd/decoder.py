@@ -1,0 +1,212 @@
+"""GPT-2 cross-attention decoder + joint CTC/attention forward on the HIP kernels.
+
+Host-side orchestration (one C-ABI call per op) of
+  * reference `src/models/decoders/multi_head_gpt2.py:80-170` (GPT2LMMultiHeadModel: auxiliary lm heads on intermediate
+    hidden states, shifted label-smoothed CE),
+  * the transformers GPT-2 block it inherits (ln_1 -> causal self-attn -> ln_cross_attn -> cross-attn over the encoder
+    frames -> ln_2 -> gelu_new MLP; Conv1D weights are stored (in, out) and are transposed once at pack time),
+  * reference `src/models/embeddings.py` (fixed sinusoidal positions + sqrt(d)-scaled embedding when `pos_emb_fixed`),
+  * reference `src/models/ctc_encoder_plus_autoregressive_decoder.py:237-358` (JointAED: encoder CTC loss, enc_to_dec_proj,
+    cross mask from the OUTER length formula, shift_tokens_right, loss = w*CTC + (1-w)*CE).
+Eval-mode semantics; the fp32 residual stream / bf16 GEMM operands precision model is the encoder's.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .engine import EBranchformerEngine
+
+BF16 = torch.bfloat16
+
+
+class GPT2DecoderEngine:
+    def __init__(self, cfg: dict, device="cuda:0"):
+        self.cfg = dict(cfg)
+        self.device = torch.device(device)
+        d, H = cfg["n_embd"], cfg["n_head"]
+        if d // H not in (64, 128):
+            raise NotImplementedError("HIP decoder attention supports head sizes 64 and 128 (the reference's GPT-2 configs use 64)")
+        if cfg.get("activation_function", "gelu_new") != "gelu_new":
+            raise NotImplementedError("decoder MLP activation other than gelu_new")
+        self.w = None
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd: dict, prefix: str = "decoder."):
+        c, dev = self.cfg, self.device
+        d, L = c["n_embd"], c["n_layer"]
+        f32 = lambda t: t.detach().to(dev, torch.float32).contiguous()
+        lin = lambda t: t.detach().to(dev, torch.float32).t().to(BF16).contiguous()      # Conv1D (in,out) -> (out,in) bf16
+        w = {"layers": []}
+        if c.get("pos_emb_fixed", False):
+            w["wte"] = f32(sd[prefix + "transformer.wte.emb_layers.0.weight"])
+            w["scale"] = float(d) ** 0.5
+            n = c.get("n_positions", 1024)
+            inv = 1 / (10000 ** (torch.arange(0.0, d, 2.0) / d))
+            s = torch.outer(torch.arange(n).float(), inv)
+            w["pos"] = torch.cat([s.sin(), s.cos()], -1).to(dev).contiguous()
+        else:
+            w["wte"] = f32(sd[prefix + "transformer.wte.weight"])
+            w["scale"] = 1.0
+            w["pos"] = f32(sd[prefix + "transformer.wpe.weight"])
+        for l in range(L):
+            p = f"{prefix}transformer.h.{l}."
+            g = lambda n: f32(sd[p + n])
+            w["layers"].append(dict(
+                ln1=(g("ln_1.weight"), g("ln_1.bias")), wqkv=lin(sd[p + "attn.c_attn.weight"]), bqkv=g("attn.c_attn.bias"),
+                wo=lin(sd[p + "attn.c_proj.weight"]), bo=g("attn.c_proj.bias"),
+                lnc=(g("ln_cross_attn.weight"), g("ln_cross_attn.bias")),
+                wq=lin(sd[p + "crossattention.q_attn.weight"]), bq=g("crossattention.q_attn.bias"),
+                wkv=lin(sd[p + "crossattention.c_attn.weight"]), bkv=g("crossattention.c_attn.bias"),
+                wco=lin(sd[p + "crossattention.c_proj.weight"]), bco=g("crossattention.c_proj.bias"),
+                ln2=(g("ln_2.weight"), g("ln_2.bias")), wfc=lin(sd[p + "mlp.c_fc.weight"]), bfc=g("mlp.c_fc.bias"),
+                wpr=lin(sd[p + "mlp.c_proj.weight"]), bpr=g("mlp.c_proj.bias")))
+        w["lnf"] = (f32(sd[prefix + "transformer.ln_f.weight"]), f32(sd[prefix + "transformer.ln_f.bias"]))
+        w["heads"] = [sd[f"{prefix}additional_lm_heads.{k}.weight"].detach().to(dev, torch.float32).to(BF16).contiguous()
+                      for k in range(len(c.get("head_locations") or []))]
+        w["lm_head"] = sd[prefix + "lm_head.weight"].detach().to(dev, torch.float32).to(BF16).contiguous()
+        self.w = w
+
+    # ------------------------------------------------------------------ building blocks
+    def cross_kv(self, enc_bf16: torch.Tensor):
+        """Per-layer cross-attention keys/values of the encoder frames: list of (B*T', 2d) bf16 (computed once per utterance)."""
+        return [ops.gemm(enc_bf16, lw["wkv"], lw["bkv"]) for lw in self.w["layers"]]
+
+    def _logits(self, hid_bf16, head_w):
+        V = head_w.shape[0]
+        Vp = (V + 7) // 8 * 8
+        buf = torch.empty((hid_bf16.shape[0], Vp), device=self.device, dtype=torch.float32)
+        ops.gemm(hid_bf16, head_w, None, out=buf[:, :V])
+        return buf[:, :V]
+
+    def _block(self, l, x, B, U, kv, T_enc, enc_len, self_k=None, self_v=None, past=0, Lmax=0):
+        """One GPT-2 block on the fp32 stream x (B*U, d).  With a KV cache (self_k/self_v (B, Lmax, d)) U new tokens are
+        appended at position `past` and attend to past+U keys."""
+        c, lw = self.cfg, self.w["layers"][l]
+        d, H, eps = c["n_embd"], c["n_head"], c.get("layer_norm_epsilon", 1e-5)
+        M = x.shape[0]
+        a = torch.empty((M, d), device=self.device, dtype=BF16)
+        ops.layernorm_chain(x, lna=lw["ln1"], eps2=eps, outa=a)
+        qkv = ops.gemm(a, lw["wqkv"], lw["bqkv"])
+        if self_k is None:
+            ctx = ops.attention_general(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, U, U, H, causal=True)
+        else:
+            self_k[:, past:past + U] = qkv[:, d:2 * d].reshape(B, U, d)
+            self_v[:, past:past + U] = qkv[:, 2 * d:].reshape(B, U, d)
+            ctx = ops.attention_general(qkv[:, :d], self_k.view(B * Lmax, d), self_v.view(B * Lmax, d), B, U, past + U, H,
+                                        causal=True, kv_bstride=Lmax * d)
+        ops.gemm(ctx, lw["wo"], lw["bo"], out=x, resid=x, alpha=1.0)
+        ops.layernorm_chain(x, lna=lw["lnc"], eps2=eps, outa=a)
+        qq = ops.gemm(a, lw["wq"], lw["bq"])
+        ctx = ops.attention_general(qq, kv[:, :d], kv[:, d:], B, U, T_enc, H, lengths=enc_len)
+        ops.gemm(ctx, lw["wco"], lw["bco"], out=x, resid=x, alpha=1.0)
+        ops.layernorm_chain(x, lna=lw["ln2"], eps2=eps, outa=a)
+        m = ops.gemm(a, lw["wfc"], lw["bfc"], act="gelu_new")
+        ops.gemm(m, lw["wpr"], lw["bpr"], out=x, resid=x, alpha=1.0)
+        return x
+
+    # ------------------------------------------------------------------ teacher-forced forward
+    def forward(self, ids: torch.Tensor, enc_bf16: torch.Tensor, T_enc: int, enc_len, labels=None):
+        """ids (B,U) int64; enc_bf16 (B*T', d) bf16 (already projected to the decoder width); enc_len (B) int32 valid frames
+        or None.  Returns dict(logits (B,U,V) fp32, loss | None) = GPT2LMMultiHeadModel.forward."""
+        c, w = self.cfg, self.w
+        B, U = ids.shape
+        d, L, eps = c["n_embd"], c["n_layer"], c.get("layer_norm_epsilon", 1e-5)
+        x = ops.embed_tokens(ids, w["wte"], w["pos"], scale=w["scale"])
+        kvs = self.cross_kv(enc_bf16)
+        locs = list(c.get("head_locations") or [])
+        taps = {}
+        if 0 in locs:
+            taps[0] = x.clone()
+        for l in range(L):
+            x = self._block(l, x, B, U, kvs[l], T_enc, enc_len)
+            if (l + 1) in locs and l + 1 < L:
+                taps[l + 1] = x.clone()
+        hid = torch.empty((B * U, d), device=self.device, dtype=BF16)
+        ops.layernorm_chain(x, lna=w["lnf"], eps2=eps, outa=hid)
+        logits = self._logits(hid, w["lm_head"]).view(B, U, -1)
+        loss = None
+        if labels is not None:
+            weights = list(c.get("head_weights") or [1.0])
+            loss = weights[-1] * ops.ce_label_smoothing(logits, labels, shift=1, eps=c.get("lsm_factor", 0.0))
+            for k, loc in enumerate(locs):
+                hb = ops.cast_bf16(taps[loc]) if loc in taps else hid
+                lg = self._logits(hb, w["heads"][k]).view(B, U, -1)
+                loss = loss + weights[k] * ops.ce_label_smoothing(lg, labels, shift=1, eps=c.get("lsm_factor", 0.0))
+        return dict(logits=logits, loss=loss)
+
+    # ------------------------------------------------------------------ incremental decoding
+    def init_cache(self, B: int, Lmax: int):
+        d, L = self.cfg["n_embd"], self.cfg["n_layer"]
+        z = lambda: torch.zeros((B, Lmax, d), device=self.device, dtype=BF16)
+        return dict(k=[z() for _ in range(L)], v=[z() for _ in range(L)], past=0, Lmax=Lmax)
+
+    def reorder_cache(self, cache, beam_idx: torch.Tensor):
+        for l in range(len(cache["k"])):
+            cache["k"][l] = cache["k"][l].index_select(0, beam_idx)
+            cache["v"][l] = cache["v"][l].index_select(0, beam_idx)
+
+    def step(self, ids_new: torch.Tensor, cache, kvs, T_enc: int, enc_len):
+        """ids_new (B, U_new) -> logits (B, V) of the LAST new position; appends to the KV cache."""
+        c, w = self.cfg, self.w
+        B, U = ids_new.shape
+        d, L, eps = c["n_embd"], c["n_layer"], c.get("layer_norm_epsilon", 1e-5)
+        past, Lmax = cache["past"], cache["Lmax"]
+        x = ops.embed_tokens(ids_new, w["wte"], w["pos"], scale=w["scale"], pos_offset=past)
+        for l in range(L):
+            x = self._block(l, x, B, U, kvs[l], T_enc, enc_len, cache["k"][l], cache["v"][l], past, Lmax)
+        cache["past"] = past + U
+        last = x.view(B, U, d)[:, -1].contiguous()
+        hid = torch.empty((B, d), device=self.device, dtype=BF16)
+        ops.layernorm_chain(last, lna=w["lnf"], eps2=eps, outa=hid)
+        return self._logits(hid, w["lm_head"])
+
+
+def shift_tokens_right(labels: torch.Tensor, pad_id: int, start_id: int) -> torch.Tensor:
+    out = labels.new_zeros(labels.shape)
+    out[:, 1:] = labels[:, :-1]
+    out[:, 0] = start_id
+    return out.masked_fill(out == -100, pad_id)
+
+
+class JointAEDEngine:
+    """JointCTCAttentionEncoderDecoder.forward (eval) on the HIP path."""
+
+    def __init__(self, enc_cfg: dict, dec_cfg: dict, joint_cfg: dict, device="cuda:0"):
+        self.enc = EBranchformerEngine(enc_cfg, device)
+        self.dec = GPT2DecoderEngine(dec_cfg, device)
+        self.jcfg = dict(joint_cfg)
+        self.device = torch.device(device)
+        self.proj = None
+
+    def load_state_dict(self, sd: dict):
+        self.enc.load_state_dict({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")})
+        self.dec.load_state_dict(sd, "decoder.")
+        if "enc_to_dec_proj.weight" in sd:
+            self.proj = (sd["enc_to_dec_proj.weight"].detach().to(self.device, torch.float32).to(BF16).contiguous(),
+                         sd["enc_to_dec_proj.bias"].detach().to(self.device, torch.float32).contiguous())
+
+    def encode(self, feats, feat_len):
+        """-> (encoder out dict, encoder states for the decoder (B*T', d_dec) bf16, T', cross-attention key lengths)."""
+        out = self.enc.forward(feats, feat_len, want_hidden=True)
+        B, T2, d = out["last_hidden"].shape
+        hid = out["last_hidden"].reshape(B * T2, d)
+        if self.proj is not None:
+            enc_bf = ops.gemm(ops.cast_bf16(hid), self.proj[0], self.proj[1])       # ctc_encoder_plus...:289-293
+        else:
+            enc_bf = ops.cast_bf16(hid)
+        # cross mask uses the OUTER (un-padded) length formula, quirk 8' (:296-301); no attention_mask -> all frames
+        key_len = torch.clamp(out["outer_len"], max=T2) if feat_len is not None else None
+        return out, enc_bf, T2, key_len
+
+    def forward(self, feats, feat_len, labels):
+        c = self.jcfg
+        enc_out, enc_bf, T2, key_len = self.encode(feats, feat_len)
+        enc_loss, _, _ = ops.ctc_loss(enc_out["logits"], labels, enc_out["outer_len"],
+                                      reduction=self.enc.cfg.get("ctc_loss_reduction", "mean"),
+                                      zero_infinity=self.enc.cfg.get("ctc_zero_infinity", False))
+        dec_ids = shift_tokens_right(labels, c["pad_token_id"], c["decoder_start_token_id"])
+        d = self.dec.forward(dec_ids, enc_bf, T2, key_len, labels)
+        w = c["ctc_weight"]
+        return dict(loss=w * enc_loss + (1 - w) * d["loss"], enc_loss=enc_loss, dec_loss=d["loss"], logits=d["logits"],
+                    encoder_logits=enc_out["logits"], encoder_hidden=enc_bf)

@@ -43,7 +43,7 @@ def gemm(a, w, bias=None, out=None, *, out_dtype=BF16, act="none", resid=None, a
                                  (2 if bias_per_row else 1) if bias is not None else 0,
                                  out.data_ptr(), out.stride(0), int(out.dtype == torch.float32),
                                  _p(resid), resid.stride(0) if resid is not None else 0, float(alpha),
-                                 {"none": 0, "gelu": 1}[act], M, N, K, ct, ctp, _stream())
+                                 {"none": 0, "gelu": 1, "gelu_new": 2}[act], M, N, K, ct, ctp, _stream())
     _lib.check(rc, "mi_gemm_bf16")
     return out
 
@@ -119,7 +119,21 @@ def attention_qkv(qkv, B, T, H, *, pos=None, bias_u=None, bias_v=None, lengths=N
     q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
     rc = _lib.lib().mi_attention_qkv_bf16(q.data_ptr(), qkv.stride(0), k.data_ptr(), qkv.stride(0), v.data_ptr(), qkv.stride(0),
                                           _p(pos), pos.stride(0) if pos is not None else 0, _p(bias_u), _p(bias_v), _p(lengths),
-                                          out.data_ptr(), out.stride(0), B, T, H, hd, 1.0 / math.sqrt(hd), int(causal), _stream())
+                                          out.data_ptr(), out.stride(0), B, T, 0, 0, H, hd, 1.0 / math.sqrt(hd), int(causal), _stream())
+    _lib.check(rc, "mi_attention_qkv_bf16")
+    return out
+
+
+def attention_general(q, k, v, B, Tq, Tk, H, *, lengths=None, causal=False, out=None, kv_bstride=0):
+    """q (B*Tq, .) / k, v (B*Tk, .) bf16 row views with head h at columns [h*hd, (h+1)*hd) -> context (B*Tq, d) bf16.
+    Cross-attention (Tk = encoder frames, `lengths` = valid keys) and KV-cache steps (causal offset Tk - Tq)."""
+    d = q.shape[1]
+    hd = d // H
+    if out is None:
+        out = torch.empty((B * Tq, d), device=q.device, dtype=BF16)
+    rc = _lib.lib().mi_attention_qkv_bf16(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+                                          0, 0, 0, 0, _p(lengths), out.data_ptr(), out.stride(0), B, Tq, Tk, kv_bstride, H, hd,
+                                          1.0 / math.sqrt(hd), int(causal), _stream())
     _lib.check(rc, "mi_attention_qkv_bf16")
     return out
 
@@ -184,3 +198,34 @@ def ctc_loss(logits, labels, in_len, *, reduction="mean", zero_infinity=False, l
         out = torch.where(torch.isinf(nll), torch.zeros_like(nll), nll) if zero_infinity else nll
         return out, nll, tl
     return loss[0], nll, tl
+
+
+def embed_tokens(ids, wte, pos, *, scale=1.0, pos_offset=0, U=None):
+    """ids (B,U) int64 -> (B*U, d) fp32 = wte[ids]*scale + pos[pos_offset + u]."""
+    ids = ids.contiguous()
+    M = ids.numel()
+    U = ids.shape[-1] if U is None else U
+    V, d = wte.shape
+    out = torch.empty((M, d), device=ids.device, dtype=torch.float32)
+    rc = _lib.lib().mi_embed_tokens(ids.data_ptr(), wte.data_ptr(), float(scale), pos.data_ptr(), pos_offset, U, d, M, V, out.data_ptr(), _stream())
+    _lib.check(rc, "mi_embed_tokens")
+    return out
+
+
+def ce_label_smoothing(logits, labels, *, shift=1, eps=0.0):
+    """mean over valid targets of the label-smoothed CE of logits[b,u] vs labels[b,u+shift] (ignore < 0). logits (B,U,V) fp32."""
+    B, U, V = logits.shape
+    labels = labels.contiguous()
+    acc = torch.zeros((2,), device=logits.device, dtype=torch.float32)
+    rc = _lib.lib().mi_ce_label_smoothing(logits.data_ptr(), logits.stride(1), labels.data_ptr(), B, U, shift, V, float(eps), acc.data_ptr(), _stream())
+    _lib.check(rc, "mi_ce_label_smoothing")
+    return acc[0] / acc[1]
+
+
+def cast_bf16(x):
+    """(M,d) fp32 -> bf16 (round to nearest even) on the HIP path."""
+    M, d = x.shape
+    out = torch.empty((M, d), device=x.device, dtype=BF16)
+    rc = _lib.lib().mi_cast_f32_bf16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), M, d, _stream())
+    _lib.check(rc, "mi_cast_f32_bf16")
+    return out

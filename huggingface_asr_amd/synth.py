@@ -50,7 +50,8 @@ def init_param(seed: int, name: str, shape) -> np.ndarray:
     depthwise conv taps +-1/sqrt(k), positional biases +-0.1.
     """
     leaf = name.rsplit(".", 1)[-1]
-    is_norm = ("layer_norm" in name) or (".norm." in name) or name.endswith((".ff1.0.weight", ".ff1.0.bias", ".ff2.0.weight", ".ff2.0.bias"))
+    is_norm = ("layer_norm" in name) or (".norm." in name) or (".ln_" in name) or \
+        name.endswith((".ff1.0.weight", ".ff1.0.bias", ".ff2.0.weight", ".ff2.0.bias"))
     if is_norm:
         if leaf == "weight":
             return 1.0 + uniform(seed, name, shape, -0.1, 0.1)

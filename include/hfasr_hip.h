@@ -68,6 +68,9 @@ int mi_layernorm_chain(const float* x, long ldx, const int* lengths, int T,
                        const float* gb, const float* bb, void* outb_bf16, long ldb,
                        int M, int d, mi_stream_t stream);
 
+/* ---- fp32 -> bf16 cast of a (M,d) state (A operand of a following GEMM). */
+int mi_cast_f32_bf16(const float* x, long ldx, void* out, long ldo, int M, int d, mi_stream_t stream);
+
 /* ---- rotary embedding of the Q/K projection input. replaces: wav2vec2_conformer _apply_rotary_embedding (:509-526). */
 int mi_rotary_bf16(const void* x, long ldx, void* out, long ldo, const float* cos_t, const float* sin_t,
                    int M, int T, int H, int hd, mi_stream_t stream);
@@ -84,8 +87,10 @@ int mi_attention_bf16(const void* q, long ldq, const void* k, long ldk, const vo
  * no transposed V copy; the position rows / K / V tiles are shared by the 4 waves of a 128-query block. */
 int mi_attention_qkv_bf16(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                           const void* pos, long ldp, const float* bias_u, const float* bias_v,
-                          const int* lengths, void* out, long ldo, int B, int T, int H, int hd,
+                          const int* lengths, void* out, long ldo, int B, int T, int Tk, long kv_bstride, int H, int hd,
                           float scale, int causal, mi_stream_t stream);
+/* (kv_bstride = elements between batches of k/v, 0 = Tk*ld (KV caches are (B, Lmax, d)); T = queries per batch, Tk = keys per batch, 0 = T: cross-attention over encoder frames and KV-cache decoding use Tk != T;
+ *  with causal != 0 query i sees keys <= i + (Tk - T).) */
 
 /* ---- cgMLP gate: per-row LN statistics + fused LN -> depthwise conv(time) -> gate.
  * replaces: ConvolutionalSpatialGatingUnit.forward e_branchformer.py:184-204. */
@@ -123,6 +128,14 @@ int mi_ctc_prefix_score(const float* x, int B, int T, int O, int blank, int W, c
 int mi_ctc_prefix_select(const float* x, int B, int T, int O, int blank, int W, const float* r_prev, const long* last_ids,
                          long ld_last, int out_len, const int* hyp, const long* tok, long ld_tok, int K, float* r_out,
                          mi_stream_t stream);
+
+/* ---- GPT-2 cross-attention decoder helpers (the rest of the decoder runs on the shared LN / GEMM / attention entry points).
+ * replaces: GPT2Model embeddings (wte + wpe) and the fixed-position variant src/models/embeddings.py:33-86;
+ *           the shifted, label-smoothed CE of src/models/decoders/multi_head_gpt2.py:138-158. */
+int mi_embed_tokens(const long* ids, const float* wte, float scale, const float* pos, int pos_offset, int U, int d,
+                    int M, int V, float* out, mi_stream_t stream);
+int mi_ce_label_smoothing(const float* logits, long ld, const long* labels, int B, int U, int shift, int V, float eps,
+                          float* acc, mi_stream_t stream);
 
 /* ---- whole encoder + CTC head: Wav2Vec2EBranchformerForCTC.forward (e_branchformer.py:422-496), eval mode. */
 typedef struct {

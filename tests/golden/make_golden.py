@@ -50,7 +50,7 @@ def load_seeded(model, seed):
     # parameters only: buffers (e.g. the rotary `embed_positions.inv_freq`) keep their computed values
     new = {k: torch.from_numpy(synth.init_param(seed, k, tuple(v.shape))) for k, v in model.named_parameters()}
     missing, unexpected = model.load_state_dict(new, strict=False)
-    assert not unexpected and all("inv_freq" in m for m in missing), (missing, unexpected)
+    assert not unexpected and all(("inv_freq" in m or ".attn.bias" in m or "masked_bias" in m) for m in missing), (missing, unexpected)
     return float(sum(v.double().sum() for v in new.values()))
 
 
@@ -180,6 +180,80 @@ def run_ctc_known_answers():
     np.savez_compressed(os.path.join(HERE, "ctc_known.npz"), **rec)
 
 
+TINY_DEC = dict(vocab_size=51, n_embd=128, n_layer=3, n_head=2, n_positions=64, head_locations=[1], head_weights=[0.4, 0.6])
+
+
+def build_reference_aed(pos_emb_fixed=False):
+    from utilities.bind import bind_all
+    bind_all()
+    from models.ctc_encoder_plus_autoregressive_decoder import JointCTCAttentionEncoderDecoder, JointCTCAttentionEncoderDecoderConfig
+    from models.decoders.multi_head_gpt2 import GPT2LMMultiHeadModel, GPT2MultiHeadConfig
+    from models.embeddings import AdaptiveEmbedding, PositionalEmbedding
+    from transformers.models.gpt2.modeling_gpt2 import GPT2LMHeadModel
+
+    class Dec(GPT2LMMultiHeadModel):          # shim (4) of SURVEY.md §8c
+        model_parallel = False
+
+        def tie_weights(self, *a, **k):
+            return GPT2LMHeadModel.tie_weights(self, *a, **k)
+
+    ecfg, enc = build_reference(TINY)
+    dcfg = GPT2MultiHeadConfig(**TINY_DEC, add_cross_attention=True, attn_implementation="eager", bos_token_id=2, eos_token_id=1,
+                               pad_token_id=50, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0, tie_word_embeddings=False)
+    dcfg.lsm_factor = 0.1
+    dcfg.cross_attention_hidden_size = None
+    dcfg.pos_emb_fixed = pos_emb_fixed
+    dec = Dec(dcfg)
+    if pos_emb_fixed:                         # what PositionalEncodingInitModifier does (auto_wrappers.py:186-209)
+        dec.transformer.wte = AdaptiveEmbedding(n_token=dcfg.vocab_size, d_embed=dcfg.hidden_size, d_proj=dcfg.hidden_size, cutoffs=[])
+        dec.transformer.wpe = PositionalEmbedding(demb=dcfg.hidden_size)
+    dec = dec.eval()
+    # shim (5): transformers 5.15's GPT2Model.forward DROPS `encoder_attention_mask` (it rebuilds the cross mask from None),
+    # whereas the pinned 4.39.3 applies invert_attention_mask(encoder_attention_mask) = (1 - mask) * finfo.min.  Restore the
+    # pinned behaviour harness-side: remember the mask given to the decoder and hand it to the block as the 4-D additive mask.
+    import transformers.models.gpt2.modeling_gpt2 as mg
+    holder = {}
+    orig_forward = dec.forward
+
+    def fwd(*a, **k):
+        holder["mask"] = k.get("encoder_attention_mask")
+        return orig_forward(*a, **k)
+
+    def bidir(config=None, inputs_embeds=None, attention_mask=None, encoder_hidden_states=None, **kw):
+        m = holder.get("mask")
+        if m is None:
+            return None
+        return (1.0 - m[:, None, None, :].to(inputs_embeds.dtype)) * torch.finfo(inputs_embeds.dtype).min
+
+    dec.forward = fwd
+    mg.create_bidirectional_mask = bidir
+    jcfg = JointCTCAttentionEncoderDecoderConfig.from_encoder_decoder_configs(ecfg, dcfg, ctc_weight=0.3, lsm_factor=0.1, pad_token_id=50,
+                                                                               decoder_start_token_id=2, shared_lm_head=False)
+    return JointCTCAttentionEncoderDecoder(config=jcfg, encoder=enc, decoder=dec).eval()
+
+
+def run_aed_cases():
+    for name, fixed, seed in (("aed_tiny", False, 31), ("aed_tiny_fixedpos", True, 32)):
+        try:
+            model = build_reference_aed(fixed)
+            wsum = load_seeded(model, seed)
+            B, T, U = 2, 200, 9
+            x, am = synth_feats(seed, B, T, [198, 150])
+            lab = synth_labels(seed, B, U, 50, [9, 6])
+            lab[lab >= 0] = np.maximum(lab[lab >= 0], 3)
+            with torch.no_grad():
+                out = model(input_values=torch.from_numpy(x), attention_mask=torch.from_numpy(am), labels=torch.from_numpy(lab))
+            rec = dict(seed=seed, weight_sum=wsum, lengths=np.array([198, 150]), shape=np.array([B, T, U]), labels=lab,
+                       loss=float(out.loss), enc_loss=float(out.enc_loss), dec_loss=float(out.dec_loss), logits=out.logits.numpy(),
+                       encoder_logits=out.encoder_logits.numpy(), encoder_hidden=out.encoder_last_hidden_state.numpy(),
+                       param_names=np.array([k for k, _ in model.named_parameters()]),
+                       param_shapes=np.array([str(tuple(v.shape)) for _, v in model.named_parameters()]))
+            np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
+            print(name, "loss", rec["loss"], rec["enc_loss"], rec["dec_loss"])
+        except Exception as e:      # noqa: BLE001
+            print(name, "FAILED in the reference under transformers 5.15:", type(e).__name__, str(e)[:200])
+
+
 def run_ctc_prefix_cases():
     """reference src/decoding/ctc_scorer.py: CTCRescorerLogitsProcessor over 4 decoding steps (B=2, W=3)."""
     from decoding.ctc_scorer import CTCPrefixScoreTH, CTCRescorerLogitsProcessor, LogSoftmaxProcessor
@@ -222,7 +296,7 @@ def run_ctc_prefix_cases():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "base", "fbank", "lengths", "ctc", "prefix"]
+    which = sys.argv[1:] or ["tiny", "base", "fbank", "lengths", "ctc", "prefix", "aed"]
     if "tiny" in which:
         run_encoder_case("tiny_rel", TINY, seed=11, B=2, T=200, lengths=[198, 150], U=7, tgt_lens=[7, 5])
         run_encoder_case("tiny_rotary", TINY, seed=12, B=2, T=200, lengths=[200, 131], U=6, tgt_lens=[6, 4],
@@ -244,3 +318,5 @@ if __name__ == "__main__":
         run_ctc_known_answers()
     if "prefix" in which:
         run_ctc_prefix_cases()
+    if "aed" in which:
+        run_aed_cases()

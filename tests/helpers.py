@@ -44,3 +44,20 @@ def case_inputs(g, cfg):
     x, am = synth_feats(seed, B, T, [int(v) for v in g["lengths"]])
     lab = synth_labels(seed, B, U, cfg["vocab_size"], [int(v) for v in g["tgt_lens"]])
     return sd, x, am, lab
+
+
+TINY_DEC = dict(vocab_size=51, n_embd=128, n_layer=3, n_head=2, n_positions=64, head_locations=[1], head_weights=[0.4, 0.6],
+                lsm_factor=0.1, layer_norm_epsilon=1e-5)
+AED_JCFG = dict(ctc_weight=0.3, pad_token_id=50, decoder_start_token_id=2)
+
+
+def aed_case_inputs(g):
+    """(state_dict, feats, attention_mask, labels) for a golden AED case: weights re-seeded from the stored names/shapes."""
+    import ast
+    seed = int(g["seed"])
+    sd = {str(n): torch.from_numpy(synth.init_param(seed, str(n), ast.literal_eval(str(s)))) for n, s in zip(g["param_names"], g["param_shapes"])}
+    wsum = float(sum(v.double().sum() for v in sd.values()))
+    assert abs(wsum - float(g["weight_sum"])) < 1e-6 * max(1.0, abs(wsum))
+    B, T, U = [int(v) for v in g["shape"]]
+    x, am = synth_feats(seed, B, T, [int(v) for v in g["lengths"]])
+    return sd, x, am, torch.from_numpy(g["labels"])

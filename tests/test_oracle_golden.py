@@ -125,3 +125,21 @@ def test_ctc_prefix_scorer_matches_reference(case):
             wo = g[f"{case}/step{step}/out"]
             ok = wo > -1e9
             np.testing.assert_allclose(out[ok], wo[ok], atol=2e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name,fixed", [("aed_tiny", False), ("aed_tiny_fixedpos", True)])
+def test_joint_aed_forward_matches_reference(name, fixed):
+    """oracle/aed_ref.py against JointCTCAttentionEncoderDecoder.forward of the reference (3 losses, both logits)."""
+    from helpers import AED_JCFG, TINY_DEC, aed_case_inputs
+    from oracle import aed_ref as A
+    g = load_golden(name)
+    sd, x, am, lab = aed_case_inputs(g)
+    enc_cfg = _cfg(shapes.TINY)
+    dec_cfg = dict(TINY_DEC, pos_emb_fixed=fixed)
+    with torch.no_grad():
+        out = A.joint_forward(sd, enc_cfg, dec_cfg, AED_JCFG, x, am, lab)
+    np.testing.assert_allclose(out["encoder_logits"].numpy(), g["encoder_logits"], atol=2e-4, rtol=0)
+    np.testing.assert_allclose(out["encoder_hidden"].numpy(), g["encoder_hidden"], atol=2e-4, rtol=0)
+    np.testing.assert_allclose(out["logits"].numpy(), g["logits"], atol=3e-4, rtol=0)
+    for k in ("loss", "enc_loss", "dec_loss"):
+        assert abs(float(out[k]) - float(g[k])) < 1e-4 * abs(float(g[k])), k
