@@ -210,3 +210,88 @@ class JointAEDEngine:
         w = c["ctc_weight"]
         return dict(loss=w * enc_loss + (1 - w) * d["loss"], enc_loss=enc_loss, dec_loss=d["loss"], logits=d["logits"],
                     encoder_logits=enc_out["logits"], encoder_hidden=enc_bf)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Joint CTC/attention decoding (config 5 of BASELINE.json): greedy (W = 1) and beam search with the device-side CTC
+# prefix scorer.  Mirrors what the reference obtains from GenerationMixin.generate + its logits processors
+# (ctc_encoder_plus_autoregressive_decoder.py:360-482, hf_shared_models/ED_small.py:20-22: ctc_weight 0.3, num_beams 5):
+# scores = log_softmax(decoder logits) -> pad masked -> (1-w)*att + w*ctc -> + beam score -> top 2W over W*V ->
+# finished hypotheses scored sum_logprob / len**length_penalty (HF BeamSearchScorer semantics, early_stopping=False).
+def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_length=64, ctc_weight=0.3, length_penalty=1.0,
+             eos_token_id=1, pad_token_id=None, start_token_id=None, space_token_id=-1):
+    from .decoding import CTCRescorerLogitsProcessor
+    dev = joint.device
+    c = joint.jcfg
+    pad = c["pad_token_id"] if pad_token_id is None else pad_token_id
+    start = c["decoder_start_token_id"] if start_token_id is None else start_token_id
+    W = num_beams
+    enc_out, enc_bf, T2, key_len = joint.encode(feats, feat_len)
+    B = feats.shape[0]
+    d = enc_bf.shape[1]
+    # every beam attends to its utterance's encoder frames
+    enc_rep = enc_bf.view(B, T2, d).repeat_interleave(W, 0).reshape(B * W * T2, d)
+    key_rep = key_len.repeat_interleave(W) if key_len is not None else None
+    kvs = joint.dec.cross_kv(enc_rep)
+    cache = joint.dec.init_cache(B * W, max_length + 1)
+    proc = None
+    if ctc_weight > 0:
+        lens = enc_out["outer_len"].clamp(max=T2)
+        proc = CTCRescorerLogitsProcessor(enc_out["logits"], lens, pad, eos_token_id, 0, ctc_weight, W, space_token_id, False, 1.0)
+    ids = torch.full((B * W, 1), start, dtype=torch.long, device=dev)
+    beam_scores = torch.zeros((B, W), device=dev)
+    beam_scores[:, 1:] = -1e9
+    beam_scores = beam_scores.view(-1)
+    finished = [[] for _ in range(B)]          # (score, tokens)
+    done = [False] * B
+    new_tok = ids
+    V = joint.dec.w["lm_head"].shape[0]
+    while ids.shape[1] < max_length and not all(done):
+        logits = joint.dec.step(new_tok, cache, kvs, T2, key_rep)                       # (B*W, V)
+        from . import ops as _ops
+        scores = logits - _ops.row_lse(logits.contiguous())[:, None]                     # log_softmax
+        if proc is not None:
+            scores = proc(ids, scores.clone())
+        else:
+            scores = scores.clone(); scores[:, pad] = -10000000000.0
+        cand = (scores + beam_scores[:, None]).view(B, W * V)
+        top_s, top_i = cand.topk(2 * W, dim=1)
+        top_s, top_i = top_s.cpu(), top_i.cpu()
+        cur_len = ids.shape[1]
+        nb_scores = torch.zeros((B, W)); nb_tok = torch.zeros((B, W), dtype=torch.long); nb_idx = torch.zeros((B, W), dtype=torch.long)
+        ids_cpu = ids.cpu()
+        for b in range(B):
+            if done[b]:
+                nb_scores[b] = 0; nb_tok[b] = pad; nb_idx[b] = b * W
+                continue
+            k = 0
+            for rank in range(2 * W):
+                s, idx = float(top_s[b, rank]), int(top_i[b, rank])
+                beam, tok = idx // V, idx % V
+                if tok == eos_token_id:
+                    if rank >= W:
+                        continue
+                    finished[b].append((s / (cur_len ** length_penalty), ids_cpu[b * W + beam].tolist() + [tok]))
+                else:
+                    nb_scores[b, k], nb_tok[b, k], nb_idx[b, k] = s, tok, b * W + beam
+                    k += 1
+                if k == W:
+                    break
+            if len(finished[b]) >= W:            # HF early_stopping=False heuristic: best running beam cannot beat the worst kept
+                worst = sorted(finished[b], key=lambda t: -t[0])[W - 1][0]
+                if float(top_s[b].max()) / (cur_len ** length_penalty) <= worst:
+                    done[b] = True
+        beam_idx = nb_idx.view(-1).to(dev)
+        new_tok = nb_tok.view(-1, 1).to(dev)
+        beam_scores = nb_scores.view(-1).to(dev)
+        ids = torch.cat([ids.index_select(0, beam_idx), new_tok], 1)
+        joint.dec.reorder_cache(cache, beam_idx)
+    ids_cpu, bs = ids.cpu(), beam_scores.cpu().view(B, W)
+    out = []
+    for b in range(B):
+        if not done[b]:
+            for k in range(W):
+                finished[b].append((float(bs[b, k]) / (ids_cpu.shape[1] ** length_penalty), ids_cpu[b * W + k].tolist()))
+        best = max(finished[b], key=lambda t: t[0])
+        out.append(dict(tokens=best[1], score=best[0]))
+    return out
