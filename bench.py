@@ -88,16 +88,14 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="process the per-GPU batch as S independent sub-batches on S HIP streams")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from huggingface_asr_amd import parallel as PL
+    world, rank, local = PL.env_world()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    PL.init("nccl", dev)                      # RCCL; no-op for one process
     dist = world > 1
     if dist:
         import torch.distributed as td
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", device_id=torch.device("cuda", local))
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
 
     cfg = dict(shapes.BASE, position_embeddings_type=args.pos, ctc_zero_infinity=True, ctc_loss_reduction="mean")
     sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()}
@@ -148,28 +146,18 @@ def main():
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         loss = step()
-    torch.cuda.synchronize()
-    if dist:
-        td.barrier()
-    torch.cuda.synchronize()
     # HIP events (recorded on the launch stream) bracket every 7th launch of the dense GEMM kernel inside the timed region:
     # 7 is coprime with the 10 GEMMs per layer, so every shape is sampled evenly; timing all 163 launches/step costs ~10 %.
     if use_events:
         L.mi_profile_reset(); L.mi_profile_enable(args.event_stride)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if dist:
-        td.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    state = {}
+
+    def one():
+        state["loss"] = step()
+    dt = PL.timed(one, args.steps, sync=torch.cuda.synchronize, device=dev)      # barrier + sync both sides, MAX over ranks
+    loss = state["loss"]
     if use_events:
         L.mi_profile_enable(0)
-    if dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        dt = float(t[0])
     loss_v = float(loss)
 
     roof = None

@@ -1,0 +1,50 @@
+"""CPU, world_size 2 over gloo: the N>1 plumbing bench.py uses (sharding, barrier-bracketed timing with MAX over ranks,
+loss averaging).  The forward path itself has no collective (replicas)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    import time
+
+    from huggingface_asr_amd import parallel as P
+    w, r, _ = P.init("gloo")
+    assert (w, r) == (world, rank)
+    lo, hi = P.shard_range(7, rank, world)
+    loss = torch.tensor(float(rank + 1))                  # stand-in for a per-rank batch-mean loss
+    mean = float(P.mean_over_ranks(loss))
+    dt = P.timed(lambda: time.sleep(0.01 * (rank + 1)), 3)  # rank 1 is slower: everyone must report ITS time
+    out[rank] = (lo, hi, mean, dt)
+    P.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_world2_sharding_timing_and_loss_mean():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    (lo0, hi0, m0, t0), (lo1, hi1, m1, t1) = out[0], out[1]
+    assert (lo0, hi0, lo1, hi1) == (0, 4, 4, 7)           # balanced, contiguous, covering
+    assert m0 == m1 == pytest.approx(1.5)
+    assert t0 == pytest.approx(t1, abs=1e-9) and t0 >= 0.06   # MAX over ranks: 3 x 20 ms of the slow rank
+
+
+def test_shard_range_properties():
+    from huggingface_asr_amd.parallel import shard_range
+    for n in (0, 1, 5, 32, 33):
+        for w in (1, 2, 3, 8):
+            cuts = [shard_range(n, r, w) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in cuts]
+            assert max(sizes) - min(sizes) <= 1
