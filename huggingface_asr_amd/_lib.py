@@ -46,6 +46,9 @@ SIGNATURES = {
     "mi_ctc_prefix_select": [vp, i32, i32, i32, i32, i32, vp, vp, i64, i32, vp, vp, i64, i32, vp, vp],
     "mi_embed_tokens": [vp, vp, f32, vp, i32, i32, i32, i32, i32, vp, vp],
     "mi_ce_label_smoothing": [vp, i64, vp, i32, i32, i32, i32, f32, vp, vp],
+    "mi_whisper_logmel": [vp, i64, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp],
+    "mi_transpose_cast_bct_btc": [vp, vp, i32, i32, i32, vp],
+    "mi_add_positions": [vp, vp, vp, i32, i32, i32, vp],
     "mi_ebf_workspace_bytes": [C.POINTER(EbfConfig)],
     "mi_ebf_forward": [C.POINTER(EbfConfig), vp, vp, vp, vp, vp, i32, vp, sz, vp, vp, vp, vp, vp],
 }

@@ -115,13 +115,16 @@ __global__ __launch_bounds__(CWM * CWN * 64, (TBM == 128 && TBN == 128 && STAGES
     const int krot = p.krot ? (int)((unsigned)(tm * 5 + tn * 3) % (unsigned)nk) : 0;
     auto ktile = [&](int t) { int v = t + krot; return v >= nk ? v - nk : v; };
 
-    issue(ktile(0), 0);
-    if (STAGES == 3 && nk > 1) issue(ktile(1), 1);
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < nk) issue(ktile(t), t);
 
     for (int kt = 0; kt < nk; ++kt) {
         const int stage = kt % STAGES;
-        // tile kt has landed for THIS wave's pieces once at most the younger tile's pieces are outstanding
-        if (STAGES == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        // tile kt has landed for THIS wave's pieces once at most the younger in-flight tiles' pieces are outstanding
+        const int younger = min(STAGES - 2, nk - 1 - kt);
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");    // every wave's pieces of tile kt landed; stage of tile kt-1 is free
         if (kt + STAGES - 1 < nk && !(p.dbg & 2)) issue(ktile(kt + STAGES - 1), (kt + STAGES - 1) % STAGES);
@@ -271,7 +274,7 @@ int g_krot = 0;   // measured: rotating the K loop start per block does not help
 
 }  // namespace
 
-extern "C" void mi_gemm_set_stages(int stages) { g_stages = (stages == 2) ? 2 : 3; }
+extern "C" void mi_gemm_set_stages(int stages) { g_stages = (stages >= 2 && stages <= 4) ? stages : 2; }
 extern "C" void mi_gemm_set_krot(int on) { g_krot = on; }
 extern "C" void mi_gemm_set_variant(int v) { g_variant = v; }
 extern "C" void mi_gemm_set_debug(int v) { g_dbg = v; }   // timing experiments only: 1 = no MFMA, 2 = no loads (wrong results)
@@ -300,8 +303,11 @@ int gemm_glds_launch(const GemmArgs& a_in, bool conv, hipStream_t stream) {
     }
     const int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
     const int stages = g_stages;
-    const size_t lds = (size_t)(stages == 2 ? 2 : 3) * STAGE_BYTES;       // >= 64 KiB: also holds the fp32 C tile
-    if (stages == 2) {
+    const size_t lds = (size_t)stages * STAGE_BYTES;
+    if (stages == 4) {
+        if (conv) hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, 4, true>), dim3(grid), dim3(NT), lds, stream, a);
+        else hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, 4, false>), dim3(grid), dim3(NT), lds, stream, a);
+    } else if (stages == 2) {
         if (conv) hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, 2, true>), dim3(grid), dim3(NT), lds, stream, a);
         else hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, 2, false>), dim3(grid), dim3(NT), lds, stream, a);
     } else {

@@ -63,14 +63,17 @@ def conv2d_first_gelu(x, w, bias, stride=2, pad=1, causal=False):
 
 
 def conv2d_cl(x, w, bias, K=3, stride=2, pad=1, causal=False, act="gelu"):
-    """x (B,T,F,Cin) bf16 channels-last, w (Cout, K*K*Cin) bf16 -> (B,T',F',Cout) bf16."""
+    """x (B,T,F,Cin) bf16 channels-last, w (Cout, KH*KW*Cin) bf16 -> (B,T',F',Cout) bf16.  K / pad may be (time, freq) pairs
+    (a Conv1d over time is K=(k,1), pad=(p,0) on an F=1 layout)."""
     B, T, F, Cin = x.shape
     Cout = w.shape[0]
-    T1, F1 = (T + 2 * pad - K) // stride + 1, (F + 2 * pad - K) // stride + 1
+    KH, KW = (K, K) if isinstance(K, int) else K
+    pt, pf = (pad, pad) if isinstance(pad, int) else pad
+    T1, F1 = (T + 2 * pt - KH) // stride + 1, (F + 2 * pf - KW) // stride + 1
     out = torch.empty((B, T1, F1, Cout), device=x.device, dtype=BF16)
-    pl = 2 * pad if causal else pad
-    rc = _lib.lib().mi_conv2d_cl_bf16(x.data_ptr(), w.data_ptr(), _p(bias), out.data_ptr(), B, T, F, Cin, Cout, K, K, stride,
-                                      pl, pl, T1, F1, {"none": 0, "gelu": 1}[act], _stream())
+    plt, plf = (2 * pt, 2 * pf) if causal else (pt, pf)
+    rc = _lib.lib().mi_conv2d_cl_bf16(x.data_ptr(), w.data_ptr(), _p(bias), out.data_ptr(), B, T, F, Cin, Cout, KH, KW, stride,
+                                      plt, plf, T1, F1, {"none": 0, "gelu": 1}[act], _stream())
     _lib.check(rc, "mi_conv2d_cl_bf16")
     return out
 

@@ -137,6 +137,14 @@ int mi_embed_tokens(const long* ids, const float* wte, float scale, const float*
 int mi_ce_label_smoothing(const float* logits, long ld, const long* labels, int B, int U, int shift, int V, float eps,
                           float* acc, mi_stream_t stream);
 
+/* ---- Whisper-style front end + glue (BASELINE config 4).  replaces: transformers WhisperFeatureExtractor numpy path
+ *      (selected by configs/default_data_preprocessing_whisper.json:20-29) and the conv/position prologue of WhisperEncoder. */
+int mi_whisper_logmel(const float* wave, long ldw, const int* num_samples, int n_samples, const double* window,
+                      const double* twiddle, const double* mel_t, int nmel, int B, float* scratch,
+                      float* out_features, void* out_cl_bf16, mi_stream_t stream);
+int mi_transpose_cast_bct_btc(const float* x, void* out_bf16, int B, int C, int T, mi_stream_t stream);
+int mi_add_positions(const void* a_bf16, const float* pos, float* x, int M, int T, int d, mi_stream_t stream);
+
 /* ---- whole encoder + CTC head: Wav2Vec2EBranchformerForCTC.forward (e_branchformer.py:422-496), eval mode. */
 typedef struct {
     int B, T, F;                 /* padded log-mel input (B,T,F) fp32 */

@@ -254,6 +254,34 @@ def run_aed_cases():
             print(name, "FAILED in the reference under transformers 5.15:", type(e).__name__, str(e)[:200])
 
 
+WHISPER_TINY = dict(d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256, num_mel_bins=80, max_source_positions=100)
+
+
+def run_whisper_cases():
+    """transformers WhisperFeatureExtractor (numpy path = the pinned 4.39.3 behaviour) and WhisperEncoder."""
+    from transformers import WhisperConfig, WhisperFeatureExtractor
+    from transformers.models.whisper.modeling_whisper import WhisperEncoder
+    fe = WhisperFeatureExtractor(feature_size=80)
+    rec = {}
+    waves = {"noise": synth.normal(3, "wh_noise", (16000 * 3,), 0.1),
+             "tone": (0.3 * np.sin(2 * np.pi * 440 * np.arange(16000 * 2) / 16000)).astype(np.float32)}
+    for k, w in waves.items():
+        padded = np.zeros(fe.n_samples, np.float32); padded[: len(w)] = w
+        rec[f"fe/{k}_wave"] = w
+        rec[f"fe/{k}_logmel"] = fe._np_extract_fbank_features(padded[None], "cpu")[0].astype(np.float32)   # (80, 3000)
+    cfg = WhisperConfig(**WHISPER_TINY, attn_implementation="eager", dropout=0.0, activation_function="gelu")
+    enc = WhisperEncoder(cfg).eval()
+    wsum = load_seeded(enc, 41)
+    x = synth.normal(41, "wh_feats", (2, 80, 200), 0.5)
+    with torch.no_grad():
+        out = enc(torch.from_numpy(x)).last_hidden_state
+    rec.update(seed=41, weight_sum=wsum, enc_out=out.numpy(),
+               param_names=np.array([k for k, _ in enc.named_parameters()]),
+               param_shapes=np.array([str(tuple(v.shape)) for _, v in enc.named_parameters()]))
+    np.savez_compressed(os.path.join(HERE, "whisper.npz"), **rec)
+    print("whisper cases written", out.shape, float(out.std()))
+
+
 def run_ctc_prefix_cases():
     """reference src/decoding/ctc_scorer.py: CTCRescorerLogitsProcessor over 4 decoding steps (B=2, W=3)."""
     from decoding.ctc_scorer import CTCPrefixScoreTH, CTCRescorerLogitsProcessor, LogSoftmaxProcessor
@@ -296,7 +324,7 @@ def run_ctc_prefix_cases():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "base", "fbank", "lengths", "ctc", "prefix", "aed"]
+    which = sys.argv[1:] or ["tiny", "base", "fbank", "lengths", "ctc", "prefix", "aed", "whisper"]
     if "tiny" in which:
         run_encoder_case("tiny_rel", TINY, seed=11, B=2, T=200, lengths=[198, 150], U=7, tgt_lens=[7, 5])
         run_encoder_case("tiny_rotary", TINY, seed=12, B=2, T=200, lengths=[200, 131], U=6, tgt_lens=[6, 4],
@@ -320,3 +348,5 @@ if __name__ == "__main__":
         run_ctc_prefix_cases()
     if "aed" in which:
         run_aed_cases()
+    if "whisper" in which:
+        run_whisper_cases()

@@ -143,3 +143,21 @@ def test_joint_aed_forward_matches_reference(name, fixed):
     np.testing.assert_allclose(out["logits"].numpy(), g["logits"], atol=3e-4, rtol=0)
     for k in ("loss", "enc_loss", "dec_loss"):
         assert abs(float(out[k]) - float(g[k])) < 1e-4 * abs(float(g[k])), k
+
+
+def test_whisper_frontend_and_encoder_match_transformers():
+    import ast
+    from huggingface_asr_amd import synth
+    from oracle import whisper_ref as W
+    g = load_golden("whisper")
+    for k in ("noise", "tone"):
+        got = W.log_mel(g[f"fe/{k}_wave"])
+        assert got.shape == (80, 3000)
+        np.testing.assert_allclose(got, g[f"fe/{k}_logmel"], atol=2e-5, rtol=0)
+    seed = int(g["seed"])
+    sd = {str(n): torch.from_numpy(synth.init_param(seed, str(n), ast.literal_eval(str(s)))) for n, s in zip(g["param_names"], g["param_shapes"])}
+    cfg = dict(d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256)
+    x = torch.from_numpy(synth.normal(seed, "wh_feats", (2, 80, 200), 0.5))
+    with torch.no_grad():
+        out = W.encoder_forward(sd, cfg, x)
+    np.testing.assert_allclose(out.numpy(), g["enc_out"], atol=2e-4, rtol=0)
