@@ -1,0 +1,239 @@
+"""Drop-in `JointCTCAttentionEncoderDecoder` (+ configs) for the reference's joint CTC/attention model surface.
+
+Mirrors reference `src/models/ctc_encoder_plus_autoregressive_decoder.py` (config :38-40, output dataclass :43-47, model :55-482)
+and the decoder config of `src/models/decoders/multi_head_gpt2.py:12-29`: same model types (so `AutoConfig` /
+`AutoModelForSpeechSeq2Seq` route here after `bind_all()`), same state-dict keys (encoder.* = our E-Branchformer CTC model,
+decoder.* = GPT-2 multi-head keys, enc_to_dec_proj.*), same forward arguments and `Seq2SeqLMOutputLosses` fields, and a
+`generate()` that performs the reference's joint CTC/attention greedy / beam decoding.  The modules only hold parameters;
+all tensor work runs in `huggingface_asr_amd.decoder` (HIP kernels).  Eval-mode only this round."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+from torch import nn
+from transformers import GPT2Config, PreTrainedModel
+from transformers.modeling_outputs import Seq2SeqLMOutput
+from transformers.models.speech_encoder_decoder.configuration_speech_encoder_decoder import SpeechEncoderDecoderConfig
+
+from .configuration_ebranchformer import Wav2Vec2EBranchformerConfig
+from .decoder import JointAEDEngine, generate as _generate
+from .engine import cfg_from_hf
+from .modeling_ebranchformer import Wav2Vec2EBranchformerForCTC, _Holder
+
+
+class GPT2MultiHeadConfig(GPT2Config):
+    model_type = "gpt2-multi-head"
+
+    def __init__(self, head_locations=None, head_weights=None, tie_additional_weights=False, average_logits=False, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.head_locations = head_locations
+        self.head_weights = head_weights
+        self.tie_additional_weights = tie_additional_weights
+        self.average_logits = average_logits
+
+
+class JointCTCAttentionEncoderDecoderConfig(SpeechEncoderDecoderConfig):
+    model_type = "joint_aed_ctc_speech-encoder-decoder"
+    is_composition = True
+
+
+@dataclass
+class Seq2SeqLMOutputLosses(Seq2SeqLMOutput):
+    enc_loss: Optional[torch.FloatTensor] = None
+    dec_loss: Optional[torch.FloatTensor] = None
+    encoder_logits: Optional[torch.FloatTensor] = None
+
+
+class _Conv1D(_Holder):          # transformers Conv1D parameter layout: weight (in, out)
+    def __init__(self, nf, nx):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(nx, nf).normal_(std=0.02))
+        self.bias = nn.Parameter(torch.zeros(nf))
+
+
+class _Attn(_Holder):
+    def __init__(self, d, cross):
+        super().__init__()
+        if cross:
+            self.c_attn = _Conv1D(2 * d, d)
+            self.q_attn = _Conv1D(d, d)
+        else:
+            self.c_attn = _Conv1D(3 * d, d)
+        self.c_proj = _Conv1D(d, d)
+
+
+class _MLP(_Holder):
+    def __init__(self, d, inner):
+        super().__init__()
+        self.c_fc = _Conv1D(inner, d)
+        self.c_proj = _Conv1D(d, inner)
+
+
+class _Block(_Holder):
+    def __init__(self, cfg):
+        super().__init__()
+        d = cfg.hidden_size
+        eps = cfg.layer_norm_epsilon
+        self.ln_1 = nn.LayerNorm(d, eps=eps)
+        self.attn = _Attn(d, False)
+        self.ln_2 = nn.LayerNorm(d, eps=eps)
+        self.crossattention = _Attn(d, True)
+        self.ln_cross_attn = nn.LayerNorm(d, eps=eps)
+        self.mlp = _MLP(d, cfg.n_inner if cfg.n_inner is not None else 4 * d)
+
+
+class _AdaptiveEmb(_Holder):     # reference src/models/embeddings.py:5-31 (div_val = 1): key `emb_layers.0.weight`
+    def __init__(self, n_token, d):
+        super().__init__()
+        self.emb_layers = nn.ModuleList([nn.Embedding(n_token, d)])
+        self.emb_projs = nn.ParameterList()
+
+
+class _FixedPos(_Holder):        # reference src/models/embeddings.py:65-86: persistent buffer `inv_freq`
+    def __init__(self, d):
+        super().__init__()
+        self.register_buffer("inv_freq", 1 / (10000 ** (torch.arange(0.0, d, 2.0) / d)))
+
+
+class _GPT2Body(_Holder):
+    def __init__(self, cfg):
+        super().__init__()
+        d = cfg.hidden_size
+        if getattr(cfg, "pos_emb_fixed", False):
+            self.wte = _AdaptiveEmb(cfg.vocab_size, d)
+            self.wpe = _FixedPos(d)
+        else:
+            self.wte = nn.Embedding(cfg.vocab_size, d)
+            self.wpe = nn.Embedding(cfg.max_position_embeddings, d)
+        self.h = nn.ModuleList([_Block(cfg) for _ in range(cfg.num_hidden_layers)])
+        self.ln_f = nn.LayerNorm(d, eps=cfg.layer_norm_epsilon)
+
+
+class _Decoder(_Holder):
+    def __init__(self, cfg):
+        super().__init__()
+        self.config = cfg
+        self.transformer = _GPT2Body(cfg)
+        self.lm_head = nn.Linear(cfg.hidden_size, cfg.vocab_size, bias=False)
+        self.additional_lm_heads = nn.ModuleList([nn.Linear(cfg.hidden_size, cfg.vocab_size, bias=False) for _ in (cfg.head_locations or [])])
+
+
+def _dec_cfg_dict(c) -> dict:
+    return dict(vocab_size=c.vocab_size, n_embd=c.hidden_size, n_layer=c.num_hidden_layers, n_head=c.num_attention_heads,
+                n_positions=c.max_position_embeddings, head_locations=list(c.head_locations or []),
+                head_weights=list(c.head_weights or [1.0]), lsm_factor=getattr(c, "lsm_factor", 0.0),
+                layer_norm_epsilon=c.layer_norm_epsilon, pos_emb_fixed=bool(getattr(c, "pos_emb_fixed", False)),
+                activation_function=c.activation_function)
+
+
+class JointCTCAttentionEncoderDecoder(PreTrainedModel):
+    config_class = JointCTCAttentionEncoderDecoderConfig
+    base_model_prefix = "joint_aed_ctc_speech-encoder-decoder"
+    main_input_name = "inputs"
+
+    def __init__(self, config=None, encoder=None, decoder=None):
+        if config is None and (encoder is None or decoder is None):
+            raise ValueError("Either a configuration or an encoder and a decoder has to be provided.")
+        if config is None:
+            config = JointCTCAttentionEncoderDecoderConfig.from_encoder_decoder_configs(encoder.config, decoder.config)
+        elif not isinstance(config, self.config_class):
+            raise ValueError(f"Config: {config} has to be of type {self.config_class}")
+        if config.decoder.cross_attention_hidden_size is not None and \
+                config.decoder.cross_attention_hidden_size != config.encoder.hidden_size:
+            raise ValueError("If `cross_attention_hidden_size` is specified in the decoder's configuration, it has to be equal to the "
+                             "encoder's `hidden_size`.")
+        config.tie_word_embeddings = False
+        super().__init__(config)
+        self.encoder = encoder if encoder is not None else Wav2Vec2EBranchformerForCTC(config.encoder)
+        self.decoder = decoder if decoder is not None else _Decoder(config.decoder)
+        self.encoder.config = self.config.encoder
+        self.decoder.config = self.config.decoder
+        self.encoder_output_dim = getattr(config.encoder, "output_hidden_size", config.encoder.hidden_size)
+        if self.encoder_output_dim != self.decoder.config.hidden_size and self.decoder.config.cross_attention_hidden_size is None:
+            self.enc_to_dec_proj = nn.Linear(self.encoder.config.hidden_size, self.decoder.config.hidden_size)
+        if self.encoder.get_output_embeddings() is not None:
+            raise ValueError(f"The encoder {self.encoder} should not have a LM Head. Please use a model without LM Head")
+        self.enc_loss_weight = config.ctc_weight
+        self.dec_loss_weight = 1 - config.ctc_weight
+        self.lsm_factor = config.decoder.lsm_factor
+        self._engine = None
+        self._engine_key = None
+        from .decoding import GenerationConfigCustom
+        # trainers overwrite this (train_enc_dec_asr.py:85); the default carries the ids of the model config
+        self.generation_config = GenerationConfigCustom(pad_token_id=config.pad_token_id, eos_token_id=config.decoder.eos_token_id,
+                                                        decoder_start_token_id=config.decoder_start_token_id, num_beams=1, max_length=64)
+
+    def _init_weights(self, module):
+        pass
+
+    def get_encoder(self):
+        return self.encoder
+
+    def get_decoder(self):
+        return self.decoder
+
+    def freeze_feature_encoder(self):
+        self.encoder.freeze_feature_encoder()
+
+    def _get_engine(self, device) -> JointAEDEngine:
+        if self._engine is None or self._engine.device != torch.device(device):
+            jc = dict(ctc_weight=self.config.ctc_weight, pad_token_id=self.config.pad_token_id,
+                      decoder_start_token_id=self.config.decoder_start_token_id)
+            self._engine = JointAEDEngine(cfg_from_hf(self.config.encoder), _dec_cfg_dict(self.config.decoder), jc, device)
+            self._engine_key = None
+        key = (sum(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()))
+        if key != self._engine_key:
+            self._engine.load_state_dict(dict(self.state_dict()))
+            self._engine_key = key
+        return self._engine
+
+    @staticmethod
+    def _pick_inputs(inputs, input_values, input_features):
+        if inputs is None:
+            if input_values is not None and input_features is not None:
+                raise ValueError("You cannot specify both input_values and input_features at the same time")
+            inputs = input_values if input_values is not None else input_features
+            if inputs is None:
+                raise ValueError("You have to specify either input_values or input_features")
+        return inputs
+
+    def forward(self, inputs=None, attention_mask=None, decoder_input_ids=None, decoder_attention_mask=None, encoder_outputs=None,
+                past_key_values=None, decoder_inputs_embeds=None, labels=None, use_cache=None, output_attentions=None,
+                output_hidden_states=None, input_values=None, input_features=None, return_dict=None, **kwargs):
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("training-mode forward/backward through the HIP path is not built yet (DESIGN.md §7)")
+        if labels is None or decoder_input_ids is not None or encoder_outputs is not None or decoder_inputs_embeds is not None:
+            raise NotImplementedError("HIP joint forward implements the teacher-forced path driven by `labels` (reference :303-304); "
+                                      "use generate() for decoding")
+        inputs = self._pick_inputs(inputs, input_values, input_features)
+        if not inputs.is_cuda:
+            raise RuntimeError("JointCTCAttentionEncoderDecoder (HIP): inputs must be on the GPU; there is no CPU fallback")
+        if labels.max() >= self.config.encoder.vocab_size:
+            raise ValueError(f"Label values must be <= vocab_size: {self.config.encoder.vocab_size}")
+        eng = self._get_engine(inputs.device)
+        fl = attention_mask.sum(-1).to(torch.int32) if attention_mask is not None else None
+        out = eng.forward(inputs, fl, labels.to(inputs.device))
+        B, T2 = out["encoder_logits"].shape[:2]
+        return Seq2SeqLMOutputLosses(loss=out["loss"], enc_loss=out["enc_loss"], dec_loss=out["dec_loss"], logits=out["logits"],
+                                     encoder_last_hidden_state=out["encoder_hidden"].view(B, T2, -1), encoder_logits=out["encoder_logits"])
+
+    @torch.no_grad()
+    def generate(self, inputs=None, generation_config=None, attention_mask=None, input_values=None, input_features=None, **kwargs):
+        """Joint CTC/attention decoding (reference :450-482 + :360-404): returns (B, L) token ids padded with pad_token_id."""
+        inputs = self._pick_inputs(inputs, input_values, input_features)
+        g = generation_config if generation_config is not None else self.generation_config
+        gv = lambda k, d: kwargs.get(k, getattr(g, k, None)) if kwargs.get(k, getattr(g, k, None)) is not None else d
+        eng = self._get_engine(inputs.device)
+        fl = attention_mask.sum(-1).to(torch.int32) if attention_mask is not None else None
+        pad = gv("pad_token_id", self.config.pad_token_id)
+        hyps = _generate(eng, inputs, fl, num_beams=gv("num_beams", 1), max_length=gv("max_length", 64), ctc_weight=gv("ctc_weight", 0.0),
+                         length_penalty=gv("length_penalty", 1.0), eos_token_id=gv("eos_token_id", self.config.decoder.eos_token_id),
+                         pad_token_id=pad, start_token_id=gv("decoder_start_token_id", self.config.decoder_start_token_id),
+                         space_token_id=gv("space_token_id", -1))
+        L = max(len(h["tokens"]) for h in hyps)
+        out = torch.full((len(hyps), L), pad, dtype=torch.long, device=inputs.device)
+        for b, h in enumerate(hyps):
+            out[b, : len(h["tokens"])] = torch.tensor(h["tokens"], device=inputs.device)
+        return out

@@ -135,3 +135,27 @@ def test_joint_decoding_matches_oracle(W):
     for b in range(2):
         assert abs(got[b]["score"] - want[b][0]) < 0.05 * max(1.0, abs(want[b][0])), (got[b], want[b])
         assert got[b]["tokens"] == want[b][1], (got[b], want[b])
+
+
+def test_hf_joint_model_surface():
+    """AutoModelForSpeechSeq2Seq route: reference state dict in, Seq2SeqLMOutputLosses out, generate() tokens."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_surface_cpu import _joint_model
+    from huggingface_asr_amd.decoder import generate
+    g = load_golden("aed_tiny")
+    sd, x, am, lab = aed_case_inputs(g)
+    model = _joint_model(False)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        out = model(input_values=x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))
+    for k in ("loss", "enc_loss", "dec_loss"):
+        assert abs(float(getattr(out, k)) - float(g[k])) < 2e-3 * abs(float(g[k])), k
+    assert np.abs(out.logits.cpu().numpy() - g["logits"]).max() < 0.08
+    assert out.encoder_logits.shape == (2, 50, 51) and out.encoder_last_hidden_state.shape == (2, 50, 128)
+    toks = model.generate(input_values=x.to(DEV), attention_mask=am.to(DEV), num_beams=3, max_length=8, ctc_weight=0.3)
+    ref = generate(model._get_engine(DEV), x.to(DEV), am.sum(-1).to(DEV, torch.int32), num_beams=3, max_length=8, ctc_weight=0.3)
+    for b in range(2):
+        assert toks[b, : len(ref[b]["tokens"])].tolist() == ref[b]["tokens"]
