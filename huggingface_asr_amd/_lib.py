@@ -49,6 +49,32 @@ SIGNATURES = {
     "mi_whisper_logmel": [vp, i64, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp],
     "mi_transpose_cast_bct_btc": [vp, vp, i32, i32, i32, vp],
     "mi_add_positions": [vp, vp, vp, i32, i32, i32, vp],
+    "mi_transpose_bf16": [vp, i64, vp, i64, i32, i32, i32, vp],
+    "mi_colsum": [vp, i64, i32, i32, i32, vp, vp],
+    "mi_act_fwd_bf16": [vp, i64, vp, i64, i32, i32, i32, vp],
+    "mi_act_bwd_bf16": [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp],
+    "mi_layernorm_bwd": [vp, i64, i32, vp, f32, vp, i64, i32, vp, i64, i32, i32, vp, vp, i32, i32, vp],
+    "mi_ln_apply_bf16": [vp, i64, vp, vp, vp, vp, i64, i32, i32, vp],
+    "mi_axpy_f32": [vp, vp, i64, f32, vp],
+    "mi_scale_f32": [vp, i64, f32, vp],
+    "mi_add2_cast_bf16": [vp, i64, vp, i64, vp, i64, i32, i32, f32, vp],
+    "mi_add_rowvec_bf16": [vp, i64, vp, vp, i64, i32, i32, vp],
+    "mi_gate_bwd_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, vp],
+    "mi_mask_rows_f32": [vp, i64, vp, i32, i32, i32, vp],
+    "mi_sumsq_f32": [vp, i64, vp, vp],
+    "mi_clip_coef": [vp, f32, vp, vp],
+    "mi_adamw_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, vp, vp],
+    "mi_bgemm_bf16": [vp, i64, i64, i64, i64, vp, i64, i64, i64, i64, vp, i64, i64, i64, i32, i32, f32, i32, i32, i32, i32, i32, vp],
+    "mi_attn_softmax_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
+    "mi_attn_softmax_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "mi_csgu_bwd_bf16": [vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, vp],
+    "mi_dwconv_residual_bwd_bf16": [vp, i64, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, vp],
+    "mi_im2col_cl_bf16": [vp, vp] + [i32] * 11 + [vp],
+    "mi_conv2d_first_bwd": [vp, vp, vp, vp, vp, vp] + [i32] * 16 + [vp],
+    "mi_ctc_bwd_workspace_bytes": [i32, i32, i32],
+    "mi_ctc_loss_bwd": [vp, i64, i64, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, f32, vp, sz, vp, i64, vp],
+    "mi_ce_label_smoothing_bwd": [vp, i64, vp, i32, i32, i32, i32, f32, f32, vp, vp, i64, vp],
+    "mi_embed_tokens_bwd": [vp, vp, f32, i32, i32, i32, i32, i32, vp, vp, vp],
     "mi_ebf_workspace_bytes": [C.POINTER(EbfConfig)],
     "mi_ebf_forward": [C.POINTER(EbfConfig), vp, vp, vp, vp, vp, i32, vp, sz, vp, vp, vp, vp, vp],
 }
@@ -76,7 +102,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(h, name)          # AttributeError here = header/library mismatch: fail loudly
             fn.argtypes = args
-            fn.restype = sz if name == "mi_ebf_workspace_bytes" else i32
+            fn.restype = sz if name in ("mi_ebf_workspace_bytes", "mi_ctc_bwd_workspace_bytes") else i32
         h.mi_profile_create.argtypes = [i32]; h.mi_profile_create.restype = i32
         h.mi_profile_enable.argtypes = [i32]; h.mi_profile_enable.restype = None
         h.mi_profile_reset.argtypes = []; h.mi_profile_reset.restype = None

@@ -1,0 +1,103 @@
+// Softmax stage of the attention backward pass on gfx950 (the matrix products around it are mi_bgemm_bf16).
+//
+// Reference forward being differentiated: e_branchformer.py:100-135 + tf wav2vec2_conformer:528-565 (relative shift):
+//   s[i,j] = ((q_i+u)·k_j + (q_i+v)·p[T-1-i+j]) / sqrt(hd) + mask,  P = softmax_j(s),  ctx = P V
+// and the GPT-2 decoder's causal self-attention / length-masked cross-attention (tf gpt2 eager attention).
+// Head-major layouts: AC, dP, dS, P are (H, B, Tq, Tk); BD, dBD are (H, B, Tq, 2T-1) — for one head the (b, t) rows are
+// contiguous, so the batch-reduced products of the position branch are plain strided GEMMs.
+#include "common.hpp"
+
+namespace {
+
+struct SmArgs {
+    const float* ac; const float* bd;     // bd may be null
+    const float* dp;                      // backward only
+    bf16_t* prob;                         // fwd: out, bwd: in
+    bf16_t* ds; bf16_t* dbd;              // backward outputs (dbd may be null)
+    const int* lengths;                   // valid keys per utterance or null
+    int H, B, Tq, Tk, causal;
+    float scale;
+};
+
+__device__ __forceinline__ bool key_masked(const SmArgs& p, int b, int i, int j) {
+    if (p.lengths && j >= p.lengths[b]) return true;
+    if (p.causal && j > i + (p.Tk - p.Tq)) return true;
+    return false;
+}
+
+// one wave per (h, b, i) row
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(SmArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long rows = (long)p.H * p.B * p.Tq;
+    if (row >= rows) return;
+    const int i = (int)(row % p.Tq), b = (int)((row / p.Tq) % p.B);
+    const int P = 2 * p.Tq - 1;
+    const float* ac = p.ac + row * p.Tk;
+    const float* bd = p.bd ? p.bd + row * P + (p.Tq - 1 - i) : nullptr;
+    float mx = -INFINITY;
+    for (int j = lane; j < p.Tk; j += 64) {
+        if (key_masked(p, b, i, j)) continue;
+        mx = fmaxf(mx, (ac[j] + (bd ? bd[j] : 0.f)) * p.scale);
+    }
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int j = lane; j < p.Tk; j += 64) {
+        if (key_masked(p, b, i, j)) continue;
+        s += __expf((ac[j] + (bd ? bd[j] : 0.f)) * p.scale - mx);
+    }
+    s = wave_sum(s);
+    const float inv = s > 0.f ? 1.f / s : 0.f;
+    bf16_t* out = p.prob + row * p.Tk;
+    for (int j = lane; j < p.Tk; j += 64) {
+        float v = 0.f;
+        if (!key_masked(p, b, i, j)) v = __expf((ac[j] + (bd ? bd[j] : 0.f)) * p.scale - mx) * inv;
+        out[j] = f2bf(v);
+    }
+}
+
+// dS = P * (dP - sum_j P dP) * scale;  dBD[i, T-1-i+j] = dS[i,j], zero elsewhere
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(SmArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long rows = (long)p.H * p.B * p.Tq;
+    if (row >= rows) return;
+    const int i = (int)(row % p.Tq);
+    const bf16_t* pr = p.prob + row * p.Tk;
+    const float* dp = p.dp + row * p.Tk;
+    float dot = 0.f;
+    for (int j = lane; j < p.Tk; j += 64) dot += bf2f(pr[j]) * dp[j];
+    dot = wave_sum(dot);
+    bf16_t* ds = p.ds + row * p.Tk;
+    for (int j = lane; j < p.Tk; j += 64) ds[j] = f2bf(bf2f(pr[j]) * (dp[j] - dot) * p.scale);
+    if (p.dbd) {
+        const int P = 2 * p.Tq - 1, off = p.Tq - 1 - i;
+        bf16_t* dbd = p.dbd + row * P;
+        for (int q = lane; q < P; q += 64) {
+            const int j = q - off;
+            dbd[q] = (j >= 0 && j < p.Tk) ? f2bf(bf2f(pr[j]) * (dp[j] - dot) * p.scale) : (bf16_t)0.f;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mi_attn_softmax_fwd(const float* ac, const float* bd, const int* lengths, void* prob, int H, int B, int Tq, int Tk,
+                                   float scale, int causal, hipStream_t st) {
+    MI_ENTER();
+    if (H <= 0 || B <= 0 || Tq <= 0 || Tk <= 0 || (bd && Tq != Tk)) return MI_ERR_ARG;
+    SmArgs p{ac, bd, nullptr, (bf16_t*)prob, nullptr, nullptr, lengths, H, B, Tq, Tk, causal, scale};
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv((long)H * B * Tq, 4)), dim3(256), 0, st, p);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+extern "C" int mi_attn_softmax_bwd(const void* prob, const float* dp, void* ds, void* dbd, int H, int B, int Tq, int Tk, float scale,
+                                   hipStream_t st) {
+    MI_ENTER();
+    if (H <= 0 || B <= 0 || Tq <= 0 || Tk <= 0 || (dbd && Tq != Tk)) return MI_ERR_ARG;
+    SmArgs p{nullptr, nullptr, dp, (bf16_t*)prob, (bf16_t*)ds, (bf16_t*)dbd, nullptr, H, B, Tq, Tk, 0, scale};
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(cdiv((long)H * B * Tq, 4)), dim3(256), 0, st, p);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}

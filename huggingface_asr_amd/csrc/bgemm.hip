@@ -1,0 +1,134 @@
+// Strided, batched bf16 MFMA GEMM for the small per-(utterance, head) products of the attention backward pass
+// (scores / probabilities are materialised only there; the forward keeps its fused LDS kernel, attention.hip):
+//
+//   C[z1,z2][m][n] = alpha * sum_k A[z1,z2][m][k] * B[z1,z2][n][k]  (+ C)
+//
+// Every operand is addressed by element strides, so Q·Kᵀ, P·V, Pᵀ·dO, dSᵀ·Q and the batch-reduced dBDᵀ·(q+v) (K runs over
+// (b, t) with one uniform stride) are the same kernel.  One of (row stride, k stride) must be 1 per operand: k-contiguous
+// operands are staged with 16-B loads, row-contiguous ones with 16-B loads + a transposing LDS write.
+// Tile 64x64x32, 4 waves (2x2) of one v_mfma_f32_32x32x16_bf16 tile each, register-staged prefetch of the next K tile.
+#include "common.hpp"
+
+namespace {
+
+struct BgArgs {
+    const bf16_t* A; long a_z1, a_z2, a_m, a_k;
+    const bf16_t* B; long b_z1, b_z2, b_n, b_k;
+    void* C; long c_z1, c_z2, c_m;
+    int out_f32, accumulate;
+    float alpha;
+    int Z2, M, N, K;
+};
+
+constexpr int TM = 64, TK = 32, LDS_LD = TK + 8;
+
+// stage a 64 x 32 tile of an operand whose rows are `rows` (bound R) into registers (8 elements per thread)
+template <int MODE>   // 0: k-contiguous (s_k == 1), 1: row-contiguous (s_r == 1)
+__device__ __forceinline__ bf16x8 stage_load(const bf16_t* base, long s_r, long s_k, int r0, int R, int k0, int K, int tid) {
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (MODE == 0) {
+        const int row = r0 + (tid >> 2), k = k0 + (tid & 3) * 8;
+        if (row < R && k < K) {
+            const bf16_t* p = base + (long)row * s_r + k;
+            if (k + 8 <= K && ((s_r & 7) == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) v = *reinterpret_cast<const bf16x8*>(p);
+            else
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (k + j < K) v[j] = p[j];
+        }
+    } else {
+        const int k = k0 + (tid >> 3), row = r0 + (tid & 7) * 8;
+        if (k < K && row < R) {
+            const bf16_t* p = base + (long)k * s_k + row;
+            if (row + 8 <= R && ((s_k & 7) == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) v = *reinterpret_cast<const bf16x8*>(p);
+            else
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (row + j < R) v[j] = p[j];
+        }
+    }
+    return v;
+}
+template <int MODE>
+__device__ __forceinline__ void stage_store(bf16_t* s, const bf16x8& v, int tid) {
+    if (MODE == 0) {
+        *reinterpret_cast<bf16x8*>(s + (tid >> 2) * LDS_LD + (tid & 3) * 8) = v;
+    } else {
+        const int k = tid >> 3, row = (tid & 7) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[(row + j) * LDS_LD + k] = v[j];
+    }
+}
+
+template <int MA, int MB>
+__global__ __launch_bounds__(256) void bgemm_kernel(BgArgs p) {
+    __shared__ __attribute__((aligned(16))) bf16_t sA[TM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) bf16_t sB[TM * LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+    const int z1 = blockIdx.z / p.Z2, z2 = blockIdx.z % p.Z2;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TM;
+    const bf16_t* A = p.A + z1 * p.a_z1 + z2 * p.a_z2;
+    const bf16_t* B = p.B + z1 * p.b_z1 + z2 * p.b_z2;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nk = (p.K + TK - 1) / TK;
+    bf16x8 ra = stage_load<MA>(A, p.a_m, p.a_k, m0, p.M, 0, p.K, tid);
+    bf16x8 rb = stage_load<MB>(B, p.b_n, p.b_k, n0, p.N, 0, p.K, tid);
+    for (int kt = 0; kt < nk; ++kt) {
+        stage_store<MA>(sA, ra, tid);
+        stage_store<MB>(sB, rb, tid);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            ra = stage_load<MA>(A, p.a_m, p.a_k, m0, p.M, (kt + 1) * TK, p.K, tid);
+            rb = stage_load<MB>(B, p.b_n, p.b_k, n0, p.N, (kt + 1) * TK, p.K, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < TK / 16; ++ks) {
+            const bf16x8 fa = *reinterpret_cast<const bf16x8*>(sA + (wm * 32 + lr) * LDS_LD + ks * 16 + lh * 8);
+            const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sB + (wn * 32 + lr) * LDS_LD + ks * 16 + lh * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const int n = n0 + wn * 32 + lr;
+    if (n >= p.N) return;
+    char* Cb = reinterpret_cast<char*>(p.C);
+    const long zoff = z1 * p.c_z1 + z2 * p.c_z2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= p.M) continue;
+        const long off = zoff + (long)m * p.c_m + n;
+        float v = p.alpha * acc[r];
+        if (p.out_f32) {
+            float* c = reinterpret_cast<float*>(Cb) + off;
+            if (p.accumulate) v += *c;
+            *c = v;
+        } else {
+            bf16_t* c = reinterpret_cast<bf16_t*>(Cb) + off;
+            if (p.accumulate) v += bf2f(*c);
+            *c = f2bf(v);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mi_bgemm_bf16(const void* A, long a_z1, long a_z2, long a_m, long a_k,
+                             const void* B, long b_z1, long b_z2, long b_n, long b_k,
+                             void* C, long c_z1, long c_z2, long c_m, int out_f32, int accumulate, float alpha,
+                             int Z1, int Z2, int M, int N, int K, hipStream_t st) {
+    MI_ENTER();
+    if (Z1 <= 0 || Z2 <= 0 || M <= 0 || N <= 0 || K <= 0 || (long)Z1 * Z2 > 65535) return MI_ERR_ARG;
+    if ((a_k != 1 && a_m != 1) || (b_k != 1 && b_n != 1)) return MI_ERR_UNSUPPORTED;
+    BgArgs p{(const bf16_t*)A, a_z1, a_z2, a_m, a_k, (const bf16_t*)B, b_z1, b_z2, b_n, b_k, C, c_z1, c_z2, c_m, out_f32, accumulate, alpha, Z2, M, N, K};
+    dim3 grid(cdiv(N, TM), cdiv(M, TM), Z1 * Z2);
+    const int ma = a_k == 1 ? 0 : 1, mb = b_k == 1 ? 0 : 1;
+    if (ma == 0 && mb == 0) hipLaunchKernelGGL((bgemm_kernel<0, 0>), grid, dim3(256), 0, st, p);
+    else if (ma == 0 && mb == 1) hipLaunchKernelGGL((bgemm_kernel<0, 1>), grid, dim3(256), 0, st, p);
+    else if (ma == 1 && mb == 0) hipLaunchKernelGGL((bgemm_kernel<1, 0>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((bgemm_kernel<1, 1>), grid, dim3(256), 0, st, p);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}

@@ -1,0 +1,292 @@
+// Backward kernels of the convolutional pieces of the path on gfx950 (training step):
+//   * depthwise Conv1d over time (CSGU e_branchformer.py:184-204 with its LayerNorm + gating, merge block :296-304),
+//   * the Conv2d sub-sampling front end (extractors.py:71-113): im2col for the weight gradient of conv2 and a fused
+//     col2im + GELU' + conv1 weight-gradient kernel (conv1's activation gradient is never materialised).
+// Gradients of the forward kernels in conv.hip; checked against torch autograd of the CPU oracle in tests/.
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.f + fast_erf(x * 0.70710678118654752440f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ------------------------------------------------------------------------------------------------ depthwise conv backward
+constexpr int DB_TT = 64, DB_CT = 64, DB_KMAX = 31;
+
+struct DwBwdArgs {
+    const bf16_t* x; long ldx;            // conv input rows (CSGU: the gate half x_g, LayerNorm applied on load)
+    const bf16_t* r; long ldr;            // CSGU: x_r
+    const float* stats; const float* gamma; const float* beta;   // CSGU LayerNorm
+    const bf16_t* dy; long lddy;          // CSGU: ds (gradient of x_r * conv);  MERGE: gradient of m + conv(m)
+    const float* w; const float* bias;    // (C,K), (C)
+    bf16_t* dx; long lddx;                // CSGU: gradient w.r.t. LN(x_g);  MERGE: dy + conv^T(dy)
+    bf16_t* dr; long lddr;                // CSGU: ds * conv
+    float* dw; float* db;                 // accumulated
+    int B, T, C, K, pad_left;
+};
+
+// block = (64 channels, utterance b); walks the time tiles, keeps the K tap gradients of its channel in registers
+template <bool CSGU>
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int halo = p.K - 1;
+    const int rows = DB_TT + halo;
+    float* tx_ = reinterpret_cast<float*>(smem);          // [rows][64] conv input, t from t0 - pad
+    float* ty_ = tx_ + rows * DB_CT;                      // [rows][64] conv output gradient, t from t0 + pad - halo
+    float* sw = ty_ + rows * DB_CT;                       // [K][64]
+    float* red = sw + DB_KMAX * DB_CT;                    // [4][K+1][64] tap-gradient partials
+    const int c0 = blockIdx.x * DB_CT, b = blockIdx.y;
+    const int tx = threadIdx.x & 63, tq = threadIdx.x >> 6;
+    const int c = c0 + tx;
+    const bool cok = c < p.C;
+    for (int i = threadIdx.x; i < p.K * DB_CT; i += 256) {
+        const int k = i / DB_CT, cc = i % DB_CT;
+        sw[i] = (c0 + cc < p.C) ? p.w[(long)(c0 + cc) * p.K + k] : 0.f;
+    }
+    float g = 1.f, be = 0.f, bias = 0.f;
+    if (CSGU && cok) { g = p.gamma[c]; be = p.beta[c]; }
+    if (cok && p.bias) bias = p.bias[c];
+    float gw[DB_KMAX];
+#pragma unroll
+    for (int k = 0; k < DB_KMAX; ++k) gw[k] = 0.f;
+    float gb = 0.f;
+    const int per = DB_TT / 4;
+    for (int t0 = 0; t0 < p.T; t0 += DB_TT) {
+        __syncthreads();
+        for (int rr = tq; rr < rows; rr += 4) {
+            const int t = t0 - p.pad_left + rr;
+            float v = 0.f;
+            if (cok && t >= 0 && t < p.T) {
+                const long row = (long)b * p.T + t;
+                v = bf2f(p.x[row * p.ldx + c]);
+                if (CSGU) v = (v - p.stats[2 * row]) * p.stats[2 * row + 1] * g + be;
+            }
+            tx_[rr * DB_CT + tx] = v;
+            const int t2 = t0 + p.pad_left - halo + rr;
+            float d = 0.f;
+            if (cok && t2 >= 0 && t2 < p.T) {
+                const long row = (long)b * p.T + t2;
+                d = bf2f(p.dy[row * p.lddy + c]);
+                if (CSGU) d *= bf2f(p.r[row * p.ldr + c]);
+            }
+            ty_[rr * DB_CT + tx] = d;
+        }
+        __syncthreads();
+        if (!cok) continue;
+        for (int j = 0; j < per; ++j) {
+            const int tl = tq * per + j, t = t0 + tl;
+            if (t >= p.T) break;
+            // dx[t] = sum_k w[k] * dyc[t + pad - k]  -> ty_ row (tl + halo - k)
+            float acc = 0.f;
+            for (int k = 0; k < p.K; ++k) acc = fmaf(sw[k * DB_CT + tx], ty_[(tl + halo - k) * DB_CT + tx], acc);
+            const float dyc = ty_[(tl + halo - p.pad_left) * DB_CT + tx];      // conv-output gradient at t
+            const long row = (long)b * p.T + t;
+            if (CSGU) {
+                float cv = bias;                                              // conv output at t (recomputed)
+                for (int k = 0; k < p.K; ++k) cv = fmaf(sw[k * DB_CT + tx], tx_[(tl + k) * DB_CT + tx], cv);
+                p.dr[row * p.lddr + c] = f2bf(bf2f(p.dy[row * p.lddy + c]) * cv);
+            } else {
+                acc += dyc;                                                   // residual path of m + conv(m)
+            }
+            p.dx[row * p.lddx + c] = f2bf(acc);
+            gb += dyc;
+#pragma unroll
+            for (int k = 0; k < DB_KMAX; ++k)
+                if (k < p.K) gw[k] = fmaf(dyc, tx_[(tl + k) * DB_CT + tx], gw[k]);
+        }
+    }
+    __syncthreads();
+    float* mine = red + (size_t)tq * (DB_KMAX + 1) * DB_CT;
+#pragma unroll
+    for (int k = 0; k < DB_KMAX; ++k) mine[k * DB_CT + tx] = gw[k];
+    mine[DB_KMAX * DB_CT + tx] = gb;
+    __syncthreads();
+    for (int i = threadIdx.x; i < (p.K + 1) * DB_CT; i += 256) {
+        const int k = i / DB_CT, cc = i % DB_CT;
+        if (c0 + cc >= p.C) continue;
+        const int kk = (k == p.K) ? DB_KMAX : k;
+        float s = 0.f;
+        for (int q = 0; q < 4; ++q) s += red[(size_t)q * (DB_KMAX + 1) * DB_CT + kk * DB_CT + cc];
+        if (k == p.K) { if (p.db) atomic_add_f32(p.db + c0 + cc, s); }
+        else atomic_add_f32(p.dw + (long)(c0 + cc) * p.K + k, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ im2col (channels-last)
+// in (B,Tin,Fin,Cin) bf16 -> col (B*Tout*Fout, KH*KW*Cin) bf16, k = (kh*KW + kw)*Cin + c  (the A operand of conv2 made explicit)
+__global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ col, int B, int Tin, int Fin,
+                                                      int Cin, int KH, int KW, int stride, int pad_t, int pad_f, int Tout, int Fout) {
+    const int c8 = Cin / 8;
+    const long total = (long)B * Tout * Fout * KH * KW * c8;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cc = (int)(i % c8);
+        long r = i / c8;
+        const int tap = (int)(r % (KH * KW)); r /= (KH * KW);
+        const int fo = (int)(r % Fout); r /= Fout;
+        const int to = (int)(r % Tout);
+        const int b = (int)(r / Tout);
+        const int kh = tap / KW, kw = tap % KW;
+        const int ti = to * stride - pad_t + kh, fi = fo * stride - pad_f + kw;
+        bf16x8 v = zero8;
+        if (ti >= 0 && ti < Tin && fi >= 0 && fi < Fin)
+            v = *reinterpret_cast<const bf16x8*>(in + (((long)b * Tin + ti) * Fin + fi) * Cin + cc * 8);
+        *reinterpret_cast<bf16x8*>(col + i * 8) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ conv1 backward (3x3)
+// Fused: dact1[b,t1,f1,c] = sum over the conv2 taps that read this position of dcol[(b,t2,f2), (kh,kw,c)]   (col2im gather)
+//        dpre1 = dact1 * gelu'(pre1), pre1 recomputed from the features;  dW1[c][tap] += dpre1 * x[tap];  db1[c] += dpre1.
+// Thread layout of conv2d_first3_kernel: a thread owns 8 channels and walks positions.
+__global__ __launch_bounds__(256) void conv1_bwd3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          const bf16_t* __restrict__ dcol, float* __restrict__ dw, float* __restrict__ db,
+                                                          int B, int T, int F, int C, int stride, int pad_t, int pad_f, int T1, int F1,
+                                                          int K2, int stride2, int pad2_t, int pad2_f, int T2, int F2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sacc = reinterpret_cast<float*>(smem);        // [C][10]
+    const int cg = C >> 3, ppb = 256 / cg;
+    const int g = threadIdx.x % cg, pl = threadIdx.x / cg;
+    for (int i = threadIdx.x; i < C * 10; i += 256) sacc[i] = 0.f;
+    __syncthreads();
+    float wr[9][8], br[8], gwr[9][8], gbr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        br[j] = bias[g * 8 + j]; gbr[j] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) { wr[tap][j] = w[(g * 8 + j) * 9 + tap]; gwr[tap][j] = 0.f; }
+    }
+    const long total = (long)B * T1 * F1;
+    const long ldcol = (long)K2 * K2 * C;
+    if (pl < ppb)
+    for (long pos = (long)blockIdx.x * ppb + pl; pos < total; pos += (long)gridDim.x * ppb) {
+        const int f1 = (int)(pos % F1);
+        const int t1 = (int)((pos / F1) % T1);
+        const int b = (int)(pos / ((long)F1 * T1));
+        // gather the activation gradient
+        float da[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) da[j] = 0.f;
+        for (int kh = 0; kh < K2; ++kh) {
+            const int nt = t1 + pad2_t - kh;
+            if (nt < 0 || (nt % stride2) != 0) continue;
+            const int t2 = nt / stride2;
+            if (t2 >= T2) continue;
+            for (int kw = 0; kw < K2; ++kw) {
+                const int nf = f1 + pad2_f - kw;
+                if (nf < 0 || (nf % stride2) != 0) continue;
+                const int f2 = nf / stride2;
+                if (f2 >= F2) continue;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(dcol + (((long)b * T2 + t2) * F2 + f2) * ldcol + (long)(kh * K2 + kw) * C + g * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) da[j] += bf2f(v[j]);
+            }
+        }
+        float xv[9];
+        const float* xb = x + (long)b * T * F;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int t = t1 * stride - pad_t + kh;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int f = f1 * stride - pad_f + kw;
+                xv[kh * 3 + kw] = (t >= 0 && t < T && f >= 0 && f < F) ? xb[(long)t * F + f] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float pre = br[j];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) pre = fmaf(xv[tap], wr[tap][j], pre);
+            const float dpre = da[j] * gelu_erf_grad(pre);
+            gbr[j] += dpre;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) gwr[tap][j] = fmaf(dpre, xv[tap], gwr[tap][j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = g * 8 + j;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) atomicAdd(sacc + ch * 10 + tap, gwr[tap][j]);
+        atomicAdd(sacc + ch * 10 + 9, gbr[j]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 10; i += 256) {
+        const int ch = i / 10, tap = i % 10;
+        if (tap == 9) atomic_add_f32(db + ch, sacc[i]);
+        else atomic_add_f32(dw + ch * 9 + tap, sacc[i]);
+    }
+}
+
+int grid_for(long n, int cap) { const long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > cap ? cap : g)); }
+
+int dw_bwd_launch(const DwBwdArgs& a, bool csgu, hipStream_t st) {
+    if (a.B <= 0 || a.T <= 0 || a.C <= 0 || a.K <= 0 || a.K > DB_KMAX || a.pad_left < 0 || a.pad_left > a.K - 1) return MI_ERR_ARG;
+    const int rows = DB_TT + a.K - 1;
+    const size_t lds = (size_t)(2 * rows * DB_CT + DB_KMAX * DB_CT + 4 * (DB_KMAX + 1) * DB_CT) * sizeof(float);
+    dim3 grid(cdiv(a.C, DB_CT), a.B);
+    if (csgu) hipLaunchKernelGGL(dwconv_bwd_kernel<true>, grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(dwconv_bwd_kernel<false>, grid, dim3(256), lds, st, a);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+}  // namespace
+
+// CSGU backward (identity activation, dilation 1): u (B*T, 2C) = [x_r | x_g], ds = gradient of x_r * (dwconv(LN(x_g)) + b)
+//   -> dr (B*T, C) = ds * conv,  dgn (B*T, C) = gradient w.r.t. LN(x_g),  dw (C,K) +=, db (C) +=
+extern "C" int mi_csgu_bwd_bf16(const void* u, long ldu, const float* stats, const float* gamma, const float* beta, const float* w,
+                                const float* bias, const void* ds, long ldds, void* dr, long lddr, void* dgn, long lddgn,
+                                float* dw, float* db, int B, int T, int C, int K, int pad_left, hipStream_t st) {
+    MI_ENTER();
+    DwBwdArgs a{};
+    a.x = (const bf16_t*)u + C; a.ldx = ldu; a.r = (const bf16_t*)u; a.ldr = ldu; a.stats = stats; a.gamma = gamma; a.beta = beta;
+    a.dy = (const bf16_t*)ds; a.lddy = ldds; a.w = w; a.bias = bias; a.dx = (bf16_t*)dgn; a.lddx = lddgn; a.dr = (bf16_t*)dr; a.lddr = lddr;
+    a.dw = dw; a.db = db; a.B = B; a.T = T; a.C = C; a.K = K; a.pad_left = pad_left;
+    return dw_bwd_launch(a, true, st);
+}
+
+// merge-block backward: y = m + dwconv(m) + b  ->  dm = dy + conv^T(dy),  dw +=, db +=
+extern "C" int mi_dwconv_residual_bwd_bf16(const void* m, long ldm, const float* w, const void* dy, long lddy, void* dm, long lddm,
+                                           float* dw, float* db, int B, int T, int C, int K, int pad_left, hipStream_t st) {
+    MI_ENTER();
+    DwBwdArgs a{};
+    a.x = (const bf16_t*)m; a.ldx = ldm; a.dy = (const bf16_t*)dy; a.lddy = lddy; a.w = w; a.dx = (bf16_t*)dm; a.lddx = lddm;
+    a.dw = dw; a.db = db; a.B = B; a.T = T; a.C = C; a.K = K; a.pad_left = pad_left;
+    return dw_bwd_launch(a, false, st);
+}
+
+extern "C" int mi_im2col_cl_bf16(const void* in, void* col, int B, int Tin, int Fin, int Cin, int KH, int KW, int stride, int pad_t,
+                                 int pad_f, int Tout, int Fout, hipStream_t st) {
+    MI_ENTER();
+    if (B <= 0 || Cin <= 0 || (Cin % 8) != 0 || Tout <= 0 || Fout <= 0) return MI_ERR_ARG;
+    const long total = (long)B * Tout * Fout * KH * KW * (Cin / 8);
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total, 65536)), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)col, B, Tin, Fin, Cin, KH, KW,
+                       stride, pad_t, pad_f, Tout, Fout);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// x (B,T,F) f32, w (C,9), bias (C); dcol (B*T2*F2, K2*K2*C) bf16 = gradient of conv2's im2col operand -> dw (C,9) +=, db (C) +=
+extern "C" int mi_conv2d_first_bwd(const float* x, const float* w, const float* bias, const void* dcol, float* dw, float* db,
+                                   int B, int T, int F, int C, int K, int stride, int pad_t, int pad_f, int T1, int F1,
+                                   int K2, int stride2, int pad2_t, int pad2_f, int T2, int F2, hipStream_t st) {
+    MI_ENTER();
+    const int cgs = C / 8;
+    if (B <= 0 || K != 3 || (C % 8) != 0 || cgs > 256 || stride2 <= 0) return MI_ERR_UNSUPPORTED;
+    const long npos = (long)B * T1 * F1;
+    const int ppb = 256 / cgs;
+    const long nb = (npos + ppb - 1) / ppb;
+    const size_t lds = (size_t)C * 10 * sizeof(float);
+    hipLaunchKernelGGL(conv1_bwd3_kernel, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), lds, st, x, w, bias, (const bf16_t*)dcol, dw, db,
+                       B, T, F, C, stride, pad_t, pad_f, T1, F1, K2, stride2, pad2_t, pad2_f, T2, F2);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}

@@ -1,0 +1,240 @@
+// Loss gradients on gfx950 (training step):
+//   * CTC (e_branchformer.py:472-488, F.ctc_loss): alpha/beta recursions per utterance, then
+//       dlogit[t,c] = scale_b * ( softmax(logits)[t,c] - exp(logsum_{s: l'_s = c}(alpha_t(s) + beta_t(s)) + nll_b - lp[t,c]) )
+//     (the gradient torch's ctc_loss_backward composes with log_softmax), zero for t >= input length,
+//   * label-smoothed cross entropy of the decoder heads (multi_head_gpt2.py:138-158, CrossEntropyLoss(label_smoothing)),
+//   * token / position embedding scatter (embeddings.py:33-62, GPT-2 wte / wpe).
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float lse3f(float a, float b, float c) {
+    const float m = fmaxf(a, fmaxf(b, c));
+    if (m == -INFINITY) return -INFINITY;
+    return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+}
+
+// one block per utterance: alpha forward (stored), beta backward, per-state contributions
+//   contrib[b][t][s] = -scale_b * exp(alpha_t(s) + beta_t(s) + nll_b - lp_t(s));   meta[b] = {tl, Tb, scale_b as float bits}
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const T* __restrict__ logits, long ld_b, long ld_t, const float* __restrict__ lse,
+                                                              int Tmax, const long* __restrict__ labels, int U, const int* __restrict__ in_len,
+                                                              int blank, const float* __restrict__ nll, int reduction, int B, float gscale,
+                                                              float* __restrict__ alpha_ws, float* __restrict__ contrib,
+                                                              int* __restrict__ ext_ws, int* __restrict__ meta) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int S_max = 2 * U + 1;
+    int* hdr = reinterpret_cast<int*>(smem);          // [4]
+    int* ext = hdr + 4;                               // [S_max]
+    float* buf = reinterpret_cast<float*>(ext + S_max);   // [2][S_max]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int n = 0;
+        for (int u = 0; u < U; ++u) {
+            const long v = labels[(long)b * U + u];
+            if (v >= 0) { ext[2 * n + 1] = (int)v; ++n; }
+        }
+        for (int s = 0; s <= 2 * n; s += 2) ext[s] = blank;
+        hdr[0] = n;
+    }
+    __syncthreads();
+    const int tl = hdr[0], S = 2 * tl + 1;
+    const int Tb = min(in_len[b], Tmax);
+    const float nl = nll[b];
+    float scale = (reduction == 1) ? gscale / ((float)max(tl, 1) * (float)B) : gscale;
+    if (!isfinite(nl) || Tb <= 0) scale = 0.f;        // infeasible alignment: zero gradient (zero_infinity semantics)
+    for (int s = tid; s < S; s += 256) ext_ws[(long)b * S_max + s] = ext[s];
+    if (tid == 0) { meta[3 * b] = tl; meta[3 * b + 1] = Tb; meta[3 * b + 2] = __float_as_int(scale); }
+    if (scale == 0.f) return;
+    const T* lg = logits + (long)b * ld_b;
+    const float* ls = lse + (long)b * Tmax;
+    float* aw = alpha_ws + (long)b * Tmax * S_max;
+    float* cw = contrib + (long)b * Tmax * S_max;
+    // ---- alpha
+    for (int s = tid; s < S; s += 256) {
+        const float v = (s < 2) ? (float)lg[ext[s]] - ls[0] : -INFINITY;
+        buf[s] = v; aw[s] = v;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int t = 1; t < Tb; ++t) {
+        const float* a = buf + cur * S_max;
+        float* an = buf + (cur ^ 1) * S_max;
+        const T* lt = lg + (long)t * ld_t;
+        const float l0 = ls[t];
+        for (int s = tid; s < S; s += 256) {
+            const bool skip = s >= 2 && ext[s] != blank && ext[s] != ext[s - 2];
+            const float v = lse3f(a[s], s >= 1 ? a[s - 1] : -INFINITY, skip ? a[s - 2] : -INFINITY) + ((float)lt[ext[s]] - l0);
+            an[s] = v; aw[(long)t * S_max + s] = v;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // ---- beta (buf reused)
+    {
+        const int t = Tb - 1;
+        const T* lt = lg + (long)t * ld_t;
+        for (int s = tid; s < S; s += 256) {
+            const float lp = (float)lt[ext[s]] - ls[t];
+            const float v = (s >= S - 2) ? lp : -INFINITY;
+            buf[s] = v;
+            cw[(long)t * S_max + s] = -scale * __expf(aw[(long)t * S_max + s] + v + nl - lp);
+        }
+        __syncthreads();
+    }
+    cur = 0;
+    for (int t = Tb - 2; t >= 0; --t) {
+        const float* bt = buf + cur * S_max;
+        float* bn = buf + (cur ^ 1) * S_max;
+        const T* lt = lg + (long)t * ld_t;
+        const float l0 = ls[t];
+        for (int s = tid; s < S; s += 256) {
+            const bool skip = s + 2 < S && ext[s + 2] != blank && ext[s + 2] != ext[s];
+            const float lp = (float)lt[ext[s]] - l0;
+            const float v = lse3f(bt[s], s + 1 < S ? bt[s + 1] : -INFINITY, skip ? bt[s + 2] : -INFINITY) + lp;
+            bn[s] = v;
+            cw[(long)t * S_max + s] = -scale * __expf(aw[(long)t * S_max + s] + v + nl - lp);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// one block per (b, t) row: dense softmax part + scatter of the per-state contributions -> bf16 gradient row (pad columns zero)
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_grad_rows_kernel(const T* __restrict__ logits, long ld_b, long ld_t, const float* __restrict__ lse,
+                                                             int Tmax, int U, int V1, const float* __restrict__ contrib,
+                                                             const int* __restrict__ ext_ws, const int* __restrict__ meta,
+                                                             bf16_t* __restrict__ out, long ldo) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* row = reinterpret_cast<float*>(smem);      // [V1]
+    const int b = blockIdx.x / Tmax, t = blockIdx.x % Tmax, tid = threadIdx.x;
+    const int S_max = 2 * U + 1;
+    const int tl = meta[3 * b], Tb = meta[3 * b + 1];
+    const float scale = __int_as_float(meta[3 * b + 2]);
+    bf16_t* o = out + ((long)b * Tmax + t) * ldo;
+    if (t >= Tb || scale == 0.f) {
+        for (int c = tid; c < ldo; c += 256) o[c] = (bf16_t)0.f;
+        return;
+    }
+    const T* lt = logits + (long)b * ld_b + (long)t * ld_t;
+    const float l0 = lse[(long)b * Tmax + t];
+    for (int c = tid; c < V1; c += 256) row[c] = scale * __expf((float)lt[c] - l0);
+    __syncthreads();
+    const int S = 2 * tl + 1;
+    const float* cw = contrib + ((long)b * Tmax + t) * S_max;
+    const int* ext = ext_ws + (long)b * S_max;
+    for (int s = tid; s < S; s += 256) atomicAdd(row + ext[s], cw[s]);
+    __syncthreads();
+    for (int c = tid; c < ldo; c += 256) o[c] = (c < V1) ? f2bf(row[c]) : (bf16_t)0.f;
+}
+
+// d/dlogits of  weight * mean_valid( (1-eps) nll + eps * (-mean_c logp) ),  target of row (b,u) = labels[b, u+shift]
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, long ld, const long* __restrict__ labels, int B, int U,
+                                                      int shift, int V, float eps, float weight, const float* __restrict__ acc /* [sum, count] */,
+                                                      bf16_t* __restrict__ out, long ldo) {
+    __shared__ float red[8];
+    const int rowi = blockIdx.x, b = rowi / U, u = rowi % U, tid = threadIdx.x;
+    bf16_t* o = out + (long)rowi * ldo;
+    const long tgt = (u + shift < U) ? labels[(long)b * U + u + shift] : -100;
+    const float cnt = acc[1];
+    if (tgt < 0 || cnt <= 0.f) {
+        for (int c = tid; c < ldo; c += 256) o[c] = (bf16_t)0.f;
+        return;
+    }
+    const float* x = logits + (long)rowi * ld;
+    float mx = -INFINITY;
+    for (int c = tid; c < V; c += 256) mx = fmaxf(mx, x[c]);
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float s = 0.f;
+    for (int c = tid; c < V; c += 256) s += __expf(x[c] - mx);
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = s;
+    __syncthreads();
+    s = red[4] + red[5] + red[6] + red[7];
+    const float inv = 1.f / s, k = weight / cnt, sm = eps / V;
+    for (int c = tid; c < ldo; c += 256) {
+        float g = 0.f;
+        if (c < V) g = k * (__expf(x[c] - mx) * inv - sm - ((c == tgt) ? (1.f - eps) : 0.f));
+        o[c] = f2bf(g);
+    }
+}
+
+// dwte[ids[m]] += scale * dx[m];  dwpe[pos_offset + m % U] += dx[m]  (learned positions only)
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long* __restrict__ ids, const float* __restrict__ dx, float scale, int pos_offset,
+                                                         int U, int d, int M, int V, float* __restrict__ dwte, float* __restrict__ dwpe) {
+    const long total = (long)M * d;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / d), c = (int)(i % d);
+        const long id = ids[m];
+        const float g = dx[i];
+        if (id >= 0 && id < V) atomic_add_f32(dwte + id * d + c, scale * g);
+        if (dwpe) atomic_add_f32(dwpe + (long)(pos_offset + m % U) * d + c, g);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t mi_ctc_bwd_workspace_bytes(int B, int T, int U) {
+    const size_t S = 2 * (size_t)U + 1;
+    return 2 * (size_t)B * T * S * sizeof(float) + (size_t)B * S * sizeof(int) + (size_t)3 * B * sizeof(int) + 1024;
+}
+
+// logits (B,T,V1) f32 (dtype 0) | bf16 (1) with strides; lse (B*T) and nll (B) from mi_row_lse / mi_ctc_loss_fwd;
+// dlogits (B*T, ldo) bf16, ldo >= V1 (pad columns zeroed); gscale = upstream gradient of the reduced loss (e.g. ctc_weight)
+extern "C" int mi_ctc_loss_bwd(const void* logits, long ld_b, long ld_t, int dtype, const float* lse, int T, const long* labels, int U,
+                               const int* in_len, int blank, int B, int reduction, const float* nll, float gscale, void* workspace,
+                               size_t workspace_bytes, void* dlogits, long ldo, hipStream_t st) {
+    MI_ENTER();
+    const int V1 = blank + 1;
+    if (B <= 0 || T <= 0 || U < 0 || ldo < V1 || dtype < 0 || dtype > 1) return MI_ERR_ARG;
+    if (workspace_bytes < mi_ctc_bwd_workspace_bytes(B, T, U)) return MI_ERR_ARG;
+    const size_t S = 2 * (size_t)U + 1;
+    float* alpha_ws = (float*)workspace;
+    float* contrib = alpha_ws + (size_t)B * T * S;
+    int* ext_ws = (int*)(contrib + (size_t)B * T * S);
+    int* meta = ext_ws + (size_t)B * S;
+    const size_t lds = (4 + S) * sizeof(int) + 2 * S * sizeof(float);
+    const size_t lds_rows = (size_t)V1 * sizeof(float);
+    if (lds > 150 * 1024 || lds_rows > 150 * 1024) return MI_ERR_UNSUPPORTED;
+    if (dtype == 0) {
+        hipLaunchKernelGGL(ctc_alpha_beta_kernel<float>, dim3(B), dim3(256), lds, st, (const float*)logits, ld_b, ld_t, lse, T, labels, U, in_len,
+                           blank, nll, reduction, B, gscale, alpha_ws, contrib, ext_ws, meta);
+        hipLaunchKernelGGL(ctc_grad_rows_kernel<float>, dim3(B * T), dim3(256), lds_rows, st, (const float*)logits, ld_b, ld_t, lse, T, U, V1,
+                           contrib, ext_ws, meta, (bf16_t*)dlogits, ldo);
+    } else {
+        hipLaunchKernelGGL(ctc_alpha_beta_kernel<bf16_t>, dim3(B), dim3(256), lds, st, (const bf16_t*)logits, ld_b, ld_t, lse, T, labels, U, in_len,
+                           blank, nll, reduction, B, gscale, alpha_ws, contrib, ext_ws, meta);
+        hipLaunchKernelGGL(ctc_grad_rows_kernel<bf16_t>, dim3(B * T), dim3(256), lds_rows, st, (const bf16_t*)logits, ld_b, ld_t, lse, T, U, V1,
+                           contrib, ext_ws, meta, (bf16_t*)dlogits, ldo);
+    }
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// logits (B,U,V) f32 rows of stride ld; acc = [sum, count] written by mi_ce_label_smoothing; dlogits (B*U, ldo) bf16
+extern "C" int mi_ce_label_smoothing_bwd(const float* logits, long ld, const long* labels, int B, int U, int shift, int V, float eps,
+                                         float weight, const float* acc, void* dlogits, long ldo, hipStream_t st) {
+    MI_ENTER();
+    if (B <= 0 || U <= 0 || V <= 0 || ldo < V) return MI_ERR_ARG;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(B * U), dim3(256), 0, st, logits, ld, labels, B, U, shift, V, eps, weight, acc, (bf16_t*)dlogits, ldo);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+extern "C" int mi_embed_tokens_bwd(const long* ids, const float* dx, float scale, int pos_offset, int U, int d, int M, int V, float* dwte,
+                                   float* dwpe, hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || d <= 0 || U <= 0) return MI_ERR_ARG;
+    const long total = (long)M * d;
+    const long g = (total + 255) / 256;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, st, ids, dx, scale, pos_offset, U, d, M, V, dwte, dwpe);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}

@@ -1,0 +1,410 @@
+// Backward / optimizer building blocks of the training step on gfx950.
+//
+// Reference: the training step the reference delegates to torch autograd + HF Trainer (bf16 autocast, fp32 master weights,
+// AdamW, clip 1.0 — src/utilities/training_utils.py:93-115, recipes .../train_small_baseline.sh:43,53-58).  Autograd has no
+// source to restate: every kernel here is the analytic gradient of the forward kernel it is paired with, checked against
+// torch autograd of the CPU oracle in tests/.
+//
+// Conventions: activations bf16 (row-major, leading dimension in elements), residual stream / parameter gradients fp32.
+// Parameter gradients ACCUMULATE (+=, float atomics at block granularity): the step zeroes the flat gradient buffer once.
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------------------------------------ transpose
+// in (M,N) bf16 -> out (N, Mp) bf16 with columns M..Mp-1 zero (Mp = K extent of the weight-gradient GEMM, % 64 == 0)
+constexpr int TR = 64;
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, long ld_in, bf16_t* __restrict__ out,
+                                                         long ld_out, int M, int N, int Mp) {
+    __shared__ bf16_t tile[TR][TR + 2];
+    const int m0 = blockIdx.y * TR, n0 = blockIdx.x * TR;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < TR; r += 4) {
+        const int m = m0 + r, n = n0 + tx;
+        tile[r][tx] = (m < M && n < N) ? in[(long)m * ld_in + n] : (bf16_t)0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < TR; r += 4) {
+        const int n = n0 + r, m = m0 + tx;
+        if (n < N && m < Mp) out[(long)n * ld_out + m] = tile[tx][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ column sums (bias grads)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long ld, int M, int N, float* __restrict__ out,
+                                                      int rows_per_block) {
+    __shared__ float part[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + tx;
+    const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    float s = 0.f;
+    if (n < N)
+        for (int m = m0 + ty; m < m1; m += 4) s += (float)x[(long)m * ld + n];
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && n < N) atomic_add_f32(out + n, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+}
+
+// ------------------------------------------------------------------------------------------------ activations
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.f + fast_erf(x * 0.70710678118654752440f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ float gelu_tanh_grad(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float u = k0 * (x + k1 * x * x * x);
+    const float e = __expf(2.f * u);
+    const float th = 1.f - 2.f / (e + 1.f);
+    return 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * k0 * (1.f + 3.f * k1 * x * x);
+}
+
+// MODE 0: out = act(a);  MODE 1: out = a * act'(b)   (a = dy, b = pre-activation);  kind 1 erf-GELU, 2 tanh-GELU
+template <int MODE>
+__global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ a, long lda, const bf16_t* __restrict__ b, long ldb,
+                                                   bf16_t* __restrict__ out, long ldo, int M, int N8, int kind) {
+    const long total = (long)M * N8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / N8), c = (int)(i % N8) * 8;
+        const bf16x8 va = *reinterpret_cast<const bf16x8*>(a + (long)m * lda + c);
+        bf16x8 vb = va, o;
+        if (MODE == 1) vb = *reinterpret_cast<const bf16x8*>(b + (long)m * ldb + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (MODE == 0) {
+                const float x = bf2f(va[j]);
+                o[j] = f2bf(kind == 1 ? gelu_erf(x) : gelu_tanh(x));
+            } else {
+                const float x = bf2f(vb[j]);
+                o[j] = f2bf(bf2f(va[j]) * (kind == 1 ? gelu_erf_grad(x) : gelu_tanh_grad(x)));
+            }
+        }
+        *reinterpret_cast<bf16x8*>(out + (long)m * ldo + c) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm backward
+// one wave per row, columns c = lane + 64 j;  dx (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+template <int NJ>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x, long ldx, int x_bf16, const float* __restrict__ gamma,
+                                                      float eps, const void* __restrict__ dy, long lddy, int dy_f32,
+                                                      void* __restrict__ dx, long lddx, int dx_bf16, int accumulate,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int d,
+                                                      int rows_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sg = reinterpret_cast<float*>(smem);          // [d] dgamma partial, [d] dbeta partial
+    float* sb = sg + d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 2 * d; i += 256) sg[i] = 0.f;
+    __syncthreads();
+    float gm[NJ], ag[NJ], ab[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = lane + 64 * j;
+        gm[j] = (c < d) ? gamma[c] : 0.f;
+        ag[j] = 0.f; ab[j] = 0.f;
+    }
+    const long r0 = ((long)blockIdx.x * 4 + wave) * rows_per_wave;
+    const float inv_d = 1.f / d;
+    for (int i = 0; i < rows_per_wave; ++i) {
+        const long r = r0 + i;
+        if (r >= M) break;
+        float xv[NJ], gv[NJ];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = lane + 64 * j;
+            float v = 0.f, g = 0.f;
+            if (c < d) {
+                v = x_bf16 ? bf2f(reinterpret_cast<const bf16_t*>(x)[r * ldx + c]) : reinterpret_cast<const float*>(x)[r * ldx + c];
+                g = dy_f32 ? reinterpret_cast<const float*>(dy)[r * lddy + c] : bf2f(reinterpret_cast<const bf16_t*>(dy)[r * lddy + c]);
+            }
+            xv[j] = v; gv[j] = g; s += v;
+        }
+        const float mean = wave_sum(s) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = lane + 64 * j;
+            const float a = (c < d) ? xv[j] - mean : 0.f;
+            xv[j] = a; q += a * a;
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            xv[j] *= rstd;                        // xhat
+            ag[j] += gv[j] * xv[j];
+            ab[j] += gv[j];
+            gv[j] *= gm[j];                       // g = dy * gamma
+            s1 += gv[j]; s2 += gv[j] * xv[j];
+        }
+        s1 = wave_sum(s1) * inv_d; s2 = wave_sum(s2) * inv_d;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = lane + 64 * j;
+            if (c >= d) continue;
+            float v = rstd * (gv[j] - s1 - xv[j] * s2);
+            if (dx_bf16) {
+                bf16_t* p = reinterpret_cast<bf16_t*>(dx) + r * lddx + c;
+                if (accumulate) v += bf2f(*p);
+                *p = f2bf(v);
+            } else {
+                float* p = reinterpret_cast<float*>(dx) + r * lddx + c;
+                if (accumulate) v += *p;
+                *p = v;
+            }
+        }
+    }
+    if (dgamma) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = lane + 64 * j;
+            if (c < d) { atomicAdd(sg + c, ag[j]); atomicAdd(sb + c, ab[j]); }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < d; c += 256) { atomic_add_f32(dgamma + c, sg[c]); atomic_add_f32(dbeta + c, sb[c]); }
+    }
+}
+
+// y = LN(x) with precomputed (mean, rstd) per row: the CSGU gate normalisation re-materialised for the backward pass
+__global__ __launch_bounds__(256) void ln_apply_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ stats,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        bf16_t* __restrict__ y, long ldy, int M, int N) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / N), c = (int)(i % N);
+        y[(long)m * ldy + c] = f2bf((bf2f(x[(long)m * ldx + c]) - stats[2 * m]) * stats[2 * m + 1] * gamma[c] + beta[c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ small element-wise ops
+__global__ __launch_bounds__(256) void add_f32_kernel(float* __restrict__ a, const float* __restrict__ b, long n, float alpha) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a[i] += alpha * b[i];
+}
+__global__ __launch_bounds__(256) void scale_f32_kernel(float* __restrict__ a, long n, float alpha) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a[i] *= alpha;
+}
+// out = bf16(alpha * (a [+ b])) on (M,N) views
+__global__ __launch_bounds__(256) void add2_cast_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
+                                                         bf16_t* __restrict__ out, long ldo, int M, int N, float alpha) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / N), c = (int)(i % N);
+        float v = a[(long)m * lda + c];
+        if (b) v += b[(long)m * ldb + c];
+        out[(long)m * ldo + c] = f2bf(alpha * v);
+    }
+}
+// out = bf16(x + vec[c])   (q + pos_bias_u / pos_bias_v, flattened (H*hd) vector)
+__global__ __launch_bounds__(256) void add_rowvec_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ vec,
+                                                          bf16_t* __restrict__ out, long ldo, int M, int N) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / N), c = (int)(i % N);
+        out[(long)m * ldo + c] = f2bf(bf2f(x[(long)m * ldx + c]) + vec[c]);
+    }
+}
+// gating backward of s = r * c:  dr = ds * c,  dc = ds * r
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* __restrict__ ds, long ldds, const bf16_t* __restrict__ c, long ldc,
+                                                        const bf16_t* __restrict__ r, long ldr, bf16_t* __restrict__ dr, long lddr,
+                                                        bf16_t* __restrict__ dc, long lddc, int M, int N) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        const float g = bf2f(ds[(long)m * ldds + n]);
+        dr[(long)m * lddr + n] = f2bf(g * bf2f(c[(long)m * ldc + n]));
+        dc[(long)m * lddc + n] = f2bf(g * bf2f(r[(long)m * ldr + n]));
+    }
+}
+// zero the rows of padded frames: row (b, t) with t >= lengths[b]
+__global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, long ld, const int* __restrict__ lengths, int T, int M, int N) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / N), c = (int)(i % N);
+        if ((m % T) >= lengths[m / T]) x[(long)m * ld + c] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ optimizer
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    __shared__ float part[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += x[i] * x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomic_add_f32(out, part[0] + part[1] + part[2] + part[3]);
+}
+// norm = sqrt(sumsq); coef = min(1, max_norm / (norm + 1e-6))  (torch.nn.utils.clip_grad_norm_); non-finite norm -> coef 0 (step skipped)
+__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* out /* [norm, coef] */) {
+    const float norm = sqrtf(sumsq[0]);
+    float coef = 1.f;
+    if (max_norm > 0.f) coef = fminf(1.f, max_norm / (norm + 1e-6f));
+    if (!isfinite(norm)) coef = 0.f;
+    out[0] = norm; out[1] = coef;
+}
+// torch.optim.AdamW (decoupled weight decay) on the flat fp32 master buffer; also refreshes the bf16 mirror the GEMMs read
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                     float* __restrict__ v, const unsigned char* __restrict__ decay, long n,
+                                                     float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
+                                                     const float* __restrict__ clip /* [norm, coef] or null */, bf16_t* __restrict__ mirror) {
+    const float coef = clip ? clip[1] : 1.f;
+    const bool skip = clip && !isfinite(clip[0]);
+    const float step = lr / bc1, rs2 = rsqrtf(bc2);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float pv = p[i];
+        if (!skip) {
+            const float gi = g[i] * coef;
+            const float mi = b1 * m[i] + (1.f - b1) * gi;
+            const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+            m[i] = mi; v[i] = vi;
+            if (!decay || decay[i]) pv *= (1.f - lr * wd);
+            pv -= step * mi / (sqrtf(vi) * rs2 + eps);
+            p[i] = pv;
+        }
+        if (mirror) mirror[i] = f2bf(pv);
+    }
+}
+
+int grid_for(long n) { const long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g)); }
+
+}  // namespace
+
+extern "C" int mi_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int M, int N, int Mp, hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || N <= 0 || Mp < M || ld_out < Mp) return MI_ERR_ARG;
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(N, TR), cdiv(Mp, TR)), dim3(256), 0, st, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, M, N, Mp);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// out[n] += sum_m x[m,n];  dtype 0 f32, 1 bf16
+extern "C" int mi_colsum(const void* x, long ld, int dtype, int M, int N, float* out, hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || N <= 0) return MI_ERR_ARG;
+    const int rpb = 128;
+    dim3 grid(cdiv(N, 64), cdiv(M, rpb));
+    if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ld, M, N, out, rpb);
+    else if (dtype == 1) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ld, M, N, out, rpb);
+    else return MI_ERR_ARG;
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// kind 1 erf-GELU (ACT2FN["gelu"]), 2 tanh-GELU (gelu_new)
+extern "C" int mi_act_fwd_bf16(const void* pre, long ldp, void* out, long ldo, int M, int N, int kind, hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || N <= 0 || (N % 8) || (ldp % 8) || (ldo % 8) || (kind != 1 && kind != 2)) return MI_ERR_ARG;
+    hipLaunchKernelGGL(act_kernel<0>, dim3(grid_for((long)M * N / 8)), dim3(256), 0, st, (const bf16_t*)pre, ldp, (const bf16_t*)nullptr, 0L, (bf16_t*)out, ldo, M, N / 8, kind);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+extern "C" int mi_act_bwd_bf16(const void* dy, long lddy, const void* pre, long ldp, void* dx, long lddx, int M, int N, int kind, hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || N <= 0 || (N % 8) || (ldp % 8) || (lddy % 8) || (lddx % 8) || (kind != 1 && kind != 2)) return MI_ERR_ARG;
+    hipLaunchKernelGGL(act_kernel<1>, dim3(grid_for((long)M * N / 8)), dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)pre, ldp, (bf16_t*)dx, lddx, M, N / 8, kind);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+extern "C" int mi_layernorm_bwd(const void* x, long ldx, int x_bf16, const float* gamma, float eps, const void* dy, long lddy, int dy_f32,
+                                void* dx, long lddx, int dx_bf16, int accumulate, float* dgamma, float* dbeta, int M, int d, hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || d <= 0 || d > 2048 || !gamma) return MI_ERR_ARG;
+    const int rpw = 16;
+    const int grid = cdiv(M, 4 * rpw);
+    const size_t lds = (size_t)2 * d * sizeof(float);
+    const int nj = cdiv(d, 64);
+#define LN_BWD(NJ) hipLaunchKernelGGL(ln_bwd_kernel<NJ>, dim3(grid), dim3(256), lds, st, x, ldx, x_bf16, gamma, eps, dy, lddy, dy_f32, dx, lddx, dx_bf16, accumulate, dgamma, dbeta, M, d, rpw)
+    if (nj <= 1) LN_BWD(1); else if (nj <= 2) LN_BWD(2); else if (nj <= 4) LN_BWD(4); else if (nj <= 8) LN_BWD(8);
+    else if (nj <= 16) LN_BWD(16); else LN_BWD(32);
+#undef LN_BWD
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+extern "C" int mi_ln_apply_bf16(const void* x, long ldx, const float* stats, const float* gamma, const float* beta, void* y, long ldy,
+                                int M, int N, hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || N <= 0) return MI_ERR_ARG;
+    hipLaunchKernelGGL(ln_apply_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, st, (const bf16_t*)x, ldx, stats, gamma, beta, (bf16_t*)y, ldy, M, N);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+extern "C" int mi_axpy_f32(float* a, const float* b, long n, float alpha, hipStream_t st) {
+    MI_ENTER();
+    if (n <= 0) return MI_ERR_ARG;
+    hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n)), dim3(256), 0, st, a, b, n, alpha);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+extern "C" int mi_scale_f32(float* a, long n, float alpha, hipStream_t st) {
+    MI_ENTER();
+    if (n <= 0) return MI_ERR_ARG;
+    hipLaunchKernelGGL(scale_f32_kernel, dim3(grid_for(n)), dim3(256), 0, st, a, n, alpha);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+extern "C" int mi_add2_cast_bf16(const float* a, long lda, const float* b, long ldb, void* out, long ldo, int M, int N, float alpha, hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || N <= 0) return MI_ERR_ARG;
+    hipLaunchKernelGGL(add2_cast_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, st, a, lda, b, ldb, (bf16_t*)out, ldo, M, N, alpha);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+extern "C" int mi_add_rowvec_bf16(const void* x, long ldx, const float* vec, void* out, long ldo, int M, int N, hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || N <= 0) return MI_ERR_ARG;
+    hipLaunchKernelGGL(add_rowvec_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, st, (const bf16_t*)x, ldx, vec, (bf16_t*)out, ldo, M, N);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+extern "C" int mi_gate_bwd_bf16(const void* ds, long ldds, const void* c, long ldc, const void* r, long ldr, void* dr, long lddr,
+                                void* dc, long lddc, int M, int N, hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || N <= 0) return MI_ERR_ARG;
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, st, (const bf16_t*)ds, ldds, (const bf16_t*)c, ldc,
+                       (const bf16_t*)r, ldr, (bf16_t*)dr, lddr, (bf16_t*)dc, lddc, M, N);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+extern "C" int mi_mask_rows_f32(float* x, long ld, const int* lengths, int T, int M, int N, hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || N <= 0 || T <= 0 || !lengths) return MI_ERR_ARG;
+    hipLaunchKernelGGL(mask_rows_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, st, x, ld, lengths, T, M, N);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// sumsq[0] += sum x^2 (caller zeroes sumsq);  clip: out = [norm, coef]
+extern "C" int mi_sumsq_f32(const float* x, long n, float* sumsq, hipStream_t st) {
+    MI_ENTER();
+    if (n <= 0) return MI_ERR_ARG;
+    const int grid = grid_for(n) > 2048 ? 2048 : grid_for(n);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, st, x, n, sumsq);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+extern "C" int mi_clip_coef(const float* sumsq, float max_norm, float* norm_coef, hipStream_t st) {
+    MI_ENTER();
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, st, sumsq, max_norm, norm_coef);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+extern "C" int mi_adamw_step(float* p, const float* g, float* m, float* v, const unsigned char* decay, long n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int step, const float* norm_coef, void* mirror_bf16, hipStream_t st) {
+    MI_ENTER();
+    if (n <= 0 || step < 1) return MI_ERR_ARG;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, m, v, decay, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
+                       norm_coef, (bf16_t*)mirror_bf16);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}

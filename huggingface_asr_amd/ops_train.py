@@ -1,0 +1,224 @@
+"""torch-tensor wrappers over the training-step entry points of the C ABI (include/hfasr_hip.h, "training step" block).
+
+Same rules as ops.py: device tensors only, kernels run on torch.cuda.current_stream(), no CPU path.
+Parameter-gradient outputs (dgamma, dbeta, dw, db, colsum targets ...) ACCUMULATE into the tensors passed in.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib
+from .ops import BF16, _p, _req, _stream, gemm
+
+F32 = torch.float32
+
+
+def _L():
+    return _lib.lib()
+
+
+def pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+def transpose(x, Mp=None, out=None):
+    """x (M,N) bf16 (row stride free) -> (N, Mp) bf16, columns M..Mp zero."""
+    _req(x, BF16)
+    M, N = x.shape
+    Mp = pad64(M) if Mp is None else Mp
+    if out is None:
+        out = torch.empty((N, Mp), device=x.device, dtype=BF16)
+    _lib.check(_L().mi_transpose_bf16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), M, N, Mp, _stream()), "mi_transpose_bf16")
+    return out
+
+
+def colsum_(out, x):
+    """out (N) f32 += column sums of x (M,N) f32|bf16."""
+    M, N = x.shape
+    _lib.check(_L().mi_colsum(x.data_ptr(), x.stride(0), 0 if x.dtype == F32 else 1, M, N, out.data_ptr(), _stream()), "mi_colsum")
+
+
+KIND = {"gelu": 1, "gelu_new": 2}
+
+
+def act_fwd(pre, kind="gelu", out=None):
+    M, N = pre.shape
+    if out is None:
+        out = torch.empty((M, N), device=pre.device, dtype=BF16)
+    _lib.check(_L().mi_act_fwd_bf16(pre.data_ptr(), pre.stride(0), out.data_ptr(), out.stride(0), M, N, KIND[kind], _stream()), "mi_act_fwd_bf16")
+    return out
+
+
+def act_bwd(dy, pre, kind="gelu", out=None):
+    M, N = pre.shape
+    if out is None:
+        out = torch.empty((M, N), device=pre.device, dtype=BF16)
+    _lib.check(_L().mi_act_bwd_bf16(dy.data_ptr(), dy.stride(0), pre.data_ptr(), pre.stride(0), out.data_ptr(), out.stride(0), M, N,
+                                    KIND[kind], _stream()), "mi_act_bwd_bf16")
+    return out
+
+
+def layernorm_bwd(x, gamma, dy, dx, *, accumulate, dgamma=None, dbeta=None, eps=1e-5):
+    """dx (+)= dLN(x)/dx · dy ; dgamma/dbeta += .  x f32|bf16, dy f32|bf16, dx f32|bf16 (all (M,d) row views)."""
+    M, d = x.shape
+    _lib.check(_L().mi_layernorm_bwd(x.data_ptr(), x.stride(0), int(x.dtype == BF16), gamma.data_ptr(), float(eps),
+                                     dy.data_ptr(), dy.stride(0), int(dy.dtype == F32), dx.data_ptr(), dx.stride(0), int(dx.dtype == BF16),
+                                     int(accumulate), _p(dgamma), _p(dbeta), M, d, _stream()), "mi_layernorm_bwd")
+    return dx
+
+
+def axpy_(a, b, alpha=1.0):
+    """a += alpha * b (contiguous f32)."""
+    assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
+    _lib.check(_L().mi_axpy_f32(a.data_ptr(), b.data_ptr(), a.numel(), float(alpha), _stream()), "mi_axpy_f32")
+
+
+def scale_(a, alpha):
+    _lib.check(_L().mi_scale_f32(a.data_ptr(), a.numel(), float(alpha), _stream()), "mi_scale_f32")
+
+
+def add_cast(a, b=None, alpha=1.0, out=None):
+    """bf16(alpha * (a [+ b])) for f32 (M,N) views."""
+    M, N = a.shape
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=BF16)
+    _lib.check(_L().mi_add2_cast_bf16(a.data_ptr(), a.stride(0), _p(b), b.stride(0) if b is not None else 0, out.data_ptr(), out.stride(0),
+                                      M, N, float(alpha), _stream()), "mi_add2_cast_bf16")
+    return out
+
+
+def add_rowvec(x, vec, out=None):
+    M, N = x.shape
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=BF16)
+    _lib.check(_L().mi_add_rowvec_bf16(x.data_ptr(), x.stride(0), vec.data_ptr(), out.data_ptr(), out.stride(0), M, N, _stream()), "mi_add_rowvec_bf16")
+    return out
+
+
+def mask_rows_(x, lengths, T):
+    M, N = x.shape
+    _lib.check(_L().mi_mask_rows_f32(x.data_ptr(), x.stride(0), lengths.data_ptr(), T, M, N, _stream()), "mi_mask_rows_f32")
+
+
+def bgemm(A, a_str, B, b_str, C, c_str, Z1, Z2, M, N, K, *, alpha=1.0, accumulate=False):
+    """C[z1,z2][m][n] = alpha * sum_k A[..][m][k] B[..][n][k] (+C). a_str = (z1, z2, m, k) element strides, b_str = (z1, z2, n, k),
+    c_str = (z1, z2, m); A/B bf16 storage, C f32|bf16 with unit column stride."""
+    _lib.check(_L().mi_bgemm_bf16(A.data_ptr(), *[int(s) for s in a_str], B.data_ptr(), *[int(s) for s in b_str],
+                                  C.data_ptr(), *[int(s) for s in c_str], int(C.dtype == F32), int(accumulate), float(alpha),
+                                  Z1, Z2, M, N, K, _stream()), "mi_bgemm_bf16")
+    return C
+
+
+def attn_softmax_fwd(ac, bd, lengths, H, B, Tq, Tk, scale, causal=False):
+    prob = torch.empty((H, B, Tq, Tk), device=ac.device, dtype=BF16)
+    _lib.check(_L().mi_attn_softmax_fwd(ac.data_ptr(), _p(bd), _p(lengths), prob.data_ptr(), H, B, Tq, Tk, float(scale), int(causal), _stream()),
+               "mi_attn_softmax_fwd")
+    return prob
+
+
+def attn_softmax_bwd(prob, dp, H, B, Tq, Tk, scale, want_dbd=False):
+    ds = torch.empty((H, B, Tq, Tk), device=prob.device, dtype=BF16)
+    dbd = torch.empty((H, B, Tq, 2 * Tq - 1), device=prob.device, dtype=BF16) if want_dbd else None
+    _lib.check(_L().mi_attn_softmax_bwd(prob.data_ptr(), dp.data_ptr(), ds.data_ptr(), _p(dbd), H, B, Tq, Tk, float(scale), _stream()),
+               "mi_attn_softmax_bwd")
+    return ds, dbd
+
+
+def csgu_bwd(u, stats, gamma, beta, w, bias, ds, dr, dgn, dw, db, B, T):
+    M, C2 = u.shape
+    Cc = C2 // 2
+    K = w.shape[-1]
+    _lib.check(_L().mi_csgu_bwd_bf16(u.data_ptr(), u.stride(0), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), _p(bias),
+                                     ds.data_ptr(), ds.stride(0), dr.data_ptr(), dr.stride(0), dgn.data_ptr(), dgn.stride(0),
+                                     dw.data_ptr(), _p(db), B, T, Cc, K, (K - 1) // 2, _stream()), "mi_csgu_bwd_bf16")
+
+
+def dwconv_residual_bwd(m, w, dy, dm, dw, db, B, T):
+    M, Cc = m.shape
+    K = w.shape[-1]
+    _lib.check(_L().mi_dwconv_residual_bwd_bf16(m.data_ptr(), m.stride(0), w.data_ptr(), dy.data_ptr(), dy.stride(0), dm.data_ptr(), dm.stride(0),
+                                                dw.data_ptr(), _p(db), B, T, Cc, K, (K - 1) // 2, _stream()), "mi_dwconv_residual_bwd_bf16")
+
+
+def im2col(x, K, stride, pad, T1, F1):
+    B, T, F, Cin = x.shape
+    col = torch.empty((B * T1 * F1, K * K * Cin), device=x.device, dtype=BF16)
+    _lib.check(_L().mi_im2col_cl_bf16(x.data_ptr(), col.data_ptr(), B, T, F, Cin, K, K, stride, pad, pad, T1, F1, _stream()), "mi_im2col_cl_bf16")
+    return col
+
+
+def conv2d_first_bwd(x, w, bias, dcol, dw, db, K, stride, pad, T1, F1, K2, stride2, pad2, T2, F2):
+    B, T, F = x.shape
+    Cc = w.shape[0]
+    _lib.check(_L().mi_conv2d_first_bwd(x.data_ptr(), w.data_ptr(), bias.data_ptr(), dcol.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                        B, T, F, Cc, K, stride, pad, pad, T1, F1, K2, stride2, pad2, pad2, T2, F2, _stream()), "mi_conv2d_first_bwd")
+
+
+def ctc_loss_bwd(logits, lse, labels, in_len, nll, *, reduction="mean", gscale=1.0, ldo=None):
+    """-> dlogits (B*T, ldo) bf16 of gscale * ctc_loss(reduction), pad columns zero."""
+    B, T, V1 = logits.shape
+    labels = labels.contiguous()
+    U = labels.shape[1]
+    ldo = (V1 + 7) // 8 * 8 if ldo is None else ldo
+    nbytes = _L().mi_ctc_bwd_workspace_bytes(B, T, U)
+    ws = torch.empty(nbytes, device=logits.device, dtype=torch.uint8)
+    out = torch.empty((B * T, ldo), device=logits.device, dtype=BF16)
+    _lib.check(_L().mi_ctc_loss_bwd(logits.data_ptr(), logits.stride(0), logits.stride(1), 0 if logits.dtype == F32 else 1, lse.data_ptr(), T,
+                                    labels.data_ptr(), U, in_len.data_ptr(), V1 - 1, B, 1 if reduction == "mean" else 0, nll.data_ptr(),
+                                    float(gscale), ws.data_ptr(), nbytes, out.data_ptr(), ldo, _stream()), "mi_ctc_loss_bwd")
+    return out
+
+
+def ce_label_smoothing_bwd(logits, labels, acc, *, shift=1, eps=0.0, weight=1.0, ldo=None):
+    B, U, V = logits.shape
+    labels = labels.contiguous()
+    ldo = (V + 7) // 8 * 8 if ldo is None else ldo
+    out = torch.empty((B * U, ldo), device=logits.device, dtype=BF16)
+    _lib.check(_L().mi_ce_label_smoothing_bwd(logits.data_ptr(), logits.stride(1), labels.data_ptr(), B, U, shift, V, float(eps), float(weight),
+                                              acc.data_ptr(), out.data_ptr(), ldo, _stream()), "mi_ce_label_smoothing_bwd")
+    return out
+
+
+def embed_tokens_bwd(ids, dx, dwte, dwpe=None, *, scale=1.0, pos_offset=0):
+    ids = ids.contiguous()
+    M = ids.numel()
+    U = ids.shape[-1]
+    V, d = dwte.shape
+    _lib.check(_L().mi_embed_tokens_bwd(ids.data_ptr(), dx.data_ptr(), float(scale), pos_offset, U, d, M, V, dwte.data_ptr(), _p(dwpe), _stream()),
+               "mi_embed_tokens_bwd")
+
+
+def sumsq_(acc, x):
+    _lib.check(_L().mi_sumsq_f32(x.data_ptr(), x.numel(), acc.data_ptr(), _stream()), "mi_sumsq_f32")
+
+
+def clip_coef(sumsq, max_norm, out):
+    _lib.check(_L().mi_clip_coef(sumsq.data_ptr(), float(max_norm), out.data_ptr(), _stream()), "mi_clip_coef")
+
+
+def adamw_step_(p, g, m, v, decay, *, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, step=1, norm_coef=None, mirror=None):
+    _lib.check(_L().mi_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(decay), p.numel(), float(lr), float(betas[0]),
+                                  float(betas[1]), float(eps), float(weight_decay), int(step), _p(norm_coef), _p(mirror), _stream()), "mi_adamw_step")
+
+
+# ---------------------------------------------------------------------------------------------------------------- composites
+def linear_bwd(dy, x, wT, *, dw=None, db=None, dx_out=None, dx_dtype=BF16, xT=None, dyT=None, need_dx=True):
+    """Backward of y = x W^T + b for bf16 row-major activations.
+    dy (M,N) bf16, x (M,K) bf16, wT (K,N) bf16 (the transposed copy of W the trainer keeps).
+    dx = dy · W (GEMM with W^T as the (N',K') operand); dW (N,K) f32 += dy^T · x (GEMM over the zero-padded transposes); db += colsum(dy)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    dx = None
+    if need_dx:
+        dx = gemm(dy, wT, out=dx_out, out_dtype=dx_dtype)
+    if dw is not None:
+        if dyT is None:
+            dyT = transpose(dy)
+        if xT is None:
+            xT = transpose(x)
+        gemm(dyT, xT, out=dw, resid=dw, alpha=1.0)
+    if db is not None:
+        colsum_(db, dy)
+    return dx

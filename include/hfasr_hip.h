@@ -137,6 +137,64 @@ int mi_embed_tokens(const long* ids, const float* wte, float scale, const float*
 int mi_ce_label_smoothing(const float* logits, long ld, const long* labels, int B, int U, int shift, int V, float eps,
                           float* acc, mi_stream_t stream);
 
+/* ---- training step: backward + optimizer building blocks.
+ * replaces: torch autograd of the modules above under HF Trainer's bf16 autocast + torch.optim.AdamW + clip_grad_norm_
+ *           (src/utilities/training_utils.py:93-115 GradAwareTrainer.training_step; recipes .../train_small_baseline.sh:43,53-58).
+ * Activations bf16, residual stream / parameter gradients fp32; parameter gradients ACCUMULATE (+=). */
+int mi_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int M, int N, int Mp, mi_stream_t stream);
+int mi_colsum(const void* x, long ld, int dtype, int M, int N, float* out, mi_stream_t stream);
+int mi_act_fwd_bf16(const void* pre, long ldp, void* out, long ldo, int M, int N, int kind, mi_stream_t stream);
+int mi_act_bwd_bf16(const void* dy, long lddy, const void* pre, long ldp, void* dx, long lddx, int M, int N, int kind,
+                    mi_stream_t stream);
+int mi_layernorm_bwd(const void* x, long ldx, int x_bf16, const float* gamma, float eps, const void* dy, long lddy, int dy_f32,
+                     void* dx, long lddx, int dx_bf16, int accumulate, float* dgamma, float* dbeta, int M, int d,
+                     mi_stream_t stream);
+int mi_ln_apply_bf16(const void* x, long ldx, const float* stats, const float* gamma, const float* beta, void* y, long ldy,
+                     int M, int N, mi_stream_t stream);
+int mi_axpy_f32(float* a, const float* b, long n, float alpha, mi_stream_t stream);
+int mi_scale_f32(float* a, long n, float alpha, mi_stream_t stream);
+int mi_add2_cast_bf16(const float* a, long lda, const float* b, long ldb, void* out, long ldo, int M, int N, float alpha,
+                      mi_stream_t stream);
+int mi_add_rowvec_bf16(const void* x, long ldx, const float* vec, void* out, long ldo, int M, int N, mi_stream_t stream);
+int mi_gate_bwd_bf16(const void* ds, long ldds, const void* c, long ldc, const void* r, long ldr, void* dr, long lddr,
+                     void* dc, long lddc, int M, int N, mi_stream_t stream);
+int mi_mask_rows_f32(float* x, long ld, const int* lengths, int T, int M, int N, mi_stream_t stream);
+int mi_sumsq_f32(const float* x, long n, float* sumsq, mi_stream_t stream);
+int mi_clip_coef(const float* sumsq, float max_norm, float* norm_coef, mi_stream_t stream);
+int mi_adamw_step(float* p, const float* g, float* m, float* v, const unsigned char* decay, long n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, const float* norm_coef, void* mirror_bf16,
+                  mi_stream_t stream);
+/* strided batched GEMM C[z1,z2] = alpha * A[z1,z2] · B[z1,z2]^T (+ C): the per-(utterance, head) products of attention backward */
+int mi_bgemm_bf16(const void* A, long a_z1, long a_z2, long a_m, long a_k, const void* B, long b_z1, long b_z2, long b_n, long b_k,
+                  void* C, long c_z1, long c_z2, long c_m, int out_f32, int accumulate, float alpha, int Z1, int Z2, int M, int N,
+                  int K, mi_stream_t stream);
+/* softmax stage of attention (e_branchformer.py:100-135, tf wav2vec2_conformer:528-565 relative shift), head-major (H,B,Tq,Tk) */
+int mi_attn_softmax_fwd(const float* ac, const float* bd, const int* lengths, void* prob, int H, int B, int Tq, int Tk, float scale,
+                        int causal, mi_stream_t stream);
+int mi_attn_softmax_bwd(const void* prob, const float* dp, void* ds, void* dbd, int H, int B, int Tq, int Tk, float scale,
+                        mi_stream_t stream);
+/* depthwise-conv / conv front-end gradients (e_branchformer.py:184-204,296-304; extractors.py:71-113) */
+int mi_csgu_bwd_bf16(const void* u, long ldu, const float* stats, const float* gamma, const float* beta, const float* w,
+                     const float* bias, const void* ds, long ldds, void* dr, long lddr, void* dgn, long lddgn, float* dw,
+                     float* db, int B, int T, int C, int K, int pad_left, mi_stream_t stream);
+int mi_dwconv_residual_bwd_bf16(const void* m, long ldm, const float* w, const void* dy, long lddy, void* dm, long lddm,
+                                float* dw, float* db, int B, int T, int C, int K, int pad_left, mi_stream_t stream);
+int mi_im2col_cl_bf16(const void* in, void* col, int B, int Tin, int Fin, int Cin, int KH, int KW, int stride, int pad_t,
+                      int pad_f, int Tout, int Fout, mi_stream_t stream);
+int mi_conv2d_first_bwd(const float* x, const float* w, const float* bias, const void* dcol, float* dw, float* db, int B, int T,
+                        int F, int C, int K, int stride, int pad_t, int pad_f, int T1, int F1, int K2, int stride2, int pad2_t,
+                        int pad2_f, int T2, int F2, mi_stream_t stream);
+/* loss gradients: F.ctc_loss backward composed with log_softmax (e_branchformer.py:472-488); label-smoothed CE of the decoder
+ * heads (multi_head_gpt2.py:138-158); embedding scatter (embeddings.py:33-62) */
+size_t mi_ctc_bwd_workspace_bytes(int B, int T, int U);
+int mi_ctc_loss_bwd(const void* logits, long ld_b, long ld_t, int dtype, const float* lse, int T, const long* labels, int U,
+                    const int* in_len, int blank, int B, int reduction, const float* nll, float gscale, void* workspace,
+                    size_t workspace_bytes, void* dlogits, long ldo, mi_stream_t stream);
+int mi_ce_label_smoothing_bwd(const float* logits, long ld, const long* labels, int B, int U, int shift, int V, float eps,
+                              float weight, const float* acc, void* dlogits, long ldo, mi_stream_t stream);
+int mi_embed_tokens_bwd(const long* ids, const float* dx, float scale, int pos_offset, int U, int d, int M, int V, float* dwte,
+                        float* dwpe, mi_stream_t stream);
+
 /* ---- Whisper-style front end + glue (BASELINE config 4).  replaces: transformers WhisperFeatureExtractor numpy path
  *      (selected by configs/default_data_preprocessing_whisper.json:20-29) and the conv/position prologue of WhisperEncoder. */
 int mi_whisper_logmel(const float* wave, long ldw, const int* num_samples, int n_samples, const double* window,

@@ -1,0 +1,307 @@
+"""GPU parity of the training-step kernels (backward + optimizer), op by op: each C-ABI entry point against torch autograd
+(CPU, fp32) of the ORACLE's restatement of the forward op, on identical bf16-rounded inputs.
+
+Tolerances: bf16-stored gradients at ~1 bf16 ulp relative + a small absolute floor scaled to the gradient magnitude;
+fp32 parameter gradients (sums over thousands of bf16 products) at 1 % of the tensor's max |value|."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ebranchformer_ref as R
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def _o():
+    from huggingface_asr_amd import ops, ops_train
+    return ops, ops_train
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def bfr(x):
+    return x.to(BF).float()
+
+
+def dev16(x):
+    return x.to(DEV, BF)
+
+
+def close(got, want, rel=1.2e-2, floor=2e-2, what=""):
+    """|got - want| <= floor * max|want| + rel * |want|"""
+    got, want = got.float().cpu(), want.float().cpu()
+    err = (got - want).abs()
+    tol = floor * want.abs().max() + rel * want.abs()
+    bad = err > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.4g} (max |want| {float(want.abs().max()):.4g})"
+
+
+def test_transpose_colsum():
+    ops, T = _o()
+    x = bfr(rnd(250, 136, seed=1))
+    xt = T.transpose(dev16(x))
+    assert xt.shape == (136, 256)
+    assert torch.equal(xt[:, :250].float().cpu(), x.t())
+    assert float(xt[:, 250:].float().abs().max()) == 0.0
+    view = dev16(torch.cat([x, x], 1))[:, 136:]                      # strided view
+    assert torch.equal(T.transpose(view)[:, :250].float().cpu(), x.t())
+    out = torch.zeros(136, device=DEV)
+    T.colsum_(out, dev16(x)); T.colsum_(out, x.to(DEV))
+    torch.testing.assert_close(out.cpu(), 2 * x.sum(0), atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("kind", ["gelu", "gelu_new"])
+def test_act_fwd_bwd(kind):
+    ops, T = _o()
+    pre = bfr(rnd(100, 256, seed=2, scale=2.0)).requires_grad_(True)
+    dy = bfr(rnd(100, 256, seed=3))
+    f = (lambda v: F.gelu(v)) if kind == "gelu" else (lambda v: F.gelu(v, approximate="tanh"))
+    y = f(pre)
+    y.backward(dy)
+    close(T.act_fwd(dev16(pre.detach()), kind), y.detach(), floor=2e-3, what="act fwd")
+    close(T.act_bwd(dev16(dy), dev16(pre.detach()), kind), pre.grad, floor=2e-3, what="act bwd")
+
+
+@pytest.mark.parametrize("d,xbf", [(64, False), (512, False), (1024, True), (768, False), (2048, True)])
+def test_layernorm_bwd(d, xbf):
+    ops, T = _o()
+    M = 300
+    x = rnd(M, d, seed=4, scale=1.5) + 0.3
+    if xbf:
+        x = bfr(x)
+    g, b = 1 + 0.1 * rnd(d, seed=5), 0.1 * rnd(d, seed=6)
+    dy = bfr(rnd(M, d, seed=7))
+    xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.layer_norm(xr, (d,), gr, br, 1e-5).backward(dy)
+    base = rnd(M, d, seed=8)
+    dx = base.clone().to(DEV)
+    dg, db = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    T.layernorm_bwd(x.to(DEV, BF) if xbf else x.to(DEV), g.to(DEV), dev16(dy), dx, accumulate=True, dgamma=dg, dbeta=db)
+    torch.testing.assert_close(dx.cpu() - base, xr.grad, atol=2e-4, rtol=1e-3)
+    torch.testing.assert_close(dg.cpu(), gr.grad, atol=2e-3, rtol=1e-3)
+    torch.testing.assert_close(db.cpu(), br.grad, atol=2e-3, rtol=1e-3)
+    dxb = torch.empty(M, d, device=DEV, dtype=BF)
+    T.layernorm_bwd(x.to(DEV, BF) if xbf else x.to(DEV), g.to(DEV), dy.to(DEV), dxb, accumulate=False)
+    close(dxb, xr.grad, floor=4e-3, what="ln bwd bf16 out")
+
+
+@pytest.mark.parametrize("M,N,K", [(250, 512, 256), (1000, 64, 128), (333, 136, 72)])
+def test_linear_bwd(M, N, K):
+    ops, T = _o()
+    x, w, dy = bfr(rnd(M, K, seed=1)), bfr(rnd(N, K, seed=2, scale=K ** -0.5)), bfr(rnd(M, N, seed=3))
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), torch.zeros(N, requires_grad=True)
+    F.linear(xr, wr, br).backward(dy)
+    dw = torch.zeros(N, K, device=DEV)
+    db = torch.zeros(N, device=DEV)
+    dx = T.linear_bwd(dev16(dy), dev16(x), dev16(w.t().contiguous()), dw=dw, db=db)
+    close(dx, xr.grad, what="dx")
+    torch.testing.assert_close(dw.cpu(), wr.grad, atol=2e-3 * float(wr.grad.abs().max()), rtol=1e-3)
+    torch.testing.assert_close(db.cpu(), br.grad, atol=1e-3, rtol=1e-4)
+    T.linear_bwd(dev16(dy), dev16(x), dev16(w.t().contiguous()), dw=dw, need_dx=False)        # accumulates
+    torch.testing.assert_close(dw.cpu(), 2 * wr.grad, atol=4e-3 * float(wr.grad.abs().max()), rtol=1e-3)
+
+
+def test_bgemm_modes():
+    ops, T = _o()
+    Z1, Z2, M, N, K = 3, 2, 70, 50, 90
+    A = bfr(rnd(Z1, Z2, M, K, seed=1)); Bm = bfr(rnd(Z1, Z2, N, K, seed=2))
+    want = torch.einsum("abmk,abnk->abmn", A, Bm)
+    for ta in (False, True):
+        for tb in (False, True):
+            a = dev16(A.transpose(2, 3).contiguous()) if ta else dev16(A)
+            b = dev16(Bm.transpose(2, 3).contiguous()) if tb else dev16(Bm)
+            a_str = (a.stride(0), a.stride(1), 1, a.stride(2)) if ta else (a.stride(0), a.stride(1), a.stride(2), 1)
+            b_str = (b.stride(0), b.stride(1), 1, b.stride(2)) if tb else (b.stride(0), b.stride(1), b.stride(2), 1)
+            C = torch.zeros(Z1, Z2, M, N, device=DEV)
+            T.bgemm(a, a_str, b, b_str, C, (C.stride(0), C.stride(1), C.stride(2)), Z1, Z2, M, N, K, alpha=0.5)
+            torch.testing.assert_close(C.cpu(), 0.5 * want, atol=2e-3, rtol=1e-4)
+            T.bgemm(a, a_str, b, b_str, C, (C.stride(0), C.stride(1), C.stride(2)), Z1, Z2, M, N, K, alpha=0.5, accumulate=True)
+            torch.testing.assert_close(C.cpu(), want, atol=4e-3, rtol=1e-4)
+    Cb = torch.zeros(Z1, Z2, M, N, device=DEV, dtype=BF)
+    a, b = dev16(A), dev16(Bm)
+    T.bgemm(a, (a.stride(0), a.stride(1), a.stride(2), 1), b, (b.stride(0), b.stride(1), b.stride(2), 1), Cb, (Cb.stride(0), Cb.stride(1), Cb.stride(2)), Z1, Z2, M, N, K)
+    close(Cb, want, what="bgemm bf16 out")
+
+
+@pytest.mark.parametrize("rel,causal,masked", [(True, False, True), (False, True, False), (False, False, True)])
+def test_attn_softmax_fwd_bwd(rel, causal, masked):
+    ops, T = _o()
+    H, B, Tq = 2, 3, 37
+    Tk = Tq if (rel or causal) else 53
+    P = 2 * Tq - 1
+    scale = 0.25
+    ac = rnd(H, B, Tq, Tk, seed=1, scale=2.0).requires_grad_(True)
+    bd = rnd(H, B, Tq, P, seed=2, scale=2.0).requires_grad_(True) if rel else None
+    lens = torch.tensor([Tk, Tk - 9, 5], dtype=torch.int32) if masked else None
+    s = ac
+    if rel:
+        idx = (Tq - 1) - torch.arange(Tq)[:, None] + torch.arange(Tq)[None, :]
+        s = s + torch.gather(bd, 3, idx[None, None].expand(H, B, Tq, Tq))
+    s = s * scale
+    fmin = torch.finfo(torch.float32).min
+    if masked:
+        km = torch.arange(Tk)[None, :] >= lens[:, None]
+        s = s.masked_fill(km[None, :, None, :], fmin)
+    if causal:
+        s = s.masked_fill(torch.ones(Tq, Tk, dtype=torch.bool).triu(1)[None, None], fmin)
+    prob = torch.softmax(s, -1)
+    dp = rnd(H, B, Tq, Tk, seed=3)
+    got = T.attn_softmax_fwd(ac.detach().to(DEV), bd.detach().to(DEV) if rel else None, lens.to(DEV) if masked else None, H, B, Tq, Tk, scale, causal)
+    close(got, prob.detach(), floor=4e-3, what="prob")
+    # backward through the bf16-rounded probabilities the kernel consumes
+    pb = bfr(prob.detach())
+    ds_want = pb * (dp - (pb * dp).sum(-1, keepdim=True)) * scale
+    ds, dbd = T.attn_softmax_bwd(dev16(pb), dp.to(DEV), H, B, Tq, Tk, scale, want_dbd=rel)
+    close(ds, ds_want, floor=4e-3, what="ds")
+    prob.backward(dp)
+    close(ds, ac.grad, floor=2e-2, what="ds vs autograd")
+    if rel:
+        close(dbd, bd.grad, floor=2e-2, what="dbd vs autograd")
+
+
+def test_csgu_and_merge_dwconv_bwd():
+    ops, T = _o()
+    B, Tt, Cc, K = 3, 150, 128, 31
+    M = B * Tt
+    u = bfr(rnd(M, 2 * Cc, seed=1))
+    g, be = 1 + 0.1 * rnd(Cc, seed=2), 0.1 * rnd(Cc, seed=3)
+    w, bias = rnd(Cc, K, seed=4, scale=0.2), 0.1 * rnd(Cc, seed=5)
+    ds = bfr(rnd(M, Cc, seed=6))
+    ur, gr, ber, wr, br = [t.clone().requires_grad_(True) for t in (u, g, be, w, bias)]
+    r_, g_ = ur[:, :Cc], ur[:, Cc:]
+    gn = F.layer_norm(g_, (Cc,), gr, ber, 1e-5)
+    gn.retain_grad()
+    conv = R.dwconv1d(gn.view(B, Tt, Cc), wr.view(Cc, 1, K), br).reshape(M, Cc)
+    (r_ * conv).backward(ds)
+    ud = dev16(u)
+    st = ops.row_stats(ud[:, Cc:])
+    dr = torch.empty(M, Cc, device=DEV, dtype=BF); dgn = torch.empty(M, Cc, device=DEV, dtype=BF)
+    dw = torch.zeros(Cc, K, device=DEV); db = torch.zeros(Cc, device=DEV)
+    T.csgu_bwd(ud, st, g.to(DEV), be.to(DEV), w.to(DEV), bias.to(DEV), dev16(ds), dr, dgn, dw, db, B, Tt)
+    close(dr, ur.grad[:, :Cc], what="dr")
+    close(dgn, gn.grad, what="dgn")
+    torch.testing.assert_close(dw.cpu(), wr.grad, atol=1e-2 * float(wr.grad.abs().max()), rtol=1e-2)
+    torch.testing.assert_close(db.cpu(), br.grad, atol=1e-2 * float(br.grad.abs().max()), rtol=1e-2)
+    # merge block: y = m + dwconv(m) + b
+    m = bfr(rnd(M, Cc, seed=7))
+    mr, wr2, br2 = m.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    dy = bfr(rnd(M, Cc, seed=8))
+    (mr + R.dwconv1d(mr.view(B, Tt, Cc), wr2.view(Cc, 1, K), br2).reshape(M, Cc)).backward(dy)
+    dm = torch.empty(M, Cc, device=DEV, dtype=BF)
+    dw2 = torch.zeros(Cc, K, device=DEV); db2 = torch.zeros(Cc, device=DEV)
+    T.dwconv_residual_bwd(dev16(m), w.to(DEV), dev16(dy), dm, dw2, db2, B, Tt)
+    close(dm, mr.grad, what="dm")
+    torch.testing.assert_close(dw2.cpu(), wr2.grad, atol=1e-2 * float(wr2.grad.abs().max()), rtol=1e-2)
+    torch.testing.assert_close(db2.cpu(), br2.grad, atol=1e-2 * float(br2.grad.abs().max()), rtol=1e-2)
+
+
+def test_conv_frontend_bwd():
+    ops, T = _o()
+    B, Tt, Fq, C1, K, s, pad = 2, 61, 40, 32, 3, 2, 1
+    T1, F1 = (Tt + 2 * pad - K) // s + 1, (Fq + 2 * pad - K) // s + 1
+    T2, F2 = (T1 + 2 * pad - K) // s + 1, (F1 + 2 * pad - K) // s + 1
+    x = rnd(B, Tt, Fq, seed=1)
+    w1, b1 = rnd(C1, 1, K, K, seed=2, scale=0.3), 0.1 * rnd(C1, seed=3)
+    w1r, b1r = w1.clone().requires_grad_(True), b1.clone().requires_grad_(True)
+    act1 = F.gelu(F.conv2d(x[:, None], w1r, b1r, stride=s, padding=pad))                  # (B,C1,T1,F1)
+    col_ref = F.unfold(act1, K, padding=pad, stride=s)                                      # (B, C1*K*K, T2*F2), k = c*K*K + kh*K + kw
+    col_ref = col_ref.view(B, C1, K * K, T2 * F2).permute(0, 3, 2, 1).reshape(B * T2 * F2, K * K * C1)   # -> k = (kh*K+kw)*C1 + c
+    dcol = bfr(rnd(B * T2 * F2, K * K * C1, seed=4))
+    col_ref.backward(dcol)
+    # im2col of the channels-last bf16 activation
+    a1 = ops.conv2d_first_gelu(x.to(DEV), w1.reshape(C1, K * K).to(DEV), b1.to(DEV), stride=s, pad=pad)
+    col = T.im2col(a1, K, s, pad, T2, F2)
+    close(col, col_ref.detach(), floor=4e-3, what="im2col")
+    dw = torch.zeros(C1, K * K, device=DEV); db = torch.zeros(C1, device=DEV)
+    T.conv2d_first_bwd(x.to(DEV), w1.reshape(C1, K * K).to(DEV), b1.to(DEV), dev16(dcol), dw, db, K, s, pad, T1, F1, K, s, pad, T2, F2)
+    torch.testing.assert_close(dw.cpu(), w1r.grad.reshape(C1, K * K), atol=5e-3 * float(w1r.grad.abs().max()), rtol=5e-3)
+    torch.testing.assert_close(db.cpu(), b1r.grad, atol=5e-3 * float(b1r.grad.abs().max()), rtol=5e-3)
+
+
+@pytest.mark.parametrize("reduction", ["mean", "sum"])
+def test_ctc_loss_bwd(reduction):
+    ops, T = _o()
+    B, Tt, V1, U = 4, 60, 51, 9
+    logits = rnd(B, Tt, V1, seed=1, scale=1.5)
+    labels = torch.randint(0, V1 - 1, (B, U), generator=torch.Generator().manual_seed(2))
+    labels[1, 6:] = -100; labels[2, 1] = labels[2, 0]; labels[3, :] = labels[3, 0]          # padding, repeats
+    in_len = torch.tensor([60, 47, 33, 12], dtype=torch.int32)                              # utterance 3: 9 repeats need 17 frames > 12: infeasible
+    lg = logits.clone().requires_grad_(True)
+    lp = torch.log_softmax(lg, -1).transpose(0, 1)
+    tl = (labels >= 0).sum(-1)
+    flat = labels[labels >= 0]
+    loss = F.ctc_loss(lp, flat, in_len.long(), tl, blank=V1 - 1, reduction=reduction, zero_infinity=True)
+    (0.3 * loss).backward()
+    ld = logits.to(DEV)
+    lse = ops.row_lse(ld.reshape(B * Tt, V1))
+    got_loss, nll, _ = ops.ctc_loss(ld, labels.to(DEV), in_len.to(DEV), reduction=reduction, zero_infinity=True, lse=lse)
+    torch.testing.assert_close(got_loss.cpu(), loss.detach(), atol=1e-3, rtol=1e-4)
+    dl = T.ctc_loss_bwd(ld, lse, labels.to(DEV), in_len.to(DEV), nll, reduction=reduction, gscale=0.3)
+    assert dl.shape == (B * Tt, 56)
+    assert float(dl[:, V1:].float().abs().max()) == 0.0
+    close(dl[:, :V1].reshape(B, Tt, V1), lg.grad, floor=5e-3, what="ctc dlogits")
+
+
+def test_ce_and_embed_bwd():
+    ops, T = _o()
+    B, U, V, d = 3, 11, 50, 64
+    logits = rnd(B, U, V, seed=1, scale=2.0)
+    labels = torch.randint(0, V, (B, U), generator=torch.Generator().manual_seed(2))
+    labels[1, 7:] = -100
+    lg = logits.clone().requires_grad_(True)
+    loss = F.cross_entropy(lg[:, :-1].reshape(-1, V), labels[:, 1:].reshape(-1), label_smoothing=0.1, ignore_index=-100)
+    (0.6 * loss).backward()
+    ld = logits.to(DEV)
+    acc = torch.zeros(2, device=DEV)
+    rc_loss = ops.ce_label_smoothing(ld, labels.to(DEV), shift=1, eps=0.1)
+    torch.testing.assert_close(rc_loss.cpu(), loss.detach(), atol=1e-4, rtol=1e-4)
+    # the backward kernel reads the [sum, count] pair of the forward
+    from huggingface_asr_amd import _lib
+    _lib.check(_lib.lib().mi_ce_label_smoothing(ld.data_ptr(), ld.stride(1), labels.to(DEV).data_ptr(), B, U, 1, V, 0.1, acc.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream), "ce")
+    dl = T.ce_label_smoothing_bwd(ld, labels.to(DEV), acc, shift=1, eps=0.1, weight=0.6)
+    close(dl[:, :V].reshape(B, U, V), lg.grad, floor=5e-3, what="ce dlogits")
+    # embeddings
+    ids = torch.randint(0, V, (B, U), generator=torch.Generator().manual_seed(3))
+    wte, wpe = rnd(V, d, seed=4).requires_grad_(True), rnd(32, d, seed=5).requires_grad_(True)
+    dx = rnd(B * U, d, seed=6)
+    (wte[ids] * 2.0 + wpe[torch.arange(U)][None]).reshape(B * U, d).backward(dx)
+    dwte, dwpe = torch.zeros(V, d, device=DEV), torch.zeros(32, d, device=DEV)
+    T.embed_tokens_bwd(ids.to(DEV), dx.to(DEV), dwte, dwpe, scale=2.0)
+    torch.testing.assert_close(dwte.cpu(), wte.grad, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(dwpe.cpu(), wpe.grad, atol=1e-4, rtol=1e-4)
+
+
+def test_adamw_matches_torch():
+    ops, T = _o()
+    n = 5000
+    p0, g1, g2 = rnd(n, seed=1), rnd(n, seed=2, scale=3.0), rnd(n, seed=3, scale=0.1)
+    decay = (torch.arange(n) % 3 != 0)
+    pa, pb = p0[decay].clone().requires_grad_(True), p0[~decay].clone().requires_grad_(True)
+    opt = torch.optim.AdamW([{"params": [pa], "weight_decay": 0.01}, {"params": [pb], "weight_decay": 0.0}], lr=2e-3, betas=(0.9, 0.98), eps=1e-8)
+    p = p0.clone().to(DEV); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    mirror = torch.empty(n, device=DEV, dtype=BF)
+    dmask = decay.to(DEV, torch.uint8)
+    for step, g in enumerate((g1, g2), start=1):
+        full = torch.cat([pa.detach(), pb.detach()])
+        gg = g.clone()
+        norm = gg.norm()
+        coef = min(1.0, 1.0 / (float(norm) + 1e-6))
+        pa.grad, pb.grad = (gg[decay] * coef), (gg[~decay] * coef)
+        opt.step()
+        ss = torch.zeros(1, device=DEV); nc = torch.zeros(2, device=DEV)
+        gd = g.to(DEV)
+        T.sumsq_(ss, gd); T.clip_coef(ss, 1.0, nc)
+        torch.testing.assert_close(nc.cpu(), torch.tensor([float(norm), coef]), atol=1e-4, rtol=1e-4)
+        T.adamw_step_(p, gd, m, v, dmask, lr=2e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01, step=step, norm_coef=nc, mirror=mirror)
+    want = torch.empty(n); want[decay] = pa.detach(); want[~decay] = pb.detach()
+    torch.testing.assert_close(p.cpu(), want, atol=1e-6, rtol=1e-5)
+    assert torch.equal(mirror.cpu(), p.cpu().to(BF))
