@@ -212,7 +212,7 @@ def linear_bwd(dy, x, wT, *, dw=None, db=None, dx_out=None, dx_dtype=BF16, xT=No
     K = x.shape[1]
     dx = None
     if need_dx:
-        dx = gemm(dy, wT, out=dx_out, out_dtype=dx_dtype)
+        dx = gemm(dy, wT[:, :N], out=dx_out, out_dtype=dx_dtype)
     if dw is not None:
         if dyT is None:
             dyT = transpose(dy)

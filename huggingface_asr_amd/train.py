@@ -1,0 +1,639 @@
+"""Training step of the E-Branchformer encoder + CTC head on the HIP path.
+
+Replaces, for this model, what the reference gets from torch autograd + HF Trainer around `Wav2Vec2EBranchformerForCTC.forward`
+(src/models/encoders/e_branchformer.py:422-496; trainer src/utilities/training_utils.py:93-115; recipe hyper-parameters
+recipes/librispeech/.../train_small_baseline.sh:43,53-58: bf16 autocast, AdamW, clip 1.0):
+
+  * `ParamStore`   — ONE flat fp32 master buffer (+ flat gradient, Adam moments, bf16 mirror the GEMMs read, and K-major
+                     transposed bf16 copies for the dX GEMMs), parameters kept in the packed layouts the kernels want;
+                     import / export in the reference's state-dict names.
+  * `EncoderCTCTrainer.forward_backward` — forward with saved activations, analytic backward on the HIP kernels of
+                     csrc/{train_ops,bgemm,attn_bwd,conv_bwd,loss_bwd}.hip + the forward GEMM kernel (dX = dY·W, dW = dYᵀ·X).
+  * `GradSync`     — data-parallel gradient SUM all-reduce (RCCL through torch.distributed) per layer bucket, issued while the
+                     earlier layers' backward is still running; the 1/world factor is folded into the loss gradient.
+  * `AdamW`        — one fused kernel over the flat buffer (grad-norm clip coefficient read on device, bf16 mirror refreshed).
+
+Precision model = the reference's autocast recipe: fp32 master weights and residual stream, bf16 GEMM operands (activations AND
+activation gradients), fp32 accumulation, fp32 LayerNorm / softmax / CTC, fp32 parameter gradients.
+Not yet on this path (raise NotImplementedError): dropout > 0, in-model SpecAugment, LayerDrop, causal encoders.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import ops
+from . import ops_train as T
+from .shapes import conv_freq_out
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+# ====================================================================================================== parameter store
+@dataclass
+class Spec:
+    name: str
+    shape: tuple
+    mat: bool          # bf16 (N,K) GEMM operand -> also keeps the transposed bf16 copy
+    decay: bool
+
+
+def _al(n, a=64):
+    return (n + a - 1) // a * a
+
+
+class ParamStore:
+    def __init__(self, specs: list[Spec], device):
+        self.specs = {s.name: s for s in specs}
+        self.order = [s.name for s in specs]
+        self.device = torch.device(device)
+        off, offT = 0, 0
+        self.off, self.offT = {}, {}
+        for s in specs:
+            self.off[s.name] = off
+            off += _al(math.prod(s.shape))
+            if s.mat:
+                N, K = s.shape
+                self.offT[s.name] = offT
+                offT += _al(K * _al(N))
+        self.n = off
+        z = lambda dt, n=off: torch.zeros(n, dtype=dt, device=self.device)
+        self.flat_p, self.flat_g, self.flat_m, self.flat_v = z(F32), z(F32), z(F32), z(F32)
+        self.flat_bf = z(BF16)
+        self.flat_T = z(BF16, max(offT, 64))
+        self.decay = torch.zeros(off, dtype=torch.uint8, device=self.device)
+        for s in specs:
+            if s.decay:
+                o = self.off[s.name]
+                self.decay[o:o + math.prod(s.shape)] = 1
+        self.step_count = 0
+
+    def _view(self, flat, name):
+        s = self.specs[name]
+        o = self.off[name]
+        return flat[o:o + math.prod(s.shape)].view(*s.shape)
+
+    def p(self, name): return self._view(self.flat_p, name)
+    def g(self, name): return self._view(self.flat_g, name)
+    def bf(self, name): return self._view(self.flat_bf, name)
+
+    def bfT(self, name):
+        """(K, pad64(N)) bf16 transposed copy of the (N,K) matrix (columns N.. zero)."""
+        N, K = self.specs[name].shape
+        o = self.offT[name]
+        return self.flat_T[o:o + K * _al(N)].view(K, _al(N))
+
+    def range_of(self, names):
+        lo = min(self.off[n] for n in names)
+        hi = max(self.off[n] + _al(math.prod(self.specs[n].shape)) for n in names)
+        return lo, hi
+
+    def refresh_mirrors(self, cast=True):
+        """bf16 mirror (if not already written by the optimizer kernel) + transposed copies of every matrix."""
+        if cast:
+            ops_cast_flat(self.flat_p, self.flat_bf)
+        for name, s in self.specs.items():
+            if s.mat:
+                N, K = s.shape
+                T.transpose(self.bf(name), Mp=_al(N), out=self.bfT(name))
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+
+def ops_cast_flat(src_f32, dst_bf16):
+    n = src_f32.numel()
+    w = 4096
+    rows = n // w
+    if rows:
+        ops_cast = ops._lib.lib().mi_cast_f32_bf16
+        ops._lib.check(ops_cast(src_f32.data_ptr(), w, dst_bf16.data_ptr(), w, rows, w, torch.cuda.current_stream().cuda_stream), "mi_cast_f32_bf16")
+    rem = n - rows * w
+    if rem:
+        ops._lib.check(ops._lib.lib().mi_cast_f32_bf16(src_f32[rows * w:].data_ptr(), rem, dst_bf16[rows * w:].data_ptr(), rem, 1, rem,
+                                                       torch.cuda.current_stream().cuda_stream), "mi_cast_f32_bf16")
+
+
+# ====================================================================================================== encoder parameters
+def encoder_specs(c: dict) -> list[Spec]:
+    d, I, L, V1 = c["hidden_size"], c["intermediate_size"], c["num_hidden_layers"], c["vocab_size"] + 1
+    C1, C2 = c["conv_dim"]
+    K = c["conv_kernel"][0]
+    F2 = conv_freq_out(c.get("num_fbanks", 80), c["conv_kernel"], c["conv_stride"], c["conv_padding"])
+    kc, km = c.get("csgu_kernel_size", 31), c.get("merge_conv_kernel", 31)
+    rel = c.get("position_embeddings_type", "relative") == "relative"
+    S = []
+    mat = lambda n, *sh: S.append(Spec(n, tuple(sh), True, True))
+    vec = lambda n, *sh, decay=False: S.append(Spec(n, tuple(sh), False, decay))
+    vec("masked_spec_embed", d)     # SpecAugment fill vector: carried for state-dict parity, never receives a gradient on this path (torch skips it too)
+    vec("conv1_w", C1, K * K, decay=True); vec("conv1_b", C1)
+    mat("conv2_w", C2, K * K * C1); vec("conv2_b", C2)
+    mat("feout_w", d, F2 * C2); vec("feout_b", d)
+    vec("fp_ln_g", d); vec("fp_ln_b", d); mat("fp_w", d, d); vec("fp_b", d)
+    for l in range(L):
+        p = f"l{l}."
+        ffs = ("ff1", "ff2") if c.get("use_macaron_ff", True) else ()
+        for ff in ffs[:1]:
+            vec(p + ff + "_ln_g", d); vec(p + ff + "_ln_b", d); mat(p + ff + "_w1", I, d); vec(p + ff + "_b1", I); mat(p + ff + "_w2", d, I); vec(p + ff + "_b2", d)
+        vec(p + "att_ln_g", d); vec(p + "att_ln_b", d)
+        mat(p + "att_wqkv", 3 * d, d); vec(p + "att_bqkv", 3 * d); mat(p + "att_wo", d, d); vec(p + "att_bo", d)
+        if rel:
+            mat(p + "att_wpos", d, d); vec(p + "att_u", d); vec(p + "att_v", d)          # pos_bias_* : "bias" in the name -> no decay
+        vec(p + "mlp_ln_g", d); vec(p + "mlp_ln_b", d); mat(p + "mlp_w1", I, d); vec(p + "mlp_b1", I)
+        vec(p + "csgu_ln_g", I // 2); vec(p + "csgu_ln_b", I // 2); vec(p + "csgu_w", I // 2, kc, decay=True); vec(p + "csgu_b", I // 2)
+        mat(p + "mlp_w2", d, I // 2); vec(p + "mlp_b2", d)
+        vec(p + "mrg_dw_w", 2 * d, km, decay=True); vec(p + "mrg_dw_b", 2 * d); mat(p + "mrg_w", d, 2 * d); vec(p + "mrg_b", d)
+        for ff in ffs[1:]:
+            vec(p + ff + "_ln_g", d); vec(p + ff + "_ln_b", d); mat(p + ff + "_w1", I, d); vec(p + ff + "_b1", I); mat(p + ff + "_w2", d, I); vec(p + ff + "_b2", d)
+        vec(p + "fin_ln_g", d); vec(p + "fin_ln_b", d)
+    vec("enc_ln_g", d); vec("enc_ln_b", d)
+    mat("head_w", V1, d); vec("head_b", V1)
+    return S
+
+
+def _enc_map(c: dict):
+    """packed name -> (to_packed(sd) -> tensor, [(reference key, from_packed(tensor) -> tensor), ...])"""
+    d, L = c["hidden_size"], c["num_hidden_layers"]
+    C1, C2 = c["conv_dim"]
+    K = c["conv_kernel"][0]
+    V = c["vocab_size"]
+    F2 = conv_freq_out(c.get("num_fbanks", 80), c["conv_kernel"], c["conv_stride"], c["conv_padding"])
+    kc, km = c.get("csgu_kernel_size", 31), c.get("merge_conv_kernel", 31)
+    fe, fp = "wav2vec2.feature_extractor.", "wav2vec2.feature_projection."
+    cw = "" if c.get("is_causal", False) else ".conv"
+    m = {}
+    one = lambda name, key, fwd=lambda t: t, bwd=lambda t: t: m.__setitem__(name, (lambda sd: fwd(sd[key]), [(key, bwd)]))
+    one("masked_spec_embed", "wav2vec2.masked_spec_embed")
+    one("conv1_w", f"{fe}conv.0.0{cw}.weight", lambda t: t.reshape(C1, K * K), lambda t: t.reshape(C1, 1, K, K))
+    one("conv1_b", f"{fe}conv.0.0{cw}.bias")
+    one("conv2_w", f"{fe}conv.1.0{cw}.weight", lambda t: t.permute(0, 2, 3, 1).reshape(C2, K * K * C1),
+        lambda t: t.reshape(C2, K, K, C1).permute(0, 3, 1, 2).contiguous())
+    one("conv2_b", f"{fe}conv.1.0{cw}.bias")
+    one("feout_w", fe + "out.weight", lambda t: t.reshape(d, C2, F2).permute(0, 2, 1).reshape(d, F2 * C2),
+        lambda t: t.reshape(d, F2, C2).permute(0, 2, 1).reshape(d, C2 * F2).contiguous())
+    one("feout_b", fe + "out.bias")
+    one("fp_ln_g", fp + "layer_norm.weight"); one("fp_ln_b", fp + "layer_norm.bias")
+    one("fp_w", fp + "projection.weight"); one("fp_b", fp + "projection.bias")
+    one("enc_ln_g", "wav2vec2.encoder.layer_norm.weight"); one("enc_ln_b", "wav2vec2.encoder.layer_norm.bias")
+    m["head_w"] = (lambda sd: torch.cat([sd["lm_head.weight"], sd["blank_projection.weight"]], 0),
+                   [("lm_head.weight", lambda t: t[:V].contiguous()), ("blank_projection.weight", lambda t: t[V:].contiguous())])
+    m["head_b"] = (lambda sd: torch.cat([sd["lm_head.bias"], sd["blank_projection.bias"]], 0),
+                   [("lm_head.bias", lambda t: t[:V].contiguous()), ("blank_projection.bias", lambda t: t[V:].contiguous())])
+    for l in range(L):
+        p, r = f"l{l}.", f"wav2vec2.encoder.layers.{l}."
+        if c.get("use_macaron_ff", True):
+            for ff in ("ff1", "ff2"):
+                one(p + ff + "_ln_g", r + ff + ".0.weight"); one(p + ff + "_ln_b", r + ff + ".0.bias")
+                one(p + ff + "_w1", r + ff + ".1.intermediate_dense.weight"); one(p + ff + "_b1", r + ff + ".1.intermediate_dense.bias")
+                one(p + ff + "_w2", r + ff + ".1.output_dense.weight"); one(p + ff + "_b2", r + ff + ".1.output_dense.bias")
+        one(p + "att_ln_g", r + "self_attn_layer_norm.weight"); one(p + "att_ln_b", r + "self_attn_layer_norm.bias")
+        a = r + "self_attn."
+        m[p + "att_wqkv"] = (lambda sd, a=a: torch.cat([sd[a + f"linear_{n}.weight"] for n in "qkv"], 0),
+                             [(a + f"linear_{n}.weight", (lambda t, i=i: t[i * d:(i + 1) * d].contiguous())) for i, n in enumerate("qkv")])
+        m[p + "att_bqkv"] = (lambda sd, a=a: torch.cat([sd[a + f"linear_{n}.bias"] for n in "qkv"], 0),
+                             [(a + f"linear_{n}.bias", (lambda t, i=i: t[i * d:(i + 1) * d].contiguous())) for i, n in enumerate("qkv")])
+        one(p + "att_wo", a + "linear_out.weight"); one(p + "att_bo", a + "linear_out.bias")
+        if c.get("position_embeddings_type", "relative") == "relative":
+            H = c["num_attention_heads"]
+            one(p + "att_wpos", a + "linear_pos.weight")
+            one(p + "att_u", a + "pos_bias_u", lambda t: t.reshape(d), lambda t: t.reshape(H, d // H))
+            one(p + "att_v", a + "pos_bias_v", lambda t: t.reshape(d), lambda t: t.reshape(H, d // H))
+        one(p + "mlp_ln_g", r + "cgMLP_layer_norm.weight"); one(p + "mlp_ln_b", r + "cgMLP_layer_norm.bias")
+        g = r + "cgMLP."
+        one(p + "mlp_w1", g + "channel_proj1.0.weight"); one(p + "mlp_b1", g + "channel_proj1.0.bias")
+        one(p + "csgu_ln_g", g + "csgu.norm.weight"); one(p + "csgu_ln_b", g + "csgu.norm.bias")
+        one(p + "csgu_w", g + "csgu.conv.weight", lambda t: t.reshape(-1, kc), lambda t: t.reshape(-1, 1, kc))
+        one(p + "csgu_b", g + "csgu.conv.bias")
+        one(p + "mlp_w2", g + "channel_proj2.weight"); one(p + "mlp_b2", g + "channel_proj2.bias")
+        one(p + "mrg_dw_w", r + "depthwise_conv_fusion.weight", lambda t: t.reshape(-1, km), lambda t: t.reshape(-1, 1, km))
+        one(p + "mrg_dw_b", r + "depthwise_conv_fusion.bias")
+        one(p + "mrg_w", r + "merge_proj.weight"); one(p + "mrg_b", r + "merge_proj.bias")
+        one(p + "fin_ln_g", r + "final_layer_norm.weight"); one(p + "fin_ln_b", r + "final_layer_norm.bias")
+    return m
+
+
+# ====================================================================================================== gradient sync (DP)
+class GradSync:
+    """Data-parallel SUM all-reduce of flat-gradient ranges, launched as soon as a range is final (reverse layer order) so the
+    collective of layer l overlaps the backward of layers < l.  RCCL over xGMI on MI355X (backend 'nccl'), gloo in the CPU tests."""
+
+    def __init__(self, flat_g: torch.Tensor, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.flat_g, self.group, self.pending = flat_g, group, []
+
+    def launch(self, lo: int, hi: int):
+        if self.on and hi > lo:
+            self.pending.append(self.dist.all_reduce(self.flat_g[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for h in self.pending:
+            h.wait()
+        self.pending = []
+
+
+# ====================================================================================================== trainer
+class EncoderCTCTrainer:
+    """forward + backward + AdamW for Wav2Vec2EBranchformerForCTC on one GPU (one process per GPU under DP)."""
+
+    def __init__(self, cfg: dict, device="cuda:0", *, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None):
+        c = self.cfg = dict(cfg)
+        if c.get("is_causal", False):
+            raise NotImplementedError("training path: causal encoders are not supported yet")
+        if len(c["conv_dim"]) != 2 or c["conv_kernel"][0] != 3 or len(set(c["conv_kernel"])) != 1:
+            raise NotImplementedError("training path: 2-layer 3x3 Conv2d sub-sampling only")
+        if c.get("csgu_activation", "identity") != "identity" or c.get("csgu_use_linear_after_conv", False):
+            raise NotImplementedError("training path: CSGU with identity activation and no linear-after-conv only")
+        for k in ("hidden_dropout", "activation_dropout", "attention_dropout", "final_dropout", "feat_proj_dropout", "layerdrop", "csgu_conv_dropout"):
+            if float(c.get(k, 0.0) or 0.0) != 0.0:
+                raise NotImplementedError(f"training path: {k} > 0 is not supported yet (set it to 0.0)")
+        if c.get("apply_spec_augment", False) and float(c.get("mask_time_prob", 0.0) or 0.0) > 0.0:
+            raise NotImplementedError("training path: in-model SpecAugment is not supported yet (apply_spec_augment=False)")
+        self.device = torch.device(device)
+        self.store = ParamStore(encoder_specs(c), self.device)
+        self.map = _enc_map(c)
+        self.hp = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        self.sync = GradSync(self.store.flat_g, group)
+        self._pos = {}
+        self._scal = torch.zeros(4, dtype=F32, device=self.device)       # [sumsq, norm, coef, -]
+        L = c["num_hidden_layers"]
+        names = self.store.order
+        self._layer_names = [[n for n in names if n.startswith(f"l{l}.")] for l in range(L)]
+        self._front_names = [n for n in names if n.startswith(("masked_spec", "conv", "feout", "fp_"))]
+        self._head_names = ["enc_ln_g", "enc_ln_b", "head_w", "head_b"]
+
+    # ------------------------------------------------------------------ weights in / out
+    def load_state_dict(self, sd: dict):
+        dev = self.device
+        sdd = {k: v.detach().to(dev, F32) for k, v in sd.items() if torch.is_tensor(v) and v.is_floating_point()}
+        for name in self.store.order:
+            self.store.p(name).copy_(self.map[name][0](sdd).reshape(self.store.specs[name].shape))
+        self.store.refresh_mirrors(cast=True)
+
+    def state_dict(self) -> dict:
+        out = {}
+        for name in self.store.order:
+            t = self.store.p(name)
+            for key, fn in self.map[name][1]:
+                out[key] = fn(t).clone()
+        return out
+
+    def grad_dict(self) -> dict:
+        """gradients in the reference's parameter names / shapes (tests, checkpoint tooling)."""
+        out = {}
+        for name in self.store.order:
+            t = self.store.g(name)
+            for key, fn in self.map[name][1]:
+                out[key] = fn(t).clone()
+        return out
+
+    # ------------------------------------------------------------------ tables
+    def out_frames(self, Tn):
+        c = self.cfg
+        k, s, p = c["conv_kernel"][0], c["conv_stride"][0], c["conv_padding"][0]
+        out = []
+        for _ in range(2):
+            Tn = (Tn + 2 * p - k) // s + 1
+            out.append(Tn)
+        return out
+
+    def _pos_table(self, T2):
+        c = self.cfg
+        ptype = c.get("position_embeddings_type", "relative")
+        key = (ptype, T2)
+        if key not in self._pos:
+            d, H = c["hidden_size"], c["num_attention_heads"]
+            if ptype == "relative":
+                pos = torch.arange(T2 - 1, -T2, -1, dtype=F32)[:, None]
+                div = torch.exp(torch.arange(0, d, 2, dtype=torch.int64).float() * -(math.log(10000.0) / d))
+                pe = torch.zeros(2 * T2 - 1, d)
+                pe[:, 0::2] = torch.sin(pos * div); pe[:, 1::2] = torch.cos(pos * div)
+                t = pe.to(self.device).to(BF16).contiguous()
+                self._pos[key] = (t, T.transpose(t))
+            elif ptype == "rotary":
+                hd = d // H
+                inv = 1.0 / (c.get("rotary_embedding_base", 10000) ** (torch.arange(0, hd, 2, dtype=torch.int64).float() / hd))
+                fr = torch.einsum("i,j->ij", torch.arange(T2).float(), inv)
+                emb = torch.cat((fr, fr), dim=-1)
+                self._pos[key] = (emb.cos().contiguous().to(self.device), emb.sin().contiguous().to(self.device), (-emb.sin()).contiguous().to(self.device))
+            else:
+                self._pos[key] = None
+        return self._pos[key]
+
+    # ------------------------------------------------------------------ forward + backward
+    def forward_backward(self, feats, feat_lengths, labels, *, loss_scale=1.0, extra_hidden_grad=None, backward=True, keep_hidden=False):
+        """feats (B,T,F) f32 device; feat_lengths (B) int32 or None; labels (B,U) int64 (<0 = padding).
+        Returns dict(loss, logits (B,T2,V+1) f32, outer_len, last_hidden).  Gradients of loss_scale/world * loss accumulate into the store.
+        `extra_hidden_grad`: optional callable(last_hidden f32 (M,d)) -> f32 (M,d) gradient to add at the encoder output
+        (the attention decoder of the joint model hooks in here)."""
+        c, st = self.cfg, self.store
+        P, G, W, WT = st.p, st.g, st.bf, st.bfT
+        dev = self.device
+        feats = feats.to(F32).contiguous()
+        B, Tn, Fq = feats.shape
+        d, H, I, L, V1 = c["hidden_size"], c["num_attention_heads"], c["intermediate_size"], c["num_hidden_layers"], c["vocab_size"] + 1
+        C1, C2 = c["conv_dim"]
+        K, s_, pad = c["conv_kernel"][0], c["conv_stride"][0], c["conv_padding"][0]
+        T1, T2 = self.out_frames(Tn)
+        F1 = (Fq + 2 * pad - K) // s_ + 1
+        F2 = (F1 + 2 * pad - K) // s_ + 1
+        M, hd = B * T2, d // H
+        ptype = c.get("position_embeddings_type", "relative")
+        macaron = c.get("use_macaron_ff", True)
+        eps_e = float(c.get("layer_norm_eps", 1e-5))
+        kc = c.get("csgu_kernel_size", 31)
+        scale = 1.0 / math.sqrt(hd)
+        if feat_lengths is not None:
+            feat_lengths = feat_lengths.to(device=dev, dtype=torch.int32).contiguous()
+            inner, outer = self._lengths(feat_lengths, T2)
+        else:
+            inner = None
+            outer = torch.full((B,), self._outer_len(Tn), dtype=torch.int32, device=dev)
+        e32 = lambda *sh: torch.empty(sh, device=dev, dtype=F32)
+        e16 = lambda *sh: torch.empty(sh, device=dev, dtype=BF16)
+        LN = ops.layernorm_chain
+
+        # ---------------- front end
+        act1 = ops.conv2d_first_gelu(feats, P("conv1_w"), P("conv1_b"), stride=s_, pad=pad)
+        pre2 = ops.conv2d_cl(act1, W("conv2_w"), P("conv2_b"), K=K, stride=s_, pad=pad, act="none").view(B * T2 * F2, C2)
+        act2 = T.act_fwd(pre2).view(M, F2 * C2)
+        feo = ops.gemm(act2, W("feout_w"), P("feout_b"), out_dtype=F32)
+        a_fp = e16(M, d)
+        LN(feo, lna=(P("fp_ln_g"), P("fp_ln_b")), eps2=eps_e, outa=a_fp)
+        x = ops.gemm(a_fp, W("fp_w"), P("fp_b"), out_dtype=F32)
+        if inner is not None:
+            T.mask_rows_(x, inner, T2)
+        pos = self._pos_table(T2)
+        saved = []
+        # ---------------- layers
+        for l in range(L):
+            p = f"l{l}."
+            S = {"x_in": x}
+            if macaron:
+                x, S["ff1"] = self._ffn_fwd(x, p + "ff1", LN, e16)
+            S["x1"] = x
+            a1, a2 = e16(M, d), e16(M, d)
+            LN(x, lna=(P(p + "att_ln_g"), P(p + "att_ln_b")), outa=a1, lnb=(P(p + "mlp_ln_g"), P(p + "mlp_ln_b")), outb=a2)
+            cat = e16(M, 2 * d)
+            # global branch
+            qkv = e16(M, 3 * d)
+            if ptype == "rotary":
+                a1r = ops.rotary(a1, pos[0].reshape(-1), pos[1].reshape(-1), T2, H)
+                ops.gemm(a1r, W(p + "att_wqkv")[:2 * d], P(p + "att_bqkv")[:2 * d], out=qkv[:, :2 * d])
+                ops.gemm(a1, W(p + "att_wqkv")[2 * d:], P(p + "att_bqkv")[2 * d:], out=qkv[:, 2 * d:])
+                S["a1r"] = a1r
+            else:
+                ops.gemm(a1, W(p + "att_wqkv"), P(p + "att_bqkv"), out=qkv)
+            posp = None
+            if ptype == "relative":
+                posp = ops.gemm(pos[0], W(p + "att_wpos"))
+            ctx = self._attention_fwd(qkv, posp, P(p + "att_u") if posp is not None else None, P(p + "att_v") if posp is not None else None,
+                                      inner, B, T2, H, S)
+            ops.gemm(ctx, W(p + "att_wo"), P(p + "att_bo"), out=cat[:, :d])
+            # local branch (cgMLP)
+            hp = ops.gemm(a2, W(p + "mlp_w1"), P(p + "mlp_b1"))
+            h = T.act_fwd(hp)
+            stats = ops.row_stats(h[:, I // 2:])
+            sg = ops.csgu(h, P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), B, T2)
+            ops.gemm(sg, W(p + "mlp_w2"), P(p + "mlp_b2"), out=cat[:, d:])
+            # merge
+            m2 = ops.dwconv_residual(cat, P(p + "mrg_dw_w"), P(p + "mrg_dw_b"), B, T2)
+            x2 = ops.gemm(m2, W(p + "mrg_w"), P(p + "mrg_b"), out_dtype=F32, resid=x, alpha=1.0)
+            S.update(a1=a1, a2=a2, qkv=qkv, posp=posp, ctx=ctx, hp=hp, h=h, stats=stats, sg=sg, cat=cat, m2=m2, x2=x2)
+            x = x2
+            if macaron:
+                x, S["ff2"] = self._ffn_fwd(x, p + "ff2", LN, e16)
+            S["x3"] = x
+            xo = e32(M, d)
+            LN(x, ln1=(P(p + "fin_ln_g"), P(p + "fin_ln_b")), store_y=xo)
+            x = xo
+            saved.append(S)
+        # ---------------- head + CTC
+        hid = e16(M, d)
+        last_hidden = e32(M, d)
+        LN(x, lna=(P("enc_ln_g"), P("enc_ln_b")), eps2=eps_e, outa=hid, outa32=last_hidden)
+        ldl = T.pad64(V1)
+        lbuf = e32(B, T2, ldl)
+        ops.gemm(hid, W("head_w"), P("head_b"), out=lbuf.view(M, ldl))
+        logits = lbuf[..., :V1]
+        red = c.get("ctc_loss_reduction", "mean")
+        lse = ops.row_lse(lbuf.view(M, ldl)[:, :V1])
+        loss, nll, _ = ops.ctc_loss(logits, labels, outer, reduction=red, zero_infinity=bool(c.get("ctc_zero_infinity", False)), lse=lse)
+        out = dict(loss=loss, logits=logits, outer_len=outer, inner_len=inner, last_hidden=last_hidden.view(B, T2, d) if keep_hidden or extra_hidden_grad else None)
+        if not backward:
+            return out
+
+        # =================================================================== backward
+        gs = float(loss_scale) / self.sync.world
+        dlog = T.ctc_loss_bwd(logits, lse, labels, outer, nll, reduction=red, gscale=gs, ldo=ldl)         # (M, ldl) bf16
+        dhid = T.gemm(dlog, WT("head_w"))                                                                # (M, d) bf16
+        dlT = T.transpose(dlog)
+        hidT = T.transpose(hid)
+        ops.gemm(dlT[:V1], hidT, out=G("head_w"), resid=G("head_w"), alpha=1.0)
+        T.colsum_(G("head_b"), dlog[:, :V1])
+        dx = e32(M, d)
+        T.layernorm_bwd(x, P("enc_ln_g"), dhid, dx, accumulate=False, dgamma=G("enc_ln_g"), dbeta=G("enc_ln_b"), eps=eps_e)
+        if extra_hidden_grad is not None:
+            dh32 = extra_hidden_grad(last_hidden)
+            if dh32 is not None:
+                T.layernorm_bwd(x, P("enc_ln_g"), dh32, dx, accumulate=True, dgamma=G("enc_ln_g"), dbeta=G("enc_ln_b"), eps=eps_e)
+        self.sync.launch(*st.range_of(self._head_names))
+        for l in range(L - 1, -1, -1):
+            p = f"l{l}."
+            S = saved[l]
+            # final_layer_norm
+            d3 = e32(M, d)
+            T.layernorm_bwd(S["x3"], P(p + "fin_ln_g"), dx, d3, accumulate=False, dgamma=G(p + "fin_ln_g"), dbeta=G(p + "fin_ln_b"))
+            dx = d3
+            if macaron:
+                self._ffn_bwd(dx, S["x2"], S["ff2"], p + "ff2")
+            # merge:  x2 = x1 + merge_proj(m2)
+            dyb = T.add_cast(dx)
+            dm2 = T.linear_bwd(dyb, S["m2"], WT(p + "mrg_w"), dw=G(p + "mrg_w"), db=G(p + "mrg_b"))
+            dcat = e16(M, 2 * d)
+            T.dwconv_residual_bwd(S["cat"], P(p + "mrg_dw_w"), dm2, dcat, G(p + "mrg_dw_w"), G(p + "mrg_dw_b"), B, T2)
+            # local branch
+            dsg = T.linear_bwd(dcat[:, d:], S["sg"], WT(p + "mlp_w2"), dw=G(p + "mlp_w2"), db=G(p + "mlp_b2"))
+            dh = e16(M, I)
+            dgn = e16(M, I // 2)
+            T.csgu_bwd(S["h"], S["stats"], P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), dsg, dh[:, :I // 2], dgn,
+                       G(p + "csgu_w"), G(p + "csgu_b"), B, T2)
+            T.layernorm_bwd(S["h"][:, I // 2:], P(p + "csgu_ln_g"), dgn, dh[:, I // 2:], accumulate=False, dgamma=G(p + "csgu_ln_g"), dbeta=G(p + "csgu_ln_b"))
+            dhp = T.act_bwd(dh, S["hp"])
+            da2 = T.linear_bwd(dhp, S["a2"], WT(p + "mlp_w1"), dw=G(p + "mlp_w1"), db=G(p + "mlp_b1"))
+            T.layernorm_bwd(S["x1"], P(p + "mlp_ln_g"), da2, dx, accumulate=True, dgamma=G(p + "mlp_ln_g"), dbeta=G(p + "mlp_ln_b"))
+            # global branch
+            dctx = T.linear_bwd(dcat[:, :d], S["ctx"], WT(p + "att_wo"), dw=G(p + "att_wo"), db=G(p + "att_bo"))
+            dqkv = self._attention_bwd(dctx, S, p, pos, inner, B, T2, H)
+            if ptype == "rotary":
+                wt = WT(p + "att_wqkv")
+                da1r = T.linear_bwd(dqkv[:, :2 * d], S["a1r"], wt[:, :2 * d], dw=G(p + "att_wqkv")[:2 * d], db=G(p + "att_bqkv")[:2 * d])
+                da1 = T.linear_bwd(dqkv[:, 2 * d:], S["a1"], wt[:, 2 * d:3 * d], dw=G(p + "att_wqkv")[2 * d:], db=G(p + "att_bqkv")[2 * d:], dx_dtype=F32)
+                rot = ops.rotary(da1r, pos[0].reshape(-1), pos[2].reshape(-1), T2, H)             # R^T = rotation by -theta
+                T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), da1, dx, accumulate=True, dgamma=G(p + "att_ln_g"), dbeta=G(p + "att_ln_b"))
+                T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), rot, dx, accumulate=True, dgamma=G(p + "att_ln_g"), dbeta=G(p + "att_ln_b"))
+            else:
+                da1 = T.linear_bwd(dqkv, S["a1"], WT(p + "att_wqkv")[:, :3 * d], dw=G(p + "att_wqkv"), db=G(p + "att_bqkv"))
+                T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), da1, dx, accumulate=True, dgamma=G(p + "att_ln_g"), dbeta=G(p + "att_ln_b"))
+            if macaron:
+                self._ffn_bwd(dx, S["x_in"], S["ff1"], p + "ff1")
+            self.sync.launch(*st.range_of(self._layer_names[l]))
+        # ---------------- front end
+        if inner is not None:
+            T.mask_rows_(dx, inner, T2)
+        dyb = T.add_cast(dx)
+        da = T.linear_bwd(dyb, a_fp, WT("fp_w"), dw=G("fp_w"), db=G("fp_b"))
+        dfeo = e32(M, d)
+        T.layernorm_bwd(feo, P("fp_ln_g"), da, dfeo, accumulate=False, dgamma=G("fp_ln_g"), dbeta=G("fp_ln_b"), eps=eps_e)
+        dact2 = T.linear_bwd(T.add_cast(dfeo), act2, WT("feout_w"), dw=G("feout_w"), db=G("feout_b"))      # (M, F2*C2)
+        dpre2 = T.act_bwd(dact2.view(B * T2 * F2, C2), pre2)
+        T.colsum_(G("conv2_b"), dpre2)
+        col = T.im2col(act1, K, s_, pad, T2, F2)
+        ops.gemm(T.transpose(dpre2), T.transpose(col), out=G("conv2_w"), resid=G("conv2_w"), alpha=1.0)
+        dcol = ops.gemm(dpre2, WT("conv2_w")[:, :C2])
+        del col
+        T.conv2d_first_bwd(feats, P("conv1_w"), P("conv1_b"), dcol, G("conv1_w"), G("conv1_b"), K, s_, pad, T1, F1, K, s_, pad, T2, F2)
+        self.sync.launch(*st.range_of(self._front_names))
+        return out
+
+    # ------------------------------------------------------------------ pieces
+    def _outer_len(self, n):
+        k, s = self.cfg["conv_kernel"][0], self.cfg["conv_stride"][0]
+        for _ in range(2):
+            n = (n - k) // s + 1
+        return n
+
+    def _lengths(self, feat_lengths, T2):
+        c = self.cfg
+        k, s, p = c["conv_kernel"][0], c["conv_stride"][0], c["conv_padding"][0]
+        li, lo = feat_lengths.clone(), feat_lengths.clone()
+        for _ in range(2):
+            li = torch.div(li + 2 * p - k, s, rounding_mode="floor") + 1
+            lo = torch.div(lo - k, s, rounding_mode="floor") + 1
+        return torch.clamp(li, max=T2).to(torch.int32), lo.to(torch.int32)
+
+    def _ffn_fwd(self, x, pre, LN, e16):
+        """x + 0.5 * W2 gelu(W1 LN(x))  (e_branchformer.py:271-273, 307-309)"""
+        P, W = self.store.p, self.store.bf
+        M, d = x.shape
+        a = e16(M, d)
+        LN(x, lna=(P(pre + "_ln_g"), P(pre + "_ln_b")), outa=a)
+        hp = ops.gemm(a, W(pre + "_w1"), P(pre + "_b1"))
+        h = T.act_fwd(hp)
+        y = ops.gemm(h, W(pre + "_w2"), P(pre + "_b2"), out_dtype=F32, resid=x, alpha=0.5)
+        return y, dict(a=a, hp=hp, h=h)
+
+    def _ffn_bwd(self, dx, x_in, S, pre):
+        """dx (f32, in place): gradient w.r.t. the block output -> gradient w.r.t. its input (residual + LN path)."""
+        P, G, WT = self.store.p, self.store.g, self.store.bfT
+        dyb = T.add_cast(dx, alpha=0.5)
+        dh = T.linear_bwd(dyb, S["h"], WT(pre + "_w2"), dw=G(pre + "_w2"), db=G(pre + "_b2"))
+        dhp = T.act_bwd(dh, S["hp"])
+        da = T.linear_bwd(dhp, S["a"], WT(pre + "_w1"), dw=G(pre + "_w1"), db=G(pre + "_b1"))
+        T.layernorm_bwd(x_in, P(pre + "_ln_g"), da, dx, accumulate=True, dgamma=G(pre + "_ln_g"), dbeta=G(pre + "_ln_b"))
+
+    def _attention_fwd(self, qkv, posp, u, v, lengths, B, Tt, H, S):
+        d = qkv.shape[1] // 3
+        hd = d // H
+        if hd in (64, 128):
+            return ops.attention_qkv(qkv, B, Tt, H, pos=posp, bias_u=u, bias_v=v, lengths=lengths)
+        # small heads (test configs): probabilities through the generic pieces, kept for the backward pass
+        prob = self._probs(qkv, posp, u, v, lengths, B, Tt, H, S)
+        ctx = torch.empty((B * Tt, d), device=qkv.device, dtype=BF16)
+        vv = qkv[:, 2 * d:]
+        T.bgemm(prob, (B * Tt * Tt, Tt * Tt, Tt, 1), vv, (hd, Tt * 3 * d, 1, 3 * d), ctx, (hd, Tt * d, d), H, B, Tt, hd, Tt)
+        S["prob"] = prob
+        return ctx
+
+    def _probs(self, qkv, posp, u, v, lengths, B, Tt, H, S):
+        d = qkv.shape[1] // 3
+        hd = d // H
+        M = B * Tt
+        dev = qkv.device
+        q, k = qkv[:, :d], qkv[:, d:2 * d]
+        if posp is not None:
+            qu, qv = T.add_rowvec(q, u), T.add_rowvec(q, v)
+            a_q, a_str = qu, (hd, Tt * d, d, 1)
+        else:
+            qu = qv = None
+            a_q, a_str = q, (hd, Tt * 3 * d, 3 * d, 1)
+        ac = torch.empty((H, B, Tt, Tt), device=dev, dtype=F32)
+        T.bgemm(a_q, a_str, k, (hd, Tt * 3 * d, 3 * d, 1), ac, (B * Tt * Tt, Tt * Tt, Tt), H, B, Tt, Tt, hd)
+        bd = None
+        if posp is not None:
+            Pn = 2 * Tt - 1
+            bd = torch.empty((H, B, Tt, Pn), device=dev, dtype=F32)
+            T.bgemm(qv, (hd, Tt * d, d, 1), posp, (hd, 0, d, 1), bd, (B * Tt * Pn, Tt * Pn, Pn), H, B, Tt, Pn, hd)
+        S["qu"], S["qv"] = qu, qv
+        return T.attn_softmax_fwd(ac, bd, lengths, H, B, Tt, Tt, 1.0 / math.sqrt(hd))
+
+    def _attention_bwd(self, dctx, S, p, pos, lengths, B, Tt, H):
+        """-> dqkv (M, 3d) bf16; accumulates pos_bias_u / pos_bias_v / linear_pos gradients."""
+        G, P = self.store.g, self.store.p
+        qkv, posp = S["qkv"], S["posp"]
+        d = qkv.shape[1] // 3
+        hd = d // H
+        M = B * Tt
+        dev = qkv.device
+        scale = 1.0 / math.sqrt(hd)
+        rel = posp is not None
+        prob = S.get("prob")
+        if prob is None:
+            prob = self._probs(qkv, posp, P(p + "att_u") if rel else None, P(p + "att_v") if rel else None, lengths, B, Tt, H, S)
+        qu, qv = S["qu"], S["qv"]
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        sTT = (B * Tt * Tt, Tt * Tt)
+        dqkv = torch.empty((M, 3 * d), device=dev, dtype=BF16)
+        # dP = dctx · V^T
+        dp = torch.empty((H, B, Tt, Tt), device=dev, dtype=F32)
+        T.bgemm(dctx, (hd, Tt * d, d, 1), v, (hd, Tt * 3 * d, 3 * d, 1), dp, (*sTT, Tt), H, B, Tt, Tt, hd)
+        ds, dbd = T.attn_softmax_bwd(prob, dp, H, B, Tt, Tt, scale, want_dbd=rel)
+        # dV = P^T · dctx
+        T.bgemm(prob, (*sTT, 1, Tt), dctx, (hd, Tt * d, 1, d), dqkv[:, 2 * d:], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt)
+        # dK = dS^T · (q + u)
+        aq, aq_str = (qu, (hd, Tt * d, 1, d)) if rel else (q, (hd, Tt * 3 * d, 1, 3 * d))
+        T.bgemm(ds, (*sTT, 1, Tt), aq, aq_str, dqkv[:, d:2 * d], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt)
+        if not rel:
+            # dQ = dS · K
+            T.bgemm(ds, (*sTT, Tt, 1), k, (hd, Tt * 3 * d, 1, 3 * d), dqkv[:, :d], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt)
+            return dqkv
+        Pn = 2 * Tt - 1
+        dqu = torch.empty((M, d), device=dev, dtype=F32)
+        dqv = torch.empty((M, d), device=dev, dtype=F32)
+        T.bgemm(ds, (*sTT, Tt, 1), k, (hd, Tt * 3 * d, 1, 3 * d), dqu, (hd, Tt * d, d), H, B, Tt, hd, Tt)
+        T.bgemm(dbd, (B * Tt * Pn, Tt * Pn, Pn, 1), posp, (hd, 0, 1, d), dqv, (hd, Tt * d, d), H, B, Tt, hd, Pn)
+        # d(posp) (P, d) = sum_b dBD^T · (q + v): K runs over the (b, t) rows of one head
+        dposp = torch.empty((Pn, d), device=dev, dtype=F32)
+        T.bgemm(dbd, (B * Tt * Pn, 0, 1, Pn), qv, (hd, 0, 1, d), dposp, (hd, 0, d), H, 1, Pn, hd, B * Tt)
+        T.add_cast(dqu, dqv, out=dqkv[:, :d])
+        T.colsum_(G(p + "att_u"), dqu)
+        T.colsum_(G(p + "att_v"), dqv)
+        # linear_pos: posp = table · Wpos^T  ->  dWpos += dposp^T · table
+        dpb = T.add_cast(dposp)
+        ops.gemm(T.transpose(dpb), pos[1], out=G(p + "att_wpos"), resid=G(p + "att_wpos"), alpha=1.0)
+        return dqkv
+
+    # ------------------------------------------------------------------ optimizer
+    def optimizer_step(self, lr=None):
+        """waits for the gradient all-reduces, clips by global norm, applies AdamW, refreshes the bf16 mirrors."""
+        st, hp = self.store, self.hp
+        self.sync.wait()
+        sc = self._scal
+        sc.zero_()
+        T.sumsq_(sc[0:1], st.flat_g)
+        T.clip_coef(sc[0:1], hp["max_grad_norm"] if hp["max_grad_norm"] else 0.0, sc[1:3])
+        st.step_count += 1
+        T.adamw_step_(st.flat_p, st.flat_g, st.flat_m, st.flat_v, st.decay, lr=hp["lr"] if lr is None else lr, betas=hp["betas"], eps=hp["eps"],
+                      weight_decay=hp["weight_decay"], step=st.step_count, norm_coef=sc[1:3], mirror=st.flat_bf)
+        st.refresh_mirrors(cast=False)
+        return sc[1]          # gradient norm (device scalar)
+
+    def train_step(self, feats, feat_lengths, labels, lr=None):
+        self.store.zero_grad()
+        out = self.forward_backward(feats, feat_lengths, labels)
+        out["grad_norm"] = self.optimizer_step(lr)
+        return out

@@ -107,6 +107,42 @@ def run_encoder_case(name, cfg_kwargs, seed, B, T, lengths, U, tgt_lens, full=Tr
     print(name, "loss", rec["loss"], "logit std", float(logits.std()), {k: v for k, v in rec.items() if k.startswith("bf16")})
 
 
+# the CSGU dropout's constructor argument is `ebranchformer_conv_dropout` (stored as config.csgu_conv_dropout, e_branchformer.py:44,57)
+NO_DROPOUT = dict(hidden_dropout=0.0, activation_dropout=0.0, attention_dropout=0.0, final_dropout=0.0, feat_proj_dropout=0.0,
+                  ebranchformer_conv_dropout=0.0, apply_spec_augment=False)
+
+
+def run_grad_case(name, cfg_kwargs, seed, B, T, lengths, U, tgt_lens, **extra):
+    """training-mode forward + backward of the reference model (dropouts 0, no SpecAugment): loss and every parameter gradient."""
+    cfg, model = build_reference(cfg_kwargs, **NO_DROPOUT, **extra)
+    model.train()
+    wsum = load_seeded(model, seed)
+    x, am = synth_feats(seed, B, T, lengths)
+    lab = synth_labels(seed, B, U, cfg.vocab_size, tgt_lens)
+    out = model(torch.from_numpy(x), attention_mask=torch.from_numpy(am), labels=torch.from_numpy(lab))
+    out.loss.backward()
+    rec = dict(seed=seed, weight_sum=wsum, lengths=np.array(lengths), tgt_lens=np.array(tgt_lens), shape=np.array([B, T, U]), loss=float(out.loss))
+    assert cfg.csgu_conv_dropout == 0.0
+    g32 = {k: v.grad.float().clone() for k, v in model.named_parameters() if v.grad is not None}
+    for k, v in g32.items():
+        rec["grad:" + k] = v.numpy()
+    # the reference's own bf16-autocast backward vs its fp32 backward: the yard-stick for the HIP path's bf16 gradients
+    model.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ob = model(torch.from_numpy(x), attention_mask=torch.from_numpy(am), labels=torch.from_numpy(lab))
+    ob.loss.float().backward()
+    rec["bf16_loss"] = float(ob.loss)
+    gaps = []
+    for k, v in model.named_parameters():
+        if v.grad is not None and float(g32[k].norm()) > 1e-6:
+            gaps.append(float((v.grad.float() - g32[k]).norm() / g32[k].norm()))
+    rec["bf16_grad_relerr_max"] = max(gaps)
+    rec["bf16_grad_relerr_mean"] = float(np.mean(gaps))
+    print("  autocast-vs-fp32 gradient gap: max", max(gaps), "mean", float(np.mean(gaps)))
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
+    print(name, "loss", rec["loss"], "n grads", sum(k.startswith("grad:") for k in rec))
+
+
 def run_fbank_cases():
     from utilities.feature_extractors import CustomFeatureExtractor
 
@@ -324,7 +360,7 @@ def run_ctc_prefix_cases():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "base", "fbank", "lengths", "ctc", "prefix", "aed", "whisper"]
+    which = sys.argv[1:] or ["tiny", "grads", "base", "fbank", "lengths", "ctc", "prefix", "aed", "whisper"]
     if "tiny" in which:
         run_encoder_case("tiny_rel", TINY, seed=11, B=2, T=200, lengths=[198, 150], U=7, tgt_lens=[7, 5])
         run_encoder_case("tiny_rotary", TINY, seed=12, B=2, T=200, lengths=[200, 131], U=6, tgt_lens=[6, 4],
@@ -332,6 +368,10 @@ if __name__ == "__main__":
         run_encoder_case("tiny_causal", TINY, seed=13, B=2, T=160, lengths=[160, 97], U=5, tgt_lens=[5, 3], is_causal=True)
         run_encoder_case("tiny_nomacaron", TINY, seed=14, B=1, T=120, lengths=[120], U=4, tgt_lens=[4], use_macaron_ff=True,
                          csgu_activation="gelu", csgu_use_linear_after_conv=True)
+    if "grads" in which:
+        run_grad_case("grads_tiny_rel", TINY, seed=11, B=2, T=200, lengths=[198, 150], U=7, tgt_lens=[7, 5])
+        run_grad_case("grads_tiny_rotary", TINY, seed=12, B=2, T=200, lengths=[200, 131], U=6, tgt_lens=[6, 4], position_embeddings_type="rotary")
+        # (use_macaron_ff=False is not runnable in the reference: its layer forward reads self.ff1 unconditionally, e_branchformer.py:271)
     if "base" in which:
         run_encoder_case("small_rel", SMALL, seed=21, B=2, T=1000, lengths=[998, 700], U=40, tgt_lens=[40, 31], full=False)
         run_encoder_case("base_rel", BASE, seed=22, B=2, T=1000, lengths=[998, 700], U=40, tgt_lens=[40, 31], full=False,

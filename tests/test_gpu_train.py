@@ -1,0 +1,116 @@
+"""GPU parity of the training step: loss + EVERY parameter gradient of the HIP trainer against
+  (a) the golden gradients of the imported reference model (tests/golden/grads_*.npz, made by make_golden.py from
+      Wav2Vec2EBranchformerForCTC in train() mode with dropouts 0, fp32), and
+  (b) torch autograd of the CPU oracle on other configurations (head size 64 -> fused forward attention + recomputed probabilities).
+
+Tolerance: the HIP path computes activations AND activation gradients in bf16 (the reference's autocast recipe), the fixtures
+are fp32: per tensor,  |g - g_ref|_2 <= 3 % of |g_ref|_2  and cosine >= 0.999.  The yard-stick is stored in the fixtures: the reference's own
+bf16-autocast backward differs from its fp32 backward by 1.7-2.0 % (mean over tensors, `bf16_grad_relerr_mean`); measured here: <= 1.4 % on
+every tensor.  Loss within 1e-3 relative."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import case_inputs, load_golden
+from huggingface_asr_amd import shapes
+from oracle import ebranchformer_ref as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+NO_DROPOUT = dict(hidden_dropout=0.0, activation_dropout=0.0, attention_dropout=0.0, final_dropout=0.0, feat_proj_dropout=0.0,
+                  csgu_conv_dropout=0.0, apply_spec_augment=False, layerdrop=0.0)
+
+
+def _trainer(cfg, sd, **kw):
+    from huggingface_asr_amd.train import EncoderCTCTrainer
+    tr = EncoderCTCTrainer(dict(cfg, **NO_DROPOUT), DEV, **kw)
+    tr.load_state_dict(sd)
+    return tr
+
+
+def _compare(grads, ref, rel=0.03, cos_min=0.999):
+    worst = []
+    gmax = max(float(torch.as_tensor(v).float().norm()) for v in ref.values())
+    for k, want in ref.items():
+        got = grads[k].float().cpu().reshape(-1)
+        want = torch.as_tensor(want).float().reshape(-1)
+        assert got.shape == want.shape, k
+        nw = float(want.norm())
+        err = float((got - want).norm())
+        cos = float(F.cosine_similarity(got, want, dim=0)) if nw > 0 else 1.0
+        if nw < 1e-5:          # mathematically zero gradients (key bias under softmax): only bf16 noise on our side, fp32 noise in the fixture
+            assert err < 1e-3 * gmax, (k, err, gmax)
+            continue
+        worst.append((err / nw, cos, k))
+    worst.sort(reverse=True)
+    bad = [(e, c, k) for e, c, k in worst if e > rel or c < cos_min]
+    assert not bad, f"{len(bad)} gradient tensors off; worst: {bad[:6]}"
+    return worst[0]
+
+
+@pytest.mark.parametrize("name,extra", [("grads_tiny_rel", {}), ("grads_tiny_rotary", {"position_embeddings_type": "rotary"})])
+def test_gradients_match_reference_golden(name, extra):
+    g = load_golden(name)
+    cfg = dict(shapes.TINY, ctc_zero_infinity=True, ctc_loss_reduction="mean", **extra)
+    sd, x, am, lab = case_inputs(g, cfg)
+    tr = _trainer(cfg, sd)
+    tr.store.zero_grad()
+    out = tr.forward_backward(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV))
+    torch.cuda.synchronize()
+    assert abs(float(out["loss"]) - float(g["loss"])) <= 1e-3 * abs(float(g["loss"])) + 1e-3
+    ref = {k[5:]: g[k] for k in g.files if k.startswith("grad:")}
+    grads = tr.grad_dict()
+    assert set(ref) <= set(grads), sorted(set(ref) - set(grads))[:5]
+    _compare(grads, ref)
+
+
+def _oracle_grads(cfg, sd, x, am, lab):
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    hidden = R.encoder_forward(sdr, cfg, x, am)
+    logits = R.ctc_head(sdr, hidden)
+    in_len = R.conv_out_lengths_outer(am.sum(-1), cfg).long()
+    tl = (lab >= 0).sum(-1)
+    loss = F.ctc_loss(torch.log_softmax(logits, -1).transpose(0, 1), lab[lab >= 0], in_len, tl, blank=logits.shape[-1] - 1,
+                      reduction=cfg.get("ctc_loss_reduction", "mean"), zero_infinity=True)
+    loss.backward()
+    return float(loss.detach()), {k: v.grad for k, v in sdr.items() if v.grad is not None}
+
+
+def test_gradients_match_oracle_autograd_head64():
+    """d=256 / 4 heads (head 64: fused LDS attention forward, probabilities recomputed in backward), no attention mask."""
+    cfg = dict(shapes.TINY, hidden_size=256, intermediate_size=512, num_hidden_layers=2, vocab_size=50, ctc_zero_infinity=True, ctc_loss_reduction="sum")
+    from helpers import seeded_state_dict, synth_feats, synth_labels
+    sd = seeded_state_dict(cfg, 31)
+    x, am = synth_feats(31, 3, 160, [160, 160, 160])
+    lab = synth_labels(31, 3, 6, 50, [6, 4, 5])
+    loss_ref, ref = _oracle_grads(cfg, sd, x, am, lab)
+    tr = _trainer(cfg, sd)
+    tr.store.zero_grad()
+    out = tr.forward_backward(x.to(DEV), None, lab.to(DEV))
+    assert abs(float(out["loss"]) - loss_ref) <= 2e-3 * abs(loss_ref)
+    _compare(tr.grad_dict(), ref, rel=0.04)
+
+
+def test_train_steps_reduce_loss_and_roundtrip_state_dict():
+    g = load_golden("grads_tiny_rel")
+    cfg = dict(shapes.TINY, ctc_zero_infinity=True, ctc_loss_reduction="mean")
+    sd, x, am, lab = case_inputs(g, cfg)
+    tr = _trainer(cfg, sd, lr=1e-3, weight_decay=1e-6)
+    back = tr.state_dict()
+    for k, v in sd.items():
+        assert torch.equal(back[k].cpu(), v), k
+    losses = []
+    for _ in range(8):
+        out = tr.train_step(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV))
+        losses.append(float(out["loss"]))
+    assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[0], losses
+    assert float(out["grad_norm"]) > 0
+    # the inference engine loads the trained weights and reproduces the trainer's forward
+    from huggingface_asr_amd.engine import EBranchformerEngine
+    eng = EBranchformerEngine(cfg, DEV)
+    eng.load_state_dict(tr.state_dict())
+    o_inf = eng.forward(x.to(DEV), am.sum(-1).to(DEV))
+    o_tr = tr.forward_backward(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV), backward=False)
+    d = (o_inf["logits"].float() - o_tr["logits"].float()).abs()
+    assert float(d.max()) < 0.06 and float(d.mean()) < 0.009

@@ -1,0 +1,85 @@
+"""CPU tests of the training step's host logic (no kernels): the flat parameter store's packed layout <-> the reference's
+state-dict names, the weight-decay mask (HF Trainer rule), and the data-parallel gradient all-reduce over gloo, world size 2."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from huggingface_asr_amd import shapes, synth
+from huggingface_asr_amd.train import GradSync, ParamStore, _enc_map, encoder_specs
+
+
+def _sd(cfg, seed=3):
+    return {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), seed).items()}
+
+
+@pytest.mark.parametrize("extra", [{}, {"position_embeddings_type": "rotary"}])
+def test_packed_layout_roundtrips_every_reference_parameter(extra):
+    cfg = dict(shapes.TINY, **extra)
+    sd = _sd(cfg)
+    specs = encoder_specs(cfg)
+    mp_ = _enc_map(cfg)
+    store = ParamStore(specs, "cpu")
+    covered = {}
+    for s in specs:
+        packed = mp_[s.name][0](sd).reshape(s.shape)
+        store.p(s.name).copy_(packed)
+        for key, back in mp_[s.name][1]:
+            covered[key] = back(store.p(s.name))
+    assert set(covered) == set(sd), (sorted(set(sd) - set(covered))[:5], sorted(set(covered) - set(sd))[:5])
+    for k, v in sd.items():
+        assert covered[k].shape == v.shape and torch.equal(covered[k], v), k
+    # offsets are 64-element aligned (16-B aligned bf16 rows for the GEMM loads), ranges do not overlap
+    offs = sorted((store.off[n], n) for n in store.order)
+    for (o, n), (o2, _) in zip(offs, offs[1:]):
+        assert o % 64 == 0 and o + torch.Size(store.specs[n].shape).numel() <= o2
+
+
+def test_weight_decay_mask_follows_hf_trainer_rule():
+    """HF Trainer: decay everything except LayerNorm parameters and names containing 'bias' (so pos_bias_u / pos_bias_v are excluded)."""
+    cfg = dict(shapes.TINY)
+    specs = {s.name: s for s in encoder_specs(cfg)}
+    assert specs["l0.ff1_w1"].decay and specs["conv1_w"].decay and specs["l0.csgu_w"].decay and specs["l1.mrg_dw_w"].decay and specs["head_w"].decay
+    for n in ("l0.ff1_b1", "l0.att_ln_g", "l0.att_ln_b", "l0.att_u", "l0.att_v", "head_b", "enc_ln_g", "l1.csgu_ln_g", "conv2_b"):
+        assert not specs[n].decay, n
+    store = ParamStore(list(specs.values()), "cpu")
+    o = store.off["l0.ff1_w1"]
+    assert int(store.decay[o]) == 1 and int(store.decay[store.off["l0.ff1_b1"]]) == 0
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    from huggingface_asr_amd import parallel as P
+    P.init("gloo")
+    n = 1000
+    flat = torch.arange(n, dtype=torch.float32) * (rank + 1)          # stand-in for this rank's flat gradient
+    sync = GradSync(flat)
+    assert sync.on and sync.world == world
+    for lo, hi in ((768, 1000), (256, 768), (0, 256)):               # head bucket, layer buckets in reverse order, front end
+        sync.launch(lo, hi)
+    sync.wait()
+    out[rank] = flat.clone()
+    P.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_gradsync_gloo_world2_sums_every_bucket():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    want = torch.arange(1000, dtype=torch.float32) * 3
+    assert torch.equal(out[0], want) and torch.equal(out[1], want)
+
+
+def test_gradsync_single_process_is_a_noop():
+    flat = torch.ones(10)
+    s = GradSync(flat)
+    s.launch(0, 10); s.wait()
+    assert not s.on and s.world == 1 and torch.equal(flat, torch.ones(10))
