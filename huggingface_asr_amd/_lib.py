@@ -64,6 +64,8 @@ SIGNATURES = {
     "mi_sumsq_f32": [vp, i64, vp, vp],
     "mi_clip_coef": [vp, f32, vp, vp],
     "mi_adamw_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, vp, vp],
+    "mi_gemm_tn_workspace_bytes": [i32, i32, i32],
+    "mi_gemm_tn_bf16": [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp, sz, vp],
     "mi_bgemm_bf16": [vp, i64, i64, i64, i64, vp, i64, i64, i64, i64, vp, i64, i64, i64, i32, i32, f32, i32, i32, i32, i32, i32, vp],
     "mi_attn_softmax_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "mi_attn_softmax_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
@@ -102,7 +104,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(h, name)          # AttributeError here = header/library mismatch: fail loudly
             fn.argtypes = args
-            fn.restype = sz if name in ("mi_ebf_workspace_bytes", "mi_ctc_bwd_workspace_bytes") else i32
+            fn.restype = sz if name in ("mi_ebf_workspace_bytes", "mi_ctc_bwd_workspace_bytes", "mi_gemm_tn_workspace_bytes") else i32
         h.mi_profile_create.argtypes = [i32]; h.mi_profile_create.restype = i32
         h.mi_profile_enable.argtypes = [i32]; h.mi_profile_enable.restype = None
         h.mi_profile_reset.argtypes = []; h.mi_profile_reset.restype = None

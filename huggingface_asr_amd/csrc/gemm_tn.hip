@@ -1,0 +1,183 @@
+// Weight-gradient GEMM for gfx950:   dW[n][k] += sum_m dY[m][n] * X[m][k]      (dY (M,N) bf16, X (M,K) bf16, dW (N,K) fp32)
+//
+// The contraction runs over the ROWS of both operands (M = B*T' is long, the output N x K is small), so neither operand is
+// K-contiguous for the MFMA: instead of materialising dYᵀ / Xᵀ in HBM, the [64 m][128 cols] tiles go to LDS as they lie in
+// memory (`global_load_lds_dwordx4`, 16-B chunk index XOR-swizzled with the row on the SOURCE side) and the MFMA fragments are
+// fetched with the transposing LDS read `ds_read_b64_tr_b16` (a 16-lane group turns a 4 x 16 block around: lane i gets the 4
+// consecutive m of column i).  Both operands use the same m-permutation inside a 16-step, so the products line up.
+// Output tiles are few (N*K/128² = 16 ... 160), so M is split over `splits` blocks per tile: each writes its fp32 partial tile
+// to a slab, `slab_reduce_kernel` adds the slabs into dW (splits == 1: accumulate in place).
+// Block 128 x 128, 4 waves (2x2) of 64 x 64, 2-stage LDS ring (64 KiB -> two blocks per CU).
+#include "common.hpp"
+
+namespace {
+
+constexpr int TN_T = 128, TN_KM = 64, TN_STAGE = 2 * TN_KM * TN_T * 2;   // 32 KiB per stage (dY tile + X tile)
+
+__device__ __attribute__((aligned(16))) uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct TnArgs {
+    const bf16_t* Y; long ldy;
+    const bf16_t* X; long ldx;
+    float* out; long ldo;          // splits == 1: dW (accumulated);  else: slab base, slab s at out + s * slab_stride
+    long slab_stride;
+    int M, N, K, n_store, splits, rows_per_split;
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int cb, int s, int lane) {
+    const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+    const int col = cb + (g & 1) * 16 + 4 * p4;
+    const int lc = col >> 3, within = (col & 7) * 2;
+    const int k0 = 16 * s + 4 * (g >> 1) + q4, k1 = k0 + 8;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + k0 * 256 + ((lc ^ (k0 & 15)) << 4) + within));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + k1 * 256 + ((lc ^ (k1 & 15)) << 4) + within));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int ntn = (p.N + TN_T - 1) / TN_T, ntk = (p.K + TN_T - 1) / TN_T;
+    const int ntiles = ntn * ntk;
+    const int split = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
+    const int n0 = (tile / ntk) * TN_T, k0 = (tile % ntk) * TN_T;
+    const int m_lo = split * p.rows_per_split, m_hi = min(p.M, m_lo + p.rows_per_split);
+    const int nit = (m_hi - m_lo + TN_KM - 1) / TN_KM;
+
+    // piece q of this wave: 1 KiB = 4 rows x 256 B of one operand tile; pieces [0,16) dY, [16,32) X
+    const int prow = lane >> 4, cs = lane & 15;
+    const bf16_t* src[8];
+    int rowin[8];
+    bool colok[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int g = wave * 8 + q;
+        const bool isY = g < 16;
+        const int row = (g & 15) * 4 + prow;                 // m within the stage
+        const int c = cs ^ (row & 15);                       // source chunk for LDS slot cs
+        rowin[q] = row;
+        if (isY) { colok[q] = n0 + c * 8 < p.N; src[q] = p.Y + n0 + c * 8; }
+        else { colok[q] = k0 + c * 8 < p.K; src[q] = p.X + k0 + c * 8; }
+    }
+    auto issue = [&](int it, int stage) {
+        char* sbase = smem + stage * TN_STAGE + wave * 8 * 1024;
+        const int mb = m_lo + it * TN_KM;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int g = wave * 8 + q;
+            const int m = mb + rowin[q];
+            const bf16_t* sp = (m < m_hi && colok[q]) ? src[q] + (long)m * (g < 16 ? p.ldy : p.ldx) : reinterpret_cast<const bf16_t*>(&g_zero16);
+            __builtin_amdgcn_global_load_lds((gptr_t)sp, (lptr_t)(sbase + q * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nit > 0) issue(0, 0);
+    for (int it = 0; it < nit; ++it) {
+        const int stage = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (it + 1 < nit) issue(it + 1, stage ^ 1);
+        const char* ty = smem + stage * TN_STAGE;
+        const char* tx = ty + TN_KM * TN_T * 2;
+#pragma unroll
+        for (int s = 0; s < TN_KM / 16; ++s) {
+            bf16x8 fy[2], fx[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fy[i] = tr_frag(ty, wn * 64 + i * 32, s, lane);
+                fx[i] = tr_frag(tx, wk * 64 + i * 32, s, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);   // rows n (regs), cols k (lanes)
+        }
+    }
+    // C layout: col (k) = lane & 31, row (n) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const int lr = lane & 31, lh = lane >> 5;
+    float* outp = p.out + (p.splits > 1 ? (long)split * p.slab_stride : 0L);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = k0 + wk * 64 + j * 32 + lr;
+            if (k >= p.K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (n >= p.n_store) continue;
+                float* o = outp + (long)n * p.ldo + k;
+                if (p.splits > 1) *o = acc[i][j][r];
+                else *o += acc[i][j][r];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ out, long ldo, const float* __restrict__ slabs, long slab_stride,
+                                                           int splits, int rows, int cols) {
+    const long total = (long)rows * cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        float s = 0.f;
+        for (int q = 0; q < splits; ++q) s += slabs[q * slab_stride + i];
+        out[(long)r * ldo + c] += s;
+    }
+}
+
+}  // namespace
+
+// workspace floats needed for a given problem (0 when a single split is used)
+static int tn_splits(int M, int N, int K) {
+    const int tiles = cdiv(N, TN_T) * cdiv(K, TN_T);
+    int s = 512 / tiles;                               // two blocks per CU on 256 CUs
+    const int max_s = cdiv(M, 4 * TN_KM);              // at least 4 K-iterations per block
+    if (s > max_s) s = max_s;
+    return s < 1 ? 1 : s;
+}
+extern "C" size_t mi_gemm_tn_workspace_bytes(int M, int N, int K) {
+    const int s = tn_splits(M, N, K);
+    return s > 1 ? (size_t)s * N * K * sizeof(float) : 0;
+}
+
+// dW (n_store, K) fp32 (row stride ldo) += dY[:, :N]^T · X;  N, K % 8 == 0, rows of dY / X 16-B aligned; n_store <= N
+extern "C" int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx, float* dW, long ldo, int M, int N, int K, int n_store,
+                               void* workspace, size_t workspace_bytes, hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || N <= 0 || K <= 0 || (N % 8) || (K % 8) || (ldy % 8) || (ldx % 8) || n_store > N || n_store <= 0) return MI_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(dY) & 15) || (reinterpret_cast<uintptr_t>(X) & 15)) return MI_ERR_ARG;
+    int splits = tn_splits(M, N, K);
+    if (splits > 1 && workspace_bytes < (size_t)splits * N * K * sizeof(float)) return MI_ERR_ARG;
+    TnArgs p{};
+    p.Y = (const bf16_t*)dY; p.ldy = ldy; p.X = (const bf16_t*)X; p.ldx = ldx;
+    p.M = M; p.N = N; p.K = K; p.n_store = n_store; p.splits = splits;
+    p.rows_per_split = cdiv(cdiv(M, splits), TN_KM) * TN_KM;
+    if (splits > 1) { p.out = (float*)workspace; p.ldo = K; p.slab_stride = (long)N * K; }
+    else { p.out = dW; p.ldo = ldo; p.slab_stride = 0; }
+    const int tiles = cdiv(N, TN_T) * cdiv(K, TN_T);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), 2 * TN_STAGE, st, p);
+    MI_CHECK_LAUNCH();
+    if (splits > 1) {
+        const long total = (long)n_store * K;
+        const long g = (total + 255) / 256;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, st, dW, ldo, (const float*)workspace, p.slab_stride,
+                           splits, n_store, K);
+        MI_CHECK_LAUNCH();
+    }
+    return MI_OK;
+}

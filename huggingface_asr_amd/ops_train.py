@@ -203,22 +203,36 @@ def adamw_step_(p, g, m, v, decay, *, lr, betas=(0.9, 0.999), eps=1e-8, weight_d
                                   float(betas[1]), float(eps), float(weight_decay), int(step), _p(norm_coef), _p(mirror), _stream()), "mi_adamw_step")
 
 
+_TN_WS = {}
+
+
+def gemm_tn_(dw, dy, x, n_store=None):
+    """dw (n_store, K) f32 += dy[:, :N]^T · x   (dy (M,N) bf16, x (M,K) bf16 row views; contraction over rows, no transposes)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    n_store = dw.shape[0] if n_store is None else n_store
+    nbytes = _L().mi_gemm_tn_workspace_bytes(M, N, K)
+    key = dy.device
+    ws = _TN_WS.get(key)
+    if nbytes and (ws is None or ws.numel() < nbytes):
+        ws = _TN_WS[key] = torch.empty(nbytes, device=dy.device, dtype=torch.uint8)
+    _lib.check(_L().mi_gemm_tn_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0), M, N, K, n_store,
+                                    ws.data_ptr() if nbytes else 0, nbytes, _stream()), "mi_gemm_tn_bf16")
+    return dw
+
+
 # ---------------------------------------------------------------------------------------------------------------- composites
-def linear_bwd(dy, x, wT, *, dw=None, db=None, dx_out=None, dx_dtype=BF16, xT=None, dyT=None, need_dx=True):
+def linear_bwd(dy, x, wT, *, dw=None, db=None, dx_out=None, dx_dtype=BF16, need_dx=True):
     """Backward of y = x W^T + b for bf16 row-major activations.
     dy (M,N) bf16, x (M,K) bf16, wT (K,N) bf16 (the transposed copy of W the trainer keeps).
-    dx = dy · W (GEMM with W^T as the (N',K') operand); dW (N,K) f32 += dy^T · x (GEMM over the zero-padded transposes); db += colsum(dy)."""
+    dx = dy · W (GEMM with W^T as the (N',K') operand); dW (N,K) f32 += dy^T · x (row-contraction GEMM, gemm_tn.hip); db += colsum(dy)."""
     M, N = dy.shape
     K = x.shape[1]
     dx = None
     if need_dx:
         dx = gemm(dy, wT[:, :N], out=dx_out, out_dtype=dx_dtype)
     if dw is not None:
-        if dyT is None:
-            dyT = transpose(dy)
-        if xT is None:
-            xT = transpose(x)
-        gemm(dyT, xT, out=dw, resid=dw, alpha=1.0)
+        gemm_tn_(dw, dy, x)
     if db is not None:
         colsum_(db, dy)
     return dx

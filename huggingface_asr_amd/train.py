@@ -313,7 +313,7 @@ class EncoderCTCTrainer:
                 pe = torch.zeros(2 * T2 - 1, d)
                 pe[:, 0::2] = torch.sin(pos * div); pe[:, 1::2] = torch.cos(pos * div)
                 t = pe.to(self.device).to(BF16).contiguous()
-                self._pos[key] = (t, T.transpose(t))
+                self._pos[key] = (t,)
             elif ptype == "rotary":
                 hd = d // H
                 inv = 1.0 / (c.get("rotary_embedding_base", 10000) ** (torch.arange(0, hd, 2, dtype=torch.int64).float() / hd))
@@ -431,9 +431,7 @@ class EncoderCTCTrainer:
         gs = float(loss_scale) / self.sync.world
         dlog = T.ctc_loss_bwd(logits, lse, labels, outer, nll, reduction=red, gscale=gs, ldo=ldl)         # (M, ldl) bf16
         dhid = T.gemm(dlog, WT("head_w"))                                                                # (M, d) bf16
-        dlT = T.transpose(dlog)
-        hidT = T.transpose(hid)
-        ops.gemm(dlT[:V1], hidT, out=G("head_w"), resid=G("head_w"), alpha=1.0)
+        T.gemm_tn_(G("head_w"), dlog, hid, n_store=V1)
         T.colsum_(G("head_b"), dlog[:, :V1])
         dx = e32(M, d)
         T.layernorm_bwd(x, P("enc_ln_g"), dhid, dx, accumulate=False, dgamma=G("enc_ln_g"), dbeta=G("enc_ln_b"), eps=eps_e)
@@ -493,7 +491,7 @@ class EncoderCTCTrainer:
         dpre2 = T.act_bwd(dact2.view(B * T2 * F2, C2), pre2)
         T.colsum_(G("conv2_b"), dpre2)
         col = T.im2col(act1, K, s_, pad, T2, F2)
-        ops.gemm(T.transpose(dpre2), T.transpose(col), out=G("conv2_w"), resid=G("conv2_w"), alpha=1.0)
+        T.gemm_tn_(G("conv2_w"), dpre2, col)
         dcol = ops.gemm(dpre2, WT("conv2_w")[:, :C2])
         del col
         T.conv2d_first_bwd(feats, P("conv1_w"), P("conv1_b"), dcol, G("conv1_w"), G("conv1_b"), K, s_, pad, T1, F1, K, s_, pad, T2, F2)
@@ -614,7 +612,7 @@ class EncoderCTCTrainer:
         T.colsum_(G(p + "att_v"), dqv)
         # linear_pos: posp = table · Wpos^T  ->  dWpos += dposp^T · table
         dpb = T.add_cast(dposp)
-        ops.gemm(T.transpose(dpb), pos[1], out=G(p + "att_wpos"), resid=G(p + "att_wpos"), alpha=1.0)
+        T.gemm_tn_(G(p + "att_wpos"), dpb, pos[0])
         return dqkv
 
     # ------------------------------------------------------------------ optimizer
