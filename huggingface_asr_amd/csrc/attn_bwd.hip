@@ -16,6 +16,7 @@ struct SmArgs {
     bf16_t* ds; bf16_t* dbd;              // backward outputs (dbd may be null)
     const int* lengths;                   // valid keys per utterance or null
     int H, B, Tq, Tk, causal;
+    long ld_s, ld_p;                      // row strides (elements) of the (.., Tk) and (.., 2T-1) matrices
     float scale;
 };
 
@@ -32,9 +33,8 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(SmArgs p) {
     const long rows = (long)p.H * p.B * p.Tq;
     if (row >= rows) return;
     const int i = (int)(row % p.Tq), b = (int)((row / p.Tq) % p.B);
-    const int P = 2 * p.Tq - 1;
-    const float* ac = p.ac + row * p.Tk;
-    const float* bd = p.bd ? p.bd + row * P + (p.Tq - 1 - i) : nullptr;
+    const float* ac = p.ac + row * p.ld_s;
+    const float* bd = p.bd ? p.bd + row * p.ld_p + (p.Tq - 1 - i) : nullptr;
     float mx = -INFINITY;
     for (int j = lane; j < p.Tk; j += 64) {
         if (key_masked(p, b, i, j)) continue;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(SmArgs p) {
     }
     s = wave_sum(s);
     const float inv = s > 0.f ? 1.f / s : 0.f;
-    bf16_t* out = p.prob + row * p.Tk;
+    bf16_t* out = p.prob + row * p.ld_s;
     for (int j = lane; j < p.Tk; j += 64) {
         float v = 0.f;
         if (!key_masked(p, b, i, j)) v = __expf((ac[j] + (bd ? bd[j] : 0.f)) * p.scale - mx) * inv;
@@ -63,16 +63,16 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(SmArgs p) {
     const long rows = (long)p.H * p.B * p.Tq;
     if (row >= rows) return;
     const int i = (int)(row % p.Tq);
-    const bf16_t* pr = p.prob + row * p.Tk;
-    const float* dp = p.dp + row * p.Tk;
+    const bf16_t* pr = p.prob + row * p.ld_s;
+    const float* dp = p.dp + row * p.ld_s;
     float dot = 0.f;
     for (int j = lane; j < p.Tk; j += 64) dot += bf2f(pr[j]) * dp[j];
     dot = wave_sum(dot);
-    bf16_t* ds = p.ds + row * p.Tk;
+    bf16_t* ds = p.ds + row * p.ld_s;
     for (int j = lane; j < p.Tk; j += 64) ds[j] = f2bf(bf2f(pr[j]) * (dp[j] - dot) * p.scale);
     if (p.dbd) {
         const int P = 2 * p.Tq - 1, off = p.Tq - 1 - i;
-        bf16_t* dbd = p.dbd + row * P;
+        bf16_t* dbd = p.dbd + row * p.ld_p;
         for (int q = lane; q < P; q += 64) {
             const int j = q - off;
             dbd[q] = (j >= 0 && j < p.Tk) ? f2bf(bf2f(pr[j]) * (dp[j] - dot) * p.scale) : (bf16_t)0.f;
@@ -82,21 +82,22 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(SmArgs p) {
 
 }  // namespace
 
+// ld_s: row stride of ac / prob / dp / ds (>= Tk); ld_p: row stride of bd / dbd (>= 2 Tq - 1).  Padding columns are never read.
 extern "C" int mi_attn_softmax_fwd(const float* ac, const float* bd, const int* lengths, void* prob, int H, int B, int Tq, int Tk,
-                                   float scale, int causal, hipStream_t st) {
+                                   long ld_s, long ld_p, float scale, int causal, hipStream_t st) {
     MI_ENTER();
-    if (H <= 0 || B <= 0 || Tq <= 0 || Tk <= 0 || (bd && Tq != Tk)) return MI_ERR_ARG;
-    SmArgs p{ac, bd, nullptr, (bf16_t*)prob, nullptr, nullptr, lengths, H, B, Tq, Tk, causal, scale};
+    if (H <= 0 || B <= 0 || Tq <= 0 || Tk <= 0 || (bd && Tq != Tk) || ld_s < Tk || (bd && ld_p < 2 * Tq - 1)) return MI_ERR_ARG;
+    SmArgs p{ac, bd, nullptr, (bf16_t*)prob, nullptr, nullptr, lengths, H, B, Tq, Tk, causal, ld_s, ld_p, scale};
     hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv((long)H * B * Tq, 4)), dim3(256), 0, st, p);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
 
-extern "C" int mi_attn_softmax_bwd(const void* prob, const float* dp, void* ds, void* dbd, int H, int B, int Tq, int Tk, float scale,
-                                   hipStream_t st) {
+extern "C" int mi_attn_softmax_bwd(const void* prob, const float* dp, void* ds, void* dbd, int H, int B, int Tq, int Tk, long ld_s, long ld_p,
+                                   float scale, hipStream_t st) {
     MI_ENTER();
-    if (H <= 0 || B <= 0 || Tq <= 0 || Tk <= 0 || (dbd && Tq != Tk)) return MI_ERR_ARG;
-    SmArgs p{nullptr, nullptr, dp, (bf16_t*)prob, (bf16_t*)ds, (bf16_t*)dbd, nullptr, H, B, Tq, Tk, 0, scale};
+    if (H <= 0 || B <= 0 || Tq <= 0 || Tk <= 0 || (dbd && Tq != Tk) || ld_s < Tk || (dbd && ld_p < 2 * Tq - 1)) return MI_ERR_ARG;
+    SmArgs p{nullptr, nullptr, dp, (bf16_t*)prob, (bf16_t*)ds, (bf16_t*)dbd, nullptr, H, B, Tq, Tk, 0, ld_s, ld_p, scale};
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3(cdiv((long)H * B * Tq, 4)), dim3(256), 0, st, p);
     MI_CHECK_LAUNCH();
     return MI_OK;

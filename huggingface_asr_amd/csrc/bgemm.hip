@@ -4,9 +4,13 @@
 //   C[z1,z2][m][n] = alpha * sum_k A[z1,z2][m][k] * B[z1,z2][n][k]  (+ C)
 //
 // Every operand is addressed by element strides, so Q·Kᵀ, P·V, Pᵀ·dO, dSᵀ·Q and the batch-reduced dBDᵀ·(q+v) (K runs over
-// (b, t) with one uniform stride) are the same kernel.  One of (row stride, k stride) must be 1 per operand: k-contiguous
-// operands are staged with 16-B loads, row-contiguous ones with 16-B loads + a transposing LDS write.
-// Tile 64x64x32, 4 waves (2x2) of one v_mfma_f32_32x32x16_bf16 tile each, register-staged prefetch of the next K tile.
+// (b, t) with one uniform stride) are the same kernel.  One of (row stride, k stride) must be 1 per operand:
+//   * k-contiguous operands are staged [row][k] (16-B loads / stores) and read as two 8-B halves per lane,
+//   * row-contiguous operands are staged as they lie in memory, [k][row] (16-B loads / stores), and read with the transposing
+//     LDS read ds_read_b64_tr_b16 (no scalar transposing writes);
+// both read paths deliver the same k-permutation inside a 16-step ({4h..4h+3} ∪ {8+4h..8+4h+3}, h = lane >> 5), so any mix of
+// operand layouts multiplies correctly.  Tile 64x64x32, 4 waves (2x2) of one v_mfma_f32_32x32x16_bf16 tile each,
+// register-staged prefetch of the next K tile.
 #include "common.hpp"
 
 namespace {
@@ -20,7 +24,13 @@ struct BgArgs {
     int Z2, M, N, K;
 };
 
-constexpr int TM = 64, TK = 32, LDS_LD = TK + 8;
+constexpr int TM = 64, TK = 32;
+constexpr int LD0 = TK + 8;       // [row][k] image: 80-B rows
+constexpr int LD1 = TM + 8;       // [k][row] image: 144-B rows (4 consecutive k rows land on disjoint bank groups)
+constexpr int TILE_ELEMS = (TM * LD0 > TK * LD1) ? TM * LD0 : TK * LD1;
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 // stage a 64 x 32 tile of an operand whose rows are `rows` (bound R) into registers (8 elements per thread)
 template <int MODE>   // 0: k-contiguous (s_k == 1), 1: row-contiguous (s_r == 1)
@@ -30,7 +40,7 @@ __device__ __forceinline__ bf16x8 stage_load(const bf16_t* base, long s_r, long 
         const int row = r0 + (tid >> 2), k = k0 + (tid & 3) * 8;
         if (row < R && k < K) {
             const bf16_t* p = base + (long)row * s_r + k;
-            if (k + 8 <= K && ((s_r & 7) == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) v = *reinterpret_cast<const bf16x8*>(p);
+            if (k + 8 <= K && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) v = *reinterpret_cast<const bf16x8*>(p);
             else
 #pragma unroll
                 for (int j = 0; j < 8; ++j) if (k + j < K) v[j] = p[j];
@@ -39,7 +49,7 @@ __device__ __forceinline__ bf16x8 stage_load(const bf16_t* base, long s_r, long 
         const int k = k0 + (tid >> 3), row = r0 + (tid & 7) * 8;
         if (k < K && row < R) {
             const bf16_t* p = base + (long)k * s_k + row;
-            if (row + 8 <= R && ((s_k & 7) == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) v = *reinterpret_cast<const bf16x8*>(p);
+            if (row + 8 <= R && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) v = *reinterpret_cast<const bf16x8*>(p);
             else
 #pragma unroll
                 for (int j = 0; j < 8; ++j) if (row + j < R) v[j] = p[j];
@@ -49,19 +59,34 @@ __device__ __forceinline__ bf16x8 stage_load(const bf16_t* base, long s_r, long 
 }
 template <int MODE>
 __device__ __forceinline__ void stage_store(bf16_t* s, const bf16x8& v, int tid) {
+    if (MODE == 0) *reinterpret_cast<bf16x8*>(s + (tid >> 2) * LD0 + (tid & 3) * 8) = v;
+    else *reinterpret_cast<bf16x8*>(s + (tid >> 3) * LD1 + (tid & 7) * 8) = v;
+}
+// MFMA operand fragment of the 32 rows starting at rb, 16-step ks (0 / 1) of the staged K tile
+template <int MODE>
+__device__ __forceinline__ bf16x8 frag(const bf16_t* s, int rb, int ks, int lane) {
     if (MODE == 0) {
-        *reinterpret_cast<bf16x8*>(s + (tid >> 2) * LDS_LD + (tid & 3) * 8) = v;
+        const int row = rb + (lane & 31), h = lane >> 5;
+        const s16x4 lo = *reinterpret_cast<const s16x4*>(s + row * LD0 + ks * 16 + 4 * h);
+        const s16x4 hi = *reinterpret_cast<const s16x4*>(s + row * LD0 + ks * 16 + 8 + 4 * h);
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
     } else {
-        const int k = tid >> 3, row = (tid & 7) * 8;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s[(row + j) * LDS_LD + k] = v[j];
+        const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+        const int col = rb + (g & 1) * 16 + 4 * p4;
+        const int k0 = ks * 16 + 4 * (g >> 1) + q4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s + k0 * LD1 + col));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s + (k0 + 8) * LD1 + col));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
     }
 }
 
 template <int MA, int MB>
 __global__ __launch_bounds__(256) void bgemm_kernel(BgArgs p) {
-    __shared__ __attribute__((aligned(16))) bf16_t sA[TM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) bf16_t sB[TM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * TILE_ELEMS];
+    bf16_t* sA = smem;
+    bf16_t* sB = smem + TILE_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
     const int z1 = blockIdx.z / p.Z2, z2 = blockIdx.z % p.Z2;
@@ -84,8 +109,8 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgArgs p) {
         }
 #pragma unroll
         for (int ks = 0; ks < TK / 16; ++ks) {
-            const bf16x8 fa = *reinterpret_cast<const bf16x8*>(sA + (wm * 32 + lr) * LDS_LD + ks * 16 + lh * 8);
-            const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sB + (wn * 32 + lr) * LDS_LD + ks * 16 + lh * 8);
+            const bf16x8 fa = frag<MA>(sA, wm * 32, ks, lane);
+            const bf16x8 fb = frag<MB>(sB, wn * 32, ks, lane);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
         }
         __syncthreads();

@@ -118,6 +118,127 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwBwdArgs p) {
     }
 }
 
+
+// ---- fast form for the reference's kernel size 31 (pad 15, dilation 1), mirror of dwconv31_kernel (conv.hip):
+// block = (64 channels, utterance), 128 time steps per tile; the (128+30) x 64 conv-input tile (LayerNorm applied on the way in)
+// and the conv-output-gradient tile live in LDS as fp32, every thread keeps both 62-sample windows, the 31 taps and the 31
+// tap gradients of its channel in registers and produces 32 consecutive steps.  Tap / bias gradients leave as per-utterance
+// partials (workspace (B, C, 32)), summed over B by dw_partial_reduce_kernel — no float atomics.
+constexpr int FB_K = 31, FB_TT = 128, FB_CT = 64, FB_ROWS = FB_TT + FB_K - 1, FB_PER = FB_TT / 4;
+
+template <bool CSGU>
+__global__ __launch_bounds__(256) void dwconv31_bwd_kernel(DwBwdArgs p, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tile_x = reinterpret_cast<float*>(smem);                     // [FB_ROWS][64]
+    float* tile_d = tile_x + FB_ROWS * FB_CT;                           // [FB_ROWS][64]
+    bf16_t* io = reinterpret_cast<bf16_t*>(tile_d + FB_ROWS * FB_CT);   // [128][64]: raw ds in (CSGU), result out
+    const int c0 = blockIdx.x * FB_CT, b = blockIdx.y;
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    const int c = c0 + tx;
+    float wk[FB_K], gw[FB_K];
+#pragma unroll
+    for (int k = 0; k < FB_K; ++k) { wk[k] = p.w[(long)c * FB_K + k]; gw[k] = 0.f; }
+    float gb = 0.f;
+    const float bias = (CSGU && p.bias) ? p.bias[c] : 0.f;
+    for (int t0 = 0; t0 < p.T; t0 += FB_TT) {
+        __syncthreads();
+        for (int id = tid; id < FB_ROWS * (FB_CT / 8); id += 256) {
+            const int r = id >> 3, ch = id & 7;
+            const int t = t0 - 15 + r;
+            f32x4 xl = {0.f, 0.f, 0.f, 0.f}, xh = xl, dl = xl, dh = xl;
+            if (t >= 0 && t < p.T) {
+                const long row = (long)b * p.T + t;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(p.x + row * p.ldx + c0 + ch * 8);
+                const bf16x8 g = *reinterpret_cast<const bf16x8*>(p.dy + row * p.lddy + c0 + ch * 8);
+                float f[8], e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { f[j] = bf2f(v[j]); e[j] = bf2f(g[j]); }
+                if (CSGU) {
+                    const float mu = p.stats[2 * row], rs = p.stats[2 * row + 1];
+                    const bf16x8 rr = *reinterpret_cast<const bf16x8*>(p.r + row * p.ldr + c0 + ch * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        f[j] = (f[j] - mu) * rs * p.gamma[c0 + ch * 8 + j] + p.beta[c0 + ch * 8 + j];
+                        e[j] *= bf2f(rr[j]);
+                    }
+                    if (r >= 15 && r < 15 + FB_TT) *reinterpret_cast<bf16x8*>(io + (r - 15) * FB_CT + ch * 8) = g;
+                }
+                xl = f32x4{f[0], f[1], f[2], f[3]}; xh = f32x4{f[4], f[5], f[6], f[7]};
+                dl = f32x4{e[0], e[1], e[2], e[3]}; dh = f32x4{e[4], e[5], e[6], e[7]};
+            }
+            *reinterpret_cast<f32x4*>(tile_x + r * FB_CT + ch * 8) = xl;
+            *reinterpret_cast<f32x4*>(tile_x + r * FB_CT + ch * 8 + 4) = xh;
+            *reinterpret_cast<f32x4*>(tile_d + r * FB_CT + ch * 8) = dl;
+            *reinterpret_cast<f32x4*>(tile_d + r * FB_CT + ch * 8 + 4) = dh;
+        }
+        __syncthreads();
+        float xw[FB_PER + FB_K - 1], dwn[FB_PER + FB_K - 1];
+#pragma unroll
+        for (int i = 0; i < FB_PER + FB_K - 1; ++i) {
+            xw[i] = tile_x[(ty * FB_PER + i) * FB_CT + tx];
+            dwn[i] = tile_d[(ty * FB_PER + i) * FB_CT + tx];
+        }
+        __syncthreads();                                   // windows are in registers: io / tiles may be overwritten below
+#pragma unroll
+        for (int j = 0; j < FB_PER; ++j) {
+            const int rl = ty * FB_PER + j;
+            const float dyc = dwn[j + 15];                 // rows beyond T hold zeros: no contribution
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < FB_K; ++k) acc = fmaf(wk[k], dwn[j + 30 - k], acc);
+            gb += dyc;
+#pragma unroll
+            for (int k = 0; k < FB_K; ++k) gw[k] = fmaf(dyc, xw[j + k], gw[k]);
+            if (CSGU) {
+                float cv = bias;
+#pragma unroll
+                for (int k = 0; k < FB_K; ++k) cv = fmaf(wk[k], xw[j + k], cv);
+                const float dsv = bf2f(io[rl * FB_CT + tx]);
+                io[rl * FB_CT + tx] = f2bf(dsv * cv);                                       // dr
+                reinterpret_cast<bf16_t*>(tile_x)[rl * FB_CT + tx] = f2bf(acc);            // dgn (tile_x reused as a bf16 [128][64] buffer)
+            } else {
+                io[rl * FB_CT + tx] = f2bf(acc + dyc);                                      // dm = dy + conv^T(dy)
+            }
+        }
+        __syncthreads();
+        for (int id = tid; id < FB_TT * (FB_CT / 8); id += 256) {
+            const int r = id >> 3, ch = id & 7;
+            const int t = t0 + r;
+            if (t >= p.T) continue;
+            const long row = (long)b * p.T + t;
+            if (CSGU) {
+                *reinterpret_cast<bf16x8*>(p.dr + row * p.lddr + c0 + ch * 8) = *reinterpret_cast<const bf16x8*>(io + r * FB_CT + ch * 8);
+                *reinterpret_cast<bf16x8*>(p.dx + row * p.lddx + c0 + ch * 8) = *reinterpret_cast<const bf16x8*>(reinterpret_cast<bf16_t*>(tile_x) + r * FB_CT + ch * 8);
+            } else {
+                *reinterpret_cast<bf16x8*>(p.dx + row * p.lddx + c0 + ch * 8) = *reinterpret_cast<const bf16x8*>(io + r * FB_CT + ch * 8);
+            }
+        }
+    }
+    // reduce the 4 time groups' tap gradients through LDS, store this utterance's partial
+    __syncthreads();
+    float* red = tile_x;                                   // [4][32][64]
+#pragma unroll
+    for (int k = 0; k < FB_K; ++k) red[(ty * 32 + k) * FB_CT + tx] = gw[k];
+    red[(ty * 32 + 31) * FB_CT + tx] = gb;
+    __syncthreads();
+    for (int i = tid; i < 32 * FB_CT; i += 256) {
+        const int k = i / FB_CT, cc = i % FB_CT;
+        const float sum = red[k * FB_CT + cc] + red[(32 + k) * FB_CT + cc] + red[(64 + k) * FB_CT + cc] + red[(96 + k) * FB_CT + cc];
+        partial[((long)b * p.C + c0 + cc) * 32 + k] = sum;
+    }
+}
+
+// dw[c][k] += sum_b partial[b][c][k] (k < 31),  db[c] += sum_b partial[b][c][31]
+__global__ __launch_bounds__(256) void dw_partial_reduce_kernel(const float* __restrict__ partial, int B, int C, float* __restrict__ dw, float* __restrict__ db) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= C * 32) return;
+    const int c = i >> 5, k = i & 31;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += partial[((long)b * C + c) * 32 + k];
+    if (k < 31) dw[(long)c * 31 + k] += s;
+    else if (db) db[c] += s;
+}
+
 // ------------------------------------------------------------------------------------------------ im2col (channels-last)
 // in (B,Tin,Fin,Cin) bf16 -> col (B*Tout*Fout, KH*KW*Cin) bf16, k = (kh*KW + kw)*Cin + c  (the A operand of conv2 made explicit)
 __global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ col, int B, int Tin, int Fin,
@@ -227,8 +348,21 @@ __global__ __launch_bounds__(256) void conv1_bwd3_kernel(const float* __restrict
 
 int grid_for(long n, int cap) { const long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > cap ? cap : g)); }
 
-int dw_bwd_launch(const DwBwdArgs& a, bool csgu, hipStream_t st) {
+int dw_bwd_launch(const DwBwdArgs& a, bool csgu, float* workspace, hipStream_t st) {
     if (a.B <= 0 || a.T <= 0 || a.C <= 0 || a.K <= 0 || a.K > DB_KMAX || a.pad_left < 0 || a.pad_left > a.K - 1) return MI_ERR_ARG;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool fast = workspace && a.K == FB_K && a.pad_left == 15 && (a.C % FB_CT) == 0 && (a.ldx % 8) == 0 && (a.lddy % 8) == 0 && (a.lddx % 8) == 0 &&
+                      al16(a.x) && al16(a.dy) && al16(a.dx) && (!csgu || ((a.ldr % 8) == 0 && (a.lddr % 8) == 0 && al16(a.r) && al16(a.dr)));
+    if (fast) {
+        const size_t ldsf = (size_t)2 * FB_ROWS * FB_CT * sizeof(float) + (size_t)FB_TT * FB_CT * sizeof(bf16_t);
+        dim3 gridf(a.C / FB_CT, a.B);
+        if (csgu) hipLaunchKernelGGL(dwconv31_bwd_kernel<true>, gridf, dim3(256), ldsf, st, a, workspace);
+        else hipLaunchKernelGGL(dwconv31_bwd_kernel<false>, gridf, dim3(256), ldsf, st, a, workspace);
+        MI_CHECK_LAUNCH();
+        hipLaunchKernelGGL(dw_partial_reduce_kernel, dim3(cdiv((long)a.C * 32, 256)), dim3(256), 0, st, workspace, a.B, a.C, a.dw, a.db);
+        MI_CHECK_LAUNCH();
+        return MI_OK;
+    }
     const int rows = DB_TT + a.K - 1;
     const size_t lds = (size_t)(2 * rows * DB_CT + DB_KMAX * DB_CT + 4 * (DB_KMAX + 1) * DB_CT) * sizeof(float);
     dim3 grid(cdiv(a.C, DB_CT), a.B);
@@ -240,27 +374,28 @@ int dw_bwd_launch(const DwBwdArgs& a, bool csgu, hipStream_t st) {
 
 }  // namespace
 
+// `workspace`: B*C*32 floats (per-utterance tap-gradient partials of the K = 31 fast path) or NULL (generic kernel, atomics).
 // CSGU backward (identity activation, dilation 1): u (B*T, 2C) = [x_r | x_g], ds = gradient of x_r * (dwconv(LN(x_g)) + b)
 //   -> dr (B*T, C) = ds * conv,  dgn (B*T, C) = gradient w.r.t. LN(x_g),  dw (C,K) +=, db (C) +=
 extern "C" int mi_csgu_bwd_bf16(const void* u, long ldu, const float* stats, const float* gamma, const float* beta, const float* w,
                                 const float* bias, const void* ds, long ldds, void* dr, long lddr, void* dgn, long lddgn,
-                                float* dw, float* db, int B, int T, int C, int K, int pad_left, hipStream_t st) {
+                                float* dw, float* db, int B, int T, int C, int K, int pad_left, float* workspace, hipStream_t st) {
     MI_ENTER();
     DwBwdArgs a{};
     a.x = (const bf16_t*)u + C; a.ldx = ldu; a.r = (const bf16_t*)u; a.ldr = ldu; a.stats = stats; a.gamma = gamma; a.beta = beta;
     a.dy = (const bf16_t*)ds; a.lddy = ldds; a.w = w; a.bias = bias; a.dx = (bf16_t*)dgn; a.lddx = lddgn; a.dr = (bf16_t*)dr; a.lddr = lddr;
     a.dw = dw; a.db = db; a.B = B; a.T = T; a.C = C; a.K = K; a.pad_left = pad_left;
-    return dw_bwd_launch(a, true, st);
+    return dw_bwd_launch(a, true, workspace, st);
 }
 
 // merge-block backward: y = m + dwconv(m) + b  ->  dm = dy + conv^T(dy),  dw +=, db +=
 extern "C" int mi_dwconv_residual_bwd_bf16(const void* m, long ldm, const float* w, const void* dy, long lddy, void* dm, long lddm,
-                                           float* dw, float* db, int B, int T, int C, int K, int pad_left, hipStream_t st) {
+                                           float* dw, float* db, int B, int T, int C, int K, int pad_left, float* workspace, hipStream_t st) {
     MI_ENTER();
     DwBwdArgs a{};
     a.x = (const bf16_t*)m; a.ldx = ldm; a.dy = (const bf16_t*)dy; a.lddy = lddy; a.w = w; a.dx = (bf16_t*)dm; a.lddx = lddm;
     a.dw = dw; a.db = db; a.B = B; a.T = T; a.C = C; a.K = K; a.pad_left = pad_left;
-    return dw_bwd_launch(a, false, st);
+    return dw_bwd_launch(a, false, workspace, st);
 }
 
 extern "C" int mi_im2col_cl_bf16(const void* in, void* col, int B, int Tin, int Fin, int Cin, int KH, int KW, int stride, int pad_t,

@@ -89,8 +89,9 @@ __global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ a, 
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm backward
-// one wave per row, columns c = lane + 64 j;  dx (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
-template <int NJ>
+// one wave per row, 4 consecutive columns per lane and step (16-B / 8-B accesses): c = 4 (lane + 64 j);
+//   dx (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;   dgamma += dy * xhat, dbeta += dy (block-reduced, then atomics)
+template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x, long ldx, int x_bf16, const float* __restrict__ gamma,
                                                       float eps, const void* __restrict__ dy, long lddy, int dy_f32,
                                                       void* __restrict__ dx, long lddx, int dx_bf16, int accumulate,
@@ -100,62 +101,69 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
     float* sg = reinterpret_cast<float*>(smem);          // [d] dgamma partial, [d] dbeta partial
     float* sb = sg + d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 2 * d; i += 256) sg[i] = 0.f;
-    __syncthreads();
-    float gm[NJ], ag[NJ], ab[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int c = lane + 64 * j;
-        gm[j] = (c < d) ? gamma[c] : 0.f;
-        ag[j] = 0.f; ab[j] = 0.f;
+    const int d4 = d >> 2;
+    if (dgamma) {
+        for (int i = threadIdx.x; i < 2 * d; i += 256) sg[i] = 0.f;
+        __syncthreads();
     }
-    const long r0 = ((long)blockIdx.x * 4 + wave) * rows_per_wave;
+    f32x4 gm[NV], ag[NV], ab[NV];
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = lane + 64 * j;
+        gm[j] = (c < d4) ? reinterpret_cast<const f32x4*>(gamma)[c] : z4;
+        ag[j] = z4; ab[j] = z4;
+    }
     const float inv_d = 1.f / d;
+    const long wave_id = (long)blockIdx.x * 4 + wave, nwaves = (long)gridDim.x * 4;
     for (int i = 0; i < rows_per_wave; ++i) {
-        const long r = r0 + i;
+        const long r = wave_id + (long)i * nwaves;          // interleaved rows: neighbouring waves touch neighbouring rows
         if (r >= M) break;
-        float xv[NJ], gv[NJ];
+        f32x4 xv[NV], gv[NV];
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
+        for (int j = 0; j < NV; ++j) {
             const int c = lane + 64 * j;
-            float v = 0.f, g = 0.f;
-            if (c < d) {
-                v = x_bf16 ? bf2f(reinterpret_cast<const bf16_t*>(x)[r * ldx + c]) : reinterpret_cast<const float*>(x)[r * ldx + c];
-                g = dy_f32 ? reinterpret_cast<const float*>(dy)[r * lddy + c] : bf2f(reinterpret_cast<const bf16_t*>(dy)[r * lddy + c]);
+            f32x4 v = z4, g = z4;
+            if (c < d4) {
+                if (x_bf16) { const bf16x4 t = reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(x) + r * ldx)[c]; v = f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])}; }
+                else v = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + r * ldx)[c];
+                if (dy_f32) g = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dy) + r * lddy)[c];
+                else { const bf16x4 t = reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(dy) + r * lddy)[c]; g = f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])}; }
             }
-            xv[j] = v; gv[j] = g; s += v;
+            xv[j] = v; gv[j] = g; s += v.x + v.y + v.z + v.w;
         }
         const float mean = wave_sum(s) * inv_d;
         float q = 0.f;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
+        for (int j = 0; j < NV; ++j) {
             const int c = lane + 64 * j;
-            const float a = (c < d) ? xv[j] - mean : 0.f;
-            xv[j] = a; q += a * a;
+            const f32x4 a = (c < d4) ? xv[j] - mean : z4;
+            xv[j] = a; q += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
         }
         const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
+        for (int j = 0; j < NV; ++j) {
             xv[j] *= rstd;                        // xhat
             ag[j] += gv[j] * xv[j];
             ab[j] += gv[j];
             gv[j] *= gm[j];                       // g = dy * gamma
-            s1 += gv[j]; s2 += gv[j] * xv[j];
+            const f32x4 t = gv[j] * xv[j];
+            s1 += gv[j].x + gv[j].y + gv[j].z + gv[j].w; s2 += t.x + t.y + t.z + t.w;
         }
         s1 = wave_sum(s1) * inv_d; s2 = wave_sum(s2) * inv_d;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
+        for (int j = 0; j < NV; ++j) {
             const int c = lane + 64 * j;
-            if (c >= d) continue;
-            float v = rstd * (gv[j] - s1 - xv[j] * s2);
+            if (c >= d4) continue;
+            f32x4 v = (gv[j] - s1 - xv[j] * s2) * rstd;
             if (dx_bf16) {
-                bf16_t* p = reinterpret_cast<bf16_t*>(dx) + r * lddx + c;
-                if (accumulate) v += bf2f(*p);
-                *p = f2bf(v);
+                bf16x4* p = reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(dx) + r * lddx) + c;
+                if (accumulate) { const bf16x4 t = *p; v += f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])}; }
+                *p = bf16x4{f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
             } else {
-                float* p = reinterpret_cast<float*>(dx) + r * lddx + c;
+                f32x4* p = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(dx) + r * lddx) + c;
                 if (accumulate) v += *p;
                 *p = v;
             }
@@ -163,9 +171,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
     }
     if (dgamma) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
+        for (int j = 0; j < NV; ++j) {
             const int c = lane + 64 * j;
-            if (c < d) { atomicAdd(sg + c, ag[j]); atomicAdd(sb + c, ab[j]); }
+            if (c < d4) {
+                atomicAdd(sg + 4 * c, ag[j].x); atomicAdd(sg + 4 * c + 1, ag[j].y); atomicAdd(sg + 4 * c + 2, ag[j].z); atomicAdd(sg + 4 * c + 3, ag[j].w);
+                atomicAdd(sb + 4 * c, ab[j].x); atomicAdd(sb + 4 * c + 1, ab[j].y); atomicAdd(sb + 4 * c + 2, ab[j].z); atomicAdd(sb + 4 * c + 3, ab[j].w);
+            }
         }
         __syncthreads();
         for (int c = threadIdx.x; c < d; c += 256) { atomic_add_f32(dgamma + c, sg[c]); atomic_add_f32(dbeta + c, sb[c]); }
@@ -316,14 +327,16 @@ extern "C" int mi_act_bwd_bf16(const void* dy, long lddy, const void* pre, long 
 extern "C" int mi_layernorm_bwd(const void* x, long ldx, int x_bf16, const float* gamma, float eps, const void* dy, long lddy, int dy_f32,
                                 void* dx, long lddx, int dx_bf16, int accumulate, float* dgamma, float* dbeta, int M, int d, hipStream_t st) {
     MI_ENTER();
-    if (M <= 0 || d <= 0 || d > 2048 || !gamma) return MI_ERR_ARG;
-    const int rpw = 16;
-    const int grid = cdiv(M, 4 * rpw);
+    if (M <= 0 || d <= 0 || d > 2048 || (d % 4) || (ldx % 4) || (lddy % 4) || (lddx % 4) || !gamma) return MI_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) & (x_bf16 ? 7 : 15)) || (reinterpret_cast<uintptr_t>(dy) & (dy_f32 ? 15 : 7)) ||
+        (reinterpret_cast<uintptr_t>(dx) & (dx_bf16 ? 7 : 15))) return MI_ERR_ARG;
+    int grid = cdiv(M, 4);
+    if (grid > 1024) grid = 1024;                       // 4 blocks per CU; each wave walks rows wave_id, wave_id + nwaves, ...
+    const int rpw = cdiv(M, (long)grid * 4);
     const size_t lds = (size_t)2 * d * sizeof(float);
-    const int nj = cdiv(d, 64);
-#define LN_BWD(NJ) hipLaunchKernelGGL(ln_bwd_kernel<NJ>, dim3(grid), dim3(256), lds, st, x, ldx, x_bf16, gamma, eps, dy, lddy, dy_f32, dx, lddx, dx_bf16, accumulate, dgamma, dbeta, M, d, rpw)
-    if (nj <= 1) LN_BWD(1); else if (nj <= 2) LN_BWD(2); else if (nj <= 4) LN_BWD(4); else if (nj <= 8) LN_BWD(8);
-    else if (nj <= 16) LN_BWD(16); else LN_BWD(32);
+    const int nv = cdiv(d, 256);
+#define LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(grid), dim3(256), lds, st, x, ldx, x_bf16, gamma, eps, dy, lddy, dy_f32, dx, lddx, dx_bf16, accumulate, dgamma, dbeta, M, d, rpw)
+    if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4); else LN_BWD(8);
 #undef LN_BWD
     MI_CHECK_LAUNCH();
     return MI_OK;

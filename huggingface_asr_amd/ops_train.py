@@ -111,19 +111,38 @@ def bgemm(A, a_str, B, b_str, C, c_str, Z1, Z2, M, N, K, *, alpha=1.0, accumulat
     return C
 
 
+def pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
 def attn_softmax_fwd(ac, bd, lengths, H, B, Tq, Tk, scale, causal=False):
-    prob = torch.empty((H, B, Tq, Tk), device=ac.device, dtype=BF16)
-    _lib.check(_L().mi_attn_softmax_fwd(ac.data_ptr(), _p(bd), _p(lengths), prob.data_ptr(), H, B, Tq, Tk, float(scale), int(causal), _stream()),
+    """ac (H,B,Tq,lds) f32, bd (H,B,Tq,ldp) f32 | None (row strides = last-dim sizes) -> prob (H,B,Tq,lds) bf16."""
+    lds = ac.shape[-1]
+    ldp = bd.shape[-1] if bd is not None else 0
+    prob = torch.empty((H, B, Tq, lds), device=ac.device, dtype=BF16)
+    _lib.check(_L().mi_attn_softmax_fwd(ac.data_ptr(), _p(bd), _p(lengths), prob.data_ptr(), H, B, Tq, Tk, lds, ldp, float(scale), int(causal), _stream()),
                "mi_attn_softmax_fwd")
     return prob
 
 
 def attn_softmax_bwd(prob, dp, H, B, Tq, Tk, scale, want_dbd=False):
-    ds = torch.empty((H, B, Tq, Tk), device=prob.device, dtype=BF16)
-    dbd = torch.empty((H, B, Tq, 2 * Tq - 1), device=prob.device, dtype=BF16) if want_dbd else None
-    _lib.check(_L().mi_attn_softmax_bwd(prob.data_ptr(), dp.data_ptr(), ds.data_ptr(), _p(dbd), H, B, Tq, Tk, float(scale), _stream()),
+    lds = prob.shape[-1]
+    ldp = pad8(2 * Tq - 1)
+    ds = torch.empty((H, B, Tq, lds), device=prob.device, dtype=BF16)
+    dbd = torch.empty((H, B, Tq, ldp), device=prob.device, dtype=BF16) if want_dbd else None
+    _lib.check(_L().mi_attn_softmax_bwd(prob.data_ptr(), dp.data_ptr(), ds.data_ptr(), _p(dbd), H, B, Tq, Tk, lds, ldp, float(scale), _stream()),
                "mi_attn_softmax_bwd")
     return ds, dbd
+
+
+_DW_WS = {}
+
+
+def _dw_ws(device, nfloats):
+    ws = _DW_WS.get(device)
+    if ws is None or ws.numel() < nfloats:
+        ws = _DW_WS[device] = torch.empty(nfloats, device=device, dtype=F32)
+    return ws.data_ptr()
 
 
 def csgu_bwd(u, stats, gamma, beta, w, bias, ds, dr, dgn, dw, db, B, T):
@@ -132,14 +151,14 @@ def csgu_bwd(u, stats, gamma, beta, w, bias, ds, dr, dgn, dw, db, B, T):
     K = w.shape[-1]
     _lib.check(_L().mi_csgu_bwd_bf16(u.data_ptr(), u.stride(0), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), _p(bias),
                                      ds.data_ptr(), ds.stride(0), dr.data_ptr(), dr.stride(0), dgn.data_ptr(), dgn.stride(0),
-                                     dw.data_ptr(), _p(db), B, T, Cc, K, (K - 1) // 2, _stream()), "mi_csgu_bwd_bf16")
+                                     dw.data_ptr(), _p(db), B, T, Cc, K, (K - 1) // 2, _dw_ws(u.device, B * Cc * 32), _stream()), "mi_csgu_bwd_bf16")
 
 
 def dwconv_residual_bwd(m, w, dy, dm, dw, db, B, T):
     M, Cc = m.shape
     K = w.shape[-1]
     _lib.check(_L().mi_dwconv_residual_bwd_bf16(m.data_ptr(), m.stride(0), w.data_ptr(), dy.data_ptr(), dy.stride(0), dm.data_ptr(), dm.stride(0),
-                                                dw.data_ptr(), _p(db), B, T, Cc, K, (K - 1) // 2, _stream()), "mi_dwconv_residual_bwd_bf16")
+                                                dw.data_ptr(), _p(db), B, T, Cc, K, (K - 1) // 2, _dw_ws(m.device, B * Cc * 32), _stream()), "mi_dwconv_residual_bwd_bf16")
 
 
 def im2col(x, K, stride, pad, T1, F1):

@@ -543,14 +543,14 @@ class EncoderCTCTrainer:
         prob = self._probs(qkv, posp, u, v, lengths, B, Tt, H, S)
         ctx = torch.empty((B * Tt, d), device=qkv.device, dtype=BF16)
         vv = qkv[:, 2 * d:]
-        T.bgemm(prob, (B * Tt * Tt, Tt * Tt, Tt, 1), vv, (hd, Tt * 3 * d, 1, 3 * d), ctx, (hd, Tt * d, d), H, B, Tt, hd, Tt)
+        Ts = prob.shape[-1]
+        T.bgemm(prob, (B * Tt * Ts, Tt * Ts, Ts, 1), vv, (hd, Tt * 3 * d, 1, 3 * d), ctx, (hd, Tt * d, d), H, B, Tt, hd, Tt)
         S["prob"] = prob
         return ctx
 
     def _probs(self, qkv, posp, u, v, lengths, B, Tt, H, S):
         d = qkv.shape[1] // 3
         hd = d // H
-        M = B * Tt
         dev = qkv.device
         q, k = qkv[:, :d], qkv[:, d:2 * d]
         if posp is not None:
@@ -559,13 +559,15 @@ class EncoderCTCTrainer:
         else:
             qu = qv = None
             a_q, a_str = q, (hd, Tt * 3 * d, 3 * d, 1)
-        ac = torch.empty((H, B, Tt, Tt), device=dev, dtype=F32)
-        T.bgemm(a_q, a_str, k, (hd, Tt * 3 * d, 3 * d, 1), ac, (B * Tt * Tt, Tt * Tt, Tt), H, B, Tt, Tt, hd)
+        Ts = T.pad8(Tt)                                    # padded row strides: 16-B aligned rows for the 16-B staging loads
+        ac = torch.empty((H, B, Tt, Ts), device=dev, dtype=F32)
+        T.bgemm(a_q, a_str, k, (hd, Tt * 3 * d, 3 * d, 1), ac, (B * Tt * Ts, Tt * Ts, Ts), H, B, Tt, Tt, hd)
         bd = None
         if posp is not None:
             Pn = 2 * Tt - 1
-            bd = torch.empty((H, B, Tt, Pn), device=dev, dtype=F32)
-            T.bgemm(qv, (hd, Tt * d, d, 1), posp, (hd, 0, d, 1), bd, (B * Tt * Pn, Tt * Pn, Pn), H, B, Tt, Pn, hd)
+            Ps = T.pad8(Pn)
+            bd = torch.empty((H, B, Tt, Ps), device=dev, dtype=F32)
+            T.bgemm(qv, (hd, Tt * d, d, 1), posp, (hd, 0, d, 1), bd, (B * Tt * Ps, Tt * Ps, Ps), H, B, Tt, Pn, hd)
         S["qu"], S["qv"] = qu, qv
         return T.attn_softmax_fwd(ac, bd, lengths, H, B, Tt, Tt, 1.0 / math.sqrt(hd))
 
@@ -584,29 +586,31 @@ class EncoderCTCTrainer:
             prob = self._probs(qkv, posp, P(p + "att_u") if rel else None, P(p + "att_v") if rel else None, lengths, B, Tt, H, S)
         qu, qv = S["qu"], S["qv"]
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-        sTT = (B * Tt * Tt, Tt * Tt)
+        Ts = prob.shape[-1]
+        sTT = (B * Tt * Ts, Tt * Ts)
         dqkv = torch.empty((M, 3 * d), device=dev, dtype=BF16)
         # dP = dctx · V^T
-        dp = torch.empty((H, B, Tt, Tt), device=dev, dtype=F32)
-        T.bgemm(dctx, (hd, Tt * d, d, 1), v, (hd, Tt * 3 * d, 3 * d, 1), dp, (*sTT, Tt), H, B, Tt, Tt, hd)
+        dp = torch.empty((H, B, Tt, Ts), device=dev, dtype=F32)
+        T.bgemm(dctx, (hd, Tt * d, d, 1), v, (hd, Tt * 3 * d, 3 * d, 1), dp, (*sTT, Ts), H, B, Tt, Tt, hd)
         ds, dbd = T.attn_softmax_bwd(prob, dp, H, B, Tt, Tt, scale, want_dbd=rel)
         # dV = P^T · dctx
-        T.bgemm(prob, (*sTT, 1, Tt), dctx, (hd, Tt * d, 1, d), dqkv[:, 2 * d:], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt)
+        T.bgemm(prob, (*sTT, 1, Ts), dctx, (hd, Tt * d, 1, d), dqkv[:, 2 * d:], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt)
         # dK = dS^T · (q + u)
         aq, aq_str = (qu, (hd, Tt * d, 1, d)) if rel else (q, (hd, Tt * 3 * d, 1, 3 * d))
-        T.bgemm(ds, (*sTT, 1, Tt), aq, aq_str, dqkv[:, d:2 * d], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt)
+        T.bgemm(ds, (*sTT, 1, Ts), aq, aq_str, dqkv[:, d:2 * d], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt)
         if not rel:
             # dQ = dS · K
-            T.bgemm(ds, (*sTT, Tt, 1), k, (hd, Tt * 3 * d, 1, 3 * d), dqkv[:, :d], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt)
+            T.bgemm(ds, (*sTT, Ts, 1), k, (hd, Tt * 3 * d, 1, 3 * d), dqkv[:, :d], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt)
             return dqkv
         Pn = 2 * Tt - 1
+        Ps = dbd.shape[-1]
         dqu = torch.empty((M, d), device=dev, dtype=F32)
         dqv = torch.empty((M, d), device=dev, dtype=F32)
-        T.bgemm(ds, (*sTT, Tt, 1), k, (hd, Tt * 3 * d, 1, 3 * d), dqu, (hd, Tt * d, d), H, B, Tt, hd, Tt)
-        T.bgemm(dbd, (B * Tt * Pn, Tt * Pn, Pn, 1), posp, (hd, 0, 1, d), dqv, (hd, Tt * d, d), H, B, Tt, hd, Pn)
+        T.bgemm(ds, (*sTT, Ts, 1), k, (hd, Tt * 3 * d, 1, 3 * d), dqu, (hd, Tt * d, d), H, B, Tt, hd, Tt)
+        T.bgemm(dbd, (B * Tt * Ps, Tt * Ps, Ps, 1), posp, (hd, 0, 1, d), dqv, (hd, Tt * d, d), H, B, Tt, hd, Pn)
         # d(posp) (P, d) = sum_b dBD^T · (q + v): K runs over the (b, t) rows of one head
         dposp = torch.empty((Pn, d), device=dev, dtype=F32)
-        T.bgemm(dbd, (B * Tt * Pn, 0, 1, Pn), qv, (hd, 0, 1, d), dposp, (hd, 0, d), H, 1, Pn, hd, B * Tt)
+        T.bgemm(dbd, (B * Tt * Ps, 0, 1, Ps), qv, (hd, 0, 1, d), dposp, (hd, 0, d), H, 1, Pn, hd, B * Tt)
         T.add_cast(dqu, dqv, out=dqkv[:, :d])
         T.colsum_(G(p + "att_u"), dqu)
         T.colsum_(G(p + "att_v"), dqv)

@@ -173,16 +173,16 @@ int mi_bgemm_bf16(const void* A, long a_z1, long a_z2, long a_m, long a_k, const
                   void* C, long c_z1, long c_z2, long c_m, int out_f32, int accumulate, float alpha, int Z1, int Z2, int M, int N,
                   int K, mi_stream_t stream);
 /* softmax stage of attention (e_branchformer.py:100-135, tf wav2vec2_conformer:528-565 relative shift), head-major (H,B,Tq,Tk) */
-int mi_attn_softmax_fwd(const float* ac, const float* bd, const int* lengths, void* prob, int H, int B, int Tq, int Tk, float scale,
-                        int causal, mi_stream_t stream);
-int mi_attn_softmax_bwd(const void* prob, const float* dp, void* ds, void* dbd, int H, int B, int Tq, int Tk, float scale,
-                        mi_stream_t stream);
+int mi_attn_softmax_fwd(const float* ac, const float* bd, const int* lengths, void* prob, int H, int B, int Tq, int Tk, long ld_s,
+                        long ld_p, float scale, int causal, mi_stream_t stream);
+int mi_attn_softmax_bwd(const void* prob, const float* dp, void* ds, void* dbd, int H, int B, int Tq, int Tk, long ld_s, long ld_p,
+                        float scale, mi_stream_t stream);
 /* depthwise-conv / conv front-end gradients (e_branchformer.py:184-204,296-304; extractors.py:71-113) */
 int mi_csgu_bwd_bf16(const void* u, long ldu, const float* stats, const float* gamma, const float* beta, const float* w,
                      const float* bias, const void* ds, long ldds, void* dr, long lddr, void* dgn, long lddgn, float* dw,
-                     float* db, int B, int T, int C, int K, int pad_left, mi_stream_t stream);
+                     float* db, int B, int T, int C, int K, int pad_left, float* workspace /* B*C*32 floats or NULL */, mi_stream_t stream);
 int mi_dwconv_residual_bwd_bf16(const void* m, long ldm, const float* w, const void* dy, long lddy, void* dm, long lddm,
-                                float* dw, float* db, int B, int T, int C, int K, int pad_left, mi_stream_t stream);
+                                float* dw, float* db, int B, int T, int C, int K, int pad_left, float* workspace, mi_stream_t stream);
 int mi_im2col_cl_bf16(const void* in, void* col, int B, int Tin, int Fin, int Cin, int KH, int KW, int stride, int pad_t,
                       int pad_f, int Tout, int Fout, mi_stream_t stream);
 int mi_conv2d_first_bwd(const float* x, const float* w, const float* bias, const void* dcol, float* dw, float* db, int B, int T,

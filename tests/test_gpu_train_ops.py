@@ -170,12 +170,22 @@ def test_attn_softmax_fwd_bwd(rel, causal, masked):
         s = s.masked_fill(torch.ones(Tq, Tk, dtype=torch.bool).triu(1)[None, None], fmin)
     prob = torch.softmax(s, -1)
     dp = rnd(H, B, Tq, Tk, seed=3)
-    got = T.attn_softmax_fwd(ac.detach().to(DEV), bd.detach().to(DEV) if rel else None, lens.to(DEV) if masked else None, H, B, Tq, Tk, scale, causal)
+    Ts, Ps = T.pad8(Tk), T.pad8(P)                      # padded row strides, as the trainer allocates them
+    acp = torch.zeros(H, B, Tq, Ts); acp[..., :Tk] = ac.detach()
+    bdp = None
+    if rel:
+        bdp = torch.zeros(H, B, Tq, Ps); bdp[..., :P] = bd.detach()
+    got = T.attn_softmax_fwd(acp.to(DEV), bdp.to(DEV) if rel else None, lens.to(DEV) if masked else None, H, B, Tq, Tk, scale, causal)[..., :Tk]
     close(got, prob.detach(), floor=4e-3, what="prob")
     # backward through the bf16-rounded probabilities the kernel consumes
     pb = bfr(prob.detach())
     ds_want = pb * (dp - (pb * dp).sum(-1, keepdim=True)) * scale
-    ds, dbd = T.attn_softmax_bwd(dev16(pb), dp.to(DEV), H, B, Tq, Tk, scale, want_dbd=rel)
+    pbp = torch.zeros(H, B, Tq, Ts); pbp[..., :Tk] = pb
+    dpp = torch.zeros(H, B, Tq, Ts); dpp[..., :Tk] = dp
+    ds, dbd = T.attn_softmax_bwd(dev16(pbp), dpp.to(DEV), H, B, Tq, Tk, scale, want_dbd=rel)
+    ds = ds[..., :Tk]
+    if rel:
+        dbd = dbd[..., :P]
     close(ds, ds_want, floor=4e-3, what="ds")
     prob.backward(dp)
     close(ds, ac.grad, floor=2e-2, what="ds vs autograd")
