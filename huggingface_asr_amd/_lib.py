@@ -53,7 +53,8 @@ SIGNATURES = {
     "mi_colsum": [vp, i64, i32, i32, i32, vp, vp],
     "mi_act_fwd_bf16": [vp, i64, vp, i64, i32, i32, i32, vp],
     "mi_act_bwd_bf16": [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp],
-    "mi_layernorm_bwd": [vp, i64, i32, vp, f32, vp, i64, i32, vp, i64, i32, i32, vp, vp, i32, i32, vp],
+    "mi_layernorm_bwd_workspace_floats": [i32],
+    "mi_layernorm_bwd": [vp, i64, i32, vp, f32, vp, i64, i32, vp, i64, i32, i32, vp, vp, vp, i32, i32, vp],
     "mi_ln_apply_bf16": [vp, i64, vp, vp, vp, vp, i64, i32, i32, vp],
     "mi_axpy_f32": [vp, vp, i64, f32, vp],
     "mi_scale_f32": [vp, i64, f32, vp],
@@ -104,7 +105,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(h, name)          # AttributeError here = header/library mismatch: fail loudly
             fn.argtypes = args
-            fn.restype = sz if name in ("mi_ebf_workspace_bytes", "mi_ctc_bwd_workspace_bytes", "mi_gemm_tn_workspace_bytes") else i32
+            fn.restype = sz if name in ("mi_ebf_workspace_bytes", "mi_ctc_bwd_workspace_bytes", "mi_gemm_tn_workspace_bytes", "mi_layernorm_bwd_workspace_floats") else i32
         h.mi_profile_create.argtypes = [i32]; h.mi_profile_create.restype = i32
         h.mi_profile_enable.argtypes = [i32]; h.mi_profile_enable.restype = None
         h.mi_profile_reset.argtypes = []; h.mi_profile_reset.restype = None

@@ -16,13 +16,37 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
 }
 
 // ------------------------------------------------------------------------------------------------ transpose
-// in (M,N) bf16 -> out (N, Mp) bf16 with columns M..Mp-1 zero (Mp = K extent of the weight-gradient GEMM, % 64 == 0)
+// in (M,N) bf16 -> out (N, Mp) bf16 with columns M..Mp-1 zero (Mp = K extent of the GEMM that reads it, % 64 == 0).
+// 64 x 64 tiles through LDS, 16-B global accesses on both sides when rows are 16-B aligned (scalar edge path otherwise).
 constexpr int TR = 64;
 __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, long ld_in, bf16_t* __restrict__ out,
-                                                         long ld_out, int M, int N, int Mp) {
-    __shared__ bf16_t tile[TR][TR + 2];
+                                                         long ld_out, int M, int N, int Mp, int vec) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[TR][TR + 8];
     const int m0 = blockIdx.y * TR, n0 = blockIdx.x * TR;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int tid = threadIdx.x;
+    if (vec) {
+        for (int id = tid; id < TR * 8; id += 256) {
+            const int r = id >> 3, ch = id & 7;
+            const int m = m0 + r, n = n0 + ch * 8;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (m < M && n + 8 <= N) v = *reinterpret_cast<const bf16x8*>(in + (long)m * ld_in + n);
+            else if (m < M)
+                for (int j = 0; j < 8; ++j) if (n + j < N) v[j] = in[(long)m * ld_in + n + j];
+            *reinterpret_cast<bf16x8*>(&tile[r][ch * 8]) = v;
+        }
+        __syncthreads();
+        for (int id = tid; id < TR * 8; id += 256) {
+            const int r = id >> 3, ch = id & 7;              // output row n0 + r, columns m0 + ch*8 ..
+            const int n = n0 + r, m = m0 + ch * 8;
+            if (n >= N || m >= Mp) continue;
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tile[ch * 8 + j][r];
+            *reinterpret_cast<bf16x8*>(out + (long)n * ld_out + m) = v;      // Mp % 8 == 0 and ld_out % 8 == 0 on this path
+        }
+        return;
+    }
+    const int tx = tid & 63, ty = tid >> 6;
     for (int r = ty; r < TR; r += 4) {
         const int m = m0 + r, n = n0 + tx;
         tile[r][tx] = (m < M && n < N) ? in[(long)m * ld_in + n] : (bf16_t)0.f;
@@ -95,9 +119,10 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x, long ldx, int x_bf16, const float* __restrict__ gamma,
                                                       float eps, const void* __restrict__ dy, long lddy, int dy_f32,
                                                       void* __restrict__ dx, long lddx, int dx_bf16, int accumulate,
-                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int d,
+                                                      float* __restrict__ partial, int M, int d,
                                                       int rows_per_wave) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const dgamma = partial;                       // non-null: this block's (2d) partial row goes to partial[blockIdx.x]
     float* sg = reinterpret_cast<float*>(smem);          // [d] dgamma partial, [d] dbeta partial
     float* sb = sg + d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -179,7 +204,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
             }
         }
         __syncthreads();
-        for (int c = threadIdx.x; c < d; c += 256) { atomic_add_f32(dgamma + c, sg[c]); atomic_add_f32(dbeta + c, sb[c]); }
+        float* prow = partial + (long)blockIdx.x * 2 * d;
+        for (int c = threadIdx.x; c < 2 * d; c += 256) prow[c] = sg[c];
+    }
+}
+
+// dgamma[c] += sum_blk partial[blk][c],  dbeta[c] += sum_blk partial[blk][d + c]
+__global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __restrict__ partial, int nblk, int d, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float s = 0.f;
+    if (c < 2 * d)
+        for (int b = ty; b < nblk; b += 4) s += partial[(long)b * 2 * d + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < 2 * d) {
+        const float t = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+        if (c < d) dgamma[c] += t; else dbeta[c - d] += t;
     }
 }
 
@@ -290,7 +333,9 @@ int grid_for(long n) { const long g = (n + 255) / 256; return (int)(g < 1 ? 1 : 
 extern "C" int mi_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int M, int N, int Mp, hipStream_t st) {
     MI_ENTER();
     if (M <= 0 || N <= 0 || Mp < M || ld_out < Mp) return MI_ERR_ARG;
-    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(N, TR), cdiv(Mp, TR)), dim3(256), 0, st, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, M, N, Mp);
+    const int vec = ((ld_in % 8) == 0 && (ld_out % 8) == 0 && (Mp % 8) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(N, TR), cdiv(Mp, TR)), dim3(256), 0, st, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, M, N, Mp, vec);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
@@ -324,21 +369,30 @@ extern "C" int mi_act_bwd_bf16(const void* dy, long lddy, const void* pre, long 
     return MI_OK;
 }
 
+// workspace: >= mi_layernorm_bwd_workspace_floats(d) floats when dgamma != NULL (per-block partial sums; no float atomics)
+extern "C" size_t mi_layernorm_bwd_workspace_floats(int d) { return (size_t)512 * 2 * d; }
 extern "C" int mi_layernorm_bwd(const void* x, long ldx, int x_bf16, const float* gamma, float eps, const void* dy, long lddy, int dy_f32,
-                                void* dx, long lddx, int dx_bf16, int accumulate, float* dgamma, float* dbeta, int M, int d, hipStream_t st) {
+                                void* dx, long lddx, int dx_bf16, int accumulate, float* dgamma, float* dbeta, float* workspace, int M, int d,
+                                hipStream_t st) {
     MI_ENTER();
     if (M <= 0 || d <= 0 || d > 2048 || (d % 4) || (ldx % 4) || (lddy % 4) || (lddx % 4) || !gamma) return MI_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(x) & (x_bf16 ? 7 : 15)) || (reinterpret_cast<uintptr_t>(dy) & (dy_f32 ? 15 : 7)) ||
         (reinterpret_cast<uintptr_t>(dx) & (dx_bf16 ? 7 : 15))) return MI_ERR_ARG;
+    if (dgamma && (!dbeta || !workspace)) return MI_ERR_ARG;
     int grid = cdiv(M, 4);
-    if (grid > 1024) grid = 1024;                       // 4 blocks per CU; each wave walks rows wave_id, wave_id + nwaves, ...
+    if (grid > 512) grid = 512;                         // two blocks per CU; each wave walks rows wave_id, wave_id + nwaves, ...
     const int rpw = cdiv(M, (long)grid * 4);
     const size_t lds = (size_t)2 * d * sizeof(float);
     const int nv = cdiv(d, 256);
-#define LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(grid), dim3(256), lds, st, x, ldx, x_bf16, gamma, eps, dy, lddy, dy_f32, dx, lddx, dx_bf16, accumulate, dgamma, dbeta, M, d, rpw)
+    float* partial = dgamma ? workspace : nullptr;
+#define LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(grid), dim3(256), lds, st, x, ldx, x_bf16, gamma, eps, dy, lddy, dy_f32, dx, lddx, dx_bf16, accumulate, partial, M, d, rpw)
     if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4); else LN_BWD(8);
 #undef LN_BWD
     MI_CHECK_LAUNCH();
+    if (dgamma) {
+        hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(cdiv(2 * d, 64)), dim3(256), 0, st, partial, grid, d, dgamma, dbeta);
+        MI_CHECK_LAUNCH();
+    }
     return MI_OK;
 }
 

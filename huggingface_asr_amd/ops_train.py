@@ -19,6 +19,17 @@ def _L():
     return _lib.lib()
 
 
+_DW_WS = {}
+
+
+def _dw_ws(device, nfloats):
+    """scratch for per-block partial sums (LayerNorm / depthwise-conv parameter gradients); stream-ordered reuse"""
+    ws = _DW_WS.get(device)
+    if ws is None or ws.numel() < nfloats:
+        ws = _DW_WS[device] = torch.empty(max(nfloats, 512 * 2 * 2048), device=device, dtype=F32)
+    return ws.data_ptr()
+
+
 def pad64(n: int) -> int:
     return (n + 63) // 64 * 64
 
@@ -63,9 +74,10 @@ def act_bwd(dy, pre, kind="gelu", out=None):
 def layernorm_bwd(x, gamma, dy, dx, *, accumulate, dgamma=None, dbeta=None, eps=1e-5):
     """dx (+)= dLN(x)/dx · dy ; dgamma/dbeta += .  x f32|bf16, dy f32|bf16, dx f32|bf16 (all (M,d) row views)."""
     M, d = x.shape
+    ws = _dw_ws(x.device, 512 * 2 * 2048) if dgamma is not None else 0
     _lib.check(_L().mi_layernorm_bwd(x.data_ptr(), x.stride(0), int(x.dtype == BF16), gamma.data_ptr(), float(eps),
                                      dy.data_ptr(), dy.stride(0), int(dy.dtype == F32), dx.data_ptr(), dx.stride(0), int(dx.dtype == BF16),
-                                     int(accumulate), _p(dgamma), _p(dbeta), M, d, _stream()), "mi_layernorm_bwd")
+                                     int(accumulate), _p(dgamma), _p(dbeta), ws, M, d, _stream()), "mi_layernorm_bwd")
     return dx
 
 
@@ -133,16 +145,6 @@ def attn_softmax_bwd(prob, dp, H, B, Tq, Tk, scale, want_dbd=False):
     _lib.check(_L().mi_attn_softmax_bwd(prob.data_ptr(), dp.data_ptr(), ds.data_ptr(), _p(dbd), H, B, Tq, Tk, lds, ldp, float(scale), _stream()),
                "mi_attn_softmax_bwd")
     return ds, dbd
-
-
-_DW_WS = {}
-
-
-def _dw_ws(device, nfloats):
-    ws = _DW_WS.get(device)
-    if ws is None or ws.numel() < nfloats:
-        ws = _DW_WS[device] = torch.empty(nfloats, device=device, dtype=F32)
-    return ws.data_ptr()
 
 
 def csgu_bwd(u, stats, gamma, beta, w, bias, ds, dr, dgn, dw, db, B, T):

@@ -609,8 +609,11 @@ class EncoderCTCTrainer:
         T.bgemm(ds, (*sTT, Ts, 1), k, (hd, Tt * 3 * d, 1, 3 * d), dqu, (hd, Tt * d, d), H, B, Tt, hd, Tt)
         T.bgemm(dbd, (B * Tt * Ps, Tt * Ps, Ps, 1), posp, (hd, 0, 1, d), dqv, (hd, Tt * d, d), H, B, Tt, hd, Pn)
         # d(posp) (P, d) = sum_b dBD^T · (q + v): K runs over the (b, t) rows of one head
-        dposp = torch.empty((Pn, d), device=dev, dtype=F32)
-        T.bgemm(dbd, (B * Tt * Ps, 0, 1, Ps), qv, (hd, 0, 1, d), dposp, (hd, 0, d), H, 1, Pn, hd, B * Tt)
+        # per-utterance partials (B, P, d), then a column sum over B: one long-K product per head would occupy 64 blocks only
+        dpp = torch.empty((B, Pn * d), device=dev, dtype=F32)
+        T.bgemm(dbd, (B * Tt * Ps, Tt * Ps, 1, Ps), qv, (hd, Tt * d, 1, d), dpp, (hd, Pn * d, d), H, B, Pn, hd, Tt)
+        dposp = torch.zeros((Pn, d), device=dev, dtype=F32)
+        T.colsum_(dposp.view(-1), dpp)
         T.add_cast(dqu, dqv, out=dqkv[:, :d])
         T.colsum_(G(p + "att_u"), dqu)
         T.colsum_(G(p + "att_v"), dqv)

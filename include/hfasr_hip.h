@@ -146,8 +146,9 @@ int mi_colsum(const void* x, long ld, int dtype, int M, int N, float* out, mi_st
 int mi_act_fwd_bf16(const void* pre, long ldp, void* out, long ldo, int M, int N, int kind, mi_stream_t stream);
 int mi_act_bwd_bf16(const void* dy, long lddy, const void* pre, long ldp, void* dx, long lddx, int M, int N, int kind,
                     mi_stream_t stream);
+size_t mi_layernorm_bwd_workspace_floats(int d);
 int mi_layernorm_bwd(const void* x, long ldx, int x_bf16, const float* gamma, float eps, const void* dy, long lddy, int dy_f32,
-                     void* dx, long lddx, int dx_bf16, int accumulate, float* dgamma, float* dbeta, int M, int d,
+                     void* dx, long lddx, int dx_bf16, int accumulate, float* dgamma, float* dbeta, float* workspace, int M, int d,
                      mi_stream_t stream);
 int mi_ln_apply_bf16(const void* x, long ldx, const float* stats, const float* gamma, const float* beta, void* y, long ldy,
                      int M, int N, mi_stream_t stream);
