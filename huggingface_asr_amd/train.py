@@ -328,7 +328,7 @@ class EncoderCTCTrainer:
     def forward_backward(self, feats, feat_lengths, labels, *, loss_scale=1.0, extra_hidden_grad=None, backward=True, keep_hidden=False):
         """feats (B,T,F) f32 device; feat_lengths (B) int32 or None; labels (B,U) int64 (<0 = padding).
         Returns dict(loss, logits (B,T2,V+1) f32, outer_len, last_hidden).  Gradients of loss_scale/world * loss accumulate into the store.
-        `extra_hidden_grad`: optional callable(last_hidden f32 (M,d)) -> f32 (M,d) gradient to add at the encoder output
+        `extra_hidden_grad`: optional callable(last_hidden f32 (M,d), outer_len (B) int32) -> f32 (M,d) gradient to add at the encoder output
         (the attention decoder of the joint model hooks in here)."""
         c, st = self.cfg, self.store
         P, G, W, WT = st.p, st.g, st.bf, st.bfT
@@ -436,7 +436,7 @@ class EncoderCTCTrainer:
         dx = e32(M, d)
         T.layernorm_bwd(x, P("enc_ln_g"), dhid, dx, accumulate=False, dgamma=G("enc_ln_g"), dbeta=G("enc_ln_b"), eps=eps_e)
         if extra_hidden_grad is not None:
-            dh32 = extra_hidden_grad(last_hidden)
+            dh32 = extra_hidden_grad(last_hidden, outer)
             if dh32 is not None:
                 T.layernorm_bwd(x, P("enc_ln_g"), dh32, dx, accumulate=True, dgamma=G("enc_ln_g"), dbeta=G("enc_ln_b"), eps=eps_e)
         self.sync.launch(*st.range_of(self._head_names))

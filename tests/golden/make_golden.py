@@ -219,7 +219,7 @@ def run_ctc_known_answers():
 TINY_DEC = dict(vocab_size=51, n_embd=128, n_layer=3, n_head=2, n_positions=64, head_locations=[1], head_weights=[0.4, 0.6])
 
 
-def build_reference_aed(pos_emb_fixed=False):
+def build_reference_aed(pos_emb_fixed=False, enc_extra=None):
     from utilities.bind import bind_all
     bind_all()
     from models.ctc_encoder_plus_autoregressive_decoder import JointCTCAttentionEncoderDecoder, JointCTCAttentionEncoderDecoderConfig
@@ -233,7 +233,7 @@ def build_reference_aed(pos_emb_fixed=False):
         def tie_weights(self, *a, **k):
             return GPT2LMHeadModel.tie_weights(self, *a, **k)
 
-    ecfg, enc = build_reference(TINY)
+    ecfg, enc = build_reference(TINY, **(enc_extra or {}))
     dcfg = GPT2MultiHeadConfig(**TINY_DEC, add_cross_attention=True, attn_implementation="eager", bos_token_id=2, eos_token_id=1,
                                pad_token_id=50, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0, tie_word_embeddings=False)
     dcfg.lsm_factor = 0.1
@@ -288,6 +288,30 @@ def run_aed_cases():
             print(name, "loss", rec["loss"], rec["enc_loss"], rec["dec_loss"])
         except Exception as e:      # noqa: BLE001
             print(name, "FAILED in the reference under transformers 5.15:", type(e).__name__, str(e)[:200])
+
+
+def run_aed_grad_cases():
+    """training-mode forward + backward of the reference joint model (all dropouts 0): three losses and every parameter gradient."""
+    for name, fixed, seed in (("grads_aed_tiny", False, 31), ("grads_aed_tiny_fixedpos", True, 32)):
+        model = build_reference_aed(fixed, enc_extra=NO_DROPOUT)
+        model.train()
+        wsum = load_seeded(model, seed)
+        B, T, U = 2, 200, 9
+        x, am = synth_feats(seed, B, T, [198, 150])
+        lab = synth_labels(seed, B, U, 50, [9, 6])
+        lab[lab >= 0] = np.maximum(lab[lab >= 0], 3)
+        out = model(input_values=torch.from_numpy(x), attention_mask=torch.from_numpy(am), labels=torch.from_numpy(lab))
+        out.loss.backward()
+        rec = dict(seed=seed, weight_sum=wsum, lengths=np.array([198, 150]), shape=np.array([B, T, U]), labels=lab,
+                   loss=float(out.loss), enc_loss=float(out.enc_loss), dec_loss=float(out.dec_loss),
+                   param_names=np.array([k for k, _ in model.named_parameters()]),
+                   param_shapes=np.array([str(tuple(v.shape)) for _, v in model.named_parameters()]))
+        n = 0
+        for k, v in model.named_parameters():
+            if v.grad is not None:
+                rec["grad:" + k] = v.grad.float().numpy(); n += 1
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
+        print(name, "loss", rec["loss"], rec["enc_loss"], rec["dec_loss"], "n grads", n)
 
 
 WHISPER_TINY = dict(d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256, num_mel_bins=80, max_source_positions=100)
@@ -360,7 +384,7 @@ def run_ctc_prefix_cases():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "grads", "base", "fbank", "lengths", "ctc", "prefix", "aed", "whisper"]
+    which = sys.argv[1:] or ["tiny", "grads", "base", "fbank", "lengths", "ctc", "prefix", "aed", "aedgrads", "whisper"]
     if "tiny" in which:
         run_encoder_case("tiny_rel", TINY, seed=11, B=2, T=200, lengths=[198, 150], U=7, tgt_lens=[7, 5])
         run_encoder_case("tiny_rotary", TINY, seed=12, B=2, T=200, lengths=[200, 131], U=6, tgt_lens=[6, 4],
@@ -388,5 +412,7 @@ if __name__ == "__main__":
         run_ctc_prefix_cases()
     if "aed" in which:
         run_aed_cases()
+    if "aedgrads" in which:
+        run_aed_grad_cases()
     if "whisper" in which:
         run_whisper_cases()
