@@ -286,14 +286,26 @@ __global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, l
 }
 
 // ------------------------------------------------------------------------------------------------ optimizer
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+// deterministic sum of squares (every data-parallel rank must derive the SAME clip coefficient from the same reduced gradient, or the
+// replicas drift): fixed grid of per-block partials, then one block adds them in a fixed order.  No float atomics.
+constexpr int SSQ_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ partial) {
     __shared__ float part[4];
     float s = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += x[i] * x[i];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomic_add_f32(out, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ out) {
+    __shared__ float part[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += partial[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] += (part[0] + part[1]) + (part[2] + part[3]);
 }
 // norm = sqrt(sumsq); coef = min(1, max_norm / (norm + 1e-6))  (torch.nn.utils.clip_grad_norm_); non-finite norm -> coef 0 (step skipped)
 __global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* out /* [norm, coef] */) {
@@ -450,12 +462,12 @@ extern "C" int mi_mask_rows_f32(float* x, long ld, const int* lengths, int T, in
     return MI_OK;
 }
 
-// sumsq[0] += sum x^2 (caller zeroes sumsq);  clip: out = [norm, coef]
-extern "C" int mi_sumsq_f32(const float* x, long n, float* sumsq, hipStream_t st) {
+// sumsq[0] += sum x^2 (caller zeroes sumsq; bit-reproducible);  workspace: 1024 floats;  clip: out = [norm, coef]
+extern "C" int mi_sumsq_f32(const float* x, long n, float* sumsq, float* workspace, hipStream_t st) {
     MI_ENTER();
-    if (n <= 0) return MI_ERR_ARG;
-    const int grid = grid_for(n) > 2048 ? 2048 : grid_for(n);
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, st, x, n, sumsq);
+    if (n <= 0 || !workspace) return MI_ERR_ARG;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(SSQ_BLOCKS), dim3(256), 0, st, x, n, workspace);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, workspace, SSQ_BLOCKS, sumsq);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

@@ -212,7 +212,7 @@ def embed_tokens_bwd(ids, dx, dwte, dwpe=None, *, scale=1.0, pos_offset=0):
 
 
 def sumsq_(acc, x):
-    _lib.check(_L().mi_sumsq_f32(x.data_ptr(), x.numel(), acc.data_ptr(), _stream()), "mi_sumsq_f32")
+    _lib.check(_L().mi_sumsq_f32(x.data_ptr(), x.numel(), acc.data_ptr(), _dw_ws(x.device, 1024), _stream()), "mi_sumsq_f32")
 
 
 def clip_coef(sumsq, max_norm, out):

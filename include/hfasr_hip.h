@@ -160,7 +160,7 @@ int mi_add_rowvec_bf16(const void* x, long ldx, const float* vec, void* out, lon
 int mi_gate_bwd_bf16(const void* ds, long ldds, const void* c, long ldc, const void* r, long ldr, void* dr, long lddr,
                      void* dc, long lddc, int M, int N, mi_stream_t stream);
 int mi_mask_rows_f32(float* x, long ld, const int* lengths, int T, int M, int N, mi_stream_t stream);
-int mi_sumsq_f32(const float* x, long n, float* sumsq, mi_stream_t stream);
+int mi_sumsq_f32(const float* x, long n, float* sumsq, float* workspace /* 1024 floats */, mi_stream_t stream);
 int mi_clip_coef(const float* sumsq, float max_norm, float* norm_coef, mi_stream_t stream);
 int mi_adamw_step(float* p, const float* g, float* m, float* v, const unsigned char* decay, long n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, const float* norm_coef, void* mirror_bf16,

@@ -1,0 +1,71 @@
+"""Data-parallel training step on the GPU box: two ranks (two processes sharing the one GPU of the box, gloo process group —
+RCCL needs one device per rank) each run forward+backward on HALF the batch with the trainer's per-layer gradient all-reduce;
+the synchronised gradients must equal the full-batch gradients of the reference fixture (mean reduction: the average of the
+per-rank gradients IS the full-batch gradient), and both ranks must hold identical weights after the optimizer step."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from helpers import case_inputs, load_golden
+    from huggingface_asr_amd import shapes
+    from huggingface_asr_amd.train import EncoderCTCTrainer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    g = load_golden("grads_tiny_rel")
+    cfg = dict(shapes.TINY, ctc_zero_infinity=True, ctc_loss_reduction="mean", hidden_dropout=0.0, activation_dropout=0.0, attention_dropout=0.0,
+               final_dropout=0.0, feat_proj_dropout=0.0, csgu_conv_dropout=0.0, apply_spec_augment=False, layerdrop=0.0)
+    sd, x, am, lab = case_inputs(g, cfg)
+    tr = EncoderCTCTrainer(cfg, "cuda:0", lr=1e-3)
+    tr.load_state_dict(sd)
+    assert tr.sync.on and tr.sync.world == world
+    sl = slice(rank, rank + 1)                                   # this rank's shard of the batch
+    tr.store.zero_grad()
+    o = tr.forward_backward(x[sl].to("cuda:0"), am[sl].sum(-1).to("cuda:0"), lab[sl].to("cuda:0"))
+    tr.sync.wait()
+    torch.cuda.synchronize()
+    grads = {k: v.cpu().numpy() for k, v in tr.grad_dict().items()}
+    tr.optimizer_step()
+    torch.cuda.synchronize()
+    out[rank] = dict(loss=float(o["loss"]), grads=grads, wsum=float(tr.store.flat_p.double().sum()), norm=float(tr._scal[1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step_matches_full_batch_fixture():
+    from helpers import load_golden
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    g = load_golden("grads_tiny_rel")
+    r0, r1 = out[0], out[1]
+    assert abs(0.5 * (r0["loss"] + r1["loss"]) - float(g["loss"])) <= 1e-3 * float(g["loss"])     # mean of per-rank losses = batch loss
+    worst = 0.0
+    for k in g.files:
+        if not k.startswith("grad:"):
+            continue
+        want = g[k].reshape(-1)
+        a, b = r0["grads"][k[5:]].reshape(-1), r1["grads"][k[5:]].reshape(-1)
+        assert np.array_equal(a, b), k                                   # both ranks hold the same reduced gradient
+        nw = float(np.linalg.norm(want))
+        if nw > 1e-5:
+            worst = max(worst, float(np.linalg.norm(a - want)) / nw)
+    assert worst < 0.03, worst
+    assert r0["wsum"] == r1["wsum"] and r0["norm"] == r1["norm"] and r0["norm"] > 0

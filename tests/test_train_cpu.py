@@ -83,3 +83,37 @@ def test_gradsync_single_process_is_a_noop():
     s = GradSync(flat)
     s.launch(0, 10); s.wait()
     assert not s.on and s.world == 1 and torch.equal(flat, torch.ones(10))
+
+
+def test_decoder_layout_roundtrips_reference_names():
+    """GPT-2 Conv1D weights are stored (in, out) in the reference: packed as (out, in) rows for the GEMM, transposed back on export."""
+    from helpers import TINY_DEC
+    from huggingface_asr_amd.train_aed import _dec_map, decoder_specs
+    for fixed in (False, True):
+        c = dict(TINY_DEC, pos_emb_fixed=fixed, tie_word_embeddings=False)
+        specs = decoder_specs(c, 64, True)
+        mp_ = _dec_map(c, True)
+        d, V, L = c["n_embd"], c["vocab_size"], c["n_layer"]
+        sd = {"enc_to_dec_proj.weight": torch.randn(d, 64), "enc_to_dec_proj.bias": torch.randn(d), "decoder.lm_head.weight": torch.randn(V, d),
+              "decoder.additional_lm_heads.0.weight": torch.randn(V, d), "decoder.transformer.ln_f.weight": torch.randn(d), "decoder.transformer.ln_f.bias": torch.randn(d)}
+        if fixed:
+            sd["decoder.transformer.wte.emb_layers.0.weight"] = torch.randn(V, d)
+        else:
+            sd["decoder.transformer.wte.weight"] = torch.randn(V, d); sd["decoder.transformer.wpe.weight"] = torch.randn(c["n_positions"], d)
+        for l in range(L):
+            r = f"decoder.transformer.h.{l}."
+            for n, shp in (("ln_1", None), ("ln_cross_attn", None), ("ln_2", None)):
+                sd[r + n + ".weight"] = torch.randn(d); sd[r + n + ".bias"] = torch.randn(d)
+            for n, (i, o) in (("attn.c_attn", (d, 3 * d)), ("attn.c_proj", (d, d)), ("crossattention.q_attn", (d, d)), ("crossattention.c_attn", (d, 2 * d)),
+                              ("crossattention.c_proj", (d, d)), ("mlp.c_fc", (d, 4 * d)), ("mlp.c_proj", (4 * d, d))):
+                sd[r + n + ".weight"] = torch.randn(i, o); sd[r + n + ".bias"] = torch.randn(o)
+        store = ParamStore(specs, "cpu")
+        covered = {}
+        for s_ in specs:
+            store.p(s_.name).copy_(mp_[s_.name][0](sd).reshape(s_.shape))
+            for key, back in mp_[s_.name][1]:
+                covered[key] = back(store.p(s_.name))
+        assert set(covered) == set(sd)
+        for k, v in sd.items():
+            assert torch.equal(covered[k], v), k
+        assert store.specs["h0.wqkv"].shape == (3 * d, d) and store.specs["h0.wpr"].shape == (d, 4 * d)
