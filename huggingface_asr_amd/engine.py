@@ -43,7 +43,11 @@ def cfg_from_hf(config) -> dict:
                 use_macaron_ff=g("use_macaron_ff", True), is_causal=g("is_causal", False), layer_norm_eps=g("layer_norm_eps", 1e-5),
                 hidden_act=g("hidden_act", "gelu"), feat_extract_activation=g("feat_extract_activation", "gelu"),
                 mask_time_prob=g("mask_time_prob", 0.05), mask_feature_prob=g("mask_feature_prob", 0.0),
-                ctc_loss_reduction=g("ctc_loss_reduction", "sum"), ctc_zero_infinity=g("ctc_zero_infinity", False))
+                ctc_loss_reduction=g("ctc_loss_reduction", "sum"), ctc_zero_infinity=g("ctc_zero_infinity", False),
+                # training-mode randomness (train.py refuses non-zero values: the HIP training step has no dropout yet)
+                hidden_dropout=g("hidden_dropout", 0.0), activation_dropout=g("activation_dropout", 0.0), attention_dropout=g("attention_dropout", 0.0),
+                final_dropout=g("final_dropout", 0.0), feat_proj_dropout=g("feat_proj_dropout", 0.0), layerdrop=g("layerdrop", 0.0),
+                csgu_conv_dropout=g("csgu_conv_dropout", 0.0), apply_spec_augment=g("apply_spec_augment", False))
 
 
 class EBranchformerEngine:

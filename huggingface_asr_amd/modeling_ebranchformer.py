@@ -6,8 +6,10 @@ out-of-vocabulary labels, `freeze_encoder()`, `_get_feat_extract_output_lengths`
 reference inherits from Wav2Vec2ForCTC) and `_get_feature_vector_attention_mask`.  The nn.Modules below only HOLD the
 parameters (for state_dict / optimizers / checkpoint averaging); no tensor op of the forward goes through them.
 
-Round-1 scope: eval-mode forward (+ CTC loss value).  Training-mode forward/backward through the HIP path is the next
-row of SURVEY.md §8 and raises NotImplementedError here rather than silently falling back to PyTorch."""
+Eval mode / no_grad: the inference engine (engine.py).  Training mode with labels: forward AND backward run on the HIP trainer
+(train.py) behind a torch.autograd bridge (autograd_bridge.py), so `loss.backward()` fills ordinary `.grad`s for HF Trainer's
+optimizer; configurations the HIP training step does not cover yet (dropout > 0, in-model SpecAugment) raise NotImplementedError
+rather than silently falling back to PyTorch."""
 from __future__ import annotations
 
 from typing import Optional, Tuple, Union
@@ -200,6 +202,33 @@ class Wav2Vec2EBranchformerForCTC(PreTrainedModel):
             self._engine_key = key
         return self._engine
 
+    def _get_trainer(self, device):
+        from .train import EncoderCTCTrainer
+        if getattr(self, "_trainer", None) is None or self._trainer.device != torch.device(device):
+            self._trainer = EncoderCTCTrainer(cfg_from_hf(self.config), device, dp_sync=False)      # optimizer / all-reduce stay with the caller (HF Trainer)
+        return self._trainer
+
+    def _training_forward(self, input_values, attention_mask, labels, output_hidden_states, return_dict):
+        """training step through the HIP trainer; gradients reach the nn.Parameters via autograd_bridge.HipStep."""
+        from .autograd_bridge import run_training_forward
+        if labels is None:
+            raise NotImplementedError("HIP training forward needs `labels` (the CTC loss is the only differentiable output of this head)")
+        if any(not p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("HIP training step with frozen parameters (freeze_encoder / freeze_feature_encoder) is not supported yet")
+        if labels.max() >= self.config.vocab_size:
+            raise ValueError(f"Label values must be <= vocab_size: {self.config.vocab_size}")
+        tr = self._get_trainer(input_values.device)
+        feat_len = attention_mask.sum(-1).to(torch.int32) if attention_mask is not None else None
+
+        def step(t):
+            t.store.zero_grad()
+            return t.forward_backward(input_values, feat_len, labels.to(input_values.device), keep_hidden=bool(output_hidden_states))
+        loss, out = run_training_forward(self, tr, step)
+        hidden_states = (out["last_hidden"],) if output_hidden_states else None
+        if not return_dict:
+            return (loss, out["logits"]) + ((hidden_states,) if hidden_states is not None else ())
+        return CausalLMOutput(loss=loss, logits=out["logits"], hidden_states=hidden_states, attentions=None)
+
     def forward(
         self,
         input_values: Optional[torch.Tensor],
@@ -213,11 +242,10 @@ class Wav2Vec2EBranchformerForCTC(PreTrainedModel):
         return_dict = return_dict if return_dict is not None else getattr(self.config, "return_dict", True)
         if output_attentions:
             raise NotImplementedError("attention probabilities are never materialised by the fused HIP attention kernel")
-        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("training-mode forward/backward through the HIP path is not built yet (SURVEY.md §8f); "
-                                      "call model.eval() / torch.no_grad() for the HIP forward")
         if not input_values.is_cuda:
             raise RuntimeError("Wav2Vec2EBranchformerForCTC (HIP): inputs must be on the GPU; there is no CPU fallback")
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._training_forward(input_values, attention_mask, labels, output_hidden_states, return_dict)
         eng = self._get_engine(input_values.device)
         feat_len = attention_mask.sum(-1).to(torch.int32) if attention_mask is not None else None
         out = eng.forward(input_values, feat_len, want_hidden=True)

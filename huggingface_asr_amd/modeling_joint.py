@@ -189,6 +189,17 @@ class JointCTCAttentionEncoderDecoder(PreTrainedModel):
             self._engine_key = key
         return self._engine
 
+    def _get_trainer(self, device):
+        from .train_aed import JointAEDTrainer
+        if getattr(self, "_trainer", None) is None or self._trainer.device != torch.device(device):
+            jc = dict(ctc_weight=self.config.ctc_weight, pad_token_id=self.config.pad_token_id,
+                      decoder_start_token_id=self.config.decoder_start_token_id)
+            dc = dict(_dec_cfg_dict(self.config.decoder), tie_word_embeddings=False,
+                      resid_pdrop=getattr(self.config.decoder, "resid_pdrop", 0.0), embd_pdrop=getattr(self.config.decoder, "embd_pdrop", 0.0),
+                      attn_pdrop=getattr(self.config.decoder, "attn_pdrop", 0.0))
+            self._trainer = JointAEDTrainer(cfg_from_hf(self.config.encoder), dc, jc, device, with_proj=hasattr(self, "enc_to_dec_proj"), dp_sync=False)
+        return self._trainer
+
     @staticmethod
     def _pick_inputs(inputs, input_values, input_features):
         if inputs is None:
@@ -202,8 +213,7 @@ class JointCTCAttentionEncoderDecoder(PreTrainedModel):
     def forward(self, inputs=None, attention_mask=None, decoder_input_ids=None, decoder_attention_mask=None, encoder_outputs=None,
                 past_key_values=None, decoder_inputs_embeds=None, labels=None, use_cache=None, output_attentions=None,
                 output_hidden_states=None, input_values=None, input_features=None, return_dict=None, **kwargs):
-        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("training-mode forward/backward through the HIP path is not built yet (DESIGN.md §7)")
+        training = self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if labels is None or decoder_input_ids is not None or encoder_outputs is not None or decoder_inputs_embeds is not None:
             raise NotImplementedError("HIP joint forward implements the teacher-forced path driven by `labels` (reference :303-304); "
                                       "use generate() for decoding")
@@ -212,9 +222,20 @@ class JointCTCAttentionEncoderDecoder(PreTrainedModel):
             raise RuntimeError("JointCTCAttentionEncoderDecoder (HIP): inputs must be on the GPU; there is no CPU fallback")
         if labels.max() >= self.config.encoder.vocab_size:
             raise ValueError(f"Label values must be <= vocab_size: {self.config.encoder.vocab_size}")
-        eng = self._get_engine(inputs.device)
         fl = attention_mask.sum(-1).to(torch.int32) if attention_mask is not None else None
-        out = eng.forward(inputs, fl, labels.to(inputs.device))
+        if training:                                       # forward + backward on the HIP trainer, gradients handed to autograd
+            from .autograd_bridge import run_training_forward
+            if any(not p.requires_grad for p in self.parameters()):
+                raise NotImplementedError("HIP training step with frozen parameters is not supported yet")
+            tr = self._get_trainer(inputs.device)
+
+            def step(t):
+                t.enc.store.zero_grad(); t.store.zero_grad()
+                return t.forward_backward(inputs, fl, labels.to(inputs.device))
+            loss, out = run_training_forward(self, tr, step)
+            out = dict(out, loss=loss)
+        else:
+            out = self._get_engine(inputs.device).forward(inputs, fl, labels.to(inputs.device))
         B, T2 = out["encoder_logits"].shape[:2]
         return Seq2SeqLMOutputLosses(loss=out["loss"], enc_loss=out["enc_loss"], dec_loss=out["dec_loss"], logits=out["logits"],
                                      encoder_last_hidden_state=out["encoder_hidden"].view(B, T2, -1), encoder_logits=out["encoder_logits"])

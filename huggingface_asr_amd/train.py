@@ -165,7 +165,9 @@ def _enc_map(c: dict):
     cw = "" if c.get("is_causal", False) else ".conv"
     m = {}
     one = lambda name, key, fwd=lambda t: t, bwd=lambda t: t: m.__setitem__(name, (lambda sd: fwd(sd[key]), [(key, bwd)]))
-    one("masked_spec_embed", "wav2vec2.masked_spec_embed")
+    # optional in the reference (present iff mask_time_prob > 0 or mask_feature_prob > 0): absent -> zeros, not exported
+    m["masked_spec_embed"] = (lambda sd: sd["wav2vec2.masked_spec_embed"] if "wav2vec2.masked_spec_embed" in sd else torch.zeros(d),
+                              [("wav2vec2.masked_spec_embed", lambda t: t)])
     one("conv1_w", f"{fe}conv.0.0{cw}.weight", lambda t: t.reshape(C1, K * K), lambda t: t.reshape(C1, 1, K, K))
     one("conv1_b", f"{fe}conv.0.0{cw}.bias")
     one("conv2_w", f"{fe}conv.1.0{cw}.weight", lambda t: t.permute(0, 2, 3, 1).reshape(C2, K * K * C1),
@@ -219,10 +221,10 @@ class GradSync:
     """Data-parallel SUM all-reduce of flat-gradient ranges, launched as soon as a range is final (reverse layer order) so the
     collective of layer l overlaps the backward of layers < l.  RCCL over xGMI on MI355X (backend 'nccl'), gloo in the CPU tests."""
 
-    def __init__(self, flat_g: torch.Tensor, group=None):
+    def __init__(self, flat_g: torch.Tensor, group=None, enabled=True):
         import torch.distributed as dist
         self.dist = dist
-        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.on = bool(enabled) and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.world = dist.get_world_size(group) if self.on else 1
         self.flat_g, self.group, self.pending = flat_g, group, []
 
@@ -240,7 +242,9 @@ class GradSync:
 class EncoderCTCTrainer:
     """forward + backward + AdamW for Wav2Vec2EBranchformerForCTC on one GPU (one process per GPU under DP)."""
 
-    def __init__(self, cfg: dict, device="cuda:0", *, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None):
+    def __init__(self, cfg: dict, device="cuda:0", *, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
+                 dp_sync=True):
+        """dp_sync=False: no gradient all-reduce here (the caller, e.g. HF Trainer's DDP wrapper, owns data parallelism)."""
         c = self.cfg = dict(cfg)
         if c.get("is_causal", False):
             raise NotImplementedError("training path: causal encoders are not supported yet")
@@ -257,7 +261,7 @@ class EncoderCTCTrainer:
         self.store = ParamStore(encoder_specs(c), self.device)
         self.map = _enc_map(c)
         self.hp = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
-        self.sync = GradSync(self.store.flat_g, group)
+        self.sync = GradSync(self.store.flat_g, group, enabled=dp_sync)
         self._pos = {}
         self._scal = torch.zeros(4, dtype=F32, device=self.device)       # [sumsq, norm, coef, -]
         L = c["num_hidden_layers"]
@@ -270,26 +274,27 @@ class EncoderCTCTrainer:
     def load_state_dict(self, sd: dict):
         dev = self.device
         sdd = {k: v.detach().to(dev, F32) for k, v in sd.items() if torch.is_tensor(v) and v.is_floating_point()}
+        self._has_mse = "wav2vec2.masked_spec_embed" in sdd
         for name in self.store.order:
             self.store.p(name).copy_(self.map[name][0](sdd).reshape(self.store.specs[name].shape))
         self.store.refresh_mirrors(cast=True)
 
-    def state_dict(self) -> dict:
+    def _export(self, view):
         out = {}
         for name in self.store.order:
-            t = self.store.p(name)
+            if name == "masked_spec_embed" and not getattr(self, "_has_mse", True):
+                continue
+            t = view(name)
             for key, fn in self.map[name][1]:
                 out[key] = fn(t).clone()
         return out
 
+    def state_dict(self) -> dict:
+        return self._export(self.store.p)
+
     def grad_dict(self) -> dict:
-        """gradients in the reference's parameter names / shapes (tests, checkpoint tooling)."""
-        out = {}
-        for name in self.store.order:
-            t = self.store.g(name)
-            for key, fn in self.map[name][1]:
-                out[key] = fn(t).clone()
-        return out
+        """gradients in the reference's parameter names / shapes (tests, checkpoint tooling, the autograd bridge)."""
+        return self._export(self.store.g)
 
     # ------------------------------------------------------------------ tables
     def out_frames(self, Tn):

@@ -104,7 +104,7 @@ class JointAEDTrainer:
     """forward + backward + AdamW for JointCTCAttentionEncoderDecoder (E-Branchformer encoder + multi-head GPT-2 decoder)."""
 
     def __init__(self, enc_cfg: dict, dec_cfg: dict, joint_cfg: dict, device="cuda:0", *, lr=2e-3, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.0, max_grad_norm=1.0, group=None, with_proj=None):
+                 weight_decay=0.0, max_grad_norm=1.0, group=None, with_proj=None, dp_sync=True):
         c = self.dcfg = dict(dec_cfg)
         self.jcfg = dict(joint_cfg)
         self.device = torch.device(device)
@@ -116,12 +116,13 @@ class JointAEDTrainer:
         for k in ("resid_pdrop", "embd_pdrop", "attn_pdrop"):
             if float(c.get(k, 0.0) or 0.0) != 0.0:
                 raise NotImplementedError(f"training path: decoder {k} > 0 is not supported yet (set it to 0.0)")
-        self.enc = EncoderCTCTrainer(enc_cfg, device, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group)
+        self.enc = EncoderCTCTrainer(enc_cfg, device, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group,
+                                     dp_sync=dp_sync)
         enc_dim = enc_cfg["hidden_size"]
         self.with_proj = (enc_dim != d) if with_proj is None else with_proj
         self.store = ParamStore(decoder_specs(c, enc_dim, self.with_proj), self.device)
         self.map = _dec_map(c, self.with_proj)
-        self.sync = GradSync(self.store.flat_g, group)
+        self.sync = GradSync(self.store.flat_g, group, enabled=dp_sync)
         self.hp = self.enc.hp
         if c.get("pos_emb_fixed", False):
             n = c.get("n_positions", 1024)

@@ -145,3 +145,67 @@ def test_joint_aed_gradients_match_reference_golden(name, fixed):
     for _ in range(4):
         o = tr.train_step(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV))
     assert np.isfinite(float(o["loss"])) and float(o["loss"]) < l0
+
+
+# ---------------------------------------------------------------------------------------------------------------- HF surface
+HF_NO_DROPOUT = dict(hidden_dropout=0.0, activation_dropout=0.0, attention_dropout=0.0, final_dropout=0.0, feat_proj_dropout=0.0,
+                     ebranchformer_conv_dropout=0.0, apply_spec_augment=False, layerdrop=0.0)
+
+
+def test_hf_ctc_model_trains_through_autograd_bridge():
+    """AutoModelForCTC route in train() mode: `model(**batch).loss.backward()` fills the nn.Parameters' .grad (== the reference's
+    gradients), a torch optimizer steps them, and default configs with dropout > 0 are refused instead of silently running without it."""
+    from transformers import AutoModelForCTC
+    from huggingface_asr_amd.bind import bind_all
+    from huggingface_asr_amd.configuration_ebranchformer import Wav2Vec2EBranchformerConfig
+    bind_all()
+    g = load_golden("grads_tiny_rel")
+    cfg = dict(shapes.TINY, ctc_zero_infinity=True, ctc_loss_reduction="mean")
+    sd, x, am, lab = case_inputs(g, cfg)
+    base = dict(shapes.TINY); base.pop("num_fbanks")
+    model = AutoModelForCTC.from_config(Wav2Vec2EBranchformerConfig(**base, ctc_zero_infinity=True, ctc_loss_reduction="mean", **HF_NO_DROPOUT))
+    assert not any(model.load_state_dict(sd, strict=False))
+    model = model.to(DEV).train()
+    out = model(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))
+    assert out.loss.requires_grad and abs(float(out.loss.detach()) - float(g["loss"])) <= 1e-3 * float(g["loss"]) + 1e-3
+    (2.0 * out.loss).backward()                                   # an upstream factor (loss scaling / accumulation) must reach the gradients
+    ref = {k[5:]: 2.0 * g[k] for k in g.files if k.startswith("grad:")}
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert set(ref) <= set(grads)
+    _compare(grads, ref)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    l0 = float(out.loss)
+    for _ in range(5):
+        opt.zero_grad()
+        o = model(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))
+        o.loss.backward()
+        opt.step()
+    assert float(o.loss) < l0
+    # reference-default dropouts: refuse loudly
+    dflt = AutoModelForCTC.from_config(Wav2Vec2EBranchformerConfig(**base)).to(DEV).train()
+    with pytest.raises(NotImplementedError):
+        dflt(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))
+
+
+def test_hf_joint_model_trains_through_autograd_bridge():
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import aed_case_inputs
+    from test_surface_cpu import _joint_model
+    g = load_golden("grads_aed_tiny")
+    sd, x, am, lab = aed_case_inputs(g)
+    model = _joint_model(False)
+    for k, v in HF_NO_DROPOUT.items():
+        setattr(model.config.encoder, "csgu_conv_dropout" if k == "ebranchformer_conv_dropout" else k, v)
+    for k in ("resid_pdrop", "embd_pdrop", "attn_pdrop"):
+        setattr(model.config.decoder, k, 0.0)
+    assert not any(model.load_state_dict(sd, strict=False))
+    model = model.to(DEV).train()
+    out = model(input_values=x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))
+    for key in ("loss", "enc_loss", "dec_loss"):
+        assert abs(float(getattr(out, key)) - float(g[key])) <= 2e-3 * abs(float(g[key])) + 1e-3, key
+    out.loss.backward()
+    ref = {k[5:]: g[k] for k in g.files if k.startswith("grad:")}
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert set(ref) <= set(grads)
+    _compare(grads, ref)

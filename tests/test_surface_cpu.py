@@ -58,7 +58,7 @@ def test_length_helpers_and_errors():
     with pytest.raises(RuntimeError):          # CPU tensors: no fallback
         model(torch.zeros(1, 100, 80))
     model.train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):          # the training step runs on the HIP trainer: CPU tensors are refused as well
         model(torch.zeros(1, 100, 80))
     assert model.get_output_embeddings() is None
     model.freeze_encoder()
