@@ -18,7 +18,24 @@ struct SmArgs {
     int H, B, Tq, Tk, causal;
     long ld_s, ld_p;                      // row strides (elements) of the (.., Tk) and (.., 2T-1) matrices
     float scale;
+    float drop_p; unsigned long long drop_key;   // attention-probability dropout (dropout.hip's counter-based mask); 0 = off
+    bf16_t* prob_drop;                    // fwd: dropped probabilities for the PV product (null when drop_p == 0)
 };
+
+__device__ __forceinline__ unsigned long long sm_splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// logical index of P[h][b][i][j] = ((h*B + b)*Tq + i)*Tk + j  (independent of the padded row stride)
+__device__ __forceinline__ float sm_keep(const SmArgs& p, long row, int j) {
+    const unsigned long long idx = (unsigned long long)row * (unsigned long long)p.Tk + (unsigned long long)j;
+    const unsigned long long h = sm_splitmix64(sm_splitmix64(idx ^ p.drop_key) + p.drop_key);
+    const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
+    return u >= p.drop_p ? 1.f / (1.f - p.drop_p) : 0.f;
+}
 
 __device__ __forceinline__ bool key_masked(const SmArgs& p, int b, int i, int j) {
     if (p.lengths && j >= p.lengths[b]) return true;
@@ -53,6 +70,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(SmArgs p) {
         float v = 0.f;
         if (!key_masked(p, b, i, j)) v = __expf((ac[j] + (bd ? bd[j] : 0.f)) * p.scale - mx) * inv;
         out[j] = f2bf(v);
+        if (p.prob_drop) p.prob_drop[row * p.ld_s + j] = f2bf(v * sm_keep(p, row, j));
     }
 }
 
@@ -65,17 +83,19 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(SmArgs p) {
     const int i = (int)(row % p.Tq);
     const bf16_t* pr = p.prob + row * p.ld_s;
     const float* dp = p.dp + row * p.ld_s;
+    // with dropout, dp is the gradient w.r.t. the DROPPED probabilities: dP = dp * keep / (1 - p) (mask regenerated)
+    const bool dr = p.drop_p > 0.f;
     float dot = 0.f;
-    for (int j = lane; j < p.Tk; j += 64) dot += bf2f(pr[j]) * dp[j];
+    for (int j = lane; j < p.Tk; j += 64) dot += bf2f(pr[j]) * dp[j] * (dr ? sm_keep(p, row, j) : 1.f);
     dot = wave_sum(dot);
     bf16_t* ds = p.ds + row * p.ld_s;
-    for (int j = lane; j < p.Tk; j += 64) ds[j] = f2bf(bf2f(pr[j]) * (dp[j] - dot) * p.scale);
+    for (int j = lane; j < p.Tk; j += 64) ds[j] = f2bf(bf2f(pr[j]) * (dp[j] * (dr ? sm_keep(p, row, j) : 1.f) - dot) * p.scale);
     if (p.dbd) {
         const int P = 2 * p.Tq - 1, off = p.Tq - 1 - i;
         bf16_t* dbd = p.dbd + row * p.ld_p;
         for (int q = lane; q < P; q += 64) {
             const int j = q - off;
-            dbd[q] = (j >= 0 && j < p.Tk) ? f2bf(bf2f(pr[j]) * (dp[j] - dot) * p.scale) : (bf16_t)0.f;
+            dbd[q] = (j >= 0 && j < p.Tk) ? f2bf(bf2f(pr[j]) * (dp[j] * (dr ? sm_keep(p, row, j) : 1.f) - dot) * p.scale) : (bf16_t)0.f;
         }
     }
 }
@@ -83,21 +103,26 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(SmArgs p) {
 }  // namespace
 
 // ld_s: row stride of ac / prob / dp / ds (>= Tk); ld_p: row stride of bd / dbd (>= 2 Tq - 1).  Padding columns are never read.
-extern "C" int mi_attn_softmax_fwd(const float* ac, const float* bd, const int* lengths, void* prob, int H, int B, int Tq, int Tk,
-                                   long ld_s, long ld_p, float scale, int causal, hipStream_t st) {
+// prob_drop / drop_p / seed / stream_id: attention-probability dropout (prob stays un-dropped for the backward pass); pass NULL / 0 for none
+extern "C" int mi_attn_softmax_fwd(const float* ac, const float* bd, const int* lengths, void* prob, void* prob_drop, int H, int B, int Tq, int Tk,
+                                   long ld_s, long ld_p, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, hipStream_t st) {
     MI_ENTER();
     if (H <= 0 || B <= 0 || Tq <= 0 || Tk <= 0 || (bd && Tq != Tk) || ld_s < Tk || (bd && ld_p < 2 * Tq - 1)) return MI_ERR_ARG;
-    SmArgs p{ac, bd, nullptr, (bf16_t*)prob, nullptr, nullptr, lengths, H, B, Tq, Tk, causal, ld_s, ld_p, scale};
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !prob_drop)) return MI_ERR_ARG;
+    SmArgs p{ac, bd, nullptr, (bf16_t*)prob, nullptr, nullptr, lengths, H, B, Tq, Tk, causal, ld_s, ld_p, scale, drop_p,
+             ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed, drop_p > 0.f ? (bf16_t*)prob_drop : nullptr};
     hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv((long)H * B * Tq, 4)), dim3(256), 0, st, p);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
 
 extern "C" int mi_attn_softmax_bwd(const void* prob, const float* dp, void* ds, void* dbd, int H, int B, int Tq, int Tk, long ld_s, long ld_p,
-                                   float scale, hipStream_t st) {
+                                   float scale, float drop_p, unsigned seed, unsigned stream_id, hipStream_t st) {
     MI_ENTER();
     if (H <= 0 || B <= 0 || Tq <= 0 || Tk <= 0 || (dbd && Tq != Tk) || ld_s < Tk || (dbd && ld_p < 2 * Tq - 1)) return MI_ERR_ARG;
-    SmArgs p{nullptr, nullptr, dp, (bf16_t*)prob, (bf16_t*)ds, (bf16_t*)dbd, nullptr, H, B, Tq, Tk, 0, ld_s, ld_p, scale};
+    if (drop_p < 0.f || drop_p >= 1.f) return MI_ERR_ARG;
+    SmArgs p{nullptr, nullptr, dp, (bf16_t*)prob, (bf16_t*)ds, (bf16_t*)dbd, nullptr, H, B, Tq, Tk, 0, ld_s, ld_p, scale, drop_p,
+             ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed, nullptr};
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3(cdiv((long)H * B * Tq, 4)), dim3(256), 0, st, p);
     MI_CHECK_LAUNCH();
     return MI_OK;

@@ -1,0 +1,79 @@
+// Dropout for the training step on gfx950 — counter-based masks (no RNG state, no stored masks).
+//
+// Reference: torch.nn.Dropout at the points the reference applies it in train() mode (e_branchformer.py:132,203,288,301,451;
+// tf wav2vec2_conformer FFN :353,356, encoder input :674; GPT-2 embd / attn / resid dropouts).  torch's Philox stream cannot be
+// reproduced, so the mask is DEFINED here as a pure function of (seed, stream, logical element index):
+//     keep(idx) = (splitmix64(splitmix64(idx ^ key) + key) >> 40) * 2^-24 >= p,      key = (stream << 32) ^ seed
+// the same hash as huggingface_asr_amd/synth.py (`dropout_keep`), so the CPU oracle is run with the identical masks in the parity
+// tests and the backward pass regenerates the mask instead of storing it.   out = x * keep / (1 - p).
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float keep_scale(unsigned long long key, unsigned long long idx, float p, float inv_keep) {
+    const unsigned long long h = splitmix64(splitmix64(idx ^ key) + key);
+    const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
+    return u >= p ? inv_keep : 0.f;
+}
+
+// element (m, n) of an (M, N) matrix has logical index m * N + n whatever the leading dimensions are
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void dropout_kernel(const TI* __restrict__ x, long ldx, TO* __restrict__ out, long ldo, int M, int N,
+                                                       float alpha, float p, unsigned long long key) {
+    const long total = (long)M * N;
+    const float inv_keep = 1.f / (1.f - p);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        const float v = (float)x[(long)m * ldx + n] * alpha * keep_scale(key, (unsigned long long)i, p, inv_keep);
+        out[(long)m * ldo + n] = (TO)v;
+    }
+}
+
+// y = resid + alpha * dropout(t)
+__global__ __launch_bounds__(256) void dropout_add_kernel(float* __restrict__ y, long ldy, const float* __restrict__ resid, long ldr,
+                                                           const float* __restrict__ t, long ldt, int M, int N, float alpha, float p,
+                                                           unsigned long long key) {
+    const long total = (long)M * N;
+    const float inv_keep = 1.f / (1.f - p);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        y[(long)m * ldy + n] = resid[(long)m * ldr + n] + alpha * t[(long)m * ldt + n] * keep_scale(key, (unsigned long long)i, p, inv_keep);
+    }
+}
+
+int grid_for(long n) { const long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g)); }
+
+}  // namespace
+
+// out = alpha * dropout(x);  in_dtype / out_dtype: 0 fp32, 1 bf16;  out may alias x when the dtypes match
+extern "C" int mi_dropout(const void* x, long ldx, int in_dtype, void* out, long ldo, int out_dtype, int M, int N, float alpha, float p,
+                          unsigned seed, unsigned stream_id, hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || N <= 0 || p < 0.f || p >= 1.f) return MI_ERR_ARG;
+    const unsigned long long key = ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed;
+    const int g = grid_for((long)M * N);
+    if (in_dtype == 0 && out_dtype == 0) hipLaunchKernelGGL((dropout_kernel<float, float>), dim3(g), dim3(256), 0, st, (const float*)x, ldx, (float*)out, ldo, M, N, alpha, p, key);
+    else if (in_dtype == 0 && out_dtype == 1) hipLaunchKernelGGL((dropout_kernel<float, bf16_t>), dim3(g), dim3(256), 0, st, (const float*)x, ldx, (bf16_t*)out, ldo, M, N, alpha, p, key);
+    else if (in_dtype == 1 && out_dtype == 1) hipLaunchKernelGGL((dropout_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, M, N, alpha, p, key);
+    else if (in_dtype == 1 && out_dtype == 0) hipLaunchKernelGGL((dropout_kernel<bf16_t, float>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx, (float*)out, ldo, M, N, alpha, p, key);
+    else return MI_ERR_ARG;
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+extern "C" int mi_dropout_add_f32(float* y, long ldy, const float* resid, long ldr, const float* t, long ldt, int M, int N, float alpha, float p,
+                                  unsigned seed, unsigned stream_id, hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || N <= 0 || p < 0.f || p >= 1.f) return MI_ERR_ARG;
+    const unsigned long long key = ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed;
+    hipLaunchKernelGGL(dropout_add_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, st, y, ldy, resid, ldr, t, ldt, M, N, alpha, p, key);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}

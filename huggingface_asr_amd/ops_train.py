@@ -127,24 +127,46 @@ def pad8(n: int) -> int:
     return (n + 7) // 8 * 8
 
 
-def attn_softmax_fwd(ac, bd, lengths, H, B, Tq, Tk, scale, causal=False):
-    """ac (H,B,Tq,lds) f32, bd (H,B,Tq,ldp) f32 | None (row strides = last-dim sizes) -> prob (H,B,Tq,lds) bf16."""
+def attn_softmax_fwd(ac, bd, lengths, H, B, Tq, Tk, scale, causal=False, drop=None):
+    """ac (H,B,Tq,lds) f32, bd (H,B,Tq,ldp) f32 | None (row strides = last-dim sizes) -> prob (H,B,Tq,lds) bf16.
+    drop = (p, seed, stream_id): also returns the dropped probabilities (for the PV product); prob itself stays un-dropped."""
     lds = ac.shape[-1]
     ldp = bd.shape[-1] if bd is not None else 0
     prob = torch.empty((H, B, Tq, lds), device=ac.device, dtype=BF16)
-    _lib.check(_L().mi_attn_softmax_fwd(ac.data_ptr(), _p(bd), _p(lengths), prob.data_ptr(), H, B, Tq, Tk, lds, ldp, float(scale), int(causal), _stream()),
-               "mi_attn_softmax_fwd")
-    return prob
+    p, seed, sid = drop if drop else (0.0, 0, 0)
+    pd = torch.empty_like(prob) if p > 0 else None
+    _lib.check(_L().mi_attn_softmax_fwd(ac.data_ptr(), _p(bd), _p(lengths), prob.data_ptr(), _p(pd), H, B, Tq, Tk, lds, ldp, float(scale), int(causal),
+                                        float(p), int(seed) & 0xFFFFFFFF, int(sid) & 0xFFFFFFFF, _stream()), "mi_attn_softmax_fwd")
+    return (prob, pd) if drop else prob
 
 
-def attn_softmax_bwd(prob, dp, H, B, Tq, Tk, scale, want_dbd=False):
+def attn_softmax_bwd(prob, dp, H, B, Tq, Tk, scale, want_dbd=False, drop=None):
     lds = prob.shape[-1]
     ldp = pad8(2 * Tq - 1)
     ds = torch.empty((H, B, Tq, lds), device=prob.device, dtype=BF16)
     dbd = torch.empty((H, B, Tq, ldp), device=prob.device, dtype=BF16) if want_dbd else None
-    _lib.check(_L().mi_attn_softmax_bwd(prob.data_ptr(), dp.data_ptr(), ds.data_ptr(), _p(dbd), H, B, Tq, Tk, lds, ldp, float(scale), _stream()),
-               "mi_attn_softmax_bwd")
+    p, seed, sid = drop if drop else (0.0, 0, 0)
+    _lib.check(_L().mi_attn_softmax_bwd(prob.data_ptr(), dp.data_ptr(), ds.data_ptr(), _p(dbd), H, B, Tq, Tk, lds, ldp, float(scale),
+                                        float(p), int(seed) & 0xFFFFFFFF, int(sid) & 0xFFFFFFFF, _stream()), "mi_attn_softmax_bwd")
     return ds, dbd
+
+
+def dropout_(x, p, seed, stream_id, out=None, alpha=1.0):
+    """out (default: in place) = alpha * x * keep / (1 - p) on an (M,N) f32|bf16 row view; mask = f(seed, stream_id, m*N + n)."""
+    M, N = x.shape
+    out = x if out is None else out
+    _lib.check(_L().mi_dropout(x.data_ptr(), x.stride(0), int(x.dtype == BF16), out.data_ptr(), out.stride(0), int(out.dtype == BF16), M, N,
+                               float(alpha), float(p), int(seed) & 0xFFFFFFFF, int(stream_id) & 0xFFFFFFFF, _stream()), "mi_dropout")
+    return out
+
+
+def dropout_add(resid, t, alpha, p, seed, stream_id):
+    """resid + alpha * dropout(t)  (f32 (M,N))."""
+    M, N = t.shape
+    y = torch.empty((M, N), device=t.device, dtype=F32)
+    _lib.check(_L().mi_dropout_add_f32(y.data_ptr(), y.stride(0), resid.data_ptr(), resid.stride(0), t.data_ptr(), t.stride(0), M, N, float(alpha),
+                                       float(p), int(seed) & 0xFFFFFFFF, int(stream_id) & 0xFFFFFFFF, _stream()), "mi_dropout_add_f32")
+    return y
 
 
 def csgu_bwd(u, stats, gamma, beta, w, bias, ds, dr, dgn, dw, db, B, T):

@@ -83,3 +83,13 @@ def waveforms(seed: int, batch: int, num_samples: int, tone_hz: float = 220.0) -
 def labels(seed: int, batch: int, length: int, vocab: int, lo: int = 5) -> np.ndarray:
     u = uniform(seed, "labels", (batch, length), 0.0, 1.0)
     return (lo + np.floor(u * (vocab - lo))).astype(np.int64).clip(lo, vocab - 1)
+
+
+def dropout_keep(seed: int, stream_id: int, n: int, p: float) -> np.ndarray:
+    """bool keep-mask of csrc/dropout.hip for logical element indices 0..n-1 (the CPU oracle runs with the kernels' exact masks)."""
+    key = np.uint64(((stream_id & 0xFFFFFFFF) << 32) ^ (seed & 0xFFFFFFFF))
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64)
+        h = _splitmix64(_splitmix64(idx ^ key) + key)
+    u = (h >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24))
+    return u >= np.float32(p)

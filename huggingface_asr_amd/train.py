@@ -15,7 +15,8 @@ recipes/librispeech/.../train_small_baseline.sh:43,53-58: bf16 autocast, AdamW, 
 
 Precision model = the reference's autocast recipe: fp32 master weights and residual stream, bf16 GEMM operands (activations AND
 activation gradients), fp32 accumulation, fp32 LayerNorm / softmax / CTC, fp32 parameter gradients.
-Not yet on this path (raise NotImplementedError): dropout > 0, in-model SpecAugment, LayerDrop, causal encoders.
+Dropout (all eight sites of the layer, encoder input, feature projection, CTC head) uses counter-based masks that the backward
+pass regenerates.  Not yet on this path (raise NotImplementedError): in-model SpecAugment, LayerDrop, causal encoders.
 """
 from __future__ import annotations
 
@@ -243,8 +244,9 @@ class EncoderCTCTrainer:
     """forward + backward + AdamW for Wav2Vec2EBranchformerForCTC on one GPU (one process per GPU under DP)."""
 
     def __init__(self, cfg: dict, device="cuda:0", *, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
-                 dp_sync=True):
-        """dp_sync=False: no gradient all-reduce here (the caller, e.g. HF Trainer's DDP wrapper, owns data parallelism)."""
+                 dp_sync=True, seed=0):
+        """dp_sync=False: no gradient all-reduce here (the caller, e.g. HF Trainer's DDP wrapper, owns data parallelism).
+        seed: dropout mask seed (masks are counter-based: f(seed, step, layer, site, element), csrc/dropout.hip); give every DP rank its own."""
         c = self.cfg = dict(cfg)
         if c.get("is_causal", False):
             raise NotImplementedError("training path: causal encoders are not supported yet")
@@ -252,9 +254,14 @@ class EncoderCTCTrainer:
             raise NotImplementedError("training path: 2-layer 3x3 Conv2d sub-sampling only")
         if c.get("csgu_activation", "identity") != "identity" or c.get("csgu_use_linear_after_conv", False):
             raise NotImplementedError("training path: CSGU with identity activation and no linear-after-conv only")
-        for k in ("hidden_dropout", "activation_dropout", "attention_dropout", "final_dropout", "feat_proj_dropout", "layerdrop", "csgu_conv_dropout"):
-            if float(c.get(k, 0.0) or 0.0) != 0.0:
-                raise NotImplementedError(f"training path: {k} > 0 is not supported yet (set it to 0.0)")
+        if float(c.get("layerdrop", 0.0) or 0.0) != 0.0:
+            raise NotImplementedError("training path: layerdrop > 0 is not supported (the reference's recipes force it to 0.0, model_utils.py:125,160)")
+        g = lambda k: float(c.get(k, 0.0) or 0.0)
+        # dropout probabilities by site (which config value feeds which nn.Dropout: e_branchformer.py:132,182,229-246,451; tf :353,356,674)
+        self.pdrop = dict(act=g("activation_dropout"), hidden=g("hidden_dropout"), att=g("attention_dropout"), csgu=g("csgu_conv_dropout"),
+                          final=g("final_dropout"), fp=g("feat_proj_dropout"))
+        self.seed = int(seed) & 0xFFFFFFFF
+        self.train_steps_seen = 0
         if c.get("apply_spec_augment", False) and float(c.get("mask_time_prob", 0.0) or 0.0) > 0.0:
             raise NotImplementedError("training path: in-model SpecAugment is not supported yet (apply_spec_augment=False)")
         self.device = torch.device(device)
@@ -330,7 +337,8 @@ class EncoderCTCTrainer:
         return self._pos[key]
 
     # ------------------------------------------------------------------ forward + backward
-    def forward_backward(self, feats, feat_lengths, labels, *, loss_scale=1.0, extra_hidden_grad=None, backward=True, keep_hidden=False):
+    def forward_backward(self, feats, feat_lengths, labels, *, loss_scale=1.0, extra_hidden_grad=None, backward=True, keep_hidden=False,
+                         train_mode=False, step_index=None):
         """feats (B,T,F) f32 device; feat_lengths (B) int32 or None; labels (B,U) int64 (<0 = padding).
         Returns dict(loss, logits (B,T2,V+1) f32, outer_len, last_hidden).  Gradients of loss_scale/world * loss accumulate into the store.
         `extra_hidden_grad`: optional callable(last_hidden f32 (M,d), outer_len (B) int32) -> f32 (M,d) gradient to add at the encoder output
@@ -361,6 +369,10 @@ class EncoderCTCTrainer:
         e32 = lambda *sh: torch.empty(sh, device=dev, dtype=F32)
         e16 = lambda *sh: torch.empty(sh, device=dev, dtype=BF16)
         LN = ops.layernorm_chain
+        pd, seed = (self.pdrop if (backward or train_mode) else dict.fromkeys(self.pdrop, 0.0)), self.seed
+        self._step_idx = self.train_steps_seen if step_index is None else int(step_index)
+        if backward or train_mode:
+            self.train_steps_seen += 1
 
         # ---------------- front end
         act1 = ops.conv2d_first_gelu(feats, P("conv1_w"), P("conv1_b"), stride=s_, pad=pad)
@@ -370,8 +382,12 @@ class EncoderCTCTrainer:
         a_fp = e16(M, d)
         LN(feo, lna=(P("fp_ln_g"), P("fp_ln_b")), eps2=eps_e, outa=a_fp)
         x = ops.gemm(a_fp, W("fp_w"), P("fp_b"), out_dtype=F32)
+        if pd["fp"] > 0:
+            T.dropout_(x, pd["fp"], seed, self._sid(L, 0))
         if inner is not None:
             T.mask_rows_(x, inner, T2)
+        if pd["hidden"] > 0:
+            T.dropout_(x, pd["hidden"], seed, self._sid(L, 1))
         pos = self._pos_table(T2)
         saved = []
         # ---------------- layers
@@ -379,7 +395,7 @@ class EncoderCTCTrainer:
             p = f"l{l}."
             S = {"x_in": x}
             if macaron:
-                x, S["ff1"] = self._ffn_fwd(x, p + "ff1", LN, e16)
+                x, S["ff1"] = self._ffn_fwd(x, p + "ff1", LN, e16, pd, l, (0, 1))
             S["x1"] = x
             a1, a2 = e16(M, d), e16(M, d)
             LN(x, lna=(P(p + "att_ln_g"), P(p + "att_ln_b")), outa=a1, lnb=(P(p + "mlp_ln_g"), P(p + "mlp_ln_b")), outb=a2)
@@ -397,21 +413,28 @@ class EncoderCTCTrainer:
             if ptype == "relative":
                 posp = ops.gemm(pos[0], W(p + "att_wpos"))
             ctx = self._attention_fwd(qkv, posp, P(p + "att_u") if posp is not None else None, P(p + "att_v") if posp is not None else None,
-                                      inner, B, T2, H, S)
+                                      inner, B, T2, H, S, (pd["att"], seed, self._sid(l, 2)) if pd["att"] > 0 else None)
             ops.gemm(ctx, W(p + "att_wo"), P(p + "att_bo"), out=cat[:, :d])
+            if pd["att"] > 0:
+                T.dropout_(cat[:, :d], pd["att"], seed, self._sid(l, 3))
             # local branch (cgMLP)
             hp = ops.gemm(a2, W(p + "mlp_w1"), P(p + "mlp_b1"))
             h = T.act_fwd(hp)
             stats = ops.row_stats(h[:, I // 2:])
             sg = ops.csgu(h, P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), B, T2)
+            if pd["csgu"] > 0:
+                T.dropout_(sg, pd["csgu"], seed, self._sid(l, 4))
             ops.gemm(sg, W(p + "mlp_w2"), P(p + "mlp_b2"), out=cat[:, d:])
             # merge
             m2 = ops.dwconv_residual(cat, P(p + "mrg_dw_w"), P(p + "mrg_dw_b"), B, T2)
-            x2 = ops.gemm(m2, W(p + "mrg_w"), P(p + "mrg_b"), out_dtype=F32, resid=x, alpha=1.0)
+            if pd["att"] > 0:       # the layer's `final_dropout` module takes config.attention_dropout (e_branchformer.py:229,246)
+                x2 = T.dropout_add(x, ops.gemm(m2, W(p + "mrg_w"), P(p + "mrg_b"), out_dtype=F32), 1.0, pd["att"], seed, self._sid(l, 5))
+            else:
+                x2 = ops.gemm(m2, W(p + "mrg_w"), P(p + "mrg_b"), out_dtype=F32, resid=x, alpha=1.0)
             S.update(a1=a1, a2=a2, qkv=qkv, posp=posp, ctx=ctx, hp=hp, h=h, stats=stats, sg=sg, cat=cat, m2=m2, x2=x2)
             x = x2
             if macaron:
-                x, S["ff2"] = self._ffn_fwd(x, p + "ff2", LN, e16)
+                x, S["ff2"] = self._ffn_fwd(x, p + "ff2", LN, e16, pd, l, (6, 7))
             S["x3"] = x
             xo = e32(M, d)
             LN(x, ln1=(P(p + "fin_ln_g"), P(p + "fin_ln_b")), store_y=xo)
@@ -421,6 +444,8 @@ class EncoderCTCTrainer:
         hid = e16(M, d)
         last_hidden = e32(M, d)
         LN(x, lna=(P("enc_ln_g"), P("enc_ln_b")), eps2=eps_e, outa=hid, outa32=last_hidden)
+        if pd["final"] > 0:
+            T.dropout_(hid, pd["final"], seed, self._sid(L, 2))
         ldl = T.pad64(V1)
         lbuf = e32(B, T2, ldl)
         ops.gemm(hid, W("head_w"), P("head_b"), out=lbuf.view(M, ldl))
@@ -436,6 +461,8 @@ class EncoderCTCTrainer:
         gs = float(loss_scale) / self.sync.world
         dlog = T.ctc_loss_bwd(logits, lse, labels, outer, nll, reduction=red, gscale=gs, ldo=ldl)         # (M, ldl) bf16
         dhid = T.gemm(dlog, WT("head_w"))                                                                # (M, d) bf16
+        if pd["final"] > 0:
+            T.dropout_(dhid, pd["final"], seed, self._sid(L, 2))
         T.gemm_tn_(G("head_w"), dlog, hid, n_store=V1)
         T.colsum_(G("head_b"), dlog[:, :V1])
         dx = e32(M, d)
@@ -453,14 +480,16 @@ class EncoderCTCTrainer:
             T.layernorm_bwd(S["x3"], P(p + "fin_ln_g"), dx, d3, accumulate=False, dgamma=G(p + "fin_ln_g"), dbeta=G(p + "fin_ln_b"))
             dx = d3
             if macaron:
-                self._ffn_bwd(dx, S["x2"], S["ff2"], p + "ff2")
-            # merge:  x2 = x1 + merge_proj(m2)
-            dyb = T.add_cast(dx)
+                self._ffn_bwd(dx, S["x2"], S["ff2"], p + "ff2", pd, l, (6, 7))
+            # merge:  x2 = x1 + dropout(merge_proj(m2))
+            dyb = T.dropout_(dx, pd["att"], seed, self._sid(l, 5), out=e16(M, d)) if pd["att"] > 0 else T.add_cast(dx)
             dm2 = T.linear_bwd(dyb, S["m2"], WT(p + "mrg_w"), dw=G(p + "mrg_w"), db=G(p + "mrg_b"))
             dcat = e16(M, 2 * d)
             T.dwconv_residual_bwd(S["cat"], P(p + "mrg_dw_w"), dm2, dcat, G(p + "mrg_dw_w"), G(p + "mrg_dw_b"), B, T2)
             # local branch
             dsg = T.linear_bwd(dcat[:, d:], S["sg"], WT(p + "mlp_w2"), dw=G(p + "mlp_w2"), db=G(p + "mlp_b2"))
+            if pd["csgu"] > 0:
+                T.dropout_(dsg, pd["csgu"], seed, self._sid(l, 4))
             dh = e16(M, I)
             dgn = e16(M, I // 2)
             T.csgu_bwd(S["h"], S["stats"], P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), dsg, dh[:, :I // 2], dgn,
@@ -470,8 +499,10 @@ class EncoderCTCTrainer:
             da2 = T.linear_bwd(dhp, S["a2"], WT(p + "mlp_w1"), dw=G(p + "mlp_w1"), db=G(p + "mlp_b1"))
             T.layernorm_bwd(S["x1"], P(p + "mlp_ln_g"), da2, dx, accumulate=True, dgamma=G(p + "mlp_ln_g"), dbeta=G(p + "mlp_ln_b"))
             # global branch
+            if pd["att"] > 0:
+                T.dropout_(dcat[:, :d], pd["att"], seed, self._sid(l, 3))
             dctx = T.linear_bwd(dcat[:, :d], S["ctx"], WT(p + "att_wo"), dw=G(p + "att_wo"), db=G(p + "att_bo"))
-            dqkv = self._attention_bwd(dctx, S, p, pos, inner, B, T2, H)
+            dqkv = self._attention_bwd(dctx, S, p, pos, inner, B, T2, H, (pd["att"], seed, self._sid(l, 2)) if pd["att"] > 0 else None)
             if ptype == "rotary":
                 wt = WT(p + "att_wqkv")
                 da1r = T.linear_bwd(dqkv[:, :2 * d], S["a1r"], wt[:, :2 * d], dw=G(p + "att_wqkv")[:2 * d], db=G(p + "att_bqkv")[:2 * d])
@@ -483,12 +514,14 @@ class EncoderCTCTrainer:
                 da1 = T.linear_bwd(dqkv, S["a1"], WT(p + "att_wqkv")[:, :3 * d], dw=G(p + "att_wqkv"), db=G(p + "att_bqkv"))
                 T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), da1, dx, accumulate=True, dgamma=G(p + "att_ln_g"), dbeta=G(p + "att_ln_b"))
             if macaron:
-                self._ffn_bwd(dx, S["x_in"], S["ff1"], p + "ff1")
+                self._ffn_bwd(dx, S["x_in"], S["ff1"], p + "ff1", pd, l, (0, 1))
             self.sync.launch(*st.range_of(self._layer_names[l]))
         # ---------------- front end
+        if pd["hidden"] > 0:
+            T.dropout_(dx, pd["hidden"], seed, self._sid(L, 1))
         if inner is not None:
             T.mask_rows_(dx, inner, T2)
-        dyb = T.add_cast(dx)
+        dyb = T.dropout_(dx, pd["fp"], seed, self._sid(L, 0), out=e16(M, d)) if pd["fp"] > 0 else T.add_cast(dx)
         da = T.linear_bwd(dyb, a_fp, WT("fp_w"), dw=G("fp_w"), db=G("fp_b"))
         dfeo = e32(M, d)
         T.layernorm_bwd(feo, P("fp_ln_g"), da, dfeo, accumulate=False, dgamma=G("fp_ln_g"), dbeta=G("fp_ln_b"), eps=eps_e)
@@ -504,6 +537,10 @@ class EncoderCTCTrainer:
         return out
 
     # ------------------------------------------------------------------ pieces
+    def _sid(self, layer: int, site: int) -> int:
+        """dropout stream id of (this step, layer, site); layer = num_hidden_layers for the global sites (0 feat-proj, 1 encoder input, 2 head)"""
+        return ((self._step_idx * 64 + layer) * 16 + site) & 0xFFFFFFFF
+
     def _outer_len(self, n):
         k, s = self.cfg["conv_kernel"][0], self.cfg["conv_stride"][0]
         for _ in range(2):
@@ -519,33 +556,46 @@ class EncoderCTCTrainer:
             lo = torch.div(lo - k, s, rounding_mode="floor") + 1
         return torch.clamp(li, max=T2).to(torch.int32), lo.to(torch.int32)
 
-    def _ffn_fwd(self, x, pre, LN, e16):
-        """x + 0.5 * W2 gelu(W1 LN(x))  (e_branchformer.py:271-273, 307-309)"""
+    def _ffn_fwd(self, x, pre, LN, e16, pd, l, sites):
+        """x + 0.5 * dropout(W2 dropout(gelu(W1 LN(x))))  (e_branchformer.py:271-273, 307-309; tf:350-357)"""
         P, W = self.store.p, self.store.bf
         M, d = x.shape
         a = e16(M, d)
         LN(x, lna=(P(pre + "_ln_g"), P(pre + "_ln_b")), outa=a)
         hp = ops.gemm(a, W(pre + "_w1"), P(pre + "_b1"))
         h = T.act_fwd(hp)
-        y = ops.gemm(h, W(pre + "_w2"), P(pre + "_b2"), out_dtype=F32, resid=x, alpha=0.5)
+        if pd["act"] > 0:
+            T.dropout_(h, pd["act"], self.seed, self._sid(l, sites[0]))
+        if pd["hidden"] > 0:
+            y = T.dropout_add(x, ops.gemm(h, W(pre + "_w2"), P(pre + "_b2"), out_dtype=F32), 0.5, pd["hidden"], self.seed, self._sid(l, sites[1]))
+        else:
+            y = ops.gemm(h, W(pre + "_w2"), P(pre + "_b2"), out_dtype=F32, resid=x, alpha=0.5)
         return y, dict(a=a, hp=hp, h=h)
 
-    def _ffn_bwd(self, dx, x_in, S, pre):
+    def _ffn_bwd(self, dx, x_in, S, pre, pd, l, sites):
         """dx (f32, in place): gradient w.r.t. the block output -> gradient w.r.t. its input (residual + LN path)."""
         P, G, WT = self.store.p, self.store.g, self.store.bfT
-        dyb = T.add_cast(dx, alpha=0.5)
+        if pd["hidden"] > 0:
+            dyb = T.dropout_(dx, pd["hidden"], self.seed, self._sid(l, sites[1]), out=torch.empty(dx.shape, device=dx.device, dtype=BF16), alpha=0.5)
+        else:
+            dyb = T.add_cast(dx, alpha=0.5)
         dh = T.linear_bwd(dyb, S["h"], WT(pre + "_w2"), dw=G(pre + "_w2"), db=G(pre + "_b2"))
+        if pd["act"] > 0:
+            T.dropout_(dh, pd["act"], self.seed, self._sid(l, sites[0]))
         dhp = T.act_bwd(dh, S["hp"])
         da = T.linear_bwd(dhp, S["a"], WT(pre + "_w1"), dw=G(pre + "_w1"), db=G(pre + "_b1"))
         T.layernorm_bwd(x_in, P(pre + "_ln_g"), da, dx, accumulate=True, dgamma=G(pre + "_ln_g"), dbeta=G(pre + "_ln_b"))
 
-    def _attention_fwd(self, qkv, posp, u, v, lengths, B, Tt, H, S):
+    def _attention_fwd(self, qkv, posp, u, v, lengths, B, Tt, H, S, drop=None):
         d = qkv.shape[1] // 3
         hd = d // H
-        if hd in (64, 128):
+        if hd in (64, 128) and drop is None:
             return ops.attention_qkv(qkv, B, Tt, H, pos=posp, bias_u=u, bias_v=v, lengths=lengths)
-        # small heads (test configs): probabilities through the generic pieces, kept for the backward pass
-        prob = self._probs(qkv, posp, u, v, lengths, B, Tt, H, S)
+        # probability dropout (e_branchformer.py:132) or small heads (test configs): probabilities through the generic pieces,
+        # kept for the backward pass; the dropped copy feeds the PV product
+        prob = self._probs(qkv, posp, u, v, lengths, B, Tt, H, S, drop)
+        if drop is not None:
+            S["prob_pre"], prob = prob
         ctx = torch.empty((B * Tt, d), device=qkv.device, dtype=BF16)
         vv = qkv[:, 2 * d:]
         Ts = prob.shape[-1]
@@ -553,7 +603,7 @@ class EncoderCTCTrainer:
         S["prob"] = prob
         return ctx
 
-    def _probs(self, qkv, posp, u, v, lengths, B, Tt, H, S):
+    def _probs(self, qkv, posp, u, v, lengths, B, Tt, H, S, drop=None):
         d = qkv.shape[1] // 3
         hd = d // H
         dev = qkv.device
@@ -574,9 +624,9 @@ class EncoderCTCTrainer:
             bd = torch.empty((H, B, Tt, Ps), device=dev, dtype=F32)
             T.bgemm(qv, (hd, Tt * d, d, 1), posp, (hd, 0, d, 1), bd, (B * Tt * Ps, Tt * Ps, Ps), H, B, Tt, Pn, hd)
         S["qu"], S["qv"] = qu, qv
-        return T.attn_softmax_fwd(ac, bd, lengths, H, B, Tt, Tt, 1.0 / math.sqrt(hd))
+        return T.attn_softmax_fwd(ac, bd, lengths, H, B, Tt, Tt, 1.0 / math.sqrt(hd), drop=drop)
 
-    def _attention_bwd(self, dctx, S, p, pos, lengths, B, Tt, H):
+    def _attention_bwd(self, dctx, S, p, pos, lengths, B, Tt, H, drop=None):
         """-> dqkv (M, 3d) bf16; accumulates pos_bias_u / pos_bias_v / linear_pos gradients."""
         G, P = self.store.g, self.store.p
         qkv, posp = S["qkv"], S["posp"]
@@ -586,9 +636,10 @@ class EncoderCTCTrainer:
         dev = qkv.device
         scale = 1.0 / math.sqrt(hd)
         rel = posp is not None
-        prob = S.get("prob")
+        prob = S.get("prob")                           # what multiplied V in the forward (dropped copy under dropout)
         if prob is None:
             prob = self._probs(qkv, posp, P(p + "att_u") if rel else None, P(p + "att_v") if rel else None, lengths, B, Tt, H, S)
+        prob_pre = S.get("prob_pre", prob)             # un-dropped probabilities: the softmax Jacobian
         qu, qv = S["qu"], S["qv"]
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         Ts = prob.shape[-1]
@@ -597,7 +648,7 @@ class EncoderCTCTrainer:
         # dP = dctx · V^T
         dp = torch.empty((H, B, Tt, Ts), device=dev, dtype=F32)
         T.bgemm(dctx, (hd, Tt * d, d, 1), v, (hd, Tt * 3 * d, 3 * d, 1), dp, (*sTT, Ts), H, B, Tt, Tt, hd)
-        ds, dbd = T.attn_softmax_bwd(prob, dp, H, B, Tt, Tt, scale, want_dbd=rel)
+        ds, dbd = T.attn_softmax_bwd(prob_pre, dp, H, B, Tt, Tt, scale, want_dbd=rel, drop=drop)
         # dV = P^T · dctx
         T.bgemm(prob, (*sTT, 1, Ts), dctx, (hd, Tt * d, 1, d), dqkv[:, 2 * d:], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt)
         # dK = dS^T · (q + u)

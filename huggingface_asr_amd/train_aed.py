@@ -8,7 +8,7 @@ gelu_new MLP):   loss = w * CTC + (1 - w) * sum_k head_weight_k * CE_k.
 
 The encoder side is `train.EncoderCTCTrainer`; the decoder hooks into its backward at the encoder output (`extra_hidden_grad`),
 so the encoder's per-layer gradient all-reduces still overlap the remaining backward.  Same precision model and the same
-restrictions (dropouts 0) as train.py.
+restrictions as train.py; GPT-2's embd / attn / resid dropouts use the same counter-based masks (decoder layer l = stream layer 32 + l).
 """
 from __future__ import annotations
 
@@ -78,24 +78,43 @@ def _dec_map(c: dict, with_proj: bool, prefix="decoder."):
     return m
 
 
-def attention_bwd_plain(q, k, v, dctx, dq, dk, dv, B, Tq, Tk, H, *, lengths=None, causal=False):
-    """Backward of ctx = softmax(q k^T / sqrt(hd) + mask) v per (utterance, head); all operands are (rows, >= d) bf16 row views
-    with head h at columns [h*hd, (h+1)*hd); probabilities are recomputed (the forward is the fused LDS kernel)."""
+def _scores(q, k, B, Tq, Tk, H, hd):
+    Ts = T.pad8(Tk)
+    ac = torch.empty((H, B, Tq, Ts), device=q.device, dtype=F32)
+    T.bgemm(q, (hd, Tq * q.stride(0), q.stride(0), 1), k, (hd, Tk * k.stride(0), k.stride(0), 1), ac, (B * Tq * Ts, Tq * Ts, Ts), H, B, Tq, Tk, hd)
+    return ac, Ts
+
+
+def attention_fwd_plain(q, k, v, B, Tq, Tk, H, *, lengths=None, causal=False, drop=None):
+    """Un-fused attention forward (used when attention-probability dropout is on): -> (ctx (B*Tq, d) bf16, prob, prob_dropped)."""
+    d = q.shape[1]
+    hd = d // H
+    ac, Ts = _scores(q, k, B, Tq, Tk, H, hd)
+    prob, pdrop = T.attn_softmax_fwd(ac, None, lengths, H, B, Tq, Tk, 1.0 / math.sqrt(hd), causal, drop=drop)
+    ctx = torch.empty((B * Tq, d), device=q.device, dtype=BF16)
+    T.bgemm(pdrop, (B * Tq * Ts, Tq * Ts, Ts, 1), v, (hd, Tk * v.stride(0), 1, v.stride(0)), ctx, (hd, Tq * d, d), H, B, Tq, hd, Tk)
+    return ctx, prob, pdrop
+
+
+def attention_bwd_plain(q, k, v, dctx, dq, dk, dv, B, Tq, Tk, H, *, lengths=None, causal=False, drop=None, saved=None):
+    """Backward of ctx = dropout(softmax(q k^T / sqrt(hd) + mask)) v per (utterance, head); all operands are (rows, >= d) bf16 row
+    views with head h at columns [h*hd, (h+1)*hd).  Probabilities are recomputed when the forward was the fused LDS kernel
+    (saved = None), or passed in as saved = (prob, prob_dropped) from attention_fwd_plain."""
     d = dctx.shape[1]
     hd = d // H
-    dev = q.device
     scale = 1.0 / math.sqrt(hd)
-    Ts = T.pad8(Tk)
     sq, sk, sv = q.stride(0), k.stride(0), v.stride(0)
+    ac, Ts = _scores(q, k, B, Tq, Tk, H, hd)
     sS = (B * Tq * Ts, Tq * Ts)
-    ac = torch.empty((H, B, Tq, Ts), device=dev, dtype=F32)
-    T.bgemm(q, (hd, Tq * sq, sq, 1), k, (hd, Tk * sk, sk, 1), ac, (*sS, Ts), H, B, Tq, Tk, hd)
-    prob = T.attn_softmax_fwd(ac, None, lengths, H, B, Tq, Tk, scale, causal)
+    if saved is None:
+        prob = pdrop = T.attn_softmax_fwd(ac, None, lengths, H, B, Tq, Tk, scale, causal)
+    else:
+        prob, pdrop = saved
     dp = ac                                                # reuse the fp32 buffer
     sd_ = dctx.stride(0)
     T.bgemm(dctx, (hd, Tq * sd_, sd_, 1), v, (hd, Tk * sv, sv, 1), dp, (*sS, Ts), H, B, Tq, Tk, hd)
-    ds, _ = T.attn_softmax_bwd(prob, dp, H, B, Tq, Tk, scale)
-    T.bgemm(prob, (*sS, 1, Ts), dctx, (hd, Tq * sd_, 1, sd_), dv, (hd, Tk * dv.stride(0), dv.stride(0)), H, B, Tk, hd, Tq)
+    ds, _ = T.attn_softmax_bwd(prob, dp, H, B, Tq, Tk, scale, drop=drop)
+    T.bgemm(pdrop, (*sS, 1, Ts), dctx, (hd, Tq * sd_, 1, sd_), dv, (hd, Tk * dv.stride(0), dv.stride(0)), H, B, Tk, hd, Tq)
     T.bgemm(ds, (*sS, 1, Ts), q, (hd, Tq * sq, 1, sq), dk, (hd, Tk * dk.stride(0), dk.stride(0)), H, B, Tk, hd, Tq)
     T.bgemm(ds, (*sS, Ts, 1), k, (hd, Tk * sk, 1, sk), dq, (hd, Tq * dq.stride(0), dq.stride(0)), H, B, Tq, hd, Tk)
 
@@ -104,7 +123,7 @@ class JointAEDTrainer:
     """forward + backward + AdamW for JointCTCAttentionEncoderDecoder (E-Branchformer encoder + multi-head GPT-2 decoder)."""
 
     def __init__(self, enc_cfg: dict, dec_cfg: dict, joint_cfg: dict, device="cuda:0", *, lr=2e-3, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.0, max_grad_norm=1.0, group=None, with_proj=None, dp_sync=True):
+                 weight_decay=0.0, max_grad_norm=1.0, group=None, with_proj=None, dp_sync=True, seed=0):
         c = self.dcfg = dict(dec_cfg)
         self.jcfg = dict(joint_cfg)
         self.device = torch.device(device)
@@ -113,11 +132,9 @@ class JointAEDTrainer:
             raise NotImplementedError("HIP decoder attention supports head sizes 64 and 128")
         if c.get("activation_function", "gelu_new") != "gelu_new":
             raise NotImplementedError("decoder MLP activation other than gelu_new")
-        for k in ("resid_pdrop", "embd_pdrop", "attn_pdrop"):
-            if float(c.get(k, 0.0) or 0.0) != 0.0:
-                raise NotImplementedError(f"training path: decoder {k} > 0 is not supported yet (set it to 0.0)")
+        self.pdrop = {k: float(c.get(k, 0.0) or 0.0) for k in ("resid_pdrop", "embd_pdrop", "attn_pdrop")}
         self.enc = EncoderCTCTrainer(enc_cfg, device, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group,
-                                     dp_sync=dp_sync)
+                                     dp_sync=dp_sync, seed=seed)
         enc_dim = enc_cfg["hidden_size"]
         self.with_proj = (enc_dim != d) if with_proj is None else with_proj
         self.store = ParamStore(decoder_specs(c, enc_dim, self.with_proj), self.device)
@@ -172,6 +189,16 @@ class JointAEDTrainer:
         enc_bf = ops.gemm(hb, W("proj_w"), P("proj_b")) if self.with_proj else hb
         pos = self.pos_fixed if self.pos_fixed is not None else P("wpe")
         x = ops.embed_tokens(ids, P("wte"), pos, scale=self.emb_scale)
+        pe, pa, pr = self.pdrop["embd_pdrop"], self.pdrop["attn_pdrop"], self.pdrop["resid_pdrop"]
+        seed, sid = self.enc.seed, self.enc._sid
+        if pe > 0:
+            T.dropout_(x, pe, seed, sid(63, 0))
+
+        def resid_add(res, a16, wname, bname, lay, site):
+            """res + dropout(a16 W^T + b)"""
+            if pr > 0:
+                return T.dropout_add(res, ops.gemm(a16, W(wname), P(bname), out_dtype=F32), 1.0, pr, seed, sid(lay, site))
+            return ops.gemm(a16, W(wname), P(bname), out_dtype=F32, resid=res, alpha=1.0)
         locs = list(c.get("head_locations") or [])
         weights = list(c.get("head_weights") or [1.0])
         lsm = float(c.get("lsm_factor", 0.0))
@@ -180,23 +207,29 @@ class JointAEDTrainer:
             taps[0] = x
         for l in range(L):
             p = f"h{l}."
-            S = {"x": x}
+            S = {"x": x, "p1": None, "p2": None}
             a1 = e16(M, d)
             LN(x, lna=(P(p + "ln1_g"), P(p + "ln1_b")), eps2=eps, outa=a1)
             qkv = ops.gemm(a1, W(p + "wqkv"), P(p + "bqkv"))
-            ctx1 = ops.attention_general(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, U, U, H, causal=True)
-            x1 = ops.gemm(ctx1, W(p + "wo"), P(p + "bo"), out_dtype=F32, resid=x, alpha=1.0)
+            if pa > 0:
+                ctx1, *S["p1"] = attention_fwd_plain(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, U, U, H, causal=True, drop=(pa, seed, sid(32 + l, 0)))
+            else:
+                ctx1 = ops.attention_general(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, U, U, H, causal=True)
+            x1 = resid_add(x, ctx1, p + "wo", p + "bo", 32 + l, 1)
             a2 = e16(M, d)
             LN(x1, lna=(P(p + "lnc_g"), P(p + "lnc_b")), eps2=eps, outa=a2)
             qq = ops.gemm(a2, W(p + "wq"), P(p + "bq"))
             kv = ops.gemm(enc_bf, W(p + "wkv"), P(p + "bkv"))
-            ctx2 = ops.attention_general(qq, kv[:, :d], kv[:, d:], B, U, T2, H, lengths=key_len)
-            x2 = ops.gemm(ctx2, W(p + "wco"), P(p + "bco"), out_dtype=F32, resid=x1, alpha=1.0)
+            if pa > 0:
+                ctx2, *S["p2"] = attention_fwd_plain(qq, kv[:, :d], kv[:, d:], B, U, T2, H, lengths=key_len, drop=(pa, seed, sid(32 + l, 2)))
+            else:
+                ctx2 = ops.attention_general(qq, kv[:, :d], kv[:, d:], B, U, T2, H, lengths=key_len)
+            x2 = resid_add(x1, ctx2, p + "wco", p + "bco", 32 + l, 3)
             a3 = e16(M, d)
             LN(x2, lna=(P(p + "ln2_g"), P(p + "ln2_b")), eps2=eps, outa=a3)
             mp = ops.gemm(a3, W(p + "wfc"), P(p + "bfc"))
             mm = T.act_fwd(mp, "gelu_new")
-            x3 = ops.gemm(mm, W(p + "wpr"), P(p + "bpr"), out_dtype=F32, resid=x2, alpha=1.0)
+            x3 = resid_add(x2, mm, p + "wpr", p + "bpr", 32 + l, 4)
             S.update(a1=a1, qkv=qkv, ctx1=ctx1, x1=x1, a2=a2, qq=qq, kv=kv, ctx2=ctx2, x2=x2, a3=a3, mp=mp, mm=mm)
             saved.append(S)
             x = x3
@@ -243,32 +276,37 @@ class JointAEDTrainer:
             S = saved[l]
             if (l + 1) in tap_grads:
                 T.axpy_(dx, tap_grads[l + 1])
+            dres = (lambda lay, site: T.dropout_(dx, pr, seed, sid(lay, site), out=e16(M, d))) if pr > 0 else (lambda lay, site: T.add_cast(dx))
             # MLP
-            dyb = T.add_cast(dx)
+            dyb = dres(32 + l, 4)
             dm = T.linear_bwd(dyb, S["mm"], WT(p + "wpr"), dw=G(p + "wpr"), db=G(p + "bpr"))
             dmp = T.act_bwd(dm, S["mp"], "gelu_new")
             da3 = T.linear_bwd(dmp, S["a3"], WT(p + "wfc"), dw=G(p + "wfc"), db=G(p + "bfc"))
             T.layernorm_bwd(S["x2"], P(p + "ln2_g"), da3, dx, accumulate=True, dgamma=G(p + "ln2_g"), dbeta=G(p + "ln2_b"), eps=eps)
             # cross-attention
-            dyb = T.add_cast(dx)
+            dyb = dres(32 + l, 3)
             dctx2 = T.linear_bwd(dyb, S["ctx2"], WT(p + "wco"), dw=G(p + "wco"), db=G(p + "bco"))
             dqq, dkv = e16(M, d), e16(Me, 2 * d)
             kv = S["kv"]
-            attention_bwd_plain(S["qq"], kv[:, :d], kv[:, d:], dctx2, dqq, dkv[:, :d], dkv[:, d:], B, U, T2, H, lengths=key_len)
+            attention_bwd_plain(S["qq"], kv[:, :d], kv[:, d:], dctx2, dqq, dkv[:, :d], dkv[:, d:], B, U, T2, H, lengths=key_len,
+                                drop=(pa, seed, sid(32 + l, 2)) if pa > 0 else None, saved=S["p2"])
             da2 = T.linear_bwd(dqq, S["a2"], WT(p + "wq"), dw=G(p + "wq"), db=G(p + "bq"))
             T.linear_bwd(dkv, enc_bf, WT(p + "wkv"), dw=G(p + "wkv"), db=G(p + "bkv"), need_dx=False)
             ops.gemm(dkv, WT(p + "wkv")[:, :2 * d], out=denc, resid=denc, alpha=1.0)
             T.layernorm_bwd(S["x1"], P(p + "lnc_g"), da2, dx, accumulate=True, dgamma=G(p + "lnc_g"), dbeta=G(p + "lnc_b"), eps=eps)
             # causal self-attention
-            dyb = T.add_cast(dx)
+            dyb = dres(32 + l, 1)
             dctx1 = T.linear_bwd(dyb, S["ctx1"], WT(p + "wo"), dw=G(p + "wo"), db=G(p + "bo"))
             qkv = S["qkv"]
             dqkv = e16(M, 3 * d)
-            attention_bwd_plain(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], dctx1, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, U, U, H, causal=True)
+            attention_bwd_plain(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], dctx1, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, U, U, H, causal=True,
+                                drop=(pa, seed, sid(32 + l, 0)) if pa > 0 else None, saved=S["p1"])
             da1 = T.linear_bwd(dqkv, S["a1"], WT(p + "wqkv"), dw=G(p + "wqkv"), db=G(p + "bqkv"))
             T.layernorm_bwd(S["x"], P(p + "ln1_g"), da1, dx, accumulate=True, dgamma=G(p + "ln1_g"), dbeta=G(p + "ln1_b"), eps=eps)
         if 0 in tap_grads:
             T.axpy_(dx, tap_grads[0])
+        if pe > 0:
+            T.dropout_(dx, pe, seed, sid(63, 0))
         T.embed_tokens_bwd(ids, dx, G("wte"), None if self.pos_fixed is not None else G("wpe"), scale=self.emb_scale)
         if self.with_proj:
             dh = T.linear_bwd(T.add_cast(denc), hb, WT("proj_w"), dw=G("proj_w"), db=G("proj_b"), dx_dtype=F32)

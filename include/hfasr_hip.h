@@ -174,10 +174,16 @@ int mi_bgemm_bf16(const void* A, long a_z1, long a_z2, long a_m, long a_k, const
                   void* C, long c_z1, long c_z2, long c_m, int out_f32, int accumulate, float alpha, int Z1, int Z2, int M, int N,
                   int K, mi_stream_t stream);
 /* softmax stage of attention (e_branchformer.py:100-135, tf wav2vec2_conformer:528-565 relative shift), head-major (H,B,Tq,Tk) */
-int mi_attn_softmax_fwd(const float* ac, const float* bd, const int* lengths, void* prob, int H, int B, int Tq, int Tk, long ld_s,
-                        long ld_p, float scale, int causal, mi_stream_t stream);
+int mi_attn_softmax_fwd(const float* ac, const float* bd, const int* lengths, void* prob, void* prob_drop, int H, int B, int Tq, int Tk,
+                        long ld_s, long ld_p, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, mi_stream_t stream);
 int mi_attn_softmax_bwd(const void* prob, const float* dp, void* ds, void* dbd, int H, int B, int Tq, int Tk, long ld_s, long ld_p,
-                        float scale, mi_stream_t stream);
+                        float scale, float drop_p, unsigned seed, unsigned stream_id, mi_stream_t stream);
+/* dropout with counter-based masks (torch.nn.Dropout sites of e_branchformer.py:132,203,288,301,451, tf wav2vec2_conformer :353,356,674,
+ * GPT-2 embd/attn/resid): keep(idx) is a pure function of (seed, stream_id, logical element index) — see csrc/dropout.hip */
+int mi_dropout(const void* x, long ldx, int in_dtype, void* out, long ldo, int out_dtype, int M, int N, float alpha, float p, unsigned seed,
+               unsigned stream_id, mi_stream_t stream);
+int mi_dropout_add_f32(float* y, long ldy, const float* resid, long ldr, const float* t, long ldt, int M, int N, float alpha, float p,
+                       unsigned seed, unsigned stream_id, mi_stream_t stream);
 /* depthwise-conv / conv front-end gradients (e_branchformer.py:184-204,296-304; extractors.py:71-113) */
 int mi_csgu_bwd_bf16(const void* u, long ldu, const float* stats, const float* gamma, const float* beta, const float* w,
                      const float* bias, const void* ds, long ldds, void* dr, long lddr, void* dgn, long lddgn, float* dw,

@@ -42,7 +42,8 @@ def conv1d(x, w, b):          # transformers Conv1D: weight (in, out)
     return x @ w + b
 
 
-def mha(q, k, v, H, add_mask):
+def mha(q, k, v, H, add_mask, drop=None):
+    """drop(probs in the kernels' head-major (H,B,Tq,Tk) layout) -> dropped probs (GPT-2 attn_dropout, train mode)"""
     B, Tq, d = q.shape
     hd = d // H
     qh = q.view(B, Tq, H, hd).transpose(1, 2)
@@ -51,7 +52,10 @@ def mha(q, k, v, H, add_mask):
     s = qh @ kh.transpose(-1, -2) / math.sqrt(hd)
     if add_mask is not None:
         s = s + add_mask
-    return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Tq, d)
+    pr = torch.softmax(s, -1)
+    if drop is not None:
+        pr = drop(pr.transpose(0, 1)).transpose(0, 1)
+    return (pr @ vh).transpose(1, 2).reshape(B, Tq, d)
 
 
 def embed(sd, pre, cfg, ids, past=0):
@@ -68,12 +72,18 @@ def embed(sd, pre, cfg, ids, past=0):
     return tok + pe[None]
 
 
-def decoder_hidden_states(sd, pre, cfg, ids, enc, enc_mask, q: Callable = _id):
+def decoder_hidden_states(sd, pre, cfg, ids, enc, enc_mask, q: Callable = _id, dm=None):
     """GPT2Model.forward with cross-attention, no cache -> list of hidden states as HF returns them:
-    [embeddings, block_0 out, ..., block_{L-2} out, ln_f(block_{L-1} out)]."""
+    [embeddings, block_0 out, ..., block_{L-2} out, ln_f(block_{L-1} out)].
+    dm(x, layer, site): train-mode dropout hook; decoder layer l uses layer index 32 + l with sites 0 self-attn probs, 1 self-attn output,
+    2 cross-attn probs, 3 cross-attn output, 4 MLP output; the embedding dropout is (63, 0)."""
     d, H, L = cfg["n_embd"], cfg["n_head"], cfg["n_layer"]
     eps = cfg.get("layer_norm_epsilon", 1e-5)
     x = embed(sd, pre, cfg, ids)
+    if dm is not None:
+        x = dm(x, 63, 0)
+    dr = (lambda lay, site: (lambda t: dm(t, lay, site))) if dm is not None else (lambda lay, site: None)
+    dz = (lambda t, lay, site: dm(t, lay, site)) if dm is not None else (lambda t, lay, site: t)
     B, U, _ = x.shape
     fmin = torch.finfo(torch.float32).min
     causal = torch.ones(U, U, dtype=torch.bool).triu(1)
@@ -86,16 +96,16 @@ def decoder_hidden_states(sd, pre, cfg, ids, enc, enc_mask, q: Callable = _id):
         p = f"{pre}transformer.h.{l}."
         h = q(E.layer_norm(x, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], eps))
         qkv = q(conv1d(h, q(sd[p + "attn.c_attn.weight"]), sd[p + "attn.c_attn.bias"]))
-        a = q(mha(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, self_mask))
-        x = x + conv1d(a, q(sd[p + "attn.c_proj.weight"]), sd[p + "attn.c_proj.bias"])
+        a = q(mha(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, self_mask, dr(32 + l, 0)))
+        x = x + dz(conv1d(a, q(sd[p + "attn.c_proj.weight"]), sd[p + "attn.c_proj.bias"]), 32 + l, 1)
         h = q(E.layer_norm(x, sd[p + "ln_cross_attn.weight"], sd[p + "ln_cross_attn.bias"], eps))
         qq = q(conv1d(h, q(sd[p + "crossattention.q_attn.weight"]), sd[p + "crossattention.q_attn.bias"]))
         kv = q(conv1d(q(enc), q(sd[p + "crossattention.c_attn.weight"]), sd[p + "crossattention.c_attn.bias"]))
-        a = q(mha(qq, kv[..., :d], kv[..., d:], H, cross_mask))
-        x = x + conv1d(a, q(sd[p + "crossattention.c_proj.weight"]), sd[p + "crossattention.c_proj.bias"])
+        a = q(mha(qq, kv[..., :d], kv[..., d:], H, cross_mask, dr(32 + l, 2)))
+        x = x + dz(conv1d(a, q(sd[p + "crossattention.c_proj.weight"]), sd[p + "crossattention.c_proj.bias"]), 32 + l, 3)
         h = q(E.layer_norm(x, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], eps))
         m = q(gelu_new(conv1d(h, q(sd[p + "mlp.c_fc.weight"]), sd[p + "mlp.c_fc.bias"])))
-        x = x + conv1d(m, q(sd[p + "mlp.c_proj.weight"]), sd[p + "mlp.c_proj.bias"])
+        x = x + dz(conv1d(m, q(sd[p + "mlp.c_proj.weight"]), sd[p + "mlp.c_proj.bias"]), 32 + l, 4)
         if l + 1 < L:
             hs.append(x)
     hs.append(E.layer_norm(x, sd[pre + "transformer.ln_f.weight"], sd[pre + "transformer.ln_f.bias"], eps))
@@ -113,9 +123,9 @@ def smoothed_ce(logits: torch.Tensor, target: torch.Tensor, eps: float) -> torch
     return (per * valid).sum() / valid.sum()
 
 
-def decoder_forward(sd, pre, cfg, ids, enc, enc_mask, labels=None, q: Callable = _id):
+def decoder_forward(sd, pre, cfg, ids, enc, enc_mask, labels=None, q: Callable = _id, dm=None):
     """GPT2LMMultiHeadModel.forward (multi_head_gpt2.py:80-170) -> (loss|None, logits of the last head)."""
-    hs = decoder_hidden_states(sd, pre, cfg, ids, enc, enc_mask, q)
+    hs = decoder_hidden_states(sd, pre, cfg, ids, enc, enc_mask, q, dm)
     logits = F.linear(q(hs[-1]), q(sd[pre + "lm_head.weight"]))
     loss = None
     if labels is not None:
@@ -129,12 +139,12 @@ def decoder_forward(sd, pre, cfg, ids, enc, enc_mask, labels=None, q: Callable =
     return loss, logits
 
 
-def joint_forward(sd, enc_cfg, dec_cfg, jcfg, feats, attention_mask, labels, q: Optional[Callable] = None):
-    """JointCTCAttentionEncoderDecoder.forward in eval mode -> dict(loss, enc_loss, dec_loss, logits, encoder_logits)."""
+def joint_forward(sd, enc_cfg, dec_cfg, jcfg, feats, attention_mask, labels, q: Optional[Callable] = None, dm=None):
+    """JointCTCAttentionEncoderDecoder.forward (eval mode, or train mode with the dropout hook dm) -> dict(loss, enc_loss, dec_loss, logits, encoder_logits)."""
     qq = q or _id
     esd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
-    hidden = E.encoder_forward(esd, enc_cfg, feats, attention_mask, q)
-    enc_logits = E.ctc_head(esd, hidden, q)
+    hidden = E.encoder_forward(esd, enc_cfg, feats, attention_mask, q, dm=dm)
+    enc_logits = E.ctc_head(esd, hidden, q, dm, enc_cfg["num_hidden_layers"])
     am = attention_mask if attention_mask is not None else torch.ones(feats.shape[:2], dtype=torch.long)
     outer = E.conv_out_lengths_outer(am.sum(-1), enc_cfg).long()
     enc_loss = None
@@ -147,7 +157,7 @@ def joint_forward(sd, enc_cfg, dec_cfg, jcfg, feats, attention_mask, labels, q: 
         enc_h = F.linear(qq(hidden), qq(sd["enc_to_dec_proj.weight"]), sd["enc_to_dec_proj.bias"])
     enc_mask = (torch.arange(hidden.shape[1])[None, :] < outer[:, None]) if attention_mask is not None else None   # :296-301 (outer lengths)
     dec_ids = shift_tokens_right(labels, jcfg["pad_token_id"], jcfg["decoder_start_token_id"])   # :303-304
-    dec_loss, logits = decoder_forward(sd, "decoder.", dec_cfg, dec_ids, enc_h, enc_mask, labels, qq)
+    dec_loss, logits = decoder_forward(sd, "decoder.", dec_cfg, dec_ids, enc_h, enc_mask, labels, qq, dm)
     w = jcfg["ctc_weight"]
     loss = w * enc_loss + (1 - w) * dec_loss if labels is not None else None
     return dict(loss=loss, enc_loss=enc_loss, dec_loss=dec_loss, logits=logits, encoder_logits=enc_logits, encoder_hidden=enc_h)

@@ -120,8 +120,8 @@ def rel_attention_scores(qh, kh, pos_proj, u, v, q: Callable = _id):
     return (ac + bd) / math.sqrt(qh.shape[-1])
 
 
-def self_attention(sd, pre, cfg, x, add_mask, pos, q: Callable = _id):
-    """e_branchformer.py:74-141.  x: LN output (B,T,d)."""
+def self_attention(sd, pre, cfg, x, add_mask, pos, q: Callable = _id, dm=None, layer=None):
+    """e_branchformer.py:74-141.  x: LN output (B,T,d).  dm(x, layer, site): training-mode dropout hook (site 2 = probabilities, :132)."""
     b, t, d = x.shape
     H = cfg["num_attention_heads"]
     hd = d // H
@@ -146,6 +146,8 @@ def self_attention(sd, pre, cfg, x, add_mask, pos, q: Callable = _id):
         scores = scores + add_mask
     if q is _id:
         probs = torch.softmax(scores, dim=-1)
+        if dm is not None:                      # mask indexed over the head-major (H,B,T,T) layout of the kernels
+            probs = dm(probs.transpose(0, 1), layer, 2).transpose(0, 1)
         ctx = torch.matmul(probs, vh)
     else:  # precision model of the fused kernel: un-normalised p rounded for the PV product
         m = scores.max(dim=-1, keepdim=True).values
@@ -167,8 +169,8 @@ def dwconv1d(x, w, b, causal=False, dilation=1):
     return y.transpose(1, 2)
 
 
-def cgmlp(sd, pre, cfg, x, q: Callable = _id):
-    """e_branchformer.py:184-222.  x: LN output."""
+def cgmlp(sd, pre, cfg, x, q: Callable = _id, dm=None, layer=None):
+    """e_branchformer.py:184-222.  x: LN output.  dropout site 4 = after the gating (:203)."""
     h = q(F.gelu(F.linear(x, q(sd[pre + "channel_proj1.0.weight"]), sd[pre + "channel_proj1.0.bias"])))
     r, g = h.chunk(2, dim=-1)
     g = layer_norm(g, sd[pre + "csgu.norm.weight"], sd[pre + "csgu.norm.bias"])
@@ -182,38 +184,48 @@ def cgmlp(sd, pre, cfg, x, q: Callable = _id):
     if act != "identity":
         g = {"gelu": F.gelu, "relu": F.relu, "silu": F.silu, "swish": F.silu}[act](g)
     s = q(r * g)
+    if dm is not None:
+        s = dm(s, layer, 4)
     return F.linear(s, q(sd[pre + "channel_proj2.weight"]), sd[pre + "channel_proj2.bias"])
 
 
-def ffn(sd, pre, x, q: Callable = _id):
-    """tf:350-357 (hidden_act gelu)."""
+def ffn(sd, pre, x, q: Callable = _id, dm=None, layer=None, sites=(0, 1)):
+    """tf:350-357 (hidden_act gelu); dropout after the activation (:353) and after the output projection (:356)."""
     h = q(F.gelu(F.linear(x, q(sd[pre + "intermediate_dense.weight"]), sd[pre + "intermediate_dense.bias"])))
-    return F.linear(h, q(sd[pre + "output_dense.weight"]), sd[pre + "output_dense.bias"])
+    if dm is not None:
+        h = dm(h, layer, sites[0])
+    y = F.linear(h, q(sd[pre + "output_dense.weight"]), sd[pre + "output_dense.bias"])
+    return dm(y, layer, sites[1]) if dm is not None else y
 
 
-def encoder_layer(sd, i, cfg, x, add_mask, pos, q: Callable = _id):
-    """e_branchformer.py:263-313."""
+def encoder_layer(sd, i, cfg, x, add_mask, pos, q: Callable = _id, dm=None):
+    """e_branchformer.py:263-313.  dm: training-mode dropout hook; sites 0/1 ff1, 2 attention probabilities, 3 attention output (:288),
+    4 CSGU, 5 merge output (:301), 6/7 ff2."""
     pre = f"wav2vec2.encoder.layers.{i}."
     eps = 1e-5  # nn.LayerNorm default (layers use nn.LayerNorm(embed_dim), e_branchformer.py:233-261)
     if cfg.get("use_macaron_ff", True):
-        x = x + 0.5 * ffn(sd, pre + "ff1.1.", q(layer_norm(x, sd[pre + "ff1.0.weight"], sd[pre + "ff1.0.bias"], eps)), q)
+        x = x + 0.5 * ffn(sd, pre + "ff1.1.", q(layer_norm(x, sd[pre + "ff1.0.weight"], sd[pre + "ff1.0.bias"], eps)), q, dm, i, (0, 1))
     res = x
     g = self_attention(sd, pre + "self_attn.", cfg,
                        q(layer_norm(x, sd[pre + "self_attn_layer_norm.weight"], sd[pre + "self_attn_layer_norm.bias"], eps)),
-                       add_mask, pos, q)
+                       add_mask, pos, q, dm, i)
+    if dm is not None:
+        g = dm(g, i, 3)
     l = cgmlp(sd, pre + "cgMLP.", cfg,
-              q(layer_norm(x, sd[pre + "cgMLP_layer_norm.weight"], sd[pre + "cgMLP_layer_norm.bias"], eps)), q)
+              q(layer_norm(x, sd[pre + "cgMLP_layer_norm.weight"], sd[pre + "cgMLP_layer_norm.bias"], eps)), q, dm, i)
     m = q(torch.cat([g, l], dim=-1))
     m = q(m + dwconv1d(m, sd[pre + "depthwise_conv_fusion.weight"], sd[pre + "depthwise_conv_fusion.bias"]))
-    x = res + F.linear(m, q(sd[pre + "merge_proj.weight"]), sd[pre + "merge_proj.bias"])
+    mo = F.linear(m, q(sd[pre + "merge_proj.weight"]), sd[pre + "merge_proj.bias"])
+    x = res + (dm(mo, i, 5) if dm is not None else mo)
     if cfg.get("use_macaron_ff", True):
-        x = x + 0.5 * ffn(sd, pre + "ff2.1.", q(layer_norm(x, sd[pre + "ff2.0.weight"], sd[pre + "ff2.0.bias"], eps)), q)
+        x = x + 0.5 * ffn(sd, pre + "ff2.1.", q(layer_norm(x, sd[pre + "ff2.0.weight"], sd[pre + "ff2.0.bias"], eps)), q, dm, i, (6, 7))
     return layer_norm(x, sd[pre + "final_layer_norm.weight"], sd[pre + "final_layer_norm.bias"], eps)
 
 
 def encoder_forward(sd: dict, cfg: dict, feats: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-                    q: Optional[Callable] = None, return_layers: bool = False):
-    """Wav2Vec2EBranchformerModel.forward in eval mode (tf:1133-1195, tf:651-717) -> last hidden state (B,T',d)."""
+                    q: Optional[Callable] = None, return_layers: bool = False, dm=None):
+    """Wav2Vec2EBranchformerModel.forward (tf:1133-1195, tf:651-717) -> last hidden state (B,T',d).  Eval mode, or train mode with the
+    dropout hook dm(x, layer, site) (global sites use layer = num_hidden_layers: 0 feature projection, 1 encoder input tf:674)."""
     q = q or _id
     eps = cfg.get("layer_norm_eps", 1e-5)
     h = conv_subsample(sd, cfg, feats, q)
@@ -222,6 +234,9 @@ def encoder_forward(sd: dict, cfg: dict, feats: torch.Tensor, attention_mask: Op
     p = "wav2vec2.feature_projection."
     h = q(layer_norm(h, sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"], eps))
     x = F.linear(h, q(sd[p + "projection.weight"]), sd[p + "projection.bias"])
+    nl = cfg["num_hidden_layers"]
+    if dm is not None:
+        x = dm(x, nl, 0)
     add_mask = None
     if mask is not None:
         x = x * mask[..., None]                                  # tf:662-665 zero padded frames once
@@ -230,18 +245,22 @@ def encoder_forward(sd: dict, cfg: dict, feats: torch.Tensor, attention_mask: Op
     d, H = cfg["hidden_size"], cfg["num_attention_heads"]
     ptype = cfg.get("position_embeddings_type", "relative")
     pos = rel_pos_table(t, d) if ptype == "relative" else (rotary_table(t, d // H, cfg.get("rotary_embedding_base", 10000)) if ptype == "rotary" else None)
+    if dm is not None:
+        x = dm(x, nl, 1)
     layers = []
     for i in range(cfg["num_hidden_layers"]):
-        x = encoder_layer(sd, i, cfg, x, add_mask, pos, q)
+        x = encoder_layer(sd, i, cfg, x, add_mask, pos, q, dm)
         if return_layers:
             layers.append(x)
     x = layer_norm(x, sd["wav2vec2.encoder.layer_norm.weight"], sd["wav2vec2.encoder.layer_norm.bias"], eps)
     return (x, layers) if return_layers else x
 
 
-def ctc_head(sd: dict, hidden: torch.Tensor, q: Optional[Callable] = None) -> torch.Tensor:
-    """e_branchformer.py:456-457 — lm_head ⊕ blank_projection, blank is the LAST class."""
+def ctc_head(sd: dict, hidden: torch.Tensor, q: Optional[Callable] = None, dm=None, nl=None) -> torch.Tensor:
+    """e_branchformer.py:451-457 — dropout (train mode; global site 2), lm_head ⊕ blank_projection, blank is the LAST class."""
     q = q or _id
+    if dm is not None:
+        hidden = dm(hidden, nl, 2)
     w = torch.cat([sd["lm_head.weight"], sd["blank_projection.weight"]], 0)
     b = torch.cat([sd["lm_head.bias"], sd["blank_projection.bias"]], 0)
     return F.linear(q(hidden), q(w), b)

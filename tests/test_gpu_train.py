@@ -209,3 +209,97 @@ def test_hf_joint_model_trains_through_autograd_bridge():
     grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
     assert set(ref) <= set(grads)
     _compare(grads, ref)
+
+
+# ---------------------------------------------------------------------------------------------------------------- dropout
+def _dm(seed, step, pmap):
+    """the kernels' counter-based dropout masks (csrc/dropout.hip), regenerated on the host for the oracle"""
+    from huggingface_asr_amd import synth
+
+    def dm(x, layer, site):
+        p = pmap(layer, site)
+        if p == 0.0:
+            return x
+        sid = ((step * 64 + layer) * 16 + site) & 0xFFFFFFFF
+        keep = synth.dropout_keep(seed, sid, x.numel(), p).reshape(tuple(x.shape))
+        return x * (torch.from_numpy(keep).float() / (1.0 - p))
+    return dm
+
+
+DROP = dict(activation_dropout=0.1, hidden_dropout=0.15, attention_dropout=0.1, csgu_conv_dropout=0.2, final_dropout=0.1, feat_proj_dropout=0.05)
+
+
+def _enc_pmap(L):
+    def pmap(layer, site):
+        if layer == L:
+            return {0: DROP["feat_proj_dropout"], 1: DROP["hidden_dropout"], 2: DROP["final_dropout"]}[site]
+        if layer < L:
+            return {0: DROP["activation_dropout"], 6: DROP["activation_dropout"], 1: DROP["hidden_dropout"], 7: DROP["hidden_dropout"],
+                    2: DROP["attention_dropout"], 3: DROP["attention_dropout"], 5: DROP["attention_dropout"], 4: DROP["csgu_conv_dropout"]}[site]
+        if layer == 63:
+            return 0.1                                    # embd_pdrop
+        return {0: 0.1, 2: 0.1, 1: 0.2, 3: 0.2, 4: 0.2}[site]   # decoder: attn_pdrop 0.1, resid_pdrop 0.2
+    return pmap
+
+
+@pytest.mark.parametrize("pos", ["relative", "rotary"])
+def test_dropout_training_step_matches_oracle_with_identical_masks(pos):
+    """All eleven dropout sites of the encoder + CTC head on (p = 0.05 .. 0.2): loss and every gradient vs torch autograd of the oracle
+    run with the SAME masks; a second step draws different masks; eval-mode forward is unaffected."""
+    from helpers import seeded_state_dict, synth_feats, synth_labels
+    cfg = dict(shapes.TINY, position_embeddings_type=pos, ctc_zero_infinity=True, ctc_loss_reduction="mean")
+    sd = seeded_state_dict(cfg, 41)
+    x, am = synth_feats(41, 2, 200, [200, 163])
+    lab = synth_labels(41, 2, 6, 50, [6, 4])
+    from huggingface_asr_amd.train import EncoderCTCTrainer
+    tr = EncoderCTCTrainer(dict(cfg, layerdrop=0.0, apply_spec_augment=False, **DROP), DEV, seed=1234)
+    tr.load_state_dict(sd)
+    L = cfg["num_hidden_layers"]
+
+    def oracle(step):
+        dm = _dm(1234, step, _enc_pmap(L))
+        sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        hidden = R.encoder_forward(sdr, cfg, x, am, dm=dm)
+        logits = R.ctc_head(sdr, hidden, None, dm, L)
+        in_len = R.conv_out_lengths_outer(am.sum(-1), cfg).long()
+        loss = F.ctc_loss(torch.log_softmax(logits, -1).transpose(0, 1), lab[lab >= 0], in_len, (lab >= 0).sum(-1), blank=logits.shape[-1] - 1,
+                          reduction="mean", zero_infinity=True)
+        loss.backward()
+        return float(loss.detach()), {k: v.grad for k, v in sdr.items() if v.grad is not None}
+
+    losses = []
+    for step in range(2):
+        want_loss, ref = oracle(step)
+        tr.store.zero_grad()
+        out = tr.forward_backward(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV))
+        assert abs(float(out["loss"]) - want_loss) <= 2e-3 * want_loss, (step, float(out["loss"]), want_loss)
+        _compare(tr.grad_dict(), ref, rel=0.04)
+        losses.append(want_loss)
+    assert abs(losses[0] - losses[1]) > 1e-3               # the step index feeds the mask streams
+    ev = tr.forward_backward(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV), backward=False)
+    with torch.no_grad():
+        want_eval, _ = R.ctc_forward(sd, cfg, x, am, lab)
+    assert abs(float(ev["loss"]) - float(want_eval)) <= 2e-3 * float(want_eval)
+
+
+def test_dropout_joint_training_step_matches_oracle_with_identical_masks():
+    from helpers import AED_JCFG, TINY_DEC, aed_case_inputs
+    from huggingface_asr_amd.train_aed import JointAEDTrainer
+    from oracle import aed_ref as A
+    g = load_golden("grads_aed_tiny")
+    sd, x, am, lab = aed_case_inputs(g)
+    enc_cfg = dict(shapes.TINY, ctc_zero_infinity=True, ctc_loss_reduction="mean")
+    dec_cfg = dict(TINY_DEC, pos_emb_fixed=False, tie_word_embeddings=False)
+    tr = JointAEDTrainer(dict(enc_cfg, layerdrop=0.0, apply_spec_augment=False, **DROP), dict(dec_cfg, embd_pdrop=0.1, attn_pdrop=0.1, resid_pdrop=0.2),
+                         AED_JCFG, DEV, seed=77)
+    tr.load_state_dict(sd)
+    dm = _dm(77, 0, _enc_pmap(enc_cfg["num_hidden_layers"]))
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    o = A.joint_forward(sdr, enc_cfg, dec_cfg, AED_JCFG, x, am, lab, dm=dm)
+    o["loss"].backward()
+    ref = {k: v.grad for k, v in sdr.items() if v.grad is not None}
+    tr.enc.store.zero_grad(); tr.store.zero_grad()
+    out = tr.forward_backward(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV))
+    for key in ("loss", "enc_loss", "dec_loss"):
+        assert abs(float(out[key]) - float(o[key].detach())) <= 3e-3 * abs(float(o[key].detach())), (key, float(out[key]), float(o[key].detach()))
+    _compare(tr.grad_dict(), ref, rel=0.04)
