@@ -285,6 +285,39 @@ __global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, l
     }
 }
 
+// in-model SpecAugment (tf wav2vec2_conformer `_mask_hidden_states` :1086-1130): rows with time_mask != 0 are REPLACED by the learned
+// masked_spec_embed vector, then columns with feat_mask[b][c] != 0 are zeroed.  Backward: masked rows send their gradient to the embed
+// vector (column sums, atomics at block granularity) and nothing upstream; masked columns send nothing.
+__global__ __launch_bounds__(256) void spec_mask_apply_kernel(float* __restrict__ x, long ld, const unsigned char* __restrict__ tmask,
+                                                               const float* __restrict__ embed, const unsigned char* __restrict__ fmask, int T, int M, int N) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / N), c = (int)(i % N);
+        float v = x[(long)m * ld + c];
+        if (tmask && tmask[m]) v = embed[c];
+        if (fmask && fmask[(long)(m / T) * N + c]) v = 0.f;
+        x[(long)m * ld + c] = v;
+    }
+}
+__global__ __launch_bounds__(256) void spec_mask_bwd_kernel(float* __restrict__ dx, long ld, const unsigned char* __restrict__ tmask, float* __restrict__ dembed,
+                                                             const unsigned char* __restrict__ fmask, int T, int M, int N, int rows_per_block) {
+    __shared__ float part[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    float s = 0.f;
+    if (c < N)
+        for (int m = m0 + ty; m < m1; m += 4) {
+            float g = dx[(long)m * ld + c];
+            if (fmask && fmask[(long)(m / T) * N + c]) g = 0.f;          // zeroed AFTER the replacement in the forward
+            if (tmask && tmask[m]) { s += g; g = 0.f; }
+            dx[(long)m * ld + c] = g;
+        }
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < N && tmask) atomic_add_f32(dembed + c, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+}
+
 // ------------------------------------------------------------------------------------------------ optimizer
 // deterministic sum of squares (every data-parallel rank must derive the SAME clip coefficient from the same reduced gradient, or the
 // replicas drift): fixed grid of per-block partials, then one block adds them in a fixed order.  No float atomics.
@@ -458,6 +491,24 @@ extern "C" int mi_mask_rows_f32(float* x, long ld, const int* lengths, int T, in
     MI_ENTER();
     if (M <= 0 || N <= 0 || T <= 0 || !lengths) return MI_ERR_ARG;
     hipLaunchKernelGGL(mask_rows_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, st, x, ld, lengths, T, M, N);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+extern "C" int mi_spec_mask_apply(float* x, long ld, const unsigned char* time_mask, const float* embed, const unsigned char* feat_mask, int T, int M, int N,
+                                  hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || N <= 0 || T <= 0 || (time_mask && !embed)) return MI_ERR_ARG;
+    hipLaunchKernelGGL(spec_mask_apply_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, st, x, ld, time_mask, embed, feat_mask, T, M, N);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+extern "C" int mi_spec_mask_bwd(float* dx, long ld, const unsigned char* time_mask, float* dembed, const unsigned char* feat_mask, int T, int M, int N,
+                                hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || N <= 0 || T <= 0 || (time_mask && !dembed)) return MI_ERR_ARG;
+    const int rpb = 128;
+    hipLaunchKernelGGL(spec_mask_bwd_kernel, dim3(cdiv(N, 64), cdiv(M, rpb)), dim3(256), 0, st, dx, ld, time_mask, dembed, feat_mask, T, M, N, rpb);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

@@ -24,6 +24,12 @@ from .configuration_ebranchformer import Wav2Vec2EBranchformerConfig
 from .engine import EBranchformerEngine, cfg_from_hf
 
 
+def _dropout_seed() -> int:
+    """dropout-mask seed of the HIP training step: torch's seed (set by HF Trainer's set_seed) offset by the data-parallel rank"""
+    rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+    return (torch.initial_seed() + 7919 * rank) & 0xFFFFFFFF
+
+
 class _Holder(nn.Module):
     """parameter container; calling it is a bug"""
 
@@ -205,7 +211,7 @@ class Wav2Vec2EBranchformerForCTC(PreTrainedModel):
     def _get_trainer(self, device):
         from .train import EncoderCTCTrainer
         if getattr(self, "_trainer", None) is None or self._trainer.device != torch.device(device):
-            self._trainer = EncoderCTCTrainer(cfg_from_hf(self.config), device, dp_sync=False)      # optimizer / all-reduce stay with the caller (HF Trainer)
+            self._trainer = EncoderCTCTrainer(cfg_from_hf(self.config), device, dp_sync=False, seed=_dropout_seed())      # optimizer / all-reduce stay with the caller (HF Trainer)
         return self._trainer
 
     def _training_forward(self, input_values, attention_mask, labels, output_hidden_states, return_dict):

@@ -20,7 +20,7 @@ from transformers.models.speech_encoder_decoder.configuration_speech_encoder_dec
 from .configuration_ebranchformer import Wav2Vec2EBranchformerConfig
 from .decoder import JointAEDEngine, generate as _generate
 from .engine import cfg_from_hf
-from .modeling_ebranchformer import Wav2Vec2EBranchformerForCTC, _Holder
+from .modeling_ebranchformer import _dropout_seed, Wav2Vec2EBranchformerForCTC, _Holder
 
 
 class GPT2MultiHeadConfig(GPT2Config):
@@ -197,7 +197,7 @@ class JointCTCAttentionEncoderDecoder(PreTrainedModel):
             dc = dict(_dec_cfg_dict(self.config.decoder), tie_word_embeddings=False,
                       resid_pdrop=getattr(self.config.decoder, "resid_pdrop", 0.0), embd_pdrop=getattr(self.config.decoder, "embd_pdrop", 0.0),
                       attn_pdrop=getattr(self.config.decoder, "attn_pdrop", 0.0))
-            self._trainer = JointAEDTrainer(cfg_from_hf(self.config.encoder), dc, jc, device, with_proj=hasattr(self, "enc_to_dec_proj"), dp_sync=False)
+            self._trainer = JointAEDTrainer(cfg_from_hf(self.config.encoder), dc, jc, device, with_proj=hasattr(self, "enc_to_dec_proj"), dp_sync=False, seed=_dropout_seed())
         return self._trainer
 
     @staticmethod

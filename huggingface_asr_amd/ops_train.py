@@ -114,6 +114,16 @@ def mask_rows_(x, lengths, T):
     _lib.check(_L().mi_mask_rows_f32(x.data_ptr(), x.stride(0), lengths.data_ptr(), T, M, N, _stream()), "mi_mask_rows_f32")
 
 
+def spec_mask_apply_(x, time_mask, embed, feat_mask, T):
+    M, N = x.shape
+    _lib.check(_L().mi_spec_mask_apply(x.data_ptr(), x.stride(0), _p(time_mask), _p(embed), _p(feat_mask), T, M, N, _stream()), "mi_spec_mask_apply")
+
+
+def spec_mask_bwd_(dx, time_mask, dembed, feat_mask, T):
+    M, N = dx.shape
+    _lib.check(_L().mi_spec_mask_bwd(dx.data_ptr(), dx.stride(0), _p(time_mask), _p(dembed), _p(feat_mask), T, M, N, _stream()), "mi_spec_mask_bwd")
+
+
 def bgemm(A, a_str, B, b_str, C, c_str, Z1, Z2, M, N, K, *, alpha=1.0, accumulate=False):
     """C[z1,z2][m][n] = alpha * sum_k A[..][m][k] B[..][n][k] (+C). a_str = (z1, z2, m, k) element strides, b_str = (z1, z2, n, k),
     c_str = (z1, z2, m); A/B bf16 storage, C f32|bf16 with unit column stride."""

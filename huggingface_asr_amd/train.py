@@ -16,7 +16,8 @@ recipes/librispeech/.../train_small_baseline.sh:43,53-58: bf16 autocast, AdamW, 
 Precision model = the reference's autocast recipe: fp32 master weights and residual stream, bf16 GEMM operands (activations AND
 activation gradients), fp32 accumulation, fp32 LayerNorm / softmax / CTC, fp32 parameter gradients.
 Dropout (all eight sites of the layer, encoder input, feature projection, CTC head) uses counter-based masks that the backward
-pass regenerates.  Not yet on this path (raise NotImplementedError): in-model SpecAugment, LayerDrop, causal encoders.
+pass regenerates; in-model SpecAugment draws its masks on the host with transformers' own `_compute_mask_indices` (numpy RNG), exactly as the
+reference does.  Not on this path (raise NotImplementedError): LayerDrop (the recipes force it to 0), causal encoders.
 """
 from __future__ import annotations
 
@@ -262,8 +263,8 @@ class EncoderCTCTrainer:
                           final=g("final_dropout"), fp=g("feat_proj_dropout"))
         self.seed = int(seed) & 0xFFFFFFFF
         self.train_steps_seen = 0
-        if c.get("apply_spec_augment", False) and float(c.get("mask_time_prob", 0.0) or 0.0) > 0.0:
-            raise NotImplementedError("training path: in-model SpecAugment is not supported yet (apply_spec_augment=False)")
+        self.specaug = bool(c.get("apply_spec_augment", False)) and (float(c.get("mask_time_prob", 0.0) or 0.0) > 0.0 or
+                                                                     float(c.get("mask_feature_prob", 0.0) or 0.0) > 0.0)
         self.device = torch.device(device)
         self.store = ParamStore(encoder_specs(c), self.device)
         self.map = _enc_map(c)
@@ -384,6 +385,10 @@ class EncoderCTCTrainer:
         x = ops.gemm(a_fp, W("fp_w"), P("fp_b"), out_dtype=F32)
         if pd["fp"] > 0:
             T.dropout_(x, pd["fp"], seed, self._sid(L, 0))
+        tmask = fmask = None
+        if self.specaug and (backward or train_mode):
+            tmask, fmask = self._spec_masks(B, T2, d, inner)
+            T.spec_mask_apply_(x, tmask, P("masked_spec_embed"), fmask, T2)
         if inner is not None:
             T.mask_rows_(x, inner, T2)
         if pd["hidden"] > 0:
@@ -521,6 +526,8 @@ class EncoderCTCTrainer:
             T.dropout_(dx, pd["hidden"], seed, self._sid(L, 1))
         if inner is not None:
             T.mask_rows_(dx, inner, T2)
+        if tmask is not None or fmask is not None:
+            T.spec_mask_bwd_(dx, tmask, G("masked_spec_embed"), fmask, T2)
         dyb = T.dropout_(dx, pd["fp"], seed, self._sid(L, 0), out=e16(M, d)) if pd["fp"] > 0 else T.add_cast(dx)
         da = T.linear_bwd(dyb, a_fp, WT("fp_w"), dw=G("fp_w"), db=G("fp_b"))
         dfeo = e32(M, d)
@@ -540,6 +547,26 @@ class EncoderCTCTrainer:
     def _sid(self, layer: int, site: int) -> int:
         """dropout stream id of (this step, layer, site); layer = num_hidden_layers for the global sites (0 feat-proj, 1 encoder input, 2 head)"""
         return ((self._step_idx * 64 + layer) * 16 + site) & 0xFFFFFFFF
+
+    def _spec_masks(self, B, T2, d, inner):
+        """SpecAugment masks of tf `_mask_hidden_states` (:1086-1130), drawn on the host by transformers' own helper with numpy's global RNG
+        (so a run seeded like the reference's draws the reference's masks).  -> (time mask (B*T2) u8 | None, feature mask (B, d) u8 | None)"""
+        import numpy as np
+        from transformers.models.wav2vec2.modeling_wav2vec2 import _compute_mask_indices
+        c = self.cfg
+        tm = fm = None
+        if float(c.get("mask_time_prob", 0.0) or 0.0) > 0:
+            am = None
+            if inner is not None:
+                am = torch.arange(T2)[None, :] < inner.cpu()[:, None].long()
+            m = _compute_mask_indices((B, T2), mask_prob=c["mask_time_prob"], mask_length=c.get("mask_time_length", 10), attention_mask=am,
+                                      min_masks=c.get("mask_time_min_masks", 2))
+            tm = torch.from_numpy(np.ascontiguousarray(m).astype(np.uint8)).reshape(-1).to(self.device)
+        if float(c.get("mask_feature_prob", 0.0) or 0.0) > 0:
+            m = _compute_mask_indices((B, d), mask_prob=c["mask_feature_prob"], mask_length=c.get("mask_feature_length", 10),
+                                      min_masks=c.get("mask_feature_min_masks", 0))
+            fm = torch.from_numpy(np.ascontiguousarray(m).astype(np.uint8)).to(self.device)
+        return tm, fm
 
     def _outer_len(self, n):
         k, s = self.cfg["conv_kernel"][0], self.cfg["conv_stride"][0]

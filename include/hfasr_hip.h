@@ -160,6 +160,11 @@ int mi_add_rowvec_bf16(const void* x, long ldx, const float* vec, void* out, lon
 int mi_gate_bwd_bf16(const void* ds, long ldds, const void* c, long ldc, const void* r, long ldr, void* dr, long lddr,
                      void* dc, long lddc, int M, int N, mi_stream_t stream);
 int mi_mask_rows_f32(float* x, long ld, const int* lengths, int T, int M, int N, mi_stream_t stream);
+/* in-model SpecAugment of the encoder input (tf wav2vec2_conformer _mask_hidden_states :1086-1130): time_mask (M) / feat_mask (B, N) bytes */
+int mi_spec_mask_apply(float* x, long ld, const unsigned char* time_mask, const float* embed, const unsigned char* feat_mask, int T, int M, int N,
+                       mi_stream_t stream);
+int mi_spec_mask_bwd(float* dx, long ld, const unsigned char* time_mask, float* dembed, const unsigned char* feat_mask, int T, int M, int N,
+                     mi_stream_t stream);
 int mi_sumsq_f32(const float* x, long n, float* sumsq, float* workspace /* 1024 floats */, mi_stream_t stream);
 int mi_clip_coef(const float* sumsq, float max_norm, float* norm_coef, mi_stream_t stream);
 int mi_adamw_step(float* p, const float* g, float* m, float* v, const unsigned char* decay, long n, float lr, float beta1,

@@ -112,22 +112,28 @@ NO_DROPOUT = dict(hidden_dropout=0.0, activation_dropout=0.0, attention_dropout=
                   ebranchformer_conv_dropout=0.0, apply_spec_augment=False)
 
 
-def run_grad_case(name, cfg_kwargs, seed, B, T, lengths, U, tgt_lens, **extra):
-    """training-mode forward + backward of the reference model (dropouts 0, no SpecAugment): loss and every parameter gradient."""
-    cfg, model = build_reference(cfg_kwargs, **NO_DROPOUT, **extra)
+def run_grad_case(name, cfg_kwargs, seed, B, T, lengths, U, tgt_lens, np_seed=None, **extra):
+    """training-mode forward + backward of the reference model (dropouts 0; SpecAugment only when `extra` turns it on, its numpy RNG seeded
+    with np_seed right before the forward): loss and every parameter gradient."""
+    cfg, model = build_reference(cfg_kwargs, **{**NO_DROPOUT, **extra})
     model.train()
     wsum = load_seeded(model, seed)
     x, am = synth_feats(seed, B, T, lengths)
     lab = synth_labels(seed, B, U, cfg.vocab_size, tgt_lens)
+    if np_seed is not None:
+        np.random.seed(np_seed)
     out = model(torch.from_numpy(x), attention_mask=torch.from_numpy(am), labels=torch.from_numpy(lab))
     out.loss.backward()
-    rec = dict(seed=seed, weight_sum=wsum, lengths=np.array(lengths), tgt_lens=np.array(tgt_lens), shape=np.array([B, T, U]), loss=float(out.loss))
+    rec = dict(seed=seed, weight_sum=wsum, lengths=np.array(lengths), tgt_lens=np.array(tgt_lens), shape=np.array([B, T, U]), loss=float(out.loss),
+               np_seed=-1 if np_seed is None else np_seed)
     assert cfg.csgu_conv_dropout == 0.0
     g32 = {k: v.grad.float().clone() for k, v in model.named_parameters() if v.grad is not None}
     for k, v in g32.items():
         rec["grad:" + k] = v.numpy()
     # the reference's own bf16-autocast backward vs its fp32 backward: the yard-stick for the HIP path's bf16 gradients
     model.zero_grad()
+    if np_seed is not None:
+        np.random.seed(np_seed)
     with torch.autocast("cpu", dtype=torch.bfloat16):
         ob = model(torch.from_numpy(x), attention_mask=torch.from_numpy(am), labels=torch.from_numpy(lab))
     ob.loss.float().backward()
@@ -395,6 +401,8 @@ if __name__ == "__main__":
     if "grads" in which:
         run_grad_case("grads_tiny_rel", TINY, seed=11, B=2, T=200, lengths=[198, 150], U=7, tgt_lens=[7, 5])
         run_grad_case("grads_tiny_rotary", TINY, seed=12, B=2, T=200, lengths=[200, 131], U=6, tgt_lens=[6, 4], position_embeddings_type="rotary")
+        run_grad_case("grads_tiny_specaug", TINY, seed=16, B=2, T=200, lengths=[200, 140], U=5, tgt_lens=[5, 3], np_seed=5, apply_spec_augment=True,
+                      mask_time_prob=0.3, mask_time_length=4, mask_time_min_masks=2, mask_feature_prob=0.2, mask_feature_length=3, mask_feature_min_masks=1)
         # (use_macaron_ff=False is not runnable in the reference: its layer forward reads self.ff1 unconditionally, e_branchformer.py:271)
     if "base" in which:
         run_encoder_case("small_rel", SMALL, seed=21, B=2, T=1000, lengths=[998, 700], U=40, tgt_lens=[40, 31], full=False)

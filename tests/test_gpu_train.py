@@ -303,3 +303,26 @@ def test_dropout_joint_training_step_matches_oracle_with_identical_masks():
     for key in ("loss", "enc_loss", "dec_loss"):
         assert abs(float(out[key]) - float(o[key].detach())) <= 3e-3 * abs(float(o[key].detach())), (key, float(out[key]), float(o[key].detach()))
     _compare(tr.grad_dict(), ref, rel=0.04)
+
+
+def test_in_model_specaugment_matches_reference_golden():
+    """apply_spec_augment with time AND feature masks: the trainer draws its masks with transformers' `_compute_mask_indices` from numpy's global
+    RNG like the reference does, so seeding numpy identically reproduces the reference's masks -> loss and all gradients (incl. masked_spec_embed)."""
+    g = load_golden("grads_tiny_specaug")
+    sa = dict(apply_spec_augment=True, mask_time_prob=0.3, mask_time_length=4, mask_time_min_masks=2, mask_feature_prob=0.2, mask_feature_length=3,
+              mask_feature_min_masks=1)
+    cfg = dict(shapes.TINY, ctc_zero_infinity=True, ctc_loss_reduction="mean")
+    sd, x, am, lab = case_inputs(g, cfg)
+    from huggingface_asr_amd.train import EncoderCTCTrainer
+    tr = EncoderCTCTrainer(dict(cfg, **{**NO_DROPOUT, **sa}), DEV)
+    tr.load_state_dict(sd)
+    tr.store.zero_grad()
+    np.random.seed(int(g["np_seed"]))
+    out = tr.forward_backward(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV))
+    assert abs(float(out["loss"]) - float(g["loss"])) <= 1e-3 * float(g["loss"]) + 1e-3, (float(out["loss"]), float(g["loss"]))
+    ref = {k[5:]: g[k] for k in g.files if k.startswith("grad:")}
+    assert "wav2vec2.masked_spec_embed" in ref
+    _compare(tr.grad_dict(), ref)
+    # without the masks the loss differs: the fixture really exercises SpecAugment
+    base = load_golden("grads_tiny_rel")
+    assert abs(float(g["loss"]) - float(base["loss"])) > 1.0
