@@ -209,20 +209,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
     }
 }
 
-// dgamma[c] += sum_blk partial[blk][c],  dbeta[c] += sum_blk partial[blk][d + c]
+// dgamma[c] += sum_blk partial[blk][c],  dbeta[c] += sum_blk partial[blk][d + c];  grid (2d/64, row chunks): each block sums 64 partial rows
 __global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __restrict__ partial, int nblk, int d, float* __restrict__ dgamma,
                                                                  float* __restrict__ dbeta) {
     __shared__ float red[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
+    const int b0 = blockIdx.y * 64, b1 = min(nblk, b0 + 64);
     float s = 0.f;
     if (c < 2 * d)
-        for (int b = ty; b < nblk; b += 4) s += partial[(long)b * 2 * d + c];
+        for (int b = b0 + ty; b < b1; b += 4) s += partial[(long)b * 2 * d + c];
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && c < 2 * d) {
         const float t = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
-        if (c < d) dgamma[c] += t; else dbeta[c - d] += t;
+        atomic_add_f32(c < d ? dgamma + c : dbeta + (c - d), t);
     }
 }
 
@@ -435,7 +436,7 @@ extern "C" int mi_layernorm_bwd(const void* x, long ldx, int x_bf16, const float
 #undef LN_BWD
     MI_CHECK_LAUNCH();
     if (dgamma) {
-        hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(cdiv(2 * d, 64)), dim3(256), 0, st, partial, grid, d, dgamma, dbeta);
+        hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(cdiv(2 * d, 64), cdiv(grid, 64)), dim3(256), 0, st, partial, grid, d, dgamma, dbeta);
         MI_CHECK_LAUNCH();
     }
     return MI_OK;
