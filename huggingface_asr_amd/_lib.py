@@ -115,6 +115,7 @@ def lib():
         h.mi_profile_reset.argtypes = []; h.mi_profile_reset.restype = None
         h.mi_profile_count.argtypes = []; h.mi_profile_count.restype = i32
         h.mi_profile_summary.argtypes = [C.POINTER(f64), C.POINTER(f64)]; h.mi_profile_summary.restype = i32
+        h.mi_profile_calibrate.argtypes = [vp, i32, C.POINTER(f64)]; h.mi_profile_calibrate.restype = i32
         h.mi_gemm_set_stages.argtypes = [i32]; h.mi_gemm_set_stages.restype = None
         if os.environ.get("HFASR_GEMM_STAGES"):
             h.mi_gemm_set_stages(int(os.environ["HFASR_GEMM_STAGES"]))

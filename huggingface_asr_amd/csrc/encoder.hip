@@ -146,6 +146,28 @@ extern "C" int mi_profile_summary(double* total_ms, double* total_flops) {
     return MI_OK;
 }
 
+// cost of an EMPTY begin/end event pair on `stream` (median of n, ms): the dispatch gap a HIP-event bracket adds to a short kernel.
+// bench.py subtracts it so that the event-timed average agrees with the kernel durations rocprofv3 reports.
+extern "C" int mi_profile_calibrate(hipStream_t stream, int n, double* median_ms) {
+    if (n <= 0 || n > 256) return MI_ERR_ARG;
+    hipEvent_t a[256], b[256];
+    float t[256];
+    for (int i = 0; i < n; ++i) {
+        if (hipEventCreate(&a[i]) != hipSuccess || hipEventCreate(&b[i]) != hipSuccess) return MI_ERR_LAUNCH;
+        hipEventRecord(a[i], stream);
+        hipEventRecord(b[i], stream);
+    }
+    if (hipStreamSynchronize(stream) != hipSuccess) return MI_ERR_LAUNCH;
+    for (int i = 0; i < n; ++i) {
+        t[i] = 0.f;
+        hipEventElapsedTime(&t[i], a[i], b[i]);
+        hipEventDestroy(a[i]); hipEventDestroy(b[i]);
+    }
+    for (int i = 1; i < n; ++i) { const float v = t[i]; int j = i - 1; while (j >= 0 && t[j] > v) { t[j + 1] = t[j]; --j; } t[j + 1] = v; }
+    *median_ms = t[n / 2];
+    return MI_OK;
+}
+
 extern "C" size_t mi_ebf_workspace_bytes(const mi_ebf_config* cfg) { return carve(*cfg, nullptr).bytes; }
 
 // posp: (L, 2*T2-1, d) bf16 projected relative positions, (re)computed from pos_table when compute_posp != 0

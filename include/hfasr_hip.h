@@ -32,6 +32,7 @@ void mi_profile_enable(int on);
 void mi_profile_reset(void);
 int mi_profile_count(void);
 int mi_profile_summary(double* total_ms, double* total_flops);
+int mi_profile_calibrate(mi_stream_t stream, int n, double* median_ms);   /* cost of an empty event pair (subtracted per launch by bench.py) */
 
 /* tuning knob: LDS ring depth of the pipelined GEMM (2: 64 KiB, two blocks per CU; 3: 96 KiB, one block per CU). */
 void mi_gemm_set_stages(int stages);
