@@ -21,6 +21,11 @@ class EbfConfig(C.Structure):
                [("ln_eps", f32), ("logits_f32", i32), ("logits_ld", i32)]
 
 
+class Gpt2Config(C.Structure):
+    """mirror of mi_gpt2_config (include/hfasr_hip.h)"""
+    _fields_ = [("d", i32), ("H", i32), ("L", i32), ("V", i32), ("eps", f32)]
+
+
 GLOBAL_SLOTS, LAYER_SLOTS = 24, 48
 
 # name -> (argtypes); every function returns int (0 = ok), except mi_ebf_workspace_bytes (size_t)
@@ -82,6 +87,9 @@ SIGNATURES = {
     "mi_ctc_loss_bwd": [vp, i64, i64, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, f32, vp, sz, vp, i64, vp],
     "mi_ce_label_smoothing_bwd": [vp, i64, vp, i32, i32, i32, i32, f32, f32, vp, vp, i64, vp],
     "mi_embed_tokens_bwd": [vp, vp, f32, i32, i32, i32, i32, i32, vp, vp, vp],
+    "mi_gpt2_step_workspace_bytes": [C.POINTER(Gpt2Config), i32, i32],
+    "mi_gpt2_step": [C.POINTER(Gpt2Config), vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, f32, vp, sz, vp, i64, vp],
+    "mi_kv_cache_reorder": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "mi_ebf_workspace_bytes": [C.POINTER(EbfConfig)],
     "mi_ebf_forward": [C.POINTER(EbfConfig), vp, vp, vp, vp, vp, i32, vp, sz, vp, vp, vp, vp, vp],
 }
@@ -109,7 +117,8 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(h, name)          # AttributeError here = header/library mismatch: fail loudly
             fn.argtypes = args
-            fn.restype = sz if name in ("mi_ebf_workspace_bytes", "mi_ctc_bwd_workspace_bytes", "mi_gemm_tn_workspace_bytes", "mi_layernorm_bwd_workspace_floats") else i32
+            fn.restype = sz if name in ("mi_ebf_workspace_bytes", "mi_ctc_bwd_workspace_bytes", "mi_gemm_tn_workspace_bytes", "mi_layernorm_bwd_workspace_floats",
+                                          "mi_gpt2_step_workspace_bytes") else i32
         h.mi_profile_create.argtypes = [i32]; h.mi_profile_create.restype = i32
         h.mi_profile_enable.argtypes = [i32]; h.mi_profile_enable.restype = None
         h.mi_profile_reset.argtypes = []; h.mi_profile_reset.restype = None

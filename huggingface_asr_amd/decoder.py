@@ -12,9 +12,11 @@ Eval-mode semantics; the fp32 residual stream / bf16 GEMM operands precision mod
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 
-from . import ops
+from . import _lib, ops
 from .engine import EBranchformerEngine
 
 BF16 = torch.bfloat16
@@ -66,6 +68,14 @@ class GPT2DecoderEngine:
                       for k in range(len(c.get("head_locations") or []))]
         w["lm_head"] = sd[prefix + "lm_head.weight"].detach().to(dev, torch.float32).to(BF16).contiguous()
         self.w = w
+        # pointer table of mi_gpt2_step (csrc/decoder_step.hip): 5 globals, then 18 per layer
+        ptrs = [w["wte"], w["pos"], w["lnf"][0], w["lnf"][1], w["lm_head"]]
+        for lw in w["layers"]:
+            ptrs += [lw["ln1"][0], lw["ln1"][1], lw["wqkv"], lw["bqkv"], lw["wo"], lw["bo"], lw["lnc"][0], lw["lnc"][1], lw["wq"], lw["bq"],
+                     lw["wco"], lw["bco"], lw["ln2"][0], lw["ln2"][1], lw["wfc"], lw["bfc"], lw["wpr"], lw["bpr"]]
+        self._wtable = (C.c_void_p * len(ptrs))(*[t.data_ptr() for t in ptrs])
+        self._gcfg = _lib.Gpt2Config(d=d, H=c["n_head"], L=L, V=w["lm_head"].shape[0], eps=float(c.get("layer_norm_epsilon", 1e-5)))
+        self._step_ws = None
 
     # ------------------------------------------------------------------ building blocks
     def cross_kv(self, enc_bf16: torch.Tensor):
@@ -137,17 +147,54 @@ class GPT2DecoderEngine:
 
     # ------------------------------------------------------------------ incremental decoding
     def init_cache(self, B: int, Lmax: int):
+        """KV cache: two sets of (B, Lmax, d) tensors per layer (beam re-ordering copies set A -> set B in one kernel and swaps)."""
         d, L = self.cfg["n_embd"], self.cfg["n_layer"]
         z = lambda: torch.zeros((B, Lmax, d), device=self.device, dtype=BF16)
-        return dict(k=[z() for _ in range(L)], v=[z() for _ in range(L)], past=0, Lmax=Lmax)
+        cache = dict(k=[z() for _ in range(L)], v=[z() for _ in range(L)], k2=[z() for _ in range(L)], v2=[z() for _ in range(L)], past=0, Lmax=Lmax)
+        self._cache_tables(cache)
+        return cache
+
+    @staticmethod
+    def _cache_tables(cache):
+        tab = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        cache["tk"], cache["tv"], cache["tk2"], cache["tv2"] = tab(cache["k"]), tab(cache["v"]), tab(cache["k2"]), tab(cache["v2"])
 
     def reorder_cache(self, cache, beam_idx: torch.Tensor):
-        for l in range(len(cache["k"])):
-            cache["k"][l] = cache["k"][l].index_select(0, beam_idx)
-            cache["v"][l] = cache["v"][l].index_select(0, beam_idx)
+        """transformers' `_reorder_cache`: every layer's K and V rows follow their beam (one kernel for all 2L tensors)."""
+        L = len(cache["k"])
+        B, Lmax, d = cache["k"][0].shape
+        beam_idx = beam_idx.to(device=self.device, dtype=torch.long).contiguous()
+        _lib.check(_lib.lib().mi_kv_cache_reorder(cache["tk"], cache["tv"], cache["tk2"], cache["tv2"], beam_idx.data_ptr(), L, B, cache["past"], Lmax, d,
+                                                  torch.cuda.current_stream().cuda_stream), "mi_kv_cache_reorder")
+        cache["k"], cache["k2"] = cache["k2"], cache["k"]
+        cache["v"], cache["v2"] = cache["v2"], cache["v"]
+        cache["tk"], cache["tk2"] = cache["tk2"], cache["tk"]
+        cache["tv"], cache["tv2"] = cache["tv2"], cache["tv"]
 
     def step(self, ids_new: torch.Tensor, cache, kvs, T_enc: int, enc_len):
-        """ids_new (B, U_new) -> logits (B, V) of the LAST new position; appends to the KV cache."""
+        """ids_new (B, U_new) -> logits (B, V) of the LAST new position; appends to the KV cache.  One C call (mi_gpt2_step)."""
+        c, w = self.cfg, self.w
+        ids_new = ids_new.contiguous()
+        B, U = ids_new.shape
+        past, Lmax = cache["past"], cache["Lmax"]
+        L_ = _lib.lib()
+        nbytes = L_.mi_gpt2_step_workspace_bytes(C.byref(self._gcfg), B, U)
+        if self._step_ws is None or self._step_ws.numel() < nbytes:
+            self._step_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        if cache.get("kv_id") != id(kvs):                              # pointer table of the per-layer encoder K/V
+            cache["tkv"] = (C.c_void_p * len(kvs))(*[t.data_ptr() for t in kvs])
+            cache["kv_id"] = id(kvs)
+        V = self._gcfg.V
+        Vp = (V + 7) // 8 * 8
+        buf = torch.empty((B, Vp), device=self.device, dtype=torch.float32)
+        _lib.check(L_.mi_gpt2_step(C.byref(self._gcfg), self._wtable, ids_new.data_ptr(), B, U, past, Lmax, cache["tk"], cache["tv"], cache["tkv"], T_enc,
+                                   enc_len.data_ptr() if enc_len is not None else None, float(w["scale"]), self._step_ws.data_ptr(), self._step_ws.numel(),
+                                   buf.data_ptr(), Vp, torch.cuda.current_stream().cuda_stream), "mi_gpt2_step")
+        cache["past"] = past + U
+        return buf[:, :V]
+
+    def step_py(self, ids_new: torch.Tensor, cache, kvs, T_enc: int, enc_len):
+        """same step driven op by op from Python (kept as the cross-check of the C driver)"""
         c, w = self.cfg, self.w
         B, U = ids_new.shape
         d, L, eps = c["n_embd"], c["n_layer"], c.get("layer_norm_epsilon", 1e-5)

@@ -212,6 +212,19 @@ int mi_ce_label_smoothing_bwd(const float* logits, long ld, const long* labels, 
 int mi_embed_tokens_bwd(const long* ids, const float* dx, float scale, int pos_offset, int U, int d, int M, int V, float* dwte,
                         float* dwpe, mi_stream_t stream);
 
+/* ---- GPT-2 decoder token step as one call (KV cache, cross-attention over cached encoder K/V) + beam re-ordering of the caches.
+ * replaces: GPT2LMMultiHeadModel.forward with past_key_values (multi_head_gpt2.py:80-170; tf gpt2 :262-310) and `_reorder_cache`. */
+typedef struct {
+    int d, H, L, V;
+    float eps;
+} mi_gpt2_config;
+size_t mi_gpt2_step_workspace_bytes(const mi_gpt2_config* cfg, int B, int U);
+int mi_gpt2_step(const mi_gpt2_config* cfg, const void* const* weights, const long* ids_new, int B, int U, int past, int Lmax,
+                 void* const* kcache, void* const* vcache, const void* const* cross_kv, int T_enc, const int* enc_len, float emb_scale,
+                 void* workspace, size_t workspace_bytes, float* logits, long ld_logits, mi_stream_t stream);
+int mi_kv_cache_reorder(const void* const* src_k, const void* const* src_v, void* const* dst_k, void* const* dst_v, const long* beam_idx,
+                        int L, int BW, int rows, int Lmax, int d, mi_stream_t stream);
+
 /* ---- Whisper-style front end + glue (BASELINE config 4).  replaces: transformers WhisperFeatureExtractor numpy path
  *      (selected by configs/default_data_preprocessing_whisper.json:20-29) and the conv/position prologue of WhisperEncoder. */
 int mi_whisper_logmel(const float* wave, long ldw, const int* num_samples, int n_samples, const double* window,

@@ -159,3 +159,32 @@ def test_hf_joint_model_surface():
     ref = generate(model._get_engine(DEV), x.to(DEV), am.sum(-1).to(DEV, torch.int32), num_beams=3, max_length=8, ctc_weight=0.3)
     for b in range(2):
         assert toks[b, : len(ref[b]["tokens"])].tolist() == ref[b]["tokens"]
+
+
+def test_c_step_driver_matches_python_step_and_reorders_cache():
+    """mi_gpt2_step (whole token step in one C call) == the op-by-op Python step, bit for bit (same kernels, same order); the one-kernel
+    beam re-ordering of all KV caches == index_select per tensor."""
+    from huggingface_asr_amd.decoder import JointAEDEngine, shift_tokens_right
+    g = load_golden("aed_tiny")
+    sd, x, am, lab = aed_case_inputs(g)
+    eng = JointAEDEngine(_enc_cfg(), dict(TINY_DEC), AED_JCFG, DEV)
+    eng.load_state_dict(sd)
+    enc_out, enc_bf, T2, key_len = eng.encode(x.to(DEV), am.sum(-1).to(DEV, torch.int32))
+    ids = shift_tokens_right(lab, 50, 2).to(DEV)
+    kvs = eng.dec.cross_kv(enc_bf)
+    ca, cb = eng.dec.init_cache(ids.shape[0], 16), eng.dec.init_cache(ids.shape[0], 16)
+    for lo, hi in ((0, 3), (3, 4), (4, 5)):
+        a = eng.dec.step(ids[:, lo:hi], ca, kvs, T2, key_len)
+        b = eng.dec.step_py(ids[:, lo:hi], cb, kvs, T2, key_len)
+        assert torch.equal(a, b), (lo, hi, float((a - b).abs().max()))
+    for l in range(len(ca["k"])):
+        assert torch.equal(ca["k"][l][:, :5], cb["k"][l][:, :5]) and torch.equal(ca["v"][l][:, :5], cb["v"][l][:, :5])
+    perm = torch.tensor([1, 1], device=DEV)
+    want_k = [t.index_select(0, perm)[:, :5].clone() for t in ca["k"]]
+    want_v = [t.index_select(0, perm)[:, :5].clone() for t in ca["v"]]
+    eng.dec.reorder_cache(ca, perm)
+    for l in range(len(want_k)):
+        assert torch.equal(ca["k"][l][:, :5], want_k[l]) and torch.equal(ca["v"][l][:, :5], want_v[l])
+    # decoding continues on the re-ordered cache
+    a = eng.dec.step(ids[:, 5:6], ca, kvs, T2, key_len)
+    assert torch.isfinite(a).all()
