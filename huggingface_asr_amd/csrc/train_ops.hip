@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void spec_mask_bwd_kernel(float* __restrict__ 
         }
     part[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && c < N && tmask) atomic_add_f32(dembed + c, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+    if (ty == 0 && c < N && tmask && dembed) atomic_add_f32(dembed + c, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
 }
 
 // ------------------------------------------------------------------------------------------------ optimizer
@@ -507,7 +507,7 @@ extern "C" int mi_spec_mask_apply(float* x, long ld, const unsigned char* time_m
 extern "C" int mi_spec_mask_bwd(float* dx, long ld, const unsigned char* time_mask, float* dembed, const unsigned char* feat_mask, int T, int M, int N,
                                 hipStream_t st) {
     MI_ENTER();
-    if (M <= 0 || N <= 0 || T <= 0 || (time_mask && !dembed)) return MI_ERR_ARG;
+    if (M <= 0 || N <= 0 || T <= 0) return MI_ERR_ARG;      // dembed == NULL: masked rows were replaced by a constant (noise): gradient dropped
     const int rpb = 128;
     hipLaunchKernelGGL(spec_mask_bwd_kernel, dim3(cdiv(N, 64), cdiv(M, rpb)), dim3(256), 0, st, dx, ld, time_mask, dembed, feat_mask, T, M, N, rpb);
     MI_CHECK_LAUNCH();

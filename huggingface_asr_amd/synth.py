@@ -93,3 +93,16 @@ def dropout_keep(seed: int, stream_id: int, n: int, p: float) -> np.ndarray:
         h = _splitmix64(_splitmix64(idx ^ key) + key)
     u = (h >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24))
     return u >= np.float32(p)
+
+
+def mask_noise(seed: int, stream_id: int, shape, std: float) -> np.ndarray:
+    """float32 noise of csrc/bestrq.hip's mask_noise_kernel for logical indices 0..prod(shape)-1 (Box-Muller on two hashed uniforms)."""
+    n = int(np.prod(shape))
+    key = np.uint64(((stream_id & 0xFFFFFFFF) << 32) ^ (seed & 0xFFFFFFFF))
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64)
+        h1 = _splitmix64(_splitmix64((np.uint64(2) * idx) ^ key) + key)
+        h2 = _splitmix64(_splitmix64((np.uint64(2) * idx + np.uint64(1)) ^ key) + key)
+    u1 = np.maximum((h1 >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24)), np.float32(2.98023224e-08))
+    u2 = (h2 >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24))
+    return (np.float32(std) * np.sqrt(np.float32(-2.0) * np.log(u1)) * np.cos(np.float32(6.283185307179586) * u2)).astype(np.float32).reshape(shape)

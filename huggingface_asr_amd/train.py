@@ -119,7 +119,7 @@ def ops_cast_flat(src_f32, dst_bf16):
 
 
 # ====================================================================================================== encoder parameters
-def encoder_specs(c: dict) -> list[Spec]:
+def encoder_specs(c: dict, head: bool = True) -> list[Spec]:
     d, I, L, V1 = c["hidden_size"], c["intermediate_size"], c["num_hidden_layers"], c["vocab_size"] + 1
     C1, C2 = c["conv_dim"]
     K = c["conv_kernel"][0]
@@ -151,11 +151,12 @@ def encoder_specs(c: dict) -> list[Spec]:
             vec(p + ff + "_ln_g", d); vec(p + ff + "_ln_b", d); mat(p + ff + "_w1", I, d); vec(p + ff + "_b1", I); mat(p + ff + "_w2", d, I); vec(p + ff + "_b2", d)
         vec(p + "fin_ln_g", d); vec(p + "fin_ln_b", d)
     vec("enc_ln_g", d); vec("enc_ln_b", d)
-    mat("head_w", V1, d); vec("head_b", V1)
+    if head:
+        mat("head_w", V1, d); vec("head_b", V1)
     return S
 
 
-def _enc_map(c: dict):
+def _enc_map(c: dict, head: bool = True):
     """packed name -> (to_packed(sd) -> tensor, [(reference key, from_packed(tensor) -> tensor), ...])"""
     d, L = c["hidden_size"], c["num_hidden_layers"]
     C1, C2 = c["conv_dim"]
@@ -181,10 +182,11 @@ def _enc_map(c: dict):
     one("fp_ln_g", fp + "layer_norm.weight"); one("fp_ln_b", fp + "layer_norm.bias")
     one("fp_w", fp + "projection.weight"); one("fp_b", fp + "projection.bias")
     one("enc_ln_g", "wav2vec2.encoder.layer_norm.weight"); one("enc_ln_b", "wav2vec2.encoder.layer_norm.bias")
-    m["head_w"] = (lambda sd: torch.cat([sd["lm_head.weight"], sd["blank_projection.weight"]], 0),
-                   [("lm_head.weight", lambda t: t[:V].contiguous()), ("blank_projection.weight", lambda t: t[V:].contiguous())])
-    m["head_b"] = (lambda sd: torch.cat([sd["lm_head.bias"], sd["blank_projection.bias"]], 0),
-                   [("lm_head.bias", lambda t: t[:V].contiguous()), ("blank_projection.bias", lambda t: t[V:].contiguous())])
+    if head:
+        m["head_w"] = (lambda sd: torch.cat([sd["lm_head.weight"], sd["blank_projection.weight"]], 0),
+                       [("lm_head.weight", lambda t: t[:V].contiguous()), ("blank_projection.weight", lambda t: t[V:].contiguous())])
+        m["head_b"] = (lambda sd: torch.cat([sd["lm_head.bias"], sd["blank_projection.bias"]], 0),
+                       [("lm_head.bias", lambda t: t[:V].contiguous()), ("blank_projection.bias", lambda t: t[V:].contiguous())])
     for l in range(L):
         p, r = f"l{l}.", f"wav2vec2.encoder.layers.{l}."
         if c.get("use_macaron_ff", True):
@@ -245,7 +247,7 @@ class EncoderCTCTrainer:
     """forward + backward + AdamW for Wav2Vec2EBranchformerForCTC on one GPU (one process per GPU under DP)."""
 
     def __init__(self, cfg: dict, device="cuda:0", *, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
-                 dp_sync=True, seed=0):
+                 dp_sync=True, seed=0, head=True):
         """dp_sync=False: no gradient all-reduce here (the caller, e.g. HF Trainer's DDP wrapper, owns data parallelism).
         seed: dropout mask seed (masks are counter-based: f(seed, step, layer, site, element), csrc/dropout.hip); give every DP rank its own."""
         c = self.cfg = dict(cfg)
@@ -266,8 +268,9 @@ class EncoderCTCTrainer:
         self.specaug = bool(c.get("apply_spec_augment", False)) and (float(c.get("mask_time_prob", 0.0) or 0.0) > 0.0 or
                                                                      float(c.get("mask_feature_prob", 0.0) or 0.0) > 0.0)
         self.device = torch.device(device)
-        self.store = ParamStore(encoder_specs(c), self.device)
-        self.map = _enc_map(c)
+        self.head = bool(head)            # False: bare encoder (BEST-RQ pre-training puts its own classifier on the last hidden state)
+        self.store = ParamStore(encoder_specs(c, self.head), self.device)
+        self.map = _enc_map(c, self.head)
         self.hp = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
         self.sync = GradSync(self.store.flat_g, group, enabled=dp_sync)
         self._pos = {}
@@ -276,7 +279,7 @@ class EncoderCTCTrainer:
         names = self.store.order
         self._layer_names = [[n for n in names if n.startswith(f"l{l}.")] for l in range(L)]
         self._front_names = [n for n in names if n.startswith(("masked_spec", "conv", "feout", "fp_"))]
-        self._head_names = ["enc_ln_g", "enc_ln_b", "head_w", "head_b"]
+        self._head_names = ["enc_ln_g", "enc_ln_b"] + (["head_w", "head_b"] if self.head else [])
 
     # ------------------------------------------------------------------ weights in / out
     def load_state_dict(self, sd: dict):
@@ -339,11 +342,13 @@ class EncoderCTCTrainer:
 
     # ------------------------------------------------------------------ forward + backward
     def forward_backward(self, feats, feat_lengths, labels, *, loss_scale=1.0, extra_hidden_grad=None, backward=True, keep_hidden=False,
-                         train_mode=False, step_index=None):
+                         train_mode=False, step_index=None, noise_mask=None):
         """feats (B,T,F) f32 device; feat_lengths (B) int32 or None; labels (B,U) int64 (<0 = padding).
         Returns dict(loss, logits (B,T2,V+1) f32, outer_len, last_hidden).  Gradients of loss_scale/world * loss accumulate into the store.
         `extra_hidden_grad`: optional callable(last_hidden f32 (M,d), outer_len (B) int32) -> f32 (M,d) gradient to add at the encoder output
-        (the attention decoder of the joint model hooks in here)."""
+        (the attention decoder of the joint model hooks in here).
+        `noise_mask` = (time mask (B*T2) uint8, std): BEST-RQ masking — those frames of the encoder input are replaced by N(0, std) noise
+        (bestrq.py:84-97), counter-based like the dropout masks (global stream site 3)."""
         c, st = self.cfg, self.store
         P, G, W, WT = st.p, st.g, st.bf, st.bfT
         dev = self.device
@@ -386,7 +391,12 @@ class EncoderCTCTrainer:
         if pd["fp"] > 0:
             T.dropout_(x, pd["fp"], seed, self._sid(L, 0))
         tmask = fmask = None
-        if self.specaug and (backward or train_mode):
+        if noise_mask is not None:
+            from . import _lib
+            nm, nstd = noise_mask
+            _lib.check(_lib.lib().mi_mask_noise_f32(x.data_ptr(), x.stride(0), nm.data_ptr(), M, d, float(nstd), seed, self._sid(L, 3),
+                                                    torch.cuda.current_stream().cuda_stream), "mi_mask_noise_f32")
+        elif self.specaug and (backward or train_mode):
             tmask, fmask = self._spec_masks(B, T2, d, inner)
             T.spec_mask_apply_(x, tmask, P("masked_spec_embed"), fmask, T2)
         if inner is not None:
@@ -449,33 +459,41 @@ class EncoderCTCTrainer:
         hid = e16(M, d)
         last_hidden = e32(M, d)
         LN(x, lna=(P("enc_ln_g"), P("enc_ln_b")), eps2=eps_e, outa=hid, outa32=last_hidden)
-        if pd["final"] > 0:
-            T.dropout_(hid, pd["final"], seed, self._sid(L, 2))
-        ldl = T.pad64(V1)
-        lbuf = e32(B, T2, ldl)
-        ops.gemm(hid, W("head_w"), P("head_b"), out=lbuf.view(M, ldl))
-        logits = lbuf[..., :V1]
+        loss = logits = lse = nll = None
         red = c.get("ctc_loss_reduction", "mean")
-        lse = ops.row_lse(lbuf.view(M, ldl)[:, :V1])
-        loss, nll, _ = ops.ctc_loss(logits, labels, outer, reduction=red, zero_infinity=bool(c.get("ctc_zero_infinity", False)), lse=lse)
-        out = dict(loss=loss, logits=logits, outer_len=outer, inner_len=inner, last_hidden=last_hidden.view(B, T2, d) if keep_hidden or extra_hidden_grad else None)
+        ldl = T.pad64(V1)
+        if self.head:
+            if pd["final"] > 0:
+                T.dropout_(hid, pd["final"], seed, self._sid(L, 2))
+            lbuf = e32(B, T2, ldl)
+            ops.gemm(hid, W("head_w"), P("head_b"), out=lbuf.view(M, ldl))
+            logits = lbuf[..., :V1]
+            lse = ops.row_lse(lbuf.view(M, ldl)[:, :V1])
+            loss, nll, _ = ops.ctc_loss(logits, labels, outer, reduction=red, zero_infinity=bool(c.get("ctc_zero_infinity", False)), lse=lse)
+        out = dict(loss=loss, logits=logits, outer_len=outer, inner_len=inner,
+                   last_hidden=last_hidden.view(B, T2, d) if keep_hidden or extra_hidden_grad or not self.head else None)
         if not backward:
             return out
 
         # =================================================================== backward
         gs = float(loss_scale) / self.sync.world
-        dlog = T.ctc_loss_bwd(logits, lse, labels, outer, nll, reduction=red, gscale=gs, ldo=ldl)         # (M, ldl) bf16
-        dhid = T.gemm(dlog, WT("head_w"))                                                                # (M, d) bf16
-        if pd["final"] > 0:
-            T.dropout_(dhid, pd["final"], seed, self._sid(L, 2))
-        T.gemm_tn_(G("head_w"), dlog, hid, n_store=V1)
-        T.colsum_(G("head_b"), dlog[:, :V1])
+        dhid = None
+        if self.head:
+            dlog = T.ctc_loss_bwd(logits, lse, labels, outer, nll, reduction=red, gscale=gs, ldo=ldl)         # (M, ldl) bf16
+            dhid = T.gemm(dlog, WT("head_w"))                                                                # (M, d) bf16
+            if pd["final"] > 0:
+                T.dropout_(dhid, pd["final"], seed, self._sid(L, 2))
+            T.gemm_tn_(G("head_w"), dlog, hid, n_store=V1)
+            T.colsum_(G("head_b"), dlog[:, :V1])
         dx = e32(M, d)
-        T.layernorm_bwd(x, P("enc_ln_g"), dhid, dx, accumulate=False, dgamma=G("enc_ln_g"), dbeta=G("enc_ln_b"), eps=eps_e)
+        if dhid is not None:
+            T.layernorm_bwd(x, P("enc_ln_g"), dhid, dx, accumulate=False, dgamma=G("enc_ln_g"), dbeta=G("enc_ln_b"), eps=eps_e)
         if extra_hidden_grad is not None:
             dh32 = extra_hidden_grad(last_hidden, outer)
             if dh32 is not None:
-                T.layernorm_bwd(x, P("enc_ln_g"), dh32, dx, accumulate=True, dgamma=G("enc_ln_g"), dbeta=G("enc_ln_b"), eps=eps_e)
+                T.layernorm_bwd(x, P("enc_ln_g"), dh32, dx, accumulate=dhid is not None, dgamma=G("enc_ln_g"), dbeta=G("enc_ln_b"), eps=eps_e)
+            elif dhid is None:
+                dx.zero_()
         self.sync.launch(*st.range_of(self._head_names))
         for l in range(L - 1, -1, -1):
             p = f"l{l}."
@@ -526,7 +544,9 @@ class EncoderCTCTrainer:
             T.dropout_(dx, pd["hidden"], seed, self._sid(L, 1))
         if inner is not None:
             T.mask_rows_(dx, inner, T2)
-        if tmask is not None or fmask is not None:
+        if noise_mask is not None:
+            T.spec_mask_bwd_(dx, noise_mask[0], None, None, T2)          # replaced frames pass no gradient upstream
+        elif tmask is not None or fmask is not None:
             T.spec_mask_bwd_(dx, tmask, G("masked_spec_embed"), fmask, T2)
         dyb = T.dropout_(dx, pd["fp"], seed, self._sid(L, 0), out=e16(M, d)) if pd["fp"] > 0 else T.add_cast(dx)
         da = T.linear_bwd(dyb, a_fp, WT("fp_w"), dw=G("fp_w"), db=G("fp_b"))

@@ -212,6 +212,12 @@ int mi_ce_label_smoothing_bwd(const float* logits, long ld, const long* labels, 
 int mi_embed_tokens_bwd(const long* ids, const float* dx, float scale, int pos_offset, int U, int d, int M, int V, float* dwte,
                         float* dwpe, mi_stream_t stream);
 
+/* ---- BEST-RQ pre-training (src/models/bestrq.py:66-97): random-projection quantizer targets, noise masking of the encoder input */
+int mi_rpq_targets(const float* x, long ldx, const float* P, const float* CB, long* targets, int M, int in_dim, int cd, int C, int books,
+                   mi_stream_t stream);
+int mi_mask_noise_f32(float* x, long ld, const unsigned char* time_mask, int M, int N, float std, unsigned seed, unsigned stream_id,
+                      mi_stream_t stream);
+
 /* ---- GPT-2 decoder token step as one call (KV cache, cross-attention over cached encoder K/V) + beam re-ordering of the caches.
  * replaces: GPT2LMMultiHeadModel.forward with past_key_values (multi_head_gpt2.py:80-170; tf gpt2 :262-310) and `_reorder_cache`. */
 typedef struct {

@@ -50,7 +50,7 @@ def load_seeded(model, seed):
     # parameters only: buffers (e.g. the rotary `embed_positions.inv_freq`) keep their computed values
     new = {k: torch.from_numpy(synth.init_param(seed, k, tuple(v.shape))) for k, v in model.named_parameters()}
     missing, unexpected = model.load_state_dict(new, strict=False)
-    assert not unexpected and all(("inv_freq" in m or ".attn.bias" in m or "masked_bias" in m) for m in missing), (missing, unexpected)
+    assert not unexpected and all(("inv_freq" in m or ".attn.bias" in m or "masked_bias" in m or m.startswith("rpq.")) for m in missing), (missing, unexpected)
     return float(sum(v.double().sum() for v in new.values()))
 
 
@@ -320,6 +320,50 @@ def run_aed_grad_cases():
         print(name, "loss", rec["loss"], rec["enc_loss"], rec["dec_loss"], "n grads", n)
 
 
+BESTRQ = dict(best_rq_codebook_size=96, best_rq_codebook_dim=8, best_rq_in_dim=320, best_rq_num_books=2)
+
+
+def run_bestrq_case():
+    """BEST-RQ pre-training (src/models/bestrq.py): quantizer targets, loss and every gradient of the reference model in train() mode.
+    Harness-side shims: (2') the BestRQConfig attributes are set with setattr (its __init__ is not reached through the multiple-inheritance
+    chain under transformers 5.15, same cause as shim (2) of SURVEY.md §8c); (6) `BestRQMask._mask_hidden_states` draws N(0, 0.1) from
+    torch's RNG — the harness substitutes a version that writes a GIVEN noise tensor (huggingface_asr_amd.synth.mask_noise, the kernels'
+    counter-based noise) at the masked frames, so that the fixture is reproducible by the HIP path."""
+    from models import bestrq as BQ
+    seed, B, T, lengths = 51, 2, 200, [200, 168]
+    cfg = BQ.BestRQEBranchformerForPreTrainingConfig(**TINY, attn_implementation="eager", layerdrop=0.0, **NO_DROPOUT)
+    for k, v in dict(num_fbanks=80, conv_padding=[1, 1], context_awareness_type=None, **BESTRQ).items():
+        setattr(cfg, k, v)
+    model = BQ.BestRQEBranchformerForPreTraining(cfg).train()
+    wsum = load_seeded(model, seed)
+    x, am = synth_feats(seed, B, T, lengths)
+    T2, d, L = 50, cfg.hidden_size, cfg.num_hidden_layers
+    mask = np.zeros((B, T2), dtype=bool)
+    mask[0, 4:12] = True; mask[0, 30:37] = True; mask[1, 10:22] = True
+    sid = ((0 * 64 + L) * 16 + 3) & 0xFFFFFFFF
+    noise = torch.from_numpy(synth.mask_noise(seed, sid, (B, T2, d), 0.1))
+    mt = torch.from_numpy(mask)
+
+    def patched(self, hidden_states, mask_time_indices=None, attention_mask=None, std=0.1):
+        if mask_time_indices is not None:
+            hidden_states[mask_time_indices] = noise[mask_time_indices]
+        return hidden_states
+    BQ.BestRQMask._mask_hidden_states = patched
+    out = model(torch.from_numpy(x), attention_mask=torch.from_numpy(am), mask_time_indices=mt)
+    out.loss.backward()
+    with torch.no_grad():
+        tg = model.rpq(torch.from_numpy(x).view(B, T2, -1))
+    rec = dict(seed=seed, weight_sum=wsum, lengths=np.array(lengths), shape=np.array([B, T, T2]), mask=mask, loss=float(out.loss),
+               rpq_P=model.rpq.P.numpy(), rpq_CB=model.rpq.CB.numpy(), targets=tg.numpy(), last_hidden=out.projected_states.detach().numpy(),
+               param_names=np.array([k for k, _ in model.named_parameters()]),
+               param_shapes=np.array([str(tuple(v.shape)) for _, v in model.named_parameters()]))
+    for k, v in model.named_parameters():
+        if v.grad is not None:
+            rec["grad:" + k] = v.grad.float().numpy()
+    np.savez_compressed(os.path.join(HERE, "bestrq_tiny.npz"), **rec)
+    print("bestrq_tiny loss", rec["loss"], "targets", tg.shape, "n grads", sum(k.startswith("grad:") for k in rec))
+
+
 WHISPER_TINY = dict(d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256, num_mel_bins=80, max_source_positions=100)
 
 
@@ -390,7 +434,7 @@ def run_ctc_prefix_cases():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "grads", "base", "fbank", "lengths", "ctc", "prefix", "aed", "aedgrads", "whisper"]
+    which = sys.argv[1:] or ["tiny", "grads", "base", "fbank", "lengths", "ctc", "prefix", "aed", "aedgrads", "bestrq", "whisper"]
     if "tiny" in which:
         run_encoder_case("tiny_rel", TINY, seed=11, B=2, T=200, lengths=[198, 150], U=7, tgt_lens=[7, 5])
         run_encoder_case("tiny_rotary", TINY, seed=12, B=2, T=200, lengths=[200, 131], U=6, tgt_lens=[6, 4],
@@ -422,5 +466,7 @@ if __name__ == "__main__":
         run_aed_cases()
     if "aedgrads" in which:
         run_aed_grad_cases()
+    if "bestrq" in which:
+        run_bestrq_case()
     if "whisper" in which:
         run_whisper_cases()

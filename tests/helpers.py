@@ -61,3 +61,19 @@ def aed_case_inputs(g):
     B, T, U = [int(v) for v in g["shape"]]
     x, am = synth_feats(seed, B, T, [int(v) for v in g["lengths"]])
     return sd, x, am, torch.from_numpy(g["labels"])
+
+
+BESTRQ_CFG = dict(best_rq_codebook_size=96, best_rq_codebook_dim=8, best_rq_in_dim=320, best_rq_num_books=2)
+
+
+def bestrq_case_inputs(g):
+    """(state_dict incl. the frozen rpq buffers, feats, attention_mask, mask_time_indices) of the BEST-RQ golden case."""
+    import ast
+    seed = int(g["seed"])
+    sd = {str(n): torch.from_numpy(synth.init_param(seed, str(n), ast.literal_eval(str(s)))) for n, s in zip(g["param_names"], g["param_shapes"])}
+    wsum = float(sum(v.double().sum() for v in sd.values()))
+    assert abs(wsum - float(g["weight_sum"])) < 1e-6 * max(1.0, abs(wsum))
+    sd["rpq.P"], sd["rpq.CB"] = torch.from_numpy(g["rpq_P"]), torch.from_numpy(g["rpq_CB"])
+    B, T, T2 = [int(v) for v in g["shape"]]
+    x, am = synth_feats(seed, B, T, [int(v) for v in g["lengths"]])
+    return sd, x, am, torch.from_numpy(g["mask"])

@@ -326,3 +326,60 @@ def test_in_model_specaugment_matches_reference_golden():
     # without the masks the loss differs: the fixture really exercises SpecAugment
     base = load_golden("grads_tiny_rel")
     assert abs(float(g["loss"]) - float(base["loss"])) > 1.0
+
+
+def test_bestrq_pretraining_step_matches_reference_golden():
+    """BEST-RQ: random-projection-quantizer targets, masked-frame noise, classifier CE (sum / books) and every gradient of the
+    HIP trainer vs the imported reference (`BestRQEBranchformerForPreTraining`, train mode, the kernels' counter-based noise injected)."""
+    from helpers import BESTRQ_CFG, bestrq_case_inputs
+    from huggingface_asr_amd.train_bestrq import BestRQTrainer
+    g = load_golden("bestrq_tiny")
+    sd, x, am, mask = bestrq_case_inputs(g)
+    cfg = dict(shapes.TINY, **NO_DROPOUT, **BESTRQ_CFG)
+    tr = BestRQTrainer(cfg, DEV, seed=int(g["seed"]))
+    tr.load_state_dict(sd)
+    tr.enc.store.zero_grad(); tr.store.zero_grad()
+    out = tr.forward_backward(x.to(DEV), am.sum(-1).to(DEV), mask.to(DEV))
+    tg = out["targets"].cpu().numpy()
+    want = np.where(g["mask"][:, None, :], g["targets"], -100)
+    assert (tg == want).mean() == 1.0, float((tg == want).mean())
+    assert abs(float(out["loss"]) - float(g["loss"])) <= 2e-3 * float(g["loss"]), (float(out["loss"]), float(g["loss"]))
+    d = np.abs(out["last_hidden"].float().cpu().numpy() - g["last_hidden"])
+    assert d.max() < 0.06 and d.mean() < 0.009
+    ref = {k[5:]: g[k] for k in g.files if k.startswith("grad:")}
+    _compare(tr.grad_dict(), ref)
+    l0 = float(out["loss"])
+    for _ in range(5):
+        o = tr.train_step(x.to(DEV), am.sum(-1).to(DEV), mask.to(DEV))
+    assert float(o["loss"]) < l0
+
+
+def test_hf_bestrq_model_forward_and_training_bridge():
+    """AutoModelForPreTraining route: eval forward and train()-mode loss.backward() of the drop-in BEST-RQ class vs the reference fixture."""
+    from transformers import AutoModelForPreTraining
+    from helpers import BESTRQ_CFG, bestrq_case_inputs
+    from huggingface_asr_amd.bind import bind_all
+    from huggingface_asr_amd.modeling_bestrq import BestRQEBranchformerForPreTrainingConfig, _bestrq_cfg
+    from huggingface_asr_amd.train_bestrq import BestRQTrainer
+    bind_all()
+    g = load_golden("bestrq_tiny")
+    sd, x, am, mask = bestrq_case_inputs(g)
+    base = dict(shapes.TINY); base.pop("num_fbanks")
+    model = AutoModelForPreTraining.from_config(BestRQEBranchformerForPreTrainingConfig(**base, **BESTRQ_CFG, **HF_NO_DROPOUT))
+    assert not any(model.load_state_dict(sd, strict=False))
+    model = model.to(DEV)
+    model._trainer = BestRQTrainer(_bestrq_cfg(model.config), DEV, dp_sync=False, seed=int(g["seed"]))     # the fixture's noise seed
+    model._trainer_key = None
+    model.eval()
+    with torch.no_grad():
+        out = model(x.to(DEV), attention_mask=am.to(DEV), mask_time_indices=mask.to(DEV))
+    assert abs(float(out.loss) - float(g["loss"])) <= 2e-3 * float(g["loss"])
+    assert out.projected_states.shape == (2, 50, 64)
+    model.train()
+    model._trainer.enc.train_steps_seen = 0                                   # same noise stream (step 0) as the fixture
+    out = model(x.to(DEV), attention_mask=am.to(DEV), mask_time_indices=mask.to(DEV))
+    out.loss.backward()
+    ref = {k[5:]: g[k] for k in g.files if k.startswith("grad:")}
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert set(ref) <= set(grads)
+    _compare(grads, ref)

@@ -161,3 +161,29 @@ def test_whisper_frontend_and_encoder_match_transformers():
     with torch.no_grad():
         out = W.encoder_forward(sd, cfg, x)
     np.testing.assert_allclose(out.numpy(), g["enc_out"], atol=2e-4, rtol=0)
+
+
+def test_bestrq_oracle_matches_reference_fixture():
+    """BEST-RQ (src/models/bestrq.py): quantizer targets bit-exact, loss, last hidden state and every gradient of the oracle (autograd) vs
+    the imported reference model run with the same injected masking noise."""
+    import torch
+    from helpers import BESTRQ_CFG, bestrq_case_inputs
+    from huggingface_asr_amd import shapes, synth
+    from oracle import bestrq_ref as Bq
+    g = load_golden("bestrq_tiny")
+    sd, x, am, mask = bestrq_case_inputs(g)
+    cfg = dict(shapes.TINY, **BESTRQ_CFG)
+    B, T2 = mask.shape
+    L, d = cfg["num_hidden_layers"], cfg["hidden_size"]
+    noise = torch.from_numpy(synth.mask_noise(int(g["seed"]), ((0 * 64 + L) * 16 + 3), (B, T2, d), 0.1))
+    sdr = {k: (v.clone().requires_grad_(True) if not k.startswith("rpq.") else v) for k, v in sd.items()}
+    out = Bq.forward(sdr, cfg, x, am, mask, noise)
+    tg = Bq.rpq_targets(x.reshape(B, T2, -1), sd["rpq.P"], sd["rpq.CB"])
+    assert np.array_equal(tg.numpy(), g["targets"])
+    assert abs(float(out["loss"].detach()) - float(g["loss"])) <= 1e-4 * float(g["loss"])
+    np.testing.assert_allclose(out["last_hidden"].detach().numpy(), g["last_hidden"], atol=2e-4, rtol=0)
+    out["loss"].backward()
+    for k in g.files:
+        if k.startswith("grad:"):
+            got, want = sdr[k[5:]].grad.numpy(), g[k]
+            assert np.abs(got - want).max() <= 2e-4 * max(1.0, np.abs(want).max()), k
