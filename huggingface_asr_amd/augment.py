@@ -1,0 +1,94 @@
+"""Drop-in `SpecAug` (reference src/augmentations/spec_aug.py — the ESPnet SpecAugment the recipes name in
+configs/default_data_preprocessing2d.json:36-58) that augments a whole (B, T, F) feature batch on the GPU in one HIP kernel
+(`mi_specaug_f32`, csrc/specaug.hip) instead of per utterance inside dataloader workers.
+
+Same constructor arguments and `forward(x, x_lengths=None) -> (x, x_lengths)`.  The random parameters (warp centre / target, mask
+positions and widths) are drawn on the HOST with torch's CPU generator in exactly the reference's order and shapes
+(time_warp :122-123, mask_along_axis :63-72), so `torch.manual_seed(k)` reproduces the reference's augmentation; only the arithmetic
+(bicubic warp + masking) runs on the device.  Masked values are replaced with zero (the reference's default and the recipes' setting).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence, Union
+
+import torch
+
+from . import _lib
+
+
+class SpecAug(torch.nn.Module):
+    def __init__(self, apply_time_warp: bool = True, time_warp_window: int = 5, time_warp_mode: str = "bicubic", apply_freq_mask: bool = True,
+                 freq_mask_width_range: Union[int, Sequence[int]] = (0, 20), num_freq_mask: int = 2, apply_time_mask: bool = True,
+                 time_mask_width_range: Optional[Union[int, Sequence[int]]] = None,
+                 time_mask_width_ratio_range: Optional[Union[float, Sequence[float]]] = None, num_time_mask: int = 2):
+        if not apply_time_warp and not apply_time_mask and not apply_freq_mask:
+            raise ValueError("Either one of time_warp, time_mask, or freq_mask should be applied")
+        if apply_time_mask and (time_mask_width_range is not None) and (time_mask_width_ratio_range is not None):
+            raise ValueError('Either one of "time_mask_width_range" or "time_mask_width_ratio_range" can be used')
+        if apply_time_warp and time_warp_mode != "bicubic":
+            raise NotImplementedError("HIP SpecAug implements the bicubic time warp of the recipes")
+        super().__init__()
+        self.apply_time_warp, self.window = apply_time_warp, time_warp_window
+        self.apply_freq_mask, self.apply_time_mask = apply_freq_mask, apply_time_mask
+        rng = lambda r: (0, r) if isinstance(r, (int, float)) else tuple(r)
+        self.freq_range, self.num_freq_mask = rng(freq_mask_width_range), num_freq_mask
+        self.time_range = rng(time_mask_width_range) if time_mask_width_range is not None else None
+        self.time_ratio = rng(time_mask_width_ratio_range) if time_mask_width_ratio_range is not None else None
+        if apply_time_mask and self.time_range is None and self.time_ratio is None:
+            raise ValueError('Either one of "time_mask_width_range" or "time_mask_width_ratio_range" should be used.')
+        self.num_time_mask = num_time_mask
+
+    # --- the reference's random draws, in its order --------------------------------------------------------------
+    def _warp_params(self, t: int):
+        if t - self.window <= self.window:
+            return 0, 0, 0
+        center = int(torch.randint(self.window, t - self.window, (1,))[0])
+        warped = int(torch.randint(center - self.window, center + self.window, (1,))[0]) + 1
+        return 1, center, warped
+
+    @staticmethod
+    def _mask_params(B, D, lo, hi, num):
+        length = torch.randint(lo, hi, (B, num))
+        pos = torch.randint(0, max(1, D - int(length.max())), (B, num))
+        return pos, length
+
+    def forward(self, x: torch.Tensor, x_lengths: Optional[torch.Tensor] = None):
+        if not x.is_cuda:
+            raise RuntimeError("huggingface_asr_amd.augment.SpecAug runs on the GPU (no CPU fallback); keep the reference class for CPU workers")
+        squeeze = x.dim() == 2
+        if squeeze:
+            x = x[None]
+        x = x.to(torch.float32).contiguous()
+        B, Tn, Fq = x.shape
+        lens = [Tn] * B if x_lengths is None else [int(v) for v in x_lengths]
+        nf = self.num_freq_mask if self.apply_freq_mask else 0
+        nt = self.num_time_mask if self.apply_time_mask else 0
+        P = torch.zeros((B, 4 + 2 * nf + 2 * nt), dtype=torch.int32)
+        P[:, 0] = torch.tensor(lens, dtype=torch.int32)
+        if self.apply_time_warp:
+            if x_lengths is None or all(le == lens[0] for le in lens):
+                P[:, 1:4] = torch.tensor(self._warp_params(Tn), dtype=torch.int32)          # one warp for the whole padded batch (:165-167)
+            else:
+                for b in range(B):                                                             # per utterance, sequential draws (:170-178)
+                    P[b, 1:4] = torch.tensor(self._warp_params(lens[b]), dtype=torch.int32)
+        pad_to_zero = self.apply_time_warp and x_lengths is not None and not all(le == lens[0] for le in lens)
+        if nf:
+            pos, ln = self._mask_params(B, Fq, self.freq_range[0], self.freq_range[1], nf)
+            P[:, 4:4 + 2 * nf:2], P[:, 5:5 + 2 * nf:2] = pos.int(), ln.int()
+        if nt:
+            if self.time_range is not None:
+                lo, hi = self.time_range
+            else:
+                lo = max(0, math.floor(Tn * self.time_ratio[0]))
+                hi = min(Tn, math.floor(Tn * self.time_ratio[1]))
+            if hi > lo:
+                pos, ln = self._mask_params(B, Tn, lo, hi, nt)
+                P[:, 4 + 2 * nf::2], P[:, 5 + 2 * nf::2] = pos.int(), ln.int()
+        if not pad_to_zero:
+            P[:, 0] = Tn            # equal lengths: the reference warps / masks the whole padded tensor and leaves the padding as it is
+        Pd = P.to(x.device)
+        out = torch.empty_like(x)
+        _lib.check(_lib.lib().mi_specaug_f32(x.data_ptr(), out.data_ptr(), B, Tn, Fq, Pd.data_ptr(), nf, nt, 0.0, torch.cuda.current_stream().cuda_stream),
+                   "mi_specaug_f32")
+        return (out[0] if squeeze else out), x_lengths

@@ -212,6 +212,9 @@ int mi_ce_label_smoothing_bwd(const float* logits, long ld, const long* labels, 
 int mi_embed_tokens_bwd(const long* ids, const float* dx, float scale, int pos_offset, int U, int d, int M, int V, float* dwte,
                         float* dwpe, mi_stream_t stream);
 
+/* ---- feature-level SpecAugment on the device (src/augmentations/spec_aug.py:40-137: bicubic time warp + frequency / time masks) */
+int mi_specaug_f32(const float* x, float* out, int B, int T, int F, const int* params, int nf, int nt, float pad_value, mi_stream_t stream);
+
 /* ---- BEST-RQ pre-training (src/models/bestrq.py:66-97): random-projection quantizer targets, noise masking of the encoder input */
 int mi_rpq_targets(const float* x, long ldx, const float* P, const float* CB, long* targets, int M, int in_dim, int cd, int C, int books,
                    mi_stream_t stream);

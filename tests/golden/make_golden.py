@@ -364,6 +364,26 @@ def run_bestrq_case():
     print("bestrq_tiny loss", rec["loss"], "targets", tg.shape, "n grads", sum(k.startswith("grad:") for k in rec))
 
 
+SPECAUG_RECIPE = dict(apply_time_warp=True, time_warp_window=5, time_warp_mode="bicubic", apply_freq_mask=True, freq_mask_width_range=[0, 27],
+                      num_freq_mask=2, apply_time_mask=True, time_mask_width_ratio_range=[0, 0.05], num_time_mask=5)
+
+
+def run_specaug_cases():
+    """reference src/augmentations/spec_aug.py (recipe parameters of configs/default_data_preprocessing2d.json:36-58) on seeded features."""
+    from augmentations.spec_aug import SpecAug
+    rec = {}
+    cases = {"equal": (2, 240, None, 3), "single": (1, 333, None, 4), "ragged": (3, 260, [260, 197, 121], 5), "short": (2, 9, None, 6)}
+    for name, (B, T, lens, seed) in cases.items():
+        x = torch.from_numpy(synth.normal(seed, "specaug/" + name, (B, T, 80), 1.0))
+        aug = SpecAug(**SPECAUG_RECIPE)
+        torch.manual_seed(100 + seed)
+        y, _ = aug(x.clone(), None if lens is None else torch.tensor(lens))
+        rec[name + "/shape"] = np.array([B, T, seed]); rec[name + "/lens"] = np.array(lens if lens else [])
+        rec[name + "/out"] = y.numpy()
+    np.savez_compressed(os.path.join(HERE, "specaug.npz"), **rec)
+    print("specaug cases", {k: v.shape for k, v in rec.items() if k.endswith("/out")})
+
+
 WHISPER_TINY = dict(d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256, num_mel_bins=80, max_source_positions=100)
 
 
@@ -434,7 +454,7 @@ def run_ctc_prefix_cases():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "grads", "base", "fbank", "lengths", "ctc", "prefix", "aed", "aedgrads", "bestrq", "whisper"]
+    which = sys.argv[1:] or ["tiny", "grads", "base", "fbank", "lengths", "ctc", "prefix", "aed", "aedgrads", "bestrq", "specaug", "whisper"]
     if "tiny" in which:
         run_encoder_case("tiny_rel", TINY, seed=11, B=2, T=200, lengths=[198, 150], U=7, tgt_lens=[7, 5])
         run_encoder_case("tiny_rotary", TINY, seed=12, B=2, T=200, lengths=[200, 131], U=6, tgt_lens=[6, 4],
@@ -468,5 +488,7 @@ if __name__ == "__main__":
         run_aed_grad_cases()
     if "bestrq" in which:
         run_bestrq_case()
+    if "specaug" in which:
+        run_specaug_cases()
     if "whisper" in which:
         run_whisper_cases()
