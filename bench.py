@@ -46,6 +46,21 @@ def algorithmic_gflop_per_utt(cfg, T2):
     return 2.0 * mac / 1e9
 
 
+def pmc_traffic_bytes(kernel_prefix="gemm_glds_kernel<128, 128, 2, 2, 2, false>"):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*pmc*per_launch.txt: rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate runs of this command, FETCH_SIZE doubled for 16-B/lane reads as MI355X_MICROARCH.md prescribes).  PMC counters cannot
+    be collected inside the timed region, so the bench line carries the recorded value and names its source; None if the file is absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*per_launch*.txt")))
+    if not files:
+        return None, None
+    for line in open(files[-1]):
+        if line.startswith(kernel_prefix):
+            cols = [c.strip() for c in line.split("|")]
+            return (float(cols[3]) + float(cols[4])) * 1e6, os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def cpu_baseline(cfg, sd, seconds_budget=25.0):
     """Time the ORACLE (CPU restatement; checker only, never the product path) on the host cores:
     feature extraction + encoder forward + CTC head, fp32, bounded sample."""
@@ -173,8 +188,10 @@ def main():
             raw_us = ms.value * 1e3 / n
             ker_ms = max(ms.value - n * cal.value, 0.5 * ms.value)
             ach = fl.value / (ker_ms * 1e-3) / 1e12
+            traffic, tsrc = pmc_traffic_bytes()
             roof = dict(bound="mfma", kernel="gemm_glds_kernel<128,128,2,2,2,false> (all nn.Linear GEMMs)", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None, launches=n, avg_launch_us=round(ker_ms * 1e3 / n, 2),
+                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic, traffic_unit="HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                        traffic_source=tsrc, launches=n, avg_launch_us=round(ker_ms * 1e3 / n, 2),
                         avg_launch_us_raw_events=round(raw_us, 2), event_pair_overhead_us=round(cal.value * 1e3, 2),
                         gflop_per_launch=round(fl.value / n / 1e9, 3), sampled_every=args.event_stride)
 
