@@ -26,6 +26,111 @@ __global__ __launch_bounds__(256) void kv_append_kernel(const bf16_t* __restrict
     }
 }
 
+// ---- skinny fused linear for the token step (M <= 8 rows, e.g. 1 utterance x 5 beams): y = act(LN?(x) · W^T + b) (+ resid)
+// A 128x128 MFMA tile is 96 % padding at M = 5 and every separate LayerNorm / residual launch costs more than its work, so this
+// kernel does it GEMV-style: the block normalises the M rows into LDS (bf16-rounded, like the LN kernel's output), then every wave
+// streams 4 weight rows (16-B loads, K split over the lanes) and reduces the M dot products with wave shuffles.
+constexpr int SK_MAXM = 8, SK_COLS = 4;
+
+struct SkArgs {
+    const float* x32; long ldx;            // fp32 input (residual stream) when ln_g != null or x16 == null
+    const bf16_t* x16; long ldx16;         // bf16 input (attention context / MLP hidden)
+    const float* ln_g; const float* ln_b; float eps;
+    const bf16_t* W; long ldw; const float* bias;
+    float* out32; long ldo32;              // fp32 output: out32 = resid32 + acc (in-place residual add) or plain logits
+    const float* resid32;
+    bf16_t* out16; long ldo16;             // bf16 output
+    int M, N, K, act;                      // act: 0 none, 2 gelu_new
+};
+
+__global__ __launch_bounds__(256) void skinny_linear_kernel(SkArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = reinterpret_cast<float*>(smem);                       // [M][K]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = (blockIdx.x * 4 + wave) * SK_COLS;
+    // the weight vectors of this wave's columns do not depend on the input: request them first (SK_COLS x K/512 independent 16-B loads in
+    // flight under the LayerNorm prologue), consume them after the barrier
+    constexpr int MAXP = 4;                                               // K <= 2048
+    bf16x8 wv[SK_COLS][MAXP];
+    const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < SK_COLS; ++c)
+#pragma unroll
+        for (int ps = 0; ps < MAXP; ++ps) {
+            const int n = n0 + c, k = ps * 512 + lane * 8;
+            wv[c][ps] = (n < p.N && k < p.K) ? *reinterpret_cast<const bf16x8*>(p.W + (long)n * p.ldw + k) : z8;
+        }
+    for (int m = wave; m < p.M; m += 4) {
+        if (p.x16) {
+            for (int k = lane; k < p.K; k += 64) xs[m * p.K + k] = bf2f(p.x16[(long)m * p.ldx16 + k]);
+        } else if (p.ln_g) {
+            const float* xr = p.x32 + (long)m * p.ldx;
+            float xv[32];                                                 // the row stays in registers: one global pass (K <= 2048)
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) { const int k = lane + 64 * i; xv[i] = k < p.K ? xr[k] : 0.f; s += xv[i]; }
+            const float mean = wave_sum(s) / p.K;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) { const int k = lane + 64 * i; const float a = k < p.K ? xv[i] - mean : 0.f; q += a * a; }
+            const float rstd = rsqrtf(wave_sum(q) / p.K + p.eps);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) { const int k = lane + 64 * i; if (k < p.K) xs[m * p.K + k] = bf2f(f2bf((xv[i] - mean) * rstd * p.ln_g[k] + p.ln_b[k])); }
+        } else {
+            for (int k = lane; k < p.K; k += 64) xs[m * p.K + k] = bf2f(f2bf(p.x32[(long)m * p.ldx + k]));
+        }
+    }
+    __syncthreads();
+    float acc[SK_COLS][SK_MAXM];
+#pragma unroll
+    for (int c = 0; c < SK_COLS; ++c)
+#pragma unroll
+        for (int m = 0; m < SK_MAXM; ++m) acc[c][m] = 0.f;
+#pragma unroll
+    for (int ps = 0; ps < MAXP; ++ps) {
+        const int k = ps * 512 + lane * 8;
+        if (k >= p.K) continue;
+#pragma unroll
+        for (int m = 0; m < SK_MAXM; ++m) {
+            if (m >= p.M) continue;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + m * p.K + k), x1 = *reinterpret_cast<const f32x4*>(xs + m * p.K + k + 4);
+#pragma unroll
+            for (int c = 0; c < SK_COLS; ++c) {
+                const bf16x8 w8 = wv[c][ps];
+                float a = acc[c][m];
+                a = fmaf(bf2f(w8[0]), x0.x, a); a = fmaf(bf2f(w8[1]), x0.y, a); a = fmaf(bf2f(w8[2]), x0.z, a); a = fmaf(bf2f(w8[3]), x0.w, a);
+                a = fmaf(bf2f(w8[4]), x1.x, a); a = fmaf(bf2f(w8[5]), x1.y, a); a = fmaf(bf2f(w8[6]), x1.z, a); a = fmaf(bf2f(w8[7]), x1.w, a);
+                acc[c][m] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < SK_COLS; ++c) {
+        const int n = n0 + c;
+        if (n >= p.N) break;                                          // wave-uniform
+#pragma unroll
+        for (int m = 0; m < SK_MAXM; ++m)
+            if (m < p.M) acc[c][m] = wave_sum(acc[c][m]);
+        if (lane < p.M) {
+            float v = 0.f;
+#pragma unroll
+            for (int m = 0; m < SK_MAXM; ++m) if (m == lane) v = acc[c][m];
+            v += p.bias ? p.bias[n] : 0.f;
+            if (p.act == 2) v = gelu_tanh(v);
+            if (p.out32) p.out32[(long)lane * p.ldo32 + n] = (p.resid32 ? p.resid32[(long)lane * p.ldo32 + n] : 0.f) + v;
+            else p.out16[(long)lane * p.ldo16 + n] = f2bf(v);
+        }
+    }
+}
+
+int skinny(const SkArgs& a, hipStream_t st) {
+    if (a.M <= 0 || a.M > SK_MAXM || (a.K % 8) || (a.ldw % 8) || a.K > 2048) return MI_ERR_ARG;
+    const size_t lds = (size_t)a.M * a.K * sizeof(float);
+    if (lds > 150 * 1024) return MI_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(skinny_linear_kernel, dim3(cdiv(a.N, 4 * SK_COLS)), dim3(256), lds, st, a);
+    return MI_OK;
+}
+
 constexpr int MAX_LAYERS = 48;
 struct ReorderArgs { const bf16_t* src[2 * MAX_LAYERS]; bf16_t* dst[2 * MAX_LAYERS]; };
 
@@ -93,6 +198,43 @@ extern "C" int mi_gpt2_step(const mi_gpt2_config* cfg, const void* const* weight
         return mi_layernorm_chain(x, ldx, nullptr, 1, nullptr, nullptr, 0.f, nullptr, 0, g, b, c.eps, out, d, nullptr, 0, nullptr, nullptr, nullptr, 0, rows, d, st);
     };
     RUN(mi_embed_tokens(ids_new, Gf(0), emb_scale, Gf(1), past, U, d, M, c.V, w.x, st));
+    if (M <= SK_MAXM && (d % 8) == 0 && 4 * d <= 2048) {
+        // ---- skinny token step: LayerNorms, biases, activations and residual adds fused into GEMV-style linears (8 launches per layer)
+        auto lin_ln = [&](const float* g, const float* b, const void* W, const float* bias, int N, bf16_t* out, int act) {
+            SkArgs a{}; a.x32 = w.x; a.ldx = d; a.ln_g = g; a.ln_b = b; a.eps = c.eps; a.W = (const bf16_t*)W; a.ldw = d; a.bias = bias;
+            a.out16 = out; a.ldo16 = N; a.M = M; a.N = N; a.K = d; a.act = act;
+            return skinny(a, st);
+        };
+        auto lin_res = [&](const bf16_t* in, int K, const void* W, const float* bias) {      // x += in · W^T + b
+            SkArgs a{}; a.x16 = in; a.ldx16 = K; a.W = (const bf16_t*)W; a.ldw = K; a.bias = bias; a.out32 = w.x; a.ldo32 = d; a.resid32 = w.x;
+            a.M = M; a.N = d; a.K = K; a.act = 0;
+            return skinny(a, st);
+        };
+        for (int l = 0; l < c.L; ++l) {
+            bf16_t* kc = (bf16_t*)kcache[l];
+            bf16_t* vc = (bf16_t*)vcache[l];
+            const bf16_t* ckv = (const bf16_t*)cross_kv[l];
+            RUN(lin_ln(Lf(l, 0), Lf(l, 1), Lw(l, 2), Lf(l, 3), 3 * d, w.qkv, 0));
+            {
+                const long total = (long)M * (d / 8);
+                hipLaunchKernelGGL(kv_append_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w.qkv, (long)3 * d, kc, vc, B, U, past, Lmax, d);
+            }
+            RUN(mi_attention_qkv_bf16(w.qkv, 3 * d, kc, d, vc, d, nullptr, 0, nullptr, nullptr, nullptr, w.ctx, d, B, U, past + U, (long)Lmax * d, c.H, hd,
+                                      scale, 1, st));
+            RUN(lin_res(w.ctx, d, Lw(l, 4), Lf(l, 5)));
+            RUN(lin_ln(Lf(l, 6), Lf(l, 7), Lw(l, 8), Lf(l, 9), d, w.qq, 0));
+            RUN(mi_attention_qkv_bf16(w.qq, d, ckv, 2 * d, ckv + d, 2 * d, nullptr, 0, nullptr, nullptr, enc_len, w.ctx, d, B, U, T_enc, 0, c.H, hd, scale, 0, st));
+            RUN(lin_res(w.ctx, d, Lw(l, 10), Lf(l, 11)));
+            RUN(lin_ln(Lf(l, 12), Lf(l, 13), Lw(l, 14), Lf(l, 15), 4 * d, w.m, 2));
+            RUN(lin_res(w.m, 4 * d, Lw(l, 16), Lf(l, 17)));
+        }
+        // ln_f on the last new position of every sequence + lm head -> fp32 logits
+        SkArgs a{}; a.x32 = w.x + (size_t)(U - 1) * d; a.ldx = (long)U * d; a.ln_g = Gf(2); a.ln_b = Gf(3); a.eps = c.eps; a.W = (const bf16_t*)weights[4];
+        a.ldw = d; a.out32 = logits; a.ldo32 = ld_logits; a.M = B; a.N = c.V; a.K = d; a.act = 0;
+        RUN(skinny(a, st));
+        MI_CHECK_LAUNCH();
+        return MI_OK;
+    }
     for (int l = 0; l < c.L; ++l) {
         bf16_t* kc = (bf16_t*)kcache[l];
         bf16_t* vc = (bf16_t*)vcache[l];

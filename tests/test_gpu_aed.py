@@ -162,8 +162,9 @@ def test_hf_joint_model_surface():
 
 
 def test_c_step_driver_matches_python_step_and_reorders_cache():
-    """mi_gpt2_step (whole token step in one C call) == the op-by-op Python step, bit for bit (same kernels, same order); the one-kernel
-    beam re-ordering of all KV caches == index_select per tensor."""
+    """mi_gpt2_step (whole token step in one C call) vs the op-by-op Python step: bit for bit on the MFMA path (more than 8 rows: same
+    kernels, same order), within bf16 noise on the fused skinny path (<= 8 rows: LayerNorm / bias / gelu_new / residual fused into GEMV-style
+    linears, different summation order); the one-kernel beam re-ordering of all KV caches == index_select per tensor."""
     from huggingface_asr_amd.decoder import JointAEDEngine, shift_tokens_right
     g = load_golden("aed_tiny")
     sd, x, am, lab = aed_case_inputs(g)
@@ -173,18 +174,22 @@ def test_c_step_driver_matches_python_step_and_reorders_cache():
     ids = shift_tokens_right(lab, 50, 2).to(DEV)
     kvs = eng.dec.cross_kv(enc_bf)
     ca, cb = eng.dec.init_cache(ids.shape[0], 16), eng.dec.init_cache(ids.shape[0], 16)
-    for lo, hi in ((0, 3), (3, 4), (4, 5)):
+    for lo, hi in ((0, 5), (5, 6), (6, 7)):
         a = eng.dec.step(ids[:, lo:hi], ca, kvs, T2, key_len)
         b = eng.dec.step_py(ids[:, lo:hi], cb, kvs, T2, key_len)
-        assert torch.equal(a, b), (lo, hi, float((a - b).abs().max()))
+        if ids.shape[0] * (hi - lo) > 8:
+            assert torch.equal(a, b), (lo, hi, float((a - b).abs().max()))
+        else:
+            torch.testing.assert_close(a, b, atol=3e-2, rtol=0)
     for l in range(len(ca["k"])):
         assert torch.equal(ca["k"][l][:, :5], cb["k"][l][:, :5]) and torch.equal(ca["v"][l][:, :5], cb["v"][l][:, :5])
+        torch.testing.assert_close(ca["k"][l][:, :7].float(), cb["k"][l][:, :7].float(), atol=3e-2, rtol=0)
     perm = torch.tensor([1, 1], device=DEV)
-    want_k = [t.index_select(0, perm)[:, :5].clone() for t in ca["k"]]
-    want_v = [t.index_select(0, perm)[:, :5].clone() for t in ca["v"]]
+    want_k = [t.index_select(0, perm)[:, :7].clone() for t in ca["k"]]
+    want_v = [t.index_select(0, perm)[:, :7].clone() for t in ca["v"]]
     eng.dec.reorder_cache(ca, perm)
     for l in range(len(want_k)):
-        assert torch.equal(ca["k"][l][:, :5], want_k[l]) and torch.equal(ca["v"][l][:, :5], want_v[l])
+        assert torch.equal(ca["k"][l][:, :7], want_k[l]) and torch.equal(ca["v"][l][:, :7], want_v[l])
     # decoding continues on the re-ordered cache
-    a = eng.dec.step(ids[:, 5:6], ca, kvs, T2, key_len)
+    a = eng.dec.step(ids[:, 7:8], ca, kvs, T2, key_len)
     assert torch.isfinite(a).all()
