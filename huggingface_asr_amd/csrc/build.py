@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libhfasr_hip.so")
 OBJ = os.path.join(HERE, "build")
-SOURCES = ["gemm_bf16.hip", "gemm_glds.hip", "norm.hip", "conv.hip", "attention.hip", "fbank.hip", "ctc.hip", "ctc_prefix.hip", "decoder.hip", "decoder_step.hip", "whisper.hip", "encoder.hip",
+SOURCES = ["gemm_bf16.hip", "gemm_glds.hip", "gemm_256.hip", "norm.hip", "conv.hip", "attention.hip", "fbank.hip", "ctc.hip", "ctc_prefix.hip", "decoder.hip", "decoder_step.hip", "whisper.hip", "encoder.hip",
            "train_ops.hip", "gemm_tn.hip", "bgemm.hip", "attn_bwd.hip", "conv_bwd.hip", "loss_bwd.hip", "dropout.hip", "bestrq.hip", "specaug.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-result", "-munsafe-fp-atomics"]
 

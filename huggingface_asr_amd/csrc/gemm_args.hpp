@@ -22,3 +22,7 @@ struct GemmArgs {
 // gemm_glds.hip; returns MI_ERR_UNSUPPORTED when the shape/alignment does not fit the fast path
 bool gemm_glds_supported(const GemmArgs& a, bool conv);
 int gemm_glds_launch(const GemmArgs& a, bool conv, hipStream_t stream);
+
+// gemm_256.hip: 256x256 tiles, 8 waves, 4-deep ring of 32-wide K tiles (N % 256 == 0, K % 32 == 0)
+bool gemm_256_supported(const GemmArgs& a);
+int gemm_256_launch(const GemmArgs& a, hipStream_t stream);

@@ -295,6 +295,9 @@ int gemm_glds_launch(const GemmArgs& a_in, bool conv, hipStream_t stream) {
     a.dbg = g_dbg;
     // symmetric kernels: 256x256 tiles when they still give every CU a block, else 128x128 at two blocks per CU
     const int t256 = cdiv(a.M, 256) * cdiv(a.N, 256);
+    // opt-in (HFASR_GEMM_VARIANT=20): 256x256 tiles on a 4-deep ring of 32-wide K tiles (gemm_256.hip).  Measured: +8 % on the isolated
+    // 8000x2048x512 GEMM, +4 % at 8192^3, nothing on the end-to-end step -> not the default.
+    if (!conv && g_variant == 20 && gemm_256_supported(a)) return gemm_256_launch(a, stream);
     if (g_variant == 6 && t256 >= 200 && (a.N % 256) == 0) {   // opt-in: no gain on this workload's K=512 shapes, spills with look-ahead
         const size_t l = (size_t)2 * (256 + 256) * BK * 2;
         if (conv) hipLaunchKernelGGL((gemm_glds_kernel<256, 256, 2, 4, 2, true>), dim3(t256), dim3(512), l, stream, a);
