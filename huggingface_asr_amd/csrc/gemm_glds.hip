@@ -31,22 +31,22 @@ __device__ __forceinline__ int fsw(int row) { return (row >> 1) & 7; }
 //                      prologue/epilogue);  <256,256,2,4,S=2>: 8 waves (wave tile 128x64), 128 KiB ring, half the L2->LDS
 //                      bytes per flop — for GEMMs whose 256x256 tile count still fills the chip.
 template <int TBM, int TBN, int CWM, int CWN, int STAGES, bool CONV>
-__global__ __launch_bounds__(CWM * CWN * 64, (TBM == 128 && TBN == 128 && STAGES == 2) ? 2 : 1) void gemm_glds_kernel(GemmArgs p) {
+__device__ __forceinline__ void gemm_glds_tile(const GemmArgs& p, int bid, char* smem, int next_bid, bool prologue_done) {
     constexpr int NW = CWM * CWN, NTH = NW * 64;
     constexpr int WM = TBM / CWM, WN = TBN / CWN, MI = WM / 32, NI = WN / 32;
     constexpr int STG = (TBM + TBN) * BK * 2, ABYTES = TBM * BK * 2;
     constexpr int PPW = (TBM + TBN) / 8 / NW;          // 1-KiB pieces per wave per K tile
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / CWN, wn = wave % CWN;
 
     const int ntm = (p.M + TBM - 1) / TBM, ntn = (p.N + TBN - 1) / TBN;
     const int nwg = ntm * ntn;
-    int bid = blockIdx.x;
-    {   // XCD-aware bijective remap: the blocks of one XCD walk N fastest within an A row panel
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    // XCD-aware bijective remap: the blocks of one XCD walk N fastest within an A row panel
+    auto remap = [&](int id) {
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, idx = id >> 3;
+        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    };
+    bid = remap(bid);
     const int tm = bid / ntn, tn = bid % ntn;
     const int m0 = tm * TBM, n0 = tn * TBN;
 
@@ -115,9 +115,11 @@ __global__ __launch_bounds__(CWM * CWN * 64, (TBM == 128 && TBN == 128 && STAGES
     const int krot = p.krot ? (int)((unsigned)(tm * 5 + tn * 3) % (unsigned)nk) : 0;
     auto ktile = [&](int t) { int v = t + krot; return v >= nk ? v - nk : v; };
 
+    if (!prologue_done) {
 #pragma unroll
-    for (int t = 0; t < STAGES - 1; ++t)
-        if (t < nk) issue(ktile(t), t);
+        for (int t = 0; t < STAGES - 1; ++t)
+            if (t < nk) issue(ktile(t), t);
+    }
 
     for (int kt = 0; kt < nk; ++kt) {
         const int stage = kt % STAGES;
@@ -151,6 +153,24 @@ __global__ __launch_bounds__(CWM * CWN * 64, (TBM == 128 && TBN == 128 && STAGES
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // C^T tile: lane = m, regs = n
         }
     }
+    // ---- cross-tile prefetch (persistent grid): the first K tile of this block's NEXT output tile is requested before the epilogue,
+    // so its L2->LDS latency hides under the epilogue's stores.  Stage 0 is free once every wave has left the main loop (barrier).
+    auto prefetch_next = [&]() {
+        if (CONV || STAGES != 2 || next_bid < 0) return;
+        const int nb_ = remap(next_bid);
+        const int nm0 = (nb_ / ntn) * TBM, nn0 = (nb_ % ntn) * TBN;
+        asm volatile("s_barrier" ::: "memory");
+        char* sbase = smem + wave * PPW * 1024;
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            const int g = wave * PPW + q;
+            const bool isA = g < TBM / 8;
+            const int row = (isA ? g : g - TBM / 8) * 8 + prow;
+            const int lc = pc ^ fsw(row);
+            const bf16_t* sp = isA ? p.A + (long)min(nm0 + row, p.M - 1) * p.lda + lc * 8 : p.W + (long)min(nn0 + row, p.N - 1) * p.ldw + lc * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)sp, (lptr_t)(sbase + q * 1024), 16, 0, 0);
+        }
+    };
     if (p.dbg & 4) {                             // timing experiment: no epilogue (keep the accumulators alive)
         float keep = 0.f;
 #pragma unroll
@@ -199,6 +219,7 @@ __global__ __launch_bounds__(CWM * CWN * 64, (TBM == 128 && TBN == 128 && STAGES
     f32x4 rcur[4], rnext[4];
     const bool use_res = vec_ok && p.resid != nullptr;
     if (SMALL && use_res) load_resid(0, rcur);
+    prefetch_next();            // after the epilogue's own early loads: a later load would have to wait behind the prefetch (in-order vmcnt)
 #pragma unroll
     for (int t = 0; t < MI * NI; ++t) {
         // SMALL: row-major tile order with all biases preloaded; else column-block-major so one bias fetch serves MI tiles
@@ -267,6 +288,21 @@ __global__ __launch_bounds__(CWM * CWN * 64, (TBM == 128 && TBN == 128 && STAGES
     }
 }
 
+// Grid-stride over output tiles: with gridDim.x == number of tiles this is the plain one-tile-per-block launch; with a persistent grid
+// (two blocks per CU) a block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... — half the workgroup dispatches for the same work.
+template <int TBM, int TBN, int CWM, int CWN, int STAGES, bool CONV>
+__global__ __launch_bounds__(CWM * CWN * 64, (TBM == 128 && TBN == 128 && STAGES == 2) ? 2 : 1) void gemm_glds_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwg = ((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN);
+    const bool pf = !CONV && STAGES == 2 && p.krot == 0 && !(p.dbg & 15);
+    for (int tile = blockIdx.x; tile < nwg; tile += gridDim.x) {
+        const bool first = tile == (int)blockIdx.x;
+        if (!first && !pf) asm volatile("s_barrier" ::: "memory");     // every wave is done reading the previous tile's last LDS stage
+        const int next = (pf && tile + (int)gridDim.x < nwg) ? tile + (int)gridDim.x : -1;
+        gemm_glds_tile<TBM, TBN, CWM, CWN, STAGES, CONV>(p, tile, smem, next, pf && !first);
+    }
+}
+
 int g_variant = 0;   // 0: symmetric kernel above; 1: loader/consumer 128x128; 2: loader/consumer 256x128 where it fills the chip
 int g_stages = 2;
 int g_dbg = 0;
@@ -304,7 +340,10 @@ int gemm_glds_launch(const GemmArgs& a_in, bool conv, hipStream_t stream) {
         else hipLaunchKernelGGL((gemm_glds_kernel<256, 256, 2, 4, 2, false>), dim3(t256), dim3(512), l, stream, a);
         return MI_OK;
     }
-    const int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
+    int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
+    // persistent grid (two blocks per CU walk the tiles, the next tile's first K tile is prefetched under the epilogue): +1.5-2 % on the
+    // end-to-end step vs one block per tile; HFASR_GEMM_VARIANT=31 restores the one-block-per-tile launch for A/B
+    if (g_variant != 31 && grid > 512) grid = 512;
     const int stages = g_stages;
     const size_t lds = (size_t)stages * STAGE_BYTES;
     if (stages == 4) {
