@@ -27,8 +27,8 @@ class HipStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss):
         out = [None, None]
-        for g in ctx.grads:
-            out.append(None if g is None else g * gloss)
+        for i, g in enumerate(ctx.grads):                   # frozen parameters (requires_grad False: freeze_encoder etc.) get no gradient
+            out.append(None if (g is None or not ctx.needs_input_grad[2 + i]) else g * gloss)
         return tuple(out)
 
 

@@ -219,8 +219,6 @@ class Wav2Vec2EBranchformerForCTC(PreTrainedModel):
         from .autograd_bridge import run_training_forward
         if labels is None:
             raise NotImplementedError("HIP training forward needs `labels` (the CTC loss is the only differentiable output of this head)")
-        if any(not p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("HIP training step with frozen parameters (freeze_encoder / freeze_feature_encoder) is not supported yet")
         if labels.max() >= self.config.vocab_size:
             raise ValueError(f"Label values must be <= vocab_size: {self.config.vocab_size}")
         tr = self._get_trainer(input_values.device)

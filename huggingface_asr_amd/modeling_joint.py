@@ -225,8 +225,6 @@ class JointCTCAttentionEncoderDecoder(PreTrainedModel):
         fl = attention_mask.sum(-1).to(torch.int32) if attention_mask is not None else None
         if training:                                       # forward + backward on the HIP trainer, gradients handed to autograd
             from .autograd_bridge import run_training_forward
-            if any(not p.requires_grad for p in self.parameters()):
-                raise NotImplementedError("HIP training step with frozen parameters is not supported yet")
             tr = self._get_trainer(inputs.device)
 
             def step(t):

@@ -181,6 +181,11 @@ def test_hf_ctc_model_trains_through_autograd_bridge():
         o.loss.backward()
         opt.step()
     assert float(o.loss) < l0
+    # frozen sub-modules (freeze_encoder, train_ctc_asr.py:51-52): their parameters receive no gradient, the head still does
+    model.zero_grad(set_to_none=True)
+    model.freeze_encoder()
+    model(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV)).loss.backward()
+    assert all(p.grad is None for p in model.wav2vec2.encoder.parameters()) and model.lm_head.weight.grad is not None
     # reference-default dropouts: refuse loudly
     dflt = AutoModelForCTC.from_config(Wav2Vec2EBranchformerConfig(**base)).to(DEV).train()
     with pytest.raises(NotImplementedError):
