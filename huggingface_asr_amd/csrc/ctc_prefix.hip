@@ -16,9 +16,11 @@ namespace {
 
 constexpr float LOGZERO = -10000000000.0f;
 
+// log(e^a + e^b).  Hardware exp2 / log2 (v_exp_f32 / v_log_f32, ~1 ulp) instead of libm's expf / log1pf: the 250-step scan is one
+// dependent chain of these per frame on a wave that is alone on its SIMD, so the instruction count of the chain IS the latency.
 __device__ __forceinline__ float lse2(float a, float b) {
     const float m = fmaxf(a, b);
-    return m + log1pf(expf(-fabsf(a - b)));
+    return m + __logf(1.f + __expf(-fabsf(a - b)));
 }
 
 // x = log_softmax(logits) with the padding rule of ctc_scorer.py:39-42 (frames >= len: logzero, blank = 0)
@@ -91,21 +93,36 @@ __global__ __launch_bounds__(256) void prefix_chain_kernel(ChainArgs p) {
     // r[start-1] : only r[0] can be non-logzero (out_len == 0)
     if (start - 1 != 0) r0 = LOGZERO;
     float pm = r0, ps = 1.f;                     // online logsumexp of psi, seeded with r^n_{start-1}
-    for (int t = start; t < p.T; ++t) {
-        const float rp0 = p.r_prev[((long)(t - 1) * 2 + 0) * n_bh + i];
-        const float rp1 = p.r_prev[((long)(t - 1) * 2 + 1) * n_bh + i];
-        const float phi = same ? rp1 : lse2(rp0, rp1);
-        const float xc = xb[(long)t * p.O + c], xbl = xb[(long)t * p.O + p.blank];
-        const float n0 = lse2(r0, phi) + xc;
-        const float n1 = lse2(r0, r1) + xbl;
-        r0 = n0; r1 = n1;
-        if (p.r_out) {
-            p.r_out[((long)t * 2 + 0) * Kt + k] = r0;
-            p.r_out[((long)t * 2 + 1) * Kt + k] = r1;
+    // the loads of a step do not depend on the recursion: fetch UNROLL steps ahead of the dependent lse chain (a lone wave per SIMD has
+    // nobody to hide the ~0.5 us load latency behind; per-step loads made the scan latency-bound at ~1 us per frame)
+    constexpr int UNROLL = 8;
+    for (int t0 = start; t0 < p.T; t0 += UNROLL) {
+        float rp0[UNROLL], rp1[UNROLL], xc[UNROLL], xbl[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int t = t0 + u;
+            const bool ok = t < p.T;
+            rp0[u] = ok ? p.r_prev[((long)(t - 1) * 2 + 0) * n_bh + i] : 0.f;
+            rp1[u] = ok ? p.r_prev[((long)(t - 1) * 2 + 1) * n_bh + i] : 0.f;
+            xc[u] = ok ? xb[(long)t * p.O + c] : 0.f;
+            xbl[u] = ok ? xb[(long)t * p.O + p.blank] : 0.f;
         }
-        const float term = phi + xc;
-        if (term > pm) { ps = ps * expf(pm - term) + 1.f; pm = term; }
-        else ps += expf(term - pm);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int t = t0 + u;
+            if (t >= p.T) break;
+            const float phi = same ? rp1[u] : lse2(rp0[u], rp1[u]);
+            const float n0 = lse2(r0, phi) + xc[u];
+            const float n1 = lse2(r0, r1) + xbl[u];
+            r0 = n0; r1 = n1;
+            if (p.r_out) {
+                p.r_out[((long)t * 2 + 0) * Kt + k] = r0;
+                p.r_out[((long)t * 2 + 1) * Kt + k] = r1;
+            }
+            const float term = phi + xc[u];
+            if (term > pm) { ps = ps * __expf(pm - term) + 1.f; pm = term; }
+            else ps += __expf(term - pm);
+        }
     }
     float psi = pm + logf(ps);
     if (p.scores_out || !p.hyp) { if (c == p.blank) psi = LOGZERO; }            // :173
