@@ -1,0 +1,28 @@
+"""Soak: 40 optimizer steps of the base encoder+CTC trainer WITH the recipes' randomness (dropout 0.1 everywhere, in-model SpecAugment) on a
+fixed synthetic batch: the loss must fall and stay finite, the gradient norm must stay finite (bf16 gradients, clip 1.0, AdamW 1e-3)."""
+import os, sys, json
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from huggingface_asr_amd import shapes, synth
+from huggingface_asr_amd.train import EncoderCTCTrainer
+dev = "cuda:0"
+cfg = dict(shapes.BASE, ctc_zero_infinity=True, ctc_loss_reduction="mean", hidden_dropout=0.1, activation_dropout=0.1, attention_dropout=0.1,
+           final_dropout=0.1, feat_proj_dropout=0.0, csgu_conv_dropout=0.1, layerdrop=0.0, apply_spec_augment=True, mask_time_prob=0.05,
+           mask_time_length=10, mask_time_min_masks=2)
+sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()}
+tr = EncoderCTCTrainer(cfg, dev, lr=1e-3, weight_decay=1e-6, seed=3)
+tr.load_state_dict(sd)
+B, T = 16, 600
+feats = torch.from_numpy(synth.normal(5, "feats", (B, T, 80), 1.0)).to(dev)
+lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+labels = torch.from_numpy(synth.labels(5, B, 20, cfg["vocab_size"])).to(dev)
+np.random.seed(0)
+hist = []
+for step in range(40):
+    o = tr.train_step(feats, lens, labels)
+    hist.append((float(o["loss"]), float(o["grad_norm"])))
+    if step % 5 == 0:
+        print(step, hist[-1], flush=True)
+ok = all(np.isfinite(h).all() for h in hist) and hist[-1][0] < 0.5 * hist[0][0]
+print(json.dumps({"first": hist[0], "last": hist[-1], "ok": bool(ok), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}))
+sys.exit(0 if ok else 1)
