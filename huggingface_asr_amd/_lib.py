@@ -55,6 +55,7 @@ SIGNATURES = {
     "mi_transpose_cast_bct_btc": [vp, vp, i32, i32, i32, vp],
     "mi_add_positions": [vp, vp, vp, i32, i32, i32, vp],
     "mi_transpose_bf16": [vp, i64, vp, i64, i32, i32, i32, vp],
+    "mi_transpose_many_bf16": [vp, i32, vp],
     "mi_colsum": [vp, i64, i32, i32, i32, vp, vp],
     "mi_act_fwd_bf16": [vp, i64, vp, i64, i32, i32, i32, vp],
     "mi_act_bwd_bf16": [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp],
@@ -73,7 +74,7 @@ SIGNATURES = {
     "mi_clip_coef": [vp, f32, vp, vp],
     "mi_adamw_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, vp, vp],
     "mi_gemm_tn_workspace_bytes": [i32, i32, i32],
-    "mi_gemm_tn_bf16": [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp, sz, vp],
+    "mi_gemm_tn_bf16": [vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, i32, vp, sz, vp],
     "mi_bgemm_bf16": [vp, i64, i64, i64, i64, vp, i64, i64, i64, i64, vp, i64, i64, i64, i32, i32, f32, i32, i32, i32, i32, i32, vp],
     "mi_attn_softmax_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, f32, i32, f32, C.c_uint, C.c_uint, vp],
     "mi_attn_softmax_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, f32, f32, C.c_uint, C.c_uint, vp],

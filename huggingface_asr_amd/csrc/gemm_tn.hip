@@ -26,6 +26,7 @@ struct TnArgs {
     const bf16_t* X; long ldx;
     float* out; long ldo;          // splits == 1: dW (accumulated);  else: slab base, slab s at out + s * slab_stride
     long slab_stride;
+    float* db;                     // optional: db[n] += sum_m dY[m][n] (bias gradient), taken from the dY tiles already staged in LDS
     int M, N, K, n_store, splits, rows_per_split;
 };
 
@@ -86,6 +87,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // bias gradient: the blocks of the first k-tile column also sum their dY tile over m (thread = column tid & 127, row half tid >> 7)
+    const bool do_db = p.db != nullptr && (tile % ntk) == 0;
+    const int bn = tid & 127, bh = tid >> 7;
+    float bsum = 0.f;
+
     if (nit > 0) issue(0, 0);
     for (int it = 0; it < nit; ++it) {
         const int stage = it & 1;
@@ -94,6 +100,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
         if (it + 1 < nit) issue(it + 1, stage ^ 1);
         const char* ty = smem + stage * TN_STAGE;
         const char* tx = ty + TN_KM * TN_T * 2;
+        if (do_db) {
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) {
+                const int m = bh * 32 + r;
+                bsum += bf2f(*reinterpret_cast<const bf16_t*>(ty + m * 256 + (((bn >> 3) ^ (m & 15)) << 4) + (bn & 7) * 2));
+            }
+        }
 #pragma unroll
         for (int s = 0; s < TN_KM / 16; ++s) {
             bf16x8 fy[2], fx[2];
@@ -108,6 +121,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);   // rows n (regs), cols k (lanes)
         }
+    }
+    if (do_db) {
+        asm volatile("s_barrier" ::: "memory");                          // every wave is done with the LDS tiles
+        float* red = reinterpret_cast<float*>(smem);
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.n_store) __hip_atomic_fetch_add(p.db + n0 + tid, red[tid] + red[tid + 128], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // C layout: col (k) = lane & 31, row (n) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     const int lr = lane & 31, lh = lane >> 5;
@@ -156,7 +176,8 @@ extern "C" size_t mi_gemm_tn_workspace_bytes(int M, int N, int K) {
 }
 
 // dW (n_store, K) fp32 (row stride ldo) += dY[:, :N]^T · X;  N, K % 8 == 0, rows of dY / X 16-B aligned; n_store <= N
-extern "C" int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx, float* dW, long ldo, int M, int N, int K, int n_store,
+// db (optional, n_store floats): bias gradient db[n] += sum_m dY[m][n], fused (float atomics at block granularity)
+extern "C" int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx, float* dW, long ldo, float* db, int M, int N, int K, int n_store,
                                void* workspace, size_t workspace_bytes, hipStream_t st) {
     MI_ENTER();
     if (M <= 0 || N <= 0 || K <= 0 || (N % 8) || (K % 8) || (ldy % 8) || (ldx % 8) || n_store > N || n_store <= 0) return MI_ERR_ARG;
@@ -165,7 +186,7 @@ extern "C" int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx
     if (splits > 1 && workspace_bytes < (size_t)splits * N * K * sizeof(float)) return MI_ERR_ARG;
     TnArgs p{};
     p.Y = (const bf16_t*)dY; p.ldy = ldy; p.X = (const bf16_t*)X; p.ldx = ldx;
-    p.M = M; p.N = N; p.K = K; p.n_store = n_store; p.splits = splits;
+    p.M = M; p.N = N; p.K = K; p.n_store = n_store; p.splits = splits; p.db = db;
     p.rows_per_split = cdiv(cdiv(M, splits), TN_KM) * TN_KM;
     if (splits > 1) { p.out = (float*)workspace; p.ldo = K; p.slab_stride = (long)N * K; }
     else { p.out = dW; p.ldo = ldo; p.slab_stride = 0; }

@@ -58,6 +58,38 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
     }
 }
 
+// many transposes in one launch (the K-major bf16 copies of every weight matrix after an optimizer step): descriptor i = {in, out, M, N, Mp}
+struct TrDesc { const bf16_t* in; bf16_t* out; int M, N, Mp, pad; };
+__global__ __launch_bounds__(256) void transpose_many_kernel(const TrDesc* __restrict__ descs, int tiles_x_max) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[TR][TR + 8];
+    const TrDesc d = descs[blockIdx.y];
+    const int ntx = (d.N + TR - 1) / TR, nty = (d.Mp + TR - 1) / TR;
+    const int tid = threadIdx.x;
+    for (int t = blockIdx.x; t < ntx * nty; t += gridDim.x) {
+        const int n0 = (t % ntx) * TR, m0 = (t / ntx) * TR;
+        __syncthreads();
+        for (int id = tid; id < TR * 8; id += 256) {
+            const int r = id >> 3, ch = id & 7;
+            const int m = m0 + r, n = n0 + ch * 8;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (m < d.M && n + 8 <= d.N) v = *reinterpret_cast<const bf16x8*>(d.in + (long)m * d.N + n);
+            else if (m < d.M)
+                for (int j = 0; j < 8; ++j) if (n + j < d.N) v[j] = d.in[(long)m * d.N + n + j];
+            *reinterpret_cast<bf16x8*>(&tile[r][ch * 8]) = v;
+        }
+        __syncthreads();
+        for (int id = tid; id < TR * 8; id += 256) {
+            const int r = id >> 3, ch = id & 7;
+            const int n = n0 + r, m = m0 + ch * 8;
+            if (n >= d.N || m >= d.Mp) continue;
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tile[ch * 8 + j][r];
+            *reinterpret_cast<bf16x8*>(d.out + (long)n * d.Mp + m) = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ column sums (bias grads)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long ld, int M, int N, float* __restrict__ out,
@@ -382,6 +414,15 @@ extern "C" int mi_transpose_bf16(const void* in, long ld_in, void* out, long ld_
     const int vec = ((ld_in % 8) == 0 && (ld_out % 8) == 0 && (Mp % 8) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
                      (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? 1 : 0;
     hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(N, TR), cdiv(Mp, TR)), dim3(256), 0, st, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, M, N, Mp, vec);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// descs: device array of `count` {in (M,N) contiguous bf16, out (N,Mp) contiguous bf16, M, N, Mp, pad}; N % 8 == 0, Mp % 8 == 0, 16-B aligned
+extern "C" int mi_transpose_many_bf16(const void* descs, int count, hipStream_t st) {
+    MI_ENTER();
+    if (count <= 0 || count > 65535) return MI_ERR_ARG;
+    hipLaunchKernelGGL(transpose_many_kernel, dim3(32, count), dim3(256), 0, st, (const TrDesc*)descs, 0);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

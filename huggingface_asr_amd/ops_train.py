@@ -259,8 +259,9 @@ def adamw_step_(p, g, m, v, decay, *, lr, betas=(0.9, 0.999), eps=1e-8, weight_d
 _TN_WS = {}
 
 
-def gemm_tn_(dw, dy, x, n_store=None):
-    """dw (n_store, K) f32 += dy[:, :N]^T · x   (dy (M,N) bf16, x (M,K) bf16 row views; contraction over rows, no transposes)."""
+def gemm_tn_(dw, dy, x, n_store=None, db=None):
+    """dw (n_store, K) f32 += dy[:, :N]^T · x   (dy (M,N) bf16, x (M,K) bf16 row views; contraction over rows, no transposes).
+    db (n_store) f32: the bias gradient db += column sums of dy, computed from the same LDS tiles."""
     M, N = dy.shape
     K = x.shape[1]
     n_store = dw.shape[0] if n_store is None else n_store
@@ -269,7 +270,7 @@ def gemm_tn_(dw, dy, x, n_store=None):
     ws = _TN_WS.get(key)
     if nbytes and (ws is None or ws.numel() < nbytes):
         ws = _TN_WS[key] = torch.empty(nbytes, device=dy.device, dtype=torch.uint8)
-    _lib.check(_L().mi_gemm_tn_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0), M, N, K, n_store,
+    _lib.check(_L().mi_gemm_tn_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0), _p(db), M, N, K, n_store,
                                     ws.data_ptr() if nbytes else 0, nbytes, _stream()), "mi_gemm_tn_bf16")
     return dw
 
@@ -285,7 +286,7 @@ def linear_bwd(dy, x, wT, *, dw=None, db=None, dx_out=None, dx_dtype=BF16, need_
     if need_dx:
         dx = gemm(dy, wT[:, :N], out=dx_out, out_dtype=dx_dtype)
     if dw is not None:
-        gemm_tn_(dw, dy, x)
-    if db is not None:
+        gemm_tn_(dw, dy, x, db=db)                 # bias gradient fused into the weight-gradient GEMM
+    elif db is not None:
         colsum_(db, dy)
     return dx

@@ -93,9 +93,23 @@ class ParamStore:
         return lo, hi
 
     def refresh_mirrors(self, cast=True):
-        """bf16 mirror (if not already written by the optimizer kernel) + transposed copies of every matrix."""
+        """bf16 mirror (if not already written by the optimizer kernel) + transposed copies of every matrix (ONE launch for all of them)."""
         if cast:
             ops_cast_flat(self.flat_p, self.flat_bf)
+        if getattr(self, "_tr_descs", None) is None:
+            import numpy as np
+            rec = np.zeros(len(self.offT), dtype=np.dtype([("in", "<u8"), ("out", "<u8"), ("M", "<i4"), ("N", "<i4"), ("Mp", "<i4"), ("pad", "<i4")]))
+            ok = self.device.type == "cuda"
+            for i, name in enumerate(self.offT):
+                N, K = self.specs[name].shape
+                rec[i] = (self.bf(name).data_ptr(), self.bfT(name).data_ptr(), N, K, _al(N), 0)
+                ok = ok and K % 8 == 0
+            self._tr_descs = torch.from_numpy(rec.view(np.uint8).copy()).to(self.device) if ok and len(rec) else False
+            self._tr_count = len(rec)
+        if self._tr_descs is not False:
+            ops._lib.check(ops._lib.lib().mi_transpose_many_bf16(self._tr_descs.data_ptr(), self._tr_count, torch.cuda.current_stream().cuda_stream),
+                           "mi_transpose_many_bf16")
+            return
         for name, s in self.specs.items():
             if s.mat:
                 N, K = s.shape
@@ -483,8 +497,7 @@ class EncoderCTCTrainer:
             dhid = T.gemm(dlog, WT("head_w"))                                                                # (M, d) bf16
             if pd["final"] > 0:
                 T.dropout_(dhid, pd["final"], seed, self._sid(L, 2))
-            T.gemm_tn_(G("head_w"), dlog, hid, n_store=V1)
-            T.colsum_(G("head_b"), dlog[:, :V1])
+            T.gemm_tn_(G("head_w"), dlog, hid, n_store=V1, db=G("head_b"))
         dx = e32(M, d)
         if dhid is not None:
             T.layernorm_bwd(x, P("enc_ln_g"), dhid, dx, accumulate=False, dgamma=G("enc_ln_g"), dbeta=G("enc_ln_b"), eps=eps_e)
@@ -554,9 +567,8 @@ class EncoderCTCTrainer:
         T.layernorm_bwd(feo, P("fp_ln_g"), da, dfeo, accumulate=False, dgamma=G("fp_ln_g"), dbeta=G("fp_ln_b"), eps=eps_e)
         dact2 = T.linear_bwd(T.add_cast(dfeo), act2, WT("feout_w"), dw=G("feout_w"), db=G("feout_b"))      # (M, F2*C2)
         dpre2 = T.act_bwd(dact2.view(B * T2 * F2, C2), pre2)
-        T.colsum_(G("conv2_b"), dpre2)
         col = T.im2col(act1, K, s_, pad, T2, F2)
-        T.gemm_tn_(G("conv2_w"), dpre2, col)
+        T.gemm_tn_(G("conv2_w"), dpre2, col, db=G("conv2_b"))
         dcol = ops.gemm(dpre2, WT("conv2_w")[:, :C2])
         del col
         T.conv2d_first_bwd(feats, P("conv1_w"), P("conv1_b"), dcol, G("conv1_w"), G("conv1_b"), K, s_, pad, T1, F1, K, s_, pad, T2, F2)

@@ -112,8 +112,7 @@ class BestRQTrainer:
                     one = torch.tensor([0.0, 1.0], device=dev)  # weight / count = 1 / (books * world): gradient of the SUM
                     dl = T.ce_label_smoothing_bwd(lg, lab, one, shift=0, eps=0.0, weight=1.0 / (self.nb * world), ldo=Cp)
                     ops.gemm(dl, WT(f"cls{k}_w"), out=dh, resid=dh, alpha=1.0)
-                    T.gemm_tn_(G(f"cls{k}_w"), dl, hb, n_store=self.C)
-                    T.colsum_(G(f"cls{k}_b"), dl[:, :self.C])
+                    T.gemm_tn_(G(f"cls{k}_w"), dl, hb, n_store=self.C, db=G(f"cls{k}_b"))
             out.update(loss=loss, logits=logits)
             return dh
 

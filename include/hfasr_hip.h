@@ -143,6 +143,7 @@ int mi_ce_label_smoothing(const float* logits, long ld, const long* labels, int 
  *           (src/utilities/training_utils.py:93-115 GradAwareTrainer.training_step; recipes .../train_small_baseline.sh:43,53-58).
  * Activations bf16, residual stream / parameter gradients fp32; parameter gradients ACCUMULATE (+=). */
 int mi_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int M, int N, int Mp, mi_stream_t stream);
+int mi_transpose_many_bf16(const void* descs, int count, mi_stream_t stream);   /* descs: device array of {const void* in; void* out; int M, N, Mp, pad;} */
 int mi_colsum(const void* x, long ld, int dtype, int M, int N, float* out, mi_stream_t stream);
 int mi_act_fwd_bf16(const void* pre, long ldp, void* out, long ldo, int M, int N, int kind, mi_stream_t stream);
 int mi_act_bwd_bf16(const void* dy, long lddy, const void* pre, long ldp, void* dx, long lddx, int M, int N, int kind,
@@ -173,8 +174,8 @@ int mi_adamw_step(float* p, const float* g, float* m, float* v, const unsigned c
                   mi_stream_t stream);
 /* weight-gradient GEMM dW (n_store, K) fp32 += dY[:, :N]^T · X (contraction over the rows of both operands, split over M) */
 size_t mi_gemm_tn_workspace_bytes(int M, int N, int K);
-int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx, float* dW, long ldo, int M, int N, int K, int n_store,
-                    void* workspace, size_t workspace_bytes, mi_stream_t stream);
+int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx, float* dW, long ldo, float* db /* optional bias gradient */, int M, int N,
+                    int K, int n_store, void* workspace, size_t workspace_bytes, mi_stream_t stream);
 /* strided batched GEMM C[z1,z2] = alpha * A[z1,z2] · B[z1,z2]^T (+ C): the per-(utterance, head) products of attention backward */
 int mi_bgemm_bf16(const void* A, long a_z1, long a_z2, long a_m, long a_k, const void* B, long b_z1, long b_z2, long b_n, long b_k,
                   void* C, long c_z1, long c_z2, long c_m, int out_f32, int accumulate, float alpha, int Z1, int Z2, int M, int N,

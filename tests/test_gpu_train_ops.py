@@ -116,8 +116,10 @@ def test_gemm_tn_weight_gradient(M, N, K, ns):
     want = (dy.t() @ x)[:ns]
     base = rnd(ns, K, seed=3)
     dw = base.clone().to(DEV)
-    T.gemm_tn_(dw, dev16(dy), dev16(x), n_store=ns)
+    db = torch.ones(ns, device=DEV)
+    T.gemm_tn_(dw, dev16(dy), dev16(x), n_store=ns, db=db)
     torch.testing.assert_close(dw.cpu() - base, want, atol=3e-3 * float(want.abs().max()), rtol=1e-3)
+    torch.testing.assert_close(db.cpu() - 1.0, dy.sum(0)[:ns], atol=2e-3 * float(dy.sum(0).abs().max()) + 1e-3, rtol=1e-3)      # fused bias gradient
     # strided operand views (a column block of a wider activation)
     wide = dev16(torch.cat([x, dy], 1))
     dw2 = torch.zeros(ns, K, device=DEV)
