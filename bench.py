@@ -100,7 +100,6 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events on the GEMM kernel")
     ap.add_argument("--event-stride", type=int, default=7, help="time every n-th GEMM launch with HIP events (1 = all)")
     ap.add_argument("--pos", default="relative", choices=["relative", "rotary"])
-    ap.add_argument("--streams", type=int, default=1, help="process the per-GPU batch as S independent sub-batches on S HIP streams")
     args = ap.parse_args()
 
     from huggingface_asr_amd import parallel as PL
@@ -122,32 +121,11 @@ def main():
     tables = FB.FbankTables(80)
     tables.device(dev)
 
-    S = max(1, args.streams)
-    side = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else []
-    cuts = [(i * B // S, (i + 1) * B // S) for i in range(S)]
-
     def step():
-        if S == 1:
-            feats, frames = FB.fbank_gpu(wave, tables, pad_frames_to=100)
-            out = eng.forward(feats, frames, want_hidden=False)
-            loss, _, _ = ops.ctc_loss(out["logits"], labels, out["outer_len"], reduction="mean", zero_infinity=True)
-            return loss
-        # utterances are independent in forward: S sub-batches run concurrently, each kernel's fill/drain and epilogue
-        # overlapping the other streams' main loops; per-utterance NLLs are reduced to the batch-mean loss at the end
-        main = torch.cuda.current_stream()
-        nlls, tls = [], []
-        for i, (a, b) in enumerate(cuts):
-            side[i].wait_stream(main)
-            with torch.cuda.stream(side[i]):
-                feats, frames = FB.fbank_gpu(wave[a:b], tables, pad_frames_to=100)
-                out = eng.forward(feats, frames, want_hidden=False, slot=i)
-                _, nll, tl = ops.ctc_loss(out["logits"], labels[a:b], out["outer_len"], reduction="mean", zero_infinity=True)
-                nlls.append(nll); tls.append(tl)
-        for st in side:
-            main.wait_stream(st)
-        nll, tl = torch.cat(nlls), torch.cat(tls)
-        nll = torch.where(torch.isinf(nll), torch.zeros_like(nll), nll)
-        return (nll / tl.clamp(min=1)).mean()
+        feats, frames = FB.fbank_gpu(wave, tables, pad_frames_to=100)
+        out = eng.forward(feats, frames, want_hidden=False)
+        loss, _, _ = ops.ctc_loss(out["logits"], labels, out["outer_len"], reduction="mean", zero_infinity=True)
+        return loss
 
     L = _lib.lib()
     use_events = not args.no_kernel_events
@@ -155,10 +133,6 @@ def main():
     if use_events:
         _lib.check(L.mi_profile_create(n_gemm_per_step * args.steps + 64), "mi_profile_create")
 
-    if S > 1:       # fills the shared position-projection cache on slot 0 before streams fan out
-        f0, fr0 = FB.fbank_gpu(wave[cuts[0][0]:cuts[0][1]], tables, pad_frames_to=100)
-        eng.forward(f0, fr0, want_hidden=False, slot=0)
-        torch.cuda.synchronize()
     for _ in range(args.warmup):
         loss = step()
     # HIP events (recorded on the launch stream) bracket every 7th launch of the dense GEMM kernel inside the timed region:
@@ -205,7 +179,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"E-Branchformer-base enc+CTC ({args.pos}-pos), {B}x{SECONDS}s 16kHz clips/GPU: "
                                    "fbank+CMVN -> conv2d sub -> 16 layers -> CTC head -> CTC loss",
-                       "per_gpu_batch": B, "frames": 1000, "encoder_frames": T2, "parallelism": f"replicas x{world} (no exchange step)", "streams_per_gpu": S,
+                       "per_gpu_batch": B, "frames": 1000, "encoder_frames": T2, "parallelism": f"replicas x{world} (no exchange step)",
                        "algorithmic_gflop_per_audio_s": round(algorithmic_gflop_per_utt(cfg, T2) / SECONDS, 3),
                        "ctc_loss": round(loss_v, 4)},
             "roofline": roof,

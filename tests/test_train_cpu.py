@@ -58,13 +58,16 @@ def _worker(rank, world, port, out):
     from huggingface_asr_amd import parallel as P
     P.init("gloo")
     n = 1000
-    flat = torch.arange(n, dtype=torch.float32) * (rank + 1)          # stand-in for this rank's flat gradient
-    sync = GradSync(flat)
-    assert sync.on and sync.world == world
-    for lo, hi in ((768, 1000), (256, 768), (0, 256)):               # head bucket, layer buckets in reverse order, front end
-        sync.launch(lo, hi)
-    sync.wait()
-    out[rank] = flat.clone()
+    for overlap in (False, True):                                     # one merged collective after the backward / one per bucket as it is final
+        flat = torch.arange(n, dtype=torch.float32) * (rank + 1)      # stand-in for this rank's flat gradient
+        sync = GradSync(flat, overlap=overlap)
+        assert sync.on and sync.world == world and sync.overlap == overlap
+        for lo, hi in ((768, 1000), (256, 768), (0, 256)):           # head bucket, layer buckets in reverse order, front end
+            sync.launch(lo, hi)
+        assert len(sync.pending) == (3 if overlap else 0)
+        sync.wait()
+        assert not sync.pending and sync._span is None
+        out[(rank, overlap)] = flat.clone()
     P.barrier()
     torch.distributed.destroy_process_group()
 
@@ -75,7 +78,8 @@ def test_gradsync_gloo_world2_sums_every_bucket():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     want = torch.arange(1000, dtype=torch.float32) * 3
-    assert torch.equal(out[0], want) and torch.equal(out[1], want)
+    for key in ((0, False), (1, False), (0, True), (1, True)):
+        assert torch.equal(out[key], want), key
 
 
 def test_gradsync_single_process_is_a_noop():

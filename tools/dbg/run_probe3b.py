@@ -1,0 +1,55 @@
+import os, sys, ctypes, numpy as np, torch
+here = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(here, "..", ".."))
+exec(open(os.path.join(here, "..", "race_screen.py")).read().split("noise_src =")[0])
+P = ctypes.CDLL(os.path.join(here, f"libcsgu_probe3_v{sys.argv[1]}.so"))
+P.probe3_launch.restype = ctypes.c_int
+P.probe3_launch.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p,
+                            ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+Cc = I // 2
+xg = h[:, Cc:]; xr = h[:, :Cc]
+nblk = (Cc // 64) * ((T + 127) // 128) * B
+side = torch.cuda.Stream()
+ones, zeros = torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
+gr = torch.rand(Cc, device=dev) + 1.0          # distinct values in [1, 2)
+br = torch.rand(Cc, device=dev) + 3.0          # distinct values in [3, 4)
+def run3(gam, bet):
+    st = ops.row_stats(xg)
+    out = torch.empty((M, Cc), device=dev, dtype=torch.bfloat16)
+    d1 = torch.zeros(nblk * 158 * 64, device=dev)
+    rc = P.probe3_launch(xg.data_ptr(), h.stride(0), st.data_ptr(), gam.data_ptr(), bet.data_ptr(), xr.data_ptr(), h.stride(0), cw.data_ptr(), cb.data_ptr(),
+                         out.data_ptr(), out.stride(0), B, T, Cc, d1.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    return out, d1
+_, xn = run3(ones, zeros); _, ref = run3(gr, br); torch.cuda.synchronize()
+xn = xn.cpu().numpy(); refc = ref.cpu().numpy(); G = gr.cpu().numpy(); Bv = br.cpu().numpy()
+found = 0
+for trial in range(40):
+    with torch.cuda.stream(side):
+        for _ in range(2): o, d1 = run3(gr, br)
+    om = cases["gemm"](); torch.cuda.synchronize()
+    dd = (d1.view(torch.int32) != ref.view(torch.int32)).nonzero().flatten().tolist()
+    if not dd: continue
+    found += 1
+    d1c = d1.cpu().numpy()
+    print(f"trial {trial}: {len(dd)} tile words differ")
+    for i in dd[:2]:
+        blk, rem = divmod(i, 158 * 64); r, c = divmod(rem, 64)
+        c0 = (blk % (Cc // 64)) * 64
+        x, bad, good = float(xn[i]), float(d1c[i]), float(refc[i])
+        g0, b0 = float(G[c0 + c]), float(Bv[c0 + c])
+        msg = f"   blk {blk} r {r} c {c}: x {x:.6f} g {g0:.6f} b {b0:.6f} good {good:.6f} bad {bad:.6f}"
+        # hypotheses
+        hyp = {"x*g (b=0)": x * g0, "b only (g=0)": b0, "x (g=1,b=0)": x, "0": 0.0, "x+b (g=1)": x + b0}
+        for name, v in hyp.items():
+            if abs(v - bad) < 1e-5 * max(1, abs(bad)): msg += f"  == {name}"
+        # other channel's gamma / beta?
+        if abs(x) > 1e-3:
+            gq = (bad - b0) / x
+            j = np.argmin(np.abs(G - gq))
+            if abs(G[j] - gq) < 1e-5: msg += f"  == x*g[{j}]+b (own c {c0 + c})"
+        bq = bad - x * g0
+        j = np.argmin(np.abs(Bv - bq))
+        if abs(Bv[j] - bq) < 1e-5: msg += f"  == x*g+b[{j}] (own c {c0 + c})"
+        print(msg)
+print("trials with corrupted tiles:", found)
