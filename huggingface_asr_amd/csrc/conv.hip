@@ -194,50 +194,81 @@ __global__ __launch_bounds__(256) void dwconv_time_kernel(DwArgs p) {
 // LDS, every thread keeps a 62-sample window + the 31 taps of its channel in registers and produces 32 consecutive
 // outputs (93 LDS reads per 992 FMAs), and the result leaves as 16-B-per-lane rows.
 constexpr int DWF_K = 31, DWF_TT = 128, DWF_CT = 64, DWF_ROWS = DWF_TT + DWF_K - 1, DWF_PER = DWF_TT / 4;
+constexpr int DWF_WS = DWF_CT + 1, DWF_WBUF = (DWF_K * DWF_WS + 3) / 4 * 4;     // weight rows padded to 65 floats; buffer rounded so `io` stays 16-B aligned
 
 template <bool CSGU>
 __global__ __launch_bounds__(256) void dwconv31_kernel(DwArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tile = reinterpret_cast<float*>(smem);                          // [DWF_ROWS][64] fp32
-    float* sw = tile + DWF_ROWS * DWF_CT;                                  // [31][64]
-    bf16_t* io = reinterpret_cast<bf16_t*>(sw + DWF_K * DWF_CT);           // [128][64] bf16: x_r in, result out
+    float* sw = tile + DWF_ROWS * DWF_CT;                                  // [31][DWF_WS]: tap-major, row stride 65 (conflict-free transposed fill)
+    bf16_t* io = reinterpret_cast<bf16_t*>(sw + DWF_WBUF);                 // [128][64] bf16: x_r in, result out
     const int c0 = blockIdx.x * DWF_CT, t0 = blockIdx.y * DWF_TT, b = blockIdx.z;
     const int tid = threadIdx.x;
-    for (int i = tid; i < DWF_K * DWF_CT; i += 256) {
-        const int k = i / DWF_CT, cc = i % DWF_CT;
-        sw[i] = p.w[(long)(c0 + cc) * DWF_K + k];
-    }
-    for (int id = tid; id < DWF_ROWS * (DWF_CT / 8); id += 256) {
-        const int r = id >> 3, ch = id & 7;
-        const int t = t0 - p.pad_left + r;
-        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-        if (t >= 0 && t < p.T) {
-            const long row = (long)b * p.T + t;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(p.in + row * p.ld_in + c0 + ch * 8);
-            float f[8];
+    // the block's 64 x 31 taps are one contiguous run of the (C, 31) weight: read it linearly (coalesced), all passes in flight together
+    constexpr int NPW = (DWF_K * DWF_CT + 255) / 256;
+    float wv[NPW];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = bf2f(v[j]);
-            if (CSGU) {
-                const float mu = p.stats[2 * row], rs = p.stats[2 * row + 1];
-                const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + c0 + ch * 8), g1 = *reinterpret_cast<const f32x4*>(p.gamma + c0 + ch * 8 + 4);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + c0 + ch * 8), b1 = *reinterpret_cast<const f32x4*>(p.beta + c0 + ch * 8 + 4);
-                lo = f32x4{(f[0] - mu) * rs * g0.x + b0.x, (f[1] - mu) * rs * g0.y + b0.y, (f[2] - mu) * rs * g0.z + b0.z, (f[3] - mu) * rs * g0.w + b0.w};
-                hi = f32x4{(f[4] - mu) * rs * g1.x + b1.x, (f[5] - mu) * rs * g1.y + b1.y, (f[6] - mu) * rs * g1.z + b1.z, (f[7] - mu) * rs * g1.w + b1.w};
-            } else {
-                lo = f32x4{f[0], f[1], f[2], f[3]};
-                hi = f32x4{f[4], f[5], f[6], f[7]};
-            }
+    for (int q = 0; q < NPW; ++q) wv[q] = p.w[(long)c0 * DWF_K + min(tid + q * 256, DWF_K * DWF_CT - 1)];
+    // Fill: every global load of the block (5 passes of the conv input, their row statistics, 4 passes of the gate operand, the LayerNorm
+    // affine) is issued before the first one is consumed — one memory round trip per block instead of one per pass; the block has only
+    // one or two companions on its CU, so a pass-by-pass load -> wait -> ds_write loop leaves the memory pipe idle most of the time.
+    constexpr int NPI = (DWF_ROWS * (DWF_CT / 8) + 255) / 256, NPO = DWF_TT * (DWF_CT / 8) / 256;
+    const int ch = tid & 7;                                                // 256 % 8 == 0: a thread keeps its 16-B channel chunk in every pass
+    bf16x8 vin[NPI], vio[NPO];
+    float mu[NPI], rs[NPI];
+    bool ok[NPI];
+#pragma unroll
+    for (int q = 0; q < NPI; ++q) {                                        // branch-free: out-of-range rows read a clamped (valid) row and are zeroed below
+        const int id = tid + q * 256, r = id >> 3;
+        const int t = t0 - p.pad_left + r;
+        ok[q] = id < DWF_ROWS * (DWF_CT / 8) && t >= 0 && t < p.T;
+        const long row = (long)b * p.T + min(max(t, 0), p.T - 1);
+        vin[q] = *reinterpret_cast<const bf16x8*>(p.in + row * p.ld_in + c0 + ch * 8);
+        mu[q] = 0.f; rs[q] = 0.f;
+        if (CSGU) { mu[q] = p.stats[2 * row]; rs[q] = p.stats[2 * row + 1]; }
+    }
+    f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0, b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (CSGU) {
+        g0 = *reinterpret_cast<const f32x4*>(p.gamma + c0 + ch * 8); g1 = *reinterpret_cast<const f32x4*>(p.gamma + c0 + ch * 8 + 4);
+        b0 = *reinterpret_cast<const f32x4*>(p.beta + c0 + ch * 8);  b1 = *reinterpret_cast<const f32x4*>(p.beta + c0 + ch * 8 + 4);
+#pragma unroll
+        for (int q = 0; q < NPO; ++q) {
+            const int r = (tid + q * 256) >> 3, t = t0 + r;
+            vio[q] = *reinterpret_cast<const bf16x8*>(p.mul + ((long)b * p.T + min(t, p.T - 1)) * p.ld_mul + c0 + ch * 8);   // rows past T: never stored
         }
-        *reinterpret_cast<f32x4*>(tile + r * DWF_CT + ch * 8) = lo;
-        *reinterpret_cast<f32x4*>(tile + r * DWF_CT + ch * 8 + 4) = hi;
+    }
+    __builtin_amdgcn_sched_barrier(0);                                     // keep the loads above in front of their uses below
+#pragma unroll
+    for (int q = 0; q < NPW; ++q) {
+        const int i = tid + q * 256;
+        if (i < DWF_K * DWF_CT) sw[(i % DWF_K) * DWF_WS + i / DWF_K] = wv[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NPI; ++q) {
+        const int id = tid + q * 256, r = id >> 3;
+        if (id < DWF_ROWS * (DWF_CT / 8)) {
+            f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+            if (ok[q]) {
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = bf2f(vin[q][j]);
+                if (CSGU) {
+                    lo = f32x4{(f[0] - mu[q]) * rs[q] * g0.x + b0.x, (f[1] - mu[q]) * rs[q] * g0.y + b0.y, (f[2] - mu[q]) * rs[q] * g0.z + b0.z, (f[3] - mu[q]) * rs[q] * g0.w + b0.w};
+                    hi = f32x4{(f[4] - mu[q]) * rs[q] * g1.x + b1.x, (f[5] - mu[q]) * rs[q] * g1.y + b1.y, (f[6] - mu[q]) * rs[q] * g1.z + b1.z, (f[7] - mu[q]) * rs[q] * g1.w + b1.w};
+                } else {
+                    lo = f32x4{f[0], f[1], f[2], f[3]};
+                    hi = f32x4{f[4], f[5], f[6], f[7]};
+                }
+            }
+            *reinterpret_cast<f32x4*>(tile + r * DWF_CT + ch * 8) = lo;
+            *reinterpret_cast<f32x4*>(tile + r * DWF_CT + ch * 8 + 4) = hi;
+        }
     }
     if (CSGU) {
-        for (int id = tid; id < DWF_TT * (DWF_CT / 8); id += 256) {
-            const int r = id >> 3, ch = id & 7;
-            const int t = t0 + r;
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (t < p.T) v = *reinterpret_cast<const bf16x8*>(p.mul + ((long)b * p.T + t) * p.ld_mul + c0 + ch * 8);
-            *reinterpret_cast<bf16x8*>(io + r * DWF_CT + ch * 8) = v;
+#pragma unroll
+        for (int q = 0; q < NPO; ++q) {
+            const int r = (tid + q * 256) >> 3;
+            *reinterpret_cast<bf16x8*>(io + r * DWF_CT + ch * 8) = vio[q];
         }
     }
     __syncthreads();
@@ -245,7 +276,7 @@ __global__ __launch_bounds__(256) void dwconv31_kernel(DwArgs p) {
     const int c = c0 + tx;
     float wk[DWF_K];
 #pragma unroll
-    for (int k = 0; k < DWF_K; ++k) wk[k] = sw[k * DWF_CT + tx];
+    for (int k = 0; k < DWF_K; ++k) wk[k] = sw[k * DWF_WS + tx];
     float win[DWF_PER + DWF_K - 1];
 #pragma unroll
     for (int i = 0; i < DWF_PER + DWF_K - 1; ++i) win[i] = tile[(ty * DWF_PER + i) * DWF_CT + tx];
@@ -320,7 +351,7 @@ static int dw_launch(const DwArgs& a, bool csgu, hipStream_t stream) {
                       (!csgu || ((a.ld_mul % 8) == 0 && (((uintptr_t)a.mul) & 15) == 0)) && (!csgu || (((uintptr_t)a.gamma | (uintptr_t)a.beta) & 15) == 0);
     if (fast) {
         dim3 gridf(a.C / DWF_CT, cdiv(a.T, DWF_TT), a.B);
-        const size_t ldsf = (size_t)(DWF_ROWS * DWF_CT + DWF_K * DWF_CT) * sizeof(float) + (size_t)DWF_TT * DWF_CT * sizeof(bf16_t);
+        const size_t ldsf = (size_t)(DWF_ROWS * DWF_CT + DWF_WBUF) * sizeof(float) + (size_t)DWF_TT * DWF_CT * sizeof(bf16_t);
         if (csgu) hipLaunchKernelGGL(dwconv31_kernel<true>, gridf, dim3(256), ldsf, stream, a);
         else hipLaunchKernelGGL(dwconv31_kernel<false>, gridf, dim3(256), ldsf, stream, a);
         MI_CHECK_LAUNCH();
