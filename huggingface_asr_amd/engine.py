@@ -44,7 +44,7 @@ def cfg_from_hf(config) -> dict:
                 hidden_act=g("hidden_act", "gelu"), feat_extract_activation=g("feat_extract_activation", "gelu"),
                 mask_time_prob=g("mask_time_prob", 0.05), mask_feature_prob=g("mask_feature_prob", 0.0),
                 ctc_loss_reduction=g("ctc_loss_reduction", "sum"), ctc_zero_infinity=g("ctc_zero_infinity", False),
-                # training-mode randomness (dropout sites, in-model SpecAugment; layerdrop > 0 is refused by train.py)
+                # training-mode randomness (dropout sites, in-model SpecAugment, LayerDrop: train.py)
                 hidden_dropout=g("hidden_dropout", 0.0), activation_dropout=g("activation_dropout", 0.0), attention_dropout=g("attention_dropout", 0.0),
                 final_dropout=g("final_dropout", 0.0), feat_proj_dropout=g("feat_proj_dropout", 0.0), layerdrop=g("layerdrop", 0.0),
                 csgu_conv_dropout=g("csgu_conv_dropout", 0.0), apply_spec_augment=g("apply_spec_augment", False),

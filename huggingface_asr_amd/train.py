@@ -17,7 +17,7 @@ Precision model = the reference's autocast recipe: fp32 master weights and resid
 activation gradients), fp32 accumulation, fp32 LayerNorm / softmax / CTC, fp32 parameter gradients.
 Dropout (all eight sites of the layer, encoder input, feature projection, CTC head) uses counter-based masks that the backward
 pass regenerates; in-model SpecAugment draws its masks on the host with transformers' own `_compute_mask_indices` (numpy RNG), exactly as the
-reference does.  Not on this path (raise NotImplementedError): LayerDrop (the recipes force it to 0), causal encoders.
+reference does (LayerDrop included).  Not on this path (raise NotImplementedError): causal encoders.
 """
 from __future__ import annotations
 
@@ -273,6 +273,16 @@ class GradSync:
             self.dist.all_reduce(self.flat_g[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group)
 
 
+def _u01(seed: int, stream: int) -> float:
+    """one uniform number in [0, 1) from the counter-based generator of the dropout masks (splitmix64 of (stream << 32) ^ seed)"""
+    m = (1 << 64) - 1
+    z = ((((stream & 0xFFFFFFFF) << 32) ^ (seed & 0xFFFFFFFF)) + 0x9E3779B97F4A7C15) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    z ^= z >> 31
+    return (z >> 11) / float(1 << 53)
+
+
 # ====================================================================================================== trainer
 class EncoderCTCTrainer:
     """forward + backward + AdamW for Wav2Vec2EBranchformerForCTC on one GPU (one process per GPU under DP)."""
@@ -288,8 +298,7 @@ class EncoderCTCTrainer:
             raise NotImplementedError("training path: 2-layer 3x3 Conv2d sub-sampling only")
         if c.get("csgu_activation", "identity") != "identity" or c.get("csgu_use_linear_after_conv", False):
             raise NotImplementedError("training path: CSGU with identity activation and no linear-after-conv only")
-        if float(c.get("layerdrop", 0.0) or 0.0) != 0.0:
-            raise NotImplementedError("training path: layerdrop > 0 is not supported (the reference's recipes force it to 0.0, model_utils.py:125,160)")
+        self.layerdrop = float(c.get("layerdrop", 0.0) or 0.0)      # tf:models/wav2vec2_conformer/modeling_wav2vec2_conformer.py:686-690
         g = lambda k: float(c.get(k, 0.0) or 0.0)
         # dropout probabilities by site (which config value feeds which nn.Dropout: e_branchformer.py:132,182,229-246,451; tf :353,356,674)
         self.pdrop = dict(act=g("activation_dropout"), hidden=g("hidden_dropout"), att=g("attention_dropout"), csgu=g("csgu_conv_dropout"),
@@ -373,13 +382,16 @@ class EncoderCTCTrainer:
 
     # ------------------------------------------------------------------ forward + backward
     def forward_backward(self, feats, feat_lengths, labels, *, loss_scale=1.0, extra_hidden_grad=None, backward=True, keep_hidden=False,
-                         train_mode=False, step_index=None, noise_mask=None):
+                         train_mode=False, step_index=None, noise_mask=None, skip_layers=None):
         """feats (B,T,F) f32 device; feat_lengths (B) int32 or None; labels (B,U) int64 (<0 = padding).
         Returns dict(loss, logits (B,T2,V+1) f32, outer_len, last_hidden).  Gradients of loss_scale/world * loss accumulate into the store.
         `extra_hidden_grad`: optional callable(last_hidden f32 (M,d), outer_len (B) int32) -> f32 (M,d) gradient to add at the encoder output
         (the attention decoder of the joint model hooks in here).
         `noise_mask` = (time mask (B*T2) uint8, std): BEST-RQ masking — those frames of the encoder input are replaced by N(0, std) noise
-        (bestrq.py:84-97), counter-based like the dropout masks (global stream site 3)."""
+        (bestrq.py:84-97), counter-based like the dropout masks (global stream site 3).
+        `skip_layers`: LayerDrop decisions for this step (iterable of layer indices that are skipped: the layer is the identity and its
+        parameters get no gradient).  None = draw them as the reference does — one uniform number per layer and step, layer skipped when it
+        is below `config.layerdrop` (every rank draws its own, from its dropout seed) — in training mode; nothing is skipped in eval."""
         c, st = self.cfg, self.store
         P, G, W, WT = st.p, st.g, st.bf, st.bfT
         dev = self.device
@@ -436,8 +448,15 @@ class EncoderCTCTrainer:
             T.dropout_(x, pd["hidden"], seed, self._sid(L, 1))
         pos = self._pos_table(T2)
         saved = []
+        if skip_layers is None:
+            skip_layers = [l for l in range(L) if _u01(seed, self._sid(l, 15)) < self.layerdrop] if (self.layerdrop > 0 and (backward or train_mode)) else []
+        skip = set(int(l) for l in skip_layers)
+        self.last_skipped = sorted(skip)
         # ---------------- layers
         for l in range(L):
+            if l in skip:                   # LayerDrop: identity, nothing saved, no gradient
+                saved.append(None)
+                continue
             p = f"l{l}."
             S = {"x_in": x}
             if macaron:
@@ -528,6 +547,9 @@ class EncoderCTCTrainer:
         for l in range(L - 1, -1, -1):
             p = f"l{l}."
             S = saved[l]
+            if S is None:                   # dropped layer: dx passes through, its gradient range stays zero (still reduced: other ranks may have run it)
+                self.sync.launch(*st.range_of(self._layer_names[l]))
+                continue
             # final_layer_norm
             d3 = e32(M, d)
             T.layernorm_bwd(S["x3"], P(p + "fin_ln_g"), dx, d3, accumulate=False, dgamma=G(p + "fin_ln_g"), dbeta=G(p + "fin_ln_b"))

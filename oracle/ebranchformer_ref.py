@@ -223,9 +223,10 @@ def encoder_layer(sd, i, cfg, x, add_mask, pos, q: Callable = _id, dm=None):
 
 
 def encoder_forward(sd: dict, cfg: dict, feats: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-                    q: Optional[Callable] = None, return_layers: bool = False, dm=None):
+                    q: Optional[Callable] = None, return_layers: bool = False, dm=None, skip_layers=()):
     """Wav2Vec2EBranchformerModel.forward (tf:1133-1195, tf:651-717) -> last hidden state (B,T',d).  Eval mode, or train mode with the
-    dropout hook dm(x, layer, site) (global sites use layer = num_hidden_layers: 0 feature projection, 1 encoder input tf:674)."""
+    dropout hook dm(x, layer, site) (global sites use layer = num_hidden_layers: 0 feature projection, 1 encoder input tf:674).
+    skip_layers: LayerDrop decisions (tf:686-690: a layer whose uniform draw falls below config.layerdrop is skipped = identity)."""
     q = q or _id
     eps = cfg.get("layer_norm_eps", 1e-5)
     h = conv_subsample(sd, cfg, feats, q)
@@ -249,7 +250,8 @@ def encoder_forward(sd: dict, cfg: dict, feats: torch.Tensor, attention_mask: Op
         x = dm(x, nl, 1)
     layers = []
     for i in range(cfg["num_hidden_layers"]):
-        x = encoder_layer(sd, i, cfg, x, add_mask, pos, q, dm)
+        if i not in skip_layers:
+            x = encoder_layer(sd, i, cfg, x, add_mask, pos, q, dm)
         if return_layers:
             layers.append(x)
     x = layer_norm(x, sd["wav2vec2.encoder.layer_norm.weight"], sd["wav2vec2.encoder.layer_norm.bias"], eps)

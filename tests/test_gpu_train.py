@@ -65,9 +65,9 @@ def test_gradients_match_reference_golden(name, extra):
     _compare(grads, ref)
 
 
-def _oracle_grads(cfg, sd, x, am, lab):
+def _oracle_grads(cfg, sd, x, am, lab, skip_layers=()):
     sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    hidden = R.encoder_forward(sdr, cfg, x, am)
+    hidden = R.encoder_forward(sdr, cfg, x, am, skip_layers=skip_layers)
     logits = R.ctc_head(sdr, hidden)
     in_len = R.conv_out_lengths_outer(am.sum(-1), cfg).long()
     tl = (lab >= 0).sum(-1)
@@ -90,6 +90,49 @@ def test_gradients_match_oracle_autograd_head64():
     out = tr.forward_backward(x.to(DEV), None, lab.to(DEV))
     assert abs(float(out["loss"]) - loss_ref) <= 2e-3 * abs(loss_ref)
     _compare(tr.grad_dict(), ref, rel=0.04)
+
+
+def test_layerdrop_skipped_layer_is_identity_and_gets_no_gradient():
+    """LayerDrop (tf:686-690): with layer 1 of 3 dropped the loss and every gradient equal the oracle's with that layer removed; drawn
+    decisions follow config.layerdrop, are reproducible per (seed, step) and never apply in eval."""
+    cfg = dict(shapes.TINY, num_hidden_layers=3, ctc_zero_infinity=True, ctc_loss_reduction="mean")
+    from helpers import seeded_state_dict, synth_feats, synth_labels
+    sd = seeded_state_dict(cfg, 47)
+    x, am = synth_feats(47, 3, 200, [200, 170, 140])
+    lab = synth_labels(47, 3, 6, cfg["vocab_size"], [6, 4, 5])
+    loss_ref, ref = _oracle_grads(cfg, sd, x, am, lab, skip_layers=(1,))
+    tr = _trainer(cfg, sd)
+    tr.store.zero_grad()
+    out = tr.forward_backward(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV), skip_layers=[1])
+    assert tr.last_skipped == [1]
+    assert abs(float(out["loss"]) - loss_ref) <= 2e-3 * abs(loss_ref)
+    grads = tr.grad_dict()
+    for k, v in grads.items():
+        if ".layers.1." in k:
+            assert float(v.abs().max()) == 0.0, k
+    _compare(grads, {k: v for k, v in ref.items()}, rel=0.04)
+    # drawn decisions: p = 1 drops everything (the encoder is then the front end + final LayerNorm), p = 0.5 is reproducible per step
+    from huggingface_asr_amd.train import EncoderCTCTrainer
+    tr1 = EncoderCTCTrainer(dict(cfg, **dict(NO_DROPOUT, layerdrop=1.0)), DEV, seed=5)
+    tr1.load_state_dict(sd)
+    tr1.store.zero_grad()
+    tr1.forward_backward(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV))
+    assert tr1.last_skipped == [0, 1, 2]
+    tr1.forward_backward(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV), backward=False)           # eval: nothing is dropped
+    assert tr1.last_skipped == []
+    picks = []
+    for seed in (5, 5, 6):
+        trh = EncoderCTCTrainer(dict(cfg, num_hidden_layers=3, **dict(NO_DROPOUT, layerdrop=0.5)), DEV, seed=seed)
+        trh.load_state_dict(sd)
+        seq = []
+        for step in range(8):
+            trh.store.zero_grad()
+            trh.forward_backward(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV))
+            seq.append(tuple(trh.last_skipped))
+        picks.append(seq)
+    assert picks[0] == picks[1] and picks[0] != picks[2]
+    n = sum(len(t) for t in picks[0])
+    assert 4 <= n <= 20                                             # 24 draws at p = 0.5
 
 
 def test_train_steps_reduce_loss_and_roundtrip_state_dict():
@@ -186,10 +229,12 @@ def test_hf_ctc_model_trains_through_autograd_bridge():
     model.freeze_encoder()
     model(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV)).loss.backward()
     assert all(p.grad is None for p in model.wav2vec2.encoder.parameters()) and model.lm_head.weight.grad is not None
-    # reference-default dropouts: refuse loudly
-    dflt = AutoModelForCTC.from_config(Wav2Vec2EBranchformerConfig(**base)).to(DEV).train()
-    with pytest.raises(NotImplementedError):
-        dflt(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))
+    # the reference's default config (dropouts 0.1, layerdrop 0.1, in-model SpecAugment on) trains as it stands
+    dflt = AutoModelForCTC.from_config(Wav2Vec2EBranchformerConfig(**base, ctc_zero_infinity=True)).to(DEV).train()
+    assert not any(dflt.load_state_dict(sd, strict=False))
+    o = dflt(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))
+    o.loss.backward()
+    assert torch.isfinite(o.loss) and all(torch.isfinite(p.grad).all() for p in dflt.parameters() if p.grad is not None)
 
 
 def test_hf_joint_model_trains_through_autograd_bridge():
