@@ -71,11 +71,12 @@ __global__ __launch_bounds__(256) void conv2d_first3_kernel(const float* __restr
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) wr[tap][j] = w[(g * 8 + j) * 9 + tap];
     }
-    const long total = (long)B * T1 * F1;
-    for (long pos = (long)blockIdx.x * ppb + pl; pos < total; pos += (long)gridDim.x * ppb) {
-        const int f1 = (int)(pos % F1);
-        const int t1 = (int)((pos / F1) % T1);
-        const int b = (int)(pos / ((long)F1 * T1));
+    const int total = B * T1 * F1;                       // < 2^31 (checked by the launcher): 32-bit index arithmetic, the 64-bit divisions cost more than the conv
+    for (int pos = blockIdx.x * ppb + pl; pos < total; pos += gridDim.x * ppb) {
+        const int bt = pos / F1;
+        const int f1 = pos - bt * F1;
+        const int b = bt / T1;
+        const int t1 = bt - b * T1;
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = br[j];
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void conv2d_first3_kernel(const float* __restr
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = f2bf(gelu_erf(acc[j]));
-        *reinterpret_cast<bf16x8*>(out + pos * C + g * 8) = o;
+        *reinterpret_cast<bf16x8*>(out + (long)pos * C + g * 8) = o;
     }
 }
 
@@ -315,7 +316,7 @@ extern "C" int mi_conv2d_first_gelu(const float* x, const float* w, const float*
     MI_ENTER();
     if (B <= 0 || T <= 0 || F <= 0 || C <= 0 || (C % 8) != 0 || K <= 0 || K > 7) return MI_ERR_ARG;
     const int cgs = C / 8;
-    if (K == 3 && cgs <= 256 && (256 % cgs) == 0) {
+    if (K == 3 && cgs <= 256 && (256 % cgs) == 0 && (long)B * T1 * F1 < (1L << 31) - 256L * 8192) {
         const long npos = (long)B * T1 * F1;
         const int ppb = 256 / cgs;
         const long nb = (npos + ppb - 1) / ppb;
