@@ -140,36 +140,63 @@ __global__ __launch_bounds__(256) void dwconv31_bwd_kernel(DwBwdArgs p, float* _
     for (int k = 0; k < FB_K; ++k) { wk[k] = p.w[(long)c * FB_K + k]; gw[k] = 0.f; }
     float gb = 0.f;
     const float bias = (CSGU && p.bias) ? p.bias[c] : 0.f;
+    const int ch8 = tid & 7;                               // 256 % 8 == 0: a thread keeps its 16-B channel chunk in every fill pass
+    f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0, b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (CSGU) {
+        g0 = *reinterpret_cast<const f32x4*>(p.gamma + c0 + ch8 * 8); g1 = *reinterpret_cast<const f32x4*>(p.gamma + c0 + ch8 * 8 + 4);
+        b0 = *reinterpret_cast<const f32x4*>(p.beta + c0 + ch8 * 8);  b1 = *reinterpret_cast<const f32x4*>(p.beta + c0 + ch8 * 8 + 4);
+    }
     for (int t0 = 0; t0 < p.T; t0 += FB_TT) {
         __syncthreads();
-        for (int id = tid; id < FB_ROWS * (FB_CT / 8); id += 256) {
-            const int r = id >> 3, ch = id & 7;
-            const int t = t0 - 15 + r;
-            f32x4 xl = {0.f, 0.f, 0.f, 0.f}, xh = xl, dl = xl, dh = xl;
-            if (t >= 0 && t < p.T) {
-                const long row = (long)b * p.T + t;
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(p.x + row * p.ldx + c0 + ch * 8);
-                const bf16x8 g = *reinterpret_cast<const bf16x8*>(p.dy + row * p.lddy + c0 + ch * 8);
-                float f[8], e[8];
+        // every global load of the tile (5 passes x {conv input, output gradient, gate operand, row statistics}) is issued before the first is
+        // consumed: one block per CU (97 KiB of LDS), so a pass-by-pass load -> wait -> ds_write loop would expose a memory round trip per pass
+        {
+            constexpr int NPI = (FB_ROWS * (FB_CT / 8) + 255) / 256;
+            bf16x8 vx[NPI], vg[NPI], vr[NPI];
+            float mu[NPI], rs[NPI];
+            bool ok[NPI];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { f[j] = bf2f(v[j]); e[j] = bf2f(g[j]); }
+            for (int q = 0; q < NPI; ++q) {                                // branch-free: out-of-range rows read a clamped (valid) row and are zeroed below
+                const int id = tid + q * 256, r = id >> 3;
+                const int t = t0 - 15 + r;
+                ok[q] = id < FB_ROWS * (FB_CT / 8) && t >= 0 && t < p.T;
+                const long row = (long)b * p.T + min(max(t, 0), p.T - 1);
+                vx[q] = *reinterpret_cast<const bf16x8*>(p.x + row * p.ldx + c0 + ch8 * 8);
+                vg[q] = *reinterpret_cast<const bf16x8*>(p.dy + row * p.lddy + c0 + ch8 * 8);
+                mu[q] = 0.f; rs[q] = 0.f;
+                vr[q] = vg[q];
                 if (CSGU) {
-                    const float mu = p.stats[2 * row], rs = p.stats[2 * row + 1];
-                    const bf16x8 rr = *reinterpret_cast<const bf16x8*>(p.r + row * p.ldr + c0 + ch * 8);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        f[j] = (f[j] - mu) * rs * p.gamma[c0 + ch * 8 + j] + p.beta[c0 + ch * 8 + j];
-                        e[j] *= bf2f(rr[j]);
-                    }
-                    if (r >= 15 && r < 15 + FB_TT) *reinterpret_cast<bf16x8*>(io + (r - 15) * FB_CT + ch * 8) = g;
+                    mu[q] = p.stats[2 * row]; rs[q] = p.stats[2 * row + 1];
+                    vr[q] = *reinterpret_cast<const bf16x8*>(p.r + row * p.ldr + c0 + ch8 * 8);
                 }
-                xl = f32x4{f[0], f[1], f[2], f[3]}; xh = f32x4{f[4], f[5], f[6], f[7]};
-                dl = f32x4{e[0], e[1], e[2], e[3]}; dh = f32x4{e[4], e[5], e[6], e[7]};
             }
-            *reinterpret_cast<f32x4*>(tile_x + r * FB_CT + ch * 8) = xl;
-            *reinterpret_cast<f32x4*>(tile_x + r * FB_CT + ch * 8 + 4) = xh;
-            *reinterpret_cast<f32x4*>(tile_d + r * FB_CT + ch * 8) = dl;
-            *reinterpret_cast<f32x4*>(tile_d + r * FB_CT + ch * 8 + 4) = dh;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NPI; ++q) {
+                const int id = tid + q * 256, r = id >> 3;
+                if (id >= FB_ROWS * (FB_CT / 8)) continue;
+                f32x4 xl = {0.f, 0.f, 0.f, 0.f}, xh = xl, dl = xl, dh = xl;
+                if (ok[q]) {
+                    float f[8], e[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { f[j] = bf2f(vx[q][j]); e[j] = bf2f(vg[q][j]); }
+                    if (CSGU) {
+                        const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            f[j] = (f[j] - mu[q]) * rs[q] * gm[j] + bt[j];
+                            e[j] *= bf2f(vr[q][j]);
+                        }
+                        if (r >= 15 && r < 15 + FB_TT) *reinterpret_cast<bf16x8*>(io + (r - 15) * FB_CT + ch8 * 8) = vg[q];
+                    }
+                    xl = f32x4{f[0], f[1], f[2], f[3]}; xh = f32x4{f[4], f[5], f[6], f[7]};
+                    dl = f32x4{e[0], e[1], e[2], e[3]}; dh = f32x4{e[4], e[5], e[6], e[7]};
+                }
+                *reinterpret_cast<f32x4*>(tile_x + r * FB_CT + ch8 * 8) = xl;
+                *reinterpret_cast<f32x4*>(tile_x + r * FB_CT + ch8 * 8 + 4) = xh;
+                *reinterpret_cast<f32x4*>(tile_d + r * FB_CT + ch8 * 8) = dl;
+                *reinterpret_cast<f32x4*>(tile_d + r * FB_CT + ch8 * 8 + 4) = dh;
+            }
         }
         __syncthreads();
         float xw[FB_PER + FB_K - 1], dwn[FB_PER + FB_K - 1];
@@ -352,7 +379,7 @@ int dw_bwd_launch(const DwBwdArgs& a, bool csgu, float* workspace, hipStream_t s
     if (a.B <= 0 || a.T <= 0 || a.C <= 0 || a.K <= 0 || a.K > DB_KMAX || a.pad_left < 0 || a.pad_left > a.K - 1) return MI_ERR_ARG;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const bool fast = workspace && a.K == FB_K && a.pad_left == 15 && (a.C % FB_CT) == 0 && (a.ldx % 8) == 0 && (a.lddy % 8) == 0 && (a.lddx % 8) == 0 &&
-                      al16(a.x) && al16(a.dy) && al16(a.dx) && (!csgu || ((a.ldr % 8) == 0 && (a.lddr % 8) == 0 && al16(a.r) && al16(a.dr)));
+                      al16(a.x) && al16(a.dy) && al16(a.dx) && (!csgu || ((a.ldr % 8) == 0 && (a.lddr % 8) == 0 && al16(a.r) && al16(a.dr) && al16(a.gamma) && al16(a.beta)));
     if (fast) {
         const size_t ldsf = (size_t)2 * FB_ROWS * FB_CT * sizeof(float) + (size_t)FB_TT * FB_CT * sizeof(bf16_t);
         dim3 gridf(a.C / FB_CT, a.B);

@@ -358,7 +358,12 @@ constexpr int SSQ_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ partial) {
     __shared__ float part[4];
     float s = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += x[i] * x[i];
+    const long n4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n >> 2 : 0;          // 16-B loads; fixed element -> thread map, so still run-to-run identical
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += x[i] * x[i];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -389,16 +394,42 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     const float coef = clip ? clip[1] : 1.f;
     const bool skip = clip && !isfinite(clip[0]);
     const float step = lr / bc1, rs2 = rsqrtf(bc2);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    auto one = [&](float& pv, float gi, float& mi, float& vi, bool dec) {
+        gi *= coef;
+        mi = b1 * mi + (1.f - b1) * gi;
+        vi = b2 * vi + (1.f - b2) * gi * gi;
+        if (dec) pv *= (1.f - lr * wd);
+        pv -= step * mi / (sqrtf(vi) * rs2 + eps);
+    };
+    // 16 B per lane and array (the step is pure streaming: 4 reads + 3 writes of the flat buffer + the bf16 mirror)
+    const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0 &&
+                    (!decay || (reinterpret_cast<uintptr_t>(decay) & 3) == 0) && (!mirror || (reinterpret_cast<uintptr_t>(mirror) & 7) == 0);
+    const long n4 = al ? n >> 2 : 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 p4 = reinterpret_cast<f32x4*>(p)[i];
+        float pv[4] = {p4.x, p4.y, p4.z, p4.w};
+        if (!skip) {
+            const f32x4 g4 = reinterpret_cast<const f32x4*>(g)[i], m4 = reinterpret_cast<f32x4*>(m)[i], v4 = reinterpret_cast<f32x4*>(v)[i];
+            const unsigned dm = decay ? reinterpret_cast<const unsigned*>(decay)[i] : 0x01010101u;
+            const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+            float mv[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) one(pv[j], gv[j], mv[j], vv[j], (dm >> (8 * j)) & 0xffu);
+            reinterpret_cast<f32x4*>(m)[i] = f32x4{mv[0], mv[1], mv[2], mv[3]};
+            reinterpret_cast<f32x4*>(v)[i] = f32x4{vv[0], vv[1], vv[2], vv[3]};
+            reinterpret_cast<f32x4*>(p)[i] = f32x4{pv[0], pv[1], pv[2], pv[3]};
+        }
+        if (mirror) {
+            const bf16x2 lo = {f2bf(pv[0]), f2bf(pv[1])}, hi = {f2bf(pv[2]), f2bf(pv[3])};
+            reinterpret_cast<uint2*>(mirror)[i] = uint2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+        }
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float pv = p[i];
         if (!skip) {
-            const float gi = g[i] * coef;
-            const float mi = b1 * m[i] + (1.f - b1) * gi;
-            const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-            m[i] = mi; v[i] = vi;
-            if (!decay || decay[i]) pv *= (1.f - lr * wd);
-            pv -= step * mi / (sqrtf(vi) * rs2 + eps);
-            p[i] = pv;
+            float mi = m[i], vi = v[i];
+            one(pv, g[i], mi, vi, !decay || decay[i]);
+            m[i] = mi; v[i] = vi; p[i] = pv;
         }
         if (mirror) mirror[i] = f2bf(pv);
     }
