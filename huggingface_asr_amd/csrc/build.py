@@ -18,7 +18,11 @@ OUT = os.path.join(PKG, "libhfasr_hip.so")
 OBJ = os.path.join(HERE, "build")
 SOURCES = ["gemm_bf16.hip", "gemm_glds.hip", "gemm_256.hip", "norm.hip", "conv.hip", "attention.hip", "fbank.hip", "ctc.hip", "ctc_prefix.hip", "decoder.hip", "decoder_step.hip", "whisper.hip", "encoder.hip",
            "train_ops.hip", "gemm_tn.hip", "bgemm.hip", "attn_bwd.hip", "conv_bwd.hip", "loss_bwd.hip", "dropout.hip", "bestrq.hip", "specaug.hip"]
-FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-result", "-munsafe-fp-atomics"]
+# -packed-fp32-ops (device side only): no v_pk_{add,mul,fma}_f32 in any kernel.  A wave executing packed-f32 VALU ops next to the LDS-DMA GEMM's
+# waves on one CU (kernels from two streams) lost the low-half product on 16 lanes in ~3 % of launches (tools/dbg/README.md); without packed
+# ops the same pairing ran clean, and beside MFMAs they are slower than their scalar pairs anyway (MI355X_MICROARCH.md, fillers table).
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-result", "-munsafe-fp-atomics",
+         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]      # (the host pass prints "not a recognized feature": harmless)
 
 
 def _stale(target, deps):
@@ -30,7 +34,8 @@ def _stale(target, deps):
 
 def _compile(src):
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-    deps = [os.path.join(HERE, src), os.path.join(HERE, "common.hpp"), os.path.join(HERE, "gemm_args.hpp"), os.path.join(os.path.dirname(PKG), "include", "hfasr_hip.h")]
+    deps = [os.path.join(HERE, src), os.path.join(HERE, "common.hpp"), os.path.join(HERE, "gemm_args.hpp"), os.path.join(os.path.dirname(PKG), "include", "hfasr_hip.h"),
+            os.path.abspath(__file__)]                                   # the flags live in this file
     if _stale(obj, deps):
         subprocess.run(["hipcc", *FLAGS, "-c", os.path.join(HERE, src), "-o", obj], check=True)
     return obj

@@ -24,7 +24,7 @@ def run3(gam, bet):
 _, xn = run3(ones, zeros); _, ref = run3(gr, br); torch.cuda.synchronize()
 xn = xn.cpu().numpy(); refc = ref.cpu().numpy(); G = gr.cpu().numpy(); Bv = br.cpu().numpy()
 found = 0
-for trial in range(40):
+for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     with torch.cuda.stream(side):
         for _ in range(2): o, d1 = run3(gr, br)
     om = cases["gemm"](); torch.cuda.synchronize()
