@@ -132,9 +132,26 @@ __global__ __launch_bounds__(256) void ctc_alpha_wave_kernel(const T* __restrict
     float a0 = -INFINITY, a1 = -INFINITY;
     for (int tc = 0; tc < Tb; tc += tchunk) {
         const int nt = min(tchunk, Tb - tc);
-        for (int i = tid; i < nt * 128; i += 256) {
-            const int t = i >> 7, s = i & 127;
-            lp[i] = (s < S) ? (float)lg[(long)(tc + t) * ld_t + ext[s]] - ls[tc + t] : -INFINITY;
+        {   // gather log p(t, ext[s]): a thread keeps its state s (column ext[s]) and walks the time steps, 16 gathers in flight at a time —
+            // with one block per utterance the memory round trips of a one-at-a-time loop were most of this kernel's time
+            constexpr int UN = 16;
+            const int s = tid & 127, tsub = tid >> 7;
+            const bool sv = s < S;
+            const long col = sv ? ext[s] : blank;
+            for (int t = tsub; t < nt; t += 2 * UN) {
+                float v[UN], l[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int tt = min(t + 2 * u, nt - 1);                 // clamped: branch-free loads
+                    v[u] = (float)lg[(long)(tc + tt) * ld_t + col];
+                    l[u] = ls[tc + tt];
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int tt = t + 2 * u;
+                    if (tt < nt) lp[tt * 128 + s] = sv ? v[u] - l[u] : -INFINITY;
+                }
+            }
         }
         __syncthreads();
         if (wave == 0) {
