@@ -168,6 +168,23 @@ extern "C" int mi_profile_calibrate(hipStream_t stream, int n, double* median_ms
     return MI_OK;
 }
 
+// side stream + fork/join events of the experimental branch overlap (created on first use; one forward in flight at a time)
+namespace {
+constexpr int MAX_OVL_LAYERS = 64;
+hipStream_t g_side = nullptr;
+hipEvent_t g_fork[MAX_OVL_LAYERS], g_join[MAX_OVL_LAYERS];      // one pair per layer: an event is never re-recorded while a wait on it may be pending
+bool side_ready() {
+    if (g_side) return true;
+    if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) { g_side = nullptr; return false; }
+    for (int i = 0; i < MAX_OVL_LAYERS; ++i)
+        if (hipEventCreateWithFlags(&g_fork[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g_join[i], hipEventDisableTiming) != hipSuccess) {
+            g_side = nullptr;
+            return false;
+        }
+    return true;
+}
+}  // namespace
+
 extern "C" size_t mi_ebf_workspace_bytes(const mi_ebf_config* cfg) { return carve(*cfg, nullptr).bytes; }
 
 // posp: (L, 2*T2-1, d) bf16 projected relative positions, (re)computed from pos_table when compute_posp != 0
@@ -232,6 +249,11 @@ extern "C" int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weigh
             RUN(mi_layernorm_chain(w.x, d, nullptr, T2, nullptr, nullptr, 0.f, nullptr, 0, Lf(l, ATT_LN_G), Lf(l, ATT_LN_B), leps,
                                    w.a1, d, nullptr, 0, Lf(l, MLP_LN_G), Lf(l, MLP_LN_B), w.a2, d, M, d, st));
         }
+        // the two branches read a1 / a2 and write disjoint buffers (qk, ctx, cat[:, :d] | h, stats, s, cat[:, d:]): with branch_overlap the
+        // local one is enqueued on the side stream between a fork and a join event
+        const bool ovl = c.branch_overlap && l < MAX_OVL_LAYERS && side_ready();
+        hipStream_t sl = ovl ? g_side : st;
+        if (ovl) { (void)hipEventRecord(g_fork[l], st); (void)hipStreamWaitEvent(g_side, g_fork[l], 0); }
         // global branch (e_branchformer.py:281-288)
         const bf16_t* qk_in = w.a1;
         if (c.pos_type == 2) {
@@ -263,14 +285,15 @@ extern "C" int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weigh
         }
         RUN(mi_gemm_bf16(w.ctx, d, Lw(l, ATT_WO), d, Lf(l, ATT_BO), 1, w.cat, 2 * d, 0, nullptr, 0, 1.f, 0, M, d, d, 0, 0, st));
         // local branch: cgMLP (e_branchformer.py:291-292, 184-222)
-        RUN(mi_gemm_bf16(w.a2, d, Lw(l, MLP_W1), d, Lf(l, MLP_B1), 1, w.h, I, 0, nullptr, 0, 1.f, 1, M, I, d, 0, 0, st));
-        RUN(mi_row_stats_bf16(w.h + I / 2, I, I / 2, leps, w.stats, M, st));
+        RUN(mi_gemm_bf16(w.a2, d, Lw(l, MLP_W1), d, Lf(l, MLP_B1), 1, w.h, I, 0, nullptr, 0, 1.f, 1, M, I, d, 0, 0, sl));
+        RUN(mi_row_stats_bf16(w.h + I / 2, I, I / 2, leps, w.stats, M, sl));
         // quirk: the causal CSGU conv is dilated by (K-1)/2 (e_branchformer.py:153-160 passes it in the dilation slot)
         const int dil = c.is_causal ? (kc - 1) / 2 : 1;
         const int cpad = c.is_causal ? (kc - 1) * dil : (kc - 1) / 2;
         RUN(mi_csgu_bf16(w.h, I, w.stats, Lf(l, CSGU_LN_G), Lf(l, CSGU_LN_B), Lf(l, CSGU_W), Lf(l, CSGU_B), w.s, I / 2,
-                         c.B, T2, I / 2, kc, cpad, dil, c.csgu_act, st));
-        RUN(mi_gemm_bf16(w.s, I / 2, Lw(l, MLP_W2), I / 2, Lf(l, MLP_B2), 1, w.cat + d, 2 * d, 0, nullptr, 0, 1.f, 0, M, d, I / 2, 0, 0, st));
+                         c.B, T2, I / 2, kc, cpad, dil, c.csgu_act, sl));
+        RUN(mi_gemm_bf16(w.s, I / 2, Lw(l, MLP_W2), I / 2, Lf(l, MLP_B2), 1, w.cat + d, 2 * d, 0, nullptr, 0, 1.f, 0, M, d, I / 2, 0, 0, sl));
+        if (ovl) { (void)hipEventRecord(g_join[l], g_side); (void)hipStreamWaitEvent(st, g_join[l], 0); }
         // merge (e_branchformer.py:296-304)
         RUN(mi_dwconv_residual_bf16(w.cat, 2 * d, Lf(l, MRG_DW_W), Lf(l, MRG_DW_B), w.m2, 2 * d, c.B, T2, 2 * d, km, (km - 1) / 2, st));
         RUN(mi_gemm_bf16(w.m2, 2 * d, Lw(l, MRG_W), 2 * d, Lf(l, MRG_B), 1, w.x, d, 1, w.x, d, 1.0f, 0, M, d, 2 * d, 0, 0, st));

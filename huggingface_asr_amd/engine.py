@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -59,6 +60,9 @@ class EBranchformerEngine:
         self.cfg = dict(cfg)
         self.device = torch.device(device)
         self.logits_dtype = logits_dtype
+        # experimental (HFASR_BRANCH_OVERLAP=1): attention and cgMLP branches of a layer on two streams, +1-2 % on the base model.
+        # Off by default: two kernels of different streams sharing a CU is what DESIGN.md 'Concurrent kernels' is about.
+        self.branch_overlap = os.environ.get("HFASR_BRANCH_OVERLAP", "0") == "1"
         c = self.cfg
         if len(c["conv_dim"]) != 2 or len(set(c["conv_kernel"])) != 1 or len(set(c["conv_stride"])) != 1 or len(set(c["conv_padding"])) != 1:
             raise NotImplementedError("HIP path supports the 2-layer Conv2d sub-sampling with equal kernel/stride/padding")
@@ -177,7 +181,7 @@ class EBranchformerEngine:
         self._pos[key] = t
         return t
 
-    def _config_struct(self, B, T, F):
+    def _config_struct(self, B, T, F, slot=0):
         c = self.cfg
         return _lib.EbfConfig(B=B, T=T, F=F, d=c["hidden_size"], H=c["num_attention_heads"], I=c["intermediate_size"],
                               L=c["num_hidden_layers"], V=c["vocab_size"], C1=c["conv_dim"][0], C2=c["conv_dim"][1],
@@ -186,7 +190,8 @@ class EBranchformerEngine:
                               csgu_kernel=c.get("csgu_kernel_size", 31), merge_kernel=c.get("merge_conv_kernel", 31),
                               csgu_act=ACT[c.get("csgu_activation", "identity")], use_macaron=int(c.get("use_macaron_ff", True)),
                               ln_eps=float(c.get("layer_norm_eps", 1e-5)), logits_f32=int(self.logits_dtype == torch.float32),
-                              logits_ld=(c["vocab_size"] + 1 + 7) // 8 * 8)
+                              logits_ld=(c["vocab_size"] + 1 + 7) // 8 * 8,
+                              branch_overlap=int(self.branch_overlap and slot == 0))
 
     def _workspace(self, cs, slot=0):
         key = (cs.B, cs.T, cs.F)
@@ -209,7 +214,7 @@ class EBranchformerEngine:
         feats = feats.to(torch.float32).contiguous()
         B, T, F = feats.shape
         c = self.cfg
-        cs = self._config_struct(B, T, F)
+        cs = self._config_struct(B, T, F, slot)
         T2 = self.out_frames(T)
         if T2 <= 0:
             raise ValueError("input too short for the conv sub-sampling")

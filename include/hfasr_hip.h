@@ -254,6 +254,8 @@ typedef struct {
     float ln_eps;                /* feature-projection / encoder LayerNorm eps (layer LNs use 1e-5) */
     int logits_f32;              /* 1: fp32 logits, 0: bf16 logits */
     int logits_ld;               /* row stride of the logits buffer in elements (0 = V+1); a multiple of 8 keeps the stores 16-B wide */
+    int branch_overlap;          /* experimental, default 0: run each layer's local (cgMLP) branch on a library-owned side stream beside the
+                                    attention branch (one forward in flight at a time); see DESIGN.md 'Concurrent kernels' before enabling */
 } mi_ebf_config;
 
 /* weight-table slot indices: see huggingface_asr_amd/engine.py (SLOTS) — the table is an array of device pointers. */

@@ -104,10 +104,11 @@ def test_no_attention_mask_and_batch_invariance():
     torch.testing.assert_close(one[0], a[0], atol=0, rtol=0)
 
 
-def test_forward_is_bit_reproducible_at_the_bench_size():
-    """The whole forward (one launch stream) gives identical bits run after run, also when issued from a non-default stream: every
-    reduction in it has a fixed order, and no kernel of ours shares a CU with another one from a different stream (DESIGN.md,
-    'Concurrent kernels')."""
+@pytest.mark.parametrize("overlap", [False, True])
+def test_forward_is_bit_reproducible_at_the_bench_size(overlap):
+    """The whole forward gives identical bits run after run, also when issued from a non-default stream: every reduction in it has a
+    fixed order.  overlap=True is the opt-in two-stream form (attention and cgMLP branches side by side, HFASR_BRANCH_OVERLAP=1): it
+    must reproduce the single-stream bits exactly ('Concurrent kernels': the pairing that used to corrupt the CSGU tile)."""
     from huggingface_asr_amd import synth
     from huggingface_asr_amd.engine import EBranchformerEngine
     cfg = _cfg(shapes.BASE)
@@ -117,8 +118,10 @@ def test_forward_is_bit_reproducible_at_the_bench_size():
     feats = torch.from_numpy(synth.normal(1, "feats", (16, 1000, 80), 1.0)).to(DEV)
     lens = torch.full((16,), 998, dtype=torch.int32, device=DEV)
     side = torch.cuda.Stream()
-    ref = None
-    for i in range(8):
+    o = eng.forward(feats, lens)
+    ref = (o["logits"].clone(), o["last_hidden"].clone())            # single-stream reference
+    eng.branch_overlap = overlap
+    for i in range(12 if overlap else 8):
         if i % 2:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -127,10 +130,7 @@ def test_forward_is_bit_reproducible_at_the_bench_size():
         else:
             o = eng.forward(feats, lens)
         got = (o["logits"].clone(), o["last_hidden"].clone())
-        if ref is None:
-            ref = got
-        else:
-            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), i
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), i
 
 
 def test_engine_requires_device_tensors():
