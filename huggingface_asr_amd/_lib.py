@@ -89,6 +89,7 @@ SIGNATURES = {
     "mi_ce_label_smoothing_bwd": [vp, i64, vp, i32, i32, i32, i32, f32, f32, vp, vp, i64, vp],
     "mi_embed_tokens_bwd": [vp, vp, f32, i32, i32, i32, i32, i32, vp, vp, vp],
     "mi_specaug_f32": [vp, vp, i32, i32, i32, vp, i32, i32, f32, vp],
+    "mi_speed_resample_f32": [vp, i64, vp, i32, i32, i32, i32, vp, i32, vp, i64, i32, vp, vp],
     "mi_rpq_targets": [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "mi_mask_noise_f32": [vp, i64, vp, i32, i32, f32, C.c_uint, C.c_uint, vp],
     "mi_gpt2_step_workspace_bytes": [C.POINTER(Gpt2Config), i32, i32],

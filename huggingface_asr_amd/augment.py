@@ -92,3 +92,66 @@ class SpecAug(torch.nn.Module):
         _lib.check(_lib.lib().mi_specaug_f32(x.data_ptr(), out.data_ptr(), B, Tn, Fq, Pd.data_ptr(), nf, nt, 0.0, torch.cuda.current_stream().cuda_stream),
                    "mi_specaug_f32")
         return (out[0] if squeeze else out), x_lengths
+
+
+# ============================================================================================ speed perturbation
+def _sinc_resample_kernel(orig: int, new: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """torchaudio functional.py `_get_sinc_resample_kernel` (sinc_interp_hann): index arithmetic in float64, table cast to float32.
+    -> (kernel (new, 2*width + orig) float32 CPU tensor, width)"""
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, :] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None] / new + idx
+    t *= base
+    t = t.clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t *= math.pi
+    scale = base / orig
+    k = torch.where(t == 0, torch.tensor(1.0, dtype=torch.float64), t.sin() / t)
+    return (k * window * scale).to(torch.float32).contiguous(), width
+
+
+class Speed(torch.nn.Module):
+    """Drop-in for `torchaudio.transforms.Speed(orig_freq, factor)` on GPU waveform batches: `forward(waveform (..., N), lengths=None)
+    -> (waveform', lengths')`, one HIP kernel (`mi_speed_resample_f32`, csrc/speed.hip)."""
+
+    def __init__(self, orig_freq: int, factor: float):
+        super().__init__()
+        self.orig_freq, self.factor = int(orig_freq), float(factor)
+        src, tgt = int(self.factor * self.orig_freq), self.orig_freq
+        g = math.gcd(src, tgt)
+        self.source, self.target = src // g, tgt // g
+        self._table = {}
+        if self.source != self.target:
+            self._kernel, self._width = _sinc_resample_kernel(self.source, self.target)
+
+    def forward(self, waveform: torch.Tensor, lengths: Optional[torch.Tensor] = None):
+        out_len = None if lengths is None else torch.ceil(lengths * self.target / self.source).to(lengths.dtype)
+        if self.source == self.target:
+            return waveform, out_len
+        if not waveform.is_cuda:
+            raise RuntimeError("huggingface_asr_amd.augment.Speed runs on the GPU (no CPU fallback); keep torchaudio's class for CPU workers")
+        shape = waveform.shape
+        x = waveform.reshape(-1, shape[-1]).to(torch.float32).contiguous()
+        B, N = x.shape
+        n_out = -(-self.target * N // self.source)
+        dev = x.device
+        if dev not in self._table:
+            self._table[dev] = self._kernel.to(dev)
+        out = torch.empty((B, n_out), device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib().mi_speed_resample_f32(x.data_ptr(), x.stride(0), None, B, N, self.source, self.target, self._table[dev].data_ptr(), self._width,
+                                                    out.data_ptr(), out.stride(0), n_out, None, torch.cuda.current_stream().cuda_stream), "mi_speed_resample_f32")
+        return out.reshape(*shape[:-1], n_out), out_len
+
+
+class SpeedPerturbation(torch.nn.Module):
+    """Drop-in for `torchaudio.transforms.SpeedPerturbation(orig_freq, factors)` (configs/default_data_preprocessing2d.json:3-19): one
+    `torch.randint(len(factors), ())` per call picks the factor for the whole batch, exactly as torchaudio draws it."""
+
+    def __init__(self, orig_freq: int, factors: Sequence[float]):
+        super().__init__()
+        self.speeders = torch.nn.ModuleList([Speed(orig_freq=orig_freq, factor=f) for f in factors])
+
+    def forward(self, waveform: torch.Tensor, lengths: Optional[torch.Tensor] = None):
+        idx = int(torch.randint(len(self.speeders), ()))
+        return self.speeders[idx](waveform, lengths)

@@ -216,6 +216,13 @@ int mi_embed_tokens_bwd(const long* ids, const float* dx, float scale, int pos_o
 /* ---- feature-level SpecAugment on the device (src/augmentations/spec_aug.py:40-137: bicubic time warp + frequency / time masks) */
 int mi_specaug_f32(const float* x, float* out, int B, int T, int F, const int* params, int nf, int nt, float pad_value, mi_stream_t stream);
 
+/* Speed perturbation = polyphase sinc resampling of a (B, N) fp32 waveform batch by orig/nw (both divided by their gcd), the arithmetic of
+ * torchaudio.transforms.SpeedPerturbation which the reference's training pre-processing names first (configs/default_data_preprocessing2d.json:3-19;
+ * torchaudio functional.py `speed` / `_apply_sinc_resample_kernel`).  kernel: (nw, 2*width + orig) fp32 table built by the host;
+ * N_out must equal ceil(nw * N / orig); lengths / out_lengths (B) int32 or NULL (out = ceil(len * nw / orig)). */
+int mi_speed_resample_f32(const float* wave, long ld, const int* lengths, int B, int N, int orig, int nw, const float* kernel, int width,
+                          float* out, long ld_out, int N_out, int* out_lengths, mi_stream_t stream);
+
 /* ---- BEST-RQ pre-training (src/models/bestrq.py:66-97): random-projection quantizer targets, noise masking of the encoder input */
 int mi_rpq_targets(const float* x, long ldx, const float* P, const float* CB, long* targets, int M, int in_dim, int cd, int C, int books,
                    mi_stream_t stream);
