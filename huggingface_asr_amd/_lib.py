@@ -71,7 +71,7 @@ SIGNATURES = {
     "mi_spec_mask_apply": [vp, i64, vp, vp, vp, i32, i32, i32, vp],
     "mi_spec_mask_bwd": [vp, i64, vp, vp, vp, i32, i32, i32, vp],
     "mi_sumsq_f32": [vp, i64, vp, vp, vp],
-    "mi_clip_coef": [vp, f32, vp, vp],
+    "mi_clip_coef": [vp, f32, f32, vp, vp],
     "mi_adamw_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, vp, vp],
     "mi_gemm_tn_workspace_bytes": [i32, i32, i32],
     "mi_gemm_tn_bf16": [vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, i32, vp, sz, vp],

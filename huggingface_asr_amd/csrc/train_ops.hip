@@ -378,21 +378,23 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restric
     __syncthreads();
     if (threadIdx.x == 0) out[0] += (part[0] + part[1]) + (part[2] + part[3]);
 }
-// norm = sqrt(sumsq); coef = min(1, max_norm / (norm + 1e-6))  (torch.nn.utils.clip_grad_norm_); non-finite norm -> coef 0 (step skipped)
-__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* out /* [norm, coef] */) {
+// norm = sqrt(sumsq); coef = min(1, max_norm / (norm + 1e-6))  (torch.nn.utils.clip_grad_norm_).  skip = 1 when the norm is not finite or above
+// `skip_above` (> 0): the reference's GradAwareTrainer drops such a step altogether (training_utils.py:81,101-115: grads set to None).
+__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float skip_above, float* out /* [norm, coef, skip] */) {
     const float norm = sqrtf(sumsq[0]);
     float coef = 1.f;
     if (max_norm > 0.f) coef = fminf(1.f, max_norm / (norm + 1e-6f));
-    if (!isfinite(norm)) coef = 0.f;
-    out[0] = norm; out[1] = coef;
+    const bool skip = !isfinite(norm) || (skip_above > 0.f && norm > skip_above);
+    if (skip) coef = 0.f;
+    out[0] = norm; out[1] = coef; out[2] = skip ? 1.f : 0.f;
 }
 // torch.optim.AdamW (decoupled weight decay) on the flat fp32 master buffer; also refreshes the bf16 mirror the GEMMs read
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                      float* __restrict__ v, const unsigned char* __restrict__ decay, long n,
                                                      float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
-                                                     const float* __restrict__ clip /* [norm, coef] or null */, bf16_t* __restrict__ mirror) {
+                                                     const float* __restrict__ clip /* [norm, coef, skip] or null */, bf16_t* __restrict__ mirror) {
     const float coef = clip ? clip[1] : 1.f;
-    const bool skip = clip && !isfinite(clip[0]);
+    const bool skip = clip && (clip[2] != 0.f || !isfinite(clip[0]));
     const float step = lr / bc1, rs2 = rsqrtf(bc2);
     auto one = [&](float& pv, float gi, float& mi, float& vi, bool dec) {
         gi *= coef;
@@ -595,9 +597,9 @@ extern "C" int mi_sumsq_f32(const float* x, long n, float* sumsq, float* workspa
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
-extern "C" int mi_clip_coef(const float* sumsq, float max_norm, float* norm_coef, hipStream_t st) {
+extern "C" int mi_clip_coef(const float* sumsq, float max_norm, float skip_above, float* norm_coef_skip, hipStream_t st) {
     MI_ENTER();
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, st, sumsq, max_norm, norm_coef);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, st, sumsq, max_norm, skip_above, norm_coef_skip);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

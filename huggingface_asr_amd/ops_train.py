@@ -247,8 +247,10 @@ def sumsq_(acc, x):
     _lib.check(_L().mi_sumsq_f32(x.data_ptr(), x.numel(), acc.data_ptr(), _dw_ws(x.device, 1024), _stream()), "mi_sumsq_f32")
 
 
-def clip_coef(sumsq, max_norm, out):
-    _lib.check(_L().mi_clip_coef(sumsq.data_ptr(), float(max_norm), out.data_ptr(), _stream()), "mi_clip_coef")
+def clip_coef(sumsq, max_norm, out, skip_above=0.0):
+    """out (3 floats) <- [norm, clip coefficient, skip flag]; skip when the norm is non-finite or above `skip_above` (> 0)"""
+    assert out.numel() >= 3
+    _lib.check(_L().mi_clip_coef(sumsq.data_ptr(), float(max_norm), float(skip_above or 0.0), out.data_ptr(), _stream()), "mi_clip_coef")
 
 
 def adamw_step_(p, g, m, v, decay, *, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, step=1, norm_coef=None, mirror=None):

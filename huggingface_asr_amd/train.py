@@ -288,8 +288,10 @@ class EncoderCTCTrainer:
     """forward + backward + AdamW for Wav2Vec2EBranchformerForCTC on one GPU (one process per GPU under DP)."""
 
     def __init__(self, cfg: dict, device="cuda:0", *, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
-                 dp_sync=True, seed=0, head=True):
-        """dp_sync=False: no gradient all-reduce here (the caller, e.g. HF Trainer's DDP wrapper, owns data parallelism).
+                 dp_sync=True, seed=0, head=True, grad_norm_skip=100.0):
+        """grad_norm_skip: a step whose global gradient norm exceeds it (or is not finite) is dropped — parameters and moments untouched — as
+        GradAwareTrainer does with its fixed threshold of 100 (training_utils.py:81,101-115); 0 disables.
+        dp_sync=False: no gradient all-reduce here (the caller, e.g. HF Trainer's DDP wrapper, owns data parallelism).
         seed: dropout mask seed (masks are counter-based: f(seed, step, layer, site, element), csrc/dropout.hip); give every DP rank its own."""
         c = self.cfg = dict(cfg)
         if c.get("is_causal", False):
@@ -311,7 +313,7 @@ class EncoderCTCTrainer:
         self.head = bool(head)            # False: bare encoder (BEST-RQ pre-training puts its own classifier on the last hidden state)
         self.store = ParamStore(encoder_specs(c, self.head), self.device)
         self.map = _enc_map(c, self.head)
-        self.hp = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        self.hp = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm, grad_norm_skip=grad_norm_skip)
         self.sync = GradSync(self.store.flat_g, group, enabled=dp_sync)
         self._pos = {}
         self._scal = torch.zeros(4, dtype=F32, device=self.device)       # [sumsq, norm, coef, -]
@@ -784,10 +786,10 @@ class EncoderCTCTrainer:
         sc = self._scal
         sc.zero_()
         T.sumsq_(sc[0:1], st.flat_g)
-        T.clip_coef(sc[0:1], hp["max_grad_norm"] if hp["max_grad_norm"] else 0.0, sc[1:3])
+        T.clip_coef(sc[0:1], hp["max_grad_norm"] if hp["max_grad_norm"] else 0.0, sc[1:4], hp.get("grad_norm_skip", 0.0))
         st.step_count += 1
         T.adamw_step_(st.flat_p, st.flat_g, st.flat_m, st.flat_v, st.decay, lr=hp["lr"] if lr is None else lr, betas=hp["betas"], eps=hp["eps"],
-                      weight_decay=hp["weight_decay"], step=st.step_count, norm_coef=sc[1:3], mirror=st.flat_bf)
+                      weight_decay=hp["weight_decay"], step=st.step_count, norm_coef=sc[1:4], mirror=st.flat_bf)
         st.refresh_mirrors(cast=False)
         return sc[1]          # gradient norm (device scalar)
 

@@ -340,11 +340,11 @@ class JointAEDTrainer:
         sc.zero_()
         T.sumsq_(sc[0:1], self.enc.store.flat_g)
         T.sumsq_(sc[0:1], self.store.flat_g)
-        T.clip_coef(sc[0:1], hp["max_grad_norm"] if hp["max_grad_norm"] else 0.0, sc[1:3])
+        T.clip_coef(sc[0:1], hp["max_grad_norm"] if hp["max_grad_norm"] else 0.0, sc[1:4], hp.get("grad_norm_skip", 0.0))
         for st in (self.enc.store, self.store):
             st.step_count += 1
             T.adamw_step_(st.flat_p, st.flat_g, st.flat_m, st.flat_v, st.decay, lr=hp["lr"] if lr is None else lr, betas=hp["betas"], eps=hp["eps"],
-                          weight_decay=hp["weight_decay"], step=st.step_count, norm_coef=sc[1:3], mirror=st.flat_bf)
+                          weight_decay=hp["weight_decay"], step=st.step_count, norm_coef=sc[1:4], mirror=st.flat_bf)
             st.refresh_mirrors(cast=False)
         return sc[1]
 

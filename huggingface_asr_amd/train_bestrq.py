@@ -135,11 +135,11 @@ class BestRQTrainer:
         sc.zero_()
         T.sumsq_(sc[0:1], self.enc.store.flat_g)
         T.sumsq_(sc[0:1], self.store.flat_g)
-        T.clip_coef(sc[0:1], hp["max_grad_norm"] if hp["max_grad_norm"] else 0.0, sc[1:3])
+        T.clip_coef(sc[0:1], hp["max_grad_norm"] if hp["max_grad_norm"] else 0.0, sc[1:4], hp.get("grad_norm_skip", 0.0))
         for s_ in (self.enc.store, self.store):
             s_.step_count += 1
             T.adamw_step_(s_.flat_p, s_.flat_g, s_.flat_m, s_.flat_v, s_.decay, lr=hp["lr"] if lr is None else lr, betas=hp["betas"], eps=hp["eps"],
-                          weight_decay=hp["weight_decay"], step=s_.step_count, norm_coef=sc[1:3], mirror=s_.flat_bf)
+                          weight_decay=hp["weight_decay"], step=s_.step_count, norm_coef=sc[1:4], mirror=s_.flat_bf)
             s_.refresh_mirrors(cast=False)
         return sc[1]
 

@@ -168,7 +168,10 @@ int mi_spec_mask_apply(float* x, long ld, const unsigned char* time_mask, const 
 int mi_spec_mask_bwd(float* dx, long ld, const unsigned char* time_mask, float* dembed, const unsigned char* feat_mask, int T, int M, int N,
                      mi_stream_t stream);
 int mi_sumsq_f32(const float* x, long n, float* sumsq, float* workspace /* 1024 floats */, mi_stream_t stream);
-int mi_clip_coef(const float* sumsq, float max_norm, float* norm_coef, mi_stream_t stream);
+/* norm_coef_skip (3 floats): [sqrt(sumsq), clip coefficient min(1, max_norm / (norm + 1e-6)), skip flag].  skip = 1 (and coef 0) when the norm is not
+ * finite or exceeds skip_above > 0 — GradAwareTrainer.training_step drops such a step (src/utilities/training_utils.py:81,101-115). mi_adamw_step
+ * given this array leaves parameters and moments untouched when skip is set. */
+int mi_clip_coef(const float* sumsq, float max_norm, float skip_above, float* norm_coef_skip, mi_stream_t stream);
 int mi_adamw_step(float* p, const float* g, float* m, float* v, const unsigned char* decay, long n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, const float* norm_coef, void* mirror_bf16,
                   mi_stream_t stream);

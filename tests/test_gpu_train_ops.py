@@ -325,11 +325,19 @@ def test_adamw_matches_torch():
         coef = min(1.0, 1.0 / (float(norm) + 1e-6))
         pa.grad, pb.grad = (gg[decay] * coef), (gg[~decay] * coef)
         opt.step()
-        ss = torch.zeros(1, device=DEV); nc = torch.zeros(2, device=DEV)
+        ss = torch.zeros(1, device=DEV); nc = torch.zeros(3, device=DEV)
         gd = g.to(DEV)
         T.sumsq_(ss, gd); T.clip_coef(ss, 1.0, nc)
-        torch.testing.assert_close(nc.cpu(), torch.tensor([float(norm), coef]), atol=1e-4, rtol=1e-4)
+        torch.testing.assert_close(nc.cpu(), torch.tensor([float(norm), coef, 0.0]), atol=1e-4, rtol=1e-4)
         T.adamw_step_(p, gd, m, v, dmask, lr=2e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01, step=step, norm_coef=nc, mirror=mirror)
     want = torch.empty(n); want[decay] = pa.detach(); want[~decay] = pb.detach()
     torch.testing.assert_close(p.cpu(), want, atol=1e-6, rtol=1e-5)
     assert torch.equal(mirror.cpu(), p.cpu().to(BF))
+    # a step whose norm is above the skip threshold (GradAwareTrainer, training_utils.py:81,101-115) or not finite leaves everything untouched
+    p0, m0, v0 = p.clone(), m.clone(), v.clone()
+    for bad, thr in ((gd * 1e4, 100.0), (torch.full_like(gd, float("nan")), 0.0)):
+        ss.zero_(); T.sumsq_(ss, bad); T.clip_coef(ss, 1.0, nc, skip_above=thr)
+        assert float(nc[2]) == 1.0 and float(nc[1]) == 0.0
+        T.adamw_step_(p, bad, m, v, dmask, lr=2e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01, step=9, norm_coef=nc, mirror=mirror)
+        assert torch.equal(p, p0) and torch.equal(m, m0) and torch.equal(v, v0)
+
