@@ -9,9 +9,11 @@ recipes/librispeech/.../train_small_baseline.sh:43,53-58: bf16 autocast, AdamW, 
                      import / export in the reference's state-dict names.
   * `EncoderCTCTrainer.forward_backward` — forward with saved activations, analytic backward on the HIP kernels of
                      csrc/{train_ops,bgemm,attn_bwd,conv_bwd,loss_bwd}.hip + the forward GEMM kernel (dX = dY·W, dW = dYᵀ·X).
-  * `GradSync`     — data-parallel gradient SUM all-reduce (RCCL through torch.distributed) per layer bucket, issued while the
-                     earlier layers' backward is still running; the 1/world factor is folded into the loss gradient.
-  * `AdamW`        — one fused kernel over the flat buffer (grad-norm clip coefficient read on device, bf16 mirror refreshed).
+  * `GradSync`     — data-parallel gradient SUM all-reduce (RCCL through torch.distributed): one merged collective after the backward by
+                     default, per layer bucket while the earlier layers' backward is still running with overlap=True; the 1/world
+                     factor is folded into the loss gradient.
+  * `AdamW`        — one fused kernel over the flat buffer (grad-norm clip coefficient and the skip-this-step flag read on device,
+                     bf16 mirror refreshed).
 
 Precision model = the reference's autocast recipe: fp32 master weights and residual stream, bf16 GEMM operands (activations AND
 activation gradients), fp32 accumulation, fp32 LayerNorm / softmax / CTC, fp32 parameter gradients.
