@@ -133,6 +133,41 @@ def test_forward_is_bit_reproducible_at_the_bench_size(overlap):
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), i
 
 
+def test_full_size_batch_independence_and_loss_additivity():
+    """BASELINE configs[1] size (base, 32 x 10 s): size-independent properties instead of an oracle run — an utterance's logits do not depend on
+    its batch neighbours (bit for bit: every kernel reduces over an utterance's own rows only), extra zero padding behind an utterance does not
+    move its valid frames, and the batch-mean CTC loss is the mean of the per-utterance losses."""
+    from huggingface_asr_amd import ops, synth
+    from huggingface_asr_amd.engine import EBranchformerEngine
+    cfg = _cfg(shapes.BASE)
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()}
+    eng = EBranchformerEngine(cfg, DEV)
+    eng.load_state_dict(sd)
+    B, T = 32, 1000
+    feats = torch.from_numpy(synth.normal(7, "feats", (B, T, 80), 1.0)).to(DEV)
+    lens = torch.tensor([998 - 37 * (i % 9) for i in range(B)], dtype=torch.int32, device=DEV)
+    feats = feats * (torch.arange(T, device=DEV)[None, :, None] < lens[:, None, None])          # the collator's zero padding
+    labels = torch.from_numpy(synth.labels(7, B, 40, cfg["vocab_size"])).to(DEV)
+    out = eng.forward(feats, lens)
+    logits, outer = out["logits"].clone(), out["outer_len"].clone()
+    assert torch.isfinite(logits).all()
+    for i in (0, 5, 31):
+        one = eng.forward(feats[i:i + 1].contiguous(), lens[i:i + 1].contiguous())["logits"]
+        n = int(outer[i])
+        assert torch.equal(one[0, :n], logits[i, :n]), i
+    # 200 more frames of padding: T' grows from 250 to 300, the valid frames keep their values up to bf16 re-rounding of the position table
+    padded = torch.zeros(1, T + 200, 80, device=DEV); padded[0, :T] = feats[5]
+    more = eng.forward(padded, lens[5:6].contiguous())["logits"]
+    n = int(outer[5])
+    dpad = (more[0, :n] - logits[5, :n]).abs()                      # bf16 noise of 16 layers (the reference's own bf16-vs-fp32 gap is 0.044 max, SURVEY.md §7)
+    assert float(dpad.max()) < 0.12 and float(dpad.mean()) < 0.01, (float(dpad.max()), float(dpad.mean()))
+    loss, nll, tl = ops.ctc_loss(logits, labels, outer, reduction="mean", zero_infinity=True)
+    want = (nll / tl.clamp(min=1)).mean()
+    assert abs(float(loss) - float(want)) < 1e-4 * abs(float(want))
+    each = [float(ops.ctc_loss(logits[i:i + 1].contiguous(), labels[i:i + 1].contiguous(), outer[i:i + 1].contiguous(), reduction="sum", zero_infinity=True)[0]) for i in (0, 9)]
+    assert abs(each[0] - float(nll[0])) < 1e-3 * abs(each[0]) and abs(each[1] - float(nll[9])) < 1e-3 * abs(each[1])
+
+
 def test_engine_requires_device_tensors():
     from huggingface_asr_amd.engine import EBranchformerEngine
     cfg = _cfg(shapes.TINY)
