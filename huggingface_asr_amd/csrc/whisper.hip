@@ -4,7 +4,7 @@
 // selected by the reference's configs/default_data_preprocessing_whisper.json:20-29): reflect-padded 400/160 STFT with a
 // periodic Hann window, 400-point DFT (stored as complex64), power, 80 Slaney mel filters, log10(max(.,1e-10)), last frame
 // dropped, clamp to (clip max - 8), (x+4)/4.  n_fft = 400 is not a power of two, so the transform is a direct float64 DFT
-// against a 400-entry twiddle table in LDS (1 GFLOP per 30 s clip — noise next to the encoder's 0.35 TFLOP).
+// against a 400-entry twiddle table in LDS, four bins per lane through the factor-4 symmetry of 400 (whisper_logmel_kernel).
 // The encoder itself (Conv1d x2 as implicit GEMMs, pre-LN MHA + FFN layers) runs on the shared kernels; this file only adds
 // the (B,mel,T) -> channels-last bf16 transpose and the "+ embed_positions" step.
 #include "common.hpp"
@@ -29,62 +29,101 @@ __device__ __forceinline__ float sample_reflect(const float* w, int ns, int n_sa
     return j < ns ? w[j] : 0.f;
 }
 
-__global__ __launch_bounds__(256) void whisper_logmel_kernel(WhArgs p) {
-    __shared__ double xs[WN];
+// float max through integer atomics (values of either sign; the target starts at -inf)
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+    if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
+}
+
+// A wave per frame, four frames per block.  400 = 4 x 100, so the bins k, 100-k, 100+k and 200-k (k = 0..50) share their twiddles up to
+// factors (-i)^n and a conjugation: lane k accumulates S_j = sum over n = j (mod 4) of x[n] e^{-2 pi i nk/400} (two FMAs per sample) and
+//   X[k] = S0 + S1 + S2 + S3,  X[200-k] = S0* - S1* + S2* - S3*,  X[100+k] = S0 - i S1 - S2 + i S3,  X[100-k] = S0* - i S1* - S2* + i S3*
+// — a quarter of the multiply-adds and of the twiddle gathers of one-lane-per-bin.  The mel filters are applied over their non-zero span only,
+// and the per-clip maximum the normalisation needs is taken here (one global atomic per frame).
+__global__ __launch_bounds__(256) void whisper_logmel_kernel(WhArgs p, float* __restrict__ clipmax) {
+    __shared__ double xs[4][WN];
     __shared__ double2 tw[WN];
-    __shared__ double pw[WBINS];
-    const int tid = threadIdx.x;
+    __shared__ double pw[4][WBINS + 3];
+    __shared__ int mlo[256], mhi[256];
+    __shared__ float smax[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i < WN; i += 256) tw[i] = double2{p.twiddle[2 * i], p.twiddle[2 * i + 1]};
+    if (tid < p.nmel) {                                    // non-zero span of this mel filter (triangles: contiguous)
+        const double* mt = p.mel_t + (long)tid * WBINS;
+        int lo = WBINS, hi = 0;
+        for (int k = 0; k < WBINS; ++k)
+            if (mt[k] != 0.0) { lo = min(lo, k); hi = k + 1; }
+        mlo[tid] = lo; mhi[tid] = hi;
+    }
     const long total = (long)p.B * p.frames;
-    for (long f = blockIdx.x; f < total; f += gridDim.x) {
-        const int b = (int)(f / p.frames), t = (int)(f % p.frames);
-        const float* w = p.wave + (long)b * p.ldw;
-        const int ns = p.num_samples ? min(p.num_samples[b], p.n_samples) : p.n_samples;
+    for (long f0 = (long)blockIdx.x * 4; f0 < total; f0 += (long)gridDim.x * 4) {
+        const long f = f0 + wave;
+        const bool valid = f < total;
+        const int b = valid ? (int)(f / p.frames) : 0, t = valid ? (int)(f % p.frames) : 0;
         __syncthreads();
-        for (int i = tid; i < WN; i += 256) xs[i] = (double)sample_reflect(w, ns, p.n_samples, t * WHOP + i) * p.window[i];
+        if (tid < 4) smax[tid] = -INFINITY;
+        if (valid) {
+            const float* w = p.wave + (long)b * p.ldw;
+            const int ns = p.num_samples ? min(p.num_samples[b], p.n_samples) : p.n_samples;
+            for (int i = lane; i < WN; i += 64) xs[wave][i] = (double)sample_reflect(w, ns, p.n_samples, t * WHOP + i) * p.window[i];
+        }
         __syncthreads();
-        if (tid < WBINS) {
-            double re = 0.0, im = 0.0;
+        if (valid && lane <= 50) {
+            const int k = lane;
+            double re[4] = {0.0, 0.0, 0.0, 0.0}, im[4] = {0.0, 0.0, 0.0, 0.0};      // S_j = re[j] + i im[j]
             int idx = 0;
-            for (int n = 0; n < WN; ++n) {
-                const double2 c = tw[idx];
-                re += xs[n] * c.x;
-                im -= xs[n] * c.y;
-                idx += tid;
-                if (idx >= WN) idx -= WN;
+            for (int n = 0; n < WN; n += 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double2 c = tw[idx];
+                    const double x = xs[wave][n + j];
+                    re[j] = fma(x, c.x, re[j]);
+                    im[j] = fma(-x, c.y, im[j]);
+                    idx += k;
+                    if (idx >= WN) idx -= WN;
+                }
             }
-            const double r32 = (double)(float)re, i32 = (double)(float)im;
-            const double mag = sqrt(r32 * r32 + i32 * i32);
-            pw[tid] = mag * mag;
+            auto put = [&](int bin, double r, double i_) {
+                const double r32 = (double)(float)r, i32 = (double)(float)i_;          // the reference stores the STFT as complex64
+                const double mag = sqrt(r32 * r32 + i32 * i32);
+                pw[wave][bin] = mag * mag;
+            };
+            put(k, (re[0] + re[2]) + (re[1] + re[3]), (im[0] + im[2]) + (im[1] + im[3]));
+            put(200 - k, (re[0] + re[2]) - (re[1] + re[3]), -((im[0] + im[2]) - (im[1] + im[3])));
+            // -i S1 = (im1, -re1),  +i S3 = (-im3, re3)
+            put(100 + k, (re[0] - re[2]) + (im[1] - im[3]), (im[0] - im[2]) - (re[1] - re[3]));
+            // S* terms: S0* - i S1* - S2* + i S3*;  -i (re1 - i im1) = (-im1, -re1),  +i (re3 - i im3) = (im3, re3)
+            put(100 - k, (re[0] - re[2]) - (im[1] - im[3]), -(im[0] - im[2]) - (re[1] - re[3]));
         }
         __syncthreads();
-        if (tid < p.nmel) {
-            const double* mt = p.mel_t + (long)tid * WBINS;
+        for (int q = tid; q < 4 * p.nmel; q += 256) {
+            const int fr = q / p.nmel, m = q - fr * p.nmel;
+            const long ff = f0 + fr;
+            if (ff >= total) continue;
+            const double* mt = p.mel_t + (long)m * WBINS;
             double acc = 0.0;
-            for (int k = 0; k < WBINS; ++k) acc += pw[k] * mt[k];
-            p.out[((long)b * p.frames + t) * p.nmel + tid] = (float)log10(fmax(acc, 1e-10));
+            for (int kk = mlo[m]; kk < mhi[m]; ++kk) acc = fma(pw[fr][kk], mt[kk], acc);
+            const float v = (float)log10(fmax(acc, 1e-10));
+            p.out[ff * p.nmel + m] = v;
+            atomic_max_f32(&smax[fr], v);
         }
+        __syncthreads();
+        if (tid < 4 && f0 + tid < total) atomic_max_f32(clipmax + (int)((f0 + tid) / p.frames), smax[tid]);
     }
 }
 
-// per clip: m = max over (frames, nmel); out = (max(x, m - 8) + 4) / 4, written both as (B, nmel, frames) fp32 (the HF
-// `input_features` layout) and as channels-last bf16 (B, frames, nmel) for the first conv
-__global__ __launch_bounds__(256) void whisper_norm_kernel(const float* __restrict__ x, int frames, int nmel,
+// out = (max(x, m - 8) + 4) / 4 with m = the clip's maximum (taken by the log-mel kernel), written both as (B, nmel, frames) fp32 (the HF
+// `input_features` layout, optional) and as channels-last bf16 (B, frames, nmel) for the first conv
+__global__ __launch_bounds__(256) void whisper_norm_kernel(const float* __restrict__ x, const float* __restrict__ clipmax, int frames, int nmel, int B,
                                                             float* __restrict__ out_ft, bf16_t* __restrict__ out_cl) {
-    __shared__ float red[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const float* xb = x + (long)b * frames * nmel;
-    float m = -INFINITY;
-    for (int i = tid; i < frames * nmel; i += 256) m = fmaxf(m, xb[i]);
-    m = wave_max(m);
-    if ((tid & 63) == 0) red[tid >> 6] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    for (int i = tid; i < frames * nmel; i += 256) {
-        const int t = i / nmel, f = i % nmel;
-        const float v = (fmaxf(xb[i], m - 8.0f) + 4.0f) / 4.0f;
+    const long per = (long)frames * nmel, total = per * B;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / per);
+        const int r = (int)(i - (long)b * per);
+        const int t = r / nmel, f = r - t * nmel;
+        const float v = (fmaxf(x[i], clipmax[b] - 8.0f) + 4.0f) / 4.0f;
         if (out_ft) out_ft[((long)b * nmel + f) * frames + t] = v;
-        if (out_cl) out_cl[(long)b * frames * nmel + i] = f2bf(v);
+        if (out_cl) out_cl[i] = f2bf(v);
     }
 }
 
@@ -118,7 +157,7 @@ __global__ __launch_bounds__(256) void add_pos_kernel(const bf16_t* __restrict__
 
 }  // namespace
 
-// wave (B, ldw) fp32; scratch (B, frames, nmel) fp32; outputs: features (B, nmel, frames) fp32 (nullable) and channels-last bf16 (nullable)
+// wave (B, ldw) fp32; scratch (B * frames * nmel + B) fp32; outputs: features (B, nmel, frames) fp32 (nullable) and channels-last bf16 (nullable)
 extern "C" int mi_whisper_logmel(const float* wave, long ldw, const int* num_samples, int n_samples, const double* window,
                                  const double* twiddle, const double* mel_t, int nmel, int B, float* scratch,
                                  float* out_features, void* out_cl_bf16, hipStream_t stream) {
@@ -127,8 +166,13 @@ extern "C" int mi_whisper_logmel(const float* wave, long ldw, const int* num_sam
     const int frames = n_samples / WHOP;                       // 1 + n_samples/160 frames, last one dropped
     WhArgs a{wave, ldw, num_samples, n_samples, window, twiddle, mel_t, nmel, scratch, frames, B};
     const long total = (long)B * frames;
-    hipLaunchKernelGGL(whisper_logmel_kernel, dim3((unsigned)(total < 8192 ? total : 8192)), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(whisper_norm_kernel, dim3(B), dim3(256), 0, stream, scratch, frames, nmel, out_features, (bf16_t*)out_cl_bf16);
+    float* clipmax = scratch + total * nmel;                   // B floats behind the (B, frames, nmel) scratch
+    if (hipMemsetD32Async((hipDeviceptr_t)clipmax, 0xFF800000u /* -inf */, B, stream) != hipSuccess) return MI_ERR_LAUNCH;
+    const long nblk = (total + 3) / 4;
+    hipLaunchKernelGGL(whisper_logmel_kernel, dim3((unsigned)(nblk < 4096 ? nblk : 4096)), dim3(256), 0, stream, a, clipmax);
+    const long nel = total * nmel;
+    hipLaunchKernelGGL(whisper_norm_kernel, dim3((unsigned)((nel + 255) / 256 < 8192 ? (nel + 255) / 256 : 8192)), dim3(256), 0, stream, scratch, clipmax, frames, nmel, B,
+                       out_features, (bf16_t*)out_cl_bf16);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

@@ -57,7 +57,7 @@ class WhisperFrontend:
         win, tw, mel = self._tables(wave.device)
         frames = self.n_samples // 160
         ns = num_samples.to(torch.int32) if num_samples is not None else torch.full((B,), min(N, self.n_samples), dtype=torch.int32, device=wave.device)
-        scratch = torch.empty((B, frames, self.num_mel), dtype=torch.float32, device=wave.device)
+        scratch = torch.empty(B * frames * self.num_mel + B, dtype=torch.float32, device=wave.device)       # log-mel before the clamp + the per-clip maxima
         feats = torch.empty((B, self.num_mel, frames), dtype=torch.float32, device=wave.device) if want_features else None
         cl = torch.empty((B, frames, self.num_mel), dtype=BF16, device=wave.device)
         rc = _lib.lib().mi_whisper_logmel(wave.data_ptr(), wave.stride(0), ns.data_ptr(), self.n_samples, win.data_ptr(), tw.data_ptr(),

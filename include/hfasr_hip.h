@@ -247,6 +247,7 @@ int mi_kv_cache_reorder(const void* const* src_k, const void* const* src_v, void
 
 /* ---- Whisper-style front end + glue (BASELINE config 4).  replaces: transformers WhisperFeatureExtractor numpy path
  *      (selected by configs/default_data_preprocessing_whisper.json:20-29) and the conv/position prologue of WhisperEncoder. */
+/* scratch: B * frames * nmel + B floats (frames = n_samples / 160): the log-mel before the clamp, then the per-clip maxima. */
 int mi_whisper_logmel(const float* wave, long ldw, const int* num_samples, int n_samples, const double* window,
                       const double* twiddle, const double* mel_t, int nmel, int B, float* scratch,
                       float* out_features, void* out_cl_bf16, mi_stream_t stream);
