@@ -39,6 +39,9 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double2* buf0 = reinterpret_cast<double2*>(smem) + wave * 2 * NFFT;
     double2* buf1 = buf0 + NFFT;
+    double2* twl = reinterpret_cast<double2*>(smem) + 4 * 2 * NFFT;       // [NFFT/2] twiddles, shared by the four waves (an LDS read instead of a global load per butterfly)
+    for (int i = threadIdx.x; i < NFFT / 2; i += 256) twl[i] = double2{p.twiddle[2 * i], p.twiddle[2 * i + 1]};
+    __syncthreads();
     const long total = (long)p.B * p.T_out;
     for (long fidx = (long)blockIdx.x * 4 + wave; fidx < total; fidx += (long)gridDim.x * 4) {
         const int b = (int)(fidx / p.T_out), t = (int)(fidx % p.T_out);
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs p) {
                 const double2 a = src[q + st * pp];
                 const double2 bb = src[q + st * (pp + mh)];
                 const int tw = pp * st;                 // exp(-2 pi i pp / nn) = exp(-2 pi i pp*st / 512)
-                const double wr = p.twiddle[2 * tw], wi = p.twiddle[2 * tw + 1];
+                const double wr = twl[tw].x, wi = twl[tw].y;
                 const double dr = a.x - bb.x, di = a.y - bb.y;
                 dst[q + st * (2 * pp)] = double2{a.x + bb.x, a.y + bb.y};
                 dst[q + st * (2 * pp + 1)] = double2{dr * wr - di * wi, dr * wi + di * wr};
@@ -208,7 +211,7 @@ extern "C" int mi_fbank_f64(const float* wave, long ldw, const int* num_samples,
                 B, nmel, mel_floor, preemph};
     const long total = (long)B * T_out;
     const int grid = (int)((total + 3) / 4 < 2048 ? (total + 3) / 4 : 2048);
-    const size_t lds = 4 * 2 * NFFT * sizeof(double2);
+    const size_t lds = (4 * 2 * NFFT + NFFT / 2) * sizeof(double2);
     hipLaunchKernelGGL(fbank_kernel, dim3(grid), dim3(256), lds, stream, a);
     MI_CHECK_LAUNCH();
     return MI_OK;
