@@ -45,7 +45,7 @@ struct SkArgs {
 
 __global__ __launch_bounds__(256) void skinny_linear_kernel(SkArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xs = reinterpret_cast<float*>(smem);                       // [M][K]
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                     // [M][K] bf16 (the operand precision of every linear on this path)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = (blockIdx.x * 4 + wave) * SK_COLS;
     // the weight vectors of this wave's columns do not depend on the input: request them first (SK_COLS x K/512 independent 16-B loads in
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(SkArgs p) {
         }
     for (int m = wave; m < p.M; m += 4) {
         if (p.x16) {
-            for (int k = lane; k < p.K; k += 64) xs[m * p.K + k] = bf2f(p.x16[(long)m * p.ldx16 + k]);
+            for (int k = lane; k < p.K; k += 64) xs[m * p.K + k] = p.x16[(long)m * p.ldx16 + k];
         } else if (p.ln_g) {
             const float* xr = p.x32 + (long)m * p.ldx;
             float xv[32];                                                 // the row stays in registers: one global pass (K <= 2048)
@@ -75,12 +75,13 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(SkArgs p) {
             for (int i = 0; i < 32; ++i) { const int k = lane + 64 * i; const float a = k < p.K ? xv[i] - mean : 0.f; q += a * a; }
             const float rstd = rsqrtf(wave_sum(q) / p.K + p.eps);
 #pragma unroll
-            for (int i = 0; i < 32; ++i) { const int k = lane + 64 * i; if (k < p.K) xs[m * p.K + k] = bf2f(f2bf((xv[i] - mean) * rstd * p.ln_g[k] + p.ln_b[k])); }
+            for (int i = 0; i < 32; ++i) { const int k = lane + 64 * i; if (k < p.K) xs[m * p.K + k] = f2bf((xv[i] - mean) * rstd * p.ln_g[k] + p.ln_b[k]); }
         } else {
-            for (int k = lane; k < p.K; k += 64) xs[m * p.K + k] = bf2f(f2bf(p.x32[(long)m * p.ldx + k]));
+            for (int k = lane; k < p.K; k += 64) xs[m * p.K + k] = f2bf(p.x32[(long)m * p.ldx + k]);
         }
     }
     __syncthreads();
+    // bf16 x bf16 products accumulated in fp32 two at a time (v_dot2c_f32_bf16): a quarter of the instructions of convert + fma per element
     float acc[SK_COLS][SK_MAXM];
 #pragma unroll
     for (int c = 0; c < SK_COLS; ++c)
@@ -93,13 +94,15 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(SkArgs p) {
 #pragma unroll
         for (int m = 0; m < SK_MAXM; ++m) {
             if (m >= p.M) continue;
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs + m * p.K + k), x1 = *reinterpret_cast<const f32x4*>(xs + m * p.K + k + 4);
+            const bf16x8 x8 = *reinterpret_cast<const bf16x8*>(xs + m * p.K + k);
 #pragma unroll
             for (int c = 0; c < SK_COLS; ++c) {
                 const bf16x8 w8 = wv[c][ps];
                 float a = acc[c][m];
-                a = fmaf(bf2f(w8[0]), x0.x, a); a = fmaf(bf2f(w8[1]), x0.y, a); a = fmaf(bf2f(w8[2]), x0.z, a); a = fmaf(bf2f(w8[3]), x0.w, a);
-                a = fmaf(bf2f(w8[4]), x1.x, a); a = fmaf(bf2f(w8[5]), x1.y, a); a = fmaf(bf2f(w8[6]), x1.z, a); a = fmaf(bf2f(w8[7]), x1.w, a);
+                a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(w8, w8, 0, 1), __builtin_shufflevector(x8, x8, 0, 1), a, false);
+                a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(w8, w8, 2, 3), __builtin_shufflevector(x8, x8, 2, 3), a, false);
+                a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(w8, w8, 4, 5), __builtin_shufflevector(x8, x8, 4, 5), a, false);
+                a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(w8, w8, 6, 7), __builtin_shufflevector(x8, x8, 6, 7), a, false);
                 acc[c][m] = a;
             }
         }
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(SkArgs p) {
 
 int skinny(const SkArgs& a, hipStream_t st) {
     if (a.M <= 0 || a.M > SK_MAXM || (a.K % 8) || (a.ldw % 8) || a.K > 2048) return MI_ERR_ARG;
-    const size_t lds = (size_t)a.M * a.K * sizeof(float);
+    const size_t lds = (size_t)a.M * a.K * sizeof(bf16_t);
     if (lds > 150 * 1024) return MI_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(skinny_linear_kernel, dim3(cdiv(a.N, 4 * SK_COLS)), dim3(256), lds, st, a);
     return MI_OK;
