@@ -43,6 +43,7 @@ struct SkArgs {
     int M, N, K, act;                      // act: 0 none, 2 gelu_new
 };
 
+template <int NCH>      // 64-wide chunks of a LayerNorm row a lane holds: 8 for K = 512 (exact), 32 for any K <= 2048
 __global__ __launch_bounds__(256) void skinny_linear_kernel(SkArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                     // [M][K] bf16 (the operand precision of every linear on this path)
@@ -65,17 +66,22 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(SkArgs p) {
             for (int k = lane; k < p.K; k += 64) xs[m * p.K + k] = p.x16[(long)m * p.ldx16 + k];
         } else if (p.ln_g) {
             const float* xr = p.x32 + (long)m * p.ldx;
-            float xv[32];                                                 // the row stays in registers: one global pass (K <= 2048)
+            float xv[NCH], gv[NCH], bv[NCH];                              // row + affine in registers, requested together: ONE global round trip
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) { const int k = lane + 64 * i; xv[i] = k < p.K ? xr[k] : 0.f; s += xv[i]; }
+            for (int i = 0; i < NCH; ++i) {
+                const int k = lane + 64 * i;
+                const bool ok = k < p.K;
+                xv[i] = ok ? xr[k] : 0.f; gv[i] = ok ? p.ln_g[k] : 0.f; bv[i] = ok ? p.ln_b[k] : 0.f;
+                s += xv[i];
+            }
             const float mean = wave_sum(s) / p.K;
             float q = 0.f;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) { const int k = lane + 64 * i; const float a = k < p.K ? xv[i] - mean : 0.f; q += a * a; }
+            for (int i = 0; i < NCH; ++i) { const int k = lane + 64 * i; const float a = k < p.K ? xv[i] - mean : 0.f; q += a * a; }
             const float rstd = rsqrtf(wave_sum(q) / p.K + p.eps);
 #pragma unroll
-            for (int i = 0; i < 32; ++i) { const int k = lane + 64 * i; if (k < p.K) xs[m * p.K + k] = f2bf((xv[i] - mean) * rstd * p.ln_g[k] + p.ln_b[k]); }
+            for (int i = 0; i < NCH; ++i) { const int k = lane + 64 * i; if (k < p.K) xs[m * p.K + k] = f2bf((xv[i] - mean) * rstd * gv[i] + bv[i]); }
         } else {
             for (int k = lane; k < p.K; k += 64) xs[m * p.K + k] = f2bf(p.x32[(long)m * p.ldx + k]);
         }
@@ -130,7 +136,8 @@ int skinny(const SkArgs& a, hipStream_t st) {
     if (a.M <= 0 || a.M > SK_MAXM || (a.K % 8) || (a.ldw % 8) || a.K > 2048) return MI_ERR_ARG;
     const size_t lds = (size_t)a.M * a.K * sizeof(bf16_t);
     if (lds > 150 * 1024) return MI_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(skinny_linear_kernel, dim3(cdiv(a.N, 4 * SK_COLS)), dim3(256), lds, st, a);
+    if (a.K <= 512) hipLaunchKernelGGL(skinny_linear_kernel<8>, dim3(cdiv(a.N, 4 * SK_COLS)), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(skinny_linear_kernel<32>, dim3(cdiv(a.N, 4 * SK_COLS)), dim3(256), lds, st, a);
     return MI_OK;
 }
 
