@@ -41,6 +41,7 @@ struct SkArgs {
     const float* resid32;
     bf16_t* out16; long ldo16;             // bf16 output
     int M, N, K, act;                      // act: 0 none, 2 gelu_new
+    bf16_t* kc; bf16_t* vc; int U, past, Lmax, dkv;      // optional (kc != null): columns [dkv, 2 dkv) / [2 dkv, 3 dkv) are ALSO appended to the K / V caches at row past + u
 };
 
 template <int NCH>      // 64-wide chunks of a LayerNorm row a lane holds: 8 for K = 512 (exact), 32 for any K <= 2048
@@ -127,7 +128,15 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(SkArgs p) {
             v += p.bias ? p.bias[n] : 0.f;
             if (p.act == 2) v = gelu_tanh(v);
             if (p.out32) p.out32[(long)lane * p.ldo32 + n] = (p.resid32 ? p.resid32[(long)lane * p.ldo32 + n] : 0.f) + v;
-            else p.out16[(long)lane * p.ldo16 + n] = f2bf(v);
+            else {
+                const bf16_t o = f2bf(v);
+                p.out16[(long)lane * p.ldo16 + n] = o;
+                if (p.kc && n >= p.dkv) {                              // fused KV-cache append (was a separate launch per layer)
+                    const int b = lane / p.U, u = lane - b * p.U;
+                    const long row = ((long)b * p.Lmax + p.past + u) * p.dkv;
+                    if (n < 2 * p.dkv) p.kc[row + n - p.dkv] = o; else p.vc[row + n - 2 * p.dkv] = o;
+                }
+            }
         }
     }
 }
@@ -224,10 +233,11 @@ extern "C" int mi_gpt2_step(const mi_gpt2_config* cfg, const void* const* weight
             bf16_t* kc = (bf16_t*)kcache[l];
             bf16_t* vc = (bf16_t*)vcache[l];
             const bf16_t* ckv = (const bf16_t*)cross_kv[l];
-            RUN(lin_ln(Lf(l, 0), Lf(l, 1), Lw(l, 2), Lf(l, 3), 3 * d, w.qkv, 0));
-            {
-                const long total = (long)M * (d / 8);
-                hipLaunchKernelGGL(kv_append_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w.qkv, (long)3 * d, kc, vc, B, U, past, Lmax, d);
+            {   // LN1 + fused QKV projection; its K / V columns go straight into the caches as well
+                SkArgs a{}; a.x32 = w.x; a.ldx = d; a.ln_g = Lf(l, 0); a.ln_b = Lf(l, 1); a.eps = c.eps; a.W = (const bf16_t*)Lw(l, 2); a.ldw = d; a.bias = Lf(l, 3);
+                a.out16 = w.qkv; a.ldo16 = 3 * d; a.M = M; a.N = 3 * d; a.K = d; a.act = 0;
+                a.kc = kc; a.vc = vc; a.U = U; a.past = past; a.Lmax = Lmax; a.dkv = d;
+                RUN(skinny(a, st));
             }
             RUN(mi_attention_qkv_bf16(w.qkv, 3 * d, kc, d, vc, d, nullptr, 0, nullptr, nullptr, nullptr, w.ctx, d, B, U, past + U, (long)Lmax * d, c.H, hd,
                                       scale, 1, st));
