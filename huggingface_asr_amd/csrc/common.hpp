@@ -58,15 +58,30 @@ __device__ __forceinline__ float gelu_tanh(float x) {
     return 0.5f * x * (2.f - 2.f / (e + 1.f));
 }
 
+// Wave-wide reductions by DPP (no LDS round trips: `__shfl_xor` is a ds_bpermute_b32 per step on gfx9, ~100 cycles of latency each, and the
+// small latency-bound kernels — token-step GEMVs, CTC, row statistics — are chains of them).  Within a row of 16 lanes: quad_perm, row_half_mirror,
+// row_mirror leave the row total in every lane; row_bcast:15 / row_bcast:31 carry it across the four rows into lane 63; v_readlane broadcasts it.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f32<0xB1, 0xF>(0.f, v);        // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E, 0xF>(0.f, v);        // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141, 0xF>(0.f, v);       // row_half_mirror
+    v += dpp_f32<0x140, 0xF>(0.f, v);       // row_mirror: every lane of a row holds the row total
+    v += dpp_f32<0x142, 0xA>(0.f, v);       // row_bcast:15 into rows 1 and 3
+    v += dpp_f32<0x143, 0xC>(0.f, v);       // row_bcast:31 into rows 2 and 3: lane 63 holds the wave total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f32<0xB1, 0xF>(v, v));
+    v = fmaxf(v, dpp_f32<0x4E, 0xF>(v, v));
+    v = fmaxf(v, dpp_f32<0x141, 0xF>(v, v));
+    v = fmaxf(v, dpp_f32<0x140, 0xF>(v, v));
+    v = fmaxf(v, dpp_f32<0x142, 0xA>(v, v));        // rows outside the mask keep `old` = their own value
+    v = fmaxf(v, dpp_f32<0x143, 0xC>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
