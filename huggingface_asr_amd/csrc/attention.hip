@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
             S[e] = dead ? -INFINITY : S[e] * p.scale;
             mx = fmaxf(mx, S[e]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = half_swap_max(mx);
         const float mnew = fmaxf(m, mx);
         const float alpha = __expf(m - mnew);
         float ls = 0.f;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
             S[e] = __expf(S[e] - mnew);
             ls += S[e];
         }
-        ls += __shfl_xor(ls, 32, 64);
+        ls = half_swap_sum(ls);
         l = l * alpha + ls;
         m = mnew;
 #pragma unroll
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
             S[e] = dead ? -INFINITY : S[e] * p.scale;
             mx = fmaxf(mx, S[e]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = half_swap_max(mx);
         const float mnew = fmaxf(m, mx);
         const float alpha = __expf(m - mnew);
         float ls = 0.f;
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
             S[e] = __expf(S[e] - mnew);
             ls += S[e];
         }
-        ls += __shfl_xor(ls, 32, 64);
+        ls = half_swap_sum(ls);
         l = l * alpha + ls;
         m = mnew;
 #pragma unroll
