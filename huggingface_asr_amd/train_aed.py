@@ -7,7 +7,7 @@ the transformers GPT-2 block (ln_1 -> causal self-attention -> ln_cross_attn -> 
 gelu_new MLP):   loss = w * CTC + (1 - w) * sum_k head_weight_k * CE_k.
 
 The encoder side is `train.EncoderCTCTrainer`; the decoder hooks into its backward at the encoder output (`extra_hidden_grad`),
-so the encoder's per-layer gradient all-reduces still overlap the remaining backward.  Same precision model and the same
+so, with `GradSync(overlap=True)`, the encoder's per-layer gradient all-reduces still overlap the remaining backward.  Same precision model and the same
 restrictions as train.py; GPT-2's embd / attn / resid dropouts use the same counter-based masks (decoder layer l = stream layer 32 + l).
 """
 from __future__ import annotations
