@@ -48,6 +48,8 @@ def run_training_forward(model, trainer, step_fn):
             grads = trainer.grad_dict()
             return outs, grads
 
+    if hasattr(trainer, "set_frozen"):                  # frozen sub-modules: their weight-gradient GEMMs are skipped, not computed and dropped
+        trainer.set_frozen({n for n, p in named if not p.requires_grad})
     runner = _Runner()
     loss = HipStep.apply(runner, names, *[p for _, p in named])
     return loss, runner.outputs

@@ -302,6 +302,7 @@ class EncoderCTCTrainer:
             raise NotImplementedError("training path: 2-layer 3x3 Conv2d sub-sampling only")
         if c.get("csgu_activation", "identity") != "identity" or c.get("csgu_use_linear_after_conv", False):
             raise NotImplementedError("training path: CSGU with identity activation and no linear-after-conv only")
+        self.frozen = set()
         self.layerdrop = float(c.get("layerdrop", 0.0) or 0.0)      # tf:models/wav2vec2_conformer/modeling_wav2vec2_conformer.py:686-690
         g = lambda k: float(c.get(k, 0.0) or 0.0)
         # dropout probabilities by site (which config value feeds which nn.Dropout: e_branchformer.py:132,182,229-246,451; tf :353,356,674)
@@ -346,6 +347,13 @@ class EncoderCTCTrainer:
 
     def state_dict(self) -> dict:
         return self._export(self.store.p)
+
+    def set_frozen(self, reference_names):
+        """Names (reference state-dict keys) of parameters that do not train (`requires_grad False`: `freeze_encoder()`, train_ctc_asr.py:51-52).
+        A packed store parameter counts as frozen when all of its reference pieces are; the weight / bias gradient GEMMs of frozen linears
+        are then skipped in the backward (their input gradients are still computed: something upstream may train)."""
+        ref = set(reference_names or ())
+        self.frozen = {name for name in self.store.order if name in self.map and self.map[name][1] and all(k in ref for k, _ in self.map[name][1])}
 
     def grad_dict(self) -> dict:
         """gradients in the reference's parameter names / shapes (tests, checkpoint tooling, the autograd bridge)."""
@@ -398,6 +406,7 @@ class EncoderCTCTrainer:
         is below `config.layerdrop` (every rank draws its own, from its dropout seed) — in training mode; nothing is skipped in eval."""
         c, st = self.cfg, self.store
         P, G, W, WT = st.p, st.g, st.bf, st.bfT
+        GL = lambda n, sl=None: None if n in self.frozen else (st.g(n) if sl is None else st.g(n)[sl])      # gradient of a linear's weight / bias, None when frozen
         dev = self.device
         feats = feats.to(F32).contiguous()
         B, Tn, Fq = feats.shape
@@ -562,11 +571,11 @@ class EncoderCTCTrainer:
                 self._ffn_bwd(dx, S["x2"], S["ff2"], p + "ff2", pd, l, (6, 7))
             # merge:  x2 = x1 + dropout(merge_proj(m2))
             dyb = T.dropout_(dx, pd["att"], seed, self._sid(l, 5), out=e16(M, d)) if pd["att"] > 0 else T.add_cast(dx)
-            dm2 = T.linear_bwd(dyb, S["m2"], WT(p + "mrg_w"), dw=G(p + "mrg_w"), db=G(p + "mrg_b"))
+            dm2 = T.linear_bwd(dyb, S["m2"], WT(p + "mrg_w"), dw=GL(p + "mrg_w"), db=GL(p + "mrg_b"))
             dcat = e16(M, 2 * d)
             T.dwconv_residual_bwd(S["cat"], P(p + "mrg_dw_w"), dm2, dcat, G(p + "mrg_dw_w"), G(p + "mrg_dw_b"), B, T2)
             # local branch
-            dsg = T.linear_bwd(dcat[:, d:], S["sg"], WT(p + "mlp_w2"), dw=G(p + "mlp_w2"), db=G(p + "mlp_b2"))
+            dsg = T.linear_bwd(dcat[:, d:], S["sg"], WT(p + "mlp_w2"), dw=GL(p + "mlp_w2"), db=GL(p + "mlp_b2"))
             if pd["csgu"] > 0:
                 T.dropout_(dsg, pd["csgu"], seed, self._sid(l, 4))
             dh = e16(M, I)
@@ -575,22 +584,22 @@ class EncoderCTCTrainer:
                        G(p + "csgu_w"), G(p + "csgu_b"), B, T2)
             T.layernorm_bwd(S["h"][:, I // 2:], P(p + "csgu_ln_g"), dgn, dh[:, I // 2:], accumulate=False, dgamma=G(p + "csgu_ln_g"), dbeta=G(p + "csgu_ln_b"))
             dhp = T.act_bwd(dh, S["hp"])
-            da2 = T.linear_bwd(dhp, S["a2"], WT(p + "mlp_w1"), dw=G(p + "mlp_w1"), db=G(p + "mlp_b1"))
+            da2 = T.linear_bwd(dhp, S["a2"], WT(p + "mlp_w1"), dw=GL(p + "mlp_w1"), db=GL(p + "mlp_b1"))
             T.layernorm_bwd(S["x1"], P(p + "mlp_ln_g"), da2, dx, accumulate=True, dgamma=G(p + "mlp_ln_g"), dbeta=G(p + "mlp_ln_b"))
             # global branch
             if pd["att"] > 0:
                 T.dropout_(dcat[:, :d], pd["att"], seed, self._sid(l, 3))
-            dctx = T.linear_bwd(dcat[:, :d], S["ctx"], WT(p + "att_wo"), dw=G(p + "att_wo"), db=G(p + "att_bo"))
+            dctx = T.linear_bwd(dcat[:, :d], S["ctx"], WT(p + "att_wo"), dw=GL(p + "att_wo"), db=GL(p + "att_bo"))
             dqkv = self._attention_bwd(dctx, S, p, pos, inner, B, T2, H, (pd["att"], seed, self._sid(l, 2)) if pd["att"] > 0 else None)
             if ptype == "rotary":
                 wt = WT(p + "att_wqkv")
-                da1r = T.linear_bwd(dqkv[:, :2 * d], S["a1r"], wt[:, :2 * d], dw=G(p + "att_wqkv")[:2 * d], db=G(p + "att_bqkv")[:2 * d])
-                da1 = T.linear_bwd(dqkv[:, 2 * d:], S["a1"], wt[:, 2 * d:3 * d], dw=G(p + "att_wqkv")[2 * d:], db=G(p + "att_bqkv")[2 * d:], dx_dtype=F32)
+                da1r = T.linear_bwd(dqkv[:, :2 * d], S["a1r"], wt[:, :2 * d], dw=GL(p + "att_wqkv", slice(0, 2 * d)), db=GL(p + "att_bqkv", slice(0, 2 * d)))
+                da1 = T.linear_bwd(dqkv[:, 2 * d:], S["a1"], wt[:, 2 * d:3 * d], dw=GL(p + "att_wqkv", slice(2 * d, None)), db=GL(p + "att_bqkv", slice(2 * d, None)), dx_dtype=F32)
                 rot = ops.rotary(da1r, pos[0].reshape(-1), pos[2].reshape(-1), T2, H)             # R^T = rotation by -theta
                 T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), da1, dx, accumulate=True, dgamma=G(p + "att_ln_g"), dbeta=G(p + "att_ln_b"))
                 T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), rot, dx, accumulate=True, dgamma=G(p + "att_ln_g"), dbeta=G(p + "att_ln_b"))
             else:
-                da1 = T.linear_bwd(dqkv, S["a1"], WT(p + "att_wqkv")[:, :3 * d], dw=G(p + "att_wqkv"), db=G(p + "att_bqkv"))
+                da1 = T.linear_bwd(dqkv, S["a1"], WT(p + "att_wqkv")[:, :3 * d], dw=GL(p + "att_wqkv"), db=GL(p + "att_bqkv"))
                 T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), da1, dx, accumulate=True, dgamma=G(p + "att_ln_g"), dbeta=G(p + "att_ln_b"))
             if macaron:
                 self._ffn_bwd(dx, S["x_in"], S["ff1"], p + "ff1", pd, l, (0, 1))
@@ -605,10 +614,10 @@ class EncoderCTCTrainer:
         elif tmask is not None or fmask is not None:
             T.spec_mask_bwd_(dx, tmask, G("masked_spec_embed"), fmask, T2)
         dyb = T.dropout_(dx, pd["fp"], seed, self._sid(L, 0), out=e16(M, d)) if pd["fp"] > 0 else T.add_cast(dx)
-        da = T.linear_bwd(dyb, a_fp, WT("fp_w"), dw=G("fp_w"), db=G("fp_b"))
+        da = T.linear_bwd(dyb, a_fp, WT("fp_w"), dw=GL("fp_w"), db=GL("fp_b"))
         dfeo = e32(M, d)
         T.layernorm_bwd(feo, P("fp_ln_g"), da, dfeo, accumulate=False, dgamma=G("fp_ln_g"), dbeta=G("fp_ln_b"), eps=eps_e)
-        dact2 = T.linear_bwd(T.add_cast(dfeo), act2, WT("feout_w"), dw=G("feout_w"), db=G("feout_b"))      # (M, F2*C2)
+        dact2 = T.linear_bwd(T.add_cast(dfeo), act2, WT("feout_w"), dw=GL("feout_w"), db=GL("feout_b"))      # (M, F2*C2)
         dpre2 = T.act_bwd(dact2.view(B * T2 * F2, C2), pre2)
         col = T.im2col(act1, K, s_, pad, T2, F2)
         T.gemm_tn_(G("conv2_w"), dpre2, col, db=G("conv2_b"))
@@ -677,15 +686,16 @@ class EncoderCTCTrainer:
     def _ffn_bwd(self, dx, x_in, S, pre, pd, l, sites):
         """dx (f32, in place): gradient w.r.t. the block output -> gradient w.r.t. its input (residual + LN path)."""
         P, G, WT = self.store.p, self.store.g, self.store.bfT
+        GL = lambda n: None if n in self.frozen else self.store.g(n)
         if pd["hidden"] > 0:
             dyb = T.dropout_(dx, pd["hidden"], self.seed, self._sid(l, sites[1]), out=torch.empty(dx.shape, device=dx.device, dtype=BF16), alpha=0.5)
         else:
             dyb = T.add_cast(dx, alpha=0.5)
-        dh = T.linear_bwd(dyb, S["h"], WT(pre + "_w2"), dw=G(pre + "_w2"), db=G(pre + "_b2"))
+        dh = T.linear_bwd(dyb, S["h"], WT(pre + "_w2"), dw=GL(pre + "_w2"), db=GL(pre + "_b2"))
         if pd["act"] > 0:
             T.dropout_(dh, pd["act"], self.seed, self._sid(l, sites[0]))
         dhp = T.act_bwd(dh, S["hp"])
-        da = T.linear_bwd(dhp, S["a"], WT(pre + "_w1"), dw=G(pre + "_w1"), db=G(pre + "_b1"))
+        da = T.linear_bwd(dhp, S["a"], WT(pre + "_w1"), dw=GL(pre + "_w1"), db=GL(pre + "_b1"))
         T.layernorm_bwd(x_in, P(pre + "_ln_g"), da, dx, accumulate=True, dgamma=G(pre + "_ln_g"), dbeta=G(pre + "_ln_b"))
 
     def _attention_fwd(self, qkv, posp, u, v, lengths, B, Tt, H, S, drop=None):

@@ -158,6 +158,10 @@ class JointAEDTrainer:
             self.store.p(name).copy_(self.map[name][0](sdd).reshape(self.store.specs[name].shape))
         self.store.refresh_mirrors(cast=True)
 
+    def set_frozen(self, reference_names):
+        """frozen encoder parameters (freeze_encoder): their weight-gradient GEMMs are skipped (train.EncoderCTCTrainer.set_frozen); decoder: computed"""
+        self.enc.set_frozen({k[len("encoder."):] for k in (reference_names or ()) if k.startswith("encoder.")})
+
     def _export(self, view):
         out = {"encoder." + k: v for k, v in (self.enc.state_dict() if view == "p" else self.enc.grad_dict()).items()}
         for name in self.store.order:

@@ -229,6 +229,11 @@ def test_hf_ctc_model_trains_through_autograd_bridge():
     model.freeze_encoder()
     model(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV)).loss.backward()
     assert all(p.grad is None for p in model.wav2vec2.encoder.parameters()) and model.lm_head.weight.grad is not None
+    tr = getattr(model, "_trainer", None)
+    if tr is not None:                                        # the frozen linears' dW GEMMs were skipped: their gradient ranges stayed zero
+        assert "l0.ff1_w1" in tr.frozen and "head_w" not in tr.frozen and "conv1_w" not in tr.frozen
+        assert float(tr.store.g("l0.ff1_w1").abs().max()) == 0.0 and float(tr.store.g("head_w").abs().max()) > 0.0
+        assert float(tr.store.g("feout_w").abs().max()) > 0.0                  # still reached through the frozen layers
     # the reference's default config (dropouts 0.1, layerdrop 0.1, in-model SpecAugment on) trains as it stands
     dflt = AutoModelForCTC.from_config(Wav2Vec2EBranchformerConfig(**base, ctc_zero_infinity=True)).to(DEV).train()
     assert not any(dflt.load_state_dict(sd, strict=False))
