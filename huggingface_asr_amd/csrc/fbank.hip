@@ -7,7 +7,7 @@
 //   -> povey window -> 512-pt FFT (result rounded to complex64) -> |.|^2 -> 80 Kaldi mel triangles
 //   -> max(., 1.19e-7) -> log -> float32,
 // and utterance_cmvn (:141-163) / global_normalize (feature_extractors.py:47-49).
-// One wave per frame: a radix-2 Stockham FFT in wave-private LDS, twiddles/window/filters from
+// One wave per frame: the real 512-point transform as a complex 256-point radix-4 Stockham FFT (4 stages) + unpack, in wave-private LDS, twiddles/window/filters from
 // host-built float64 tables (identical numbers to numpy's).  52 MFLOP per 10 s clip -> latency/LDS bound,
 // not HBM bound (0.64 MB in, 0.32 MB out per clip).
 #include "common.hpp"
@@ -49,59 +49,76 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs p) {
         const int nframes = ns >= FRAME ? 1 + (ns - FRAME) / HOP : 0;
         if (t >= nframes) continue;                         // wave-uniform
         const float* w = p.wave + (long)b * p.ldw + (long)t * HOP;
-        // 1. load (x * 2^15 in float32, then float64), DC offset
-        double x[7], xm1[7];
+        // 1. load (x * 2^15 in float32, then float64), DC offset.  Lane owns the sample PAIRS (2m, 2m+1), m = lane + 64 i: the real 512-point
+        //    transform is done as a complex 256-point FFT of z[m] = x[2m] + i x[2m+1] and unpacked afterwards (half the butterflies)
+        double xa[4], xb[4], xp[4];
         double s = 0.0;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const int n = lane + 64 * i;
-            x[i] = (n < FRAME) ? (double)(w[n] * 32768.0f) : 0.0;
-            xm1[i] = (n >= 1 && n < FRAME) ? (double)(w[n - 1] * 32768.0f) : 0.0;
-            s += x[i];
+        for (int i = 0; i < 4; ++i) {
+            const int n0 = 2 * (lane + 64 * i), n1 = n0 + 1;
+            xa[i] = (n0 < FRAME) ? (double)(w[n0] * 32768.0f) : 0.0;
+            xb[i] = (n1 < FRAME) ? (double)(w[n1] * 32768.0f) : 0.0;
+            xp[i] = (n0 >= 1 && n0 < FRAME) ? (double)(w[n0 - 1] * 32768.0f) : 0.0;
+            s += xa[i] + xb[i];
         }
         const double mean = wave_sum_d(s) / (double)FRAME;
-        // 2. pre-emphasis on the DC-removed frame, window, into the FFT buffer (zero padded to 512)
+        // 2. pre-emphasis on the DC-removed frame, window, into the FFT buffer (zero padded to 512 samples = 256 pairs)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int n = lane + 64 * i;
-            double v = 0.0;
-            if (i < 7 && n < FRAME) {
-                const double c = x[i] - mean;
-                v = (n == 0) ? c * (1.0 - p.preemph) : c - p.preemph * (xm1[i] - mean);
-                v *= p.window[n];
+        for (int i = 0; i < 4; ++i) {
+            const int m = lane + 64 * i, n0 = 2 * m, n1 = n0 + 1;
+            double v0 = 0.0, v1 = 0.0;
+            if (n0 < FRAME) {
+                const double c0 = xa[i] - mean;
+                v0 = ((n0 == 0) ? c0 * (1.0 - p.preemph) : c0 - p.preemph * (xp[i] - mean)) * p.window[n0];
+                if (n1 < FRAME) v1 = ((xb[i] - mean) - p.preemph * c0) * p.window[n1];
             }
-            buf0[n] = double2{v, 0.0};
+            buf0[m] = double2{v0, v1};
         }
         wave_lds_sync();
-        // 3. Stockham radix-2 DIF, 9 stages
+        // 3. Stockham radix-4 DIF, 256 points = 4 stages, one butterfly per lane and stage.  w(j) = exp(-2 pi i j / 256) from the 512th-root table.
+        auto w256 = [&](int j) { const double2 t = twl[2 * (j & 127)]; return (j & 128) ? double2{-t.x, -t.y} : t; };
+        auto cmul = [](double2 a, double2 b) { return double2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; };
         double2* src = buf0;
         double2* dst = buf1;
-        int nn = NFFT, st = 1;
-        for (int stage = 0; stage < 9; ++stage) {
-            const int mh = nn >> 1;
+        int nn = 256, st = 1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int tt = lane + 64 * i;           // butterfly 0..255
-                const int q = tt & (st - 1), pp = tt / st;
-                const double2 a = src[q + st * pp];
-                const double2 bb = src[q + st * (pp + mh)];
-                const int tw = pp * st;                 // exp(-2 pi i pp / nn) = exp(-2 pi i pp*st / 512)
-                const double wr = twl[tw].x, wi = twl[tw].y;
-                const double dr = a.x - bb.x, di = a.y - bb.y;
-                dst[q + st * (2 * pp)] = double2{a.x + bb.x, a.y + bb.y};
-                dst[q + st * (2 * pp + 1)] = double2{dr * wr - di * wi, dr * wi + di * wr};
-            }
+        for (int stage = 0; stage < 4; ++stage) {
+            const int n4 = nn >> 2;
+            const int q = lane & (st - 1), pp = lane / st;         // butterfly `lane`: 0..63 = (n/4) * s
+            const double2 a = src[q + st * pp], b = src[q + st * (pp + n4)], c = src[q + st * (pp + 2 * n4)], d = src[q + st * (pp + 3 * n4)];
+            const double2 apc = {a.x + c.x, a.y + c.y}, amc = {a.x - c.x, a.y - c.y};
+            const double2 bpd = {b.x + d.x, b.y + d.y}, bmd = {b.x - d.x, b.y - d.y};
+            const int j = pp * st;                                 // exp(-2 pi i pp / nn) = w256(pp * st)
+            dst[q + st * (4 * pp + 0)] = double2{apc.x + bpd.x, apc.y + bpd.y};
+            dst[q + st * (4 * pp + 1)] = cmul(double2{amc.x + bmd.y, amc.y - bmd.x}, w256(j));          // a - i b - c + i d
+            dst[q + st * (4 * pp + 2)] = cmul(double2{apc.x - bpd.x, apc.y - bpd.y}, w256(2 * j));
+            dst[q + st * (4 * pp + 3)] = cmul(double2{amc.x - bmd.y, amc.y + bmd.x}, w256(3 * j));      // a + i b - c - i d
             wave_lds_sync();
             double2* tmp = src; src = dst; dst = tmp;
-            nn = mh; st <<= 1;
+            nn = n4; st <<= 2;
         }
-        // 4. power of the complex64-rounded spectrum, kept in LDS (reuse dst as 257 doubles)
+        // 4. unpack the real transform, X[k] = E[k] + W512^k O[k] with E = (Z[k] + conj Z[256-k]) / 2, O = (Z[k] - conj Z[256-k]) / (2i), and take the
+        //    power of the complex64-rounded spectrum (kept in LDS: dst reused as 257 doubles)
         double* pw = reinterpret_cast<double*>(dst);
-        for (int k = lane; k < NBINS; k += 64) {
-            const double re = (double)(float)src[k].x, im = (double)(float)src[k].y;
-            const double mag = sqrt(re * re + im * im);
-            pw[k] = mag * mag;
+        double pk[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int k = lane + 64 * i;
+            pk[i] = 0.0;
+            if (k < NBINS) {
+                const double2 zk = src[k & 255], zc = src[(256 - k) & 255];
+                const double2 e = {0.5 * (zk.x + zc.x), 0.5 * (zk.y - zc.y)};
+                const double2 o = {0.5 * (zk.y + zc.y), -0.5 * (zk.x - zc.x)};              // (zk - conj zc) / (2i)
+                const double2 wk = (k < 256) ? twl[k] : double2{-1.0, 0.0};
+                const double2 ow = cmul(o, wk);
+                const double re = (double)(float)(e.x + ow.x), im = (double)(float)(e.y + ow.y);
+                const double mag = sqrt(re * re + im * im);
+                pk[i] = mag * mag;
+            }
         }
+        wave_lds_sync();                                            // every lane has read Z before dst/src are reused for the powers
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { const int k = lane + 64 * i; if (k < NBINS) pw[k] = pk[i]; }
         wave_lds_sync();
         // 5. mel filters, floor, log
         float* o = p.out + (long)b * p.ld_out_b + (long)t * p.nmel;
