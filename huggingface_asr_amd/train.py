@@ -290,9 +290,11 @@ class EncoderCTCTrainer:
     """forward + backward + AdamW for Wav2Vec2EBranchformerForCTC on one GPU (one process per GPU under DP)."""
 
     def __init__(self, cfg: dict, device="cuda:0", *, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
-                 dp_sync=True, seed=0, head=True, grad_norm_skip=100.0):
-        """grad_norm_skip: a step whose global gradient norm exceeds it (or is not finite) is dropped — parameters and moments untouched — as
-        GradAwareTrainer does with its fixed threshold of 100 (training_utils.py:81,101-115); 0 disables.
+                 dp_sync=True, seed=0, head=True, grad_norm_skip=0.0):
+        """grad_norm_skip: > 0: a step whose global gradient norm exceeds it is dropped — parameters and moments untouched — which is what
+        GradAwareTrainer does with its fixed threshold of 100 (training_utils.py:81,101-115; pass 100.0 to mirror it).  Off by default: on
+        randomly initialised models the norm sits above 100 and every step would be dropped silently.  A non-finite norm always drops the step.
+        `optimizer_step` leaves the decision in `self.last_step_flags` ([norm, clip coefficient, skipped] on the device).
         dp_sync=False: no gradient all-reduce here (the caller, e.g. HF Trainer's DDP wrapper, owns data parallelism).
         seed: dropout mask seed (masks are counter-based: f(seed, step, layer, site, element), csrc/dropout.hip); give every DP rank its own."""
         c = self.cfg = dict(cfg)
@@ -803,6 +805,7 @@ class EncoderCTCTrainer:
         T.adamw_step_(st.flat_p, st.flat_g, st.flat_m, st.flat_v, st.decay, lr=hp["lr"] if lr is None else lr, betas=hp["betas"], eps=hp["eps"],
                       weight_decay=hp["weight_decay"], step=st.step_count, norm_coef=sc[1:4], mirror=st.flat_bf)
         st.refresh_mirrors(cast=False)
+        self.last_step_flags = sc[1:4]
         return sc[1]          # gradient norm (device scalar)
 
     def train_step(self, feats, feat_lengths, labels, lr=None):

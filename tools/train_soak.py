@@ -7,7 +7,7 @@ from huggingface_asr_amd import shapes, synth
 from huggingface_asr_amd.train import EncoderCTCTrainer
 dev = "cuda:0"
 cfg = dict(shapes.BASE, ctc_zero_infinity=True, ctc_loss_reduction="mean", hidden_dropout=0.1, activation_dropout=0.1, attention_dropout=0.1,
-           final_dropout=0.1, feat_proj_dropout=0.0, csgu_conv_dropout=0.1, layerdrop=0.0, apply_spec_augment=True, mask_time_prob=0.05,
+           final_dropout=0.1, feat_proj_dropout=0.0, csgu_conv_dropout=0.1, layerdrop=0.05, apply_spec_augment=True, mask_time_prob=0.05,
            mask_time_length=10, mask_time_min_masks=2)
 sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()}
 tr = EncoderCTCTrainer(cfg, dev, lr=1e-3, weight_decay=1e-6, seed=3)
