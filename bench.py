@@ -46,7 +46,7 @@ def algorithmic_gflop_per_utt(cfg, T2):
     return 2.0 * mac / 1e9
 
 
-def pmc_traffic_bytes(kernel_prefix="gemm_glds_kernel<128, 128, 2, 2, 2, false>"):
+def pmc_traffic_bytes(kernel_prefix="gemm_glds_kernel<128, 64, 2, 2, 2, false>"):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*pmc*per_launch.txt: rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate runs of this command, FETCH_SIZE doubled for 16-B/lane reads as MI355X_MICROARCH.md prescribes).  PMC counters cannot
     be collected inside the timed region, so the bench line carries the recorded value and names its source; None if the file is absent."""
@@ -163,7 +163,7 @@ def main():
             ker_ms = max(ms.value - n * cal.value, 0.5 * ms.value)
             ach = fl.value / (ker_ms * 1e-3) / 1e12
             traffic, tsrc = pmc_traffic_bytes()
-            roof = dict(bound="mfma", kernel="gemm_glds_kernel<128,128,2,2,2,false> (all nn.Linear GEMMs)", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+            roof = dict(bound="mfma", kernel="gemm_glds_kernel<128,64,2,2,2,false> (all nn.Linear GEMMs)", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic, traffic_unit="HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
                         traffic_source=tsrc, launches=n, avg_launch_us=round(ker_ms * 1e3 / n, 2),
                         avg_launch_us_raw_events=round(raw_us, 2), event_pair_overhead_us=round(cal.value * 1e3, 2),

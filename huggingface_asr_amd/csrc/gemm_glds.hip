@@ -291,7 +291,7 @@ __device__ __forceinline__ void gemm_glds_tile(const GemmArgs& p, int bid, char*
 // Grid-stride over output tiles: with gridDim.x == number of tiles this is the plain one-tile-per-block launch; with a persistent grid
 // (two blocks per CU) a block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... — half the workgroup dispatches for the same work.
 template <int TBM, int TBN, int CWM, int CWN, int STAGES, bool CONV>
-__global__ __launch_bounds__(CWM * CWN * 64, (TBM == 128 && TBN == 128 && STAGES == 2) ? 2 : 1) void gemm_glds_kernel(GemmArgs p) {
+__global__ __launch_bounds__(CWM * CWN * 64, (TBM <= 128 && TBN <= 128 && STAGES == 2) ? 2 : 1) void gemm_glds_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = ((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN);
     const bool pf = !CONV && STAGES == 2 && p.krot == 0 && !(p.dbg & 15);
@@ -340,9 +340,20 @@ int gemm_glds_launch(const GemmArgs& a_in, bool conv, hipStream_t stream) {
         else hipLaunchKernelGGL((gemm_glds_kernel<256, 256, 2, 4, 2, false>), dim3(t256), dim3(512), l, stream, a);
         return MI_OK;
     }
+    // Default for the dense (non-conv) GEMMs: 128 x 64 output tiles, 48 KiB of LDS -> THREE persistent blocks per CU (768 walk the tiles).  In the real step
+    // the operands arrive cold (the other kernels move hundreds of MB between two GEMMs) and every K step of a block is a dependent fetch: what pays is
+    // more blocks in flight per CU, not fewer bytes per flop.  Measured end to end (bench.py, one box, same build): 128x128 / 512 blocks 7.04 ms per step,
+    // 128x64 / 768 blocks 6.57, 128x64 one block per tile 6.74, 64x64 / 1024 blocks 6.80, 64x128 7.90, 128x32 7.81; the conv GEMM (K = 2304) stays at 128x128.
+    // HFASR_GEMM_VARIANT=30 restores the 128x128 tiles for A/B.
+    if (!conv && g_variant != 30 && g_variant != 31 && g_stages == 2) {
+        int g = cdiv(a.M, 128) * cdiv(a.N, 64);
+        if (g > 768) g = 768;
+        hipLaunchKernelGGL((gemm_glds_kernel<128, 64, 2, 2, 2, false>), dim3(g), dim3(NT), (size_t)2 * (128 + 64) * BK * 2, stream, a);
+        return MI_OK;
+    }
     int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
-    // persistent grid (two blocks per CU walk the tiles, the next tile's first K tile is prefetched under the epilogue): +1.5-2 % on the
-    // end-to-end step vs one block per tile; HFASR_GEMM_VARIANT=31 restores the one-block-per-tile launch for A/B
+    // 128 x 128 tiles (conv GEMM; dense GEMMs with HFASR_GEMM_VARIANT=30 / 31 or a non-default ring depth): persistent grid of two blocks per CU, the next
+    // tile's first K tile prefetched under the epilogue; variant 31 = one block per tile
     if (g_variant != 31 && grid > 512) grid = 512;
     const int stages = g_stages;
     const size_t lds = (size_t)stages * STAGE_BYTES;
