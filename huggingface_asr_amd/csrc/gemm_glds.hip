@@ -345,7 +345,10 @@ int gemm_glds_launch(const GemmArgs& a_in, bool conv, hipStream_t stream) {
     // more blocks in flight per CU, not fewer bytes per flop.  Measured end to end (bench.py, one box, same build): 128x128 / 512 blocks 7.04 ms per step,
     // 128x64 / 768 blocks 6.57, 128x64 one block per tile 6.74, 64x64 / 1024 blocks 6.80, 64x128 7.90, 128x32 7.81; the conv GEMM (K = 2304) stays at 128x128.
     // HFASR_GEMM_VARIANT=30 restores the 128x128 tiles for A/B.
-    if (!conv && g_variant != 30 && g_variant != 31 && g_stages == 2) {
+    // Only SHORT launches take the small tile: up to ~48 K steps of 128 x 128 work per CU (every encoder-layer GEMM of the base model at 32 x 10 s: 31.5).  Longer ones
+    // (Whisper-small at 16 x 30 s: 53 and up; the CTC head: 79) amortise their start-up and are 5 % faster on 128 x 128 tiles (fewer bytes per flop).
+    const long steps_per_cu = (long)cdiv(a.M, BM) * cdiv(a.N, BN) * (a.K / BK) / 256;
+    if (!conv && g_variant != 30 && g_variant != 31 && g_stages == 2 && (steps_per_cu <= 48 || g_variant == 8)) {
         int g = cdiv(a.M, 128) * cdiv(a.N, 64);
         if (g > 768) g = 768;
         hipLaunchKernelGGL((gemm_glds_kernel<128, 64, 2, 2, 2, false>), dim3(g), dim3(NT), (size_t)2 * (128 + 64) * BK * 2, stream, a);
