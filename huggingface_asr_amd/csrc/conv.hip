@@ -192,8 +192,8 @@ __global__ __launch_bounds__(256) void dwconv_time_kernel(DwArgs p) {
 
 // Fast form for the reference's kernel size 31, dilation 1.  A block owns 64 channels x 64 time steps (4 blocks per CU; 128 steps at 2 per CU was 1 % slower end to end): the (64+30) x 64
 // input tile (16-B global loads, LayerNorm applied on the way in), the gate operand x_r and the result tile all live in
-// LDS, every thread keeps a 62-sample window + the 31 taps of its channel in registers and produces 32 consecutive
-// outputs (93 LDS reads per 992 FMAs), and the result leaves as 16-B-per-lane rows.
+// LDS, every thread keeps a 46-sample window + the 31 taps of its channel in registers and produces 16 consecutive
+// outputs (77 LDS reads per 496 FMAs), and the result leaves as 16-B-per-lane rows.
 constexpr int DWF_K = 31, DWF_TT = 64, DWF_CT = 64, DWF_ROWS = DWF_TT + DWF_K - 1, DWF_PER = DWF_TT / 4;
 constexpr int DWF_WS = DWF_CT + 1, DWF_WBUF = (DWF_K * DWF_WS + 3) / 4 * 4;     // weight rows padded to 65 floats; buffer rounded so `io` stays 16-B aligned
 

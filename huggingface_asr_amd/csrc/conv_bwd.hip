@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwBwdArgs p) {
 // and the conv-output-gradient tile live in LDS as fp32, every thread keeps both 62-sample windows, the 31 taps and the 31
 // tap gradients of its channel in registers and produces 32 consecutive steps.  Tap / bias gradients leave as per-utterance
 // partials (workspace (B, C, 32)), summed over B by dw_partial_reduce_kernel — no float atomics.
-constexpr int FB_K = 31, FB_TT = 128, FB_CT = 64, FB_ROWS = FB_TT + FB_K - 1, FB_PER = FB_TT / 4;
+constexpr int FB_K = 31, FB_TT = 64, FB_CT = 64, FB_ROWS = FB_TT + FB_K - 1, FB_PER = FB_TT / 4;
 
 template <bool CSGU>
 __global__ __launch_bounds__(256) void dwconv31_bwd_kernel(DwBwdArgs p, float* __restrict__ partial) {
