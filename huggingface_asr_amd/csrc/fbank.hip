@@ -37,9 +37,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double2* buf0 = reinterpret_cast<double2*>(smem) + wave * 2 * NFFT;
-    double2* buf1 = buf0 + NFFT;
-    double2* twl = reinterpret_cast<double2*>(smem) + 4 * 2 * NFFT;       // [NFFT/2] twiddles, shared by the four waves (an LDS read instead of a global load per butterfly)
+    constexpr int NZ = NFFT / 2;                                          // the complex transform has 256 points: two 4-KiB buffers per wave, 36 KiB per block -> 4 blocks per CU
+    double2* buf0 = reinterpret_cast<double2*>(smem) + wave * 2 * NZ;
+    double2* buf1 = buf0 + NZ;
+    double2* twl = reinterpret_cast<double2*>(smem) + 4 * 2 * NZ;         // [NFFT/2] twiddles, shared by the four waves (an LDS read instead of a global load per butterfly)
     for (int i = threadIdx.x; i < NFFT / 2; i += 256) twl[i] = double2{p.twiddle[2 * i], p.twiddle[2 * i + 1]};
     __syncthreads();
     const long total = (long)p.B * p.T_out;
@@ -227,8 +228,8 @@ extern "C" int mi_fbank_f64(const float* wave, long ldw, const int* num_samples,
     FbankArgs a{wave, ldw, num_samples, N, window, twiddle, mel_t, mel_lo, mel_hi, out, (long)T_out * nmel, T_out,
                 B, nmel, mel_floor, preemph};
     const long total = (long)B * T_out;
-    const int grid = (int)((total + 3) / 4 < 2048 ? (total + 3) / 4 : 2048);
-    const size_t lds = (4 * 2 * NFFT + NFFT / 2) * sizeof(double2);
+    const int grid = (int)((total + 3) / 4 < 4096 ? (total + 3) / 4 : 4096);
+    const size_t lds = (4 * 2 * (NFFT / 2) + NFFT / 2) * sizeof(double2);
     hipLaunchKernelGGL(fbank_kernel, dim3(grid), dim3(256), lds, stream, a);
     MI_CHECK_LAUNCH();
     return MI_OK;
