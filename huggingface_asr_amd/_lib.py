@@ -140,6 +140,10 @@ def lib():
         if os.environ.get("HFASR_GEMM_VARIANT"):
             h.mi_gemm_set_variant(int(os.environ["HFASR_GEMM_VARIANT"]))
         h.mi_gemm_set_debug.argtypes = [i32]; h.mi_gemm_set_debug.restype = None
+        if os.environ.get("HFASR_TN_WIDE"):
+            h.mi_gemm_tn_set_wide.restype = None
+            h.mi_gemm_tn_set_wide.argtypes = [C.c_int]
+            h.mi_gemm_tn_set_wide(int(os.environ["HFASR_TN_WIDE"]))
         if os.environ.get("HFASR_GEMM_DEBUG"):
             h.mi_gemm_set_debug(int(os.environ["HFASR_GEMM_DEBUG"]))
         h.mi_last_error.argtypes = []

@@ -7,12 +7,14 @@
 // consecutive m of column i).  Both operands use the same m-permutation inside a 16-step, so the products line up.
 // Output tiles are few (N*K/128² = 16 ... 160), so M is split over `splits` blocks per tile: each writes its fp32 partial tile
 // to a slab, `slab_reduce_kernel` adds the slabs into dW (splits == 1: accumulate in place).
-// Block 128 x 128, 4 waves (2x2) of 64 x 64, 2-stage LDS ring (64 KiB -> two blocks per CU).
+// Block 128 x 128, 4 waves (2x2) of 64 x 64, 2-stage LDS ring (64 KiB -> two blocks per CU).  A 128 (n) x 64 (k) form (48 KiB, three per CU; HFASR_TN_WIDE=0) exists
+// for A/B: unlike the forward GEMM it is slower here (more slabs to write and reduce).
 #include "common.hpp"
 
 namespace {
 
-constexpr int TN_T = 128, TN_KM = 64, TN_STAGE = 2 * TN_KM * TN_T * 2;   // 32 KiB per stage (dY tile + X tile)
+constexpr int TN_T = 128, TN_KM = 64;                   // dY tile: 64 m x 128 n;  X tile: 64 m x XW k (XW = 128: 32 KiB per stage, 64: 24 KiB)
+int g_tn_wide = 1;                                      // 128-wide X tiles, two blocks per CU (default: measured 32.9 vs 33.6 ms per training step); 0 = 64-wide, three per CU
 
 __device__ __attribute__((aligned(16))) uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
@@ -30,60 +32,71 @@ struct TnArgs {
     int M, N, K, n_store, splits, rows_per_split;
 };
 
+template <int ROWB>                                       // bytes per tile row (256: 128 columns, 128: 64 columns); 16-B chunk index XOR (row & (chunks - 1))
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int cb, int s, int lane) {
+    constexpr int CM = ROWB / 16 - 1;
     const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
     const int col = cb + (g & 1) * 16 + 4 * p4;
     const int lc = col >> 3, within = (col & 7) * 2;
     const int k0 = 16 * s + 4 * (g >> 1) + q4, k1 = k0 + 8;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + k0 * 256 + ((lc ^ (k0 & 15)) << 4) + within));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + k1 * 256 + ((lc ^ (k1 & 15)) << 4) + within));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + k0 * ROWB + ((lc ^ (k0 & CM)) << 4) + within));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + k1 * ROWB + ((lc ^ (k1 & CM)) << 4) + within));
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
 }
 
+template <int XW>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
+    constexpr int XB = XW * 2, XCH = XW / 8;                  // X tile row bytes, 16-B chunks per row
+    constexpr int YP = 16, XP = TN_KM * XB / 1024, PPW = (YP + XP) / 4;   // 1-KiB pieces per stage: dY, X, per wave
+    constexpr int STAGE = TN_KM * (TN_T * 2 + XB);
+    constexpr int NJ = XW / 64;                               // 32-column k blocks per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wk = wave & 1;
-    const int ntn = (p.N + TN_T - 1) / TN_T, ntk = (p.K + TN_T - 1) / TN_T;
+    const int ntn = (p.N + TN_T - 1) / TN_T, ntk = (p.K + XW - 1) / XW;
     const int ntiles = ntn * ntk;
     const int split = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
-    const int n0 = (tile / ntk) * TN_T, k0 = (tile % ntk) * TN_T;
+    const int n0 = (tile / ntk) * TN_T, k0 = (tile % ntk) * XW;
     const int m_lo = split * p.rows_per_split, m_hi = min(p.M, m_lo + p.rows_per_split);
     const int nit = (m_hi - m_lo + TN_KM - 1) / TN_KM;
 
-    // piece q of this wave: 1 KiB = 4 rows x 256 B of one operand tile; pieces [0,16) dY, [16,32) X
-    const int prow = lane >> 4, cs = lane & 15;
-    const bf16_t* src[8];
-    int rowin[8];
-    bool colok[8];
+    // piece g of the stage: 1 KiB of one operand tile — pieces [0, 16) dY (4 rows x 256 B each), then X (4 rows x 256 B, or 8 rows x 128 B at XW = 64)
+    const bf16_t* src[PPW];
+    int rowin[PPW];
+    bool colok[PPW];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int g = wave * 8 + q;
-        const bool isY = g < 16;
-        const int row = (g & 15) * 4 + prow;                 // m within the stage
-        const int c = cs ^ (row & 15);                       // source chunk for LDS slot cs
-        rowin[q] = row;
-        if (isY) { colok[q] = n0 + c * 8 < p.N; src[q] = p.Y + n0 + c * 8; }
-        else { colok[q] = k0 + c * 8 < p.K; src[q] = p.X + k0 + c * 8; }
+    for (int q = 0; q < PPW; ++q) {
+        const int g = wave * PPW + q;
+        const bool isY = g < YP;
+        if (isY) {
+            const int row = g * 4 + (lane >> 4), cs = lane & 15;
+            const int c = cs ^ (row & 15);                   // source chunk for LDS slot cs
+            rowin[q] = row; colok[q] = n0 + c * 8 < p.N; src[q] = p.Y + n0 + c * 8;
+        } else {
+            constexpr int RPP = 1024 / XB;                   // rows per piece
+            const int row = (g - YP) * RPP + lane / XCH, cs = lane % XCH;
+            const int c = cs ^ (row & (XCH - 1));
+            rowin[q] = row; colok[q] = k0 + c * 8 < p.K; src[q] = p.X + k0 + c * 8;
+        }
     }
     auto issue = [&](int it, int stage) {
-        char* sbase = smem + stage * TN_STAGE + wave * 8 * 1024;
+        char* sbase = smem + stage * STAGE + wave * PPW * 1024;
         const int mb = m_lo + it * TN_KM;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int g = wave * 8 + q;
+        for (int q = 0; q < PPW; ++q) {
+            const int g = wave * PPW + q;
             const int m = mb + rowin[q];
-            const bf16_t* sp = (m < m_hi && colok[q]) ? src[q] + (long)m * (g < 16 ? p.ldy : p.ldx) : reinterpret_cast<const bf16_t*>(&g_zero16);
+            const bf16_t* sp = (m < m_hi && colok[q]) ? src[q] + (long)m * (g < YP ? p.ldy : p.ldx) : reinterpret_cast<const bf16_t*>(&g_zero16);
             __builtin_amdgcn_global_load_lds((gptr_t)sp, (lptr_t)(sbase + q * 1024), 16, 0, 0);
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -98,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
         if (it + 1 < nit) issue(it + 1, stage ^ 1);
-        const char* ty = smem + stage * TN_STAGE;
+        const char* ty = smem + stage * STAGE;
         const char* tx = ty + TN_KM * TN_T * 2;
         if (do_db) {
 #pragma unroll 8
@@ -109,16 +122,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
         }
 #pragma unroll
         for (int s = 0; s < TN_KM / 16; ++s) {
-            bf16x8 fy[2], fx[2];
+            bf16x8 fy[2], fx[NJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fy[i] = tr_frag(ty, wn * 64 + i * 32, s, lane);
-                fx[i] = tr_frag(tx, wk * 64 + i * 32, s, lane);
-            }
+            for (int i = 0; i < 2; ++i) fy[i] = tr_frag<256>(ty, wn * 64 + i * 32, s, lane);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fx[j] = tr_frag<XB>(tx, wk * (XW / 2) + j * 32, s, lane);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);   // rows n (regs), cols k (lanes)
         }
     }
@@ -135,8 +147,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int k = k0 + wk * 64 + j * 32 + lr;
+        for (int j = 0; j < NJ; ++j) {
+            const int k = k0 + wk * (XW / 2) + j * 32 + lr;
             if (k >= p.K) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -162,10 +174,13 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ ou
 
 }  // namespace
 
+extern "C" void mi_gemm_tn_set_wide(int wide) { g_tn_wide = wide; }
+
 // workspace floats needed for a given problem (0 when a single split is used)
+static int tn_xw() { return g_tn_wide ? 128 : 64; }
 static int tn_splits(int M, int N, int K) {
-    const int tiles = cdiv(N, TN_T) * cdiv(K, TN_T);
-    int s = 512 / tiles;                               // two blocks per CU on 256 CUs
+    const int tiles = cdiv(N, TN_T) * cdiv(K, tn_xw());
+    int s = (g_tn_wide ? 512 : 768) / tiles;           // two (128-wide X tiles, 64 KiB of LDS) or three (64-wide, 48 KiB) blocks per CU on 256 CUs
     const int max_s = cdiv(M, 4 * TN_KM);              // at least 4 K-iterations per block
     if (s > max_s) s = max_s;
     return s < 1 ? 1 : s;
@@ -190,8 +205,9 @@ extern "C" int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx
     p.rows_per_split = cdiv(cdiv(M, splits), TN_KM) * TN_KM;
     if (splits > 1) { p.out = (float*)workspace; p.ldo = K; p.slab_stride = (long)N * K; }
     else { p.out = dW; p.ldo = ldo; p.slab_stride = 0; }
-    const int tiles = cdiv(N, TN_T) * cdiv(K, TN_T);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), 2 * TN_STAGE, st, p);
+    const int tiles = cdiv(N, TN_T) * cdiv(K, tn_xw());
+    if (g_tn_wide) hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(tiles * splits), dim3(256), (size_t)2 * TN_KM * (TN_T * 2 + 256), st, p);
+    else hipLaunchKernelGGL(gemm_tn_kernel<64>, dim3(tiles * splits), dim3(256), (size_t)2 * TN_KM * (TN_T * 2 + 128), st, p);
     MI_CHECK_LAUNCH();
     if (splits > 1) {
         const long total = (long)n_store * K;
