@@ -14,6 +14,24 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const T* __restrict__ x, l
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const T* xr = x + (long)row * ld;
+    constexpr int NR = 80;                          // rows up to 5120 columns (the 5001-class CTC head) stay in registers: ONE pass over HBM instead of two
+    if (V <= NR * 64) {
+        float v[NR];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < V ? (float)xr[c] : -INFINITY;
+            mx = fmaxf(mx, v[i]);
+        }
+        mx = wave_max(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) s += __expf(v[i] - mx);        // exp(-inf) = 0 for the padding
+        s = wave_sum(s);
+        if (lane == 0) lse[row] = mx + __logf(s);
+        return;
+    }
     float mx = -INFINITY;
     for (int c = lane; c < V; c += 64) mx = fmaxf(mx, (float)xr[c]);
     mx = wave_max(mx);
