@@ -159,6 +159,30 @@ def test_train_steps_reduce_loss_and_roundtrip_state_dict():
     assert float(d.max()) < 0.06 and float(d.mean()) < 0.009
 
 
+def test_checkpoint_average_loads_into_the_flat_store():
+    """the average of trainer checkpoints (reference names; model_utils.py:54-65) loaded back into the device store."""
+    from huggingface_asr_amd import checkpoint as C
+    g = load_golden("grads_tiny_rel")
+    cfg = dict(shapes.TINY, ctc_zero_infinity=True, ctc_loss_reduction="mean")
+    sd, x, am, lab = case_inputs(g, cfg)
+    tr = _trainer(cfg, sd, lr=1e-3)
+    snaps = []
+    for _ in range(3):
+        tr.train_step(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV))
+        snaps.append({k: v.cpu() for k, v in tr.state_dict().items()})
+    want = {k: ((snaps[0][k] + snaps[1][k]) + snaps[2][k]).div(3) for k in snaps[0]}
+    first = {k: v.clone() for k, v in snaps[0].items()}
+    avg = C.average_into_trainer(tr, *snaps)
+    back = tr.state_dict()
+    for k in want:
+        assert torch.equal(avg[k], want[k]), k
+        assert torch.equal(back[k].cpu(), want[k]), k
+    for k in first:
+        assert torch.equal(snaps[0][k], first[k]), k                                     # inputs are not modified (cloned before the in-place sum)
+    out = tr.forward_backward(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV), backward=False)
+    assert np.isfinite(float(out["loss"]))
+
+
 @pytest.mark.parametrize("name,fixed", [("grads_aed_tiny", False), ("grads_aed_tiny_fixedpos", True)])
 def test_joint_aed_gradients_match_reference_golden(name, fixed):
     """JointCTCAttentionEncoderDecoder (E-Branchformer + multi-head GPT-2, auxiliary head, label smoothing, ctc_weight 0.3):
