@@ -43,8 +43,12 @@ def param_shapes(cfg: dict) -> dict:
     out["wav2vec2.feature_projection.projection.bias"] = (d,)
     out["wav2vec2.encoder.layer_norm.weight"] = (d,)
     out["wav2vec2.encoder.layer_norm.bias"] = (d,)
-    for i in range(L):
-        p = f"wav2vec2.encoder.layers.{i}."
+    prefixes = [f"wav2vec2.encoder.layers.{i}." for i in range(L)]
+    if cfg.get("finetune_with_layer_mixing", False):          # BestRQEBranchformerForCTC (bestrq.py:202-205)
+        out["per_layer_weights"] = (L + 1,)
+    if cfg.get("finetune_with_additional_layer", False):      # bestrq.py:199-200
+        prefixes.append("additional_layer.")
+    for p in prefixes:
         ffs = ("ff1", "ff2") if cfg.get("use_macaron_ff", True) else ()
         if "ff1" in ffs:
             out[p + "ff1.0.weight"] = (d,); out[p + "ff1.0.bias"] = (d,)

@@ -198,10 +198,11 @@ def ffn(sd, pre, x, q: Callable = _id, dm=None, layer=None, sites=(0, 1)):
     return dm(y, layer, sites[1]) if dm is not None else y
 
 
-def encoder_layer(sd, i, cfg, x, add_mask, pos, q: Callable = _id, dm=None):
+def encoder_layer(sd, i, cfg, x, add_mask, pos, q: Callable = _id, dm=None, pre=None):
     """e_branchformer.py:263-313.  dm: training-mode dropout hook; sites 0/1 ff1, 2 attention probabilities, 3 attention output (:288),
-    4 CSGU, 5 merge output (:301), 6/7 ff2."""
-    pre = f"wav2vec2.encoder.layers.{i}."
+    4 CSGU, 5 merge output (:301), 6/7 ff2.  `pre`: state-dict prefix when the layer is not one of the encoder's own
+    (the fine-tuning head's `additional_layer.`, bestrq.py:199-200)."""
+    pre = pre or f"wav2vec2.encoder.layers.{i}."
     eps = 1e-5  # nn.LayerNorm default (layers use nn.LayerNorm(embed_dim), e_branchformer.py:233-261)
     if cfg.get("use_macaron_ff", True):
         x = x + 0.5 * ffn(sd, pre + "ff1.1.", q(layer_norm(x, sd[pre + "ff1.0.weight"], sd[pre + "ff1.0.bias"], eps)), q, dm, i, (0, 1))
@@ -223,10 +224,12 @@ def encoder_layer(sd, i, cfg, x, add_mask, pos, q: Callable = _id, dm=None):
 
 
 def encoder_forward(sd: dict, cfg: dict, feats: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-                    q: Optional[Callable] = None, return_layers: bool = False, dm=None, skip_layers=()):
+                    q: Optional[Callable] = None, return_layers: bool = False, dm=None, skip_layers=(), hidden_states: Optional[list] = None):
     """Wav2Vec2EBranchformerModel.forward (tf:1133-1195, tf:651-717) -> last hidden state (B,T',d).  Eval mode, or train mode with the
     dropout hook dm(x, layer, site) (global sites use layer = num_hidden_layers: 0 feature projection, 1 encoder input tf:674).
-    skip_layers: LayerDrop decisions (tf:686-690: a layer whose uniform draw falls below config.layerdrop is skipped = identity)."""
+    skip_layers: LayerDrop decisions (tf:686-690: a layer whose uniform draw falls below config.layerdrop is skipped = identity).
+    hidden_states: a list that receives HF's `output_hidden_states` tuple (tf:679-680,714-715): the INPUT of every layer, then the output of
+    the encoder's final LayerNorm — num_hidden_layers + 1 tensors."""
     q = q or _id
     eps = cfg.get("layer_norm_eps", 1e-5)
     h = conv_subsample(sd, cfg, feats, q)
@@ -250,12 +253,57 @@ def encoder_forward(sd: dict, cfg: dict, feats: torch.Tensor, attention_mask: Op
         x = dm(x, nl, 1)
     layers = []
     for i in range(cfg["num_hidden_layers"]):
+        if hidden_states is not None:
+            hidden_states.append(x)
         if i not in skip_layers:
             x = encoder_layer(sd, i, cfg, x, add_mask, pos, q, dm)
         if return_layers:
             layers.append(x)
     x = layer_norm(x, sd["wav2vec2.encoder.layer_norm.weight"], sd["wav2vec2.encoder.layer_norm.bias"], eps)
+    if hidden_states is not None:
+        hidden_states.append(x)
     return (x, layers) if return_layers else x
+
+
+def finetune_hidden(sd: dict, cfg: dict, feats: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, q: Optional[Callable] = None, dm=None,
+                    skip_layers=()):
+    """What BestRQEBranchformerForCTC puts between the encoder and the CTC head (bestrq.py:229-279): with `finetune_with_layer_mixing` the
+    softmax(per_layer_weights)-weighted sum of all num_hidden_layers + 1 hidden states instead of the last one (:239-245); with
+    `finetune_with_additional_layer` one more E-Branchformer layer (`additional_layer.*`) on top, padded frames zeroed first, same key mask and
+    the encoder's position table (:247-274) — and NO LayerNorm after it."""
+    q = q or _id
+    hs: list = []
+    x = encoder_forward(sd, cfg, feats, attention_mask, q, dm=dm, skip_layers=skip_layers, hidden_states=hs)
+    if cfg.get("finetune_with_layer_mixing", False):
+        w = torch.softmax(sd["per_layer_weights"].float(), dim=-1)
+        x = (torch.stack(hs) * w[:, None, None, None]).sum(dim=0)
+    if cfg.get("finetune_with_additional_layer", False):
+        t = x.shape[1]
+        d, H = cfg["hidden_size"], cfg["num_attention_heads"]
+        ptype = cfg.get("position_embeddings_type", "relative")
+        pos = rel_pos_table(t, d) if ptype == "relative" else (rotary_table(t, d // H, cfg.get("rotary_embedding_base", 10000)) if ptype == "rotary" else None)
+        add_mask = None
+        if attention_mask is not None:
+            mask = feature_vector_attention_mask(t, attention_mask, cfg)
+            x = x * mask[..., None]                                                      # bestrq.py:260
+            am = (1.0 - mask[:, None, None, :].float()) * torch.finfo(torch.float32).min
+            add_mask = am.expand(-1, 1, t, -1)
+        x = encoder_layer(sd, cfg["num_hidden_layers"], cfg, x, add_mask, pos, q, dm, pre="additional_layer.")
+    return x
+
+
+def finetune_ctc_forward(sd: dict, cfg: dict, feats, attention_mask=None, labels=None, q=None, dm=None, skip_layers=()):
+    """BestRQEBranchformerForCTC.forward (bestrq.py:212-322) -> (loss|None, logits); the head and the loss are those of ctc_forward."""
+    hidden = finetune_hidden(sd, cfg, feats, attention_mask, q, dm, skip_layers)
+    logits = ctc_head(sd, hidden, q, dm, cfg["num_hidden_layers"])
+    loss = None
+    if labels is not None:
+        am = attention_mask if attention_mask is not None else torch.ones(feats.shape[:2], dtype=torch.long)
+        in_len = conv_out_lengths_outer(am.sum(-1), cfg).long()
+        lmask = labels >= 0
+        loss = ctc_loss_ref(torch.log_softmax(logits.float(), -1), labels, in_len, lmask.sum(-1), blank=logits.shape[-1] - 1,
+                            reduction=cfg.get("ctc_loss_reduction", "mean"), zero_infinity=cfg.get("ctc_zero_infinity", False))
+    return loss, logits
 
 
 def ctc_head(sd: dict, hidden: torch.Tensor, q: Optional[Callable] = None, dm=None, nl=None) -> torch.Tensor:

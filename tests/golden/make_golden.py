@@ -368,6 +368,40 @@ SPECAUG_RECIPE = dict(apply_time_warp=True, time_warp_window=5, time_warp_mode="
                       num_freq_mask=2, apply_time_mask=True, time_mask_width_ratio_range=[0, 0.05], num_time_mask=5)
 
 
+def run_finetune_cases():
+    """CTC fine-tuning head of a BEST-RQ encoder with the recipes' two options (src/models/bestrq.py:192-322;
+    `finetune_with_additional_layer=True,finetune_with_layer_mixing=True` in recipes/librispeech/ssl/*/lumi/finetune_frozen*.sh):
+    eval logits + loss, and train-mode (dropouts 0) loss + every parameter gradient.  Same shim (2') as run_bestrq_case."""
+    from models import bestrq as BQ
+    for name, seed, lengths, tgt, flags in [("finetune_tiny_mix_extra", 61, [200, 142], [6, 4], dict(finetune_with_additional_layer=True, finetune_with_layer_mixing=True)),
+                                            ("finetune_tiny_mix", 62, [188, 200], [5, 6], dict(finetune_with_additional_layer=False, finetune_with_layer_mixing=True)),
+                                            ("finetune_tiny_extra", 63, [200, 120], [6, 3], dict(finetune_with_additional_layer=True, finetune_with_layer_mixing=False))]:
+        B, T, U = 2, 200, 6
+        cfg = BQ.BestRQEBranchformerForPreTrainingConfig(**TINY, attn_implementation="eager", layerdrop=0.0, ctc_zero_infinity=True,
+                                                         ctc_loss_reduction="mean", **NO_DROPOUT, **flags)
+        for k, v in dict(num_fbanks=80, conv_padding=[1, 1], context_awareness_type=None, **BESTRQ, **flags).items():
+            setattr(cfg, k, v)
+        model = BQ.BestRQEBranchformerForCTC(cfg).eval()
+        wsum = load_seeded(model, seed)
+        x, am = synth_feats(seed, B, T, lengths)
+        lab = synth_labels(seed, B, U, cfg.vocab_size, tgt)
+        xs, ams, labs = torch.from_numpy(x), torch.from_numpy(am), torch.from_numpy(lab)
+        with torch.no_grad():
+            ev = model(xs, attention_mask=ams, labels=labs)
+        rec = dict(seed=seed, weight_sum=wsum, lengths=np.array(lengths), tgt_lens=np.array(tgt), shape=np.array([B, T, U]),
+                   eval_loss=float(ev.loss), eval_logits=ev.logits.float().numpy(), flags=np.array([int(flags["finetune_with_additional_layer"]), int(flags["finetune_with_layer_mixing"])]))
+        model.train()
+        out = model(xs, attention_mask=ams, labels=labs)
+        out.loss.backward()
+        rec["loss"] = float(out.loss)
+        for k, v in model.named_parameters():
+            if v.grad is not None:
+                rec["grad:" + k] = v.grad.float().numpy()
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
+        print(name, "eval loss", rec["eval_loss"], "train loss", rec["loss"], "n grads", sum(k.startswith("grad:") for k in rec),
+              "params", [k for k, _ in model.named_parameters() if "additional" in k or "per_layer" in k][:3])
+
+
 def run_specaug_cases():
     """reference src/augmentations/spec_aug.py (recipe parameters of configs/default_data_preprocessing2d.json:36-58) on seeded features."""
     from augmentations.spec_aug import SpecAug
@@ -454,7 +488,7 @@ def run_ctc_prefix_cases():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "grads", "base", "fbank", "lengths", "ctc", "prefix", "aed", "aedgrads", "bestrq", "specaug", "whisper"]
+    which = sys.argv[1:] or ["tiny", "grads", "base", "fbank", "lengths", "ctc", "prefix", "aed", "aedgrads", "bestrq", "finetune", "specaug", "whisper"]
     if "tiny" in which:
         run_encoder_case("tiny_rel", TINY, seed=11, B=2, T=200, lengths=[198, 150], U=7, tgt_lens=[7, 5])
         run_encoder_case("tiny_rotary", TINY, seed=12, B=2, T=200, lengths=[200, 131], U=6, tgt_lens=[6, 4],
@@ -488,6 +522,8 @@ if __name__ == "__main__":
         run_aed_grad_cases()
     if "bestrq" in which:
         run_bestrq_case()
+    if "finetune" in which:
+        run_finetune_cases()
     if "specaug" in which:
         run_specaug_cases()
     if "whisper" in which:
