@@ -70,6 +70,10 @@ SIGNATURES = {
     "mi_mask_rows_f32": [vp, i64, vp, i32, i32, i32, vp],
     "mi_spec_mask_apply": [vp, i64, vp, vp, vp, i32, i32, i32, vp],
     "mi_spec_mask_bwd": [vp, i64, vp, vp, vp, i32, i32, i32, vp],
+    "mi_softmax_vec_f32": [vp, i32, vp, vp],
+    "mi_softmax_vec_bwd_f32": [vp, vp, i32, vp, vp],
+    "mi_axpy_dev_f32": [vp, vp, i64, vp, i32, vp],
+    "mi_dot_f32": [vp, vp, i64, vp, vp, vp],
     "mi_sumsq_f32": [vp, i64, vp, vp, vp],
     "mi_clip_coef": [vp, f32, f32, vp, vp],
     "mi_adamw_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, vp, vp],

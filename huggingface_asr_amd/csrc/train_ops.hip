@@ -378,6 +378,52 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restric
     __syncthreads();
     if (threadIdx.x == 0) out[0] += (part[0] + part[1]) + (part[2] + part[3]);
 }
+// ---- layer mixing of the CTC fine-tuning head (bestrq.py:239-245): hidden = sum_l softmax(per_layer_weights)_l * hidden_states[l].
+// The weights stay on the device: the axpy reads its coefficient from memory, so the step has no host round trip.
+__global__ __launch_bounds__(256) void axpy_dev_kernel(float* __restrict__ a, const float* __restrict__ b, long n, const float* __restrict__ alpha, int overwrite) {
+    const float w = alpha[0];
+    const bool al = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+    const long n4 = al ? n >> 2 : 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 bv = reinterpret_cast<const f32x4*>(b)[i];
+        f32x4 av = overwrite ? f32x4{0.f, 0.f, 0.f, 0.f} : reinterpret_cast<f32x4*>(a)[i];
+        av.x += w * bv.x; av.y += w * bv.y; av.z += w * bv.z; av.w += w * bv.w;
+        reinterpret_cast<f32x4*>(a)[i] = av;
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a[i] = (overwrite ? 0.f : a[i]) + w * b[i];
+}
+// <a, b> with the partial scheme of sumsq_kernel (fixed element -> thread map, fixed-order final add: run-to-run identical)
+__global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, float* __restrict__ partial) {
+    __shared__ float part[4];
+    float s = 0.f;
+    const bool al = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+    const long n4 = al ? n >> 2 : 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 u = reinterpret_cast<const f32x4*>(a)[i], v = reinterpret_cast<const f32x4*>(b)[i];
+        s += (u.x * v.x + u.y * v.y) + (u.z * v.z + u.w * v.w);
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += a[i] * b[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+// softmax of a short vector (n <= 1024, one block) and its backward dw += s * (g - <s, g>)
+__global__ __launch_bounds__(64) void softmax_vec_kernel(const float* __restrict__ w, int n, float* __restrict__ s) {
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 64) m = fmaxf(m, w[i]);
+    m = wave_max(m);
+    float z = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) z += expf(w[i] - m);
+    z = wave_sum(z);
+    for (int i = threadIdx.x; i < n; i += 64) s[i] = expf(w[i] - m) / z;
+}
+__global__ __launch_bounds__(64) void softmax_vec_bwd_kernel(const float* __restrict__ s, const float* __restrict__ g, int n, float* __restrict__ dw) {
+    float sg = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) sg += s[i] * g[i];
+    sg = wave_sum(sg);
+    for (int i = threadIdx.x; i < n; i += 64) dw[i] += s[i] * (g[i] - sg);
+}
 // norm = sqrt(sumsq); coef = min(1, max_norm / (norm + 1e-6))  (torch.nn.utils.clip_grad_norm_).  skip = 1 when the norm is not finite or above
 // `skip_above` (> 0): the reference's GradAwareTrainer drops such a step altogether (training_utils.py:81,101-115: grads set to None).
 __global__ void clip_coef_kernel(const float* sumsq, float max_norm, float skip_above, float* out /* [norm, coef, skip] */) {
@@ -594,6 +640,35 @@ extern "C" int mi_sumsq_f32(const float* x, long n, float* sumsq, float* workspa
     if (n <= 0 || !workspace) return MI_ERR_ARG;
     hipLaunchKernelGGL(sumsq_kernel, dim3(SSQ_BLOCKS), dim3(256), 0, st, x, n, workspace);
     hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, workspace, SSQ_BLOCKS, sumsq);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+extern "C" int mi_axpy_dev_f32(float* a, const float* b, long n, const float* alpha, int overwrite, hipStream_t st) {
+    MI_ENTER();
+    if (n <= 0 || !alpha) return MI_ERR_ARG;
+    hipLaunchKernelGGL(axpy_dev_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, a, b, n, alpha, overwrite);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+extern "C" int mi_dot_f32(const float* a, const float* b, long n, float* out, float* workspace, hipStream_t st) {
+    MI_ENTER();
+    if (n <= 0 || !workspace) return MI_ERR_ARG;
+    hipLaunchKernelGGL(dot_kernel, dim3(SSQ_BLOCKS), dim3(256), 0, st, a, b, n, workspace);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, workspace, SSQ_BLOCKS, out);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+extern "C" int mi_softmax_vec_f32(const float* w, int n, float* s, hipStream_t st) {
+    MI_ENTER();
+    if (n <= 0 || n > 1024) return MI_ERR_ARG;
+    hipLaunchKernelGGL(softmax_vec_kernel, dim3(1), dim3(64), 0, st, w, n, s);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+extern "C" int mi_softmax_vec_bwd_f32(const float* s, const float* g, int n, float* dw, hipStream_t st) {
+    MI_ENTER();
+    if (n <= 0 || n > 1024) return MI_ERR_ARG;
+    hipLaunchKernelGGL(softmax_vec_bwd_kernel, dim3(1), dim3(64), 0, st, s, g, n, dw);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

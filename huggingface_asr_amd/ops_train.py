@@ -243,6 +243,31 @@ def embed_tokens_bwd(ids, dx, dwte, dwpe=None, *, scale=1.0, pos_offset=0):
                "mi_embed_tokens_bwd")
 
 
+def softmax_vec(w, out=None):
+    """softmax of a short f32 vector on the device (layer-mixing weights, bestrq.py:242)"""
+    out = torch.empty_like(w) if out is None else out
+    _lib.check(_L().mi_softmax_vec_f32(w.data_ptr(), w.numel(), out.data_ptr(), _stream()), "mi_softmax_vec_f32")
+    return out
+
+
+def softmax_vec_bwd_(dw, s, g):
+    """dw += s * (g - <s, g>)"""
+    _lib.check(_L().mi_softmax_vec_bwd_f32(s.data_ptr(), g.data_ptr(), s.numel(), dw.data_ptr(), _stream()), "mi_softmax_vec_bwd_f32")
+
+
+def axpy_dev_(a, b, alpha_dev, overwrite=False):
+    """a = (0 if overwrite else a) + alpha_dev[0] * b — contiguous f32, the coefficient is a one-element DEVICE tensor (view)."""
+    assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel() and a.dtype == b.dtype == torch.float32
+    _lib.check(_L().mi_axpy_dev_f32(a.data_ptr(), b.data_ptr(), a.numel(), alpha_dev.data_ptr(), int(overwrite), _stream()), "mi_axpy_dev_f32")
+    return a
+
+
+def dot_(acc, a, b):
+    """acc[0] += <a, b> (contiguous f32; deterministic)"""
+    assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel() and a.dtype == b.dtype == torch.float32
+    _lib.check(_L().mi_dot_f32(a.data_ptr(), b.data_ptr(), a.numel(), acc.data_ptr(), _dw_ws(a.device, 1024), _stream()), "mi_dot_f32")
+
+
 def sumsq_(acc, x):
     _lib.check(_L().mi_sumsq_f32(x.data_ptr(), x.numel(), acc.data_ptr(), _dw_ws(x.device, 1024), _stream()), "mi_sumsq_f32")
 

@@ -151,7 +151,7 @@ def encoder_specs(c: dict, head: bool = True) -> list[Spec]:
     mat("conv2_w", C2, K * K * C1); vec("conv2_b", C2)
     mat("feout_w", d, F2 * C2); vec("feout_b", d)
     vec("fp_ln_g", d); vec("fp_ln_b", d); mat("fp_w", d, d); vec("fp_b", d)
-    for l in range(L):
+    for l in range(L + int(bool(c.get("finetune_with_additional_layer", False)))):     # layer L = the fine-tuning head's `additional_layer` (bestrq.py:199-200)
         p = f"l{l}."
         ffs = ("ff1", "ff2") if c.get("use_macaron_ff", True) else ()
         for ff in ffs[:1]:
@@ -168,6 +168,8 @@ def encoder_specs(c: dict, head: bool = True) -> list[Spec]:
             vec(p + ff + "_ln_g", d); vec(p + ff + "_ln_b", d); mat(p + ff + "_w1", I, d); vec(p + ff + "_b1", I); mat(p + ff + "_w2", d, I); vec(p + ff + "_b2", d)
         vec(p + "fin_ln_g", d); vec(p + "fin_ln_b", d)
     vec("enc_ln_g", d); vec("enc_ln_b", d)
+    if c.get("finetune_with_layer_mixing", False):
+        vec("mix_w", L + 1, decay=True)          # `per_layer_weights` (bestrq.py:202-205): a plain nn.Parameter, so weight decay applies
     if head:
         mat("head_w", V1, d); vec("head_b", V1)
     return S
@@ -204,8 +206,10 @@ def _enc_map(c: dict, head: bool = True):
                        [("lm_head.weight", lambda t: t[:V].contiguous()), ("blank_projection.weight", lambda t: t[V:].contiguous())])
         m["head_b"] = (lambda sd: torch.cat([sd["lm_head.bias"], sd["blank_projection.bias"]], 0),
                        [("lm_head.bias", lambda t: t[:V].contiguous()), ("blank_projection.bias", lambda t: t[V:].contiguous())])
-    for l in range(L):
-        p, r = f"l{l}.", f"wav2vec2.encoder.layers.{l}."
+    if c.get("finetune_with_layer_mixing", False):
+        one("mix_w", "per_layer_weights")
+    for l in range(L + int(bool(c.get("finetune_with_additional_layer", False)))):
+        p, r = f"l{l}.", (f"wav2vec2.encoder.layers.{l}." if l < L else "additional_layer.")
         if c.get("use_macaron_ff", True):
             for ff in ("ff1", "ff2"):
                 one(p + ff + "_ln_g", r + ff + ".0.weight"); one(p + ff + "_ln_b", r + ff + ".0.bias")
@@ -323,10 +327,16 @@ class EncoderCTCTrainer:
         self._pos = {}
         self._scal = torch.zeros(4, dtype=F32, device=self.device)       # [sumsq, norm, coef, -]
         L = c["num_hidden_layers"]
+        # CTC fine-tuning head of a BEST-RQ encoder (bestrq.py:192-279): softmax-weighted mix of all hidden states and / or one more layer on top
+        self.mix = bool(c.get("finetune_with_layer_mixing", False))
+        self.extra = bool(c.get("finetune_with_additional_layer", False))
+        if (self.mix or self.extra) and not self.head:
+            raise NotImplementedError("layer mixing / additional layer belong to the CTC fine-tuning head")
         names = self.store.order
-        self._layer_names = [[n for n in names if n.startswith(f"l{l}.")] for l in range(L)]
+        self._layer_names = [[n for n in names if n.startswith(f"l{l}.")] for l in range(L + int(self.extra))]
         self._front_names = [n for n in names if n.startswith(("masked_spec", "conv", "feout", "fp_"))]
-        self._head_names = ["enc_ln_g", "enc_ln_b"] + (["head_w", "head_b"] if self.head else [])
+        self._encln_names = ["enc_ln_g", "enc_ln_b"] + (["mix_w"] if self.mix else [])
+        self._head_names = self._encln_names + (["head_w", "head_b"] if self.head else [])
 
     # ------------------------------------------------------------------ weights in / out
     def load_state_dict(self, sd: dict):
@@ -468,14 +478,11 @@ class EncoderCTCTrainer:
         skip = set(int(l) for l in skip_layers)
         self.last_skipped = sorted(skip)
         # ---------------- layers
-        for l in range(L):
-            if l in skip:                   # LayerDrop: identity, nothing saved, no gradient
-                saved.append(None)
-                continue
-            p = f"l{l}."
+        def layer_fwd(x, l):
+            p, sl = f"l{l}.", l + int(l >= L)          # sl: dropout-stream layer id (L itself names the global sites; the additional layer takes L + 1)
             S = {"x_in": x}
             if macaron:
-                x, S["ff1"] = self._ffn_fwd(x, p + "ff1", LN, e16, pd, l, (0, 1))
+                x, S["ff1"] = self._ffn_fwd(x, p + "ff1", LN, e16, pd, sl, (0, 1))
             S["x1"] = x
             a1, a2 = e16(M, d), e16(M, d)
             LN(x, lna=(P(p + "att_ln_g"), P(p + "att_ln_b")), outa=a1, lnb=(P(p + "mlp_ln_g"), P(p + "mlp_ln_b")), outb=a2)
@@ -493,37 +500,65 @@ class EncoderCTCTrainer:
             if ptype == "relative":
                 posp = ops.gemm(pos[0], W(p + "att_wpos"))
             ctx = self._attention_fwd(qkv, posp, P(p + "att_u") if posp is not None else None, P(p + "att_v") if posp is not None else None,
-                                      inner, B, T2, H, S, (pd["att"], seed, self._sid(l, 2)) if pd["att"] > 0 else None)
+                                      inner, B, T2, H, S, (pd["att"], seed, self._sid(sl, 2)) if pd["att"] > 0 else None)
             ops.gemm(ctx, W(p + "att_wo"), P(p + "att_bo"), out=cat[:, :d])
             if pd["att"] > 0:
-                T.dropout_(cat[:, :d], pd["att"], seed, self._sid(l, 3))
+                T.dropout_(cat[:, :d], pd["att"], seed, self._sid(sl, 3))
             # local branch (cgMLP)
             hp = ops.gemm(a2, W(p + "mlp_w1"), P(p + "mlp_b1"))
             h = T.act_fwd(hp)
             stats = ops.row_stats(h[:, I // 2:])
             sg = ops.csgu(h, P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), B, T2)
             if pd["csgu"] > 0:
-                T.dropout_(sg, pd["csgu"], seed, self._sid(l, 4))
+                T.dropout_(sg, pd["csgu"], seed, self._sid(sl, 4))
             ops.gemm(sg, W(p + "mlp_w2"), P(p + "mlp_b2"), out=cat[:, d:])
             # merge
             m2 = ops.dwconv_residual(cat, P(p + "mrg_dw_w"), P(p + "mrg_dw_b"), B, T2)
             if pd["att"] > 0:       # the layer's `final_dropout` module takes config.attention_dropout (e_branchformer.py:229,246)
-                x2 = T.dropout_add(x, ops.gemm(m2, W(p + "mrg_w"), P(p + "mrg_b"), out_dtype=F32), 1.0, pd["att"], seed, self._sid(l, 5))
+                x2 = T.dropout_add(x, ops.gemm(m2, W(p + "mrg_w"), P(p + "mrg_b"), out_dtype=F32), 1.0, pd["att"], seed, self._sid(sl, 5))
             else:
                 x2 = ops.gemm(m2, W(p + "mrg_w"), P(p + "mrg_b"), out_dtype=F32, resid=x, alpha=1.0)
             S.update(a1=a1, a2=a2, qkv=qkv, posp=posp, ctx=ctx, hp=hp, h=h, stats=stats, sg=sg, cat=cat, m2=m2, x2=x2)
             x = x2
             if macaron:
-                x, S["ff2"] = self._ffn_fwd(x, p + "ff2", LN, e16, pd, l, (6, 7))
+                x, S["ff2"] = self._ffn_fwd(x, p + "ff2", LN, e16, pd, sl, (6, 7))
             S["x3"] = x
             xo = e32(M, d)
             LN(x, ln1=(P(p + "fin_ln_g"), P(p + "fin_ln_b")), store_y=xo)
             x = xo
+            return x, S
+
+        hs = [] if self.mix else None       # HF's `hidden_states` tuple: the INPUT of every layer, then the final LayerNorm's output (tf:679-680,714-715)
+        for l in range(L):
+            if hs is not None:
+                hs.append(x)
+            if l in skip:                   # LayerDrop: identity, nothing saved, no gradient
+                saved.append(None)
+                continue
+            x, S = layer_fwd(x, l)
             saved.append(S)
         # ---------------- head + CTC
         hid = e16(M, d)
         last_hidden = e32(M, d)
         LN(x, lna=(P("enc_ln_g"), P("enc_ln_b")), eps2=eps_e, outa=hid, outa32=last_hidden)
+        sw = mixed = S_extra = None
+        if self.mix or self.extra:
+            if extra_hidden_grad is not None:
+                raise NotImplementedError("layer mixing / additional layer: CTC fine-tuning head only (no attention decoder on top)")
+            top = last_hidden
+            if self.mix:            # bestrq.py:239-245 — the weights never leave the device
+                hs.append(last_hidden)
+                sw = T.softmax_vec(P("mix_w"))
+                mixed = e32(M, d)
+                for i, h in enumerate(hs):
+                    T.axpy_dev_(mixed, h, sw[i:i + 1], overwrite=(i == 0))
+                top = mixed
+            if self.extra:          # bestrq.py:247-274: padded frames zeroed, then one more layer with the encoder's mask and position table; no LayerNorm after it
+                xin = top if top is mixed else top.clone()
+                if inner is not None:
+                    T.mask_rows_(xin, inner, T2)
+                top, S_extra = layer_fwd(xin, L)
+            hid = T.add_cast(top)
         loss = logits = lse = nll = None
         red = c.get("ctc_loss_reduction", "mean")
         ldl = T.pad64(V1)
@@ -541,45 +576,23 @@ class EncoderCTCTrainer:
             return out
 
         # =================================================================== backward
-        gs = float(loss_scale) / self.sync.world
-        dhid = None
-        if self.head:
-            dlog = T.ctc_loss_bwd(logits, lse, labels, outer, nll, reduction=red, gscale=gs, ldo=ldl)         # (M, ldl) bf16
-            dhid = T.gemm(dlog, WT("head_w"))                                                                # (M, d) bf16
-            if pd["final"] > 0:
-                T.dropout_(dhid, pd["final"], seed, self._sid(L, 2))
-            T.gemm_tn_(G("head_w"), dlog, hid, n_store=V1, db=G("head_b"))
-        dx = e32(M, d)
-        if dhid is not None:
-            T.layernorm_bwd(x, P("enc_ln_g"), dhid, dx, accumulate=False, dgamma=G("enc_ln_g"), dbeta=G("enc_ln_b"), eps=eps_e)
-        if extra_hidden_grad is not None:
-            dh32 = extra_hidden_grad(last_hidden, outer)
-            if dh32 is not None:
-                T.layernorm_bwd(x, P("enc_ln_g"), dh32, dx, accumulate=dhid is not None, dgamma=G("enc_ln_g"), dbeta=G("enc_ln_b"), eps=eps_e)
-            elif dhid is None:
-                dx.zero_()
-        self.sync.launch(*st.range_of(self._head_names))
-        for l in range(L - 1, -1, -1):
-            p = f"l{l}."
-            S = saved[l]
-            if S is None:                   # dropped layer: dx passes through, its gradient range stays zero (still reduced: other ranks may have run it)
-                self.sync.launch(*st.range_of(self._layer_names[l]))
-                continue
+        def layer_bwd(dx, S, l):
+            p, sl = f"l{l}.", l + int(l >= L)
             # final_layer_norm
             d3 = e32(M, d)
             T.layernorm_bwd(S["x3"], P(p + "fin_ln_g"), dx, d3, accumulate=False, dgamma=G(p + "fin_ln_g"), dbeta=G(p + "fin_ln_b"))
             dx = d3
             if macaron:
-                self._ffn_bwd(dx, S["x2"], S["ff2"], p + "ff2", pd, l, (6, 7))
+                self._ffn_bwd(dx, S["x2"], S["ff2"], p + "ff2", pd, sl, (6, 7))
             # merge:  x2 = x1 + dropout(merge_proj(m2))
-            dyb = T.dropout_(dx, pd["att"], seed, self._sid(l, 5), out=e16(M, d)) if pd["att"] > 0 else T.add_cast(dx)
+            dyb = T.dropout_(dx, pd["att"], seed, self._sid(sl, 5), out=e16(M, d)) if pd["att"] > 0 else T.add_cast(dx)
             dm2 = T.linear_bwd(dyb, S["m2"], WT(p + "mrg_w"), dw=GL(p + "mrg_w"), db=GL(p + "mrg_b"))
             dcat = e16(M, 2 * d)
             T.dwconv_residual_bwd(S["cat"], P(p + "mrg_dw_w"), dm2, dcat, G(p + "mrg_dw_w"), G(p + "mrg_dw_b"), B, T2)
             # local branch
             dsg = T.linear_bwd(dcat[:, d:], S["sg"], WT(p + "mlp_w2"), dw=GL(p + "mlp_w2"), db=GL(p + "mlp_b2"))
             if pd["csgu"] > 0:
-                T.dropout_(dsg, pd["csgu"], seed, self._sid(l, 4))
+                T.dropout_(dsg, pd["csgu"], seed, self._sid(sl, 4))
             dh = e16(M, I)
             dgn = e16(M, I // 2)
             T.csgu_bwd(S["h"], S["stats"], P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), dsg, dh[:, :I // 2], dgn,
@@ -590,9 +603,9 @@ class EncoderCTCTrainer:
             T.layernorm_bwd(S["x1"], P(p + "mlp_ln_g"), da2, dx, accumulate=True, dgamma=G(p + "mlp_ln_g"), dbeta=G(p + "mlp_ln_b"))
             # global branch
             if pd["att"] > 0:
-                T.dropout_(dcat[:, :d], pd["att"], seed, self._sid(l, 3))
+                T.dropout_(dcat[:, :d], pd["att"], seed, self._sid(sl, 3))
             dctx = T.linear_bwd(dcat[:, :d], S["ctx"], WT(p + "att_wo"), dw=GL(p + "att_wo"), db=GL(p + "att_bo"))
-            dqkv = self._attention_bwd(dctx, S, p, pos, inner, B, T2, H, (pd["att"], seed, self._sid(l, 2)) if pd["att"] > 0 else None)
+            dqkv = self._attention_bwd(dctx, S, p, pos, inner, B, T2, H, (pd["att"], seed, self._sid(sl, 2)) if pd["att"] > 0 else None)
             if ptype == "rotary":
                 wt = WT(p + "att_wqkv")
                 da1r = T.linear_bwd(dqkv[:, :2 * d], S["a1r"], wt[:, :2 * d], dw=GL(p + "att_wqkv", slice(0, 2 * d)), db=GL(p + "att_bqkv", slice(0, 2 * d)))
@@ -604,7 +617,50 @@ class EncoderCTCTrainer:
                 da1 = T.linear_bwd(dqkv, S["a1"], WT(p + "att_wqkv")[:, :3 * d], dw=GL(p + "att_wqkv"), db=GL(p + "att_bqkv"))
                 T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), da1, dx, accumulate=True, dgamma=G(p + "att_ln_g"), dbeta=G(p + "att_ln_b"))
             if macaron:
-                self._ffn_bwd(dx, S["x_in"], S["ff1"], p + "ff1", pd, l, (0, 1))
+                self._ffn_bwd(dx, S["x_in"], S["ff1"], p + "ff1", pd, sl, (0, 1))
+            return dx
+
+        gs = float(loss_scale) / self.sync.world
+        dhid = None
+        if self.head:
+            dlog = T.ctc_loss_bwd(logits, lse, labels, outer, nll, reduction=red, gscale=gs, ldo=ldl)         # (M, ldl) bf16
+            dhid = T.gemm(dlog, WT("head_w"), out_dtype=F32 if (self.mix or self.extra) else BF16)           # (M, d)
+            if pd["final"] > 0:
+                T.dropout_(dhid, pd["final"], seed, self._sid(L, 2))
+            T.gemm_tn_(G("head_w"), dlog, hid, n_store=V1, db=G("head_b"))
+        dx = e32(M, d)
+        dmix = None
+        if self.mix or self.extra:
+            self.sync.launch(*st.range_of(["head_w", "head_b"]))
+            dtop = dhid                                               # f32: gradient at the head's input
+            if self.extra:
+                dtop = layer_bwd(dtop, S_extra, L)
+                if inner is not None:
+                    T.mask_rows_(dtop, inner, T2)
+                self.sync.launch(*st.range_of(self._layer_names[L]))
+            if self.mix:            # d hidden_l = s_l * d mixed;  d per_layer_weights = s * (g - <s, g>),  g_l = <d mixed, hidden_l>
+                dmix = dtop
+                gdot = torch.zeros(L + 1, device=dev, dtype=F32)
+                for i, h in enumerate(hs):
+                    T.dot_(gdot[i:i + 1], dmix, h.reshape(M, d))
+                T.softmax_vec_bwd_(G("mix_w"), sw, gdot)
+                dtop = T.axpy_dev_(e32(M, d), dmix, sw[L:L + 1], overwrite=True)
+            T.layernorm_bwd(x, P("enc_ln_g"), dtop, dx, accumulate=False, dgamma=G("enc_ln_g"), dbeta=G("enc_ln_b"), eps=eps_e)
+        elif dhid is not None:
+            T.layernorm_bwd(x, P("enc_ln_g"), dhid, dx, accumulate=False, dgamma=G("enc_ln_g"), dbeta=G("enc_ln_b"), eps=eps_e)
+        if extra_hidden_grad is not None:
+            dh32 = extra_hidden_grad(last_hidden, outer)
+            if dh32 is not None:
+                T.layernorm_bwd(x, P("enc_ln_g"), dh32, dx, accumulate=dhid is not None, dgamma=G("enc_ln_g"), dbeta=G("enc_ln_b"), eps=eps_e)
+            elif dhid is None:
+                dx.zero_()
+        self.sync.launch(*st.range_of(self._encln_names if (self.mix or self.extra) else self._head_names))
+        for l in range(L - 1, -1, -1):
+            S = saved[l]
+            if S is not None:               # (a dropped layer: dx passes through, its gradient range stays zero — still reduced: other ranks may have run it)
+                dx = layer_bwd(dx, S, l)
+            if dmix is not None:            # layer mixing: hidden_states[l] is this layer's input
+                T.axpy_dev_(dx, dmix, sw[l:l + 1])
             self.sync.launch(*st.range_of(self._layer_names[l]))
         # ---------------- front end
         if pd["hidden"] > 0:

@@ -167,6 +167,15 @@ int mi_spec_mask_apply(float* x, long ld, const unsigned char* time_mask, const 
                        mi_stream_t stream);
 int mi_spec_mask_bwd(float* dx, long ld, const unsigned char* time_mask, float* dembed, const unsigned char* feat_mask, int T, int M, int N,
                      mi_stream_t stream);
+/* ---- layer mixing of the CTC fine-tuning head — replaces src/models/bestrq.py:239-245
+ *      (`(torch.stack(hidden_states) * softmax(per_layer_weights)[:, None, None, None]).sum(0)`) and its autograd backward.
+ *  mi_softmax_vec_f32:      s = softmax(w), n <= 1024.        mi_softmax_vec_bwd_f32:  dw += s * (g - <s, g>)  (g_l = <d mixed, hidden_l>).
+ *  mi_axpy_dev_f32:         a = (overwrite ? 0 : a) + alpha[0] * b  with the coefficient read from DEVICE memory (no host round trip).
+ *  mi_dot_f32:              out[0] += <a, b>  (caller zeroes out; bit-reproducible; workspace: 1024 floats). */
+int mi_softmax_vec_f32(const float* w, int n, float* s, mi_stream_t stream);
+int mi_softmax_vec_bwd_f32(const float* s, const float* g, int n, float* dw, mi_stream_t stream);
+int mi_axpy_dev_f32(float* a, const float* b, long n, const float* alpha, int overwrite, mi_stream_t stream);
+int mi_dot_f32(const float* a, const float* b, long n, float* out, float* workspace /* 1024 floats */, mi_stream_t stream);
 int mi_sumsq_f32(const float* x, long n, float* sumsq, float* workspace /* 1024 floats */, mi_stream_t stream);
 /* norm_coef_skip (3 floats): [sqrt(sumsq), clip coefficient min(1, max_norm / (norm + 1e-6)), skip flag].  skip = 1 (and coef 0) when the norm is not
  * finite or exceeds skip_above > 0 — GradAwareTrainer.training_step drops such a step (src/utilities/training_utils.py:81,101-115). mi_adamw_step

@@ -65,6 +65,58 @@ def test_gradients_match_reference_golden(name, extra):
     _compare(grads, ref)
 
 
+FINETUNE_CASES = ["finetune_tiny_mix_extra", "finetune_tiny_mix", "finetune_tiny_extra"]
+
+
+def _finetune_cfg(g):
+    extra, mix = (bool(v) for v in g["flags"])
+    return dict(shapes.TINY, ctc_zero_infinity=True, ctc_loss_reduction="mean", finetune_with_additional_layer=extra, finetune_with_layer_mixing=mix)
+
+
+@pytest.mark.parametrize("name", FINETUNE_CASES)
+def test_finetune_head_matches_reference_golden(name):
+    """BestRQEBranchformerForCTC with the recipes' fine-tuning options (bestrq.py:192-322): softmax-weighted mix of all hidden states and /
+    or one more E-Branchformer layer before the CTC head — eval logits + loss and every training gradient against the reference's own."""
+    g = load_golden(name)
+    cfg = _finetune_cfg(g)
+    sd, x, am, lab = case_inputs(g, cfg)
+    tr = _trainer(cfg, sd)
+    ev = tr.forward_backward(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV), backward=False)
+    assert abs(float(ev["loss"]) - float(g["eval_loss"])) <= 1e-3 * abs(float(g["eval_loss"])) + 1e-3
+    valid = int(ev["outer_len"].min())
+    dl = (ev["logits"].float().cpu() - torch.from_numpy(g["eval_logits"]))[:, :valid].abs()
+    assert float(dl.max()) < 0.06 and float(dl.mean()) < 0.009, (float(dl.max()), float(dl.mean()))
+    tr.store.zero_grad()
+    out = tr.forward_backward(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV))
+    torch.cuda.synchronize()
+    assert abs(float(out["loss"]) - float(g["loss"])) <= 1e-3 * abs(float(g["loss"])) + 1e-3
+    ref = {k[5:]: g[k] for k in g.files if k.startswith("grad:")}
+    grads = tr.grad_dict()
+    assert set(ref) <= set(grads), sorted(set(ref) - set(grads))[:5]
+    if cfg["finetune_with_layer_mixing"]:
+        assert "per_layer_weights" in ref and float(np.abs(ref["per_layer_weights"]).max()) > 0
+    if cfg["finetune_with_additional_layer"]:
+        assert any(k.startswith("additional_layer.") for k in ref)
+    _compare(grads, ref)
+    # round trip of the extra parameters through the reference's names
+    back = tr.state_dict()
+    for k, v in sd.items():
+        assert torch.equal(back[k].cpu(), v), k
+
+
+def test_finetune_head_trains_and_layerdrop_keeps_the_mix_consistent():
+    """a few optimizer steps reduce the loss; with a dropped layer the mix still sees that layer's (unchanged) input, like the oracle"""
+    g = load_golden("finetune_tiny_mix_extra")
+    cfg = _finetune_cfg(g)
+    sd, x, am, lab = case_inputs(g, cfg)
+    tr = _trainer(cfg, sd, lr=1e-3)
+    out = tr.forward_backward(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV), backward=False, skip_layers=[1])
+    want, _ = R.finetune_ctc_forward(sd, dict(cfg), x, am, lab, skip_layers=(1,))
+    assert abs(float(out["loss"]) - float(want)) <= 2e-3 * abs(float(want))
+    losses = [float(tr.train_step(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV))["loss"]) for _ in range(8)]
+    assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0], losses
+
+
 def _oracle_grads(cfg, sd, x, am, lab, skip_layers=()):
     sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     hidden = R.encoder_forward(sdr, cfg, x, am, skip_layers=skip_layers)

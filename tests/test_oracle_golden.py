@@ -187,3 +187,15 @@ def test_bestrq_oracle_matches_reference_fixture():
         if k.startswith("grad:"):
             got, want = sdr[k[5:]].grad.numpy(), g[k]
             assert np.abs(got - want).max() <= 2e-4 * max(1.0, np.abs(want).max()), k
+
+
+@pytest.mark.parametrize("name", ["finetune_tiny_mix_extra", "finetune_tiny_mix", "finetune_tiny_extra"])
+def test_finetune_head_oracle_matches_reference(name):
+    """oracle.finetune_ctc_forward (layer mixing / additional layer of BestRQEBranchformerForCTC, bestrq.py:212-322) against the reference's eval outputs"""
+    g = load_golden(name)
+    extra, mix = (bool(v) for v in g["flags"])
+    cfg = dict(shapes.TINY, ctc_zero_infinity=True, ctc_loss_reduction="mean", finetune_with_additional_layer=extra, finetune_with_layer_mixing=mix)
+    sd, x, am, lab = case_inputs(g, cfg)
+    loss, logits = R.finetune_ctc_forward(sd, cfg, x, am, lab)
+    assert float((logits - torch.from_numpy(g["eval_logits"])).abs().max()) < 2e-4
+    assert abs(float(loss) - float(g["eval_loss"])) < 2e-4 * abs(float(g["eval_loss"]))
