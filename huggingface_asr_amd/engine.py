@@ -50,7 +50,10 @@ def cfg_from_hf(config) -> dict:
                 final_dropout=g("final_dropout", 0.0), feat_proj_dropout=g("feat_proj_dropout", 0.0), layerdrop=g("layerdrop", 0.0),
                 csgu_conv_dropout=g("csgu_conv_dropout", 0.0), apply_spec_augment=g("apply_spec_augment", False),
                 mask_time_length=g("mask_time_length", 10), mask_time_min_masks=g("mask_time_min_masks", 2),
-                mask_feature_length=g("mask_feature_length", 10), mask_feature_min_masks=g("mask_feature_min_masks", 0))
+                mask_feature_length=g("mask_feature_length", 10), mask_feature_min_masks=g("mask_feature_min_masks", 0),
+                # CTC fine-tuning head of a BEST-RQ encoder (bestrq.py:155-205)
+                finetune_with_additional_layer=bool(g("finetune_with_additional_layer", False)),
+                finetune_with_layer_mixing=bool(g("finetune_with_layer_mixing", False)))
 
 
 class EBranchformerEngine:
@@ -64,6 +67,9 @@ class EBranchformerEngine:
         # Off by default: two kernels of different streams sharing a CU is what DESIGN.md 'Concurrent kernels' is about.
         self.branch_overlap = os.environ.get("HFASR_BRANCH_OVERLAP", "0") == "1"
         c = self.cfg
+        if c.get("finetune_with_additional_layer", False) or c.get("finetune_with_layer_mixing", False):
+            raise NotImplementedError("the single-call forward engine has no layer mixing / additional layer: BestRQEBranchformerForCTC runs these "
+                                      "through the per-op path (train.EncoderCTCTrainer.forward_backward(backward=False))")
         if len(c["conv_dim"]) != 2 or len(set(c["conv_kernel"])) != 1 or len(set(c["conv_stride"])) != 1 or len(set(c["conv_padding"])) != 1:
             raise NotImplementedError("HIP path supports the 2-layer Conv2d sub-sampling with equal kernel/stride/padding")
         if c.get("csgu_use_linear_after_conv", False):

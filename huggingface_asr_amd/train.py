@@ -569,7 +569,10 @@ class EncoderCTCTrainer:
             ops.gemm(hid, W("head_w"), P("head_b"), out=lbuf.view(M, ldl))
             logits = lbuf[..., :V1]
             lse = ops.row_lse(lbuf.view(M, ldl)[:, :V1])
-            loss, nll, _ = ops.ctc_loss(logits, labels, outer, reduction=red, zero_infinity=bool(c.get("ctc_zero_infinity", False)), lse=lse)
+            if labels is not None:
+                loss, nll, _ = ops.ctc_loss(logits, labels, outer, reduction=red, zero_infinity=bool(c.get("ctc_zero_infinity", False)), lse=lse)
+            elif backward:
+                raise ValueError("forward_backward: the backward pass of the CTC head needs `labels`")
         out = dict(loss=loss, logits=logits, outer_len=outer, inner_len=inner,
                    last_hidden=last_hidden.view(B, T2, d) if keep_hidden or extra_hidden_grad or not self.head else None)
         if not backward:

@@ -514,3 +514,57 @@ def test_hf_bestrq_model_forward_and_training_bridge():
     grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
     assert set(ref) <= set(grads)
     _compare(grads, ref)
+
+
+def test_hf_bestrq_ctc_finetune_options_forward_and_training_bridge():
+    """AutoModelForCTC route of BestRQEBranchformerForCTC with the recipes' `finetune_with_additional_layer=True,finetune_with_layer_mixing=True`
+    (recipes/librispeech/ssl/*/lumi/finetune_frozen*.sh): eval forward vs the reference's logits, train()-mode loss.backward() vs its gradients,
+    and `freeze_encoder()` (train_ctc_asr.py:51-52) leaving exactly the encoder's parameters without a gradient."""
+    from transformers import AutoModelForCTC
+    from huggingface_asr_amd.bind import bind_all
+    from huggingface_asr_amd.modeling_bestrq import BestRQEBranchformerForCTC, BestRQEBranchformerForPreTrainingConfig
+    bind_all()
+    g = load_golden("finetune_tiny_mix_extra")
+    cfg = _finetune_cfg(g)
+    sd, x, am, lab = case_inputs(g, cfg)
+    base = dict(shapes.TINY); base.pop("num_fbanks")
+    model = AutoModelForCTC.from_config(BestRQEBranchformerForPreTrainingConfig(**base, ctc_zero_infinity=True, ctc_loss_reduction="mean", **HF_NO_DROPOUT,
+                                                                                finetune_with_additional_layer=True, finetune_with_layer_mixing=True))
+    assert isinstance(model, BestRQEBranchformerForCTC)
+    assert float(model.per_layer_weights[-1]) == 1.0 and float(model.per_layer_weights[:-1].abs().sum()) == 0.0          # bestrq.py:203-205
+    assert not any(model.load_state_dict(sd, strict=False))
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        out = model(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))
+        nolab = model(x.to(DEV), attention_mask=am.to(DEV))
+    assert nolab.loss is None and torch.equal(nolab.logits, out.logits)
+    assert abs(float(out.loss) - float(g["eval_loss"])) <= 1e-3 * float(g["eval_loss"]) + 1e-3
+    valid = int(model._get_feat_extract_output_lengths(am.sum(-1)).min())
+    dl = (out.logits.float().cpu() - torch.from_numpy(g["eval_logits"]))[:, :valid].abs()
+    assert float(dl.max()) < 0.06 and float(dl.mean()) < 0.009
+    model.train()
+    out = model(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))
+    out.loss.backward()
+    ref = {k[5:]: g[k] for k in g.files if k.startswith("grad:")}
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert set(ref) <= set(grads)
+    _compare(grads, ref)
+    # frozen encoder: the recipes' setting — front end, mixing weights, additional layer and head still train
+    model.zero_grad()
+    model.freeze_encoder()
+    out = model(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))
+    out.loss.backward()
+    got = {n for n, p in model.named_parameters() if p.grad is not None}
+    assert not any(n.startswith("wav2vec2.encoder.") for n in got)
+    assert {"per_layer_weights", "lm_head.weight", "additional_layer.merge_proj.weight", "wav2vec2.feature_projection.projection.weight"} <= got
+    live = {k: v for k, v in ref.items() if not k.startswith("wav2vec2.encoder.")}
+    _compare({n: p.grad for n, p in model.named_parameters() if p.grad is not None}, live)
+    # after an optimizer step the eval route sees the new weights
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.grad is not None:
+                p.add_(p.grad, alpha=-1e-3)
+    model.eval()
+    with torch.no_grad():
+        after = model(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))
+    assert float(after.loss) != float(out.loss) and np.isfinite(float(after.loss))

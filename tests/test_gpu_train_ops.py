@@ -341,3 +341,40 @@ def test_adamw_matches_torch():
         T.adamw_step_(p, bad, m, v, dmask, lr=2e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01, step=9, norm_coef=nc, mirror=mirror)
         assert torch.equal(p, p0) and torch.equal(m, m0) and torch.equal(v, v0)
 
+
+
+def test_layer_mixing_ops_match_torch():
+    """the four entries behind the fine-tuning head's layer mixing (bestrq.py:239-245): softmax of the weights, device-coefficient axpy,
+    deterministic dot product, softmax backward — against torch fp32/fp64 on the same inputs."""
+    _, T = _o()
+    torch.manual_seed(5)
+    n, L1 = 2 * 50 * 64 + 3, 13                      # odd length: the scalar tail of the 16-B loops runs too
+    w = torch.randn(L1, device=DEV)
+    s = T.softmax_vec(w)
+    assert torch.allclose(s, torch.softmax(w, 0), rtol=1e-6, atol=1e-7) and abs(float(s.sum()) - 1.0) < 1e-6
+    hs = [torch.randn(n, device=DEV) for _ in range(L1)]
+    mixed = torch.empty(n, device=DEV)
+    for i, h in enumerate(hs):
+        T.axpy_dev_(mixed, h, s[i:i + 1], overwrite=(i == 0))
+    want = (torch.stack(hs).double() * s.double()[:, None]).sum(0)
+    assert float((mixed.double() - want).abs().max()) < 1e-5
+    d = torch.randn(n, device=DEV)
+    g = torch.zeros(L1, device=DEV)
+    for i, h in enumerate(hs):
+        T.dot_(g[i:i + 1], d, h)
+    gw = torch.stack([(d.double() * h.double()).sum() for h in hs])
+    assert float((g.double() - gw).abs().max()) < 1e-3 * float(gw.abs().max())
+    g2 = torch.zeros(L1, device=DEV)
+    for i, h in enumerate(hs):
+        T.dot_(g2[i:i + 1], d, h)
+    assert torch.equal(g, g2)                         # bit-reproducible
+    dw = torch.full((L1,), 0.25, device=DEV)
+    T.softmax_vec_bwd_(dw, s, g)
+    wr = w.double().clone().requires_grad_(True)
+    (torch.softmax(wr, 0) * gw).sum().backward()
+    assert float((dw.double() - 0.25 - wr.grad).abs().max()) < 1e-3 * float(wr.grad.abs().max()) + 1e-6
+    # unaligned views take the scalar path
+    a = torch.zeros(n + 1, device=DEV)[1:]
+    b = torch.randn(n + 1, device=DEV)[1:]
+    T.axpy_dev_(a, b.contiguous() if not b.is_contiguous() else b, s[0:1], overwrite=True)
+    assert torch.allclose(a, b * s[0], rtol=1e-6, atol=1e-7)

@@ -142,5 +142,10 @@ def test_bestrq_classes_match_reference_parameter_list_and_registry():
         model(torch.zeros(1, 200, 80))                                   # mask_time_indices is mandatory (bestrq.py:127)
     with pytest.raises(RuntimeError):
         model(torch.zeros(1, 200, 80), mask_time_indices=torch.zeros(1, 50, dtype=torch.bool))   # CPU tensors: no fallback
-    with pytest.raises(NotImplementedError):
-        AutoModelForCTC.from_config(BestRQEBranchformerForPreTrainingConfig(**base, **BESTRQ_CFG, finetune_with_layer_mixing=True))
+    # the recipes' fine-tuning options add exactly the reference's extra parameters (bestrq.py:199-205)
+    ft = AutoModelForCTC.from_config(BestRQEBranchformerForPreTrainingConfig(**base, **BESTRQ_CFG, finetune_with_layer_mixing=True, finetune_with_additional_layer=True))
+    plain = AutoModelForCTC.from_config(BestRQEBranchformerForPreTrainingConfig(**base, **BESTRQ_CFG))
+    added = {k: tuple(v.shape) for k, v in ft.named_parameters() if k not in dict(plain.named_parameters())}
+    layer0 = {k[len("wav2vec2.encoder.layers.0."):]: tuple(v.shape) for k, v in plain.named_parameters() if k.startswith("wav2vec2.encoder.layers.0.")}
+    assert added == {"per_layer_weights": (base["num_hidden_layers"] + 1,), **{"additional_layer." + k: v for k, v in layer0.items()}}
+    assert ft.per_layer_weights.detach().tolist() == [0.0] * base["num_hidden_layers"] + [1.0]
