@@ -69,11 +69,33 @@ class ParamStore:
         self.flat_bf = z(BF16)
         self.flat_T = z(BF16, max(offT, 64))
         self.decay = torch.zeros(off, dtype=torch.uint8, device=self.device)
-        for s in specs:
-            if s.decay:
-                o = self.off[s.name]
-                self.decay[o:o + math.prod(s.shape)] = 1
+        self.frozen_spans = []
+        self.set_frozen(())
         self.step_count = 0
+
+    def set_frozen(self, names):
+        """Parameters that must not change: no weight decay on them (the mask AdamW reads), and their gradient spans — merged into as few
+        contiguous ranges as the layout allows — are cleared before the norm / AdamW (`zero_frozen_grads`), so that with m = v = 0 the update
+        is exactly zero and the clipping norm counts trainable parameters only (torch's optimizers never see a frozen parameter)."""
+        frozen = set(names)
+        mask = torch.zeros(self.n if hasattr(self, "n") else self.decay.numel(), dtype=torch.uint8)
+        spans = []
+        for name in self.order:
+            s, o = self.specs[name], self.off[name]
+            if name in frozen:
+                hi = o + _al(math.prod(s.shape))
+                if spans and spans[-1][1] == o:
+                    spans[-1][1] = hi
+                else:
+                    spans.append([o, hi])
+            elif s.decay:
+                mask[o:o + math.prod(s.shape)] = 1
+        self.decay.copy_(mask)
+        self.frozen_spans = [(lo, hi) for lo, hi in spans]
+
+    def zero_frozen_grads(self):
+        for lo, hi in self.frozen_spans:
+            self.flat_g[lo:hi].zero_()
 
     def _view(self, flat, name):
         s = self.specs[name]
@@ -363,9 +385,13 @@ class EncoderCTCTrainer:
     def set_frozen(self, reference_names):
         """Names (reference state-dict keys) of parameters that do not train (`requires_grad False`: `freeze_encoder()`, train_ctc_asr.py:51-52).
         A packed store parameter counts as frozen when all of its reference pieces are; the weight / bias gradient GEMMs of frozen linears
-        are then skipped in the backward (their input gradients are still computed: something upstream may train)."""
+        are then skipped in the backward (their input gradients are still computed: something upstream may train).  On the native route
+        (`train_step`) frozen parameters stay bit-identical: no weight decay, gradients cleared before the clip norm and AdamW."""
         ref = set(reference_names or ())
-        self.frozen = {name for name in self.store.order if name in self.map and self.map[name][1] and all(k in ref for k, _ in self.map[name][1])}
+        frozen = {name for name in self.store.order if name in self.map and self.map[name][1] and all(k in ref for k, _ in self.map[name][1])}
+        if frozen != self.frozen:                 # the autograd bridge calls this every step: rebuild the device mask only when the set changes
+            self.store.set_frozen(frozen)         # native route: AdamW leaves them bit-identical (no decay, zero gradient), the clip norm skips them
+        self.frozen = frozen
 
     def grad_dict(self) -> dict:
         """gradients in the reference's parameter names / shapes (tests, checkpoint tooling, the autograd bridge)."""
@@ -856,6 +882,7 @@ class EncoderCTCTrainer:
         """waits for the gradient all-reduces, clips by global norm, applies AdamW, refreshes the bf16 mirrors."""
         st, hp = self.store, self.hp
         self.sync.wait()
+        st.zero_frozen_grads()
         sc = self._scal
         sc.zero_()
         T.sumsq_(sc[0:1], st.flat_g)

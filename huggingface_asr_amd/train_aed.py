@@ -159,7 +159,8 @@ class JointAEDTrainer:
         self.store.refresh_mirrors(cast=True)
 
     def set_frozen(self, reference_names):
-        """frozen encoder parameters (freeze_encoder): their weight-gradient GEMMs are skipped (train.EncoderCTCTrainer.set_frozen); decoder: computed"""
+        """frozen encoder parameters (freeze_encoder): their weight-gradient GEMMs are skipped and, on the native route, AdamW leaves them
+        untouched (train.EncoderCTCTrainer.set_frozen); decoder parameters always train"""
         self.enc.set_frozen({k[len("encoder."):] for k in (reference_names or ()) if k.startswith("encoder.")})
 
     def _export(self, view):
@@ -340,6 +341,7 @@ class JointAEDTrainer:
     def optimizer_step(self, lr=None):
         hp = self.hp
         self.enc.sync.wait(); self.sync.wait()
+        self.enc.store.zero_frozen_grads()          # frozen encoder parameters (set_frozen): no update, not in the clip norm
         sc = self.enc._scal
         sc.zero_()
         T.sumsq_(sc[0:1], self.enc.store.flat_g)

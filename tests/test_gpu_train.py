@@ -115,6 +115,24 @@ def test_finetune_head_trains_and_layerdrop_keeps_the_mix_consistent():
     assert abs(float(out["loss"]) - float(want)) <= 2e-3 * abs(float(want))
     losses = [float(tr.train_step(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV))["loss"]) for _ in range(8)]
     assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0], losses
+    # the recipes' frozen fine-tuning on the native route: encoder parameters stay bit-identical (no decay, no update), everything else moves,
+    # and the clip norm counts trainable gradients only
+    tr = _trainer(cfg, sd, lr=1e-3, weight_decay=0.1)
+    enc_keys = {k for k in sd if k.startswith("wav2vec2.encoder.")}
+    tr.set_frozen(enc_keys)
+    for _ in range(3):
+        out = tr.train_step(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV))
+    live = torch.sqrt(sum((v.double() ** 2).sum() for k, v in tr.grad_dict().items() if k not in enc_keys))
+    assert abs(float(out["grad_norm"]) - float(live)) <= 1e-4 * float(live)
+    after = tr.state_dict()
+    for k, v in sd.items():
+        if k in enc_keys:
+            assert torch.equal(after[k].cpu(), v), k
+    moved = [k for k, v in sd.items() if k not in enc_keys and k != "wav2vec2.masked_spec_embed" and not torch.equal(after[k].cpu(), v)]
+    assert {"per_layer_weights", "additional_layer.merge_proj.weight", "lm_head.weight", "wav2vec2.feature_projection.projection.weight"} <= set(moved)
+    tr.set_frozen(())                                   # thawing restores decay and updates
+    tr.train_step(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV))
+    assert not torch.equal(tr.state_dict()["wav2vec2.encoder.layers.0.merge_proj.weight"].cpu(), sd["wav2vec2.encoder.layers.0.merge_proj.weight"])
 
 
 def _oracle_grads(cfg, sd, x, am, lab, skip_layers=()):

@@ -14,6 +14,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", default="base"); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3); ap.add_argument("--pos", default="relative"); ap.add_argument("--frames", type=int, default=1000)
 ap.add_argument("--fwd-only", action="store_true")
+ap.add_argument("--finetune", action="store_true", help="the frozen fine-tuning recipes' setting (recipes/librispeech/ssl/*/lumi/finetune_frozen*.sh): layer mixing + "
+                                                        "additional layer before the CTC head, encoder layers frozen")
 ap.add_argument("--model", default="ctc", choices=["ctc", "aed"], help="aed = BASELINE config 3: small encoder + 6x256 GPT-2 decoder, ctc_weight 0.3, lsm 0.1, "
                                                                          "fixed positions, per-GPU batch 96, lengths uniform 1-20 s sorted into the batch")
 a = ap.parse_args()
@@ -22,7 +24,8 @@ dev = torch.device("cuda", local); torch.cuda.set_device(dev)
 PL.init("nccl", dev)
 base = {"base": shapes.BASE, "small": shapes.SMALL, "tiny": shapes.TINY}[a.size]
 cfg = dict(base, position_embeddings_type=a.pos, ctc_zero_infinity=True, ctc_loss_reduction="mean", hidden_dropout=0.0, activation_dropout=0.0,
-           attention_dropout=0.0, final_dropout=0.0, feat_proj_dropout=0.0, csgu_conv_dropout=0.0, layerdrop=0.0, apply_spec_augment=False)
+           attention_dropout=0.0, final_dropout=0.0, feat_proj_dropout=0.0, csgu_conv_dropout=0.0, layerdrop=0.0, apply_spec_augment=False,
+           finetune_with_additional_layer=a.finetune, finetune_with_layer_mixing=a.finetune)
 sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()}
 B, T = a.batch, a.frames
 if a.model == "aed":
@@ -44,6 +47,8 @@ if a.model == "aed":
 else:
     tr = EncoderCTCTrainer(cfg, dev, lr=2e-3, weight_decay=1e-6)
     tr.load_state_dict(sd)
+    if a.finetune:
+        tr.set_frozen({k for k in sd if k.startswith("wav2vec2.encoder.")})          # freeze_encoder(): train_ctc_asr.py:51-52
     fl = np.full((B,), T - 2)
     U = 40
 feats = torch.from_numpy(synth.normal(100 + rank, "feats", (B, T, 80), 1.0)).to(dev)
