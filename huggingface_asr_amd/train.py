@@ -393,6 +393,12 @@ class EncoderCTCTrainer:
             self.store.set_frozen(frozen)         # native route: AdamW leaves them bit-identical (no decay, zero gradient), the clip norm skips them
         self.frozen = frozen
 
+    def _lng(self, gname, bname):
+        """gradient targets of a LayerNorm's affine pair: none when both are frozen (the cross-row reduction is then skipped)"""
+        if gname in self.frozen and bname in self.frozen:
+            return dict(dgamma=None, dbeta=None)
+        return dict(dgamma=self.store.g(gname), dbeta=self.store.g(bname))
+
     def grad_dict(self) -> dict:
         """gradients in the reference's parameter names / shapes (tests, checkpoint tooling, the autograd bridge)."""
         return self._export(self.store.g)
@@ -609,7 +615,7 @@ class EncoderCTCTrainer:
             p, sl = f"l{l}.", l + int(l >= L)
             # final_layer_norm
             d3 = e32(M, d)
-            T.layernorm_bwd(S["x3"], P(p + "fin_ln_g"), dx, d3, accumulate=False, dgamma=G(p + "fin_ln_g"), dbeta=G(p + "fin_ln_b"))
+            T.layernorm_bwd(S["x3"], P(p + "fin_ln_g"), dx, d3, accumulate=False, **self._lng(p + "fin_ln_g", p + "fin_ln_b"))
             dx = d3
             if macaron:
                 self._ffn_bwd(dx, S["x2"], S["ff2"], p + "ff2", pd, sl, (6, 7))
@@ -626,10 +632,10 @@ class EncoderCTCTrainer:
             dgn = e16(M, I // 2)
             T.csgu_bwd(S["h"], S["stats"], P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), dsg, dh[:, :I // 2], dgn,
                        G(p + "csgu_w"), G(p + "csgu_b"), B, T2)
-            T.layernorm_bwd(S["h"][:, I // 2:], P(p + "csgu_ln_g"), dgn, dh[:, I // 2:], accumulate=False, dgamma=G(p + "csgu_ln_g"), dbeta=G(p + "csgu_ln_b"))
+            T.layernorm_bwd(S["h"][:, I // 2:], P(p + "csgu_ln_g"), dgn, dh[:, I // 2:], accumulate=False, **self._lng(p + "csgu_ln_g", p + "csgu_ln_b"))
             dhp = T.act_bwd(dh, S["hp"])
             da2 = T.linear_bwd(dhp, S["a2"], WT(p + "mlp_w1"), dw=GL(p + "mlp_w1"), db=GL(p + "mlp_b1"))
-            T.layernorm_bwd(S["x1"], P(p + "mlp_ln_g"), da2, dx, accumulate=True, dgamma=G(p + "mlp_ln_g"), dbeta=G(p + "mlp_ln_b"))
+            T.layernorm_bwd(S["x1"], P(p + "mlp_ln_g"), da2, dx, accumulate=True, **self._lng(p + "mlp_ln_g", p + "mlp_ln_b"))
             # global branch
             if pd["att"] > 0:
                 T.dropout_(dcat[:, :d], pd["att"], seed, self._sid(sl, 3))
@@ -640,11 +646,11 @@ class EncoderCTCTrainer:
                 da1r = T.linear_bwd(dqkv[:, :2 * d], S["a1r"], wt[:, :2 * d], dw=GL(p + "att_wqkv", slice(0, 2 * d)), db=GL(p + "att_bqkv", slice(0, 2 * d)))
                 da1 = T.linear_bwd(dqkv[:, 2 * d:], S["a1"], wt[:, 2 * d:3 * d], dw=GL(p + "att_wqkv", slice(2 * d, None)), db=GL(p + "att_bqkv", slice(2 * d, None)), dx_dtype=F32)
                 rot = ops.rotary(da1r, pos[0].reshape(-1), pos[2].reshape(-1), T2, H)             # R^T = rotation by -theta
-                T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), da1, dx, accumulate=True, dgamma=G(p + "att_ln_g"), dbeta=G(p + "att_ln_b"))
-                T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), rot, dx, accumulate=True, dgamma=G(p + "att_ln_g"), dbeta=G(p + "att_ln_b"))
+                T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), da1, dx, accumulate=True, **self._lng(p + "att_ln_g", p + "att_ln_b"))
+                T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), rot, dx, accumulate=True, **self._lng(p + "att_ln_g", p + "att_ln_b"))
             else:
                 da1 = T.linear_bwd(dqkv, S["a1"], WT(p + "att_wqkv")[:, :3 * d], dw=GL(p + "att_wqkv"), db=GL(p + "att_bqkv"))
-                T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), da1, dx, accumulate=True, dgamma=G(p + "att_ln_g"), dbeta=G(p + "att_ln_b"))
+                T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), da1, dx, accumulate=True, **self._lng(p + "att_ln_g", p + "att_ln_b"))
             if macaron:
                 self._ffn_bwd(dx, S["x_in"], S["ff1"], p + "ff1", pd, sl, (0, 1))
             return dx
@@ -674,13 +680,13 @@ class EncoderCTCTrainer:
                     T.dot_(gdot[i:i + 1], dmix, h.reshape(M, d))
                 T.softmax_vec_bwd_(G("mix_w"), sw, gdot)
                 dtop = T.axpy_dev_(e32(M, d), dmix, sw[L:L + 1], overwrite=True)
-            T.layernorm_bwd(x, P("enc_ln_g"), dtop, dx, accumulate=False, dgamma=G("enc_ln_g"), dbeta=G("enc_ln_b"), eps=eps_e)
+            T.layernorm_bwd(x, P("enc_ln_g"), dtop, dx, accumulate=False, **self._lng("enc_ln_g", "enc_ln_b"), eps=eps_e)
         elif dhid is not None:
-            T.layernorm_bwd(x, P("enc_ln_g"), dhid, dx, accumulate=False, dgamma=G("enc_ln_g"), dbeta=G("enc_ln_b"), eps=eps_e)
+            T.layernorm_bwd(x, P("enc_ln_g"), dhid, dx, accumulate=False, **self._lng("enc_ln_g", "enc_ln_b"), eps=eps_e)
         if extra_hidden_grad is not None:
             dh32 = extra_hidden_grad(last_hidden, outer)
             if dh32 is not None:
-                T.layernorm_bwd(x, P("enc_ln_g"), dh32, dx, accumulate=dhid is not None, dgamma=G("enc_ln_g"), dbeta=G("enc_ln_b"), eps=eps_e)
+                T.layernorm_bwd(x, P("enc_ln_g"), dh32, dx, accumulate=dhid is not None, **self._lng("enc_ln_g", "enc_ln_b"), eps=eps_e)
             elif dhid is None:
                 dx.zero_()
         self.sync.launch(*st.range_of(self._encln_names if (self.mix or self.extra) else self._head_names))
@@ -703,7 +709,7 @@ class EncoderCTCTrainer:
         dyb = T.dropout_(dx, pd["fp"], seed, self._sid(L, 0), out=e16(M, d)) if pd["fp"] > 0 else T.add_cast(dx)
         da = T.linear_bwd(dyb, a_fp, WT("fp_w"), dw=GL("fp_w"), db=GL("fp_b"))
         dfeo = e32(M, d)
-        T.layernorm_bwd(feo, P("fp_ln_g"), da, dfeo, accumulate=False, dgamma=G("fp_ln_g"), dbeta=G("fp_ln_b"), eps=eps_e)
+        T.layernorm_bwd(feo, P("fp_ln_g"), da, dfeo, accumulate=False, **self._lng("fp_ln_g", "fp_ln_b"), eps=eps_e)
         dact2 = T.linear_bwd(T.add_cast(dfeo), act2, WT("feout_w"), dw=GL("feout_w"), db=GL("feout_b"))      # (M, F2*C2)
         dpre2 = T.act_bwd(dact2.view(B * T2 * F2, C2), pre2)
         col = T.im2col(act1, K, s_, pad, T2, F2)
@@ -783,7 +789,7 @@ class EncoderCTCTrainer:
             T.dropout_(dh, pd["act"], self.seed, self._sid(l, sites[0]))
         dhp = T.act_bwd(dh, S["hp"])
         da = T.linear_bwd(dhp, S["a"], WT(pre + "_w1"), dw=GL(pre + "_w1"), db=GL(pre + "_b1"))
-        T.layernorm_bwd(x_in, P(pre + "_ln_g"), da, dx, accumulate=True, dgamma=G(pre + "_ln_g"), dbeta=G(pre + "_ln_b"))
+        T.layernorm_bwd(x_in, P(pre + "_ln_g"), da, dx, accumulate=True, **self._lng(pre + "_ln_g", pre + "_ln_b"))
 
     def _attention_fwd(self, qkv, posp, u, v, lengths, B, Tt, H, S, drop=None):
         d = qkv.shape[1] // 3
