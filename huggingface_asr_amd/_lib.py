@@ -18,7 +18,7 @@ class EbfConfig(C.Structure):
     """mirror of mi_ebf_config (include/hfasr_hip.h)"""
     _fields_ = [(n, i32) for n in ("B", "T", "F", "d", "H", "I", "L", "V", "C1", "C2", "K", "stride", "pad",
                                    "is_causal", "pos_type", "csgu_kernel", "merge_kernel", "csgu_act", "use_macaron")] + \
-               [("ln_eps", f32), ("logits_f32", i32), ("logits_ld", i32), ("branch_overlap", i32)]
+               [("ln_eps", f32), ("logits_f32", i32), ("logits_ld", i32), ("branch_overlap", i32), ("extra_layers", i32), ("layer_mixing", i32)]
 
 
 class Gpt2Config(C.Structure):

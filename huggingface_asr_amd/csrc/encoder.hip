@@ -19,7 +19,7 @@
 namespace {
 
 enum G { G_CONV1_W, G_CONV1_B, G_CONV2_W, G_CONV2_B, G_FEOUT_W, G_FEOUT_B, G_FP_LN_G, G_FP_LN_B, G_FP_W, G_FP_B,
-         G_ENC_LN_G, G_ENC_LN_B, G_HEAD_W, G_HEAD_B };
+         G_ENC_LN_G, G_ENC_LN_B, G_HEAD_W, G_HEAD_B, G_MIX_W /* per_layer_weights (L+1) f32, bestrq.py:202-205 */ };
 enum LS { FF1_LN_G, FF1_LN_B, FF1_W1, FF1_B1, FF1_W2, FF1_B2,
           ATT_LN_G, ATT_LN_B, ATT_WQK, ATT_BQK, ATT_WV, ATT_BV, ATT_WO, ATT_BO, ATT_WPOS, ATT_U, ATT_V,
           MLP_LN_G, MLP_LN_B, MLP_W1, MLP_B1, CSGU_LN_G, CSGU_LN_B, CSGU_W, CSGU_B, MLP_W2, MLP_B2,
@@ -47,6 +47,7 @@ struct Carver {
 struct Ws {
     bf16_t *act1, *act2, *a0, *a1, *a2, *a1r, *h, *qk, *vt, *ctx, *cat, *m2, *s, *hid;
     float *feo, *x, *stats;
+    float *mixed, *lh, *sw;   // fine-tuning head: weighted sum of the hidden states, fp32 copy of the last one, softmax(per_layer_weights)
     int* lens;   // [inner(B) | outer(B)]
     size_t bytes;
 };
@@ -74,6 +75,12 @@ Ws carve(const mi_ebf_config& c, void* base) {
     w.hid = (bf16_t*)k.take(M * c.d * 2);
     w.stats = (float*)k.take(M * 2 * 4);
     w.lens = (int*)k.take((size_t)2 * c.B * 4);
+    w.mixed = w.lh = w.sw = nullptr;
+    if (c.layer_mixing) {
+        w.mixed = (float*)k.take(M * c.d * 4);
+        w.sw = (float*)k.take((size_t)(c.L + 1) * 4);
+    }
+    if (c.layer_mixing || c.extra_layers) w.lh = (float*)k.take(M * c.d * 4);
     w.bytes = k.off;
     return w;
 }
@@ -195,6 +202,8 @@ extern "C" int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weigh
     MI_ENTER();
     const mi_ebf_config& c = *cfg;
     if (c.B <= 0 || c.T <= 0 || c.L <= 0 || c.d % c.H || c.I % 2) return MI_ERR_ARG;
+    if (c.extra_layers < 0 || c.extra_layers > 1 || (c.layer_mixing && c.L + 1 > 1024)) return MI_ERR_ARG;
+    const int Lt = c.L + c.extra_layers;      // the fine-tuning head's additional layer (bestrq.py:247-274) is layer L of the weight table
     const Dims D = dims(c);
     if (D.T2 <= 0) return MI_ERR_ARG;
     Ws w = carve(c, workspace);
@@ -225,16 +234,19 @@ extern "C" int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weigh
                            w.a0, d, nullptr, 0, nullptr, nullptr, nullptr, 0, M, d, st));
     RUN(mi_gemm_bf16(w.a0, d, Gw(G_FP_W), d, Gf(G_FP_B), 1, w.x, d, 1, nullptr, 0, 1.f, 0, M, d, d, 0, 0, st));
     // --- zero padded frames once (tf:662-665) + first LayerNorm(s) of layer 0
-    if (c.use_macaron)
-        RUN(mi_layernorm_chain(w.x, d, mask_len, T2, nullptr, nullptr, 0.f, w.x, d, Lf(0, FF1_LN_G), Lf(0, FF1_LN_B), leps,
-                               w.a0, d, nullptr, 0, nullptr, nullptr, nullptr, 0, M, d, st));
-    else
-        RUN(mi_layernorm_chain(w.x, d, mask_len, T2, nullptr, nullptr, 0.f, w.x, d, Lf(0, ATT_LN_G), Lf(0, ATT_LN_B), leps,
-                               w.a1, d, nullptr, 0, Lf(0, MLP_LN_G), Lf(0, MLP_LN_B), w.a2, d, M, d, st));
+    auto enter_layer = [&](const float* src, int l) -> int {      // x = src with padded frames zeroed; first LayerNorm(s) of layer l
+        if (c.use_macaron)
+            return mi_layernorm_chain(src, d, mask_len, T2, nullptr, nullptr, 0.f, w.x, d, Lf(l, FF1_LN_G), Lf(l, FF1_LN_B), leps,
+                                      w.a0, d, nullptr, 0, nullptr, nullptr, nullptr, 0, M, d, st);
+        return mi_layernorm_chain(src, d, mask_len, T2, nullptr, nullptr, 0.f, w.x, d, Lf(l, ATT_LN_G), Lf(l, ATT_LN_B), leps,
+                                  w.a1, d, nullptr, 0, Lf(l, MLP_LN_G), Lf(l, MLP_LN_B), w.a2, d, M, d, st);
+    };
+    RUN(enter_layer(w.x, 0));
+    if (c.layer_mixing) RUN(mi_softmax_vec_f32(Gf(G_MIX_W), c.L + 1, w.sw, st));
     // --- relative positions: p_l = linear_pos_l(table) for every layer (batch independent; tf:531-536)
     const int P = 2 * T2 - 1;
     if (c.pos_type == 1 && compute_posp)
-        for (int l = 0; l < c.L; ++l)
+        for (int l = 0; l < Lt; ++l)
             RUN(mi_gemm_bf16(pos_table, d, Lw(l, ATT_WPOS), d, nullptr, 0, (bf16_t*)posp + (size_t)l * P * d, d, 0, nullptr, 0, 1.f, 0,
                              P, d, d, 0, 0, st));
     const float* rot_cos = (const float*)pos_table;
@@ -242,7 +254,9 @@ extern "C" int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weigh
     const float scale = 1.0f / sqrtf((float)D.hd);
     const int kc = c.csgu_kernel, km = c.merge_kernel;
 
-    for (int l = 0; l < c.L; ++l) {
+    for (int l = 0; l < Lt; ++l) {
+        // layer mixing (bestrq.py:239-245): hidden_states[l] is this layer's input; the weight is read on the device
+        if (c.layer_mixing && l < c.L) RUN(mi_axpy_dev_f32(w.mixed, w.x, (long)M * d, w.sw + l, l == 0, st));
         if (c.use_macaron) {   // x += 0.5 * FFN(LN(x))   e_branchformer.py:271-273
             RUN(mi_gemm_bf16(w.a0, d, Lw(l, FF1_W1), d, Lf(l, FF1_B1), 1, w.h, I, 0, nullptr, 0, 1.f, 1, M, I, d, 0, 0, st));
             RUN(mi_gemm_bf16(w.h, I, Lw(l, FF1_W2), I, Lf(l, FF1_B2), 1, w.x, d, 1, w.x, d, 0.5f, 0, M, d, I, 0, 0, st));
@@ -304,10 +318,23 @@ extern "C" int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weigh
             RUN(mi_gemm_bf16(w.h, I, Lw(l, FF2_W2), I, Lf(l, FF2_B2), 1, w.x, d, 1, w.x, d, 0.5f, 0, M, d, I, 0, 0, st));
         }
         // final_layer_norm (:312) chained with the next consumer's LayerNorm(s)
-        if (l + 1 == c.L)
+        if (l + 1 == c.L) {
+            float* lh = (last_hidden || !(c.layer_mixing || c.extra_layers)) ? last_hidden : w.lh;     // the head below needs the fp32 rows even when the caller does not
             RUN(mi_layernorm_chain(w.x, d, nullptr, T2, Lf(l, FIN_LN_G), Lf(l, FIN_LN_B), leps, nullptr, 0,
-                                   Gf(G_ENC_LN_G), Gf(G_ENC_LN_B), c.ln_eps, w.hid, d, last_hidden, d, nullptr, nullptr, nullptr, 0, M, d, st));
-        else if (c.use_macaron)
+                                   Gf(G_ENC_LN_G), Gf(G_ENC_LN_B), c.ln_eps, w.hid, d, lh, d, nullptr, nullptr, nullptr, 0, M, d, st));
+            if (c.layer_mixing || c.extra_layers) {       // the CTC fine-tuning head of a BEST-RQ encoder (bestrq.py:229-279)
+                const float* top = lh;
+                if (c.layer_mixing) {
+                    RUN(mi_axpy_dev_f32(w.mixed, lh, (long)M * d, w.sw + c.L, 0, st));
+                    top = w.mixed;
+                }
+                if (c.extra_layers) RUN(enter_layer(top, c.L));
+                else RUN(mi_add2_cast_bf16(top, d, nullptr, 0, w.hid, d, M, d, 1.f, st));
+            }
+        } else if (l + 1 == Lt) {                         // end of the additional layer: its final_layer_norm feeds the head directly
+            RUN(mi_layernorm_chain(w.x, d, nullptr, T2, nullptr, nullptr, 0.f, nullptr, 0, Lf(l, FIN_LN_G), Lf(l, FIN_LN_B), leps,
+                                   w.hid, d, nullptr, 0, nullptr, nullptr, nullptr, 0, M, d, st));
+        } else if (c.use_macaron)
             RUN(mi_layernorm_chain(w.x, d, nullptr, T2, Lf(l, FIN_LN_G), Lf(l, FIN_LN_B), leps, w.x, d,
                                    Lf(l + 1, FF1_LN_G), Lf(l + 1, FF1_LN_B), leps, w.a0, d, nullptr, 0, nullptr, nullptr, nullptr, 0, M, d, st));
         else

@@ -20,7 +20,7 @@ from . import _lib
 from .shapes import conv_freq_out
 
 G = dict(CONV1_W=0, CONV1_B=1, CONV2_W=2, CONV2_B=3, FEOUT_W=4, FEOUT_B=5, FP_LN_G=6, FP_LN_B=7, FP_W=8, FP_B=9,
-         ENC_LN_G=10, ENC_LN_B=11, HEAD_W=12, HEAD_B=13)
+         ENC_LN_G=10, ENC_LN_B=11, HEAD_W=12, HEAD_B=13, MIX_W=14)
 LS = {n: i for i, n in enumerate(
     ["FF1_LN_G", "FF1_LN_B", "FF1_W1", "FF1_B1", "FF1_W2", "FF1_B2",
      "ATT_LN_G", "ATT_LN_B", "ATT_WQK", "ATT_BQK", "ATT_WV", "ATT_BV", "ATT_WO", "ATT_BO", "ATT_WPOS", "ATT_U", "ATT_V",
@@ -67,9 +67,9 @@ class EBranchformerEngine:
         # Off by default: two kernels of different streams sharing a CU is what DESIGN.md 'Concurrent kernels' is about.
         self.branch_overlap = os.environ.get("HFASR_BRANCH_OVERLAP", "0") == "1"
         c = self.cfg
-        if c.get("finetune_with_additional_layer", False) or c.get("finetune_with_layer_mixing", False):
-            raise NotImplementedError("the single-call forward engine has no layer mixing / additional layer: BestRQEBranchformerForCTC runs these "
-                                      "through the per-op path (train.EncoderCTCTrainer.forward_backward(backward=False))")
+        # CTC fine-tuning head of a BEST-RQ encoder (bestrq.py:239-274): weighted mix of all hidden states and / or one more layer before the head
+        self.extra = int(bool(c.get("finetune_with_additional_layer", False)))
+        self.mix = int(bool(c.get("finetune_with_layer_mixing", False)))
         if len(c["conv_dim"]) != 2 or len(set(c["conv_kernel"])) != 1 or len(set(c["conv_stride"])) != 1 or len(set(c["conv_padding"])) != 1:
             raise NotImplementedError("HIP path supports the 2-layer Conv2d sub-sampling with equal kernel/stride/padding")
         if c.get("csgu_use_linear_after_conv", False):
@@ -97,7 +97,7 @@ class EBranchformerEngine:
         F2 = conv_freq_out(c.get("num_fbanks", 80), c["conv_kernel"], c["conv_stride"], c["conv_padding"])
         fe = "wav2vec2.feature_extractor."
         cw = "" if c.get("is_causal", False) else ".conv"
-        slots = [None] * (_lib.GLOBAL_SLOTS + L * _lib.LAYER_SLOTS)
+        slots = [None] * (_lib.GLOBAL_SLOTS + (L + self.extra) * _lib.LAYER_SLOTS)
         keep = []
 
         def put(idx, t):
@@ -116,9 +116,11 @@ class EBranchformerEngine:
         put(G["ENC_LN_G"], f32(sd["wav2vec2.encoder.layer_norm.weight"])); put(G["ENC_LN_B"], f32(sd["wav2vec2.encoder.layer_norm.bias"]))
         put(G["HEAD_W"], bf(torch.cat([sd["lm_head.weight"].detach().to(dev), sd["blank_projection.weight"].detach().to(dev)], 0)))
         put(G["HEAD_B"], f32(torch.cat([sd["lm_head.bias"].detach().to(dev), sd["blank_projection.bias"].detach().to(dev)], 0)))
+        if self.mix:
+            put(G["MIX_W"], f32(sd["per_layer_weights"]))
         rel = c.get("position_embeddings_type", "relative") == "relative"
-        for l in range(L):
-            p = f"wav2vec2.encoder.layers.{l}."
+        for l in range(L + self.extra):
+            p = f"wav2vec2.encoder.layers.{l}." if l < L else "additional_layer."
             base = _lib.GLOBAL_SLOTS + l * _lib.LAYER_SLOTS
             lp = lambda name, t: put(base + LS[name], t)
             if c.get("use_macaron_ff", True):
@@ -197,7 +199,7 @@ class EBranchformerEngine:
                               csgu_act=ACT[c.get("csgu_activation", "identity")], use_macaron=int(c.get("use_macaron_ff", True)),
                               ln_eps=float(c.get("layer_norm_eps", 1e-5)), logits_f32=int(self.logits_dtype == torch.float32),
                               logits_ld=(c["vocab_size"] + 1 + 7) // 8 * 8,
-                              branch_overlap=int(self.branch_overlap and slot == 0))
+                              branch_overlap=int(self.branch_overlap and slot == 0), extra_layers=self.extra, layer_mixing=self.mix)
 
     def _workspace(self, cs, slot=0):
         key = (cs.B, cs.T, cs.F)
@@ -230,7 +232,7 @@ class EBranchformerEngine:
         posp, compute = None, 0
         if cs.pos_type == 1:
             if T2 not in self._posp:
-                self._posp = {T2: torch.empty((c["num_hidden_layers"], 2 * T2 - 1, d), dtype=torch.bfloat16, device=self.device)}
+                self._posp = {T2: torch.empty((c["num_hidden_layers"] + self.extra, 2 * T2 - 1, d), dtype=torch.bfloat16, device=self.device)}
                 self._posp_valid = {}
             posp = self._posp[T2]
             compute = 0 if self._posp_valid.get(T2) == self.weights_version else 1

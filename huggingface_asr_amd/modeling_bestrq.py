@@ -117,54 +117,22 @@ class BestRQEBranchformerForPreTraining(PreTrainedModel):
 
 
 class BestRQEBranchformerForCTC(Wav2Vec2EBranchformerForCTC):
-    """CTC fine-tuning head on a BEST-RQ pre-trained encoder (bestrq.py:192-322).  With the recipes' options
+    """CTC fine-tuning head on a BEST-RQ pre-trained encoder (bestrq.py:192-322), incl. the recipes' options
     (`finetune_with_layer_mixing`: softmax(per_layer_weights)-weighted sum of all hidden states, :239-245; `finetune_with_additional_layer`: one
-    more E-Branchformer layer `additional_layer.*` before the head, :247-274) the forward runs on the per-op HIP path (the trainer's
-    forward, which also serves eval) instead of the single-call engine; without them it is the parent class."""
+    more E-Branchformer layer `additional_layer.*` before the head, :247-274).  Both run inside the single-call forward engine (eval) and the
+    HIP trainer (train() + loss.backward()); this class only adds the parameters."""
     config_class = BestRQEBranchformerForPreTrainingConfig
 
     def __init__(self, config):
         super().__init__(config)
-        self._extra = bool(getattr(config, "finetune_with_additional_layer", False))
-        self._mix = bool(getattr(config, "finetune_with_layer_mixing", False))
-        if self._extra:
+        extra = bool(getattr(config, "finetune_with_additional_layer", False))
+        mix = bool(getattr(config, "finetune_with_layer_mixing", False))
+        if extra:
             from .modeling_ebranchformer import _Layer
             self.additional_layer = _Layer(config)
-        if self._mix:
+        if mix:
             w = torch.zeros(config.num_hidden_layers + 1)
             w[-1] = 1.0                                            # bestrq.py:203-205
             self.per_layer_weights = nn.Parameter(w)
-        if self._extra or self._mix:
-            self._trainer_key = None
+        if extra or mix:
             self.post_init()
-
-    def forward(self, input_values, attention_mask=None, output_attentions=None, output_hidden_states=None, return_dict=None, labels=None, **kwargs):
-        training = self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if not (self._extra or self._mix) or training:
-            return super().forward(input_values, attention_mask=attention_mask, output_attentions=output_attentions,
-                                   output_hidden_states=output_hidden_states, return_dict=return_dict, labels=labels, **kwargs)
-        return_dict = return_dict if return_dict is not None else getattr(self.config, "return_dict", True)
-        if output_attentions:
-            raise NotImplementedError("attention probabilities are never materialised by the fused HIP attention kernel")
-        if not input_values.is_cuda:
-            raise RuntimeError("BestRQEBranchformerForCTC (HIP): inputs must be on the GPU; there is no CPU fallback")
-        if labels is not None and labels.max() >= self.config.vocab_size:
-            raise ValueError(f"Label values must be <= vocab_size: {self.config.vocab_size}")
-        tr = self._get_trainer(input_values.device)
-        key = (sum(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()))
-        if self._trainer_key != key:
-            tr.load_state_dict(dict(self.state_dict()))
-            self._trainer_key = key
-        feat_len = attention_mask.sum(-1).to(torch.int32) if attention_mask is not None else None
-        out = tr.forward_backward(input_values, feat_len, labels.to(input_values.device) if labels is not None else None, backward=False,
-                                  keep_hidden=bool(output_hidden_states))
-        hidden_states = (out["last_hidden"],) if output_hidden_states else None
-        if not return_dict:
-            output = (out["logits"],) + ((hidden_states,) if hidden_states is not None else ())
-            return ((out["loss"],) + output) if out["loss"] is not None else output
-        from transformers.modeling_outputs import CausalLMOutput
-        return CausalLMOutput(loss=out["loss"], logits=out["logits"], hidden_states=hidden_states, attentions=None)
-
-    def _training_forward(self, *a, **k):
-        self._trainer_key = None              # the bridge reloads the trainer's store every step: the eval cache is stale afterwards
-        return super()._training_forward(*a, **k)

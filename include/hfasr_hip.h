@@ -276,6 +276,11 @@ typedef struct {
     int logits_ld;               /* row stride of the logits buffer in elements (0 = V+1); a multiple of 8 keeps the stores 16-B wide */
     int branch_overlap;          /* experimental, default 0: run each layer's local (cgMLP) branch on a library-owned side stream beside the
                                     attention branch (one forward in flight at a time); see DESIGN.md 'Concurrent kernels' before enabling */
+    /* CTC fine-tuning head of a BEST-RQ encoder — BestRQEBranchformerForCTC.forward, src/models/bestrq.py:239-274 */
+    int extra_layers;            /* 0 | 1: `finetune_with_additional_layer` — one more layer (weight-table layer index L) between the encoder's
+                                    final LayerNorm and the head: padded frames zeroed, same key mask and position table, no LayerNorm after it */
+    int layer_mixing;            /* `finetune_with_layer_mixing`: softmax(per_layer_weights, global slot 14)-weighted sum of the L+1 hidden states
+                                    (the input of every layer + the final LayerNorm's output) replaces the last hidden state */
 } mi_ebf_config;
 
 /* weight-table slot indices: see huggingface_asr_amd/engine.py (SLOTS) — the table is an array of device pointers. */
@@ -289,7 +294,8 @@ size_t mi_ebf_workspace_bytes(const mi_ebf_config* cfg);
  *       (it depends only on the weights and T2, so callers cache it across calls at inference);
  * workspace: mi_ebf_workspace_bytes(cfg) bytes, ZERO-INITIALISED ONCE by the caller (time padding of V^T);
  * outputs: last_hidden (B*T2, d) fp32 (nullable), logits (B*T2, V+1) fp32|bf16 (nullable),
- *          inner_len/outer_len (B) int32 (mask lengths / CTC input lengths, nullable). */
+ *          inner_len/outer_len (B) int32 (mask lengths / CTC input lengths, nullable).
+ * With cfg->extra_layers the weight table holds L+1 layers and posp (L+1, 2*T2-1, d); last_hidden stays the ENCODER's last hidden state. */
 int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weights, const float* feats, const int* feat_lengths,
                    const void* pos_table, void* posp, int compute_posp, void* workspace, size_t workspace_bytes,
                    float* last_hidden, void* logits, int* inner_len, int* outer_len, mi_stream_t stream);

@@ -86,6 +86,22 @@ def test_finetune_head_matches_reference_golden(name):
     valid = int(ev["outer_len"].min())
     dl = (ev["logits"].float().cpu() - torch.from_numpy(g["eval_logits"]))[:, :valid].abs()
     assert float(dl.max()) < 0.06 and float(dl.mean()) < 0.009, (float(dl.max()), float(dl.mean()))
+    # the single-call forward engine (mi_ebf_forward with extra_layers / layer_mixing): same bound against the reference, and it agrees
+    # with the per-op path to bf16 rounding; with and without the caller asking for the encoder's last hidden state
+    from huggingface_asr_amd import ops
+    from huggingface_asr_amd.engine import EBranchformerEngine
+    eng = EBranchformerEngine(cfg, DEV)
+    eng.load_state_dict(sd)
+    eo = eng.forward(x.to(DEV), am.sum(-1).to(torch.int32).to(DEV), want_hidden=True)
+    eo2 = eng.forward(x.to(DEV), am.sum(-1).to(torch.int32).to(DEV), want_hidden=False)
+    assert torch.equal(eo["logits"], eo2["logits"])
+    de = (eo["logits"].float().cpu() - torch.from_numpy(g["eval_logits"]))[:, :valid].abs()
+    assert float(de.max()) < 0.06 and float(de.mean()) < 0.009, (float(de.max()), float(de.mean()))
+    dt = (eo["logits"].float() - ev["logits"].float())[:, :valid].abs()
+    assert float(dt.max()) < 0.06 and float(dt.mean()) < 0.006, (float(dt.max()), float(dt.mean()))
+    el, _, _ = ops.ctc_loss(eo["logits"], lab.to(DEV), eo["outer_len"], reduction="mean", zero_infinity=True)
+    assert abs(float(el) - float(g["eval_loss"])) <= 1e-3 * abs(float(g["eval_loss"])) + 1e-3
+    assert float((eo["last_hidden"].reshape(-1, 64) - ev["last_hidden"].reshape(-1, 64)).abs().max()) < 0.1 if ev["last_hidden"] is not None else True
     tr.store.zero_grad()
     out = tr.forward_backward(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV))
     torch.cuda.synchronize()
