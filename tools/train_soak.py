@@ -1,5 +1,6 @@
 """Soak: 40 optimizer steps of the base encoder+CTC trainer WITH the recipes' randomness (dropout 0.1 everywhere, in-model SpecAugment) on a
-fixed synthetic batch: the loss must fall and stay finite, the gradient norm must stay finite (bf16 gradients, clip 1.0, AdamW 1e-3)."""
+fixed synthetic batch: the loss must fall and stay finite, the gradient norm must stay finite (bf16 gradients, clip 1.0, AdamW 1e-3).
+`--finetune`: the frozen fine-tuning recipes' head (layer mixing + additional layer, encoder layers frozen)."""
 import os, sys, json
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -9,9 +10,14 @@ dev = "cuda:0"
 cfg = dict(shapes.BASE, ctc_zero_infinity=True, ctc_loss_reduction="mean", hidden_dropout=0.1, activation_dropout=0.1, attention_dropout=0.1,
            final_dropout=0.1, feat_proj_dropout=0.0, csgu_conv_dropout=0.1, layerdrop=0.05, apply_spec_augment=True, mask_time_prob=0.05,
            mask_time_length=10, mask_time_min_masks=2)
+FT = "--finetune" in sys.argv
+if FT:
+    cfg.update(finetune_with_additional_layer=True, finetune_with_layer_mixing=True)
 sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()}
 tr = EncoderCTCTrainer(cfg, dev, lr=1e-3, weight_decay=1e-6, seed=3)
 tr.load_state_dict(sd)
+if FT:
+    tr.set_frozen({k for k in sd if k.startswith("wav2vec2.encoder.")})
 B, T = 16, 600
 feats = torch.from_numpy(synth.normal(5, "feats", (B, T, 80), 1.0)).to(dev)
 lens = torch.full((B,), T, dtype=torch.int32, device=dev)
@@ -23,6 +29,8 @@ for step in range(40):
     hist.append((float(o["loss"]), float(o["grad_norm"])))
     if step % 5 == 0:
         print(step, hist[-1], flush=True)
-ok = all(np.isfinite(h).all() for h in hist) and hist[-1][0] < 0.5 * hist[0][0]
+ok = all(np.isfinite(h).all() for h in hist) and hist[-1][0] < (0.8 if FT else 0.5) * hist[0][0]
+if FT:
+    print("mix weights", [round(v, 4) for v in tr.state_dict()["per_layer_weights"].tolist()])
 print(json.dumps({"first": hist[0], "last": hist[-1], "ok": bool(ok), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}))
 sys.exit(0 if ok else 1)
