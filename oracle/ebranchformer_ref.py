@@ -288,7 +288,8 @@ def finetune_hidden(sd: dict, cfg: dict, feats: torch.Tensor, attention_mask: Op
             x = x * mask[..., None]                                                      # bestrq.py:260
             am = (1.0 - mask[:, None, None, :].float()) * torch.finfo(torch.float32).min
             add_mask = am.expand(-1, 1, t, -1)
-        x = encoder_layer(sd, cfg["num_hidden_layers"], cfg, x, add_mask, pos, q, dm, pre="additional_layer.")
+        # dropout-hook layer id: num_hidden_layers names the global sites, so the additional layer takes num_hidden_layers + 1
+        x = encoder_layer(sd, cfg["num_hidden_layers"] + 1, cfg, x, add_mask, pos, q, dm, pre="additional_layer.")
     return x
 
 

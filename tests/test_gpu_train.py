@@ -447,6 +447,39 @@ def test_dropout_training_step_matches_oracle_with_identical_masks(pos):
     assert abs(float(ev["loss"]) - float(want_eval)) <= 2e-3 * float(want_eval)
 
 
+def test_dropout_finetune_head_matches_oracle_with_identical_masks():
+    """the fine-tuning head in training mode: every dropout site of the additional layer (its own stream ids, layer L + 1), the head dropout on
+    the mixed states, and LayerDrop of an encoder layer whose input still enters the mix — loss and all gradients vs autograd of the oracle."""
+    from helpers import seeded_state_dict, synth_feats, synth_labels
+    cfg = dict(shapes.TINY, ctc_zero_infinity=True, ctc_loss_reduction="mean", finetune_with_additional_layer=True, finetune_with_layer_mixing=True)
+    sd = seeded_state_dict(cfg, 43)
+    x, am = synth_feats(43, 2, 200, [200, 157])
+    lab = synth_labels(43, 2, 6, 50, [6, 5])
+    from huggingface_asr_amd.train import EncoderCTCTrainer
+    tr = EncoderCTCTrainer(dict(cfg, layerdrop=0.0, apply_spec_augment=False, **DROP), DEV, seed=77)
+    tr.load_state_dict(sd)
+    L = cfg["num_hidden_layers"]
+    base = _enc_pmap(L)
+    pmap = lambda layer, site: base(0, site) if layer == L + 1 else base(layer, site)
+    for step, skip in ((0, ()), (1, (1,))):
+        dm = _dm(77, step, pmap)
+        sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        hidden = R.finetune_hidden(sdr, cfg, x, am, dm=dm, skip_layers=skip)
+        logits = R.ctc_head(sdr, hidden, None, dm, L)
+        in_len = R.conv_out_lengths_outer(am.sum(-1), cfg).long()
+        loss = F.ctc_loss(torch.log_softmax(logits, -1).transpose(0, 1), lab[lab >= 0], in_len, (lab >= 0).sum(-1), blank=logits.shape[-1] - 1,
+                          reduction="mean", zero_infinity=True)
+        loss.backward()
+        ref = {k: v.grad for k, v in sdr.items() if v.grad is not None}
+        tr.store.zero_grad()
+        out = tr.forward_backward(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV), skip_layers=list(skip))
+        assert abs(float(out["loss"]) - float(loss)) <= 2e-3 * float(loss), (step, float(out["loss"]), float(loss))
+        grads = tr.grad_dict()
+        if skip:                       # the dropped layer has no gradient in the oracle; ours stays zero
+            assert all(float(grads[k].abs().max()) == 0.0 for k in grads if k.startswith("wav2vec2.encoder.layers.1."))
+        _compare(grads, ref, rel=0.04)
+
+
 def test_dropout_joint_training_step_matches_oracle_with_identical_masks():
     from helpers import AED_JCFG, TINY_DEC, aed_case_inputs
     from huggingface_asr_amd.train_aed import JointAEDTrainer
