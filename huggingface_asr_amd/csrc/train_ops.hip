@@ -173,23 +173,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
     }
     const float inv_d = 1.f / d;
     const long wave_id = (long)blockIdx.x * 4 + wave, nwaves = (long)gridDim.x * 4;
-    for (int i = 0; i < rows_per_wave; ++i) {
-        const long r = wave_id + (long)i * nwaves;          // interleaved rows: neighbouring waves touch neighbouring rows
-        if (r >= M) break;
-        f32x4 xv[NV], gv[NV];
-        float s = 0.f;
+    // A wave walks its rows (wave_id, wave_id + nwaves, ...) two at a time: the reads of both rows — x, dy and, when accumulating, the old dx —
+    // are issued before either row is reduced, so the second row's memory round trip hides behind the first row's arithmetic.
+    auto load_row = [&](long r, f32x4 (&xv)[NV], f32x4 (&gv)[NV], f32x4 (&ov)[NV]) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int c = lane + 64 * j;
-            f32x4 v = z4, g = z4;
+            f32x4 v = z4, g = z4, o = z4;
             if (c < d4) {
                 if (x_bf16) { const bf16x4 t = reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(x) + r * ldx)[c]; v = f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])}; }
                 else v = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + r * ldx)[c];
                 if (dy_f32) g = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dy) + r * lddy)[c];
                 else { const bf16x4 t = reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(dy) + r * lddy)[c]; g = f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])}; }
+                if (accumulate) {
+                    if (dx_bf16) { const bf16x4 t = reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(dx) + r * lddx)[c]; o = f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])}; }
+                    else o = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dx) + r * lddx)[c];
+                }
             }
-            xv[j] = v; gv[j] = g; s += v.x + v.y + v.z + v.w;
+            xv[j] = v; gv[j] = g; ov[j] = o;
         }
+    };
+    auto do_row = [&](long r, f32x4 (&xv)[NV], f32x4 (&gv)[NV], f32x4 (&ov)[NV]) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) s += xv[j].x + xv[j].y + xv[j].z + xv[j].w;
         const float mean = wave_sum(s) * inv_d;
         float q = 0.f;
 #pragma unroll
@@ -214,17 +221,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
         for (int j = 0; j < NV; ++j) {
             const int c = lane + 64 * j;
             if (c >= d4) continue;
-            f32x4 v = (gv[j] - s1 - xv[j] * s2) * rstd;
-            if (dx_bf16) {
-                bf16x4* p = reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(dx) + r * lddx) + c;
-                if (accumulate) { const bf16x4 t = *p; v += f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])}; }
-                *p = bf16x4{f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
-            } else {
-                f32x4* p = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(dx) + r * lddx) + c;
-                if (accumulate) v += *p;
-                *p = v;
-            }
+            const f32x4 v = (gv[j] - s1 - xv[j] * s2) * rstd + ov[j];            // ov = 0 unless accumulating
+            if (dx_bf16) reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(dx) + r * lddx)[c] = bf16x4{f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+            else reinterpret_cast<f32x4*>(reinterpret_cast<float*>(dx) + r * lddx)[c] = v;
         }
+    };
+    for (int i = 0; i < rows_per_wave; i += 2) {
+        const long r0 = wave_id + (long)i * nwaves, r1 = r0 + nwaves;          // interleaved rows: neighbouring waves touch neighbouring rows
+        if (r0 >= M) break;
+        const bool two = (i + 1 < rows_per_wave) && r1 < M;
+        f32x4 xa[NV], ga[NV], oa[NV], xb[NV], gb[NV], ob[NV];
+        load_row(r0, xa, ga, oa);
+        if (two) load_row(r1, xb, gb, ob);
+        do_row(r0, xa, ga, oa);
+        if (two) do_row(r1, xb, gb, ob);
     }
     if (dgamma) {
 #pragma unroll
