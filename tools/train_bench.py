@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", default="base"); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3); ap.add_argument("--pos", default="relative"); ap.add_argument("--frames", type=int, default=1000)
 ap.add_argument("--fwd-only", action="store_true")
+ap.add_argument("--dropout", type=float, default=0.0, help="the recipes train with 0.1 at every dropout site (hidden, activation, attention, CSGU, final)")
 ap.add_argument("--finetune", action="store_true", help="the frozen fine-tuning recipes' setting (recipes/librispeech/ssl/*/lumi/finetune_frozen*.sh): layer mixing + "
                                                         "additional layer before the CTC head, encoder layers frozen")
 ap.add_argument("--model", default="ctc", choices=["ctc", "aed"], help="aed = BASELINE config 3: small encoder + 6x256 GPT-2 decoder, ctc_weight 0.3, lsm 0.1, "
@@ -23,8 +24,8 @@ world, rank, local = PL.env_world()
 dev = torch.device("cuda", local); torch.cuda.set_device(dev)
 PL.init("nccl", dev)
 base = {"base": shapes.BASE, "small": shapes.SMALL, "tiny": shapes.TINY}[a.size]
-cfg = dict(base, position_embeddings_type=a.pos, ctc_zero_infinity=True, ctc_loss_reduction="mean", hidden_dropout=0.0, activation_dropout=0.0,
-           attention_dropout=0.0, final_dropout=0.0, feat_proj_dropout=0.0, csgu_conv_dropout=0.0, layerdrop=0.0, apply_spec_augment=False,
+cfg = dict(base, position_embeddings_type=a.pos, ctc_zero_infinity=True, ctc_loss_reduction="mean", hidden_dropout=a.dropout, activation_dropout=a.dropout,
+           attention_dropout=a.dropout, final_dropout=a.dropout, feat_proj_dropout=0.0, csgu_conv_dropout=a.dropout, layerdrop=0.0, apply_spec_augment=False,
            finetune_with_additional_layer=a.finetune, finetune_with_layer_mixing=a.finetune)
 sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()}
 B, T = a.batch, a.frames
