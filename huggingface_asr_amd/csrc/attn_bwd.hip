@@ -22,19 +22,10 @@ struct SmArgs {
     bf16_t* prob_drop;                    // fwd: dropped probabilities for the PV product (null when drop_p == 0)
 };
 
-__device__ __forceinline__ unsigned long long sm_splitmix64(unsigned long long x) {
-    x += 0x9E3779B97F4A7C15ull;
-    unsigned long long z = x;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
 // logical index of P[h][b][i][j] = ((h*B + b)*Tq + i)*Tk + j  (independent of the padded row stride)
 __device__ __forceinline__ float sm_keep(const SmArgs& p, long row, int j) {
     const unsigned long long idx = (unsigned long long)row * (unsigned long long)p.Tk + (unsigned long long)j;
-    const unsigned long long h = sm_splitmix64(sm_splitmix64(idx ^ p.drop_key) + p.drop_key);
-    const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
-    return u >= p.drop_p ? 1.f / (1.f - p.drop_p) : 0.f;
+    return mask_u01_at(p.drop_key, idx) >= p.drop_p ? 1.f / (1.f - p.drop_p) : 0.f;
 }
 
 __device__ __forceinline__ bool key_masked(const SmArgs& p, int b, int i, int j) {

@@ -99,3 +99,18 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Counter-based uniform draws of the dropout masks (dropout.hip, attn_bwd.hip; host twin: huggingface_asr_amd/synth.py `dropout_keep`):
+// one splitmix64 round over (pair index ^ key) yields TWO 24-bit draws — element idx takes bits 63..40 when even, bits 39..16 when odd —
+// so a mask costs one 64-bit hash per two elements (the hash, quarter-rate integer multiplies, is what bounds the mask kernels).
+__device__ __forceinline__ unsigned long long mask_hash(unsigned long long key, unsigned long long pair) {
+    unsigned long long z = (pair ^ key) + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float mask_u01(unsigned long long h, int odd) {
+    return (float)(odd ? (unsigned)(h >> 16) & 0xFFFFFFu : (unsigned)(h >> 40)) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float mask_u01_at(unsigned long long key, unsigned long long idx) { return mask_u01(mask_hash(key, idx >> 1), (int)(idx & 1)); }
+

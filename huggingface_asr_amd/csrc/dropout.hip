@@ -3,24 +3,15 @@
 // Reference: torch.nn.Dropout at the points the reference applies it in train() mode (e_branchformer.py:132,203,288,301,451;
 // tf wav2vec2_conformer FFN :353,356, encoder input :674; GPT-2 embd / attn / resid dropouts).  torch's Philox stream cannot be
 // reproduced, so the mask is DEFINED here as a pure function of (seed, stream, logical element index):
-//     keep(idx) = (splitmix64(splitmix64(idx ^ key) + key) >> 40) * 2^-24 >= p,      key = (stream << 32) ^ seed
+//     keep(idx) = u24(idx) * 2^-24 >= p,   u24 = bits 63..40 (idx even) or 39..16 (idx odd) of splitmix64((idx >> 1) ^ key),   key = (stream << 32) ^ seed
 // the same hash as huggingface_asr_amd/synth.py (`dropout_keep`), so the CPU oracle is run with the identical masks in the parity
 // tests and the backward pass regenerates the mask instead of storing it.   out = x * keep / (1 - p).
 #include "common.hpp"
 
 namespace {
 
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
-    x += 0x9E3779B97F4A7C15ull;
-    unsigned long long z = x;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
 __device__ __forceinline__ float keep_scale(unsigned long long key, unsigned long long idx, float p, float inv_keep) {
-    const unsigned long long h = splitmix64(splitmix64(idx ^ key) + key);
-    const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
-    return u >= p ? inv_keep : 0.f;
+    return mask_u01_at(key, idx) >= p ? inv_keep : 0.f;
 }
 
 // element (m, n) of an (M, N) matrix has logical index m * N + n whatever the leading dimensions are
@@ -56,9 +47,13 @@ __global__ __launch_bounds__(256) void dropout_vec8_kernel(const TI* __restrict_
             const f32x4 a = *reinterpret_cast<const f32x4*>(x + (long)m * ldx + c), b = *reinterpret_cast<const f32x4*>(x + (long)m * ldx + c + 4);
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
         }
-        const unsigned long long base = (unsigned long long)i << 3;
+        const unsigned long long pair0 = (unsigned long long)i << 2;              // 8 elements = 4 hashes
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * alpha * keep_scale(key, base + e, p, inv_keep);
+        for (int e = 0; e < 4; ++e) {
+            const unsigned long long h = mask_hash(key, pair0 + e);
+            v[2 * e] = v[2 * e] * alpha * (mask_u01(h, 0) >= p ? inv_keep : 0.f);
+            v[2 * e + 1] = v[2 * e + 1] * alpha * (mask_u01(h, 1) >= p ? inv_keep : 0.f);
+        }
         if constexpr (sizeof(TO) == 2) {
             bf16x8 o;
 #pragma unroll
@@ -79,12 +74,12 @@ __global__ __launch_bounds__(256) void dropout_add_vec4_kernel(float* __restrict
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total4; i += gridDim.x * 256u) {
         const unsigned m = i / n4, c = (i - m * n4) << 2;
         const f32x4 r = *reinterpret_cast<const f32x4*>(resid + (long)m * ldr + c), tv = *reinterpret_cast<const f32x4*>(t + (long)m * ldt + c);
-        const unsigned long long base = (unsigned long long)i << 2;
+        const unsigned long long h0 = mask_hash(key, (unsigned long long)i << 1), h1 = mask_hash(key, ((unsigned long long)i << 1) + 1);
         f32x4 o;
-        o.x = r.x + alpha * tv.x * keep_scale(key, base, p, inv_keep);
-        o.y = r.y + alpha * tv.y * keep_scale(key, base + 1, p, inv_keep);
-        o.z = r.z + alpha * tv.z * keep_scale(key, base + 2, p, inv_keep);
-        o.w = r.w + alpha * tv.w * keep_scale(key, base + 3, p, inv_keep);
+        o.x = r.x + alpha * tv.x * (mask_u01(h0, 0) >= p ? inv_keep : 0.f);
+        o.y = r.y + alpha * tv.y * (mask_u01(h0, 1) >= p ? inv_keep : 0.f);
+        o.z = r.z + alpha * tv.z * (mask_u01(h1, 0) >= p ? inv_keep : 0.f);
+        o.w = r.w + alpha * tv.w * (mask_u01(h1, 1) >= p ? inv_keep : 0.f);
         *reinterpret_cast<f32x4*>(y + (long)m * ldy + c) = o;
     }
 }

@@ -90,8 +90,9 @@ def dropout_keep(seed: int, stream_id: int, n: int, p: float) -> np.ndarray:
     key = np.uint64(((stream_id & 0xFFFFFFFF) << 32) ^ (seed & 0xFFFFFFFF))
     with np.errstate(over="ignore"):
         idx = np.arange(n, dtype=np.uint64)
-        h = _splitmix64(_splitmix64(idx ^ key) + key)
-    u = (h >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24))
+        h = _splitmix64((idx >> np.uint64(1)) ^ key)                # one hash per PAIR of elements: two 24-bit draws (csrc/common.hpp mask_hash / mask_u01)
+    u24 = np.where((idx & np.uint64(1)) == 0, h >> np.uint64(40), (h >> np.uint64(16)) & np.uint64(0xFFFFFF))
+    u = u24.astype(np.float32) * np.float32(1.0 / (1 << 24))
     return u >= np.float32(p)
 
 
