@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", default="base"); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3); ap.add_argument("--pos", default="relative"); ap.add_argument("--frames", type=int, default=1000)
 ap.add_argument("--fwd-only", action="store_true")
+ap.add_argument("--specaug", action="store_true", help="in-model SpecAugment as in the recipes (mask_time_prob 0.05, length 10, min 2 masks)")
 ap.add_argument("--dropout", type=float, default=0.0, help="the recipes train with 0.1 at every dropout site (hidden, activation, attention, CSGU, final)")
 ap.add_argument("--finetune", action="store_true", help="the frozen fine-tuning recipes' setting (recipes/librispeech/ssl/*/lumi/finetune_frozen*.sh): layer mixing + "
                                                         "additional layer before the CTC head, encoder layers frozen")
@@ -25,7 +26,8 @@ dev = torch.device("cuda", local); torch.cuda.set_device(dev)
 PL.init("nccl", dev)
 base = {"base": shapes.BASE, "small": shapes.SMALL, "tiny": shapes.TINY}[a.size]
 cfg = dict(base, position_embeddings_type=a.pos, ctc_zero_infinity=True, ctc_loss_reduction="mean", hidden_dropout=a.dropout, activation_dropout=a.dropout,
-           attention_dropout=a.dropout, final_dropout=a.dropout, feat_proj_dropout=0.0, csgu_conv_dropout=a.dropout, layerdrop=0.0, apply_spec_augment=False,
+           attention_dropout=a.dropout, final_dropout=a.dropout, feat_proj_dropout=0.0, csgu_conv_dropout=a.dropout, layerdrop=0.0, apply_spec_augment=a.specaug,
+           mask_time_prob=0.05, mask_time_length=10, mask_time_min_masks=2,
            finetune_with_additional_layer=a.finetune, finetune_with_layer_mixing=a.finetune)
 sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()}
 B, T = a.batch, a.frames
