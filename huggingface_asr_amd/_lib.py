@@ -59,6 +59,8 @@ SIGNATURES = {
     "mi_colsum": [vp, i64, i32, i32, i32, vp, vp],
     "mi_act_fwd_bf16": [vp, i64, vp, i64, i32, i32, i32, vp],
     "mi_act_bwd_bf16": [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp],
+    "mi_act_dropout_fwd_bf16": [vp, i64, vp, i64, i32, i32, i32, f32, C.c_uint, C.c_uint, vp],
+    "mi_act_dropout_bwd_bf16": [vp, i64, vp, i64, vp, i64, i32, i32, i32, f32, C.c_uint, C.c_uint, vp],
     "mi_layernorm_bwd_workspace_floats": [i32],
     "mi_layernorm_bwd": [vp, i64, i32, vp, f32, vp, i64, i32, vp, i64, i32, i32, vp, vp, vp, i32, i32, vp],
     "mi_ln_apply_bf16": [vp, i64, vp, vp, vp, vp, i64, i32, i32, vp],

@@ -121,23 +121,40 @@ __device__ __forceinline__ float gelu_tanh_grad(float x) {
 }
 
 // MODE 0: out = act(a);  MODE 1: out = a * act'(b)   (a = dy, b = pre-activation);  kind 1 erf-GELU, 2 tanh-GELU
-template <int MODE>
+// DROP: the activation dropout of the FFN (tf wav2vec2_conformer :353) applied in the same pass — forward out = dropout(act(a)), backward
+// out = dropout(a) * act'(b) — with the mask of dropout.hip for logical index m * N + n and the same bf16 rounding points as the two-pass form
+// (act / dropout each rounded to bf16), so results are bit-identical to running mi_dropout separately.
+template <int MODE, bool DROP>
 __global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ a, long lda, const bf16_t* __restrict__ b, long ldb,
-                                                   bf16_t* __restrict__ out, long ldo, int M, int N8, int kind) {
+                                                   bf16_t* __restrict__ out, long ldo, int M, int N8, int kind, float p, unsigned long long key) {
     const long total = (long)M * N8;
+    const float inv_keep = DROP ? 1.f / (1.f - p) : 1.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int m = (int)(i / N8), c = (int)(i % N8) * 8;
         const bf16x8 va = *reinterpret_cast<const bf16x8*>(a + (long)m * lda + c);
         bf16x8 vb = va, o;
         if (MODE == 1) vb = *reinterpret_cast<const bf16x8*>(b + (long)m * ldb + c);
+        float ks[8];
+        if (DROP) {
+            const unsigned long long pair0 = (unsigned long long)i << 2;          // logical index of the first element = 8 i (rows are N = 8 N8 long)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned long long h = mask_hash(key, pair0 + e);
+                ks[2 * e] = mask_u01(h, 0) >= p ? inv_keep : 0.f;
+                ks[2 * e + 1] = mask_u01(h, 1) >= p ? inv_keep : 0.f;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (MODE == 0) {
                 const float x = bf2f(va[j]);
-                o[j] = f2bf(kind == 1 ? gelu_erf(x) : gelu_tanh(x));
+                bf16_t r = f2bf(kind == 1 ? gelu_erf(x) : gelu_tanh(x));
+                if (DROP) r = f2bf(bf2f(r) * ks[j]);
+                o[j] = r;
             } else {
                 const float x = bf2f(vb[j]);
-                o[j] = f2bf(bf2f(va[j]) * (kind == 1 ? gelu_erf_grad(x) : gelu_tanh_grad(x)));
+                const float g = DROP ? bf2f(f2bf(bf2f(va[j]) * ks[j])) : bf2f(va[j]);
+                o[j] = f2bf(g * (kind == 1 ? gelu_erf_grad(x) : gelu_tanh_grad(x)));
             }
         }
         *reinterpret_cast<bf16x8*>(out + (long)m * ldo + c) = o;
@@ -533,14 +550,33 @@ extern "C" int mi_colsum(const void* x, long ld, int dtype, int M, int N, float*
 extern "C" int mi_act_fwd_bf16(const void* pre, long ldp, void* out, long ldo, int M, int N, int kind, hipStream_t st) {
     MI_ENTER();
     if (M <= 0 || N <= 0 || (N % 8) || (ldp % 8) || (ldo % 8) || (kind != 1 && kind != 2)) return MI_ERR_ARG;
-    hipLaunchKernelGGL(act_kernel<0>, dim3(grid_for((long)M * N / 8)), dim3(256), 0, st, (const bf16_t*)pre, ldp, (const bf16_t*)nullptr, 0L, (bf16_t*)out, ldo, M, N / 8, kind);
+    hipLaunchKernelGGL((act_kernel<0, false>), dim3(grid_for((long)M * N / 8)), dim3(256), 0, st, (const bf16_t*)pre, ldp, (const bf16_t*)nullptr, 0L, (bf16_t*)out, ldo, M, N / 8, kind, 0.f, 0ull);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+// out = dropout(act(pre)) / dx = dropout(dy) * act'(pre): activation + the FFN's activation dropout in one pass (mask of mi_dropout for the (M, N) matrix)
+extern "C" int mi_act_dropout_fwd_bf16(const void* pre, long ldp, void* out, long ldo, int M, int N, int kind, float p, unsigned seed, unsigned stream_id,
+                                       hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || N <= 0 || (N % 8) || (ldp % 8) || (ldo % 8) || (kind != 1 && kind != 2) || p < 0.f || p >= 1.f) return MI_ERR_ARG;
+    const unsigned long long key = ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed;
+    hipLaunchKernelGGL((act_kernel<0, true>), dim3(grid_for((long)M * N / 8)), dim3(256), 0, st, (const bf16_t*)pre, ldp, (const bf16_t*)nullptr, 0L, (bf16_t*)out, ldo, M, N / 8, kind, p, key);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+extern "C" int mi_act_dropout_bwd_bf16(const void* dy, long lddy, const void* pre, long ldp, void* dx, long lddx, int M, int N, int kind, float p,
+                                       unsigned seed, unsigned stream_id, hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || N <= 0 || (N % 8) || (ldp % 8) || (lddy % 8) || (lddx % 8) || (kind != 1 && kind != 2) || p < 0.f || p >= 1.f) return MI_ERR_ARG;
+    const unsigned long long key = ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed;
+    hipLaunchKernelGGL((act_kernel<1, true>), dim3(grid_for((long)M * N / 8)), dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)pre, ldp, (bf16_t*)dx, lddx, M, N / 8, kind, p, key);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
 extern "C" int mi_act_bwd_bf16(const void* dy, long lddy, const void* pre, long ldp, void* dx, long lddx, int M, int N, int kind, hipStream_t st) {
     MI_ENTER();
     if (M <= 0 || N <= 0 || (N % 8) || (ldp % 8) || (lddy % 8) || (lddx % 8) || (kind != 1 && kind != 2)) return MI_ERR_ARG;
-    hipLaunchKernelGGL(act_kernel<1>, dim3(grid_for((long)M * N / 8)), dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)pre, ldp, (bf16_t*)dx, lddx, M, N / 8, kind);
+    hipLaunchKernelGGL((act_kernel<1, false>), dim3(grid_for((long)M * N / 8)), dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)pre, ldp, (bf16_t*)dx, lddx, M, N / 8, kind, 0.f, 0ull);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

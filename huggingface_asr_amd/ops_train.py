@@ -54,18 +54,30 @@ def colsum_(out, x):
 KIND = {"gelu": 1, "gelu_new": 2}
 
 
-def act_fwd(pre, kind="gelu", out=None):
+def act_fwd(pre, kind="gelu", out=None, drop=None):
+    """out = act(pre); with drop = (p, seed, stream_id): out = dropout(act(pre)) in the same pass (bit-identical to act_fwd + dropout_)."""
     M, N = pre.shape
     if out is None:
         out = torch.empty((M, N), device=pre.device, dtype=BF16)
+    if drop is not None:
+        p, seed, sid = drop
+        _lib.check(_L().mi_act_dropout_fwd_bf16(pre.data_ptr(), pre.stride(0), out.data_ptr(), out.stride(0), M, N, KIND[kind], float(p),
+                                                int(seed) & 0xFFFFFFFF, int(sid) & 0xFFFFFFFF, _stream()), "mi_act_dropout_fwd_bf16")
+        return out
     _lib.check(_L().mi_act_fwd_bf16(pre.data_ptr(), pre.stride(0), out.data_ptr(), out.stride(0), M, N, KIND[kind], _stream()), "mi_act_fwd_bf16")
     return out
 
 
-def act_bwd(dy, pre, kind="gelu", out=None):
+def act_bwd(dy, pre, kind="gelu", out=None, drop=None):
+    """out = dy * act'(pre); with drop = (p, seed, stream_id): out = dropout(dy) * act'(pre) (the backward of act_fwd(..., drop=...))."""
     M, N = pre.shape
     if out is None:
         out = torch.empty((M, N), device=pre.device, dtype=BF16)
+    if drop is not None:
+        p, seed, sid = drop
+        _lib.check(_L().mi_act_dropout_bwd_bf16(dy.data_ptr(), dy.stride(0), pre.data_ptr(), pre.stride(0), out.data_ptr(), out.stride(0), M, N,
+                                                KIND[kind], float(p), int(seed) & 0xFFFFFFFF, int(sid) & 0xFFFFFFFF, _stream()), "mi_act_dropout_bwd_bf16")
+        return out
     _lib.check(_L().mi_act_bwd_bf16(dy.data_ptr(), dy.stride(0), pre.data_ptr(), pre.stride(0), out.data_ptr(), out.stride(0), M, N,
                                     KIND[kind], _stream()), "mi_act_bwd_bf16")
     return out

@@ -767,9 +767,7 @@ class EncoderCTCTrainer:
         a = e16(M, d)
         LN(x, lna=(P(pre + "_ln_g"), P(pre + "_ln_b")), outa=a)
         hp = ops.gemm(a, W(pre + "_w1"), P(pre + "_b1"))
-        h = T.act_fwd(hp)
-        if pd["act"] > 0:
-            T.dropout_(h, pd["act"], self.seed, self._sid(l, sites[0]))
+        h = T.act_fwd(hp, drop=(pd["act"], self.seed, self._sid(l, sites[0])) if pd["act"] > 0 else None)      # GELU + activation dropout in one pass
         if pd["hidden"] > 0:
             y = T.dropout_add(x, ops.gemm(h, W(pre + "_w2"), P(pre + "_b2"), out_dtype=F32), 0.5, pd["hidden"], self.seed, self._sid(l, sites[1]))
         else:
@@ -785,9 +783,7 @@ class EncoderCTCTrainer:
         else:
             dyb = T.add_cast(dx, alpha=0.5)
         dh = T.linear_bwd(dyb, S["h"], WT(pre + "_w2"), dw=GL(pre + "_w2"), db=GL(pre + "_b2"))
-        if pd["act"] > 0:
-            T.dropout_(dh, pd["act"], self.seed, self._sid(l, sites[0]))
-        dhp = T.act_bwd(dh, S["hp"])
+        dhp = T.act_bwd(dh, S["hp"], drop=(pd["act"], self.seed, self._sid(l, sites[0])) if pd["act"] > 0 else None)
         da = T.linear_bwd(dhp, S["a"], WT(pre + "_w1"), dw=GL(pre + "_w1"), db=GL(pre + "_b1"))
         T.layernorm_bwd(x_in, P(pre + "_ln_g"), da, dx, accumulate=True, **self._lng(pre + "_ln_g", pre + "_ln_b"))
 

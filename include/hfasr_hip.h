@@ -148,6 +148,12 @@ int mi_colsum(const void* x, long ld, int dtype, int M, int N, float* out, mi_st
 int mi_act_fwd_bf16(const void* pre, long ldp, void* out, long ldo, int M, int N, int kind, mi_stream_t stream);
 int mi_act_bwd_bf16(const void* dy, long lddy, const void* pre, long ldp, void* dx, long lddx, int M, int N, int kind,
                     mi_stream_t stream);
+/* the same with the FFN's activation dropout (tf wav2vec2_conformer :353 `intermediate_dropout`) applied in the pass: out = dropout(act(pre)),
+ * dx = dropout(dy) * act'(pre); mask and rounding points of mi_dropout on the (M, N) matrix, i.e. bit-identical to the two-pass form. */
+int mi_act_dropout_fwd_bf16(const void* pre, long ldp, void* out, long ldo, int M, int N, int kind, float p, unsigned seed, unsigned stream_id,
+                            mi_stream_t stream);
+int mi_act_dropout_bwd_bf16(const void* dy, long lddy, const void* pre, long ldp, void* dx, long lddx, int M, int N, int kind, float p,
+                            unsigned seed, unsigned stream_id, mi_stream_t stream);
 size_t mi_layernorm_bwd_workspace_floats(int d);
 int mi_layernorm_bwd(const void* x, long ldx, int x_bf16, const float* gamma, float eps, const void* dy, long lddy, int dy_f32,
                      void* dx, long lddx, int dx_bf16, int accumulate, float* dgamma, float* dbeta, float* workspace, int M, int d,

@@ -378,3 +378,26 @@ def test_layer_mixing_ops_match_torch():
     b = torch.randn(n + 1, device=DEV)[1:]
     T.axpy_dev_(a, b.contiguous() if not b.is_contiguous() else b, s[0:1], overwrite=True)
     assert torch.allclose(a, b * s[0], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("kind", ["gelu", "gelu_new"])
+def test_activation_with_fused_dropout_is_bit_identical_to_two_passes(kind):
+    """mi_act_dropout_fwd/bwd_bf16 = activation + mi_dropout in one pass: same mask (logical index m*N + n), same bf16 rounding points"""
+    _, T = _o()
+    if kind not in T.KIND:
+        pytest.skip(kind)
+    M, N = 333, 256
+    pre = bfr(rnd(M, N + 8, seed=3)).to(BF).to(DEV)[:, :N]           # a row stride different from N: the mask must follow the logical index
+    dy = bfr(rnd(M, N, seed=4)).to(BF).to(DEV)
+    drop = (0.2, 99, 1234)
+    two = T.act_fwd(pre, kind)
+    T.dropout_(two, *drop)
+    one = T.act_fwd(pre, kind, drop=drop)
+    assert torch.equal(one, two)
+    kept = float((one != 0).float().mean())
+    assert 0.75 < kept < 0.85
+    d2 = dy.clone()
+    T.dropout_(d2, *drop)
+    two_b = T.act_bwd(d2, pre, kind)
+    one_b = T.act_bwd(dy, pre, kind, drop=drop)
+    assert torch.equal(one_b, two_b)
