@@ -91,6 +91,89 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(SmArgs p) {
     }
 }
 
+// Register forms for Tk <= 64 NR (the encoder's 250 frames: NR = 4): a row lives in the wave's registers, so scores are read once, exponentiated
+// once and a dropout keep factor is hashed once per element (the loops above read three times, exponentiate twice and — backward, with dropout —
+// hash three times).  Same arithmetic in the same order: results are bit-identical to the loop forms.
+template <int NR>
+__global__ __launch_bounds__(256) void softmax_fwd_reg_kernel(SmArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long rows = (long)p.H * p.B * p.Tq;
+    if (row >= rows) return;
+    const int i = (int)(row % p.Tq), b = (int)((row / p.Tq) % p.B);
+    const float* ac = p.ac + row * p.ld_s;
+    const float* bd = p.bd ? p.bd + row * p.ld_p + (p.Tq - 1 - i) : nullptr;
+    float v[NR];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int j = lane + 64 * r;
+        const bool ok = j < p.Tk && !key_masked(p, b, i, j);
+        v[r] = ok ? (ac[j] + (bd ? bd[j] : 0.f)) * p.scale : -INFINITY;
+        mx = fmaxf(mx, v[r]);
+    }
+    mx = wave_max(mx);
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        v[r] = v[r] > -INFINITY ? __expf(v[r] - mx) : 0.f;
+        s += v[r];
+    }
+    s = wave_sum(s);
+    const float inv = s > 0.f ? 1.f / s : 0.f;
+    bf16_t* out = p.prob + row * p.ld_s;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int j = lane + 64 * r;
+        if (j >= p.Tk) continue;
+        const float pv = v[r] * inv;
+        out[j] = f2bf(pv);
+        if (p.prob_drop) p.prob_drop[row * p.ld_s + j] = f2bf(pv * sm_keep(p, row, j));
+    }
+}
+template <int NR>
+__global__ __launch_bounds__(256) void softmax_bwd_reg_kernel(SmArgs p) {
+    __shared__ bf16_t srow[4][64 * NR];                   // a wave's dS row, re-read at the relative-position shift for dBD
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    const long rows = (long)p.H * p.B * p.Tq;
+    if (row >= rows) return;
+    const int i = (int)(row % p.Tq);
+    const bf16_t* pr = p.prob + row * p.ld_s;
+    const float* dp = p.dp + row * p.ld_s;
+    const bool dr = p.drop_p > 0.f;
+    float pv[NR], gv[NR];
+    float dot = 0.f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int j = lane + 64 * r;
+        pv[r] = 0.f; gv[r] = 0.f;
+        if (j < p.Tk) {
+            pv[r] = bf2f(pr[j]);
+            gv[r] = dp[j] * (dr ? sm_keep(p, row, j) : 1.f);
+            dot += pv[r] * gv[r];
+        }
+    }
+    dot = wave_sum(dot);
+    bf16_t* ds = p.ds + row * p.ld_s;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int j = lane + 64 * r;
+        const bf16_t o = f2bf(pv[r] * (gv[r] - dot) * p.scale);
+        srow[wave][j] = o;
+        if (j < p.Tk) ds[j] = o;
+    }
+    if (p.dbd) {
+        __builtin_amdgcn_wave_barrier();                  // LDS accesses of one wave complete in order: the row above is visible to the reads below
+        const int P = 2 * p.Tq - 1, off = p.Tq - 1 - i;
+        bf16_t* dbd = p.dbd + row * p.ld_p;
+        for (int q = lane; q < P; q += 64) {
+            const int j = q - off;
+            dbd[q] = (j >= 0 && j < p.Tk) ? srow[wave][j] : (bf16_t)0.f;
+        }
+    }
+}
+
 }  // namespace
 
 // ld_s: row stride of ac / prob / dp / ds (>= Tk); ld_p: row stride of bd / dbd (>= 2 Tq - 1).  Padding columns are never read.
@@ -102,7 +185,8 @@ extern "C" int mi_attn_softmax_fwd(const float* ac, const float* bd, const int* 
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !prob_drop)) return MI_ERR_ARG;
     SmArgs p{ac, bd, nullptr, (bf16_t*)prob, nullptr, nullptr, lengths, H, B, Tq, Tk, causal, ld_s, ld_p, scale, drop_p,
              ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed, drop_p > 0.f ? (bf16_t*)prob_drop : nullptr};
-    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv((long)H * B * Tq, 4)), dim3(256), 0, st, p);
+    if (Tk <= 256) hipLaunchKernelGGL(softmax_fwd_reg_kernel<4>, dim3(cdiv((long)H * B * Tq, 4)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv((long)H * B * Tq, 4)), dim3(256), 0, st, p);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
@@ -114,7 +198,8 @@ extern "C" int mi_attn_softmax_bwd(const void* prob, const float* dp, void* ds, 
     if (drop_p < 0.f || drop_p >= 1.f) return MI_ERR_ARG;
     SmArgs p{nullptr, nullptr, dp, (bf16_t*)prob, (bf16_t*)ds, (bf16_t*)dbd, nullptr, H, B, Tq, Tk, 0, ld_s, ld_p, scale, drop_p,
              ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed, nullptr};
-    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(cdiv((long)H * B * Tq, 4)), dim3(256), 0, st, p);
+    if (Tk <= 256) hipLaunchKernelGGL(softmax_bwd_reg_kernel<4>, dim3(cdiv((long)H * B * Tq, 4)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(softmax_bwd_kernel, dim3(cdiv((long)H * B * Tq, 4)), dim3(256), 0, st, p);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
