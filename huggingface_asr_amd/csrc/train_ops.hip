@@ -315,6 +315,22 @@ __global__ __launch_bounds__(256) void add2_cast_kernel(const float* __restrict_
         out[(long)m * ldo + c] = f2bf(alpha * v);
     }
 }
+// fast form: 8 columns per thread (two 16-B reads per operand, one 16-B write), 32-bit index math; same arithmetic per element
+__global__ __launch_bounds__(256) void add2_cast_vec8_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
+                                                              bf16_t* __restrict__ out, long ldo, int M, int N8, float alpha) {
+    const unsigned total = (unsigned)M * (unsigned)N8;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned m = i / (unsigned)N8, c = (i - m * (unsigned)N8) << 3;
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(a + (long)m * lda + c), v1 = *reinterpret_cast<const f32x4*>(a + (long)m * lda + c + 4);
+        if (b) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(b + (long)m * ldb + c), w1 = *reinterpret_cast<const f32x4*>(b + (long)m * ldb + c + 4);
+            v0 += w0; v1 += w1;
+        }
+        const bf16x8 o = {f2bf(alpha * v0.x), f2bf(alpha * v0.y), f2bf(alpha * v0.z), f2bf(alpha * v0.w),
+                          f2bf(alpha * v1.x), f2bf(alpha * v1.y), f2bf(alpha * v1.z), f2bf(alpha * v1.w)};
+        *reinterpret_cast<bf16x8*>(out + (long)m * ldo + c) = o;
+    }
+}
 // out = bf16(x + vec[c])   (q + pos_bias_u / pos_bias_v, flattened (H*hd) vector)
 __global__ __launch_bounds__(256) void add_rowvec_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ vec,
                                                           bf16_t* __restrict__ out, long ldo, int M, int N) {
@@ -634,7 +650,10 @@ extern "C" int mi_scale_f32(float* a, long n, float alpha, hipStream_t st) {
 extern "C" int mi_add2_cast_bf16(const float* a, long lda, const float* b, long ldb, void* out, long ldo, int M, int N, float alpha, hipStream_t st) {
     MI_ENTER();
     if (M <= 0 || N <= 0) return MI_ERR_ARG;
-    hipLaunchKernelGGL(add2_cast_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, st, a, lda, b, ldb, (bf16_t*)out, ldo, M, N, alpha);
+    const bool vec = (N % 8) == 0 && (lda % 4) == 0 && (!b || (ldb % 4) == 0) && (ldo % 8) == 0 && (long)M * N < (1L << 31) &&
+                     ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(add2_cast_vec8_kernel, dim3(grid_for((long)M * N / 8)), dim3(256), 0, st, a, lda, b, ldb, (bf16_t*)out, ldo, M, N / 8, alpha);
+    else hipLaunchKernelGGL(add2_cast_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, st, a, lda, b, ldb, (bf16_t*)out, ldo, M, N, alpha);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
