@@ -293,10 +293,14 @@ __global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ 
 // Fused: dact1[b,t1,f1,c] = sum over the conv2 taps that read this position of dcol[(b,t2,f2), (kh,kw,c)]   (col2im gather)
 //        dpre1 = dact1 * gelu'(pre1), pre1 recomputed from the features;  dW1[c][tap] += dpre1 * x[tap];  db1[c] += dpre1.
 // Thread layout of conv2d_first3_kernel: a thread owns 8 channels and walks positions.
+// FIX32: conv2 is the usual 3x3 / stride 2 and there are fewer than 2^31 positions: tap loops unrolled over constants, shifts instead of
+// divisions by the stride, 32-bit position arithmetic.
+template <bool FIX32>
 __global__ __launch_bounds__(256) void conv1_bwd3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                           const bf16_t* __restrict__ dcol, float* __restrict__ dw, float* __restrict__ db,
                                                           int B, int T, int F, int C, int stride, int pad_t, int pad_f, int T1, int F1,
-                                                          int K2, int stride2, int pad2_t, int pad2_f, int T2, int F2) {
+                                                          int K2r, int stride2r, int pad2_t, int pad2_f, int T2, int F2) {
+    const int K2 = FIX32 ? 3 : K2r, stride2 = FIX32 ? 2 : stride2r;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sacc = reinterpret_cast<float*>(smem);        // [C][10]
     const int cg = C >> 3, ppb = 256 / cg;
@@ -314,22 +318,30 @@ __global__ __launch_bounds__(256) void conv1_bwd3_kernel(const float* __restrict
     const long ldcol = (long)K2 * K2 * C;
     if (pl < ppb)
     for (long pos = (long)blockIdx.x * ppb + pl; pos < total; pos += (long)gridDim.x * ppb) {
-        const int f1 = (int)(pos % F1);
-        const int t1 = (int)((pos / F1) % T1);
-        const int b = (int)(pos / ((long)F1 * T1));
+        int f1, t1, b;
+        if (FIX32) {
+            const unsigned up = (unsigned)pos, q = up / (unsigned)F1;
+            f1 = (int)(up - q * (unsigned)F1); b = (int)(q / (unsigned)T1); t1 = (int)(q - (unsigned)b * (unsigned)T1);
+        } else {
+            f1 = (int)(pos % F1);
+            t1 = (int)((pos / F1) % T1);
+            b = (int)(pos / ((long)F1 * T1));
+        }
         // gather the activation gradient
         float da[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) da[j] = 0.f;
-        for (int kh = 0; kh < K2; ++kh) {
+#pragma unroll
+        for (int kh = 0; kh < (FIX32 ? 3 : K2); ++kh) {
             const int nt = t1 + pad2_t - kh;
-            if (nt < 0 || (nt % stride2) != 0) continue;
-            const int t2 = nt / stride2;
+            if (nt < 0 || (FIX32 ? (nt & 1) : (nt % stride2)) != 0) continue;
+            const int t2 = FIX32 ? nt >> 1 : nt / stride2;
             if (t2 >= T2) continue;
-            for (int kw = 0; kw < K2; ++kw) {
+#pragma unroll
+            for (int kw = 0; kw < (FIX32 ? 3 : K2); ++kw) {
                 const int nf = f1 + pad2_f - kw;
-                if (nf < 0 || (nf % stride2) != 0) continue;
-                const int f2 = nf / stride2;
+                if (nf < 0 || (FIX32 ? (nf & 1) : (nf % stride2)) != 0) continue;
+                const int f2 = FIX32 ? nf >> 1 : nf / stride2;
                 if (f2 >= F2) continue;
                 const bf16x8 v = *reinterpret_cast<const bf16x8*>(dcol + (((long)b * T2 + t2) * F2 + f2) * ldcol + (long)(kh * K2 + kw) * C + g * 8);
 #pragma unroll
@@ -447,8 +459,12 @@ extern "C" int mi_conv2d_first_bwd(const float* x, const float* w, const float* 
     const int ppb = 256 / cgs;
     const long nb = (npos + ppb - 1) / ppb;
     const size_t lds = (size_t)C * 10 * sizeof(float);
-    hipLaunchKernelGGL(conv1_bwd3_kernel, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), lds, st, x, w, bias, (const bf16_t*)dcol, dw, db,
-                       B, T, F, C, stride, pad_t, pad_f, T1, F1, K2, stride2, pad2_t, pad2_f, T2, F2);
+    if (K2 == 3 && stride2 == 2 && npos < (1L << 31))
+        hipLaunchKernelGGL(conv1_bwd3_kernel<true>, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), lds, st, x, w, bias, (const bf16_t*)dcol, dw, db,
+                           B, T, F, C, stride, pad_t, pad_f, T1, F1, K2, stride2, pad2_t, pad2_f, T2, F2);
+    else
+        hipLaunchKernelGGL(conv1_bwd3_kernel<false>, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), lds, st, x, w, bias, (const bf16_t*)dcol, dw, db,
+                           B, T, F, C, stride, pad_t, pad_f, T1, F1, K2, stride2, pad2_t, pad2_f, T2, F2);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
