@@ -150,6 +150,10 @@ def lib():
             h.mi_gemm_tn_set_wide.restype = None
             h.mi_gemm_tn_set_wide.argtypes = [C.c_int]
             h.mi_gemm_tn_set_wide(int(os.environ["HFASR_TN_WIDE"]))
+        if os.environ.get("HFASR_TN_TARGET"):
+            h.mi_gemm_tn_set_target.restype = None
+            h.mi_gemm_tn_set_target.argtypes = [C.c_int]
+            h.mi_gemm_tn_set_target(int(os.environ["HFASR_TN_TARGET"]))
         if os.environ.get("HFASR_GEMM_DEBUG"):
             h.mi_gemm_set_debug(int(os.environ["HFASR_GEMM_DEBUG"]))
         h.mi_last_error.argtypes = []

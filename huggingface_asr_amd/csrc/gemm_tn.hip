@@ -14,6 +14,7 @@
 namespace {
 
 constexpr int TN_T = 128, TN_KM = 64;                   // dY tile: 64 m x 128 n;  X tile: 64 m x XW k (XW = 128: 32 KiB per stage, 64: 24 KiB)
+int g_tn_target = 0;
 int g_tn_wide = 1;                                      // 128-wide X tiles, two blocks per CU (default: measured 32.9 vs 33.6 ms per training step); 0 = 64-wide, three per CU
 
 __device__ __attribute__((aligned(16))) uint4 g_zero16 = {0u, 0u, 0u, 0u};
@@ -175,12 +176,13 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ ou
 }  // namespace
 
 extern "C" void mi_gemm_tn_set_wide(int wide) { g_tn_wide = wide; }
+extern "C" void mi_gemm_tn_set_target(int blocks) { g_tn_target = blocks; }       // A/B: blocks per launch the M split aims for (0 = default)
 
 // workspace floats needed for a given problem (0 when a single split is used)
 static int tn_xw() { return g_tn_wide ? 128 : 64; }
 static int tn_splits(int M, int N, int K) {
     const int tiles = cdiv(N, TN_T) * cdiv(K, tn_xw());
-    int s = (g_tn_wide ? 512 : 768) / tiles;           // two (128-wide X tiles, 64 KiB of LDS) or three (64-wide, 48 KiB) blocks per CU on 256 CUs
+    int s = (g_tn_target > 0 ? g_tn_target : (g_tn_wide ? 512 : 768)) / tiles;   // two (128-wide X tiles, 64 KiB of LDS) or three (64-wide, 48 KiB) blocks per CU on 256 CUs
     const int max_s = cdiv(M, 4 * TN_KM);              // at least 4 K-iterations per block
     if (s > max_s) s = max_s;
     return s < 1 ? 1 : s;
