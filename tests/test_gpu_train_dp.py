@@ -17,20 +17,23 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, name="grads_tiny_rel", overlap=False):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0",
+                      HFASR_DP_OVERLAP="1" if overlap else "0")
     import torch.distributed as dist
     from helpers import case_inputs, load_golden
     from huggingface_asr_amd import shapes
     from huggingface_asr_amd.train import EncoderCTCTrainer
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    g = load_golden("grads_tiny_rel")
+    g = load_golden(name)
     cfg = dict(shapes.TINY, ctc_zero_infinity=True, ctc_loss_reduction="mean", hidden_dropout=0.0, activation_dropout=0.0, attention_dropout=0.0,
                final_dropout=0.0, feat_proj_dropout=0.0, csgu_conv_dropout=0.0, apply_spec_augment=False, layerdrop=0.0)
+    if "flags" in g.files:          # the CTC fine-tuning head: its gradient ranges (head, additional layer, encoder LayerNorm + mixing weights) are reduced too
+        cfg.update(finetune_with_additional_layer=bool(g["flags"][0]), finetune_with_layer_mixing=bool(g["flags"][1]))
     sd, x, am, lab = case_inputs(g, cfg)
     tr = EncoderCTCTrainer(cfg, "cuda:0", lr=1e-3)
     tr.load_state_dict(sd)
@@ -48,13 +51,14 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_step_matches_full_batch_fixture():
+@pytest.mark.parametrize("name,overlap", [("grads_tiny_rel", False), ("finetune_tiny_mix_extra", False), ("finetune_tiny_mix_extra", True)])
+def test_two_rank_data_parallel_step_matches_full_batch_fixture(name, overlap):
     from helpers import load_golden
     world, port = 2, _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
-    g = load_golden("grads_tiny_rel")
+    mp.spawn(_worker, args=(world, port, out, name, overlap), nprocs=world, join=True)
+    g = load_golden(name)
     r0, r1 = out[0], out[1]
     assert abs(0.5 * (r0["loss"] + r1["loss"]) - float(g["loss"])) <= 1e-3 * float(g["loss"])     # mean of per-rank losses = batch loss
     worst = 0.0
