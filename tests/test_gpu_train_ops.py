@@ -149,11 +149,13 @@ def test_bgemm_modes():
     close(Cb, want, what="bgemm bf16 out")
 
 
-@pytest.mark.parametrize("rel,causal,masked", [(True, False, True), (False, True, False), (False, False, True)])
-def test_attn_softmax_fwd_bwd(rel, causal, masked):
+@pytest.mark.parametrize("rel,causal,masked,Tq", [(True, False, True, 37), (False, True, False, 37), (False, False, True, 37),
+                                                  (True, False, True, 250),      # the encoder's row length: four registers per lane
+                                                  (True, False, True, 290), (False, False, True, 290)])    # rows beyond 256 keys: the loop-form kernels
+def test_attn_softmax_fwd_bwd(rel, causal, masked, Tq):
     ops, T = _o()
-    H, B, Tq = 2, 3, 37
-    Tk = Tq if (rel or causal) else 53
+    H, B = 2, 3
+    Tk = Tq if (rel or causal) else Tq + 16
     P = 2 * Tq - 1
     scale = 0.25
     ac = rnd(H, B, Tq, Tk, seed=1, scale=2.0).requires_grad_(True)
@@ -401,3 +403,41 @@ def test_activation_with_fused_dropout_is_bit_identical_to_two_passes(kind):
     two_b = T.act_bwd(d2, pre, kind)
     one_b = T.act_bwd(dy, pre, kind, drop=drop)
     assert torch.equal(one_b, two_b)
+
+
+def test_dropout_kernels_match_the_host_twin_masks():
+    """mi_dropout (8-per-thread form and the scalar fall-back), mi_dropout_add_f32 and the attention softmax's probability dropout (register
+    form, Tk <= 256, and loop form) against masks regenerated on the host by synth.dropout_keep for the same (seed, stream, logical index)."""
+    import numpy as np
+    from huggingface_asr_amd import synth
+    _, T = _o()
+    p, seed, sid = 0.25, 4321, 77
+    for (M, N, ld) in ((61, 256, 256), (61, 256, 264), (61, 250, 250)):         # aligned; padded rows (mask follows m*N + n); odd width -> scalar kernel
+        keep = torch.from_numpy(synth.dropout_keep(seed, sid, M * N, p).reshape(M, N))
+        for dt in (torch.float32, BF):
+            x = bfr(rnd(M, ld, seed=9)).to(dt)
+            xd = x.to(DEV)[:, :N]
+            got = T.dropout_(xd.clone() if ld == N else xd, p, seed, sid, out=torch.empty((M, N), device=DEV, dtype=dt), alpha=0.5)
+            want = (x[:, :N].float() * 0.5 * keep.float() * (1.0 / (1.0 - p))).to(dt)
+            assert torch.equal(got.cpu(), want), (M, N, ld, dt)
+    r, t = rnd(40, 128, seed=1), rnd(40, 128, seed=2)
+    keep = torch.from_numpy(synth.dropout_keep(seed, sid, 40 * 128, p).reshape(40, 128)).float()
+    y = T.dropout_add(r.to(DEV), t.to(DEV), 0.5, p, seed, sid)
+    assert torch.allclose(y.cpu(), r + 0.5 * t * keep / (1 - p), rtol=1e-6, atol=1e-6)
+    for Tq in (37, 290):
+        H, B, Tk = 2, 2, Tq
+        lds = T.pad8(Tk)
+        ac = torch.zeros(H, B, Tq, lds); ac[..., :Tk] = rnd(H, B, Tq, Tk, seed=3)
+        prob, pdrop = T.attn_softmax_fwd(ac.to(DEV), None, None, H, B, Tq, Tk, 0.3, False, drop=(p, seed, sid))
+        keep = torch.from_numpy(synth.dropout_keep(seed, sid, H * B * Tq * Tk, p).reshape(H, B, Tq, Tk)).float()
+        got = pdrop[..., :Tk].float().cpu()
+        assert torch.equal(got == 0, (keep == 0) | (prob[..., :Tk].float().cpu() == 0)), Tq          # exactly the host twin's mask
+        want = prob[..., :Tk].float().cpu() * keep / (1 - p)                                          # (the kernel scales the un-rounded probability: 1 bf16 ulp)
+        assert float((got - want).abs().max()) <= 2 ** -7 * float(want.abs().max()), Tq
+        dp = torch.zeros(H, B, Tq, lds); dp[..., :Tk] = rnd(H, B, Tq, Tk, seed=4)
+        ds, _ = T.attn_softmax_bwd(prob, dp.to(DEV), H, B, Tq, Tk, 0.3, drop=(p, seed, sid))
+        pf = prob[..., :Tk].float().cpu()
+        g = dp[..., :Tk] * keep / (1 - p)
+        wds = pf * (g - (pf * g).sum(-1, keepdim=True)) * 0.3
+        err = (ds[..., :Tk].float().cpu() - wds).abs().max()
+        assert float(err) < 2e-2 * float(wds.abs().max()) + 1e-4, (Tq, float(err))
