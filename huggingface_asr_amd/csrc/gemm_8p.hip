@@ -1,0 +1,430 @@
+// 256x256x64 eight-wave "phase-interleaved" bf16 MFMA GEMM for gfx950 (wide-N fast path of mi_gemm_bf16).
+//
+//   C[M,N] (bf16) = act(A[M,K] · W[N,K]^T + bias)      N % 256 == 0, K % 64 == 0, K >= 128
+//
+// One workgroup of 8 waves (2 x 4) per 256 x 256 output tile; a wave owns 128 x 64 = 8 x 4 MFMA 16x16x32 tiles (128 accumulator
+// registers).  K tiles of 64 live in a two-deep LDS ring (2 x 64 KiB); each K tile is staged as FOUR half-tiles of 16 KiB by
+// `global_load_lds_dwordx4` (two 1-KiB pieces per wave and half-tile):
+//     Ha0 / Ha1 = the A rows of every wave's first / second 64-row half,   Hb0 / Hb1 = the W rows of its first / second 32 columns.
+// A K tile is consumed in four PHASES, one output quadrant (64 x 32 per wave = 16 MFMAs) each:
+//     p1: read B0, A0 -> quadrant (0,0)     p2: read B1 -> (0,1)     p3: read A1 -> (1,1)     p4: (nothing to read) -> (1,0)
+// and every phase is   { ds_reads ; stage ONE half-tile ; counted vmcnt } s_barrier { lgkmcnt(0) ; 16 MFMAs } s_barrier.
+// The two wave rows run ONE barrier apart (waves w and w+4 share a SIMD): while one row's waves issue their 16 MFMAs the other
+// row's waves read LDS and issue the next loads, so the matrix pipe of every SIMD always has a wave to take from.
+//
+// Staging schedule (the order never changes, so a counted vmcnt retires exactly what the next phase reads):
+//     tile t:  p1 stages Hb1(t+1)   p2 stages Ha1(t+1)   p3 stages Ha0(t+2)   p4 stages Hb0(t+2)
+//   WAR: a region is re-staged >= 2 phases after its last read (reads of phase g are retired by lgkmcnt(0) behind the barrier that
+//        opens that phase's MFMA segment; the lagging wave row is one barrier behind) — Ha0/Hb0 read in p1, re-staged in p3/p4;
+//        Hb1 read in p2, re-staged in p1 of the next tile; Ha1 read in p3, re-staged in p2 of the next tile.
+//   RAW: a half-tile is read one phase after the wait that retires it: `vmcnt(8)` (four younger half-tiles stay in flight = 64 KiB
+//        per CU) in p4 (-> Ha0/Hb0 of t+1), p1 (-> Hb1 of t) and p2 (-> Ha1 of t), each in front of the phase's first barrier.
+//   The last two K tiles run with their stagings peeled off and the counts lowered accordingly (8,8,4 / 2,0).
+//
+// LDS image per K tile: A rows [256][128 B] then W rows [256][128 B]; pieces are lane-linear (8 rows x 128 B), the bank swizzle
+// (16-B chunk ^ ((row>>1)&7): conflict-free ds_read_b128 for the 16x16x32 fragment pattern) is applied to the per-lane SOURCE
+// address and again on the read.  MFMAs are issued as W·A^T, so a lane owns an output ROW (lane & 15) and its four registers are
+// four consecutive COLUMNS.  Epilogue: bias / activation on the accumulators, bf16 rows through a wave-private 16-KiB LDS region
+// (the ring is dead by then), out as whole 128-B lines (8 lanes x 16 B per row).
+#include "gemm_args.hpp"
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int TB = 256, BK = 64;
+constexpr int BUF = 65536, BOFF = 32768;
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    if constexpr (N >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void wait_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+struct Ctx {
+    const char* A; const char* W;
+    unsigned offA[2][2], offB[2][2];     // per-lane source byte offsets of this wave's two pieces of Ha(mq) / Hb(nq), K tile 0
+    unsigned dA[2][2], dB[2][2];         // wave-uniform LDS byte offsets of those pieces inside a ring buffer
+    unsigned aRd[2], bRd[2];             // per-lane LDS byte offsets of the fragment reads (k-step 0 / 1), ring buffer 0
+};
+
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int ntm = (p.M + TB - 1) / TB, ntn = p.N / TB;
+    const int nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap: the blocks of one XCD walk N fastest within an A row panel
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / ntn) * TB, n0 = (bid % ntn) * TB;
+
+    Ctx c;
+    c.A = reinterpret_cast<const char*>(p.A);
+    c.W = reinterpret_cast<const char*>(p.W);
+    {
+        const int prow = lane >> 3, pc = lane & 7;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int ra = wr * 128 + h * 64 + (2 * wc + e) * 8;
+                const int rb = (wave >> 1) * 64 + h * 32 + (2 * (wave & 1) + e) * 8;
+                const int lcA = pc ^ (((ra + prow) >> 1) & 7), lcB = pc ^ (((rb + prow) >> 1) & 7);
+                c.offA[h][e] = (unsigned)min(m0 + ra + prow, p.M - 1) * (unsigned)(p.lda * 2) + lcA * 16;
+                c.offB[h][e] = (unsigned)min(n0 + rb + prow, p.N - 1) * (unsigned)(p.ldw * 2) + lcB * 16;
+                c.dA[h][e] = ra * 128;
+                c.dB[h][e] = BOFF + rb * 128;
+            }
+        const int fr = lane & 15, fq = lane >> 4, swz = (fr >> 1) & 7;
+        const unsigned low = fr * 128 + ((fq ^ swz) << 4);
+        c.aRd[0] = wr * 128 * 128 + low;
+        c.aRd[1] = c.aRd[0] ^ 64;
+        c.bRd[0] = BOFF + wc * 64 * 128 + low;
+        c.bRd[1] = c.bRd[0] ^ 64;
+    }
+    auto stageA = [&](int kt, unsigned buf, int mq) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            __builtin_amdgcn_global_load_lds((gptr_t)(c.A + c.offA[mq][e] + (unsigned)kt * 128u), (lptr_t)(smem + buf + c.dA[mq][e]), 16, 0, 0);
+    };
+    auto stageB = [&](int kt, unsigned buf, int nq) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            __builtin_amdgcn_global_load_lds((gptr_t)(c.W + c.offB[nq][e] + (unsigned)kt * 128u), (lptr_t)(smem + buf + c.dB[nq][e]), 16, 0, 0);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[4][2], fb[2][2][2];        // A fragments of the current 64-row half; W fragments of both 32-column halves
+
+    auto readA = [&](unsigned cb, int mq) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                fa[i][s] = *reinterpret_cast<const bf16x8*>(smem + (cb + c.aRd[s]) + (mq * 64 + i * 16) * 128);
+    };
+    auto readB = [&](unsigned cb, int nq) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                fb[nq][j][s] = *reinterpret_cast<const bf16x8*>(smem + (cb + c.bRd[s]) + (nq * 32 + j * 16) * 128);
+    };
+    auto quad = [&](int mq, int nq) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[mq * 4 + i][nq * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nq][j][s], fa[i][s], acc[mq * 4 + i][nq * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // one K tile = four phases; S* = stage in that phase, W* = vmcnt count in front of that phase's first barrier (-1: none)
+    auto tile = [&](int kt, unsigned cb, auto S1, auto S2, auto S3, auto S4, auto W1, auto W2, auto W4) {
+        // p1
+        readB(cb, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        readA(cb, 0);
+        if constexpr (decltype(S1)::value) stageB(kt + 1, cb ^ BUF, 1);
+        wait_vm<decltype(W1)::value>();
+        barrier();
+        wait_lds();
+        quad(0, 0);
+        barrier();
+        // p2
+        readB(cb, 1);
+        if constexpr (decltype(S2)::value) stageA(kt + 1, cb ^ BUF, 1);
+        wait_vm<decltype(W2)::value>();
+        barrier();
+        wait_lds();
+        quad(0, 1);
+        barrier();
+        // p3
+        readA(cb, 1);
+        if constexpr (decltype(S3)::value) stageA(kt + 2, cb, 0);
+        barrier();
+        wait_lds();
+        quad(1, 1);
+        barrier();
+        // p4
+        if constexpr (decltype(S4)::value) stageB(kt + 2, cb, 0);
+        wait_vm<decltype(W4)::value>();
+        barrier();
+        quad(1, 0);
+        barrier();
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    auto I = [](auto v) { return v; };
+    (void)I;
+
+    const int nk = p.K / BK;
+    // prologue: Ha0(0) Hb0(0) Hb1(0) Ha1(0) Ha0(1) Hb0(1) — the steady-state order
+    stageA(0, 0, 0); stageB(0, 0, 0); stageB(0, 0, 1); stageA(0, 0, 1); stageA(1, BUF, 0); stageB(1, BUF, 0);
+    wait_vm<8>();
+    barrier();
+    if (wr == 1) barrier();              // the second wave row runs one barrier behind
+    unsigned cb = 0;
+    int kt = 0;
+    for (; kt < nk - 2; ++kt) {
+        tile(kt, cb, T{}, T{}, T{}, T{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 8>{});
+        cb ^= BUF;
+    }
+    tile(kt, cb, T{}, T{}, F{}, F{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{});
+    cb ^= BUF;
+    tile(kt + 1, cb, F{}, F{}, F{}, F{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, -1>{});
+    if (wr == 0) barrier();              // barrier counts match; every wave's last LDS reads are retired
+
+    // ---- epilogue: bias / activation, bf16 rows through a wave-private LDS region, whole 128-B lines out
+    char* reg = smem + wave * 16384;
+    const int fr = lane & 15, fq = lane >> 4, swz = (fr >> 1) & 7;
+    const int nb = n0 + wc * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias_mode == 1) b4 = *reinterpret_cast<const f32x4*>(p.bias + nb + j * 16 + fq * 4);
+        const int chunk = j * 2 + (fq >> 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            f32x4 v = acc[i][j] + b4;
+            if (p.act == 1) v = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+            else if (p.act == 2) v = f32x4{gelu_tanh(v.x), gelu_tanh(v.y), gelu_tanh(v.z), gelu_tanh(v.w)};
+            const bf16x4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+            const int row = i * 16 + fr;
+            *reinterpret_cast<bf16x4*>(reg + row * 128 + ((chunk ^ swz) << 4) + (fq & 1) * 8) = o;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int prow = lane >> 3, pc = lane & 7;
+    bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int row = u * 8 + prow;
+        const uint4 v = *reinterpret_cast<const uint4*>(reg + row * 128 + ((pc ^ ((row >> 1) & 7)) << 4));
+        const int m = m0 + wr * 128 + row;
+        if (m < p.M) *reinterpret_cast<uint4*>(C + (long)m * p.ldc + nb + pc * 8) = v;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// 128 x 128 x 64 variant for the N = 512 GEMMs (FFN out, attention out, cgMLP out, merge): 8 waves (2 x 4), wave tile 64 x 32 =
+// 4 x 2 MFMA tiles, ONE phase per K tile { 12 ds_reads ; stage K tile t+3 (4 pieces per wave) ; vmcnt ; lgkmcnt(0) } s_barrier
+// { 16 MFMAs } s_barrier on a FOUR-deep ring of 32-KiB K tiles; the two wave rows again run one barrier apart.
+//   WAR: the reads of phase t are retired (lgkmcnt(0)) BEFORE the barrier that ends its read segment, so buffer (t-1) & 3 may be
+//        re-staged in phase t (one phase after its last read) by either wave row.
+//   RAW: K tile t+1 (staged in phase t-2) is retired by `vmcnt(8)` in phase t — the stagings of phases t-1 and t stay in flight
+//        (64 KiB per CU) — and read in phase t+1.  Tail: vmcnt(4) in phase nk-3, vmcnt(0) in phase nk-2.
+// Epilogue: fp32 (+ residual, read at kernel start in the store layout) or bf16 rows through a wave-private LDS region, out as
+// 128-B (fp32) / 64-B (bf16) row segments.
+constexpr int B128_BUF = 32768, B128_BOFF = 16384;
+
+__global__ __launch_bounds__(512, 2) void gemm8p128_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int ntm = (p.M + 127) / 128, ntn = p.N / 128;
+    const int nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / ntn) * 128, n0 = (bid % ntn) * 128;
+    const int prow = lane >> 3, pc = lane & 7;
+
+    // residual rows in the store layout (8 lanes x 16 B per row), requested before anything else
+    const int nb = n0 + wc * 32;
+    f32x4 rres[8];
+    const bool use_res = p.out_f32 && p.resid != nullptr;
+    if (use_res) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int m = min(m0 + wr * 64 + u * 8 + prow, p.M - 1);
+            rres[u] = *reinterpret_cast<const f32x4*>(p.resid + (long)m * p.ldr + nb + pc * 4);
+        }
+    }
+
+    // staging: waves 0-3 bring the A rows, waves 4-7 the W rows; 4 pieces of 8 rows per wave and K tile
+    const char* src_base = reinterpret_cast<const char*>(wave < 4 ? (const void*)p.A : (const void*)p.W);
+    unsigned off[4], dst[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int r0 = (4 * (wave & 3) + e) * 8;
+        const int lc = pc ^ (((r0 + prow) >> 1) & 7);
+        if (wave < 4) off[e] = (unsigned)min(m0 + r0 + prow, p.M - 1) * (unsigned)(p.lda * 2) + lc * 16;
+        else off[e] = (unsigned)min(n0 + r0 + prow, p.N - 1) * (unsigned)(p.ldw * 2) + lc * 16;
+        dst[e] = (wave < 4 ? 0 : B128_BOFF) + r0 * 128;
+    }
+    auto stage = [&](int kt) {
+        const unsigned buf = (unsigned)(kt & 3) * B128_BUF;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src_base + off[e] + (unsigned)kt * 128u), (lptr_t)(smem + buf + dst[e]), 16, 0, 0);
+    };
+    const int fr = lane & 15, fq = lane >> 4, swz = (fr >> 1) & 7;
+    const unsigned low = fr * 128 + ((fq ^ swz) << 4);
+    const unsigned aRd0 = wr * 64 * 128 + low, bRd0 = B128_BOFF + wc * 32 * 128 + low;
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[4][2], fb[2][2];
+    auto phase = [&](int kt, auto DO_STAGE, auto WAIT) {
+        const unsigned cb = (unsigned)(kt & 3) * B128_BUF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) fb[j][s] = *reinterpret_cast<const bf16x8*>(smem + ((cb + bRd0) ^ (s * 64)) + j * 16 * 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) fa[i][s] = *reinterpret_cast<const bf16x8*>(smem + ((cb + aRd0) ^ (s * 64)) + i * 16 * 128);
+        if constexpr (decltype(DO_STAGE)::value) stage(kt + 3);
+        wait_vm<decltype(WAIT)::value>();
+        wait_lds();
+        barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][s], fa[i][s], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        barrier();
+    };
+    const int nk = p.K / BK;
+    stage(0); stage(1); stage(2);
+    wait_vm<8>();
+    barrier();
+    if (wr == 1) barrier();
+    int kt = 0;
+    for (; kt < nk - 3; ++kt) phase(kt, std::true_type{}, std::integral_constant<int, 8>{});
+    phase(kt, std::false_type{}, std::integral_constant<int, 4>{});
+    phase(kt + 1, std::false_type{}, std::integral_constant<int, 0>{});
+    phase(kt + 2, std::false_type{}, std::integral_constant<int, -1>{});
+    if (wr == 0) barrier();
+
+    // ---- epilogue
+    char* reg = smem + wave * 8192;                       // 64 rows x 128 B
+    f32x4 b4[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        b4[j] = (p.bias_mode == 1) ? *reinterpret_cast<const f32x4*>(p.bias + nb + j * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.out_f32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 v = acc[i][j] + b4[j];
+                if (p.act == 1) v = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+                else if (p.act == 2) v = f32x4{gelu_tanh(v.x), gelu_tanh(v.y), gelu_tanh(v.z), gelu_tanh(v.w)};
+                const int row = i * 16 + fr;
+                *reinterpret_cast<f32x4*>(reg + row * 128 + (((j * 4 + fq) ^ swz) << 4)) = v;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float* C = reinterpret_cast<float*>(p.C);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = u * 8 + prow;
+            f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * 128 + ((pc ^ ((row >> 1) & 7)) << 4));
+            if (use_res) v = rres[u] + p.alpha * v;
+            const int m = m0 + wr * 64 + row;
+            if (m < p.M) *reinterpret_cast<f32x4*>(C + (long)m * p.ldc + nb + pc * 4) = v;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 v = acc[i][j] + b4[j];
+                if (p.act == 1) v = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+                else if (p.act == 2) v = f32x4{gelu_tanh(v.x), gelu_tanh(v.y), gelu_tanh(v.z), gelu_tanh(v.w)};
+                const bf16x4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+                const int row = i * 16 + fr;
+                *reinterpret_cast<bf16x4*>(reg + row * 128 + (((j * 2 + (fq >> 1)) ^ (swz & 3)) << 4) + (fq & 1) * 8) = o;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+        const int r4 = lane >> 2, c4 = lane & 3;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = u * 16 + r4;
+            const uint4 v = *reinterpret_cast<const uint4*>(reg + row * 128 + ((c4 ^ ((row >> 1) & 3)) << 4));
+            const int m = m0 + wr * 64 + row;
+            if (m < p.M) *reinterpret_cast<uint4*>(C + (long)m * p.ldc + nb + c4 * 8) = v;
+        }
+    }
+}
+
+}  // namespace
+
+bool gemm_8p_supported(const GemmArgs& a) {
+    if (a.M <= 0 || a.N <= 0 || (a.N % TB) != 0 || (a.K % BK) != 0 || a.K < 2 * BK) return false;
+    if (a.out_f32 || a.resid || a.col_T || a.bias_mode == 2) return false;
+    if (((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) || ((uintptr_t)a.C & 15) || (a.lda % 8) || (a.ldw % 8) || (a.ldc % 8)) return false;
+    if (a.bias_mode == 1 && ((uintptr_t)a.bias & 15)) return false;
+    if ((long)a.M * a.lda * 2 >= (1l << 32) || (long)a.N * a.ldw * 2 >= (1l << 32)) return false;     // 32-bit source offsets
+    return true;
+}
+
+int gemm_8p_launch(const GemmArgs& a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+        attr_set = true;
+    }
+    const int grid = cdiv(a.M, TB) * (a.N / TB);
+    hipLaunchKernelGGL(gemm8p_kernel, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
+    return MI_OK;
+}
+
+bool gemm_8p128_supported(const GemmArgs& a) {
+    if (a.M <= 0 || a.N <= 0 || (a.N % 128) != 0 || (a.K % BK) != 0 || a.K < 4 * BK) return false;
+    if (a.col_T || a.bias_mode == 2) return false;
+    if (a.resid && !a.out_f32) return false;
+    if (((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) || ((uintptr_t)a.C & 15) || (a.lda % 8) || (a.ldw % 8)) return false;
+    if (a.out_f32 ? (a.ldc % 4) != 0 : (a.ldc % 8) != 0) return false;
+    if (a.resid && (((uintptr_t)a.resid & 15) || (a.ldr % 4) != 0)) return false;
+    if (a.bias_mode == 1 && ((uintptr_t)a.bias & 15)) return false;
+    if ((long)a.M * a.lda * 2 >= (1l << 32) || (long)a.N * a.ldw * 2 >= (1l << 32)) return false;
+    return true;
+}
+
+int gemm_8p128_launch(const GemmArgs& a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * B128_BUF);
+        attr_set = true;
+    }
+    const int grid = cdiv(a.M, 128) * (a.N / 128);
+    hipLaunchKernelGGL(gemm8p128_kernel, dim3(grid), dim3(512), (size_t)4 * B128_BUF, stream, a);
+    return MI_OK;
+}

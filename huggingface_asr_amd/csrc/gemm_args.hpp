@@ -26,3 +26,9 @@ int gemm_glds_launch(const GemmArgs& a, bool conv, hipStream_t stream);
 // gemm_256.hip: 256x256 tiles, 8 waves, 4-deep ring of 32-wide K tiles (N % 256 == 0, K % 32 == 0)
 bool gemm_256_supported(const GemmArgs& a);
 int gemm_256_launch(const GemmArgs& a, hipStream_t stream);
+
+// gemm_8p.hip: 256x256x64 tiles, 8 waves, phase-interleaved schedule on a two-deep LDS ring (bf16 out, N % 256 == 0, K % 64 == 0, K >= 128)
+bool gemm_8p_supported(const GemmArgs& a);
+int gemm_8p_launch(const GemmArgs& a, hipStream_t stream);
+bool gemm_8p128_supported(const GemmArgs& a);
+int gemm_8p128_launch(const GemmArgs& a, hipStream_t stream);
