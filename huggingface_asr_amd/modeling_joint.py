@@ -5,7 +5,7 @@ and the decoder config of `src/models/decoders/multi_head_gpt2.py:12-29`: same m
 `AutoModelForSpeechSeq2Seq` route here after `bind_all()`), same state-dict keys (encoder.* = our E-Branchformer CTC model,
 decoder.* = GPT-2 multi-head keys, enc_to_dec_proj.*), same forward arguments and `Seq2SeqLMOutputLosses` fields, and a
 `generate()` that performs the reference's joint CTC/attention greedy / beam decoding.  The modules only hold parameters;
-all tensor work runs in `huggingface_asr_amd.decoder` (HIP kernels).  Eval-mode only this round."""
+all tensor work runs in `huggingface_asr_amd.decoder` (HIP kernels); training-mode forwards run forward AND backward on the HIP trainer (autograd_bridge.py)."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -111,13 +111,53 @@ class _GPT2Body(_Holder):
         self.ln_f = nn.LayerNorm(d, eps=cfg.layer_norm_epsilon)
 
 
-class _Decoder(_Holder):
-    def __init__(self, cfg):
-        super().__init__()
-        self.config = cfg
-        self.transformer = _GPT2Body(cfg)
-        self.lm_head = nn.Linear(cfg.hidden_size, cfg.vocab_size, bias=False)
-        self.additional_lm_heads = nn.ModuleList([nn.Linear(cfg.hidden_size, cfg.vocab_size, bias=False) for _ in (cfg.head_locations or [])])
+class GPT2LMMultiHeadModel(PreTrainedModel):
+    """Parameter holder with the reference decoder's class name, config class and state-dict keys (`src/models/decoders/multi_head_gpt2.py:31-49`;
+    with `pos_emb_fixed` the embeddings the reference's `PositionalEncodingInitModifier` swaps in, `src/models/auto_wrappers.py:186-209`).  It is what
+    `CustomModelForCausalLM.from_config / from_pretrained` return after `bind.install()`; the tensor work of the decoder runs in
+    `huggingface_asr_amd.decoder` when the module sits inside `JointCTCAttentionEncoderDecoder` — called on its own it raises."""
+    config_class = GPT2MultiHeadConfig
+    base_model_prefix = "transformer"
+    main_input_name = "input_ids"
+    _no_split_modules = []
+
+    def __init__(self, config):
+        super().__init__(config)
+        if config.head_locations is not None and len(config.head_locations) + 1 != len(config.head_weights or []):
+            raise ValueError("The number of head locations should be equal to the number of head weights minus 1")     # reference :36-37
+        self.transformer = _GPT2Body(config)
+        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.additional_lm_heads = nn.ModuleList([nn.Linear(config.hidden_size, config.vocab_size, bias=False) for _ in (config.head_locations or [])])
+        self.head_locations = list(config.head_locations or [])
+        self.head_weights = list(config.head_weights or [1.0])
+        self.lsm_factor = getattr(config, "lsm_factor", 0.0)
+        self.post_init()
+
+    def _init_weights(self, module):          # GPT-2's initialiser (tf:models/gpt2/modeling_gpt2.py `_init_weights`): N(0, initializer_range), LayerNorm 1 / 0
+        std = getattr(self.config, "initializer_range", 0.02)
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=std)
+            if getattr(module, "bias", None) is not None:
+                module.bias.data.zero_()
+        elif isinstance(module, nn.LayerNorm):
+            module.weight.data.fill_(1.0)
+            module.bias.data.zero_()
+
+    def get_input_embeddings(self):
+        return self.transformer.wte
+
+    def get_output_embeddings(self):
+        return self.lm_head
+
+    def tie_weights(self, *a, **k):           # the joint model forces tie_word_embeddings = False (reference ctc_encoder_plus...:90)
+        pass
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("GPT2LMMultiHeadModel (HIP): the decoder runs inside JointCTCAttentionEncoderDecoder (huggingface_asr_amd.decoder); "
+                           "it has no stand-alone forward and no CPU fallback")
+
+
+_Decoder = GPT2LMMultiHeadModel
 
 
 def _dec_cfg_dict(c) -> dict:
@@ -140,33 +180,84 @@ class JointCTCAttentionEncoderDecoder(PreTrainedModel):
             config = JointCTCAttentionEncoderDecoderConfig.from_encoder_decoder_configs(encoder.config, decoder.config)
         elif not isinstance(config, self.config_class):
             raise ValueError(f"Config: {config} has to be of type {self.config_class}")
-        if config.decoder.cross_attention_hidden_size is not None and \
-                config.decoder.cross_attention_hidden_size != config.encoder.hidden_size:
+        for k, v in (("ctc_weight", 0.0), ("shared_lm_head", False)):      # set by the reference's instantiate_aed_model (model_utils.py:159-174)
+            if not hasattr(config, k):
+                setattr(config, k, v)
+        if not hasattr(config.decoder, "lsm_factor"):
+            config.decoder.lsm_factor = 0.0
+        xh = getattr(config.decoder, "cross_attention_hidden_size", None)      # a PretrainedConfig default in transformers 4.x, absent in 5.x
+        if xh is not None and xh != config.encoder.hidden_size:
             raise ValueError("If `cross_attention_hidden_size` is specified in the decoder's configuration, it has to be equal to the "
                              "encoder's `hidden_size`.")
         config.tie_word_embeddings = False
         super().__init__(config)
+        if encoder is not None and not isinstance(encoder, Wav2Vec2EBranchformerForCTC):
+            raise TypeError(f"encoder must be the HIP Wav2Vec2EBranchformerForCTC, got {type(encoder)} (no PyTorch fallback)")
+        if decoder is not None and not isinstance(decoder, GPT2LMMultiHeadModel):
+            raise TypeError(f"decoder must be the HIP GPT2LMMultiHeadModel, got {type(decoder)} (no PyTorch fallback)")
         self.encoder = encoder if encoder is not None else Wav2Vec2EBranchformerForCTC(config.encoder)
-        self.decoder = decoder if decoder is not None else _Decoder(config.decoder)
+        self.decoder = decoder if decoder is not None else GPT2LMMultiHeadModel(config.decoder)
         self.encoder.config = self.config.encoder
         self.decoder.config = self.config.decoder
         self.encoder_output_dim = getattr(config.encoder, "output_hidden_size", config.encoder.hidden_size)
-        if self.encoder_output_dim != self.decoder.config.hidden_size and self.decoder.config.cross_attention_hidden_size is None:
+        if self.encoder_output_dim != self.decoder.config.hidden_size and xh is None:
             self.enc_to_dec_proj = nn.Linear(self.encoder.config.hidden_size, self.decoder.config.hidden_size)
         if self.encoder.get_output_embeddings() is not None:
             raise ValueError(f"The encoder {self.encoder} should not have a LM Head. Please use a model without LM Head")
         self.enc_loss_weight = config.ctc_weight
         self.dec_loss_weight = 1 - config.ctc_weight
         self.lsm_factor = config.decoder.lsm_factor
+        if getattr(config, "shared_lm_head", False):                  # reference :132-133
+            self.encoder.lm_head.weight = self.decoder.lm_head.weight
         self._engine = None
         self._engine_key = None
         from .decoding import GenerationConfigCustom
         # trainers overwrite this (train_enc_dec_asr.py:85); the default carries the ids of the model config
         self.generation_config = GenerationConfigCustom(pad_token_id=config.pad_token_id, eos_token_id=config.decoder.eos_token_id,
                                                         decoder_start_token_id=config.decoder_start_token_id, num_beams=1, max_length=64)
+        self.post_init()
 
     def _init_weights(self, module):
         pass
+
+    @classmethod
+    def from_encoder_decoder_pretrained(cls, encoder_pretrained_model_name_or_path=None, decoder_pretrained_model_name_or_path=None, *model_args, **kwargs):
+        """Reference `ctc_encoder_plus_autoregressive_decoder.py:138-235` (called by `instantiate_aed_model`, `model_utils.py:199-204`): kwargs
+        prefixed `encoder_` / `decoder_` (except `decoder_start_token_id`) go to the sub-model configs, the rest to the joint config; `encoder_model` /
+        `decoder_model` pass ready modules.  Sub-models are loaded through the Auto registry (`bind_all()` must have run) and must resolve to the HIP classes."""
+        from transformers import AutoConfig, AutoModelForCTC
+        kw_enc = {k[len("encoder_"):]: v for k, v in kwargs.items() if k.startswith("encoder_")}
+        kw_dec = {k[len("decoder_"):]: v for k, v in kwargs.items() if k.startswith("decoder_") and k != "decoder_start_token_id"}
+        for k in kw_enc:
+            del kwargs["encoder_" + k]
+        for k in kw_dec:
+            del kwargs["decoder_" + k]
+        encoder = kw_enc.pop("model", None)
+        if encoder is None:
+            if encoder_pretrained_model_name_or_path is None:
+                raise ValueError("If `encoder_model` is not defined as an argument, a `encoder_pretrained_model_name_or_path` has to be defined.")
+            if "config" not in kw_enc:
+                enc_cfg, kw_enc = AutoConfig.from_pretrained(encoder_pretrained_model_name_or_path, **kw_enc, return_unused_kwargs=True)
+                if getattr(enc_cfg, "is_decoder", False) or getattr(enc_cfg, "add_cross_attention", False):
+                    enc_cfg.is_decoder = False
+                    enc_cfg.add_cross_attention = False
+                kw_enc["config"] = enc_cfg
+            encoder = AutoModelForCTC.from_pretrained(encoder_pretrained_model_name_or_path, *model_args, **kw_enc)
+        decoder = kw_dec.pop("model", None)
+        if decoder is None:
+            if decoder_pretrained_model_name_or_path is None:
+                raise ValueError("If `decoder_model` is not defined as an argument, a `decoder_pretrained_model_name_or_path` has to be defined.")
+            if "config" not in kw_dec:
+                dec_cfg, kw_dec = AutoConfig.from_pretrained(decoder_pretrained_model_name_or_path, **kw_dec, return_unused_kwargs=True)
+                dec_cfg.is_decoder = True
+                dec_cfg.add_cross_attention = True
+                kw_dec["config"] = dec_cfg
+            if not isinstance(kw_dec["config"], GPT2MultiHeadConfig):
+                raise ValueError(f"decoder config {type(kw_dec['config'])} is not a GPT2MultiHeadConfig: only the multi-head GPT-2 decoder has a HIP implementation")
+            decoder = GPT2LMMultiHeadModel.from_pretrained(decoder_pretrained_model_name_or_path, **kw_dec)
+        config = JointCTCAttentionEncoderDecoderConfig.from_encoder_decoder_configs(encoder.config, decoder.config, **kwargs)
+        config.tie_word_embeddings = False
+        return cls(encoder=encoder, decoder=decoder, config=config)
 
     def get_encoder(self):
         return self.encoder
