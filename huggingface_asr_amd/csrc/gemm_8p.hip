@@ -51,13 +51,19 @@ __device__ __forceinline__ void wait_lds() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+__device__ __attribute__((aligned(16))) uint4 g_zero_page8p = {0u, 0u, 0u, 0u};      // source of implicit-im2col zero padding
+
 struct Ctx {
     const char* A; const char* W;
     unsigned offA[2][2], offB[2][2];     // per-lane source byte offsets of this wave's two pieces of Ha(mq) / Hb(nq), K tile 0
+    int cti[2][2], cfi[2][2];            // CONV: input (time, freq) of tap (0,0) for the lane's output row; offA = batch base + swizzled chunk
     unsigned dA[2][2], dB[2][2];         // wave-uniform LDS byte offsets of those pieces inside a ring buffer
     unsigned aRd[2], bRd[2];             // per-lane LDS byte offsets of the fragment reads (k-step 0 / 1), ring buffer 0
 };
 
+// CONV: A is a channels-last activation (B, Tin, Fin, Cin), row m = (b, to, fo), k = (kh*KW + kw)*Cin + c with Cin % 64 == 0, so a K tile is one
+// tap and a 64-channel slice: the per-lane source row moves with the tap, rows that fall into the zero padding read a 16-B zero page.
+template <bool CONV>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -85,7 +91,15 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
                 const int ra = wr * 128 + h * 64 + (2 * wc + e) * 8;
                 const int rb = (wave >> 1) * 64 + h * 32 + (2 * (wave & 1) + e) * 8;
                 const int lcA = pc ^ (((ra + prow) >> 1) & 7), lcB = pc ^ (((rb + prow) >> 1) & 7);
-                c.offA[h][e] = (unsigned)min(m0 + ra + prow, p.M - 1) * (unsigned)(p.lda * 2) + lcA * 16;
+                if constexpr (CONV) {
+                    const int m = min(m0 + ra + prow, p.M - 1);
+                    const int fo = m % p.Fout, to = (m / p.Fout) % p.Tout, b = m / (p.Fout * p.Tout);
+                    c.cti[h][e] = to * p.stride - p.pad_t;
+                    c.cfi[h][e] = fo * p.stride - p.pad_f;
+                    c.offA[h][e] = (unsigned)b * (unsigned)(p.Tin * p.Fin * p.Cin * 2) + lcA * 16;
+                } else {
+                    c.offA[h][e] = (unsigned)min(m0 + ra + prow, p.M - 1) * (unsigned)(p.lda * 2) + lcA * 16;
+                }
                 c.offB[h][e] = (unsigned)min(n0 + rb + prow, p.N - 1) * (unsigned)(p.ldw * 2) + lcB * 16;
                 c.dA[h][e] = ra * 128;
                 c.dB[h][e] = BOFF + rb * 128;
@@ -98,9 +112,22 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
         c.bRd[1] = c.bRd[0] ^ 64;
     }
     auto stageA = [&](int kt, unsigned buf, int mq) {
+        if constexpr (CONV) {
+            const int k0 = kt * BK;
+            const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
-            __builtin_amdgcn_global_load_lds((gptr_t)(c.A + c.offA[mq][e] + (unsigned)kt * 128u), (lptr_t)(smem + buf + c.dA[mq][e]), 16, 0, 0);
+            for (int e = 0; e < 2; ++e) {
+                const int ti = c.cti[mq][e] + kh, fi = c.cfi[mq][e] + kw;
+                const bool ok = (unsigned)ti < (unsigned)p.Tin && (unsigned)fi < (unsigned)p.Fin;
+                const char* sp = ok ? c.A + (c.offA[mq][e] + (unsigned)(((ti * p.Fin + fi) * p.Cin + c0) * 2)) : reinterpret_cast<const char*>(&g_zero_page8p);
+                __builtin_amdgcn_global_load_lds((gptr_t)sp, (lptr_t)(smem + buf + c.dA[mq][e]), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                __builtin_amdgcn_global_load_lds((gptr_t)(c.A + c.offA[mq][e] + (unsigned)kt * 128u), (lptr_t)(smem + buf + c.dA[mq][e]), 16, 0, 0);
+        }
     };
     auto stageB = [&](int kt, unsigned buf, int nq) {
 #pragma unroll
@@ -240,6 +267,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
 // 128-B (fp32) / 64-B (bf16) row segments.
 constexpr int B128_BUF = 32768, B128_BOFF = 16384;
 
+template <int NB>     // ring depth (K tiles of 32 KiB): 4 -> three tiles requested ahead, 5 -> four (all 160 KiB of LDS)
 __global__ __launch_bounds__(512, 2) void gemm8p128_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -280,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p128_kernel(GemmArgs p) {
         dst[e] = (wave < 4 ? 0 : B128_BOFF) + r0 * 128;
     }
     auto stage = [&](int kt) {
-        const unsigned buf = (unsigned)(kt & 3) * B128_BUF;
+        const unsigned buf = (unsigned)(NB == 4 ? (kt & 3) : kt % NB) * B128_BUF;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             __builtin_amdgcn_global_load_lds((gptr_t)(src_base + off[e] + (unsigned)kt * 128u), (lptr_t)(smem + buf + dst[e]), 16, 0, 0);
@@ -296,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p128_kernel(GemmArgs p) {
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 fa[4][2], fb[2][2];
     auto phase = [&](int kt, auto DO_STAGE, auto WAIT) {
-        const unsigned cb = (unsigned)(kt & 3) * B128_BUF;
+        const unsigned cb = (unsigned)(NB == 4 ? (kt & 3) : kt % NB) * B128_BUF;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -305,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p128_kernel(GemmArgs p) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int s = 0; s < 2; ++s) fa[i][s] = *reinterpret_cast<const bf16x8*>(smem + ((cb + aRd0) ^ (s * 64)) + i * 16 * 128);
-        if constexpr (decltype(DO_STAGE)::value) stage(kt + 3);
+        if constexpr (decltype(DO_STAGE)::value) stage(kt + NB - 1);
         wait_vm<decltype(WAIT)::value>();
         wait_lds();
         barrier();
@@ -321,12 +349,14 @@ __global__ __launch_bounds__(512, 2) void gemm8p128_kernel(GemmArgs p) {
         barrier();
     };
     const int nk = p.K / BK;
-    stage(0); stage(1); stage(2);
-    wait_vm<8>();
+#pragma unroll
+    for (int t = 0; t < NB - 1; ++t) stage(t);
+    wait_vm<4 * (NB - 2)>();
     barrier();
     if (wr == 1) barrier();
     int kt = 0;
-    for (; kt < nk - 3; ++kt) phase(kt, std::true_type{}, std::integral_constant<int, 8>{});
+    for (; kt < nk - (NB - 1); ++kt) phase(kt, std::true_type{}, std::integral_constant<int, 4 * (NB - 2)>{});
+    if constexpr (NB == 5) { phase(kt, std::false_type{}, std::integral_constant<int, 8>{}); ++kt; }
     phase(kt, std::false_type{}, std::integral_constant<int, 4>{});
     phase(kt + 1, std::false_type{}, std::integral_constant<int, 0>{});
     phase(kt + 2, std::false_type{}, std::integral_constant<int, -1>{});
@@ -384,30 +414,213 @@ __global__ __launch_bounds__(512, 2) void gemm8p128_kernel(GemmArgs p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// 128 x 128 x 64, register-pipelined form: the fragments of K tile t+1 are read (12 ds_read_b128 per wave) WHILE the 16 MFMAs of K tile t
+// issue — two fragment sets in registers — so a phase is as long as its MFMAs, not as its LDS reads + their latency; ONE barrier per K tile,
+// all eight waves symmetric.  Ring of four 32-KiB K tiles, four tiles requested ahead:
+//   phase t:  stage K tile t+4 into buffer t & 3 (tile t was read into registers in phase t-1; those reads were retired before that phase's barrier)
+//             read K tile t+1 -> fragment set (t+1) & 1      ||      MFMAs of K tile t from fragment set t & 1
+//             vmcnt(8): tile t+2 has landed (t+3, t+4 stay in flight)  ;  lgkmcnt(0)  ;  s_barrier
+// Tail: no staging from phase nk-4 on, counts 4 / 0 / none.  Needs an even number of K tiles (static fragment-set indices, loop unrolled by 2), nk >= 4.
+__global__ __launch_bounds__(512, 2) void gemm8p128p_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int ntm = (p.M + 127) / 128, ntn = p.N / 128;
+    const int nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / ntn) * 128, n0 = (bid % ntn) * 128;
+    const int prow = lane >> 3, pc = lane & 7;
+
+    const int nb = n0 + wc * 32;
+    f32x4 rres[8];
+    const bool use_res = p.out_f32 && p.resid != nullptr;
+    if (use_res) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int m = min(m0 + wr * 64 + u * 8 + prow, p.M - 1);
+            rres[u] = *reinterpret_cast<const f32x4*>(p.resid + (long)m * p.ldr + nb + pc * 4);
+        }
+    }
+    const char* src_base = reinterpret_cast<const char*>(wave < 4 ? (const void*)p.A : (const void*)p.W);
+    unsigned off[4], dst[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int r0 = (4 * (wave & 3) + e) * 8;
+        const int lc = pc ^ (((r0 + prow) >> 1) & 7);
+        if (wave < 4) off[e] = (unsigned)min(m0 + r0 + prow, p.M - 1) * (unsigned)(p.lda * 2) + lc * 16;
+        else off[e] = (unsigned)min(n0 + r0 + prow, p.N - 1) * (unsigned)(p.ldw * 2) + lc * 16;
+        dst[e] = (wave < 4 ? 0 : B128_BOFF) + r0 * 128;
+    }
+    auto stage = [&](int kt) {
+        const unsigned buf = (unsigned)(kt & 3) * B128_BUF;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src_base + off[e] + (unsigned)kt * 128u), (lptr_t)(smem + buf + dst[e]), 16, 0, 0);
+    };
+    const int fr = lane & 15, fq = lane >> 4, swz = (fr >> 1) & 7;
+    const unsigned low = fr * 128 + ((fq ^ swz) << 4);
+    const unsigned aRd0 = wr * 64 * 128 + low, bRd0 = B128_BOFF + wc * 32 * 128 + low;
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[2][4][2], fb[2][2][2];
+    auto read_frags = [&](int kt, auto SET) {
+        constexpr int S = decltype(SET)::value;
+        const unsigned cb = (unsigned)(kt & 3) * B128_BUF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) fb[S][j][s] = *reinterpret_cast<const bf16x8*>(smem + ((cb + bRd0) ^ (s * 64)) + j * 16 * 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) fa[S][i][s] = *reinterpret_cast<const bf16x8*>(smem + ((cb + aRd0) ^ (s * 64)) + i * 16 * 128);
+    };
+    auto mfmas = [&](auto SET) {
+        constexpr int S = decltype(SET)::value;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[S][j][s], fa[S][i][s], acc[i][j], 0, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    // CUR = fragment set of K tile kt; DO_STAGE: request K tile kt+4; DO_READ: read K tile kt+1; WAIT: vmcnt count (-1 none)
+    auto phase = [&](int kt, auto CUR, auto DO_STAGE, auto DO_READ, auto WAIT) {
+        constexpr int C = decltype(CUR)::value;
+        if constexpr (decltype(DO_STAGE)::value) stage(kt + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (decltype(DO_READ)::value) read_frags(kt + 1, std::integral_constant<int, 1 - C>{});
+        mfmas(CUR);
+        if constexpr (decltype(DO_READ)::value) {
+#pragma unroll
+            for (int g = 0; g < 12; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one DS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vm<decltype(WAIT)::value>();
+        if constexpr (decltype(DO_READ)::value) wait_lds();
+        barrier();
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    const int nk = p.K / BK;
+    stage(0); stage(1); stage(2); stage(3);
+    wait_vm<12>();
+    barrier();
+    read_frags(0, I0{});
+    wait_vm<8>();
+    wait_lds();
+    barrier();
+    int kt = 0;
+    for (; kt < nk - 4; kt += 2) {
+        phase(kt, I0{}, T{}, T{}, std::integral_constant<int, 8>{});
+        phase(kt + 1, I1{}, T{}, T{}, std::integral_constant<int, 8>{});
+    }
+    phase(kt, I0{}, F{}, T{}, std::integral_constant<int, 4>{});
+    phase(kt + 1, I1{}, F{}, T{}, std::integral_constant<int, 0>{});
+    phase(kt + 2, I0{}, F{}, T{}, std::integral_constant<int, -1>{});
+    phase(kt + 3, I1{}, F{}, F{}, std::integral_constant<int, -1>{});
+
+    // ---- epilogue (as gemm8p128_kernel)
+    char* reg = smem + wave * 8192;
+    f32x4 b4[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        b4[j] = (p.bias_mode == 1) ? *reinterpret_cast<const f32x4*>(p.bias + nb + j * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.out_f32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 v = acc[i][j] + b4[j];
+                if (p.act == 1) v = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+                else if (p.act == 2) v = f32x4{gelu_tanh(v.x), gelu_tanh(v.y), gelu_tanh(v.z), gelu_tanh(v.w)};
+                const int row = i * 16 + fr;
+                *reinterpret_cast<f32x4*>(reg + row * 128 + (((j * 4 + fq) ^ swz) << 4)) = v;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float* C = reinterpret_cast<float*>(p.C);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = u * 8 + prow;
+            f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * 128 + ((pc ^ ((row >> 1) & 7)) << 4));
+            if (use_res) v = rres[u] + p.alpha * v;
+            const int m = m0 + wr * 64 + row;
+            if (m < p.M) *reinterpret_cast<f32x4*>(C + (long)m * p.ldc + nb + pc * 4) = v;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 v = acc[i][j] + b4[j];
+                if (p.act == 1) v = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+                else if (p.act == 2) v = f32x4{gelu_tanh(v.x), gelu_tanh(v.y), gelu_tanh(v.z), gelu_tanh(v.w)};
+                const bf16x4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+                const int row = i * 16 + fr;
+                *reinterpret_cast<bf16x4*>(reg + row * 128 + (((j * 2 + (fq >> 1)) ^ (swz & 3)) << 4) + (fq & 1) * 8) = o;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+        const int r4 = lane >> 2, c4 = lane & 3;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = u * 16 + r4;
+            const uint4 v = *reinterpret_cast<const uint4*>(reg + row * 128 + ((c4 ^ ((row >> 1) & 3)) << 4));
+            const int m = m0 + wr * 64 + row;
+            if (m < p.M) *reinterpret_cast<uint4*>(C + (long)m * p.ldc + nb + c4 * 8) = v;
+        }
+    }
+}
+
 }  // namespace
 
-bool gemm_8p_supported(const GemmArgs& a) {
+bool gemm_8p_supported(const GemmArgs& a, bool conv) {
     if (a.M <= 0 || a.N <= 0 || (a.N % TB) != 0 || (a.K % BK) != 0 || a.K < 2 * BK) return false;
     if (a.out_f32 || a.resid || a.col_T || a.bias_mode == 2) return false;
-    if (((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) || ((uintptr_t)a.C & 15) || (a.lda % 8) || (a.ldw % 8) || (a.ldc % 8)) return false;
+    if (((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) || ((uintptr_t)a.C & 15) || (a.ldw % 8) || (a.ldc % 8)) return false;
     if (a.bias_mode == 1 && ((uintptr_t)a.bias & 15)) return false;
-    if ((long)a.M * a.lda * 2 >= (1l << 32) || (long)a.N * a.ldw * 2 >= (1l << 32)) return false;     // 32-bit source offsets
+    if ((long)a.N * a.ldw * 2 >= (1l << 32)) return false;                                             // 32-bit source offsets
+    if (conv) {
+        if ((a.Cin % BK) != 0 || a.Fout <= 0 || a.Tout <= 0) return false;
+        if ((long)cdiv(a.M, (long)a.Fout * a.Tout) * a.Tin * a.Fin * a.Cin * 2 >= (1l << 32)) return false;
+    } else if ((a.lda % 8) || (long)a.M * a.lda * 2 >= (1l << 32)) return false;
     return true;
 }
 
-int gemm_8p_launch(const GemmArgs& a, hipStream_t stream) {
+int gemm_8p_launch(const GemmArgs& a, bool conv, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
         attr_set = true;
     }
     const int grid = cdiv(a.M, TB) * (a.N / TB);
-    hipLaunchKernelGGL(gemm8p_kernel, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
+    if (conv) hipLaunchKernelGGL(gemm8p_kernel<true>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
+    else hipLaunchKernelGGL(gemm8p_kernel<false>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
     return MI_OK;
 }
 
 bool gemm_8p128_supported(const GemmArgs& a) {
-    if (a.M <= 0 || a.N <= 0 || (a.N % 128) != 0 || (a.K % BK) != 0 || a.K < 4 * BK) return false;
+    if (a.M <= 0 || a.N <= 0 || (a.N % 128) != 0 || (a.K % BK) != 0 || a.K < 5 * BK) return false;
     if (a.col_T || a.bias_mode == 2) return false;
     if (a.resid && !a.out_f32) return false;
     if (((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) || ((uintptr_t)a.C & 15) || (a.lda % 8) || (a.ldw % 8)) return false;
@@ -418,13 +631,21 @@ bool gemm_8p128_supported(const GemmArgs& a) {
     return true;
 }
 
-int gemm_8p128_launch(const GemmArgs& a, hipStream_t stream) {
+int gemm_8p128_launch(const GemmArgs& a, int ring, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * B128_BUF);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p128_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * B128_BUF);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p128_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * B128_BUF);
         attr_set = true;
     }
     const int grid = cdiv(a.M, 128) * (a.N / 128);
-    hipLaunchKernelGGL(gemm8p128_kernel, dim3(grid), dim3(512), (size_t)4 * B128_BUF, stream, a);
+    if (ring == 0) {          // register-pipelined form (even number of K tiles)
+        static bool attr_p = false;
+        if (!attr_p) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p128p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * B128_BUF); attr_p = true; }
+        hipLaunchKernelGGL(gemm8p128p_kernel, dim3(grid), dim3(512), (size_t)4 * B128_BUF, stream, a);
+        return MI_OK;
+    }
+    if (ring == 5) hipLaunchKernelGGL(gemm8p128_kernel<5>, dim3(grid), dim3(512), (size_t)5 * B128_BUF, stream, a);
+    else hipLaunchKernelGGL(gemm8p128_kernel<4>, dim3(grid), dim3(512), (size_t)4 * B128_BUF, stream, a);
     return MI_OK;
 }

@@ -28,7 +28,7 @@ bool gemm_256_supported(const GemmArgs& a);
 int gemm_256_launch(const GemmArgs& a, hipStream_t stream);
 
 // gemm_8p.hip: 256x256x64 tiles, 8 waves, phase-interleaved schedule on a two-deep LDS ring (bf16 out, N % 256 == 0, K % 64 == 0, K >= 128)
-bool gemm_8p_supported(const GemmArgs& a);
-int gemm_8p_launch(const GemmArgs& a, hipStream_t stream);
+bool gemm_8p_supported(const GemmArgs& a, bool conv);
+int gemm_8p_launch(const GemmArgs& a, bool conv, hipStream_t stream);
 bool gemm_8p128_supported(const GemmArgs& a);
-int gemm_8p128_launch(const GemmArgs& a, hipStream_t stream);
+int gemm_8p128_launch(const GemmArgs& a, int ring, hipStream_t stream);

@@ -18,8 +18,8 @@ h = _lib.lib()
 
 shapes = [  # M, N, K, kind
     (8000, 2048, 512, "gelu"), (8000, 2048, 512, "none"), (8000, 1536, 512, "none"), (8000, 2048, 128, "gelu"), (8000, 2048, 192, "none"),
-    (8000, 512, 2048, "resid"), (8000, 512, 1024, "resid"), (8000, 512, 512, "none"), (8000, 512, 1024, "none"),
-    (777, 512, 256, "gelu"), (256, 256, 128, "none"), (4096, 4096, 4096, "none"), (8192, 8192, 8192, "none"),
+    (8000, 512, 2048, "resid"), (8000, 512, 1024, "resid"), (8000, 512, 512, "none"), (8000, 512, 1024, "none"), (8000, 512, 5120, "f32"),
+    (777, 512, 320, "gelu"), (777, 384, 320, "resid"), (256, 256, 128, "none"), (4096, 4096, 4096, "none"), (8192, 8192, 8192, "none"),
 ]
 scratch = torch.empty(128 * 1024 * 1024, device=dev) if cold else None
 
@@ -27,6 +27,8 @@ scratch = torch.empty(128 * 1024 * 1024, device=dev) if cold else None
 def run(a, w, b, out, kind, r):
     if kind == "resid":
         return ops.gemm(a, w, b, out=out, resid=r, alpha=0.5)
+    if kind == "f32":
+        return ops.gemm(a, w, b, out=out)
     return ops.gemm(a, w, b, out=out, act="gelu" if kind == "gelu" else "none")
 
 
@@ -44,7 +46,7 @@ for (m, n, k, kind) in shapes:
     outs = {}
     for v in variants:
         h.mi_gemm_set_variant(v)
-        out = torch.full((m, n), float("nan"), device=dev, dtype=torch.float32 if kind == "resid" else torch.bfloat16)
+        out = torch.full((m, n), float("nan"), device=dev, dtype=torch.float32 if kind in ("resid", "f32") else torch.bfloat16)
         r = r0.clone() if r0 is not None else None
         run(a, w, b, out, kind, r)
         torch.cuda.synchronize()
@@ -55,7 +57,7 @@ for (m, n, k, kind) in shapes:
         line += f" | v{variants[0]}==v{variants[-1]}: {bool(torch.equal(outs[variants[0]], outs[variants[-1]]))} maxdiff {float((outs[variants[0]].float() - outs[variants[-1]].float()).abs().max()):.5f}"
     # interleaved timing rounds
     iters = 20 if m * n * k < 1e11 else 5
-    out = torch.empty((m, n), device=dev, dtype=torch.float32 if kind == "resid" else torch.bfloat16)
+    out = torch.empty((m, n), device=dev, dtype=torch.float32 if kind in ("resid", "f32") else torch.bfloat16)
     r = r0
     best = {v: [] for v in variants}
     for rnd in range(5):
