@@ -50,7 +50,30 @@ def build(force: bool = False) -> str:
         objs = list(ex.map(_compile, SOURCES))
     if force or _stale(OUT, objs):
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs], check=True)
+        check_no_packed_f32(objs)
     return OUT
+
+
+def check_no_packed_f32(objs) -> None:
+    """Fail the build if any gfx950 code object of the library contains packed-f32 VALU arithmetic (v_pk_{add,mul,fma}_f32): the flag above is passed
+    through -Xclang and a toolchain that stopped honouring it would re-open the co-residency fault silently (DESIGN.md 'Concurrent kernels')."""
+    import re
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    bundler, objdump, objcopy = (os.path.join(llvm, t) for t in ("clang-offload-bundler", "llvm-objdump", "llvm-objcopy"))
+    if not all(os.path.exists(t) for t in (bundler, objdump, objcopy)):
+        raise RuntimeError(f"cannot verify the packed-f32-free build: clang-offload-bundler / llvm-objdump / llvm-objcopy not found under {llvm}")
+    pat = re.compile(r"\bv_pk_(add|mul|fma)_f32\b")
+    with tempfile.TemporaryDirectory() as td:
+        for o in objs:
+            fb, co = os.path.join(td, os.path.basename(o) + ".fatbin"), os.path.join(td, os.path.basename(o) + ".co")
+            subprocess.run([objcopy, "-O", "binary", "--only-section=.hip_fatbin", o, fb], check=True)        # the device code of a host object
+            subprocess.run([bundler, "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fb}", f"--output={co}"], check=True)
+            dis = subprocess.run([objdump, "-d", "--mcpu=gfx950", co], check=True, capture_output=True, text=True).stdout
+            hits = pat.findall(dis)
+            if hits:
+                os.remove(OUT)
+                raise RuntimeError(f"{os.path.basename(o)}: {len(hits)} packed-f32 VALU instructions in the gfx950 code object; the library must be built without them")
 
 
 if __name__ == "__main__":

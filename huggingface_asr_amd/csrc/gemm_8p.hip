@@ -63,7 +63,7 @@ struct Ctx {
 
 // CONV: A is a channels-last activation (B, Tin, Fin, Cin), row m = (b, to, fo), k = (kh*KW + kw)*Cin + c with Cin % 64 == 0, so a K tile is one
 // tap and a 64-channel slice: the per-lane source row moves with the tap, rows that fall into the zero padding read a 16-B zero page.
-template <bool CONV>
+template <bool CONV, int ACT>     // ACT: 0 none, 1 erf-GELU, 2 tanh-GELU — compile-time, so the epilogue is straight-line code with many independent chains in flight
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -223,37 +223,42 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
     tile(kt + 1, cb, F{}, F{}, F{}, F{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, -1>{});
     if (wr == 0) barrier();              // barrier counts match; every wave's last LDS reads are retired
 
-    // ---- epilogue: bias / activation, bf16 rows through a wave-private LDS region, whole 128-B lines out
+    // ---- epilogue: bias / activation, bf16 rows through a wave-private LDS region, whole 128-B lines out.  Done in four blocks of 32 rows so that the
+    // stores of one block drain while the next block's activation (VALU-bound: ~16 instructions per element for erf-GELU) is evaluated.
     char* reg = smem + wave * 16384;
     const int fr = lane & 15, fq = lane >> 4, swz = (fr >> 1) & 7;
     const int nb = n0 + wc * 64;
+    f32x4 b4[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias_mode == 1) b4 = *reinterpret_cast<const f32x4*>(p.bias + nb + j * 16 + fq * 4);
-        const int chunk = j * 2 + (fq >> 1);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            f32x4 v = acc[i][j] + b4;
-            if (p.act == 1) v = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
-            else if (p.act == 2) v = f32x4{gelu_tanh(v.x), gelu_tanh(v.y), gelu_tanh(v.z), gelu_tanh(v.w)};
-            const bf16x4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
-            const int row = i * 16 + fr;
-            *reinterpret_cast<bf16x4*>(reg + row * 128 + ((chunk ^ swz) << 4) + (fq & 1) * 8) = o;
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int j = 0; j < 4; ++j)
+        b4[j] = (p.bias_mode == 1) ? *reinterpret_cast<const f32x4*>(p.bias + nb + j * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     const int prow = lane >> 3, pc = lane & 7;
     bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int row = u * 8 + prow;
-        const uint4 v = *reinterpret_cast<const uint4*>(reg + row * 128 + ((pc ^ ((row >> 1) & 7)) << 4));
-        const int m = m0 + wr * 128 + row;
-        if (m < p.M) *reinterpret_cast<uint4*>(C + (long)m * p.ldc + nb + pc * 8) = v;
+    for (int blk = 0; blk < 4; ++blk) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = blk * 2 + ii;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = acc[i][j] + b4[j];
+                if constexpr (ACT == 1) v = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+                else if constexpr (ACT == 2) v = f32x4{gelu_tanh(v.x), gelu_tanh(v.y), gelu_tanh(v.z), gelu_tanh(v.w)};
+                const bf16x4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+                const int row = i * 16 + fr;
+                *reinterpret_cast<bf16x4*>(reg + row * 128 + (((j * 2 + (fq >> 1)) ^ swz) << 4) + (fq & 1) * 8) = o;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = blk * 4; u < blk * 4 + 4; ++u) {
+            const int row = u * 8 + prow;
+            const uint4 v = *reinterpret_cast<const uint4*>(reg + row * 128 + ((pc ^ ((row >> 1) & 7)) << 4));
+            const int m = m0 + wr * 128 + row;
+            if (m < p.M) *reinterpret_cast<uint4*>(C + (long)m * p.ldc + nb + pc * 8) = v;
+        }
     }
 }
-
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // 128 x 128 x 64 variant for the N = 512 GEMMs (FFN out, attention out, cgMLP out, merge): 8 waves (2 x 4), wave tile 64 x 32 =
@@ -607,15 +612,18 @@ bool gemm_8p_supported(const GemmArgs& a, bool conv) {
 }
 
 int gemm_8p_launch(const GemmArgs& a, bool conv, hipStream_t stream) {
+    using kern_t = void (*)(GemmArgs);
+    static const kern_t kerns[2][3] = {{gemm8p_kernel<false, 0>, gemm8p_kernel<false, 1>, gemm8p_kernel<false, 2>},
+                                       {gemm8p_kernel<true, 0>, gemm8p_kernel<true, 1>, gemm8p_kernel<true, 2>}};
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+        for (int c = 0; c < 2; ++c)
+            for (int t = 0; t < 3; ++t) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[c][t]), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
         attr_set = true;
     }
+    if (a.act < 0 || a.act > 2) return MI_ERR_ARG;
     const int grid = cdiv(a.M, TB) * (a.N / TB);
-    if (conv) hipLaunchKernelGGL(gemm8p_kernel<true>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
-    else hipLaunchKernelGGL(gemm8p_kernel<false>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
+    hipLaunchKernelGGL(kerns[conv ? 1 : 0][a.act], dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
     return MI_OK;
 }
 

@@ -336,9 +336,9 @@ int gemm_glds_launch(const GemmArgs& a_in, bool conv, hipStream_t stream) {
     if (!conv && g_variant == 20 && gemm_256_supported(a)) return gemm_256_launch(a, stream);
     // wide-N bf16-out GEMMs (FFN in, cgMLP in, QKV): 256x256 tiles on the phase-interleaved schedule (gemm_8p.hip) once the tiles fill half the chip;
     // HFASR_GEMM_VARIANT=40 takes it for every supported shape (tests), 41 never
-    if (g_variant != 41 && gemm_8p_supported(a, conv) && (t256 >= 128 || g_variant == 40)) return gemm_8p_launch(a, conv, stream);
+    if (g_variant != 41 && g_variant != 30 && g_variant != 31 && gemm_8p_supported(a, conv) && (t256 >= 128 || g_variant == 40)) return gemm_8p_launch(a, conv, stream);
     // N = 512-class GEMMs: 128x128 tiles on the same schedule (fp32 + residual or bf16 out); 42 = wherever supported, 43 = never
-    if (!conv && g_variant != 41 && g_variant != 43 && gemm_8p128_supported(a) && (cdiv(a.M, 128) * (a.N / 128) >= 128 || g_variant == 40 || g_variant == 42))
+    if (!conv && g_variant != 41 && g_variant != 43 && g_variant != 30 && g_variant != 31 && gemm_8p128_supported(a) && (cdiv(a.M, 128) * (a.N / 128) >= 128 || g_variant == 40 || g_variant == 42))
         return gemm_8p128_launch(a, g_variant == 45 ? 5 : (g_variant != 47 && (a.K % 128) == 0) ? 0 : 4, stream);   // 0 = register-pipelined form (even number of K tiles); 47 forces the two-segment form
     if (g_variant == 6 && t256 >= 200 && (a.N % 256) == 0) {   // opt-in: no gain on this workload's K=512 shapes, spills with look-ahead
         const size_t l = (size_t)2 * (256 + 256) * BK * 2;

@@ -272,7 +272,8 @@ class GradSync:
     model, of the order of 1–3 ms over xGMI against a 35 ms step.  `overlap=True` (or HFASR_DP_OVERLAP=1): each range is
     all-reduced as soon as it is final (reverse layer order), the collective of layer l running beside the backward of layers < l.
     That puts RCCL's kernels on the same CUs as the LDS-DMA GEMMs; a kernel of ours sharing a CU with those GEMMs from another
-    stream produced wrong values on MI355X ('Concurrent kernels'), so co-scheduling stays opt-in until that is understood."""
+    stream produced wrong values on MI355X ('Concurrent kernels': a packed-f32 VALU instruction loses a product; our library is built without packed
+    ops, librccl is not ours to rebuild), so co-scheduling stays opt-in and warns on the nccl backend."""
 
     def __init__(self, flat_g: torch.Tensor, group=None, enabled=True, overlap=None):
         import torch.distributed as dist
@@ -282,6 +283,12 @@ class GradSync:
         self.flat_g, self.group, self.pending = flat_g, group, []
         self.overlap = (os.environ.get("HFASR_DP_OVERLAP", "0") == "1") if overlap is None else bool(overlap)
         self._span = None
+        if self.on and self.overlap and dist.get_backend(group) == "nccl":
+            import warnings
+            warnings.warn("GradSync(overlap=True) on RCCL: the all-reduce kernels (librccl's gfx950 code objects contain v_pk_{add,mul,fma}_f32) then run beside the "
+                          "backward's LDS-DMA GEMMs on shared CUs; a packed-f32 kernel in that position lost products on MI355X (DESIGN.md 'Concurrent kernels', "
+                          "tools/dbg/README.md).  Unverified pairing: gradients may be silently wrong; the default (one collective after the backward) avoids it.",
+                          RuntimeWarning, stacklevel=2)
 
     def launch(self, lo: int, hi: int):
         if not self.on or hi <= lo:

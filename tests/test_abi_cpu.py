@@ -58,3 +58,21 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.HipLibraryError):
         _lib.lib()
+
+
+def test_library_code_objects_hold_no_packed_f32_arithmetic():
+    """DESIGN.md 'Concurrent kernels': the library must stay free of v_pk_{add,mul,fma}_f32; build.py checks it after linking, this re-checks the objects
+    of the build that produced the .so under test (skipped when only the .so travelled, e.g. on the GPU box)."""
+    import glob
+    import os
+    import pytest
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(os.path.dirname(here), "huggingface_asr_amd", "csrc")
+    objs = sorted(glob.glob(os.path.join(csrc, "build", "*.o")))
+    if not objs or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no object files / no llvm-objdump here")
+    sys.path.insert(0, csrc)
+    import build
+    assert len(objs) == len(build.SOURCES)
+    build.check_no_packed_f32(objs)

@@ -58,8 +58,46 @@ __global__ __launch_bounds__(256) void dwconv31_kernel(DwArgs p) {
                 __builtin_amdgcn_s_sleep(4);
                 __builtin_amdgcn_sched_barrier(0);
 #endif
+#if VAR == 4
+                // round 2: is the failure a LOST WRITE-BACK of the packed FMA?  The destination pair is a register pair of its own, pre-set to a sentinel
+                // (777 / 778); the FMA is written by hand so that the destination is neither a source nor the accumulator input.  A corrupted tile word
+                // equal to the sentinel = the low-half result of v_pk_fma_f32 never reached the register file.
+                f32x2 xn[4], gg[4] = {{g0.x, g0.y}, {g0.z, g0.w}, {g1.x, g1.y}, {g1.z, g1.w}}, bb[4] = {{b0.x, b0.y}, {b0.z, b0.w}, {b1.x, b1.y}, {b1.z, b1.w}}, dd[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    xn[q] = f32x2{(f[2 * q] - mu) * rs, (f[2 * q + 1] - mu) * rs};
+                    dd[q] = f32x2{777.0f, 778.0f};
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "+v"(dd[q]) : "v"(xn[q]), "v"(gg[q]), "v"(bb[q]));
+                lo = f32x4{dd[0].x, dd[0].y, dd[1].x, dd[1].y};
+                hi = f32x4{dd[2].x, dd[2].y, dd[3].x, dd[3].y};
+#elif VAR == 6
+                // packed normalisation (compiler: v_pk_mul_f32), SCALAR affine step written by hand (v_fma_f32 x 8): which packed instruction is the victim?
+                float xn6[8], o6[8];
+                const float gg6[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb6[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) xn6[q] = (f[q] - mu) * rs;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(o6[q]) : "v"(xn6[q]), "v"(gg6[q]), "v"(bb6[q]));
+                lo = f32x4{o6[0], o6[1], o6[2], o6[3]};
+                hi = f32x4{o6[4], o6[5], o6[6], o6[7]};
+#elif VAR == 7
+                // SCALAR normalisation written by hand (v_sub_f32 / v_mul_f32), packed affine step left to the compiler (v_pk_fma_f32)
+                float xn7[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float d;
+                    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(f[q]), "v"(mu));
+                    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(xn7[q]) : "v"(d), "v"(rs));
+                }
+                lo = f32x4{xn7[0] * g0.x + b0.x, xn7[1] * g0.y + b0.y, xn7[2] * g0.z + b0.z, xn7[3] * g0.w + b0.w};
+                hi = f32x4{xn7[4] * g1.x + b1.x, xn7[5] * g1.y + b1.y, xn7[6] * g1.z + b1.z, xn7[7] * g1.w + b1.w};
+#else
                 lo = f32x4{(f[0] - mu) * rs * g0.x + b0.x, (f[1] - mu) * rs * g0.y + b0.y, (f[2] - mu) * rs * g0.z + b0.z, (f[3] - mu) * rs * g0.w + b0.w};
                 hi = f32x4{(f[4] - mu) * rs * g1.x + b1.x, (f[5] - mu) * rs * g1.y + b1.y, (f[6] - mu) * rs * g1.z + b1.z, (f[7] - mu) * rs * g1.w + b1.w};
+#endif
             } else {
                 lo = f32x4{f[0], f[1], f[2], f[3]};
                 hi = f32x4{f[4], f[5], f[6], f[7]};

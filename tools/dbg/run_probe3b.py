@@ -40,7 +40,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
         g0, b0 = float(G[c0 + c]), float(Bv[c0 + c])
         msg = f"   blk {blk} r {r} c {c}: x {x:.6f} g {g0:.6f} b {b0:.6f} good {good:.6f} bad {bad:.6f}"
         # hypotheses
-        hyp = {"x*g (b=0)": x * g0, "b only (g=0)": b0, "x (g=1,b=0)": x, "0": 0.0, "x+b (g=1)": x + b0}
+        hyp = {"x*g (b=0)": x * g0, "b only (g=0)": b0, "x (g=1,b=0)": x, "0": 0.0, "x+b (g=1)": x + b0, "SENTINEL 777 (low-half write-back lost)": 777.0, "SENTINEL 778 (high-half write-back lost)": 778.0}
         for name, v in hyp.items():
             if abs(v - bad) < 1e-5 * max(1, abs(bad)): msg += f"  == {name}"
         # other channel's gamma / beta?
