@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """Headline benchmark: audio-seconds/sec, encoder forward + CTC, E-Branchformer-base (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 outside torchrun: the bench starts its N ranks itself, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --train                             (BASELINE config 3: data-parallel training step, gradient all-reduce over RCCL)
 
 A step = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
   32 x 10 s of 16 kHz audio -> log-mel + utterance CMVN (HIP) -> pad to 1000 frames -> Conv2d sub-sampling ->
@@ -46,7 +47,7 @@ def algorithmic_gflop_per_utt(cfg, T2):
     return 2.0 * mac / 1e9
 
 
-def pmc_traffic_bytes(kernel_prefix="gemm_glds_kernel<128, 64, 2, 2, 2, false>"):
+def pmc_traffic_bytes(kernel_prefix="gemm8p_kernel<false, 1>"):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*pmc*per_launch.txt: rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate runs of this command, FETCH_SIZE doubled for 16-B/lane reads as MI355X_MICROARCH.md prescribes).  PMC counters cannot
     be collected inside the timed region, so the bench line carries the recorded value and names its source; None if the file is absent."""
@@ -90,32 +91,142 @@ def cpu_baseline(cfg, sd, seconds_budget=25.0):
                 sample=f"{it} x (B={B} x {SECONDS}s clips): numpy float64 fbank+CMVN, torch-CPU fp32 encoder + CTC head")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks on this node; without a torchrun environment the bench starts them itself")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 32 forward / 96 --train)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events on the GEMM kernel")
-    ap.add_argument("--event-stride", type=int, default=7, help="time every n-th GEMM launch with HIP events (1 = all)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip the separate HIP-event pass over the dense GEMM launches (roofline leg)")
+    ap.add_argument("--event-steps", type=int, default=5, help="steps of the separate roofline pass (every dense launch timed, stride 1; never inside the timed region)")
     ap.add_argument("--pos", default="relative", choices=["relative", "rotary"])
-    args = ap.parse_args()
+    ap.add_argument("--train", action="store_true", help="BASELINE config 3 instead of the headline: data-parallel TRAINING step of the joint AED model "
+                                                         "(small encoder + 6x256 GPT-2 decoder, per-GPU batch 96, 1-20 s clips), gradient all-reduce over RCCL")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check on a box without GPUs: gloo, no HIP work, value null")
+    return ap.parse_args(argv)
 
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` outside torchrun: start N ranks of this script (one per GPU) with torch.distributed.run and hand their exit code on.
+    This process has not touched the GPU (no torch.cuda / HIP call), and it stays the parent: nothing is exec'ed over it."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+
+
+def dry_run(args, world, rank):
+    """no GPU on this box: exercise the launcher, the rendezvous and the timing collectives only (explicit flag; never a silent fallback)"""
     from huggingface_asr_amd import parallel as PL
+    PL.init("gloo")
+    import torch.distributed as td
+    dt = PL.timed(lambda: time.sleep(0.001), args.steps)
+    if rank == 0:
+        print(json.dumps({"metric": "audio-seconds/sec encoder fwd+CTC, E-Branchformer-base", "value": None, "unit": "audio-seconds/sec", "n_gpus": world,
+                          "rccl_ranks": td.get_world_size() if td.is_initialized() else 1, "backend": "gloo", "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                          "data": "none", "dry_run": True, "config": {"workload": "dry run: no HIP work (launcher / rendezvous / timing collectives only)"}}), flush=True)
+    if td.is_initialized():
+        td.barrier(); td.destroy_process_group()
+
+
+def train_bench(args, world, rank, dev, PL):
+    """BASELINE config 3: one data-parallel training step of the joint CTC/attention model per rank shard (recipes_v0.0.1/librispeech_aed/train_small_baseline.sh:
+    small encoder + 6x256 GPT-2 decoder, ctc_weight 0.3, label smoothing 0.1, fixed positions, AdamW 2e-3 / wd 1e-6, per-GPU batch 96, clips 1-20 s sorted into the batch)."""
+    import torch.distributed as td
+    from huggingface_asr_amd.train_aed import JointAEDTrainer
+    cfg = dict(shapes.SMALL, position_embeddings_type=args.pos, ctc_zero_infinity=True, ctc_loss_reduction="mean", hidden_dropout=0.0, activation_dropout=0.0,
+               attention_dropout=0.0, final_dropout=0.0, feat_proj_dropout=0.0, csgu_conv_dropout=0.0, layerdrop=0.0, apply_spec_augment=False)
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()}
+    dcfg = dict(vocab_size=5000, n_embd=256, n_layer=6, n_head=4, n_positions=1024, head_locations=[], head_weights=[1.0], lsm_factor=0.1,
+                layer_norm_epsilon=1e-5, pos_emb_fixed=True, tie_word_embeddings=False)
+    jcfg = dict(ctc_weight=0.3, pad_token_id=3, decoder_start_token_id=1)
+    B = args.batch or 96
+    tr = JointAEDTrainer(cfg, dcfg, jcfg, dev, lr=2e-3, weight_decay=1e-6)
+    tr.enc.load_state_dict(sd)
+    g = torch.Generator().manual_seed(1)
+    for s_ in tr.store.specs.values():                      # seeded decoder weights straight into the packed store (same on every rank)
+        zero = s_.name.endswith(("_b", "bqkv", "bq", "bkv", "bo", "bco", "bfc", "bpr"))
+        tr.store.p(s_.name).copy_((torch.ones(s_.shape) if s_.name.endswith("_g") else torch.randn(s_.shape, generator=g) * (0.0 if zero else 0.02)).to(dev))
+    tr.store.refresh_mirrors(cast=True)
+    rng = np.random.default_rng(rank)
+    fl = np.sort(rng.integers(100, 2001, size=B))[::-1].copy()
+    T = 2000                                                # every rank pads to the same 20 s bucket (weak scaling: same work per rank)
+    feats = torch.from_numpy(synth.normal(100 + rank, "feats", (B, T, 80), 1.0)).to(dev)
+    lens = torch.from_numpy(fl.astype(np.int32)).to(dev)
+    labels = torch.from_numpy(synth.labels(rank, B, 60, cfg["vocab_size"], lo=5)).to(dev)
+    for b in range(B):
+        labels[b, max(2, int(fl[b] / 100 * 3)):] = -100
+    state = {}
+
+    def one():
+        state["o"] = tr.train_step(feats, lens, labels)
+    for _ in range(args.warmup):
+        one()
+    dt = PL.timed(one, args.steps, sync=torch.cuda.synchronize, device=dev)
+    # the gradient all-reduce on its own: same buffers, same message sizes, timed on the compute stream (it runs after the backward by default)
+    ar_ms = None
+    if world > 1:
+        bufs = [tr.enc.store.flat_g, tr.store.flat_g]
+        for _ in range(3):
+            for b_ in bufs: td.all_reduce(b_)
+        torch.cuda.synchronize(); td.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            for b_ in bufs: td.all_reduce(b_)
+        e1.record(); torch.cuda.synchronize()
+        ar_ms = round(e0.elapsed_time(e1) / 10, 3)
+    if rank == 0:
+        n_params = tr.store.n + tr.enc.store.n
+        # every rank drew its own lengths; the job's audio = sum over ranks (same distribution): use this rank's sum x world
+        sec = world * float(fl.sum()) / 100.0 * args.steps
+        print(json.dumps({"metric": "audio-seconds/sec, joint CTC/attention TRAINING step (fwd+bwd+AdamW), ED-small, DP", "value": round(sec / dt, 1),
+                          "unit": "audio-seconds/sec (un-padded audio)", "n_gpus": world, "rccl_ranks": td.get_world_size() if td.is_initialized() else 1,
+                          "backend": td.get_backend() if td.is_initialized() else "none", "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                          "data": "synthetic",
+                          "config": {"workload": "BASELINE config 3: small E-Branchformer encoder + 6x256 GPT-2 decoder, joint CTC/attention loss, AdamW; "
+                                                 f"{B} clips of 1-20 s per GPU padded to 2000 frames", "per_gpu_batch": B, "frames": T, "n_params": n_params,
+                                     "parallelism": f"dp{world}: SUM all-reduce of {n_params * 4 / 1e6:.0f} MB fp32 gradients after the backward",
+                                     "loss": round(float(state["o"]["loss"]), 4)},
+                          "all_reduce_ms": ar_ms, "all_reduce_note": "the step's gradient all-reduce timed on its own (same buffers), per step" if ar_ms else None,
+                          "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)
+    if world > 1:
+        td.barrier(); td.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    from huggingface_asr_amd import parallel as PL
+    in_torchrun = "WORLD_SIZE" in os.environ
+    if not in_torchrun and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     world, rank, local = PL.env_world()
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); pass the same number to both")
+    if args.dry_run:
+        return dry_run(args, world, rank)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible. The hot path is HIP-only (no CPU fallback); use --dry-run to check the launcher on a GPU-less box.")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     PL.init("nccl", dev)                      # RCCL; no-op for one process
     dist = world > 1
-    if dist:
-        import torch.distributed as td
+    import torch.distributed as td
+    if args.train:
+        return train_bench(args, world, rank, dev, PL)
 
     cfg = dict(shapes.BASE, position_embeddings_type=args.pos, ctc_zero_infinity=True, ctc_loss_reduction="mean")
     sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()}
     eng = EBranchformerEngine(cfg, dev)
     eng.load_state_dict(sd)
-    B = args.batch
+    B = args.batch or BATCH
     wave = torch.from_numpy(synth.waveforms(100 + rank, B, SR * SECONDS)).to(dev)       # resident in HBM
     labels = torch.from_numpy(synth.labels(rank, B, U, cfg["vocab_size"])).to(dev)
     tables = FB.FbankTables(80)
@@ -128,34 +239,32 @@ def main():
         return loss
 
     L = _lib.lib()
-    use_events = not args.no_kernel_events
-    n_gemm_per_step = 3 + cfg["num_hidden_layers"] * 10 + 1
-    if use_events:
-        _lib.check(L.mi_profile_create(n_gemm_per_step * args.steps + 64), "mi_profile_create")
-
+    use_events = not args.no_kernel_events and rank == 0
+    n_gemm_per_step = 4 + cfg["num_hidden_layers"] * 10 + 1
     for _ in range(args.warmup):
         loss = step()
-    # HIP events (recorded on the launch stream) bracket every 7th launch of the dense GEMM kernel inside the timed region:
-    # 7 is coprime with the 10 GEMMs per layer, so every shape is sampled evenly; timing all 163 launches/step costs ~10 %.
-    if use_events:
-        L.mi_profile_reset(); L.mi_profile_enable(args.event_stride)
     state = {}
 
     def one():
         state["loss"] = step()
     dt = PL.timed(one, args.steps, sync=torch.cuda.synchronize, device=dev)      # barrier + sync both sides, MAX over ranks
-    loss = state["loss"]
-    if use_events:
-        L.mi_profile_enable(0)
-    loss_v = float(loss)
+    loss_v = float(state["loss"])
 
+    # ---- roofline leg, AFTER the timed region: every dense contraction launch of `event_steps` further steps is bracketed by HIP events recorded on the
+    # launch stream (mi_profile_*; the nn.Linear GEMMs and the implicit-GEMM conv), achieved = sum of their algorithmic FLOPs / sum of their durations
     roof = None
-    if use_events and rank == 0:
+    if use_events:
+        _lib.check(L.mi_profile_create(n_gemm_per_step * args.event_steps + 64), "mi_profile_create")
+        L.mi_profile_reset(); L.mi_profile_enable(1)
+        for _ in range(args.event_steps):
+            step()
+        torch.cuda.synchronize()
+        L.mi_profile_enable(0)
         ms, fl = C.c_double(0), C.c_double(0)
         _lib.check(L.mi_profile_summary(C.byref(ms), C.byref(fl)), "mi_profile_summary")
         n = L.mi_profile_count()
         if n and ms.value > 0:
-            # an event bracket around a ~30 us kernel also times the dispatch gap of the pair itself: calibrate it with empty pairs on the
+            # an event bracket around a ~20 us kernel also times the dispatch gap of the pair itself: calibrate it with empty pairs on the
             # same stream and subtract it per launch, so the average is the kernel's own duration (what rocprofv3 --kernel-trace reports)
             cal = C.c_double(0)
             _lib.check(L.mi_profile_calibrate(torch.cuda.current_stream().cuda_stream, 101, C.byref(cal)), "mi_profile_calibrate")
@@ -163,22 +272,26 @@ def main():
             ker_ms = max(ms.value - n * cal.value, 0.5 * ms.value)
             ach = fl.value / (ker_ms * 1e-3) / 1e12
             traffic, tsrc = pmc_traffic_bytes()
-            roof = dict(bound="mfma", kernel="gemm_glds_kernel<128,64,2,2,2,false> (the nn.Linear GEMMs; the two longest of the 149 per step run its 128x128 form)", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic, traffic_unit="HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
-                        traffic_source=tsrc, launches=n, avg_launch_us=round(ker_ms * 1e3 / n, 2),
-                        avg_launch_us_raw_events=round(raw_us, 2), event_pair_overhead_us=round(cal.value * 1e3, 2),
-                        gflop_per_launch=round(fl.value / n / 1e9, 3), sampled_every=args.event_stride)
+            roof = dict(bound="mfma", kernel="all dense contraction launches of the step: gemm8p_kernel (256x256 tiles: FFN in, cgMLP in, QKV, conv2), gemm8p128p_kernel "
+                                             "(128x128 tiles: FFN out, attention out, cgMLP out, merge, front-end out), gemm_glds_kernel (CTC head)",
+                        achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic,
+                        traffic_unit="HBM bytes per launch of gemm8p_kernel<false,1> (PMC FETCH_SIZE x2 + WRITE_SIZE)", traffic_source=tsrc, launches=n,
+                        launches_per_step=n // args.event_steps, avg_launch_us=round(ker_ms * 1e3 / n, 2), avg_launch_us_raw_events=round(raw_us, 2),
+                        event_pair_overhead_us=round(cal.value * 1e3, 2), gflop_per_launch=round(fl.value / n / 1e9, 3), sampled_every=1,
+                        measured="separate pass after the timed region")
 
     if rank == 0:
         audio_s = world * B * SECONDS * args.steps
         T2 = eng.out_frames(1000)
         rec = {
             "metric": "audio-seconds/sec encoder fwd+CTC, E-Branchformer-base", "value": round(audio_s / dt, 1),
-            "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "audio-seconds/sec", "n_gpus": world, "rccl_ranks": td.get_world_size() if td.is_initialized() else 1,
+            "backend": td.get_backend() if td.is_initialized() else "none", "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"E-Branchformer-base enc+CTC ({args.pos}-pos), {B}x{SECONDS}s 16kHz clips/GPU: "
-                                   "fbank+CMVN -> conv2d sub -> 16 layers -> CTC head -> CTC loss",
+                                   "fbank+CMVN -> conv2d sub -> 16 layers -> CTC head -> CTC loss"
+                                   + (" (the batch-independent projection of the relative-position table, 0.2 % of the FLOPs, is cached across steps)" if args.pos == "relative" else ""),
                        "per_gpu_batch": B, "frames": 1000, "encoder_frames": T2, "parallelism": f"replicas x{world} (no exchange step)",
                        "algorithmic_gflop_per_audio_s": round(algorithmic_gflop_per_utt(cfg, T2) / SECONDS, 3),
                        "ctc_loss": round(loss_v, 4)},

@@ -182,7 +182,7 @@ int launch(const GemmArgs& a, bool conv, hipStream_t stream) {
     if ((a.ldw % 8) != 0) return MI_ERR_ARG;
     if (conv && (a.Cin % 8) != 0) return MI_ERR_ARG;
     if (gemm_glds_supported(a, conv)) {   // LDS-DMA pipelined fast path (gemm_glds.hip)
-        const int slot = conv ? -1 : mi_profile_hook_begin(stream, 2.0 * a.M * a.N * a.K);
+        const int slot = mi_profile_hook_begin(stream, 2.0 * a.M * a.N * a.K);     // the implicit-GEMM conv is a dense contraction too
         const int rc = gemm_glds_launch(a, conv, stream);
         if (slot >= 0) mi_profile_hook_end(slot, stream);
         if (rc != MI_OK) return rc;

@@ -48,3 +48,25 @@ def test_shard_range_properties():
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in cuts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` outside torchrun starts two ranks itself; --dry-run: gloo, no HIP work, on this GPU-less box.
+    A --gpus that disagrees with the launcher's world size is refused."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                    # rank 0 prints ONE JSON line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["dry_run"] is True and rec["value"] is None and rec["steps"] == 2
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+                        os.path.join(root, "bench.py"), "--gpus", "3", "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 3 but the launcher started 2" in (r.stdout + r.stderr)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no GPU visible" in (r.stdout + r.stderr)      # the real bench never falls back to the CPU
