@@ -42,6 +42,7 @@ SIGNATURES = {
     "mi_csgu_bf16": [vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp],
     "mi_dwconv_residual_bf16": [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp],
     "mi_fbank_f64": [vp, i64, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, f64, f64, vp],
+    "mi_trim_zeros_pad_f32": [vp, i64, vp, i32, i32, i32, vp, i64, i32, vp, vp, vp, vp],
     "mi_cmvn_utterance": [vp, vp, i32, i32, i32, i32, i32, f32, vp],
     "mi_cmvn_global": [vp, i64, i32, vp, vp, vp],
     "mi_row_lse": [vp, i64, i32, i32, vp, i32, vp],

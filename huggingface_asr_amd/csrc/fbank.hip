@@ -217,6 +217,38 @@ __global__ void global_norm_kernel(float* x, long total, int nmel, const float* 
     }
 }
 
+// ---- the dataloader-side `default_transform` of the reference on the device (src/utilities/callbacks.py:108-118): `audio_object_stripper` = np.trim_zeros
+// (leading AND trailing samples equal to zero, src/utilities/data_utils.py:173-177), then zero-padding up to `min_len` (8000) samples.
+// trim_bounds: one block per clip finds the first / last non-zero sample; trim_copy: the stripped clip, left-aligned, zeros behind it.
+__global__ __launch_bounds__(256) void trim_bounds_kernel(const float* wave, long ldw, const int* num_samples, int N, int min_len, int* first, int* valid, int* eff) {
+    __shared__ int slo[4], shi[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int ns = num_samples ? min(num_samples[b], N) : N;
+    const float* w = wave + (long)b * ldw;
+    int lo = 0x7fffffff, hi = -1;
+    for (int i = tid; i < ns; i += 256)
+        if (w[i] != 0.f) { lo = min(lo, i); hi = max(hi, i); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+    if ((tid & 63) == 0) { slo[tid >> 6] = lo; shi[tid >> 6] = hi; }
+    __syncthreads();
+    if (tid == 0) {
+        lo = min(min(slo[0], slo[1]), min(slo[2], slo[3]));
+        hi = max(max(shi[0], shi[1]), max(shi[2], shi[3]));
+        const int v = hi < 0 ? 0 : hi - lo + 1;             // an all-zero clip strips to nothing (and is then padded to min_len zeros)
+        first[b] = hi < 0 ? 0 : lo;
+        valid[b] = v;
+        eff[b] = max(v, min_len);
+    }
+}
+__global__ __launch_bounds__(256) void trim_copy_kernel(const float* wave, long ldw, const int* first, const int* valid, float* out, long ldo, int N_out) {
+    const int b = blockIdx.y;
+    const int f = first[b], v = valid[b];
+    const float* w = wave + (long)b * ldw + f;
+    float* o = out + (long)b * ldo;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N_out; i += gridDim.x * 256) o[i] = i < v ? w[i] : 0.f;
+}
+
 }  // namespace
 
 // wave (B, ldw) f32 in [-1,1]; out (B, T_out, nmel) f32 (frames beyond a clip's own count are not written).
@@ -261,6 +293,19 @@ extern "C" int mi_cmvn_global(float* x, long total, int nmel, const float* means
     if (total <= 0 || nmel <= 0) return MI_ERR_ARG;
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(global_norm_kernel, dim3(grid), dim3(256), 0, stream, x, total, nmel, means, stds);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// out (B, ldo >= N_out) <- clip b stripped of leading / trailing zero samples, zeros behind; eff_len[b] = max(stripped length, min_len) = the sample count the
+// feature extractor sees; first / valid (B) = offset and length of the stripped clip.  N_out >= max(N, min_len).
+extern "C" int mi_trim_zeros_pad_f32(const float* wave, long ldw, const int* num_samples, int N, int B, int min_len, float* out, long ldo, int N_out,
+                                     int* first, int* valid, int* eff_len, hipStream_t stream) {
+    MI_ENTER();
+    if (B <= 0 || N <= 0 || min_len < 0 || N_out < N || N_out < min_len || ldo < N_out) return MI_ERR_ARG;
+    hipLaunchKernelGGL(trim_bounds_kernel, dim3(B), dim3(256), 0, stream, wave, ldw, num_samples, N, min_len, first, valid, eff_len);
+    MI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(trim_copy_kernel, dim3(cdiv(N_out, 256 * 8) < 256 ? cdiv(N_out, 256 * 8) : 256, B), dim3(256), 0, stream, wave, ldw, first, valid, out, ldo, N_out);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

@@ -96,3 +96,21 @@ def fbank_gpu(wave, tables: FbankTables, num_samples=None, pad_frames_to: int | 
         _lib.check(L.mi_cmvn_global(out.data_ptr(), out.numel(), tables.num_mel, global_means.data_ptr(), global_stds.data_ptr(), st),
                    "mi_cmvn_global")
     return out, frames
+
+
+def strip_zeros_pad_gpu(wave, num_samples=None, min_len: int = 8000):
+    """The array handling of the reference's `default_transform` (callbacks.py:108-118) for a device batch: every clip stripped of leading / trailing
+    zero samples (`np.trim_zeros`, data_utils.py:173-177) and zero-padded to at least `min_len` samples.
+    wave (B,N) float32 device tensor -> (stripped (B, max(N, min_len)) float32, eff_len (B,) int32 = samples the feature extractor sees)."""
+    import torch
+
+    from . import _lib
+    B, N = wave.shape
+    n_out = max(N, int(min_len))
+    out = torch.empty((B, n_out), dtype=torch.float32, device=wave.device)
+    meta = torch.empty((3, B), dtype=torch.int32, device=wave.device)
+    ns = None if num_samples is None else num_samples.to(device=wave.device, dtype=torch.int32).contiguous()
+    _lib.check(_lib.lib().mi_trim_zeros_pad_f32(wave.data_ptr(), wave.stride(0), 0 if ns is None else ns.data_ptr(), N, B, int(min_len), out.data_ptr(), out.stride(0),
+                                                n_out, meta[0].data_ptr(), meta[1].data_ptr(), meta[2].data_ptr(), torch.cuda.current_stream().cuda_stream),
+               "mi_trim_zeros_pad_f32")
+    return out, meta[2]

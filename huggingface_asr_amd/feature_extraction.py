@@ -61,11 +61,17 @@ class CustomFeatureExtractor(Speech2TextFeatureExtractor):
         return batch
 
     # ---- GPU pre-stage (not part of the reference surface)
-    def extract_on_device(self, waveforms, num_samples=None, pad_to_multiple_of=None):
-        """waveforms (B,N) float32 CUDA tensor -> (input_features (B,T,80) fp32, attention_mask (B,T) int32)."""
+    def extract_on_device(self, waveforms, num_samples=None, pad_to_multiple_of=None, default_transform=True, min_audio_length=8000, trim_to_longest=True):
+        """waveforms (B,N) float32 CUDA tensor -> (input_features (B,T,80) fp32, attention_mask (B,T) int32): the batch the reference's dataloader side
+        hands to the model.  `default_transform=True` applies what `DataPreprocessingManagerCallback.default_transform` does to every clip before the extractor
+        (callbacks.py:108-118: strip leading / trailing zero samples, zero-pad to >= `min_audio_length` samples) on the device; `pad_to_multiple_of` is the
+        collator's (collators.py:82-88), and like the collator the time axis ends at the longest clip of the batch (`trim_to_longest`, one host sync; pass False
+        in a throughput loop and keep the buffer's own length).  Pass default_transform=False for clips that already went through it."""
         import torch
 
-        from .fbank import fbank_gpu
+        from .fbank import fbank_gpu, strip_zeros_pad_gpu
+        if default_transform:
+            waveforms, num_samples = strip_zeros_pad_gpu(waveforms, num_samples, min_audio_length)
         kw = {}
         if self.norm_type == "global":
             kw = dict(normalize="global", global_means=torch.as_tensor(self.global_means, dtype=torch.float32, device=waveforms.device),
@@ -74,5 +80,11 @@ class CustomFeatureExtractor(Speech2TextFeatureExtractor):
             kw = dict(normalize=None)
         feats, frames = fbank_gpu(waveforms, self._get_tables(), num_samples, pad_to_multiple_of, normalize_means=self.normalize_means,
                                   normalize_vars=self.normalize_vars, padding_value=self.padding_value, **kw)
+        if trim_to_longest and num_samples is not None:
+            # the collator pads to the LONGEST clip of the batch (then up to the multiple); the device buffer may be longer.  One host sync for the length.
+            t_max = int(frames.max().item())
+            if pad_to_multiple_of:
+                t_max = (t_max + pad_to_multiple_of - 1) // pad_to_multiple_of * pad_to_multiple_of
+            feats = feats[:, : max(t_max, 1)].contiguous() if t_max < feats.shape[1] else feats
         mask = (torch.arange(feats.shape[1], device=feats.device)[None, :] < frames[:, None]).to(torch.int32)
         return feats, mask

@@ -109,6 +109,10 @@ int mi_dwconv_residual_bf16(const void* m, long ldm, const float* w, const float
 int mi_fbank_f64(const float* wave, long ldw, const int* num_samples, int N, const double* window,
                  const double* twiddle, const double* mel_t, const int* mel_lo, const int* mel_hi,
                  float* out, int T_out, int B, int nmel, double mel_floor, double preemph, mi_stream_t stream);
+/* replaces: DataPreprocessingManagerCallback.default_transform's array handling (src/utilities/callbacks.py:108-118: audio_object_stripper =
+   np.trim_zeros, src/utilities/data_utils.py:173-177, then zero-pad to >= min_len = 8000 samples) for clips that are already on the device. */
+int mi_trim_zeros_pad_f32(const float* wave, long ldw, const int* num_samples, int N, int B, int min_len, float* out, long ldo, int N_out,
+                          int* first, int* valid, int* eff_len, mi_stream_t stream);
 int mi_cmvn_utterance(float* x, const int* frames, int B, int T, int nmel, int norm_means, int norm_vars,
                       float pad, mi_stream_t stream);
 int mi_cmvn_global(float* x, long total, int nmel, const float* means, const float* stds, mi_stream_t stream);

@@ -302,6 +302,13 @@ def finetune_ctc_forward(sd: dict, cfg: dict, feats, attention_mask=None, labels
         am = attention_mask if attention_mask is not None else torch.ones(feats.shape[:2], dtype=torch.long)
         in_len = conv_out_lengths_outer(am.sum(-1), cfg).long()
         lmask = labels >= 0
+        # the reference flattens `labels.masked_select(labels >= 0)` (e_branchformer.py:472-475): the valid ids of a row count wherever the -100s sit
+        # (the collator's `mask_unks` puts them mid-row, collators.py:97-98) -> compact them to the front of the row
+        packed = torch.full_like(labels, -100)
+        for b in range(labels.shape[0]):
+            v = labels[b][lmask[b]]
+            packed[b, : v.numel()] = v
+        labels = packed
         loss = ctc_loss_ref(torch.log_softmax(logits.float(), -1), labels, in_len, lmask.sum(-1), blank=logits.shape[-1] - 1,
                             reduction=cfg.get("ctc_loss_reduction", "mean"), zero_infinity=cfg.get("ctc_zero_infinity", False))
     return loss, logits
@@ -328,6 +335,13 @@ def ctc_forward(sd: dict, cfg: dict, feats, attention_mask=None, labels=None, q=
         am = attention_mask if attention_mask is not None else torch.ones(feats.shape[:2], dtype=torch.long)
         in_len = conv_out_lengths_outer(am.sum(-1), cfg).long()
         lmask = labels >= 0
+        # the reference flattens `labels.masked_select(labels >= 0)` (e_branchformer.py:472-475): the valid ids of a row count wherever the -100s sit
+        # (the collator's `mask_unks` puts them mid-row, collators.py:97-98) -> compact them to the front of the row
+        packed = torch.full_like(labels, -100)
+        for b in range(labels.shape[0]):
+            v = labels[b][lmask[b]]
+            packed[b, : v.numel()] = v
+        labels = packed
         loss = ctc_loss_ref(torch.log_softmax(logits.float(), -1), labels, in_len, lmask.sum(-1),
                             blank=logits.shape[-1] - 1, reduction=cfg.get("ctc_loss_reduction", "mean"),
                             zero_infinity=cfg.get("ctc_zero_infinity", False))

@@ -180,6 +180,108 @@ def run_fbank_cases():
     np.savez_compressed(os.path.join(HERE, "fbank.npz"), **rec)
 
 
+def _stub_absent_third_party():
+    """`utilities.callbacks` / `utilities.collators` import the reference's whole glue layer (wandb, jiwer, librosa, torchaudio, ... are absent from this image);
+    nothing of those is executed by the transform chain or the collator.  Harness side, after transformers is loaded (it probes the same names itself)."""
+    import importlib.abc
+    import importlib.machinery
+    import types
+    import transformers.generation.utils as gu
+    for n in ("BeamSearchOutput", "GreedySearchOutput", "SampleOutput", "BeamSampleOutput"):          # names of transformers 4.39 the glue imports
+        if not hasattr(gu, n):
+            setattr(gu, n, getattr(gu, "GenerateBeamOutput", object))
+    stubs = ("librosa", "jiwer", "wandb", "torchaudio", "evaluate", "kaldiio", "soundfile", "flashlight", "pyannote")
+
+    class Stub(types.ModuleType):
+        __path__ = []
+
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            v = Stub(self.__name__ + "." + name)
+            setattr(self, name, v)
+            return v
+
+        def __call__(self, *a, **k):
+            return self
+
+        def __mro_entries__(self, bases):
+            return (object,)
+
+    class Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+        def find_spec(self, name, path, target=None):
+            return importlib.machinery.ModuleSpec(name, self, is_package=True) if name.split(".")[0] in stubs else None
+
+        def create_module(self, spec):
+            return Stub(spec.name)
+
+        def exec_module(self, module):
+            pass
+    if not any(type(f).__name__ == "Finder" for f in sys.meta_path):
+        sys.meta_path.insert(0, Finder())
+
+
+def run_harness_cases():
+    """the reference's OWN dataloader-side harness — `DataPreprocessingManagerCallback.default_transform` (callbacks.py:108-118: zero strip
+    through `audio_object_stripper`, data_utils.py:173-177, zero-pad to >= 8000 samples, the evaluation transform chain of configs/default_data_preprocessing2d.json =
+    feature extractor only) and `SpeechCollatorWithPadding.__call__` (collators.py:65-106: pad to a multiple of 100, attention mask, labels with pad -> -100 and
+    unk -> -100, rename to the model's input name) — run on seeded clips with silent edges / fewer than 8000 samples / interior zeros, then the reference model on
+    the collated batch."""
+    import transformers  # noqa: F401
+    from transformers import PreTrainedTokenizerFast
+    _stub_absent_third_party()
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from utilities.callbacks import DataPreprocessingManagerCallback
+    from utilities.collators import SpeechCollatorWithPadding
+    from utilities.feature_extractors import CustomFeatureExtractor
+
+    fe = CustomFeatureExtractor(feature_size=80, norm_type="utterance")
+    cfg_pre = {"default_preprocessing": [{"name": "feature_extractor", "steps_before_activation": 0,
+                                          "fn_call_params": {"return_attention_mask": False, "padding": False, "sampling_rate": 16000, "return_tensors": "pt"},
+                                          "return_behaviour": ["input_features[0]"]}]}
+    cb = DataPreprocessingManagerCallback(cfg_pre, {}, "audio", fe)
+    from transformers import TrainerState
+    cb.propagate_state_to_transforms(TrainerState())        # what on_init_end does (callbacks.py:133): step 0 activates the chain's steps_before_activation = 0 entries
+    N = 16000 * 3
+    clips = {   # stored padded to N samples with zeros (what a device batch looks like), true lengths alongside
+        "silent_edges": np.concatenate([np.zeros(1000, np.float32), synth.normal(2, "h_a", (26000,), 0.1), np.zeros(3000, np.float32)]),
+        "short": synth.normal(3, "h_b", (4800,), 0.08),                                           # < 8000 samples: zero-padded to 8000
+        "interior_zeros": np.concatenate([synth.normal(4, "h_c", (9000,), 0.05), np.zeros(2000, np.float32), synth.normal(5, "h_d", (13000,), 0.05)]),
+        "leading_only": np.concatenate([np.zeros(7, np.float32), synth.normal(6, "h_e", (40001,), 0.2)]),
+    }
+    names = list(clips)
+    lens = np.array([len(clips[k]) for k in names], np.int32)
+    waves = np.zeros((len(names), N), np.float32)
+    for i, k in enumerate(names):
+        waves[i, : lens[i]] = clips[k]
+    out = cb.default_transform({"audio": [{"array": clips[k]} for k in names]}, "default_preprocessing")["audio"]
+    feats = [np.asarray(o, np.float32) for o in out]
+    vocab = {"<pad>": 0, "<s>": 1, "</s>": 2, "<unk>": 3, "a": 4, "b": 5, "c": 6, "d": 7, "e": 8, "f": 9}
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+
+    class Tok(PreTrainedTokenizerFast):            # transformers 5.x dropped `batch_encode_plus` (4.39: the batched form of __call__); harness-side shim
+        def batch_encode_plus(self, batch_text, **kw):
+            return self(batch_text, **kw)
+    tok = Tok(tokenizer_object=tk, pad_token="<pad>", unk_token="<unk>", bos_token="<s>", eos_token="</s>")
+    texts = ["a b c d", "b zzz a", "f e d c b a", "c"]
+    coll = SpeechCollatorWithPadding(feature_extractor=fe, tokenizer=tok, padding=True, pad_to_multiple_of=100, audio_path="audio", text_path="text",
+                                     model_input_name="input_values", mask_unks=True)
+    batch = coll([{"audio": torch.from_numpy(f)[None], "text": t} for f, t in zip(feats, texts)])
+    assert "input_features" not in batch
+    rec = dict(waves=waves, lens=lens, frames=np.array([f.shape[0] for f in feats], np.int32), feats_cat=np.concatenate(feats, 0),
+               input_values=batch["input_values"].numpy().astype(np.float32), attention_mask=batch["attention_mask"].numpy().astype(np.int64),
+               labels=batch["labels"].numpy().astype(np.int64), texts=np.array(texts), vocab_keys=np.array(list(vocab)), vocab_ids=np.array(list(vocab.values())))
+    # the reference model on the collated batch
+    cfg, model = build_reference(TINY)
+    rec["weight_sum"] = load_seeded(model, 31)
+    with torch.no_grad():
+        o = model(batch["input_values"].clone(), attention_mask=batch["attention_mask"], labels=batch["labels"])
+    rec["loss"], rec["logits"], rec["seed"] = np.float32(o.loss.item()), o.logits.numpy().astype(np.float32), np.int64(31)
+    print("harness", [f.shape for f in feats], batch["input_values"].shape, batch["labels"].tolist(), float(o.loss))
+    np.savez_compressed(os.path.join(HERE, "harness.npz"), **rec)
+
+
 def run_length_tables():
     cfg, model = build_reference(TINY)
     L = torch.arange(50, 3001)
@@ -488,7 +590,7 @@ def run_ctc_prefix_cases():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "grads", "base", "fbank", "lengths", "ctc", "prefix", "aed", "aedgrads", "bestrq", "finetune", "specaug", "whisper"]
+    which = sys.argv[1:] or ["tiny", "grads", "base", "fbank", "harness", "lengths", "ctc", "prefix", "aed", "aedgrads", "bestrq", "finetune", "specaug", "whisper"]
     if "tiny" in which:
         run_encoder_case("tiny_rel", TINY, seed=11, B=2, T=200, lengths=[198, 150], U=7, tgt_lens=[7, 5])
         run_encoder_case("tiny_rotary", TINY, seed=12, B=2, T=200, lengths=[200, 131], U=6, tgt_lens=[6, 4],
@@ -510,6 +612,8 @@ if __name__ == "__main__":
                          position_embeddings_type="rotary")
     if "fbank" in which:
         run_fbank_cases()
+    if "harness" in which:
+        run_harness_cases()
     if "lengths" in which:
         run_length_tables()
     if "ctc" in which:
