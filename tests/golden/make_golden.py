@@ -282,6 +282,48 @@ def run_harness_cases():
     np.savez_compressed(os.path.join(HERE, "harness.npz"), **rec)
 
 
+def _ckpt_avg_state_dicts():
+    """three small 'checkpoints' from the seeded generator: fp32 tensors, a bf16 tensor, an int64 step counter, and a key the middle checkpoint lacks"""
+    sds = []
+    for i in range(3):
+        sd = {"enc.weight": torch.from_numpy(synth.normal(40 + i, "ck_w", (7, 5), 1.0)), "enc.bias": torch.from_numpy(synth.normal(40 + i, "ck_b", (5,), 0.3)),
+              "head.weight": torch.from_numpy(synth.normal(40 + i, "ck_h", (4, 6), 2.0)).to(torch.bfloat16), "step_counter": torch.tensor(10 * (i + 1) + i, dtype=torch.int64)}
+        if i != 1:
+            sd["extra.scale"] = torch.from_numpy(synth.normal(40 + i, "ck_e", (3,), 1.0))
+        sds.append(sd)
+    return sds
+
+
+def run_ckpt_average_case():
+    """the reference's OWN `average_checkpoints` (model_utils.py:54-65, with `average_dicts`, general_utils.py:88-101) run on three seeded checkpoints
+    in a temporary experiment directory; the fixture keeps what it wrote (the tests rebuild the same checkpoints from the seeds)."""
+    import tempfile
+    import transformers  # noqa: F401
+    _stub_absent_third_party()
+    import utilities.model_utils as MU
+    with tempfile.TemporaryDirectory() as td:
+        for i, sd in enumerate(_ckpt_avg_state_dicts()):
+            os.makedirs(os.path.join(td, f"checkpoint-{(i + 1) * 500}"))
+            torch.save(sd, os.path.join(td, f"checkpoint-{(i + 1) * 500}", "pytorch_model.bin"))
+            with open(os.path.join(td, f"checkpoint-{(i + 1) * 500}", "config.json"), "w") as f:
+                f.write('{"ckpt": %d}' % i)
+        for aux, fn in (("tokenizer", "tokenizer.json"), ("feature_extractor", "preprocessor_config.json")):
+            os.makedirs(os.path.join(td, aux))
+            open(os.path.join(td, aux, fn), "w").write("{}")
+        import glob
+        order = [os.path.basename(os.path.dirname(p)) for p in glob.glob(f"{td}/checkpoint*/pytorch_model.bin")]
+        dst = MU.average_checkpoints(td)
+        avg = torch.load(os.path.join(dst, "pytorch_model.bin"), weights_only=True)
+        files = sorted(os.listdir(dst))
+        first_cfg = open(os.path.join(dst, "config.json")).read()
+    rec = {"files": np.array(files), "glob_order": np.array(order), "first_cfg": np.array(first_cfg)}
+    for k, v in avg.items():
+        rec["avg/" + k] = v.float().numpy() if v.dtype == torch.bfloat16 else v.numpy()
+        rec["dtype/" + k] = np.array(str(v.dtype))
+    print("ckpt_avg", order, {k: (str(v.dtype), tuple(v.shape)) for k, v in avg.items()}, files)
+    np.savez_compressed(os.path.join(HERE, "ckpt_avg.npz"), **rec)
+
+
 def run_length_tables():
     cfg, model = build_reference(TINY)
     L = torch.arange(50, 3001)
@@ -590,7 +632,7 @@ def run_ctc_prefix_cases():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "grads", "base", "fbank", "harness", "lengths", "ctc", "prefix", "aed", "aedgrads", "bestrq", "finetune", "specaug", "whisper"]
+    which = sys.argv[1:] or ["tiny", "grads", "base", "fbank", "harness", "ckptavg", "lengths", "ctc", "prefix", "aed", "aedgrads", "bestrq", "finetune", "specaug", "whisper"]
     if "tiny" in which:
         run_encoder_case("tiny_rel", TINY, seed=11, B=2, T=200, lengths=[198, 150], U=7, tgt_lens=[7, 5])
         run_encoder_case("tiny_rotary", TINY, seed=12, B=2, T=200, lengths=[200, 131], U=6, tgt_lens=[6, 4],
@@ -614,6 +656,8 @@ if __name__ == "__main__":
         run_fbank_cases()
     if "harness" in which:
         run_harness_cases()
+    if "ckptavg" in which:
+        run_ckpt_average_case()
     if "lengths" in which:
         run_length_tables()
     if "ctc" in which:

@@ -89,3 +89,47 @@ def test_error_behaviour(tmp_path):
         C.average_checkpoints(str(tmp_path))                                                 # no tokenizer directory: copytree raises there too
     with pytest.raises(ValueError):
         C.average_state_dicts()
+
+
+def test_against_the_reference_average_checkpoints_fixture(tmp_path):
+    """tests/golden/ckpt_avg.npz was written by the REFERENCE's `average_checkpoints` (make_golden.py `run_ckpt_average_case`: model_utils.py:54-65 +
+    general_utils.py:88-101 run in a temporary experiment directory).  Same checkpoints rebuilt from the seeds, summed in the order the reference's glob
+    returned: bit-identical tensors, dtypes (bf16 stays bf16, the int64 counter becomes float32), a key one checkpoint lacks still divided by 3."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from helpers import load_golden
+    from huggingface_asr_amd import synth
+    g = load_golden("ckpt_avg")
+
+    def sds():
+        out = {}
+        for i in range(3):
+            sd = {"enc.weight": torch.from_numpy(synth.normal(40 + i, "ck_w", (7, 5), 1.0)), "enc.bias": torch.from_numpy(synth.normal(40 + i, "ck_b", (5,), 0.3)),
+                  "head.weight": torch.from_numpy(synth.normal(40 + i, "ck_h", (4, 6), 2.0)).to(torch.bfloat16), "step_counter": torch.tensor(10 * (i + 1) + i, dtype=torch.int64)}
+            if i != 1:
+                sd["extra.scale"] = torch.from_numpy(synth.normal(40 + i, "ck_e", (3,), 1.0))
+            out[f"checkpoint-{(i + 1) * 500}"] = sd
+        return out
+    by_name = sds()
+    avg = C.average_state_dicts(*[by_name[str(n)] for n in g["glob_order"]])
+    keys = sorted(k[4:] for k in g.files if k.startswith("avg/"))
+    assert sorted(avg) == keys
+    for k in keys:
+        assert str(avg[k].dtype) == str(g["dtype/" + k]), k
+        got = avg[k].float().numpy() if avg[k].dtype == torch.bfloat16 else avg[k].numpy()
+        np.testing.assert_array_equal(got, g["avg/" + k], err_msg=k)
+    # the directory-level entry point: same files in the output, first checkpoint's config, same numbers (this file system's glob order may differ: allclose)
+    for name, sd in sds().items():
+        (tmp_path / name).mkdir()
+        torch.save(sd, tmp_path / name / "pytorch_model.bin")
+        (tmp_path / name / "config.json").write_text('{"ckpt": %d}' % (int(name.split("-")[1]) // 500 - 1))
+    for aux, fn in (("tokenizer", "tokenizer.json"), ("feature_extractor", "preprocessor_config.json")):
+        (tmp_path / aux).mkdir()
+        (tmp_path / aux / fn).write_text("{}")
+    dst = C.average_checkpoints(str(tmp_path))
+    assert sorted(os.listdir(dst)) == list(g["files"])
+    first = os.path.basename(os.path.dirname(C.checkpoint_files(str(tmp_path))[0]))
+    assert open(os.path.join(dst, "config.json")).read() == '{"ckpt": %d}' % (int(first.split("-")[1]) // 500 - 1)
+    out = torch.load(os.path.join(dst, "pytorch_model.bin"), weights_only=True)
+    for k in keys:
+        np.testing.assert_allclose(out[k].float().numpy(), g["avg/" + k].astype(np.float32), rtol=1e-6, atol=1e-7 if out[k].dtype != torch.bfloat16 else 2e-2)
