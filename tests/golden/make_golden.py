@@ -590,6 +590,34 @@ def run_whisper_cases():
     print("whisper cases written", out.shape, float(out.std()))
 
 
+def run_whisper_small_case():
+    """BASELINE config 4 at its REAL shape: transformers' WhisperEncoder with the whisper-small configuration (d 768, 12 layers, 12 heads x 64, FFN 3072,
+    1500 positions), seeded weights, two 30 s inputs (80 x 3000).  Stored: a strided slice of the output, per-frame L2 norms, and the same slice under the
+    reference stack's own bf16 autocast (the size of the bf16 gap the HIP path is held to)."""
+    from transformers import WhisperConfig
+    from transformers.models.whisper.modeling_whisper import WhisperEncoder
+    cfg = WhisperConfig(d_model=768, encoder_layers=12, encoder_attention_heads=12, encoder_ffn_dim=3072, num_mel_bins=80, max_source_positions=1500,
+                        attn_implementation="eager", dropout=0.0, activation_function="gelu")
+    enc = WhisperEncoder(cfg).eval()
+    wsum = load_seeded(enc, 43)
+    # keep transformers' sinusoid position table (it is a non-trained embedding that load_seeded would otherwise overwrite with noise)
+    from transformers.models.whisper.modeling_whisper import sinusoids
+    with torch.no_grad():
+        enc.embed_positions.weight.copy_(sinusoids(1500, 768))
+    x = synth.normal(43, "wh_small_feats", (2, 80, 3000), 0.5)
+    with torch.no_grad():
+        out = enc(torch.from_numpy(x)).last_hidden_state
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out16 = enc(torch.from_numpy(x)).last_hidden_state.float()
+    rec = dict(seed=43, weight_sum=wsum, out_slice=out[:, ::50, ::16].numpy(), out_norm=out.norm(dim=-1).numpy(), out_slice_bf16=out16[:, ::50, ::16].numpy(),
+               out_std=np.float32(out.std()), param_names=np.array([k for k, _ in enc.named_parameters()]),
+               param_shapes=np.array([str(tuple(v.shape)) for _, v in enc.named_parameters()]))
+    d = (out16 - out).abs()
+    print("whisper small", out.shape, float(out.std()), "bf16 autocast gap max/mean", float(d.max()), float(d.mean()))
+    rec["bf16_gap_max"], rec["bf16_gap_mean"] = np.float32(d.max()), np.float32(d.mean())
+    np.savez_compressed(os.path.join(HERE, "whisper_small.npz"), **rec)
+
+
 def run_ctc_prefix_cases():
     """reference src/decoding/ctc_scorer.py: CTCRescorerLogitsProcessor over 4 decoding steps (B=2, W=3)."""
     from decoding.ctc_scorer import CTCPrefixScoreTH, CTCRescorerLogitsProcessor, LogSoftmaxProcessor
@@ -632,7 +660,7 @@ def run_ctc_prefix_cases():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "grads", "base", "fbank", "harness", "ckptavg", "lengths", "ctc", "prefix", "aed", "aedgrads", "bestrq", "finetune", "specaug", "whisper"]
+    which = sys.argv[1:] or ["tiny", "grads", "base", "fbank", "harness", "ckptavg", "lengths", "ctc", "prefix", "aed", "aedgrads", "bestrq", "finetune", "specaug", "whisper", "whispersmall"]
     if "tiny" in which:
         run_encoder_case("tiny_rel", TINY, seed=11, B=2, T=200, lengths=[198, 150], U=7, tgt_lens=[7, 5])
         run_encoder_case("tiny_rotary", TINY, seed=12, B=2, T=200, lengths=[200, 131], U=6, tgt_lens=[6, 4],
@@ -676,3 +704,5 @@ if __name__ == "__main__":
         run_specaug_cases()
     if "whisper" in which:
         run_whisper_cases()
+    if "whispersmall" in which:
+        run_whisper_small_case()

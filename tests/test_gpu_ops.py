@@ -190,7 +190,7 @@ def test_attention(T, H, hd, rel, causal):
 
 @pytest.mark.parametrize("T,H,hd,rel,causal", [(250, 4, 128, True, False), (75, 2, 64, False, False), (97, 4, 64, True, True),
                                                (33, 2, 128, False, True), (300, 4, 128, True, False), (129, 1, 128, True, False),
-                                               (500, 2, 64, True, False)])
+                                               (500, 2, 64, True, False), (1500, 12, 64, False, False), (1500, 2, 128, True, False)])
 def test_attention_lds_staged(T, H, hd, rel, causal):
     """LDS-staged kernel (fused QKV input, tr-read V, carried G tile) against the same oracle."""
     ops = _ops()

@@ -44,3 +44,42 @@ def test_whisper_encoder_matches_transformers_and_oracle():
     assert dq.max() < 0.04 and dq.mean() < 0.004, (dq.max(), dq.mean())
     with pytest.raises(ValueError):
         eng.forward(x[:, :, :100].to(DEV))
+
+
+def _whisper_small_sd(g):
+    seed = int(g["seed"])
+    sd = {str(n): torch.from_numpy(synth.init_param(seed, str(n), ast.literal_eval(str(s)))) for n, s in zip(g["param_names"], g["param_shapes"])}
+    # transformers' fixed sinusoid table (modeling_whisper.sinusoids: log-spaced timescales, [sin | cos]), which the generator kept instead of seeded noise
+    half = 768 // 2
+    inv = torch.exp(-np.log(10000.0) / (half - 1) * torch.arange(half, dtype=torch.float32))
+    t = torch.arange(1500, dtype=torch.float32)[:, None] * inv[None, :]
+    sd["embed_positions.weight"] = torch.cat([t.sin(), t.cos()], 1)
+    return sd
+
+
+def test_whisper_small_real_shape_vs_transformers():
+    """BASELINE config 4 at its real size (d 768, 12 x 64 heads, 1500 keys, FFN 3072): strided output slice + per-frame norms of transformers' WhisperEncoder
+    (tests/golden/whisper_small.npz), held to the reference stack's own bf16-autocast gap (stored alongside: max 0.027 / mean 0.0038 at output std 1.0)."""
+    from huggingface_asr_amd.whisper import WhisperEncoderEngine
+    g = load_golden("whisper_small")
+    sd = _whisper_small_sd(g)
+    cfg = dict(d_model=768, encoder_layers=12, encoder_attention_heads=12, encoder_ffn_dim=3072)
+    x = torch.from_numpy(synth.normal(int(g["seed"]), "wh_small_feats", (2, 80, 3000), 0.5))
+    eng = WhisperEncoderEngine(cfg, DEV)
+    eng.load_state_dict(sd)
+    out = eng.forward(x.to(DEV))
+    assert tuple(out.shape) == (2, 1500, 768)
+    o = out.float().cpu()
+    d = (o[:, ::50, ::16].numpy() - g["out_slice"])
+    gap_max, gap_mean = float(g["bf16_gap_max"]), float(g["bf16_gap_mean"])
+    assert np.abs(d).max() < 2.0 * gap_max and np.abs(d).mean() < 1.5 * gap_mean, (np.abs(d).max(), np.abs(d).mean(), gap_max, gap_mean)
+    rel = np.abs(o.norm(dim=-1).numpy() - g["out_norm"]) / g["out_norm"]
+    assert rel.max() < 5e-3, rel.max()
+    # batch independence at the bench batch (16 x 30 s): rows 0 / 1 of a 16-clip batch equal the 2-clip run up to kernel-selection noise (other GEMM tiles at M = 24000)
+    xb = torch.from_numpy(synth.normal(77, "wh_small_more", (16, 80, 3000), 0.5))
+    xb[3], xb[11] = x[0], x[1]
+    ob = eng.forward(xb.to(DEV)).float().cpu()
+    for src, row in ((0, 3), (1, 11)):
+        dd = (ob[row] - o[src]).abs()
+        assert dd.max() < 2.0 * gap_max and dd.mean() < 0.5 * gap_mean, (src, float(dd.max()), float(dd.mean()))
+    assert torch.isfinite(ob).all()
