@@ -73,3 +73,63 @@ def test_two_rank_data_parallel_step_matches_full_batch_fixture(name, overlap):
             worst = max(worst, float(np.linalg.norm(a - want)) / nw)
     assert worst < 0.03, worst
     assert r0["wsum"] == r1["wsum"] and r0["norm"] == r1["norm"] and r0["norm"] > 0
+
+
+def _aed_worker(rank, world, port, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0", HFASR_DP_OVERLAP="0")
+    import torch.distributed as dist
+    from helpers import AED_JCFG, TINY_DEC, aed_case_inputs, load_golden
+    from huggingface_asr_amd import shapes
+    from huggingface_asr_amd.train_aed import JointAEDTrainer
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    g = load_golden("grads_aed_tiny")
+    sd, x, am, lab = aed_case_inputs(g)
+    enc_cfg = dict(shapes.TINY, ctc_zero_infinity=True, ctc_loss_reduction="mean", hidden_dropout=0.0, activation_dropout=0.0, attention_dropout=0.0,
+                   final_dropout=0.0, feat_proj_dropout=0.0, csgu_conv_dropout=0.0, apply_spec_augment=False, layerdrop=0.0)
+    tr = JointAEDTrainer(enc_cfg, dict(TINY_DEC, pos_emb_fixed=False, tie_word_embeddings=False), AED_JCFG, "cuda:0", lr=1e-3)
+    tr.load_state_dict(sd)
+    res = {}
+    for shard in ([rank] if world > 1 else [0, 1]):          # world == 1: the per-shard gradients, un-synchronised (the expectation is built from them)
+        sl = slice(shard, shard + 1)
+        tr.enc.store.zero_grad(); tr.store.zero_grad()
+        o = tr.forward_backward(x[sl].to("cuda:0"), am[sl].sum(-1).to("cuda:0"), lab[sl].to("cuda:0"))
+        tr.enc.sync.wait(); tr.sync.wait()                    # default schedule: the merged all-reduce of each store runs here (optimizer_step calls the same)
+        torch.cuda.synchronize()
+        res[shard] = dict(loss=float(o["loss"]), enc_loss=float(o["enc_loss"]), dec_loss=float(o["dec_loss"]), grads={k: v.cpu().numpy() for k, v in tr.grad_dict().items()})
+    if world > 1:
+        assert tr.sync.on and tr.enc.sync.on and tr.sync.world == world
+        tr.optimizer_step()
+        torch.cuda.synchronize()
+        res[rank]["wsum"] = float(tr.store.flat_p.double().sum()) + float(tr.enc.store.flat_p.double().sum())
+        dist.barrier()
+        dist.destroy_process_group()
+    out[f"{world}:{rank}"] = res
+
+
+def test_two_rank_data_parallel_joint_aed_step():
+    """BASELINE config 3 is 'AED, data parallel': JointAEDTrainer on two ranks, one utterance each.  DDP semantics (what the reference gets from HF Trainer): every rank
+    differentiates the mean loss of ITS shard and the gradients are averaged — so the expectation is the average of the two shards' own gradients (a single
+    process, no sync), for the encoder's store AND the decoder's; both ranks must hold the same reduced gradients and the same weights after AdamW."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_aed_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    mp.spawn(_aed_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    single, r0, r1 = out["1:0"], out["2:0"][0], out["2:1"][1]
+    for key in ("loss", "enc_loss", "dec_loss"):              # a rank reports the loss of its own shard
+        assert abs(r0[key] - single[0][key]) <= 1e-6 * abs(single[0][key]) and abs(r1[key] - single[1][key]) <= 1e-6 * abs(single[1][key]), key
+    worst, n = 0.0, 0
+    for k, g0 in single[0]["grads"].items():
+        want = 0.5 * (g0.astype(np.float64) + single[1]["grads"][k].astype(np.float64)).reshape(-1)
+        a, b = r0["grads"][k].reshape(-1), r1["grads"][k].reshape(-1)
+        assert np.array_equal(a, b), k
+        nw = float(np.linalg.norm(want))
+        if nw > 1e-6:
+            worst = max(worst, float(np.linalg.norm(a - want)) / nw)
+            n += 1
+    assert n > 100 and worst < 1e-4, (n, worst)          # 1 / world = 0.5 scales exactly; what is left is the float atomics of the bias / LayerNorm reductions
+    assert r0["wsum"] == r1["wsum"]
