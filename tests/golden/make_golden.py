@@ -149,6 +149,44 @@ def run_grad_case(name, cfg_kwargs, seed, B, T, lengths, U, tgt_lens, np_seed=No
     print(name, "loss", rec["loss"], "n grads", sum(k.startswith("grad:") for k in rec))
 
 
+def run_grad_case_strided(name, cfg_kwargs, seed, B, T, lengths, U, tgt_lens, **extra):
+    """run_grad_case for a FULL-SIZE model (base: 129 M parameters, head size 128 = the LDS-staged attention and its backward): the loss, and for every parameter
+    gradient its L2 norm and a strided sample of 256 elements — fp32 and under the reference stack's own bf16 autocast (the yard-stick)."""
+    cfg, model = build_reference(cfg_kwargs, **{**NO_DROPOUT, **extra})
+    model.train()
+    wsum = load_seeded(model, seed)
+    x, am = synth_feats(seed, B, T, lengths)
+    lab = synth_labels(seed, B, U, cfg.vocab_size, tgt_lens)
+    out = model(torch.from_numpy(x), attention_mask=torch.from_numpy(am), labels=torch.from_numpy(lab))
+    out.loss.backward()
+    rec = dict(seed=seed, weight_sum=wsum, lengths=np.array(lengths), tgt_lens=np.array(tgt_lens), shape=np.array([B, T, U]), loss=float(out.loss))
+    g32 = {k: v.grad.float().clone() for k, v in model.named_parameters() if v.grad is not None}
+
+    def sample(t):
+        f = t.reshape(-1)
+        return f[:: max(1, f.numel() // 256) | 1][:256].numpy()          # odd stride: the sample walks across the columns instead of sitting in one
+    for k, v in g32.items():
+        rec["norm:" + k] = np.float64(v.double().norm())
+        rec["samp:" + k] = sample(v)
+    model.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ob = model(torch.from_numpy(x), attention_mask=torch.from_numpy(am), labels=torch.from_numpy(lab))
+    ob.loss.float().backward()
+    rec["bf16_loss"] = float(ob.loss)
+    gaps, sgaps = [], []
+    for k, v in model.named_parameters():
+        if v.grad is not None and float(g32[k].norm()) > 1e-6:
+            gaps.append(float((v.grad.float() - g32[k]).norm() / g32[k].norm()))
+            a, b = sample(v.grad.float()), sample(g32[k])
+            if np.linalg.norm(b) > 1e-9:
+                sgaps.append(float(np.linalg.norm(a - b) / np.linalg.norm(b)))
+    rec["bf16_grad_relerr_max"], rec["bf16_grad_relerr_mean"] = max(gaps), float(np.mean(gaps))
+    rec["bf16_samp_relerr_max"], rec["bf16_samp_relerr_mean"] = max(sgaps), float(np.mean(sgaps))
+    print("  autocast-vs-fp32 gradient gap: whole tensors max", max(gaps), "mean", float(np.mean(gaps)), "| strided samples max", max(sgaps), "mean", float(np.mean(sgaps)))
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
+    print(name, "loss", rec["loss"], "n grads", len(g32))
+
+
 def run_fbank_cases():
     from utilities.feature_extractors import CustomFeatureExtractor
 
@@ -660,7 +698,7 @@ def run_ctc_prefix_cases():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "grads", "base", "fbank", "harness", "ckptavg", "lengths", "ctc", "prefix", "aed", "aedgrads", "bestrq", "finetune", "specaug", "whisper", "whispersmall"]
+    which = sys.argv[1:] or ["tiny", "grads", "base", "basegrads", "fbank", "harness", "ckptavg", "lengths", "ctc", "prefix", "aed", "aedgrads", "bestrq", "finetune", "specaug", "whisper", "whispersmall"]
     if "tiny" in which:
         run_encoder_case("tiny_rel", TINY, seed=11, B=2, T=200, lengths=[198, 150], U=7, tgt_lens=[7, 5])
         run_encoder_case("tiny_rotary", TINY, seed=12, B=2, T=200, lengths=[200, 131], U=6, tgt_lens=[6, 4],
@@ -674,6 +712,8 @@ if __name__ == "__main__":
         run_grad_case("grads_tiny_specaug", TINY, seed=16, B=2, T=200, lengths=[200, 140], U=5, tgt_lens=[5, 3], np_seed=5, apply_spec_augment=True,
                       mask_time_prob=0.3, mask_time_length=4, mask_time_min_masks=2, mask_feature_prob=0.2, mask_feature_length=3, mask_feature_min_masks=1)
         # (use_macaron_ff=False is not runnable in the reference: its layer forward reads self.ff1 unconditionally, e_branchformer.py:271)
+    if "basegrads" in which:
+        run_grad_case_strided("grads_base_rel", BASE, seed=24, B=2, T=1000, lengths=[998, 700], U=40, tgt_lens=[40, 31])
     if "base" in which:
         run_encoder_case("small_rel", SMALL, seed=21, B=2, T=1000, lengths=[998, 700], U=40, tgt_lens=[40, 31], full=False)
         run_encoder_case("base_rel", BASE, seed=22, B=2, T=1000, lengths=[998, 700], U=40, tgt_lens=[40, 31], full=False,

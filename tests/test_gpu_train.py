@@ -65,6 +65,108 @@ def test_gradients_match_reference_golden(name, extra):
     _compare(grads, ref)
 
 
+
+def test_base_size_gradients_match_reference_strided_golden():
+    """The BASE model's training step (d 512, 16 layers, head size 128 = the LDS-staged attention forward and its backward, B = 2 x 10 s, one padded row) against the
+    imported reference in train() mode (tests/golden/grads_base_rel.npz, make_golden.py `run_grad_case_strided`): loss, and for each of the 672 parameter gradients
+    its L2 norm and a strided 256-element sample.  Yard-stick in the fixture: the reference's own bf16-autocast backward vs its fp32 backward (mean gap 1.4-1.5 %)."""
+    g = load_golden("grads_base_rel")
+    cfg = dict(shapes.BASE, ctc_zero_infinity=True, ctc_loss_reduction="mean")
+    sd, x, am, lab = case_inputs(g, cfg)
+    tr = _trainer(cfg, sd)
+    tr.store.zero_grad()
+    out = tr.forward_backward(x.to(DEV), am.sum(-1).to(DEV), lab.to(DEV))
+    torch.cuda.synchronize()
+    assert abs(float(out["loss"]) - float(g["loss"])) <= 1e-3 * abs(float(g["loss"])), (float(out["loss"]), float(g["loss"]))
+    grads = tr.grad_dict()
+    names = [k[5:] for k in g.files if k.startswith("norm:")]
+    assert len(names) == 672 and set(names) <= set(grads)
+    gmax = max(float(g["norm:" + k]) for k in names)
+    rel_n, rel_s, bad = [], [], []
+    for k in names:
+        got = grads[k].float().cpu().reshape(-1)
+        nw = float(g["norm:" + k])
+        if nw < 1e-4 * gmax:                     # mathematically (near-)zero gradients, e.g. the key bias under softmax: noise on both sides
+            assert float(got.norm()) < 2e-3 * gmax, (k, float(got.norm()), gmax)
+            continue
+        en = abs(float(got.double().norm()) - nw) / nw
+        samp = got[:: max(1, got.numel() // 256) | 1][:256].numpy()
+        want = g["samp:" + k]
+        es = float(np.linalg.norm(samp - want) / max(np.linalg.norm(want), 1e-12))
+        cos = float(np.dot(samp, want) / max(np.linalg.norm(samp) * np.linalg.norm(want), 1e-20))
+        rel_n.append(en); rel_s.append(es)
+        if en > 0.04 or es > 0.08 or cos < 0.997:
+            bad.append((k, round(en, 4), round(es, 4), round(cos, 5)))
+    worst = sorted(zip(rel_s, rel_n, [k for k in names if float(g["norm:" + k]) >= 1e-4 * gmax]), reverse=True)[:12]
+    print("worst sample errors:", [(k, round(a, 4), round(b, 4)) for a, b, k in worst])
+    assert not bad, f"{len(bad)} of {len(names)} gradient tensors off: {bad[:8]}"
+    # on average no worse than the reference's own bf16 backward
+    assert float(np.mean(rel_s)) < 1.5 * float(g["bf16_samp_relerr_mean"]), (float(np.mean(rel_s)), float(g["bf16_samp_relerr_mean"]))
+    print(f"base-size gradients: norm rel err mean {np.mean(rel_n):.4f} max {np.max(rel_n):.4f}; sample rel err mean {np.mean(rel_s):.4f} max {np.max(rel_s):.4f} "
+          f"(reference bf16-vs-fp32: mean {float(g['bf16_samp_relerr_mean']):.4f})")
+
+
+def test_config3_shape_joint_training_step_properties():
+    """BASELINE config 3 at its real size (small encoder 12 x 256 + 6 x 256 GPT-2 decoder, per-GPU batch 96, clips of 1-20 s padded to 2000 frames; what
+    `bench.py --train` times).  No reference output exists at this size (CPU), so the step is held to size-independent properties of the reference's losses:
+    additivity over a split of the batch (CTC: mean of per-utterance normalised nll; CE: mean over valid tokens), independence of an utterance from its batch
+    mates, invariance to extra zero padding, finite gradients in every tensor."""
+    from huggingface_asr_amd import synth
+    from huggingface_asr_amd.train_aed import JointAEDTrainer
+    cfg = dict(shapes.SMALL, position_embeddings_type="relative", ctc_zero_infinity=True, ctc_loss_reduction="mean", **NO_DROPOUT)
+    dcfg = dict(vocab_size=5000, n_embd=256, n_layer=6, n_head=4, n_positions=1024, head_locations=[], head_weights=[1.0], lsm_factor=0.1,
+                layer_norm_epsilon=1e-5, pos_emb_fixed=True, tie_word_embeddings=False)
+    jcfg = dict(ctc_weight=0.3, pad_token_id=3, decoder_start_token_id=1)
+    tr = JointAEDTrainer(cfg, dcfg, jcfg, DEV)
+    tr.enc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()})
+    gen = torch.Generator().manual_seed(1)
+    for s_ in tr.store.specs.values():
+        zero = s_.name.endswith(("_b", "bqkv", "bq", "bkv", "bo", "bco", "bfc", "bpr"))
+        tr.store.p(s_.name).copy_((torch.ones(s_.shape) if s_.name.endswith("_g") else torch.randn(s_.shape, generator=gen) * (0.0 if zero else 0.02)).to(DEV))
+    tr.store.refresh_mirrors(cast=True)
+    B, T, U = 96, 2000, 60
+    rng = np.random.default_rng(0)
+    fl = np.sort(rng.integers(100, 2001, size=B))[::-1].copy()
+    feats = torch.from_numpy(synth.normal(100, "feats", (B, T, 80), 1.0))
+    for b in range(B):
+        feats[b, fl[b]:] = 0.0
+    labels = torch.from_numpy(synth.labels(0, B, U, 5000, lo=5))
+    ntok = []
+    for b in range(B):
+        n = max(2, int(fl[b] / 100 * 3))
+        labels[b, n:] = -100
+        ntok.append(min(n, U))
+    lens = torch.from_numpy(fl.astype(np.int32))
+
+    def run(idx, t_pad=T):
+        x = feats[idx]
+        if t_pad > T:
+            x = torch.cat([x, torch.zeros(len(idx), t_pad - T, 80)], 1)
+        tr.enc.store.zero_grad(); tr.store.zero_grad()
+        o = tr.forward_backward(x.to(DEV), lens[idx].to(DEV), labels[idx].to(DEV))
+        torch.cuda.synchronize()
+        return {k: float(o[k]) for k in ("loss", "enc_loss", "dec_loss")}, o["encoder_logits"].float().cpu()
+    allb = np.arange(B)
+    full, lg_full = run(allb)
+    assert all(np.isfinite(v) for v in full.values()), full
+    for st in (tr.enc.store, tr.store):
+        assert bool(torch.isfinite(st.flat_g).all()) and float(st.flat_g.abs().max()) > 0
+    ha, lg_a = run(allb[0::2])
+    hb, _ = run(allb[1::2])
+    # additivity: CTC mean over utterances; CE mean over the (shifted) valid target tokens
+    assert abs(full["enc_loss"] - 0.5 * (ha["enc_loss"] + hb["enc_loss"])) < 2e-4 * full["enc_loss"], (full, ha, hb)
+    na, nb = sum(ntok[i] - 1 for i in allb[0::2]), sum(ntok[i] - 1 for i in allb[1::2])        # the decoder loss is over labels[:, 1:] (double shift, SURVEY row 16)
+    assert abs(full["dec_loss"] - (na * ha["dec_loss"] + nb * hb["dec_loss"]) / (na + nb)) < 2e-4 * full["dec_loss"], (full, ha, hb, na, nb)
+    assert abs(full["loss"] - (0.3 * full["enc_loss"] + 0.7 * full["dec_loss"])) < 1e-5 * full["loss"]
+    # batch independence: an utterance's encoder logits do not depend on its batch mates (other GEMM tiles / kernels at the other M: bf16-level differences only)
+    d = (lg_full[0::2] - lg_a).abs()
+    assert float(d.max()) < 0.05 and float(d.mean()) < 2e-3, (float(d.max()), float(d.mean()))
+    # padding invariance: 100 more zero frames behind every clip
+    pad, _ = run(allb, T + 100)
+    for k in full:
+        assert abs(pad[k] - full[k]) < 2e-4 * abs(full[k]), (k, pad[k], full[k])
+
+
 FINETUNE_CASES = ["finetune_tiny_mix_extra", "finetune_tiny_mix", "finetune_tiny_extra"]
 
 
