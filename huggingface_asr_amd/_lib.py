@@ -32,6 +32,8 @@ GLOBAL_SLOTS, LAYER_SLOTS = 24, 48
 SIGNATURES = {
     "mi_gemm_bf16": [vp, i64, vp, i64, vp, i32, vp, i64, i32, vp, i64, f32, i32, i32, i32, i32, i32, i32, vp],
     "mi_conv2d_cl_bf16": [vp, vp, vp, vp] + [i32] * 13 + [vp],
+    "mi_gemm_bf16_v": [vp, i64, vp, i64, vp, i32, vp, i64, i32, vp, i64, f32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "mi_conv2d_cl_bf16_v": [vp, vp, vp, vp] + [i32] * 14 + [vp],
     "mi_conv2d_first_gelu": [vp, vp, vp, vp] + [i32] * 10 + [vp],
     "mi_layernorm_chain": [vp, i64, vp, i32, vp, vp, f32, vp, i64, vp, vp, f32, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, vp],
     "mi_cast_f32_bf16": [vp, i64, vp, i64, i32, i32, vp],
@@ -137,16 +139,6 @@ def lib():
         h.mi_profile_count.argtypes = []; h.mi_profile_count.restype = i32
         h.mi_profile_summary.argtypes = [C.POINTER(f64), C.POINTER(f64)]; h.mi_profile_summary.restype = i32
         h.mi_profile_calibrate.argtypes = [vp, i32, C.POINTER(f64)]; h.mi_profile_calibrate.restype = i32
-        h.mi_gemm_set_stages.argtypes = [i32]; h.mi_gemm_set_stages.restype = None
-        if os.environ.get("HFASR_GEMM_STAGES"):
-            h.mi_gemm_set_stages(int(os.environ["HFASR_GEMM_STAGES"]))
-        h.mi_gemm_set_krot.argtypes = [i32]; h.mi_gemm_set_krot.restype = None
-        if os.environ.get("HFASR_GEMM_KROT"):
-            h.mi_gemm_set_krot(int(os.environ["HFASR_GEMM_KROT"]))
-        h.mi_gemm_set_variant.argtypes = [i32]; h.mi_gemm_set_variant.restype = None
-        if os.environ.get("HFASR_GEMM_VARIANT"):
-            h.mi_gemm_set_variant(int(os.environ["HFASR_GEMM_VARIANT"]))
-        h.mi_gemm_set_debug.argtypes = [i32]; h.mi_gemm_set_debug.restype = None
         if os.environ.get("HFASR_TN_WIDE"):
             h.mi_gemm_tn_set_wide.restype = None
             h.mi_gemm_tn_set_wide.argtypes = [C.c_int]
@@ -155,8 +147,6 @@ def lib():
             h.mi_gemm_tn_set_target.restype = None
             h.mi_gemm_tn_set_target.argtypes = [C.c_int]
             h.mi_gemm_tn_set_target(int(os.environ["HFASR_TN_TARGET"]))
-        if os.environ.get("HFASR_GEMM_DEBUG"):
-            h.mi_gemm_set_debug(int(os.environ["HFASR_GEMM_DEBUG"]))
         h.mi_last_error.argtypes = []
         h.mi_last_error.restype = C.c_char_p
         _lib = h

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libhfasr_hip.so")
 OBJ = os.path.join(HERE, "build")
-SOURCES = ["gemm_bf16.hip", "gemm_glds.hip", "gemm_256.hip", "gemm_8p.hip", "norm.hip", "conv.hip", "attention.hip", "fbank.hip", "ctc.hip", "ctc_prefix.hip", "decoder.hip", "decoder_step.hip", "whisper.hip", "encoder.hip",
+SOURCES = ["gemm_bf16.hip", "gemm_glds.hip", "gemm_8p.hip", "norm.hip", "conv.hip", "attention.hip", "fbank.hip", "ctc.hip", "ctc_prefix.hip", "decoder.hip", "decoder_step.hip", "whisper.hip", "encoder.hip",
            "train_ops.hip", "gemm_tn.hip", "bgemm.hip", "attn_bwd.hip", "conv_bwd.hip", "loss_bwd.hip", "dropout.hip", "bestrq.hip", "specaug.hip", "speed.hip"]
 # -packed-fp32-ops (device side only): no v_pk_{add,mul,fma}_f32 in any kernel.  A wave executing packed-f32 VALU ops next to the LDS-DMA GEMM's
 # waves on one CU (kernels from two streams) lost the low-half product on 16 lanes in ~3 % of launches (tools/dbg/README.md); without packed
@@ -45,6 +45,9 @@ def build(force: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     if force:
         for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    for f in os.listdir(OBJ):          # objects of sources that no longer exist
+        if f.endswith(".o") and f.replace(".o", ".hip") not in SOURCES:
             os.remove(os.path.join(OBJ, f))
     with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(_compile, SOURCES))

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
 // 128-B (fp32) / 64-B (bf16) row segments.
 constexpr int B128_BUF = 32768, B128_BOFF = 16384;
 
-template <int NB>     // ring depth (K tiles of 32 KiB): 4 -> three tiles requested ahead, 5 -> four (all 160 KiB of LDS)
+template <int NB>     // ring depth (K tiles of 32 KiB): 4 -> three tiles requested ahead (measured: a 5-deep ring, all 160 KiB of LDS, is 7 % SLOWER at K = 2048)
 __global__ __launch_bounds__(512, 2) void gemm8p128_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -643,7 +643,6 @@ int gemm_8p128_launch(const GemmArgs& a, int ring, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p128_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * B128_BUF);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p128_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * B128_BUF);
         attr_set = true;
     }
     const int grid = cdiv(a.M, 128) * (a.N / 128);
@@ -653,7 +652,6 @@ int gemm_8p128_launch(const GemmArgs& a, int ring, hipStream_t stream) {
         hipLaunchKernelGGL(gemm8p128p_kernel, dim3(grid), dim3(512), (size_t)4 * B128_BUF, stream, a);
         return MI_OK;
     }
-    if (ring == 5) hipLaunchKernelGGL(gemm8p128_kernel<5>, dim3(grid), dim3(512), (size_t)5 * B128_BUF, stream, a);
-    else hipLaunchKernelGGL(gemm8p128_kernel<4>, dim3(grid), dim3(512), (size_t)4 * B128_BUF, stream, a);
+    hipLaunchKernelGGL(gemm8p128_kernel<4>, dim3(grid), dim3(512), (size_t)4 * B128_BUF, stream, a);
     return MI_OK;
 }

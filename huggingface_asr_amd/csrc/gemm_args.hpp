@@ -12,8 +12,7 @@ struct GemmArgs {
     int act;                                // 0 none, 1 gelu(erf)
     int col_T, col_Tp;                      // != 0: output column n -> (n / col_T) * col_Tp + n % col_T
     int M, N, K;
-    int dbg;                                // timing experiments only
-    int krot;                               // fast path: rotate the K loop start per block
+    int variant;                            // kernel selection for A/B runs and tests (mi_gemm_bf16_v); 0 = the product's dispatch.  Per call: no process state.
     // implicit im2col (CONV): A is a channels-last activation (B, Tin, Fin, Cin); row m = (b, to, fo);
     // k = (kh*KW + kw)*Cin + c
     int Tin, Fin, Cin, Tout, Fout, KW, stride, pad_t, pad_f;
@@ -23,9 +22,6 @@ struct GemmArgs {
 bool gemm_glds_supported(const GemmArgs& a, bool conv);
 int gemm_glds_launch(const GemmArgs& a, bool conv, hipStream_t stream);
 
-// gemm_256.hip: 256x256 tiles, 8 waves, 4-deep ring of 32-wide K tiles (N % 256 == 0, K % 32 == 0)
-bool gemm_256_supported(const GemmArgs& a);
-int gemm_256_launch(const GemmArgs& a, hipStream_t stream);
 
 // gemm_8p.hip: 256x256x64 tiles, 8 waves, phase-interleaved schedule on a two-deep LDS ring (bf16 out, N % 256 == 0, K % 64 == 0, K >= 128)
 bool gemm_8p_supported(const GemmArgs& a, bool conv);

@@ -203,26 +203,33 @@ int launch(const GemmArgs& a, bool conv, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int mi_gemm_bf16(const void* A, long lda, const void* W, long ldw, const float* bias, int bias_mode,
-                            void* C, long ldc, int out_f32, const float* resid, long ldr, float alpha, int act,
-                            int M, int N, int K, int col_T, int col_Tp, hipStream_t stream) {
+extern "C" int mi_gemm_bf16_v(const void* A, long lda, const void* W, long ldw, const float* bias, int bias_mode,
+                              void* C, long ldc, int out_f32, const float* resid, long ldr, float alpha, int act,
+                              int M, int N, int K, int col_T, int col_Tp, int variant, hipStream_t stream) {
     MI_ENTER();
     GemmArgs a{};
+    a.variant = variant;
     a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw;
     a.bias = bias; a.bias_mode = bias ? bias_mode : 0;
     a.C = C; a.ldc = ldc; a.out_f32 = out_f32; a.resid = resid; a.ldr = ldr; a.alpha = alpha; a.act = act;
     a.M = M; a.N = N; a.K = K; a.col_T = col_T; a.col_Tp = col_Tp;
     return launch(a, false, stream);
 }
+extern "C" int mi_gemm_bf16(const void* A, long lda, const void* W, long ldw, const float* bias, int bias_mode,
+                            void* C, long ldc, int out_f32, const float* resid, long ldr, float alpha, int act,
+                            int M, int N, int K, int col_T, int col_Tp, hipStream_t stream) {
+    return mi_gemm_bf16_v(A, lda, W, ldw, bias, bias_mode, C, ldc, out_f32, resid, ldr, alpha, act, M, N, K, col_T, col_Tp, 0, stream);
+}
 
 // Conv2d (KHxKW, stride s, zero padding) over a channels-last bf16 activation as an implicit GEMM:
 //   in  (B, Tin, Fin, Cin) bf16, weight (Cout, KH*KW*Cin) bf16 with k = (kh*KW + kw)*Cin + c,
 //   out (B, Tout, Fout, Cout) bf16 = act(conv + bias).
-extern "C" int mi_conv2d_cl_bf16(const void* in, const void* weight, const float* bias, void* out,
-                                 int B, int Tin, int Fin, int Cin, int Cout, int KH, int KW, int stride,
-                                 int pad_t, int pad_f, int Tout, int Fout, int act, hipStream_t stream) {
+extern "C" int mi_conv2d_cl_bf16_v(const void* in, const void* weight, const float* bias, void* out,
+                                   int B, int Tin, int Fin, int Cin, int Cout, int KH, int KW, int stride,
+                                   int pad_t, int pad_f, int Tout, int Fout, int act, int variant, hipStream_t stream) {
     MI_ENTER();
     GemmArgs a{};
+    a.variant = variant;
     a.A = (const bf16_t*)in; a.lda = 0; a.W = (const bf16_t*)weight; a.ldw = (long)KH * KW * Cin;
     a.bias = bias; a.bias_mode = bias ? 1 : 0;
     a.C = out; a.ldc = Cout; a.out_f32 = 0; a.resid = nullptr; a.ldr = 0; a.alpha = 1.f; a.act = act;
@@ -230,4 +237,9 @@ extern "C" int mi_conv2d_cl_bf16(const void* in, const void* weight, const float
     a.Tin = Tin; a.Fin = Fin; a.Cin = Cin; a.Tout = Tout; a.Fout = Fout; a.KW = KW; a.stride = stride;
     a.pad_t = pad_t; a.pad_f = pad_f;
     return launch(a, true, stream);
+}
+extern "C" int mi_conv2d_cl_bf16(const void* in, const void* weight, const float* bias, void* out,
+                                 int B, int Tin, int Fin, int Cin, int Cout, int KH, int KW, int stride,
+                                 int pad_t, int pad_f, int Tout, int Fout, int act, hipStream_t stream) {
+    return mi_conv2d_cl_bf16_v(in, weight, bias, out, B, Tin, Fin, Cin, Cout, KH, KW, stride, pad_t, pad_f, Tout, Fout, act, 0, stream);
 }

@@ -111,9 +111,7 @@ __device__ __forceinline__ void gemm_glds_tile(const GemmArgs& p, int bid, char*
 
     const int nk = p.K / BK;
     const int lr = lane & 31, lh = lane >> 5;
-    if (p.dbg & 8) return;                       // timing experiment: launch + setup only
-    const int krot = p.krot ? (int)((unsigned)(tm * 5 + tn * 3) % (unsigned)nk) : 0;
-    auto ktile = [&](int t) { int v = t + krot; return v >= nk ? v - nk : v; };
+    auto ktile = [&](int t) { return t; };
 
     if (!prologue_done) {
 #pragma unroll
@@ -129,8 +127,7 @@ __device__ __forceinline__ void gemm_glds_tile(const GemmArgs& p, int bid, char*
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");    // every wave's pieces of tile kt landed; stage of tile kt-1 is free
-        if (kt + STAGES - 1 < nk && !(p.dbg & 2)) issue(ktile(kt + STAGES - 1), (kt + STAGES - 1) % STAGES);
-        if (p.dbg & 1) continue;
+        if (kt + STAGES - 1 < nk) issue(ktile(kt + STAGES - 1), (kt + STAGES - 1) % STAGES);
         const char* a = smem + stage * STG;
         const char* b = a + ABYTES;
 #pragma unroll
@@ -171,15 +168,6 @@ __device__ __forceinline__ void gemm_glds_tile(const GemmArgs& p, int bid, char*
             __builtin_amdgcn_global_load_lds((gptr_t)sp, (lptr_t)(sbase + q * 1024), 16, 0, 0);
         }
     };
-    if (p.dbg & 4) {                             // timing experiment: no epilogue (keep the accumulators alive)
-        float keep = 0.f;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) keep += acc[i][j][0];
-        if (keep == 123.456f) reinterpret_cast<float*>(p.C)[0] = keep;
-        return;
-    }
     // ---- epilogue straight from the accumulators, no LDS, no block barrier: the MFMAs were issued as W·A^T, so a lane owns
     // output ROW m = lane&31 and its registers walk the COLUMNS: 4 consecutive n per register group -> fp32 leaves as 16-B
     // stores, bf16 is widened to 16 B per lane with v_permlane32_swap (halves hold n+0..3 / n+4..7 of the same row).
@@ -294,7 +282,7 @@ template <int TBM, int TBN, int CWM, int CWN, int STAGES, bool CONV>
 __global__ __launch_bounds__(CWM * CWN * 64, (TBM <= 128 && TBN <= 128 && STAGES == 2) ? 2 : 1) void gemm_glds_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = ((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN);
-    const bool pf = !CONV && STAGES == 2 && p.krot == 0 && !(p.dbg & 15);
+    const bool pf = !CONV && STAGES == 2;
     for (int tile = blockIdx.x; tile < nwg; tile += gridDim.x) {
         const bool first = tile == (int)blockIdx.x;
         if (!first && !pf) asm volatile("s_barrier" ::: "memory");     // every wave is done reading the previous tile's last LDS stage
@@ -302,18 +290,7 @@ __global__ __launch_bounds__(CWM * CWN * 64, (TBM <= 128 && TBN <= 128 && STAGES
         gemm_glds_tile<TBM, TBN, CWM, CWN, STAGES, CONV>(p, tile, smem, next, pf && !first);
     }
 }
-
-int g_variant = 0;   // 0: symmetric kernel above; 1: loader/consumer 128x128; 2: loader/consumer 256x128 where it fills the chip
-int g_stages = 2;
-int g_dbg = 0;
-int g_krot = 0;   // measured: rotating the K loop start per block does not help (no channel camping on these shapes)   // tuning knob (mi_gemm_set_stages), default chosen from measurements
-
 }  // namespace
-
-extern "C" void mi_gemm_set_stages(int stages) { g_stages = (stages >= 2 && stages <= 4) ? stages : 2; }
-extern "C" void mi_gemm_set_krot(int on) { g_krot = on; }
-extern "C" void mi_gemm_set_variant(int v) { g_variant = v; }
-extern "C" void mi_gemm_set_debug(int v) { g_dbg = v; }   // timing experiments only: 1 = no MFMA, 2 = no loads (wrong results)
 
 bool gemm_glds_supported(const GemmArgs& a, bool conv) {
     if ((a.K % BK) != 0 || a.M <= 0 || a.N <= 0) return false;
@@ -324,57 +301,33 @@ bool gemm_glds_supported(const GemmArgs& a, bool conv) {
     return true;
 }
 
-int gemm_glds_launch(const GemmArgs& a_in, bool conv, hipStream_t stream) {
-    if (!gemm_glds_supported(a_in, conv)) return MI_ERR_UNSUPPORTED;
-    GemmArgs a = a_in;
-    a.krot = g_krot;
-    a.dbg = g_dbg;
-    // symmetric kernels: 256x256 tiles when they still give every CU a block, else 128x128 at two blocks per CU
+// Kernel selection.  a.variant (mi_gemm_bf16_v / mi_conv2d_cl_bf16_v; 0 from every product call site) exists for A/B runs and for tests that must reach a kernel
+// at a size its default dispatch would not pick:  40 = phase kernels wherever supported, 41 = never (this file's kernels only), 42 = 128x128 phase kernel wherever
+// supported, 47 = its two-segment form, 30 = this file's 128x128 tiles, 31 = the same, one block per tile.
+int gemm_glds_launch(const GemmArgs& a, bool conv, hipStream_t stream) {
+    if (!gemm_glds_supported(a, conv)) return MI_ERR_UNSUPPORTED;
+    const int v = a.variant;
+    const bool phase_ok = v != 41 && v != 30 && v != 31;
+    // wide-N bf16-out GEMMs (FFN in, cgMLP in, QKV) and the implicit-GEMM conv: 256x256 tiles on the phase-interleaved schedule (gemm_8p.hip) once the tiles fill half the chip
     const int t256 = cdiv(a.M, 256) * cdiv(a.N, 256);
-    // opt-in (HFASR_GEMM_VARIANT=20): 256x256 tiles on a 4-deep ring of 32-wide K tiles (gemm_256.hip).  Measured: +8 % on the isolated
-    // 8000x2048x512 GEMM, +4 % at 8192^3, nothing on the end-to-end step -> not the default.
-    if (!conv && g_variant == 20 && gemm_256_supported(a)) return gemm_256_launch(a, stream);
-    // wide-N bf16-out GEMMs (FFN in, cgMLP in, QKV): 256x256 tiles on the phase-interleaved schedule (gemm_8p.hip) once the tiles fill half the chip;
-    // HFASR_GEMM_VARIANT=40 takes it for every supported shape (tests), 41 never
-    if (g_variant != 41 && g_variant != 30 && g_variant != 31 && gemm_8p_supported(a, conv) && (t256 >= 128 || g_variant == 40)) return gemm_8p_launch(a, conv, stream);
-    // N = 512-class GEMMs: 128x128 tiles on the same schedule (fp32 + residual or bf16 out); 42 = wherever supported, 43 = never
-    if (!conv && g_variant != 41 && g_variant != 43 && g_variant != 30 && g_variant != 31 && gemm_8p128_supported(a) && (cdiv(a.M, 128) * (a.N / 128) >= 128 || g_variant == 40 || g_variant == 42))
-        return gemm_8p128_launch(a, g_variant == 45 ? 5 : (g_variant != 47 && (a.K % 128) == 0) ? 0 : 4, stream);   // 0 = register-pipelined form (even number of K tiles); 47 forces the two-segment form
-    if (g_variant == 6 && t256 >= 200 && (a.N % 256) == 0) {   // opt-in: no gain on this workload's K=512 shapes, spills with look-ahead
-        const size_t l = (size_t)2 * (256 + 256) * BK * 2;
-        if (conv) hipLaunchKernelGGL((gemm_glds_kernel<256, 256, 2, 4, 2, true>), dim3(t256), dim3(512), l, stream, a);
-        else hipLaunchKernelGGL((gemm_glds_kernel<256, 256, 2, 4, 2, false>), dim3(t256), dim3(512), l, stream, a);
-        return MI_OK;
-    }
-    // Default for the dense (non-conv) GEMMs: 128 x 64 output tiles, 48 KiB of LDS -> THREE persistent blocks per CU (768 walk the tiles).  In the real step
-    // the operands arrive cold (the other kernels move hundreds of MB between two GEMMs) and every K step of a block is a dependent fetch: what pays is
-    // more blocks in flight per CU, not fewer bytes per flop.  Measured end to end (bench.py, one box, same build): 128x128 / 512 blocks 7.04 ms per step,
-    // 128x64 / 768 blocks 6.57, 128x64 one block per tile 6.74, 64x64 / 1024 blocks 6.80, 64x128 7.90, 128x32 7.81; the conv GEMM (K = 2304) stays at 128x128.
-    // HFASR_GEMM_VARIANT=30 restores the 128x128 tiles for A/B.
-    // Only SHORT launches take the small tile: up to ~48 K steps of 128 x 128 work per CU (every encoder-layer GEMM of the base model at 32 x 10 s: 31.5).  Longer ones
-    // (Whisper-small at 16 x 30 s: 53 and up; the CTC head: 79) amortise their start-up and are 5 % faster on 128 x 128 tiles (fewer bytes per flop).
+    if (phase_ok && gemm_8p_supported(a, conv) && (t256 >= 128 || v == 40)) return gemm_8p_launch(a, conv, stream);
+    // N = 512-class GEMMs: 128x128 tiles (fp32 + residual or bf16 out); register-pipelined form for an even number of K tiles
+    if (!conv && phase_ok && gemm_8p128_supported(a) && (cdiv(a.M, 128) * (a.N / 128) >= 128 || v == 40 || v == 42 || v == 47))
+        return gemm_8p128_launch(a, (v != 47 && (a.K % 128) == 0) ? 0 : 4, stream);
+    // Everything else (small problems, the CTC head's odd N, K < 320): this file's LDS-DMA kernel.  Short launches — up to ~48 K steps of 128 x 128 work per CU — run
+    // 128 x 64 output tiles, 48 KiB of LDS -> THREE persistent blocks per CU (blocks in flight beat bytes per flop when operands arrive cold); longer ones
+    // (the CTC head: 79) and the conv GEMM keep 128 x 128 tiles, two persistent blocks per CU, the next tile's first K tile prefetched under the epilogue.
     const long steps_per_cu = (long)cdiv(a.M, BM) * cdiv(a.N, BN) * (a.K / BK) / 256;
-    if (!conv && g_variant != 30 && g_variant != 31 && g_stages == 2 && (steps_per_cu <= 48 || g_variant == 8)) {
+    if (!conv && v != 30 && v != 31 && steps_per_cu <= 48) {
         int g = cdiv(a.M, 128) * cdiv(a.N, 64);
         if (g > 768) g = 768;
         hipLaunchKernelGGL((gemm_glds_kernel<128, 64, 2, 2, 2, false>), dim3(g), dim3(NT), (size_t)2 * (128 + 64) * BK * 2, stream, a);
         return MI_OK;
     }
     int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
-    // 128 x 128 tiles (conv GEMM; dense GEMMs with HFASR_GEMM_VARIANT=30 / 31 or a non-default ring depth): persistent grid of two blocks per CU, the next
-    // tile's first K tile prefetched under the epilogue; variant 31 = one block per tile
-    if (g_variant != 31 && grid > 512) grid = 512;
-    const int stages = g_stages;
-    const size_t lds = (size_t)stages * STAGE_BYTES;
-    if (stages == 4) {
-        if (conv) hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, 4, true>), dim3(grid), dim3(NT), lds, stream, a);
-        else hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, 4, false>), dim3(grid), dim3(NT), lds, stream, a);
-    } else if (stages == 2) {
-        if (conv) hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, 2, true>), dim3(grid), dim3(NT), lds, stream, a);
-        else hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, 2, false>), dim3(grid), dim3(NT), lds, stream, a);
-    } else {
-        if (conv) hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, 3, true>), dim3(grid), dim3(NT), lds, stream, a);
-        else hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, 3, false>), dim3(grid), dim3(NT), lds, stream, a);
-    }
+    if (v != 31 && grid > 512) grid = 512;
+    const size_t lds = (size_t)2 * STAGE_BYTES;
+    if (conv) hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, 2, true>), dim3(grid), dim3(NT), lds, stream, a);
+    else hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, 2, false>), dim3(grid), dim3(NT), lds, stream, a);
     return MI_OK;
 }

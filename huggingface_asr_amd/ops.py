@@ -31,19 +31,19 @@ def _req(t: torch.Tensor, dtype=None):
 
 
 def gemm(a, w, bias=None, out=None, *, out_dtype=BF16, act="none", resid=None, alpha=1.0, bias_per_row=False,
-         col_remap=None):
-    """out[M,N] = epi(a[M,K] @ w[N,K]^T); a/w bf16 (last dim contiguous)."""
+         col_remap=None, variant=0):
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T); a/w bf16 (last dim contiguous).  `variant`: kernel selection of mi_gemm_bf16_v (tests / A-B tools; 0 = product dispatch)."""
     _req(a, BF16); _req(w, BF16)
     M, K = a.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=out_dtype)
     ct, ctp = col_remap if col_remap else (0, 0)
-    rc = _lib.lib().mi_gemm_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _p(bias),
-                                 (2 if bias_per_row else 1) if bias is not None else 0,
-                                 out.data_ptr(), out.stride(0), int(out.dtype == torch.float32),
-                                 _p(resid), resid.stride(0) if resid is not None else 0, float(alpha),
-                                 {"none": 0, "gelu": 1, "gelu_new": 2}[act], M, N, K, ct, ctp, _stream())
+    rc = _lib.lib().mi_gemm_bf16_v(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _p(bias),
+                                   (2 if bias_per_row else 1) if bias is not None else 0,
+                                   out.data_ptr(), out.stride(0), int(out.dtype == torch.float32),
+                                   _p(resid), resid.stride(0) if resid is not None else 0, float(alpha),
+                                   {"none": 0, "gelu": 1, "gelu_new": 2}[act], M, N, K, ct, ctp, int(variant), _stream())
     _lib.check(rc, "mi_gemm_bf16")
     return out
 
@@ -62,7 +62,7 @@ def conv2d_first_gelu(x, w, bias, stride=2, pad=1, causal=False):
     return out
 
 
-def conv2d_cl(x, w, bias, K=3, stride=2, pad=1, causal=False, act="gelu"):
+def conv2d_cl(x, w, bias, K=3, stride=2, pad=1, causal=False, act="gelu", variant=0):
     """x (B,T,F,Cin) bf16 channels-last, w (Cout, KH*KW*Cin) bf16 -> (B,T',F',Cout) bf16.  K / pad may be (time, freq) pairs
     (a Conv1d over time is K=(k,1), pad=(p,0) on an F=1 layout)."""
     B, T, F, Cin = x.shape
@@ -72,8 +72,8 @@ def conv2d_cl(x, w, bias, K=3, stride=2, pad=1, causal=False, act="gelu"):
     T1, F1 = (T + 2 * pt - KH) // stride + 1, (F + 2 * pf - KW) // stride + 1
     out = torch.empty((B, T1, F1, Cout), device=x.device, dtype=BF16)
     plt, plf = (2 * pt, 2 * pf) if causal else (pt, pf)
-    rc = _lib.lib().mi_conv2d_cl_bf16(x.data_ptr(), w.data_ptr(), _p(bias), out.data_ptr(), B, T, F, Cin, Cout, KH, KW, stride,
-                                      plt, plf, T1, F1, {"none": 0, "gelu": 1}[act], _stream())
+    rc = _lib.lib().mi_conv2d_cl_bf16_v(x.data_ptr(), w.data_ptr(), _p(bias), out.data_ptr(), B, T, F, Cin, Cout, KH, KW, stride,
+                                        plt, plf, T1, F1, {"none": 0, "gelu": 1}[act], int(variant), _stream())
     _lib.check(rc, "mi_conv2d_cl_bf16")
     return out
 

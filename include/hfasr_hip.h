@@ -26,16 +26,13 @@ typedef struct ihipStream_t* mi_stream_t; /* = hipStream_t */
 const char* mi_last_error(void);
 
 /* profiling facility (off by default; process-global, not thread-safe, not for production): HIP events recorded on
- * the launch stream around every launch of the dense GEMM kernel, for bench.py's roofline.achieved. */
+ * the launch stream around every launch of a dense contraction (GEMM / implicit-GEMM conv), for bench.py's roofline.achieved. */
 int mi_profile_create(int capacity);
 void mi_profile_enable(int on);
 void mi_profile_reset(void);
 int mi_profile_count(void);
 int mi_profile_summary(double* total_ms, double* total_flops);
 int mi_profile_calibrate(mi_stream_t stream, int n, double* median_ms);   /* cost of an empty event pair (subtracted per launch by bench.py) */
-
-/* tuning knob: LDS ring depth of the pipelined GEMM (2: 64 KiB, two blocks per CU; 3: 96 KiB, one block per CU). */
-void mi_gemm_set_stages(int stages);
 
 /* ---- nn.Linear / lm_head / projections: C[M,N] = epi(A[M,K] * W[N,K]^T), bf16 in, fp32 accumulate (MFMA).
  * replaces: every nn.Linear on the path — reference src/models/encoders/e_branchformer.py:96-98,139,212-216,247,456-457;
@@ -46,12 +43,21 @@ void mi_gemm_set_stages(int stages);
 int mi_gemm_bf16(const void* A, long lda, const void* W, long ldw, const float* bias, int bias_mode,
                  void* C, long ldc, int out_f32, const float* resid, long ldr, float alpha, int act,
                  int M, int N, int K, int col_T, int col_Tp, mi_stream_t stream);
+/* the same with an explicit kernel selection (A/B runs, tests that must reach a kernel below the size its default dispatch picks it at): 0 = the product's
+ * dispatch (= mi_gemm_bf16), 40 / 41 = phase-interleaved kernels wherever supported / never, 42 / 47 = the 128x128 phase kernel (pipelined / two-segment form),
+ * 30 / 31 = the older 128x128 LDS-DMA tiles (persistent / one block per tile).  Per call — the library keeps no kernel-selection state. */
+int mi_gemm_bf16_v(const void* A, long lda, const void* W, long ldw, const float* bias, int bias_mode,
+                   void* C, long ldc, int out_f32, const float* resid, long ldr, float alpha, int act,
+                   int M, int N, int K, int col_T, int col_Tp, int variant, mi_stream_t stream);
 
 /* ---- Conv2d sub-sampling, second layer (C->C, KxK, stride s) as implicit GEMM over a channels-last activation.
  * replaces: src/models/extractors.py:71-96 (layers >= 1) incl. the causal left-padded form src/models/streaming_modules.py:31-55. */
 int mi_conv2d_cl_bf16(const void* in, const void* weight, const float* bias, void* out,
                       int B, int Tin, int Fin, int Cin, int Cout, int KH, int KW, int stride,
                       int pad_t, int pad_f, int Tout, int Fout, int act, mi_stream_t stream);
+int mi_conv2d_cl_bf16_v(const void* in, const void* weight, const float* bias, void* out,
+                        int B, int Tin, int Fin, int Cin, int Cout, int KH, int KW, int stride,
+                        int pad_t, int pad_f, int Tout, int Fout, int act, int variant, mi_stream_t stream);   /* variant: as mi_gemm_bf16_v */
 
 /* ---- Conv2d sub-sampling, first layer (1->C) + GELU over the padded (B,T,F) fp32 log-mel layout; output channels-last bf16.
  * replaces: src/models/extractors.py:71-96 (layer 0) and :111. */

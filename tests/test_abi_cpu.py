@@ -31,11 +31,11 @@ def test_header_symbols_exported(built):
     assert len(decl) >= 16
     for name, nargs in decl.items():
         assert hasattr(h, name), f"{name} declared in hfasr_hip.h but not exported"
-        if name.startswith("mi_profile_") or name == "mi_gemm_set_stages":
+        if name.startswith("mi_profile_"):
             continue
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
         assert len(_lib.SIGNATURES[name]) == nargs, f"{name}: header has {nargs} args, binding {len(_lib.SIGNATURES[name])}"
-    assert set(_lib.SIGNATURES) == {n for n in decl if not n.startswith("mi_profile_") and n != "mi_gemm_set_stages"}
+    assert set(_lib.SIGNATURES) == {n for n in decl if not n.startswith("mi_profile_")}
     assert hasattr(h, "mi_last_error")
 
 

@@ -5,7 +5,6 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from huggingface_asr_amd import ops, _lib
 dev = "cuda:0"
-h = _lib.lib()
 torch.manual_seed(0)
 variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "41,40").split(",")]
 for (B, T, Fd, Cin, Cout, causal) in [(2, 61, 40, 64, 256, False), (3, 100, 40, 128, 256, True), (32, 500, 40, 256, 256, False)]:
@@ -18,23 +17,20 @@ for (B, T, Fd, Cin, Cout, causal) in [(2, 61, 40, 64, 256, False), (3, 100, 40, 
     outs = {}
     line = f"B{B} T{T} F{Fd} Cin{Cin} causal={causal}"
     for v in variants:
-        h.mi_gemm_set_variant(v)
-        o = ops.conv2d_cl(x, wp, b, causal=causal)
+        o = ops.conv2d_cl(x, wp, b, causal=causal, variant=v)
         torch.cuda.synchronize()
         outs[v] = o
         line += f" | v{v} err {float((o.float() - ref).abs().max()):.4f}"
     line += f" | equal {bool(torch.equal(outs[variants[0]], outs[variants[-1]]))}"
     for rnd in range(2):
         for v in variants:
-            h.mi_gemm_set_variant(v)
-            for _ in range(2): ops.conv2d_cl(x, wp, b, causal=causal)
+            for _ in range(2): ops.conv2d_cl(x, wp, b, causal=causal, variant=v)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(10): ops.conv2d_cl(x, wp, b, causal=causal)
+            for _ in range(10): ops.conv2d_cl(x, wp, b, causal=causal, variant=v)
             e1.record(); torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 100
             M = o.numel() // Cout
             if rnd: line += f" | v{v} {us:.1f} us {2.0 * M * Cout * 9 * Cin / us / 1e6:.0f} TF"
     print(line, flush=True)
-h.mi_gemm_set_variant(0)

@@ -2,8 +2,8 @@
 
     python tools/gemm_ab.py [variants, default "41,0"]  [--cold]
 
-Variants are the values of mi_gemm_set_variant (0 default dispatch, 40 = 256x256 phase kernel wherever supported, 41 = never,
-30 = 128x128 tiles).  --cold writes 512 MB to another buffer between launches (the state a real step leaves the memory system in).
+Variants are the per-call kernel selection of mi_gemm_bf16_v (0 default dispatch, 40 = phase kernels wherever supported, 41 = never,
+42 / 47 = 128x128 phase kernel pipelined / two-segment, 30 = older 128x128 tiles).  --cold writes 512 MB to another buffer between launches (the state a real step leaves the memory system in).
 """
 import os, sys
 import torch
@@ -14,7 +14,6 @@ dev = "cuda:0"
 variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "41,0").split(",")]
 cold = "--cold" in sys.argv
 torch.manual_seed(0)
-h = _lib.lib()
 
 shapes = [  # M, N, K, kind
     (8000, 2048, 512, "gelu"), (8000, 2048, 512, "none"), (8000, 1536, 512, "none"), (8000, 2048, 128, "gelu"), (8000, 2048, 192, "none"),
@@ -24,12 +23,12 @@ shapes = [  # M, N, K, kind
 scratch = torch.empty(128 * 1024 * 1024, device=dev) if cold else None
 
 
-def run(a, w, b, out, kind, r):
+def run(a, w, b, out, kind, r, v=0):
     if kind == "resid":
-        return ops.gemm(a, w, b, out=out, resid=r, alpha=0.5)
+        return ops.gemm(a, w, b, out=out, resid=r, alpha=0.5, variant=v)
     if kind == "f32":
-        return ops.gemm(a, w, b, out=out)
-    return ops.gemm(a, w, b, out=out, act="gelu" if kind == "gelu" else "none")
+        return ops.gemm(a, w, b, out=out, variant=v)
+    return ops.gemm(a, w, b, out=out, act="gelu" if kind == "gelu" else "none", variant=v)
 
 
 for (m, n, k, kind) in shapes:
@@ -45,10 +44,9 @@ for (m, n, k, kind) in shapes:
     line = f"{m}x{n}x{k} {kind:5s}"
     outs = {}
     for v in variants:
-        h.mi_gemm_set_variant(v)
         out = torch.full((m, n), float("nan"), device=dev, dtype=torch.float32 if kind in ("resid", "f32") else torch.bfloat16)
         r = r0.clone() if r0 is not None else None
-        run(a, w, b, out, kind, r)
+        run(a, w, b, out, kind, r, v)
         torch.cuda.synchronize()
         err = float((out.float() - ref).abs().max())
         outs[v] = out
@@ -62,26 +60,24 @@ for (m, n, k, kind) in shapes:
     best = {v: [] for v in variants}
     for rnd in range(5):
         for v in variants:
-            h.mi_gemm_set_variant(v)
-            run(a, w, b, out, kind, r)
+            run(a, w, b, out, kind, r, v)
             torch.cuda.synchronize()
             if cold:
                 ts = []
                 for _ in range(iters):
                     scratch.fill_(1.0)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(); run(a, w, b, out, kind, r); e1.record(); torch.cuda.synchronize()
+                    e0.record(); run(a, w, b, out, kind, r, v); e1.record(); torch.cuda.synchronize()
                     ts.append(e0.elapsed_time(e1) * 1e3)
                 best[v].append(sorted(ts)[len(ts) // 2])
             else:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(iters):
-                    run(a, w, b, out, kind, r)
+                    run(a, w, b, out, kind, r, v)
                 e1.record(); torch.cuda.synchronize()
                 best[v].append(e0.elapsed_time(e1) * 1e3 / iters)
     for v in variants:
         t = sorted(best[v])[len(best[v]) // 2]
         line += f" | v{v} {t:7.1f} us {2.0 * m * n * k / t / 1e6:7.1f} TF (min {min(best[v]):.1f})"
     print(line, flush=True)
-h.mi_gemm_set_variant(0)
