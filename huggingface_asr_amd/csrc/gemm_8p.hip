@@ -63,14 +63,15 @@ struct Ctx {
 
 // CONV: A is a channels-last activation (B, Tin, Fin, Cin), row m = (b, to, fo), k = (kh*KW + kw)*Cin + c with Cin % 64 == 0, so a K tile is one
 // tap and a 64-channel slice: the per-lane source row moves with the tap, rows that fall into the zero padding read a 16-B zero page.
-template <bool CONV, int ACT>     // ACT: 0 none, 1 erf-GELU, 2 tanh-GELU — compile-time, so the epilogue is straight-line code with many independent chains in flight
+// OUT32: fp32 output (the CTC head) — N need not be a multiple of the tile: W rows beyond N are clamped, columns beyond N never stored.
+template <bool CONV, int ACT, bool OUT32 = false>     // ACT: 0 none, 1 erf-GELU, 2 tanh-GELU — compile-time, so the epilogue is straight-line code with many independent chains in flight
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
-    const int ntm = (p.M + TB - 1) / TB, ntn = p.N / TB;
+    const int ntm = (p.M + TB - 1) / TB, ntn = (p.N + TB - 1) / TB;
     const int nwg = ntm * ntn;
     int bid = blockIdx.x;
     {   // XCD-aware bijective remap: the blocks of one XCD walk N fastest within an A row panel
@@ -228,6 +229,45 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
     char* reg = smem + wave * 16384;
     const int fr = lane & 15, fq = lane >> 4, swz = (fr >> 1) & 7;
     const int nb = n0 + wc * 64;
+    if constexpr (OUT32) {
+        // fp32 rows (256 B per row of the wave tile): two halves of 64 rows through the same 16-KiB region, 16 lanes x 16 B per row on the way out
+        const int n4 = (p.N + 3) & ~3;                      // ldc >= n4 (checked by the launcher): a 16-B store may cover the row's own padding columns
+        float* C = reinterpret_cast<float*>(p.C);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                       // the bias goes into the accumulators first: no bias registers live across the two halves
+            const int n = nb + j * 16 + fq * 4;
+            f32x4 bj = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias_mode == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < p.N) bj[e] = p.bias[n + e];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i][j] += bj;
+        }
+        const int r16 = lane >> 4, c16 = lane & 15;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = ii * 16 + fr;                                  // row within the half
+                    *reinterpret_cast<f32x4*>(reg + row * 256 + (((j * 4 + fq) ^ (row & 15)) << 4)) = acc[half * 4 + ii][j];
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int row = u * 4 + r16;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * 256 + ((c16 ^ (row & 15)) << 4));
+                const int m = m0 + wr * 128 + half * 64 + row, n = nb + c16 * 4;
+                if (m < p.M && n < n4) *reinterpret_cast<f32x4*>(C + (long)m * p.ldc + n) = v;
+                if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four rows in flight at a time: all 128 accumulator registers are still live in the first half
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the second half overwrites the region
+        }
+        return;
+    }
     f32x4 b4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -599,10 +639,15 @@ __global__ __launch_bounds__(512, 2) void gemm8p128p_kernel(GemmArgs p) {
 }  // namespace
 
 bool gemm_8p_supported(const GemmArgs& a, bool conv) {
-    if (a.M <= 0 || a.N <= 0 || (a.N % TB) != 0 || (a.K % BK) != 0 || a.K < 2 * BK) return false;
-    if (a.out_f32 || a.resid || a.col_T || a.bias_mode == 2) return false;
-    if (((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) || ((uintptr_t)a.C & 15) || (a.ldw % 8) || (a.ldc % 8)) return false;
-    if (a.bias_mode == 1 && ((uintptr_t)a.bias & 15)) return false;
+    if (a.M <= 0 || a.N <= 0 || (a.K % BK) != 0 || a.K < 2 * BK) return false;
+    if (a.resid || a.col_T || a.bias_mode == 2) return false;
+    if (((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) || ((uintptr_t)a.C & 15) || (a.ldw % 8)) return false;
+    if (a.out_f32) {                 // fp32 output (CTC head): any N, no activation, 16-B stores may touch the row's padding up to the next multiple of 4
+        if (conv || a.act != 0 || (a.ldc % 4) != 0 || a.ldc < ((a.N + 3) & ~3)) return false;
+    } else {
+        if ((a.N % TB) != 0 || (a.ldc % 8) != 0) return false;
+        if (a.bias_mode == 1 && ((uintptr_t)a.bias & 15)) return false;
+    }
     if ((long)a.N * a.ldw * 2 >= (1l << 32)) return false;                                             // 32-bit source offsets
     if (conv) {
         if ((a.Cin % BK) != 0 || a.Fout <= 0 || a.Tout <= 0) return false;
@@ -622,7 +667,13 @@ int gemm_8p_launch(const GemmArgs& a, bool conv, hipStream_t stream) {
         attr_set = true;
     }
     if (a.act < 0 || a.act > 2) return MI_ERR_ARG;
-    const int grid = cdiv(a.M, TB) * (a.N / TB);
+    const int grid = cdiv(a.M, TB) * cdiv(a.N, TB);
+    if (a.out_f32) {
+        static bool attr32 = false;
+        if (!attr32) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF); attr32 = true; }
+        hipLaunchKernelGGL((gemm8p_kernel<false, 0, true>), dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
+        return MI_OK;
+    }
     hipLaunchKernelGGL(kerns[conv ? 1 : 0][a.act], dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
     return MI_OK;
 }

@@ -17,7 +17,7 @@ torch.manual_seed(0)
 
 shapes = [  # M, N, K, kind
     (8000, 2048, 512, "gelu"), (8000, 2048, 512, "none"), (8000, 1536, 512, "none"), (8000, 2048, 128, "gelu"), (8000, 2048, 192, "none"),
-    (8000, 512, 2048, "resid"), (8000, 512, 1024, "resid"), (8000, 512, 512, "none"), (8000, 512, 1024, "none"), (8000, 512, 5120, "f32"),
+    (8000, 512, 2048, "resid"), (8000, 512, 1024, "resid"), (8000, 512, 512, "none"), (8000, 512, 1024, "none"), (8000, 512, 5120, "f32"), (8000, 5001, 512, "f32"), (300, 517, 192, "f32"),
     (777, 512, 320, "gelu"), (777, 384, 320, "resid"), (256, 256, 128, "none"), (4096, 4096, 4096, "none"), (8192, 8192, 8192, "none"),
 ]
 scratch = torch.empty(128 * 1024 * 1024, device=dev) if cold else None
@@ -44,7 +44,8 @@ for (m, n, k, kind) in shapes:
     line = f"{m}x{n}x{k} {kind:5s}"
     outs = {}
     for v in variants:
-        out = torch.full((m, n), float("nan"), device=dev, dtype=torch.float32 if kind in ("resid", "f32") else torch.bfloat16)
+        ldp = (n + 7) // 8 * 8                       # rows padded to a multiple of 8 elements, as the engine's logits buffer (16-B stores)
+        out = torch.full((m, ldp), float("nan"), device=dev, dtype=torch.float32 if kind in ("resid", "f32") else torch.bfloat16)[:, :n]
         r = r0.clone() if r0 is not None else None
         run(a, w, b, out, kind, r, v)
         torch.cuda.synchronize()
@@ -55,7 +56,7 @@ for (m, n, k, kind) in shapes:
         line += f" | v{variants[0]}==v{variants[-1]}: {bool(torch.equal(outs[variants[0]], outs[variants[-1]]))} maxdiff {float((outs[variants[0]].float() - outs[variants[-1]].float()).abs().max()):.5f}"
     # interleaved timing rounds
     iters = 20 if m * n * k < 1e11 else 5
-    out = torch.empty((m, n), device=dev, dtype=torch.float32 if kind in ("resid", "f32") else torch.bfloat16)
+    out = torch.empty((m, (n + 7) // 8 * 8), device=dev, dtype=torch.float32 if kind in ("resid", "f32") else torch.bfloat16)[:, :n]
     r = r0
     best = {v: [] for v in variants}
     for rnd in range(5):
