@@ -7,6 +7,15 @@ analytic backward needs no autograd graph — and hands the finished parameter g
 incoming d(loss) (gradient accumulation / loss scaling).  torch's optimizer and DDP hooks then see ordinary `.grad`s.
 The trainer's own all-reduce and AdamW are not used on this route (HF Trainer owns them); the native route is
 `huggingface_asr_amd.train.EncoderCTCTrainer.train_step` / `train_aed.JointAEDTrainer.train_step`.
+
+Zero-copy parameters (round 2).  On the first training forward the bridge ADOPTS the model's nn.Parameters: `p.data` becomes a view into the
+trainer's flat fp32 master store (`alias_views("p")`: reshapes, row slices of the packed [Wq;Wk;Wv] / lm_head ⊕ blank matrices, the
+permuted channels-last conv weight, the transposed GPT-2 Conv1D weights), so torch's optimizer updates the masters in place and a step costs one
+bf16-mirror refresh instead of a state-dict import; the gradients handed to autograd are the matching views of the flat gradient store
+(`alias_views("g")`), which autograd installs as `.grad` without a copy when `.grad` is None (`zero_grad(set_to_none=True)`, torch's and HF Trainer's
+default).  Pieces whose reference layout is not a view of the packed one (the front end's `out` Linear) are copied in / out.  Gradient accumulation
+(`.grad` still set when the next forward starts) takes a slower path that leaves the accumulated `.grad`s intact.  Trainers without `alias_views`
+(BEST-RQ) keep the import / export path.
 """
 from __future__ import annotations
 
@@ -15,41 +24,107 @@ import torch
 
 class HipStep(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, runner, names, *params):
-        """runner(state_dict) -> (dict of output tensors, grad_dict in reference names).  Returns the loss (graph-connected to `params`)."""
-        sd = {n: p.detach() for n, p in zip(names, params)}
-        outs, grads = runner(sd)
-        ctx.grads = [grads.get(n) for n in names]
+    def forward(ctx, bridge, step_fn, *params):
+        outs = bridge._forward(step_fn)
+        ctx.bridge = bridge
         ctx.mark_non_differentiable(*[v for k, v in outs.items() if k != "loss" and torch.is_tensor(v)])
-        runner.outputs = outs
+        bridge.outputs = outs
         return outs["loss"].clone()
 
     @staticmethod
     def backward(ctx, gloss):
-        out = [None, None]
-        for i, g in enumerate(ctx.grads):                   # frozen parameters (requires_grad False: freeze_encoder etc.) get no gradient
-            out.append(None if (g is None or not ctx.needs_input_grad[2 + i]) else g * gloss)
-        return tuple(out)
+        grads = ctx.bridge._grads(gloss)
+        return (None, None) + tuple(g if ctx.needs_input_grad[2 + i] else None for i, g in enumerate(grads))
+
+
+class _Bridge:
+    def __init__(self, model, trainer):
+        self.model, self.trainer = model, trainer
+        self.named = list(model.named_parameters())
+        self.names = [n for n, _ in self.named]
+        pset = set(self.names)
+        self.extra = {k: v for k, v in model.state_dict().items() if k not in pset}      # buffers (e.g. rotary inv_freq)
+        self.zero_copy = hasattr(trainer, "alias_views")
+        self.adopted_ptrs = None
+        self.outputs = None
+        self._saved = None
+
+    # ------------------------------------------------------------------ zero-copy parameters
+    def _adopt(self):
+        """make every aliasable nn.Parameter a view into the flat master store (values carried over); remember the rest for the copy path"""
+        tr = self.trainer
+        tr.load_state_dict({**self.extra, **{n: p.detach() for n, p in self.named}})       # one full import: masters, mirrors, non-parameter state
+        views = tr.alias_views("p")
+        self.copy_names = []
+        with torch.no_grad():
+            for n, p in self.named:
+                v = views.get(n)
+                if v is None or tuple(v.shape) != tuple(p.shape) or v.dtype != p.dtype or v.device != p.device:
+                    self.copy_names.append(n)
+                    continue
+                p.data = v                                  # same values (just imported); from here on optimizer updates land in the flat store
+        self.adopted_ptrs = [p.data_ptr() for _, p in self.named]
+        self._versions = None
+
+    def _still_adopted(self):
+        return self.adopted_ptrs is not None and all(p.data_ptr() == q for (_, p), q in zip(self.named, self.adopted_ptrs))
+
+    def _forward(self, step_fn):
+        tr = self.trainer
+        if hasattr(tr, "set_frozen"):                       # frozen sub-modules: their weight-gradient GEMMs are skipped, not computed and dropped
+            tr.set_frozen({n for n, p in self.named if not p.requires_grad})
+        if not self.zero_copy:
+            tr.load_state_dict({**self.extra, **{n: p.detach() for n, p in self.named}})
+            return step_fn(tr)
+        if not self._still_adopted():                       # first call, or the parameters were re-allocated (model.to(...), .float(), ...)
+            self._adopt()
+        else:
+            pd = dict(self.named)
+            for n in self.copy_names:
+                tr.import_piece(n, pd[n])
+            for st in tr.stores():                          # the optimizer wrote the fp32 masters in place: bf16 mirrors + K-major transposes follow
+                st.refresh_mirrors(cast=True)
+        # gradient accumulation in progress?  (.grad of an adopted parameter still aliases the flat gradient store the step is about to overwrite)
+        self._saved = None
+        bases = {st.flat_g.untyped_storage().data_ptr() for st in tr.stores()}
+        if any(p.grad is not None and p.grad.untyped_storage().data_ptr() in bases for _, p in self.named[:8] + self.named[-8:]):
+            self._saved = [st.flat_g.clone() for st in tr.stores()]
+        return step_fn(tr)
+
+    def _grads(self, gloss):
+        tr = self.trainer
+        if not self.zero_copy:
+            gd = tr.grad_dict()
+            return [None if gd.get(n) is None else gd[n] * gloss for n in self.names]
+        stores = tr.stores()
+        for st in stores:
+            st.flat_g.mul_(gloss)                           # one kernel per store instead of one multiply per parameter
+        copies = {n: tr.export_grad_piece(n) for n in self.copy_names}
+        if self._saved is not None:                         # accumulation: hand out fresh tensors, put the accumulated sums back under the live .grad views
+            fresh = [st.flat_g.clone() for st in stores]
+            for st, old in zip(stores, self._saved):
+                st.flat_g.copy_(old)
+            self._saved = None
+            keep = [st.flat_g for st in stores]
+            try:
+                for st, f in zip(stores, fresh):
+                    st.flat_g = f
+                views = tr.alias_views("g")
+            finally:
+                for st, k in zip(stores, keep):
+                    st.flat_g = k
+        else:
+            views = tr.alias_views("g")
+        return [copies[n] if n in copies else views.get(n) for n in self.names]
 
 
 def run_training_forward(model, trainer, step_fn):
-    """model: nn.Module whose named_parameters() carry the reference names; trainer: object with load_state_dict / grad_dict / zero grads;
-    step_fn(trainer) -> dict of outputs incl. 'loss' (runs forward + backward on the HIP path).  Returns (loss with grad_fn, outputs)."""
-    named = [(n, p) for n, p in model.named_parameters()]
-    names = [n for n, _ in named]
-    extra = {k: v for k, v in model.state_dict().items() if k not in set(names)}      # buffers (e.g. rotary inv_freq)
-
-    class _Runner:
-        outputs = None
-
-        def __call__(self, sd):
-            trainer.load_state_dict({**extra, **sd})
-            outs = step_fn(trainer)
-            grads = trainer.grad_dict()
-            return outs, grads
-
-    if hasattr(trainer, "set_frozen"):                  # frozen sub-modules: their weight-gradient GEMMs are skipped, not computed and dropped
-        trainer.set_frozen({n for n, p in named if not p.requires_grad})
-    runner = _Runner()
-    loss = HipStep.apply(runner, names, *[p for _, p in named])
-    return loss, runner.outputs
+    """model: nn.Module whose named_parameters() carry the reference names; trainer: the HIP trainer (load_state_dict / grad_dict, and for the zero-copy
+    route alias_views / import_piece / export_grad_piece / stores); step_fn(trainer) -> dict of outputs incl. 'loss' (runs forward + backward on the HIP
+    path, zeroing the gradient stores first).  Returns (loss with grad_fn, outputs)."""
+    bridge = getattr(model, "_hip_bridge", None)
+    if bridge is None or bridge.trainer is not trainer or len(bridge.named) != sum(1 for _ in model.parameters()):
+        bridge = _Bridge(model, trainer)
+        object.__setattr__(model, "_hip_bridge", bridge)
+    loss = HipStep.apply(bridge, step_fn, *[p for _, p in bridge.named])
+    return loss, bridge.outputs

@@ -8,8 +8,8 @@ parameters (for state_dict / optimizers / checkpoint averaging); no tensor op of
 
 Eval mode / no_grad: the inference engine (engine.py).  Training mode with labels: forward AND backward run on the HIP trainer
 (train.py) behind a torch.autograd bridge (autograd_bridge.py), so `loss.backward()` fills ordinary `.grad`s for HF Trainer's
-optimizer; configurations the HIP training step does not cover yet (dropout > 0, in-model SpecAugment) raise NotImplementedError
-rather than silently falling back to PyTorch."""
+optimizer; dropout, LayerDrop and in-model SpecAugment are supported (counter-based masks); configurations the HIP training step does not cover
+(causal encoders) raise NotImplementedError rather than silently falling back to PyTorch."""
 from __future__ import annotations
 
 from typing import Optional, Tuple, Union
@@ -195,14 +195,24 @@ class Wav2Vec2EBranchformerForCTC(PreTrainedModel):
         return torch.arange(feature_vector_length, device=attention_mask.device)[None, :] < lens[:, None]
 
     # ---- engine plumbing
+    def _param_list(self):
+        """cached flat list of the parameters (walking the module tree per forward costs more than the check it feeds); parameters are never
+        added or removed after construction"""
+        pl = self.__dict__.get("_plist")
+        if pl is None:
+            pl = list(self.parameters())
+            self.__dict__["_plist"] = pl
+        return pl
+
     def _weights_version(self):
-        return sum(p._version for p in self.parameters())
+        return sum(p._version for p in self._param_list())
 
     def _get_engine(self, device) -> EBranchformerEngine:
         if self._engine is None or self._engine.device != torch.device(device):
             self._engine = EBranchformerEngine(cfg_from_hf(self.config), device)
             self._engine_key = None
-        key = (self._weights_version(), tuple(p.data_ptr() for p in self.parameters()))
+        pl = self._param_list()
+        key = (self._weights_version(), pl[0].data_ptr(), pl[-1].data_ptr(), pl[len(pl) // 2].data_ptr())
         if key != self._engine_key:
             self._engine.load_state_dict({k: v for k, v in self.state_dict().items()})
             self._engine_key = key

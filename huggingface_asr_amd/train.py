@@ -215,19 +215,19 @@ def _enc_map(c: dict, head: bool = True):
     one("conv1_w", f"{fe}conv.0.0{cw}.weight", lambda t: t.reshape(C1, K * K), lambda t: t.reshape(C1, 1, K, K))
     one("conv1_b", f"{fe}conv.0.0{cw}.bias")
     one("conv2_w", f"{fe}conv.1.0{cw}.weight", lambda t: t.permute(0, 2, 3, 1).reshape(C2, K * K * C1),
-        lambda t: t.reshape(C2, K, K, C1).permute(0, 3, 1, 2).contiguous())
+        lambda t: t.reshape(C2, K, K, C1).permute(0, 3, 1, 2))
     one("conv2_b", f"{fe}conv.1.0{cw}.bias")
     one("feout_w", fe + "out.weight", lambda t: t.reshape(d, C2, F2).permute(0, 2, 1).reshape(d, F2 * C2),
-        lambda t: t.reshape(d, F2, C2).permute(0, 2, 1).reshape(d, C2 * F2).contiguous())
+        lambda t: t.reshape(d, F2, C2).permute(0, 2, 1).reshape(d, C2 * F2))
     one("feout_b", fe + "out.bias")
     one("fp_ln_g", fp + "layer_norm.weight"); one("fp_ln_b", fp + "layer_norm.bias")
     one("fp_w", fp + "projection.weight"); one("fp_b", fp + "projection.bias")
     one("enc_ln_g", "wav2vec2.encoder.layer_norm.weight"); one("enc_ln_b", "wav2vec2.encoder.layer_norm.bias")
     if head:
         m["head_w"] = (lambda sd: torch.cat([sd["lm_head.weight"], sd["blank_projection.weight"]], 0),
-                       [("lm_head.weight", lambda t: t[:V].contiguous()), ("blank_projection.weight", lambda t: t[V:].contiguous())])
+                       [("lm_head.weight", lambda t: t[:V]), ("blank_projection.weight", lambda t: t[V:])])
         m["head_b"] = (lambda sd: torch.cat([sd["lm_head.bias"], sd["blank_projection.bias"]], 0),
-                       [("lm_head.bias", lambda t: t[:V].contiguous()), ("blank_projection.bias", lambda t: t[V:].contiguous())])
+                       [("lm_head.bias", lambda t: t[:V]), ("blank_projection.bias", lambda t: t[V:])])
     if c.get("finetune_with_layer_mixing", False):
         one("mix_w", "per_layer_weights")
     for l in range(L + int(bool(c.get("finetune_with_additional_layer", False)))):
@@ -240,9 +240,9 @@ def _enc_map(c: dict, head: bool = True):
         one(p + "att_ln_g", r + "self_attn_layer_norm.weight"); one(p + "att_ln_b", r + "self_attn_layer_norm.bias")
         a = r + "self_attn."
         m[p + "att_wqkv"] = (lambda sd, a=a: torch.cat([sd[a + f"linear_{n}.weight"] for n in "qkv"], 0),
-                             [(a + f"linear_{n}.weight", (lambda t, i=i: t[i * d:(i + 1) * d].contiguous())) for i, n in enumerate("qkv")])
+                             [(a + f"linear_{n}.weight", (lambda t, i=i: t[i * d:(i + 1) * d])) for i, n in enumerate("qkv")])
         m[p + "att_bqkv"] = (lambda sd, a=a: torch.cat([sd[a + f"linear_{n}.bias"] for n in "qkv"], 0),
-                             [(a + f"linear_{n}.bias", (lambda t, i=i: t[i * d:(i + 1) * d].contiguous())) for i, n in enumerate("qkv")])
+                             [(a + f"linear_{n}.bias", (lambda t, i=i: t[i * d:(i + 1) * d])) for i, n in enumerate("qkv")])
         one(p + "att_wo", a + "linear_out.weight"); one(p + "att_bo", a + "linear_out.bias")
         if c.get("position_embeddings_type", "relative") == "relative":
             H = c["num_attention_heads"]
@@ -383,11 +383,46 @@ class EncoderCTCTrainer:
                 continue
             t = view(name)
             for key, fn in self.map[name][1]:
-                out[key] = fn(t).clone()
+                out[key] = fn(t).clone(memory_format=torch.contiguous_format)
         return out
 
     def state_dict(self) -> dict:
         return self._export(self.store.p)
+
+    def alias_views(self, which: str = "p", prefix: str = "") -> dict:
+        """reference name -> a tensor that ALIASES the flat parameter ("p") or gradient ("g") store in the reference's shape (possibly strided: conv2's
+        channels-last weight is a permuted view), for every piece whose reference layout is a view of the packed layout; None where it is not
+        (the front end's `out` Linear, whose columns are re-ordered): those pieces are copied.  The autograd bridge makes the model's nn.Parameters
+        these views, so the HF route neither imports the state dict nor exports gradients per step (autograd_bridge.py)."""
+        flat = self.store.flat_p if which == "p" else self.store.flat_g
+        base = flat.untyped_storage().data_ptr()
+        out = {}
+        for name in self.store.order:
+            if name == "masked_spec_embed" and not getattr(self, "_has_mse", True):
+                continue
+            t = self.store._view(flat, name)
+            for key, fn in self.map[name][1]:
+                v = fn(t)
+                out[prefix + key] = v if v.untyped_storage().data_ptr() == base else None
+        return out
+
+    def stores(self):
+        return [self.store]
+
+    def import_piece(self, key: str, value: torch.Tensor):
+        """copy ONE reference tensor into its (non-aliasable) packed slot"""
+        for name in self.store.order:
+            if len(self.map[name][1]) == 1 and self.map[name][1][0][0] == key:
+                self.store.p(name).copy_(self.map[name][0]({key: value.detach().to(self.device, F32)}).reshape(self.store.specs[name].shape))
+                return
+        raise KeyError(key)
+
+    def export_grad_piece(self, key: str) -> torch.Tensor:
+        for name in self.store.order:
+            for k, fn in self.map[name][1]:
+                if k == key:
+                    return fn(self.store.g(name)).clone(memory_format=torch.contiguous_format)
+        raise KeyError(key)
 
     def set_frozen(self, reference_names):
         """Names (reference state-dict keys) of parameters that do not train (`requires_grad False`: `freeze_encoder()`, train_ctc_asr.py:51-52).

@@ -50,7 +50,8 @@ def _dec_map(c: dict, with_proj: bool, prefix="decoder."):
     L = c["n_layer"]
     m = {}
     one = lambda name, key, fwd=lambda t: t, bwd=lambda t: t: m.__setitem__(name, (lambda sd: fwd(sd[key]), [(key, bwd)]))
-    tr = lambda t: t.t().contiguous()                      # transformers Conv1D stores (in, out)
+    tr_in = lambda t: t.t().contiguous()                   # transformers Conv1D stores (in, out); the store keeps (out, in)
+    tr = lambda t: t.t()                                   # export: a transposed VIEW (alias_views hands it to the nn.Parameter; state_dict() clones it contiguous)
     if with_proj:
         one("proj_w", "enc_to_dec_proj.weight"); one("proj_b", "enc_to_dec_proj.bias")
     t = prefix + "transformer."
@@ -61,15 +62,15 @@ def _dec_map(c: dict, with_proj: bool, prefix="decoder."):
     for l in range(L):
         p, r = f"h{l}.", f"{t}h.{l}."
         one(p + "ln1_g", r + "ln_1.weight"); one(p + "ln1_b", r + "ln_1.bias")
-        one(p + "wqkv", r + "attn.c_attn.weight", tr, tr); one(p + "bqkv", r + "attn.c_attn.bias")
-        one(p + "wo", r + "attn.c_proj.weight", tr, tr); one(p + "bo", r + "attn.c_proj.bias")
+        one(p + "wqkv", r + "attn.c_attn.weight", tr_in, tr); one(p + "bqkv", r + "attn.c_attn.bias")
+        one(p + "wo", r + "attn.c_proj.weight", tr_in, tr); one(p + "bo", r + "attn.c_proj.bias")
         one(p + "lnc_g", r + "ln_cross_attn.weight"); one(p + "lnc_b", r + "ln_cross_attn.bias")
-        one(p + "wq", r + "crossattention.q_attn.weight", tr, tr); one(p + "bq", r + "crossattention.q_attn.bias")
-        one(p + "wkv", r + "crossattention.c_attn.weight", tr, tr); one(p + "bkv", r + "crossattention.c_attn.bias")
-        one(p + "wco", r + "crossattention.c_proj.weight", tr, tr); one(p + "bco", r + "crossattention.c_proj.bias")
+        one(p + "wq", r + "crossattention.q_attn.weight", tr_in, tr); one(p + "bq", r + "crossattention.q_attn.bias")
+        one(p + "wkv", r + "crossattention.c_attn.weight", tr_in, tr); one(p + "bkv", r + "crossattention.c_attn.bias")
+        one(p + "wco", r + "crossattention.c_proj.weight", tr_in, tr); one(p + "bco", r + "crossattention.c_proj.bias")
         one(p + "ln2_g", r + "ln_2.weight"); one(p + "ln2_b", r + "ln_2.bias")
-        one(p + "wfc", r + "mlp.c_fc.weight", tr, tr); one(p + "bfc", r + "mlp.c_fc.bias")
-        one(p + "wpr", r + "mlp.c_proj.weight", tr, tr); one(p + "bpr", r + "mlp.c_proj.bias")
+        one(p + "wfc", r + "mlp.c_fc.weight", tr_in, tr); one(p + "bfc", r + "mlp.c_fc.bias")
+        one(p + "wpr", r + "mlp.c_proj.weight", tr_in, tr); one(p + "bpr", r + "mlp.c_proj.bias")
     one("lnf_g", t + "ln_f.weight"); one("lnf_b", t + "ln_f.bias")
     if not c.get("tie_word_embeddings", False):
         one("lm_head", prefix + "lm_head.weight")
@@ -168,11 +169,44 @@ class JointAEDTrainer:
         for name in self.store.order:
             t = self.store.p(name) if view == "p" else self.store.g(name)
             for key, fn in self.map[name][1]:
-                out[key] = fn(t).clone()
+                out[key] = fn(t).clone(memory_format=torch.contiguous_format)
         return out
 
     def state_dict(self): return self._export("p")
     def grad_dict(self): return self._export("g")
+
+    def alias_views(self, which: str = "p") -> dict:
+        """train.EncoderCTCTrainer.alias_views for both stores (encoder keys prefixed `encoder.`)"""
+        out = self.enc.alias_views(which, prefix="encoder.")
+        flat = self.store.flat_p if which == "p" else self.store.flat_g
+        base = flat.untyped_storage().data_ptr()
+        for name in self.store.order:
+            t = self.store._view(flat, name)
+            for key, fn in self.map[name][1]:
+                v = fn(t)
+                out[key] = v if v.untyped_storage().data_ptr() == base else None
+        return out
+
+    def import_piece(self, key: str, value):
+        if key.startswith("encoder."):
+            return self.enc.import_piece(key[len("encoder."):], value)
+        for name in self.store.order:
+            if len(self.map[name][1]) == 1 and self.map[name][1][0][0] == key:
+                self.store.p(name).copy_(self.map[name][0]({key: value.detach().to(self.device, F32)}).reshape(self.store.specs[name].shape))
+                return
+        raise KeyError(key)
+
+    def export_grad_piece(self, key: str):
+        if key.startswith("encoder."):
+            return self.enc.export_grad_piece(key[len("encoder."):])
+        for name in self.store.order:
+            for k, fn in self.map[name][1]:
+                if k == key:
+                    return fn(self.store.g(name)).clone(memory_format=torch.contiguous_format)
+        raise KeyError(key)
+
+    def stores(self):
+        return [self.enc.store, self.store]
 
     # ------------------------------------------------------------------ decoder forward + backward (called inside the encoder's backward)
     def _decoder(self, last_hidden, B, T2, key_len, labels, out, gs):

@@ -454,6 +454,62 @@ def test_hf_ctc_model_trains_through_autograd_bridge():
     assert torch.isfinite(o.loss) and all(torch.isfinite(p.grad).all() for p in dflt.parameters() if p.grad is not None)
 
 
+def test_hf_route_parameters_and_gradients_alias_the_flat_store():
+    """Round 2: after the first training forward the model's nn.Parameters ARE views of the trainer's flat fp32 master store and the
+    `.grad`s autograd installs ARE views of its flat gradient store — no per-step state-dict import / gradient export; the one piece whose reference layout is
+    not a view of the packed one (the front end's `out` Linear) is copied.  torch's optimizer therefore updates the masters in place; gradient accumulation
+    (no zero_grad between two backwards) sums; re-allocating the parameters (`.to()`) is detected and re-adopted."""
+    from transformers import AutoModelForCTC
+    from huggingface_asr_amd.bind import bind_all
+    from huggingface_asr_amd.configuration_ebranchformer import Wav2Vec2EBranchformerConfig
+    bind_all()
+    g = load_golden("grads_tiny_rel")
+    cfg = dict(shapes.TINY, ctc_zero_infinity=True, ctc_loss_reduction="mean")
+    sd, x, am, lab = case_inputs(g, cfg)
+    base = dict(shapes.TINY); base.pop("num_fbanks")
+    model = AutoModelForCTC.from_config(Wav2Vec2EBranchformerConfig(**base, ctc_zero_infinity=True, ctc_loss_reduction="mean", **HF_NO_DROPOUT))
+    model.load_state_dict(sd, strict=False)
+    model = model.to(DEV).train()
+    batch = dict(input_values=x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))
+    model(**batch).loss.backward()
+    tr = model._trainer
+    pbase, gbase = tr.store.flat_p.untyped_storage().data_ptr(), tr.store.flat_g.untyped_storage().data_ptr()
+    named = dict(model.named_parameters())
+    copied = [n for n, p in named.items() if p.untyped_storage().data_ptr() != pbase]
+    assert copied == ["wav2vec2.feature_extractor.out.weight"], copied
+    conv2 = named["wav2vec2.feature_extractor.conv.1.0.conv.weight"]
+    assert not conv2.is_contiguous() and conv2.untyped_storage().data_ptr() == pbase            # the channels-last packed weight seen through a permuted view
+    for n, p in named.items():
+        assert p.grad is not None and tuple(p.grad.shape) == tuple(p.shape), n
+        if n not in copied:
+            assert p.grad.untyped_storage().data_ptr() == gbase, n
+    ref = {k[5:]: g[k] for k in g.files if k.startswith("grad:")}
+    _compare({n: p.grad for n, p in named.items()}, ref)
+    for n, v in sd.items():                                       # values survived the adoption bit for bit
+        if n in named:
+            assert torch.equal(named[n].detach().cpu(), v), n
+    # accumulation: a second backward without zero_grad doubles the gradients and keeps them where they are
+    g1 = {n: p.grad.clone() for n, p in named.items()}
+    model(**batch).loss.backward()
+    for n, p in named.items():
+        assert p.grad.untyped_storage().data_ptr() == (gbase if n not in copied else p.grad.untyped_storage().data_ptr())
+        torch.testing.assert_close(p.grad, 2.0 * g1[n], rtol=2e-3, atol=1e-6 + 2e-3 * float(g1[n].abs().max()))
+    # an optimizer step lands in the flat store; the next forward sees it (loss moves), and state_dict() returns contiguous copies in the reference layout
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    opt.zero_grad()
+    l0 = float(model(**batch).loss.detach())
+    model.zero_grad(); model(**batch).loss.backward(); opt.step(); opt.zero_grad()
+    assert torch.equal(tr.store.p("head_w")[: cfg["vocab_size"]], named["lm_head.weight"].detach())
+    l1 = float(model(**batch).loss.detach())
+    assert l1 < l0
+    back = tr.state_dict()
+    assert all(v.is_contiguous() for v in back.values()) and torch.equal(back["lm_head.weight"], named["lm_head.weight"].detach())
+    # re-allocated parameters are adopted again
+    model.float(); model.to("cpu"); model.to(DEV)
+    model.zero_grad(); model(**batch).loss.backward()
+    assert dict(model.named_parameters())["lm_head.weight"].untyped_storage().data_ptr() == model._trainer.store.flat_p.untyped_storage().data_ptr()
+
+
 def test_hf_joint_model_trains_through_autograd_bridge():
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
