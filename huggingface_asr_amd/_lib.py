@@ -106,6 +106,7 @@ SIGNATURES = {
     "mi_kv_cache_reorder": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "mi_ebf_workspace_bytes": [C.POINTER(EbfConfig)],
     "mi_ebf_forward": [C.POINTER(EbfConfig), vp, vp, vp, vp, vp, i32, vp, sz, vp, vp, vp, vp, vp],
+    "mi_ebf_forward_hs": [C.POINTER(EbfConfig), vp, vp, vp, vp, vp, i32, vp, sz, vp, vp, vp, vp, vp, vp],
 }
 
 _lib = None

@@ -195,12 +195,15 @@ bool side_ready() {
 extern "C" size_t mi_ebf_workspace_bytes(const mi_ebf_config* cfg) { return carve(*cfg, nullptr).bytes; }
 
 // posp: (L, 2*T2-1, d) bf16 projected relative positions, (re)computed from pos_table when compute_posp != 0
-extern "C" int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weights, const float* feats,
-                              const int* feat_lengths, const void* pos_table, void* posp, int compute_posp,
-                              void* workspace, size_t workspace_bytes, float* last_hidden, void* logits,
-                              int* inner_len, int* outer_len, hipStream_t st) {
+// hidden_states (nullable): (L+1, B*T2, d) fp32 = the tuple HF returns for output_hidden_states (tf:685-713): the input of every encoder layer, then the
+// encoder's last hidden state (after encoder.layer_norm); needs last_hidden.  Device-to-device copies on the same stream, only when asked for.
+extern "C" int mi_ebf_forward_hs(const mi_ebf_config* cfg, const void* const* weights, const float* feats,
+                                 const int* feat_lengths, const void* pos_table, void* posp, int compute_posp,
+                                 void* workspace, size_t workspace_bytes, float* last_hidden, void* logits,
+                                 int* inner_len, int* outer_len, float* hidden_states, hipStream_t st) {
     MI_ENTER();
     const mi_ebf_config& c = *cfg;
+    if (hidden_states && !last_hidden) return MI_ERR_ARG;
     if (c.B <= 0 || c.T <= 0 || c.L <= 0 || c.d % c.H || c.I % 2) return MI_ERR_ARG;
     if (c.extra_layers < 0 || c.extra_layers > 1 || (c.layer_mixing && c.L + 1 > 1024)) return MI_ERR_ARG;
     const int Lt = c.L + c.extra_layers;      // the fine-tuning head's additional layer (bestrq.py:247-274) is layer L of the weight table
@@ -255,6 +258,8 @@ extern "C" int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weigh
     const int kc = c.csgu_kernel, km = c.merge_kernel;
 
     for (int l = 0; l < Lt; ++l) {
+        if (hidden_states && l < c.L && hipMemcpyAsync(hidden_states + (size_t)l * M * d, w.x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return MI_ERR_LAUNCH;
         // layer mixing (bestrq.py:239-245): hidden_states[l] is this layer's input; the weight is read on the device
         if (c.layer_mixing && l < c.L) RUN(mi_axpy_dev_f32(w.mixed, w.x, (long)M * d, w.sw + l, l == 0, st));
         if (c.use_macaron) {   // x += 0.5 * FFN(LN(x))   e_branchformer.py:271-273
@@ -346,6 +351,16 @@ extern "C" int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weigh
     if (logits)
         RUN(mi_gemm_bf16(w.hid, d, Gw(G_HEAD_W), d, Gf(G_HEAD_B), 1, logits, c.logits_ld > 0 ? c.logits_ld : c.V + 1, c.logits_f32, nullptr, 0, 1.f, 0,
                          M, c.V + 1, d, 0, 0, st));
+    if (hidden_states && hipMemcpyAsync(hidden_states + (size_t)c.L * M * d, last_hidden, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return MI_ERR_LAUNCH;
     MI_CHECK_LAUNCH();
     return MI_OK;
+}
+
+extern "C" int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weights, const float* feats,
+                              const int* feat_lengths, const void* pos_table, void* posp, int compute_posp,
+                              void* workspace, size_t workspace_bytes, float* last_hidden, void* logits,
+                              int* inner_len, int* outer_len, hipStream_t st) {
+    return mi_ebf_forward_hs(cfg, weights, feats, feat_lengths, pos_table, posp, compute_posp, workspace, workspace_bytes, last_hidden, logits, inner_len, outer_len,
+                             nullptr, st);
 }

@@ -211,9 +211,10 @@ class EBranchformerEngine:
         return self._ws[slot]
 
     # ------------------------------------------------------------------ forward
-    def forward(self, feats: torch.Tensor, feat_lengths: torch.Tensor | None = None, *, want_hidden=True, want_logits=True, slot=0):
+    def forward(self, feats: torch.Tensor, feat_lengths: torch.Tensor | None = None, *, want_hidden=True, want_logits=True, slot=0, want_all_hidden=False):
         """feats (B,T,F) fp32 device tensor; feat_lengths (B) int32 (= attention_mask.sum(-1)) or None.
-        Returns dict(logits (B,T2,V+1), last_hidden (B,T2,d) fp32, inner_len, outer_len int32 (B)).
+        Returns dict(logits (B,T2,V+1), last_hidden (B,T2,d) fp32, inner_len, outer_len int32 (B)); with want_all_hidden also
+        hidden_states = the L+1 tensors HF returns for output_hidden_states (every layer's input, then the last hidden state).
         `slot` selects a private workspace: calls issued on different streams must use different slots."""
         if self._table is None:
             raise RuntimeError("EBranchformerEngine: load_state_dict() first")
@@ -242,13 +243,17 @@ class EBranchformerEngine:
         # rows padded to a multiple of 8 elements (16-B stores in the GEMM epilogue); callers get the (B,T2,V+1) view
         lbuf = torch.empty((B, T2, cs.logits_ld), dtype=self.logits_dtype, device=self.device) if want_logits else None
         logits = lbuf[..., :V1] if want_logits else None
-        hidden = torch.empty((B, T2, d), dtype=torch.float32, device=self.device) if want_hidden else None
+        hidden = torch.empty((B, T2, d), dtype=torch.float32, device=self.device) if (want_hidden or want_all_hidden) else None
+        hs = torch.empty((c["num_hidden_layers"] + 1, B, T2, d), dtype=torch.float32, device=self.device) if want_all_hidden else None
         lens = torch.empty((2, B), dtype=torch.int32, device=self.device)
         if feat_lengths is not None:
             feat_lengths = feat_lengths.to(device=self.device, dtype=torch.int32).contiguous()
         p = lambda t: None if t is None else t.data_ptr()
-        rc = _lib.lib().mi_ebf_forward(C.byref(cs), self._table, feats.data_ptr(), p(feat_lengths), p(pos), p(posp), compute,
-                                       ws.data_ptr(), ws.numel(), p(hidden), p(lbuf), lens[0].data_ptr(), lens[1].data_ptr(),
-                                       torch.cuda.current_stream().cuda_stream)
+        rc = _lib.lib().mi_ebf_forward_hs(C.byref(cs), self._table, feats.data_ptr(), p(feat_lengths), p(pos), p(posp), compute,
+                                          ws.data_ptr(), ws.numel(), p(hidden), p(lbuf), lens[0].data_ptr(), lens[1].data_ptr(), p(hs),
+                                          torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "mi_ebf_forward")
-        return dict(logits=logits, last_hidden=hidden, inner_len=lens[0], outer_len=lens[1])
+        out = dict(logits=logits, last_hidden=hidden, inner_len=lens[0], outer_len=lens[1])
+        if hs is not None:
+            out["hidden_states"] = tuple(hs[i] for i in range(hs.shape[0]))
+        return out

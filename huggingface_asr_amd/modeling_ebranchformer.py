@@ -262,7 +262,7 @@ class Wav2Vec2EBranchformerForCTC(PreTrainedModel):
             return self._training_forward(input_values, attention_mask, labels, output_hidden_states, return_dict)
         eng = self._get_engine(input_values.device)
         feat_len = attention_mask.sum(-1).to(torch.int32) if attention_mask is not None else None
-        out = eng.forward(input_values, feat_len, want_hidden=True)
+        out = eng.forward(input_values, feat_len, want_hidden=True, want_all_hidden=bool(output_hidden_states))
         logits = out["logits"]
         loss = None
         if labels is not None:
@@ -270,7 +270,7 @@ class Wav2Vec2EBranchformerForCTC(PreTrainedModel):
                 raise ValueError(f"Label values must be <= vocab_size: {self.config.vocab_size}")
             loss, _, _ = ops.ctc_loss(logits, labels.to(logits.device), out["outer_len"],
                                       reduction=self.config.ctc_loss_reduction, zero_infinity=self.config.ctc_zero_infinity)
-        hidden_states = (out["last_hidden"],) if output_hidden_states else None
+        hidden_states = out["hidden_states"] if output_hidden_states else None          # L + 1 tensors, as HF (tf:685-713)
         if not return_dict:
             output = (logits,) + ((hidden_states,) if hidden_states is not None else ())
             return ((loss,) + output) if loss is not None else output

@@ -315,6 +315,11 @@ size_t mi_ebf_workspace_bytes(const mi_ebf_config* cfg);
 int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weights, const float* feats, const int* feat_lengths,
                    const void* pos_table, void* posp, int compute_posp, void* workspace, size_t workspace_bytes,
                    float* last_hidden, void* logits, int* inner_len, int* outer_len, mi_stream_t stream);
+/* the same, additionally filling hidden_states (L+1, B*T2, d) fp32 = HuggingFace's `output_hidden_states` tuple (transformers wav2vec2_conformer :685-713): the
+ * input of every encoder layer, then the last hidden state; needs last_hidden != NULL. */
+int mi_ebf_forward_hs(const mi_ebf_config* cfg, const void* const* weights, const float* feats, const int* feat_lengths,
+                      const void* pos_table, void* posp, int compute_posp, void* workspace, size_t workspace_bytes,
+                      float* last_hidden, void* logits, int* inner_len, int* outer_len, float* hidden_states, mi_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -200,6 +200,13 @@ def test_hf_model_surface_matches_reference_golden():
     assert d.max() < 0.06 and d.mean() < 0.009
     assert abs(float(out.loss) - float(g["loss"])) < 1e-3 * abs(float(g["loss"]))
     assert out.hidden_states[-1].shape == (2, 50, 64)
+    # output_hidden_states: L + 1 tensors as HuggingFace returns them (the input of every layer, then the last hidden state), against the reference's own tuple
+    assert len(out.hidden_states) == cfg["num_hidden_layers"] + 1
+    for i in range(cfg["num_hidden_layers"]):
+        dh = np.abs(out.hidden_states[i].cpu().numpy() - g[f"layer_in_{i}"])
+        assert dh.mean() < 0.01 and dh.max() < 0.12, (i, dh.mean(), dh.max())
+    assert np.abs(out.hidden_states[-1].cpu().numpy() - g["last_hidden"]).mean() < 0.01
+    assert np.array_equal(out.hidden_states[0].cpu().numpy()[1, 38:], g["layer_in_0"][1, 38:])      # padded frames of layer 0's input are zero (tf:662-665)
     # weights edited in place -> engine repacks (version bump)
     with torch.no_grad():
         model.lm_head.bias.add_(1.0)
