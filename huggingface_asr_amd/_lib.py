@@ -83,7 +83,7 @@ SIGNATURES = {
     "mi_clip_coef": [vp, f32, f32, vp, vp],
     "mi_adamw_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, vp, vp],
     "mi_gemm_tn_workspace_bytes": [i32, i32, i32],
-    "mi_gemm_tn_bf16": [vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, i32, vp, sz, vp],
+    "mi_gemm_tn_bf16": [vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, i32, vp, sz, i32, vp],
     "mi_bgemm_bf16": [vp, i64, i64, i64, i64, vp, i64, i64, i64, i64, vp, i64, i64, i64, i32, i32, f32, i32, i32, i32, i32, i32, vp],
     "mi_attn_softmax_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, f32, i32, f32, C.c_uint, C.c_uint, vp],
     "mi_attn_softmax_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, f32, f32, C.c_uint, C.c_uint, vp],
@@ -140,14 +140,6 @@ def lib():
         h.mi_profile_count.argtypes = []; h.mi_profile_count.restype = i32
         h.mi_profile_summary.argtypes = [C.POINTER(f64), C.POINTER(f64)]; h.mi_profile_summary.restype = i32
         h.mi_profile_calibrate.argtypes = [vp, i32, C.POINTER(f64)]; h.mi_profile_calibrate.restype = i32
-        if os.environ.get("HFASR_TN_WIDE"):
-            h.mi_gemm_tn_set_wide.restype = None
-            h.mi_gemm_tn_set_wide.argtypes = [C.c_int]
-            h.mi_gemm_tn_set_wide(int(os.environ["HFASR_TN_WIDE"]))
-        if os.environ.get("HFASR_TN_TARGET"):
-            h.mi_gemm_tn_set_target.restype = None
-            h.mi_gemm_tn_set_target.argtypes = [C.c_int]
-            h.mi_gemm_tn_set_target(int(os.environ["HFASR_TN_TARGET"]))
         h.mi_last_error.argtypes = []
         h.mi_last_error.restype = C.c_char_p
         _lib = h

@@ -7,15 +7,18 @@
 // consecutive m of column i).  Both operands use the same m-permutation inside a 16-step, so the products line up.
 // Output tiles are few (N*K/128² = 16 ... 160), so M is split over `splits` blocks per tile: each writes its fp32 partial tile
 // to a slab, `slab_reduce_kernel` adds the slabs into dW (splits == 1: accumulate in place).
-// Block 128 x 128, 4 waves (2x2) of 64 x 64, 2-stage LDS ring (64 KiB -> two blocks per CU).  A 128 (n) x 64 (k) form (48 KiB, three per CU; HFASR_TN_WIDE=0) exists
-// for A/B: unlike the forward GEMM it is slower here (more slabs to write and reduce).
+// Block 128 x 128, 4 waves (2x2) of 64 x 64, 2-stage LDS ring (64 KiB -> two blocks per CU).  A 128 (n) x 64 (k) form (48 KiB, three per CU; variant 1 of
+// mi_gemm_tn_bf16) exists for A/B: unlike the forward GEMM it is slower here (more slabs to write and reduce).
+// Round 2 tried the forward GEMM's recipe here — eight waves of 64 x 32, four-deep ring, fragments of stage t+1 read under the MFMAs of stage t, one block per CU (half
+// the splits): SLOWER on every layer shape (435 vs 419 us per layer over the nine dW GEMMs, 189 vs 114 us for the CTC head's dW at one split: 1.5 us per 64-row
+// stage against 0.5 us for the forward kernel's stage of the same bytes).  What differs from the forward kernel is the transposing fragment read — three
+// `ds_read_b64_tr_b16` per MFMA at a 64 x 32 wave tile against two at 64 x 64 — so the suspect is the LDS read side, not ingest: the next attempt should keep
+// the 64 x 64 wave tile (fewer, larger wave tiles) rather than add waves.  The attempt is not in the tree (tools/gemm_tn_ab.py is the A/B harness it was measured with).
 #include "common.hpp"
 
 namespace {
 
 constexpr int TN_T = 128, TN_KM = 64;                   // dY tile: 64 m x 128 n;  X tile: 64 m x XW k (XW = 128: 32 KiB per stage, 64: 24 KiB)
-int g_tn_target = 0;
-int g_tn_wide = 1;                                      // 128-wide X tiles, two blocks per CU (default: measured 32.9 vs 33.6 ms per training step); 0 = 64-wide, three per CU
 
 __device__ __attribute__((aligned(16))) uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
@@ -175,31 +178,33 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ ou
 
 }  // namespace
 
-extern "C" void mi_gemm_tn_set_wide(int wide) { g_tn_wide = wide; }
-extern "C" void mi_gemm_tn_set_target(int blocks) { g_tn_target = blocks; }       // A/B: blocks per launch the M split aims for (0 = default)
-
-// workspace floats needed for a given problem (0 when a single split is used)
-static int tn_xw() { return g_tn_wide ? 128 : 64; }
-static int tn_splits(int M, int N, int K) {
-    const int tiles = cdiv(N, TN_T) * cdiv(K, tn_xw());
-    int s = (g_tn_target > 0 ? g_tn_target : (g_tn_wide ? 512 : 768)) / tiles;   // two (128-wide X tiles, 64 KiB of LDS) or three (64-wide, 48 KiB) blocks per CU on 256 CUs
+// M splits: two (128-wide X tiles, 64 KiB of LDS) or three (64-wide, 48 KiB) blocks per CU on 256 CUs — 512 blocks per launch measured as the optimum (round 1)
+static int tn_splits(int M, int N, int K, int variant) {
+    const int xw = variant == 1 ? 64 : 128;
+    const int tiles = cdiv(N, TN_T) * cdiv(K, xw);
+    int s = (variant == 1 ? 768 : 512) / tiles;
     const int max_s = cdiv(M, 4 * TN_KM);              // at least 4 K-iterations per block
     if (s > max_s) s = max_s;
     return s < 1 ? 1 : s;
 }
-extern "C" size_t mi_gemm_tn_workspace_bytes(int M, int N, int K) {
-    const int s = tn_splits(M, N, K);
-    return s > 1 ? (size_t)s * N * K * sizeof(float) : 0;
+extern "C" size_t mi_gemm_tn_workspace_bytes(int M, int N, int K) {       // enough for either variant
+    size_t best = 0;
+    for (int v = 0; v < 2; ++v) {
+        const int s = tn_splits(M, N, K, v);
+        if (s > 1 && (size_t)s * N * K * sizeof(float) > best) best = (size_t)s * N * K * sizeof(float);
+    }
+    return best;
 }
 
 // dW (n_store, K) fp32 (row stride ldo) += dY[:, :N]^T · X;  N, K % 8 == 0, rows of dY / X 16-B aligned; n_store <= N
 // db (optional, n_store floats): bias gradient db[n] += sum_m dY[m][n], fused (float atomics at block granularity)
+// variant: 0 = the product's tile (128 x 128), 1 = 128 (n) x 64 (k) for A/B.  Per call: the library keeps no kernel-selection state.
 extern "C" int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx, float* dW, long ldo, float* db, int M, int N, int K, int n_store,
-                               void* workspace, size_t workspace_bytes, hipStream_t st) {
+                               void* workspace, size_t workspace_bytes, int variant, hipStream_t st) {
     MI_ENTER();
-    if (M <= 0 || N <= 0 || K <= 0 || (N % 8) || (K % 8) || (ldy % 8) || (ldx % 8) || n_store > N || n_store <= 0) return MI_ERR_ARG;
+    if (M <= 0 || N <= 0 || K <= 0 || (N % 8) || (K % 8) || (ldy % 8) || (ldx % 8) || n_store > N || n_store <= 0 || variant < 0 || variant > 1) return MI_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(dY) & 15) || (reinterpret_cast<uintptr_t>(X) & 15)) return MI_ERR_ARG;
-    int splits = tn_splits(M, N, K);
+    const int splits = tn_splits(M, N, K, variant);
     if (splits > 1 && workspace_bytes < (size_t)splits * N * K * sizeof(float)) return MI_ERR_ARG;
     TnArgs p{};
     p.Y = (const bf16_t*)dY; p.ldy = ldy; p.X = (const bf16_t*)X; p.ldx = ldx;
@@ -207,8 +212,8 @@ extern "C" int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx
     p.rows_per_split = cdiv(cdiv(M, splits), TN_KM) * TN_KM;
     if (splits > 1) { p.out = (float*)workspace; p.ldo = K; p.slab_stride = (long)N * K; }
     else { p.out = dW; p.ldo = ldo; p.slab_stride = 0; }
-    const int tiles = cdiv(N, TN_T) * cdiv(K, tn_xw());
-    if (g_tn_wide) hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(tiles * splits), dim3(256), (size_t)2 * TN_KM * (TN_T * 2 + 256), st, p);
+    const int tiles = cdiv(N, TN_T) * cdiv(K, variant == 1 ? 64 : 128);
+    if (variant == 0) hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(tiles * splits), dim3(256), (size_t)2 * TN_KM * (TN_T * 2 + 256), st, p);
     else hipLaunchKernelGGL(gemm_tn_kernel<64>, dim3(tiles * splits), dim3(256), (size_t)2 * TN_KM * (TN_T * 2 + 128), st, p);
     MI_CHECK_LAUNCH();
     if (splits > 1) {

@@ -298,7 +298,7 @@ def adamw_step_(p, g, m, v, decay, *, lr, betas=(0.9, 0.999), eps=1e-8, weight_d
 _TN_WS = {}
 
 
-def gemm_tn_(dw, dy, x, n_store=None, db=None):
+def gemm_tn_(dw, dy, x, n_store=None, db=None, variant=0):
     """dw (n_store, K) f32 += dy[:, :N]^T · x   (dy (M,N) bf16, x (M,K) bf16 row views; contraction over rows, no transposes).
     db (n_store) f32: the bias gradient db += column sums of dy, computed from the same LDS tiles."""
     M, N = dy.shape
@@ -310,7 +310,7 @@ def gemm_tn_(dw, dy, x, n_store=None, db=None):
     if nbytes and (ws is None or ws.numel() < nbytes):
         ws = _TN_WS[key] = torch.empty(nbytes, device=dy.device, dtype=torch.uint8)
     _lib.check(_L().mi_gemm_tn_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0), _p(db), M, N, K, n_store,
-                                    ws.data_ptr() if nbytes else 0, nbytes, _stream()), "mi_gemm_tn_bf16")
+                                    ws.data_ptr() if nbytes else 0, nbytes, int(variant), _stream()), "mi_gemm_tn_bf16")
     return dw
 
 

@@ -109,21 +109,22 @@ def test_linear_bwd(M, N, K):
     torch.testing.assert_close(dw.cpu(), 2 * wr.grad, atol=4e-3 * float(wr.grad.abs().max()), rtol=1e-3)
 
 
-@pytest.mark.parametrize("M,N,K,ns", [(8000, 512, 512, 512), (499, 64, 64, 64), (1000, 136, 264, 131), (4000, 5056, 64, 5001), (130, 128, 2304, 128)])
-def test_gemm_tn_weight_gradient(M, N, K, ns):
+@pytest.mark.parametrize("variant", [0, 1])          # 0: 128 x 128 output tiles (product), 1: 128 x 64
+@pytest.mark.parametrize("M,N,K,ns", [(8000, 512, 512, 512), (499, 64, 64, 64), (1000, 136, 264, 131), (4000, 5056, 64, 5001), (130, 128, 2304, 128), (8000, 2048, 512, 2048)])
+def test_gemm_tn_weight_gradient(M, N, K, ns, variant):
     ops, T = _o()
     dy, x = bfr(rnd(M, N, seed=1)), bfr(rnd(M, K, seed=2))
     want = (dy.t() @ x)[:ns]
     base = rnd(ns, K, seed=3)
     dw = base.clone().to(DEV)
     db = torch.ones(ns, device=DEV)
-    T.gemm_tn_(dw, dev16(dy), dev16(x), n_store=ns, db=db)
+    T.gemm_tn_(dw, dev16(dy), dev16(x), n_store=ns, db=db, variant=variant)
     torch.testing.assert_close(dw.cpu() - base, want, atol=3e-3 * float(want.abs().max()), rtol=1e-3)
     torch.testing.assert_close(db.cpu() - 1.0, dy.sum(0)[:ns], atol=2e-3 * float(dy.sum(0).abs().max()) + 1e-3, rtol=1e-3)      # fused bias gradient
     # strided operand views (a column block of a wider activation)
     wide = dev16(torch.cat([x, dy], 1))
     dw2 = torch.zeros(ns, K, device=DEV)
-    T.gemm_tn_(dw2, wide[:, K:], wide[:, :K], n_store=ns)
+    T.gemm_tn_(dw2, wide[:, K:], wide[:, :K], n_store=ns, variant=variant)
     torch.testing.assert_close(dw2.cpu(), want, atol=3e-3 * float(want.abs().max()), rtol=1e-3)
 
 
