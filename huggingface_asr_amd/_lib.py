@@ -89,8 +89,8 @@ SIGNATURES = {
     "mi_attn_softmax_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, f32, f32, C.c_uint, C.c_uint, vp],
     "mi_dropout": [vp, i64, i32, vp, i64, i32, i32, i32, f32, f32, C.c_uint, C.c_uint, vp],
     "mi_dropout_add_f32": [vp, i64, vp, i64, vp, i64, i32, i32, f32, f32, C.c_uint, C.c_uint, vp],
-    "mi_csgu_bwd_bf16": [vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, vp, vp],
-    "mi_dwconv_residual_bwd_bf16": [vp, i64, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, vp, vp],
+    "mi_csgu_bwd_bf16": [vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
+    "mi_dwconv_residual_bwd_bf16": [vp, i64, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
     "mi_im2col_cl_bf16": [vp, vp] + [i32] * 11 + [vp],
     "mi_conv2d_first_bwd": [vp, vp, vp, vp, vp, vp] + [i32] * 16 + [vp],
     "mi_ctc_bwd_workspace_bytes": [i32, i32, i32],

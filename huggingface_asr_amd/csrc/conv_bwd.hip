@@ -28,7 +28,7 @@ struct DwBwdArgs {
     bf16_t* dx; long lddx;                // CSGU: gradient w.r.t. LN(x_g);  MERGE: dy + conv^T(dy)
     bf16_t* dr; long lddr;                // CSGU: ds * conv
     float* dw; float* db;                 // accumulated
-    int B, T, C, K, pad_left;
+    int B, T, C, K, pad_left, dilation;
 };
 
 // block = (64 channels, utterance b); walks the time tiles, keeps the K tap gradients of its channel in registers
@@ -118,6 +118,75 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwBwdArgs p) {
     }
 }
 
+
+// ---- dilated form (the reference's CAUSAL CSGU: e_branchformer.py:153-160 passes (K-1)/2 in CausalConv1d's dilation slot, so the conv is dilated by 15 with a left
+// pad of 450; also any causal / dilated merge conv).  A streaming model's training path, not a hot one: no LDS tiling (the halo would be 450 rows), every tap is read
+// from L2.  block = 64 channels x 64 time steps of utterance b; thread = (channel, 16 consecutive steps); tap gradients in registers, reduced like the kernel above.
+template <bool CSGU>
+__global__ __launch_bounds__(256) void dwconv_bwd_dilated_kernel(DwBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);          // [4][K+1][64]
+    const int c0 = blockIdx.x * DB_CT, t0 = blockIdx.y * DB_TT, b = blockIdx.z;
+    const int tx = threadIdx.x & 63, tq = threadIdx.x >> 6;
+    const int c = c0 + tx;
+    const bool cok = c < p.C;
+    float wk[DB_KMAX], gw[DB_KMAX];
+#pragma unroll
+    for (int k = 0; k < DB_KMAX; ++k) { wk[k] = (cok && k < p.K) ? p.w[(long)c * p.K + k] : 0.f; gw[k] = 0.f; }
+    float g = 1.f, be = 0.f, bias = 0.f, gb = 0.f;
+    if (CSGU && cok) { g = p.gamma[c]; be = p.beta[c]; }
+    if (cok && p.bias) bias = p.bias[c];
+    auto xin = [&](int t) -> float {                       // conv input at time t (LayerNorm applied for CSGU), zero outside the utterance
+        if (t < 0 || t >= p.T) return 0.f;
+        const long row = (long)b * p.T + t;
+        float v = bf2f(p.x[row * p.ldx + c]);
+        if (CSGU) v = (v - p.stats[2 * row]) * p.stats[2 * row + 1] * g + be;
+        return v;
+    };
+    auto dyc = [&](int t) -> float {                       // gradient w.r.t. the conv output at time t
+        if (t < 0 || t >= p.T) return 0.f;
+        const long row = (long)b * p.T + t;
+        float d = bf2f(p.dy[row * p.lddy + c]);
+        if (CSGU) d *= bf2f(p.r[row * p.ldr + c]);
+        return d;
+    };
+    if (cok) {
+        for (int j = 0; j < DB_TT / 4; ++j) {
+            const int t = t0 + tq * (DB_TT / 4) + j;
+            if (t >= p.T) break;
+            const long row = (long)b * p.T + t;
+            // y[t] = bias + sum_k w[k] x[t - pad + k dil];   dx[u] = sum_k w[k] dyc[u + pad - k dil]
+            float acc = 0.f, cv = bias;
+            const float dt = dyc(t);
+#pragma unroll
+            for (int k = 0; k < DB_KMAX; ++k)
+                if (k < p.K) {
+                    const float xv = xin(t - p.pad_left + k * p.dilation);
+                    acc = fmaf(wk[k], dyc(t + p.pad_left - k * p.dilation), acc);
+                    cv = fmaf(wk[k], xv, cv);
+                    gw[k] = fmaf(dt, xv, gw[k]);
+                }
+            if (CSGU) p.dr[row * p.lddr + c] = f2bf(bf2f(p.dy[row * p.lddy + c]) * cv);
+            else acc += dt;                                    // residual path of m + conv(m)
+            p.dx[row * p.lddx + c] = f2bf(acc);
+            gb += dt;
+        }
+    }
+    float* mine = red + (size_t)tq * (DB_KMAX + 1) * DB_CT;
+#pragma unroll
+    for (int k = 0; k < DB_KMAX; ++k) mine[k * DB_CT + tx] = gw[k];
+    mine[DB_KMAX * DB_CT + tx] = gb;
+    __syncthreads();
+    for (int i = threadIdx.x; i < (p.K + 1) * DB_CT; i += 256) {
+        const int k = i / DB_CT, cc = i % DB_CT;
+        if (c0 + cc >= p.C) continue;
+        const int kk = (k == p.K) ? DB_KMAX : k;
+        float s2 = 0.f;
+        for (int q = 0; q < 4; ++q) s2 += red[(size_t)q * (DB_KMAX + 1) * DB_CT + kk * DB_CT + cc];
+        if (k == p.K) { if (p.db) atomic_add_f32(p.db + c0 + cc, s2); }
+        else atomic_add_f32(p.dw + (long)(c0 + cc) * p.K + k, s2);
+    }
+}
 
 // ---- fast form for the reference's kernel size 31 (pad 15, dilation 1), mirror of dwconv31_kernel (conv.hip):
 // block = (64 channels, utterance), 128 time steps per tile; the (128+30) x 64 conv-input tile (LayerNorm applied on the way in)
@@ -388,7 +457,15 @@ __global__ __launch_bounds__(256) void conv1_bwd3_kernel(const float* __restrict
 int grid_for(long n, int cap) { const long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > cap ? cap : g)); }
 
 int dw_bwd_launch(const DwBwdArgs& a, bool csgu, float* workspace, hipStream_t st) {
-    if (a.B <= 0 || a.T <= 0 || a.C <= 0 || a.K <= 0 || a.K > DB_KMAX || a.pad_left < 0 || a.pad_left > a.K - 1) return MI_ERR_ARG;
+    if (a.B <= 0 || a.T <= 0 || a.C <= 0 || a.K <= 0 || a.K > DB_KMAX || a.dilation < 1 || a.pad_left < 0 || a.pad_left > (a.K - 1) * a.dilation) return MI_ERR_ARG;
+    if (a.dilation > 1) {                                   // the causal (dilated) CSGU / merge conv
+        const size_t ldsd = (size_t)4 * (DB_KMAX + 1) * DB_CT * sizeof(float);
+        dim3 gridd(cdiv(a.C, DB_CT), cdiv(a.T, DB_TT), a.B);
+        if (csgu) hipLaunchKernelGGL(dwconv_bwd_dilated_kernel<true>, gridd, dim3(256), ldsd, st, a);
+        else hipLaunchKernelGGL(dwconv_bwd_dilated_kernel<false>, gridd, dim3(256), ldsd, st, a);
+        MI_CHECK_LAUNCH();
+        return MI_OK;
+    }
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const bool fast = workspace && a.K == FB_K && a.pad_left == 15 && (a.C % FB_CT) == 0 && (a.ldx % 8) == 0 && (a.lddy % 8) == 0 && (a.lddx % 8) == 0 &&
                       al16(a.x) && al16(a.dy) && al16(a.dx) && (!csgu || ((a.ldr % 8) == 0 && (a.lddr % 8) == 0 && al16(a.r) && al16(a.dr) && al16(a.gamma) && al16(a.beta)));
@@ -414,13 +491,14 @@ int dw_bwd_launch(const DwBwdArgs& a, bool csgu, float* workspace, hipStream_t s
 }  // namespace
 
 // `workspace`: B*C*32 floats (per-utterance tap-gradient partials of the K = 31 fast path) or NULL (generic kernel, atomics).
-// CSGU backward (identity activation, dilation 1): u (B*T, 2C) = [x_r | x_g], ds = gradient of x_r * (dwconv(LN(x_g)) + b)
+// CSGU backward (identity activation; dilation > 1 = the causal form): u (B*T, 2C) = [x_r | x_g], ds = gradient of x_r * (dwconv(LN(x_g)) + b)
 //   -> dr (B*T, C) = ds * conv,  dgn (B*T, C) = gradient w.r.t. LN(x_g),  dw (C,K) +=, db (C) +=
 extern "C" int mi_csgu_bwd_bf16(const void* u, long ldu, const float* stats, const float* gamma, const float* beta, const float* w,
                                 const float* bias, const void* ds, long ldds, void* dr, long lddr, void* dgn, long lddgn,
-                                float* dw, float* db, int B, int T, int C, int K, int pad_left, float* workspace, hipStream_t st) {
+                                float* dw, float* db, int B, int T, int C, int K, int pad_left, int dilation, float* workspace, hipStream_t st) {
     MI_ENTER();
     DwBwdArgs a{};
+    a.dilation = dilation;
     a.x = (const bf16_t*)u + C; a.ldx = ldu; a.r = (const bf16_t*)u; a.ldr = ldu; a.stats = stats; a.gamma = gamma; a.beta = beta;
     a.dy = (const bf16_t*)ds; a.lddy = ldds; a.w = w; a.bias = bias; a.dx = (bf16_t*)dgn; a.lddx = lddgn; a.dr = (bf16_t*)dr; a.lddr = lddr;
     a.dw = dw; a.db = db; a.B = B; a.T = T; a.C = C; a.K = K; a.pad_left = pad_left;
@@ -429,9 +507,10 @@ extern "C" int mi_csgu_bwd_bf16(const void* u, long ldu, const float* stats, con
 
 // merge-block backward: y = m + dwconv(m) + b  ->  dm = dy + conv^T(dy),  dw +=, db +=
 extern "C" int mi_dwconv_residual_bwd_bf16(const void* m, long ldm, const float* w, const void* dy, long lddy, void* dm, long lddm,
-                                           float* dw, float* db, int B, int T, int C, int K, int pad_left, float* workspace, hipStream_t st) {
+                                           float* dw, float* db, int B, int T, int C, int K, int pad_left, int dilation, float* workspace, hipStream_t st) {
     MI_ENTER();
     DwBwdArgs a{};
+    a.dilation = dilation;
     a.x = (const bf16_t*)m; a.ldx = ldm; a.dy = (const bf16_t*)dy; a.lddy = lddy; a.w = w; a.dx = (bf16_t*)dm; a.lddx = lddm;
     a.dw = dw; a.db = db; a.B = B; a.T = T; a.C = C; a.K = K; a.pad_left = pad_left;
     return dw_bwd_launch(a, false, workspace, st);

@@ -8,8 +8,8 @@ parameters (for state_dict / optimizers / checkpoint averaging); no tensor op of
 
 Eval mode / no_grad: the inference engine (engine.py).  Training mode with labels: forward AND backward run on the HIP trainer
 (train.py) behind a torch.autograd bridge (autograd_bridge.py), so `loss.backward()` fills ordinary `.grad`s for HF Trainer's
-optimizer; dropout, LayerDrop and in-model SpecAugment are supported (counter-based masks); configurations the HIP training step does not cover
-(causal encoders) raise NotImplementedError rather than silently falling back to PyTorch."""
+optimizer; dropout, LayerDrop, in-model SpecAugment (counter-based masks) and causal (streaming) encoders are supported; configurations the HIP training
+step does not cover raise NotImplementedError rather than silently falling back to PyTorch."""
 from __future__ import annotations
 
 from typing import Optional, Tuple, Union

@@ -163,12 +163,12 @@ def csgu(u, gamma, beta, w, bias, B, T, *, pad_left=None, dilation=1, act=0, eps
     return out
 
 
-def dwconv_residual(m, w, bias, B, T):
+def dwconv_residual(m, w, bias, B, T, pad_left=None):
     M, Cc = m.shape
     K = w.shape[-1]
     out = torch.empty_like(m)
     rc = _lib.lib().mi_dwconv_residual_bf16(m.data_ptr(), m.stride(0), w.data_ptr(), _p(bias), out.data_ptr(), out.stride(0),
-                                            B, T, Cc, K, (K - 1) // 2, _stream())
+                                            B, T, Cc, K, (K - 1) // 2 if pad_left is None else int(pad_left), _stream())
     _lib.check(rc, "mi_dwconv_residual_bf16")
     return out
 

@@ -191,23 +191,27 @@ def dropout_add(resid, t, alpha, p, seed, stream_id):
     return y
 
 
-def csgu_bwd(u, stats, gamma, beta, w, bias, ds, dr, dgn, dw, db, B, T):
+def csgu_bwd(u, stats, gamma, beta, w, bias, ds, dr, dgn, dw, db, B, T, pad_left=None, dilation=1):
+    """pad_left / dilation: None / 1 = the symmetric conv; the causal encoder passes ((K-1)*dil, dil = (K-1)//2), as ops.csgu does."""
     M, C2 = u.shape
     Cc = C2 // 2
     K = w.shape[-1]
+    pl = (K - 1) // 2 if pad_left is None else int(pad_left)
     _lib.check(_L().mi_csgu_bwd_bf16(u.data_ptr(), u.stride(0), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), _p(bias),
                                      ds.data_ptr(), ds.stride(0), dr.data_ptr(), dr.stride(0), dgn.data_ptr(), dgn.stride(0),
-                                     dw.data_ptr(), _p(db), B, T, Cc, K, (K - 1) // 2, _dw_ws(u.device, B * Cc * 32), _stream()), "mi_csgu_bwd_bf16")
+                                     dw.data_ptr(), _p(db), B, T, Cc, K, pl, int(dilation), _dw_ws(u.device, B * Cc * 32), _stream()), "mi_csgu_bwd_bf16")
 
 
-def dwconv_residual_bwd(m, w, dy, dm, dw, db, B, T):
+def dwconv_residual_bwd(m, w, dy, dm, dw, db, B, T, pad_left=None):
     M, Cc = m.shape
     K = w.shape[-1]
+    pl = (K - 1) // 2 if pad_left is None else int(pad_left)
     _lib.check(_L().mi_dwconv_residual_bwd_bf16(m.data_ptr(), m.stride(0), w.data_ptr(), dy.data_ptr(), dy.stride(0), dm.data_ptr(), dm.stride(0),
-                                                dw.data_ptr(), _p(db), B, T, Cc, K, (K - 1) // 2, _dw_ws(m.device, B * Cc * 32), _stream()), "mi_dwconv_residual_bwd_bf16")
+                                                dw.data_ptr(), _p(db), B, T, Cc, K, pl, 1, _dw_ws(m.device, B * Cc * 32), _stream()), "mi_dwconv_residual_bwd_bf16")
 
 
 def im2col(x, K, stride, pad, T1, F1):
+    """pad = the LEFT / TOP pad (2 * conv pad for the causal front end)"""
     B, T, F, Cin = x.shape
     col = torch.empty((B * T1 * F1, K * K * Cin), device=x.device, dtype=BF16)
     _lib.check(_L().mi_im2col_cl_bf16(x.data_ptr(), col.data_ptr(), B, T, F, Cin, K, K, stride, pad, pad, T1, F1, _stream()), "mi_im2col_cl_bf16")

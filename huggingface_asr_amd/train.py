@@ -19,7 +19,8 @@ Precision model = the reference's autocast recipe: fp32 master weights and resid
 activation gradients), fp32 accumulation, fp32 LayerNorm / softmax / CTC, fp32 parameter gradients.
 Dropout (all eight sites of the layer, encoder input, feature projection, CTC head) uses counter-based masks that the backward
 pass regenerates; in-model SpecAugment draws its masks on the host with transformers' own `_compute_mask_indices` (numpy RNG), exactly as the
-reference does (LayerDrop included).  Not on this path (raise NotImplementedError): causal encoders.
+reference does (LayerDrop included).  Causal (streaming) encoders train on the same path (left-padded front end, causal attention mask,
+the reference's dilated causal CSGU conv).
 """
 from __future__ import annotations
 
@@ -331,8 +332,7 @@ class EncoderCTCTrainer:
         dp_sync=False: no gradient all-reduce here (the caller, e.g. HF Trainer's DDP wrapper, owns data parallelism).
         seed: dropout mask seed (masks are counter-based: f(seed, step, layer, site, element), csrc/dropout.hip); give every DP rank its own."""
         c = self.cfg = dict(cfg)
-        if c.get("is_causal", False):
-            raise NotImplementedError("training path: causal encoders are not supported yet")
+        self.causal = bool(c.get("is_causal", False))               # streaming encoder: left-padded front end, triu attention mask, dilated causal CSGU conv
         if len(c["conv_dim"]) != 2 or c["conv_kernel"][0] != 3 or len(set(c["conv_kernel"])) != 1:
             raise NotImplementedError("training path: 2-layer 3x3 Conv2d sub-sampling only")
         if c.get("csgu_activation", "identity") != "identity" or c.get("csgu_use_linear_after_conv", False):
@@ -523,8 +523,13 @@ class EncoderCTCTrainer:
             self.train_steps_seen += 1
 
         # ---------------- front end
-        act1 = ops.conv2d_first_gelu(feats, P("conv1_w"), P("conv1_b"), stride=s_, pad=pad)
-        pre2 = ops.conv2d_cl(act1, W("conv2_w"), P("conv2_b"), K=K, stride=s_, pad=pad, act="none").view(B * T2 * F2, C2)
+        causal = self.causal
+        padl = 2 * pad if causal else pad                  # CausalConv2d: all of the padding on the top / left (streaming_modules.py:31-55)
+        # e_branchformer.py:153-160 hands (K-1)//2 to CausalConv1d's dilation slot: the causal CSGU conv is dilated by 15 with a left pad of (K-1)*15
+        cs_dil = (kc - 1) // 2 if causal else 1
+        cs_pad = (kc - 1) * cs_dil if causal else (kc - 1) // 2
+        act1 = ops.conv2d_first_gelu(feats, P("conv1_w"), P("conv1_b"), stride=s_, pad=pad, causal=causal)
+        pre2 = ops.conv2d_cl(act1, W("conv2_w"), P("conv2_b"), K=K, stride=s_, pad=pad, causal=causal, act="none").view(B * T2 * F2, C2)
         act2 = T.act_fwd(pre2).view(M, F2 * C2)
         feo = ops.gemm(act2, W("feout_w"), P("feout_b"), out_dtype=F32)
         a_fp = e16(M, d)
@@ -582,7 +587,7 @@ class EncoderCTCTrainer:
             hp = ops.gemm(a2, W(p + "mlp_w1"), P(p + "mlp_b1"))
             h = T.act_fwd(hp)
             stats = ops.row_stats(h[:, I // 2:])
-            sg = ops.csgu(h, P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), B, T2)
+            sg = ops.csgu(h, P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), B, T2, pad_left=cs_pad, dilation=cs_dil)
             if pd["csgu"] > 0:
                 T.dropout_(sg, pd["csgu"], seed, self._sid(sl, 4))
             ops.gemm(sg, W(p + "mlp_w2"), P(p + "mlp_b2"), out=cat[:, d:])
@@ -673,7 +678,7 @@ class EncoderCTCTrainer:
             dh = e16(M, I)
             dgn = e16(M, I // 2)
             T.csgu_bwd(S["h"], S["stats"], P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), dsg, dh[:, :I // 2], dgn,
-                       G(p + "csgu_w"), G(p + "csgu_b"), B, T2)
+                       G(p + "csgu_w"), G(p + "csgu_b"), B, T2, pad_left=cs_pad, dilation=cs_dil)
             T.layernorm_bwd(S["h"][:, I // 2:], P(p + "csgu_ln_g"), dgn, dh[:, I // 2:], accumulate=False, **self._lng(p + "csgu_ln_g", p + "csgu_ln_b"))
             dhp = T.act_bwd(dh, S["hp"])
             da2 = T.linear_bwd(dhp, S["a2"], WT(p + "mlp_w1"), dw=GL(p + "mlp_w1"), db=GL(p + "mlp_b1"))
@@ -754,11 +759,11 @@ class EncoderCTCTrainer:
         T.layernorm_bwd(feo, P("fp_ln_g"), da, dfeo, accumulate=False, **self._lng("fp_ln_g", "fp_ln_b"), eps=eps_e)
         dact2 = T.linear_bwd(T.add_cast(dfeo), act2, WT("feout_w"), dw=GL("feout_w"), db=GL("feout_b"))      # (M, F2*C2)
         dpre2 = T.act_bwd(dact2.view(B * T2 * F2, C2), pre2)
-        col = T.im2col(act1, K, s_, pad, T2, F2)
+        col = T.im2col(act1, K, s_, padl, T2, F2)
         T.gemm_tn_(G("conv2_w"), dpre2, col, db=G("conv2_b"))
         dcol = ops.gemm(dpre2, WT("conv2_w")[:, :C2])
         del col
-        T.conv2d_first_bwd(feats, P("conv1_w"), P("conv1_b"), dcol, G("conv1_w"), G("conv1_b"), K, s_, pad, T1, F1, K, s_, pad, T2, F2)
+        T.conv2d_first_bwd(feats, P("conv1_w"), P("conv1_b"), dcol, G("conv1_w"), G("conv1_b"), K, s_, padl, T1, F1, K, s_, padl, T2, F2)
         self.sync.launch(*st.range_of(self._front_names))
         return out
 
@@ -833,7 +838,7 @@ class EncoderCTCTrainer:
         d = qkv.shape[1] // 3
         hd = d // H
         if hd in (64, 128) and drop is None:
-            return ops.attention_qkv(qkv, B, Tt, H, pos=posp, bias_u=u, bias_v=v, lengths=lengths)
+            return ops.attention_qkv(qkv, B, Tt, H, pos=posp, bias_u=u, bias_v=v, lengths=lengths, causal=self.causal)
         # probability dropout (e_branchformer.py:132) or small heads (test configs): probabilities through the generic pieces,
         # kept for the backward pass; the dropped copy feeds the PV product
         prob = self._probs(qkv, posp, u, v, lengths, B, Tt, H, S, drop)
@@ -867,7 +872,7 @@ class EncoderCTCTrainer:
             bd = torch.empty((H, B, Tt, Ps), device=dev, dtype=F32)
             T.bgemm(qv, (hd, Tt * d, d, 1), posp, (hd, 0, d, 1), bd, (B * Tt * Ps, Tt * Ps, Ps), H, B, Tt, Pn, hd)
         S["qu"], S["qv"] = qu, qv
-        return T.attn_softmax_fwd(ac, bd, lengths, H, B, Tt, Tt, 1.0 / math.sqrt(hd), drop=drop)
+        return T.attn_softmax_fwd(ac, bd, lengths, H, B, Tt, Tt, 1.0 / math.sqrt(hd), causal=self.causal, drop=drop)
 
     def _attention_bwd(self, dctx, S, p, pos, lengths, B, Tt, H, drop=None):
         """-> dqkv (M, 3d) bf16; accumulates pos_bias_u / pos_bias_v / linear_pos gradients."""

@@ -222,9 +222,10 @@ int mi_dropout_add_f32(float* y, long ldy, const float* resid, long ldr, const f
 /* depthwise-conv / conv front-end gradients (e_branchformer.py:184-204,296-304; extractors.py:71-113) */
 int mi_csgu_bwd_bf16(const void* u, long ldu, const float* stats, const float* gamma, const float* beta, const float* w,
                      const float* bias, const void* ds, long ldds, void* dr, long lddr, void* dgn, long lddgn, float* dw,
-                     float* db, int B, int T, int C, int K, int pad_left, float* workspace /* B*C*32 floats or NULL */, mi_stream_t stream);
+                     float* db, int B, int T, int C, int K, int pad_left, int dilation /* 1, or the causal form's (K-1)/2 */,
+                     float* workspace /* B*C*32 floats or NULL */, mi_stream_t stream);
 int mi_dwconv_residual_bwd_bf16(const void* m, long ldm, const float* w, const void* dy, long lddy, void* dm, long lddm,
-                                float* dw, float* db, int B, int T, int C, int K, int pad_left, float* workspace, mi_stream_t stream);
+                                float* dw, float* db, int B, int T, int C, int K, int pad_left, int dilation, float* workspace, mi_stream_t stream);
 int mi_im2col_cl_bf16(const void* in, void* col, int B, int Tin, int Fin, int Cin, int KH, int KW, int stride, int pad_t,
                       int pad_f, int Tout, int Fout, mi_stream_t stream);
 int mi_conv2d_first_bwd(const float* x, const float* w, const float* bias, const void* dcol, float* dw, float* db, int B, int T,

@@ -711,6 +711,9 @@ if __name__ == "__main__":
         run_grad_case("grads_tiny_rotary", TINY, seed=12, B=2, T=200, lengths=[200, 131], U=6, tgt_lens=[6, 4], position_embeddings_type="rotary")
         run_grad_case("grads_tiny_specaug", TINY, seed=16, B=2, T=200, lengths=[200, 140], U=5, tgt_lens=[5, 3], np_seed=5, apply_spec_augment=True,
                       mask_time_prob=0.3, mask_time_length=4, mask_time_min_masks=2, mask_feature_prob=0.2, mask_feature_length=3, mask_feature_min_masks=1)
+    if "gradscausal" in which or "grads" in which:
+        # the streaming encoder: left-padded Conv2d front end, triu attention mask, the CSGU conv dilated by 15 (T' = 100 frames: 7 of its 31 taps see data)
+        run_grad_case("grads_tiny_causal", TINY, seed=17, B=2, T=400, lengths=[400, 263], U=6, tgt_lens=[6, 4], is_causal=True)
         # (use_macaron_ff=False is not runnable in the reference: its layer forward reads self.ff1 unconditionally, e_branchformer.py:271)
     if "basegrads" in which:
         run_grad_case_strided("grads_base_rel", BASE, seed=24, B=2, T=1000, lengths=[998, 700], U=40, tgt_lens=[40, 31])

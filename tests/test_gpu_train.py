@@ -49,8 +49,11 @@ def _compare(grads, ref, rel=0.03, cos_min=0.999):
     return worst[0]
 
 
-@pytest.mark.parametrize("name,extra", [("grads_tiny_rel", {}), ("grads_tiny_rotary", {"position_embeddings_type": "rotary"})])
+@pytest.mark.parametrize("name,extra", [("grads_tiny_rel", {}), ("grads_tiny_rotary", {"position_embeddings_type": "rotary"}),
+                                        ("grads_tiny_causal", {"is_causal": True})])
 def test_gradients_match_reference_golden(name, extra):
+    """every parameter gradient of the HIP training step vs the imported reference in train() mode.  `grads_tiny_causal` = the streaming encoder
+    (left-padded front end, triu attention mask, CSGU conv dilated by 15: conv_bwd.hip's dilated kernel)."""
     g = load_golden(name)
     cfg = dict(shapes.TINY, ctc_zero_infinity=True, ctc_loss_reduction="mean", **extra)
     sd, x, am, lab = case_inputs(g, cfg)

@@ -234,6 +234,38 @@ def test_csgu_and_merge_dwconv_bwd():
     torch.testing.assert_close(db2.cpu(), br2.grad, atol=1e-2 * float(br2.grad.abs().max()), rtol=1e-2)
 
 
+@pytest.mark.parametrize("B,Tt,Cc", [(2, 100, 128), (3, 77, 96), (1, 520, 64)])
+def test_causal_dilated_csgu_bwd(B, Tt, Cc):
+    """the streaming encoder's CSGU: CausalConv1d with (K-1)//2 = 15 in its dilation slot (e_branchformer.py:153-160; left pad 450) — conv_bwd.hip's dilated kernel
+    against autograd of the oracle's restatement, incl. a channel count that is not a multiple of the 64-channel block and T above the 450-frame reach"""
+    ops, T = _o()
+    K = 31
+    dil = (K - 1) // 2
+    M = B * Tt
+    u = bfr(rnd(M, 2 * Cc, seed=11))
+    g, be = 1 + 0.1 * rnd(Cc, seed=12), 0.1 * rnd(Cc, seed=13)
+    w, bias = rnd(Cc, K, seed=14, scale=0.2), 0.1 * rnd(Cc, seed=15)
+    ds = bfr(rnd(M, Cc, seed=16))
+    ur, gr, ber, wr, br = [t.clone().requires_grad_(True) for t in (u, g, be, w, bias)]
+    gn = F.layer_norm(ur[:, Cc:], (Cc,), gr, ber, 1e-5)
+    gn.retain_grad()
+    conv = R.dwconv1d(gn.view(B, Tt, Cc), wr.view(Cc, 1, K), br, True, dil).reshape(M, Cc)
+    (ur[:, :Cc] * conv).backward(ds)
+    ud = dev16(u)
+    fwd = ops.csgu(ud, g.to(DEV), be.to(DEV), w.to(DEV), bias.to(DEV), B, Tt, pad_left=(K - 1) * dil, dilation=dil)
+    close(fwd, (ur[:, :Cc] * conv).detach(), what="forward")
+    st = ops.row_stats(ud[:, Cc:])
+    dr = torch.empty(M, Cc, device=DEV, dtype=BF); dgn = torch.empty(M, Cc, device=DEV, dtype=BF)
+    dw = torch.zeros(Cc, K, device=DEV); db = torch.zeros(Cc, device=DEV)
+    T.csgu_bwd(ud, st, g.to(DEV), be.to(DEV), w.to(DEV), bias.to(DEV), dev16(ds), dr, dgn, dw, db, B, Tt, pad_left=(K - 1) * dil, dilation=dil)
+    close(dr, ur.grad[:, :Cc], what="dr")
+    close(dgn, gn.grad, what="dgn")
+    torch.testing.assert_close(dw.cpu(), wr.grad, atol=1e-2 * float(wr.grad.abs().max()), rtol=1e-2)
+    torch.testing.assert_close(db.cpu(), br.grad, atol=1e-2 * float(br.grad.abs().max()), rtol=1e-2)
+    seen = (K - 1 - torch.arange(K)) * dil < Tt                     # taps whose reach stays inside the utterance; the others never meet data
+    assert float(dw.cpu()[:, ~seen].abs().max() if (~seen).any() else 0.0) == 0.0
+
+
 def test_conv_frontend_bwd():
     ops, T = _o()
     B, Tt, Fq, C1, K, s, pad = 2, 61, 40, 32, 3, 2, 1
