@@ -18,7 +18,7 @@ class EbfConfig(C.Structure):
     """mirror of mi_ebf_config (include/hfasr_hip.h)"""
     _fields_ = [(n, i32) for n in ("B", "T", "F", "d", "H", "I", "L", "V", "C1", "C2", "K", "stride", "pad",
                                    "is_causal", "pos_type", "csgu_kernel", "merge_kernel", "csgu_act", "use_macaron")] + \
-               [("ln_eps", f32), ("logits_f32", i32), ("logits_ld", i32), ("branch_overlap", i32), ("extra_layers", i32), ("layer_mixing", i32)]
+               [("ln_eps", f32), ("logits_f32", i32), ("logits_ld", i32), ("branch_overlap", i32), ("extra_layers", i32), ("layer_mixing", i32), ("csgu_linear", i32)]
 
 
 class Gpt2Config(C.Structure):
@@ -89,6 +89,9 @@ SIGNATURES = {
     "mi_attn_softmax_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, f32, f32, C.c_uint, C.c_uint, vp],
     "mi_dropout": [vp, i64, i32, vp, i64, i32, i32, i32, f32, f32, C.c_uint, C.c_uint, vp],
     "mi_dropout_add_f32": [vp, i64, vp, i64, vp, i64, i32, i32, f32, f32, C.c_uint, C.c_uint, vp],
+    "mi_csgu_conv_bf16": [vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp],
+    "mi_gate_act_mul_bf16": [vp, i64, vp, i64, vp, i64, i64, i32, i32, vp],
+    "mi_gate_act_mul_bwd_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, i32, vp],
     "mi_csgu_bwd_bf16": [vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
     "mi_dwconv_residual_bwd_bf16": [vp, i64, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
     "mi_im2col_cl_bf16": [vp, vp] + [i32] * 11 + [vp],

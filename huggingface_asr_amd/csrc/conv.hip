@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void dwconv_time_kernel(DwArgs p) {
             if (p.act == 1) acc = gelu_erf(acc);
             else if (p.act == 2) acc = fmaxf(acc, 0.f);
             else if (p.act == 3) acc = acc / (1.f + __expf(-acc));
-            o = bf2f(p.mul[row * p.ld_mul + c]) * acc;
+            o = p.mul ? bf2f(p.mul[row * p.ld_mul + c]) * acc : acc;       // mul == NULL: the conv alone (linear-after-conv / split-gate form)
         } else {
             o = tile[(tl + p.pad_left) * DW_CT + tx] + acc;
         }
@@ -347,7 +347,7 @@ static int dw_launch(const DwArgs& a, bool csgu, hipStream_t stream) {
     const int halo = (a.K - 1) * a.dilation;
     const size_t lds = (size_t)((DW_TT + halo) * DW_CT + a.K * DW_CT) * sizeof(float);
     if (lds > 160 * 1024) return MI_ERR_UNSUPPORTED;
-    const bool fast = a.K == DWF_K && a.dilation == 1 && a.pad_left == (DWF_K - 1) / 2 && (a.C % DWF_CT) == 0 &&
+    const bool fast = !(csgu && !a.mul) && a.K == DWF_K && a.dilation == 1 && a.pad_left == (DWF_K - 1) / 2 && (a.C % DWF_CT) == 0 &&
                       (a.ld_in % 8) == 0 && (((uintptr_t)a.in) & 15) == 0 && (a.ld_out % 8) == 0 && (((uintptr_t)a.out) & 15) == 0 &&
                       (!csgu || ((a.ld_mul % 8) == 0 && (((uintptr_t)a.mul) & 15) == 0)) && (!csgu || (((uintptr_t)a.gamma | (uintptr_t)a.beta) & 15) == 0);
     if (fast) {
@@ -375,6 +375,43 @@ extern "C" int mi_csgu_bf16(const void* u, long ldu, const float* stats, const f
     a.gamma = gamma; a.beta = beta; a.w = w; a.bias = bias; a.out = (bf16_t*)out; a.ld_out = ldo;
     a.B = B; a.T = T; a.C = C; a.K = K; a.pad_left = pad_left; a.dilation = dilation; a.act = act;
     return dw_launch(a, true, stream);
+}
+
+// The CSGU conv alone: out (B*T, C) bf16 = dwconv(LN(x_g)) + bias, for `csgu_use_linear_after_conv` (e_branchformer.py:172-175,196-201: conv -> Linear -> act -> gate),
+// whose Linear runs as a GEMM between this and mi_gate_act_mul_bf16.
+extern "C" int mi_csgu_conv_bf16(const void* u, long ldu, const float* stats, const float* gamma, const float* beta,
+                                 const float* w, const float* bias, void* out, long ldo,
+                                 int B, int T, int C, int K, int pad_left, int dilation, hipStream_t stream) {
+    MI_ENTER();
+    DwArgs a{};
+    a.in = (const bf16_t*)u + C; a.ld_in = ldu; a.mul = nullptr; a.ld_mul = 0; a.stats = stats;
+    a.gamma = gamma; a.beta = beta; a.w = w; a.bias = bias; a.out = (bf16_t*)out; a.ld_out = ldo;
+    a.B = B; a.T = T; a.C = C; a.K = K; a.pad_left = pad_left; a.dilation = dilation; a.act = 0;
+    return dw_launch(a, true, stream);
+}
+
+__global__ __launch_bounds__(256) void gate_act_mul_kernel(const bf16_t* r, long ldr, const bf16_t* g, long ldg, bf16_t* out, long ldo, long M, int C, int act) {
+    const long n = M * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long row = i / C;
+        const int c = (int)(i - row * C);
+        float v = bf2f(g[row * ldg + c]);
+        if (act == 1) v = gelu_erf(v);
+        else if (act == 2) v = fmaxf(v, 0.f);
+        else if (act == 3) v = v / (1.f + __expf(-v));
+        out[row * ldo + c] = f2bf(bf2f(r[row * ldr + c]) * v);
+    }
+}
+
+// out = x_r * act(g): the gate of the split CSGU form (act: 0 identity, 1 gelu, 2 relu, 3 silu)
+extern "C" int mi_gate_act_mul_bf16(const void* r, long ldr, const void* g, long ldg, void* out, long ldo, long M, int C, int act, hipStream_t stream) {
+    MI_ENTER();
+    if (M <= 0 || C <= 0 || act < 0 || act > 3) return MI_ERR_ARG;
+    const long blocks = (M * C + 255) / 256;
+    hipLaunchKernelGGL(gate_act_mul_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream,
+                       (const bf16_t*)r, ldr, (const bf16_t*)g, ldg, (bf16_t*)out, ldo, M, C, act);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
 }
 
 // MERGE: out = m + dwconv(m) + bias on (B*T, C) bf16

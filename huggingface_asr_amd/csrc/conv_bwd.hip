@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwBwdArgs p) {
             if (cok && t2 >= 0 && t2 < p.T) {
                 const long row = (long)b * p.T + t2;
                 d = bf2f(p.dy[row * p.lddy + c]);
-                if (CSGU) d *= bf2f(p.r[row * p.ldr + c]);
+                if (CSGU && p.r) d *= bf2f(p.r[row * p.ldr + c]);      // r == NULL: dy already is the conv-output gradient (split-gate form)
             }
             ty_[rr * DB_CT + tx] = d;
         }
@@ -88,9 +88,11 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwBwdArgs p) {
             const float dyc = ty_[(tl + halo - p.pad_left) * DB_CT + tx];      // conv-output gradient at t
             const long row = (long)b * p.T + t;
             if (CSGU) {
-                float cv = bias;                                              // conv output at t (recomputed)
-                for (int k = 0; k < p.K; ++k) cv = fmaf(sw[k * DB_CT + tx], tx_[(tl + k) * DB_CT + tx], cv);
-                p.dr[row * p.lddr + c] = f2bf(bf2f(p.dy[row * p.lddy + c]) * cv);
+                if (p.r) {
+                    float cv = bias;                                          // conv output at t (recomputed)
+                    for (int k = 0; k < p.K; ++k) cv = fmaf(sw[k * DB_CT + tx], tx_[(tl + k) * DB_CT + tx], cv);
+                    p.dr[row * p.lddr + c] = f2bf(bf2f(p.dy[row * p.lddy + c]) * cv);
+                }
             } else {
                 acc += dyc;                                                   // residual path of m + conv(m)
             }
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_dilated_kernel(DwBwdArgs p) {
         if (t < 0 || t >= p.T) return 0.f;
         const long row = (long)b * p.T + t;
         float d = bf2f(p.dy[row * p.lddy + c]);
-        if (CSGU) d *= bf2f(p.r[row * p.ldr + c]);
+        if (CSGU && p.r) d *= bf2f(p.r[row * p.ldr + c]);
         return d;
     };
     if (cok) {
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_dilated_kernel(DwBwdArgs p) {
                     cv = fmaf(wk[k], xv, cv);
                     gw[k] = fmaf(dt, xv, gw[k]);
                 }
-            if (CSGU) p.dr[row * p.lddr + c] = f2bf(bf2f(p.dy[row * p.lddy + c]) * cv);
+            if (CSGU) { if (p.r) p.dr[row * p.lddr + c] = f2bf(bf2f(p.dy[row * p.lddy + c]) * cv); }
             else acc += dt;                                    // residual path of m + conv(m)
             p.dx[row * p.lddx + c] = f2bf(acc);
             gb += dt;
@@ -467,7 +469,7 @@ int dw_bwd_launch(const DwBwdArgs& a, bool csgu, float* workspace, hipStream_t s
         return MI_OK;
     }
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    const bool fast = workspace && a.K == FB_K && a.pad_left == 15 && (a.C % FB_CT) == 0 && (a.ldx % 8) == 0 && (a.lddy % 8) == 0 && (a.lddx % 8) == 0 &&
+    const bool fast = workspace && !(csgu && !a.r) && a.K == FB_K && a.pad_left == 15 && (a.C % FB_CT) == 0 && (a.ldx % 8) == 0 && (a.lddy % 8) == 0 && (a.lddx % 8) == 0 &&
                       al16(a.x) && al16(a.dy) && al16(a.dx) && (!csgu || ((a.ldr % 8) == 0 && (a.lddr % 8) == 0 && al16(a.r) && al16(a.dr) && al16(a.gamma) && al16(a.beta)));
     if (fast) {
         const size_t ldsf = (size_t)2 * FB_ROWS * FB_CT * sizeof(float) + (size_t)FB_TT * FB_CT * sizeof(bf16_t);
@@ -493,16 +495,54 @@ int dw_bwd_launch(const DwBwdArgs& a, bool csgu, float* workspace, hipStream_t s
 // `workspace`: B*C*32 floats (per-utterance tap-gradient partials of the K = 31 fast path) or NULL (generic kernel, atomics).
 // CSGU backward (identity activation; dilation > 1 = the causal form): u (B*T, 2C) = [x_r | x_g], ds = gradient of x_r * (dwconv(LN(x_g)) + b)
 //   -> dr (B*T, C) = ds * conv,  dgn (B*T, C) = gradient w.r.t. LN(x_g),  dw (C,K) +=, db (C) +=
+// dr == NULL: the split-gate form (mi_csgu_conv_bf16 forward) — `ds` is the gradient of the conv output itself, no gate operand is applied or produced.
 extern "C" int mi_csgu_bwd_bf16(const void* u, long ldu, const float* stats, const float* gamma, const float* beta, const float* w,
                                 const float* bias, const void* ds, long ldds, void* dr, long lddr, void* dgn, long lddgn,
                                 float* dw, float* db, int B, int T, int C, int K, int pad_left, int dilation, float* workspace, hipStream_t st) {
     MI_ENTER();
     DwBwdArgs a{};
     a.dilation = dilation;
-    a.x = (const bf16_t*)u + C; a.ldx = ldu; a.r = (const bf16_t*)u; a.ldr = ldu; a.stats = stats; a.gamma = gamma; a.beta = beta;
+    a.x = (const bf16_t*)u + C; a.ldx = ldu; a.r = dr ? (const bf16_t*)u : nullptr; a.ldr = ldu; a.stats = stats; a.gamma = gamma; a.beta = beta;
     a.dy = (const bf16_t*)ds; a.lddy = ldds; a.w = w; a.bias = bias; a.dx = (bf16_t*)dgn; a.lddx = lddgn; a.dr = (bf16_t*)dr; a.lddr = lddr;
     a.dw = dw; a.db = db; a.B = B; a.T = T; a.C = C; a.K = K; a.pad_left = pad_left;
     return dw_bwd_launch(a, true, workspace, st);
+}
+
+__device__ __forceinline__ float gate_act(float v, int act) {
+    if (act == 1) return gelu_erf(v);
+    if (act == 2) return fmaxf(v, 0.f);
+    if (act == 3) return v / (1.f + __expf(-v));
+    return v;
+}
+__device__ __forceinline__ float gate_act_grad(float v, int act) {
+    if (act == 1) return 0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v);
+    if (act == 2) return v > 0.f ? 1.f : 0.f;
+    if (act == 3) { const float sg = 1.f / (1.f + __expf(-v)); return sg * (1.f + v * (1.f - sg)); }
+    return 1.f;
+}
+
+__global__ __launch_bounds__(256) void gate_act_mul_bwd_kernel(const bf16_t* r, long ldr, const bf16_t* g, long ldg, const bf16_t* ds, long ldds,
+                                                               bf16_t* dr, long lddr, bf16_t* dg, long lddg, long M, int C, int act) {
+    const long n = M * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long row = i / C;
+        const int c = (int)(i - row * C);
+        const float gv = bf2f(g[row * ldg + c]), d = bf2f(ds[row * ldds + c]);
+        dr[row * lddr + c] = f2bf(d * gate_act(gv, act));
+        dg[row * lddg + c] = f2bf(d * bf2f(r[row * ldr + c]) * gate_act_grad(gv, act));
+    }
+}
+
+// backward of mi_gate_act_mul_bf16 (s = x_r * act(g)):  dr = ds * act(g),  dg = ds * x_r * act'(g)
+extern "C" int mi_gate_act_mul_bwd_bf16(const void* r, long ldr, const void* g, long ldg, const void* ds, long ldds, void* dr, long lddr,
+                                        void* dg, long lddg, long M, int C, int act, hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || C <= 0 || act < 0 || act > 3) return MI_ERR_ARG;
+    const long blocks = (M * C + 255) / 256;
+    hipLaunchKernelGGL(gate_act_mul_bwd_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, (const bf16_t*)r, ldr, (const bf16_t*)g, ldg,
+                       (const bf16_t*)ds, ldds, (bf16_t*)dr, lddr, (bf16_t*)dg, lddg, M, C, act);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
 }
 
 // merge-block backward: y = m + dwconv(m) + b  ->  dm = dy + conv^T(dy),  dw +=, db +=

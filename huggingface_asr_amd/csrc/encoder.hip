@@ -24,7 +24,7 @@ enum LS { FF1_LN_G, FF1_LN_B, FF1_W1, FF1_B1, FF1_W2, FF1_B2,
           ATT_LN_G, ATT_LN_B, ATT_WQK, ATT_BQK, ATT_WV, ATT_BV, ATT_WO, ATT_BO, ATT_WPOS, ATT_U, ATT_V,
           MLP_LN_G, MLP_LN_B, MLP_W1, MLP_B1, CSGU_LN_G, CSGU_LN_B, CSGU_W, CSGU_B, MLP_W2, MLP_B2,
           MRG_DW_W, MRG_DW_B, MRG_W, MRG_B, FIN_LN_G, FIN_LN_B,
-          FF2_LN_G, FF2_LN_B, FF2_W1, FF2_B1, FF2_W2, FF2_B2 };
+          FF2_LN_G, FF2_LN_B, FF2_W1, FF2_B1, FF2_W2, FF2_B2, CSGU_LIN_W, CSGU_LIN_B };
 
 struct Dims { int T1, F1, T2, F2, M, Tp, hd; };
 
@@ -46,6 +46,7 @@ struct Carver {
 
 struct Ws {
     bf16_t *act1, *act2, *a0, *a1, *a2, *a1r, *h, *qk, *vt, *ctx, *cat, *m2, *s, *hid;
+    bf16_t *cv, *lin;         // csgu_use_linear_after_conv: the CSGU conv output and the Linear's output
     float *feo, *x, *stats;
     float *mixed, *lh, *sw;   // fine-tuning head: weighted sum of the hidden states, fp32 copy of the last one, softmax(per_layer_weights)
     int* lens;   // [inner(B) | outer(B)]
@@ -72,6 +73,8 @@ Ws carve(const mi_ebf_config& c, void* base) {
     w.cat = (bf16_t*)k.take(M * 2 * c.d * 2);
     w.m2 = (bf16_t*)k.take(M * 2 * c.d * 2);
     w.s = (bf16_t*)k.take(M * (c.I / 2) * 2);
+    w.cv = w.lin = nullptr;
+    if (c.csgu_linear) { w.cv = (bf16_t*)k.take(M * (c.I / 2) * 2); w.lin = (bf16_t*)k.take(M * (c.I / 2) * 2); }
     w.hid = (bf16_t*)k.take(M * c.d * 2);
     w.stats = (float*)k.take(M * 2 * 4);
     w.lens = (int*)k.take((size_t)2 * c.B * 4);
@@ -309,6 +312,11 @@ extern "C" int mi_ebf_forward_hs(const mi_ebf_config* cfg, const void* const* we
         // quirk: the causal CSGU conv is dilated by (K-1)/2 (e_branchformer.py:153-160 passes it in the dilation slot)
         const int dil = c.is_causal ? (kc - 1) / 2 : 1;
         const int cpad = c.is_causal ? (kc - 1) * dil : (kc - 1) / 2;
+        if (c.csgu_linear) {   // conv -> Linear -> act -> gate (e_branchformer.py:196-201)
+            RUN(mi_csgu_conv_bf16(w.h, I, w.stats, Lf(l, CSGU_LN_G), Lf(l, CSGU_LN_B), Lf(l, CSGU_W), Lf(l, CSGU_B), w.cv, I / 2, c.B, T2, I / 2, kc, cpad, dil, sl));
+            RUN(mi_gemm_bf16(w.cv, I / 2, Lw(l, CSGU_LIN_W), I / 2, Lf(l, CSGU_LIN_B), 1, w.lin, I / 2, 0, nullptr, 0, 1.f, 0, M, I / 2, I / 2, 0, 0, sl));
+            RUN(mi_gate_act_mul_bf16(w.h, I, w.lin, I / 2, w.s, I / 2, M, I / 2, c.csgu_act, sl));
+        } else
         RUN(mi_csgu_bf16(w.h, I, w.stats, Lf(l, CSGU_LN_G), Lf(l, CSGU_LN_B), Lf(l, CSGU_W), Lf(l, CSGU_B), w.s, I / 2,
                          c.B, T2, I / 2, kc, cpad, dil, c.csgu_act, sl));
         RUN(mi_gemm_bf16(w.s, I / 2, Lw(l, MLP_W2), I / 2, Lf(l, MLP_B2), 1, w.cat + d, 2 * d, 0, nullptr, 0, 1.f, 0, M, d, I / 2, 0, 0, sl));

@@ -26,7 +26,7 @@ LS = {n: i for i, n in enumerate(
      "ATT_LN_G", "ATT_LN_B", "ATT_WQK", "ATT_BQK", "ATT_WV", "ATT_BV", "ATT_WO", "ATT_BO", "ATT_WPOS", "ATT_U", "ATT_V",
      "MLP_LN_G", "MLP_LN_B", "MLP_W1", "MLP_B1", "CSGU_LN_G", "CSGU_LN_B", "CSGU_W", "CSGU_B", "MLP_W2", "MLP_B2",
      "MRG_DW_W", "MRG_DW_B", "MRG_W", "MRG_B", "FIN_LN_G", "FIN_LN_B",
-     "FF2_LN_G", "FF2_LN_B", "FF2_W1", "FF2_B1", "FF2_W2", "FF2_B2"])}
+     "FF2_LN_G", "FF2_LN_B", "FF2_W1", "FF2_B1", "FF2_W2", "FF2_B2", "CSGU_LIN_W", "CSGU_LIN_B"])}
 ACT = {"identity": 0, "gelu": 1, "relu": 2, "silu": 3, "swish": 3}
 POS = {None: 0, "none": 0, "relative": 1, "rotary": 2}
 
@@ -72,8 +72,6 @@ class EBranchformerEngine:
         self.mix = int(bool(c.get("finetune_with_layer_mixing", False)))
         if len(c["conv_dim"]) != 2 or len(set(c["conv_kernel"])) != 1 or len(set(c["conv_stride"])) != 1 or len(set(c["conv_padding"])) != 1:
             raise NotImplementedError("HIP path supports the 2-layer Conv2d sub-sampling with equal kernel/stride/padding")
-        if c.get("csgu_use_linear_after_conv", False):
-            raise NotImplementedError("csgu_use_linear_after_conv is not on the HIP path yet")
         if c.get("hidden_act", "gelu") != "gelu" or c.get("feat_extract_activation", "gelu") != "gelu":
             raise NotImplementedError("HIP path implements the erf-GELU activations of the reference configs")
         if c.get("csgu_activation", "identity") not in ACT:
@@ -145,6 +143,8 @@ class EBranchformerEngine:
             lp("CSGU_LN_G", f32(sd[m + "csgu.norm.weight"])); lp("CSGU_LN_B", f32(sd[m + "csgu.norm.bias"]))
             lp("CSGU_W", f32(sd[m + "csgu.conv.weight"]).reshape(-1, c.get("csgu_kernel_size", 31)))
             lp("CSGU_B", f32(sd[m + "csgu.conv.bias"]))
+            if c.get("csgu_use_linear_after_conv", False):
+                lp("CSGU_LIN_W", bf(sd[m + "csgu.linear.weight"])); lp("CSGU_LIN_B", f32(sd[m + "csgu.linear.bias"]))
             lp("MLP_W2", bf(sd[m + "channel_proj2.weight"])); lp("MLP_B2", f32(sd[m + "channel_proj2.bias"]))
             lp("MRG_DW_W", f32(sd[p + "depthwise_conv_fusion.weight"]).reshape(-1, c.get("merge_conv_kernel", 31)))
             lp("MRG_DW_B", f32(sd[p + "depthwise_conv_fusion.bias"]))
@@ -199,7 +199,8 @@ class EBranchformerEngine:
                               csgu_act=ACT[c.get("csgu_activation", "identity")], use_macaron=int(c.get("use_macaron_ff", True)),
                               ln_eps=float(c.get("layer_norm_eps", 1e-5)), logits_f32=int(self.logits_dtype == torch.float32),
                               logits_ld=(c["vocab_size"] + 1 + 7) // 8 * 8,
-                              branch_overlap=int(self.branch_overlap and slot == 0), extra_layers=self.extra, layer_mixing=self.mix)
+                              branch_overlap=int(self.branch_overlap and slot == 0), extra_layers=self.extra, layer_mixing=self.mix,
+                              csgu_linear=int(bool(c.get("csgu_use_linear_after_conv", False))))
 
     def _workspace(self, cs, slot=0):
         key = (cs.B, cs.T, cs.F)

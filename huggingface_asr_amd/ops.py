@@ -163,6 +163,28 @@ def csgu(u, gamma, beta, w, bias, B, T, *, pad_left=None, dilation=1, act=0, eps
     return out
 
 
+def csgu_conv(u, stats, gamma, beta, w, bias, B, T, *, pad_left=None, dilation=1):
+    """the CSGU conv alone (split form: csgu_use_linear_after_conv / non-identity activation on the training path): dwconv(LN(x_g)) + b  (B*T, C) bf16;
+    stats = row_stats(u[:, C:])"""
+    M, C2 = u.shape
+    Cc = C2 // 2
+    K = w.shape[-1]
+    out = torch.empty((M, Cc), device=u.device, dtype=BF16)
+    rc = _lib.lib().mi_csgu_conv_bf16(u.data_ptr(), u.stride(0), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), _p(bias),
+                                      out.data_ptr(), out.stride(0), B, T, Cc, K, (K - 1) // 2 if pad_left is None else int(pad_left), int(dilation), _stream())
+    _lib.check(rc, "mi_csgu_conv_bf16")
+    return out
+
+
+def gate_act_mul(r, g, act=0):
+    """r * act(g) on (M, C) bf16 rows (r may be a column slice); act 0 identity, 1 gelu, 2 relu, 3 silu"""
+    M, Cc = g.shape
+    out = torch.empty((M, Cc), device=g.device, dtype=BF16)
+    rc = _lib.lib().mi_gate_act_mul_bf16(r.data_ptr(), r.stride(0), g.data_ptr(), g.stride(0), out.data_ptr(), out.stride(0), M, Cc, int(act), _stream())
+    _lib.check(rc, "mi_gate_act_mul_bf16")
+    return out
+
+
 def dwconv_residual(m, w, bias, B, T, pad_left=None):
     M, Cc = m.shape
     K = w.shape[-1]

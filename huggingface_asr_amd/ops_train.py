@@ -192,14 +192,23 @@ def dropout_add(resid, t, alpha, p, seed, stream_id):
 
 
 def csgu_bwd(u, stats, gamma, beta, w, bias, ds, dr, dgn, dw, db, B, T, pad_left=None, dilation=1):
-    """pad_left / dilation: None / 1 = the symmetric conv; the causal encoder passes ((K-1)*dil, dil = (K-1)//2), as ops.csgu does."""
+    """dr None: `ds` is the gradient of the conv output itself (split form, ops.csgu_conv).  pad_left / dilation: None / 1 = the symmetric conv; the causal encoder passes ((K-1)*dil, dil = (K-1)//2), as ops.csgu does."""
     M, C2 = u.shape
     Cc = C2 // 2
     K = w.shape[-1]
     pl = (K - 1) // 2 if pad_left is None else int(pad_left)
     _lib.check(_L().mi_csgu_bwd_bf16(u.data_ptr(), u.stride(0), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), _p(bias),
-                                     ds.data_ptr(), ds.stride(0), dr.data_ptr(), dr.stride(0), dgn.data_ptr(), dgn.stride(0),
+                                     ds.data_ptr(), ds.stride(0), _p(dr), dr.stride(0) if dr is not None else 0, dgn.data_ptr(), dgn.stride(0),
                                      dw.data_ptr(), _p(db), B, T, Cc, K, pl, int(dilation), _dw_ws(u.device, B * Cc * 32), _stream()), "mi_csgu_bwd_bf16")
+
+
+def gate_act_mul_bwd(r, g, ds, dr, act=0):
+    """backward of ops.gate_act_mul: writes dr = ds * act(g) into `dr` (a column slice is fine), returns dg = ds * r * act'(g)"""
+    M, Cc = g.shape
+    dg = torch.empty((M, Cc), device=g.device, dtype=BF16)
+    _lib.check(_L().mi_gate_act_mul_bwd_bf16(r.data_ptr(), r.stride(0), g.data_ptr(), g.stride(0), ds.data_ptr(), ds.stride(0), dr.data_ptr(), dr.stride(0),
+                                             dg.data_ptr(), dg.stride(0), M, Cc, int(act), _stream()), "mi_gate_act_mul_bwd_bf16")
+    return dg
 
 
 def dwconv_residual_bwd(m, w, dy, dm, dw, db, B, T, pad_left=None):

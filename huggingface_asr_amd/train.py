@@ -185,6 +185,8 @@ def encoder_specs(c: dict, head: bool = True) -> list[Spec]:
             mat(p + "att_wpos", d, d); vec(p + "att_u", d); vec(p + "att_v", d)          # pos_bias_* : "bias" in the name -> no decay
         vec(p + "mlp_ln_g", d); vec(p + "mlp_ln_b", d); mat(p + "mlp_w1", I, d); vec(p + "mlp_b1", I)
         vec(p + "csgu_ln_g", I // 2); vec(p + "csgu_ln_b", I // 2); vec(p + "csgu_w", I // 2, kc, decay=True); vec(p + "csgu_b", I // 2)
+        if c.get("csgu_use_linear_after_conv", False):
+            mat(p + "csgu_lin_w", I // 2, I // 2); vec(p + "csgu_lin_b", I // 2)
         mat(p + "mlp_w2", d, I // 2); vec(p + "mlp_b2", d)
         vec(p + "mrg_dw_w", 2 * d, km, decay=True); vec(p + "mrg_dw_b", 2 * d); mat(p + "mrg_w", d, 2 * d); vec(p + "mrg_b", d)
         for ff in ffs[1:]:
@@ -256,6 +258,8 @@ def _enc_map(c: dict, head: bool = True):
         one(p + "csgu_ln_g", g + "csgu.norm.weight"); one(p + "csgu_ln_b", g + "csgu.norm.bias")
         one(p + "csgu_w", g + "csgu.conv.weight", lambda t: t.reshape(-1, kc), lambda t: t.reshape(-1, 1, kc))
         one(p + "csgu_b", g + "csgu.conv.bias")
+        if c.get("csgu_use_linear_after_conv", False):
+            one(p + "csgu_lin_w", g + "csgu.linear.weight"); one(p + "csgu_lin_b", g + "csgu.linear.bias")
         one(p + "mlp_w2", g + "channel_proj2.weight"); one(p + "mlp_b2", g + "channel_proj2.bias")
         one(p + "mrg_dw_w", r + "depthwise_conv_fusion.weight", lambda t: t.reshape(-1, km), lambda t: t.reshape(-1, 1, km))
         one(p + "mrg_dw_b", r + "depthwise_conv_fusion.bias")
@@ -335,8 +339,13 @@ class EncoderCTCTrainer:
         self.causal = bool(c.get("is_causal", False))               # streaming encoder: left-padded front end, triu attention mask, dilated causal CSGU conv
         if len(c["conv_dim"]) != 2 or c["conv_kernel"][0] != 3 or len(set(c["conv_kernel"])) != 1:
             raise NotImplementedError("training path: 2-layer 3x3 Conv2d sub-sampling only")
-        if c.get("csgu_activation", "identity") != "identity" or c.get("csgu_use_linear_after_conv", False):
-            raise NotImplementedError("training path: CSGU with identity activation and no linear-after-conv only")
+        from .engine import ACT
+        if c.get("csgu_activation", "identity") not in ACT:
+            raise NotImplementedError(f"csgu_activation {c['csgu_activation']}")
+        self.csgu_act = ACT[c.get("csgu_activation", "identity")]
+        self.csgu_lin = bool(c.get("csgu_use_linear_after_conv", False))
+        # fused CSGU kernels cover the reference recipes' form (identity activation, no Linear); anything else runs split: conv -> [Linear] -> act * gate
+        self.csgu_split = self.csgu_lin or self.csgu_act != 0
         self.frozen = set()
         self.layerdrop = float(c.get("layerdrop", 0.0) or 0.0)      # tf:models/wav2vec2_conformer/modeling_wav2vec2_conformer.py:686-690
         g = lambda k: float(c.get(k, 0.0) or 0.0)
@@ -587,7 +596,14 @@ class EncoderCTCTrainer:
             hp = ops.gemm(a2, W(p + "mlp_w1"), P(p + "mlp_b1"))
             h = T.act_fwd(hp)
             stats = ops.row_stats(h[:, I // 2:])
-            sg = ops.csgu(h, P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), B, T2, pad_left=cs_pad, dilation=cs_dil)
+            cv = lin = None
+            if self.csgu_split:                              # e_branchformer.py:196-201: conv -> [Linear] -> act -> gate
+                cv = lin = ops.csgu_conv(h, stats, P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), B, T2, pad_left=cs_pad, dilation=cs_dil)
+                if self.csgu_lin:
+                    lin = ops.gemm(cv, W(p + "csgu_lin_w"), P(p + "csgu_lin_b"))
+                sg = ops.gate_act_mul(h[:, :I // 2], lin, self.csgu_act)
+            else:
+                sg = ops.csgu(h, P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), B, T2, pad_left=cs_pad, dilation=cs_dil)
             if pd["csgu"] > 0:
                 T.dropout_(sg, pd["csgu"], seed, self._sid(sl, 4))
             ops.gemm(sg, W(p + "mlp_w2"), P(p + "mlp_b2"), out=cat[:, d:])
@@ -597,7 +613,7 @@ class EncoderCTCTrainer:
                 x2 = T.dropout_add(x, ops.gemm(m2, W(p + "mrg_w"), P(p + "mrg_b"), out_dtype=F32), 1.0, pd["att"], seed, self._sid(sl, 5))
             else:
                 x2 = ops.gemm(m2, W(p + "mrg_w"), P(p + "mrg_b"), out_dtype=F32, resid=x, alpha=1.0)
-            S.update(a1=a1, a2=a2, qkv=qkv, posp=posp, ctx=ctx, hp=hp, h=h, stats=stats, sg=sg, cat=cat, m2=m2, x2=x2)
+            S.update(a1=a1, a2=a2, qkv=qkv, posp=posp, ctx=ctx, hp=hp, h=h, stats=stats, sg=sg, cat=cat, m2=m2, x2=x2, cv=cv, lin=lin)
             x = x2
             if macaron:
                 x, S["ff2"] = self._ffn_fwd(x, p + "ff2", LN, e16, pd, sl, (6, 7))
@@ -677,8 +693,14 @@ class EncoderCTCTrainer:
                 T.dropout_(dsg, pd["csgu"], seed, self._sid(sl, 4))
             dh = e16(M, I)
             dgn = e16(M, I // 2)
-            T.csgu_bwd(S["h"], S["stats"], P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), dsg, dh[:, :I // 2], dgn,
-                       G(p + "csgu_w"), G(p + "csgu_b"), B, T2, pad_left=cs_pad, dilation=cs_dil)
+            if self.csgu_split:
+                dlin = T.gate_act_mul_bwd(S["h"][:, :I // 2], S["lin"], dsg, dh[:, :I // 2], self.csgu_act)
+                dcv = T.linear_bwd(dlin, S["cv"], WT(p + "csgu_lin_w"), dw=GL(p + "csgu_lin_w"), db=GL(p + "csgu_lin_b")) if self.csgu_lin else dlin
+                T.csgu_bwd(S["h"], S["stats"], P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), dcv, None, dgn,
+                           G(p + "csgu_w"), G(p + "csgu_b"), B, T2, pad_left=cs_pad, dilation=cs_dil)
+            else:
+                T.csgu_bwd(S["h"], S["stats"], P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), dsg, dh[:, :I // 2], dgn,
+                           G(p + "csgu_w"), G(p + "csgu_b"), B, T2, pad_left=cs_pad, dilation=cs_dil)
             T.layernorm_bwd(S["h"][:, I // 2:], P(p + "csgu_ln_g"), dgn, dh[:, I // 2:], accumulate=False, **self._lng(p + "csgu_ln_g", p + "csgu_ln_b"))
             dhp = T.act_bwd(dh, S["hp"])
             da2 = T.linear_bwd(dhp, S["a2"], WT(p + "mlp_w1"), dw=GL(p + "mlp_w1"), db=GL(p + "mlp_b1"))

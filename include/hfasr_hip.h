@@ -109,6 +109,14 @@ int mi_csgu_bf16(const void* u, long ldu, const float* stats, const float* gamma
 /* ---- merge block depthwise conv + residual. replaces: e_branchformer.py:296-299. */
 int mi_dwconv_residual_bf16(const void* m, long ldm, const float* w, const float* bias, void* out, long ldo,
                             int B, int T, int C, int K, int pad_left, mi_stream_t stream);
+/* the split CSGU form — `csgu_use_linear_after_conv` (e_branchformer.py:172-175,196-201: conv -> Linear -> act -> gate) and, on the training path, any
+   csgu_activation other than identity:  conv alone (out = dwconv(LN(x_g)) + b), then [a GEMM], then out = x_r * act(g)  (act: 0 identity, 1 gelu, 2 relu, 3 silu) */
+int mi_csgu_conv_bf16(const void* u, long ldu, const float* stats, const float* gamma, const float* beta, const float* w, const float* bias,
+                      void* out, long ldo, int B, int T, int C, int K, int pad_left, int dilation, mi_stream_t stream);
+int mi_gate_act_mul_bf16(const void* r, long ldr, const void* g, long ldg, void* out, long ldo, long M, int C, int act, mi_stream_t stream);
+/* dr = ds * act(g),  dg = ds * x_r * act'(g) */
+int mi_gate_act_mul_bwd_bf16(const void* r, long ldr, const void* g, long ldg, const void* ds, long ldds, void* dr, long lddr, void* dg, long lddg,
+                             long M, int C, int act, mi_stream_t stream);
 
 /* ---- log-mel front end. replaces: CustomFeatureExtractor.__call__ (src/utilities/feature_extractors.py:51-61) =
  *      Speech2TextFeatureExtractor._extract_fbank_features / utterance_cmvn (transformers) / global_normalize (:47-49). */
@@ -298,6 +306,8 @@ typedef struct {
                                     final LayerNorm and the head: padded frames zeroed, same key mask and position table, no LayerNorm after it */
     int layer_mixing;            /* `finetune_with_layer_mixing`: softmax(per_layer_weights, global slot 14)-weighted sum of the L+1 hidden states
                                     (the input of every layer + the final LayerNorm's output) replaces the last hidden state */
+    int csgu_linear;             /* `csgu_use_linear_after_conv` (e_branchformer.py:172-175,198-199): a Linear (layer slots CSGU_LIN_W bf16 (I/2, I/2) / CSGU_LIN_B) between
+                                    the CSGU conv and its activation */
 } mi_ebf_config;
 
 /* weight-table slot indices: see huggingface_asr_amd/engine.py (SLOTS) — the table is an array of device pointers. */

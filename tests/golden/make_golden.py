@@ -714,6 +714,10 @@ if __name__ == "__main__":
     if "gradscausal" in which or "grads" in which:
         # the streaming encoder: left-padded Conv2d front end, triu attention mask, the CSGU conv dilated by 15 (T' = 100 frames: 7 of its 31 taps see data)
         run_grad_case("grads_tiny_causal", TINY, seed=17, B=2, T=400, lengths=[400, 263], U=6, tgt_lens=[6, 4], is_causal=True)
+    if "gradscsgu" in which or "grads" in which:
+        # the CSGU's optional pieces (no reference recipe turns them on): Linear after the conv + GELU before the gate; SiLU without the Linear
+        run_grad_case("grads_tiny_csgu_linear", TINY, seed=18, B=2, T=120, lengths=[120, 88], U=4, tgt_lens=[4, 3], csgu_activation="gelu", csgu_use_linear_after_conv=True)
+        run_grad_case("grads_tiny_csgu_silu", TINY, seed=19, B=1, T=120, lengths=[120], U=4, tgt_lens=[4], csgu_activation="silu")
         # (use_macaron_ff=False is not runnable in the reference: its layer forward reads self.ff1 unconditionally, e_branchformer.py:271)
     if "basegrads" in which:
         run_grad_case_strided("grads_base_rel", BASE, seed=24, B=2, T=1000, lengths=[998, 700], U=40, tgt_lens=[40, 31])

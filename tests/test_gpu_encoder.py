@@ -41,6 +41,7 @@ TINY = [
     ("tiny_rel", _cfg(shapes.TINY)),
     ("tiny_rotary", _cfg(shapes.TINY, position_embeddings_type="rotary")),
     ("tiny_causal", _cfg(shapes.TINY, is_causal=True)),
+    ("tiny_nomacaron", _cfg(shapes.TINY, csgu_activation="gelu", csgu_use_linear_after_conv=True)),      # CSGU: conv -> Linear -> GELU -> gate (e_branchformer.py:196-201)
 ]
 
 
