@@ -32,6 +32,8 @@ struct AttnArgs {
 };
 
 constexpr int SKEW_LD = 66;   // words per query row of the skew scratch: reads conflict-free, writes 2-way (free)
+constexpr int OST_B = 272;    // LDS-staged kernel, output staging: bytes per query row (hd 128 -> 256 B + 16: rows stay 16-B aligned for ds_read_b128, writes 2-way)
+constexpr int WSCR_B = 32 * OST_B;   // per-wave scratch of the LDS-staged kernel: skew rows (32 x 66 words) | Q tile (8 KiB, prologue) | output rows (epilogue)
 
 __device__ __forceinline__ int crow(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
@@ -205,11 +207,12 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
     char* sV = sK + 2 * TILEB;                                // [2][TILEB]
     char* sP = sV + 2 * TILEB;                                // [PRING][TILEB]
     float* skew_all = reinterpret_cast<float*>(sP + PRING * TILEB);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;     // wave-uniform: ring slots and band blocks stay on the scalar unit
     const int r = lane & 31, h2 = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
     const int ib = blockIdx.x * 128, i0 = ib + wave * 32;
-    float* skew = skew_all + wave * 32 * SKEW_LD;
+    char* wscr = reinterpret_cast<char*>(skew_all) + wave * WSCR_B;       // this wave's private scratch
+    float* skew = reinterpret_cast<float*>(wscr);
     const int T = p.T;                                        // queries per batch
     const int Tk = p.Tk > 0 ? p.Tk : p.T;                     // keys per batch (cross-attention / KV cache: Tk != T)
     const int coff = Tk - T;                                  // causal: query i sees keys <= i + coff
@@ -218,33 +221,66 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
     const int nkt = (kend + 31) / 32;
     const int rb0 = T - 1 - ib - 31;                          // band base of wave 0 at step 0 (REL needs Tk == T)
 
-    // ---- DMA issue helpers (this wave's PPW pieces of a 32-row tile)
+    // ---- DMA issue: this wave's PPW pieces of a 32-row tile.  Everything that does not change from step to step (the piece's row within the tile, the swizzled
+    // source column, the operand's batch base) is folded into one per-lane pointer per piece and operand before the loop; a step costs clamp + one 64-bit mad per piece.
     const int prow = lane / NCH, pc = lane % NCH;
-    auto issue_rows = [&](const bf16_t* base, long ld, int row0, int rmax, char* dst) {
+    int prw[PPW];
+    const char *kB[PPW], *vB[PPW], *pB[PPW];
+    const long kvoff = p.kv_bstride ? (long)b * p.kv_bstride : 0;
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int row = (wave * PPW + q) * RPP + prow;        // 0..31
+        const int colb = (head * HD + (pc ^ (row & (NCH - 1))) * 8) * 2;
+        prw[q] = row;
+        kB[q] = reinterpret_cast<const char*>(p.k + (p.kv_bstride ? kvoff : (long)b * Tk * p.ldk)) + colb;
+        vB[q] = reinterpret_cast<const char*>(p.vt + (p.kv_bstride ? kvoff : (long)b * Tk * p.ldvt)) + colb;       // p.vt = V [key][hd]
+        pB[q] = reinterpret_cast<const char*>(p.pos) + colb;
+    }
+    const unsigned ldkB = (unsigned)p.ldk * 2u, ldvB = (unsigned)p.ldvt * 2u, ldpB = (unsigned)p.ldp * 2u;     // row strides in bytes (< 2^32: checked on the host)
+    auto issue_rows = [&](const char* const (&base)[PPW], unsigned ldB, int row0, int rmax, char* dst) {
 #pragma unroll
         for (int q = 0; q < PPW; ++q) {
-            const int piece = wave * PPW + q;
-            const int row = piece * RPP + prow;               // 0..31
-            const int lc = pc ^ (row & (NCH - 1));
-            const int gr = min(max(row0 + row, 0), rmax);
-            const bf16_t* src = base + (long)gr * ld + head * HD + lc * 8;
+            const unsigned gr = (unsigned)min(max(row0 + prw[q], 0), rmax);
+            const char* src = base[q] + (unsigned long)gr * ldB;
             __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(dst + (wave * PPW + q) * 1024), 16, 0, 0);
         }
     };
+    int pslot_dma = (1 + PRING * 4) % PRING;                  // ring slot of position block it + 1 (the one the step's DMA fills), advanced by hand: no modulo in the loop
     auto issue_step = [&](int it) {
-        issue_rows(p.k + (p.kv_bstride ? (long)b * p.kv_bstride : (long)b * Tk * p.ldk), p.ldk, 32 * it, Tk - 1, sK + (it & 1) * TILEB);
-        issue_rows(p.vt + (p.kv_bstride ? (long)b * p.kv_bstride : (long)b * Tk * p.ldvt), p.ldvt, 32 * it, Tk - 1, sV + (it & 1) * TILEB);   // p.vt = V [key][hd]
-        if (REL) issue_rows(p.pos, p.ldp, rb0 + 32 * it + 32, 2 * T - 2, sP + ((it + PRING * 4) % PRING) * TILEB);
+        issue_rows(kB, ldkB, 32 * it, Tk - 1, sK + (it & 1) * TILEB);
+        issue_rows(vB, ldvB, 32 * it, Tk - 1, sV + (it & 1) * TILEB);
+        if (REL) issue_rows(pB, ldpB, rb0 + 32 * it + 32, 2 * T - 2, sP + pslot_dma * TILEB);
     };
 
-    // ---- prologue: Q fragments (+u / +v), step 0 tiles, position blocks -4..-1
-    const int iq = min(i0 + r, T - 1);
+    // ---- prologue: position blocks -4..-1 and the step-0 tiles, then this wave's 32 query rows — staged like a K tile (whole 1-KiB pieces = 4 or 8 full rows per
+    // instruction, swizzled) into the wave's private scratch and read back as MFMA fragments: a lane-per-row global read of Q touches 32 lines per instruction.
+    if (REL) {
+#pragma unroll
+        for (int k = -4; k < 0; ++k)
+            issue_rows(pB, ldpB, rb0 + 32 * k + 32, 2 * T - 2, sP + ((k + PRING * 4) % PRING) * TILEB);
+    }
+    pslot_dma = (0 + PRING * 4) % PRING;
+    issue_step(0);
+    pslot_dma = (1 + PRING * 4) % PRING;
+    {
+        const char* qb = reinterpret_cast<const char*>(p.q + (long)b * T * p.ldq);
+        const unsigned ldqB = (unsigned)p.ldq * 2u;
+#pragma unroll
+        for (int piece = 0; piece < PIECES; ++piece) {
+            const int row = piece * RPP + prow;
+            const int colb = (head * HD + (pc ^ (row & (NCH - 1))) * 8) * 2;
+            const char* src = qb + (unsigned long)(unsigned)min(i0 + row, T - 1) * ldqB + colb;
+            __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)src,
+                                             (__attribute__((address_space(3))) void*)(wscr + piece * 1024), 16, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // own pieces only: the scratch is wave-private (the block-wide wait + barrier for the shared tiles follows below)
     bf16x8 qu[KS], qv[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int c = head * HD + ks * 16 + h2 * 8;
-        const bf16x8 raw = *reinterpret_cast<const bf16x8*>(p.q + ((long)b * T + iq) * p.ldq + c);
+        const bf16x8 raw = *reinterpret_cast<const bf16x8*>(wscr + r * ROWB + (((ks * 2 + h2) ^ (r & (NCH - 1))) << 4));
         if (REL) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -256,57 +292,77 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
             qu[ks] = raw;
         }
     }
-    if (REL) {
-#pragma unroll
-        for (int k = -4; k < 0; ++k)
-            issue_rows(p.pos, p.ldp, rb0 + 32 * k + 32, 2 * T - 2, sP + ((k + PRING * 4) % PRING) * TILEB);
-    }
-    issue_step(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the fragments are in registers before the scratch is reused as the skew rows
 
     f32x16 O[NTO];
 #pragma unroll
     for (int t = 0; t < NTO; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) O[t][e] = 0.f;
-    float m = -1e30f, l = 0.f;
+    float m = -1e30f, l = 0.f;                               // running maximum in the exp2 domain (scores * scale * log2 e)
     f32x16 Gc;                                               // carried G tile (lower half of this step's band)
 #pragma unroll
     for (int e = 0; e < 16; ++e) Gc[e] = 0.f;
 
-    auto gtile = [&](int blk) {                              // G^T tile of position block `blk` against (q+v)
+    // per-lane LDS offsets that do not change from step to step: K / P fragment rows, V^T transposed-read addresses
+    int foff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) foff[ks] = r * ROWB + (((ks * 2 + h2) ^ (r & (NCH - 1))) << 4);
+    int voff[NTO][2];
+    {
+        const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+#pragma unroll
+        for (int t = 0; t < NTO; ++t)
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) {
+                const int col = t * 32 + (g & 1) * 16 + 4 * p4;             // hd column of this lane's 4 elements
+                const int krow = 8 * hi + 4 * (g >> 1) + q4;                // key row within a 16-key half (the half adds 16 rows: a multiple of NCH, the swizzle is unchanged)
+                voff[t][hi] = krow * ROWB + (((col >> 3) ^ (krow & (NCH - 1))) << 4) + (col & 7) * 2;
+            }
+    }
+
+    auto gtile = [&](int slot) {                             // G^T tile of the position block in ring slot `slot` against (q+v)
         f32x16 G;
 #pragma unroll
         for (int e = 0; e < 16; ++e) G[e] = 0.f;
-        const char* pb = sP + ((blk + PRING * 4) % PRING) * TILEB + r * ROWB;
+        const char* pb = sP + slot * TILEB;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 pf = *reinterpret_cast<const bf16x8*>(pb + (((ks * 2 + h2) ^ (r & (NCH - 1))) << 4));
+            const bf16x8 pf = *reinterpret_cast<const bf16x8*>(pb + foff[ks]);
             G = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, qv[ks], G, 0, 0, 0);
         }
         return G;
     };
+    // wave w's band at step it = position blocks (it - w - 1) [lower, carried] and (it - w) [upper, new]
+    int pslot_new = (0 - wave + PRING * 4) % PRING;
+    if (REL && nkt > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        Gc = gtile((0 - wave - 1 + PRING * 4) % PRING);
+    }
+    const float sc2 = p.scale * 1.4426950408889634f;
 
     for (int it = 0; it < nkt; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
         if (it + 1 < nkt) issue_step(it + 1);
+        pslot_dma = pslot_dma + 1 == PRING ? 0 : pslot_dma + 1;
         const int j0 = 32 * it;
         // ---- S^T = K_tile · (Q+u)^T
         f32x16 S;
 #pragma unroll
         for (int e = 0; e < 16; ++e) S[e] = 0.f;
         {
-            const char* kb = sK + (it & 1) * TILEB + r * ROWB;
+            const char* kb = sK + (it & 1) * TILEB;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + (((ks * 2 + h2) ^ (r & (NCH - 1))) << 4));
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + foff[ks]);
                 S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qu[ks], S, 0, 0, 0);
             }
         }
         if (REL) {
-            // wave w's band at step it = position blocks (it - w - 1) [lower, carried] and (it - w) [upper, new]
-            if (it == 0) Gc = gtile(it - wave - 1);
-            const f32x16 Gn = gtile(it - wave);
+            const f32x16 Gn = gtile(pslot_new);
+            pslot_new = pslot_new + 1 == PRING ? 0 : pslot_new + 1;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 skew[r * SKEW_LD + crow(e, h2)] = Gc[e];
@@ -321,85 +377,114 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
-        // ---- scale, mask, online softmax (lane = query)
+        // ---- scale (into the exp2 domain), mask, online softmax (lane = query).  Masks only on tiles that touch the key length or the causal diagonal (wave-uniform).
+        const bool edge = (j0 + 32 > len) || (p.causal && j0 + 31 > i0 + coff);
         float mx = -1e30f;
+        if (edge) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int jj = j0 + crow(e, h2);
-            const bool dead = (jj >= len) || (p.causal && jj > i0 + r + coff);
-            S[e] = dead ? -INFINITY : S[e] * p.scale;
-            mx = fmaxf(mx, S[e]);
+            for (int e = 0; e < 16; ++e) {
+                const int jj = j0 + crow(e, h2);
+                const bool dead = (jj >= len) || (p.causal && jj > i0 + r + coff);
+                S[e] = dead ? -INFINITY : S[e] * sc2;
+                mx = fmaxf(mx, S[e]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                S[e] *= sc2;
+                mx = fmaxf(mx, S[e]);
+            }
         }
         mx = half_swap_max(mx);
-        const float mnew = fmaxf(m, mx);
-        const float alpha = __expf(m - mnew);
+        // Lazy rescale: the running maximum is a reference point, not a value — any m with S - m bounded gives the same quotient O / l.  It moves (and O, l are rescaled:
+        // 64 accumulator registers) only when some query's maximum grew by more than 2^11; otherwise p = 2^(S - m) <= 2^11 with the stale m, exact in fp32 / bf16 range.
+        if (__builtin_amdgcn_ballot_w64(mx > m + 11.f) != 0) {
+            const float mnew = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+            l *= alpha;
+            m = mnew;
+#pragma unroll
+            for (int t = 0; t < NTO; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) O[t][e] *= alpha;
+        }
         float ls = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            S[e] = __expf(S[e] - mnew);
+            S[e] = __builtin_amdgcn_exp2f(S[e] - m);
             ls += S[e];
         }
-        ls = half_swap_sum(ls);
-        l = l * alpha + ls;
-        m = mnew;
-#pragma unroll
-        for (int t = 0; t < NTO; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) O[t][e] *= alpha;
+        l += half_swap_sum(ls);
         bf16x8 pb[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pb[s][j] = f2bf(S[8 * s + j]);
-        // ---- O^T += V^T · P^T ; V^T fragments by transposed LDS reads of the [key][hd] tile
+            for (int j = 0; j < 8; ++j) pb[s2][j] = f2bf(S[8 * s2 + j]);
+        // ---- O^T += V^T · P^T ; V^T fragments by transposed LDS reads of the [key][hd] tile.
+        // The reads are issued as inline asm with their own lgkmcnt waits: through the builtin the compiler cannot tell them from the LDS-DMA destinations of step
+        // it + 1 (issued at the top of this step) and puts `s_waitcnt vmcnt(0)` in front of them — the prefetch then has to land within ~60 % of a step.
         {
-            const char* vb = sV + (it & 1) * TILEB;
-            const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const unsigned vb = (unsigned)(size_t)(sV + (it & 1) * TILEB);          // LDS byte address (addrspace(3) pointers are 32-bit offsets)
+            s16x4 lo[NTO][2], hi[NTO][2];
+#pragma unroll
+            for (int t = 0; t < NTO; ++t)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[t][s2]) : "v"(vb + voff[t][0]), "n"(s2 * 16 * ROWB) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[t][s2]) : "v"(vb + voff[t][1]), "n"(s2 * 16 * ROWB) : "memory");
+                }
 #pragma unroll
             for (int t = 0; t < NTO; ++t) {
-                const int col = t * 32 + (g & 1) * 16 + 4 * p4;             // hd column of this lane's 4 elements
-                const int lc = col >> 3, within = (col & 7) * 2;
+                // tile t's four reads are the oldest outstanding: 4 * (NTO - 1 - t) younger ones may still be in flight
+                if (t == NTO - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                else if (t == NTO - 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                else if (t == NTO - 3) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    typedef short s16x4 __attribute__((ext_vector_type(4)));
-                    s16x4 lo, hi;
-                    {
-                        const int krow = 16 * s + 4 * (g >> 1) + q4;
-                        const char* a = vb + krow * ROWB + ((lc ^ (krow & (NCH - 1))) << 4) + within;
-                        lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
-                    }
-                    {
-                        const int krow = 16 * s + 8 + 4 * (g >> 1) + q4;
-                        const char* a = vb + krow * ROWB + ((lc ^ (krow & (NCH - 1))) << 4) + within;
-                        hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
-                    }
-                    typedef short s16x8 __attribute__((ext_vector_type(8)));
-                    const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pb[s], O[t], 0, 0, 0);
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    // the asm outputs are only valid after the wait above: keep the compiler from reading them earlier
+                    asm volatile("" : "+v"(lo[t][s2]), "+v"(hi[t][s2]));
+                    const s16x8 v8 = {lo[t][s2][0], lo[t][s2][1], lo[t][s2][2], lo[t][s2][3], hi[t][s2][0], hi[t][s2][1], hi[t][s2][2], hi[t][s2][3]};
+                    O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pb[s2], O[t], 0, 0, 0);
                 }
             }
         }
     }
 
-    if (i0 + r < T) {
+    // ---- epilogue: a lane owns a query ROW of O (hd values spread over its accumulators); row-per-lane global stores touch 64 lines per instruction and are
+    // store-issue-bound.  Rows go through the wave's scratch instead and leave as whole 16-B-per-lane rows (64 lanes = 1 KiB = 4 or 8 complete rows per store).
+    {
         const float inv = 1.f / l;
-        bf16_t* op = p.out + ((long)b * T + i0 + r) * p.ldo + head * HD;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int t = 0; t < NTO; ++t)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int c = t * 32 + 8 * g4 + 4 * h2;
-                bf16x4 o = {f2bf(O[t][4 * g4 + 0] * inv), f2bf(O[t][4 * g4 + 1] * inv),
-                            f2bf(O[t][4 * g4 + 2] * inv), f2bf(O[t][4 * g4 + 3] * inv)};
-                *reinterpret_cast<bf16x4*>(op + c) = o;
+                const bf16x4 o = {f2bf(O[t][4 * g4 + 0] * inv), f2bf(O[t][4 * g4 + 1] * inv), f2bf(O[t][4 * g4 + 2] * inv), f2bf(O[t][4 * g4 + 3] * inv)};
+                *reinterpret_cast<bf16x4*>(wscr + r * OST_B + c * 2) = o;
             }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        constexpr int LPR = ROWB / 16, RPI = 64 / LPR;       // lanes per row, rows per store instruction
+        const int orow = lane / LPR, och = lane % LPR;
+#pragma unroll
+        for (int q = 0; q < 32 / RPI; ++q) {
+            const int row = q * RPI + orow;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(wscr + row * OST_B + och * 16);
+            if (i0 + row < T) *reinterpret_cast<bf16x8*>(p.out + ((long)b * T + i0 + row) * p.ldo + head * HD + och * 8) = v;
+        }
     }
 }
 
 template <int HD>
 int launch_lds(const AttnArgs& a, bool rel, hipStream_t stream) {
     dim3 grid(cdiv(a.T, 128), a.H, a.B), block(256);
-    const size_t lds = (size_t)(2 + 2 + 6) * 32 * HD * 2 + 4 * 32 * SKEW_LD * sizeof(float);
+    const size_t lds = (size_t)(2 + 2 + 6) * 32 * HD * 2 + 4 * WSCR_B;
     if (rel) hipLaunchKernelGGL((attn_lds_kernel<HD, true>), grid, block, lds, stream, a);
     else hipLaunchKernelGGL((attn_lds_kernel<HD, false>), grid, block, lds, stream, a);
     MI_CHECK_LAUNCH();
@@ -448,7 +533,9 @@ extern "C" int mi_attention_qkv_bf16(const void* q, long ldq, const void* k, lon
     MI_ENTER();
     if (B <= 0 || T <= 0 || H <= 0 || Tk < 0) return MI_ERR_ARG;
     if (pos && Tk != 0 && Tk != T) return MI_ERR_ARG;                    // the relative term needs a square score matrix
-    if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 4)) return MI_ERR_ARG;
+    if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 8) || ((uintptr_t)out & 15)) return MI_ERR_ARG;                 // 16-B row stores
+    if (ldq >= (1l << 30)) return MI_ERR_ARG;
+    if (ldk <= 0 || ldv <= 0 || ldk >= (1l << 30) || ldv >= (1l << 30) || ldp >= (1l << 30)) return MI_ERR_ARG;      // the kernel keeps row strides as 32-bit byte counts
     if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) || (kv_bstride % 8)) return MI_ERR_ARG;
     if (pos && ((ldp % 8) || ((uintptr_t)pos & 15) || !bias_u || !bias_v)) return MI_ERR_ARG;
     AttnArgs a{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, 0, (const bf16_t*)pos, ldp,
