@@ -31,6 +31,13 @@ struct AttnArgs {
     long kv_bstride;                     // elements between consecutive batches of k / v (0 = Tk * ld): KV caches
 };
 
+// 16-B chunk swizzle of the LDS-staged kernel's tiles (applied on the DMA source and on every read).  256-B rows (hd 128): the image that is conflict-free for ds_read_b128
+// row reads (K, position rows, Q) AND for the transposed reads of V (CDNA guide, "one image for row reads and transposed reads", image (b)); chunk ^ (row & 15) leaves the
+// transposed read 4-way (four consecutive rows of a 32-lane half all start on bank 0 and stay inside one 64-B group).  128-B rows (hd 64): chunk ^ (row & 7).
+template <int CH>
+__device__ __forceinline__ int tswz(int row) {
+    return CH == 16 ? (((row & 3) << 2) | ((row >> 2) & 3)) : (row & (CH - 1));
+}
 constexpr int SKEW_LD = 66;   // words per query row of the skew scratch: reads conflict-free, writes 2-way (free)
 constexpr int OST_B = 272;    // LDS-staged kernel, output staging: bytes per query row (hd 128 -> 256 B + 16: rows stay 16-B aligned for ds_read_b128, writes 2-way)
 constexpr int WSCR_B = 32 * OST_B;   // per-wave scratch of the LDS-staged kernel: skew rows (32 x 66 words) | Q tile (8 KiB, prologue) | output rows (epilogue)
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 //  * V needs no transposed copy in HBM: the PV product's A operand (V^T) is read with ds_read_b64_tr_b16.
 //  * BD band reuse: for a wave the band of step t is [rb, rb+64); its upper half is the lower half of step t+1, so only
 //    ONE new 32-row G tile (8 MFMAs at hd=128) is computed per step and the other is carried in registers.
-//  * LDS images are lane-linear per DMA piece; the 16-B-chunk XOR swizzle (chunk ^ (row & (chunks-1))) is applied to the
+//  * LDS images are lane-linear per DMA piece; the 16-B-chunk XOR swizzle (tswz) is applied to the
 //    source address and to every read (conflict-free ds_read_b128 / tr reads).
 template <int HD, bool REL>
 __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
         const int row = (wave * PPW + q) * RPP + prow;        // 0..31
-        const int colb = (head * HD + (pc ^ (row & (NCH - 1))) * 8) * 2;
+        const int colb = (head * HD + (pc ^ tswz<NCH>(row)) * 8) * 2;
         prw[q] = row;
         kB[q] = reinterpret_cast<const char*>(p.k + (p.kv_bstride ? kvoff : (long)b * Tk * p.ldk)) + colb;
         vB[q] = reinterpret_cast<const char*>(p.vt + (p.kv_bstride ? kvoff : (long)b * Tk * p.ldvt)) + colb;       // p.vt = V [key][hd]
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
 #pragma unroll
         for (int piece = 0; piece < PIECES; ++piece) {
             const int row = piece * RPP + prow;
-            const int colb = (head * HD + (pc ^ (row & (NCH - 1))) * 8) * 2;
+            const int colb = (head * HD + (pc ^ tswz<NCH>(row)) * 8) * 2;
             const char* src = qb + (unsigned long)(unsigned)min(i0 + row, T - 1) * ldqB + colb;
             __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)src,
                                              (__attribute__((address_space(3))) void*)(wscr + piece * 1024), 16, 0, 0);
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int c = head * HD + ks * 16 + h2 * 8;
-        const bf16x8 raw = *reinterpret_cast<const bf16x8*>(wscr + r * ROWB + (((ks * 2 + h2) ^ (r & (NCH - 1))) << 4));
+        const bf16x8 raw = *reinterpret_cast<const bf16x8*>(wscr + r * ROWB + (((ks * 2 + h2) ^ tswz<NCH>(r)) << 4));
         if (REL) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
     // per-lane LDS offsets that do not change from step to step: K / P fragment rows, V^T transposed-read addresses
     int foff[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) foff[ks] = r * ROWB + (((ks * 2 + h2) ^ (r & (NCH - 1))) << 4);
+    for (int ks = 0; ks < KS; ++ks) foff[ks] = r * ROWB + (((ks * 2 + h2) ^ tswz<NCH>(r)) << 4);
     int voff[NTO][2];
     {
         const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
             for (int hi = 0; hi < 2; ++hi) {
                 const int col = t * 32 + (g & 1) * 16 + 4 * p4;             // hd column of this lane's 4 elements
                 const int krow = 8 * hi + 4 * (g >> 1) + q4;                // key row within a 16-key half (the half adds 16 rows: a multiple of NCH, the swizzle is unchanged)
-                voff[t][hi] = krow * ROWB + (((col >> 3) ^ (krow & (NCH - 1))) << 4) + (col & 7) * 2;
+                voff[t][hi] = krow * ROWB + (((col >> 3) ^ tswz<NCH>(krow)) << 4) + (col & 7) * 2;
             }
     }
 

@@ -36,15 +36,22 @@ struct TnArgs {
     int M, N, K, n_store, splits, rows_per_split;
 };
 
-template <int ROWB>                                       // bytes per tile row (256: 128 columns, 128: 64 columns); 16-B chunk index XOR (row & (chunks - 1))
+// 16-B chunk swizzle of a tile row.  256-B rows (16 chunks): chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)) — the transposed read's 32-lane half takes 4 consecutive rows x
+// 64 B, and on 256-B rows every row starts on bank 0: the row's low two bits must move the 64-B group, or the four rows collide (4-way: what `chunk ^ (row & 15)`, the
+// swizzle for ds_read_b128 row reads, leaves; CDNA guide, "one image for row reads and transposed reads", image (b)).  128-B rows (A/B variant): chunk ^ (row & 7).
+template <int CH>
+__device__ __forceinline__ int swz(int row) {
+    return CH == 16 ? (((row & 3) << 2) | ((row >> 2) & 3)) : (row & (CH - 1));
+}
+
+template <int ROWB>                                       // bytes per tile row (256: 128 columns, 128: 64 columns)
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int cb, int s, int lane) {
-    constexpr int CM = ROWB / 16 - 1;
     const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
     const int col = cb + (g & 1) * 16 + 4 * p4;
     const int lc = col >> 3, within = (col & 7) * 2;
     const int k0 = 16 * s + 4 * (g >> 1) + q4, k1 = k0 + 8;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + k0 * ROWB + ((lc ^ (k0 & CM)) << 4) + within));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + k1 * ROWB + ((lc ^ (k1 & CM)) << 4) + within));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + k0 * ROWB + ((lc ^ swz<ROWB / 16>(k0)) << 4) + within));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + k1 * ROWB + ((lc ^ swz<ROWB / 16>(k1)) << 4) + within));
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
 }
@@ -75,12 +82,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
         const bool isY = g < YP;
         if (isY) {
             const int row = g * 4 + (lane >> 4), cs = lane & 15;
-            const int c = cs ^ (row & 15);                   // source chunk for LDS slot cs
+            const int c = cs ^ swz<16>(row);                 // source chunk for LDS slot cs
             rowin[q] = row; colok[q] = n0 + c * 8 < p.N; src[q] = p.Y + n0 + c * 8;
         } else {
             constexpr int RPP = 1024 / XB;                   // rows per piece
             const int row = (g - YP) * RPP + lane / XCH, cs = lane % XCH;
-            const int c = cs ^ (row & (XCH - 1));
+            const int c = cs ^ swz<XCH>(row);
             rowin[q] = row; colok[q] = k0 + c * 8 < p.K; src[q] = p.X + k0 + c * 8;
         }
     }
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
 #pragma unroll 8
             for (int r = 0; r < 32; ++r) {
                 const int m = bh * 32 + r;
-                bsum += bf2f(*reinterpret_cast<const bf16_t*>(ty + m * 256 + (((bn >> 3) ^ (m & 15)) << 4) + (bn & 7) * 2));
+                bsum += bf2f(*reinterpret_cast<const bf16_t*>(ty + m * 256 + (((bn >> 3) ^ swz<16>(m)) << 4) + (bn & 7) * 2));
             }
         }
 #pragma unroll
