@@ -172,14 +172,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
                                                       int rows_per_wave) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const dgamma = partial;                       // non-null: this block's (2d) partial row goes to partial[blockIdx.x]
-    float* sg = reinterpret_cast<float*>(smem);          // [d] dgamma partial, [d] dbeta partial
-    float* sb = sg + d;
+    float* sg = reinterpret_cast<float*>(smem);          // [4 waves][2d]: every wave's (dgamma | dbeta) partial, summed in wave order below (no atomics: deterministic,
+                                                         // and a float atomic add on LDS is a compare-and-swap loop in this build)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int d4 = d >> 2;
-    if (dgamma) {
-        for (int i = threadIdx.x; i < 2 * d; i += 256) sg[i] = 0.f;
-        __syncthreads();
-    }
     f32x4 gm[NV], ag[NV], ab[NV];
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -254,17 +250,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
         if (two) do_row(r1, xb, gb, ob);
     }
     if (dgamma) {
+        float* mine = sg + (size_t)wave * 2 * d;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int c = lane + 64 * j;
             if (c < d4) {
-                atomicAdd(sg + 4 * c, ag[j].x); atomicAdd(sg + 4 * c + 1, ag[j].y); atomicAdd(sg + 4 * c + 2, ag[j].z); atomicAdd(sg + 4 * c + 3, ag[j].w);
-                atomicAdd(sb + 4 * c, ab[j].x); atomicAdd(sb + 4 * c + 1, ab[j].y); atomicAdd(sb + 4 * c + 2, ab[j].z); atomicAdd(sb + 4 * c + 3, ab[j].w);
+                reinterpret_cast<f32x4*>(mine)[c] = ag[j];
+                reinterpret_cast<f32x4*>(mine + d)[c] = ab[j];
             }
         }
         __syncthreads();
         float* prow = partial + (long)blockIdx.x * 2 * d;
-        for (int c = threadIdx.x; c < 2 * d; c += 256) prow[c] = sg[c];
+        for (int c = threadIdx.x; c < 2 * d; c += 256) prow[c] = (sg[c] + sg[2 * d + c]) + (sg[4 * d + c] + sg[6 * d + c]);
     }
 }
 
@@ -608,9 +605,9 @@ extern "C" int mi_layernorm_bwd(const void* x, long ldx, int x_bf16, const float
         (reinterpret_cast<uintptr_t>(dx) & (dx_bf16 ? 7 : 15))) return MI_ERR_ARG;
     if (dgamma && (!dbeta || !workspace)) return MI_ERR_ARG;
     int grid = cdiv(M, 4);
-    if (grid > 512) grid = 512;                         // two blocks per CU; each wave walks rows wave_id, wave_id + nwaves, ...
+    if (grid > 512) grid = 512;                         // two blocks per CU; each wave walks rows wave_id, wave_id + nwaves, ... (256 / 1024 / 2048 blocks measured slower)
     const int rpw = cdiv(M, (long)grid * 4);
-    const size_t lds = (size_t)2 * d * sizeof(float);
+    const size_t lds = (size_t)4 * 2 * d * sizeof(float);
     const int nv = cdiv(d, 256);
     float* partial = dgamma ? workspace : nullptr;
 #define LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(grid), dim3(256), lds, st, x, ldx, x_bf16, gamma, eps, dy, lddy, dy_f32, dx, lddx, dx_bf16, accumulate, partial, M, d, rpw)
