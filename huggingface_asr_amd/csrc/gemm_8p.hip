@@ -114,8 +114,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
     }
     auto stageA = [&](int kt, unsigned buf, int mq) {
         if constexpr (CONV) {
-            const int k0 = kt * BK;
-            const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
+            const int ntap = p.K / p.Cin;
+            const int chunk = kt / ntap, tap = kt - chunk * ntap, c0 = chunk * BK;      // K tiles in channel-slice-major order (see conv_k)
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -130,10 +130,15 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
                 __builtin_amdgcn_global_load_lds((gptr_t)(c.A + c.offA[mq][e] + (unsigned)kt * 128u), (lptr_t)(smem + buf + c.dA[mq][e]), 16, 0, 0);
         }
     };
+    // CONV: the K tiles are visited 64-channel slice by slice, the KH*KW (= K / Cin) taps of a slice back to back (k offset = tap * Cin + slice * 64; the sum over K does not care
+    // about the order).  The taps of one slice re-read the same input patch (13 output rows x 19 columns of a tile touch 27 x 39 input positions = 135 KB per slice):
+    // consecutive K tiles keep it in L2.  Tap-major order re-read the whole 540-KB patch of every tile 2.2x from beyond L2 (PMC: 690 MB fetched per launch for a 320-MB input).
+    auto conv_k = [&](int kt) { const int ntap = p.K / p.Cin; const int chunk = kt / ntap; return (kt - chunk * ntap) * p.Cin + chunk * BK; };
     auto stageB = [&](int kt, unsigned buf, int nq) {
+        const unsigned kb = CONV ? (unsigned)conv_k(kt) * 2u : (unsigned)kt * 128u;
 #pragma unroll
         for (int e = 0; e < 2; ++e)
-            __builtin_amdgcn_global_load_lds((gptr_t)(c.W + c.offB[nq][e] + (unsigned)kt * 128u), (lptr_t)(smem + buf + c.dB[nq][e]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(c.W + c.offB[nq][e] + kb), (lptr_t)(smem + buf + c.dB[nq][e]), 16, 0, 0);
     };
 
     f32x4 acc[8][4];
