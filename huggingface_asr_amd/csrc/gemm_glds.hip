@@ -78,13 +78,14 @@ __device__ __forceinline__ void gemm_glds_tile(const GemmArgs& p, int bid, char*
     }
     auto issue = [&](int kt, int stage) {
         char* sbase = smem + stage * STG + wave * PPW * 1024;
-        int kh = 0, kw = 0, c0 = 0;
-        if (CONV) {                                        // Cin % 64 == 0: one tap per K tile
-            const int k0 = kt * BK;
-            const int tap = k0 / p.Cin;
-            c0 = k0 - tap * p.Cin;
+        int kh = 0, kw = 0, c0 = 0, kofs = kt * BK;
+        if (CONV) {                                        // Cin % 64 == 0: one tap per K tile; tiles visited 64-channel slice by slice, as gemm8p_kernel does (same
+            const int ntap = p.K / p.Cin;                  // accumulation order in both kernels: a batch of one and a batch of 32 give the same bits)
+            const int chunk = kt / ntap, tap = kt - chunk * ntap;
+            c0 = chunk * BK;
             kh = tap / p.KW;
             kw = tap - kh * p.KW;
+            kofs = tap * p.Cin + c0;
         }
 #pragma unroll
         for (int q = 0; q < PPW; ++q) {
@@ -95,7 +96,7 @@ __device__ __forceinline__ void gemm_glds_tile(const GemmArgs& p, int bid, char*
                 const bool ok = ti >= 0 && ti < p.Tin && fi >= 0 && fi < p.Fin;
                 sp = ok ? src[q] + ((long)ti * p.Fin + fi) * p.Cin + c0 + c_lc[q] : reinterpret_cast<const bf16_t*>(&g_zero_page);
             } else {
-                sp = src[q] + kt * BK;
+                sp = src[q] + kofs;
             }
             __builtin_amdgcn_global_load_lds((gptr_t)sp, (lptr_t)(sbase + q * 1024), 16, 0, 0);
         }
