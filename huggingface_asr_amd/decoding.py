@@ -37,9 +37,10 @@ class CTCRescorerLogitsProcessor(LogitsProcessor):
         super().__init__()
         if not encoder_logits.is_cuda:
             raise RuntimeError("CTCRescorerLogitsProcessor (HIP) needs device tensors; there is no CPU fallback")
-        if ctc_margin and ctc_margin > 0:
-            raise NotImplementedError("ctc_margin > 0 needs attention weights, which HF generate never passes to processors "
-                                      "(the reference's windowing branch is unreachable from __call__, ctc_scorer.py:330)")
+        # ctc_margin > 0 is accepted and — exactly as in the reference — changes nothing: the windowing branch of CTCPrefixScoreTH.__call__ (ctc_scorer.py:127-132) needs
+        # `att_w`, and the processor never passes it (`self.ctc_prefix_scorer(input_ids, self.ctc_states)`, ctc_scorer.py:330), so the scan always covers
+        # [max(output_length, 1), input_length): the same scores for every margin.  tests/test_gpu_decoding.py pins that against the reference fixture.
+        self.ctc_margin = int(ctc_margin or 0)
         self.pad_token_id, self.eos_token_id = pad_token_id, eos_token_id
         self.ctc_weight, self.num_beams = ctc_weight, num_beams
         self.space_token_id, self.apply_eos_space_trick = space_token_id, apply_eos_space_trick

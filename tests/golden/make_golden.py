@@ -667,16 +667,17 @@ def run_ctc_prefix_cases():
             return out
 
     rec = {}
-    for case, (B, W, T, O, lens, trick) in {"a": (2, 3, 40, 30, [40, 33], False), "b": (1, 5, 75, 51, [75], True),
-                                            "c": (3, 2, 24, 17, [20, 24, 9], False)}.items():
+    # case "m" = case "a" with ctc_margin 6: the reference's processor never hands attention weights to the scorer (ctc_scorer.py:330), so the margin changes nothing
+    for case, (B, W, T, O, lens, trick, margin) in {"a": (2, 3, 40, 30, [40, 33], False, 0), "b": (1, 5, 75, 51, [75], True, 0),
+                                                    "c": (3, 2, 24, 17, [20, 24, 9], False, 0), "m": (2, 3, 40, 30, [40, 33], False, 6)}.items():
         g = torch.Generator().manual_seed(7)
         enc_logits = torch.randn(B, T, O, generator=g) * 2.0
         blank, eos, space = O - 1, 1, 5
-        proc = CTCRescorerLogitsProcessor(enc_logits.clone(), torch.tensor(lens), blank, eos, 0, 0.3, W, space, trick, 0.8)
+        proc = CTCRescorerLogitsProcessor(enc_logits.clone(), torch.tensor(lens), blank, eos, margin, 0.3, W, space, trick, 0.8)
         proc.ctc_prefix_scorer.__class__ = Recorder
         ids = torch.zeros((B * W, 1), dtype=torch.long) + 2                      # start token
         rec[f"{case}/enc_logits"] = enc_logits.numpy(); rec[f"{case}/lens"] = np.array(lens)
-        rec[f"{case}/meta"] = np.array([B, W, T, O, blank, eos, space, int(trick)])
+        rec[f"{case}/meta"] = np.array([B, W, T, O, blank, eos, space, int(trick), margin])
         for step in range(4):
             att = torch.log_softmax(torch.randn(B * W, O, generator=g) * 1.5, -1)
             if trick and step == 2:

@@ -10,13 +10,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("case", ["a", "b", "c"])
+@pytest.mark.parametrize("case", ["a", "b", "c", "m"])
 def test_ctc_rescorer_matches_reference(case):
     from huggingface_asr_amd.decoding import CTCRescorerLogitsProcessor, LogSoftmaxProcessor
     g = load_golden("ctc_prefix")
-    B, W, T, O, blank, eos, space, trick = [int(v) for v in g[f"{case}/meta"]]
+    B, W, T, O, blank, eos, space, trick, margin = [int(v) for v in g[f"{case}/meta"]]          # case "m": ctc_margin 6 (a no-op in the reference, and here)
     proc = CTCRescorerLogitsProcessor(torch.from_numpy(g[f"{case}/enc_logits"]).to(DEV), torch.from_numpy(g[f"{case}/lens"]).to(DEV),
-                                      blank, eos, 0, 0.3, W, space, bool(trick), 0.8)
+                                      blank, eos, margin, 0.3, W, space, bool(trick), 0.8)
     for step in range(4):
         ids = torch.from_numpy(g[f"{case}/step{step}/input_ids"]).to(DEV)
         att = torch.from_numpy(g[f"{case}/step{step}/att"]).to(DEV)
