@@ -209,8 +209,6 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
     };
     using T = std::true_type;
     using F = std::false_type;
-    auto I = [](auto v) { return v; };
-    (void)I;
 
     const int nk = p.K / BK;
     // prologue: Ha0(0) Hb0(0) Hb1(0) Ha1(0) Ha0(1) Hb0(1) — the steady-state order
