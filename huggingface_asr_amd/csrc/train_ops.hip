@@ -301,6 +301,15 @@ __global__ __launch_bounds__(256) void add_f32_kernel(float* __restrict__ a, con
 __global__ __launch_bounds__(256) void scale_f32_kernel(float* __restrict__ a, long n, float alpha) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a[i] *= alpha;
 }
+// a *= *alpha with alpha on the device; nothing is read or written when it is exactly 1 (the d(loss) that `loss.backward()` seeds: the HF route's common case)
+__global__ __launch_bounds__(256) void scale_dev_f32_kernel(float* __restrict__ a, long n, const float* __restrict__ alpha) {
+    const float s = *alpha;
+    if (s == 1.f) return;
+    const long n4 = n >> 2;
+    f32x4* a4 = reinterpret_cast<f32x4*>(a);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) a4[i] *= s;
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a[i] *= s;
+}
 // out = bf16(alpha * (a [+ b])) on (M,N) views
 __global__ __launch_bounds__(256) void add2_cast_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
                                                          bf16_t* __restrict__ out, long ldo, int M, int N, float alpha) {
@@ -641,6 +650,13 @@ extern "C" int mi_scale_f32(float* a, long n, float alpha, hipStream_t st) {
     MI_ENTER();
     if (n <= 0) return MI_ERR_ARG;
     hipLaunchKernelGGL(scale_f32_kernel, dim3(grid_for(n)), dim3(256), 0, st, a, n, alpha);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+extern "C" int mi_scale_dev_f32(float* a, long n, const float* alpha_dev, hipStream_t st) {
+    MI_ENTER();
+    if (n <= 0 || !alpha_dev || (reinterpret_cast<uintptr_t>(a) & 15)) return MI_ERR_ARG;
+    hipLaunchKernelGGL(scale_dev_f32_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, st, a, n, alpha_dev);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

@@ -103,6 +103,13 @@ def scale_(a, alpha):
     _lib.check(_L().mi_scale_f32(a.data_ptr(), a.numel(), float(alpha), _stream()), "mi_scale_f32")
 
 
+def scale_by_device_scalar_(a, alpha):
+    """a *= alpha for a one-element f32 device tensor `alpha`, without a host sync; costs a launch and nothing else when alpha == 1."""
+    assert a.is_contiguous() and a.dtype == F32 and alpha.numel() == 1
+    al = alpha.detach().reshape(1).to(device=a.device, dtype=F32)
+    _lib.check(_L().mi_scale_dev_f32(a.data_ptr(), a.numel(), al.data_ptr(), _stream()), "mi_scale_dev_f32")
+
+
 def add_cast(a, b=None, alpha=1.0, out=None):
     """bf16(alpha * (a [+ b])) for f32 (M,N) views."""
     M, N = a.shape

@@ -180,6 +180,8 @@ int mi_ln_apply_bf16(const void* x, long ldx, const float* stats, const float* g
                      int M, int N, mi_stream_t stream);
 int mi_axpy_f32(float* a, const float* b, long n, float alpha, mi_stream_t stream);
 int mi_scale_f32(float* a, long n, float alpha, mi_stream_t stream);
+/* a *= *alpha_dev (a device scalar; a 16-B aligned); a no-op launch when it is exactly 1: the autograd bridge's d(loss) factor (autograd_bridge.py) */
+int mi_scale_dev_f32(float* a, long n, const float* alpha_dev, mi_stream_t stream);
 int mi_add2_cast_bf16(const float* a, long lda, const float* b, long ldb, void* out, long ldo, int M, int N, float alpha,
                       mi_stream_t stream);
 int mi_add_rowvec_bf16(const void* x, long ldx, const float* vec, void* out, long ldo, int M, int N, mi_stream_t stream);

@@ -266,6 +266,17 @@ def test_causal_dilated_csgu_bwd(B, Tt, Cc):
     assert float(dw.cpu()[:, ~seen].abs().max() if (~seen).any() else 0.0) == 0.0
 
 
+def test_scale_by_device_scalar():
+    """the autograd bridge's d(loss) factor: a device scalar, no host sync; exactly 1 leaves the buffer untouched, anything else scales it (odd length: the scalar tail)"""
+    ops, T = _o()
+    a = rnd(4099, seed=21).to(DEV)
+    keep = a.clone()
+    T.scale_by_device_scalar_(a, torch.ones((), device=DEV))
+    assert torch.equal(a, keep)
+    T.scale_by_device_scalar_(a, torch.tensor(0.25, device=DEV))
+    assert torch.equal(a, keep * 0.25)
+
+
 def test_conv_frontend_bwd():
     ops, T = _o()
     B, Tt, Fq, C1, K, s, pad = 2, 61, 40, 32, 3, 2, 1
