@@ -48,6 +48,7 @@ class _Bridge:
         self.adopted_ptrs = None
         self.outputs = None
         self._saved = None
+        self.mirrors_fresh = False                          # set by optim.StoreAdamW: its step already wrote the bf16 mirrors and the transposes
 
     # ------------------------------------------------------------------ zero-copy parameters
     def _adopt(self):
@@ -82,8 +83,10 @@ class _Bridge:
             pd = dict(self.named)
             for n in self.copy_names:
                 tr.import_piece(n, pd[n])
-            for st in tr.stores():                          # the optimizer wrote the fp32 masters in place: bf16 mirrors + K-major transposes follow
-                st.refresh_mirrors(cast=True)
+            if not self.mirrors_fresh:
+                for st in tr.stores():                      # torch's optimizer wrote the fp32 masters in place: bf16 mirrors + K-major transposes follow
+                    st.refresh_mirrors(cast=True)
+            self.mirrors_fresh = False
         # gradient accumulation in progress?  (.grad of an adopted parameter still aliases the flat gradient store the step is about to overwrite)
         self._saved = None
         bases = {st.flat_g.untyped_storage().data_ptr() for st in tr.stores()}
@@ -117,6 +120,52 @@ class _Bridge:
         else:
             views = tr.alias_views("g")
         return [copies[n] if n in copies else views.get(n) for n in self.names]
+
+
+class LabelRangeCheck:
+    """The reference raises when a label is >= vocab_size (`labels.max() >= vocab_size`, e_branchformer.py:461-462): a device -> host read per forward, i.e. a
+    full synchronisation per training step — on this route the host then never runs ahead of the GPU and the card idles ~4 ms of every 29 ms step while the
+    next step is being enqueued.  Training forwards therefore check asynchronously: the comparison is enqueued, its one-byte result copied to pinned host memory
+    behind an event, and the flag is looked at when the NEXT forward starts (if its event has completed by then; otherwise at the one after).  A bad batch
+    still raises ValueError naming the step, one forward later than the reference would; `flush()` (called by eval forwards) checks synchronously."""
+
+    def __init__(self, limit: int, what: str):
+        self.limit, self.what = int(limit), what
+        self.host = None
+        self.pending = []                                   # (event, slot, step)
+        self.step = 0
+
+    def _raise(self, step):
+        raise ValueError(f"Label values must be <= {self.what}: {self.limit} (training forward #{step}; reported asynchronously)")
+
+    def poll(self, block=False):
+        keep = []
+        for ev, slot, step in self.pending:
+            if block:
+                ev.synchronize()
+            if ev.query():
+                if bool(self.host[slot]):
+                    self.pending = []
+                    self._raise(step)
+            else:
+                keep.append((ev, slot, step))
+        self.pending = keep
+
+    def submit(self, labels: torch.Tensor):
+        self.poll()
+        if self.host is None:
+            self.host = torch.zeros(8, dtype=torch.bool).pin_memory()
+        if len(self.pending) >= 8:                          # never more than the ring holds in flight: wait for the oldest
+            self.poll(block=True)
+        slot = self.step % 8
+        self.host[slot:slot + 1].copy_((labels.max() >= self.limit).reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((ev, slot, self.step))
+        self.step += 1
+
+    def flush(self):
+        self.poll(block=True)
 
 
 def run_training_forward(model, trainer, step_fn):

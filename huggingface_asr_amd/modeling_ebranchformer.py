@@ -229,8 +229,13 @@ class Wav2Vec2EBranchformerForCTC(PreTrainedModel):
         from .autograd_bridge import run_training_forward
         if labels is None:
             raise NotImplementedError("HIP training forward needs `labels` (the CTC loss is the only differentiable output of this head)")
-        if labels.max() >= self.config.vocab_size:
-            raise ValueError(f"Label values must be <= vocab_size: {self.config.vocab_size}")
+        chk = getattr(self, "_label_check", None)
+        if chk is None:
+            from .autograd_bridge import LabelRangeCheck
+            chk = LabelRangeCheck(self.config.vocab_size, "vocab_size")
+            object.__setattr__(self, "_label_check", chk)
+        chk.submit(labels)                                 # the reference's range check (e_branchformer.py:461-462) without its per-step host sync
+        labels = labels.clamp(max=self.config.vocab_size - 1)   # a bad batch is reported one forward later: until then its labels must stay inside the logits row
         tr = self._get_trainer(input_values.device)
         feat_len = attention_mask.sum(-1).to(torch.int32) if attention_mask is not None else None
 
@@ -266,6 +271,8 @@ class Wav2Vec2EBranchformerForCTC(PreTrainedModel):
         logits = out["logits"]
         loss = None
         if labels is not None:
+            if getattr(self, "_label_check", None) is not None:
+                self._label_check.flush()                   # a bad TRAINING batch still pending: report it now
             if labels.max() >= self.config.vocab_size:      # same check / same sync point as e_branchformer.py:461-462
                 raise ValueError(f"Label values must be <= vocab_size: {self.config.vocab_size}")
             loss, _, _ = ops.ctc_loss(logits, labels.to(logits.device), out["outer_len"],

@@ -311,8 +311,19 @@ class JointCTCAttentionEncoderDecoder(PreTrainedModel):
         inputs = self._pick_inputs(inputs, input_values, input_features)
         if not inputs.is_cuda:
             raise RuntimeError("JointCTCAttentionEncoderDecoder (HIP): inputs must be on the GPU; there is no CPU fallback")
-        if labels.max() >= self.config.encoder.vocab_size:
-            raise ValueError(f"Label values must be <= vocab_size: {self.config.encoder.vocab_size}")
+        chk = getattr(self, "_label_check", None)
+        if training:                                       # the range check without a host sync per step (autograd_bridge.LabelRangeCheck): reported one forward later
+            if chk is None:
+                from .autograd_bridge import LabelRangeCheck
+                chk = LabelRangeCheck(self.config.encoder.vocab_size, "vocab_size")
+                object.__setattr__(self, "_label_check", chk)
+            chk.submit(labels)
+            labels = labels.clamp(max=self.config.encoder.vocab_size - 1)      # reported one forward later: until then the labels must stay inside the vocabulary
+        else:
+            if chk is not None:
+                chk.flush()
+            if labels.max() >= self.config.encoder.vocab_size:
+                raise ValueError(f"Label values must be <= vocab_size: {self.config.encoder.vocab_size}")
         fl = attention_mask.sum(-1).to(torch.int32) if attention_mask is not None else None
         if training:                                       # forward + backward on the HIP trainer, gradients handed to autograd
             from .autograd_bridge import run_training_forward

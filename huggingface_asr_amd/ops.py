@@ -18,8 +18,28 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+_PINNED_STREAM = None          # set by `pinned_stream()`: the training step makes ~1100 C-ABI calls, and asking torch for the current stream costs ~5 us each
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream().cuda_stream if _PINNED_STREAM is None else _PINNED_STREAM
+
+
+class pinned_stream:
+    """`with ops.pinned_stream():` — resolve torch's current stream ONCE for the body (a trainer step runs on one stream from start to end) instead of once per
+    kernel launch.  Code inside that switches streams with `torch.cuda.stream(...)` must not rely on `_stream()` following it; nesting keeps the outer value."""
+
+    def __enter__(self):
+        global _PINNED_STREAM
+        self.prev = _PINNED_STREAM
+        if _PINNED_STREAM is None:
+            _PINNED_STREAM = torch.cuda.current_stream().cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        global _PINNED_STREAM
+        _PINNED_STREAM = self.prev
+        return False
 
 
 def _req(t: torch.Tensor, dtype=None):

@@ -433,6 +433,22 @@ class EncoderCTCTrainer:
                     return fn(self.store.g(name)).clone(memory_format=torch.contiguous_format)
         raise KeyError(key)
 
+    def import_grad_piece(self, key: str, grad: torch.Tensor):
+        """the gradient of ONE (non-aliasable) reference tensor into its packed gradient slot (optim.StoreAdamW: autograd owns that `.grad`, the step reads the flat store)"""
+        for name in self.store.order:
+            if len(self.map[name][1]) == 1 and self.map[name][1][0][0] == key:
+                self.store.g(name).copy_(self.map[name][0]({key: grad.detach().to(self.device, F32)}).reshape(self.store.specs[name].shape))
+                return
+        raise KeyError(key)
+
+    def export_piece(self, key: str) -> torch.Tensor:
+        """the current master value of ONE reference tensor, in the reference layout"""
+        for name in self.store.order:
+            for k, fn in self.map[name][1]:
+                if k == key:
+                    return fn(self.store.p(name)).clone(memory_format=torch.contiguous_format)
+        raise KeyError(key)
+
     def set_frozen(self, reference_names):
         """Names (reference state-dict keys) of parameters that do not train (`requires_grad False`: `freeze_encoder()`, train_ctc_asr.py:51-52).
         A packed store parameter counts as frozen when all of its reference pieces are; the weight / bias gradient GEMMs of frozen linears
@@ -488,8 +504,13 @@ class EncoderCTCTrainer:
         return self._pos[key]
 
     # ------------------------------------------------------------------ forward + backward
-    def forward_backward(self, feats, feat_lengths, labels, *, loss_scale=1.0, extra_hidden_grad=None, backward=True, keep_hidden=False,
-                         train_mode=False, step_index=None, noise_mask=None, skip_layers=None):
+    def forward_backward(self, *args, **kwargs):
+        """see `_forward_backward`; the whole step runs with torch's current stream resolved once (ops.pinned_stream)"""
+        with ops.pinned_stream():
+            return self._forward_backward(*args, **kwargs)
+
+    def _forward_backward(self, feats, feat_lengths, labels, *, loss_scale=1.0, extra_hidden_grad=None, backward=True, keep_hidden=False,
+                          train_mode=False, step_index=None, noise_mask=None, skip_layers=None):
         """feats (B,T,F) f32 device; feat_lengths (B) int32 or None; labels (B,U) int64 (<0 = padding).
         Returns dict(loss, logits (B,T2,V+1) f32, outer_len, last_hidden).  Gradients of loss_scale/world * loss accumulate into the store.
         `extra_hidden_grad`: optional callable(last_hidden f32 (M,d), outer_len (B) int32) -> f32 (M,d) gradient to add at the encoder output
@@ -951,6 +972,10 @@ class EncoderCTCTrainer:
     # ------------------------------------------------------------------ optimizer
     def optimizer_step(self, lr=None):
         """waits for the gradient all-reduces, clips by global norm, applies AdamW, refreshes the bf16 mirrors."""
+        with ops.pinned_stream():
+            return self._optimizer_step(lr)
+
+    def _optimizer_step(self, lr=None):
         st, hp = self.store, self.hp
         self.sync.wait()
         st.zero_frozen_grads()

@@ -205,6 +205,24 @@ class JointAEDTrainer:
                     return fn(self.store.g(name)).clone(memory_format=torch.contiguous_format)
         raise KeyError(key)
 
+    def import_grad_piece(self, key: str, grad):
+        if key.startswith("encoder."):
+            return self.enc.import_grad_piece(key[len("encoder."):], grad)
+        for name in self.store.order:
+            if len(self.map[name][1]) == 1 and self.map[name][1][0][0] == key:
+                self.store.g(name).copy_(self.map[name][0]({key: grad.detach().to(self.device, F32)}).reshape(self.store.specs[name].shape))
+                return
+        raise KeyError(key)
+
+    def export_piece(self, key: str):
+        if key.startswith("encoder."):
+            return self.enc.export_piece(key[len("encoder."):])
+        for name in self.store.order:
+            for k, fn in self.map[name][1]:
+                if k == key:
+                    return fn(self.store.p(name)).clone(memory_format=torch.contiguous_format)
+        raise KeyError(key)
+
     def stores(self):
         return [self.enc.store, self.store]
 
@@ -357,6 +375,10 @@ class JointAEDTrainer:
 
     # ------------------------------------------------------------------ step
     def forward_backward(self, feats, feat_lengths, labels):
+        with ops.pinned_stream():
+            return self._forward_backward(feats, feat_lengths, labels)
+
+    def _forward_backward(self, feats, feat_lengths, labels):
         jc = self.jcfg
         labels = labels.contiguous()
         B = feats.shape[0]
@@ -373,6 +395,10 @@ class JointAEDTrainer:
         return out
 
     def optimizer_step(self, lr=None):
+        with ops.pinned_stream():
+            return self._optimizer_step(lr)
+
+    def _optimizer_step(self, lr=None):
         hp = self.hp
         self.enc.sync.wait(); self.sync.wait()
         self.enc.store.zero_frozen_grads()          # frozen encoder parameters (set_frozen): no update, not in the clip norm

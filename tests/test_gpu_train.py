@@ -460,6 +460,85 @@ def test_hf_ctc_model_trains_through_autograd_bridge():
     assert torch.isfinite(o.loss) and all(torch.isfinite(p.grad).all() for p in dflt.parameters() if p.grad is not None)
 
 
+def test_training_label_range_check_is_asynchronous_and_still_raises():
+    """The reference's `labels.max() >= vocab_size` check is a host sync per forward; the training route reports it through pinned memory one forward later
+    (autograd_bridge.LabelRangeCheck) — no GPU fault from the out-of-range label meanwhile (clamped), ValueError at the next training forward or at the next eval one."""
+    from huggingface_asr_amd.configuration_ebranchformer import Wav2Vec2EBranchformerConfig
+    from huggingface_asr_amd.modeling_ebranchformer import Wav2Vec2EBranchformerForCTC
+    g = load_golden("grads_tiny_rel")
+    cfg = dict(shapes.TINY, ctc_zero_infinity=True, ctc_loss_reduction="mean")
+    sd, x, am, lab = case_inputs(g, cfg)
+    base = dict(shapes.TINY); base.pop("num_fbanks")
+    model = Wav2Vec2EBranchformerForCTC(Wav2Vec2EBranchformerConfig(**base, ctc_zero_infinity=True, ctc_loss_reduction="mean", **HF_NO_DROPOUT))
+    assert not any(model.load_state_dict(sd, strict=False))
+    model.to(DEV).train()
+    ok = model(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))
+    bad = lab.clone(); bad[0, 0] = cfg["vocab_size"] + 3
+    out = model(x.to(DEV), attention_mask=am.to(DEV), labels=bad.to(DEV))          # enqueued, not yet reported
+    assert torch.isfinite(out.loss)
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError):
+        model(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))
+    again = model(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))        # the report was consumed: training goes on
+    assert abs(float(again.loss) - float(ok.loss)) < 1e-4 * abs(float(ok.loss))
+    model(x.to(DEV), attention_mask=am.to(DEV), labels=bad.to(DEV))
+    model.eval()
+    with pytest.raises(ValueError), torch.no_grad():                                # an eval forward flushes what is pending
+        model(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))
+
+
+def test_store_adamw_matches_torch_adamw_on_the_hf_route():
+    """optim.StoreAdamW (the native fused clip + AdamW step behind a torch.optim.Optimizer facade, for HF Trainer's `optimizers=`) against torch's
+    `clip_grad_norm_` + AdamW with the reference trainers' parameter grouping on a twin model: same losses and parameters after four steps, the copied piece
+    (front-end `out` Linear) follows, optimizer state round-trips, and a model that is not on the zero-copy route is refused."""
+    from huggingface_asr_amd.configuration_ebranchformer import Wav2Vec2EBranchformerConfig
+    from huggingface_asr_amd.modeling_ebranchformer import Wav2Vec2EBranchformerForCTC
+    from huggingface_asr_amd.optim import StoreAdamW
+    g = load_golden("grads_tiny_rel")
+    cfg = dict(shapes.TINY, ctc_zero_infinity=True, ctc_loss_reduction="mean")
+    sd, x, am, lab = case_inputs(g, cfg)
+    base = dict(shapes.TINY); base.pop("num_fbanks")
+    mk = lambda: Wav2Vec2EBranchformerForCTC(Wav2Vec2EBranchformerConfig(**base, ctc_zero_infinity=True, ctc_loss_reduction="mean", **HF_NO_DROPOUT))
+    a, b = mk(), mk()
+    for m in (a, b):
+        assert not any(m.load_state_dict(sd, strict=False))
+        m.to(DEV).train()
+    with pytest.raises(RuntimeError):
+        StoreAdamW(mk().to(DEV), lr=1e-3).step()                         # never ran a training forward: parameters not adopted, no fallback
+    # torch side: HF Trainer's grouping (weight decay on everything but biases and LayerNorm weights: tf:trainer.py get_decay_parameter_names)
+    nodecay = lambda n, p: p.ndim == 1 or n.endswith(".bias") or "pos_bias" in n or "layer_norm" in n.lower()
+    decay = [p for n, p in b.named_parameters() if not nodecay(n, p)]
+    rest = [p for n, p in b.named_parameters() if nodecay(n, p)]
+    # eps 1e-5: elements whose gradient is pure summation noise (the key bias under softmax, far-off relative positions: |g| ~ 1e-9, float-atomic order) would
+    # otherwise take full +-lr steps in run-dependent directions and dominate the comparison
+    wd, lr, eps = 0.1, 2e-3, 1e-5
+    opt_b = torch.optim.AdamW([dict(params=decay, weight_decay=wd), dict(params=rest, weight_decay=0.0)], lr=lr, eps=eps)
+    opt_a = StoreAdamW(a, lr=lr, weight_decay=wd, eps=eps, max_grad_norm=1.0)
+    la, lb = [], []
+    for step in range(4):
+        oa = a(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV)); oa.loss.backward(); opt_a.step(); opt_a.zero_grad()
+        ob = b(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV)); ob.loss.backward()
+        torch.nn.utils.clip_grad_norm_(b.parameters(), 1.0); opt_b.step(); opt_b.zero_grad()
+        la.append(float(oa.loss)); lb.append(float(ob.loss))
+    assert la[-1] < la[0]
+    np.testing.assert_allclose(la, lb, rtol=2e-3)
+    # the UPDATES agree (relative L2 distance of the whole update vector)
+    pb = dict(b.named_parameters())
+    num = den = 0.0
+    for n, p in a.named_parameters():
+        p0 = sd[n].to(DEV).float()
+        ua, ub = p.detach().float() - p0, pb[n].detach().float() - p0
+        num += float((ua - ub).pow(2).sum()); den += float(ub.pow(2).sum())
+    assert den > 0 and (num / den) ** 0.5 < 0.01, (num / den) ** 0.5
+    assert float(opt_a.last_grad_norm) > 0
+    # checkpointing: state out, perturbed, back in
+    st = opt_a.state_dict()
+    tr = a._hip_bridge.trainer
+    m0 = tr.store.flat_m.clone(); tr.store.flat_m.zero_(); step0 = tr.store.step_count; tr.store.step_count = 0
+    opt_a.load_state_dict(st)
+    assert torch.equal(tr.store.flat_m, m0) and tr.store.step_count == step0
+
+
 def test_hf_route_parameters_and_gradients_alias_the_flat_store():
     """Round 2: after the first training forward the model's nn.Parameters ARE views of the trainer's flat fp32 master store and the
     `.grad`s autograd installs ARE views of its flat gradient store — no per-step state-dict import / gradient export; the one piece whose reference layout is

@@ -15,6 +15,7 @@ from huggingface_asr_amd.train import EncoderCTCTrainer
 ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=3); ap.add_argument("--size", default="base")
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--fused", action="store_true", help="torch.optim.AdamW(fused=True) (HF: --optim adamw_torch_fused) instead of the foreach implementation")
+ap.add_argument("--store", action="store_true", help="huggingface_asr_amd.optim.StoreAdamW (Trainer(optimizers=(opt, None)), --max_grad_norm 0): the native fused clip + AdamW step on the flat store")
 a = ap.parse_args()
 dev = "cuda:0"
 base = dict({"base": shapes.BASE, "small": shapes.SMALL, "tiny": shapes.TINY}[a.size])
@@ -45,7 +46,11 @@ hb = dict(base); hb.pop("num_fbanks", None)
 model = Wav2Vec2EBranchformerForCTC(Wav2Vec2EBranchformerConfig(**hb, ctc_zero_infinity=True, ctc_loss_reduction="mean", ebranchformer_conv_dropout=0.0, **nodrop))
 model.load_state_dict(sd, strict=False)
 model.to(dev).train()
-opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-6, fused=True if a.fused else None)   # None: torch picks its foreach implementation
+if a.store:
+    from huggingface_asr_amd.optim import StoreAdamW
+    opt = StoreAdamW(model, lr=1e-4, weight_decay=1e-6, max_grad_norm=1.0)
+else:
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-6, fused=True if a.fused else None)   # None: torch picks its foreach implementation
 parts = {}
 
 
@@ -55,7 +60,8 @@ def hf_step():
     t1 = time.perf_counter()
     out.loss.backward()
     t2 = time.perf_counter()
-    torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+    if not a.store:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
     opt.step(); opt.zero_grad()
     t3 = time.perf_counter()
     for k, v in (("host_forward_ms", t1 - t0), ("host_backward_ms", t2 - t1), ("host_clip_adamw_ms", t3 - t2)):
@@ -65,4 +71,4 @@ def hf_step():
 hf = timed(hf_step)
 n = a.steps + a.warmup
 print(json.dumps({"native_ms_per_step": round(native, 2), "hf_route_ms_per_step": round(hf, 2), "overhead_pct": round(100 * (hf / native - 1), 1),
-                  "host_side_ms": {k: round(v / n, 2) for k, v in parts.items()}, "size": a.size, "batch": B, "torch_adamw": "fused" if a.fused else "foreach"}))
+                  "host_side_ms": {k: round(v / n, 2) for k, v in parts.items()}, "size": a.size, "batch": B, "optimizer": "StoreAdamW" if a.store else "torch fused" if a.fused else "torch foreach"}))
