@@ -715,6 +715,8 @@ if __name__ == "__main__":
     if "gradscausal" in which or "grads" in which:
         # the streaming encoder: left-padded Conv2d front end, triu attention mask, the CSGU conv dilated by 15 (T' = 100 frames: 7 of its 31 taps see data)
         run_grad_case("grads_tiny_causal", TINY, seed=17, B=2, T=400, lengths=[400, 263], U=6, tgt_lens=[6, 4], is_causal=True)
+        # T' = 475 frames > the dilated conv's 450-frame reach: every one of the 31 taps of the causal CSGU conv meets data, forward and backward
+        run_grad_case("grads_tiny_causal_long", TINY, seed=20, B=1, T=1900, lengths=[1900], U=12, tgt_lens=[12], is_causal=True)
     if "gradscsgu" in which or "grads" in which:
         # the CSGU's optional pieces (no reference recipe turns them on): Linear after the conv + GELU before the gate; SiLU without the Linear
         run_grad_case("grads_tiny_csgu_linear", TINY, seed=18, B=2, T=120, lengths=[120, 88], U=4, tgt_lens=[4, 3], csgu_activation="gelu", csgu_use_linear_after_conv=True)

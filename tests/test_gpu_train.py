@@ -51,11 +51,12 @@ def _compare(grads, ref, rel=0.03, cos_min=0.999):
 
 @pytest.mark.parametrize("name,extra", [("grads_tiny_rel", {}), ("grads_tiny_rotary", {"position_embeddings_type": "rotary"}),
                                         ("grads_tiny_causal", {"is_causal": True}),
+                                        ("grads_tiny_causal_long", {"is_causal": True}),
                                         ("grads_tiny_csgu_linear", {"csgu_activation": "gelu", "csgu_use_linear_after_conv": True}),
                                         ("grads_tiny_csgu_silu", {"csgu_activation": "silu"})])
 def test_gradients_match_reference_golden(name, extra):
     """every parameter gradient of the HIP training step vs the imported reference in train() mode.  `grads_tiny_causal` = the streaming encoder
-    (left-padded front end, triu attention mask, CSGU conv dilated by 15: conv_bwd.hip's dilated kernel); `grads_tiny_csgu_*` = the CSGU's optional Linear after the
+    (left-padded front end, triu attention mask, CSGU conv dilated by 15: conv_bwd.hip's dilated kernel; `_long`: 475 encoder frames, past the conv's 450-frame reach, so all 31 taps meet data); `grads_tiny_csgu_*` = the CSGU's optional Linear after the
     conv and non-identity activations (the split conv -> [Linear] -> act * gate path)."""
     g = load_golden(name)
     cfg = dict(shapes.TINY, ctc_zero_infinity=True, ctc_loss_reduction="mean", **extra)
