@@ -726,6 +726,8 @@ if __name__ == "__main__":
         run_grad_case_strided("grads_base_rel", BASE, seed=24, B=2, T=1000, lengths=[998, 700], U=40, tgt_lens=[40, 31])
     if "base" in which:
         run_encoder_case("small_rel", SMALL, seed=21, B=2, T=1000, lengths=[998, 700], U=40, tgt_lens=[40, 31], full=False)
+        # the streaming model at a real size: causal front end, triu mask in the LDS-staged attention (head 64), the CSGU conv dilated by 15 over 250 frames
+        run_encoder_case("small_causal", SMALL, seed=25, B=2, T=1000, lengths=[998, 700], U=40, tgt_lens=[40, 31], full=False, is_causal=True)
         run_encoder_case("base_rel", BASE, seed=22, B=2, T=1000, lengths=[998, 700], U=40, tgt_lens=[40, 31], full=False,
                          with_bf16=True)
         run_encoder_case("base_rotary", BASE, seed=23, B=2, T=1000, lengths=[998, 700], U=40, tgt_lens=[40, 31], full=False,

@@ -69,6 +69,7 @@ def test_tiny_vs_reference_and_oracle(name, cfg):
 
 BIG = [
     ("small_rel", _cfg(shapes.SMALL)),
+    ("small_causal", _cfg(shapes.SMALL, is_causal=True)),           # the streaming model at a real size (config 5's encoder side)
     ("base_rel", _cfg(shapes.BASE)),
     ("base_rotary", _cfg(shapes.BASE, position_embeddings_type="rotary")),
 ]
