@@ -45,6 +45,7 @@ def test_tiny_full_tensors(name, cfg):
 
 BIG_CASES = [
     ("small_rel", _cfg(shapes.SMALL)),
+    ("small_causal", _cfg(shapes.SMALL, is_causal=True)),
     ("base_rel", _cfg(shapes.BASE)),
     ("base_rotary", _cfg(shapes.BASE, position_embeddings_type="rotary")),
 ]
