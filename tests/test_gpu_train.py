@@ -618,6 +618,17 @@ def test_hf_joint_model_trains_through_autograd_bridge():
     grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
     assert set(ref) <= set(grads)
     _compare(grads, ref)
+    # optim.StoreAdamW drives BOTH flat stores of the joint trainer (encoder + decoder): the loss falls, the moments of both stores move
+    from huggingface_asr_amd.optim import StoreAdamW
+    opt = StoreAdamW(model, lr=1e-3, max_grad_norm=1.0)
+    model.zero_grad(set_to_none=True)
+    l0 = float(out.loss.detach())
+    for _ in range(4):
+        o = model(input_values=x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))
+        o.loss.backward(); opt.step(); opt.zero_grad()
+    assert float(o.loss.detach()) < l0
+    tr = model._hip_bridge.trainer
+    assert all(float(st.flat_m.abs().max()) > 0 and st.step_count == 4 for st in tr.stores())
 
 
 # ---------------------------------------------------------------------------------------------------------------- dropout
