@@ -47,7 +47,7 @@ def algorithmic_gflop_per_utt(cfg, T2):
     return 2.0 * mac / 1e9
 
 
-def pmc_traffic_bytes(kernel_prefix="gemm8p_kernel<false, 1>"):
+def pmc_traffic_bytes(kernel_prefix="gemm8p_kernel<false, 1"):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*pmc*per_launch.txt: rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate runs of this command, FETCH_SIZE doubled for 16-B/lane reads as MI355X_MICROARCH.md prescribes).  PMC counters cannot
     be collected inside the timed region, so the bench line carries the recorded value and names its source; None if the file is absent."""
