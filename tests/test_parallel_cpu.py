@@ -70,3 +70,19 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert r.returncode != 0 and "--gpus 3 but the launcher started 2" in (r.stdout + r.stderr)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "no GPU visible" in (r.stdout + r.stderr)      # the real bench never falls back to the CPU
+
+
+def test_bench_roofline_traffic_comes_from_the_committed_pmc_table():
+    """bench.py's `roofline.traffic` is read from the newest profiles/*pmc*per_launch*.txt by kernel name: a renamed kernel (a new template parameter) must not
+    silently turn it into null"""
+    import importlib.util, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+    traffic, src = mod.pmc_traffic_bytes()
+    assert traffic is not None and 30e6 < traffic < 120e6 and src.startswith("profiles/"), (traffic, src)
