@@ -110,6 +110,10 @@ __device__ __forceinline__ float wave_shr1(float v, float fill) {   // lane i <-
     const int r = __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
     return __int_as_float(r);
 }
+__device__ __forceinline__ float wave_shl1(float v, float fill) {   // lane i <- lane i+1, lane 63 <- fill
+    const int r = __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, false);
+    return __int_as_float(r);
+}
 __device__ __forceinline__ float lse3f(float a, float b, float c) {
     const float m = fmaxf(a, fmaxf(b, c));
     if (m == -INFINITY) return -INFINITY;
@@ -124,8 +128,9 @@ __global__ __launch_bounds__(256) void ctc_alpha_wave_kernel(const T* __restrict
                                                               float* __restrict__ nll, int* __restrict__ tgt_len_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* hdr = reinterpret_cast<int*>(smem);                 // [4]
-    int* ext = hdr + 4;                                      // [128]
-    float* lp = reinterpret_cast<float*>(ext + 128);         // [tchunk][128]
+    int* ext = hdr + 4;                                      // [128 + 2]: two blank sentinels behind the last state (the beta recursion looks at s + 2)
+    float* gam = reinterpret_cast<float*>(ext + 132);        // [128]: what the backward half hands the forward half
+    float* lp = gam + 128;                                   // [tchunk][128]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) {
         int n = 0;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256) void ctc_alpha_wave_kernel(const T* __restrict
             if (v >= 0) { ext[2 * n + 1] = (int)v; ++n; }
         }
         for (int s = 0; s <= 2 * n; s += 2) ext[s] = blank;
-        for (int s = 2 * n + 1; s < 128; ++s) ext[s] = blank;
+        for (int s = 2 * n + 1; s < 130; ++s) ext[s] = blank;
         hdr[0] = n;
     }
     __syncthreads();
@@ -148,6 +153,11 @@ __global__ __launch_bounds__(256) void ctc_alpha_wave_kernel(const T* __restrict
     const bool skip0 = s0 >= 2 && s0 < S && ext[s0] != blank && ext[s0] != ext[s0 - 2];
     const bool skip1 = s1 < S && ext[s1] != blank && ext[s1] != ext[s1 - 2];
     float a0 = -INFINITY, a1 = -INFINITY;
+    // Tb <= tchunk (every 10 s clip: 250 frames): the serial chain is halved — wave 0 runs alpha over t = 0..mid while wave 1 runs beta over t = Tb-1..mid+1, and
+    //   -nll = logsumexp_s( alpha_mid(s) + gamma(s) ),   gamma(s) = logsumexp over the transitions s -> {s, s+1, s+2 if allowed} of beta_{mid+1}(.)
+    // (beta_t includes the emission at t; the virtual beta_Tb is log 1 on the last state only).  Longer inputs keep the single forward chain over chunks.
+    const bool bidir = Tb <= tchunk;
+    const int mid = (Tb - 1) / 2;
     for (int tc = 0; tc < Tb; tc += tchunk) {
         const int nt = min(tchunk, Tb - tc);
         {   // gather log p(t, ext[s]): a thread keeps its state s (column ext[s]) and walks the time steps, 16 gathers in flight at a time —
@@ -172,9 +182,40 @@ __global__ __launch_bounds__(256) void ctc_alpha_wave_kernel(const T* __restrict
             }
         }
         __syncthreads();
+        if (bidir && wave == 1) {
+            const bool sk0 = s0 + 2 < S && ext[s0 + 2] != blank && ext[s0 + 2] != ext[s0];
+            const bool sk1 = s1 + 2 < S && ext[s1 + 2] != blank && ext[s1 + 2] != ext[s1];
+            // virtual beta at time Tb: probability 1 on the last state only — the transitions S-1 -> S-1 and S-2 -> S-1 then make both final states end with weight 1
+            float b0 = (s0 == S - 1) ? 0.f : -INFINITY, b1 = (s1 == S - 1) ? 0.f : -INFINITY;
+            auto trans = [&](float& n0, float& n1) {             // logsumexp over the successors of every state
+                const float bot = __shfl(b1, 0, 64), bot2 = __shfl(b1, 1, 64);     // states 64, 65 feed states 63 / 62, 63
+                const float p0 = wave_shl1(b0, bot), q0 = wave_shl1(p0, bot2);
+                const float p1 = wave_shl1(b1, -INFINITY), q1 = wave_shl1(p1, -INFINITY);
+                n0 = lse3f(b0, p0, sk0 ? q0 : -INFINITY);
+                n1 = lse3f(b1, p1, sk1 ? q1 : -INFINITY);
+            };
+            float l0 = lp[(Tb - 1) * 128 + s0], l1 = lp[(Tb - 1) * 128 + s1];
+            for (int t = Tb - 1; t > mid; --t) {
+                const int tn = max(t - 1, 0);
+                const float l0n = lp[tn * 128 + s0], l1n = lp[tn * 128 + s1];      // next step's emissions: in flight during this step's arithmetic
+                float n0, n1;
+                trans(n0, n1);
+                b0 = (s0 < S) ? n0 + l0 : -INFINITY;
+                b1 = (s1 < S) ? n1 + l1 : -INFINITY;
+                l0 = l0n; l1 = l1n;
+            }
+            float g0, g1;
+            trans(g0, g1);
+            gam[s0] = (s0 < S) ? g0 : -INFINITY;
+            gam[s1] = (s1 < S) ? g1 : -INFINITY;
+        }
         if (wave == 0) {
-            for (int t = 0; t < nt; ++t) {
-                const float l0 = lp[t * 128 + s0], l1 = lp[t * 128 + s1];
+            const int tend = bidir ? mid + 1 : nt;
+            float l0n = lp[s0], l1n = lp[s1];
+            for (int t = 0; t < tend; ++t) {
+                const float l0 = l0n, l1 = l1n;
+                const int tn = min(t + 1, nt - 1);
+                l0n = lp[tn * 128 + s0]; l1n = lp[tn * 128 + s1];                  // prefetch: the LDS latency leaves the serial chain
                 if (tc + t == 0) {
                     a0 = (s0 < 2 && s0 < S) ? l0 : -INFINITY;
                     a1 = -INFINITY;
@@ -194,6 +235,15 @@ __global__ __launch_bounds__(256) void ctc_alpha_wave_kernel(const T* __restrict
             }
         }
         __syncthreads();
+    }
+    if (bidir) {
+        if (wave == 0) {
+            const float v0 = a0 + gam[s0], v1 = a1 + gam[s1];      // -inf + anything stays -inf (no NaN: gamma is never +inf)
+            const float m = wave_max(fmaxf(v0, v1));
+            const float sum = (m == -INFINITY) ? 0.f : wave_sum(__expf(v0 - m) + __expf(v1 - m));
+            if (lane == 0) nll[b] = (m == -INFINITY) ? INFINITY : -(m + __logf(sum));
+        }
+        return;
     }
     if (wave == 0) {
         // log-likelihood = logsumexp(alpha[S-1], alpha[S-2])
@@ -241,7 +291,7 @@ extern "C" int mi_ctc_loss_fwd(const void* logits, long ld_b, long ld_t, int dty
     const int S_max = 2 * U + 1;
     if (S_max <= 128) {
         const int tchunk = T < 256 ? T : 256;                      // 256 steps x 128 states x 4 B = 128 KiB
-        const size_t ldsw = (4 + 128) * sizeof(int) + (size_t)tchunk * 128 * sizeof(float);
+        const size_t ldsw = (4 + 132) * sizeof(int) + 128 * sizeof(float) + (size_t)tchunk * 128 * sizeof(float);
         if (dtype == 0)
             hipLaunchKernelGGL(ctc_alpha_wave_kernel<float>, dim3(B), dim3(256), ldsw, stream, (const float*)logits, ld_b, ld_t, lse, T,
                                labels, U, in_len, blank, tchunk, nll, tgt_len);
