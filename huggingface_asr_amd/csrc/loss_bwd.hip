@@ -103,6 +103,131 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const T* __restrict
     }
 }
 
+// Wave form of ctc_alpha_beta_kernel for S_max <= 128 and T <= 256 (every 10 s clip: 250 frames): the emissions lp[t][s] are gathered into LDS by the whole block first
+// (the only HBM traffic), then wave 0 runs alpha forward and wave 1 runs beta backward AT THE SAME TIME, two states per lane in registers, neighbours by whole-wave DPP
+// shifts, no barrier and no global load inside a time step (the block form above pays a dependent gather + a barrier per step, twice over the sequence).  alpha_t goes to
+// `alpha_ws`, beta_t into `contrib` as scratch; the block then turns contrib into -scale * exp(alpha + beta + nll - lp) in place.  Same recursions, same outputs.
+__device__ __forceinline__ float w_shr1(float v, float fill) {   // lane i <- lane i-1, lane 0 <- fill
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float w_shl1(float v, float fill) {   // lane i <- lane i+1, lane 63 <- fill
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, false));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_alpha_beta_wave_kernel(const T* __restrict__ logits, long ld_b, long ld_t, const float* __restrict__ lse,
+                                                                   int Tmax, const long* __restrict__ labels, int U, const int* __restrict__ in_len,
+                                                                   int blank, const float* __restrict__ nll, int reduction, int B, float gscale,
+                                                                   float* __restrict__ alpha_ws, float* __restrict__ contrib,
+                                                                   int* __restrict__ ext_ws, int* __restrict__ meta) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int S_max = 2 * U + 1;
+    int* hdr = reinterpret_cast<int*>(smem);          // [4]
+    int* ext = hdr + 4;                               // [132]: blank sentinels behind the last state
+    float* lp = reinterpret_cast<float*>(ext + 132);  // [Tmax][128]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        int n = 0;
+        for (int u = 0; u < U; ++u) {
+            const long v = labels[(long)b * U + u];
+            if (v >= 0) { ext[2 * n + 1] = (int)v; ++n; }
+        }
+        for (int s = 0; s <= 2 * n; s += 2) ext[s] = blank;
+        for (int s = 2 * n + 1; s < 132; ++s) ext[s] = blank;
+        hdr[0] = n;
+    }
+    __syncthreads();
+    const int tl = hdr[0], S = 2 * tl + 1;
+    const int Tb = min(in_len[b], Tmax);
+    const float nl = nll[b];
+    float scale = (reduction == 1) ? gscale / ((float)max(tl, 1) * (float)B) : gscale;
+    if (!isfinite(nl) || Tb <= 0) scale = 0.f;        // infeasible alignment: zero gradient (zero_infinity semantics)
+    for (int s = tid; s < S; s += 256) ext_ws[(long)b * S_max + s] = ext[s];
+    if (tid == 0) { meta[3 * b] = tl; meta[3 * b + 1] = Tb; meta[3 * b + 2] = __float_as_int(scale); }
+    if (scale == 0.f) return;
+    const T* lg = logits + (long)b * ld_b;
+    const float* ls = lse + (long)b * Tmax;
+    float* aw = alpha_ws + (long)b * Tmax * S_max;
+    float* cw = contrib + (long)b * Tmax * S_max;
+    {   // gather log p(t, ext[s]), 16 loads in flight per thread
+        constexpr int UN = 16;
+        const int s = tid & 127, tsub = tid >> 7;
+        const bool sv = s < S;
+        const long col = sv ? ext[s] : blank;
+        for (int t = tsub; t < Tb; t += 2 * UN) {
+            float v[UN], l[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int tt = min(t + 2 * u, Tb - 1);
+                v[u] = (float)lg[(long)tt * ld_t + col];
+                l[u] = ls[tt];
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int tt = t + 2 * u;
+                if (tt < Tb) lp[tt * 128 + s] = sv ? v[u] - l[u] : -INFINITY;
+            }
+        }
+    }
+    __syncthreads();
+    const int s0 = lane, s1 = lane + 64;
+    if (wave == 0) {                                   // ---- alpha, t = 0 .. Tb-1
+        const bool skip0 = s0 >= 2 && s0 < S && ext[s0] != blank && ext[s0] != ext[s0 - 2];
+        const bool skip1 = s1 < S && ext[s1] != blank && ext[s1] != ext[s1 - 2];
+        float l0n = lp[s0], l1n = lp[s1];
+        float a0 = (s0 < 2 && s0 < S) ? l0n : -INFINITY, a1 = -INFINITY;
+        if (s0 < S) aw[s0] = a0;
+        if (s1 < S) aw[s1] = a1;
+        l0n = lp[min(1, Tb - 1) * 128 + s0]; l1n = lp[min(1, Tb - 1) * 128 + s1];
+        for (int t = 1; t < Tb; ++t) {
+            const float l0 = l0n, l1 = l1n;
+            const int tn = min(t + 1, Tb - 1);
+            l0n = lp[tn * 128 + s0]; l1n = lp[tn * 128 + s1];
+            const float top = __shfl(a0, 63, 64), top2 = __shfl(a0, 62, 64);
+            const float p0 = w_shr1(a0, -INFINITY), q0 = w_shr1(p0, -INFINITY);
+            const float p1 = w_shr1(a1, top);
+            float q1 = w_shr1(p1, top2);
+            if (lane == 1) q1 = top;
+            const float n0 = lse3f(a0, p0, skip0 ? q0 : -INFINITY) + l0;
+            const float n1 = lse3f(a1, p1, skip1 ? q1 : -INFINITY) + l1;
+            a0 = (s0 < S) ? n0 : -INFINITY;
+            a1 = (s1 < S) ? n1 : -INFINITY;
+            if (s0 < S) aw[(long)t * S_max + s0] = a0;
+            if (s1 < S) aw[(long)t * S_max + s1] = a1;
+        }
+    } else if (wave == 1) {                            // ---- beta, t = Tb-1 .. 0 (stored in contrib)
+        const bool sk0 = s0 + 2 < S && ext[s0 + 2] != blank && ext[s0 + 2] != ext[s0];
+        const bool sk1 = s1 + 2 < S && ext[s1 + 2] != blank && ext[s1 + 2] != ext[s1];
+        float l0 = lp[(Tb - 1) * 128 + s0], l1 = lp[(Tb - 1) * 128 + s1];
+        float b0 = (s0 < S && s0 >= S - 2) ? l0 : -INFINITY, b1 = (s1 < S && s1 >= S - 2) ? l1 : -INFINITY;
+        if (s0 < S) cw[(long)(Tb - 1) * S_max + s0] = b0;
+        if (s1 < S) cw[(long)(Tb - 1) * S_max + s1] = b1;
+        float l0n = lp[max(Tb - 2, 0) * 128 + s0], l1n = lp[max(Tb - 2, 0) * 128 + s1];
+        for (int t = Tb - 2; t >= 0; --t) {
+            l0 = l0n; l1 = l1n;
+            const int tn = max(t - 1, 0);
+            l0n = lp[tn * 128 + s0]; l1n = lp[tn * 128 + s1];
+            const float bot = __shfl(b1, 0, 64), bot2 = __shfl(b1, 1, 64);
+            const float p0 = w_shl1(b0, bot), q0 = w_shl1(p0, bot2);
+            const float p1 = w_shl1(b1, -INFINITY), q1 = w_shl1(p1, -INFINITY);
+            const float n0 = lse3f(b0, p0, sk0 ? q0 : -INFINITY) + l0;
+            const float n1 = lse3f(b1, p1, sk1 ? q1 : -INFINITY) + l1;
+            b0 = (s0 < S) ? n0 : -INFINITY;
+            b1 = (s1 < S) ? n1 : -INFINITY;
+            if (s0 < S) cw[(long)t * S_max + s0] = b0;
+            if (s1 < S) cw[(long)t * S_max + s1] = b1;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- contributions: every (t, s) of this utterance, whole block
+    for (int i = tid; i < Tb * S; i += 256) {
+        const int t = i / S, s2 = i - t * S;
+        const long o = (long)t * S_max + s2;
+        cw[o] = -scale * __expf(aw[o] + cw[o] + nl - lp[t * 128 + s2]);
+    }
+}
+
 // one block per (b, t) row: dense softmax part + scatter of the per-state contributions -> bf16 gradient row (pad columns zero)
 template <typename T>
 __global__ __launch_bounds__(256) void ctc_grad_rows_kernel(const T* __restrict__ logits, long ld_b, long ld_t, const float* __restrict__ lse,
@@ -203,17 +328,17 @@ extern "C" int mi_ctc_loss_bwd(const void* logits, long ld_b, long ld_t, int dty
     const size_t lds = (4 + S) * sizeof(int) + 2 * S * sizeof(float);
     const size_t lds_rows = (size_t)V1 * sizeof(float);
     if (lds > 150 * 1024 || lds_rows > 150 * 1024) return MI_ERR_UNSUPPORTED;
-    if (dtype == 0) {
-        hipLaunchKernelGGL(ctc_alpha_beta_kernel<float>, dim3(B), dim3(256), lds, st, (const float*)logits, ld_b, ld_t, lse, T, labels, U, in_len,
-                           blank, nll, reduction, B, gscale, alpha_ws, contrib, ext_ws, meta);
-        hipLaunchKernelGGL(ctc_grad_rows_kernel<float>, dim3(B * T), dim3(256), lds_rows, st, (const float*)logits, ld_b, ld_t, lse, T, U, V1,
-                           contrib, ext_ws, meta, (bf16_t*)dlogits, ldo);
-    } else {
-        hipLaunchKernelGGL(ctc_alpha_beta_kernel<bf16_t>, dim3(B), dim3(256), lds, st, (const bf16_t*)logits, ld_b, ld_t, lse, T, labels, U, in_len,
-                           blank, nll, reduction, B, gscale, alpha_ws, contrib, ext_ws, meta);
-        hipLaunchKernelGGL(ctc_grad_rows_kernel<bf16_t>, dim3(B * T), dim3(256), lds_rows, st, (const bf16_t*)logits, ld_b, ld_t, lse, T, U, V1,
-                           contrib, ext_ws, meta, (bf16_t*)dlogits, ldo);
-    }
+    const bool wavef = S <= 128 && T <= 256;          // the wave form: states in one wave's registers, all emissions in LDS
+    const size_t ldsw = (4 + 132) * sizeof(int) + (size_t)T * 128 * sizeof(float);
+#define CTC_AB(TY) do { \
+        if (wavef) hipLaunchKernelGGL(ctc_alpha_beta_wave_kernel<TY>, dim3(B), dim3(256), ldsw, st, (const TY*)logits, ld_b, ld_t, lse, T, labels, U, in_len, \
+                                      blank, nll, reduction, B, gscale, alpha_ws, contrib, ext_ws, meta); \
+        else hipLaunchKernelGGL(ctc_alpha_beta_kernel<TY>, dim3(B), dim3(256), lds, st, (const TY*)logits, ld_b, ld_t, lse, T, labels, U, in_len, \
+                                blank, nll, reduction, B, gscale, alpha_ws, contrib, ext_ws, meta); \
+        hipLaunchKernelGGL(ctc_grad_rows_kernel<TY>, dim3(B * T), dim3(256), lds_rows, st, (const TY*)logits, ld_b, ld_t, lse, T, U, V1, \
+                           contrib, ext_ws, meta, (bf16_t*)dlogits, ldo); } while (0)
+    if (dtype == 0) CTC_AB(float); else CTC_AB(bf16_t);
+#undef CTC_AB
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
