@@ -179,19 +179,47 @@ __global__ __launch_bounds__(256) void cmvn_lds_kernel(float* x, long ld_b, cons
     }
     __syncthreads();
     if (tid < G) {
+        // numpy's float32 reductions along the time axis are sequential per column, and so are these — but sixteen values are fetched from LDS ahead of the
+        // sixteen dependent adds that consume them (one LDS round trip per 16 steps of the chain instead of one per step: a single partial wave has no other
+        // way to hide it).  Same operations in the same order: bit-identical.
+        constexpr int UN = 16;
         float mean = 0.f, sd = 1.f;
         const float fn = (float)max(n, 1);
+        const float* col = slab + tid;
         if (n > 0 && norm_means) {
             float s = 0.f;
-            for (int t = 0; t < n; ++t) s += slab[t * G + tid];
+            int t = 0;
+            for (; t + UN <= n; t += UN) {
+                float v[UN];
+#pragma unroll
+                for (int j = 0; j < UN; ++j) v[j] = col[(t + j) * G];
+#pragma unroll
+                for (int j = 0; j < UN; ++j) s += v[j];
+            }
+            for (; t < n; ++t) s += col[t * G];
             mean = s / fn;
         }
         if (n > 0 && norm_vars) {
             float s = 0.f;
-            for (int t = 0; t < n; ++t) s += slab[t * G + tid] - mean;
+            int t = 0;
+            for (; t + UN <= n; t += UN) {
+                float v[UN];
+#pragma unroll
+                for (int j = 0; j < UN; ++j) v[j] = col[(t + j) * G];
+#pragma unroll
+                for (int j = 0; j < UN; ++j) s += v[j] - mean;
+            }
+            for (; t < n; ++t) s += col[t * G] - mean;
             const float m2 = s / fn;
             float q = 0.f;
-            for (int t = 0; t < n; ++t) { const float d = (slab[t * G + tid] - mean) - m2; q += d * d; }
+            for (t = 0; t + UN <= n; t += UN) {
+                float v[UN];
+#pragma unroll
+                for (int j = 0; j < UN; ++j) v[j] = col[(t + j) * G];
+#pragma unroll
+                for (int j = 0; j < UN; ++j) { const float d = (v[j] - mean) - m2; q += d * d; }
+            }
+            for (; t < n; ++t) { const float d = (col[t * G] - mean) - m2; q += d * d; }
             sd = sqrtf(q / fn);
         }
         red[tid] = mean; red[G + tid] = sd;
