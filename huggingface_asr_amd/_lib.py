@@ -21,6 +21,11 @@ class EbfConfig(C.Structure):
                [("ln_eps", f32), ("logits_f32", i32), ("logits_ld", i32), ("branch_overlap", i32), ("extra_layers", i32), ("layer_mixing", i32), ("csgu_linear", i32)]
 
 
+class LnRedDesc(C.Structure):
+    """mirror of mi_lnred_desc (include/hfasr_hip.h)"""
+    _fields_ = [("partial", vp), ("nblk", i32), ("d", i32), ("dgamma", vp), ("dbeta", vp)]
+
+
 class Gpt2Config(C.Structure):
     """mirror of mi_gpt2_config (include/hfasr_hip.h)"""
     _fields_ = [("d", i32), ("H", i32), ("L", i32), ("V", i32), ("eps", f32)]
@@ -66,6 +71,8 @@ SIGNATURES = {
     "mi_act_dropout_bwd_bf16": [vp, i64, vp, i64, vp, i64, i32, i32, i32, f32, C.c_uint, C.c_uint, vp],
     "mi_layernorm_bwd_workspace_floats": [i32],
     "mi_layernorm_bwd": [vp, i64, i32, vp, f32, vp, i64, i32, vp, i64, i32, i32, vp, vp, vp, i32, i32, vp],
+    "mi_layernorm_bwd_partial": [vp, i64, i32, vp, f32, vp, i64, i32, vp, i64, i32, i32, vp, vp, i32, i32, vp],
+    "mi_ln_partial_reduce_many": [vp, i32, vp],
     "mi_ln_apply_bf16": [vp, i64, vp, vp, vp, vp, i64, i32, i32, vp],
     "mi_axpy_f32": [vp, vp, i64, f32, vp],
     "mi_scale_f32": [vp, i64, f32, vp],

@@ -8,6 +8,7 @@
 // Conventions: activations bf16 (row-major, leading dimension in elements), residual stream / parameter gradients fp32.
 // Parameter gradients ACCUMULATE (+=, float atomics at block granularity): the step zeroes the flat gradient buffer once.
 #include "common.hpp"
+#include "../../include/hfasr_hip.h"       // mi_lnred_desc
 
 namespace {
 
@@ -280,6 +281,40 @@ __global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __r
     if (ty == 0 && c < 2 * d) {
         const float t = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
         atomic_add_f32(c < d ? dgamma + c : dbeta + (c - d), t);
+    }
+}
+
+// The same reduction for up to 16 LayerNorms in ONE launch (the trainer defers the reductions of a layer's LayerNorm backward passes and flushes them together: a
+// reduce of 2 MB is all launch latency).  grid (columns / 16, LayerNorm); a block owns its 16 columns over ALL partial rows (16 row groups x 32 rows), summed in a fixed order: no atomics.
+struct LnRedMany { mi_lnred_desc d[16]; };
+__global__ __launch_bounds__(256) void ln_partial_reduce_many_kernel(LnRedMany p) {
+    __shared__ float red[16][17];
+    const mi_lnred_desc q = p.d[blockIdx.y];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;           // 16 columns x 16 row groups
+    const int c = blockIdx.x * 16 + tx;
+    if ((int)blockIdx.x * 16 >= 2 * q.d) return;
+    float s = 0.f;
+    if (c < 2 * q.d) {
+        const float* src = q.partial + c;
+        const long ld = 2 * q.d;
+        int b = ty;
+        for (; b + 7 * 16 < q.nblk; b += 8 * 16) {                    // eight loads in flight per thread; the sum order is fixed (row group, then rows ascending)
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = src[(long)(b + j * 16) * ld];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; b < q.nblk; b += 16) s += src[(long)b * ld];
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < 2 * q.d) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][tx];
+        float* o = c < q.d ? q.dgamma + c : q.dbeta + (c - q.d);
+        *o += t;
     }
 }
 
@@ -605,28 +640,63 @@ extern "C" int mi_act_bwd_bf16(const void* dy, long lddy, const void* pre, long 
 
 // workspace: >= mi_layernorm_bwd_workspace_floats(d) floats when dgamma != NULL (per-block partial sums; no float atomics)
 extern "C" size_t mi_layernorm_bwd_workspace_floats(int d) { return (size_t)512 * 2 * d; }
-extern "C" int mi_layernorm_bwd(const void* x, long ldx, int x_bf16, const float* gamma, float eps, const void* dy, long lddy, int dy_f32,
-                                void* dx, long lddx, int dx_bf16, int accumulate, float* dgamma, float* dbeta, float* workspace, int M, int d,
-                                hipStream_t st) {
-    MI_ENTER();
+static int ln_bwd_launch(const void* x, long ldx, int x_bf16, const float* gamma, float eps, const void* dy, long lddy, int dy_f32,
+                         void* dx, long lddx, int dx_bf16, int accumulate, float* partial, int* nblk, int M, int d, hipStream_t st) {
     if (M <= 0 || d <= 0 || d > 2048 || (d % 4) || (ldx % 4) || (lddy % 4) || (lddx % 4) || !gamma) return MI_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(x) & (x_bf16 ? 7 : 15)) || (reinterpret_cast<uintptr_t>(dy) & (dy_f32 ? 15 : 7)) ||
         (reinterpret_cast<uintptr_t>(dx) & (dx_bf16 ? 7 : 15))) return MI_ERR_ARG;
-    if (dgamma && (!dbeta || !workspace)) return MI_ERR_ARG;
     int grid = cdiv(M, 4);
     if (grid > 512) grid = 512;                         // two blocks per CU; each wave walks rows wave_id, wave_id + nwaves, ... (256 / 1024 / 2048 blocks measured slower)
     const int rpw = cdiv(M, (long)grid * 4);
     const size_t lds = (size_t)4 * 2 * d * sizeof(float);
     const int nv = cdiv(d, 256);
-    float* partial = dgamma ? workspace : nullptr;
 #define LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(grid), dim3(256), lds, st, x, ldx, x_bf16, gamma, eps, dy, lddy, dy_f32, dx, lddx, dx_bf16, accumulate, partial, M, d, rpw)
     if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4); else LN_BWD(8);
 #undef LN_BWD
+    if (nblk) *nblk = grid;
+    return MI_OK;
+}
+
+extern "C" int mi_layernorm_bwd(const void* x, long ldx, int x_bf16, const float* gamma, float eps, const void* dy, long lddy, int dy_f32,
+                                void* dx, long lddx, int dx_bf16, int accumulate, float* dgamma, float* dbeta, float* workspace, int M, int d,
+                                hipStream_t st) {
+    MI_ENTER();
+    if (dgamma && (!dbeta || !workspace)) return MI_ERR_ARG;
+    int grid = 0;
+    const int rc = ln_bwd_launch(x, ldx, x_bf16, gamma, eps, dy, lddy, dy_f32, dx, lddx, dx_bf16, accumulate, dgamma ? workspace : nullptr, &grid, M, d, st);
+    if (rc != MI_OK) return rc;
     MI_CHECK_LAUNCH();
     if (dgamma) {
-        hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(cdiv(2 * d, 64), cdiv(grid, 64)), dim3(256), 0, st, partial, grid, d, dgamma, dbeta);
+        hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(cdiv(2 * d, 64), cdiv(grid, 64)), dim3(256), 0, st, workspace, grid, d, dgamma, dbeta);
         MI_CHECK_LAUNCH();
     }
+    return MI_OK;
+}
+
+// as mi_layernorm_bwd, but the (dgamma | dbeta) partial rows stay in `partial` (*nblk rows of 2 d floats, at most 512: mi_layernorm_bwd_workspace_floats) and are
+// NOT reduced here: the caller hands them to mi_ln_partial_reduce_many, several LayerNorms per launch
+extern "C" int mi_layernorm_bwd_partial(const void* x, long ldx, int x_bf16, const float* gamma, float eps, const void* dy, long lddy, int dy_f32,
+                                        void* dx, long lddx, int dx_bf16, int accumulate, float* partial, int* nblk, int M, int d, hipStream_t st) {
+    MI_ENTER();
+    if (!partial || !nblk) return MI_ERR_ARG;
+    const int rc = ln_bwd_launch(x, ldx, x_bf16, gamma, eps, dy, lddy, dy_f32, dx, lddx, dx_bf16, accumulate, partial, nblk, M, d, st);
+    if (rc != MI_OK) return rc;
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+extern "C" int mi_ln_partial_reduce_many(const mi_lnred_desc* descs, int n, hipStream_t st) {
+    MI_ENTER();
+    if (!descs || n <= 0 || n > 16) return MI_ERR_ARG;
+    LnRedMany p{};
+    int dmax = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!descs[i].partial || !descs[i].dgamma || !descs[i].dbeta || descs[i].nblk <= 0 || descs[i].d <= 0) return MI_ERR_ARG;
+        p.d[i] = descs[i];
+        dmax = descs[i].d > dmax ? descs[i].d : dmax;
+    }
+    hipLaunchKernelGGL(ln_partial_reduce_many_kernel, dim3(cdiv(2 * dmax, 16), n), dim3(256), 0, st, p);
+    MI_CHECK_LAUNCH();
     return MI_OK;
 }
 

@@ -83,9 +83,53 @@ def act_bwd(dy, pre, kind="gelu", out=None, drop=None):
     return out
 
 
-def layernorm_bwd(x, gamma, dy, dx, *, accumulate, dgamma=None, dbeta=None, eps=1e-5):
-    """dx (+)= dLN(x)/dx · dy ; dgamma/dbeta += .  x f32|bf16, dy f32|bf16, dx f32|bf16 (all (M,d) row views)."""
+class LnReduceBatch:
+    """Deferred (dgamma | dbeta) reductions of LayerNorm backward passes: `layernorm_bwd(..., defer=batch)` leaves its per-block partial rows in this object's arena;
+    `flush()` reduces up to 16 of them in ONE launch (mi_ln_partial_reduce_many).  A 2-MB reduce is all launch latency: the training step has ~100 of them."""
+    SLOTS = 16
+
+    def __init__(self, device, floats_per_slot=512 * 2 * 2048):
+        self.device, self.per = device, floats_per_slot
+        self.arena = None
+        self.items = []
+        self.cursor = 0                                     # slots are handed out round-robin: the pending entries always sit in the len(items) most recent ones
+
+    def slot(self):
+        if self.arena is None:
+            self.arena = torch.empty(self.SLOTS * self.per, device=self.device, dtype=F32)
+        if len(self.items) == self.SLOTS:                   # every slot holds partial rows that are not reduced yet
+            self.flush()
+        i = self.cursor
+        self.cursor = (self.cursor + 1) % self.SLOTS
+        return self.arena[i * self.per:(i + 1) * self.per]
+
+    def add(self, partial, nblk, d, dgamma, dbeta):
+        if any(it.dgamma == dgamma.data_ptr() for it in self.items):      # two LayerNorm passes into the same target: their `+=` must not run in one launch
+            self.flush()
+        self.items.append(_lib.LnRedDesc(partial=partial.data_ptr(), nblk=int(nblk), d=int(d), dgamma=dgamma.data_ptr(), dbeta=dbeta.data_ptr()))
+
+    def flush(self):
+        if not self.items:
+            return
+        import ctypes as C
+        arr = (_lib.LnRedDesc * len(self.items))(*self.items)
+        _lib.check(_L().mi_ln_partial_reduce_many(arr, len(self.items), _stream()), "mi_ln_partial_reduce_many")
+        self.items = []
+
+
+def layernorm_bwd(x, gamma, dy, dx, *, accumulate, dgamma=None, dbeta=None, eps=1e-5, defer=None):
+    """dx (+)= dLN(x)/dx · dy ; dgamma/dbeta += .  x f32|bf16, dy f32|bf16, dx f32|bf16 (all (M,d) row views).
+    defer: an LnReduceBatch — the dgamma / dbeta reduction is left to its next `flush()` (the trainer flushes once per layer)."""
     M, d = x.shape
+    if defer is not None and dgamma is not None:
+        import ctypes as C
+        part = defer.slot()
+        nblk = C.c_int(0)
+        _lib.check(_L().mi_layernorm_bwd_partial(x.data_ptr(), x.stride(0), int(x.dtype == BF16), gamma.data_ptr(), float(eps),
+                                                 dy.data_ptr(), dy.stride(0), int(dy.dtype == F32), dx.data_ptr(), dx.stride(0), int(dx.dtype == BF16),
+                                                 int(accumulate), part.data_ptr(), C.byref(nblk), M, d, _stream()), "mi_layernorm_bwd_partial")
+        defer.add(part, nblk.value, d, dgamma, dbeta)
+        return dx
     ws = _dw_ws(x.device, 512 * 2 * 2048) if dgamma is not None else 0
     _lib.check(_L().mi_layernorm_bwd(x.data_ptr(), x.stride(0), int(x.dtype == BF16), gamma.data_ptr(), float(eps),
                                      dy.data_ptr(), dy.stride(0), int(dy.dtype == F32), dx.data_ptr(), dx.stride(0), int(dx.dtype == BF16),

@@ -460,11 +460,19 @@ class EncoderCTCTrainer:
             self.store.set_frozen(frozen)         # native route: AdamW leaves them bit-identical (no decay, zero gradient), the clip norm skips them
         self.frozen = frozen
 
+    def _range_done(self, lo, hi):
+        """the gradients of [lo, hi) are final once the deferred LayerNorm reductions have run: flush them, then hand the range to the data-parallel all-reduce"""
+        if getattr(self, "_lnred", None) is not None:
+            self._lnred.flush()
+        self.sync.launch(lo, hi)
+
     def _lng(self, gname, bname):
         """gradient targets of a LayerNorm's affine pair: none when both are frozen (the cross-row reduction is then skipped)"""
         if gname in self.frozen and bname in self.frozen:
             return dict(dgamma=None, dbeta=None)
-        return dict(dgamma=self.store.g(gname), dbeta=self.store.g(bname))
+        if getattr(self, "_lnred", None) is None:
+            self._lnred = T.LnReduceBatch(self.device)        # the (dgamma | dbeta) reductions of a layer's LayerNorms: one launch per flush, not one per LayerNorm
+        return dict(dgamma=self.store.g(gname), dbeta=self.store.g(bname), defer=self._lnred)
 
     def grad_dict(self) -> dict:
         """gradients in the reference's parameter names / shapes (tests, checkpoint tooling, the autograd bridge)."""
@@ -756,13 +764,13 @@ class EncoderCTCTrainer:
         dx = e32(M, d)
         dmix = None
         if self.mix or self.extra:
-            self.sync.launch(*st.range_of(["head_w", "head_b"]))
+            self._range_done(*st.range_of(["head_w", "head_b"]))
             dtop = dhid                                               # f32: gradient at the head's input
             if self.extra:
                 dtop = layer_bwd(dtop, S_extra, L)
                 if inner is not None:
                     T.mask_rows_(dtop, inner, T2)
-                self.sync.launch(*st.range_of(self._layer_names[L]))
+                self._range_done(*st.range_of(self._layer_names[L]))
             if self.mix:            # d hidden_l = s_l * d mixed;  d per_layer_weights = s * (g - <s, g>),  g_l = <d mixed, hidden_l>
                 dmix = dtop
                 gdot = torch.zeros(L + 1, device=dev, dtype=F32)
@@ -779,14 +787,14 @@ class EncoderCTCTrainer:
                 T.layernorm_bwd(x, P("enc_ln_g"), dh32, dx, accumulate=dhid is not None, **self._lng("enc_ln_g", "enc_ln_b"), eps=eps_e)
             elif dhid is None:
                 dx.zero_()
-        self.sync.launch(*st.range_of(self._encln_names if (self.mix or self.extra) else self._head_names))
+        self._range_done(*st.range_of(self._encln_names if (self.mix or self.extra) else self._head_names))
         for l in range(L - 1, -1, -1):
             S = saved[l]
             if S is not None:               # (a dropped layer: dx passes through, its gradient range stays zero — still reduced: other ranks may have run it)
                 dx = layer_bwd(dx, S, l)
             if dmix is not None:            # layer mixing: hidden_states[l] is this layer's input
                 T.axpy_dev_(dx, dmix, sw[l:l + 1])
-            self.sync.launch(*st.range_of(self._layer_names[l]))
+            self._range_done(*st.range_of(self._layer_names[l]))
         # ---------------- front end
         if pd["hidden"] > 0:
             T.dropout_(dx, pd["hidden"], seed, self._sid(L, 1))
@@ -807,7 +815,7 @@ class EncoderCTCTrainer:
         dcol = ops.gemm(dpre2, WT("conv2_w")[:, :C2])
         del col
         T.conv2d_first_bwd(feats, P("conv1_w"), P("conv1_b"), dcol, G("conv1_w"), G("conv1_b"), K, s_, padl, T1, F1, K, s_, padl, T2, F2)
-        self.sync.launch(*st.range_of(self._front_names))
+        self._range_done(*st.range_of(self._front_names))
         return out
 
     # ------------------------------------------------------------------ pieces

@@ -176,6 +176,12 @@ size_t mi_layernorm_bwd_workspace_floats(int d);
 int mi_layernorm_bwd(const void* x, long ldx, int x_bf16, const float* gamma, float eps, const void* dy, long lddy, int dy_f32,
                      void* dx, long lddx, int dx_bf16, int accumulate, float* dgamma, float* dbeta, float* workspace, int M, int d,
                      mi_stream_t stream);
+/* deferred form: the per-block (dgamma | dbeta) partial rows stay in `partial` (*nblk rows of 2 d floats; size as mi_layernorm_bwd_workspace_floats) and are reduced
+   later, up to 16 LayerNorms per launch, by mi_ln_partial_reduce_many (dgamma[c] += sum, dbeta[c] += sum; fixed summation order, no atomics) */
+typedef struct { const float* partial; int nblk, d; float* dgamma; float* dbeta; } mi_lnred_desc;
+int mi_layernorm_bwd_partial(const void* x, long ldx, int x_bf16, const float* gamma, float eps, const void* dy, long lddy, int dy_f32,
+                             void* dx, long lddx, int dx_bf16, int accumulate, float* partial, int* nblk, int M, int d, mi_stream_t stream);
+int mi_ln_partial_reduce_many(const mi_lnred_desc* descs, int n, mi_stream_t stream);
 int mi_ln_apply_bf16(const void* x, long ldx, const float* stats, const float* gamma, const float* beta, void* y, long ldy,
                      int M, int N, mi_stream_t stream);
 int mi_axpy_f32(float* a, const float* b, long n, float alpha, mi_stream_t stream);

@@ -266,6 +266,31 @@ def test_causal_dilated_csgu_bwd(B, Tt, Cc):
     assert float(dw.cpu()[:, ~seen].abs().max() if (~seen).any() else 0.0) == 0.0
 
 
+def test_layernorm_bwd_deferred_reductions_match_the_immediate_form():
+    """ops_train.LnReduceBatch: the (dgamma | dbeta) reductions of several LayerNorm backward passes in one launch (d 512 and 1024 mixed, a repeated target, more
+    entries than the batch holds) against the immediate form"""
+    ops, T = _o()
+    M = 1000
+    batch = T.LnReduceBatch(DEV)
+    want, got = [], []
+    cases = [(512, 1), (1024, 2), (512, 3), (64, 4)] * 5                       # 20 entries > 16 slots: an automatic flush in between
+    for d, seed in cases:
+        x = rnd(M, d, seed=seed).to(DEV); dy = dev16(rnd(M, d, seed=seed + 50)); g = (1 + 0.1 * rnd(d, seed=seed + 90)).to(DEV)
+        dg1, db1 = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+        dg2, db2 = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+        dx1, dx2 = torch.zeros(M, d, device=DEV), torch.zeros(M, d, device=DEV)
+        T.layernorm_bwd(x, g, dy, dx1, accumulate=False, dgamma=dg1, dbeta=db1)
+        T.layernorm_bwd(x, g, dy, dx2, accumulate=False, dgamma=dg2, dbeta=db2, defer=batch)
+        T.layernorm_bwd(x, g, dy, dx1, accumulate=True, dgamma=dg1, dbeta=db1)                     # the same targets again: the deferred form must not race on them
+        T.layernorm_bwd(x, g, dy, dx2, accumulate=True, dgamma=dg2, dbeta=db2, defer=batch)
+        want.append((dx1, dg1, db1)); got.append((dx2, dg2, db2))
+    batch.flush()
+    for (a, b, c), (d2, e, f) in zip(want, got):
+        assert torch.equal(a, d2)
+        torch.testing.assert_close(e, b, rtol=1e-5, atol=1e-5 * float(b.abs().max()))
+        torch.testing.assert_close(f, c, rtol=1e-5, atol=1e-5 * float(c.abs().max()))
+
+
 def test_scale_by_device_scalar():
     """the autograd bridge's d(loss) factor: a device scalar, no host sync; exactly 1 leaves the buffer untouched, anything else scales it (odd length: the scalar tail)"""
     ops, T = _o()
