@@ -18,7 +18,8 @@ class EbfConfig(C.Structure):
     """mirror of mi_ebf_config (include/hfasr_hip.h)"""
     _fields_ = [(n, i32) for n in ("B", "T", "F", "d", "H", "I", "L", "V", "C1", "C2", "K", "stride", "pad",
                                    "is_causal", "pos_type", "csgu_kernel", "merge_kernel", "csgu_act", "use_macaron")] + \
-               [("ln_eps", f32), ("logits_f32", i32), ("logits_ld", i32), ("branch_overlap", i32), ("extra_layers", i32), ("layer_mixing", i32), ("csgu_linear", i32)]
+               [("ln_eps", f32), ("logits_f32", i32), ("logits_ld", i32), ("branch_overlap", i32), ("extra_layers", i32), ("layer_mixing", i32), ("csgu_linear", i32),
+                ("context_mode", i32), ("gate_blk", i32)]
 
 
 class LnRedDesc(C.Structure):
@@ -40,6 +41,14 @@ SIGNATURES = {
     "mi_gemm_bf16_v": [vp, i64, vp, i64, vp, i32, vp, i64, i32, vp, i64, f32, i32, i32, i32, i32, i32, i32, i32, vp],
     "mi_conv2d_cl_bf16_v": [vp, vp, vp, vp] + [i32] * 14 + [vp],
     "mi_conv2d_first_gelu": [vp, vp, vp, vp] + [i32] * 10 + [vp],
+    "mi_conv2d_first_geo": [vp, vp, vp, vp] + [i32] * 13 + [vp],
+    "mi_conv2d_first_gated_gelu": [vp, vp, vp, vp, vp, vp] + [i32] * 10 + [vp],
+    "mi_conv2d_cl_geo_bf16": [vp, vp, vp, vp] + [i32] * 15 + [vp],
+    "mi_gated_act_bf16": [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp],
+    "mi_im2col_cl_geo_bf16": [vp, vp] + [i32] * 12 + [vp],
+    "mi_col2im_cl_bf16": [vp, vp] + [i32] * 13 + [vp],
+    "mi_gated_act_bwd_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp],
+    "mi_conv2d_first_wgrad": [vp, vp, vp, vp] + [i32] * 12 + [vp],
     "mi_layernorm_chain": [vp, i64, vp, i32, vp, vp, f32, vp, i64, vp, vp, f32, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, vp],
     "mi_cast_f32_bf16": [vp, i64, vp, i64, i32, i32, vp],
     "mi_rotary_bf16": [vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, vp],

@@ -51,17 +51,23 @@ __device__ __forceinline__ float fast_erf(float x) {
 }
 // Every forward GELU of the path is rounded to bf16 (8 significant bits) right after it, and in the GEMM epilogues it is the critical path: 128 values
 // per lane, VALU-bound (17 instructions per value with the erf form above, two of them quarter-rate).  So the forward uses
-//     x * Phi(x),  Phi(x) ~= 1 / (1 + 2^(x * (c1 + c3 x^2 + c5 x^4)))      (c* = -log2(e) * minimax fit of logit(Phi), odd in x)
-// 8 instructions (mul, 2 fma, mul, exp2, add, rcp, mul); |error| <= 2.6e-5 absolute over all x (the usual tanh form: 4.7e-4), relative error <= 5e-4 for
+//     x * Phi(x),  Phi(x) ~= 1 / (1 + 2^(xc * (c1 + c3 xc^2 + c5 xc^4))),  xc = clamp(x, -10, 10)      (c* = -log2(e) * minimax fit of logit(Phi), odd in x)
+// 9 instructions (med3, mul, 2 fma, mul, exp2, add, rcp, mul); |error| <= 2.6e-5 absolute for |x| <= 10 (the usual tanh form: 4.7e-4), relative error <= 5e-4 for
 // x > -2 — below a quarter of a bf16 half-ulp wherever |GELU| > 0.02 — and values in the negative tail (|GELU| < 0.016) within 2.6e-5 of exact.
-// Saturates cleanly: x -> +inf: 2^-inf = 0 -> x; x -> -inf: rcp(inf) = 0 -> -0.  The backward keeps the exact derivative (fast_erf).
+// The clamp is what makes it total: the quintic's x^5 coefficient has the opposite sign of the others, so the un-clamped exponent turns around at |x| ~ 11.1
+// (GELU(12) came out as 9e-12, GELU(-12) as -12).  At |xc| = 10 the exponent is -+28.5, i.e. Phi = 1 - 3e-9 / 3e-9: beyond it the result is x * Phi(+-10)
+// = x resp. -0 to fp32 precision, +-inf included (x = -inf: -inf * 2.6e-9 = -inf is avoided by the select below).  The backward keeps the exact derivative (fast_erf).
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float x2 = x * x;
+    const float xc = __builtin_amdgcn_fmed3f(x, -10.0f, 10.0f);
+    const float x2 = xc * xc;
     float p = fmaf(x2, 1.01426783e-3f, -1.06775756e-1f);          // -log2(e) * (-7.03036837e-4, 7.40113137e-2)
     p = fmaf(p, x2, -2.30112135f);                                //  -log2(e) * 1.59501574
-    const float e = __builtin_amdgcn_exp2f(p * x);
-    return x * __builtin_amdgcn_rcpf(1.0f + e);
+    const float e = __builtin_amdgcn_exp2f(p * xc);
+    const float r = x * __builtin_amdgcn_rcpf(1.0f + e);
+    return x < -10.0f ? -0.0f : r;                                // erf-GELU(x <= -10) = -0 to fp32 precision (|x Phi(x)| < 8e-23); also keeps -inf from producing -inf * tiny
 }
+
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }      // x -> -inf: rcp(inf) = 0;  x -> +inf: rcp(1) = 1
 
 // GPT-2's "gelu_new" (tanh form; transformers activations.NewGELUActivation), used by the decoder MLP
 __device__ __forceinline__ float gelu_tanh(float x) {

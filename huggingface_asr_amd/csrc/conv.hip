@@ -13,17 +13,20 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------ conv2d_first
-// one thread = one output position x 8 consecutive channels; 32 threads cover C=256 (generic C%8==0)
+// one thread = one output position x 8 consecutive channels; 32 threads cover C=256 (generic C%8==0).  General geometry: (KH, KW) taps,
+// strides (st, sf), pads (pad_t, pad_f) — the gate conv of GatedConv2dShared is (12,3) / (8,2) / (4,1) (extractors.py:41-47).
+// ACT: 1 = GELU (the layer's activation), 0 = raw pre-activation (the operands of mi_gated_act_bf16).
+template <int ACT>
 __global__ __launch_bounds__(256) void conv2d_first_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, bf16_t* __restrict__ out,
-                                                            int B, int T, int F, int C, int K, int stride, int pad_t, int pad_f,
+                                                            int B, int T, int F, int C, int KH, int KW, int st, int sf, int pad_t, int pad_f,
                                                             int T1, int F1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sw = reinterpret_cast<float*>(smem);          // [K*K][C]  (tap-major so 8 channels are contiguous)
-    float* sb = sw + K * K * C;                          // [C]
-    for (int i = threadIdx.x; i < K * K * C; i += blockDim.x) {
+    float* sw = reinterpret_cast<float*>(smem);          // [KH*KW][C]  (tap-major so 8 channels are contiguous)
+    float* sb = sw + KH * KW * C;                        // [C]
+    for (int i = threadIdx.x; i < KH * KW * C; i += blockDim.x) {
         const int c = i % C, tap = i / C;
-        sw[i] = w[c * K * K + tap];
+        sw[i] = w[c * KH * KW + tap];
     }
     for (int i = threadIdx.x; i < C; i += blockDim.x) sb[i] = bias[i];
     __syncthreads();
@@ -38,21 +41,21 @@ __global__ __launch_bounds__(256) void conv2d_first_kernel(const float* __restri
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = sb[g * 8 + j];
-        for (int kh = 0; kh < K; ++kh) {
-            const int t = t1 * stride - pad_t + kh;
+        for (int kh = 0; kh < KH; ++kh) {
+            const int t = t1 * st - pad_t + kh;
             if (t < 0 || t >= T) continue;
-            for (int kw = 0; kw < K; ++kw) {
-                const int f = f1 * stride - pad_f + kw;
+            for (int kw = 0; kw < KW; ++kw) {
+                const int f = f1 * sf - pad_f + kw;
                 if (f < 0 || f >= F) continue;
                 const float xv = x[((long)b * T + t) * F + f];
-                const float* wp = sw + (kh * K + kw) * C + g * 8;
+                const float* wp = sw + (kh * KW + kw) * C + g * 8;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, wp[j], acc[j]);
             }
         }
         bf16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = f2bf(gelu_erf(acc[j]));
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(ACT ? gelu_erf(acc[j]) : acc[j]);
         *reinterpret_cast<bf16x8*>(out + pos * C + g * 8) = o;
     }
 }
@@ -96,6 +99,75 @@ __global__ __launch_bounds__(256) void conv2d_first3_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = f2bf(gelu_erf(acc[j]));
         *reinterpret_cast<bf16x8*>(out + (long)pos * C + g * 8) = o;
+    }
+}
+
+// GatedConv2d (extractors.py:23-32) as the first layer, 3x3: out = GELU((conv(x) + b) * sigmoid(gate(x) + bg)) — two filter banks over the same nine
+// input samples.  A thread owns 4 output channels (2 x 36 taps + 8 biases in registers) and walks output positions.
+__global__ __launch_bounds__(256) void conv2d_first3_gated_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                   const float* __restrict__ gw, const float* __restrict__ gbias, bf16_t* __restrict__ out,
+                                                                   int B, int T, int F, int C, int stride, int pad_t, int pad_f, int T1, int F1) {
+    const int cg = C >> 2, ppb = 256 / cg;
+    const int g = threadIdx.x % cg, pl = threadIdx.x / cg;
+    float wr[9][4], gr[9][4], br[4], gb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        br[j] = bias[g * 4 + j]; gb[j] = gbias[g * 4 + j];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) { wr[tap][j] = w[(g * 4 + j) * 9 + tap]; gr[tap][j] = gw[(g * 4 + j) * 9 + tap]; }
+    }
+    const int total = B * T1 * F1;                       // < 2^31 (checked by the launcher)
+    if (pl < ppb)
+    for (int pos = blockIdx.x * ppb + pl; pos < total; pos += gridDim.x * ppb) {
+        const int bt = pos / F1;
+        const int f1 = pos - bt * F1;
+        const int b = bt / T1;
+        const int t1 = bt - b * T1;
+        float acc[4], gacc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] = br[j]; gacc[j] = gb[j]; }
+        const float* xb = x + (long)b * T * F;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int t = t1 * stride - pad_t + kh;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int f = f1 * stride - pad_f + kw;
+                const float xv = (t >= 0 && t < T && f >= 0 && f < F) ? xb[(long)t * F + f] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[j] = fmaf(xv, wr[kh * 3 + kw][j], acc[j]); gacc[j] = fmaf(xv, gr[kh * 3 + kw][j], gacc[j]); }
+            }
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = f2bf(gelu_erf(acc[j] * sigmoid_f(gacc[j])));
+        *reinterpret_cast<bf16x4*>(out + (long)pos * C + g * 4) = o;
+    }
+}
+
+// out[(b,t,f), c] = GELU(z[(b,t,f), zc(c)] * sigmoid(g[(b, t / share, f), gc(c)])): the product + activation of the context-aware Conv2d layers
+// (extractors.py:31-32 share = 1; :49-54 share = 4: one gate row per four output time steps) applied to raw conv outputs.
+// `blk`: the conv / gate columns of one row are interleaved in blocks of `blk` channels — zc(c) = (c / blk) * 2 blk + c % blk, gc(c) = zc(c) + blk —
+// when both come out of ONE stacked GEMM (z == g, the packing of the fused implicit-GEMM epilogue); blk = 0: two separate tensors, plain columns.
+__global__ __launch_bounds__(256) void gated_act_kernel(const bf16_t* __restrict__ z, long ldz, const bf16_t* __restrict__ g, long ldg, bf16_t* __restrict__ out, long ldo,
+                                                         int B, int T, int Fq, int C, int share, int blk) {
+    const int c8 = C >> 3;
+    const long total = (long)B * T * Fq * c8;
+    const int Tg = T / share;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cc = (int)(i % c8) * 8;
+        const long row = i / c8;
+        const int f = (int)(row % Fq);
+        const long bt = row / Fq;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const long grow = ((long)b * Tg + t / share) * Fq + f;
+        const int zc = blk ? (cc / blk) * 2 * blk + cc % blk : cc;
+        const bf16x8 zv = *reinterpret_cast<const bf16x8*>(z + row * ldz + zc);
+        const bf16x8 gv = *reinterpret_cast<const bf16x8*>(g + grow * ldg + (blk ? zc + blk : cc));
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(gelu_erf(bf2f(zv[j]) * sigmoid_f(bf2f(gv[j]))));
+        *reinterpret_cast<bf16x8*>(out + row * ldo + cc) = o;
     }
 }
 
@@ -328,8 +400,56 @@ extern "C" int mi_conv2d_first_gelu(const float* x, const float* w, const float*
     const long total = (long)B * T1 * F1 * (C / 8);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     const size_t lds = (size_t)(K * K * C + C) * sizeof(float);
-    hipLaunchKernelGGL(conv2d_first_kernel, dim3(grid), dim3(256), lds, stream, x, w, bias, (bf16_t*)out_cl_bf16,
-                       B, T, F, C, K, stride, pad_t, pad_f, T1, F1);
+    hipLaunchKernelGGL(conv2d_first_kernel<1>, dim3(grid), dim3(256), lds, stream, x, w, bias, (bf16_t*)out_cl_bf16,
+                       B, T, F, C, K, K, stride, stride, pad_t, pad_f, T1, F1);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// Conv2d(1 -> C) of general geometry over the (B,T,F) features -> channels-last (B,T1,F1,C) bf16; act: 1 GELU, 0 raw (pre-activation).
+// The raw form feeds mi_gated_act_bf16 (conv and gate operands of the context-aware front ends, extractors.py:23-54).
+extern "C" int mi_conv2d_first_geo(const float* x, const float* w, const float* bias, void* out_cl_bf16, int B, int T, int F, int C,
+                                   int KH, int KW, int stride_t, int stride_f, int pad_t, int pad_f, int T1, int F1, int act, hipStream_t stream) {
+    MI_ENTER();
+    if (B <= 0 || T <= 0 || F <= 0 || C <= 0 || (C % 8) != 0 || KH <= 0 || KW <= 0 || KH * KW > 64 || stride_t <= 0 || stride_f <= 0 || T1 <= 0 || F1 <= 0) return MI_ERR_ARG;
+    if ((T1 - 1) * stride_t - pad_t >= T || (F1 - 1) * stride_f - pad_f >= F) return MI_ERR_ARG;      // every window must start inside the input
+    const size_t lds = (size_t)(KH * KW * C + C) * sizeof(float);
+    if (lds > 64 * 1024) return MI_ERR_UNSUPPORTED;
+    const long total = (long)B * T1 * F1 * (C / 8);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (act) hipLaunchKernelGGL(conv2d_first_kernel<1>, dim3(grid), dim3(256), lds, stream, x, w, bias, (bf16_t*)out_cl_bf16, B, T, F, C, KH, KW, stride_t, stride_f, pad_t, pad_f, T1, F1);
+    else hipLaunchKernelGGL(conv2d_first_kernel<0>, dim3(grid), dim3(256), lds, stream, x, w, bias, (bf16_t*)out_cl_bf16, B, T, F, C, KH, KW, stride_t, stride_f, pad_t, pad_f, T1, F1);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// GatedConv2d first layer, fused (3x3 only): out = GELU((conv + b) * sigmoid(gate + bg)) -> channels-last bf16.  MI_ERR_UNSUPPORTED for other shapes:
+// the caller then runs the two raw convs + mi_gated_act_bf16.
+extern "C" int mi_conv2d_first_gated_gelu(const float* x, const float* w, const float* bias, const float* gw, const float* gbias, void* out_cl_bf16,
+                                          int B, int T, int F, int C, int K, int stride, int pad_t, int pad_f, int T1, int F1, hipStream_t stream) {
+    MI_ENTER();
+    if (B <= 0 || T <= 0 || F <= 0 || C <= 0 || T1 <= 0 || F1 <= 0) return MI_ERR_ARG;
+    const int cgs = C / 4;
+    if (K != 3 || (C % 4) != 0 || cgs > 256 || (long)B * T1 * F1 >= (1L << 31) - 256L * 8192) return MI_ERR_UNSUPPORTED;
+    const long npos = (long)B * T1 * F1;
+    const int ppb = 256 / cgs;
+    const long nb = (npos + ppb - 1) / ppb;
+    hipLaunchKernelGGL(conv2d_first3_gated_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, stream, x, w, bias, gw, gbias,
+                       (bf16_t*)out_cl_bf16, B, T, F, C, stride, pad_t, pad_f, T1, F1);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// out (B*T*Fq, C) = GELU(z * sigmoid(gate)), gate row = (b, t / share, f); see gated_act_kernel for `blk`.  T % share == 0 (the reference's view, extractors.py:52).
+extern "C" int mi_gated_act_bf16(const void* z, long ldz, const void* g, long ldg, void* out, long ldo, int B, int T, int Fq, int C, int share, int blk,
+                                 hipStream_t stream) {
+    MI_ENTER();
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (B <= 0 || T <= 0 || Fq <= 0 || C <= 0 || (C % 8) != 0 || share <= 0 || (T % share) != 0 || blk < 0 || (blk && ((blk % 8) != 0 || (C % blk) != 0))) return MI_ERR_ARG;
+    if ((ldz % 8) || (ldg % 8) || (ldo % 8) || !al16(z) || !al16(g) || !al16(out)) return MI_ERR_ARG;
+    const long blocks = ((long)B * T * Fq * (C / 8) + 255) / 256;
+    hipLaunchKernelGGL(gated_act_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, stream, (const bf16_t*)z, ldz, (const bf16_t*)g, ldg,
+                       (bf16_t*)out, ldo, B, T, Fq, C, share, blk);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void dw_partial_reduce_kernel(const float* __r
 // ------------------------------------------------------------------------------------------------ im2col (channels-last)
 // in (B,Tin,Fin,Cin) bf16 -> col (B*Tout*Fout, KH*KW*Cin) bf16, k = (kh*KW + kw)*Cin + c  (the A operand of conv2 made explicit)
 __global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ col, int B, int Tin, int Fin,
-                                                      int Cin, int KH, int KW, int stride, int pad_t, int pad_f, int Tout, int Fout) {
+                                                      int Cin, int KH, int KW, int stride, int stride_f, int pad_t, int pad_f, int Tout, int Fout) {
     const int c8 = Cin / 8;
     const long total = (long)B * Tout * Fout * KH * KW * c8;
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ 
         const int to = (int)(r % Tout);
         const int b = (int)(r / Tout);
         const int kh = tap / KW, kw = tap % KW;
-        const int ti = to * stride - pad_t + kh, fi = fo * stride - pad_f + kw;
+        const int ti = to * stride - pad_t + kh, fi = fo * stride_f - pad_f + kw;
         bf16x8 v = zero8;
         if (ti >= 0 && ti < Tin && fi >= 0 && fi < Fin)
             v = *reinterpret_cast<const bf16x8*>(in + (((long)b * Tin + ti) * Fin + fi) * Cin + cc * 8);
@@ -562,7 +562,198 @@ extern "C" int mi_im2col_cl_bf16(const void* in, void* col, int B, int Tin, int 
     if (B <= 0 || Cin <= 0 || (Cin % 8) != 0 || Tout <= 0 || Fout <= 0) return MI_ERR_ARG;
     const long total = (long)B * Tout * Fout * KH * KW * (Cin / 8);
     hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total, 65536)), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)col, B, Tin, Fin, Cin, KH, KW,
-                       stride, pad_t, pad_f, Tout, Fout);
+                       stride, stride, pad_t, pad_f, Tout, Fout);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// im2col with separate time / frequency strides (the gate conv of GatedConv2dShared: (12,3) / (8,2) / (4,1), extractors.py:41-47)
+extern "C" int mi_im2col_cl_geo_bf16(const void* in, void* col, int B, int Tin, int Fin, int Cin, int KH, int KW, int stride_t, int stride_f, int pad_t,
+                                     int pad_f, int Tout, int Fout, hipStream_t st) {
+    MI_ENTER();
+    if (B <= 0 || Cin <= 0 || (Cin % 8) != 0 || Tout <= 0 || Fout <= 0 || stride_t <= 0 || stride_f <= 0) return MI_ERR_ARG;
+    const long total = (long)B * Tout * Fout * KH * KW * (Cin / 8);
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total, 65536)), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)col, B, Tin, Fin, Cin, KH, KW,
+                       stride_t, stride_f, pad_t, pad_f, Tout, Fout);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ context-aware front ends (extractors.py:23-65): backward pieces
+// col2im gather: din[(b,ti,fi), c] (+)= sum over the taps (kh,kw) whose window (to,fo) covers (ti,fi) of dcol[(b,to,fo), (kh*KW + kw)*Cin + c]
+namespace {
+__global__ __launch_bounds__(256) void col2im_kernel(const bf16_t* __restrict__ dcol, bf16_t* __restrict__ din, int B, int Tin, int Fin, int Cin, int KH, int KW,
+                                                      int st_t, int st_f, int pad_t, int pad_f, int Tout, int Fout, int accumulate) {
+    const int c8 = Cin / 8;
+    const long total = (long)B * Tin * Fin * c8;
+    const long ldcol = (long)KH * KW * Cin;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cc = (int)(i % c8) * 8;
+        long r = i / c8;
+        const int fi = (int)(r % Fin); r /= Fin;
+        const int ti = (int)(r % Tin);
+        const int b = (int)(r / Tin);
+        float a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = 0.f;
+        for (int kh = 0; kh < KH; ++kh) {
+            const int nt = ti + pad_t - kh;
+            if (nt < 0 || (nt % st_t) != 0) continue;
+            const int to = nt / st_t;
+            if (to >= Tout) continue;
+            for (int kw = 0; kw < KW; ++kw) {
+                const int nf = fi + pad_f - kw;
+                if (nf < 0 || (nf % st_f) != 0) continue;
+                const int fo = nf / st_f;
+                if (fo >= Fout) continue;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(dcol + (((long)b * Tout + to) * Fout + fo) * ldcol + (long)(kh * KW + kw) * Cin + cc);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] += bf2f(v[j]);
+            }
+        }
+        bf16x8* dst = reinterpret_cast<bf16x8*>(din + i * 8);
+        bf16x8 o;
+        if (accumulate) {
+            const bf16x8 old = *dst;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += bf2f(old[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(a[j]);
+        *dst = o;
+    }
+}
+
+// backward of mi_gated_act_bf16: y = z * sigmoid(g), out = GELU(y).  One thread per (gate row, 8 channels); it walks the `share` conv rows of its gate row:
+//   dy = dout * GELU'(y);  dz = dy * sigmoid(g);  dg = sum over the shared rows of dy * z * sigmoid(g) (1 - sigmoid(g))
+__global__ __launch_bounds__(256) void gated_act_bwd_kernel(const bf16_t* __restrict__ dout, long lddo, const bf16_t* __restrict__ z, long ldz, const bf16_t* __restrict__ g, long ldg,
+                                                             bf16_t* __restrict__ dz, long lddz, bf16_t* __restrict__ dg, long lddg, int B, int T, int Fq, int C, int share) {
+    const int c8 = C >> 3, Tg = T / share;
+    const long total = (long)B * Tg * Fq * c8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cc = (int)(i % c8) * 8;
+        const long grow = i / c8;
+        const int f = (int)(grow % Fq);
+        const long bt = grow / Fq;
+        const int tg = (int)(bt % Tg), b = (int)(bt / Tg);
+        const bf16x8 gv = *reinterpret_cast<const bf16x8*>(g + grow * ldg + cc);
+        float sg[8], dga[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sg[j] = sigmoid_f(bf2f(gv[j])); dga[j] = 0.f; }
+        for (int s2 = 0; s2 < share; ++s2) {
+            const long row = ((long)b * T + tg * share + s2) * Fq + f;
+            const bf16x8 zv = *reinterpret_cast<const bf16x8*>(z + row * ldz + cc);
+            const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dout + row * lddo + cc);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float zz = bf2f(zv[j]);
+                const float dy = bf2f(dv[j]) * gelu_erf_grad(zz * sg[j]);
+                o[j] = f2bf(dy * sg[j]);
+                dga[j] = fmaf(dy * zz, sg[j] * (1.f - sg[j]), dga[j]);
+            }
+            *reinterpret_cast<bf16x8*>(dz + row * lddz + cc) = o;
+        }
+        bf16x8 og;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) og[j] = f2bf(dga[j]);
+        *reinterpret_cast<bf16x8*>(dg + grow * lddg + cc) = og;
+    }
+}
+
+// weight / bias gradient of a Conv2d(1 -> C) of general geometry from the gradient of its raw output: dw[c][tap] += sum_pos dy[pos][c] * x[window(pos)][tap], db[c] += sum_pos dy[pos][c].
+// A thread owns two channels and all NT taps (2 NT + 2 accumulators) and walks output positions; per-block LDS reduction, one global atomic per (channel, tap) and block.
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db,
+                                                           int B, int T, int F, int C, int st_t, int st_f, int pad_t, int pad_f, int T1, int F1) {
+    constexpr int NT = KH * KW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sacc = reinterpret_cast<float*>(smem);        // [C][NT + 1]
+    for (int i = threadIdx.x; i < C * (NT + 1); i += 256) sacc[i] = 0.f;
+    __syncthreads();
+    const int cp = C >> 1, ppb = 256 / cp;
+    const int g = threadIdx.x % cp, pl = threadIdx.x / cp;
+    float a0[NT], a1[NT], s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) { a0[k] = 0.f; a1[k] = 0.f; }
+    const long total = (long)B * T1 * F1;
+    if (pl < ppb)
+    for (long pos = (long)blockIdx.x * ppb + pl; pos < total; pos += (long)gridDim.x * ppb) {
+        const int f1 = (int)(pos % F1);
+        const int t1 = (int)((pos / F1) % T1);
+        const int b = (int)(pos / ((long)F1 * T1));
+        const bf16x2 d = *reinterpret_cast<const bf16x2*>(dy + pos * C + g * 2);
+        const float d0 = bf2f(d[0]), d1 = bf2f(d[1]);
+        s0 += d0; s1 += d1;
+        const float* xb = x + (long)b * T * F;
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+            const int t = t1 * st_t - pad_t + kh;
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw) {
+                const int f = f1 * st_f - pad_f + kw;
+                const float xv = (t >= 0 && t < T && f >= 0 && f < F) ? xb[(long)t * F + f] : 0.f;
+                a0[kh * KW + kw] = fmaf(d0, xv, a0[kh * KW + kw]);
+                a1[kh * KW + kw] = fmaf(d1, xv, a1[kh * KW + kw]);
+            }
+        }
+    }
+    if (pl < ppb) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) { atomicAdd(sacc + (g * 2) * (NT + 1) + k, a0[k]); atomicAdd(sacc + (g * 2 + 1) * (NT + 1) + k, a1[k]); }
+        atomicAdd(sacc + (g * 2) * (NT + 1) + NT, s0); atomicAdd(sacc + (g * 2 + 1) * (NT + 1) + NT, s1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * (NT + 1); i += 256) {
+        const int ch = i / (NT + 1), k = i % (NT + 1);
+        if (k == NT) atomic_add_f32(db + ch, sacc[i]);
+        else atomic_add_f32(dw + ch * NT + k, sacc[i]);
+    }
+}
+}  // namespace
+
+// din (B,Tin,Fin,Cin) bf16 (+)= col2im(dcol (B*Tout*Fout, KH*KW*Cin) bf16): the input gradient of an implicit-GEMM conv from the gradient of its im2col operand
+extern "C" int mi_col2im_cl_bf16(const void* dcol, void* din, int B, int Tin, int Fin, int Cin, int KH, int KW, int stride_t, int stride_f, int pad_t, int pad_f,
+                                 int Tout, int Fout, int accumulate, hipStream_t st) {
+    MI_ENTER();
+    if (B <= 0 || Cin <= 0 || (Cin % 8) != 0 || Tin <= 0 || Fin <= 0 || Tout <= 0 || Fout <= 0 || stride_t <= 0 || stride_f <= 0 || KH <= 0 || KW <= 0) return MI_ERR_ARG;
+    const long total = (long)B * Tin * Fin * (Cin / 8);
+    hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total, 65536)), dim3(256), 0, st, (const bf16_t*)dcol, (bf16_t*)din, B, Tin, Fin, Cin, KH, KW, stride_t, stride_f,
+                       pad_t, pad_f, Tout, Fout, accumulate);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// backward of mi_gated_act_bf16 (plain column layout: z / dz (B*T*Fq, C), g / dg (B*(T/share)*Fq, C))
+extern "C" int mi_gated_act_bwd_bf16(const void* dout, long lddo, const void* z, long ldz, const void* g, long ldg, void* dz, long lddz, void* dg, long lddg,
+                                     int B, int T, int Fq, int C, int share, hipStream_t st) {
+    MI_ENTER();
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (B <= 0 || T <= 0 || Fq <= 0 || C <= 0 || (C % 8) != 0 || share <= 0 || (T % share) != 0) return MI_ERR_ARG;
+    if ((lddo % 8) || (ldz % 8) || (ldg % 8) || (lddz % 8) || (lddg % 8) || !al16(dout) || !al16(z) || !al16(g) || !al16(dz) || !al16(dg)) return MI_ERR_ARG;
+    const long total = (long)B * (T / share) * Fq * (C / 8);
+    hipLaunchKernelGGL(gated_act_bwd_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, st, (const bf16_t*)dout, lddo, (const bf16_t*)z, ldz, (const bf16_t*)g, ldg,
+                       (bf16_t*)dz, lddz, (bf16_t*)dg, lddg, B, T, Fq, C, share);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// x (B,T,F) f32, dy (B,T1,F1,C) bf16 = gradient of the RAW output of a Conv2d(1 -> C, (KH,KW), strides, pads) -> dw (C, KH*KW) +=, db (C) +=.  (KH,KW) = (3,3) or (12,3).
+extern "C" int mi_conv2d_first_wgrad(const float* x, const void* dy, float* dw, float* db, int B, int T, int F, int C, int KH, int KW, int stride_t, int stride_f,
+                                     int pad_t, int pad_f, int T1, int F1, hipStream_t st) {
+    MI_ENTER();
+    if (B <= 0 || C <= 0 || (C % 2) != 0 || C > 512 || T1 <= 0 || F1 <= 0 || stride_t <= 0 || stride_f <= 0) return MI_ERR_ARG;
+    const int cp = C / 2, ppb = 256 / cp;
+    if (ppb < 1) return MI_ERR_UNSUPPORTED;
+    const long npos = (long)B * T1 * F1;
+    const long nb = (npos + ppb - 1) / ppb;
+    const unsigned grid = (unsigned)(nb < 1024 ? nb : 1024);
+    const size_t lds = (size_t)C * (KH * KW + 1) * sizeof(float);
+    if (KH == 3 && KW == 3)
+        hipLaunchKernelGGL((conv1_wgrad_kernel<3, 3>), dim3(grid), dim3(256), lds, st, x, (const bf16_t*)dy, dw, db, B, T, F, C, stride_t, stride_f, pad_t, pad_f, T1, F1);
+    else if (KH == 12 && KW == 3)
+        hipLaunchKernelGGL((conv1_wgrad_kernel<12, 3>), dim3(grid), dim3(256), lds, st, x, (const bf16_t*)dy, dw, db, B, T, F, C, stride_t, stride_f, pad_t, pad_f, T1, F1);
+    else return MI_ERR_UNSUPPORTED;
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

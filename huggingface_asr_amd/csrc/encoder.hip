@@ -19,7 +19,8 @@
 namespace {
 
 enum G { G_CONV1_W, G_CONV1_B, G_CONV2_W, G_CONV2_B, G_FEOUT_W, G_FEOUT_B, G_FP_LN_G, G_FP_LN_B, G_FP_W, G_FP_B,
-         G_ENC_LN_G, G_ENC_LN_B, G_HEAD_W, G_HEAD_B, G_MIX_W /* per_layer_weights (L+1) f32, bestrq.py:202-205 */ };
+         G_ENC_LN_G, G_ENC_LN_B, G_HEAD_W, G_HEAD_B, G_MIX_W /* per_layer_weights (L+1) f32, bestrq.py:202-205 */,
+         G_GATE1_W, G_GATE1_B, G_GATE2_W, G_GATE2_B /* gate filters of the context-aware front ends (extractors.py:23-54) */ };
 enum LS { FF1_LN_G, FF1_LN_B, FF1_W1, FF1_B1, FF1_W2, FF1_B2,
           ATT_LN_G, ATT_LN_B, ATT_WQK, ATT_BQK, ATT_WV, ATT_BV, ATT_WO, ATT_BO, ATT_WPOS, ATT_U, ATT_V,
           MLP_LN_G, MLP_LN_B, MLP_W1, MLP_B1, CSGU_LN_G, CSGU_LN_B, CSGU_W, CSGU_B, MLP_W2, MLP_B2,
@@ -47,6 +48,7 @@ struct Carver {
 struct Ws {
     bf16_t *act1, *act2, *a0, *a1, *a2, *a1r, *h, *qk, *vt, *ctx, *cat, *m2, *s, *hid;
     bf16_t *cv, *lin;         // csgu_use_linear_after_conv: the CSGU conv output and the Linear's output
+    bf16_t *z1, *g1, *z2, *g2;   // context-aware front ends: raw conv / gate outputs of the un-fused forms
     float *feo, *x, *stats;
     float *mixed, *lh, *sw;   // fine-tuning head: weighted sum of the hidden states, fp32 copy of the last one, softmax(per_layer_weights)
     int* lens;   // [inner(B) | outer(B)]
@@ -60,6 +62,20 @@ Ws carve(const mi_ebf_config& c, void* base) {
     const size_t M = d.M;
     w.act1 = (bf16_t*)k.take((size_t)c.B * d.T1 * d.F1 * c.C1 * 2);
     w.act2 = (bf16_t*)k.take((size_t)c.B * d.T2 * d.F2 * c.C2 * 2);
+    w.z1 = w.g1 = w.z2 = w.g2 = nullptr;
+    if (c.context_mode == 1) {            // the un-fused fallbacks of GatedConv2d: layer 1 [conv | gate] as two tensors, layer 2 as one stacked (M2, 2*C2) GEMM output
+        const bool fused1 = c.K == 3 && (c.C1 % 4) == 0 && c.C1 / 4 <= 256 && (long)c.B * d.T1 * d.F1 < (1L << 31) - 256L * 8192;      // = mi_conv2d_first_gated_gelu's own condition
+        if (!fused1) {
+            w.z1 = (bf16_t*)k.take((size_t)c.B * d.T1 * d.F1 * c.C1 * 2);
+            w.g1 = (bf16_t*)k.take((size_t)c.B * d.T1 * d.F1 * c.C1 * 2);
+        }
+        w.z2 = (bf16_t*)k.take((size_t)c.B * d.T2 * d.F2 * 2 * c.C2 * 2);
+    } else if (c.context_mode == 2) {     // GatedConv2dShared: the gate has a quarter of the conv's time steps
+        w.z1 = (bf16_t*)k.take((size_t)c.B * d.T1 * d.F1 * c.C1 * 2);
+        w.g1 = (bf16_t*)k.take((size_t)c.B * (d.T1 / 4 + 1) * d.F1 * c.C1 * 2);
+        w.z2 = (bf16_t*)k.take((size_t)c.B * d.T2 * d.F2 * c.C2 * 2);
+        w.g2 = (bf16_t*)k.take((size_t)c.B * (d.T2 / 4 + 1) * d.F2 * c.C2 * 2);
+    }
     w.feo = (float*)k.take(M * c.d * 4);
     w.x = (float*)k.take(M * c.d * 4);
     w.a0 = (bf16_t*)k.take(M * c.d * 2);
@@ -229,9 +245,40 @@ extern "C" int mi_ebf_forward_hs(const mi_ebf_config* cfg, const void* const* we
 
     // --- Conv2d sub-sampling (extractors.py:110-113)
     const int pl = c.is_causal ? 2 * c.pad : c.pad;
-    RUN(mi_conv2d_first_gelu(feats, Gf(G_CONV1_W), Gf(G_CONV1_B), w.act1, c.B, c.T, c.F, c.C1, c.K, c.stride, pl, pl, D.T1, D.F1, st));
-    RUN(mi_conv2d_cl_bf16(w.act1, Gw(G_CONV2_W), Gf(G_CONV2_B), w.act2, c.B, D.T1, D.F1, c.C1, c.C2, c.K, c.K, c.stride, pl, pl,
-                          D.T2, D.F2, 1, st));
+    if (c.context_mode < 0 || c.context_mode > 2 || (c.context_mode && c.is_causal)) return MI_ERR_ARG;      // the causal stack is CausalConv2d whatever the field says (extractors.py:74-81)
+    if (c.context_mode == 0) {
+        RUN(mi_conv2d_first_gelu(feats, Gf(G_CONV1_W), Gf(G_CONV1_B), w.act1, c.B, c.T, c.F, c.C1, c.K, c.stride, pl, pl, D.T1, D.F1, st));
+        RUN(mi_conv2d_cl_bf16(w.act1, Gw(G_CONV2_W), Gf(G_CONV2_B), w.act2, c.B, D.T1, D.F1, c.C1, c.C2, c.K, c.K, c.stride, pl, pl,
+                              D.T2, D.F2, 1, st));
+    } else if (c.context_mode == 1) {
+        // GatedConv2d (extractors.py:23-32): GELU(conv * sigmoid(gate)), both layers.  Layer 1: two filter banks in one VALU kernel; layer 2: conv and gate rows in ONE
+        // implicit GEMM with the product in its epilogue.  Shapes the fused kernels do not take run raw convs + mi_gated_act_bf16.
+        if (c.gate_blk <= 0 || (c.C2 % c.gate_blk) != 0) return MI_ERR_ARG;
+        int rc = mi_conv2d_first_gated_gelu(feats, Gf(G_CONV1_W), Gf(G_CONV1_B), Gf(G_GATE1_W), Gf(G_GATE1_B), w.act1, c.B, c.T, c.F, c.C1, c.K, c.stride, pl, pl, D.T1, D.F1, st);
+        if (rc == MI_ERR_UNSUPPORTED) {
+            RUN(mi_conv2d_first_geo(feats, Gf(G_CONV1_W), Gf(G_CONV1_B), w.z1, c.B, c.T, c.F, c.C1, c.K, c.K, c.stride, c.stride, pl, pl, D.T1, D.F1, 0, st));
+            RUN(mi_conv2d_first_geo(feats, Gf(G_GATE1_W), Gf(G_GATE1_B), w.g1, c.B, c.T, c.F, c.C1, c.K, c.K, c.stride, c.stride, pl, pl, D.T1, D.F1, 0, st));
+            RUN(mi_gated_act_bf16(w.z1, c.C1, w.g1, c.C1, w.act1, c.C1, c.B, D.T1, D.F1, c.C1, 1, 0, st));
+        } else if (rc != MI_OK) return rc;
+        rc = c.gate_blk == 32 ? mi_conv2d_cl_geo_bf16(w.act1, Gw(G_CONV2_W), Gf(G_CONV2_B), w.act2, c.B, D.T1, D.F1, c.C1, c.C2, c.K, c.K, c.stride, c.stride, pl, pl, D.T2, D.F2, 1, 1, st)
+                              : MI_ERR_UNSUPPORTED;
+        if (rc == MI_ERR_UNSUPPORTED) {
+            RUN(mi_conv2d_cl_geo_bf16(w.act1, Gw(G_CONV2_W), Gf(G_CONV2_B), w.z2, c.B, D.T1, D.F1, c.C1, 2 * c.C2, c.K, c.K, c.stride, c.stride, pl, pl, D.T2, D.F2, 0, 0, st));
+            RUN(mi_gated_act_bf16(w.z2, 2 * c.C2, w.z2, 2 * c.C2, w.act2, c.C2, c.B, D.T2, D.F2, c.C2, 1, c.gate_blk, st));
+        } else if (rc != MI_OK) return rc;
+    } else {
+        // GatedConv2dShared (extractors.py:35-54): the gate conv is (4K, K) / stride (4s, s) / padding (4p, p); conv_out.view(B, C, -1, 4, F) * gate.unsqueeze(3) needs the
+        // conv's time axis divisible by 4 and a quarter of it to be the gate's — the reference raises otherwise, so does this
+        const int KH = 4 * c.K, sg = 4 * c.stride, pg = 4 * c.pad;
+        const int Tg1 = conv_out(c.T, KH, sg, 2 * pg), Tg2 = conv_out(D.T1, KH, sg, 2 * pg);
+        if ((D.T1 % 4) != 0 || Tg1 != D.T1 / 4 || (D.T2 % 4) != 0 || Tg2 != D.T2 / 4) return MI_ERR_ARG;
+        RUN(mi_conv2d_first_geo(feats, Gf(G_CONV1_W), Gf(G_CONV1_B), w.z1, c.B, c.T, c.F, c.C1, c.K, c.K, c.stride, c.stride, pl, pl, D.T1, D.F1, 0, st));
+        RUN(mi_conv2d_first_geo(feats, Gf(G_GATE1_W), Gf(G_GATE1_B), w.g1, c.B, c.T, c.F, c.C1, KH, c.K, sg, c.stride, pg, pl, Tg1, D.F1, 0, st));
+        RUN(mi_gated_act_bf16(w.z1, c.C1, w.g1, c.C1, w.act1, c.C1, c.B, D.T1, D.F1, c.C1, 4, 0, st));
+        RUN(mi_conv2d_cl_bf16(w.act1, Gw(G_CONV2_W), Gf(G_CONV2_B), w.z2, c.B, D.T1, D.F1, c.C1, c.C2, c.K, c.K, c.stride, pl, pl, D.T2, D.F2, 0, st));
+        RUN(mi_conv2d_cl_geo_bf16(w.act1, Gw(G_GATE2_W), Gf(G_GATE2_B), w.g2, c.B, D.T1, D.F1, c.C1, c.C2, KH, c.K, sg, c.stride, pg, pl, Tg2, D.F2, 0, 0, st));
+        RUN(mi_gated_act_bf16(w.z2, c.C2, w.g2, c.C2, w.act2, c.C2, c.B, D.T2, D.F2, c.C2, 4, 0, st));
+    }
     // (B,C,T',F') -> transpose -> flatten -> Linear: act2 is already (B*T', F'*C) with the weight columns permuted to match
     RUN(mi_gemm_bf16(w.act2, (long)D.F2 * c.C2, Gw(G_FEOUT_W), (long)D.F2 * c.C2, Gf(G_FEOUT_B), 1, w.feo, d, 1, nullptr, 0, 1.f, 0,
                      M, d, D.F2 * c.C2, 0, 0, st));

@@ -64,7 +64,9 @@ struct Ctx {
 // CONV: A is a channels-last activation (B, Tin, Fin, Cin), row m = (b, to, fo), k = (kh*KW + kw)*Cin + c with Cin % 64 == 0, so a K tile is one
 // tap and a 64-channel slice: the per-lane source row moves with the tap, rows that fall into the zero padding read a 16-B zero page.
 // OUT32: fp32 output (the CTC head) — N need not be a multiple of the tile: W rows beyond N are clamped, columns beyond N never stored.
-template <bool CONV, int ACT, bool OUT32 = false>     // ACT: 0 none, 1 erf-GELU, 2 tanh-GELU — compile-time, so the epilogue is straight-line code with many independent chains in flight
+// GATED (GatedConv2d as one GEMM, extractors.py:23-32): the W rows are packed [conv c0..c0+31 ; gate c0..c0+31] per 64, so a wave's 64 columns are 32 output channels
+// twice — accumulator columns j = 0,1 the conv, j = 2,3 the gate of the SAME channels in the same lane — and the epilogue writes act((conv + b) * sigmoid(gate + bg)) as (M, N/2).
+template <bool CONV, int ACT, bool OUT32 = false, bool GATED = false>     // ACT: 0 none, 1 erf-GELU, 2 tanh-GELU — compile-time, so the epilogue is straight-line code with many independent chains in flight
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
                     const int m = min(m0 + ra + prow, p.M - 1);
                     const int fo = m % p.Fout, to = (m / p.Fout) % p.Tout, b = m / (p.Fout * p.Tout);
                     c.cti[h][e] = to * p.stride - p.pad_t;
-                    c.cfi[h][e] = fo * p.stride - p.pad_f;
+                    c.cfi[h][e] = fo * p.stride_f - p.pad_f;
                     c.offA[h][e] = (unsigned)b * (unsigned)(p.Tin * p.Fin * p.Cin * 2) + lcA * 16;
                 } else {
                     c.offA[h][e] = (unsigned)min(m0 + ra + prow, p.M - 1) * (unsigned)(p.lda * 2) + lcA * 16;
@@ -277,6 +279,36 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
         b4[j] = (p.bias_mode == 1) ? *reinterpret_cast<const f32x4*>(p.bias + nb + j * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     const int prow = lane >> 3, pc = lane & 7;
     bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+    if constexpr (GATED) {
+        // 32 output channels per wave and row: 64-B rows through the wave-private region (128 rows x 64 B), out as 4 lanes x 16 B per row
+        const int ob = (n0 >> 1) + wc * 32;
+        const int r4 = lane >> 2, c4 = lane & 3;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = blk * 2 + ii;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f32x4 z = acc[i][j] + b4[j], g = acc[i][j + 2] + b4[j + 2];
+                    f32x4 v = f32x4{z.x * sigmoid_f(g.x), z.y * sigmoid_f(g.y), z.z * sigmoid_f(g.z), z.w * sigmoid_f(g.w)};
+                    if constexpr (ACT == 1) v = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+                    const bf16x4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+                    const int row = i * 16 + fr;
+                    *reinterpret_cast<bf16x4*>(reg + row * 64 + (((j * 2 + (fq >> 1)) ^ ((row >> 2) & 3)) << 4) + (fq & 1) * 8) = o;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = blk * 2; u < blk * 2 + 2; ++u) {
+                const int row = u * 16 + r4;
+                const uint4 v = *reinterpret_cast<const uint4*>(reg + row * 64 + ((c4 ^ ((row >> 2) & 3)) << 4));
+                const int m = m0 + wr * 128 + row;
+                if (m < p.M) *reinterpret_cast<uint4*>(C + (long)m * p.ldc + ob + c4 * 8) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) {
 #pragma unroll
@@ -651,6 +683,7 @@ bool gemm_8p_supported(const GemmArgs& a, bool conv) {
         if ((a.N % TB) != 0 || (a.ldc % 8) != 0) return false;
         if (a.bias_mode == 1 && ((uintptr_t)a.bias & 15)) return false;
     }
+    if (a.gated && (!conv || a.out_f32 || a.act != 1)) return false;
     if ((long)a.N * a.ldw * 2 >= (1l << 32)) return false;                                             // 32-bit source offsets
     if (conv) {
         if ((a.Cin % BK) != 0 || a.Fout <= 0 || a.Tout <= 0) return false;
@@ -675,6 +708,12 @@ int gemm_8p_launch(const GemmArgs& a, bool conv, hipStream_t stream) {
         static bool attr32 = false;
         if (!attr32) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF); attr32 = true; }
         hipLaunchKernelGGL((gemm8p_kernel<false, 0, true>), dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
+        return MI_OK;
+    }
+    if (a.gated) {
+        static bool attr_g = false;
+        if (!attr_g) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<true, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF); attr_g = true; }
+        hipLaunchKernelGGL((gemm8p_kernel<true, 1, false, true>), dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
         return MI_OK;
     }
     hipLaunchKernelGGL(kerns[conv ? 1 : 0][a.act], dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);

@@ -16,6 +16,11 @@ struct GemmArgs {
     // implicit im2col (CONV): A is a channels-last activation (B, Tin, Fin, Cin); row m = (b, to, fo);
     // k = (kh*KW + kw)*Cin + c
     int Tin, Fin, Cin, Tout, Fout, KW, stride, pad_t, pad_f;
+    int stride_f;                           // frequency-axis stride (`stride` is the time-axis one); the gate conv of GatedConv2dShared is (12,3) / (8,2) (extractors.py:41-47)
+    // GatedConv2d as ONE implicit GEMM (extractors.py:23-32): W holds the conv and gate filters interleaved in blocks of 32 output channels
+    // ([conv c0..c0+31 ; gate c0..c0+31] per 64 rows), N = 2 * Cout, and the epilogue writes act((conv + b) * sigmoid(gate + bg)) as (M, N / 2).
+    // Only the 256-wide phase kernel has that epilogue: unsupported shapes return MI_ERR_UNSUPPORTED (the caller runs the GEMM raw + mi_gated_act_bf16).
+    int gated;
 };
 
 // gemm_glds.hip; returns MI_ERR_UNSUPPORTED when the shape/alignment does not fit the fast path

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs p) {
             const int mm = aval[i] ? m : 0;
             const int fo = mm % p.Fout, to = (mm / p.Fout) % p.Tout, b = mm / (p.Fout * p.Tout);
             ati[i] = to * p.stride - p.pad_t;
-            afi[i] = fo * p.stride - p.pad_f;
+            afi[i] = fo * p.stride_f - p.pad_f;
             abase[i] = (long)b * p.Tin * p.Fin * p.Cin;
             aptr[i] = p.A;
         } else {
@@ -181,6 +181,15 @@ int launch(const GemmArgs& a, bool conv, hipStream_t stream) {
     if (!conv && ((a.lda % 8) != 0)) return MI_ERR_ARG;
     if ((a.ldw % 8) != 0) return MI_ERR_ARG;
     if (conv && (a.Cin % 8) != 0) return MI_ERR_ARG;
+    if (a.gated) {                        // fused gated epilogue: the 256-wide phase kernel or nothing (gemm_glds_supported routes eligible shapes to it)
+        if (!conv || a.act != 1 || (a.N % 256) != 0 || !gemm_8p_supported(a, true)) return MI_ERR_UNSUPPORTED;
+        const int slot = mi_profile_hook_begin(stream, 2.0 * a.M * a.N * a.K);
+        const int rc = gemm_8p_launch(a, true, stream);
+        if (slot >= 0) mi_profile_hook_end(slot, stream);
+        if (rc != MI_OK) return rc;
+        MI_CHECK_LAUNCH();
+        return MI_OK;
+    }
     if (gemm_glds_supported(a, conv)) {   // LDS-DMA pipelined fast path (gemm_glds.hip)
         const int slot = mi_profile_hook_begin(stream, 2.0 * a.M * a.N * a.K);     // the implicit-GEMM conv is a dense contraction too
         const int rc = gemm_glds_launch(a, conv, stream);
@@ -234,7 +243,7 @@ extern "C" int mi_conv2d_cl_bf16_v(const void* in, const void* weight, const flo
     a.bias = bias; a.bias_mode = bias ? 1 : 0;
     a.C = out; a.ldc = Cout; a.out_f32 = 0; a.resid = nullptr; a.ldr = 0; a.alpha = 1.f; a.act = act;
     a.M = B * Tout * Fout; a.N = Cout; a.K = KH * KW * Cin;
-    a.Tin = Tin; a.Fin = Fin; a.Cin = Cin; a.Tout = Tout; a.Fout = Fout; a.KW = KW; a.stride = stride;
+    a.Tin = Tin; a.Fin = Fin; a.Cin = Cin; a.Tout = Tout; a.Fout = Fout; a.KW = KW; a.stride = stride; a.stride_f = stride;
     a.pad_t = pad_t; a.pad_f = pad_f;
     return launch(a, true, stream);
 }
@@ -242,4 +251,25 @@ extern "C" int mi_conv2d_cl_bf16(const void* in, const void* weight, const float
                                  int B, int Tin, int Fin, int Cin, int Cout, int KH, int KW, int stride,
                                  int pad_t, int pad_f, int Tout, int Fout, int act, hipStream_t stream) {
     return mi_conv2d_cl_bf16_v(in, weight, bias, out, B, Tin, Fin, Cin, Cout, KH, KW, stride, pad_t, pad_f, Tout, Fout, act, 0, stream);
+}
+
+// mi_conv2d_cl_bf16 with separate time / frequency strides (the (12,3) / stride (8,2) / padding (4,1) gate conv of GatedConv2dShared, extractors.py:41-47) and,
+// with gated != 0, GatedConv2d as ONE implicit GEMM: `weight` (2*Cout, KH*KW*Cin) and `bias` (2*Cout) hold conv and gate interleaved in blocks of 32 channels
+// ([conv c0..c0+31 ; gate c0..c0+31]); out (B,Tout,Fout,Cout) = act((conv + b) * sigmoid(gate + bg)).  gated: act must be 1 (GELU), Cout % 128 == 0, Cin % 64 == 0;
+// anything else returns MI_ERR_UNSUPPORTED (run it with gated = 0, act = 0 on the same packing and mi_gated_act_bf16(blk = 32) behind it).
+extern "C" int mi_conv2d_cl_geo_bf16(const void* in, const void* weight, const float* bias, void* out,
+                                     int B, int Tin, int Fin, int Cin, int Cout, int KH, int KW, int stride_t, int stride_f,
+                                     int pad_t, int pad_f, int Tout, int Fout, int act, int gated, hipStream_t stream) {
+    MI_ENTER();
+    if (stride_t <= 0 || stride_f <= 0 || KH <= 0 || KW <= 0 || Tout <= 0 || Fout <= 0) return MI_ERR_ARG;
+    if ((long)(Tout - 1) * stride_t - pad_t >= Tin || (long)(Fout - 1) * stride_f - pad_f >= Fin) return MI_ERR_ARG;       // every window starts inside the input
+    GemmArgs a{};
+    const int Nw = gated ? 2 * Cout : Cout;
+    a.A = (const bf16_t*)in; a.lda = 0; a.W = (const bf16_t*)weight; a.ldw = (long)KH * KW * Cin;
+    a.bias = bias; a.bias_mode = bias ? 1 : 0;
+    a.C = out; a.ldc = Cout; a.out_f32 = 0; a.resid = nullptr; a.ldr = 0; a.alpha = 1.f; a.act = act;
+    a.M = B * Tout * Fout; a.N = Nw; a.K = KH * KW * Cin;
+    a.Tin = Tin; a.Fin = Fin; a.Cin = Cin; a.Tout = Tout; a.Fout = Fout; a.KW = KW; a.stride = stride_t; a.stride_f = stride_f;
+    a.pad_t = pad_t; a.pad_f = pad_f; a.gated = gated ? 1 : 0;
+    return launch(a, true, stream);
 }

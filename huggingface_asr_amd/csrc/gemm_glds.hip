@@ -65,7 +65,7 @@ __device__ __forceinline__ void gemm_glds_tile(const GemmArgs& p, int bid, char*
             if (CONV) {
                 const int fo = m % p.Fout, to = (m / p.Fout) % p.Tout, b = m / (p.Fout * p.Tout);
                 c_ti[q] = to * p.stride - p.pad_t;
-                c_fi[q] = fo * p.stride - p.pad_f;
+                c_fi[q] = fo * p.stride_f - p.pad_f;
                 c_lc[q] = lc * 8;
                 src[q] = p.A + (long)b * p.Tin * p.Fin * p.Cin;
             } else {

@@ -17,10 +17,10 @@ import os
 import torch
 
 from . import _lib
-from .shapes import conv_freq_out
+from .shapes import GATE_SHARE, context_mode, conv_freq_out
 
 G = dict(CONV1_W=0, CONV1_B=1, CONV2_W=2, CONV2_B=3, FEOUT_W=4, FEOUT_B=5, FP_LN_G=6, FP_LN_B=7, FP_W=8, FP_B=9,
-         ENC_LN_G=10, ENC_LN_B=11, HEAD_W=12, HEAD_B=13, MIX_W=14)
+         ENC_LN_G=10, ENC_LN_B=11, HEAD_W=12, HEAD_B=13, MIX_W=14, GATE1_W=15, GATE1_B=16, GATE2_W=17, GATE2_B=18)
 LS = {n: i for i, n in enumerate(
     ["FF1_LN_G", "FF1_LN_B", "FF1_W1", "FF1_B1", "FF1_W2", "FF1_B2",
      "ATT_LN_G", "ATT_LN_B", "ATT_WQK", "ATT_BQK", "ATT_WV", "ATT_BV", "ATT_WO", "ATT_BO", "ATT_WPOS", "ATT_U", "ATT_V",
@@ -37,7 +37,7 @@ def cfg_from_hf(config) -> dict:
     return dict(hidden_size=g("hidden_size"), num_hidden_layers=g("num_hidden_layers"), num_attention_heads=g("num_attention_heads"),
                 intermediate_size=g("intermediate_size"), conv_dim=list(g("conv_dim")), conv_kernel=list(g("conv_kernel")),
                 conv_stride=list(g("conv_stride")), conv_padding=list(g("conv_padding", [1] * len(g("conv_kernel")))),
-                vocab_size=g("vocab_size"), num_fbanks=g("num_fbanks", 80),
+                vocab_size=g("vocab_size"), num_fbanks=g("num_fbanks", 80), context_awareness_type=g("context_awareness_type", None),
                 position_embeddings_type=g("position_embeddings_type", "relative"), rotary_embedding_base=g("rotary_embedding_base", 10000),
                 csgu_kernel_size=g("csgu_kernel_size", 31), merge_conv_kernel=g("merge_conv_kernel", 31),
                 csgu_activation=g("csgu_activation", "identity"), csgu_use_linear_after_conv=g("csgu_use_linear_after_conv", False),
@@ -76,6 +76,10 @@ class EBranchformerEngine:
             raise NotImplementedError("HIP path implements the erf-GELU activations of the reference configs")
         if c.get("csgu_activation", "identity") not in ACT:
             raise NotImplementedError(f"csgu_activation {c['csgu_activation']}")
+        # context-aware Conv2d front end (extractors.py:57-65): 1 "gated", 2 "gated_shared", 0 for None AND any other string (the reference's dict lookup
+        # falls back to nn.Conv2d, e.g. for the recipes' `shared_gated`); conv and gate filters of a gated layer 2 are packed in blocks of `gate_blk` channels
+        self.ctx_mode = context_mode(c)
+        self.gate_blk = (32 if c["conv_dim"][1] % 32 == 0 else c["conv_dim"][1]) if self.ctx_mode == 1 else 0
         self.weights = {}
         self._table = None
         self._ws = {}
@@ -102,10 +106,24 @@ class EBranchformerEngine:
             keep.append(t)
             slots[idx] = t
 
-        put(G["CONV1_W"], f32(sd[f"{fe}conv.0.0{cw}.weight"]).reshape(C1, K * K))
-        put(G["CONV1_B"], f32(sd[f"{fe}conv.0.0{cw}.bias"]))
-        put(G["CONV2_W"], bf(sd[f"{fe}conv.1.0{cw}.weight"].permute(0, 2, 3, 1).reshape(C2, K * K * C1)))
-        put(G["CONV2_B"], f32(sd[f"{fe}conv.1.0{cw}.bias"]))
+        if self.ctx_mode:       # ContextAwareConv2d.conv = Gated* module with .conv and .gate (extractors.py:23-54)
+            cl = lambda t: t.detach().to(dev, torch.float32).permute(0, 2, 3, 1).reshape(t.shape[0], -1)      # (Cout, Cin, KH, KW) -> (Cout, (kh, kw, cin))
+            put(G["CONV1_W"], f32(sd[f"{fe}conv.0.0.conv.conv.weight"]).reshape(C1, -1)); put(G["CONV1_B"], f32(sd[f"{fe}conv.0.0.conv.conv.bias"]))
+            put(G["GATE1_W"], f32(sd[f"{fe}conv.0.0.conv.gate.weight"]).reshape(C1, -1)); put(G["GATE1_B"], f32(sd[f"{fe}conv.0.0.conv.gate.bias"]))
+            wc, wg = cl(sd[f"{fe}conv.1.0.conv.conv.weight"]), cl(sd[f"{fe}conv.1.0.conv.gate.weight"])
+            bc, bg = f32(sd[f"{fe}conv.1.0.conv.conv.bias"]), f32(sd[f"{fe}conv.1.0.conv.gate.bias"])
+            if self.ctx_mode == 1:          # one implicit GEMM: [conv blk ; gate blk] per 2*blk rows (gemm_8p.hip GATED epilogue / mi_gated_act_bf16)
+                nb = C2 // self.gate_blk
+                put(G["CONV2_W"], bf(torch.stack([wc.view(nb, self.gate_blk, -1), wg.view(nb, self.gate_blk, -1)], 1).reshape(2 * C2, -1)))
+                put(G["CONV2_B"], f32(torch.stack([bc.view(nb, -1), bg.view(nb, -1)], 1).reshape(2 * C2)))
+            else:
+                put(G["CONV2_W"], bf(wc)); put(G["CONV2_B"], bc)
+                put(G["GATE2_W"], bf(wg)); put(G["GATE2_B"], bg)
+        else:
+            put(G["CONV1_W"], f32(sd[f"{fe}conv.0.0{cw}.weight"]).reshape(C1, K * K))
+            put(G["CONV1_B"], f32(sd[f"{fe}conv.0.0{cw}.bias"]))
+            put(G["CONV2_W"], bf(sd[f"{fe}conv.1.0{cw}.weight"].permute(0, 2, 3, 1).reshape(C2, K * K * C1)))
+            put(G["CONV2_B"], f32(sd[f"{fe}conv.1.0{cw}.bias"]))
         put(G["FEOUT_W"], bf(sd[fe + "out.weight"].reshape(d, C2, F2).permute(0, 2, 1).reshape(d, F2 * C2)))
         put(G["FEOUT_B"], f32(sd[fe + "out.bias"]))
         fp = "wav2vec2.feature_projection."
@@ -164,6 +182,19 @@ class EBranchformerEngine:
             T = (T + 2 * p - k) // s + 1
         return T
 
+    def _check_shared_gate(self, T: int):
+        """GatedConv2dShared.forward (extractors.py:49-54) views the conv output as (B, C, -1, 4, F) and multiplies by gate.unsqueeze(3): both conv layers' time axes must
+        be divisible by 4 and a quarter of them must equal the gate conv's output length — the reference raises a RuntimeError from `view` / broadcasting otherwise."""
+        c = self.cfg
+        k, s, p = c["conv_kernel"][0], c["conv_stride"][0], c["conv_padding"][0]
+        for _ in range(2):
+            To = (T + 2 * p - k) // s + 1
+            Tg = (T + 2 * p * GATE_SHARE - k * GATE_SHARE) // (s * GATE_SHARE) + 1
+            if To % GATE_SHARE or To // GATE_SHARE != Tg:
+                raise RuntimeError(f"gated_shared front end: a conv layer maps {T} frames to {To} and its gate to {Tg}; the reference's view(B, C, -1, {GATE_SHARE}, F) * gate "
+                                   f"needs {To} divisible by {GATE_SHARE} and {To} // {GATE_SHARE} == {Tg} (extractors.py:49-54) — pad the batch to a multiple of 16 frames")
+            T = To
+
     def _pos_table(self, T2: int):
         c = self.cfg
         ptype = c.get("position_embeddings_type", "relative")
@@ -200,7 +231,7 @@ class EBranchformerEngine:
                               ln_eps=float(c.get("layer_norm_eps", 1e-5)), logits_f32=int(self.logits_dtype == torch.float32),
                               logits_ld=(c["vocab_size"] + 1 + 7) // 8 * 8,
                               branch_overlap=int(self.branch_overlap and slot == 0), extra_layers=self.extra, layer_mixing=self.mix,
-                              csgu_linear=int(bool(c.get("csgu_use_linear_after_conv", False))))
+                              csgu_linear=int(bool(c.get("csgu_use_linear_after_conv", False))), context_mode=self.ctx_mode, gate_blk=self.gate_blk)
 
     def _workspace(self, cs, slot=0):
         key = (cs.B, cs.T, cs.F)
@@ -228,6 +259,8 @@ class EBranchformerEngine:
         T2 = self.out_frames(T)
         if T2 <= 0:
             raise ValueError("input too short for the conv sub-sampling")
+        if self.ctx_mode == 2:
+            self._check_shared_gate(T)
         d, V1 = c["hidden_size"], c["vocab_size"] + 1
         ws = self._workspace(cs, slot)
         pos = self._pos_table(T2)

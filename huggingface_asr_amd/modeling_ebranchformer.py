@@ -94,19 +94,28 @@ class _Layer(_Holder):
             self.ff2 = nn.Sequential(_ln(d), _FFN(d, cfg.intermediate_size))
 
 
-class _ConvWrap(_Holder):   # ContextAwareConv2d: the extra ".conv" level of the non-causal key (extractors.py:57-65)
-    def __init__(self, cin, cout, k, s):
+class _Gated(_Holder):      # GatedConv2d / GatedConv2dShared (extractors.py:23-54): .conv and .gate; the shared gate is a (4k, k) / stride (4s, s) / padding (4p, p) conv
+    def __init__(self, cin, cout, k, s, p, share):
         super().__init__()
-        self.conv = nn.Conv2d(cin, cout, k, stride=s)
+        self.conv = nn.Conv2d(cin, cout, (k, k), stride=(s, s), padding=p)
+        self.gate = nn.Conv2d(cin, cout, (k * share, k), stride=(s * share, s), padding=(p * share, p))
+
+
+class _ConvWrap(_Holder):   # ContextAwareConv2d: the extra ".conv" level of the non-causal key (extractors.py:57-65)
+    def __init__(self, cin, cout, k, s, p=1, mode=0):
+        super().__init__()
+        # the reference's dict lookup: "gated" / "gated_shared" select a gate, anything else (None, the recipes' `shared_gated`, ...) is the plain nn.Conv2d
+        self.conv = _Gated(cin, cout, k, s, p, 4 if mode == 2 else 1) if mode else nn.Conv2d(cin, cout, k, stride=s)
 
 
 class _FeatureExtractor(_Holder):
     def __init__(self, cfg):
         super().__init__()
-        from .shapes import conv_freq_out
+        from .shapes import context_mode, conv_freq_out
         blocks, cin = [], 1
-        for c, k, s in zip(cfg.conv_dim, cfg.conv_kernel, cfg.conv_stride):
-            conv = nn.Conv2d(cin, c, k, stride=s) if cfg.is_causal else _ConvWrap(cin, c, k, s)
+        mode = context_mode(dict(is_causal=cfg.is_causal, context_awareness_type=getattr(cfg, "context_awareness_type", None)))
+        for c, k, s, p in zip(cfg.conv_dim, cfg.conv_kernel, cfg.conv_stride, cfg.conv_padding):
+            conv = nn.Conv2d(cin, c, k, stride=s) if cfg.is_causal else _ConvWrap(cin, c, k, s, p, mode)
             blocks.append(nn.Sequential(conv, nn.GELU()))
             cin = c
         self.conv = nn.Sequential(*blocks)

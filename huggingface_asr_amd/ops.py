@@ -98,6 +98,56 @@ def conv2d_cl(x, w, bias, K=3, stride=2, pad=1, causal=False, act="gelu", varian
     return out
 
 
+def _geo_out(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+def conv2d_first_geo(x, w, bias, K=(3, 3), stride=(2, 2), pad=(1, 1), act="gelu"):
+    """Conv2d(1 -> C) of general geometry: x (B,T,F) f32, w (C, KH*KW) f32 -> channels-last (B,T1,F1,C) bf16; act "gelu" or "none" (raw pre-activation)."""
+    B, T, F = x.shape
+    Cc = w.shape[0]
+    (KH, KW), (st, sf), (pt, pf) = K, stride, pad
+    T1, F1 = _geo_out(T, KH, st, pt), _geo_out(F, KW, sf, pf)
+    out = torch.empty((B, T1, F1, Cc), device=x.device, dtype=BF16)
+    _lib.check(_lib.lib().mi_conv2d_first_geo(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), B, T, F, Cc, KH, KW, st, sf, pt, pf, T1, F1,
+                                              {"none": 0, "gelu": 1}[act], _stream()), "mi_conv2d_first_geo")
+    return out
+
+
+def conv2d_first_gated_gelu(x, w, bias, gw, gbias, stride=2, pad=1):
+    """GatedConv2d first layer fused (extractors.py:23-32): GELU((conv + b) * sigmoid(gate + bg)); 3x3 only."""
+    B, T, F = x.shape
+    Cc, KK = w.shape
+    K = int(round(math.sqrt(KK)))
+    T1, F1 = _geo_out(T, K, stride, pad), _geo_out(F, K, stride, pad)
+    out = torch.empty((B, T1, F1, Cc), device=x.device, dtype=BF16)
+    _lib.check(_lib.lib().mi_conv2d_first_gated_gelu(x.data_ptr(), w.data_ptr(), bias.data_ptr(), gw.data_ptr(), gbias.data_ptr(), out.data_ptr(), B, T, F, Cc, K,
+                                                     stride, pad, pad, T1, F1, _stream()), "mi_conv2d_first_gated_gelu")
+    return out
+
+
+def conv2d_cl_geo(x, w, bias, K=(3, 3), stride=(2, 2), pad=(1, 1), act="gelu", gated=False):
+    """conv2d_cl with (time, freq) kernel / stride / pad pairs; gated: w (2*Cout, K) / bias (2*Cout) interleaved [conv 32 ; gate 32] -> GELU(conv * sigmoid(gate))."""
+    B, T, F, Cin = x.shape
+    Cout = w.shape[0] // (2 if gated else 1)
+    (KH, KW), (st, sf), (pt, pf) = K, stride, pad
+    T1, F1 = _geo_out(T, KH, st, pt), _geo_out(F, KW, sf, pf)
+    out = torch.empty((B, T1, F1, Cout), device=x.device, dtype=BF16)
+    _lib.check(_lib.lib().mi_conv2d_cl_geo_bf16(x.data_ptr(), w.data_ptr(), _p(bias), out.data_ptr(), B, T, F, Cin, Cout, KH, KW, st, sf, pt, pf, T1, F1,
+                                                {"none": 0, "gelu": 1}[act], int(gated), _stream()), "mi_conv2d_cl_geo_bf16")
+    return out
+
+
+def gated_act(z, g, B, T, Fq, C, share=1, blk=0, out=None):
+    """GELU(z * sigmoid(g)) -> (B*T*Fq, C) bf16; z rows (b,t,f), g rows (b, t // share, f); blk > 0: z is g, columns interleaved [conv blk | gate blk]."""
+    z2, g2 = z.reshape(-1, z.shape[-1]), g.reshape(-1, g.shape[-1])
+    if out is None:
+        out = torch.empty((B * T * Fq, C), device=z.device, dtype=BF16)
+    _lib.check(_lib.lib().mi_gated_act_bf16(z2.data_ptr(), z2.stride(0), g2.data_ptr(), g2.stride(0), out.data_ptr(), out.stride(0), B, T, Fq, C, share, blk, _stream()),
+               "mi_gated_act_bf16")
+    return out
+
+
 def layernorm_chain(x, *, lengths=None, T=1, ln1=None, eps1=1e-5, store_y=None, lna=None, eps2=1e-5, outa=None,
                     outa32=None, lnb=None, outb=None):
     """see csrc/norm.hip; x (M,d) f32; ln* = (gamma, beta) f32."""

@@ -278,6 +278,46 @@ def im2col(x, K, stride, pad, T1, F1):
     return col
 
 
+def im2col_geo(x, K, stride, pad, T1, F1):
+    """im2col with (time, freq) kernel / stride / pad pairs"""
+    B, T, F, Cin = x.shape
+    (KH, KW), (st, sf), (pt, pf) = K, stride, pad
+    col = torch.empty((B * T1 * F1, KH * KW * Cin), device=x.device, dtype=BF16)
+    _lib.check(_L().mi_im2col_cl_geo_bf16(x.data_ptr(), col.data_ptr(), B, T, F, Cin, KH, KW, st, sf, pt, pf, T1, F1, _stream()), "mi_im2col_cl_geo_bf16")
+    return col
+
+
+def col2im(dcol, shape_in, K, stride, pad, T1, F1, out=None):
+    """din (B,T,F,Cin) bf16 (+= when `out` is given) = col2im(dcol (B*T1*F1, KH*KW*Cin))"""
+    B, T, F, Cin = shape_in
+    (KH, KW), (st, sf), (pt, pf) = K, stride, pad
+    acc = out is not None
+    if out is None:
+        out = torch.empty((B, T, F, Cin), device=dcol.device, dtype=BF16)
+    _lib.check(_L().mi_col2im_cl_bf16(dcol.data_ptr(), out.data_ptr(), B, T, F, Cin, KH, KW, st, sf, pt, pf, T1, F1, int(acc), _stream()), "mi_col2im_cl_bf16")
+    return out
+
+
+def gated_act_bwd(dout, z, g, B, T, Fq, C, share=1, dz=None, dg=None):
+    """backward of ops.gated_act (plain columns): -> dz like z (B*T*Fq, C), dg like g (B*(T//share)*Fq, C); dz / dg may be column views of one buffer"""
+    if dz is None:
+        dz = torch.empty((B * T * Fq, C), device=z.device, dtype=BF16)
+    if dg is None:
+        dg = torch.empty((B * (T // share) * Fq, C), device=z.device, dtype=BF16)
+    _lib.check(_L().mi_gated_act_bwd_bf16(dout.data_ptr(), dout.stride(0), z.data_ptr(), z.stride(0), g.data_ptr(), g.stride(0), dz.data_ptr(), dz.stride(0),
+                                          dg.data_ptr(), dg.stride(0), B, T, Fq, C, share, _stream()), "mi_gated_act_bwd_bf16")
+    return dz, dg
+
+
+def conv2d_first_wgrad(x, dy, dw, db, K, stride, pad):
+    """dw (C, KH*KW) +=, db (C) += from dy (B,T1,F1,C) bf16 = gradient of the raw output of Conv2d(1 -> C, K, stride, pad) over x (B,T,F) f32"""
+    B, T, F = x.shape
+    _, T1, F1, Cc = dy.shape
+    (KH, KW), (st, sf), (pt, pf) = K, stride, pad
+    _lib.check(_L().mi_conv2d_first_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), B, T, F, Cc, KH, KW, st, sf, pt, pf, T1, F1, _stream()),
+               "mi_conv2d_first_wgrad")
+
+
 def conv2d_first_bwd(x, w, bias, dcol, dw, db, K, stride, pad, T1, F1, K2, stride2, pad2, T2, F2):
     B, T, F = x.shape
     Cc = w.shape[0]

@@ -15,6 +15,23 @@ def conv_freq_out(num_fbanks: int, kernels, strides, paddings, causal: bool = Fa
     return f
 
 
+GATE_SHARE = 4          # GatedConv2dShared's shared_scale_factor (extractors.py:36): one gate value per four output time steps
+
+
+def context_mode(cfg: dict) -> int:
+    """0 plain / 1 "gated" / 2 "gated_shared" Conv2d sub-sampling (extractors.py:57-65).  The reference looks the string up in a two-entry dict and
+    falls back to nn.Conv2d for ANYTHING else — None, and also the `shared_gated` that recipes_v0.0.1/librispeech_aed/train_shared_gated_baseline.sh:94
+    passes — so unknown strings are the plain conv here too; a causal encoder ignores the field altogether (CausalConv2d, extractors.py:74-81)."""
+    if cfg.get("is_causal", False):
+        return 0
+    return {"gated": 1, "gated_shared": 2}.get(cfg.get("context_awareness_type"), 0)
+
+
+def gate_geometry(k: int, s: int, p: int, mode: int):
+    """(KH, KW, stride_t, stride_f, pad_t, pad_f) of the gate conv of a layer whose conv is (k, k) / s / p (extractors.py:27, 41-47)."""
+    return (k, k, s, s, p, p) if mode == 1 else (k * GATE_SHARE, k, s * GATE_SHARE, s, p * GATE_SHARE, p)
+
+
 def param_shapes(cfg: dict) -> dict:
     d, I, L = cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"]
     H = cfg["num_attention_heads"]
@@ -30,9 +47,16 @@ def param_shapes(cfg: dict) -> dict:
     # CausalConv2d IS the nn.Conv2d (streaming_modules.py:31) while the non-causal conv is wrapped in
     # ContextAwareConv2d (extractors.py:57-65), hence the extra ".conv" in the non-causal key.
     cw = "" if cfg.get("is_causal", False) else ".conv"
+    mode = context_mode(cfg)
     for i, (c, k) in enumerate(zip(conv_dim, ks)):
-        out[f"wav2vec2.feature_extractor.conv.{i}.0{cw}.weight"] = (c, cin, k, k)
-        out[f"wav2vec2.feature_extractor.conv.{i}.0{cw}.bias"] = (c,)
+        if mode:        # ContextAwareConv2d.conv is a Gated* module holding .conv and .gate (extractors.py:23-54)
+            out[f"wav2vec2.feature_extractor.conv.{i}.0.conv.conv.weight"] = (c, cin, k, k)
+            out[f"wav2vec2.feature_extractor.conv.{i}.0.conv.conv.bias"] = (c,)
+            out[f"wav2vec2.feature_extractor.conv.{i}.0.conv.gate.weight"] = (c, cin, k * (GATE_SHARE if mode == 2 else 1), k)
+            out[f"wav2vec2.feature_extractor.conv.{i}.0.conv.gate.bias"] = (c,)
+        else:
+            out[f"wav2vec2.feature_extractor.conv.{i}.0{cw}.weight"] = (c, cin, k, k)
+            out[f"wav2vec2.feature_extractor.conv.{i}.0{cw}.bias"] = (c,)
         cin = c
     fo = conv_freq_out(cfg.get("num_fbanks", 80), ks, cfg["conv_stride"], pads, cfg.get("is_causal", False))
     out["wav2vec2.feature_extractor.out.weight"] = (d, conv_dim[-1] * fo)

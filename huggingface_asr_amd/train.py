@@ -32,7 +32,7 @@ import torch
 
 from . import ops
 from . import ops_train as T
-from .shapes import conv_freq_out
+from .shapes import GATE_SHARE, context_mode, conv_freq_out, gate_geometry
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -170,8 +170,17 @@ def encoder_specs(c: dict, head: bool = True) -> list[Spec]:
     mat = lambda n, *sh: S.append(Spec(n, tuple(sh), True, True))
     vec = lambda n, *sh, decay=False: S.append(Spec(n, tuple(sh), False, decay))
     vec("masked_spec_embed", d)     # SpecAugment fill vector: carried for state-dict parity, never receives a gradient on this path (torch skips it too)
+    mode = context_mode(c)                                   # context-aware front end (extractors.py:23-65): 0 plain, 1 gated, 2 gated_shared
+    gkh = K * (GATE_SHARE if mode == 2 else 1)               # the shared gate's kernel is (4K, K)
     vec("conv1_w", C1, K * K, decay=True); vec("conv1_b", C1)
-    mat("conv2_w", C2, K * K * C1); vec("conv2_b", C2)
+    if mode:
+        vec("gate1_w", C1, gkh * K, decay=True); vec("gate1_b", C1)
+    if mode == 1:                                            # conv rows, then gate rows: ONE implicit GEMM forward, one dW / dX GEMM pair backward
+        mat("conv2_w", 2 * C2, K * K * C1); vec("conv2_b", 2 * C2)
+    else:
+        mat("conv2_w", C2, K * K * C1); vec("conv2_b", C2)
+    if mode == 2:
+        mat("gate2_w", C2, gkh * K * C1); vec("gate2_b", C2)
     mat("feout_w", d, F2 * C2); vec("feout_b", d)
     vec("fp_ln_g", d); vec("fp_ln_b", d); mat("fp_w", d, d); vec("fp_b", d)
     for l in range(L + int(bool(c.get("finetune_with_additional_layer", False)))):     # layer L = the fine-tuning head's `additional_layer` (bestrq.py:199-200)
@@ -215,11 +224,30 @@ def _enc_map(c: dict, head: bool = True):
     # optional in the reference (present iff mask_time_prob > 0 or mask_feature_prob > 0): absent -> zeros, not exported
     m["masked_spec_embed"] = (lambda sd: sd["wav2vec2.masked_spec_embed"] if "wav2vec2.masked_spec_embed" in sd else torch.zeros(d),
                               [("wav2vec2.masked_spec_embed", lambda t: t)])
-    one("conv1_w", f"{fe}conv.0.0{cw}.weight", lambda t: t.reshape(C1, K * K), lambda t: t.reshape(C1, 1, K, K))
-    one("conv1_b", f"{fe}conv.0.0{cw}.bias")
-    one("conv2_w", f"{fe}conv.1.0{cw}.weight", lambda t: t.permute(0, 2, 3, 1).reshape(C2, K * K * C1),
-        lambda t: t.reshape(C2, K, K, C1).permute(0, 3, 1, 2))
-    one("conv2_b", f"{fe}conv.1.0{cw}.bias")
+    mode = context_mode(c)
+    if mode:        # ContextAwareConv2d.conv is a Gated* module: keys ...conv.N.0.conv.{conv,gate}.{weight,bias} (extractors.py:23-54)
+        gkh = K * (GATE_SHARE if mode == 2 else 1)
+        c1, c2 = f"{fe}conv.0.0.conv.", f"{fe}conv.1.0.conv."
+        cl = lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0], -1)                                  # (Cout, Cin, KH, KW) -> (Cout, (kh, kw, cin))
+        uncl = lambda kh: (lambda t: t.reshape(C2, kh, K, C1).permute(0, 3, 1, 2))
+        one("conv1_w", c1 + "conv.weight", lambda t: t.reshape(C1, K * K), lambda t: t.reshape(C1, 1, K, K))
+        one("conv1_b", c1 + "conv.bias")
+        one("gate1_w", c1 + "gate.weight", lambda t: t.reshape(C1, gkh * K), lambda t: t.reshape(C1, 1, gkh, K))
+        one("gate1_b", c1 + "gate.bias")
+        if mode == 1:
+            m["conv2_w"] = (lambda sd: torch.cat([cl(sd[c2 + "conv.weight"]), cl(sd[c2 + "gate.weight"])], 0),
+                            [(c2 + "conv.weight", lambda t: uncl(K)(t[:C2])), (c2 + "gate.weight", lambda t: uncl(K)(t[C2:]))])
+            m["conv2_b"] = (lambda sd: torch.cat([sd[c2 + "conv.bias"], sd[c2 + "gate.bias"]], 0),
+                            [(c2 + "conv.bias", lambda t: t[:C2]), (c2 + "gate.bias", lambda t: t[C2:])])
+        else:
+            one("conv2_w", c2 + "conv.weight", cl, uncl(K)); one("conv2_b", c2 + "conv.bias")
+            one("gate2_w", c2 + "gate.weight", cl, uncl(gkh)); one("gate2_b", c2 + "gate.bias")
+    else:
+        one("conv1_w", f"{fe}conv.0.0{cw}.weight", lambda t: t.reshape(C1, K * K), lambda t: t.reshape(C1, 1, K, K))
+        one("conv1_b", f"{fe}conv.0.0{cw}.bias")
+        one("conv2_w", f"{fe}conv.1.0{cw}.weight", lambda t: t.permute(0, 2, 3, 1).reshape(C2, K * K * C1),
+            lambda t: t.reshape(C2, K, K, C1).permute(0, 3, 1, 2))
+        one("conv2_b", f"{fe}conv.1.0{cw}.bias")
     one("feout_w", fe + "out.weight", lambda t: t.reshape(d, C2, F2).permute(0, 2, 1).reshape(d, F2 * C2),
         lambda t: t.reshape(d, F2, C2).permute(0, 2, 1).reshape(d, C2 * F2))
     one("feout_b", fe + "out.bias")
@@ -372,7 +400,8 @@ class EncoderCTCTrainer:
             raise NotImplementedError("layer mixing / additional layer belong to the CTC fine-tuning head")
         names = self.store.order
         self._layer_names = [[n for n in names if n.startswith(f"l{l}.")] for l in range(L + int(self.extra))]
-        self._front_names = [n for n in names if n.startswith(("masked_spec", "conv", "feout", "fp_"))]
+        self._front_names = [n for n in names if n.startswith(("masked_spec", "conv", "gate", "feout", "fp_"))]
+        self.ctx_mode = context_mode(c)                              # context-aware Conv2d front end (extractors.py:23-65): 0 plain, 1 gated, 2 gated_shared
         self._encln_names = ["enc_ln_g", "enc_ln_b"] + (["mix_w"] if self.mix else [])
         self._head_names = self._encln_names + (["head_w", "head_b"] if self.head else [])
 
@@ -566,9 +595,32 @@ class EncoderCTCTrainer:
         # e_branchformer.py:153-160 hands (K-1)//2 to CausalConv1d's dilation slot: the causal CSGU conv is dilated by 15 with a left pad of (K-1)*15
         cs_dil = (kc - 1) // 2 if causal else 1
         cs_pad = (kc - 1) * cs_dil if causal else (kc - 1) // 2
-        act1 = ops.conv2d_first_gelu(feats, P("conv1_w"), P("conv1_b"), stride=s_, pad=pad, causal=causal)
-        pre2 = ops.conv2d_cl(act1, W("conv2_w"), P("conv2_b"), K=K, stride=s_, pad=pad, causal=causal, act="none").view(B * T2 * F2, C2)
-        act2 = T.act_fwd(pre2).view(M, F2 * C2)
+        cm = self.ctx_mode
+        if cm == 0:
+            act1 = ops.conv2d_first_gelu(feats, P("conv1_w"), P("conv1_b"), stride=s_, pad=pad, causal=causal)
+            pre2 = ops.conv2d_cl(act1, W("conv2_w"), P("conv2_b"), K=K, stride=s_, pad=pad, causal=causal, act="none").view(B * T2 * F2, C2)
+            act2 = T.act_fwd(pre2).view(M, F2 * C2)
+        else:
+            # GatedConv2d / GatedConv2dShared (extractors.py:23-54): GELU(conv(x) * sigmoid(gate(x))), the shared gate being one row per four conv rows from a
+            # (4K, K) / stride (4s, s) / padding (4p, p) conv.  Training keeps the raw conv / gate outputs (bf16) for the backward: un-fused passes.
+            share = GATE_SHARE if cm == 2 else 1
+            gkh, gkw, gst, gsf, gpt, gpf = gate_geometry(K, s_, pad, cm)
+            gK, gS, gP, cK, cS, cP = (gkh, gkw), (gst, gsf), (gpt, gpf), (K, K), (s_, s_), (pad, pad)
+            if cm == 2:
+                for Tc, Tg in ((T1, (Tn + 2 * gpt - gkh) // gst + 1), (T2, (T1 + 2 * gpt - gkh) // gst + 1)):
+                    if Tc % share or Tc // share != Tg:
+                        raise RuntimeError(f"gated_shared front end: conv time axis {Tc} vs gate {Tg}: the reference's view(B, C, -1, {share}, F) * gate needs "
+                                           f"{Tc} % {share} == 0 and {Tc} // {share} == {Tg} (extractors.py:49-54)")
+            z1 = ops.conv2d_first_geo(feats, P("conv1_w"), P("conv1_b"), K=cK, stride=cS, pad=cP, act="none")
+            g1 = ops.conv2d_first_geo(feats, P("gate1_w"), P("gate1_b"), K=gK, stride=gS, pad=gP, act="none")
+            act1 = ops.gated_act(z1, g1, B, T1, F1, C1, share).view(B, T1, F1, C1)
+            if cm == 1:
+                pre2 = ops.conv2d_cl(act1, W("conv2_w"), P("conv2_b"), K=K, stride=s_, pad=pad, act="none").view(B * T2 * F2, 2 * C2)
+                z2, g2 = pre2[:, :C2], pre2[:, C2:]
+            else:
+                z2 = ops.conv2d_cl(act1, W("conv2_w"), P("conv2_b"), K=K, stride=s_, pad=pad, act="none").view(B * T2 * F2, C2)
+                g2 = ops.conv2d_cl_geo(act1, W("gate2_w"), P("gate2_b"), K=gK, stride=gS, pad=gP, act="none").view(-1, C2)
+            act2 = ops.gated_act(z2, g2, B, T2, F2, C2, share).view(M, F2 * C2)
         feo = ops.gemm(act2, W("feout_w"), P("feout_b"), out_dtype=F32)
         a_fp = e16(M, d)
         LN(feo, lna=(P("fp_ln_g"), P("fp_ln_b")), eps2=eps_e, outa=a_fp)
@@ -809,12 +861,40 @@ class EncoderCTCTrainer:
         dfeo = e32(M, d)
         T.layernorm_bwd(feo, P("fp_ln_g"), da, dfeo, accumulate=False, **self._lng("fp_ln_g", "fp_ln_b"), eps=eps_e)
         dact2 = T.linear_bwd(T.add_cast(dfeo), act2, WT("feout_w"), dw=GL("feout_w"), db=GL("feout_b"))      # (M, F2*C2)
-        dpre2 = T.act_bwd(dact2.view(B * T2 * F2, C2), pre2)
-        col = T.im2col(act1, K, s_, padl, T2, F2)
-        T.gemm_tn_(G("conv2_w"), dpre2, col, db=G("conv2_b"))
-        dcol = ops.gemm(dpre2, WT("conv2_w")[:, :C2])
-        del col
-        T.conv2d_first_bwd(feats, P("conv1_w"), P("conv1_b"), dcol, G("conv1_w"), G("conv1_b"), K, s_, padl, T1, F1, K, s_, padl, T2, F2)
+        if cm == 0:
+            dpre2 = T.act_bwd(dact2.view(B * T2 * F2, C2), pre2)
+            col = T.im2col(act1, K, s_, padl, T2, F2)
+            T.gemm_tn_(G("conv2_w"), dpre2, col, db=G("conv2_b"))
+            dcol = ops.gemm(dpre2, WT("conv2_w")[:, :C2])
+            del col
+            T.conv2d_first_bwd(feats, P("conv1_w"), P("conv1_b"), dcol, G("conv1_w"), G("conv1_b"), K, s_, padl, T1, F1, K, s_, padl, T2, F2)
+        else:
+            # y = z * sigmoid(g), out = GELU(y): dz = dout GELU'(y) sigmoid(g), dg = sum over the rows sharing g of dout GELU'(y) z sigmoid(g)(1 - sigmoid(g));
+            # then conv and gate are two plain convs (ONE for "gated": conv and gate rows stacked) — dW = dY^T col, dX = col2im(dY W)
+            dact2 = dact2.view(B * T2 * F2, C2)
+            col = T.im2col(act1, K, s_, pad, T2, F2)
+            if cm == 1:
+                dzg = e16(B * T2 * F2, 2 * C2)
+                T.gated_act_bwd(dact2, z2, g2, B, T2, F2, C2, 1, dz=dzg[:, :C2], dg=dzg[:, C2:])
+                T.gemm_tn_(G("conv2_w"), dzg, col, db=G("conv2_b"))
+                dcol = ops.gemm(dzg, WT("conv2_w")[:, :2 * C2])
+                del col
+                dact1 = T.col2im(dcol, (B, T1, F1, C1), cK, cS, cP, T2, F2)
+            else:
+                dz2, dg2 = T.gated_act_bwd(dact2, z2, g2, B, T2, F2, C2, share)
+                T.gemm_tn_(G("conv2_w"), dz2, col, db=G("conv2_b"))
+                dcol = ops.gemm(dz2, WT("conv2_w")[:, :C2])
+                del col
+                dact1 = T.col2im(dcol, (B, T1, F1, C1), cK, cS, cP, T2, F2)
+                colg = T.im2col_geo(act1, gK, gS, gP, T2 // share, F2)
+                T.gemm_tn_(G("gate2_w"), dg2, colg, db=G("gate2_b"))
+                dcol = ops.gemm(dg2, WT("gate2_w")[:, :C2])
+                del colg
+                T.col2im(dcol, (B, T1, F1, C1), gK, gS, gP, T2 // share, F2, out=dact1)
+            del dcol
+            dz1, dg1 = T.gated_act_bwd(dact1.view(-1, C1), z1.view(-1, C1), g1.view(-1, C1), B, T1, F1, C1, share)
+            T.conv2d_first_wgrad(feats, dz1.view(B, T1, F1, C1), G("conv1_w"), G("conv1_b"), cK, cS, cP)
+            T.conv2d_first_wgrad(feats, dg1.view(B, T1 // share, F1, C1), G("gate1_w"), G("gate1_b"), gK, gS, gP)
         self._range_done(*st.range_of(self._front_names))
         return out
 

@@ -65,6 +65,25 @@ int mi_conv2d_first_gelu(const float* x, const float* w, const float* bias, void
                          int B, int T, int F, int C, int K, int stride, int pad_t, int pad_f,
                          int T1, int F1, mi_stream_t stream);
 
+/* ---- context-aware Conv2d sub-sampling: `context_awareness_type` = "gated" / "gated_shared" (src/models/extractors.py:23-65; selected by
+ *      recipes_v0.0.1/librispeech_aed/train_gated_baseline.sh:94, train_small_baseline_fp32_gated.sh:96).
+ * GatedConv2d (:23-32): conv(x) * sigmoid(gate(x)), same geometry; GatedConv2dShared (:35-54): the gate is a (4k, k) / stride (4s, s) / padding (4p, p) conv, one
+ * gate row per four output time steps (the conv's time axis must be divisible by 4: the reference's `view` raises otherwise).  The layer's GELU follows the product. */
+/* Conv2d(1 -> C) of general geometry over the (B,T,F) fp32 features -> channels-last bf16; act 1: GELU, 0: raw pre-activation (operand of mi_gated_act_bf16) */
+int mi_conv2d_first_geo(const float* x, const float* w, const float* bias, void* out_cl_bf16, int B, int T, int F, int C,
+                        int KH, int KW, int stride_t, int stride_f, int pad_t, int pad_f, int T1, int F1, int act, mi_stream_t stream);
+/* GatedConv2d as the first layer, fused (3x3): out = GELU((conv + b) * sigmoid(gate + bg)); MI_ERR_UNSUPPORTED for other kernel sizes (run the two raw convs + mi_gated_act_bf16) */
+int mi_conv2d_first_gated_gelu(const float* x, const float* w, const float* bias, const float* gw, const float* gbias, void* out_cl_bf16,
+                               int B, int T, int F, int C, int K, int stride, int pad_t, int pad_f, int T1, int F1, mi_stream_t stream);
+/* mi_conv2d_cl_bf16 with separate time / frequency strides; gated != 0: GatedConv2d as ONE implicit GEMM — weight (2*Cout, KH*KW*Cin) / bias (2*Cout) hold conv and gate
+ * filters interleaved in blocks of 32 output channels ([conv c0..c0+31 ; gate c0..c0+31]), out (B,Tout,Fout,Cout) = GELU((conv + b) * sigmoid(gate + bg)) in the epilogue
+ * (act must be 1; Cout % 128 == 0, Cin % 64 == 0, else MI_ERR_UNSUPPORTED: run it with gated = 0, act = 0 into a (M, 2*Cout) buffer + mi_gated_act_bf16(blk = 32)). */
+int mi_conv2d_cl_geo_bf16(const void* in, const void* weight, const float* bias, void* out, int B, int Tin, int Fin, int Cin, int Cout, int KH, int KW,
+                          int stride_t, int stride_f, int pad_t, int pad_f, int Tout, int Fout, int act, int gated, mi_stream_t stream);
+/* out (B*T*Fq, C) bf16 = GELU(z * sigmoid(g)), gate row of (b,t,f) = (b, t / share, f).  blk = 0: z (B*T*Fq, C), g (B*(T/share)*Fq, C) plain columns;
+ * blk > 0: z == g is the output of one stacked GEMM whose columns are interleaved [conv blk | gate blk] per 2*blk (share must be 1). */
+int mi_gated_act_bf16(const void* z, long ldz, const void* g, long ldg, void* out, long ldo, int B, int T, int Fq, int C, int share, int blk, mi_stream_t stream);
+
 /* ---- LayerNorm chain on the fp32 residual stream (see csrc/norm.hip).
  * replaces: nn.LayerNorm at e_branchformer.py:233,236,242,257,261; feature projection LN (extractors.py:130);
  *           encoder.layer_norm (wav2vec2_conformer :707); zeroing of padded frames (:662-665) via `lengths`. */
@@ -247,6 +266,17 @@ int mi_im2col_cl_bf16(const void* in, void* col, int B, int Tin, int Fin, int Ci
 int mi_conv2d_first_bwd(const float* x, const float* w, const float* bias, const void* dcol, float* dw, float* db, int B, int T,
                         int F, int C, int K, int stride, int pad_t, int pad_f, int T1, int F1, int K2, int stride2, int pad2_t,
                         int pad2_f, int T2, int F2, mi_stream_t stream);
+/* backward pieces of the context-aware front ends (extractors.py:23-65), un-fused: im2col / col2im with separate strides, the backward of mi_gated_act_bf16
+ * (dz = dout GELU'(y) sigmoid(g), dg = sum over the shared rows of dout GELU'(y) z sigmoid(g)(1 - sigmoid(g)), y = z sigmoid(g)), and the weight / bias gradient of a
+ * Conv2d(1 -> C) of geometry (3,3) or (12,3) from the gradient of its raw output. */
+int mi_im2col_cl_geo_bf16(const void* in, void* col, int B, int Tin, int Fin, int Cin, int KH, int KW, int stride_t, int stride_f, int pad_t,
+                          int pad_f, int Tout, int Fout, mi_stream_t stream);
+int mi_col2im_cl_bf16(const void* dcol, void* din, int B, int Tin, int Fin, int Cin, int KH, int KW, int stride_t, int stride_f, int pad_t, int pad_f,
+                      int Tout, int Fout, int accumulate, mi_stream_t stream);
+int mi_gated_act_bwd_bf16(const void* dout, long lddo, const void* z, long ldz, const void* g, long ldg, void* dz, long lddz, void* dg, long lddg,
+                          int B, int T, int Fq, int C, int share, mi_stream_t stream);
+int mi_conv2d_first_wgrad(const float* x, const void* dy, float* dw, float* db, int B, int T, int F, int C, int KH, int KW, int stride_t, int stride_f,
+                          int pad_t, int pad_f, int T1, int F1, mi_stream_t stream);
 /* loss gradients: F.ctc_loss backward composed with log_softmax (e_branchformer.py:472-488); label-smoothed CE of the decoder
  * heads (multi_head_gpt2.py:138-158); embedding scatter (embeddings.py:33-62) */
 size_t mi_ctc_bwd_workspace_bytes(int B, int T, int U);
@@ -316,6 +346,10 @@ typedef struct {
                                     (the input of every layer + the final LayerNorm's output) replaces the last hidden state */
     int csgu_linear;             /* `csgu_use_linear_after_conv` (e_branchformer.py:172-175,198-199): a Linear (layer slots CSGU_LIN_W bf16 (I/2, I/2) / CSGU_LIN_B) between
                                     the CSGU conv and its activation */
+    int context_mode;            /* `context_awareness_type` (extractors.py:57-65) of a non-causal encoder: 0 plain conv (None and every unknown string, as the reference's dict
+                                    lookup resolves them), 1 "gated", 2 "gated_shared".  Global slots: GATE1_W (15) f32 (C1, KH*KW), GATE1_B (16), and for mode 2 GATE2_W (17) bf16
+                                    (C2, 12*3*C1), GATE2_B (18).  Mode 1: CONV2_W / CONV2_B hold conv AND gate, (2*C2, 9*C1) / (2*C2), interleaved in blocks of `gate_blk` channels */
+    int gate_blk;                /* mode 1: 32 (the fused epilogue's packing; needs C2 % 32 == 0) or C2 (conv rows, then gate rows) */
 } mi_ebf_config;
 
 /* weight-table slot indices: see huggingface_asr_amd/engine.py (SLOTS) — the table is an array of device pointers. */

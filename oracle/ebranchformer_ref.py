@@ -91,14 +91,27 @@ def layer_norm(x, w, b, eps=1e-5):
 
 
 def conv_subsample(sd: dict, cfg: dict, feats: torch.Tensor, q: Callable = _id) -> torch.Tensor:
-    """extractors.py:110-113 (+ causal left padding streaming_modules.py:31-55) -> (B, T', d)."""
+    """extractors.py:110-113 (+ causal left padding streaming_modules.py:31-55; context-aware gates extractors.py:23-65) -> (B, T', d)."""
     p = "wav2vec2.feature_extractor."
     h = feats[:, None]
+    # extractors.py:59-61: a dict lookup with nn.Conv2d as the default — only the exact strings "gated" / "gated_shared" select a gate; the causal stack never looks
+    ctx = None if cfg.get("is_causal", False) else {"gated": 1, "gated_shared": 4}.get(cfg.get("context_awareness_type"))
     for i, (k, s, pad) in enumerate(zip(cfg["conv_kernel"], cfg["conv_stride"], cfg["conv_padding"])):
         cw = "" if cfg.get("is_causal", False) else ".conv"   # CausalConv2d is the Conv2d itself
+        qw = q if i > 0 else _id
+        if ctx is not None:
+            w, b = sd[f"{p}conv.{i}.0.conv.conv.weight"], sd[f"{p}conv.{i}.0.conv.conv.bias"]
+            gw, gb = sd[f"{p}conv.{i}.0.conv.gate.weight"], sd[f"{p}conv.{i}.0.conv.gate.bias"]
+            c = F.conv2d(h, qw(w), b, stride=s, padding=pad)
+            if ctx == 1:                                      # GatedConv2d.forward (extractors.py:31-32)
+                h = c * torch.sigmoid(F.conv2d(h, qw(gw), gb, stride=s, padding=pad))
+            else:                                             # GatedConv2dShared.forward (extractors.py:49-54): raises where the reference's view / broadcast does
+                g = torch.sigmoid(F.conv2d(h, qw(gw), gb, stride=(s * ctx, s), padding=(pad * ctx, pad)))
+                h = (c.view(*c.size()[:2], -1, ctx, c.size(3)) * g.unsqueeze(3)).view(c.size())
+            h = q(F.gelu(h))
+            continue
         w, b = sd[f"{p}conv.{i}.0{cw}.weight"], sd[f"{p}conv.{i}.0{cw}.bias"]
-        if i > 0:
-            w = q(w)
+        w = qw(w)
         if cfg.get("is_causal", False):
             lp = pad * 2
             h = F.conv2d(F.pad(h, (lp, 0, lp, 0)), w, b, stride=s)

@@ -40,7 +40,8 @@ def build_reference(cfg_kwargs, **extra):
 
     cfg = Wav2Vec2EBranchformerConfig(**cfg_kwargs, attn_implementation="eager", ctc_zero_infinity=True,
                                       ctc_loss_reduction="mean", layerdrop=0.0, **extra)
-    for k, v in dict(num_fbanks=80, conv_padding=[1, 1], context_awareness_type=None).items():
+    # `context_awareness_type` is a CustomFEConfig argument (extractors.py:16-20) that the multiple-inheritance chain no longer reaches: shim (2) sets it
+    for k, v in dict(num_fbanks=80, conv_padding=[1, 1], context_awareness_type=extra.get("context_awareness_type")).items():
         setattr(cfg, k, v)
     model = Wav2Vec2EBranchformerForCTC(cfg).eval()
     return cfg, model
@@ -707,6 +708,19 @@ if __name__ == "__main__":
         run_encoder_case("tiny_causal", TINY, seed=13, B=2, T=160, lengths=[160, 97], U=5, tgt_lens=[5, 3], is_causal=True)
         run_encoder_case("tiny_nomacaron", TINY, seed=14, B=1, T=120, lengths=[120], U=4, tgt_lens=[4], use_macaron_ff=True,
                          csgu_activation="gelu", csgu_use_linear_after_conv=True)
+    if "gated" in which or "tiny" in which:
+        # context-aware Conv2d front ends (extractors.py:23-65): `gated` = conv * sigmoid(gate), same geometry; `gated_shared` = one gate per four time steps from a
+        # (12,3) / stride (8,2) / padding (4,1) conv (its `view` needs both conv outputs' time axes divisible by 4: T = 208 -> 104 -> 52); any other string —
+        # incl. the recipes' `shared_gated` (train_shared_gated_baseline.sh:94) — falls through to the plain nn.Conv2d (extractors.py:60-61)
+        run_encoder_case("tiny_gated", TINY, seed=26, B=2, T=200, lengths=[200, 139], U=6, tgt_lens=[6, 4], context_awareness_type="gated")
+        run_encoder_case("tiny_gated_shared", TINY, seed=27, B=2, T=208, lengths=[208, 150], U=6, tgt_lens=[6, 4], context_awareness_type="gated_shared")
+        run_encoder_case("tiny_shared_gated_fallthrough", TINY, seed=26, B=2, T=200, lengths=[200, 139], U=6, tgt_lens=[6, 4], context_awareness_type="shared_gated")
+    if "gatedgrads" in which or "grads" in which:
+        run_grad_case("grads_tiny_gated", TINY, seed=26, B=2, T=200, lengths=[200, 139], U=6, tgt_lens=[6, 4], context_awareness_type="gated")
+        run_grad_case("grads_tiny_gated_shared", TINY, seed=27, B=2, T=208, lengths=[208, 150], U=6, tgt_lens=[6, 4], context_awareness_type="gated_shared")
+    if "gatedbase" in which or "base" in which:
+        # the recipes' size (train_gated_baseline.sh:94 on the 256-channel front end): the fused kernels (two filter banks in conv1, conv ⊕ gate rows in conv2's implicit GEMM)
+        run_encoder_case("small_gated", SMALL, seed=28, B=2, T=1000, lengths=[998, 700], U=40, tgt_lens=[40, 31], full=False, with_bf16=True, context_awareness_type="gated")
     if "grads" in which:
         run_grad_case("grads_tiny_rel", TINY, seed=11, B=2, T=200, lengths=[198, 150], U=7, tgt_lens=[7, 5])
         run_grad_case("grads_tiny_rotary", TINY, seed=12, B=2, T=200, lengths=[200, 131], U=6, tgt_lens=[6, 4], position_embeddings_type="rotary")

@@ -42,6 +42,11 @@ TINY = [
     ("tiny_rotary", _cfg(shapes.TINY, position_embeddings_type="rotary")),
     ("tiny_causal", _cfg(shapes.TINY, is_causal=True)),
     ("tiny_nomacaron", _cfg(shapes.TINY, csgu_activation="gelu", csgu_use_linear_after_conv=True)),      # CSGU: conv -> Linear -> GELU -> gate (e_branchformer.py:196-201)
+    # context-aware Conv2d front ends (extractors.py:23-65; train_gated_baseline.sh:94): conv * sigmoid(gate); the shared gate = one row per four time steps;
+    # the recipes' misspelt `shared_gated` resolves to the plain conv in the reference's dict lookup and must do so here
+    ("tiny_gated", _cfg(shapes.TINY, context_awareness_type="gated")),
+    ("tiny_gated_shared", _cfg(shapes.TINY, context_awareness_type="gated_shared")),
+    ("tiny_shared_gated_fallthrough", _cfg(shapes.TINY, context_awareness_type="shared_gated")),
 ]
 
 
@@ -72,6 +77,7 @@ BIG = [
     ("small_causal", _cfg(shapes.SMALL, is_causal=True)),           # the streaming model at a real size (config 5's encoder side)
     ("base_rel", _cfg(shapes.BASE)),
     ("base_rotary", _cfg(shapes.BASE, position_embeddings_type="rotary")),
+    ("small_gated", _cfg(shapes.SMALL, context_awareness_type="gated")),      # 256-channel gated front end: two filter banks in conv1, conv + gate rows in ONE implicit GEMM (fused epilogue)
 ]
 
 
@@ -88,6 +94,47 @@ def test_small_base_vs_reference(name, cfg):
     assert max(d1.max(), d2.max()) < 0.06 and max(d1.mean(), d2.mean()) < 0.009, (d1.max(), d2.max(), d1.mean(), d2.mean())
     assert abs(float(logits.std()) - float(g["logits_std"])) < 2e-3
     assert abs(loss - float(g["loss"])) < 1e-3 * abs(float(g["loss"])), (loss, float(g["loss"]))
+
+
+def test_gated_shared_refuses_lengths_the_reference_cannot_view():
+    """GatedConv2dShared views the conv output as (B, C, -1, 4, F) (extractors.py:52): a time axis not divisible by 4 raises in the reference; here too, never silence."""
+    from huggingface_asr_amd import synth
+    from huggingface_asr_amd.engine import EBranchformerEngine
+    cfg = _cfg(shapes.TINY, context_awareness_type="gated_shared")
+    eng = EBranchformerEngine(cfg, DEV)
+    eng.load_state_dict({k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()})
+    with pytest.raises(RuntimeError, match="gated_shared"):
+        eng.forward(torch.zeros(1, 200, 80, device=DEV), None)                    # 200 -> 100 -> 50: 50 % 4 != 0
+    assert eng.forward(torch.zeros(1, 208, 80, device=DEV), None)["logits"].shape[1] == 52
+
+
+def test_gated_layer2_fused_epilogue_equals_unfused():
+    """GatedConv2d layer 2: the fused form (conv + gate rows interleaved by 32 in ONE implicit GEMM, product + GELU in the 256-wide kernel's epilogue) against the
+    un-fused form (the same GEMM raw + mi_gated_act_bf16) and against torch on the same bf16 operands."""
+    import torch.nn.functional as F
+    from huggingface_asr_amd import ops, synth
+    B, T1, F1, C1, C2 = 2, 120, 40, 64, 256
+    x = torch.from_numpy(synth.normal(3, "g2x", (B, T1, F1, C1), 1.0)).to(DEV).to(torch.bfloat16)
+    wc = torch.from_numpy(synth.normal(3, "g2wc", (C2, C1, 3, 3), 0.05)).to(DEV).to(torch.bfloat16)
+    wg = torch.from_numpy(synth.normal(3, "g2wg", (C2, C1, 3, 3), 0.05)).to(DEV).to(torch.bfloat16)
+    bc = torch.from_numpy(synth.normal(3, "g2bc", (C2,), 0.3)).to(DEV)
+    bg = torch.from_numpy(synth.normal(3, "g2bg", (C2,), 0.3)).to(DEV)
+    cl = lambda w: w.permute(0, 2, 3, 1).reshape(C2, -1)
+    nb = C2 // 32
+    wp = torch.stack([cl(wc).view(nb, 32, -1), cl(wg).view(nb, 32, -1)], 1).reshape(2 * C2, -1).contiguous()
+    bp = torch.stack([bc.view(nb, 32), bg.view(nb, 32)], 1).reshape(2 * C2).contiguous()
+    fused = ops.conv2d_cl_geo(x, wp, bp, act="gelu", gated=True)
+    raw = ops.conv2d_cl_geo(x, wp, bp, act="none", gated=False)
+    T2, F2 = fused.shape[1], fused.shape[2]
+    unf = ops.gated_act(raw, raw, B, T2, F2, C2, 1, 32).view(B, T2, F2, C2)
+    xt = x.float().permute(0, 3, 1, 2)
+    z = F.conv2d(xt, wc.float(), bc, stride=2, padding=1)
+    g = F.conv2d(xt, wg.float(), bg, stride=2, padding=1)
+    want = F.gelu(z * torch.sigmoid(g)).permute(0, 2, 3, 1)
+    torch.cuda.synchronize()
+    assert (fused.float() - want).abs().max() < 0.02 * max(1.0, float(want.abs().max()))          # one bf16 rounding of the result
+    assert (unf.float() - want).abs().max() < 0.04 * max(1.0, float(want.abs().max()))            # + bf16 rounding of the raw conv / gate outputs
+    assert (fused.float() - want).abs().mean() < 2e-3
 
 
 def test_no_attention_mask_and_batch_invariance():

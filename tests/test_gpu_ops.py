@@ -302,3 +302,53 @@ def test_ctc_large_vs_oracle():
     got_bf, _, _ = ops.ctc_loss(logits.to(DEV, torch.bfloat16), labels.to(DEV), in_len.to(DEV), reduction="none")
     want_bf = R.ctc_loss_ref(torch.log_softmax(bfr(logits), -1), labels, in_len, tl, blank=V, reduction="none")
     np.testing.assert_allclose(got_bf.cpu().numpy(), want_bf.numpy(), rtol=2e-5)
+
+
+def test_gelu_is_total_over_the_bf16_range():
+    """The forward GELU (x * logistic(odd quintic), common.hpp) against erf-GELU over [-30, 30] and at +-inf: the quintic's exponent turns around at |x| ~ 11
+    unless its argument is clamped — un-clamped, GELU(12) came out as 9e-12 and GELU(-12) as -12."""
+    from huggingface_asr_amd import ops_train as T
+    x = torch.cat([torch.linspace(-30, 30, 8192 - 8), torch.tensor([float("inf"), float("-inf"), 10.5, -10.5, 11.2, -11.2, 12.0, -12.0])]).to(torch.bfloat16).reshape(8, 1024)
+    got = T.act_fwd(x.to(DEV)).float().cpu()
+    want = F.gelu(x.float())
+    fin = torch.isfinite(want)
+    err = (got[fin] - want[fin]).abs()
+    assert float((err - (2e-3 + 2 ** -8 * want[fin].abs())).max()) <= 0, float(err.max())
+    assert got.reshape(-1)[-8].item() == float("inf") and got.reshape(-1)[-7].item() == 0.0 and not torch.isnan(got).any()
+
+
+def test_context_aware_front_end_pieces():
+    """The kernels of the gated Conv2d front ends (extractors.py:23-65) one by one against torch on the same operands: the general-geometry first conv (raw / GELU; the
+    shared gate's (12,3) / (8,2) / (4,1)), the fused two-bank first layer, the general-geometry implicit GEMM, and GELU(z * sigmoid(g)) with one gate row per four rows."""
+    ops = _ops()
+    B, T, Fd, C1, C2 = 2, 96, 80, 32, 64
+    x = rnd(B, T, Fd, seed=21)
+    w1, b1 = rnd(C1, 1, 3, 3, seed=22, scale=0.3), rnd(C1, seed=23, scale=0.1)
+    wg, bg = rnd(C1, 1, 12, 3, seed=24, scale=0.15), rnd(C1, seed=25, scale=0.1)
+    wg3 = rnd(C1, 1, 3, 3, seed=26, scale=0.3)
+    xin = x[:, None]
+    z = F.conv2d(xin, w1, b1, stride=2, padding=1)                               # (B, C, 48, 40)
+    g = F.conv2d(xin, wg, bg, stride=(8, 2), padding=(4, 1))                     # (B, C, 12, 40)
+    cl = lambda t: t.permute(0, 2, 3, 1)
+    gz = ops.conv2d_first_geo(x.to(DEV), w1.reshape(C1, 9).to(DEV), b1.to(DEV), act="none")
+    gg = ops.conv2d_first_geo(x.to(DEV), wg.reshape(C1, 36).to(DEV), bg.to(DEV), K=(12, 3), stride=(8, 2), pad=(4, 1), act="none")
+    assert gg.shape == (B, 12, 40, C1)
+    assert_close_bf16(gz, cl(z), what="conv1 raw"); assert_close_bf16(gg, cl(g), what="shared gate conv1 raw")
+    assert_close_bf16(ops.conv2d_first_geo(x.to(DEV), w1.reshape(C1, 9).to(DEV), b1.to(DEV), act="gelu"), cl(F.gelu(z)), what="conv1 gelu (generic kernel)")
+    # fused two-bank layer 1
+    g3 = F.conv2d(xin, wg3, bg, stride=2, padding=1)
+    fused = ops.conv2d_first_gated_gelu(x.to(DEV), w1.reshape(C1, 9).to(DEV), b1.to(DEV), wg3.reshape(C1, 9).to(DEV), bg.to(DEV))
+    assert_close_bf16(fused, cl(F.gelu(z * torch.sigmoid(g3))), what="fused gated conv1")
+    # GELU(z * sigmoid(g)), shared rows: what the reference's view / unsqueeze computes (extractors.py:52-53)
+    zr, gr = bfr(cl(z)), bfr(cl(g))
+    want = F.gelu(zr.view(B, 12, 4, 40, C1) * torch.sigmoid(gr)[:, :, None])
+    got = ops.gated_act(zr.to(DEV, torch.bfloat16), gr.to(DEV, torch.bfloat16), B, 48, 40, C1, share=4)
+    assert_close_bf16(got.view(B, 12, 4, 40, C1), want, what="gated_act share=4")
+    # layer 2: the shared gate's geometry through the implicit GEMM (K = 36 * C1)
+    a1 = bfr(rnd(B, 48, 40, C1, seed=27))
+    w2g, b2g = bfr(rnd(C2, C1, 12, 3, seed=28, scale=0.03)), rnd(C2, seed=29, scale=0.1)
+    want2 = cl(F.conv2d(a1.permute(0, 3, 1, 2), w2g, b2g, stride=(8, 2), padding=(4, 1)))
+    got2 = ops.conv2d_cl_geo(a1.to(DEV, torch.bfloat16), w2g.permute(0, 2, 3, 1).reshape(C2, -1).contiguous().to(DEV, torch.bfloat16), b2g.to(DEV),
+                             K=(12, 3), stride=(8, 2), pad=(4, 1), act="none")
+    assert got2.shape == (B, 6, 20, C2)
+    assert_close_bf16(got2, want2, what="shared gate conv2")

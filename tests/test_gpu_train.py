@@ -53,11 +53,14 @@ def _compare(grads, ref, rel=0.03, cos_min=0.999):
                                         ("grads_tiny_causal", {"is_causal": True}),
                                         ("grads_tiny_causal_long", {"is_causal": True}),
                                         ("grads_tiny_csgu_linear", {"csgu_activation": "gelu", "csgu_use_linear_after_conv": True}),
-                                        ("grads_tiny_csgu_silu", {"csgu_activation": "silu"})])
+                                        ("grads_tiny_csgu_silu", {"csgu_activation": "silu"}),
+                                        ("grads_tiny_gated", {"context_awareness_type": "gated"}),
+                                        ("grads_tiny_gated_shared", {"context_awareness_type": "gated_shared"})])
 def test_gradients_match_reference_golden(name, extra):
     """every parameter gradient of the HIP training step vs the imported reference in train() mode.  `grads_tiny_causal` = the streaming encoder
     (left-padded front end, triu attention mask, CSGU conv dilated by 15: conv_bwd.hip's dilated kernel; `_long`: 475 encoder frames, past the conv's 450-frame reach, so all 31 taps meet data); `grads_tiny_csgu_*` = the CSGU's optional Linear after the
-    conv and non-identity activations (the split conv -> [Linear] -> act * gate path)."""
+    conv and non-identity activations (the split conv -> [Linear] -> act * gate path); `grads_tiny_gated*` = the context-aware Conv2d front ends (extractors.py:23-65;
+    recipes_v0.0.1/librispeech_aed/train_gated_baseline.sh:94): conv * sigmoid(gate), the shared form with one gate row per four time steps."""
     g = load_golden(name)
     cfg = dict(shapes.TINY, ctc_zero_infinity=True, ctc_loss_reduction="mean", **extra)
     sd, x, am, lab = case_inputs(g, cfg)

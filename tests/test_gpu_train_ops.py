@@ -510,3 +510,45 @@ def test_dropout_kernels_match_the_host_twin_masks():
         wds = pf * (g - (pf * g).sum(-1, keepdim=True)) * 0.3
         err = (ds[..., :Tk].float().cpu() - wds).abs().max()
         assert float(err) < 2e-2 * float(wds.abs().max()) + 1e-4, (Tq, float(err))
+
+
+@pytest.mark.parametrize("share", [1, 4])
+def test_context_aware_front_end_backward_pieces(share):
+    """backward pieces of the gated Conv2d front ends (extractors.py:23-65) against torch autograd: d GELU(z * sigmoid(g)) with shared gate rows, col2im (the
+    transpose of im2col, both geometries, accumulating), and the weight / bias gradient of the 1-channel first conv for the (3,3) and (12,3) kernels."""
+    ops, T = _o()
+    B, Tt, Fq, C = 2, 16, 10, 32
+    z = bfr(rnd(B, Tt, Fq, C, seed=31)).requires_grad_()
+    g = bfr(rnd(B, Tt // share, Fq, C, seed=32)).requires_grad_()
+    dout = bfr(rnd(B, Tt, Fq, C, seed=33))
+    y = F.gelu(z.view(B, Tt // share, share, Fq, C) * torch.sigmoid(g)[:, :, None]).reshape(B, Tt, Fq, C)
+    y.backward(dout)
+    dz, dg = T.gated_act_bwd(dev16(dout).view(-1, C), dev16(z.detach()).view(-1, C), dev16(g.detach()).view(-1, C), B, Tt, Fq, C, share)
+    close(dz.view(B, Tt, Fq, C), z.grad, what="dz"); close(dg.view(B, Tt // share, Fq, C), g.grad, what="dg")
+    # col2im == autograd of im2col (= F.unfold in channels-last order)
+    K, S, P = ((3, 3), (2, 2), (1, 1)) if share == 1 else ((12, 3), (8, 2), (4, 1))
+    Cin, Tin, Fin = 16, 32, 20
+    T1, F1 = (Tin + 2 * P[0] - K[0]) // S[0] + 1, (Fin + 2 * P[1] - K[1]) // S[1] + 1
+    a = bfr(rnd(B, Tin, Fin, Cin, seed=34))
+    col = T.im2col_geo(dev16(a), K, S, P, T1, F1)
+    unf = F.unfold(a.permute(0, 3, 1, 2), K, padding=P, stride=S)                                  # (B, Cin*KH*KW, L), k = (c, kh, kw)
+    want_col = unf.view(B, Cin, K[0] * K[1], T1 * F1).permute(0, 3, 2, 1).reshape(B * T1 * F1, -1)  # -> (b, to, fo), k = (kh, kw, c)
+    torch.testing.assert_close(col.float().cpu(), want_col, atol=0, rtol=0)
+    dcol = bfr(rnd(B * T1 * F1, K[0] * K[1] * Cin, seed=35))
+    fold_in = dcol.view(B, T1 * F1, K[0] * K[1], Cin).permute(0, 3, 2, 1).reshape(B, Cin * K[0] * K[1], T1 * F1)
+    want_in = F.fold(fold_in, (Tin, Fin), K, padding=P, stride=S).permute(0, 2, 3, 1)
+    din = T.col2im(dev16(dcol), (B, Tin, Fin, Cin), K, S, P, T1, F1)
+    close(din, want_in, what="col2im")
+    din2 = T.col2im(dev16(dcol), (B, Tin, Fin, Cin), K, S, P, T1, F1, out=din.clone())
+    close(din2, 2 * want_in, rel=2.5e-2, what="col2im accumulate")
+    # first-layer weight gradient
+    x = rnd(B, 64, 80, seed=36)
+    w = rnd(C, 1, *K, seed=37, scale=0.2).requires_grad_()
+    b = rnd(C, seed=38, scale=0.1).requires_grad_()
+    o = F.conv2d(x[:, None], w, b, stride=S, padding=P)
+    dy = bfr(rnd(*o.shape, seed=39)).permute(0, 2, 3, 1).contiguous()                              # channels-last
+    o.backward(dy.permute(0, 3, 1, 2))
+    dw = torch.zeros(C, K[0] * K[1], device=DEV); db = torch.zeros(C, device=DEV)
+    T.conv2d_first_wgrad(x.to(DEV), dev16(dy), dw, db, K, S, P)
+    torch.testing.assert_close(dw.cpu(), w.grad.reshape(C, -1), atol=2e-3 * float(w.grad.abs().max()), rtol=1e-3)
+    torch.testing.assert_close(db.cpu(), b.grad, atol=2e-3 * float(b.grad.abs().max()), rtol=1e-3)

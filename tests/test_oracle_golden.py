@@ -22,6 +22,10 @@ TINY_CASES = [
     ("tiny_rotary", _cfg(shapes.TINY, position_embeddings_type="rotary")),
     ("tiny_causal", _cfg(shapes.TINY, is_causal=True)),
     ("tiny_nomacaron", _cfg(shapes.TINY, csgu_activation="gelu", csgu_use_linear_after_conv=True)),
+    # context-aware front ends (extractors.py:23-65); the third is the recipes' misspelt `shared_gated`, which the reference resolves to the plain conv
+    ("tiny_gated", _cfg(shapes.TINY, context_awareness_type="gated")),
+    ("tiny_gated_shared", _cfg(shapes.TINY, context_awareness_type="gated_shared")),
+    ("tiny_shared_gated_fallthrough", _cfg(shapes.TINY, context_awareness_type="shared_gated")),
 ]
 
 
@@ -48,6 +52,7 @@ BIG_CASES = [
     ("small_causal", _cfg(shapes.SMALL, is_causal=True)),
     ("base_rel", _cfg(shapes.BASE)),
     ("base_rotary", _cfg(shapes.BASE, position_embeddings_type="rotary")),
+    ("small_gated", _cfg(shapes.SMALL, context_awareness_type="gated")),
 ]
 
 
