@@ -160,6 +160,7 @@ def lib():
         h.mi_profile_count.argtypes = []; h.mi_profile_count.restype = i32
         h.mi_profile_summary.argtypes = [C.POINTER(f64), C.POINTER(f64)]; h.mi_profile_summary.restype = i32
         h.mi_profile_calibrate.argtypes = [vp, i32, C.POINTER(f64)]; h.mi_profile_calibrate.restype = i32
+        h.mi_profile_summary_family.argtypes = [i32, C.POINTER(f64), C.POINTER(f64), C.POINTER(i32)]; h.mi_profile_summary_family.restype = i32
         h.mi_last_error.argtypes = []
         h.mi_last_error.restype = C.c_char_p
         _lib = h

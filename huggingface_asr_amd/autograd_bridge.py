@@ -27,13 +27,21 @@ class HipStep(torch.autograd.Function):
     def forward(ctx, bridge, step_fn, *params):
         outs = bridge._forward(step_fn)
         ctx.bridge = bridge
+        ctx.generation = bridge.generation      # the gradients live in the trainer's flat store, not in this node: only the LATEST forward's backward may read them
         ctx.mark_non_differentiable(*[v for k, v in outs.items() if k != "loss" and torch.is_tensor(v)])
         bridge.outputs = outs
         return outs["loss"].clone()
 
     @staticmethod
     def backward(ctx, gloss):
-        grads = ctx.bridge._grads(gloss)
+        b = ctx.bridge
+        if ctx.generation != b.generation:
+            raise RuntimeError("HIP training step: backward() of a forward that is no longer the latest one — the gradients of a step live in the trainer's flat store and "
+                               "the next training forward overwrote them (run forward -> backward in order; two forwards before a backward are not supported)")
+        if b.grads_taken:
+            raise RuntimeError("HIP training step: backward() called twice on the same forward (the flat gradient store was already scaled and handed to autograd)")
+        b.grads_taken = True
+        grads = b._grads(gloss)
         return (None, None) + tuple(g if ctx.needs_input_grad[2 + i] else None for i, g in enumerate(grads))
 
 
@@ -49,6 +57,8 @@ class _Bridge:
         self.outputs = None
         self._saved = None
         self.mirrors_fresh = False                          # set by optim.StoreAdamW: its step already wrote the bf16 mirrors and the transposes
+        self.generation = 0                                 # +1 per training forward and per StoreAdamW step: the drop-in models key their eval-engine cache on it
+        self.grads_taken = False                            # (an optimizer writing the masters through raw pointers bumps no tensor version)
 
     # ------------------------------------------------------------------ zero-copy parameters
     def _adopt(self):
@@ -72,6 +82,8 @@ class _Bridge:
 
     def _forward(self, step_fn):
         tr = self.trainer
+        self.generation += 1
+        self.grads_taken = False
         if hasattr(tr, "set_frozen"):                       # frozen sub-modules: their weight-gradient GEMMs are skipped, not computed and dropped
             tr.set_frozen({n for n, p in self.named if not p.requires_grad})
         if not self.zero_copy:
@@ -90,7 +102,7 @@ class _Bridge:
         # gradient accumulation in progress?  (.grad of an adopted parameter still aliases the flat gradient store the step is about to overwrite)
         self._saved = None
         bases = {st.flat_g.untyped_storage().data_ptr() for st in tr.stores()}
-        if any(p.grad is not None and p.grad.untyped_storage().data_ptr() in bases for _, p in self.named[:8] + self.named[-8:]):
+        if any(p.grad is not None and p.grad.untyped_storage().data_ptr() in bases for _, p in self.named):
             self._saved = [st.flat_g.clone() for st in tr.stores()]
         return step_fn(tr)
 
@@ -166,6 +178,23 @@ class LabelRangeCheck:
 
     def flush(self):
         self.poll(block=True)
+
+
+def bridge_generation(model) -> int:
+    """changes whenever a training forward or a StoreAdamW step may have changed the model's weights behind torch's version counters"""
+    b = getattr(model, "_hip_bridge", None)
+    return 0 if b is None else b.generation
+
+
+def detach_state_dict_views(module, state_dict, prefix, local_metadata):
+    """state-dict hook of the drop-in models.  After the bridge adopted the parameters they are views of ONE flat storage, some non-contiguous (conv2's permuted
+    weight, the GPT-2 Conv1D `.t()` views): `save_pretrained` then sees every weight as a shared tensor and transformers' `_find_disjoint` / `_end_ptr` calls
+    `.view(-1)` on the non-contiguous ones and raises.  Entries that are views of a larger storage (or non-contiguous) leave as private contiguous copies —
+    what `state_dict()` of an un-adopted model hands out, values identical."""
+    for k, t in list(state_dict.items()):
+        if torch.is_tensor(t) and (not t.is_contiguous() or t.untyped_storage().nbytes() != t.numel() * t.element_size()):
+            state_dict[k] = t.detach().clone(memory_format=torch.contiguous_format)
+    return state_dict
 
 
 def run_training_forward(model, trainer, step_fn):

@@ -13,6 +13,7 @@
 //   cat   bf16 (M, 2d)    [attention branch | cgMLP branch]  (torch.cat at e_branchformer.py:296 is free)
 //   act1  bf16 (B,T1,F1,C1), act2 bf16 (B,T2,F2,C2) channels-last conv activations
 #include "common.hpp"
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include "../../include/hfasr_hip.h"
 
@@ -132,62 +133,81 @@ extern "C" void mi_record_hip_error(int code, const char* file, int line) {
 }
 extern "C" const char* mi_last_error(void) { return g_last_error; }
 
-// ---- profiling facility (diagnostics, off by default): HIP events around every launch of the dense GEMM kernel,
-// recorded on the stream the kernel is launched on.  Used by bench.py for roofline.achieved.
+// ---- profiling facility (diagnostics, off by default): the duration of every dense-contraction launch, taken from the dispatch's own begin / end
+// timestamps (hipExtLaunchKernelGGL with a start / stop event pair: gemm_args.hpp `launch_dense`) — the figure rocprofv3 --kernel-trace reports for the
+// same launch.  Used by bench.py for roofline.achieved.  Process-global, one profiled stream at a time.
 namespace {
-struct Prof { hipEvent_t* ev = nullptr; double* flops = nullptr; int cap = 0, n = 0, stride = 1; long seen = 0; bool on = false; };
+struct Prof { hipEvent_t* ev = nullptr; double* flops = nullptr; int* family = nullptr; int cap = 0, n = 0, stride = 1, open = -1; long seen = 0; bool on = false; };
 Prof g_prof;
 }
 extern "C" int mi_profile_create(int capacity) {
     if (g_prof.ev) return MI_ERR_ARG;
     g_prof.ev = new hipEvent_t[2 * (size_t)capacity];
     g_prof.flops = new double[capacity];
+    g_prof.family = new int[capacity];
     for (int i = 0; i < 2 * capacity; ++i)
         if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return MI_ERR_LAUNCH;
-    g_prof.cap = capacity; g_prof.n = 0; g_prof.on = false;
+    g_prof.cap = capacity; g_prof.n = 0; g_prof.on = false; g_prof.open = -1;
     return MI_OK;
 }
-// on = 0: off; on = s > 0: time every s-th launch (s = 1: all).  Sampling keeps the perturbation of the timed region small.
-extern "C" void mi_profile_enable(int on) { g_prof.on = on != 0; g_prof.stride = on > 0 ? on : 1; g_prof.seen = 0; }
-extern "C" void mi_profile_reset(void) { g_prof.n = 0; }
+// on = 0: off; on = s > 0: time every s-th launch (s = 1: all)
+extern "C" void mi_profile_enable(int on) { g_prof.on = on != 0; g_prof.stride = on > 0 ? on : 1; g_prof.seen = 0; g_prof.open = -1; }
+extern "C" void mi_profile_reset(void) { g_prof.n = 0; g_prof.open = -1; }
 extern "C" int mi_profile_count(void) { return g_prof.n; }
 extern "C" int mi_profile_hook_begin(hipStream_t stream, double flops) {
+    (void)stream;
     if (!g_prof.on || g_prof.n >= g_prof.cap) return -1;
     if ((g_prof.seen++ % g_prof.stride) != 0) return -1;
     const int slot = g_prof.n++;
     g_prof.flops[slot] = flops;
-    hipEventRecord(g_prof.ev[2 * slot], stream);
+    g_prof.family[slot] = -1;              // set by the launcher that takes the events; a slot nobody took counts nothing
+    g_prof.open = slot;
     return slot;
 }
-extern "C" void mi_profile_hook_end(int slot, hipStream_t stream) { hipEventRecord(g_prof.ev[2 * slot + 1], stream); }
-// after the stream is synchronised: sum of elapsed ms and of algorithmic flops over the recorded launches
-extern "C" int mi_profile_summary(double* total_ms, double* total_flops) {
+extern "C" int mi_profile_take_events(hipEvent_t* start, hipEvent_t* stop, int family) {
+    const int slot = g_prof.open;
+    if (slot < 0) return 0;
+    g_prof.open = -1;
+    g_prof.family[slot] = family;
+    *start = g_prof.ev[2 * slot]; *stop = g_prof.ev[2 * slot + 1];
+    return 1;
+}
+extern "C" void mi_profile_hook_end(int slot, hipStream_t stream) { (void)slot; (void)stream; g_prof.open = -1; }
+// after the stream is synchronised: sum of the kernel durations (ms), of the algorithmic flops and the number of recorded launches — all families (family < 0)
+// or one (gemm_args.hpp PF_*)
+extern "C" int mi_profile_summary_family(int family, double* total_ms, double* total_flops, int* launches) {
     double ms = 0.0, fl = 0.0;
+    int n = 0;
     for (int i = 0; i < g_prof.n; ++i) {
+        if (g_prof.family[i] < 0 || (family >= 0 && g_prof.family[i] != family)) continue;
         float t = 0.f;
         if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return MI_ERR_LAUNCH;
-        ms += t; fl += g_prof.flops[i];
+        ms += t; fl += g_prof.flops[i]; ++n;
     }
     *total_ms = ms; *total_flops = fl;
+    if (launches) *launches = n;
     return MI_OK;
 }
+extern "C" int mi_profile_summary(double* total_ms, double* total_flops) { return mi_profile_summary_family(-1, total_ms, total_flops, nullptr); }
 
-// cost of an EMPTY begin/end event pair on `stream` (median of n, ms): the dispatch gap a HIP-event bracket adds to a short kernel.
-// bench.py subtracts it so that the event-timed average agrees with the kernel durations rocprofv3 reports.
+// What the (start, stop) event pair of hipExtLaunchKernelGGL adds to a kernel's own dispatch begin -> end time: the pair around an EMPTY one-wave kernel, median of n (ms).
+// rocprofv3 --kernel-trace reports the empty kernel itself (`profile_null_kernel`) at ~1.3 us on MI355X; the rest of the figure returned here is the bracket's
+// (the runtime's barrier packet in front of a profiled dispatch: 4.1-4.5 us, the same for every kernel family — profiles/r03_*).  bench.py's fall-back roofline leg
+// subtracts (this - 1.3 us) per launch; its primary leg reads the dispatch timestamps from a rocprofv3 child run instead.
+namespace { __global__ void profile_null_kernel() {} }
 extern "C" int mi_profile_calibrate(hipStream_t stream, int n, double* median_ms) {
     if (n <= 0 || n > 256) return MI_ERR_ARG;
     hipEvent_t a[256], b[256];
     float t[256];
     for (int i = 0; i < n; ++i) {
         if (hipEventCreate(&a[i]) != hipSuccess || hipEventCreate(&b[i]) != hipSuccess) return MI_ERR_LAUNCH;
-        hipEventRecord(a[i], stream);
-        hipEventRecord(b[i], stream);
+        hipExtLaunchKernelGGL(profile_null_kernel, dim3(1), dim3(64), 0, stream, a[i], b[i], 0);
     }
     if (hipStreamSynchronize(stream) != hipSuccess) return MI_ERR_LAUNCH;
     for (int i = 0; i < n; ++i) {
         t[i] = 0.f;
-        hipEventElapsedTime(&t[i], a[i], b[i]);
-        hipEventDestroy(a[i]); hipEventDestroy(b[i]);
+        (void)hipEventElapsedTime(&t[i], a[i], b[i]);
+        (void)hipEventDestroy(a[i]); (void)hipEventDestroy(b[i]);
     }
     for (int i = 1; i < n; ++i) { const float v = t[i]; int j = i - 1; while (j >= 0 && t[j] > v) { t[j + 1] = t[j]; --j; } t[j + 1] = v; }
     *median_ms = t[n / 2];

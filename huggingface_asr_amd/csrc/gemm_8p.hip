@@ -707,16 +707,16 @@ int gemm_8p_launch(const GemmArgs& a, bool conv, hipStream_t stream) {
     if (a.out_f32) {
         static bool attr32 = false;
         if (!attr32) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF); attr32 = true; }
-        hipLaunchKernelGGL((gemm8p_kernel<false, 0, true>), dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
+        launch_dense(PF_8P_OUT32, gemm8p_kernel<false, 0, true>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
         return MI_OK;
     }
     if (a.gated) {
         static bool attr_g = false;
         if (!attr_g) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<true, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF); attr_g = true; }
-        hipLaunchKernelGGL((gemm8p_kernel<true, 1, false, true>), dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
+        launch_dense(PF_8P_CONV, gemm8p_kernel<true, 1, false, true>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
         return MI_OK;
     }
-    hipLaunchKernelGGL(kerns[conv ? 1 : 0][a.act], dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
+    launch_dense(conv ? PF_8P_CONV : (a.act ? PF_8P_GELU : PF_8P), kerns[conv ? 1 : 0][a.act], dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
     return MI_OK;
 }
 
@@ -742,9 +742,9 @@ int gemm_8p128_launch(const GemmArgs& a, int ring, hipStream_t stream) {
     if (ring == 0) {          // register-pipelined form (even number of K tiles)
         static bool attr_p = false;
         if (!attr_p) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p128p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * B128_BUF); attr_p = true; }
-        hipLaunchKernelGGL(gemm8p128p_kernel, dim3(grid), dim3(512), (size_t)4 * B128_BUF, stream, a);
+        launch_dense(PF_8P128, gemm8p128p_kernel, dim3(grid), dim3(512), (size_t)4 * B128_BUF, stream, a);
         return MI_OK;
     }
-    hipLaunchKernelGGL(gemm8p128_kernel<4>, dim3(grid), dim3(512), (size_t)4 * B128_BUF, stream, a);
+    launch_dense(PF_8P128, gemm8p128_kernel<4>, dim3(grid), dim3(512), (size_t)4 * B128_BUF, stream, a);
     return MI_OK;
 }

@@ -2,6 +2,7 @@
 // gemm_glds.hip: LDS-DMA pipelined kernel for K % 64 == 0).
 #pragma once
 #include "common.hpp"
+#include <hip/hip_ext.h>
 
 struct GemmArgs {
     const bf16_t* A; long lda;
@@ -33,3 +34,19 @@ bool gemm_8p_supported(const GemmArgs& a, bool conv);
 int gemm_8p_launch(const GemmArgs& a, bool conv, hipStream_t stream);
 bool gemm_8p128_supported(const GemmArgs& a);
 int gemm_8p128_launch(const GemmArgs& a, int ring, hipStream_t stream);
+
+
+// Profiling hand-off (diagnostics; encoder.hip `mi_profile_*`): while a profiling slot is open the dense-contraction launchers start their kernel with
+// hipExtLaunchKernelGGL and the slot's (start, stop) events, so the pair carries the DISPATCH's own begin / end timestamps — the quantity rocprofv3 --kernel-trace
+// reports — instead of bracketing the launch with two hipEventRecord markers, which also times the gap between the markers and the kernel.
+// `family`: 0 gemm8p 256x256 (bf16 out, no activation), 1 gemm8p + GELU epilogue, 2 gemm8p implicit-GEMM conv, 3 gemm8p fp32 out (CTC head), 4 gemm8p128 (N = 512 class),
+//           5 gemm_glds, 6 gemm_bf16 (generic)
+extern "C" int mi_profile_take_events(hipEvent_t* start, hipEvent_t* stop, int family);
+enum { PF_8P = 0, PF_8P_GELU = 1, PF_8P_CONV = 2, PF_8P_OUT32 = 3, PF_8P128 = 4, PF_GLDS = 5, PF_GENERIC = 6, PF_COUNT = 7 };
+
+template <typename F, typename... Args>
+inline void launch_dense(int family, F kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
+    hipEvent_t e0, e1;
+    if (mi_profile_take_events(&e0, &e1, family)) hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)lds, stream, e0, e1, 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
+}

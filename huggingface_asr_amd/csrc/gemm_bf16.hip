@@ -200,12 +200,10 @@ int launch(const GemmArgs& a, bool conv, hipStream_t stream) {
     }
     const int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
     const size_t lds = 2 * (BM + BN) * BK * sizeof(bf16_t);
-    if (conv) hipLaunchKernelGGL(gemm_bf16_kernel<true>, dim3(grid), dim3(NT), lds, stream, a);
-    else {
-        const int slot = mi_profile_hook_begin(stream, 2.0 * a.M * a.N * a.K);
-        hipLaunchKernelGGL(gemm_bf16_kernel<false>, dim3(grid), dim3(NT), lds, stream, a);
-        if (slot >= 0) mi_profile_hook_end(slot, stream);
-    }
+    const int slot = mi_profile_hook_begin(stream, 2.0 * a.M * a.N * a.K);
+    if (conv) launch_dense(PF_GENERIC, gemm_bf16_kernel<true>, dim3(grid), dim3(NT), lds, stream, a);
+    else launch_dense(PF_GENERIC, gemm_bf16_kernel<false>, dim3(grid), dim3(NT), lds, stream, a);
+    if (slot >= 0) mi_profile_hook_end(slot, stream);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

@@ -322,13 +322,13 @@ int gemm_glds_launch(const GemmArgs& a, bool conv, hipStream_t stream) {
     if (!conv && v != 30 && v != 31 && steps_per_cu <= 48) {
         int g = cdiv(a.M, 128) * cdiv(a.N, 64);
         if (g > 768) g = 768;
-        hipLaunchKernelGGL((gemm_glds_kernel<128, 64, 2, 2, 2, false>), dim3(g), dim3(NT), (size_t)2 * (128 + 64) * BK * 2, stream, a);
+        launch_dense(PF_GLDS, gemm_glds_kernel<128, 64, 2, 2, 2, false>, dim3(g), dim3(NT), (size_t)2 * (128 + 64) * BK * 2, stream, a);
         return MI_OK;
     }
     int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
     if (v != 31 && grid > 512) grid = 512;
     const size_t lds = (size_t)2 * STAGE_BYTES;
-    if (conv) hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, 2, true>), dim3(grid), dim3(NT), lds, stream, a);
-    else hipLaunchKernelGGL((gemm_glds_kernel<128, 128, 2, 2, 2, false>), dim3(grid), dim3(NT), lds, stream, a);
+    if (conv) launch_dense(PF_GLDS, gemm_glds_kernel<128, 128, 2, 2, 2, true>, dim3(grid), dim3(NT), lds, stream, a);
+    else launch_dense(PF_GLDS, gemm_glds_kernel<128, 128, 2, 2, 2, false>, dim3(grid), dim3(NT), lds, stream, a);
     return MI_OK;
 }

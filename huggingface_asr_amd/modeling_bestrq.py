@@ -66,6 +66,8 @@ class BestRQEBranchformerForPreTraining(PreTrainedModel):
         if hasattr(self.wav2vec2, "masked_spec_embed"):
             del self.wav2vec2.masked_spec_embed                       # bestrq.py:174-176
         self._trainer = None
+        from .autograd_bridge import detach_state_dict_views
+        self._register_state_dict_hook(detach_state_dict_views)
         self.post_init()
 
     def _init_weights(self, module):
@@ -103,7 +105,8 @@ class BestRQEBranchformerForPreTraining(PreTrainedModel):
                 return t.forward_backward(input_values, fl, mask_time_indices)
             loss, out = run_training_forward(self, tr, step)
         else:
-            key = (sum(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()))
+            from .autograd_bridge import bridge_generation
+            key = (sum(p._version for p in self.parameters()), bridge_generation(self), tuple(p.data_ptr() for p in self.parameters()))
             if getattr(self, "_trainer_key", None) != key:
                 tr.load_state_dict(dict(self.state_dict()))
                 self._trainer_key = key

@@ -169,6 +169,8 @@ class Wav2Vec2EBranchformerForCTC(PreTrainedModel):
         self.blank_projection = nn.Linear(config.hidden_size, 1)
         self._engine: Optional[EBranchformerEngine] = None
         self._engine_key = None
+        from .autograd_bridge import detach_state_dict_views
+        self._register_state_dict_hook(detach_state_dict_views)      # adopted parameters (views of the trainer's flat store) leave state_dict() / save_pretrained() as private copies
         self.post_init()
 
     def _init_weights(self, module):
@@ -221,7 +223,8 @@ class Wav2Vec2EBranchformerForCTC(PreTrainedModel):
             self._engine = EBranchformerEngine(cfg_from_hf(self.config), device)
             self._engine_key = None
         pl = self._param_list()
-        key = (self._weights_version(), pl[0].data_ptr(), pl[-1].data_ptr(), pl[len(pl) // 2].data_ptr())
+        from .autograd_bridge import bridge_generation
+        key = (self._weights_version(), bridge_generation(self), pl[0].data_ptr(), pl[-1].data_ptr(), pl[len(pl) // 2].data_ptr())
         if key != self._engine_key:
             self._engine.load_state_dict({k: v for k, v in self.state_dict().items()})
             self._engine_key = key

@@ -211,6 +211,8 @@ class JointCTCAttentionEncoderDecoder(PreTrainedModel):
             self.encoder.lm_head.weight = self.decoder.lm_head.weight
         self._engine = None
         self._engine_key = None
+        from .autograd_bridge import detach_state_dict_views
+        self._register_state_dict_hook(detach_state_dict_views)      # adopted parameters (views of the trainers' flat stores, GPT-2 Conv1D `.t()` views) leave as private contiguous copies
         from .decoding import GenerationConfigCustom
         # trainers overwrite this (train_enc_dec_asr.py:85); the default carries the ids of the model config
         self.generation_config = GenerationConfigCustom(pad_token_id=config.pad_token_id, eos_token_id=config.decoder.eos_token_id,
@@ -274,7 +276,8 @@ class JointCTCAttentionEncoderDecoder(PreTrainedModel):
                       decoder_start_token_id=self.config.decoder_start_token_id)
             self._engine = JointAEDEngine(cfg_from_hf(self.config.encoder), _dec_cfg_dict(self.config.decoder), jc, device)
             self._engine_key = None
-        key = (sum(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()))
+        from .autograd_bridge import bridge_generation
+        key = (sum(p._version for p in self.parameters()), bridge_generation(self), tuple(p.data_ptr() for p in self.parameters()))
         if key != self._engine_key:
             self._engine.load_state_dict(dict(self.state_dict()))
             self._engine_key = key

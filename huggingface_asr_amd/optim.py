@@ -26,6 +26,7 @@ class StoreAdamW(torch.optim.Optimizer):
         params = [p for p in model.parameters() if p.requires_grad]
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm))
         self.last_grad_norm = None
+        self._pending_state = None          # moments loaded before the parameters were adopted (accelerate's prepare / a resume): applied by the first step()
 
     # ------------------------------------------------------------------ helpers
     def _bridge(self):
@@ -35,12 +36,26 @@ class StoreAdamW(torch.optim.Optimizer):
                                "`model.to(...)` / `.float()` after it re-allocates them) — there is no fallback to a torch optimizer")
         return bridge
 
+    def _adopted_bridge(self):
+        bridge = getattr(self.model, "_hip_bridge", None)
+        return bridge if (bridge is not None and getattr(bridge, "zero_copy", False) and bridge._still_adopted()) else None
+
+    def _apply_pending(self, tr):
+        if self._pending_state:
+            stores = tr.stores()
+            if len(stores) != len(self._pending_state) or any(st.flat_m.numel() != rec["m"].numel() for st, rec in zip(stores, self._pending_state)):
+                raise RuntimeError("StoreAdamW: the loaded optimizer state does not match this model's parameter stores")
+            for st, rec in zip(stores, self._pending_state):
+                st.flat_m.copy_(rec["m"]); st.flat_v.copy_(rec["v"]); st.step_count = int(rec["step"])
+        self._pending_state = None
+
     @torch.no_grad()
     def step(self, closure=None):
         if closure is not None:
             raise RuntimeError("StoreAdamW does not re-evaluate the model: closures are not supported")
         bridge = self._bridge()
         tr = bridge.trainer
+        self._apply_pending(tr)
         g = self.param_groups[0]
         named = dict(bridge.named)
         # pieces whose reference layout is not a view of the packed layout (the front end's `out` Linear): their `.grad` is a copy autograd owns — the trainer's
@@ -59,17 +74,27 @@ class StoreAdamW(torch.optim.Optimizer):
         for n in bridge.copy_names:                                             # masters -> the separately stored parameters (imported again by the next forward)
             named[n].copy_(tr.export_piece(n))
         bridge.mirrors_fresh = True                                             # the next training forward need not re-cast the masters
+        bridge.generation += 1                                                  # the masters changed through raw pointers: no tensor version moved (eval-engine cache key)
         return None
 
-    # optimizer state = the flat moment buffers (per store) + step counts: what a Trainer checkpoint saves and `--restart_from` restores
+    # optimizer state = the flat moment buffers (per store) + step counts: what a Trainer checkpoint saves and `--restart_from` restores.
+    # Both work BEFORE the first training forward (the bridge adopts the parameters there): `accelerator.prepare(optimizer)` round-trips the state at construction and
+    # HF Trainer's resume loads it before any step — an un-adopted optimizer has no moments yet (empty list), and a loaded state waits for the first step().
     def state_dict(self):
-        tr = self._bridge().trainer
-        return {"state": {"stores": [dict(m=st.flat_m.clone(), v=st.flat_v.clone(), step=st.step_count) for st in tr.stores()]},
+        bridge = self._adopted_bridge()
+        if bridge is None:
+            stores = [dict(m=r["m"].clone(), v=r["v"].clone(), step=r["step"]) for r in (self._pending_state or [])]
+        else:
+            self._apply_pending(bridge.trainer)
+            stores = [dict(m=st.flat_m.clone(), v=st.flat_v.clone(), step=st.step_count) for st in bridge.trainer.stores()]
+        return {"state": {"stores": stores},
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} | {"params": list(range(len(g["params"])))} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
-        tr = self._bridge().trainer
-        for st, rec in zip(tr.stores(), sd["state"]["stores"]):
-            st.flat_m.copy_(rec["m"]); st.flat_v.copy_(rec["v"]); st.step_count = int(rec["step"])
+        recs = list(sd.get("state", {}).get("stores", []))
+        bridge = self._adopted_bridge()
+        self._pending_state = [dict(m=r["m"].detach().clone(), v=r["v"].detach().clone(), step=int(r["step"])) for r in recs] or None
+        if bridge is not None:
+            self._apply_pending(bridge.trainer)
         for g, s in zip(self.param_groups, sd["param_groups"]):
             g.update({k: v for k, v in s.items() if k != "params"})

@@ -558,6 +558,8 @@ class EncoderCTCTrainer:
         parameters get no gradient).  None = draw them as the reference does — one uniform number per layer and step, layer skipped when it
         is below `config.layerdrop` (every rank draws its own, from its dropout seed) — in training mode; nothing is skipped in eval."""
         c, st = self.cfg, self.store
+        if getattr(self, "_lnred", None) is not None:
+            self._lnred.items = []              # a step that raised part-way leaves deferred LayerNorm reductions behind: they must not land in this step's gradients
         P, G, W, WT = st.p, st.g, st.bf, st.bfT
         GL = lambda n, sl=None: None if n in self.frozen else (st.g(n) if sl is None else st.g(n)[sl])      # gradient of a linear's weight / bias, None when frozen
         dev = self.device

@@ -25,14 +25,16 @@ typedef struct ihipStream_t* mi_stream_t; /* = hipStream_t */
 /* diagnostics: text of the last failed kernel launch on the calling thread ("" if none). */
 const char* mi_last_error(void);
 
-/* profiling facility (off by default; process-global, not thread-safe, not for production): HIP events recorded on
- * the launch stream around every launch of a dense contraction (GEMM / implicit-GEMM conv), for bench.py's roofline.achieved. */
+/* profiling facility (off by default; process-global, not thread-safe, not for production): while enabled, every launch of a dense contraction (GEMM /
+ * implicit-GEMM conv) is started with hipExtLaunchKernelGGL and a start / stop event pair, i.e. its duration is the dispatch's own begin -> end timestamps —
+ * what rocprofv3 --kernel-trace reports for the same launch — for bench.py's roofline.achieved. */
 int mi_profile_create(int capacity);
 void mi_profile_enable(int on);
 void mi_profile_reset(void);
 int mi_profile_count(void);
 int mi_profile_summary(double* total_ms, double* total_flops);
-int mi_profile_calibrate(mi_stream_t stream, int n, double* median_ms);   /* cost of an empty event pair (subtracted per launch by bench.py) */
+int mi_profile_calibrate(mi_stream_t stream, int n, double* median_ms);   /* event pair around an EMPTY kernel, median of n: what the bracket adds + the empty kernel's ~1.3 us */
+int mi_profile_summary_family(int family, double* total_ms, double* total_flops, int* launches);   /* family < 0: all; 0 gemm8p, 1 gemm8p+GELU, 2 gemm8p conv, 3 gemm8p fp32 out, 4 gemm8p128, 5 gemm_glds, 6 generic */
 
 /* ---- nn.Linear / lm_head / projections: C[M,N] = epi(A[M,K] * W[N,K]^T), bf16 in, fp32 accumulate (MFMA).
  * replaces: every nn.Linear on the path — reference src/models/encoders/e_branchformer.py:96-98,139,212-216,247,456-457;

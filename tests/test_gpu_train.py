@@ -893,3 +893,117 @@ def test_hf_bestrq_ctc_finetune_options_forward_and_training_bridge():
     with torch.no_grad():
         after = model(x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))
     assert float(after.loss) != float(out.loss) and np.isfinite(float(after.loss))
+
+
+def _tiny_ctc_model(seed=11):
+    from transformers import AutoModelForCTC
+    from huggingface_asr_amd.bind import bind_all
+    from huggingface_asr_amd.configuration_ebranchformer import Wav2Vec2EBranchformerConfig
+    bind_all()
+    base = dict(shapes.TINY); base.pop("num_fbanks")
+    model = AutoModelForCTC.from_config(Wav2Vec2EBranchformerConfig(**base, ctc_zero_infinity=True, ctc_loss_reduction="mean", **HF_NO_DROPOUT))
+    from helpers import seeded_state_dict
+    model.load_state_dict(seeded_state_dict(dict(shapes.TINY), seed), strict=False)
+    return model.to(DEV).train()
+
+
+def test_save_pretrained_after_the_bridge_adopted_the_parameters(tmp_path):
+    """after the first training forward every nn.Parameter is a view of ONE flat storage, some non-contiguous (conv2's permuted weight); transformers'
+    save path (`_find_disjoint` -> `_end_ptr` -> `.view(-1)`) raised on them.  The models' state-dict hook hands out private contiguous copies: training forward ->
+    optimizer step -> save_pretrained -> from_pretrained returns the trained weights bit for bit, for the CTC model and for the joint model (GPT-2 Conv1D `.t()` views)."""
+    from transformers import AutoModelForCTC
+    from helpers import synth_feats, synth_labels
+    model = _tiny_ctc_model()
+    x, am = synth_feats(11, 2, 200, [198, 150])
+    lab = synth_labels(11, 2, 7, 50, [7, 5])
+    batch = dict(input_values=x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    model(**batch).loss.backward(); opt.step(); opt.zero_grad()
+    conv2 = dict(model.named_parameters())["wav2vec2.feature_extractor.conv.1.0.conv.weight"]
+    assert not conv2.is_contiguous()                                     # the adoption is in place
+    sd = model.state_dict()
+    assert all(v.is_contiguous() and v.untyped_storage().nbytes() == v.numel() * v.element_size() for v in sd.values())
+    model.save_pretrained(tmp_path / "ctc")
+    back = AutoModelForCTC.from_pretrained(tmp_path / "ctc")
+    for k, v in back.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k].cpu()), k
+    # eval after training sees the trained weights (the engine cache is keyed on the bridge's generation as well as on tensor versions)
+    model.eval()
+    with torch.no_grad():
+        l_eval = float(model(**batch).loss)
+    fresh = back.to(DEV).eval()
+    with torch.no_grad():
+        assert abs(float(fresh(**batch).loss) - l_eval) < 1e-6
+    # the joint model
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import aed_case_inputs
+    from test_surface_cpu import _joint_model
+    g = load_golden("grads_aed_tiny")
+    jsd, jx, jam, jlab = aed_case_inputs(g)
+    jm = _joint_model(False)
+    jm.load_state_dict(jsd, strict=False)
+    jm = jm.to(DEV).train()
+    jopt = torch.optim.SGD(jm.parameters(), lr=1e-2)
+    jm(input_values=jx.to(DEV), attention_mask=jam.to(DEV), labels=jlab.to(DEV)).loss.backward(); jopt.step(); jopt.zero_grad()
+    jsd2 = jm.state_dict()
+    jm.save_pretrained(tmp_path / "joint")
+    from safetensors.torch import load_file
+    files = [f for f in os.listdir(tmp_path / "joint") if f.endswith(".safetensors")]
+    assert files
+    saved = {}
+    for f in files:
+        saved.update(load_file(str(tmp_path / "joint" / f)))
+    assert len(saved) >= len([k for k in jsd2 if "attn.bias" not in k and "masked_bias" not in k]) - 2
+    for k, v in saved.items():
+        assert torch.equal(v, jsd2[k].cpu()), k
+
+
+def test_backward_of_a_stale_forward_is_refused():
+    """The gradients of a step live in the trainer's flat store: forward A, forward B, A.backward() would hand A the gradients of B.  Refused, as is a second backward."""
+    from helpers import synth_feats, synth_labels
+    model = _tiny_ctc_model()
+    x, am = synth_feats(11, 2, 200, [198, 150])
+    lab = synth_labels(11, 2, 7, 50, [7, 5])
+    batch = dict(input_values=x.to(DEV), attention_mask=am.to(DEV), labels=lab.to(DEV))
+    la = model(**batch).loss
+    lb = model(**batch).loss
+    with pytest.raises(RuntimeError, match="no longer the latest"):
+        la.backward()
+    lb.backward()
+    lc = model(**batch).loss
+    lc.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="twice"):
+        lc.backward()
+
+
+def test_hf_trainer_with_store_adamw_saves_and_resumes(tmp_path):
+    """the documented route `Trainer(optimizers=(StoreAdamW(model), None))`.  accelerate's `prepare(optimizer)` round-trips the optimizer state BEFORE any
+    forward and a resume loads it before the first step; both used to raise (the parameters are adopted by the first training forward).  Two steps of a real HF Trainer with
+    save_steps=1, then a fresh model + optimizer resumed from checkpoint-1 reproduces step 2: same weights as the uninterrupted run."""
+    from transformers import Trainer, TrainingArguments
+    from huggingface_asr_amd.optim import StoreAdamW
+    from helpers import synth_feats, synth_labels
+    x, am = synth_feats(11, 4, 200, [198, 150, 200, 120])
+    lab = synth_labels(11, 4, 7, 50, [7, 5, 6, 4])
+    data = [dict(input_values=x[i], attention_mask=am[i], labels=lab[i]) for i in range(4)]
+
+    def run(out, max_steps, resume=None):
+        model = _tiny_ctc_model()
+        args = TrainingArguments(output_dir=str(out), per_device_train_batch_size=2, max_steps=max_steps, save_strategy="steps", save_steps=1, learning_rate=1e-3,
+                                 lr_scheduler_type="constant", max_grad_norm=0.0, report_to=[], remove_unused_columns=False, dataloader_num_workers=0, seed=3,
+                                 logging_steps=1, dataloader_drop_last=True)
+        opt = StoreAdamW(model, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+        sd0 = opt.state_dict()                                                # before adoption: an empty state, not a raise
+        assert sd0["state"]["stores"] == []
+        opt.load_state_dict(sd0)
+        tr = Trainer(model=model, args=args, train_dataset=data, optimizers=(opt, torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0)))
+        tr.train(resume_from_checkpoint=resume)
+        return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, opt
+    full, opt_full = run(tmp_path / "a", 2)
+    assert (tmp_path / "a" / "checkpoint-1").is_dir() and (tmp_path / "a" / "checkpoint-2").is_dir()
+    assert opt_full.state_dict()["state"]["stores"][0]["step"] == 2
+    resumed, opt_res = run(tmp_path / "a", 2, resume=str(tmp_path / "a" / "checkpoint-1"))
+    assert opt_res.state_dict()["state"]["stores"][0]["step"] == 2
+    for k, v in full.items():
+        torch.testing.assert_close(resumed[k], v, rtol=1e-5, atol=1e-6, msg=k)
