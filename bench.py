@@ -171,6 +171,11 @@ def parse_args(argv=None):
     ap.add_argument("--pos", default="relative", choices=["relative", "rotary"])
     ap.add_argument("--train", action="store_true", help="BASELINE config 3 instead of the headline: data-parallel TRAINING step of the joint AED model "
                                                          "(small encoder + 6x256 GPT-2 decoder, per-GPU batch 96, 1-20 s clips), gradient all-reduce over RCCL")
+    ap.add_argument("--overlap", type=int, default=0, choices=[0, 1], help="--train: gradient all-reduce schedule. 0 = ONE collective per parameter store after the backward "
+                                                                           "(default); 1 = one async all-reduce per layer range as soon as it is final, overlapped with the "
+                                                                           "backward of the earlier layers (what DDP's bucket hooks give the reference; DESIGN.md section 6 before enabling on RCCL)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo: tests with several ranks on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (tests on a one-GPU box; needs --backend gloo)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check on a box without GPUs: gloo, no HIP work, value null")
     return ap.parse_args(argv)
 
@@ -216,6 +221,8 @@ def train_bench(args, world, rank, dev, PL):
     jcfg = dict(ctc_weight=0.3, pad_token_id=3, decoder_start_token_id=1)
     B = args.batch or 96
     tr = JointAEDTrainer(cfg, dcfg, jcfg, dev, lr=2e-3, weight_decay=1e-6)
+    for sync in (tr.enc.sync, tr.sync):                     # the two parameter stores (encoder, decoder) each own their gradient all-reduce
+        sync.overlap = bool(args.overlap)
     tr.enc.load_state_dict(sd)
     g = torch.Generator().manual_seed(1)
     for s_ in tr.store.specs.values():                      # seeded decoder weights straight into the packed store (same on every rank)
@@ -234,6 +241,8 @@ def train_bench(args, world, rank, dev, PL):
 
     def one():
         state["o"] = tr.train_step(feats, lens, labels)
+    one()                                                   # untimed first step from the seeded weights: its global gradient norm (deterministic reduction of the all-reduced
+    first_norm = float(state["o"]["grad_norm"])             # gradients) identifies the step's gradients independently of the schedule
     for _ in range(args.warmup):
         one()
     dt = PL.timed(one, args.steps, sync=torch.cuda.synchronize, device=dev)
@@ -250,6 +259,19 @@ def train_bench(args, world, rank, dev, PL):
             for b_ in bufs: td.all_reduce(b_)
         e1.record(); torch.cuda.synchronize()
         ar_ms = round(e0.elapsed_time(e1) / 10, 3)
+    # per-rank view: every rank's own wall time per step and a checksum of its weights after the timed steps (replicas must stay bit-identical)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    mine = torch.tensor([(time.perf_counter() - t0) / 3 * 1e3, float(tr.enc.store.flat_p.double().sum()), float(tr.store.flat_p.double().sum())], dtype=torch.float64)
+    buf = mine.to(dev) if (world > 1 and td.get_backend() == "nccl") else mine
+    per_rank = [torch.zeros_like(buf) for _ in range(world)]
+    if world > 1:
+        td.all_gather(per_rank, buf)
+    else:
+        per_rank = [buf]
+    per_rank = [t.cpu() for t in per_rank]
     if rank == 0:
         n_params = tr.store.n + tr.enc.store.n
         # every rank drew its own lengths; the job's audio = sum over ranks (same distribution): use this rank's sum x world
@@ -263,6 +285,11 @@ def train_bench(args, world, rank, dev, PL):
                                                  f"{B} clips of 1-20 s per GPU padded to 2000 frames", "per_gpu_batch": B, "frames": T, "n_params": n_params,
                                      "parallelism": f"dp{world}: SUM all-reduce of {n_params * 4 / 1e6:.0f} MB fp32 gradients after the backward",
                                      "loss": round(float(state["o"]["loss"]), 4)},
+                          "schedule": "overlap: one async all-reduce per layer range, launched while the backward of the earlier layers runs" if args.overlap
+                                      else "after-backward: one all-reduce per parameter store once the backward is done",
+                          "first_step_grad_norm": first_norm, "ms_per_step_by_rank": [round(float(t[0]), 3) for t in per_rank],
+                          "weights_checksum_by_rank": [[repr(float(t[1])), repr(float(t[2]))] for t in per_rank],
+                          "replicas_identical": all(bool(torch.equal(t[1:], per_rank[0][1:])) for t in per_rank),
                           "all_reduce_ms": ar_ms, "all_reduce_note": "the step's gradient all-reduce timed on its own (same buffers), per step" if ar_ms else None,
                           "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)
     if world > 1:
@@ -282,9 +309,11 @@ def main():
         return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible. The hot path is HIP-only (no CPU fallback); use --dry-run to check the launcher on a GPU-less box.")
-    dev = torch.device("cuda", local)
+    if args.share_gpu and args.backend != "gloo":
+        raise SystemExit("bench.py: --share-gpu puts every rank on cuda:0, which RCCL refuses (one device per rank): use --backend gloo")
+    dev = torch.device("cuda", 0 if args.share_gpu else local)
     torch.cuda.set_device(dev)
-    PL.init("nccl", dev)                      # RCCL; no-op for one process
+    PL.init(args.backend, dev if args.backend == "nccl" else None)      # nccl = RCCL; no-op for one process
     dist = world > 1
     import torch.distributed as td
     if args.train:

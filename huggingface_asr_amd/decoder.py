@@ -340,5 +340,5 @@ def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_lengt
             for k in range(W):
                 finished[b].append((float(bs[b, k]) / (ids_cpu.shape[1] ** length_penalty), ids_cpu[b * W + k].tolist()))
         best = max(finished[b], key=lambda t: t[0])
-        out.append(dict(tokens=best[1], score=best[0]))
+        out.append(dict(tokens=best[1], score=best[0], hypotheses=sorted(finished[b], key=lambda t: -t[0])))      # hypotheses: every kept (score, tokens), best first
     return out

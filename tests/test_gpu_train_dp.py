@@ -133,3 +133,32 @@ def test_two_rank_data_parallel_joint_aed_step():
             n += 1
     assert n > 100 and worst < 1e-4, (n, worst)          # 1 / world = 0.5 scales exactly; what is left is the float atomics of the bias / LayerNorm reductions
     assert r0["wsum"] == r1["wsum"]
+
+
+def test_bench_train_entry_point_both_schedules_identical_weights():
+    """`bench.py --train --overlap {0,1}` through bench.py's OWN entry point (it starts its ranks itself), two ranks sharing the box's one GPU over
+    gloo: both gradient all-reduce schedules — one collective per parameter store after the backward, and one async all-reduce per layer range overlapped with the
+    backward — must leave bit-identical replicas AND the same weights as each other after the same steps; the line names the schedule and carries per-rank step times."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    recs = {}
+    for ov in (0, 1):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--train", "--gpus", "2", "--backend", "gloo", "--share-gpu", "--overlap", str(ov),
+                            "--steps", "2", "--warmup", "1", "--batch", "4"], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, HFASR_DP_OVERLAP="0"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        recs[ov] = json.loads(line)
+    for ov, rec in recs.items():
+        assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["backend"] == "gloo"
+        assert rec["replicas_identical"] is True and len(rec["ms_per_step_by_rank"]) == 2 and rec["all_reduce_ms"] is not None
+        assert ("overlap" in rec["schedule"]) == bool(ov)
+    # Same seeded weights, same shards: the first step's all-reduced gradients are the same under both schedules — their global norm (a deterministic reduction) agrees to the
+    # float-atomic noise of the bias / LayerNorm-affine reductions (<= 3e-7 between two runs of the SAME schedule, DESIGN.md 4b 'Reproducibility').  AdamW's normalisation then
+    # amplifies that noise step by step (the same between two runs of one schedule), so the weights after the 6 steps are compared loosely; within a run the replicas are
+    # bit-identical (asserted above).
+    assert abs(recs[0]["first_step_grad_norm"] - recs[1]["first_step_grad_norm"]) <= 1e-5 * recs[0]["first_step_grad_norm"], (recs[0]["first_step_grad_norm"], recs[1]["first_step_grad_norm"])
+    for a, b in zip(recs[0]["weights_checksum_by_rank"][0], recs[1]["weights_checksum_by_rank"][0]):
+        assert abs(float(a) - float(b)) <= 1e-3 * max(1.0, abs(float(a))), (a, b)
