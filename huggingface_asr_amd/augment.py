@@ -53,6 +53,40 @@ class SpecAug(torch.nn.Module):
         pos = torch.randint(0, max(1, D - int(length.max())), (B, num))
         return pos, length
 
+    def draw_single(self, t: int, fq: int) -> torch.Tensor:
+        """The parameter row of ONE utterance of t frames augmented on its own — what the reference's dataloader-side chain does (callbacks.py:100-118: SpecAug is called
+        per sample with a (T, F) tensor and no lengths): the draws `forward(x[None])` makes, in the same order.  -> int32 row [len, warp on, centre, warped, masks...]."""
+        nf = self.num_freq_mask if self.apply_freq_mask else 0
+        nt = self.num_time_mask if self.apply_time_mask else 0
+        P = torch.zeros(4 + 2 * nf + 2 * nt, dtype=torch.int32)
+        P[0] = t
+        if self.apply_time_warp:
+            P[1:4] = torch.tensor(self._warp_params(t), dtype=torch.int32)
+        if nf:
+            pos, ln = self._mask_params(1, fq, self.freq_range[0], self.freq_range[1], nf)
+            P[4:4 + 2 * nf:2], P[5:5 + 2 * nf:2] = pos[0].int(), ln[0].int()
+        if nt:
+            if self.time_range is not None:
+                lo, hi = self.time_range
+            else:
+                lo, hi = max(0, math.floor(t * self.time_ratio[0])), min(t, math.floor(t * self.time_ratio[1]))
+            if hi > lo:
+                pos, ln = self._mask_params(1, t, lo, hi, nt)
+                P[4 + 2 * nf::2], P[5 + 2 * nf::2] = pos[0].int(), ln[0].int()
+        return P
+
+    def apply_rows(self, x: torch.Tensor, P: torch.Tensor) -> torch.Tensor:
+        """x (B, T, F) fp32 CUDA (rows beyond an utterance's length are padding), P (B, 4 + 2 nf + 2 nt) int32 parameter rows (`draw_single`): every utterance warped /
+        masked over ITS OWN length, padding left zero — one launch for the batch."""
+        x = x.to(torch.float32).contiguous()
+        B, Tn, Fq = x.shape
+        nf = self.num_freq_mask if self.apply_freq_mask else 0
+        nt = self.num_time_mask if self.apply_time_mask else 0
+        Pd = P.to(device=x.device, dtype=torch.int32).contiguous()
+        out = torch.empty_like(x)
+        _lib.check(_lib.lib().mi_specaug_f32(x.data_ptr(), out.data_ptr(), B, Tn, Fq, Pd.data_ptr(), nf, nt, 0.0, torch.cuda.current_stream().cuda_stream), "mi_specaug_f32")
+        return out
+
     def forward(self, x: torch.Tensor, x_lengths: Optional[torch.Tensor] = None):
         if not x.is_cuda:
             raise RuntimeError("huggingface_asr_amd.augment.SpecAug runs on the GPU (no CPU fallback); keep the reference class for CPU workers")

@@ -39,3 +39,100 @@ def test_specaug_constructor_errors_and_device_only():
         SpecAug(time_mask_width_range=5, time_mask_width_ratio_range=0.05)
     with pytest.raises(RuntimeError):
         SpecAug(**RECIPE)(torch.zeros(1, 50, 80))
+
+
+# configs/default_data_preprocessing2d.json:3-58 of the reference (the train chain; parameters only) — the GPU box has no /root/reference
+TRAIN_CHAIN = [
+    {"name": "torchaudio.transforms.SpeedPerturbation", "params": {"orig_freq": 16000, "factors": [0.9, 1.0, 1.1]}, "steps_before_activation": 0, "return_behaviour": [0],
+     "fn_call_params": {}},
+    {"name": "feature_extractor", "steps_before_activation": 0, "fn_call_params": {"return_attention_mask": False, "padding": False, "sampling_rate": 16000, "return_tensors": "pt"},
+     "return_behaviour": ["input_features[0]"]},
+    {"name": "augmentations.spec_aug.SpecAug", "params": RECIPE, "steps_before_activation": 0, "fn_call_params": {}, "return_behaviour": [0]},
+]
+EVAL_CHAIN = [TRAIN_CHAIN[1]]
+
+
+def _clips():
+    n = 16000 * 3
+    lens = [n, 30000, 41000, 6000]                                              # the last one is < 8000 samples: zero-padded to 8000 by default_transform
+    w = np.zeros((4, n), np.float32)
+    for b, le in enumerate(lens):
+        w[b, :le] = synth.normal(60 + b, "chain", (le,), 0.1)
+    w[1, :700] = 0.0                                                            # leading zeros: stripped
+    w[2, 40000:41000] = 0.0                                                     # trailing zeros inside the valid range: stripped
+    return torch.from_numpy(w), torch.tensor(lens, dtype=torch.int32)
+
+
+def test_device_chain_equals_the_per_utterance_chain():
+    """The reference runs SpeedPerturbation -> feature_extractor -> SpecAug PER UTTERANCE in dataloader workers (callbacks.py:100-118).  The device chain on the whole batch
+    must equal applying the (individually pinned) device modules utterance by utterance in that order, with the same torch seed: one speed factor per utterance (not one
+    per batch), SpecAug drawn for the utterance's own length, utterance CMVN, zero padding + mask like the collator."""
+    from huggingface_asr_amd.augment import SpecAug, SpeedPerturbation
+    from huggingface_asr_amd.fbank import strip_zeros_pad_gpu
+    from huggingface_asr_amd.feature_extraction import CustomFeatureExtractor
+    from huggingface_asr_amd.transforms import DevicePreprocessing
+    fe = CustomFeatureExtractor(feature_size=80, norm_type="utterance")
+    chain = DevicePreprocessing({"train": TRAIN_CHAIN, "default_preprocessing": EVAL_CHAIN}, fe, pad_to_multiple_of=100)
+    wave, lens = _clips()
+    wd, ld = wave.to("cuda:0"), lens.to("cuda:0")
+    torch.manual_seed(5)
+    out = chain(wd, ld, "train")
+    feats, mask = out["input_features"], out["attention_mask"]
+    assert feats.shape[1] % 100 == 0 and len(set(out["speed_factor_index"])) > 1           # per-utterance factors
+    # the same, utterance by utterance
+    sp, sa = SpeedPerturbation(16000, [0.9, 1.0, 1.1]), SpecAug(**RECIPE)
+    torch.manual_seed(5)
+    for b in range(4):
+        w1, n1 = strip_zeros_pad_gpu(wd[b:b + 1], ld[b:b + 1], 8000)
+        n = int(n1[0])
+        k = int(torch.randint(3, ()))
+        assert k == out["speed_factor_index"][b]
+        y, _ = sp.speeders[k](w1[:, :n])
+        f1, m1 = fe.extract_on_device(y, torch.tensor([y.shape[1]], dtype=torch.int32, device="cuda:0"), default_transform=False)
+        t_b = int(m1.sum())
+        a1, _ = sa(f1[0, :t_b])                                                               # (T, F): the per-sample call of the reference's chain
+        assert int(mask[b].sum()) == t_b == int(out["num_frames"][b])
+        torch.testing.assert_close(feats[b, :t_b], a1, atol=1e-5, rtol=0)
+        assert float(feats[b, t_b:].abs().max()) == 0.0 if t_b < feats.shape[1] else True
+    # the evaluation chain (and any split the config does not name, callbacks.py:127) is the feature extractor alone
+    ev = chain(wd, ld, "validation")
+    ref, refm = fe.extract_on_device(wd, ld, pad_to_multiple_of=100)
+    assert torch.equal(ev["input_features"], ref) and torch.equal(ev["attention_mask"], refm) and ev["speed_factor_index"] is None
+
+
+def test_device_chain_honours_steps_before_activation():
+    """DelayedStartWrapper (callbacks.py:52-66): a step is the identity until the global step reaches `steps_before_activation`, then stays on."""
+    import copy
+    from huggingface_asr_amd.feature_extraction import CustomFeatureExtractor
+    from huggingface_asr_amd.transforms import DevicePreprocessing
+    cfg = copy.deepcopy(TRAIN_CHAIN)
+    cfg[0]["steps_before_activation"], cfg[2]["steps_before_activation"] = 7, 3
+    fe = CustomFeatureExtractor(feature_size=80, norm_type="utterance")
+    chain = DevicePreprocessing({"train": cfg}, fe, pad_to_multiple_of=100)
+    wave, lens = _clips()
+    wd, ld = wave.to("cuda:0"), lens.to("cuda:0")
+    plain, _ = fe.extract_on_device(wd, ld, pad_to_multiple_of=100)
+    torch.manual_seed(1)
+    assert torch.equal(chain(wd, ld, "train")["input_features"], plain)                       # step 0: nothing but the extractor
+    chain.new_step(3)
+    o3 = chain(wd, ld, "train")
+    assert o3["speed_factor_index"] is None and o3["input_features"].shape == plain.shape and not torch.equal(o3["input_features"], plain)     # SpecAug on, speed still off
+    chain.new_step(7)
+    assert chain(wd, ld, "train")["speed_factor_index"] is not None
+    chain.new_step(2)                                                                         # never switches off again
+    assert chain(wd, ld, "train")["speed_factor_index"] is not None
+
+
+def test_specaug_row_parameters_match_the_reference_single_case():
+    """The chain's SpecAug leg against the reference module itself: fixture case `single` = one (333, 80) utterance augmented on its own, as the dataloader-side chain does."""
+    from huggingface_asr_amd.augment import SpecAug
+    g = load_golden("specaug")
+    B, T, seed = [int(v) for v in g["single/shape"]]
+    x = torch.from_numpy(synth.normal(seed, "specaug/single", (B, T, 80), 1.0))
+    aug = SpecAug(**RECIPE)
+    torch.manual_seed(100 + seed)
+    P = aug.draw_single(T, 80)
+    pad = torch.zeros(1, 367, 80); pad[:, :T] = x                                              # the utterance inside a longer padded batch row
+    got = aug.apply_rows(pad.to("cuda:0"), P[None]).cpu().numpy()
+    np.testing.assert_allclose(got[:, :T], g["single/out"], atol=2e-5, rtol=0)
+    assert np.abs(got[:, T:]).max() == 0.0
