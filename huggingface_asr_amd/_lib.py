@@ -19,7 +19,7 @@ class EbfConfig(C.Structure):
     _fields_ = [(n, i32) for n in ("B", "T", "F", "d", "H", "I", "L", "V", "C1", "C2", "K", "stride", "pad",
                                    "is_causal", "pos_type", "csgu_kernel", "merge_kernel", "csgu_act", "use_macaron")] + \
                [("ln_eps", f32), ("logits_f32", i32), ("logits_ld", i32), ("branch_overlap", i32), ("extra_layers", i32), ("layer_mixing", i32), ("csgu_linear", i32),
-                ("context_mode", i32), ("gate_blk", i32)]
+                ("context_mode", i32), ("gate_blk", i32), ("ln_fold", i32)]
 
 
 class LnRedDesc(C.Structure):
@@ -32,7 +32,7 @@ class Gpt2Config(C.Structure):
     _fields_ = [("d", i32), ("H", i32), ("L", i32), ("V", i32), ("eps", f32)]
 
 
-GLOBAL_SLOTS, LAYER_SLOTS = 24, 48
+GLOBAL_SLOTS, LAYER_SLOTS = 24, 64
 
 # name -> (argtypes); every function returns int (0 = ok), except mi_ebf_workspace_bytes (size_t)
 SIGNATURES = {
@@ -49,6 +49,9 @@ SIGNATURES = {
     "mi_col2im_cl_bf16": [vp, vp] + [i32] * 13 + [vp],
     "mi_gated_act_bwd_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp],
     "mi_conv2d_first_wgrad": [vp, vp, vp, vp] + [i32] * 12 + [vp],
+    "mi_gemm_lnfold_bf16": [vp, i64, vp, i64, vp, vp, vp, i32, f32, vp, i64, i32, i32, i32, i32, vp],
+    "mi_gemm_resid_stats_f32": [vp, i64, vp, i64, vp, vp, i64, vp, i64, f32, vp, i64, vp, i32, i32, i32, vp],
+    "mi_layernorm_fold": [vp, i64, vp, i32, vp, vp, f32, vp, i64, vp, i64, vp, i32, i32, vp],
     "mi_layernorm_chain": [vp, i64, vp, i32, vp, vp, f32, vp, i64, vp, vp, f32, vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, vp],
     "mi_cast_f32_bf16": [vp, i64, vp, i64, i32, i32, vp],
     "mi_rotary_bf16": [vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, vp],

@@ -26,7 +26,9 @@ enum LS { FF1_LN_G, FF1_LN_B, FF1_W1, FF1_B1, FF1_W2, FF1_B2,
           ATT_LN_G, ATT_LN_B, ATT_WQK, ATT_BQK, ATT_WV, ATT_BV, ATT_WO, ATT_BO, ATT_WPOS, ATT_U, ATT_V,
           MLP_LN_G, MLP_LN_B, MLP_W1, MLP_B1, CSGU_LN_G, CSGU_LN_B, CSGU_W, CSGU_B, MLP_W2, MLP_B2,
           MRG_DW_W, MRG_DW_B, MRG_W, MRG_B, FIN_LN_G, FIN_LN_B,
-          FF2_LN_G, FF2_LN_B, FF2_W1, FF2_B1, FF2_W2, FF2_B2, CSGU_LIN_W, CSGU_LIN_B };
+          FF2_LN_G, FF2_LN_B, FF2_W1, FF2_B1, FF2_W2, FF2_B2, CSGU_LIN_W, CSGU_LIN_B,
+          // ln_fold: W' = bf16(W diag(gamma)), its fp32 column sums, and W beta + b for the four LayerNorm -> Linear pairs of a layer
+          FF1_WF, FF1_SF, FF1_CF, QKV_WF, QKV_SF, QKV_CF, MLP_WF, MLP_SF, MLP_CF, FF2_WF, FF2_SF, FF2_CF };
 
 struct Dims { int T1, F1, T2, F2, M, Tp, hd; };
 
@@ -50,7 +52,7 @@ struct Ws {
     bf16_t *act1, *act2, *a0, *a1, *a2, *a1r, *h, *qk, *vt, *ctx, *cat, *m2, *s, *hid;
     bf16_t *cv, *lin;         // csgu_use_linear_after_conv: the CSGU conv output and the Linear's output
     bf16_t *z1, *g1, *z2, *g2;   // context-aware front ends: raw conv / gate outputs of the un-fused forms
-    float *feo, *x, *stats;
+    float *feo, *x, *stats, *lnst;   // lnst: ln_fold's per-row partial (sum, sumsq) records, 32 floats per row
     float *mixed, *lh, *sw;   // fine-tuning head: weighted sum of the hidden states, fp32 copy of the last one, softmax(per_layer_weights)
     int* lens;   // [inner(B) | outer(B)]
     size_t bytes;
@@ -94,6 +96,7 @@ Ws carve(const mi_ebf_config& c, void* base) {
     if (c.csgu_linear) { w.cv = (bf16_t*)k.take(M * (c.I / 2) * 2); w.lin = (bf16_t*)k.take(M * (c.I / 2) * 2); }
     w.hid = (bf16_t*)k.take(M * c.d * 2);
     w.stats = (float*)k.take(M * 2 * 4);
+    w.lnst = c.ln_fold ? (float*)k.take(M * 32 * 4) : nullptr;
     w.lens = (int*)k.take((size_t)2 * c.B * 4);
     w.mixed = w.lh = w.sw = nullptr;
     if (c.layer_mixing) {
@@ -314,7 +317,7 @@ extern "C" int mi_ebf_forward_hs(const mi_ebf_config* cfg, const void* const* we
         return mi_layernorm_chain(src, d, mask_len, T2, nullptr, nullptr, 0.f, w.x, d, Lf(l, ATT_LN_G), Lf(l, ATT_LN_B), leps,
                                   w.a1, d, nullptr, 0, Lf(l, MLP_LN_G), Lf(l, MLP_LN_B), w.a2, d, M, d, st);
     };
-    RUN(enter_layer(w.x, 0));
+    if (!c.ln_fold) RUN(enter_layer(w.x, 0));
     if (c.layer_mixing) RUN(mi_softmax_vec_f32(Gf(G_MIX_W), c.L + 1, w.sw, st));
     // --- relative positions: p_l = linear_pos_l(table) for every layer (batch independent; tf:531-536)
     const int P = 2 * T2 - 1;
@@ -327,6 +330,52 @@ extern "C" int mi_ebf_forward_hs(const mi_ebf_config* cfg, const void* const* we
     const float scale = 1.0f / sqrtf((float)D.hd);
     const int kc = c.csgu_kernel, km = c.merge_kernel;
 
+    if (c.ln_fold) {
+        // ---- LayerNorm-folded layers (header: mi_ebf_config.ln_fold).  a0 holds bf16(x) of the CURRENT residual stream, lnst its per-row partial statistics (np pairs):
+        // written by the kernel that produced x (mi_layernorm_fold at layer entry and after final_layer_norm; the FFN-out / merge GEMMs' epilogues in between).
+        if (c.pos_type == 2 || !c.use_macaron || c.extra_layers || c.layer_mixing || c.csgu_linear || (D.hd != 64 && D.hd != 128)) return MI_ERR_ARG;
+        const int npg = d / 32;                                   // pairs a producer GEMM writes (one per 32 columns)
+        if (hipMemsetAsync(w.lnst, 0, (size_t)M * 32 * sizeof(float), st) != hipSuccess) return MI_ERR_LAUNCH;
+        // entry: zero padded frames once (tf:662-665); x, bf16(x), statistics
+        RUN(mi_layernorm_fold(w.x, d, mask_len, T2, nullptr, nullptr, 0.f, w.x, d, w.a0, d, w.lnst, M, d, st));
+        int np = 1;
+        for (int l = 0; l < c.L; ++l) {
+            if (hidden_states && hipMemcpyAsync(hidden_states + (size_t)l * M * d, w.x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return MI_ERR_LAUNCH;
+            // x += 0.5 * FFN(LN(x))   e_branchformer.py:271-273
+            RUN(mi_gemm_lnfold_bf16(w.a0, d, Lw(l, FF1_WF), d, Lf(l, FF1_SF), Lf(l, FF1_CF), w.lnst, np, leps, w.h, I, 1, M, I, d, st));
+            RUN(mi_gemm_resid_stats_f32(w.h, I, Lw(l, FF1_W2), I, Lf(l, FF1_B2), w.x, d, w.x, d, 0.5f, w.a0, d, w.lnst, M, d, I, st));
+            np = npg;
+            // global branch: self_attn_layer_norm folded into [Q|K|V]   (e_branchformer.py:281-288)
+            RUN(mi_gemm_lnfold_bf16(w.a0, d, Lw(l, QKV_WF), d, Lf(l, QKV_SF), Lf(l, QKV_CF), w.lnst, np, leps, w.qk, 3 * d, 0, M, 3 * d, d, st));
+            RUN(mi_attention_qkv_bf16(w.qk, 3 * d, w.qk + d, 3 * d, w.qk + 2 * d, 3 * d,
+                                      c.pos_type == 1 ? (const bf16_t*)posp + (size_t)l * P * d : nullptr, d,
+                                      c.pos_type == 1 ? Lf(l, ATT_U) : nullptr, c.pos_type == 1 ? Lf(l, ATT_V) : nullptr,
+                                      mask_len, w.ctx, d, c.B, T2, 0, 0, c.H, D.hd, scale, c.is_causal, st));
+            RUN(mi_gemm_bf16(w.ctx, d, Lw(l, ATT_WO), d, Lf(l, ATT_BO), 1, w.cat, 2 * d, 0, nullptr, 0, 1.f, 0, M, d, d, 0, 0, st));
+            // local branch: cgMLP_layer_norm folded into channel_proj1   (e_branchformer.py:291-292, 184-222)
+            RUN(mi_gemm_lnfold_bf16(w.a0, d, Lw(l, MLP_WF), d, Lf(l, MLP_SF), Lf(l, MLP_CF), w.lnst, np, leps, w.h, I, 1, M, I, d, st));
+            RUN(mi_row_stats_bf16(w.h + I / 2, I, I / 2, leps, w.stats, M, st));
+            const int dil = c.is_causal ? (kc - 1) / 2 : 1;
+            const int cpad = c.is_causal ? (kc - 1) * dil : (kc - 1) / 2;
+            RUN(mi_csgu_bf16(w.h, I, w.stats, Lf(l, CSGU_LN_G), Lf(l, CSGU_LN_B), Lf(l, CSGU_W), Lf(l, CSGU_B), w.s, I / 2, c.B, T2, I / 2, kc, cpad, dil, c.csgu_act, st));
+            RUN(mi_gemm_bf16(w.s, I / 2, Lw(l, MLP_W2), I / 2, Lf(l, MLP_B2), 1, w.cat + d, 2 * d, 0, nullptr, 0, 1.f, 0, M, d, I / 2, 0, 0, st));
+            // merge (e_branchformer.py:296-304): x += merge_proj(m + dwconv(m)); the epilogue leaves bf16(x) and its statistics for ff2's folded LayerNorm
+            RUN(mi_dwconv_residual_bf16(w.cat, 2 * d, Lf(l, MRG_DW_W), Lf(l, MRG_DW_B), w.m2, 2 * d, c.B, T2, 2 * d, km, (km - 1) / 2, st));
+            RUN(mi_gemm_resid_stats_f32(w.m2, 2 * d, Lw(l, MRG_W), 2 * d, Lf(l, MRG_B), w.x, d, w.x, d, 1.0f, w.a0, d, w.lnst, M, d, 2 * d, st));
+            // x += 0.5 * FFN(LN(x))   e_branchformer.py:307-309
+            RUN(mi_gemm_lnfold_bf16(w.a0, d, Lw(l, FF2_WF), d, Lf(l, FF2_SF), Lf(l, FF2_CF), w.lnst, np, leps, w.h, I, 1, M, I, d, st));
+            RUN(mi_gemm_bf16(w.h, I, Lw(l, FF2_W2), I, Lf(l, FF2_B2), 1, w.x, d, 1, w.x, d, 0.5f, 0, M, d, I, 0, 0, st));
+            // final_layer_norm (:312): the new residual stream, its bf16 copy and statistics for the next layer — or, after the last layer, chained with encoder.layer_norm
+            if (l + 1 == c.L) {
+                RUN(mi_layernorm_chain(w.x, d, nullptr, T2, Lf(l, FIN_LN_G), Lf(l, FIN_LN_B), leps, nullptr, 0,
+                                       Gf(G_ENC_LN_G), Gf(G_ENC_LN_B), c.ln_eps, w.hid, d, last_hidden, d, nullptr, nullptr, nullptr, 0, M, d, st));
+            } else {
+                RUN(mi_layernorm_fold(w.x, d, nullptr, T2, Lf(l, FIN_LN_G), Lf(l, FIN_LN_B), leps, w.x, d, w.a0, d, w.lnst, M, d, st));
+                np = 1;
+            }
+        }
+    } else
     for (int l = 0; l < Lt; ++l) {
         if (hidden_states && l < c.L && hipMemcpyAsync(hidden_states + (size_t)l * M * d, w.x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
             return MI_ERR_LAUNCH;

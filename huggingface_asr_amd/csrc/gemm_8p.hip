@@ -66,7 +66,10 @@ struct Ctx {
 // OUT32: fp32 output (the CTC head) — N need not be a multiple of the tile: W rows beyond N are clamped, columns beyond N never stored.
 // GATED (GatedConv2d as one GEMM, extractors.py:23-32): the W rows are packed [conv c0..c0+31 ; gate c0..c0+31] per 64, so a wave's 64 columns are 32 output channels
 // twice — accumulator columns j = 0,1 the conv, j = 2,3 the gate of the SAME channels in the same lane — and the epilogue writes act((conv + b) * sigmoid(gate + bg)) as (M, N/2).
-template <bool CONV, int ACT, bool OUT32 = false, bool GATED = false>     // ACT: 0 none, 1 erf-GELU, 2 tanh-GELU — compile-time, so the epilogue is straight-line code with many independent chains in flight
+// LNF (LayerNorm folded into the GEMM, gemm_args.hpp): the prologue reduces the per-row partial (sum, sumsq) pairs of the tile's 256 rows to (rstd, rstd * mean) in a 2-KiB LDS
+// table behind the ring — issued before the first K tile is consumed, so its memory round trip hides under the ring's fill — and the epilogue computes
+// rstd * acc - rstd * mean * s_n + bias_n instead of acc + bias_n.
+template <bool CONV, int ACT, bool OUT32 = false, bool GATED = false, bool LNF = false>     // ACT: 0 none, 1 erf-GELU, 2 tanh-GELU — compile-time, so the epilogue is straight-line code with many independent chains in flight
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -213,10 +216,39 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
     using F = std::false_type;
 
     const int nk = p.K / BK;
+    // LNF: the row-statistic partials are requested FIRST — the oldest entries of the in-order vmcnt queue — and only summed behind the first counted wait of the
+    // pipeline (which retires them on the way), so the kernel never waits for them alone; two lanes per row, each takes half of the row's partial pairs.
+    // The loads are inline asm: the compiler's own waitcnt insertion would put a vmcnt(0) in front of their first use (it does not count across the hand-placed
+    // waits), the explicit vmcnt(8) in front of the first barrier retires them.  Branch-free: every lane issues four 16-B loads (indices clamped), masks are applied at the sums.
+    f32x4 lnv[4];
+    if constexpr (LNF) {
+        const int row = tid >> 1, half = tid & 1;
+        const int n4 = p.ln_npart == 1 ? 1 : p.ln_npart >> 2;      // f32x4 records per lane: ln_npart pairs = ln_npart / 2 float4, split over the two lanes (1 pair: lane 0 alone)
+        const f32x4* s4 = reinterpret_cast<const f32x4*>(p.ln_stats + (long)min(m0 + row, p.M - 1) * LN_STATS_STRIDE) + (p.ln_npart == 1 ? 0 : half * n4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4* q = s4 + min(j, n4 - 1);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lnv[j]) : "v"(q) : "memory");
+        }
+    }
     // prologue: Ha0(0) Hb0(0) Hb1(0) Ha1(0) Ha0(1) Hb0(1) — the steady-state order
     stageA(0, 0, 0); stageB(0, 0, 0); stageB(0, 0, 1); stageA(0, 0, 1); stageA(1, BUF, 0); stageB(1, BUF, 0);
     wait_vm<8>();
     barrier();
+    float ln_r = 0.f, ln_t = 0.f;        // LNF: (rstd, rstd * mean) of row tid >> 1, kept in two registers across the K loop; shared through LDS in the epilogue
+    if constexpr (LNF) {
+        const int n4 = p.ln_npart == 1 ? 1 : p.ln_npart >> 2;
+        const float w1 = n4 > 1 ? 1.f : 0.f, w2 = n4 > 2 ? 1.f : 0.f, w3 = n4 > 3 ? 1.f : 0.f;          // records beyond n4 were clamped re-loads: weight 0
+        const float wz = p.ln_npart == 1 ? 0.f : 1.f;                                                     // one pair: only (.x, .y) of record 0 ...
+        const float wl = (p.ln_npart == 1 && (tid & 1)) ? 0.f : 1.f;                                      // ... and only on the row's first lane
+        float sm = wl * (((lnv[0].x + wz * lnv[0].z) + w1 * (lnv[1].x + lnv[1].z)) + (w2 * (lnv[2].x + lnv[2].z) + w3 * (lnv[3].x + lnv[3].z)));
+        float sq = wl * (((lnv[0].y + wz * lnv[0].w) + w1 * (lnv[1].y + lnv[1].w)) + (w2 * (lnv[2].y + lnv[2].w) + w3 * (lnv[3].y + lnv[3].w)));
+        sm += dpp_f32<0xB1, 0xF>(0.f, sm);                  // quad_perm [1,0,3,2]: lane ^ 1 holds the row's other half
+        sq += dpp_f32<0xB1, 0xF>(0.f, sq);
+        const float mean = sm / (float)p.K;
+        ln_r = rsqrtf(fmaxf(sq / (float)p.K - mean * mean, 0.f) + p.ln_eps);
+        ln_t = ln_r * mean;
+    }
     if (wr == 1) barrier();              // the second wave row runs one barrier behind
     unsigned cb = 0;
     int kt = 0;
@@ -277,6 +309,22 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         b4[j] = (p.bias_mode == 1) ? *reinterpret_cast<const f32x4*>(p.bias + nb + j * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (LNF) {
+        // acc <- rstd * acc - rstd * mean * s_n: the folded LayerNorm; the bias (W beta + b) is added with b4 below.  The 256 (rstd, rstd * mean) pairs go through a
+        // 2-KiB table behind the ring (every wave needs the rows of its wave row)
+        if ((tid & 1) == 0) *reinterpret_cast<f32x2*>(smem + 2 * BUF + (tid >> 1) * 8) = f32x2{ln_r, ln_t};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.ln_colsum + nb + j * 16 + fq * 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x2 rt = *reinterpret_cast<const f32x2*>(smem + 2 * BUF + (wr * 128 + i * 16 + fr) * 8);
+                acc[i][j] = f32x4{fmaf(rt.x, acc[i][j].x, -rt.y * s4.x), fmaf(rt.x, acc[i][j].y, -rt.y * s4.y), fmaf(rt.x, acc[i][j].z, -rt.y * s4.z), fmaf(rt.x, acc[i][j].w, -rt.y * s4.w)};
+            }
+        }
+    }
     const int prow = lane >> 3, pc = lane & 7;
     bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
     if constexpr (GATED) {
@@ -645,6 +693,15 @@ __global__ __launch_bounds__(512, 2) void gemm8p128p_kernel(GemmArgs p) {
             if (use_res) v = rres[u] + p.alpha * v;
             const int m = m0 + wr * 64 + row;
             if (m < p.M) *reinterpret_cast<f32x4*>(C + (long)m * p.ldc + nb + pc * 4) = v;
+            // LayerNorm-fold producer (gemm_args.hpp): the bf16 copy of the stored row segment and its partial (sum, sumsq) — 8 lanes hold a row's 32 columns
+            if (p.C2 && m < p.M) *reinterpret_cast<bf16x4*>(p.C2 + (long)m * p.ldc2 + nb + pc * 4) = bf16x4{f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+            if (p.stats_out) {
+                float sm = (v.x + v.y) + (v.z + v.w), sq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                sm += dpp_f32<0xB1, 0xF>(0.f, sm); sq += dpp_f32<0xB1, 0xF>(0.f, sq);          // lane ^ 1
+                sm += dpp_f32<0x4E, 0xF>(0.f, sm); sq += dpp_f32<0x4E, 0xF>(0.f, sq);          // lane ^ 2
+                sm += dpp_f32<0x141, 0xF>(0.f, sm); sq += dpp_f32<0x141, 0xF>(0.f, sq);        // row_half_mirror: the other quad of the 8 lanes
+                if (pc == 0 && m < p.M) *reinterpret_cast<f32x2*>(p.stats_out + (long)m * LN_STATS_STRIDE + (((n0 >> 7) << 2) + wc) * 2) = f32x2{sm, sq};
+            }
         }
     } else {
 #pragma unroll
@@ -684,6 +741,11 @@ bool gemm_8p_supported(const GemmArgs& a, bool conv) {
         if (a.bias_mode == 1 && ((uintptr_t)a.bias & 15)) return false;
     }
     if (a.gated && (!conv || a.out_f32 || a.act != 1)) return false;
+    if (a.ln_stats) {                // folded LayerNorm: plain bf16-out GEMM, act none / erf-GELU, 16-B aligned column vectors, a partial count the prologue can split over two lanes
+        if (conv || a.out_f32 || a.gated || a.act > 1 || a.bias_mode != 1 || !a.ln_colsum || ((uintptr_t)a.ln_colsum & 15) || ((uintptr_t)a.ln_stats & 15)) return false;
+        if (!(a.ln_npart == 1 || (a.ln_npart >= 4 && a.ln_npart <= 16 && (a.ln_npart % 4) == 0))) return false;
+    }
+    if (a.C2 || a.stats_out) return false;       // producer side lives in the 128x128 kernel
     if ((long)a.N * a.ldw * 2 >= (1l << 32)) return false;                                             // 32-bit source offsets
     if (conv) {
         if ((a.Cin % BK) != 0 || a.Fout <= 0 || a.Tout <= 0) return false;
@@ -710,6 +772,17 @@ int gemm_8p_launch(const GemmArgs& a, bool conv, hipStream_t stream) {
         launch_dense(PF_8P_OUT32, gemm8p_kernel<false, 0, true>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
         return MI_OK;
     }
+    if (a.ln_stats) {
+        static bool attr_l = false;
+        if (!attr_l) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<false, 0, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF + 2048);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<false, 1, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF + 2048);
+            attr_l = true;
+        }
+        if (a.act) launch_dense(PF_8P_GELU, gemm8p_kernel<false, 1, false, false, true>, dim3(grid), dim3(512), (size_t)2 * BUF + 2048, stream, a);
+        else launch_dense(PF_8P, gemm8p_kernel<false, 0, false, false, true>, dim3(grid), dim3(512), (size_t)2 * BUF + 2048, stream, a);
+        return MI_OK;
+    }
     if (a.gated) {
         static bool attr_g = false;
         if (!attr_g) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<true, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF); attr_g = true; }
@@ -729,6 +802,8 @@ bool gemm_8p128_supported(const GemmArgs& a) {
     if (a.resid && (((uintptr_t)a.resid & 15) || (a.ldr % 4) != 0)) return false;
     if (a.bias_mode == 1 && ((uintptr_t)a.bias & 15)) return false;
     if ((long)a.M * a.lda * 2 >= (1l << 32) || (long)a.N * a.ldw * 2 >= (1l << 32)) return false;
+    if (a.ln_stats) return false;                // consumer side lives in the 256x256 kernel
+    if ((a.C2 || a.stats_out) && (!a.out_f32 || a.N > 512 || (a.K % 128) != 0 || (a.C2 && (((uintptr_t)a.C2 & 7) || (a.ldc2 % 4))) || ((uintptr_t)a.stats_out & 7))) return false;
     return true;
 }
 

@@ -22,7 +22,16 @@ struct GemmArgs {
     // ([conv c0..c0+31 ; gate c0..c0+31] per 64 rows), N = 2 * Cout, and the epilogue writes act((conv + b) * sigmoid(gate + bg)) as (M, N / 2).
     // Only the 256-wide phase kernel has that epilogue: unsupported shapes return MI_ERR_UNSUPPORTED (the caller runs the GEMM raw + mi_gated_act_bf16).
     int gated;
+    // LayerNorm folded into the GEMM (encoder.hip `ln_fold` path).  LN(x) W^T = rstd (x W'^T) - rstd mu s + (W beta + b) with W' = W diag(gamma), s_n = sum_k W'[n,k]:
+    //  consumer (256x256 phase kernel): A = bf16(x) un-normalised, W = bf16(W'), bias = W beta + b (fp32), ln_colsum = s (fp32, summed over the bf16 W' values),
+    //    ln_stats = per-row partial (sum, sum of squares) pairs of x over its K columns — row stride 32 floats, ln_npart pairs (1, or N_producer / 32 <= 16) —
+    //    reduced in the kernel's prologue in a fixed order; out = act(rstd * acc - rstd * mu * s_n + bias_n)
+    //  producer (128x128 fp32-out kernel): C2 = bf16 copy of the fp32 rows it stores, stats_out = their per-row partial (sum, sumsq) per 32-column wave block:
+    //    slot (n0 / 128) * 4 + wave column of the row's 16 (N <= 512)
+    const float* ln_stats; int ln_npart; const float* ln_colsum; float ln_eps;
+    bf16_t* C2; long ldc2; float* stats_out;
 };
+constexpr int LN_STATS_STRIDE = 32;       // floats per row of a partial-statistics buffer (16 (sum, sumsq) pairs)
 
 // gemm_glds.hip; returns MI_ERR_UNSUPPORTED when the shape/alignment does not fit the fast path
 bool gemm_glds_supported(const GemmArgs& a, bool conv);

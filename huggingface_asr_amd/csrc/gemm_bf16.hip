@@ -271,3 +271,43 @@ extern "C" int mi_conv2d_cl_geo_bf16(const void* in, const void* weight, const f
     a.pad_t = pad_t; a.pad_f = pad_f; a.gated = gated ? 1 : 0;
     return launch(a, true, stream);
 }
+
+// ---- LayerNorm folded into the GEMMs around it (encoder.hip `ln_fold` path; algebra in gemm_args.hpp).
+// Consumer: C (M,N) bf16 = act(LN(x) W^T + b) computed as act(rstd * (xb Wf^T) - rstd * mu * colsum + cbias), xb = bf16(x) (M,K), Wf = bf16(W diag(gamma)) (N,K),
+// colsum_n = sum_k Wf[n,k], cbias = W beta + b; `stats`: per-row partial (sum, sumsq) pairs of x, row stride 32 floats, `npart` pairs (1 | 4..16 in steps of 4).
+// Runs on the 256x256 phase kernel only: N % 256 == 0, K % 64 == 0, K >= 128; MI_ERR_UNSUPPORTED otherwise (the caller keeps the LayerNorm kernel + plain GEMM).
+extern "C" int mi_gemm_lnfold_bf16(const void* xb, long lda, const void* Wf, long ldw, const float* colsum, const float* cbias, const float* stats, int npart, float eps,
+                                   void* C, long ldc, int act, int M, int N, int K, hipStream_t stream) {
+    MI_ENTER();
+    GemmArgs a{};
+    a.A = (const bf16_t*)xb; a.lda = lda; a.W = (const bf16_t*)Wf; a.ldw = ldw; a.bias = cbias; a.bias_mode = 1;
+    a.C = C; a.ldc = ldc; a.out_f32 = 0; a.alpha = 1.f; a.act = act; a.M = M; a.N = N; a.K = K;
+    a.ln_stats = stats; a.ln_npart = npart; a.ln_colsum = colsum; a.ln_eps = eps;
+    if (!xb || !Wf || !colsum || !cbias || !stats || !C || act < 0 || act > 1) return MI_ERR_ARG;
+    if (!gemm_8p_supported(a, false)) return MI_ERR_UNSUPPORTED;
+    const int slot = mi_profile_hook_begin(stream, 2.0 * M * N * K);
+    const int rc = gemm_8p_launch(a, false, stream);
+    if (slot >= 0) mi_profile_hook_end(slot, stream);
+    if (rc != MI_OK) return rc;
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// Producer: C (M,N) fp32 = resid + alpha * (A W^T + b) (resid may be C), and in the same epilogue C2 (M,N) bf16 = the stored rows, stats_out = their per-row partial
+// (sum, sumsq) pairs (slot = 32-column block of the row, N / 32 <= 16 pairs, row stride 32 floats).  128x128 phase kernel only: N % 128 == 0, N <= 512, K % 128 == 0, K >= 320.
+extern "C" int mi_gemm_resid_stats_f32(const void* A, long lda, const void* W, long ldw, const float* bias, float* C, long ldc, const float* resid, long ldr, float alpha,
+                                       void* C2, long ldc2, float* stats_out, int M, int N, int K, hipStream_t stream) {
+    MI_ENTER();
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw; a.bias = bias; a.bias_mode = bias ? 1 : 0;
+    a.C = C; a.ldc = ldc; a.out_f32 = 1; a.resid = resid; a.ldr = ldr; a.alpha = alpha; a.act = 0; a.M = M; a.N = N; a.K = K;
+    a.C2 = (bf16_t*)C2; a.ldc2 = ldc2; a.stats_out = stats_out;
+    if (!A || !W || !C) return MI_ERR_ARG;
+    if (!gemm_8p128_supported(a)) return MI_ERR_UNSUPPORTED;
+    const int slot = mi_profile_hook_begin(stream, 2.0 * M * N * K);
+    const int rc = gemm_8p128_launch(a, 0, stream);
+    if (slot >= 0) mi_profile_hook_end(slot, stream);
+    if (rc != MI_OK) return rc;
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}

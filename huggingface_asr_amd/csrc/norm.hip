@@ -21,6 +21,7 @@ struct LnArgs {
     const float* ga; const float* ba; bf16_t* outa; long lda; float* outa32; long lda32;
     const float* gb; const float* bb; bf16_t* outb; long ldb;
     int M, d; float eps1, eps2;
+    bf16_t* yb; long ldyb; float* ystats;       // LayerNorm-fold producer (mi_layernorm_fold): bf16 copy of y and its (sum, sumsq) in slot 0 of the row's 32-float statistics record
 };
 
 template <int NV>
@@ -71,6 +72,18 @@ __global__ __launch_bounds__(256) void ln_chain_kernel(LnArgs p) {
 #pragma unroll
         for (int i = 0; i < NV; ++i)
             if (nvalid(i)) yr[lane + 64 * i] = v[i];
+    }
+    if (p.yb) {
+        float s = 0.f, qq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (nvalid(i)) {
+                reinterpret_cast<bf16x4*>(p.yb + (long)row * p.ldyb)[lane + 64 * i] = bf16x4{f2bf(v[i].x), f2bf(v[i].y), f2bf(v[i].z), f2bf(v[i].w)};
+                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+                qq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+            }
+        s = wave_sum(s); qq = wave_sum(qq);
+        if (lane == 0) *reinterpret_cast<f32x2*>(p.ystats + (long)row * 32) = f32x2{s, qq};
     }
     if (!p.ga) return;
     {
@@ -169,7 +182,26 @@ extern "C" int mi_layernorm_chain(const float* x, long ldx, const int* lengths, 
     if ((ldx % 4) || (y32 && (ldy % 4)) || (outa_bf16 && (lda % 4)) || (outa_f32 && (lda32 % 4)) || (outb_bf16 && (ldb % 4)))
         return MI_ERR_ARG;
     LnArgs p{x, ldx, lengths, T, g1, b1, y32, ldy, ga, ba, (bf16_t*)outa_bf16, lda, outa_f32, lda32,
-             gb, bb, (bf16_t*)outb_bf16, ldb, M, d, eps1, eps2};
+             gb, bb, (bf16_t*)outb_bf16, ldb, M, d, eps1, eps2, nullptr, 0, nullptr};
+    const int nv = cdiv(d / 4, 64);
+    dim3 grid(cdiv(M, 4)), block(256);
+    if (nv <= 1) hipLaunchKernelGGL(ln_chain_kernel<1>, grid, block, 0, stream, p);
+    else if (nv <= 2) hipLaunchKernelGGL(ln_chain_kernel<2>, grid, block, 0, stream, p);
+    else if (nv <= 4) hipLaunchKernelGGL(ln_chain_kernel<4>, grid, block, 0, stream, p);
+    else hipLaunchKernelGGL(ln_chain_kernel<8>, grid, block, 0, stream, p);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// LayerNorm-fold producer (encoder.hip `ln_fold` path): y = g1 ? LN(mask(x); g1, b1) : mask(x) stored three ways in one pass — fp32 (the residual stream, in place allowed),
+// bf16 (the A operand of the GEMMs that fold the NEXT LayerNorm into their epilogue) and the row's (sum, sum of squares) in pair 0 of its 32-float statistics record
+// (`ln_npart` = 1 for mi_gemm_lnfold_bf16).
+extern "C" int mi_layernorm_fold(const float* x, long ldx, const int* lengths, int T, const float* g1, const float* b1, float eps1, float* y32, long ldy,
+                                 void* yb_bf16, long ldyb, float* stats, int M, int d, hipStream_t stream) {
+    MI_ENTER();
+    if (M <= 0 || d <= 0 || (d % 4) != 0 || d > 64 * 4 * MAXV || !yb_bf16 || !stats) return MI_ERR_ARG;
+    if ((ldx % 4) || (y32 && (ldy % 4)) || (ldyb % 4) || (reinterpret_cast<uintptr_t>(stats) & 7)) return MI_ERR_ARG;
+    LnArgs p{x, ldx, lengths, T, g1, b1, y32, ldy, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, M, d, eps1, eps1, (bf16_t*)yb_bf16, ldyb, stats};
     const int nv = cdiv(d / 4, 64);
     dim3 grid(cdiv(M, 4)), block(256);
     if (nv <= 1) hipLaunchKernelGGL(ln_chain_kernel<1>, grid, block, 0, stream, p);

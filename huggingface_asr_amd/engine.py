@@ -26,7 +26,9 @@ LS = {n: i for i, n in enumerate(
      "ATT_LN_G", "ATT_LN_B", "ATT_WQK", "ATT_BQK", "ATT_WV", "ATT_BV", "ATT_WO", "ATT_BO", "ATT_WPOS", "ATT_U", "ATT_V",
      "MLP_LN_G", "MLP_LN_B", "MLP_W1", "MLP_B1", "CSGU_LN_G", "CSGU_LN_B", "CSGU_W", "CSGU_B", "MLP_W2", "MLP_B2",
      "MRG_DW_W", "MRG_DW_B", "MRG_W", "MRG_B", "FIN_LN_G", "FIN_LN_B",
-     "FF2_LN_G", "FF2_LN_B", "FF2_W1", "FF2_B1", "FF2_W2", "FF2_B2", "CSGU_LIN_W", "CSGU_LIN_B"])}
+     "FF2_LN_G", "FF2_LN_B", "FF2_W1", "FF2_B1", "FF2_W2", "FF2_B2", "CSGU_LIN_W", "CSGU_LIN_B",
+     # ln_fold (csrc/gemm_args.hpp): W' = bf16(W diag(gamma)), colsum(W') fp32, W beta + b fp32 of the four LayerNorm -> Linear pairs
+     "FF1_WF", "FF1_SF", "FF1_CF", "QKV_WF", "QKV_SF", "QKV_CF", "MLP_WF", "MLP_SF", "MLP_CF", "FF2_WF", "FF2_SF", "FF2_CF"])}
 ACT = {"identity": 0, "gelu": 1, "relu": 2, "silu": 3, "swish": 3}
 POS = {None: 0, "none": 0, "relative": 1, "rotary": 2}
 
@@ -80,6 +82,10 @@ class EBranchformerEngine:
         # falls back to nn.Conv2d, e.g. for the recipes' `shared_gated`); conv and gate filters of a gated layer 2 are packed in blocks of `gate_blk` channels
         self.ctx_mode = context_mode(c)
         self.gate_blk = (32 if c["conv_dim"][1] % 32 == 0 else c["conv_dim"][1]) if self.ctx_mode == 1 else 0
+        # LayerNorm folded into the GEMMs around it (mi_ebf_config.ln_fold): None = automatic (when the shapes qualify and the batch fills the 256x256 tiles),
+        # True / False force it (tests; HFASR_LN_FOLD=0/1 sets the default)
+        env = os.environ.get("HFASR_LN_FOLD")
+        self.ln_fold = None if env is None else env == "1"
         self.weights = {}
         self._table = None
         self._ws = {}
@@ -168,11 +174,34 @@ class EBranchformerEngine:
             lp("MRG_DW_B", f32(sd[p + "depthwise_conv_fusion.bias"]))
             lp("MRG_W", bf(sd[p + "merge_proj.weight"])); lp("MRG_B", f32(sd[p + "merge_proj.bias"]))
             lp("FIN_LN_G", f32(sd[p + "final_layer_norm.weight"])); lp("FIN_LN_B", f32(sd[p + "final_layer_norm.bias"]))
+            if self._fold_shapes_ok():
+                def fold(tag, w, b, g, be):          # LN(x) W^T + b = rstd (x W'^T) - rstd mu colsum(W') + (W beta + b)
+                    w32, g32, be32 = w.detach().to(dev, torch.float32), g.detach().to(dev, torch.float32), be.detach().to(dev, torch.float32)
+                    wf = (w32 * g32[None, :]).to(torch.bfloat16).contiguous()
+                    lp(tag + "_WF", wf); lp(tag + "_SF", wf.float().sum(-1).contiguous()); lp(tag + "_CF", (w32 @ be32 + b.detach().to(dev, torch.float32)).contiguous())
+                for ff, tag in (("ff1", "FF1"), ("ff2", "FF2")):
+                    fold(tag, sd[p + ff + ".1.intermediate_dense.weight"], sd[p + ff + ".1.intermediate_dense.bias"], sd[p + ff + ".0.weight"], sd[p + ff + ".0.bias"])
+                fold("QKV", torch.cat([sd[a + f"linear_{n}.weight"].detach().to(dev) for n in "qkv"], 0), torch.cat([sd[a + f"linear_{n}.bias"].detach().to(dev) for n in "qkv"], 0),
+                     sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"])
+                fold("MLP", sd[m + "channel_proj1.0.weight"], sd[m + "channel_proj1.0.bias"], sd[p + "cgMLP_layer_norm.weight"], sd[p + "cgMLP_layer_norm.bias"])
         self._keep = keep
         self._slots = slots
         self._table = (C.c_void_p * len(slots))(*[(t.data_ptr() if t is not None else None) for t in slots])
         self._posp_valid = {}
         self.weights_version += 1
+
+    def _fold_shapes_ok(self) -> bool:
+        """shapes the folded-LayerNorm GEMM kernels take (csrc/gemm_8p.hip: 256-wide consumer tiles, 128-wide producers with <= 16 statistics pairs per row) and the
+        layer forms the folded driver covers (csrc/encoder.hip)"""
+        c = self.cfg
+        d, I, H = c["hidden_size"], c["intermediate_size"], c["num_attention_heads"]
+        return (d in (256, 512) and I % 256 == 0 and I >= 320 and (d // H) in (64, 128) and c.get("use_macaron_ff", True) and not self.extra and not self.mix
+                and c.get("position_embeddings_type", "relative") != "rotary" and not c.get("csgu_use_linear_after_conv", False))
+
+    def _use_fold(self, B: int, T2: int) -> bool:
+        if not self._fold_shapes_ok() or self.ln_fold is False or self.branch_overlap:
+            return False
+        return True if self.ln_fold else B * T2 >= 2048          # below that the 256x256 tiles cannot fill the chip: the small-problem kernels + LayerNorm kernels are faster
 
     # ------------------------------------------------------------------ tables / workspace
     def out_frames(self, T: int) -> int:
@@ -222,7 +251,8 @@ class EBranchformerEngine:
 
     def _config_struct(self, B, T, F, slot=0):
         c = self.cfg
-        return _lib.EbfConfig(B=B, T=T, F=F, d=c["hidden_size"], H=c["num_attention_heads"], I=c["intermediate_size"],
+        fold = int(self._use_fold(B, self.out_frames(T)))
+        return _lib.EbfConfig(ln_fold=fold, B=B, T=T, F=F, d=c["hidden_size"], H=c["num_attention_heads"], I=c["intermediate_size"],
                               L=c["num_hidden_layers"], V=c["vocab_size"], C1=c["conv_dim"][0], C2=c["conv_dim"][1],
                               K=c["conv_kernel"][0], stride=c["conv_stride"][0], pad=c["conv_padding"][0],
                               is_causal=int(c.get("is_causal", False)), pos_type=POS[c.get("position_embeddings_type", "relative")],
@@ -234,7 +264,7 @@ class EBranchformerEngine:
                               csgu_linear=int(bool(c.get("csgu_use_linear_after_conv", False))), context_mode=self.ctx_mode, gate_blk=self.gate_blk)
 
     def _workspace(self, cs, slot=0):
-        key = (cs.B, cs.T, cs.F)
+        key = (cs.B, cs.T, cs.F, cs.ln_fold)
         if self._ws.get("key") != key:
             self._ws = {"key": key}                                                        # keep one shape resident
         if slot not in self._ws:

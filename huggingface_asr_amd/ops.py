@@ -148,6 +148,42 @@ def gated_act(z, g, B, T, Fq, C, share=1, blk=0, out=None):
     return out
 
 
+def gemm_lnfold(xb, wf, colsum, cbias, stats, npart, eps=1e-5, act="none", out=None):
+    """act(LN(x) W^T + b) with the LayerNorm folded into the GEMM (csrc/gemm_args.hpp): xb = bf16(x) (M,K), wf = bf16(W diag(gamma)) (N,K), colsum = sum_k wf, cbias = W beta + b,
+    stats (M,32) fp32 = per-row partial (sum, sumsq) pairs of x (npart pairs)."""
+    M, K = xb.shape
+    N = wf.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=xb.device, dtype=BF16)
+    _lib.check(_lib.lib().mi_gemm_lnfold_bf16(xb.data_ptr(), xb.stride(0), wf.data_ptr(), wf.stride(0), colsum.data_ptr(), cbias.data_ptr(), stats.data_ptr(), int(npart), float(eps),
+                                              out.data_ptr(), out.stride(0), {"none": 0, "gelu": 1}[act], M, N, K, _stream()), "mi_gemm_lnfold_bf16")
+    return out
+
+
+def gemm_resid_stats(a, w, bias, resid, alpha=1.0):
+    """-> (C fp32 = resid + alpha (a W^T + b), C2 = bf16(C), stats (M,32) fp32 with one (sum, sumsq) pair per 32 columns of C)"""
+    M, K = a.shape
+    N = w.shape[0]
+    c = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    c2 = torch.empty((M, N), device=a.device, dtype=BF16)
+    st = torch.zeros((M, 32), device=a.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mi_gemm_resid_stats_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _p(bias), c.data_ptr(), c.stride(0), _p(resid), resid.stride(0) if resid is not None else 0,
+                                                  float(alpha), c2.data_ptr(), c2.stride(0), st.data_ptr(), M, N, K, _stream()), "mi_gemm_resid_stats_f32")
+    return c, c2, st
+
+
+def layernorm_fold(x, ln=None, eps=1e-5, lengths=None, T=1):
+    """y = [LN](mask(x)) -> (y fp32, bf16(y), stats (M,32) with (sum, sumsq) of y in pair 0)"""
+    M, d = x.shape
+    g, b = ln if ln else (None, None)
+    y = torch.empty_like(x)
+    yb = torch.empty((M, d), device=x.device, dtype=BF16)
+    st = torch.zeros((M, 32), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().mi_layernorm_fold(x.data_ptr(), x.stride(0), _p(lengths), T, _p(g), _p(b), float(eps), y.data_ptr(), y.stride(0), yb.data_ptr(), yb.stride(0), st.data_ptr(),
+                                            M, d, _stream()), "mi_layernorm_fold")
+    return y, yb, st
+
+
 def layernorm_chain(x, *, lengths=None, T=1, ln1=None, eps1=1e-5, store_y=None, lna=None, eps2=1e-5, outa=None,
                     outa32=None, lnb=None, outb=None):
     """see csrc/norm.hip; x (M,d) f32; ln* = (gamma, beta) f32."""

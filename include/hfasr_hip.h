@@ -86,6 +86,19 @@ int mi_conv2d_cl_geo_bf16(const void* in, const void* weight, const float* bias,
  * blk > 0: z == g is the output of one stacked GEMM whose columns are interleaved [conv blk | gate blk] per 2*blk (share must be 1). */
 int mi_gated_act_bf16(const void* z, long ldz, const void* g, long ldg, void* out, long ldo, int B, int T, int Fq, int C, int share, int blk, mi_stream_t stream);
 
+/* ---- LayerNorm folded into the GEMMs around it (the engine's `ln_fold` path).  replaces: the same nn.LayerNorm + nn.Linear pairs as mi_layernorm_chain + mi_gemm_bf16
+ *      (e_branchformer.py:233,236,242,261 in front of tf wav2vec2_conformer :350-357, e_branchformer.py:96-98,212), evaluated as
+ *      LN(x) W^T + b = rstd (bf16(x) W'^T) - rstd mu s + (W beta + b),  W' = bf16(W diag(gamma)),  s_n = sum_k W'[n,k].
+ * mi_gemm_lnfold_bf16: the consumer GEMM (256x256 phase kernel; MI_ERR_UNSUPPORTED for shapes it does not take); stats = per-row partial (sum, sumsq) pairs of x, row stride
+ *   32 floats, npart pairs.  mi_gemm_resid_stats_f32: the producer — C fp32 = resid + alpha (A W^T + b), plus C2 = bf16(C) and the partial statistics of the rows it stores
+ *   (one pair per 32 columns; 128x128 phase kernel).  mi_layernorm_fold: y = [LN](mask(x)) as fp32 + bf16 + statistics pair 0 (npart = 1). */
+int mi_gemm_lnfold_bf16(const void* xb, long lda, const void* Wf, long ldw, const float* colsum, const float* cbias, const float* stats, int npart, float eps,
+                        void* C, long ldc, int act, int M, int N, int K, mi_stream_t stream);
+int mi_gemm_resid_stats_f32(const void* A, long lda, const void* W, long ldw, const float* bias, float* C, long ldc, const float* resid, long ldr, float alpha,
+                            void* C2, long ldc2, float* stats_out, int M, int N, int K, mi_stream_t stream);
+int mi_layernorm_fold(const float* x, long ldx, const int* lengths, int T, const float* g1, const float* b1, float eps1, float* y32, long ldy,
+                      void* yb_bf16, long ldyb, float* stats, int M, int d, mi_stream_t stream);
+
 /* ---- LayerNorm chain on the fp32 residual stream (see csrc/norm.hip).
  * replaces: nn.LayerNorm at e_branchformer.py:233,236,242,257,261; feature projection LN (extractors.py:130);
  *           encoder.layer_norm (wav2vec2_conformer :707); zeroing of padded frames (:662-665) via `lengths`. */
@@ -352,10 +365,14 @@ typedef struct {
                                     lookup resolves them), 1 "gated", 2 "gated_shared".  Global slots: GATE1_W (15) f32 (C1, KH*KW), GATE1_B (16), and for mode 2 GATE2_W (17) bf16
                                     (C2, 12*3*C1), GATE2_B (18).  Mode 1: CONV2_W / CONV2_B hold conv AND gate, (2*C2, 9*C1) / (2*C2), interleaved in blocks of `gate_blk` channels */
     int gate_blk;                /* mode 1: 32 (the fused epilogue's packing; needs C2 % 32 == 0) or C2 (conv rows, then gate rows) */
+    int ln_fold;                 /* 1: the LayerNorms in front of the FFN-in / QKV / cgMLP-in GEMMs are folded into those GEMMs (LN(x) W^T = rstd (x W'^T) - rstd mu s + c, W' = W diag(gamma)):
+                                    the N = d GEMMs that produce the residual stream also emit its bf16 copy and per-row partial statistics, the consumers take those instead of
+                                    a LayerNorm kernel's output — one LayerNorm launch per layer instead of three.  Needs the layer slots *_WF / *_SF / *_CF (engine.py LS), relative
+                                    or no positions, macaron FFNs, d in {256, 512}, I % 256 == 0, no fine-tuning head.  0: LayerNorm kernels + plain GEMMs. */
 } mi_ebf_config;
 
 /* weight-table slot indices: see huggingface_asr_amd/engine.py (SLOTS) — the table is an array of device pointers. */
-enum { MI_EBF_GLOBAL_SLOTS = 24, MI_EBF_LAYER_SLOTS = 48 };
+enum { MI_EBF_GLOBAL_SLOTS = 24, MI_EBF_LAYER_SLOTS = 64 };
 
 size_t mi_ebf_workspace_bytes(const mi_ebf_config* cfg);
 

@@ -137,6 +137,34 @@ def test_gated_layer2_fused_epilogue_equals_unfused():
     assert (fused.float() - want).abs().mean() < 2e-3
 
 
+@pytest.mark.parametrize("name,cfg", [BIG[0], BIG[2]], ids=["small_rel", "base_rel"])
+def test_layernorm_fold_path_vs_reference(name, cfg):
+    """The engine's `ln_fold` path (LayerNorms folded into the FFN-in / QKV / cgMLP-in GEMMs, statistics and the bf16 residual copy out of the producing GEMMs' epilogues; it
+    selects itself at bench-size batches) forced on the two-utterance reference fixtures: the same bounds against the reference as the un-folded kernels, and both paths
+    agree with each other far inside them."""
+    from huggingface_asr_amd import ops
+    from huggingface_asr_amd.engine import EBranchformerEngine
+    g = load_golden(name)
+    sd, x, am, lab = case_inputs(g, cfg)
+    outs = {}
+    for fold in (True, False):
+        eng = EBranchformerEngine(cfg, DEV)
+        eng.ln_fold = fold
+        eng.load_state_dict(sd)
+        assert eng._config_struct(2, 1000, 80).ln_fold == int(fold)
+        out = eng.forward(x.to(DEV), am.sum(-1).to(DEV, torch.int32))
+        loss, _, _ = ops.ctc_loss(out["logits"], lab.to(DEV), out["outer_len"], reduction="mean", zero_infinity=True)
+        outs[fold] = (out["logits"].float().cpu().numpy(), float(loss), out["last_hidden"].cpu().numpy())
+    logits, loss, hid = outs[True]
+    d1 = np.abs(logits[:, ::25, :64] - g["logits_slice"])
+    d2 = np.abs(logits[:, :, -1] - g["logits_blank"])
+    assert max(d1.max(), d2.max()) < 0.06 and max(d1.mean(), d2.mean()) < 0.009, (d1.max(), d2.max(), d1.mean(), d2.mean())
+    assert abs(loss - float(g["loss"])) < 1e-3 * abs(float(g["loss"])), (loss, float(g["loss"]))
+    dd = np.abs(logits - outs[False][0])
+    assert dd.max() < 0.05 and dd.mean() < 0.006, (dd.max(), dd.mean())
+    assert np.abs(hid[1, 175:]).max() < 10 and np.isfinite(hid).all()                 # padded frames stay finite (their statistics are those of a zero row)
+
+
 def test_no_attention_mask_and_batch_invariance():
     """No mask -> all frames valid; an utterance's logits do not depend on its batch neighbours."""
     from huggingface_asr_amd.engine import EBranchformerEngine
@@ -163,6 +191,8 @@ def test_forward_is_bit_reproducible_at_the_bench_size(overlap):
     cfg = _cfg(shapes.BASE)
     sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()}
     eng = EBranchformerEngine(cfg, DEV)
+    if overlap:
+        eng.ln_fold = False          # the two-stream form exists for the un-folded layer only (engine._use_fold): compare like with like
     eng.load_state_dict(sd)
     feats = torch.from_numpy(synth.normal(1, "feats", (16, 1000, 80), 1.0)).to(DEV)
     lens = torch.full((16,), 998, dtype=torch.int32, device=DEV)
@@ -182,15 +212,19 @@ def test_forward_is_bit_reproducible_at_the_bench_size(overlap):
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), i
 
 
-def test_full_size_batch_independence_and_loss_additivity():
+@pytest.mark.parametrize("fold", [True, False])
+def test_full_size_batch_independence_and_loss_additivity(fold):
     """BASELINE configs[1] size (base, 32 x 10 s): size-independent properties instead of an oracle run — an utterance's logits do not depend on
     its batch neighbours (bit for bit: every kernel reduces over an utterance's own rows only), extra zero padding behind an utterance does not
-    move its valid frames, and the batch-mean CTC loss is the mean of the per-utterance losses."""
+    move its valid frames, and the batch-mean CTC loss is the mean of the per-utterance losses.  Both layer forms: LayerNorms folded into the GEMMs (what a batch of this
+    size selects by itself) and LayerNorm kernels + plain GEMMs (what a batch of one selects: the form is pinned here so that like is compared with like)."""
     from huggingface_asr_amd import ops, synth
     from huggingface_asr_amd.engine import EBranchformerEngine
     cfg = _cfg(shapes.BASE)
     sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()}
     eng = EBranchformerEngine(cfg, DEV)
+    assert eng._use_fold(32, 250) and not eng._use_fold(1, 250)
+    eng.ln_fold = fold
     eng.load_state_dict(sd)
     B, T = 32, 1000
     feats = torch.from_numpy(synth.normal(7, "feats", (B, T, 80), 1.0)).to(DEV)

@@ -352,3 +352,48 @@ def test_context_aware_front_end_pieces():
                              K=(12, 3), stride=(8, 2), pad=(4, 1), act="none")
     assert got2.shape == (B, 6, 20, C2)
     assert_close_bf16(got2, want2, what="shared gate conv2")
+
+
+@pytest.mark.parametrize("M,d,I", [(1000, 512, 2048), (700, 256, 1024)])
+def test_layernorm_folded_into_the_gemms(M, d, I):
+    """LN(x) W^T + b evaluated as rstd (bf16(x) W'^T) - rstd mu colsum(W') + (W beta + b) (csrc/gemm_args.hpp): the producer GEMM's epilogue (fp32 rows + bf16 copy + per-row
+    partial statistics), the LayerNorm kernel's producer mode, and the consumer GEMM with both statistic forms (1 pair / one pair per 32 columns), against torch."""
+    ops = _ops()
+    x0 = rnd(M, d, seed=41, scale=2.0) + 0.7                                        # a residual stream with a mean
+    a_in, w_p, b_p = bfr(rnd(M, I, seed=42)), bfr(rnd(d, I, seed=43, scale=I ** -0.5)), rnd(d, seed=44, scale=0.1)
+    gam, bet = 1.0 + 0.2 * rnd(d, seed=45), 0.1 * rnd(d, seed=46)
+    W, b = rnd(I, d, seed=47, scale=d ** -0.5), rnd(I, seed=48, scale=0.1)
+    # producer: x = x0 + 0.5 (a W_p^T + b_p)
+    c, c2, st = ops.gemm_resid_stats(a_in.to(DEV, torch.bfloat16), w_p.to(DEV, torch.bfloat16), b_p.to(DEV), x0.to(DEV), alpha=0.5)
+    x = x0 + 0.5 * (a_in @ w_p.t() + b_p)
+    torch.testing.assert_close(c.cpu(), x, atol=2e-3, rtol=1e-4)
+    assert torch.equal(c2.cpu(), c.cpu().to(torch.bfloat16))                        # the bf16 copy IS the rounded stored row
+    npart = d // 32
+    pairs = st.cpu().view(M, 16, 2)[:, :npart]
+    xs = c.cpu().view(M, npart, 32)
+    torch.testing.assert_close(pairs[..., 0], xs.sum(-1), atol=1e-3, rtol=1e-5)
+    torch.testing.assert_close(pairs[..., 1], (xs * xs).sum(-1), atol=1e-2, rtol=1e-5)
+    # consumer on the producer's outputs
+    wf = (W * gam[None]).to(torch.bfloat16)
+    colsum, cbias = wf.float().sum(-1), W @ bet + b
+    want = F.gelu(F.linear(F.layer_norm(c.cpu(), (d,), gam, bet, 1e-5), W, b))
+    got = ops.gemm_lnfold(c2, wf.to(DEV), colsum.to(DEV), cbias.to(DEV), st, npart, act="gelu")
+    err = (got.float().cpu() - want).abs()
+    assert float(err.max()) < 0.06 and float(err.mean()) < 0.006, (float(err.max()), float(err.mean()))        # bf16 operands: the same budget as LayerNorm kernel -> bf16 -> GEMM
+    ref_path = F.gelu(F.linear(bfr(F.layer_norm(c.cpu(), (d,), gam, bet, 1e-5)), bfr(W), b))                  # what the un-folded kernels compute
+    assert float(err.mean()) < 2.0 * float((ref_path - want).abs().mean()) + 1e-4
+    # LayerNorm kernel's producer mode (masking + LN), one statistics pair, and the consumer without activation
+    T, B = 100, M // 100
+    lens = torch.tensor([100, 37] + [100] * (B - 2), dtype=torch.int32)
+    x1 = c.cpu()[: B * T]
+    y, yb, st1 = ops.layernorm_fold(c[: B * T].contiguous(), ln=(gam.to(DEV), bet.to(DEV)), lengths=lens.to(DEV), T=T)
+    xm = x1.clone().view(B, T, d); xm[1, 37:] = 0
+    want_y = F.layer_norm(xm.view(-1, d), (d,), gam, bet, 1e-5)
+    torch.testing.assert_close(y.cpu(), want_y, atol=2e-5, rtol=1e-5)
+    assert torch.equal(yb.cpu(), y.cpu().to(torch.bfloat16))
+    torch.testing.assert_close(st1.cpu()[:, 0], want_y.sum(-1), atol=2e-3, rtol=1e-5)
+    torch.testing.assert_close(st1.cpu()[:, 1], (want_y * want_y).sum(-1), atol=2e-2, rtol=1e-5)
+    got2 = ops.gemm_lnfold(yb, wf.to(DEV), colsum.to(DEV), cbias.to(DEV), st1, 1, act="none")
+    want2 = F.linear(F.layer_norm(want_y, (d,), gam, bet, 1e-5), W, b)
+    e2 = (got2.float().cpu() - want2).abs()
+    assert float(e2.max()) < 0.08 and float(e2.mean()) < 0.008, (float(e2.max()), float(e2.mean()))
