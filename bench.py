@@ -373,7 +373,10 @@ def main():
                     fl_step[f] = ffl.value / args.event_steps
                     iso_us[f] = fms.value * 1e3 / args.event_steps
             # PIPELINED durations (the roofline figure): the dispatch timestamps of the same kernels in a rocprofv3 --kernel-trace child run of this script
-            pipe_us, child_steps, why = (None, 0, "more than one rank") if world > 1 else rocprof_child_dense_us(args, B, per_step)
+            try:
+                pipe_us, child_steps, why = (None, 0, "more than one rank") if world > 1 else rocprof_child_dense_us(args, B, per_step)
+            except Exception as e:  # noqa: BLE001 — the bench line must come out whatever happens to the profiler child
+                pipe_us, child_steps, why = None, 0, f"rocprofv3 child: {type(e).__name__}: {e}"[:200]
             dur = pipe_us if pipe_us is not None else iso_us
             tot_fl, tot_us = sum(fl_step.values()), sum(dur[f] for f in per_step)
             ach = tot_fl / (tot_us * 1e-6) / 1e12
