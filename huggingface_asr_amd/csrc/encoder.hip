@@ -335,7 +335,6 @@ extern "C" int mi_ebf_forward_hs(const mi_ebf_config* cfg, const void* const* we
         // written by the kernel that produced x (mi_layernorm_fold at layer entry and after final_layer_norm; the FFN-out / merge GEMMs' epilogues in between).
         if (c.pos_type == 2 || !c.use_macaron || c.extra_layers || c.layer_mixing || c.csgu_linear || (D.hd != 64 && D.hd != 128)) return MI_ERR_ARG;
         const int npg = d / 32;                                   // pairs a producer GEMM writes (one per 32 columns)
-        if (hipMemsetAsync(w.lnst, 0, (size_t)M * 32 * sizeof(float), st) != hipSuccess) return MI_ERR_LAUNCH;
         // entry: zero padded frames once (tf:662-665); x, bf16(x), statistics
         RUN(mi_layernorm_fold(w.x, d, mask_len, T2, nullptr, nullptr, 0.f, w.x, d, w.a0, d, w.lnst, M, d, st));
         int np = 1;

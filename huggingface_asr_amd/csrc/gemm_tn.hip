@@ -47,20 +47,32 @@ __device__ __forceinline__ int swz(int row) {
     return CH == 16 ? (((row & 3) << 2) | ((row >> 2) & 3)) : (row & (CH - 1));
 }
 
+// The transposed LDS reads are INLINE ASM with hand-placed lgkmcnt waits (round 3).  Through the builtin the compiler cannot tell them from the destinations of the
+// LDS-DMA stagings issued just before (next stage, other ring buffer) and puts `s_waitcnt vmcnt(0)` in front of the first read of every stage: the prefetch then
+// never overlaps the stage's own MFMAs — a block was a chain of full memory round trips (3.2 us per stage for a lone block; what round 2's stamps read as "1180 cycles
+// issuing 8 DMA pieces"), and only the second block of the CU hid any of it.
 template <int ROWB>                                       // bytes per tile row (256: 128 columns, 128: 64 columns)
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int cb, int s, int lane) {
+__device__ __forceinline__ void tr_frag_issue(const char* tile, int cb, int s, int lane, s16x4& lo, s16x4& hi) {
     const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
     const int col = cb + (g & 1) * 16 + 4 * p4;
     const int lc = col >> 3, within = (col & 7) * 2;
     const int k0 = 16 * s + 4 * (g >> 1) + q4, k1 = k0 + 8;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + k0 * ROWB + ((lc ^ swz<ROWB / 16>(k0)) << 4) + within));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + k1 * ROWB + ((lc ^ swz<ROWB / 16>(k1)) << 4) + within));
+    const unsigned a0 = (unsigned)(size_t)(tile + k0 * ROWB + ((lc ^ swz<ROWB / 16>(k0)) << 4) + within);      // addrspace(3) pointers are 32-bit offsets
+    const unsigned a1 = (unsigned)(size_t)(tile + k1 * ROWB + ((lc ^ swz<ROWB / 16>(k1)) << 4) + within);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1) : "memory");
+}
+__device__ __forceinline__ bf16x8 tr_frag_join(s16x4& lo, s16x4& hi) {
+    asm volatile("" : "+v"(lo), "+v"(hi));                // the asm outputs are valid only behind the wait: keep the compiler from reading them earlier
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int XW>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
+// NS = depth of the LDS ring: 2 for the split-M launches (16 stages per block, two blocks per CU hide each other's memory round trips), 4 for the grouped launch
+// (125 stages per block, one block per CU: a lone block on the two-deep ring sees the full HBM latency every stage — 3.2 us per stage measured, tools/tn_group_ab.py —
+// while three stages in flight cover it).
+template <int XW, int NS>
+__device__ __forceinline__ void tn_tile(const TnArgs& p, const int bid) {
     constexpr int XB = XW * 2, XCH = XW / 8;                  // X tile row bytes, 16-B chunks per row
     constexpr int YP = 16, XP = TN_KM * XB / 1024, PPW = (YP + XP) / 4;   // 1-KiB pieces per stage: dY, X, per wave
     constexpr int STAGE = TN_KM * (TN_T * 2 + XB);
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
     const int wn = wave >> 1, wk = wave & 1;
     const int ntn = (p.N + TN_T - 1) / TN_T, ntk = (p.K + XW - 1) / XW;
     const int ntiles = ntn * ntk;
-    const int split = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
+    const int split = bid / ntiles, tile = bid % ntiles;
     const int n0 = (tile / ntk) * TN_T, k0 = (tile % ntk) * XW;
     const int m_lo = split * p.rows_per_split, m_hi = min(p.M, m_lo + p.rows_per_split);
     const int nit = (m_hi - m_lo + TN_KM - 1) / TN_KM;
@@ -119,28 +131,59 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
     const int bn = tid & 127, bh = tid >> 7;
     float bsum = 0.f;
 
-    if (nit > 0) issue(0, 0);
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0)
+        if (s0 < nit) issue(s0, s0);
     for (int it = 0; it < nit; ++it) {
-        const int stage = it & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
-        if (it + 1 < nit) issue(it + 1, stage ^ 1);
+        const int stage = it % NS;
+        // stage `it` has landed when at most the (NS - 2) younger stagings are still in flight (in-order vmcnt); near the end fewer were issued: wait for everything
+        if (NS > 2 && it + NS - 2 < nit) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");                        // every wave is done with stage it - 1: its buffer takes stage it + NS - 1
+        if (it + NS - 1 < nit) issue(it + NS - 1, (it + NS - 1) % NS);
         const char* ty = smem + stage * STAGE;
         const char* tx = ty + TN_KM * TN_T * 2;
         if (do_db) {
-#pragma unroll 8
+            // (inline asm for the same reason as the transposed reads: a plain LDS load here would drag a vmcnt(0) in)
+            unsigned short hv[32];
+#pragma unroll
             for (int r = 0; r < 32; ++r) {
                 const int m = bh * 32 + r;
-                bsum += bf2f(*reinterpret_cast<const bf16_t*>(ty + m * 256 + (((bn >> 3) ^ swz<16>(m)) << 4) + (bn & 7) * 2));
+                const unsigned a = (unsigned)(size_t)(ty + m * 256 + (((bn >> 3) ^ swz<16>(m)) << 4) + (bn & 7) * 2);
+                unsigned v;
+                asm volatile("ds_read_u16 %0, %1" : "=v"(v) : "v"(a) : "memory");
+                hv[r] = (unsigned short)v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                asm volatile("" : "+v"(hv[r]));
+                bsum += __builtin_bit_cast(float, (unsigned)hv[r] << 16);
             }
         }
+        // 4 k-steps of 16 rows; the fragments of step s + 1 are requested before the MFMAs of step s issue (two register sets, counted lgkmcnt)
+        constexpr int NR = 2 * (2 + NJ);                      // LDS reads per k-step and lane
+        s16x4 ylo[2][2], yhi[2][2], xlo[2][NJ], xhi[2][NJ];
+        auto rd = [&](int buf, int s) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) tr_frag_issue<256>(ty, wn * 64 + i * 32, s, lane, ylo[buf][i], yhi[buf][i]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) tr_frag_issue<XB>(tx, wk * (XW / 2) + j * 32, s, lane, xlo[buf][j], xhi[buf][j]);
+        };
+        rd(0, 0);
 #pragma unroll
         for (int s = 0; s < TN_KM / 16; ++s) {
+            if (s + 1 < TN_KM / 16) {
+                rd((s + 1) & 1, s + 1);
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");      // step s's reads are the older NR
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             bf16x8 fy[2], fx[NJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fy[i] = tr_frag<256>(ty, wn * 64 + i * 32, s, lane);
+            for (int i = 0; i < 2; ++i) fy[i] = tr_frag_join(ylo[s & 1][i], yhi[s & 1][i]);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) fx[j] = tr_frag<XB>(tx, wk * (XW / 2) + j * 32, s, lane);
+            for (int j = 0; j < NJ; ++j) fx[j] = tr_frag_join(xlo[s & 1][j], xhi[s & 1][j]);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -173,6 +216,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) {
                 else *o += acc[i][j][r];
             }
         }
+}
+
+template <int XW>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) { tn_tile<XW, 2>(p, blockIdx.x); }
+
+// Grouped form: the weight-gradient GEMMs of one encoder layer (up to TN_GROUP problems: dY_i^T X_i -> dW_i) as ONE launch.  A layer's ten dW GEMMs together have
+// ~450 output tiles of 128 x 128 — enough to fill the chip WITHOUT splitting M: every block contracts over all rows of its problem and adds its tile into dW in place,
+// so there are no slabs and no reduce pass (launched one by one, each problem needs 8-32 M-splits to fill 512 blocks: 164 launches x (32 us GEMM + 9 us slab reduce)
+// per training step).  Block -> (problem, tile) by the prefix table of tile counts.
+constexpr int TN_GROUP = 16;
+struct TnGroup { TnArgs a[TN_GROUP]; int tile0[TN_GROUP + 1]; int n; };
+
+constexpr int TN_GROUP_NS = 2;
+__global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnGroup g) {
+    const int bid = blockIdx.x;
+    int i = 0;
+    while (i + 1 < g.n && bid >= g.tile0[i + 1]) ++i;
+    // the problem index is wave-uniform: say so, and take a COPY of the descriptor — indexed in place, its fields come back as vector memory loads inside the pipeline,
+    // each with a `s_waitcnt vmcnt(0)` in front of the LDS-DMA instruction that uses it (seen in the ISA: one full wait per staging instruction)
+    const int iu = __builtin_amdgcn_readfirstlane(i);
+    const TnArgs p = g.a[iu];
+    tn_tile<128, TN_GROUP_NS>(p, bid - __builtin_amdgcn_readfirstlane(g.tile0[iu]));
 }
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ out, long ldo, const float* __restrict__ slabs, long slab_stride,
@@ -233,5 +298,35 @@ extern "C" int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx
                            splits, n_store, K);
         MI_CHECK_LAUNCH();
     }
+    return MI_OK;
+}
+
+// The grouped form (see gemm_tn_group_kernel): n <= 16 problems, each dW_i (n_store_i, K_i) fp32 (row stride ldo_i) += dY_i[:, :N_i]^T X_i with optional bias gradient db_i,
+// ONE launch, no M-split, no workspace.  Arrays of length n on the HOST.  Same operand constraints as mi_gemm_tn_bf16.  Meant for >= ~256 output tiles in total
+// (sum of ceil(N_i / 128) * ceil(K_i / 128)); with fewer the chip is under-filled: use mi_gemm_tn_bf16 per problem.
+extern "C" int mi_gemm_tn_group_bf16(int n, const void* const* dY, const long* ldy, const void* const* X, const long* ldx, float* const* dW, const long* ldo,
+                                     float* const* db, const int* M, const int* N, const int* K, const int* n_store, hipStream_t st) {
+    MI_ENTER();
+    if (n <= 0 || n > TN_GROUP) return MI_ERR_ARG;
+    TnGroup g{};
+    g.n = n;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        if (M[i] <= 0 || N[i] <= 0 || K[i] <= 0 || (N[i] % 8) || (K[i] % 8) || (ldy[i] % 8) || (ldx[i] % 8) || n_store[i] > N[i] || n_store[i] <= 0) return MI_ERR_ARG;
+        if ((reinterpret_cast<uintptr_t>(dY[i]) & 15) || (reinterpret_cast<uintptr_t>(X[i]) & 15) || !dW[i]) return MI_ERR_ARG;
+        TnArgs& p = g.a[i];
+        p.Y = (const bf16_t*)dY[i]; p.ldy = ldy[i]; p.X = (const bf16_t*)X[i]; p.ldx = ldx[i];
+        p.M = M[i]; p.N = N[i]; p.K = K[i]; p.n_store = n_store[i]; p.splits = 1; p.db = db ? db[i] : nullptr;
+        p.rows_per_split = cdiv(M[i], TN_KM) * TN_KM;
+        p.out = dW[i]; p.ldo = ldo[i]; p.slab_stride = 0;
+        g.tile0[i] = tiles;
+        tiles += cdiv(N[i], TN_T) * cdiv(K[i], 128);
+    }
+    g.tile0[n] = tiles;
+    const size_t lds = (size_t)TN_GROUP_NS * TN_KM * (TN_T * 2 + 256);                    // 4 x 32 KiB: one block per CU
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return MI_ERR_LAUNCH;
+    hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(tiles), dim3(256), lds, st, g);
+    MI_CHECK_LAUNCH();
     return MI_OK;
 }

@@ -76,14 +76,19 @@ def fbank_gpu(wave, tables: FbankTables, num_samples=None, pad_frames_to: int | 
     B, N = wave.shape
     tb = tables.device(wave.device)
     if num_samples is None:
-        frames = torch.full((B,), num_frames(N), dtype=torch.int32, device=wave.device)
+        key = ("frames", str(wave.device), B, N)             # the same full-length batch every step: one fill kernel less per call
+        frames = tb.get(key)
+        if frames is None:
+            frames = tb[key] = torch.full((B,), num_frames(N), dtype=torch.int32, device=wave.device)
         T = num_frames(N)
     else:
         frames = torch.clamp((num_samples.to(torch.int32) - FRAME) // HOP + 1, min=0)
         T = num_frames(N)
     if pad_frames_to:
         T = (T + pad_frames_to - 1) // pad_frames_to * pad_frames_to
-    out = torch.full((B, T, tables.num_mel), float(padding_value), dtype=torch.float32, device=wave.device)
+    # utterance CMVN rewrites every element of the buffer, padding rows included (csrc/fbank.hip cmvn kernels): no fill pass in front of it
+    out = (torch.empty((B, T, tables.num_mel), dtype=torch.float32, device=wave.device) if normalize == "utterance"
+           else torch.full((B, T, tables.num_mel), float(padding_value), dtype=torch.float32, device=wave.device))
     st = torch.cuda.current_stream().cuda_stream
     L = _lib.lib()
     _lib.check(L.mi_fbank_f64(wave.data_ptr(), wave.stride(0), 0 if num_samples is None else num_samples.to(torch.int32).data_ptr(),

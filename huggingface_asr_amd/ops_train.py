@@ -402,12 +402,52 @@ def adamw_step_(p, g, m, v, decay, *, lr, betas=(0.9, 0.999), eps=1e-8, weight_d
 _TN_WS = {}
 
 
-def gemm_tn_(dw, dy, x, n_store=None, db=None, variant=0):
+class TnBatch:
+    """Deferred weight-gradient GEMMs: `gemm_tn_(..., defer=batch)` / `linear_bwd(..., defer=batch)` only record (dW, dY, X, db) — the tensors stay referenced, so their
+    memory is not reused — and `flush()` runs them as ONE grouped launch (mi_gemm_tn_group_bf16): a layer's ten dW GEMMs have ~450 output tiles between them, enough
+    to fill the chip without splitting M, hence no slabs and no reduce passes.  Below `MIN_TILES` output tiles in total (a mostly frozen layer) the problems run one by
+    one on the split-M path.  Callers must not modify a recorded dY / X in place before the flush."""
+    MAX, MIN_TILES = 16, 192
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, dw, dy, x, n_store, db):
+        self.items.append((dw, dy, x, n_store, db))
+        if len(self.items) == self.MAX:
+            self.flush()
+
+    def flush(self):
+        items, self.items = self.items, []
+        if not items:
+            return
+        tiles = sum(-(-dy.shape[1] // 128) * -(-x.shape[1] // 128) for _, dy, x, _, _ in items)
+        if tiles < self.MIN_TILES:
+            for dw, dy, x, n_store, db in items:
+                gemm_tn_(dw, dy, x, n_store=n_store, db=db)
+            return
+        import ctypes as C
+        n = len(items)
+        vp, lg, it = (C.c_void_p * n), (C.c_long * n), (C.c_int * n)
+        _lib.check(_L().mi_gemm_tn_group_bf16(
+            n, vp(*[dy.data_ptr() for _, dy, _, _, _ in items]), lg(*[dy.stride(0) for _, dy, _, _, _ in items]),
+            vp(*[x.data_ptr() for _, _, x, _, _ in items]), lg(*[x.stride(0) for _, _, x, _, _ in items]),
+            vp(*[dw.data_ptr() for dw, _, _, _, _ in items]), lg(*[dw.stride(0) for dw, _, _, _, _ in items]),
+            vp(*[(db.data_ptr() if db is not None else None) for _, _, _, _, db in items]),
+            it(*[dy.shape[0] for _, dy, _, _, _ in items]), it(*[dy.shape[1] for _, dy, _, _, _ in items]), it(*[x.shape[1] for _, _, x, _, _ in items]),
+            it(*[ns for _, _, _, ns, _ in items]), _stream()), "mi_gemm_tn_group_bf16")
+
+
+def gemm_tn_(dw, dy, x, n_store=None, db=None, variant=0, defer=None):
     """dw (n_store, K) f32 += dy[:, :N]^T · x   (dy (M,N) bf16, x (M,K) bf16 row views; contraction over rows, no transposes).
-    db (n_store) f32: the bias gradient db += column sums of dy, computed from the same LDS tiles."""
+    db (n_store) f32: the bias gradient db += column sums of dy, computed from the same LDS tiles.
+    defer: a TnBatch — the product is recorded and runs with the batch's next flush()."""
     M, N = dy.shape
     K = x.shape[1]
     n_store = dw.shape[0] if n_store is None else n_store
+    if defer is not None:
+        defer.add(dw, dy, x, n_store, db)
+        return dw
     nbytes = _L().mi_gemm_tn_workspace_bytes(M, N, K)
     key = dy.device
     ws = _TN_WS.get(key)
@@ -419,7 +459,7 @@ def gemm_tn_(dw, dy, x, n_store=None, db=None, variant=0):
 
 
 # ---------------------------------------------------------------------------------------------------------------- composites
-def linear_bwd(dy, x, wT, *, dw=None, db=None, dx_out=None, dx_dtype=BF16, need_dx=True):
+def linear_bwd(dy, x, wT, *, dw=None, db=None, dx_out=None, dx_dtype=BF16, need_dx=True, defer=None):
     """Backward of y = x W^T + b for bf16 row-major activations.
     dy (M,N) bf16, x (M,K) bf16, wT (K,N) bf16 (the transposed copy of W the trainer keeps).
     dx = dy · W (GEMM with W^T as the (N',K') operand); dW (N,K) f32 += dy^T · x (row-contraction GEMM, gemm_tn.hip); db += colsum(dy)."""
@@ -429,7 +469,7 @@ def linear_bwd(dy, x, wT, *, dw=None, db=None, dx_out=None, dx_dtype=BF16, need_
     if need_dx:
         dx = gemm(dy, wT[:, :N], out=dx_out, out_dtype=dx_dtype)
     if dw is not None:
-        gemm_tn_(dw, dy, x, db=db)                 # bias gradient fused into the weight-gradient GEMM
+        gemm_tn_(dw, dy, x, db=db, defer=defer)    # bias gradient fused into the weight-gradient GEMM
     elif db is not None:
         colsum_(db, dy)
     return dx

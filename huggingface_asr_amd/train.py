@@ -493,6 +493,8 @@ class EncoderCTCTrainer:
         """the gradients of [lo, hi) are final once the deferred LayerNorm reductions have run: flush them, then hand the range to the data-parallel all-reduce"""
         if getattr(self, "_lnred", None) is not None:
             self._lnred.flush()
+        if getattr(self, "_tnb", None) is not None:
+            self._tnb.flush()               # the layer's deferred weight-gradient GEMMs: one grouped launch (ops_train.TnBatch)
         self.sync.launch(lo, hi)
 
     def _lng(self, gname, bname):
@@ -560,6 +562,9 @@ class EncoderCTCTrainer:
         c, st = self.cfg, self.store
         if getattr(self, "_lnred", None) is not None:
             self._lnred.items = []              # a step that raised part-way leaves deferred LayerNorm reductions behind: they must not land in this step's gradients
+        if getattr(self, "_tnb", None) is None:
+            self._tnb = T.TnBatch()
+        self._tnb.items = []
         P, G, W, WT = st.p, st.g, st.bf, st.bfT
         GL = lambda n, sl=None: None if n in self.frozen else (st.g(n) if sl is None else st.g(n)[sl])      # gradient of a linear's weight / bias, None when frozen
         dev = self.device
@@ -767,18 +772,18 @@ class EncoderCTCTrainer:
                 self._ffn_bwd(dx, S["x2"], S["ff2"], p + "ff2", pd, sl, (6, 7))
             # merge:  x2 = x1 + dropout(merge_proj(m2))
             dyb = T.dropout_(dx, pd["att"], seed, self._sid(sl, 5), out=e16(M, d)) if pd["att"] > 0 else T.add_cast(dx)
-            dm2 = T.linear_bwd(dyb, S["m2"], WT(p + "mrg_w"), dw=GL(p + "mrg_w"), db=GL(p + "mrg_b"))
+            dm2 = T.linear_bwd(dyb, S["m2"], WT(p + "mrg_w"), dw=GL(p + "mrg_w"), db=GL(p + "mrg_b"), defer=self._tnb)
             dcat = e16(M, 2 * d)
             T.dwconv_residual_bwd(S["cat"], P(p + "mrg_dw_w"), dm2, dcat, G(p + "mrg_dw_w"), G(p + "mrg_dw_b"), B, T2)
             # local branch
-            dsg = T.linear_bwd(dcat[:, d:], S["sg"], WT(p + "mlp_w2"), dw=GL(p + "mlp_w2"), db=GL(p + "mlp_b2"))
+            dsg = T.linear_bwd(dcat[:, d:], S["sg"], WT(p + "mlp_w2"), dw=GL(p + "mlp_w2"), db=GL(p + "mlp_b2"), defer=self._tnb)
             if pd["csgu"] > 0:
                 T.dropout_(dsg, pd["csgu"], seed, self._sid(sl, 4))
             dh = e16(M, I)
             dgn = e16(M, I // 2)
             if self.csgu_split:
                 dlin = T.gate_act_mul_bwd(S["h"][:, :I // 2], S["lin"], dsg, dh[:, :I // 2], self.csgu_act)
-                dcv = T.linear_bwd(dlin, S["cv"], WT(p + "csgu_lin_w"), dw=GL(p + "csgu_lin_w"), db=GL(p + "csgu_lin_b")) if self.csgu_lin else dlin
+                dcv = T.linear_bwd(dlin, S["cv"], WT(p + "csgu_lin_w"), dw=GL(p + "csgu_lin_w"), db=GL(p + "csgu_lin_b"), defer=self._tnb) if self.csgu_lin else dlin
                 T.csgu_bwd(S["h"], S["stats"], P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), dcv, None, dgn,
                            G(p + "csgu_w"), G(p + "csgu_b"), B, T2, pad_left=cs_pad, dilation=cs_dil)
             else:
@@ -786,22 +791,22 @@ class EncoderCTCTrainer:
                            G(p + "csgu_w"), G(p + "csgu_b"), B, T2, pad_left=cs_pad, dilation=cs_dil)
             T.layernorm_bwd(S["h"][:, I // 2:], P(p + "csgu_ln_g"), dgn, dh[:, I // 2:], accumulate=False, **self._lng(p + "csgu_ln_g", p + "csgu_ln_b"))
             dhp = T.act_bwd(dh, S["hp"])
-            da2 = T.linear_bwd(dhp, S["a2"], WT(p + "mlp_w1"), dw=GL(p + "mlp_w1"), db=GL(p + "mlp_b1"))
+            da2 = T.linear_bwd(dhp, S["a2"], WT(p + "mlp_w1"), dw=GL(p + "mlp_w1"), db=GL(p + "mlp_b1"), defer=self._tnb)
             T.layernorm_bwd(S["x1"], P(p + "mlp_ln_g"), da2, dx, accumulate=True, **self._lng(p + "mlp_ln_g", p + "mlp_ln_b"))
             # global branch
             if pd["att"] > 0:
                 T.dropout_(dcat[:, :d], pd["att"], seed, self._sid(sl, 3))
-            dctx = T.linear_bwd(dcat[:, :d], S["ctx"], WT(p + "att_wo"), dw=GL(p + "att_wo"), db=GL(p + "att_bo"))
+            dctx = T.linear_bwd(dcat[:, :d], S["ctx"], WT(p + "att_wo"), dw=GL(p + "att_wo"), db=GL(p + "att_bo"), defer=self._tnb)
             dqkv = self._attention_bwd(dctx, S, p, pos, inner, B, T2, H, (pd["att"], seed, self._sid(sl, 2)) if pd["att"] > 0 else None)
             if ptype == "rotary":
                 wt = WT(p + "att_wqkv")
-                da1r = T.linear_bwd(dqkv[:, :2 * d], S["a1r"], wt[:, :2 * d], dw=GL(p + "att_wqkv", slice(0, 2 * d)), db=GL(p + "att_bqkv", slice(0, 2 * d)))
-                da1 = T.linear_bwd(dqkv[:, 2 * d:], S["a1"], wt[:, 2 * d:3 * d], dw=GL(p + "att_wqkv", slice(2 * d, None)), db=GL(p + "att_bqkv", slice(2 * d, None)), dx_dtype=F32)
+                da1r = T.linear_bwd(dqkv[:, :2 * d], S["a1r"], wt[:, :2 * d], dw=GL(p + "att_wqkv", slice(0, 2 * d)), db=GL(p + "att_bqkv", slice(0, 2 * d)), defer=self._tnb)
+                da1 = T.linear_bwd(dqkv[:, 2 * d:], S["a1"], wt[:, 2 * d:3 * d], dw=GL(p + "att_wqkv", slice(2 * d, None)), db=GL(p + "att_bqkv", slice(2 * d, None)), dx_dtype=F32, defer=self._tnb)
                 rot = ops.rotary(da1r, pos[0].reshape(-1), pos[2].reshape(-1), T2, H)             # R^T = rotation by -theta
                 T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), da1, dx, accumulate=True, **self._lng(p + "att_ln_g", p + "att_ln_b"))
                 T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), rot, dx, accumulate=True, **self._lng(p + "att_ln_g", p + "att_ln_b"))
             else:
-                da1 = T.linear_bwd(dqkv, S["a1"], WT(p + "att_wqkv")[:, :3 * d], dw=GL(p + "att_wqkv"), db=GL(p + "att_bqkv"))
+                da1 = T.linear_bwd(dqkv, S["a1"], WT(p + "att_wqkv")[:, :3 * d], dw=GL(p + "att_wqkv"), db=GL(p + "att_bqkv"), defer=self._tnb)
                 T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), da1, dx, accumulate=True, **self._lng(p + "att_ln_g", p + "att_ln_b"))
             if macaron:
                 self._ffn_bwd(dx, S["x_in"], S["ff1"], p + "ff1", pd, sl, (0, 1))
@@ -962,9 +967,9 @@ class EncoderCTCTrainer:
             dyb = T.dropout_(dx, pd["hidden"], self.seed, self._sid(l, sites[1]), out=torch.empty(dx.shape, device=dx.device, dtype=BF16), alpha=0.5)
         else:
             dyb = T.add_cast(dx, alpha=0.5)
-        dh = T.linear_bwd(dyb, S["h"], WT(pre + "_w2"), dw=GL(pre + "_w2"), db=GL(pre + "_b2"))
+        dh = T.linear_bwd(dyb, S["h"], WT(pre + "_w2"), dw=GL(pre + "_w2"), db=GL(pre + "_b2"), defer=self._tnb)
         dhp = T.act_bwd(dh, S["hp"], drop=(pd["act"], self.seed, self._sid(l, sites[0])) if pd["act"] > 0 else None)
-        da = T.linear_bwd(dhp, S["a"], WT(pre + "_w1"), dw=GL(pre + "_w1"), db=GL(pre + "_b1"))
+        da = T.linear_bwd(dhp, S["a"], WT(pre + "_w1"), dw=GL(pre + "_w1"), db=GL(pre + "_b1"), defer=self._tnb)
         T.layernorm_bwd(x_in, P(pre + "_ln_g"), da, dx, accumulate=True, **self._lng(pre + "_ln_g", pre + "_ln_b"))
 
     def _attention_fwd(self, qkv, posp, u, v, lengths, B, Tt, H, S, drop=None):
@@ -1056,7 +1061,7 @@ class EncoderCTCTrainer:
         T.colsum_(G(p + "att_v"), dqv)
         # linear_pos: posp = table · Wpos^T  ->  dWpos += dposp^T · table
         dpb = T.add_cast(dposp)
-        T.gemm_tn_(G(p + "att_wpos"), dpb, pos[0])
+        T.gemm_tn_(G(p + "att_wpos"), dpb, pos[0], defer=self._tnb)
         return dqkv
 
     # ------------------------------------------------------------------ optimizer
