@@ -44,7 +44,7 @@ struct TnArgs {
 // swizzle for ds_read_b128 row reads, leaves; CDNA guide, "one image for row reads and transposed reads", image (b)).  128-B rows (A/B variant): chunk ^ (row & 7).
 template <int CH>
 __device__ __forceinline__ int swz(int row) {
-    return CH == 16 ? (((row & 3) << 2) | ((row >> 2) & 3)) : (row & (CH - 1));
+    return CH >= 16 ? (((row & 3) << 2) | ((row >> 2) & 3)) : (row & (CH - 1));       // 512-B rows (32 chunks, the 256-wide dY tile) take the 256-B rows' pattern: the high chunk bit stays
 }
 
 // The transposed LDS reads are INLINE ASM with hand-placed lgkmcnt waits (round 3).  Through the builtin the compiler cannot tell them from the destinations of the
@@ -68,22 +68,26 @@ __device__ __forceinline__ bf16x8 tr_frag_join(s16x4& lo, s16x4& hi) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// NS = depth of the LDS ring: 2 for the split-M launches (16 stages per block, two blocks per CU hide each other's memory round trips), 4 for the grouped launch
-// (125 stages per block, one block per CU: a lone block on the two-deep ring sees the full HBM latency every stage — 3.2 us per stage measured, tools/tn_group_ab.py —
-// while three stages in flight cover it).
-template <int XW, int NS>
+// NS = depth of the LDS ring.  Measured for the grouped launch (tools/tn_group_ab.py, 125 stages per block): once the compiler's vmcnt(0) waits were out of the way
+// (inline-asm transposed reads above; the group descriptor copied into SGPRs below) a stage costs a lone block 1.1-1.3 us whatever the depth (2, 3, 4) and whatever the
+// tile (128 x 128 with four waves, 256 x 128 with eight) — the 256 transposed reads per stage and CU and the 48 KiB of DMA writes keep the LDS busy ~1400 of those
+// ~2700 cycles, the MFMAs ~1000 — so the depth stays 2.
+// TNN = output tile rows (n): 128 (4 waves, 2 x 2 of 64 x 64) or 256 (8 waves, 4 x 2: the grouped launch — 85 FLOP per ingested byte instead of 64, two waves per SIMD).
+template <int TNN, int XW, int NS>
 __device__ __forceinline__ void tn_tile(const TnArgs& p, const int bid) {
     constexpr int XB = XW * 2, XCH = XW / 8;                  // X tile row bytes, 16-B chunks per row
-    constexpr int YP = 16, XP = TN_KM * XB / 1024, PPW = (YP + XP) / 4;   // 1-KiB pieces per stage: dY, X, per wave
-    constexpr int STAGE = TN_KM * (TN_T * 2 + XB);
+    constexpr int YB = TNN * 2, YCH = TNN / 8;                // dY tile row bytes / chunks
+    constexpr int NW = (TNN / 64) * 2, NT = 64 * NW;          // waves (n x k = TNN/64 x 2), threads
+    constexpr int YP = TN_KM * YB / 1024, XP = TN_KM * XB / 1024, PPW = (YP + XP) / NW;   // 1-KiB pieces per stage: dY, X, per wave
+    constexpr int STAGE = TN_KM * (YB + XB);
     constexpr int NJ = XW / 64;                               // 32-column k blocks per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wk = wave & 1;
-    const int ntn = (p.N + TN_T - 1) / TN_T, ntk = (p.K + XW - 1) / XW;
+    const int ntn = (p.N + TNN - 1) / TNN, ntk = (p.K + XW - 1) / XW;
     const int ntiles = ntn * ntk;
     const int split = bid / ntiles, tile = bid % ntiles;
-    const int n0 = (tile / ntk) * TN_T, k0 = (tile % ntk) * XW;
+    const int n0 = (tile / ntk) * TNN, k0 = (tile % ntk) * XW;
     const int m_lo = split * p.rows_per_split, m_hi = min(p.M, m_lo + p.rows_per_split);
     const int nit = (m_hi - m_lo + TN_KM - 1) / TN_KM;
 
@@ -96,8 +100,9 @@ __device__ __forceinline__ void tn_tile(const TnArgs& p, const int bid) {
         const int g = wave * PPW + q;
         const bool isY = g < YP;
         if (isY) {
-            const int row = g * 4 + (lane >> 4), cs = lane & 15;
-            const int c = cs ^ swz<16>(row);                 // source chunk for LDS slot cs
+            constexpr int RPY = 1024 / YB;                   // rows per piece
+            const int row = g * RPY + lane / YCH, cs = lane % YCH;
+            const int c = cs ^ swz<YCH>(row);                // source chunk for LDS slot cs
             rowin[q] = row; colok[q] = n0 + c * 8 < p.N; src[q] = p.Y + n0 + c * 8;
         } else {
             constexpr int RPP = 1024 / XB;                   // rows per piece
@@ -128,7 +133,7 @@ __device__ __forceinline__ void tn_tile(const TnArgs& p, const int bid) {
 
     // bias gradient: the blocks of the first k-tile column also sum their dY tile over m (thread = column tid & 127, row half tid >> 7)
     const bool do_db = p.db != nullptr && (tile % ntk) == 0;
-    const int bn = tid & 127, bh = tid >> 7;
+    const int bn = tid % TNN, bh = tid / TNN;
     float bsum = 0.f;
 
 #pragma unroll
@@ -142,14 +147,14 @@ __device__ __forceinline__ void tn_tile(const TnArgs& p, const int bid) {
         asm volatile("s_barrier" ::: "memory");                        // every wave is done with stage it - 1: its buffer takes stage it + NS - 1
         if (it + NS - 1 < nit) issue(it + NS - 1, (it + NS - 1) % NS);
         const char* ty = smem + stage * STAGE;
-        const char* tx = ty + TN_KM * TN_T * 2;
+        const char* tx = ty + TN_KM * YB;
         if (do_db) {
             // (inline asm for the same reason as the transposed reads: a plain LDS load here would drag a vmcnt(0) in)
             unsigned short hv[32];
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
                 const int m = bh * 32 + r;
-                const unsigned a = (unsigned)(size_t)(ty + m * 256 + (((bn >> 3) ^ swz<16>(m)) << 4) + (bn & 7) * 2);
+                const unsigned a = (unsigned)(size_t)(ty + m * YB + (((bn >> 3) ^ swz<YCH>(m)) << 4) + (bn & 7) * 2);
                 unsigned v;
                 asm volatile("ds_read_u16 %0, %1" : "=v"(v) : "v"(a) : "memory");
                 hv[r] = (unsigned short)v;
@@ -166,7 +171,7 @@ __device__ __forceinline__ void tn_tile(const TnArgs& p, const int bid) {
         s16x4 ylo[2][2], yhi[2][2], xlo[2][NJ], xhi[2][NJ];
         auto rd = [&](int buf, int s) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) tr_frag_issue<256>(ty, wn * 64 + i * 32, s, lane, ylo[buf][i], yhi[buf][i]);
+            for (int i = 0; i < 2; ++i) tr_frag_issue<YB>(ty, wn * 64 + i * 32, s, lane, ylo[buf][i], yhi[buf][i]);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) tr_frag_issue<XB>(tx, wk * (XW / 2) + j * 32, s, lane, xlo[buf][j], xhi[buf][j]);
         };
@@ -196,7 +201,7 @@ __device__ __forceinline__ void tn_tile(const TnArgs& p, const int bid) {
         float* red = reinterpret_cast<float*>(smem);
         red[tid] = bsum;
         __syncthreads();
-        if (tid < 128 && n0 + tid < p.n_store) __hip_atomic_fetch_add(p.db + n0 + tid, red[tid] + red[tid + 128], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < TNN && n0 + tid < p.n_store) __hip_atomic_fetch_add(p.db + n0 + tid, red[tid] + red[tid + TNN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // C layout: col (k) = lane & 31, row (n) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     const int lr = lane & 31, lh = lane >> 5;
@@ -219,17 +224,17 @@ __device__ __forceinline__ void tn_tile(const TnArgs& p, const int bid) {
 }
 
 template <int XW>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) { tn_tile<XW, 2>(p, blockIdx.x); }
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) { tn_tile<TN_T, XW, 2>(p, blockIdx.x); }
 
 // Grouped form: the weight-gradient GEMMs of one encoder layer (up to TN_GROUP problems: dY_i^T X_i -> dW_i) as ONE launch.  A layer's ten dW GEMMs together have
-// ~450 output tiles of 128 x 128 — enough to fill the chip WITHOUT splitting M: every block contracts over all rows of its problem and adds its tile into dW in place,
+// ~230 output tiles of 256 x 128 — enough to fill the chip WITHOUT splitting M: every block contracts over all rows of its problem and adds its tile into dW in place,
 // so there are no slabs and no reduce pass (launched one by one, each problem needs 8-32 M-splits to fill 512 blocks: 164 launches x (32 us GEMM + 9 us slab reduce)
 // per training step).  Block -> (problem, tile) by the prefix table of tile counts.
 constexpr int TN_GROUP = 16;
 struct TnGroup { TnArgs a[TN_GROUP]; int tile0[TN_GROUP + 1]; int n; };
 
-constexpr int TN_GROUP_NS = 2;
-__global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnGroup g) {
+constexpr int TN_GROUP_NS = 2, TN_GROUP_N = 256;           // 256 (n) x 128 (k) tiles, 8 waves, two 48-KiB stages: one block per CU, two waves per SIMD
+__global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g) {
     const int bid = blockIdx.x;
     int i = 0;
     while (i + 1 < g.n && bid >= g.tile0[i + 1]) ++i;
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnGroup g) {
     // each with a `s_waitcnt vmcnt(0)` in front of the LDS-DMA instruction that uses it (seen in the ISA: one full wait per staging instruction)
     const int iu = __builtin_amdgcn_readfirstlane(i);
     const TnArgs p = g.a[iu];
-    tn_tile<128, TN_GROUP_NS>(p, bid - __builtin_amdgcn_readfirstlane(g.tile0[iu]));
+    tn_tile<TN_GROUP_N, 128, TN_GROUP_NS>(p, bid - __builtin_amdgcn_readfirstlane(g.tile0[iu]));
 }
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ out, long ldo, const float* __restrict__ slabs, long slab_stride,
@@ -320,13 +325,13 @@ extern "C" int mi_gemm_tn_group_bf16(int n, const void* const* dY, const long* l
         p.rows_per_split = cdiv(M[i], TN_KM) * TN_KM;
         p.out = dW[i]; p.ldo = ldo[i]; p.slab_stride = 0;
         g.tile0[i] = tiles;
-        tiles += cdiv(N[i], TN_T) * cdiv(K[i], 128);
+        tiles += cdiv(N[i], TN_GROUP_N) * cdiv(K[i], 128);
     }
     g.tile0[n] = tiles;
-    const size_t lds = (size_t)TN_GROUP_NS * TN_KM * (TN_T * 2 + 256);                    // 4 x 32 KiB: one block per CU
+    const size_t lds = (size_t)TN_GROUP_NS * TN_KM * (TN_GROUP_N * 2 + 256);              // 2 x 48 KiB: one block per CU
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return MI_ERR_LAUNCH;
-    hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(tiles), dim3(256), lds, st, g);
+    hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(tiles), dim3(512), lds, st, g);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

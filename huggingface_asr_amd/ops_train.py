@@ -404,10 +404,10 @@ _TN_WS = {}
 
 class TnBatch:
     """Deferred weight-gradient GEMMs: `gemm_tn_(..., defer=batch)` / `linear_bwd(..., defer=batch)` only record (dW, dY, X, db) — the tensors stay referenced, so their
-    memory is not reused — and `flush()` runs them as ONE grouped launch (mi_gemm_tn_group_bf16): a layer's ten dW GEMMs have ~450 output tiles between them, enough
+    memory is not reused — and `flush()` runs them as ONE grouped launch (mi_gemm_tn_group_bf16): a layer's ten dW GEMMs have ~230 output tiles of 256 x 128 between them, enough
     to fill the chip without splitting M, hence no slabs and no reduce passes.  Below `MIN_TILES` output tiles in total (a mostly frozen layer) the problems run one by
     one on the split-M path.  Callers must not modify a recorded dY / X in place before the flush."""
-    MAX, MIN_TILES = 16, 192
+    MAX, MIN_TILES = 16, 128
 
     def __init__(self):
         self.items = []
@@ -421,7 +421,7 @@ class TnBatch:
         items, self.items = self.items, []
         if not items:
             return
-        tiles = sum(-(-dy.shape[1] // 128) * -(-x.shape[1] // 128) for _, dy, x, _, _ in items)
+        tiles = sum(-(-dy.shape[1] // 256) * -(-x.shape[1] // 128) for _, dy, x, _, _ in items)          # 256 (n) x 128 (k) output tiles, one block per CU
         if tiles < self.MIN_TILES:
             for dw, dy, x, n_store, db in items:
                 gemm_tn_(dw, dy, x, n_store=n_store, db=db)

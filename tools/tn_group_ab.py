@@ -39,6 +39,6 @@ def grouped(sel):
 print(f"all 9: one by one {timeit(lambda: one_by_one(probs)):.1f} us | grouped {timeit(lambda: grouped(probs)):.1f} us")
 for k in (0, 1, 3):
     N, K = shapes[k]
-    print(f"single {N}x{K}: split-M {timeit(lambda: one_by_one(probs[k:k+1])):.1f} us | grouped alone ({-(-N//128) * -(-K//128)} blocks) {timeit(lambda: grouped(probs[k:k+1])):.1f} us")
+    print(f"single {N}x{K}: split-M {timeit(lambda: one_by_one(probs[k:k+1])):.1f} us | grouped alone ({-(-N//256) * -(-K//128)} blocks) {timeit(lambda: grouped(probs[k:k+1])):.1f} us")
 sel = [probs[0], probs[4], probs[7]]
 print(f"three 2048x512: one by one {timeit(lambda: one_by_one(sel)):.1f} | grouped {timeit(lambda: grouped(sel)):.1f}")
