@@ -29,6 +29,11 @@ struct AttnArgs {
     int B, T, H; float scale; int causal;
     int Tk;                              // LDS-staged kernel: number of key/value rows per batch (0 = T); queries are T
     long kv_bstride;                     // elements between consecutive batches of k / v (0 = Tk * ld): KV caches
+    float* lse;                          // LDS-staged kernel: (B, H, T) log2-domain log-sum-exp of the scaled scores — written by the forward when non-null, read by the backward
+    // backward form (attn_lds_kernel<.., BW = true>): `out` is the forward's context (read), and
+    const bf16_t* dctx; long ldd;        // (B*T, .) gradient of the context
+    bf16_t* prob; bf16_t* ds; long ldsr; // (H, B, T, ldsr) probabilities and score gradients dS = P (dP - delta) scale; ldsr a multiple of 32, every column written
+    bf16_t* dbd; long ldbd; int pad;     // (H, B, T, ldbd): dBD[i][T-1-i+j + pad] = dS[i][j] (the inverse of the rel-shift), zero elsewhere; ldbd a multiple of 32
 };
 
 // 16-B chunk swizzle of the LDS-staged kernel's tiles (applied on the DMA source and on every read).  256-B rows (hd 128): the image that is conflict-free for ds_read_b128
@@ -201,7 +206,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 //    ONE new 32-row G tile (8 MFMAs at hd=128) is computed per step and the other is carried in registers.
 //  * LDS images are lane-linear per DMA piece; the 16-B-chunk XOR swizzle (tswz) is applied to the
 //    source address and to every read (conflict-free ds_read_b128 / tr reads).
-template <int HD, bool REL>
+//
+// BW = true is the first half of the training backward (round 3): the same walk over the keys recomputes S^T, takes P = 2^(S - lse) with the forward's row
+// log-sum-exp, adds dP^T = V_tile · dctx^T (V rows read like K rows) and leaves P, dS = P (dP - delta) scale and the un-shifted dBD in HBM as bf16 — in place of
+// three batched GEMMs with fp32 outputs (Q K^T, Q P^T, dctx V^T: 130 MB per layer) and the two softmax passes over them.  delta_i = dctx_i · ctx_i.
+constexpr int STG_B = 80;     // BW: bytes per query row of the P / dS staging tiles (32 keys = 64 B + 16)
+constexpr int BAND_B = 144;   // BW: bytes per query row of the dBD band buffer (two 32-column blocks = 128 B + 16)
+template <int HD, bool REL, bool BW>
 __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
     constexpr int KS = HD / 16, NTO = HD / 32;
     constexpr int ROWB = HD * 2, NCH = ROWB / 16;            // bytes per row, 16-B chunks per row
@@ -220,6 +231,7 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
     const int ib = blockIdx.x * 128, i0 = ib + wave * 32;
     char* wscr = reinterpret_cast<char*>(skew_all) + wave * WSCR_B;       // this wave's private scratch
     float* skew = reinterpret_cast<float*>(wscr);
+    char* band = reinterpret_cast<char*>(skew_all) + 4 * WSCR_B + wave * (32 * BAND_B);      // BW only (the launch sizes the LDS for it)
     const int T = p.T;                                        // queries per batch
     const int Tk = p.Tk > 0 ? p.Tk : p.T;                     // keys per batch (cross-attention / KV cache: Tk != T)
     const int coff = Tk - T;                                  // causal: query i sees keys <= i + coff
@@ -301,9 +313,51 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the fragments are in registers before the scratch is reused as the skew rows
 
-    f32x16 O[NTO];
+    bf16x8 dc[BW ? KS : 1];                                  // BW: dctx rows of this wave's queries as the B operand of dP^T = V · dctx^T
+    float delta = 0.f, lse2 = 0.f;
+    if constexpr (BW) {
+        auto stage_rows = [&](const bf16_t* base, long ld) {         // this wave's 32 rows of a (B*T, ld) operand -> scratch, as Q above
+            const char* qb = reinterpret_cast<const char*>(base + (long)b * T * ld);
+            const unsigned ldB = (unsigned)ld * 2u;
 #pragma unroll
-    for (int t = 0; t < NTO; ++t)
+            for (int piece = 0; piece < PIECES; ++piece) {
+                const int row = piece * RPP + prow;
+                const int colb = (head * HD + (pc ^ tswz<NCH>(row)) * 8) * 2;
+                const char* src = qb + (unsigned long)(unsigned)min(i0 + row, T - 1) * ldB + colb;
+                __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)src,
+                                                 (__attribute__((address_space(3))) void*)(wscr + piece * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        stage_rows(p.dctx, p.ldd);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) dc[ks] = *reinterpret_cast<const bf16x8*>(wscr + r * ROWB + (((ks * 2 + h2) ^ tswz<NCH>(r)) << 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stage_rows(p.out, p.ldo);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 cx = *reinterpret_cast<const bf16x8*>(wscr + r * ROWB + (((ks * 2 + h2) ^ tswz<NCH>(r)) << 4));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) delta = fmaf(bf2f(dc[ks][j]), bf2f(cx[j]), delta);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        delta = half_swap_sum(delta);
+        lse2 = p.lse[((long)b * p.H + head) * T + min(i0 + r, T - 1)];
+        // both blocks of the band buffer start out zero
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = q * 8 + (lane >> 3), ch = lane & 7;
+            *reinterpret_cast<bf16x8*>(band + row * BAND_B + ch * 16) = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    // BW: where this wave's rows live in the three outputs; the band's block `it` is columns [cb0 + 32 it, +32) of dBD
+    const long orow0 = ((long)head * p.B + b) * T + i0;
+    const int cb0 = T - 32 + p.pad - i0;                     // a multiple of 32 (the host chose pad so)
+    const int srow = lane >> 2, sch = lane & 3;              // staging read-back: 16 rows x four 16-B chunks per instruction
+
+    f32x16 O[BW ? 1 : NTO];
+#pragma unroll
+    for (int t = 0; t < (BW ? 1 : NTO); ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) O[t][e] = 0.f;
     float m = -1e30f, l = 0.f;                               // running maximum in the exp2 domain (scores * scale * log2 e)
@@ -348,12 +402,29 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
         Gc = gtile((0 - wave - 1 + PRING * 4) % PRING);
     }
     const float sc2 = p.scale * 1.4426950408889634f;
+    bf16x8 st_p[2], st_s[2], st_b[2];                         // BW: a step's output rows, held until the next step has issued its DMA
+    auto flush_rows = [&](int its) {                          // the stores of step `its`
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = q * 16 + srow;
+            const int cb = cb0 + 32 * its;
+            if (i0 + row < T) {
+                *reinterpret_cast<bf16x8*>(p.prob + (orow0 + row) * p.ldsr + 32 * its + sch * 8) = st_p[q];
+                *reinterpret_cast<bf16x8*>(p.ds + (orow0 + row) * p.ldsr + 32 * its + sch * 8) = st_s[q];
+                if (REL && cb >= 0 && cb < (int)p.ldbd) *reinterpret_cast<bf16x8*>(p.dbd + (orow0 + row) * p.ldbd + cb + sch * 8) = st_b[q];
+            }
+        }
+    };
 
     for (int it = 0; it < nkt; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
         if (it + 1 < nkt) issue_step(it + 1);
         pslot_dma = pslot_dma + 1 == PRING ? 0 : pslot_dma + 1;
+        if constexpr (BW) {
+            if (it > 0) flush_rows(it - 1);
+            asm volatile("" ::: "memory");
+        }
         const int j0 = 32 * it;
         // ---- S^T = K_tile · (Q+u)^T
         f32x16 S;
@@ -402,88 +473,168 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
                 mx = fmaxf(mx, S[e]);
             }
         }
-        mx = half_swap_max(mx);
-        // Lazy rescale: the running maximum is a reference point, not a value — any m with S - m bounded gives the same quotient O / l.  It moves (and O, l are rescaled:
-        // 64 accumulator registers) only when some query's maximum grew by more than 2^11; otherwise p = 2^(S - m) <= 2^11 with the stale m, exact in fp32 / bf16 range.
-        if (__builtin_amdgcn_ballot_w64(mx > m + 11.f) != 0) {
-            const float mnew = fmaxf(m, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-            l *= alpha;
-            m = mnew;
+        if constexpr (BW) {
+            // ---- P = 2^(S - lse) (dead keys: S = -inf -> 0); dP^T = V_tile · dctx^T; dS = P (dP - delta) scale
+            f32x16 D;
 #pragma unroll
-            for (int t = 0; t < NTO; ++t)
+            for (int e = 0; e < 16; ++e) D[e] = 0.f;
+            {
+                const char* vb = sV + (it & 1) * TILEB;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) O[t][e] *= alpha;
-        }
-        float ls = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            S[e] = __builtin_amdgcn_exp2f(S[e] - m);
-            ls += S[e];
-        }
-        l += half_swap_sum(ls);
-        bf16x8 pb[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pb[s2][j] = f2bf(S[8 * s2 + j]);
-        // ---- O^T += V^T · P^T ; V^T fragments by transposed LDS reads of the [key][hd] tile.
-        // The reads are issued as inline asm with their own lgkmcnt waits: through the builtin the compiler cannot tell them from the LDS-DMA destinations of step
-        // it + 1 (issued at the top of this step) and puts `s_waitcnt vmcnt(0)` in front of them — the prefetch then has to land within ~60 % of a step.
-        {
-            typedef short s16x4 __attribute__((ext_vector_type(4)));
-            typedef short s16x8 __attribute__((ext_vector_type(8)));
-            const unsigned vb = (unsigned)(size_t)(sV + (it & 1) * TILEB);          // LDS byte address (addrspace(3) pointers are 32-bit offsets)
-            s16x4 lo[NTO][2], hi[NTO][2];
-#pragma unroll
-            for (int t = 0; t < NTO; ++t)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[t][s2]) : "v"(vb + voff[t][0]), "n"(s2 * 16 * ROWB) : "memory");
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[t][s2]) : "v"(vb + voff[t][1]), "n"(s2 * 16 * ROWB) : "memory");
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + foff[ks]);
+                    D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dc[ks], D, 0, 0, 0);
                 }
+            }
 #pragma unroll
-            for (int t = 0; t < NTO; ++t) {
-                // tile t's four reads are the oldest outstanding: 4 * (NTO - 1 - t) younger ones may still be in flight
-                if (t == NTO - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                else if (t == NTO - 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                else if (t == NTO - 3) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+            for (int e = 0; e < 16; ++e) {
+                S[e] = __builtin_amdgcn_exp2f(S[e] - lse2);
+                D[e] = S[e] * (D[e] - delta) * p.scale;
+            }
+            // ---- stage the two 32 x 32 tiles as [query][key] rows in the (now idle) skew scratch, and drop dS into the band buffer at column key - query + 31
+            // of block (it & 1): the lower block is complete after this step (its other half came from step it - 1), the upper one is finished by step it + 1.
+            char* stP = wscr;
+            char* stS = wscr + 32 * STG_B;
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    // the asm outputs are only valid after the wait above: keep the compiler from reading them earlier
-                    asm volatile("" : "+v"(lo[t][s2]), "+v"(hi[t][s2]));
-                    const s16x8 v8 = {lo[t][s2][0], lo[t][s2][1], lo[t][s2][2], lo[t][s2][3], hi[t][s2][0], hi[t][s2][1], hi[t][s2][2], hi[t][s2][3]};
-                    O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pb[s2], O[t], 0, 0, 0);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const bf16x4 pv = {f2bf(S[4 * g4 + 0]), f2bf(S[4 * g4 + 1]), f2bf(S[4 * g4 + 2]), f2bf(S[4 * g4 + 3])};
+                const bf16x4 dv = {f2bf(D[4 * g4 + 0]), f2bf(D[4 * g4 + 1]), f2bf(D[4 * g4 + 2]), f2bf(D[4 * g4 + 3])};
+                *reinterpret_cast<bf16x4*>(stP + r * STG_B + (8 * g4 + 4 * h2) * 2) = pv;
+                *reinterpret_cast<bf16x4*>(stS + r * STG_B + (8 * g4 + 4 * h2) * 2) = dv;
+#pragma unroll
+                for (int j = 0; REL && j < 4; ++j) {
+                    const int bc = (8 * g4 + 4 * h2 + j - r + 31 + 32 * (it & 1)) & 63;
+                    *reinterpret_cast<bf16_t*>(band + r * BAND_B + bc * 2) = dv[j];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            // back out of the staging as whole 64-B row segments, into registers: the global stores are issued at the top of the NEXT step, behind its DMA —
+            // stores count in vmcnt like loads, and issued here they would be waited for by the very next instruction (the step's vmcnt(0)).
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int row = q * 16 + srow;
+                st_p[q] = *reinterpret_cast<const bf16x8*>(stP + row * STG_B + sch * 16);
+                st_s[q] = *reinterpret_cast<const bf16x8*>(stS + row * STG_B + sch * 16);
+                char* bp = band + row * BAND_B + (it & 1) * 64 + sch * 16;
+                st_b[q] = *reinterpret_cast<const bf16x8*>(bp);
+                *reinterpret_cast<bf16x8*>(bp) = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};        // same lane, same address: this block is the upper one of step it + 1
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            mx = half_swap_max(mx);
+            // Lazy rescale: the running maximum is a reference point, not a value — any m with S - m bounded gives the same quotient O / l.  It moves (and O, l are rescaled:
+            // 64 accumulator registers) only when some query's maximum grew by more than 2^11; otherwise p = 2^(S - m) <= 2^11 with the stale m, exact in fp32 / bf16 range.
+            if (__builtin_amdgcn_ballot_w64(mx > m + 11.f) != 0) {
+                const float mnew = fmaxf(m, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+                l *= alpha;
+                m = mnew;
+#pragma unroll
+                for (int t = 0; t < NTO; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) O[t][e] *= alpha;
+            }
+            float ls = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                S[e] = __builtin_amdgcn_exp2f(S[e] - m);
+                ls += S[e];
+            }
+            l += half_swap_sum(ls);
+            bf16x8 pb[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[s2][j] = f2bf(S[8 * s2 + j]);
+            // ---- O^T += V^T · P^T ; V^T fragments by transposed LDS reads of the [key][hd] tile.
+            // The reads are issued as inline asm with their own lgkmcnt waits: through the builtin the compiler cannot tell them from the LDS-DMA destinations of step
+            // it + 1 (issued at the top of this step) and puts `s_waitcnt vmcnt(0)` in front of them — the prefetch then has to land within ~60 % of a step.
+            {
+                typedef short s16x4 __attribute__((ext_vector_type(4)));
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                const unsigned vb = (unsigned)(size_t)(sV + (it & 1) * TILEB);          // LDS byte address (addrspace(3) pointers are 32-bit offsets)
+                s16x4 lo[NTO][2], hi[NTO][2];
+#pragma unroll
+                for (int t = 0; t < NTO; ++t)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[t][s2]) : "v"(vb + voff[t][0]), "n"(s2 * 16 * ROWB) : "memory");
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[t][s2]) : "v"(vb + voff[t][1]), "n"(s2 * 16 * ROWB) : "memory");
+                    }
+#pragma unroll
+                for (int t = 0; t < NTO; ++t) {
+                    // tile t's four reads are the oldest outstanding: 4 * (NTO - 1 - t) younger ones may still be in flight
+                    if (t == NTO - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    else if (t == NTO - 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                    else if (t == NTO - 3) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        // the asm outputs are only valid after the wait above: keep the compiler from reading them earlier
+                        asm volatile("" : "+v"(lo[t][s2]), "+v"(hi[t][s2]));
+                        const s16x8 v8 = {lo[t][s2][0], lo[t][s2][1], lo[t][s2][2], lo[t][s2][3], hi[t][s2][0], hi[t][s2][1], hi[t][s2][2], hi[t][s2][3]};
+                        O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pb[s2], O[t], 0, 0, 0);
+                    }
                 }
             }
         }
     }
 
-    // ---- epilogue: a lane owns a query ROW of O (hd values spread over its accumulators); row-per-lane global stores touch 64 lines per instruction and are
-    // store-issue-bound.  Rows go through the wave's scratch instead and leave as whole 16-B-per-lane rows (64 lanes = 1 KiB = 4 or 8 complete rows per store).
-    {
-        const float inv = 1.f / l;
+    if constexpr (BW) {
+        // ---- the band's last block (upper half of the last step), then zeros over every column block of this wave's rows that no step wrote:
+        // keys past the length / the causal edge in P and dS, relative positions outside this wave's band in dBD.
+        const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+        if (nkt > 0) flush_rows(nkt - 1);
+        const int nbd = (int)p.ldbd >> 5, nbs = (int)p.ldsr >> 5;
+        const int blo = cb0 >> 5, bhi = nkt > 0 ? blo + nkt : blo - 1;          // band blocks [blo, bhi] were (or, for bhi, are now) written from the buffer
 #pragma unroll
-        for (int t = 0; t < NTO; ++t)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int c = t * 32 + 8 * g4 + 4 * h2;
-                const bf16x4 o = {f2bf(O[t][4 * g4 + 0] * inv), f2bf(O[t][4 * g4 + 1] * inv), f2bf(O[t][4 * g4 + 2] * inv), f2bf(O[t][4 * g4 + 3] * inv)};
-                *reinterpret_cast<bf16x4*>(wscr + r * OST_B + c * 2) = o;
+        for (int q = 0; q < 2; ++q) {
+            const int row = q * 16 + srow;
+            if (i0 + row >= T) continue;
+            if (REL && nkt > 0) {
+                const int cb = cb0 + 32 * nkt;
+                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(band + row * BAND_B + (nkt & 1) * 64 + sch * 16);
+                if (cb >= 0 && cb < (int)p.ldbd) *reinterpret_cast<bf16x8*>(p.dbd + (orow0 + row) * p.ldbd + cb + sch * 8) = bv;
             }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        constexpr int LPR = ROWB / 16, RPI = 64 / LPR;       // lanes per row, rows per store instruction
-        const int orow = lane / LPR, och = lane % LPR;
+            for (int blk = 0; REL && blk < nbd; ++blk)
+                if (blk < blo || blk > bhi) *reinterpret_cast<bf16x8*>(p.dbd + (orow0 + row) * p.ldbd + blk * 32 + sch * 8) = z8;
+            for (int blk = nkt; blk < nbs; ++blk) {
+                *reinterpret_cast<bf16x8*>(p.prob + (orow0 + row) * p.ldsr + blk * 32 + sch * 8) = z8;
+                *reinterpret_cast<bf16x8*>(p.ds + (orow0 + row) * p.ldsr + blk * 32 + sch * 8) = z8;
+            }
+        }
+    } else {
+        // ---- epilogue: a lane owns a query ROW of O (hd values spread over its accumulators); row-per-lane global stores touch 64 lines per instruction and are
+        // store-issue-bound.  Rows go through the wave's scratch instead and leave as whole 16-B-per-lane rows (64 lanes = 1 KiB = 4 or 8 complete rows per store).
+        {
+            const float inv = 1.f / l;
+            if (p.lse && h2 == 0 && i0 + r < T) p.lse[((long)b * p.H + head) * T + i0 + r] = m + __builtin_amdgcn_logf(l);      // log2 domain (v_log_f32)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int q = 0; q < 32 / RPI; ++q) {
-            const int row = q * RPI + orow;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(wscr + row * OST_B + och * 16);
-            if (i0 + row < T) *reinterpret_cast<bf16x8*>(p.out + ((long)b * T + i0 + row) * p.ldo + head * HD + och * 8) = v;
+            for (int t = 0; t < NTO; ++t)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int c = t * 32 + 8 * g4 + 4 * h2;
+                    const bf16x4 o = {f2bf(O[t][4 * g4 + 0] * inv), f2bf(O[t][4 * g4 + 1] * inv), f2bf(O[t][4 * g4 + 2] * inv), f2bf(O[t][4 * g4 + 3] * inv)};
+                    *reinterpret_cast<bf16x4*>(wscr + r * OST_B + c * 2) = o;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            constexpr int LPR = ROWB / 16, RPI = 64 / LPR;       // lanes per row, rows per store instruction
+            const int orow = lane / LPR, och = lane % LPR;
+#pragma unroll
+            for (int q = 0; q < 32 / RPI; ++q) {
+                const int row = q * RPI + orow;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(wscr + row * OST_B + och * 16);
+                if (i0 + row < T) *reinterpret_cast<bf16x8*>(p.out + ((long)b * T + i0 + row) * p.ldo + head * HD + och * 8) = v;
+            }
         }
     }
 }
@@ -492,8 +643,24 @@ template <int HD>
 int launch_lds(const AttnArgs& a, bool rel, hipStream_t stream) {
     dim3 grid(cdiv(a.T, 128), a.H, a.B), block(256);
     const size_t lds = (size_t)(2 + 2 + 6) * 32 * HD * 2 + 4 * WSCR_B;
-    if (rel) hipLaunchKernelGGL((attn_lds_kernel<HD, true>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((attn_lds_kernel<HD, false>), grid, block, lds, stream, a);
+    if (rel) hipLaunchKernelGGL((attn_lds_kernel<HD, true, false>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((attn_lds_kernel<HD, false, false>), grid, block, lds, stream, a);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+template <int HD>
+int launch_lds_bw(const AttnArgs& a, bool rel, hipStream_t stream) {
+    dim3 grid(cdiv(a.T, 128), a.H, a.B), block(256);
+    const size_t lds = (size_t)(2 + 2 + 6) * 32 * HD * 2 + 4 * WSCR_B + 4 * 32 * BAND_B;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_lds_kernel<HD, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_lds_kernel<HD, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    if (rel) hipLaunchKernelGGL((attn_lds_kernel<HD, true, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((attn_lds_kernel<HD, false, true>), grid, block, lds, stream, a);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
@@ -551,6 +718,55 @@ extern "C" int mi_attention_qkv_bf16(const void* q, long ldq, const void* k, lon
     switch (hd) {
         case 64: return launch_lds<64>(a, rel, stream);
         case 128: return launch_lds<128>(a, rel, stream);
+        default: return MI_ERR_UNSUPPORTED;
+    }
+}
+
+// The same kernel, also leaving the rows' log-sum-exp (log2 domain, of the scaled scores) in lse (B, H, T) fp32 for mi_attention_qkv_bwd_probs.
+extern "C" int mi_attention_qkv_lse_bf16(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                         const void* pos, long ldp, const float* bias_u, const float* bias_v,
+                                         const int* lengths, void* out, long ldo, float* lse, int B, int T, int H, int hd,
+                                         float scale, int causal, hipStream_t stream) {
+    MI_ENTER();
+    if (B <= 0 || T <= 0 || H <= 0 || !lse) return MI_ERR_ARG;
+    if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 8) || ((uintptr_t)out & 15)) return MI_ERR_ARG;
+    if (ldq >= (1l << 30) || ldk <= 0 || ldv <= 0 || ldk >= (1l << 30) || ldv >= (1l << 30) || ldp >= (1l << 30)) return MI_ERR_ARG;
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15)) return MI_ERR_ARG;
+    if (pos && ((ldp % 8) || ((uintptr_t)pos & 15) || !bias_u || !bias_v)) return MI_ERR_ARG;
+    AttnArgs a{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, 0, (const bf16_t*)pos, ldp,
+               bias_u, bias_v, lengths, (bf16_t*)out, ldo, B, T, H, scale, causal, 0, 0, lse};
+    switch (hd) {
+        case 64: return launch_lds<64>(a, pos != nullptr, stream);
+        case 128: return launch_lds<128>(a, pos != nullptr, stream);
+        default: return MI_ERR_UNSUPPORTED;
+    }
+}
+
+// First half of the attention backward (self-attention, fused QKV operand; hd in {64, 128}): from q, k, v, the projected positions, the forward's context and row
+// log-sum-exp, and dctx -> prob, ds (H, B, T, ldsr) bf16 and dbd (H, B, T, ldbd) bf16 with dbd[i][T-1-i+j + pad] = ds[i][j].  ldsr, ldbd multiples of 32,
+// ldsr >= T rounded up to 32, ldbd >= pad + 2T - 1, (T - 32 + pad) % 32 == 0: a wave's band of relative positions then starts on a 64-B boundary of its rows.
+// Every element of the three outputs is written (zeros where no key / relative position contributes).
+extern "C" int mi_attention_qkv_bwd_probs(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                          const void* pos, long ldp, const float* bias_u, const float* bias_v, const int* lengths,
+                                          const void* ctx, long ldo, const void* dctx, long ldd, const float* lse,
+                                          void* prob, void* ds, long ldsr, void* dbd, long ldbd, int pad,
+                                          int B, int T, int H, int hd, float scale, int causal, hipStream_t stream) {
+    MI_ENTER();
+    if (B <= 0 || T <= 0 || H <= 0 || !lse || !ctx || !dctx || !prob || !ds) return MI_ERR_ARG;
+    if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 8) || (ldd % 8)) return MI_ERR_ARG;
+    if (ldq >= (1l << 30) || ldk <= 0 || ldv <= 0 || ldk >= (1l << 30) || ldv >= (1l << 30) || ldp >= (1l << 30) || ldo >= (1l << 30) || ldd >= (1l << 30)) return MI_ERR_ARG;
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)ctx | (uintptr_t)dctx | (uintptr_t)prob | (uintptr_t)ds | (uintptr_t)dbd) & 15)) return MI_ERR_ARG;
+    if ((ldsr % 32) || ldsr < (T + 31) / 32 * 32) return MI_ERR_ARG;
+    if (pos) {
+        if ((ldp % 8) || ((uintptr_t)pos & 15) || !bias_u || !bias_v || !dbd) return MI_ERR_ARG;
+        if ((ldbd % 32) || pad < 0 || pad >= 32 || ((T - 32 + pad) % 32) || ldbd < pad + 2 * T - 1 || ldbd >= (1l << 30)) return MI_ERR_ARG;
+    }
+    AttnArgs a{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, 0, (const bf16_t*)pos, ldp,
+               bias_u, bias_v, lengths, (bf16_t*)const_cast<void*>(ctx), ldo, B, T, H, scale, causal, 0, 0, const_cast<float*>(lse),
+               (const bf16_t*)dctx, ldd, (bf16_t*)prob, (bf16_t*)ds, ldsr, (bf16_t*)dbd, pos ? ldbd : 0, pos ? pad : 0};
+    switch (hd) {
+        case 64: return launch_lds_bw<64>(a, pos != nullptr, stream);
+        case 128: return launch_lds_bw<128>(a, pos != nullptr, stream);
         default: return MI_ERR_UNSUPPORTED;
     }
 }

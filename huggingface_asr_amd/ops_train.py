@@ -196,6 +196,32 @@ def bgemm(A, a_str, B, b_str, C, c_str, Z1, Z2, M, N, K, *, alpha=1.0, accumulat
     return C
 
 
+def band_geometry(T: int):
+    """(pad, ldbd) of `attn_bwd_probs`' dbd: columns are relative positions shifted by pad so that every 32-query wave's band starts on a 32-column boundary."""
+    pad = (32 - T) % 32
+    return pad, (pad + 2 * T - 1 + 31) // 32 * 32
+
+
+def attn_bwd_probs(qkv, B, T, H, ctx, dctx, lse, *, pos=None, bias_u=None, bias_v=None, lengths=None, causal=False):
+    """First half of the fused attention backward (head size 64 / 128, no probability dropout): -> prob, ds (H, B, T, Ts) bf16 and, with relative positions,
+    dbd (H, B, T, Ps) bf16 with dbd[i][T-1-i+j + pad] = ds[i][j] (else None).  Ts = T rounded up to 32; (pad, Ps) = band_geometry(T).  Everything is written."""
+    d = qkv.shape[1] // 3
+    hd = d // H
+    Ts = (T + 31) // 32 * 32
+    pad, Ps = band_geometry(T)
+    dev = qkv.device
+    prob = torch.empty((H, B, T, Ts), device=dev, dtype=BF16)
+    ds = torch.empty((H, B, T, Ts), device=dev, dtype=BF16)
+    dbd = torch.empty((H, B, T, Ps), device=dev, dtype=BF16) if pos is not None else None
+    q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    _lib.check(_L().mi_attention_qkv_bwd_probs(q.data_ptr(), qkv.stride(0), k.data_ptr(), qkv.stride(0), v.data_ptr(), qkv.stride(0),
+                                               _p(pos), pos.stride(0) if pos is not None else 0, _p(bias_u), _p(bias_v), _p(lengths),
+                                               ctx.data_ptr(), ctx.stride(0), dctx.data_ptr(), dctx.stride(0), lse.data_ptr(),
+                                               prob.data_ptr(), ds.data_ptr(), Ts, _p(dbd), Ps, pad, B, T, H, hd, 1.0 / math.sqrt(hd), int(causal), _stream()),
+               "mi_attention_qkv_bwd_probs")
+    return prob, ds, dbd
+
+
 def pad8(n: int) -> int:
     return (n + 7) // 8 * 8
 

@@ -976,7 +976,9 @@ class EncoderCTCTrainer:
         d = qkv.shape[1] // 3
         hd = d // H
         if hd in (64, 128) and drop is None:
-            return ops.attention_qkv(qkv, B, Tt, H, pos=posp, bias_u=u, bias_v=v, lengths=lengths, causal=self.causal)
+            # the fused kernel; it leaves the rows' log-sum-exp for the backward's recomputation (ops_train.attn_bwd_probs)
+            S["lse"] = torch.empty((B, H, Tt), device=qkv.device, dtype=F32)
+            return ops.attention_qkv(qkv, B, Tt, H, pos=posp, bias_u=u, bias_v=v, lengths=lengths, causal=self.causal, lse=S["lse"])
         # probability dropout (e_branchformer.py:132) or small heads (test configs): probabilities through the generic pieces,
         # kept for the backward pass; the dropped copy feeds the PV product
         prob = self._probs(qkv, posp, u, v, lengths, B, Tt, H, S, drop)
@@ -1022,19 +1024,32 @@ class EncoderCTCTrainer:
         dev = qkv.device
         scale = 1.0 / math.sqrt(hd)
         rel = posp is not None
-        prob = S.get("prob")                           # what multiplied V in the forward (dropped copy under dropout)
-        if prob is None:
-            prob = self._probs(qkv, posp, P(p + "att_u") if rel else None, P(p + "att_v") if rel else None, lengths, B, Tt, H, S)
-        prob_pre = S.get("prob_pre", prob)             # un-dropped probabilities: the softmax Jacobian
-        qu, qv = S["qu"], S["qv"]
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        dqkv = torch.empty((M, 3 * d), device=dev, dtype=BF16)
+        Pn = 2 * Tt - 1
+        if "lse" in S and drop is None:
+            # fused forward: ONE walk over the keys recomputes the scores and leaves P, dS and the un-shifted dBD (bf16) — no fp32 score-sized tensors
+            prob, ds, dbd = T.attn_bwd_probs(qkv, B, Tt, H, S["ctx"], dctx, S["lse"], pos=posp, bias_u=P(p + "att_u") if rel else None,
+                                             bias_v=P(p + "att_v") if rel else None, lengths=lengths, causal=self.causal)
+            if rel:
+                qu, qv = T.add_rowvec(q, P(p + "att_u")), T.add_rowvec(q, P(p + "att_v"))
+                off, Kp = T.band_geometry(Tt)                 # dbd's columns are relative positions + off: the position rows move with them
+                posk = torch.zeros((Kp, d), device=dev, dtype=BF16)
+                posk[off:off + Pn] = posp
+        else:
+            prob = S.get("prob")                           # what multiplied V in the forward (dropped copy under dropout)
+            if prob is None:
+                prob = self._probs(qkv, posp, P(p + "att_u") if rel else None, P(p + "att_v") if rel else None, lengths, B, Tt, H, S)
+            prob_pre = S.get("prob_pre", prob)             # un-dropped probabilities: the softmax Jacobian
+            qu, qv = S["qu"], S["qv"]
+            # dP = dctx · V^T
+            Ts0 = prob.shape[-1]
+            dp = torch.empty((H, B, Tt, Ts0), device=dev, dtype=F32)
+            T.bgemm(dctx, (hd, Tt * d, d, 1), v, (hd, Tt * 3 * d, 3 * d, 1), dp, (B * Tt * Ts0, Tt * Ts0, Ts0), H, B, Tt, Tt, hd)
+            ds, dbd = T.attn_softmax_bwd(prob_pre, dp, H, B, Tt, Tt, scale, want_dbd=rel, drop=drop)
+            off, Kp, posk = 0, Pn, posp
         Ts = prob.shape[-1]
         sTT = (B * Tt * Ts, Tt * Ts)
-        dqkv = torch.empty((M, 3 * d), device=dev, dtype=BF16)
-        # dP = dctx · V^T
-        dp = torch.empty((H, B, Tt, Ts), device=dev, dtype=F32)
-        T.bgemm(dctx, (hd, Tt * d, d, 1), v, (hd, Tt * 3 * d, 3 * d, 1), dp, (*sTT, Ts), H, B, Tt, Tt, hd)
-        ds, dbd = T.attn_softmax_bwd(prob_pre, dp, H, B, Tt, Tt, scale, want_dbd=rel, drop=drop)
         # dV = P^T · dctx
         T.bgemm(prob, (*sTT, 1, Ts), dctx, (hd, Tt * d, 1, d), dqkv[:, 2 * d:], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt)
         # dK = dS^T · (q + u)
@@ -1044,23 +1059,22 @@ class EncoderCTCTrainer:
             # dQ = dS · K
             T.bgemm(ds, (*sTT, Ts, 1), k, (hd, Tt * 3 * d, 1, 3 * d), dqkv[:, :d], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt)
             return dqkv
-        Pn = 2 * Tt - 1
         Ps = dbd.shape[-1]
         dqu = torch.empty((M, d), device=dev, dtype=F32)
         dqv = torch.empty((M, d), device=dev, dtype=F32)
         T.bgemm(ds, (*sTT, Ts, 1), k, (hd, Tt * 3 * d, 1, 3 * d), dqu, (hd, Tt * d, d), H, B, Tt, hd, Tt)
-        T.bgemm(dbd, (B * Tt * Ps, Tt * Ps, Ps, 1), posp, (hd, 0, 1, d), dqv, (hd, Tt * d, d), H, B, Tt, hd, Pn)
+        T.bgemm(dbd, (B * Tt * Ps, Tt * Ps, Ps, 1), posk, (hd, 0, 1, d), dqv, (hd, Tt * d, d), H, B, Tt, hd, Kp)
         # d(posp) (P, d) = sum_b dBD^T · (q + v): K runs over the (b, t) rows of one head
         # per-utterance partials (B, P, d), then a column sum over B: one long-K product per head would occupy 64 blocks only
-        dpp = torch.empty((B, Pn * d), device=dev, dtype=F32)
-        T.bgemm(dbd, (B * Tt * Ps, Tt * Ps, 1, Ps), qv, (hd, Tt * d, 1, d), dpp, (hd, Pn * d, d), H, B, Pn, hd, Tt)
-        dposp = torch.zeros((Pn, d), device=dev, dtype=F32)
+        dpp = torch.empty((B, Kp * d), device=dev, dtype=F32)
+        T.bgemm(dbd, (B * Tt * Ps, Tt * Ps, 1, Ps), qv, (hd, Tt * d, 1, d), dpp, (hd, Kp * d, d), H, B, Kp, hd, Tt)
+        dposp = torch.zeros((Kp, d), device=dev, dtype=F32)
         T.colsum_(dposp.view(-1), dpp)
         T.add_cast(dqu, dqv, out=dqkv[:, :d])
         T.colsum_(G(p + "att_u"), dqu)
         T.colsum_(G(p + "att_v"), dqv)
         # linear_pos: posp = table · Wpos^T  ->  dWpos += dposp^T · table
-        dpb = T.add_cast(dposp)
+        dpb = T.add_cast(dposp[off:off + Pn])
         T.gemm_tn_(G(p + "att_wpos"), dpb, pos[0], defer=self._tnb)
         return dqkv
 

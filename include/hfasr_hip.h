@@ -133,6 +133,22 @@ int mi_attention_qkv_bf16(const void* q, long ldq, const void* k, long ldk, cons
 /* (kv_bstride = elements between batches of k/v, 0 = Tk*ld (KV caches are (B, Lmax, d)); T = queries per batch, Tk = keys per batch, 0 = T: cross-attention over encoder frames and KV-cache decoding use Tk != T;
  *  with causal != 0 query i sees keys <= i + (Tk - T).) */
 
+/* Training form of the above (self-attention only, Tk = T): also leaves each row's log-sum-exp of the scaled scores (log2 domain) in lse (B, H, T) fp32,
+ * which mi_attention_qkv_bwd_probs needs.  replaces: the forward half of Wav2Vec2EBranchformerSelfAttention under autograd, e_branchformer.py:105-138. */
+int mi_attention_qkv_lse_bf16(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                              const void* pos, long ldp, const float* bias_u, const float* bias_v,
+                              const int* lengths, void* out, long ldo, float* lse, int B, int T, int H, int hd,
+                              float scale, int causal, mi_stream_t stream);
+/* First half of the attention backward (what autograd derives from e_branchformer.py:105-138 and the rel-shift of tf wav2vec2_conformer :528-565): one walk over
+ * the keys recomputes the scores, P = 2^(S - lse), dP = dctx V^T, dS = P (dP - dctx·ctx) scale, and leaves bf16
+ *   prob, ds (H, B, T, ldsr)   and   dbd (H, B, T, ldbd), dbd[i][T-1-i+j + pad] = ds[i][j]  (the gradient of the un-shifted position scores; null without pos).
+ * ldsr, ldbd multiples of 32 with ldsr >= T rounded up to 32 and ldbd >= pad + 2T - 1; 0 <= pad < 32 with (T - 32 + pad) % 32 == 0.  Every element is written. */
+int mi_attention_qkv_bwd_probs(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                               const void* pos, long ldp, const float* bias_u, const float* bias_v, const int* lengths,
+                               const void* ctx, long ldo, const void* dctx, long ldd, const float* lse,
+                               void* prob, void* ds, long ldsr, void* dbd, long ldbd, int pad,
+                               int B, int T, int H, int hd, float scale, int causal, mi_stream_t stream);
+
 /* ---- cgMLP gate: per-row LN statistics + fused LN -> depthwise conv(time) -> gate.
  * replaces: ConvolutionalSpatialGatingUnit.forward e_branchformer.py:184-204. */
 int mi_row_stats_bf16(const void* x, long ldx, int d, float eps, float* stats, int M, mi_stream_t stream);

@@ -198,6 +198,70 @@ def test_attn_softmax_fwd_bwd(rel, causal, masked, Tq):
         close(dbd, bd.grad, floor=2e-2, what="dbd vs autograd")
 
 
+@pytest.mark.parametrize("T_,H,hd,rel,causal", [(250, 4, 128, True, False), (97, 2, 64, True, False), (75, 2, 64, False, False), (130, 2, 128, False, True),
+                                                (33, 1, 128, True, False), (160, 2, 64, True, True), (500, 2, 128, True, False)])
+def test_attention_backward_recomputation(T_, H, hd, rel, causal):
+    """mi_attention_qkv_bwd_probs (P, dS and the un-shifted dBD from one walk over the keys, given the fused forward's context and log-sum-exp) against
+    autograd of the oracle-style attention: scores (q+u)k^T + rel_shift((q+v)p^T), key-padding / causal mask, softmax, P V."""
+    ops, T = _o()
+    B, d, Tq = 3, H * hd, T_
+    q, k, v = (bfr(rnd(B * Tq, d, seed=250 + i, scale=0.8)) for i in range(3))
+    lengths = torch.tensor([Tq, max(1, Tq - 13), max(1, Tq // 2)], dtype=torch.int32)
+    pos = bfr(rnd(2 * Tq - 1, d, seed=255, scale=0.8)) if rel else None
+    u, vb = (0.2 * rnd(H, hd, seed=256), 0.2 * rnd(H, hd, seed=257)) if rel else (None, None)
+    dctx = bfr(rnd(B * Tq, d, seed=258))
+    scale = 1.0 / math.sqrt(hd)
+    qh = q.view(B, Tq, H, hd).permute(2, 0, 1, 3)             # (H, B, T, hd)
+    kh, vh = (t.view(B, Tq, H, hd).permute(2, 0, 1, 3) for t in (k, v))
+    if rel:
+        qu, qv = bfr(qh + u[:, None, None]), bfr(qh + vb[:, None, None])
+        ph = pos.view(2 * Tq - 1, H, hd).permute(1, 0, 2)     # (H, P, hd)
+        ac = (qu @ kh.transpose(-1, -2)).requires_grad_(True)
+        bd = torch.einsum("hbtc,hpc->hbtp", qv, ph).requires_grad_(True)
+        idx = (Tq - 1) - torch.arange(Tq)[:, None] + torch.arange(Tq)[None, :]
+        s = ac + torch.gather(bd, 3, idx[None, None].expand(H, B, Tq, Tq))
+    else:
+        ac = (qh @ kh.transpose(-1, -2)).requires_grad_(True)
+        s = ac
+    s = s * scale
+    dead = (torch.arange(Tq)[None, :] >= lengths[:, None])[None, :, None, :].expand(H, B, Tq, Tq)
+    if causal:
+        dead = dead | torch.ones(Tq, Tq, dtype=torch.bool).triu(1)[None, None]
+    prob = torch.softmax(s.masked_fill(dead, float("-inf")), -1)
+    ctx = prob @ vh
+    ctx.backward(dctx.view(B, Tq, H, hd).permute(2, 0, 1, 3))
+    ds_want = ac.grad / 1.0                                    # d loss / d(score before the scale) = P (dP - delta) scale
+    qkv = torch.cat([q, k, v], 1).to(DEV, BF)
+    kw = dict(pos=None if pos is None else dev16(pos), bias_u=None if u is None else u.to(DEV), bias_v=None if vb is None else vb.to(DEV),
+              lengths=lengths.to(DEV), causal=causal)
+    lse = torch.empty((B, H, Tq), device=DEV, dtype=torch.float32)
+    ctx_k = ops.attention_qkv(qkv, B, Tq, H, lse=lse, **kw)
+    close(ctx_k.view(B, Tq, H, hd).permute(2, 0, 1, 3), ctx.detach(), floor=1e-2, what="context (lse form)")
+    lse_want = torch.logsumexp(s.detach().masked_fill(dead, float("-inf")), -1).permute(1, 0, 2) / math.log(2.0)
+    assert (lse.cpu() - lse_want).abs().max() < 2e-2, "log-sum-exp (log2 domain)"
+    # poisoned outputs: every element must be written
+    Ts = (Tq + 31) // 32 * 32
+    pad, Ps = T.band_geometry(Tq)
+    assert (Tq - 32 + pad) % 32 == 0 and Ps % 32 == 0 and Ps >= pad + 2 * Tq - 1
+    pk, dsk, dbdk = T.attn_bwd_probs(qkv, B, Tq, H, ctx_k, dev16(dctx), lse, **kw)
+    assert pk.shape == (H, B, Tq, Ts) and (dbdk is None) == (not rel)
+    close(pk[..., :Tq], prob.detach(), floor=4e-3, what="P")
+    close(dsk[..., :Tq], ds_want, floor=2e-2, what="dS")
+    assert float(pk[..., Tq:].float().abs().max() if Ts > Tq else 0.0) == 0.0 and float(dsk[..., Tq:].float().abs().max() if Ts > Tq else 0.0) == 0.0
+    assert not bool(pk.float().isnan().any()) and not bool(dsk.float().isnan().any())
+    if rel:
+        assert dbdk.shape == (H, B, Tq, Ps)
+        close(dbdk[..., pad:pad + 2 * Tq - 1], bd.grad, floor=2e-2, what="dBD")
+        outside = torch.cat([dbdk[..., :pad], dbdk[..., pad + 2 * Tq - 1:]], -1).float()
+        assert float(outside.abs().max()) == 0.0, "columns outside the relative positions must be zero"
+        # the un-shift is exact: dBD[i][T-1-i+j + pad] is the very bf16 value of dS[i][j]
+        idx = ((Tq - 1) - torch.arange(Tq)[:, None] + torch.arange(Tq)[None, :] + pad).to(DEV)
+        assert torch.equal(torch.gather(dbdk, 3, idx[None, None].expand(H, B, Tq, Tq)), dsk[..., :Tq])
+    # second call on poisoned buffers gives the same bits (nothing depends on what the outputs held)
+    pk2, dsk2, dbdk2 = T.attn_bwd_probs(qkv, B, Tq, H, ctx_k, dev16(dctx), lse, **kw)
+    assert torch.equal(pk, pk2) and torch.equal(dsk, dsk2) and (not rel or torch.equal(dbdk, dbdk2))
+
+
 def test_csgu_and_merge_dwconv_bwd():
     ops, T = _o()
     B, Tt, Cc, K = 3, 150, 128, 31
