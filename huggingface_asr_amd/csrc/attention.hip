@@ -34,6 +34,8 @@ struct AttnArgs {
     const bf16_t* dctx; long ldd;        // (B*T, .) gradient of the context
     bf16_t* prob; bf16_t* ds; long ldsr; // (H, B, T, ldsr) probabilities and score gradients dS = P (dP - delta) scale; ldsr a multiple of 32, every column written
     bf16_t* dbd; long ldbd; int pad;     // (H, B, T, ldbd): dBD[i][T-1-i+j + pad] = dS[i][j] (the inverse of the rel-shift), zero elsewhere; ldbd a multiple of 32
+    bf16_t* dq; long lddq;               // (B*T, .) gradient of the query projection: dS K (+ dBD P with relative positions), accumulated over the walk
+    float* dsum_u; float* dsum_v;        // (B, 4 ceil(T/128), H*HD): per-wave column sums of dS K and dBD P — the pos_bias_u / pos_bias_v gradients once summed
 };
 
 // 16-B chunk swizzle of the LDS-staged kernel's tiles (applied on the DMA source and on every read).  256-B rows (hd 128): the image that is conflict-free for ds_read_b128
@@ -382,6 +384,53 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
             }
     }
 
+    // BW: dQu^T[c][query] += K^T · dS^T and dQv^T[c][query] += P_band^T · dG^T — the forward's O^T += V^T · P^T with other operands (transposed LDS reads of a
+    // [row][hd] tile as A, 32 x 32 accumulator registers re-used as the B operand)
+    f32x16 Ou[BW ? NTO : 1], Ov[BW && REL ? NTO : 1];
+    if constexpr (BW) {
+#pragma unroll
+        for (int t = 0; t < NTO; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                Ou[t][e] = 0.f;
+                if (REL) Ov[t][e] = 0.f;
+            }
+    }
+    auto tr_mma = [&](const char* tile, const bf16x8 (&bb)[2], f32x16* acc) {
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const unsigned vb = (unsigned)(size_t)tile;
+        s16x4 lo[NTO][2], hi[NTO][2];
+#pragma unroll
+        for (int t = 0; t < NTO; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[t][s2]) : "v"(vb + voff[t][0]), "n"(s2 * 16 * ROWB) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[t][s2]) : "v"(vb + voff[t][1]), "n"(s2 * 16 * ROWB) : "memory");
+            }
+#pragma unroll
+        for (int t = 0; t < NTO; ++t) {
+            if (t == NTO - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else if (t == NTO - 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            else if (t == NTO - 3) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                asm volatile("" : "+v"(lo[t][s2]), "+v"(hi[t][s2]));
+                const s16x8 v8 = {lo[t][s2][0], lo[t][s2][1], lo[t][s2][2], lo[t][s2][3], hi[t][s2][0], hi[t][s2][1], hi[t][s2][2], hi[t][s2][3]};
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), bb[s2], acc[t], 0, 0, 0);
+            }
+        }
+    };
+    // the band block's 32 relative positions of this lane's query as the B operand (k-step s2, element j <-> band row 16 s2 + 8 (j >> 2) + 4 h2 + (j & 3))
+    auto band_operand = [&](int blk, bf16x8 (&gb)[2]) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x4 a = *reinterpret_cast<const bf16x4*>(band + r * BAND_B + blk * 64 + (16 * s2 + 4 * h2) * 2);
+            const bf16x4 c = *reinterpret_cast<const bf16x4*>(band + r * BAND_B + blk * 64 + (16 * s2 + 8 + 4 * h2) * 2);
+            gb[s2] = bf16x8{a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+        }
+    };
     auto gtile = [&](int slot) {                             // G^T tile of the position block in ring slot `slot` against (q+v)
         f32x16 G;
 #pragma unroll
@@ -396,6 +445,7 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
     };
     // wave w's band at step it = position blocks (it - w - 1) [lower, carried] and (it - w) [upper, new]
     int pslot_new = (0 - wave + PRING * 4) % PRING;
+    int pslot_low = 0;
     if (REL && nkt > 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
@@ -440,6 +490,7 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
         }
         if (REL) {
             const f32x16 Gn = gtile(pslot_new);
+            pslot_low = pslot_new == 0 ? PRING - 1 : pslot_new - 1;         // the carried (lower) block's slot: BW multiplies its rows into dQv
             pslot_new = pslot_new + 1 == PRING ? 0 : pslot_new + 1;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -491,6 +542,14 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
                 S[e] = __builtin_amdgcn_exp2f(S[e] - lse2);
                 D[e] = S[e] * (D[e] - delta) * p.scale;
             }
+            {
+                bf16x8 db[2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) db[s2][j] = f2bf(D[8 * s2 + j]);
+                tr_mma(sK + (it & 1) * TILEB, db, Ou);
+            }
             // ---- stage the two 32 x 32 tiles as [query][key] rows in the (now idle) skew scratch, and drop dS into the band buffer at column key - query + 31
             // of block (it & 1): the lower block is complete after this step (its other half came from step it - 1), the upper one is finished by step it + 1.
             char* stP = wscr;
@@ -510,6 +569,12 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            if constexpr (REL) {
+                bf16x8 gb[2];
+                band_operand(it & 1, gb);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                tr_mma(sP + pslot_low * TILEB, gb, Ov);
+            }
             // back out of the staging as whole 64-B row segments, into registers: the global stores are issued at the top of the NEXT step, behind its DMA —
             // stores count in vmcnt like loads, and issued here they would be waited for by the very next instruction (the step's vmcnt(0)).
 #pragma unroll
@@ -606,6 +671,68 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
             for (int blk = nkt; blk < nbs; ++blk) {
                 *reinterpret_cast<bf16x8*>(p.prob + (orow0 + row) * p.ldsr + blk * 32 + sch * 8) = z8;
                 *reinterpret_cast<bf16x8*>(p.ds + (orow0 + row) * p.ldsr + blk * 32 + sch * 8) = z8;
+            }
+        }
+        // ---- the last band block's share of dQv (its position rows are the last step's upper block, still in the ring)
+        if constexpr (REL) {
+            if (nkt > 0) {
+                bf16x8 gb[2];
+                band_operand(nkt & 1, gb);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                tr_mma(sP + (pslot_new == 0 ? PRING - 1 : pslot_new - 1) * TILEB, gb, Ov);
+            }
+        }
+        // ---- column sums of dQu / dQv over this wave's valid queries (the bias gradients' partials): 64 channels at a time through the scratch as fp32 rows
+        const int rows_valid = min(32, T - i0);
+        const long psum0 = (((long)b * (gridDim.x * 4) + blockIdx.x * 4 + wave) * p.H + head) * HD;
+        auto colsum_out = [&](const f32x16* acc, float* dst) {
+#pragma unroll
+            for (int hh = 0; hh < HD / 64; ++hh) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x4 v4 = {acc[2 * hh + tt][4 * g4 + 0], acc[2 * hh + tt][4 * g4 + 1], acc[2 * hh + tt][4 * g4 + 2], acc[2 * hh + tt][4 * g4 + 3]};
+                        *reinterpret_cast<f32x4*>(wscr + r * OST_B + (tt * 32 + 8 * g4 + 4 * h2) * 4) = v4;
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                float su = 0.f;
+                for (int rr = 0; rr < rows_valid; ++rr) su += *reinterpret_cast<const float*>(wscr + rr * OST_B + lane * 4);
+                dst[psum0 + hh * 64 + lane] = su;
+            }
+        };
+        if constexpr (REL) {
+            colsum_out(Ou, p.dsum_u);
+            colsum_out(Ov, p.dsum_v);
+        }
+        // ---- dQ rows (dQu + dQv) as bf16, staged like the forward's output rows
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < NTO; ++t)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int c = t * 32 + 8 * g4 + 4 * h2;
+                bf16x4 o;
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) o[k4] = f2bf(REL ? Ou[t][4 * g4 + k4] + Ov[REL ? t : 0][4 * g4 + k4] : Ou[t][4 * g4 + k4]);
+                *reinterpret_cast<bf16x4*>(wscr + r * OST_B + c * 2) = o;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        {
+            constexpr int LPR = ROWB / 16, RPI = 64 / LPR;
+            const int orow = lane / LPR, och = lane % LPR;
+#pragma unroll
+            for (int q = 0; q < 32 / RPI; ++q) {
+                const int row = q * RPI + orow;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(wscr + row * OST_B + och * 16);
+                if (i0 + row < T) *reinterpret_cast<bf16x8*>(p.dq + ((long)b * T + i0 + row) * p.lddq + head * HD + och * 8) = v;
             }
         }
     } else {
@@ -743,16 +870,19 @@ extern "C" int mi_attention_qkv_lse_bf16(const void* q, long ldq, const void* k,
 }
 
 // First half of the attention backward (self-attention, fused QKV operand; hd in {64, 128}): from q, k, v, the projected positions, the forward's context and row
-// log-sum-exp, and dctx -> prob, ds (H, B, T, ldsr) bf16 and dbd (H, B, T, ldbd) bf16 with dbd[i][T-1-i+j + pad] = ds[i][j].  ldsr, ldbd multiples of 32,
+// log-sum-exp, and dctx -> prob, ds (H, B, T, ldsr) bf16 and dbd (H, B, T, ldbd) bf16 with dbd[i][T-1-i+j + pad] = ds[i][j]; and the query gradient itself,
+// dq (B*T, lddq) bf16 = dS K + dBD P, with the per-wave column sums of its two terms in dsum_u / dsum_v (B, 4 ceil(T/128), H*hd) fp32.  ldsr, ldbd multiples of 32,
 // ldsr >= T rounded up to 32, ldbd >= pad + 2T - 1, (T - 32 + pad) % 32 == 0: a wave's band of relative positions then starts on a 64-B boundary of its rows.
 // Every element of the three outputs is written (zeros where no key / relative position contributes).
 extern "C" int mi_attention_qkv_bwd_probs(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                                           const void* pos, long ldp, const float* bias_u, const float* bias_v, const int* lengths,
                                           const void* ctx, long ldo, const void* dctx, long ldd, const float* lse,
                                           void* prob, void* ds, long ldsr, void* dbd, long ldbd, int pad,
+                                          void* dq, long lddq, float* dsum_u, float* dsum_v,
                                           int B, int T, int H, int hd, float scale, int causal, hipStream_t stream) {
     MI_ENTER();
-    if (B <= 0 || T <= 0 || H <= 0 || !lse || !ctx || !dctx || !prob || !ds) return MI_ERR_ARG;
+    if (B <= 0 || T <= 0 || H <= 0 || !lse || !ctx || !dctx || !prob || !ds || !dq) return MI_ERR_ARG;
+    if ((lddq % 8) || lddq >= (1l << 30) || ((uintptr_t)dq & 15) || (pos && (!dsum_u || !dsum_v))) return MI_ERR_ARG;
     if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 8) || (ldd % 8)) return MI_ERR_ARG;
     if (ldq >= (1l << 30) || ldk <= 0 || ldv <= 0 || ldk >= (1l << 30) || ldv >= (1l << 30) || ldp >= (1l << 30) || ldo >= (1l << 30) || ldd >= (1l << 30)) return MI_ERR_ARG;
     if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)ctx | (uintptr_t)dctx | (uintptr_t)prob | (uintptr_t)ds | (uintptr_t)dbd) & 15)) return MI_ERR_ARG;
@@ -763,7 +893,8 @@ extern "C" int mi_attention_qkv_bwd_probs(const void* q, long ldq, const void* k
     }
     AttnArgs a{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, 0, (const bf16_t*)pos, ldp,
                bias_u, bias_v, lengths, (bf16_t*)const_cast<void*>(ctx), ldo, B, T, H, scale, causal, 0, 0, const_cast<float*>(lse),
-               (const bf16_t*)dctx, ldd, (bf16_t*)prob, (bf16_t*)ds, ldsr, (bf16_t*)dbd, pos ? ldbd : 0, pos ? pad : 0};
+               (const bf16_t*)dctx, ldd, (bf16_t*)prob, (bf16_t*)ds, ldsr, (bf16_t*)dbd, pos ? ldbd : 0, pos ? pad : 0,
+               (bf16_t*)dq, lddq, dsum_u, dsum_v};
     switch (hd) {
         case 64: return launch_lds_bw<64>(a, pos != nullptr, stream);
         case 128: return launch_lds_bw<128>(a, pos != nullptr, stream);

@@ -202,9 +202,11 @@ def band_geometry(T: int):
     return pad, (pad + 2 * T - 1 + 31) // 32 * 32
 
 
-def attn_bwd_probs(qkv, B, T, H, ctx, dctx, lse, *, pos=None, bias_u=None, bias_v=None, lengths=None, causal=False):
+def attn_bwd_probs(qkv, B, T, H, ctx, dctx, lse, dq, *, pos=None, bias_u=None, bias_v=None, lengths=None, causal=False):
     """First half of the fused attention backward (head size 64 / 128, no probability dropout): -> prob, ds (H, B, T, Ts) bf16 and, with relative positions,
-    dbd (H, B, T, Ps) bf16 with dbd[i][T-1-i+j + pad] = ds[i][j] (else None).  Ts = T rounded up to 32; (pad, Ps) = band_geometry(T).  Everything is written."""
+    dbd (H, B, T, Ps) bf16 with dbd[i][T-1-i+j + pad] = ds[i][j] (else None).  Ts = T rounded up to 32; (pad, Ps) = band_geometry(T).  Everything is written.
+    dq (B*T, d) bf16 row view receives the query gradient dS K + dBD P; with positions also -> (su, sv): (rows, d) fp32 whose column sums are the gradients
+    of pos_bias_u / pos_bias_v."""
     d = qkv.shape[1] // 3
     hd = d // H
     Ts = (T + 31) // 32 * 32
@@ -212,14 +214,19 @@ def attn_bwd_probs(qkv, B, T, H, ctx, dctx, lse, *, pos=None, bias_u=None, bias_
     dev = qkv.device
     prob = torch.empty((H, B, T, Ts), device=dev, dtype=BF16)
     ds = torch.empty((H, B, T, Ts), device=dev, dtype=BF16)
-    dbd = torch.empty((H, B, T, Ps), device=dev, dtype=BF16) if pos is not None else None
+    rel = pos is not None
+    dbd = torch.empty((H, B, T, Ps), device=dev, dtype=BF16) if rel else None
+    nw = 4 * ((T + 127) // 128)
+    su = torch.empty((B * nw, d), device=dev, dtype=F32) if rel else None
+    sv = torch.empty((B * nw, d), device=dev, dtype=F32) if rel else None
     q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
     _lib.check(_L().mi_attention_qkv_bwd_probs(q.data_ptr(), qkv.stride(0), k.data_ptr(), qkv.stride(0), v.data_ptr(), qkv.stride(0),
-                                               _p(pos), pos.stride(0) if pos is not None else 0, _p(bias_u), _p(bias_v), _p(lengths),
+                                               _p(pos), pos.stride(0) if rel else 0, _p(bias_u), _p(bias_v), _p(lengths),
                                                ctx.data_ptr(), ctx.stride(0), dctx.data_ptr(), dctx.stride(0), lse.data_ptr(),
-                                               prob.data_ptr(), ds.data_ptr(), Ts, _p(dbd), Ps, pad, B, T, H, hd, 1.0 / math.sqrt(hd), int(causal), _stream()),
+                                               prob.data_ptr(), ds.data_ptr(), Ts, _p(dbd), Ps, pad, dq.data_ptr(), dq.stride(0), _p(su), _p(sv),
+                                               B, T, H, hd, 1.0 / math.sqrt(hd), int(causal), _stream()),
                "mi_attention_qkv_bwd_probs")
-    return prob, ds, dbd
+    return prob, ds, dbd, su, sv
 
 
 def pad8(n: int) -> int:

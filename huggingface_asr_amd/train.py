@@ -1028,15 +1028,16 @@ class EncoderCTCTrainer:
         dqkv = torch.empty((M, 3 * d), device=dev, dtype=BF16)
         Pn = 2 * Tt - 1
         if "lse" in S and drop is None:
-            # fused forward: ONE walk over the keys recomputes the scores and leaves P, dS and the un-shifted dBD (bf16) — no fp32 score-sized tensors
-            prob, ds, dbd = T.attn_bwd_probs(qkv, B, Tt, H, S["ctx"], dctx, S["lse"], pos=posp, bias_u=P(p + "att_u") if rel else None,
-                                             bias_v=P(p + "att_v") if rel else None, lengths=lengths, causal=self.causal)
+            # fused forward: ONE walk over the keys recomputes the scores and leaves P, dS and the un-shifted dBD (bf16) — no fp32 score-sized tensors — and
+            # accumulates dQ = dS K + dBD P on the way (its two terms' column sums are the position-bias gradients)
+            prob, ds, dbd, su, sv = T.attn_bwd_probs(qkv, B, Tt, H, S["ctx"], dctx, S["lse"], dqkv[:, :d], pos=posp, bias_u=P(p + "att_u") if rel else None,
+                                                     bias_v=P(p + "att_v") if rel else None, lengths=lengths, causal=self.causal)
+            fused = True
             if rel:
                 qu, qv = T.add_rowvec(q, P(p + "att_u")), T.add_rowvec(q, P(p + "att_v"))
-                off, Kp = T.band_geometry(Tt)                 # dbd's columns are relative positions + off: the position rows move with them
-                posk = torch.zeros((Kp, d), device=dev, dtype=BF16)
-                posk[off:off + Pn] = posp
+                off, Kp = T.band_geometry(Tt)                 # dbd's columns are relative positions + off
         else:
+            fused = False
             prob = S.get("prob")                           # what multiplied V in the forward (dropped copy under dropout)
             if prob is None:
                 prob = self._probs(qkv, posp, P(p + "att_u") if rel else None, P(p + "att_v") if rel else None, lengths, B, Tt, H, S)
@@ -1047,7 +1048,7 @@ class EncoderCTCTrainer:
             dp = torch.empty((H, B, Tt, Ts0), device=dev, dtype=F32)
             T.bgemm(dctx, (hd, Tt * d, d, 1), v, (hd, Tt * 3 * d, 3 * d, 1), dp, (B * Tt * Ts0, Tt * Ts0, Ts0), H, B, Tt, Tt, hd)
             ds, dbd = T.attn_softmax_bwd(prob_pre, dp, H, B, Tt, Tt, scale, want_dbd=rel, drop=drop)
-            off, Kp, posk = 0, Pn, posp
+            off, Kp = 0, Pn
         Ts = prob.shape[-1]
         sTT = (B * Tt * Ts, Tt * Ts)
         # dV = P^T · dctx
@@ -1056,23 +1057,28 @@ class EncoderCTCTrainer:
         aq, aq_str = (qu, (hd, Tt * d, 1, d)) if rel else (q, (hd, Tt * 3 * d, 1, 3 * d))
         T.bgemm(ds, (*sTT, 1, Ts), aq, aq_str, dqkv[:, d:2 * d], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt)
         if not rel:
-            # dQ = dS · K
-            T.bgemm(ds, (*sTT, Ts, 1), k, (hd, Tt * 3 * d, 1, 3 * d), dqkv[:, :d], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt)
+            if not fused:      # dQ = dS · K
+                T.bgemm(ds, (*sTT, Ts, 1), k, (hd, Tt * 3 * d, 1, 3 * d), dqkv[:, :d], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt)
             return dqkv
         Ps = dbd.shape[-1]
-        dqu = torch.empty((M, d), device=dev, dtype=F32)
-        dqv = torch.empty((M, d), device=dev, dtype=F32)
-        T.bgemm(ds, (*sTT, Ts, 1), k, (hd, Tt * 3 * d, 1, 3 * d), dqu, (hd, Tt * d, d), H, B, Tt, hd, Tt)
-        T.bgemm(dbd, (B * Tt * Ps, Tt * Ps, Ps, 1), posk, (hd, 0, 1, d), dqv, (hd, Tt * d, d), H, B, Tt, hd, Kp)
-        # d(posp) (P, d) = sum_b dBD^T · (q + v): K runs over the (b, t) rows of one head
-        # per-utterance partials (B, P, d), then a column sum over B: one long-K product per head would occupy 64 blocks only
-        dpp = torch.empty((B, Kp * d), device=dev, dtype=F32)
-        T.bgemm(dbd, (B * Tt * Ps, Tt * Ps, 1, Ps), qv, (hd, Tt * d, 1, d), dpp, (hd, Kp * d, d), H, B, Kp, hd, Tt)
+        if fused:
+            T.colsum_(G(p + "att_u"), su)
+            T.colsum_(G(p + "att_v"), sv)
+        else:
+            dqu = torch.empty((M, d), device=dev, dtype=F32)
+            dqv = torch.empty((M, d), device=dev, dtype=F32)
+            T.bgemm(ds, (*sTT, Ts, 1), k, (hd, Tt * 3 * d, 1, 3 * d), dqu, (hd, Tt * d, d), H, B, Tt, hd, Tt)
+            T.bgemm(dbd, (B * Tt * Ps, Tt * Ps, Ps, 1), posp, (hd, 0, 1, d), dqv, (hd, Tt * d, d), H, B, Tt, hd, Pn)
+            T.add_cast(dqu, dqv, out=dqkv[:, :d])
+            T.colsum_(G(p + "att_u"), dqu)
+            T.colsum_(G(p + "att_v"), dqv)
+        # d(posp) (P, d) = sum_b dBD^T · (q + v): K runs over the (b, t) rows of one head.  Partials per group of `cg` utterances (B / cg, P, d), then a column
+        # sum over the groups: one long-K product per head would occupy 64 blocks only, per-utterance partials are 4x the fp32 traffic of groups of four
+        cg = 4 if B % 4 == 0 and B >= 16 else (2 if B % 2 == 0 and B >= 8 else 1)
+        dpp = torch.empty((B // cg, Kp * d), device=dev, dtype=F32)
+        T.bgemm(dbd, (B * Tt * Ps, cg * Tt * Ps, 1, Ps), qv, (hd, cg * Tt * d, 1, d), dpp, (hd, Kp * d, d), H, B // cg, Kp, hd, cg * Tt)
         dposp = torch.zeros((Kp, d), device=dev, dtype=F32)
         T.colsum_(dposp.view(-1), dpp)
-        T.add_cast(dqu, dqv, out=dqkv[:, :d])
-        T.colsum_(G(p + "att_u"), dqu)
-        T.colsum_(G(p + "att_v"), dqv)
         # linear_pos: posp = table · Wpos^T  ->  dWpos += dposp^T · table
         dpb = T.add_cast(dposp[off:off + Pn])
         T.gemm_tn_(G(p + "att_wpos"), dpb, pos[0], defer=self._tnb)

@@ -142,11 +142,14 @@ int mi_attention_qkv_lse_bf16(const void* q, long ldq, const void* k, long ldk, 
 /* First half of the attention backward (what autograd derives from e_branchformer.py:105-138 and the rel-shift of tf wav2vec2_conformer :528-565): one walk over
  * the keys recomputes the scores, P = 2^(S - lse), dP = dctx V^T, dS = P (dP - dctx·ctx) scale, and leaves bf16
  *   prob, ds (H, B, T, ldsr)   and   dbd (H, B, T, ldbd), dbd[i][T-1-i+j + pad] = ds[i][j]  (the gradient of the un-shifted position scores; null without pos).
+ * It also accumulates the query gradient over the walk: dq (B*T, lddq) bf16 = dS K + dBD P, and the per-wave column sums of the two terms in
+ * dsum_u / dsum_v (B, 4 ceil(T/128), H*hd) fp32 (summed over their first two axes: the pos_bias_u / pos_bias_v gradients; unused without pos).
  * ldsr, ldbd multiples of 32 with ldsr >= T rounded up to 32 and ldbd >= pad + 2T - 1; 0 <= pad < 32 with (T - 32 + pad) % 32 == 0.  Every element is written. */
 int mi_attention_qkv_bwd_probs(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                                const void* pos, long ldp, const float* bias_u, const float* bias_v, const int* lengths,
                                const void* ctx, long ldo, const void* dctx, long ldd, const float* lse,
                                void* prob, void* ds, long ldsr, void* dbd, long ldbd, int pad,
+                               void* dq, long lddq, float* dsum_u, float* dsum_v,
                                int B, int T, int H, int hd, float scale, int causal, mi_stream_t stream);
 
 /* ---- cgMLP gate: per-row LN statistics + fused LN -> depthwise conv(time) -> gate.

@@ -231,6 +231,12 @@ def test_attention_backward_recomputation(T_, H, hd, rel, causal):
     ctx = prob @ vh
     ctx.backward(dctx.view(B, Tq, H, hd).permute(2, 0, 1, 3))
     ds_want = ac.grad / 1.0                                    # d loss / d(score before the scale) = P (dP - delta) scale
+    # the query gradient and, with relative positions, its two terms' column sums (the pos_bias_u / pos_bias_v gradients)
+    dqu_want = ac.grad @ kh                                    # (H, B, T, hd)
+    dq_want = dqu_want
+    if rel:
+        dqv_want = torch.einsum("hbtp,hpc->hbtc", bd.grad, ph)
+        dq_want = dqu_want + dqv_want
     qkv = torch.cat([q, k, v], 1).to(DEV, BF)
     kw = dict(pos=None if pos is None else dev16(pos), bias_u=None if u is None else u.to(DEV), bias_v=None if vb is None else vb.to(DEV),
               lengths=lengths.to(DEV), causal=causal)
@@ -243,8 +249,13 @@ def test_attention_backward_recomputation(T_, H, hd, rel, causal):
     Ts = (Tq + 31) // 32 * 32
     pad, Ps = T.band_geometry(Tq)
     assert (Tq - 32 + pad) % 32 == 0 and Ps % 32 == 0 and Ps >= pad + 2 * Tq - 1
-    pk, dsk, dbdk = T.attn_bwd_probs(qkv, B, Tq, H, ctx_k, dev16(dctx), lse, **kw)
+    dqk = torch.full((B * Tq, 3 * d), float("nan"), device=DEV, dtype=BF)[:, :d]          # a strided row view, as the trainer's dqkv[:, :d]
+    pk, dsk, dbdk, su, sv = T.attn_bwd_probs(qkv, B, Tq, H, ctx_k, dev16(dctx), lse, dqk, **kw)
     assert pk.shape == (H, B, Tq, Ts) and (dbdk is None) == (not rel)
+    close(dqk.view(B, Tq, H, hd).permute(2, 0, 1, 3), dq_want, floor=2e-2, what="dQ")
+    if rel:
+        close(su.sum(0).view(H, hd), dqu_want.sum((1, 2)), rel=2e-2, floor=2e-2, what="sum dQu (pos_bias_u gradient)")
+        close(sv.sum(0).view(H, hd), dqv_want.sum((1, 2)), rel=2e-2, floor=2e-2, what="sum dQv (pos_bias_v gradient)")
     close(pk[..., :Tq], prob.detach(), floor=4e-3, what="P")
     close(dsk[..., :Tq], ds_want, floor=2e-2, what="dS")
     assert float(pk[..., Tq:].float().abs().max() if Ts > Tq else 0.0) == 0.0 and float(dsk[..., Tq:].float().abs().max() if Ts > Tq else 0.0) == 0.0
@@ -258,8 +269,10 @@ def test_attention_backward_recomputation(T_, H, hd, rel, causal):
         idx = ((Tq - 1) - torch.arange(Tq)[:, None] + torch.arange(Tq)[None, :] + pad).to(DEV)
         assert torch.equal(torch.gather(dbdk, 3, idx[None, None].expand(H, B, Tq, Tq)), dsk[..., :Tq])
     # second call on poisoned buffers gives the same bits (nothing depends on what the outputs held)
-    pk2, dsk2, dbdk2 = T.attn_bwd_probs(qkv, B, Tq, H, ctx_k, dev16(dctx), lse, **kw)
-    assert torch.equal(pk, pk2) and torch.equal(dsk, dsk2) and (not rel or torch.equal(dbdk, dbdk2))
+    dqk2 = torch.empty_like(dqk)
+    pk2, dsk2, dbdk2, su2, sv2 = T.attn_bwd_probs(qkv, B, Tq, H, ctx_k, dev16(dctx), lse, dqk2, **kw)
+    assert torch.equal(pk, pk2) and torch.equal(dsk, dsk2) and (not rel or torch.equal(dbdk, dbdk2)) and torch.equal(dqk, dqk2)
+    assert not rel or (torch.equal(su, su2) and torch.equal(sv, sv2))
 
 
 def test_csgu_and_merge_dwconv_bwd():
