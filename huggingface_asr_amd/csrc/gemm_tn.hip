@@ -91,24 +91,23 @@ __device__ __forceinline__ void tn_tile(const TnArgs& p, const int bid) {
     const int m_lo = split * p.rows_per_split, m_hi = min(p.M, m_lo + p.rows_per_split);
     const int nit = (m_hi - m_lo + TN_KM - 1) / TN_KM;
 
-    // piece g of the stage: 1 KiB of one operand tile — pieces [0, 16) dY (4 rows x 256 B each), then X (4 rows x 256 B, or 8 rows x 128 B at XW = 64)
-    const bf16_t* src[PPW];
-    int rowin[PPW];
-    bool colok[PPW];
+    // piece g of the stage: 1 KiB of one operand tile — pieces [0, YP) dY, then X.  Per piece a lane keeps ONE register (its chunk's column within the operand's rows,
+    // negative when outside the matrix); the row within the stage and the operand's base / row stride are recomputed from wave-uniform values at issue time
+    // (eight 64-bit source pointers per lane pushed the 256 x 256 form over its 256-register budget: the pointers spilled and every reload waited for vmcnt(0)).
+    int coloff[PPW];
+    constexpr int RPY = 1024 / YB, RPX = 1024 / XB;           // rows per piece
+    const int rsubY = lane / YCH, rsubX = lane / XCH;
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
         const int g = wave * PPW + q;
-        const bool isY = g < YP;
-        if (isY) {
-            constexpr int RPY = 1024 / YB;                   // rows per piece
-            const int row = g * RPY + lane / YCH, cs = lane % YCH;
-            const int c = cs ^ swz<YCH>(row);                // source chunk for LDS slot cs
-            rowin[q] = row; colok[q] = n0 + c * 8 < p.N; src[q] = p.Y + n0 + c * 8;
+        if (g < YP) {
+            const int row = g * RPY + rsubY, cs = lane % YCH;
+            const int c = (cs ^ swz<YCH>(row)) * 8;          // source chunk for LDS slot cs
+            coloff[q] = n0 + c < p.N ? n0 + c : -1;
         } else {
-            constexpr int RPP = 1024 / XB;                   // rows per piece
-            const int row = (g - YP) * RPP + lane / XCH, cs = lane % XCH;
-            const int c = cs ^ swz<XCH>(row);
-            rowin[q] = row; colok[q] = k0 + c * 8 < p.K; src[q] = p.X + k0 + c * 8;
+            const int row = (g - YP) * RPX + rsubX, cs = lane % XCH;
+            const int c = (cs ^ swz<XCH>(row)) * 8;
+            coloff[q] = k0 + c < p.K ? k0 + c : -1;
         }
     }
     auto issue = [&](int it, int stage) {
@@ -116,9 +115,12 @@ __device__ __forceinline__ void tn_tile(const TnArgs& p, const int bid) {
         const int mb = m_lo + it * TN_KM;
 #pragma unroll
         for (int q = 0; q < PPW; ++q) {
-            const int g = wave * PPW + q;
-            const int m = mb + rowin[q];
-            const bf16_t* sp = (m < m_hi && colok[q]) ? src[q] + (long)m * (g < YP ? p.ldy : p.ldx) : reinterpret_cast<const bf16_t*>(&g_zero16);
+            const int g = wave * PPW + q;                    // wave-uniform
+            const bool isY = g < YP;
+            const int m = mb + (isY ? g * RPY + rsubY : (g - YP) * RPX + rsubX);
+            const bf16_t* base = isY ? p.Y : p.X;
+            const long ld = isY ? p.ldy : p.ldx;
+            const bf16_t* sp = (m < m_hi && coloff[q] >= 0) ? base + (long)m * ld + coloff[q] : reinterpret_cast<const bf16_t*>(&g_zero16);
             __builtin_amdgcn_global_load_lds((gptr_t)sp, (lptr_t)(sbase + q * 1024), 16, 0, 0);
         }
     };
@@ -168,27 +170,29 @@ __device__ __forceinline__ void tn_tile(const TnArgs& p, const int bid) {
         }
         // 4 k-steps of 16 rows; the fragments of step s + 1 are requested before the MFMAs of step s issue (two register sets, counted lgkmcnt)
         constexpr int NR = 2 * (2 + NJ);                      // LDS reads per k-step and lane
-        s16x4 ylo[2][2], yhi[2][2], xlo[2][NJ], xhi[2][NJ];
+        constexpr int NB = XW >= 256 ? 1 : 2;                 // fragment register sets: the 64 x 128 wave tile (128 accumulators) has no room for a second one
+        s16x4 ylo[NB][2], yhi[NB][2], xlo[NB][NJ], xhi[NB][NJ];
         auto rd = [&](int buf, int s) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) tr_frag_issue<YB>(ty, wn * 64 + i * 32, s, lane, ylo[buf][i], yhi[buf][i]);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) tr_frag_issue<XB>(tx, wk * (XW / 2) + j * 32, s, lane, xlo[buf][j], xhi[buf][j]);
         };
-        rd(0, 0);
+        if (NB == 2) rd(0, 0);
 #pragma unroll
         for (int s = 0; s < TN_KM / 16; ++s) {
-            if (s + 1 < TN_KM / 16) {
+            if (NB == 2 && s + 1 < TN_KM / 16) {
                 rd((s + 1) & 1, s + 1);
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");      // step s's reads are the older NR
             } else {
+                if (NB == 1) rd(0, s);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             bf16x8 fy[2], fx[NJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fy[i] = tr_frag_join(ylo[s & 1][i], yhi[s & 1][i]);
+            for (int i = 0; i < 2; ++i) fy[i] = tr_frag_join(ylo[s & (NB - 1)][i], yhi[s & (NB - 1)][i]);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) fx[j] = tr_frag_join(xlo[s & 1][j], xhi[s & 1][j]);
+            for (int j = 0; j < NJ; ++j) fx[j] = tr_frag_join(xlo[s & (NB - 1)][j], xhi[s & (NB - 1)][j]);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -230,19 +234,32 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) { tn_tile<TN_
 // ~230 output tiles of 256 x 128 — enough to fill the chip WITHOUT splitting M: every block contracts over all rows of its problem and adds its tile into dW in place,
 // so there are no slabs and no reduce pass (launched one by one, each problem needs 8-32 M-splits to fill 512 blocks: 164 launches x (32 us GEMM + 9 us slab reduce)
 // per training step).  Block -> (problem, tile) by the prefix table of tile counts.
-constexpr int TN_GROUP = 16;
-struct TnGroup { TnArgs a[TN_GROUP]; int tile0[TN_GROUP + 1]; int n; };
+constexpr int TN_GROUP = 48;
+// 64-B problem descriptors: 48 of them + the tile prefix table stay under the 4-KiB kernel-argument segment (the small encoder's layers have ~50 tiles each: its
+// problems are gathered over several layers, and the attention decoder's 46 over its whole backward, before a launch fills the chip)
+struct TnDesc { const bf16_t* Y; const bf16_t* X; float* out; float* db; int ldy, ldx, ldo, M, N, K, n_store, pad_; };
+struct TnGroup { TnDesc a[TN_GROUP]; int tile0[TN_GROUP + 1]; int n; };
 
-constexpr int TN_GROUP_NS = 2, TN_GROUP_N = 256;           // 256 (n) x 128 (k) tiles, 8 waves, two 48-KiB stages: one block per CU, two waves per SIMD
+constexpr int TN_GROUP_NS = 2, TN_GROUP_N = 256;           // 256 (n) x XW (k) tiles, 8 waves, two stages: one block per CU, two waves per SIMD
+// XW = 128: 48-KiB stages, wave tiles 64 x 64 (two LDS fragment reads per MFMA).  XW = 256: 64-KiB stages, wave tiles 64 x 128 (1.5 reads per MFMA) and 128 instead of 85 FLOP per
+// ingested byte — in situ the launch is bound by what the CUs pull out of L2 (a stage takes 1.9 us with 256 blocks running against 1.2 us for a lone block), so the
+// larger tile is used whenever the recorded problems still give (nearly) every CU a block: two base-size layers per launch.
+template <int XW>
 __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g) {
     const int bid = blockIdx.x;
-    int i = 0;
-    while (i + 1 < g.n && bid >= g.tile0[i + 1]) ++i;
+    int lo = 0, hi = g.n - 1;                                // the last problem whose first tile is <= bid
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (bid >= g.tile0[mid]) lo = mid; else hi = mid - 1;
+    }
     // the problem index is wave-uniform: say so, and take a COPY of the descriptor — indexed in place, its fields come back as vector memory loads inside the pipeline,
     // each with a `s_waitcnt vmcnt(0)` in front of the LDS-DMA instruction that uses it (seen in the ISA: one full wait per staging instruction)
-    const int iu = __builtin_amdgcn_readfirstlane(i);
-    const TnArgs p = g.a[iu];
-    tn_tile<TN_GROUP_N, 128, TN_GROUP_NS>(p, bid - __builtin_amdgcn_readfirstlane(g.tile0[iu]));
+    const int iu = __builtin_amdgcn_readfirstlane(lo);
+    const TnDesc q = g.a[iu];
+    TnArgs p;
+    p.Y = q.Y; p.ldy = q.ldy; p.X = q.X; p.ldx = q.ldx; p.out = q.out; p.ldo = q.ldo; p.slab_stride = 0; p.db = q.db;
+    p.M = q.M; p.N = q.N; p.K = q.K; p.n_store = q.n_store; p.splits = 1; p.rows_per_split = (q.M + TN_KM - 1) / TN_KM * TN_KM;
+    tn_tile<TN_GROUP_N, XW, TN_GROUP_NS>(p, bid - __builtin_amdgcn_readfirstlane(g.tile0[iu]));
 }
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ out, long ldo, const float* __restrict__ slabs, long slab_stride,
@@ -306,32 +323,44 @@ extern "C" int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx
     return MI_OK;
 }
 
-// The grouped form (see gemm_tn_group_kernel): n <= 16 problems, each dW_i (n_store_i, K_i) fp32 (row stride ldo_i) += dY_i[:, :N_i]^T X_i with optional bias gradient db_i,
-// ONE launch, no M-split, no workspace.  Arrays of length n on the HOST.  Same operand constraints as mi_gemm_tn_bf16.  Meant for >= ~256 output tiles in total
+// The grouped form (see gemm_tn_group_kernel): n <= 48 problems, each dW_i (n_store_i, K_i) fp32 (row stride ldo_i) += dY_i[:, :N_i]^T X_i with optional bias gradient db_i,
+// ONE launch, no M-split, no workspace.  tile_k: k extent of the 256-row output tiles — 128, 256, or 0 = 256 when that still gives >= 200 tiles, else 128.  Arrays of length n on the HOST.  Same operand constraints as mi_gemm_tn_bf16.  Meant for >= ~256 output tiles in total
 // (sum of ceil(N_i / 128) * ceil(K_i / 128)); with fewer the chip is under-filled: use mi_gemm_tn_bf16 per problem.
 extern "C" int mi_gemm_tn_group_bf16(int n, const void* const* dY, const long* ldy, const void* const* X, const long* ldx, float* const* dW, const long* ldo,
-                                     float* const* db, const int* M, const int* N, const int* K, const int* n_store, hipStream_t st) {
+                                     float* const* db, const int* M, const int* N, const int* K, const int* n_store, int tile_k, hipStream_t st) {
     MI_ENTER();
     if (n <= 0 || n > TN_GROUP) return MI_ERR_ARG;
     TnGroup g{};
     g.n = n;
-    int tiles = 0;
+    long t256 = 0;
     for (int i = 0; i < n; ++i) {
         if (M[i] <= 0 || N[i] <= 0 || K[i] <= 0 || (N[i] % 8) || (K[i] % 8) || (ldy[i] % 8) || (ldx[i] % 8) || n_store[i] > N[i] || n_store[i] <= 0) return MI_ERR_ARG;
         if ((reinterpret_cast<uintptr_t>(dY[i]) & 15) || (reinterpret_cast<uintptr_t>(X[i]) & 15) || !dW[i]) return MI_ERR_ARG;
-        TnArgs& p = g.a[i];
-        p.Y = (const bf16_t*)dY[i]; p.ldy = ldy[i]; p.X = (const bf16_t*)X[i]; p.ldx = ldx[i];
-        p.M = M[i]; p.N = N[i]; p.K = K[i]; p.n_store = n_store[i]; p.splits = 1; p.db = db ? db[i] : nullptr;
-        p.rows_per_split = cdiv(M[i], TN_KM) * TN_KM;
-        p.out = dW[i]; p.ldo = ldo[i]; p.slab_stride = 0;
+        if (ldy[i] >= (1l << 31) || ldx[i] >= (1l << 31) || ldo[i] >= (1l << 31) || ldy[i] <= 0 || ldx[i] <= 0 || ldo[i] <= 0) return MI_ERR_ARG;
+        t256 += (long)cdiv(N[i], TN_GROUP_N) * cdiv(K[i], 256);
+    }
+    if (tile_k != 0 && tile_k != 128 && tile_k != 256) return MI_ERR_ARG;
+    const int xw = tile_k ? tile_k : (t256 >= 200 ? 256 : 128);
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        TnDesc& p = g.a[i];
+        p.Y = (const bf16_t*)dY[i]; p.ldy = (int)ldy[i]; p.X = (const bf16_t*)X[i]; p.ldx = (int)ldx[i];
+        p.M = M[i]; p.N = N[i]; p.K = K[i]; p.n_store = n_store[i]; p.db = db ? db[i] : nullptr;
+        p.out = dW[i]; p.ldo = (int)ldo[i];
         g.tile0[i] = tiles;
-        tiles += cdiv(N[i], TN_GROUP_N) * cdiv(K[i], 128);
+        tiles += cdiv(N[i], TN_GROUP_N) * cdiv(K[i], xw);
     }
     g.tile0[n] = tiles;
-    const size_t lds = (size_t)TN_GROUP_NS * TN_KM * (TN_GROUP_N * 2 + 256);              // 2 x 48 KiB: one block per CU
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return MI_ERR_LAUNCH;
-    hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(tiles), dim3(512), lds, st, g);
+    const size_t lds = (size_t)TN_GROUP_NS * TN_KM * (TN_GROUP_N * 2 + xw * 2);          // 2 x 48 KiB / 2 x 64 KiB: one block per CU
+    if (xw == 256) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_group_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr != hipSuccess) return MI_ERR_LAUNCH;
+        hipLaunchKernelGGL(gemm_tn_group_kernel<256>, dim3(tiles), dim3(512), lds, st, g);
+    } else {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_group_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr != hipSuccess) return MI_ERR_LAUNCH;
+        hipLaunchKernelGGL(gemm_tn_group_kernel<128>, dim3(tiles), dim3(512), lds, st, g);
+    }
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

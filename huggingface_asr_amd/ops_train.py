@@ -437,10 +437,10 @@ _TN_WS = {}
 
 class TnBatch:
     """Deferred weight-gradient GEMMs: `gemm_tn_(..., defer=batch)` / `linear_bwd(..., defer=batch)` only record (dW, dY, X, db) — the tensors stay referenced, so their
-    memory is not reused — and `flush()` runs them as ONE grouped launch (mi_gemm_tn_group_bf16): a layer's ten dW GEMMs have ~230 output tiles of 256 x 128 between them, enough
-    to fill the chip without splitting M, hence no slabs and no reduce passes.  Below `MIN_TILES` output tiles in total (a mostly frozen layer) the problems run one by
-    one on the split-M path.  Callers must not modify a recorded dY / X in place before the flush."""
-    MAX, MIN_TILES = 16, 128
+    memory is not reused — and `flush()` runs them as ONE grouped launch (mi_gemm_tn_group_bf16): a base-size layer's ten dW GEMMs have ~230 output tiles of 256 x 128 between
+    them, enough to fill the chip without splitting M, hence no slabs and no reduce passes.  Below `MIN_TILES` tiles a non-final flush keeps recording (small models:
+    several layers per launch); a final flush with less than half of that (a mostly frozen model) runs the problems one by one on the split-M path.  Callers must not modify a recorded dY / X in place before the flush."""
+    MAX, MIN_TILES, FULL_TILES = 48, 128, 200
 
     def __init__(self):
         self.items = []
@@ -450,15 +450,23 @@ class TnBatch:
         if len(self.items) == self.MAX:
             self.flush()
 
-    def flush(self):
+    def tiles(self, tk=128):
+        return sum(-(-dy.shape[1] // 256) * -(-x.shape[1] // tk) for _, dy, x, _, _ in self.items)          # 256 (n) x tk (k) output tiles, one block per CU
+
+    def flush(self, final=True, room=12, tile_k=0):
+        """runs what is recorded.  final=False: only once the recorded problems fill the chip with 256 x 256 output tiles (FULL_TILES: two base-size layers), or when
+        `room` more problems would not fit — otherwise they stay recorded and False is returned: the caller's gradients are not final yet.  The kernel takes
+        256 x 256 tiles when there are >= 200 of them, else 256 x 128 (tile_k = 0; a small model's 48 problems have ~130 / ~220)."""
+        if not self.items:
+            return True
+        if not final and self.tiles(256) < self.FULL_TILES and len(self.items) + room <= self.MAX:
+            return False
+        tiles = self.tiles()
         items, self.items = self.items, []
-        if not items:
-            return
-        tiles = sum(-(-dy.shape[1] // 256) * -(-x.shape[1] // 128) for _, dy, x, _, _ in items)          # 256 (n) x 128 (k) output tiles, one block per CU
-        if tiles < self.MIN_TILES:
+        if tiles < self.MIN_TILES // 2:
             for dw, dy, x, n_store, db in items:
                 gemm_tn_(dw, dy, x, n_store=n_store, db=db)
-            return
+            return True
         import ctypes as C
         n = len(items)
         vp, lg, it = (C.c_void_p * n), (C.c_long * n), (C.c_int * n)
@@ -468,7 +476,8 @@ class TnBatch:
             vp(*[dw.data_ptr() for dw, _, _, _, _ in items]), lg(*[dw.stride(0) for dw, _, _, _, _ in items]),
             vp(*[(db.data_ptr() if db is not None else None) for _, _, _, _, db in items]),
             it(*[dy.shape[0] for _, dy, _, _, _ in items]), it(*[dy.shape[1] for _, dy, _, _, _ in items]), it(*[x.shape[1] for _, _, x, _, _ in items]),
-            it(*[ns for _, _, _, ns, _ in items]), _stream()), "mi_gemm_tn_group_bf16")
+            it(*[ns for _, _, _, ns, _ in items]), int(tile_k), _stream()), "mi_gemm_tn_group_bf16")
+        return True
 
 
 def gemm_tn_(dw, dy, x, n_store=None, db=None, variant=0, defer=None):

@@ -489,13 +489,19 @@ class EncoderCTCTrainer:
             self.store.set_frozen(frozen)         # native route: AdamW leaves them bit-identical (no decay, zero gradient), the clip norm skips them
         self.frozen = frozen
 
-    def _range_done(self, lo, hi):
-        """the gradients of [lo, hi) are final once the deferred LayerNorm reductions have run: flush them, then hand the range to the data-parallel all-reduce"""
+    def _range_done(self, lo, hi, final=False):
+        """the gradients of [lo, hi) are final once the deferred LayerNorm reductions and weight-gradient GEMMs have run: flush them, then hand the range to the
+        data-parallel all-reduce.  The weight-gradient batch may decline a non-final flush (too few output tiles to fill the chip: ops_train.TnBatch) — the range
+        then waits, with any earlier ones, for the flush that does run; the backward's last range is `final`."""
         if getattr(self, "_lnred", None) is not None:
             self._lnred.flush()
-        if getattr(self, "_tnb", None) is not None:
-            self._tnb.flush()               # the layer's deferred weight-gradient GEMMs: one grouped launch (ops_train.TnBatch)
-        self.sync.launch(lo, hi)
+        pending = self.__dict__.setdefault("_ranges_waiting", [])
+        pending.append((lo, hi))
+        tnb = getattr(self, "_tnb", None)
+        if tnb is None or tnb.flush(final=final):
+            for r in pending:
+                self.sync.launch(*r)
+            pending.clear()
 
     def _lng(self, gname, bname):
         """gradient targets of a LayerNorm's affine pair: none when both are frozen (the cross-row reduction is then skipped)"""
@@ -565,6 +571,7 @@ class EncoderCTCTrainer:
         if getattr(self, "_tnb", None) is None:
             self._tnb = T.TnBatch()
         self._tnb.items = []
+        self._ranges_waiting = []
         P, G, W, WT = st.p, st.g, st.bf, st.bfT
         GL = lambda n, sl=None: None if n in self.frozen else (st.g(n) if sl is None else st.g(n)[sl])      # gradient of a linear's weight / bias, None when frozen
         dev = self.device
@@ -902,7 +909,7 @@ class EncoderCTCTrainer:
             dz1, dg1 = T.gated_act_bwd(dact1.view(-1, C1), z1.view(-1, C1), g1.view(-1, C1), B, T1, F1, C1, share)
             T.conv2d_first_wgrad(feats, dz1.view(B, T1, F1, C1), G("conv1_w"), G("conv1_b"), cK, cS, cP)
             T.conv2d_first_wgrad(feats, dg1.view(B, T1 // share, F1, C1), G("gate1_w"), G("gate1_b"), gK, gS, gP)
-        self._range_done(*st.range_of(self._front_names))
+        self._range_done(*st.range_of(self._front_names), final=True)
         return out
 
     # ------------------------------------------------------------------ pieces

@@ -313,13 +313,14 @@ class JointAEDTrainer:
         dec_loss = weights[-1] * ce
         # ---- backward of the last head
         dhid = ops.gemm(dl, WT(lm_name))
-        T.gemm_tn_(G(lm_name), dl, hid, n_store=V)
+        tnb = T.TnBatch()            # every weight gradient of the decoder's backward: one grouped launch at the end (46 problems, ~150 output tiles at 6 x 256)
+        T.gemm_tn_(G(lm_name), dl, hid, n_store=V, defer=tnb)
         tap_grads, final_dys = {}, [dhid]
         for k, loc in enumerate(locs):
             src16 = ops.cast_bf16(taps[loc]) if loc in taps else hid
             _, ce_k, dl_k = head(src16, f"head{k}", wdec * weights[k])
             dec_loss = dec_loss + weights[k] * ce_k
-            T.gemm_tn_(G(f"head{k}"), dl_k, src16, n_store=V)
+            T.gemm_tn_(G(f"head{k}"), dl_k, src16, n_store=V, defer=tnb)
             if loc in taps:
                 tap_grads[loc] = ops.gemm(dl_k, WT(f"head{k}"), out_dtype=F32)
             else:                                            # a head on the last hidden state reads ln_f's output
@@ -336,29 +337,29 @@ class JointAEDTrainer:
             dres = (lambda lay, site: T.dropout_(dx, pr, seed, sid(lay, site), out=e16(M, d))) if pr > 0 else (lambda lay, site: T.add_cast(dx))
             # MLP
             dyb = dres(32 + l, 4)
-            dm = T.linear_bwd(dyb, S["mm"], WT(p + "wpr"), dw=G(p + "wpr"), db=G(p + "bpr"))
+            dm = T.linear_bwd(dyb, S["mm"], WT(p + "wpr"), dw=G(p + "wpr"), db=G(p + "bpr"), defer=tnb)
             dmp = T.act_bwd(dm, S["mp"], "gelu_new")
-            da3 = T.linear_bwd(dmp, S["a3"], WT(p + "wfc"), dw=G(p + "wfc"), db=G(p + "bfc"))
+            da3 = T.linear_bwd(dmp, S["a3"], WT(p + "wfc"), dw=G(p + "wfc"), db=G(p + "bfc"), defer=tnb)
             T.layernorm_bwd(S["x2"], P(p + "ln2_g"), da3, dx, accumulate=True, dgamma=G(p + "ln2_g"), dbeta=G(p + "ln2_b"), eps=eps)
             # cross-attention
             dyb = dres(32 + l, 3)
-            dctx2 = T.linear_bwd(dyb, S["ctx2"], WT(p + "wco"), dw=G(p + "wco"), db=G(p + "bco"))
+            dctx2 = T.linear_bwd(dyb, S["ctx2"], WT(p + "wco"), dw=G(p + "wco"), db=G(p + "bco"), defer=tnb)
             dqq, dkv = e16(M, d), e16(Me, 2 * d)
             kv = S["kv"]
             attention_bwd_plain(S["qq"], kv[:, :d], kv[:, d:], dctx2, dqq, dkv[:, :d], dkv[:, d:], B, U, T2, H, lengths=key_len,
                                 drop=(pa, seed, sid(32 + l, 2)) if pa > 0 else None, saved=S["p2"])
-            da2 = T.linear_bwd(dqq, S["a2"], WT(p + "wq"), dw=G(p + "wq"), db=G(p + "bq"))
-            T.linear_bwd(dkv, enc_bf, WT(p + "wkv"), dw=G(p + "wkv"), db=G(p + "bkv"), need_dx=False)
+            da2 = T.linear_bwd(dqq, S["a2"], WT(p + "wq"), dw=G(p + "wq"), db=G(p + "bq"), defer=tnb)
+            T.linear_bwd(dkv, enc_bf, WT(p + "wkv"), dw=G(p + "wkv"), db=G(p + "bkv"), need_dx=False, defer=tnb)
             ops.gemm(dkv, WT(p + "wkv")[:, :2 * d], out=denc, resid=denc, alpha=1.0)
             T.layernorm_bwd(S["x1"], P(p + "lnc_g"), da2, dx, accumulate=True, dgamma=G(p + "lnc_g"), dbeta=G(p + "lnc_b"), eps=eps)
             # causal self-attention
             dyb = dres(32 + l, 1)
-            dctx1 = T.linear_bwd(dyb, S["ctx1"], WT(p + "wo"), dw=G(p + "wo"), db=G(p + "bo"))
+            dctx1 = T.linear_bwd(dyb, S["ctx1"], WT(p + "wo"), dw=G(p + "wo"), db=G(p + "bo"), defer=tnb)
             qkv = S["qkv"]
             dqkv = e16(M, 3 * d)
             attention_bwd_plain(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], dctx1, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, U, U, H, causal=True,
                                 drop=(pa, seed, sid(32 + l, 0)) if pa > 0 else None, saved=S["p1"])
-            da1 = T.linear_bwd(dqkv, S["a1"], WT(p + "wqkv"), dw=G(p + "wqkv"), db=G(p + "bqkv"))
+            da1 = T.linear_bwd(dqkv, S["a1"], WT(p + "wqkv"), dw=G(p + "wqkv"), db=G(p + "bqkv"), defer=tnb)
             T.layernorm_bwd(S["x"], P(p + "ln1_g"), da1, dx, accumulate=True, dgamma=G(p + "ln1_g"), dbeta=G(p + "ln1_b"), eps=eps)
         if 0 in tap_grads:
             T.axpy_(dx, tap_grads[0])
@@ -366,9 +367,10 @@ class JointAEDTrainer:
             T.dropout_(dx, pe, seed, sid(63, 0))
         T.embed_tokens_bwd(ids, dx, G("wte"), None if self.pos_fixed is not None else G("wpe"), scale=self.emb_scale)
         if self.with_proj:
-            dh = T.linear_bwd(T.add_cast(denc), hb, WT("proj_w"), dw=G("proj_w"), db=G("proj_b"), dx_dtype=F32)
+            dh = T.linear_bwd(T.add_cast(denc), hb, WT("proj_w"), dw=G("proj_w"), db=G("proj_b"), dx_dtype=F32, defer=tnb)
         else:
             dh = denc
+        tnb.flush()
         self.sync.launch(0, st.n)
         out.update(dec_loss=dec_loss, logits=logits, encoder_hidden=enc_bf)
         return dh

@@ -273,10 +273,11 @@ int mi_adamw_step(float* p, const float* g, float* m, float* v, const unsigned c
 size_t mi_gemm_tn_workspace_bytes(int M, int N, int K);
 int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx, float* dW, long ldo, float* db /* optional bias gradient */, int M, int N,
                     int K, int n_store, void* workspace, size_t workspace_bytes, int variant /* 0 = product tile (128 x 128); 1 = 128 x 64 for A/B */, mi_stream_t stream);
-/* grouped form: the weight-gradient GEMMs of one encoder layer (n <= 16 problems, host arrays of length n) as ONE launch — together their 128 x 128 output tiles fill the
+/* grouped form: the weight-gradient GEMMs of one encoder layer (n <= 48 problems, host arrays of length n) as ONE launch — together their 128 x 128 output tiles fill the
  * chip without splitting M, so every block adds its tile into dW in place: no slabs, no reduce pass, no workspace.  Use it for >= ~256 tiles in total. */
 int mi_gemm_tn_group_bf16(int n, const void* const* dY, const long* ldy, const void* const* X, const long* ldx, float* const* dW, const long* ldo,
-                          float* const* db, const int* M, const int* N, const int* K, const int* n_store, mi_stream_t stream);
+                          float* const* db, const int* M, const int* N, const int* K, const int* n_store, int tile_k, mi_stream_t stream);
+/* (tile_k: k extent of the 256-row output tiles: 128, 256, or 0 = 256 when the problems then still have >= 200 tiles between them, else 128) */
 /* strided batched GEMM C[z1,z2] = alpha * A[z1,z2] · B[z1,z2]^T (+ C): the per-(utterance, head) products of attention backward */
 int mi_bgemm_bf16(const void* A, long a_z1, long a_z2, long a_m, long a_k, const void* B, long b_z1, long b_z2, long b_n, long b_k,
                   void* C, long c_z1, long c_z2, long c_m, int out_f32, int accumulate, float alpha, int Z1, int Z2, int M, int N,

@@ -128,6 +128,36 @@ def test_gemm_tn_weight_gradient(M, N, K, ns, variant):
     torch.testing.assert_close(dw2.cpu(), want, atol=3e-3 * float(want.abs().max()), rtol=1e-3)
 
 
+@pytest.mark.parametrize("tile_k", [128, 256, 0])
+def test_grouped_weight_gradients_one_launch(tile_k):
+    """ops_train.TnBatch / mi_gemm_tn_group_bf16: problems of different M, ragged N / K, stored-row limits and bias gradients as ONE launch, on both output
+    tiles (256 x 128, 256 x 256) and with the entry point choosing; each adds into its dW in place."""
+    ops, T = _o()
+    shapes = [(2000, 512, 512, 512, True), (333, 136, 264, 131, True), (2000, 2048, 512, 2048, False), (777, 64, 1024, 64, True), (1500, 520, 72, 520, False),
+              (2000, 512, 2048, 512, True)]
+    b = T.TnBatch()
+    keep, wants = [], []
+    for i, (M, N, K, ns, bias) in enumerate(shapes):
+        dy, x = bfr(rnd(M, N, seed=10 + i)), bfr(rnd(M, K, seed=30 + i))
+        base = rnd(ns, K, seed=50 + i)
+        dw = base.clone().to(DEV)
+        db = torch.ones(ns, device=DEV) if bias else None
+        T.gemm_tn_(dw, dev16(dy), dev16(x), n_store=ns, db=db, defer=b)
+        keep.append((dw, db, base))
+        wants.append(((dy.t() @ x)[:ns], dy.sum(0)[:ns]))
+    assert len(b.items) == len(shapes) and b.flush(final=False, room=100, tile_k=tile_k) is True          # no room for `room` more: it must run now
+    for (dw, db, base), (want, wb) in zip(keep, wants):
+        torch.testing.assert_close(dw.cpu() - base, want, atol=3e-3 * float(want.abs().max()), rtol=1e-3)
+        if db is not None:
+            torch.testing.assert_close(db.cpu() - 1.0, wb, atol=2e-3 * float(wb.abs().max()) + 1e-3, rtol=1e-3)
+    # a non-final flush of a batch that neither fills the chip nor is about to overflow keeps recording
+    b2 = T.TnBatch()
+    dw = torch.zeros(64, 64, device=DEV)
+    T.gemm_tn_(dw, dev16(rnd(100, 64, seed=1)), dev16(rnd(100, 64, seed=2)), defer=b2)
+    assert b2.flush(final=False) is False and len(b2.items) == 1 and float(dw.abs().max()) == 0.0
+    assert b2.flush() is True and float(dw.abs().max()) > 0.0
+
+
 def test_bgemm_modes():
     ops, T = _o()
     Z1, Z2, M, N, K = 3, 2, 70, 50, 90
