@@ -76,6 +76,20 @@ __device__ __forceinline__ float gelu_tanh(float x) {
     return 0.5f * x * (2.f - 2.f / (e + 1.f));
 }
 
+// derivatives of the two GELUs (training: element-wise kernels, the conv front end's backward, the dX GEMM's training epilogue)
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.f + fast_erf(x * 0.70710678118654752440f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ float gelu_tanh_grad(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float u = k0 * (x + k1 * x * x * x);
+    const float e = __expf(2.f * u);
+    const float th = 1.f - 2.f / (e + 1.f);
+    return 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * k0 * (1.f + 3.f * k1 * x * x);
+}
+
 // Wave-wide reductions by DPP (no LDS round trips: `__shfl_xor` is a ds_bpermute_b32 per step on gfx9, ~100 cycles of latency each, and the
 // small latency-bound kernels — token-step GEMVs, CTC, row statistics — are chains of them).  Within a row of 16 lanes: quad_perm, row_half_mirror,
 // row_mirror leave the row total in every lane; row_bcast:15 / row_bcast:31 carry it across the four rows into lane 63; v_readlane broadcasts it.

@@ -10,11 +10,6 @@ namespace {
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.f + fast_erf(x * 0.70710678118654752440f));
-    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
-}
 
 // ------------------------------------------------------------------------------------------------ depthwise conv backward
 constexpr int DB_TT = 64, DB_CT = 64, DB_KMAX = 31;

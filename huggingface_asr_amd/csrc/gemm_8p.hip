@@ -357,6 +357,89 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
         }
         return;
     }
+    if constexpr (ACT >= 3) {
+        // Training epilogues (gemm_args.hpp): the bf16 rows come back from the staging region as 8 consecutive columns of one row per lane — the layout the
+        // element-wise kernels work in — and are finished there: times act'(saved pre-activation) (3), or stored and also activated into C2 (4).
+        const bool drop = p.drop_p > 0.f;
+        const float inv_keep = drop ? 1.f / (1.f - p.drop_p) : 1.f;
+        const int n8 = p.N >> 3;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            bf16x8 ax[4];
+            if constexpr (ACT == 3) {                      // the four pre-activation vectors of this block's rows: in flight while the block is staged
+#pragma unroll
+                for (int uu = 0; uu < 4; ++uu) {
+                    const int m = m0 + wr * 128 + (blk * 4 + uu) * 8 + prow;
+                    ax[uu] = *reinterpret_cast<const bf16x8*>(p.aux + (long)min(m, p.M - 1) * p.ldaux + nb + pc * 8);
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = blk * 2 + ii;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = acc[i][j] + b4[j];
+                    const bf16x4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+                    const int row = i * 16 + fr;
+                    *reinterpret_cast<bf16x4*>(reg + row * 128 + (((j * 2 + (fq >> 1)) ^ swz) << 4) + (fq & 1) * 8) = o;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+                const int row = (blk * 4 + uu) * 8 + prow;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(reg + row * 128 + ((pc ^ ((row >> 1) & 7)) << 4));
+                const int m = m0 + wr * 128 + row;
+                float ks[8];
+                if (drop) {
+                    const unsigned long long pair0 = ((unsigned long long)m * n8 + ((nb >> 3) + pc)) << 2;      // logical index m * N + n of the first element, halved
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned long long h = mask_hash(p.drop_key, pair0 + e);
+                        ks[2 * e] = mask_u01(h, 0) >= p.drop_p ? inv_keep : 0.f;
+                        ks[2 * e + 1] = mask_u01(h, 1) >= p.drop_p ? inv_keep : 0.f;
+                    }
+                }
+                bf16x8 o;
+                if constexpr (ACT == 3) {
+                    float gr[8];
+                    if (p.aux_kind == 1) {                 // block-uniform branch: ONE of the two derivatives is evaluated (a select would compute both)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gr[e] = gelu_erf_grad(bf2f(ax[uu][e]));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gr[e] = gelu_tanh_grad(bf2f(ax[uu][e]));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float g = drop ? bf2f(f2bf(bf2f(v[e]) * ks[e])) : bf2f(v[e]);
+                        o[e] = f2bf(g * gr[e]);
+                    }
+                    if (m < p.M) *reinterpret_cast<bf16x8*>(C + (long)m * p.ldc + nb + pc * 8) = o;
+                } else {
+                    float ac[8];
+                    if (p.aux_kind == 1) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ac[e] = gelu_erf(bf2f(v[e]));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ac[e] = gelu_tanh(bf2f(v[e]));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        bf16_t r = f2bf(ac[e]);
+                        if (drop) r = f2bf(bf2f(r) * ks[e]);
+                        o[e] = r;
+                    }
+                    if (m < p.M) {
+                        *reinterpret_cast<bf16x8*>(C + (long)m * p.ldc + nb + pc * 8) = v;
+                        *reinterpret_cast<bf16x8*>(p.C2 + (long)m * p.ldc2 + nb + pc * 8) = o;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) {
 #pragma unroll
@@ -745,7 +828,12 @@ bool gemm_8p_supported(const GemmArgs& a, bool conv) {
         if (conv || a.out_f32 || a.gated || a.act > 1 || a.bias_mode != 1 || !a.ln_colsum || ((uintptr_t)a.ln_colsum & 15) || ((uintptr_t)a.ln_stats & 15)) return false;
         if (!(a.ln_npart == 1 || (a.ln_npart >= 4 && a.ln_npart <= 16 && (a.ln_npart % 4) == 0))) return false;
     }
-    if (a.C2 || a.stats_out) return false;       // producer side lives in the 128x128 kernel
+    if (a.act >= 3) {                // training epilogues: plain bf16-out GEMM, 16-B aligned rows of the extra operand
+        if (conv || a.out_f32 || a.gated || a.ln_stats || a.resid || a.col_T || a.act > 4 || (a.aux_kind != 1 && a.aux_kind != 2) || a.drop_p < 0.f || a.drop_p >= 1.f) return false;
+        if (a.act == 3 && (!a.aux || ((uintptr_t)a.aux & 15) || (a.ldaux % 8))) return false;
+        if (a.act == 4 && (!a.C2 || ((uintptr_t)a.C2 & 15) || (a.ldc2 % 8))) return false;
+    } else if (a.C2) return false;
+    if (a.stats_out) return false;               // producer side lives in the 128x128 kernel
     if ((long)a.N * a.ldw * 2 >= (1l << 32)) return false;                                             // 32-bit source offsets
     if (conv) {
         if ((a.Cin % BK) != 0 || a.Fout <= 0 || a.Tout <= 0) return false;
@@ -764,8 +852,19 @@ int gemm_8p_launch(const GemmArgs& a, bool conv, hipStream_t stream) {
             for (int t = 0; t < 3; ++t) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[c][t]), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
         attr_set = true;
     }
-    if (a.act < 0 || a.act > 2) return MI_ERR_ARG;
+    if (a.act < 0 || a.act > 4) return MI_ERR_ARG;
     const int grid = cdiv(a.M, TB) * cdiv(a.N, TB);
+    if (a.act >= 3) {
+        static bool attr_t = false;
+        if (!attr_t) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+            attr_t = true;
+        }
+        if (a.act == 3) launch_dense(PF_8P, gemm8p_kernel<false, 3>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
+        else launch_dense(PF_8P_GELU, gemm8p_kernel<false, 4>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
+        return MI_OK;
+    }
     if (a.out_f32) {
         static bool attr32 = false;
         if (!attr32) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF); attr32 = true; }

@@ -30,6 +30,11 @@ struct GemmArgs {
     //    slot (n0 / 128) * 4 + wave column of the row's 16 (N <= 512)
     const float* ln_stats; int ln_npart; const float* ln_colsum; float ln_eps;
     bf16_t* C2; long ldc2; float* stats_out;
+    // Training epilogues of the 256x256 phase kernel (act = 3 / 4; gemm_8p.hip).  `aux_kind`: 1 erf-GELU, 2 tanh-GELU.  drop_p > 0: the FFN's activation dropout
+    // with the counter-based mask of dropout.hip for logical element m * N + n (key = stream_id << 32 ^ seed), same rounding points as the separate kernels.
+    //  act 3 (backward): C = dropout(bf16(acc)) * act'(aux), aux (M, N) bf16 = the saved pre-activation — the dX GEMM dh = dy W2 and mi_act_bwd in one launch
+    //  act 4 (forward):  C = bf16(acc + bias) (the pre-activation, kept for the backward), C2 = dropout(act(C)) — the FFN-in GEMM and mi_act_fwd in one launch
+    const bf16_t* aux; long ldaux; int aux_kind; float drop_p; unsigned long long drop_key;
 };
 constexpr int LN_STATS_STRIDE = 32;       // floats per row of a partial-statistics buffer (16 (sum, sumsq) pairs)
 

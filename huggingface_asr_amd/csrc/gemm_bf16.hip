@@ -293,6 +293,45 @@ extern "C" int mi_gemm_lnfold_bf16(const void* xb, long lda, const void* Wf, lon
     return MI_OK;
 }
 
+// ---- Training epilogues of the 256x256 phase kernel (gemm_args.hpp, act 3 / 4): the FFN's activation passes ride the GEMMs next to them.
+// Forward: pre (M,N) bf16 = A W^T + b and h (M,N) bf16 = dropout(act(pre)) from one launch (kind 1 erf-GELU / 2 tanh-GELU; drop_p = 0: no dropout; the mask is
+// mi_dropout's for the (M,N) matrix, so the result is bit-identical to mi_gemm_bf16 + mi_act[_dropout]_fwd_bf16).  N % 256 == 0, K % 64 == 0, K >= 128, else MI_ERR_UNSUPPORTED.
+// replaces: Wav2Vec2ConformerFeedForward.forward's intermediate_dense + intermediate_act_fn + intermediate_dropout (tf wav2vec2_conformer :350-354) under autograd.
+extern "C" int mi_gemm_act_fwd_bf16(const void* A, long lda, const void* W, long ldw, const float* bias, void* pre, long ldp, void* h, long ldh, int kind,
+                                    float drop_p, unsigned seed, unsigned stream_id, int M, int N, int K, hipStream_t stream) {
+    MI_ENTER();
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw; a.bias = bias; a.bias_mode = bias ? 1 : 0;
+    a.C = pre; a.ldc = ldp; a.out_f32 = 0; a.alpha = 1.f; a.act = 4; a.M = M; a.N = N; a.K = K;
+    a.C2 = (bf16_t*)h; a.ldc2 = ldh; a.aux_kind = kind; a.drop_p = drop_p; a.drop_key = ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed;
+    if (!A || !W || !pre || !h) return MI_ERR_ARG;
+    if (!gemm_8p_supported(a, false)) return MI_ERR_UNSUPPORTED;
+    const int slot = mi_profile_hook_begin(stream, 2.0 * M * N * K);
+    const int rc = gemm_8p_launch(a, false, stream);
+    if (slot >= 0) mi_profile_hook_end(slot, stream);
+    if (rc != MI_OK) return rc;
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+// Backward: dX (M,N) bf16 = dropout(bf16(dY Wt^T)) * act'(pre) — Wt (N,K) is the transposed weight copy the trainer keeps (dh = dy W2 as a GEMM over its rows),
+// pre (M,N) bf16 the saved pre-activation; bit-identical to mi_gemm_bf16 + mi_act[_dropout]_bwd_bf16.  Same shape limits.
+extern "C" int mi_gemm_act_bwd_bf16(const void* dY, long ldy, const void* Wt, long ldw, const void* pre, long ldp, void* dX, long ldx, int kind,
+                                    float drop_p, unsigned seed, unsigned stream_id, int M, int N, int K, hipStream_t stream) {
+    MI_ENTER();
+    GemmArgs a{};
+    a.A = (const bf16_t*)dY; a.lda = ldy; a.W = (const bf16_t*)Wt; a.ldw = ldw; a.bias = nullptr; a.bias_mode = 0;
+    a.C = dX; a.ldc = ldx; a.out_f32 = 0; a.alpha = 1.f; a.act = 3; a.M = M; a.N = N; a.K = K;
+    a.aux = (const bf16_t*)pre; a.ldaux = ldp; a.aux_kind = kind; a.drop_p = drop_p; a.drop_key = ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed;
+    if (!dY || !Wt || !pre || !dX) return MI_ERR_ARG;
+    if (!gemm_8p_supported(a, false)) return MI_ERR_UNSUPPORTED;
+    const int slot = mi_profile_hook_begin(stream, 2.0 * M * N * K);
+    const int rc = gemm_8p_launch(a, false, stream);
+    if (slot >= 0) mi_profile_hook_end(slot, stream);
+    if (rc != MI_OK) return rc;
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
 // Producer: C (M,N) fp32 = resid + alpha * (A W^T + b) (resid may be C), and in the same epilogue C2 (M,N) bf16 = the stored rows, stats_out = their per-row partial
 // (sum, sumsq) pairs (slot = 32-column block of the row, N / 32 <= 16 pairs, row stride 32 floats).  128x128 phase kernel only: N % 128 == 0, N <= 512, K % 128 == 0, K >= 320.
 extern "C" int mi_gemm_resid_stats_f32(const void* A, long lda, const void* W, long ldw, const float* bias, float* C, long ldc, const float* resid, long ldr, float alpha,

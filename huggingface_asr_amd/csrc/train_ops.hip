@@ -108,19 +108,6 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
 }
 
 // ------------------------------------------------------------------------------------------------ activations
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.f + fast_erf(x * 0.70710678118654752440f));
-    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
-}
-__device__ __forceinline__ float gelu_tanh_grad(float x) {
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    const float u = k0 * (x + k1 * x * x * x);
-    const float e = __expf(2.f * u);
-    const float th = 1.f - 2.f / (e + 1.f);
-    return 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * k0 * (1.f + 3.f * k1 * x * x);
-}
-
 // MODE 0: out = act(a);  MODE 1: out = a * act'(b)   (a = dy, b = pre-activation);  kind 1 erf-GELU, 2 tanh-GELU
 // DROP: the activation dropout of the FFN (tf wav2vec2_conformer :353) applied in the same pass — forward out = dropout(act(a)), backward
 // out = dropout(a) * act'(b) — with the mask of dropout.hip for logical index m * N + n and the same bf16 rounding points as the two-pass form

@@ -68,6 +68,38 @@ def act_fwd(pre, kind="gelu", out=None, drop=None):
     return out
 
 
+def gemm_act_fwd(a, w, bias, kind="gelu", drop=None):
+    """(pre, h) = (a W^T + b, dropout(act(pre))) — the FFN-in GEMM with the activation pass in its epilogue where the 256 x 256 kernel takes the shape
+    (N % 256 == 0, K % 64 == 0, K >= 128), else the GEMM followed by act_fwd; bit-identical either way."""
+    M, K = a.shape
+    N = w.shape[0]
+    pre = torch.empty((M, N), device=a.device, dtype=BF16)
+    h = torch.empty((M, N), device=a.device, dtype=BF16)
+    p, seed, sid = drop if drop is not None else (0.0, 0, 0)
+    rc = _L().mi_gemm_act_fwd_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _p(bias), pre.data_ptr(), pre.stride(0), h.data_ptr(), h.stride(0),
+                                   KIND[kind], float(p), int(seed) & 0xFFFFFFFF, int(sid) & 0xFFFFFFFF, M, N, K, _stream())
+    if rc == -3:                     # shape outside the fused kernel: the two launches
+        gemm(a, w, bias, out=pre)
+        return pre, act_fwd(pre, kind, out=h, drop=drop)
+    _lib.check(rc, "mi_gemm_act_fwd_bf16")
+    return pre, h
+
+
+def gemm_act_bwd(dy, wT, pre, kind="gelu", drop=None):
+    """dropout(dy wT^T) * act'(pre): the dX GEMM of the FFN's output linear with the activation backward in its epilogue (same shape rule / fallback as gemm_act_fwd).
+    wT (N, K) = rows of the transposed weight copy, pre (M, N) bf16."""
+    M, K = dy.shape
+    N = pre.shape[1]
+    out = torch.empty((M, N), device=dy.device, dtype=BF16)
+    p, seed, sid = drop if drop is not None else (0.0, 0, 0)
+    rc = _L().mi_gemm_act_bwd_bf16(dy.data_ptr(), dy.stride(0), wT.data_ptr(), wT.stride(0), pre.data_ptr(), pre.stride(0), out.data_ptr(), out.stride(0),
+                                   KIND[kind], float(p), int(seed) & 0xFFFFFFFF, int(sid) & 0xFFFFFFFF, M, N, K, _stream())
+    if rc == -3:
+        return act_bwd(gemm(dy, wT), pre, kind, out=out, drop=drop)
+    _lib.check(rc, "mi_gemm_act_bwd_bf16")
+    return out
+
+
 def act_bwd(dy, pre, kind="gelu", out=None, drop=None):
     """out = dy * act'(pre); with drop = (p, seed, stream_id): out = dropout(dy) * act'(pre) (the backward of act_fwd(..., drop=...))."""
     M, N = pre.shape

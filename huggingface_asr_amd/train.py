@@ -688,8 +688,7 @@ class EncoderCTCTrainer:
             if pd["att"] > 0:
                 T.dropout_(cat[:, :d], pd["att"], seed, self._sid(sl, 3))
             # local branch (cgMLP)
-            hp = ops.gemm(a2, W(p + "mlp_w1"), P(p + "mlp_b1"))
-            h = T.act_fwd(hp)
+            hp, h = T.gemm_act_fwd(a2, W(p + "mlp_w1"), P(p + "mlp_b1"))
             stats = ops.row_stats(h[:, I // 2:])
             cv = lin = None
             if self.csgu_split:                              # e_branchformer.py:196-201: conv -> [Linear] -> act -> gate
@@ -958,8 +957,8 @@ class EncoderCTCTrainer:
         M, d = x.shape
         a = e16(M, d)
         LN(x, lna=(P(pre + "_ln_g"), P(pre + "_ln_b")), outa=a)
-        hp = ops.gemm(a, W(pre + "_w1"), P(pre + "_b1"))
-        h = T.act_fwd(hp, drop=(pd["act"], self.seed, self._sid(l, sites[0])) if pd["act"] > 0 else None)      # GELU + activation dropout in one pass
+        # intermediate_dense + GELU + activation dropout: one launch (the GEMM's training epilogue leaves the pre-activation for the backward and the activation)
+        hp, h = T.gemm_act_fwd(a, W(pre + "_w1"), P(pre + "_b1"), drop=(pd["act"], self.seed, self._sid(l, sites[0])) if pd["act"] > 0 else None)
         if pd["hidden"] > 0:
             y = T.dropout_add(x, ops.gemm(h, W(pre + "_w2"), P(pre + "_b2"), out_dtype=F32), 0.5, pd["hidden"], self.seed, self._sid(l, sites[1]))
         else:
@@ -974,8 +973,9 @@ class EncoderCTCTrainer:
             dyb = T.dropout_(dx, pd["hidden"], self.seed, self._sid(l, sites[1]), out=torch.empty(dx.shape, device=dx.device, dtype=BF16), alpha=0.5)
         else:
             dyb = T.add_cast(dx, alpha=0.5)
-        dh = T.linear_bwd(dyb, S["h"], WT(pre + "_w2"), dw=GL(pre + "_w2"), db=GL(pre + "_b2"), defer=self._tnb)
-        dhp = T.act_bwd(dh, S["hp"], drop=(pd["act"], self.seed, self._sid(l, sites[0])) if pd["act"] > 0 else None)
+        # dh = dy W2 with the activation (+ dropout) backward in the GEMM's epilogue; the weight / bias gradients of W2 go to the layer's grouped launch
+        dhp = T.gemm_act_bwd(dyb, WT(pre + "_w2")[:, :dyb.shape[1]], S["hp"], drop=(pd["act"], self.seed, self._sid(l, sites[0])) if pd["act"] > 0 else None)
+        T.linear_bwd(dyb, S["h"], WT(pre + "_w2"), dw=GL(pre + "_w2"), db=GL(pre + "_b2"), need_dx=False, defer=self._tnb)
         da = T.linear_bwd(dhp, S["a"], WT(pre + "_w1"), dw=GL(pre + "_w1"), db=GL(pre + "_b1"), defer=self._tnb)
         T.layernorm_bwd(x_in, P(pre + "_ln_g"), da, dx, accumulate=True, **self._lng(pre + "_ln_g", pre + "_ln_b"))
 

@@ -86,6 +86,14 @@ int mi_conv2d_cl_geo_bf16(const void* in, const void* weight, const float* bias,
  * blk > 0: z == g is the output of one stacked GEMM whose columns are interleaved [conv blk | gate blk] per 2*blk (share must be 1). */
 int mi_gated_act_bf16(const void* z, long ldz, const void* g, long ldg, void* out, long ldo, int B, int T, int Fq, int C, int share, int blk, mi_stream_t stream);
 
+/* Training epilogues of the 256 x 256 GEMM: the FFN's activation passes ride the GEMMs next to them (bit-identical to the GEMM + mi_act[_dropout]_{fwd,bwd}_bf16 pair).
+ * forward: pre (M,N) bf16 = A W^T + b, h (M,N) bf16 = dropout(act(pre)); kind 1 erf-GELU / 2 tanh-GELU; drop_p = 0: none; mask of mi_dropout for (seed, stream_id).
+ * backward: dX (M,N) bf16 = dropout(bf16(dY Wt^T)) * act'(pre), Wt (N,K) the transposed weight.  N % 256 == 0, K % 64 == 0, K >= 128, else MI_ERR_UNSUPPORTED.
+ * replaces: Wav2Vec2ConformerFeedForward's intermediate_dense + intermediate_act_fn + intermediate_dropout (tf wav2vec2_conformer :350-354) and their autograd backward. */
+int mi_gemm_act_fwd_bf16(const void* A, long lda, const void* W, long ldw, const float* bias, void* pre, long ldp, void* h, long ldh, int kind,
+                         float drop_p, unsigned seed, unsigned stream_id, int M, int N, int K, mi_stream_t stream);
+int mi_gemm_act_bwd_bf16(const void* dY, long ldy, const void* Wt, long ldw, const void* pre, long ldp, void* dX, long ldx, int kind,
+                         float drop_p, unsigned seed, unsigned stream_id, int M, int N, int K, mi_stream_t stream);
 /* ---- LayerNorm folded into the GEMMs around it (the engine's `ln_fold` path).  replaces: the same nn.LayerNorm + nn.Linear pairs as mi_layernorm_chain + mi_gemm_bf16
  *      (e_branchformer.py:233,236,242,261 in front of tf wav2vec2_conformer :350-357, e_branchformer.py:96-98,212), evaluated as
  *      LN(x) W^T + b = rstd (bf16(x) W'^T) - rstd mu s + (W beta + b),  W' = bf16(W diag(gamma)),  s_n = sum_k W'[n,k].

@@ -158,6 +158,27 @@ def test_grouped_weight_gradients_one_launch(tile_k):
     assert b2.flush() is True and float(dw.abs().max()) > 0.0
 
 
+@pytest.mark.parametrize("kind", ["gelu", "gelu_new"])
+@pytest.mark.parametrize("M,N,K,p", [(1000, 512, 256, 0.0), (777, 1024, 512, 0.1), (300, 136, 72, 0.1)])       # the last shape is outside the fused kernel: two launches
+def test_ffn_activation_passes_in_the_gemm_epilogues(M, N, K, p, kind):
+    """mi_gemm_act_fwd_bf16 / mi_gemm_act_bwd_bf16 against the GEMM + element-wise pair they replace: identical bits, with and without activation dropout."""
+    ops, T = _o()
+    a, w, b = dev16(rnd(M, K, seed=1)), dev16(rnd(N, K, seed=2, scale=0.1)), rnd(N, seed=3).to(DEV)
+    drop = (p, 1234, 77) if p > 0 else None
+    pre_want = ops.gemm(a, w, b)
+    h_want = T.act_fwd(pre_want, kind, drop=drop)
+    pre, h = T.gemm_act_fwd(a, w, b, kind, drop=drop)
+    assert torch.equal(pre, pre_want) and torch.equal(h, h_want)
+    # values: against torch on the bf16-rounded pre-activation
+    ref = F.gelu(pre_want.float().cpu(), approximate="none" if kind == "gelu" else "tanh")
+    if drop is None:
+        close(h, ref, floor=4e-3, what="act")
+    dy, wt = dev16(rnd(M, K, seed=4)), dev16(rnd(N, K, seed=5, scale=0.1))                  # dh = dy (M,K) · wt^T, wt (N,K) rows of the transposed weight
+    want = T.act_bwd(ops.gemm(dy, wt), pre_want, kind, drop=drop)
+    got = T.gemm_act_bwd(dy, wt, pre_want, kind, drop=drop)
+    assert torch.equal(got, want)
+
+
 def test_bgemm_modes():
     ops, T = _o()
     Z1, Z2, M, N, K = 3, 2, 70, 50, 90
