@@ -780,12 +780,12 @@ template <int HD>
 int launch_lds_bw(const AttnArgs& a, bool rel, hipStream_t stream) {
     dim3 grid(cdiv(a.T, 128), a.H, a.B), block(256);
     const size_t lds = (size_t)(2 + 2 + 6) * 32 * HD * 2 + 4 * WSCR_B + 4 * 32 * BAND_B;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_lds_kernel<HD, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_lds_kernel<HD, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static const bool attr_set = [&] {          // once per head size (function-local static initialiser: thread-safe)
+        const bool a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_lds_kernel<HD, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        const bool a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_lds_kernel<HD, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        return a1 && a2;
+    }();
+    (void)attr_set;
     if (rel) hipLaunchKernelGGL((attn_lds_kernel<HD, true, true>), grid, block, lds, stream, a);
     else hipLaunchKernelGGL((attn_lds_kernel<HD, false, true>), grid, block, lds, stream, a);
     MI_CHECK_LAUNCH();

@@ -212,48 +212,51 @@ __global__ __launch_bounds__(256) void dwconv31_bwd_kernel(DwBwdArgs p, float* _
         g0 = *reinterpret_cast<const f32x4*>(p.gamma + c0 + ch8 * 8); g1 = *reinterpret_cast<const f32x4*>(p.gamma + c0 + ch8 * 8 + 4);
         b0 = *reinterpret_cast<const f32x4*>(p.beta + c0 + ch8 * 8);  b1 = *reinterpret_cast<const f32x4*>(p.beta + c0 + ch8 * 8 + 4);
     }
+    // The global loads of a tile (3 passes x {conv input, output gradient, gate operand, row statistics}) are all issued before the first is consumed, and — round 3 —
+    // those of tile n + 1 are issued as soon as tile n's have gone to LDS, so they fly during tile n's arithmetic and stores: one block per CU (97 KiB of LDS) walks
+    // an utterance's 4-8 tiles, and each tile used to start with a full memory round trip and nothing else to run.
+    constexpr int NPI = (FB_ROWS * (FB_CT / 8) + 255) / 256;
+    struct Fill { bf16x8 vx[NPI], vg[NPI], vr[NPI]; float mu[NPI], rs[NPI]; };
+    auto fetch = [&](int t0, Fill& f) {
+#pragma unroll
+        for (int q = 0; q < NPI; ++q) {                                // branch-free: out-of-range rows read a clamped (valid) row and are zeroed when they go to LDS
+            const int id = tid + q * 256, r = id >> 3;
+            const int t = t0 - 15 + r;
+            const long row = (long)b * p.T + min(max(t, 0), p.T - 1);
+            f.vx[q] = *reinterpret_cast<const bf16x8*>(p.x + row * p.ldx + c0 + ch8 * 8);
+            f.vg[q] = *reinterpret_cast<const bf16x8*>(p.dy + row * p.lddy + c0 + ch8 * 8);
+            f.mu[q] = 0.f; f.rs[q] = 0.f;
+            f.vr[q] = f.vg[q];
+            if (CSGU) {
+                f.mu[q] = p.stats[2 * row]; f.rs[q] = p.stats[2 * row + 1];
+                f.vr[q] = *reinterpret_cast<const bf16x8*>(p.r + row * p.ldr + c0 + ch8 * 8);
+            }
+        }
+    };
+    Fill cur, nxt;
+    fetch(0, cur);
     for (int t0 = 0; t0 < p.T; t0 += FB_TT) {
         __syncthreads();
-        // every global load of the tile (5 passes x {conv input, output gradient, gate operand, row statistics}) is issued before the first is
-        // consumed: one block per CU (97 KiB of LDS), so a pass-by-pass load -> wait -> ds_write loop would expose a memory round trip per pass
         {
-            constexpr int NPI = (FB_ROWS * (FB_CT / 8) + 255) / 256;
-            bf16x8 vx[NPI], vg[NPI], vr[NPI];
-            float mu[NPI], rs[NPI];
-            bool ok[NPI];
-#pragma unroll
-            for (int q = 0; q < NPI; ++q) {                                // branch-free: out-of-range rows read a clamped (valid) row and are zeroed below
-                const int id = tid + q * 256, r = id >> 3;
-                const int t = t0 - 15 + r;
-                ok[q] = id < FB_ROWS * (FB_CT / 8) && t >= 0 && t < p.T;
-                const long row = (long)b * p.T + min(max(t, 0), p.T - 1);
-                vx[q] = *reinterpret_cast<const bf16x8*>(p.x + row * p.ldx + c0 + ch8 * 8);
-                vg[q] = *reinterpret_cast<const bf16x8*>(p.dy + row * p.lddy + c0 + ch8 * 8);
-                mu[q] = 0.f; rs[q] = 0.f;
-                vr[q] = vg[q];
-                if (CSGU) {
-                    mu[q] = p.stats[2 * row]; rs[q] = p.stats[2 * row + 1];
-                    vr[q] = *reinterpret_cast<const bf16x8*>(p.r + row * p.ldr + c0 + ch8 * 8);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < NPI; ++q) {
                 const int id = tid + q * 256, r = id >> 3;
                 if (id >= FB_ROWS * (FB_CT / 8)) continue;
+                const int t = t0 - 15 + r;
+                const bool ok = t >= 0 && t < p.T;
                 f32x4 xl = {0.f, 0.f, 0.f, 0.f}, xh = xl, dl = xl, dh = xl;
-                if (ok[q]) {
+                if (ok) {
                     float f[8], e[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { f[j] = bf2f(vx[q][j]); e[j] = bf2f(vg[q][j]); }
+                    for (int j = 0; j < 8; ++j) { f[j] = bf2f(cur.vx[q][j]); e[j] = bf2f(cur.vg[q][j]); }
                     if (CSGU) {
                         const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
-                            f[j] = (f[j] - mu[q]) * rs[q] * gm[j] + bt[j];
-                            e[j] *= bf2f(vr[q][j]);
+                            f[j] = (f[j] - cur.mu[q]) * cur.rs[q] * gm[j] + bt[j];
+                            e[j] *= bf2f(cur.vr[q][j]);
                         }
-                        if (r >= 15 && r < 15 + FB_TT) *reinterpret_cast<bf16x8*>(io + (r - 15) * FB_CT + ch8 * 8) = vg[q];
+                        if (r >= 15 && r < 15 + FB_TT) *reinterpret_cast<bf16x8*>(io + (r - 15) * FB_CT + ch8 * 8) = cur.vg[q];
                     }
                     xl = f32x4{f[0], f[1], f[2], f[3]}; xh = f32x4{f[4], f[5], f[6], f[7]};
                     dl = f32x4{e[0], e[1], e[2], e[3]}; dh = f32x4{e[4], e[5], e[6], e[7]};
@@ -264,6 +267,9 @@ __global__ __launch_bounds__(256) void dwconv31_bwd_kernel(DwBwdArgs p, float* _
                 *reinterpret_cast<f32x4*>(tile_d + r * FB_CT + ch8 * 8 + 4) = dh;
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(min(t0 + FB_TT, (p.T - 1) / FB_TT * FB_TT), nxt);           // unconditional: the last tile re-reads itself (no branch for the compiler to wait at)
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         float xw[FB_PER + FB_K - 1], dwn[FB_PER + FB_K - 1];
 #pragma unroll
@@ -306,6 +312,8 @@ __global__ __launch_bounds__(256) void dwconv31_bwd_kernel(DwBwdArgs p, float* _
                 *reinterpret_cast<bf16x8*>(p.dx + row * p.lddx + c0 + ch * 8) = *reinterpret_cast<const bf16x8*>(io + r * FB_CT + ch * 8);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
     }
     // reduce the 4 time groups' tap gradients through LDS, store this utterance's partial
     __syncthreads();

@@ -842,49 +842,46 @@ bool gemm_8p_supported(const GemmArgs& a, bool conv) {
     return true;
 }
 
+// kernel attributes are set once per kernel behind C++11 function-local static initialisers (thread-safe; the library keeps no other process state for the GEMMs)
+template <typename K>
+static bool set_lds_attr(K kernel, int bytes) { return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess; }
+
 int gemm_8p_launch(const GemmArgs& a, bool conv, hipStream_t stream) {
     using kern_t = void (*)(GemmArgs);
     static const kern_t kerns[2][3] = {{gemm8p_kernel<false, 0>, gemm8p_kernel<false, 1>, gemm8p_kernel<false, 2>},
                                        {gemm8p_kernel<true, 0>, gemm8p_kernel<true, 1>, gemm8p_kernel<true, 2>}};
-    static bool attr_set = false;
-    if (!attr_set) {
+    static const bool attr_set = [] {
+        bool ok = true;
         for (int c = 0; c < 2; ++c)
-            for (int t = 0; t < 3; ++t) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[c][t]), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
-        attr_set = true;
-    }
+            for (int t = 0; t < 3; ++t) ok = set_lds_attr(kerns[c][t], 2 * BUF) && ok;
+        return ok;
+    }();
+    (void)attr_set;
     if (a.act < 0 || a.act > 4) return MI_ERR_ARG;
     const int grid = cdiv(a.M, TB) * cdiv(a.N, TB);
     if (a.act >= 3) {
-        static bool attr_t = false;
-        if (!attr_t) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
-            attr_t = true;
-        }
+        static const bool attr_t = set_lds_attr(gemm8p_kernel<false, 3>, 2 * BUF) && set_lds_attr(gemm8p_kernel<false, 4>, 2 * BUF);
+        (void)attr_t;
         if (a.act == 3) launch_dense(PF_8P, gemm8p_kernel<false, 3>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
         else launch_dense(PF_8P_GELU, gemm8p_kernel<false, 4>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
         return MI_OK;
     }
     if (a.out_f32) {
-        static bool attr32 = false;
-        if (!attr32) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF); attr32 = true; }
+        static const bool attr32 = set_lds_attr(gemm8p_kernel<false, 0, true>, 2 * BUF);
+        (void)attr32;
         launch_dense(PF_8P_OUT32, gemm8p_kernel<false, 0, true>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
         return MI_OK;
     }
     if (a.ln_stats) {
-        static bool attr_l = false;
-        if (!attr_l) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<false, 0, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF + 2048);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<false, 1, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF + 2048);
-            attr_l = true;
-        }
+        static const bool attr_l = set_lds_attr(gemm8p_kernel<false, 0, false, false, true>, 2 * BUF + 2048) && set_lds_attr(gemm8p_kernel<false, 1, false, false, true>, 2 * BUF + 2048);
+        (void)attr_l;
         if (a.act) launch_dense(PF_8P_GELU, gemm8p_kernel<false, 1, false, false, true>, dim3(grid), dim3(512), (size_t)2 * BUF + 2048, stream, a);
         else launch_dense(PF_8P, gemm8p_kernel<false, 0, false, false, true>, dim3(grid), dim3(512), (size_t)2 * BUF + 2048, stream, a);
         return MI_OK;
     }
     if (a.gated) {
-        static bool attr_g = false;
-        if (!attr_g) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<true, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF); attr_g = true; }
+        static const bool attr_g = set_lds_attr(gemm8p_kernel<true, 1, false, true>, 2 * BUF);
+        (void)attr_g;
         launch_dense(PF_8P_CONV, gemm8p_kernel<true, 1, false, true>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
         return MI_OK;
     }
@@ -907,15 +904,12 @@ bool gemm_8p128_supported(const GemmArgs& a) {
 }
 
 int gemm_8p128_launch(const GemmArgs& a, int ring, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p128_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * B128_BUF);
-        attr_set = true;
-    }
+    static const bool attr_set = set_lds_attr(gemm8p128_kernel<4>, 4 * B128_BUF);
+    (void)attr_set;
     const int grid = cdiv(a.M, 128) * (a.N / 128);
     if (ring == 0) {          // register-pipelined form (even number of K tiles)
-        static bool attr_p = false;
-        if (!attr_p) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p128p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * B128_BUF); attr_p = true; }
+        static const bool attr_p = set_lds_attr(gemm8p128p_kernel, 4 * B128_BUF);
+        (void)attr_p;
         launch_dense(PF_8P128, gemm8p128p_kernel, dim3(grid), dim3(512), (size_t)4 * B128_BUF, stream, a);
         return MI_OK;
     }
