@@ -37,6 +37,10 @@ struct TnArgs {
     long slab_stride;
     float* db;                     // optional: db[n] += sum_m dY[m][n] (bias gradient), taken from the dY tiles already staged in LDS
     int M, N, K, n_store, splits, rows_per_split;
+    // conv != 0: X is not a matrix but a channels-last activation (B, Tin, Fin, Cin) and row m = (b, to, fo), column k = (kh * KW + kw) * Cin + c address
+    // X[b][to * cst - cpt + kh][fo * cst - cpf + kw][c] (zero outside): the im2col operand of a Conv2d weight gradient, gathered by the LDS-DMA source addresses
+    // instead of being written to HBM first (Cin a multiple of the k tile: a tile's columns stay inside one tap)
+    int conv, Tin, Fin, Cin, Tout, Fout, KW, cst, cpt, cpf;
 };
 
 // 16-B chunk swizzle of a tile row.  256-B rows (16 chunks): chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)) — the transposed read's 32-lane half takes 4 consecutive rows x
@@ -107,7 +111,21 @@ __device__ __forceinline__ void tn_tile(const TnArgs& p, const int bid) {
         } else {
             const int row = (g - YP) * RPX + rsubX, cs = lane % XCH;
             const int c = (cs ^ swz<XCH>(row)) * 8;
-            coloff[q] = k0 + c < p.K ? k0 + c : -1;
+            coloff[q] = k0 + c < p.K ? (p.conv ? k0 % p.Cin + c : k0 + c) : -1;
+        }
+    }
+    const int ctap = p.conv ? k0 / p.Cin : 0, ckh = p.conv ? ctap / p.KW : 0, ckw = p.conv ? ctap % p.KW : 0;       // block-uniform
+    // conv: (b, to, fo) of each X piece's row, decoded once and advanced by the stage's 64 rows with carries (no divisions between a barrier and the DMA it releases)
+    int cb_[PPW], cto[PPW], cfo[PPW];
+    const int adv_f = TN_KM % max(p.Fout, 1), adv_t = TN_KM / max(p.Fout, 1);
+    if (p.conv) {
+        const unsigned ctf = (unsigned)(p.Tout * p.Fout);
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            const int g = wave * PPW + q;
+            const unsigned um = (unsigned)(m_lo + (g - YP) * RPX + rsubX);
+            const unsigned b = um / ctf, rem = um - b * ctf, to = rem / (unsigned)p.Fout;
+            cb_[q] = (int)b; cto[q] = (int)to; cfo[q] = (int)(rem - to * (unsigned)p.Fout);
         }
     }
     auto issue = [&](int it, int stage) {
@@ -121,6 +139,15 @@ __device__ __forceinline__ void tn_tile(const TnArgs& p, const int bid) {
             const bf16_t* base = isY ? p.Y : p.X;
             const long ld = isY ? p.ldy : p.ldx;
             const bf16_t* sp = (m < m_hi && coloff[q] >= 0) ? base + (long)m * ld + coloff[q] : reinterpret_cast<const bf16_t*>(&g_zero16);
+            if (p.conv && !isY) {                            // gathered im2col row (wave-uniform branch); stages are issued in order, so the carried indices are this stage's
+                const int ti = cto[q] * p.cst - p.cpt + ckh, fi = cfo[q] * p.cst - p.cpf + ckw;
+                const bool in = m < m_hi && coloff[q] >= 0 && ti >= 0 && ti < p.Tin && fi >= 0 && fi < p.Fin;
+                sp = in ? p.X + (((long)cb_[q] * p.Tin + ti) * p.Fin + fi) * p.Cin + coloff[q] : reinterpret_cast<const bf16_t*>(&g_zero16);
+                int fo = cfo[q] + adv_f, to = cto[q] + adv_t;
+                if (fo >= p.Fout) { fo -= p.Fout; ++to; }
+                while (to >= p.Tout) { to -= p.Tout; ++cb_[q]; }
+                cfo[q] = fo; cto[q] = to;
+            }
             __builtin_amdgcn_global_load_lds((gptr_t)sp, (lptr_t)(sbase + q * 1024), 16, 0, 0);
         }
     };
@@ -259,6 +286,7 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g) {
     TnArgs p;
     p.Y = q.Y; p.ldy = q.ldy; p.X = q.X; p.ldx = q.ldx; p.out = q.out; p.ldo = q.ldo; p.slab_stride = 0; p.db = q.db;
     p.M = q.M; p.N = q.N; p.K = q.K; p.n_store = q.n_store; p.splits = 1; p.rows_per_split = (q.M + TN_KM - 1) / TN_KM * TN_KM;
+    p.conv = 0; p.Tin = p.Fin = p.Cin = p.Tout = p.Fout = p.KW = 1; p.cst = 1; p.cpt = p.cpf = 0;
     tn_tile<TN_GROUP_N, XW, TN_GROUP_NS>(p, bid - __builtin_amdgcn_readfirstlane(g.tile0[iu]));
 }
 
@@ -318,6 +346,39 @@ extern "C" int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx
         const long g = (total + 255) / 256;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, st, dW, ldo, (const float*)workspace, p.slab_stride,
                            splits, n_store, K);
+        MI_CHECK_LAUNCH();
+    }
+    return MI_OK;
+}
+
+// Conv2d weight gradient without an im2col buffer: dW (n_store, KH*KW*Cin) fp32 += dY[:, :N]^T · im2col(x), x (B, Tin, Fin, Cin) bf16 channels-last, rows of dY = (b, to, fo),
+// k = (kh * KW + kw) * Cin + c; square stride, pads (pad_t, pad_f) on the leading side (the causal front end passes 2 * pad).  Cin % 128 == 0.  Workspace as for
+// mi_gemm_tn_bf16 with M = B * Tout * Fout, K = KH * KW * Cin.  replaces: the weight gradient autograd derives for extractors.py:82-89's second Conv2d.
+extern "C" int mi_conv2d_wgrad_cl_bf16(const void* dY, long ldy, const void* x, float* dW, long ldo, float* db, int B, int Tin, int Fin, int Cin, int KH, int KW,
+                                       int stride, int pad_t, int pad_f, int Tout, int Fout, int N, int n_store, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    MI_ENTER();
+    const long Ml = (long)B * Tout * Fout;
+    const int K = KH * KW * Cin;
+    if (B <= 0 || Tin <= 0 || Fin <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || Tout <= 0 || Fout <= 0 || N <= 0 || (N % 8) || (ldy % 8) || n_store > N || n_store <= 0) return MI_ERR_ARG;
+    if ((Cin % 128) || Ml >= (1l << 31) || (long)B * Tin * Fin * Cin >= (1l << 40)) return MI_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(dY) & 15) || (reinterpret_cast<uintptr_t>(x) & 15) || !dW) return MI_ERR_ARG;
+    const int M = (int)Ml;
+    const int splits = tn_splits(M, N, K, 0);
+    if (splits > 1 && workspace_bytes < (size_t)splits * N * K * sizeof(float)) return MI_ERR_ARG;
+    TnArgs p{};
+    p.Y = (const bf16_t*)dY; p.ldy = ldy; p.X = (const bf16_t*)x; p.ldx = Cin;
+    p.M = M; p.N = N; p.K = K; p.n_store = n_store; p.splits = splits; p.db = db;
+    p.rows_per_split = cdiv(cdiv(M, splits), TN_KM) * TN_KM;
+    if (splits > 1) { p.out = (float*)workspace; p.ldo = K; p.slab_stride = (long)N * K; }
+    else { p.out = dW; p.ldo = ldo; p.slab_stride = 0; }
+    p.conv = 1; p.Tin = Tin; p.Fin = Fin; p.Cin = Cin; p.Tout = Tout; p.Fout = Fout; p.KW = KW; p.cst = stride; p.cpt = pad_t; p.cpf = pad_f;
+    const int tiles = cdiv(N, TN_T) * cdiv(K, 128);
+    hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(tiles * splits), dim3(256), (size_t)2 * TN_KM * (TN_T * 2 + 256), st, p);
+    MI_CHECK_LAUNCH();
+    if (splits > 1) {
+        const long total = (long)n_store * K;
+        const long g = (total + 255) / 256;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, st, dW, ldo, (const float*)workspace, p.slab_stride, splits, n_store, K);
         MI_CHECK_LAUNCH();
     }
     return MI_OK;

@@ -343,6 +343,23 @@ def im2col(x, K, stride, pad, T1, F1):
     return col
 
 
+def conv2d_wgrad_(dw, dy, x, K, stride, pad, T1, F1, db=None, n_store=None):
+    """dw (n_store, K*K*Cin) f32 += dy[:, :N]^T · im2col(x) without the im2col buffer (the gather happens in the GEMM's LDS-DMA source addresses);
+    x (B,T,F,Cin) bf16 channels-last, dy (B*T1*F1, N) bf16, pad = the leading pad.  Cin % 128 != 0: the im2col + gemm_tn_ pair."""
+    B, T, F, Cin = x.shape
+    M, N = dy.shape
+    n_store = dw.shape[0] if n_store is None else n_store
+    if Cin % 128:
+        return gemm_tn_(dw, dy, im2col(x, K, stride, pad, T1, F1), n_store=n_store, db=db)
+    nbytes = _L().mi_gemm_tn_workspace_bytes(M, N, K * K * Cin)
+    ws = _TN_WS.get(dy.device)
+    if nbytes and (ws is None or ws.numel() < nbytes):
+        ws = _TN_WS[dy.device] = torch.empty(nbytes, device=dy.device, dtype=torch.uint8)
+    _lib.check(_L().mi_conv2d_wgrad_cl_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), dw.data_ptr(), dw.stride(0), _p(db), B, T, F, Cin, K, K, stride, pad, pad,
+                                            T1, F1, N, n_store, ws.data_ptr() if nbytes else 0, nbytes, _stream()), "mi_conv2d_wgrad_cl_bf16")
+    return dw
+
+
 def im2col_geo(x, K, stride, pad, T1, F1):
     """im2col with (time, freq) kernel / stride / pad pairs"""
     B, T, F, Cin = x.shape

@@ -876,10 +876,8 @@ class EncoderCTCTrainer:
         dact2 = T.linear_bwd(T.add_cast(dfeo), act2, WT("feout_w"), dw=GL("feout_w"), db=GL("feout_b"))      # (M, F2*C2)
         if cm == 0:
             dpre2 = T.act_bwd(dact2.view(B * T2 * F2, C2), pre2)
-            col = T.im2col(act1, K, s_, padl, T2, F2)
-            T.gemm_tn_(G("conv2_w"), dpre2, col, db=G("conv2_b"))
+            T.conv2d_wgrad_(G("conv2_w"), dpre2, act1, K, s_, padl, T2, F2, db=G("conv2_b"))      # the im2col operand is gathered inside the GEMM, never written
             dcol = ops.gemm(dpre2, WT("conv2_w")[:, :C2])
-            del col
             T.conv2d_first_bwd(feats, P("conv1_w"), P("conv1_b"), dcol, G("conv1_w"), G("conv1_b"), K, s_, padl, T1, F1, K, s_, padl, T2, F2)
         else:
             # y = z * sigmoid(g), out = GELU(y): dz = dout GELU'(y) sigmoid(g), dg = sum over the rows sharing g of dout GELU'(y) z sigmoid(g)(1 - sigmoid(g));

@@ -281,6 +281,11 @@ int mi_adamw_step(float* p, const float* g, float* m, float* v, const unsigned c
 size_t mi_gemm_tn_workspace_bytes(int M, int N, int K);
 int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx, float* dW, long ldo, float* db /* optional bias gradient */, int M, int N,
                     int K, int n_store, void* workspace, size_t workspace_bytes, int variant /* 0 = product tile (128 x 128); 1 = 128 x 64 for A/B */, mi_stream_t stream);
+/* Conv2d weight gradient without an im2col buffer: dW (n_store, KH*KW*Cin) fp32 += dY[:, :N]^T · im2col(x); x (B,Tin,Fin,Cin) bf16 channels-last, dY rows (b,to,fo),
+ * k = (kh*KW + kw)*Cin + c, square stride, leading pads (pad_t, pad_f); Cin % 128 == 0 else MI_ERR_UNSUPPORTED; workspace: mi_gemm_tn_workspace_bytes(B*Tout*Fout, N, KH*KW*Cin).
+ * replaces: the weight gradient autograd derives for the second Conv2d of extractors.py:82-89. */
+int mi_conv2d_wgrad_cl_bf16(const void* dY, long ldy, const void* x, float* dW, long ldo, float* db, int B, int Tin, int Fin, int Cin, int KH, int KW,
+                            int stride, int pad_t, int pad_f, int Tout, int Fout, int N, int n_store, void* workspace, size_t workspace_bytes, mi_stream_t stream);
 /* grouped form: the weight-gradient GEMMs of one encoder layer (n <= 48 problems, host arrays of length n) as ONE launch — together their 128 x 128 output tiles fill the
  * chip without splitting M, so every block adds its tile into dW in place: no slabs, no reduce pass, no workspace.  Use it for >= ~256 tiles in total. */
 int mi_gemm_tn_group_bf16(int n, const void* const* dY, const long* ldy, const void* const* X, const long* ldx, float* const* dW, const long* ldo,

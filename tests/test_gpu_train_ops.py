@@ -179,6 +179,32 @@ def test_ffn_activation_passes_in_the_gemm_epilogues(M, N, K, p, kind):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("B,T1,F1,Cin,Cout,pad", [(2, 61, 39, 128, 256, 1), (3, 50, 19, 256, 64, 2), (1, 9, 7, 128, 136, 1)])
+def test_conv2d_weight_gradient_without_the_im2col_buffer(B, T1, F1, Cin, Cout, pad):
+    """mi_conv2d_wgrad_cl_bf16 (rows of the im2col operand gathered by the GEMM's LDS-DMA addresses) against im2col + the row-contraction GEMM and against torch."""
+    ops, T = _o()
+    K, st = 3, 2
+    # the kernels take the LEADING pad only (the trailing side follows from T2 / F2): a geometry where every window starts inside the input
+    T2, F2 = (T1 + pad - K) // st + 1, (F1 + pad - K) // st + 1
+    x = bfr(rnd(B, T1, F1, Cin, seed=1))
+    dy = bfr(rnd(B * T2 * F2, Cout, seed=2))
+    xd, dyd = dev16(x), dev16(dy)
+    col = T.im2col(xd, K, st, pad, T2, F2)
+    want = torch.zeros(Cout, K * K * Cin, device=DEV); wb = torch.zeros(Cout, device=DEV)
+    T.gemm_tn_(want, dyd, col, db=wb)
+    got = torch.zeros(Cout, K * K * Cin, device=DEV); gb = torch.zeros(Cout, device=DEV)
+    T.conv2d_wgrad_(got, dyd, xd, K, st, pad, T2, F2, db=gb)
+    torch.testing.assert_close(got, want, atol=1e-4 * float(want.abs().max()), rtol=1e-5)
+    torch.testing.assert_close(gb, wb, atol=1e-4 * float(wb.abs().max()), rtol=1e-5)
+    # and the definition: conv weight gradient of torch on the leading-padded input
+    xp = F.pad(x.permute(0, 3, 1, 2), (pad, K, pad, K)).requires_grad_(False)            # generous trailing pad: windows that run past it read zeros
+    w = torch.zeros(Cout, Cin, K, K, requires_grad=True)
+    y = F.conv2d(xp, w, stride=st)[:, :, :T2, :F2]
+    y.backward(dy.view(B, T2, F2, Cout).permute(0, 3, 1, 2))
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Cout, K * K * Cin)
+    close(got, ref, rel=1e-2, floor=3e-3, what="conv2 weight gradient")
+
+
 def test_bgemm_modes():
     ops, T = _o()
     Z1, Z2, M, N, K = 3, 2, 70, 50, 90
