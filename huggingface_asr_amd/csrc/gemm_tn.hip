@@ -273,7 +273,13 @@ constexpr int TN_GROUP_NS = 2, TN_GROUP_N = 256;           // 256 (n) x XW (k) t
 // larger tile is used whenever the recorded problems still give (nearly) every CU a block: two base-size layers per launch.
 template <int XW>
 __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g) {
-    const int bid = blockIdx.x;
+    // XCD-aware tile order: the hardware deals consecutive block ids round-robin over the 8 XCDs (each with its own L2), so XCD x works through one contiguous run of
+    // the tile list — the tiles of one or two problems, which share their dY / X stage tiles — instead of every XCD pulling every problem's operands (worth 1.6 %)
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
     int lo = 0, hi = g.n - 1;                                // the last problem whose first tile is <= bid
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
