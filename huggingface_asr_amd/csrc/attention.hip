@@ -36,6 +36,9 @@ struct AttnArgs {
     bf16_t* dbd; long ldbd; int pad;     // (H, B, T, ldbd): dBD[i][T-1-i+j + pad] = dS[i][j] (the inverse of the rel-shift), zero elsewhere; ldbd a multiple of 32
     bf16_t* dq; long lddq;               // (B*T, .) gradient of the query projection: dS K (+ dBD P with relative positions), accumulated over the walk
     float* dsum_u; float* dsum_v;        // (B, 4 ceil(T/128), H*HD): per-wave column sums of dS K and dBD P — the pos_bias_u / pos_bias_v gradients once summed
+    // attention-probability dropout (e_branchformer.py:132) in the LDS-staged kernel, training forward and backward: the counter-based mask of dropout.hip for the
+    // logical element ((h * B + b) * T + i) * Tk + j of the (H, B, T, Tk) probabilities — the same mask the generic softmax kernels (attn_bwd.hip) and the host twin draw
+    float drop_p; unsigned long long drop_key;
 };
 
 // 16-B chunk swizzle of the LDS-staged kernel's tiles (applied on the DMA source and on every read).  256-B rows (hd 128): the image that is conflict-free for ds_read_b128
@@ -50,6 +53,27 @@ constexpr int OST_B = 272;    // LDS-staged kernel, output staging: bytes per qu
 constexpr int WSCR_B = 32 * OST_B;   // per-wave scratch of the LDS-staged kernel: skew rows (32 x 66 words) | Q tile (8 KiB, prologue) | output rows (epilogue)
 
 __device__ __forceinline__ int crow(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+// keep factors (0 or 1 / (1 - p)) of a lane's 16 score registers of one 32-key step: register e is key j0 + crow(e, half); idx0 = logical index of key j0 of the
+// lane's query row.  One hash per PAIR of logical indices (common.hpp): a run of four consecutive keys takes two hashes, three when it starts odd (Tk odd only).
+__device__ __forceinline__ void keep16(unsigned long long key, float p, unsigned long long idx0, int half, bool tk_odd, float (&ks)[16]) {
+    const float inv = 1.f / (1.f - p);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        const unsigned long long s = idx0 + 8 * g4 + 4 * half, p0 = s >> 1;
+        const unsigned long long h0 = mask_hash(key, p0), h1 = mask_hash(key, p0 + 1);
+        unsigned long long h2 = h1;
+        if (tk_odd) h2 = mask_hash(key, p0 + 2);           // wave-uniform
+        const bool odd = (s & 1) != 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // even start: (h0 e, h0 o, h1 e, h1 o); odd start: (h0 o, h1 e, h1 o, h2 e)
+            const unsigned long long he = k < 2 ? h0 : h1, ho = k == 0 ? h0 : (k == 3 ? h2 : h1);
+            const float u = odd ? mask_u01(ho, (k & 1) == 0 ? 1 : 0) : mask_u01(he, k & 1);
+            ks[4 * g4 + k] = u >= p ? inv : 0.f;
+        }
+    }
+}
 
 template <int HD, bool REL>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
@@ -354,6 +378,7 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
     }
     // BW: where this wave's rows live in the three outputs; the band's block `it` is columns [cb0 + 32 it, +32) of dBD
     const long orow0 = ((long)head * p.B + b) * T + i0;
+    const unsigned long long drop_row0 = (unsigned long long)(((long)head * p.B + b) * T + min(i0 + r, T - 1)) * (unsigned long long)Tk;     // logical index of this lane's query row, key 0
     const int cb0 = T - 32 + p.pad - i0;                     // a multiple of 32 (the host chose pad so)
     const int srow = lane >> 2, sch = lane & 3;              // staging read-back: 16 rows x four 16-B chunks per instruction
 
@@ -537,10 +562,23 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
                     D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dc[ks], D, 0, 0, 0);
                 }
             }
+            if (p.drop_p > 0.f) {
+                // the forward multiplied V by P keep / (1 - p): dctx V^T is the gradient of THAT, delta = dctx · ctx already is sum_j P_j keep_j dP_j, and the P that
+                // leaves for dV = P^T dctx is the dropped one
+                float ks[16];
+                keep16(p.drop_key, p.drop_p, drop_row0 + (unsigned long long)j0, h2, (Tk & 1) != 0, ks);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                S[e] = __builtin_amdgcn_exp2f(S[e] - lse2);
-                D[e] = S[e] * (D[e] - delta) * p.scale;
+                for (int e = 0; e < 16; ++e) {
+                    const float pr = __builtin_amdgcn_exp2f(S[e] - lse2);
+                    D[e] = pr * (D[e] * ks[e] - delta) * p.scale;
+                    S[e] = pr * ks[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    S[e] = __builtin_amdgcn_exp2f(S[e] - lse2);
+                    D[e] = S[e] * (D[e] - delta) * p.scale;
+                }
             }
             {
                 bf16x8 db[2];
@@ -609,6 +647,12 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
                 ls += S[e];
             }
             l += half_swap_sum(ls);
+            if (p.drop_p > 0.f) {                            // probability dropout (training forward): the normaliser keeps every key, the PV product the survivors / (1 - p)
+                float ks[16];
+                keep16(p.drop_key, p.drop_p, drop_row0 + (unsigned long long)j0, h2, (Tk & 1) != 0, ks);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) S[e] *= ks[e];
+            }
             bf16x8 pb[2];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
@@ -853,15 +897,16 @@ extern "C" int mi_attention_qkv_bf16(const void* q, long ldq, const void* k, lon
 extern "C" int mi_attention_qkv_lse_bf16(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                                          const void* pos, long ldp, const float* bias_u, const float* bias_v,
                                          const int* lengths, void* out, long ldo, float* lse, int B, int T, int H, int hd,
-                                         float scale, int causal, hipStream_t stream) {
+                                         float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, hipStream_t stream) {
     MI_ENTER();
-    if (B <= 0 || T <= 0 || H <= 0 || !lse) return MI_ERR_ARG;
+    if (B <= 0 || T <= 0 || H <= 0 || !lse || drop_p < 0.f || drop_p >= 1.f) return MI_ERR_ARG;
     if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 8) || ((uintptr_t)out & 15)) return MI_ERR_ARG;
     if (ldq >= (1l << 30) || ldk <= 0 || ldv <= 0 || ldk >= (1l << 30) || ldv >= (1l << 30) || ldp >= (1l << 30)) return MI_ERR_ARG;
     if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15)) return MI_ERR_ARG;
     if (pos && ((ldp % 8) || ((uintptr_t)pos & 15) || !bias_u || !bias_v)) return MI_ERR_ARG;
     AttnArgs a{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, 0, (const bf16_t*)pos, ldp,
                bias_u, bias_v, lengths, (bf16_t*)out, ldo, B, T, H, scale, causal, 0, 0, lse};
+    a.drop_p = drop_p; a.drop_key = ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed;
     switch (hd) {
         case 64: return launch_lds<64>(a, pos != nullptr, stream);
         case 128: return launch_lds<128>(a, pos != nullptr, stream);
@@ -879,9 +924,9 @@ extern "C" int mi_attention_qkv_bwd_probs(const void* q, long ldq, const void* k
                                           const void* ctx, long ldo, const void* dctx, long ldd, const float* lse,
                                           void* prob, void* ds, long ldsr, void* dbd, long ldbd, int pad,
                                           void* dq, long lddq, float* dsum_u, float* dsum_v,
-                                          int B, int T, int H, int hd, float scale, int causal, hipStream_t stream) {
+                                          int B, int T, int H, int hd, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, hipStream_t stream) {
     MI_ENTER();
-    if (B <= 0 || T <= 0 || H <= 0 || !lse || !ctx || !dctx || !prob || !ds || !dq) return MI_ERR_ARG;
+    if (B <= 0 || T <= 0 || H <= 0 || !lse || !ctx || !dctx || !prob || !ds || !dq || drop_p < 0.f || drop_p >= 1.f) return MI_ERR_ARG;
     if ((lddq % 8) || lddq >= (1l << 30) || ((uintptr_t)dq & 15) || (pos && (!dsum_u || !dsum_v))) return MI_ERR_ARG;
     if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 8) || (ldd % 8)) return MI_ERR_ARG;
     if (ldq >= (1l << 30) || ldk <= 0 || ldv <= 0 || ldk >= (1l << 30) || ldv >= (1l << 30) || ldp >= (1l << 30) || ldo >= (1l << 30) || ldd >= (1l << 30)) return MI_ERR_ARG;
@@ -894,7 +939,7 @@ extern "C" int mi_attention_qkv_bwd_probs(const void* q, long ldq, const void* k
     AttnArgs a{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, 0, (const bf16_t*)pos, ldp,
                bias_u, bias_v, lengths, (bf16_t*)const_cast<void*>(ctx), ldo, B, T, H, scale, causal, 0, 0, const_cast<float*>(lse),
                (const bf16_t*)dctx, ldd, (bf16_t*)prob, (bf16_t*)ds, ldsr, (bf16_t*)dbd, pos ? ldbd : 0, pos ? pad : 0,
-               (bf16_t*)dq, lddq, dsum_u, dsum_v};
+               (bf16_t*)dq, lddq, dsum_u, dsum_v, drop_p, ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed};
     switch (hd) {
         case 64: return launch_lds_bw<64>(a, pos != nullptr, stream);
         case 128: return launch_lds_bw<128>(a, pos != nullptr, stream);

@@ -234,12 +234,13 @@ def band_geometry(T: int):
     return pad, (pad + 2 * T - 1 + 31) // 32 * 32
 
 
-def attn_bwd_probs(qkv, B, T, H, ctx, dctx, lse, dq, *, pos=None, bias_u=None, bias_v=None, lengths=None, causal=False):
+def attn_bwd_probs(qkv, B, T, H, ctx, dctx, lse, dq, *, pos=None, bias_u=None, bias_v=None, lengths=None, causal=False, drop=None):
     """First half of the fused attention backward (head size 64 / 128, no probability dropout): -> prob, ds (H, B, T, Ts) bf16 and, with relative positions,
     dbd (H, B, T, Ps) bf16 with dbd[i][T-1-i+j + pad] = ds[i][j] (else None).  Ts = T rounded up to 32; (pad, Ps) = band_geometry(T).  Everything is written.
     dq (B*T, d) bf16 row view receives the query gradient dS K + dBD P; with positions also -> (su, sv): (rows, d) fp32 whose column sums are the gradients
-    of pos_bias_u / pos_bias_v."""
+    of pos_bias_u / pos_bias_v.  drop = the (p, seed, stream_id) the forward used: prob is then the DROPPED probabilities (what multiplied V)."""
     d = qkv.shape[1] // 3
+    dp, dseed, dsid = drop if drop is not None else (0.0, 0, 0)
     hd = d // H
     Ts = (T + 31) // 32 * 32
     pad, Ps = band_geometry(T)
@@ -256,7 +257,7 @@ def attn_bwd_probs(qkv, B, T, H, ctx, dctx, lse, dq, *, pos=None, bias_u=None, b
                                                _p(pos), pos.stride(0) if rel else 0, _p(bias_u), _p(bias_v), _p(lengths),
                                                ctx.data_ptr(), ctx.stride(0), dctx.data_ptr(), dctx.stride(0), lse.data_ptr(),
                                                prob.data_ptr(), ds.data_ptr(), Ts, _p(dbd), Ps, pad, dq.data_ptr(), dq.stride(0), _p(su), _p(sv),
-                                               B, T, H, hd, 1.0 / math.sqrt(hd), int(causal), _stream()),
+                                               B, T, H, hd, 1.0 / math.sqrt(hd), int(causal), float(dp), int(dseed) & 0xFFFFFFFF, int(dsid) & 0xFFFFFFFF, _stream()),
                "mi_attention_qkv_bwd_probs")
     return prob, ds, dbd, su, sv
 

@@ -980,11 +980,11 @@ class EncoderCTCTrainer:
     def _attention_fwd(self, qkv, posp, u, v, lengths, B, Tt, H, S, drop=None):
         d = qkv.shape[1] // 3
         hd = d // H
-        if hd in (64, 128) and drop is None:
-            # the fused kernel; it leaves the rows' log-sum-exp for the backward's recomputation (ops_train.attn_bwd_probs)
+        if hd in (64, 128):
+            # the fused kernel (probability dropout, e_branchformer.py:132, included); it leaves the rows' log-sum-exp for the backward's recomputation (ops_train.attn_bwd_probs)
             S["lse"] = torch.empty((B, H, Tt), device=qkv.device, dtype=F32)
-            return ops.attention_qkv(qkv, B, Tt, H, pos=posp, bias_u=u, bias_v=v, lengths=lengths, causal=self.causal, lse=S["lse"])
-        # probability dropout (e_branchformer.py:132) or small heads (test configs): probabilities through the generic pieces,
+            return ops.attention_qkv(qkv, B, Tt, H, pos=posp, bias_u=u, bias_v=v, lengths=lengths, causal=self.causal, lse=S["lse"], drop=drop)
+        # small heads (test configs): probabilities through the generic pieces,
         # kept for the backward pass; the dropped copy feeds the PV product
         prob = self._probs(qkv, posp, u, v, lengths, B, Tt, H, S, drop)
         if drop is not None:
@@ -1032,11 +1032,11 @@ class EncoderCTCTrainer:
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         dqkv = torch.empty((M, 3 * d), device=dev, dtype=BF16)
         Pn = 2 * Tt - 1
-        if "lse" in S and drop is None:
+        if "lse" in S:
             # fused forward: ONE walk over the keys recomputes the scores and leaves P, dS and the un-shifted dBD (bf16) — no fp32 score-sized tensors — and
             # accumulates dQ = dS K + dBD P on the way (its two terms' column sums are the position-bias gradients)
             prob, ds, dbd, su, sv = T.attn_bwd_probs(qkv, B, Tt, H, S["ctx"], dctx, S["lse"], dqkv[:, :d], pos=posp, bias_u=P(p + "att_u") if rel else None,
-                                                     bias_v=P(p + "att_v") if rel else None, lengths=lengths, causal=self.causal)
+                                                     bias_v=P(p + "att_v") if rel else None, lengths=lengths, causal=self.causal, drop=drop)
             fused = True
             if rel:
                 qu, qv = T.add_rowvec(q, P(p + "att_u")), T.add_rowvec(q, P(p + "att_v"))

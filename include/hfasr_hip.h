@@ -146,7 +146,9 @@ int mi_attention_qkv_bf16(const void* q, long ldq, const void* k, long ldk, cons
 int mi_attention_qkv_lse_bf16(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                               const void* pos, long ldp, const float* bias_u, const float* bias_v,
                               const int* lengths, void* out, long ldo, float* lse, int B, int T, int H, int hd,
-                              float scale, int causal, mi_stream_t stream);
+                              float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, mi_stream_t stream);
+/* (drop_p > 0: attention-probability dropout, e_branchformer.py:132 — the normaliser keeps every key, the context sums the survivors / (1 - p); mask of mi_dropout for the
+ *  logical element ((h*B + b)*T + i)*T + j of the (H,B,T,T) probabilities, the one mi_attn_softmax_fwd draws) */
 /* First half of the attention backward (what autograd derives from e_branchformer.py:105-138 and the rel-shift of tf wav2vec2_conformer :528-565): one walk over
  * the keys recomputes the scores, P = 2^(S - lse), dP = dctx V^T, dS = P (dP - dctx·ctx) scale, and leaves bf16
  *   prob, ds (H, B, T, ldsr)   and   dbd (H, B, T, ldbd), dbd[i][T-1-i+j + pad] = ds[i][j]  (the gradient of the un-shifted position scores; null without pos).
@@ -158,7 +160,8 @@ int mi_attention_qkv_bwd_probs(const void* q, long ldq, const void* k, long ldk,
                                const void* ctx, long ldo, const void* dctx, long ldd, const float* lse,
                                void* prob, void* ds, long ldsr, void* dbd, long ldbd, int pad,
                                void* dq, long lddq, float* dsum_u, float* dsum_v,
-                               int B, int T, int H, int hd, float scale, int causal, mi_stream_t stream);
+                               int B, int T, int H, int hd, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, mi_stream_t stream);
+/* (drop_p / seed / stream_id as given to the forward: prob then holds the DROPPED probabilities, ds the gradient through the un-dropped softmax) */
 
 /* ---- cgMLP gate: per-row LN statistics + fused LN -> depthwise conv(time) -> gate.
  * replaces: ConvolutionalSpatialGatingUnit.forward e_branchformer.py:184-204. */

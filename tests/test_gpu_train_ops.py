@@ -275,9 +275,10 @@ def test_attn_softmax_fwd_bwd(rel, causal, masked, Tq):
         close(dbd, bd.grad, floor=2e-2, what="dbd vs autograd")
 
 
-@pytest.mark.parametrize("T_,H,hd,rel,causal", [(250, 4, 128, True, False), (97, 2, 64, True, False), (75, 2, 64, False, False), (130, 2, 128, False, True),
-                                                (33, 1, 128, True, False), (160, 2, 64, True, True), (500, 2, 128, True, False)])
-def test_attention_backward_recomputation(T_, H, hd, rel, causal):
+@pytest.mark.parametrize("T_,H,hd,rel,causal,pdrop", [(250, 4, 128, True, False, 0.0), (97, 2, 64, True, False, 0.0), (75, 2, 64, False, False, 0.0), (130, 2, 128, False, True, 0.0),
+                                                      (33, 1, 128, True, False, 0.0), (160, 2, 64, True, True, 0.0), (500, 2, 128, True, False, 0.0),
+                                                      (250, 4, 128, True, False, 0.1), (97, 2, 64, True, False, 0.25), (75, 2, 64, False, True, 0.1)])
+def test_attention_backward_recomputation(T_, H, hd, rel, causal, pdrop):
     """mi_attention_qkv_bwd_probs (P, dS and the un-shifted dBD from one walk over the keys, given the fused forward's context and log-sum-exp) against
     autograd of the oracle-style attention: scores (q+u)k^T + rel_shift((q+v)p^T), key-padding / causal mask, softmax, P V."""
     ops, T = _o()
@@ -305,6 +306,12 @@ def test_attention_backward_recomputation(T_, H, hd, rel, causal):
     if causal:
         dead = dead | torch.ones(Tq, Tq, dtype=torch.bool).triu(1)[None, None]
     prob = torch.softmax(s.masked_fill(dead, float("-inf")), -1)
+    drop = None
+    if pdrop > 0:          # attention-probability dropout (e_branchformer.py:132) with the kernels' own counter-based mask, regenerated on the host
+        from huggingface_asr_amd import synth
+        drop = (pdrop, 4321, 55)
+        keep = torch.from_numpy(synth.dropout_keep(drop[1], drop[2], H * B * Tq * Tq, pdrop).reshape(H, B, Tq, Tq)).float()
+        prob = prob * keep / (1.0 - pdrop)          # what multiplies V (and what the backward kernel leaves as `prob`)
     ctx = prob @ vh
     ctx.backward(dctx.view(B, Tq, H, hd).permute(2, 0, 1, 3))
     ds_want = ac.grad / 1.0                                    # d loss / d(score before the scale) = P (dP - delta) scale
@@ -318,7 +325,7 @@ def test_attention_backward_recomputation(T_, H, hd, rel, causal):
     kw = dict(pos=None if pos is None else dev16(pos), bias_u=None if u is None else u.to(DEV), bias_v=None if vb is None else vb.to(DEV),
               lengths=lengths.to(DEV), causal=causal)
     lse = torch.empty((B, H, Tq), device=DEV, dtype=torch.float32)
-    ctx_k = ops.attention_qkv(qkv, B, Tq, H, lse=lse, **kw)
+    ctx_k = ops.attention_qkv(qkv, B, Tq, H, lse=lse, drop=drop, **kw)
     close(ctx_k.view(B, Tq, H, hd).permute(2, 0, 1, 3), ctx.detach(), floor=1e-2, what="context (lse form)")
     lse_want = torch.logsumexp(s.detach().masked_fill(dead, float("-inf")), -1).permute(1, 0, 2) / math.log(2.0)
     assert (lse.cpu() - lse_want).abs().max() < 2e-2, "log-sum-exp (log2 domain)"
@@ -327,7 +334,7 @@ def test_attention_backward_recomputation(T_, H, hd, rel, causal):
     pad, Ps = T.band_geometry(Tq)
     assert (Tq - 32 + pad) % 32 == 0 and Ps % 32 == 0 and Ps >= pad + 2 * Tq - 1
     dqk = torch.full((B * Tq, 3 * d), float("nan"), device=DEV, dtype=BF)[:, :d]          # a strided row view, as the trainer's dqkv[:, :d]
-    pk, dsk, dbdk, su, sv = T.attn_bwd_probs(qkv, B, Tq, H, ctx_k, dev16(dctx), lse, dqk, **kw)
+    pk, dsk, dbdk, su, sv = T.attn_bwd_probs(qkv, B, Tq, H, ctx_k, dev16(dctx), lse, dqk, drop=drop, **kw)
     assert pk.shape == (H, B, Tq, Ts) and (dbdk is None) == (not rel)
     close(dqk.view(B, Tq, H, hd).permute(2, 0, 1, 3), dq_want, floor=2e-2, what="dQ")
     if rel:
@@ -347,7 +354,7 @@ def test_attention_backward_recomputation(T_, H, hd, rel, causal):
         assert torch.equal(torch.gather(dbdk, 3, idx[None, None].expand(H, B, Tq, Tq)), dsk[..., :Tq])
     # second call on poisoned buffers gives the same bits (nothing depends on what the outputs held)
     dqk2 = torch.empty_like(dqk)
-    pk2, dsk2, dbdk2, su2, sv2 = T.attn_bwd_probs(qkv, B, Tq, H, ctx_k, dev16(dctx), lse, dqk2, **kw)
+    pk2, dsk2, dbdk2, su2, sv2 = T.attn_bwd_probs(qkv, B, Tq, H, ctx_k, dev16(dctx), lse, dqk2, drop=drop, **kw)
     assert torch.equal(pk, pk2) and torch.equal(dsk, dsk2) and (not rel or torch.equal(dbdk, dbdk2)) and torch.equal(dqk, dqk2)
     assert not rel or (torch.equal(su, su2) and torch.equal(sv, sv2))
 
