@@ -107,6 +107,7 @@ SIGNATURES = {
     "mi_adamw_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, vp, vp],
     "mi_gemm_tn_workspace_bytes": [i32, i32, i32],
     "mi_gemm_tn_bf16": [vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, i32, vp, sz, i32, vp],
+    "mi_gemm_dropout_bf16": [vp, i64, vp, i64, vp, vp, i64, i32, vp, i64, f32, f32, C.c_uint, C.c_uint, i32, i32, i32, vp],
     "mi_gemm_act_fwd_bf16": [vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, f32, C.c_uint, C.c_uint, i32, i32, i32, vp],
     "mi_gemm_act_bwd_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, i32, f32, C.c_uint, C.c_uint, i32, i32, i32, vp],
     "mi_conv2d_wgrad_cl_bf16": [vp, i64, vp, vp, i64, vp] + [i32] * 13 + [vp, C.c_size_t, vp],

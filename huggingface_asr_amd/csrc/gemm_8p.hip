@@ -773,8 +773,15 @@ __global__ __launch_bounds__(512, 2) void gemm8p128p_kernel(GemmArgs p) {
         for (int u = 0; u < 8; ++u) {
             const int row = u * 8 + prow;
             f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * 128 + ((pc ^ ((row >> 1) & 7)) << 4));
-            if (use_res) v = rres[u] + p.alpha * v;
             const int m = m0 + wr * 64 + row;
+            if (p.drop_p > 0.f) {            // dropout of the linear's output before the residual add (training: hidden / final dropout): mask of mi_dropout_add_f32 for (m, n)
+                const unsigned long long pair0 = ((unsigned long long)m * (unsigned)(p.N >> 2) + (unsigned)((nb >> 2) + pc)) << 1;
+                const unsigned long long h0 = mask_hash(p.drop_key, pair0), h1 = mask_hash(p.drop_key, pair0 + 1);
+                const float ik = 1.f / (1.f - p.drop_p);
+                v = f32x4{v.x * (mask_u01(h0, 0) >= p.drop_p ? ik : 0.f), v.y * (mask_u01(h0, 1) >= p.drop_p ? ik : 0.f),
+                          v.z * (mask_u01(h1, 0) >= p.drop_p ? ik : 0.f), v.w * (mask_u01(h1, 1) >= p.drop_p ? ik : 0.f)};
+            }
+            if (use_res) v = rres[u] + p.alpha * v;
             if (m < p.M) *reinterpret_cast<f32x4*>(C + (long)m * p.ldc + nb + pc * 4) = v;
             // LayerNorm-fold producer (gemm_args.hpp): the bf16 copy of the stored row segment and its partial (sum, sumsq) — 8 lanes hold a row's 32 columns
             if (p.C2 && m < p.M) *reinterpret_cast<bf16x4*>(p.C2 + (long)m * p.ldc2 + nb + pc * 4) = bf16x4{f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
@@ -804,8 +811,20 @@ __global__ __launch_bounds__(512, 2) void gemm8p128p_kernel(GemmArgs p) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = u * 16 + r4;
-            const uint4 v = *reinterpret_cast<const uint4*>(reg + row * 128 + ((c4 ^ ((row >> 1) & 3)) << 4));
+            uint4 v = *reinterpret_cast<const uint4*>(reg + row * 128 + ((c4 ^ ((row >> 1) & 3)) << 4));
             const int m = m0 + wr * 64 + row;
+            if (p.drop_p > 0.f) {            // dropout on the bf16 rows (mask and rounding of mi_dropout's bf16 form for element m * N + n)
+                bf16x8 e = __builtin_bit_cast(bf16x8, v);
+                const unsigned long long pair0 = ((unsigned long long)m * (unsigned)(p.N >> 3) + (unsigned)((nb >> 3) + c4)) << 2;
+                const float ik = 1.f / (1.f - p.drop_p);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned long long h = mask_hash(p.drop_key, pair0 + q);
+                    e[2 * q] = f2bf(bf2f(e[2 * q]) * (mask_u01(h, 0) >= p.drop_p ? ik : 0.f));
+                    e[2 * q + 1] = f2bf(bf2f(e[2 * q + 1]) * (mask_u01(h, 1) >= p.drop_p ? ik : 0.f));
+                }
+                v = __builtin_bit_cast(uint4, e);
+            }
             if (m < p.M) *reinterpret_cast<uint4*>(C + (long)m * p.ldc + nb + c4 * 8) = v;
         }
     }

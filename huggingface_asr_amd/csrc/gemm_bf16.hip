@@ -332,6 +332,26 @@ extern "C" int mi_gemm_act_bwd_bf16(const void* dY, long ldy, const void* Wt, lo
     return MI_OK;
 }
 
+// C (M,N) = [resid +] alpha * dropout(A W^T + b): the hidden / final / attention-output dropout of the training forward (and of gradients flowing back through such a site)
+// in the epilogue of the 128 x 128 kernel — fp32 out with optional fp32 residual (mask of mi_dropout_add_f32), or bf16 out (mask and rounding of mi_dropout's bf16 form).
+// N % 128 == 0, K % 128 == 0, K >= 320, else MI_ERR_UNSUPPORTED (the caller runs the GEMM and the dropout kernel).
+extern "C" int mi_gemm_dropout_bf16(const void* A, long lda, const void* W, long ldw, const float* bias, void* C, long ldc, int out_f32, const float* resid, long ldr,
+                                    float alpha, float drop_p, unsigned seed, unsigned stream_id, int M, int N, int K, hipStream_t stream) {
+    MI_ENTER();
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw; a.bias = bias; a.bias_mode = bias ? 1 : 0;
+    a.C = C; a.ldc = ldc; a.out_f32 = out_f32; a.resid = resid; a.ldr = ldr; a.alpha = alpha; a.act = 0; a.M = M; a.N = N; a.K = K;
+    a.drop_p = drop_p; a.drop_key = ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed;
+    if (!A || !W || !C || drop_p < 0.f || drop_p >= 1.f || (!out_f32 && (resid || alpha != 1.f))) return MI_ERR_ARG;
+    if ((K % 128) != 0 || !gemm_8p128_supported(a)) return MI_ERR_UNSUPPORTED;
+    const int slot = mi_profile_hook_begin(stream, 2.0 * M * N * K);
+    const int rc = gemm_8p128_launch(a, 0, stream);
+    if (slot >= 0) mi_profile_hook_end(slot, stream);
+    if (rc != MI_OK) return rc;
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
 // Producer: C (M,N) fp32 = resid + alpha * (A W^T + b) (resid may be C), and in the same epilogue C2 (M,N) bf16 = the stored rows, stats_out = their per-row partial
 // (sum, sumsq) pairs (slot = 32-column block of the row, N / 32 <= 16 pairs, row stride 32 floats).  128x128 phase kernel only: N % 128 == 0, N <= 512, K % 128 == 0, K >= 320.
 extern "C" int mi_gemm_resid_stats_f32(const void* A, long lda, const void* W, long ldw, const float* bias, float* C, long ldc, const float* resid, long ldr, float alpha,

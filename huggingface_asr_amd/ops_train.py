@@ -299,6 +299,26 @@ def dropout_(x, p, seed, stream_id, out=None, alpha=1.0):
     return out
 
 
+def gemm_dropout(a, w, bias, p, seed, stream_id, *, resid=None, alpha=1.0, out=None):
+    """[resid +] alpha * dropout(a W^T + b): fp32 (M,N) when `resid` is given (the residual add of a dropped linear output), else bf16 (out may be a column view);
+    one launch where the 128 x 128 kernel takes the shape, else the GEMM followed by the dropout kernel — same mask either way."""
+    M, K = a.shape
+    N = w.shape[0]
+    f32 = resid is not None
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=F32 if f32 else BF16)
+    rc = _L().mi_gemm_dropout_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _p(bias), out.data_ptr(), out.stride(0), int(f32),
+                                   _p(resid), resid.stride(0) if f32 else 0, float(alpha), float(p), int(seed) & 0xFFFFFFFF, int(stream_id) & 0xFFFFFFFF,
+                                   M, N, K, _stream())
+    if rc == -3:
+        if f32:
+            return dropout_add(resid, gemm(a, w, bias, out_dtype=F32), alpha, p, seed, stream_id)
+        gemm(a, w, bias, out=out)
+        return dropout_(out, p, seed, stream_id)
+    _lib.check(rc, "mi_gemm_dropout_bf16")
+    return out
+
+
 def dropout_add(resid, t, alpha, p, seed, stream_id):
     """resid + alpha * dropout(t)  (f32 (M,N))."""
     M, N = t.shape

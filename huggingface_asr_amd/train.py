@@ -684,9 +684,10 @@ class EncoderCTCTrainer:
                 posp = ops.gemm(pos[0], W(p + "att_wpos"))
             ctx = self._attention_fwd(qkv, posp, P(p + "att_u") if posp is not None else None, P(p + "att_v") if posp is not None else None,
                                       inner, B, T2, H, S, (pd["att"], seed, self._sid(sl, 2)) if pd["att"] > 0 else None)
-            ops.gemm(ctx, W(p + "att_wo"), P(p + "att_bo"), out=cat[:, :d])
-            if pd["att"] > 0:
-                T.dropout_(cat[:, :d], pd["att"], seed, self._sid(sl, 3))
+            if pd["att"] > 0:       # linear_out + self_attn_dropout (e_branchformer.py:288): the dropout rides the GEMM's epilogue
+                T.gemm_dropout(ctx, W(p + "att_wo"), P(p + "att_bo"), pd["att"], seed, self._sid(sl, 3), out=cat[:, :d])
+            else:
+                ops.gemm(ctx, W(p + "att_wo"), P(p + "att_bo"), out=cat[:, :d])
             # local branch (cgMLP)
             hp, h = T.gemm_act_fwd(a2, W(p + "mlp_w1"), P(p + "mlp_b1"))
             stats = ops.row_stats(h[:, I // 2:])
@@ -704,7 +705,7 @@ class EncoderCTCTrainer:
             # merge
             m2 = ops.dwconv_residual(cat, P(p + "mrg_dw_w"), P(p + "mrg_dw_b"), B, T2)
             if pd["att"] > 0:       # the layer's `final_dropout` module takes config.attention_dropout (e_branchformer.py:229,246)
-                x2 = T.dropout_add(x, ops.gemm(m2, W(p + "mrg_w"), P(p + "mrg_b"), out_dtype=F32), 1.0, pd["att"], seed, self._sid(sl, 5))
+                x2 = T.gemm_dropout(m2, W(p + "mrg_w"), P(p + "mrg_b"), pd["att"], seed, self._sid(sl, 5), resid=x, alpha=1.0)
             else:
                 x2 = ops.gemm(m2, W(p + "mrg_w"), P(p + "mrg_b"), out_dtype=F32, resid=x, alpha=1.0)
             S.update(a1=a1, a2=a2, qkv=qkv, posp=posp, ctx=ctx, hp=hp, h=h, stats=stats, sg=sg, cat=cat, m2=m2, x2=x2, cv=cv, lin=lin)
@@ -958,7 +959,7 @@ class EncoderCTCTrainer:
         # intermediate_dense + GELU + activation dropout: one launch (the GEMM's training epilogue leaves the pre-activation for the backward and the activation)
         hp, h = T.gemm_act_fwd(a, W(pre + "_w1"), P(pre + "_b1"), drop=(pd["act"], self.seed, self._sid(l, sites[0])) if pd["act"] > 0 else None)
         if pd["hidden"] > 0:
-            y = T.dropout_add(x, ops.gemm(h, W(pre + "_w2"), P(pre + "_b2"), out_dtype=F32), 0.5, pd["hidden"], self.seed, self._sid(l, sites[1]))
+            y = T.gemm_dropout(h, W(pre + "_w2"), P(pre + "_b2"), pd["hidden"], self.seed, self._sid(l, sites[1]), resid=x, alpha=0.5)
         else:
             y = ops.gemm(h, W(pre + "_w2"), P(pre + "_b2"), out_dtype=F32, resid=x, alpha=0.5)
         return y, dict(a=a, hp=hp, h=h)

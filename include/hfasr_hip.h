@@ -86,6 +86,11 @@ int mi_conv2d_cl_geo_bf16(const void* in, const void* weight, const float* bias,
  * blk > 0: z == g is the output of one stacked GEMM whose columns are interleaved [conv blk | gate blk] per 2*blk (share must be 1). */
 int mi_gated_act_bf16(const void* z, long ldz, const void* g, long ldg, void* out, long ldo, int B, int T, int Fq, int C, int share, int blk, mi_stream_t stream);
 
+/* C (M,N) = [resid +] alpha * dropout(A W^T + b) from one launch of the 128 x 128 GEMM: fp32 out with optional fp32 residual (mask of mi_dropout_add_f32 for element m*N + n)
+ * or bf16 out (resid NULL, alpha 1; mask and rounding of mi_dropout's bf16 form).  N % 128 == 0, K % 128 == 0, K >= 320, else MI_ERR_UNSUPPORTED.
+ * replaces: a Linear followed by nn.Dropout under autograd (tf wav2vec2_conformer :355-357 output_dense + output_dropout; e_branchformer.py:288, 301). */
+int mi_gemm_dropout_bf16(const void* A, long lda, const void* W, long ldw, const float* bias, void* C, long ldc, int out_f32, const float* resid, long ldr,
+                         float alpha, float drop_p, unsigned seed, unsigned stream_id, int M, int N, int K, mi_stream_t stream);
 /* Training epilogues of the 256 x 256 GEMM: the FFN's activation passes ride the GEMMs next to them (bit-identical to the GEMM + mi_act[_dropout]_{fwd,bwd}_bf16 pair).
  * forward: pre (M,N) bf16 = A W^T + b, h (M,N) bf16 = dropout(act(pre)); kind 1 erf-GELU / 2 tanh-GELU; drop_p = 0: none; mask of mi_dropout for (seed, stream_id).
  * backward: dX (M,N) bf16 = dropout(bf16(dY Wt^T)) * act'(pre), Wt (N,K) the transposed weight.  N % 256 == 0, K % 64 == 0, K >= 128, else MI_ERR_UNSUPPORTED.

@@ -205,6 +205,24 @@ def test_conv2d_weight_gradient_without_the_im2col_buffer(B, T1, F1, Cin, Cout, 
     close(got, ref, rel=1e-2, floor=3e-3, what="conv2 weight gradient")
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 2048), (777, 256, 1024), (300, 512, 512), (200, 136, 72)])      # the last shape is outside the fused kernel: two launches
+def test_linear_output_dropout_in_the_gemm_epilogue(M, N, K):
+    """mi_gemm_dropout_bf16 against the GEMM + dropout kernels it replaces: the fp32 residual form (x + alpha * dropout(linear)) and the bf16 in-place form."""
+    ops, T = _o()
+    a, w, b = dev16(rnd(M, K, seed=1)), dev16(rnd(N, K, seed=2, scale=0.05)), rnd(N, seed=3).to(DEV)
+    x = rnd(M, N, seed=4).to(DEV)
+    p, seed, sid = 0.1, 99, 1234
+    want = T.dropout_add(x, ops.gemm(a, w, b, out_dtype=torch.float32), 0.5, p, seed, sid)
+    got = T.gemm_dropout(a, w, b, p, seed, sid, resid=x, alpha=0.5)
+    torch.testing.assert_close(got, want, atol=1e-5 * float(want.abs().max()), rtol=1e-5)            # same mask; the products may be contracted differently
+    dropped = T.dropout_add(torch.zeros_like(x), torch.ones_like(x), 1.0, p, seed, sid) == 0
+    assert torch.equal(got[dropped], x[dropped]) and 0.05 < float(dropped.float().mean()) < 0.15      # dropped elements leave the residual untouched
+    wide = torch.zeros((M, 2 * N), device=DEV, dtype=BF)
+    want16 = T.dropout_(ops.gemm(a, w, b), p, seed, sid)
+    got16 = T.gemm_dropout(a, w, b, p, seed, sid, out=wide[:, :N])
+    assert torch.equal(got16, want16) and float(wide[:, N:].float().abs().max()) == 0.0
+
+
 def test_bgemm_modes():
     ops, T = _o()
     Z1, Z2, M, N, K = 3, 2, 70, 50, 90
