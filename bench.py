@@ -174,6 +174,8 @@ def parse_args(argv=None):
     ap.add_argument("--overlap", type=int, default=0, choices=[0, 1], help="--train: gradient all-reduce schedule. 0 = ONE collective per parameter store after the backward "
                                                                            "(default); 1 = one async all-reduce per layer range as soon as it is final, overlapped with the "
                                                                            "backward of the earlier layers (what DDP's bucket hooks give the reference; DESIGN.md section 6 before enabling on RCCL)")
+    ap.add_argument("--dropout", type=float, default=0.1, help="--train: dropout probability at every site of encoder and decoder (the reference's config defaults, which the "
+                    "recipes leave in place: hidden / activation / attention / final / conv 0.1, GPT-2 resid / embd / attn 0.1); masks are counter-based, identical on re-runs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo: tests with several ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (tests on a one-GPU box; needs --backend gloo)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check on a box without GPUs: gloo, no HIP work, value null")
@@ -213,11 +215,12 @@ def train_bench(args, world, rank, dev, PL):
     small encoder + 6x256 GPT-2 decoder, ctc_weight 0.3, label smoothing 0.1, fixed positions, AdamW 2e-3 / wd 1e-6, per-GPU batch 96, clips 1-20 s sorted into the batch)."""
     import torch.distributed as td
     from huggingface_asr_amd.train_aed import JointAEDTrainer
-    cfg = dict(shapes.SMALL, position_embeddings_type=args.pos, ctc_zero_infinity=True, ctc_loss_reduction="mean", hidden_dropout=0.0, activation_dropout=0.0,
-               attention_dropout=0.0, final_dropout=0.0, feat_proj_dropout=0.0, csgu_conv_dropout=0.0, layerdrop=0.0, apply_spec_augment=False)
+    pd = float(args.dropout)
+    cfg = dict(shapes.SMALL, position_embeddings_type=args.pos, ctc_zero_infinity=True, ctc_loss_reduction="mean", hidden_dropout=pd, activation_dropout=pd,
+               attention_dropout=pd, final_dropout=pd, feat_proj_dropout=0.0, csgu_conv_dropout=pd, layerdrop=0.0, apply_spec_augment=False)
     sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()}
     dcfg = dict(vocab_size=5000, n_embd=256, n_layer=6, n_head=4, n_positions=1024, head_locations=[], head_weights=[1.0], lsm_factor=0.1,
-                layer_norm_epsilon=1e-5, pos_emb_fixed=True, tie_word_embeddings=False)
+                layer_norm_epsilon=1e-5, pos_emb_fixed=True, tie_word_embeddings=False, resid_pdrop=pd, embd_pdrop=pd, attn_pdrop=pd)
     jcfg = dict(ctc_weight=0.3, pad_token_id=3, decoder_start_token_id=1)
     B = args.batch or 96
     tr = JointAEDTrainer(cfg, dcfg, jcfg, dev, lr=2e-3, weight_decay=1e-6)
@@ -282,7 +285,7 @@ def train_bench(args, world, rank, dev, PL):
                           "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                           "data": "synthetic",
                           "config": {"workload": "BASELINE config 3: small E-Branchformer encoder + 6x256 GPT-2 decoder, joint CTC/attention loss, AdamW; "
-                                                 f"{B} clips of 1-20 s per GPU padded to 2000 frames", "per_gpu_batch": B, "frames": T, "n_params": n_params,
+                                                 f"{B} clips of 1-20 s per GPU padded to 2000 frames", "per_gpu_batch": B, "frames": T, "n_params": n_params, "dropout": pd,
                                      "parallelism": f"dp{world}: SUM all-reduce of {n_params * 4 / 1e6:.0f} MB fp32 gradients after the backward",
                                      "loss": round(float(state["o"]["loss"]), 4)},
                           "schedule": "overlap: one async all-reduce per layer range, launched while the backward of the earlier layers runs" if args.overlap
