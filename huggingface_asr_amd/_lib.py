@@ -178,7 +178,8 @@ def lib():
     return _lib
 
 
-_ERR = {-1: "invalid argument", -2: "kernel launch failed", -3: "unsupported configuration"}
+ERR_ARG, ERR_LAUNCH, ERR_UNSUPPORTED = -1, -2, -3          # MI_ERR_* of include/hfasr_hip.h
+_ERR = {ERR_ARG: "invalid argument", ERR_LAUNCH: "kernel launch failed", ERR_UNSUPPORTED: "unsupported configuration"}
 
 
 def check(rc: int, what: str):

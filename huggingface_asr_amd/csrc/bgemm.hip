@@ -11,7 +11,6 @@
 // both read paths deliver the same k-permutation inside a 16-step ({4h..4h+3} ∪ {8+4h..8+4h+3}, h = lane >> 5), so any mix of
 // operand layouts multiplies correctly.  Tile 64x64x32, 4 waves (2x2) of one v_mfma_f32_32x32x16_bf16 tile each,
 // register-staged prefetch of the next K tile.
-#include <cstdlib>
 #include "common.hpp"
 
 namespace {
@@ -276,9 +275,8 @@ extern "C" int mi_bgemm_bf16(const void* A, long a_z1, long a_z2, long a_m, long
     BgArgs p{(const bf16_t*)A, a_z1, a_z2, a_m, a_k, (const bf16_t*)B, b_z1, b_z2, b_n, b_k, C, c_z1, c_z2, c_m, out_f32, accumulate, alpha, Z2, M, N, K};
     const int ma = a_k == 1 ? 0 : 1, mb = b_k == 1 ? 0 : 1;
     const bool fast = bg_operand_fast(A, a_z1, a_z2, a_m, a_k, M, K) && bg_operand_fast(B, b_z1, b_z2, b_n, b_k, N, K);
-    static const int force64 = getenv("HFASR_BG_TILE64") ? atoi(getenv("HFASR_BG_TILE64")) : 0;
     const long blocks128 = (long)cdiv(M, 128) * cdiv(N, 128) * Z1 * Z2;
-    if (M > 64 && N > 64 && blocks128 >= 256 && !force64) {                    // 2 x 2 MFMA tiles per wave, when that still gives every CU a block
+    if (M > 64 && N > 64 && blocks128 >= 256) {                    // 2 x 2 MFMA tiles per wave, when that still gives every CU a block
         if (fast) bg_launch<128, 64, true>(p, Z1 * Z2, ma, mb, st);
         else bg_launch<128, 64, false>(p, Z1 * Z2, ma, mb, st);
     } else {

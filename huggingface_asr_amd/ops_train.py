@@ -78,7 +78,7 @@ def gemm_act_fwd(a, w, bias, kind="gelu", drop=None):
     p, seed, sid = drop if drop is not None else (0.0, 0, 0)
     rc = _L().mi_gemm_act_fwd_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _p(bias), pre.data_ptr(), pre.stride(0), h.data_ptr(), h.stride(0),
                                    KIND[kind], float(p), int(seed) & 0xFFFFFFFF, int(sid) & 0xFFFFFFFF, M, N, K, _stream())
-    if rc == -3:                     # shape outside the fused kernel: the two launches
+    if rc == _lib.ERR_UNSUPPORTED:   # shape outside the fused kernel: the two launches
         gemm(a, w, bias, out=pre)
         return pre, act_fwd(pre, kind, out=h, drop=drop)
     _lib.check(rc, "mi_gemm_act_fwd_bf16")
@@ -94,7 +94,7 @@ def gemm_act_bwd(dy, wT, pre, kind="gelu", drop=None):
     p, seed, sid = drop if drop is not None else (0.0, 0, 0)
     rc = _L().mi_gemm_act_bwd_bf16(dy.data_ptr(), dy.stride(0), wT.data_ptr(), wT.stride(0), pre.data_ptr(), pre.stride(0), out.data_ptr(), out.stride(0),
                                    KIND[kind], float(p), int(seed) & 0xFFFFFFFF, int(sid) & 0xFFFFFFFF, M, N, K, _stream())
-    if rc == -3:
+    if rc == _lib.ERR_UNSUPPORTED:
         return act_bwd(gemm(dy, wT), pre, kind, out=out, drop=drop)
     _lib.check(rc, "mi_gemm_act_bwd_bf16")
     return out
@@ -310,7 +310,7 @@ def gemm_dropout(a, w, bias, p, seed, stream_id, *, resid=None, alpha=1.0, out=N
     rc = _L().mi_gemm_dropout_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _p(bias), out.data_ptr(), out.stride(0), int(f32),
                                    _p(resid), resid.stride(0) if f32 else 0, float(alpha), float(p), int(seed) & 0xFFFFFFFF, int(stream_id) & 0xFFFFFFFF,
                                    M, N, K, _stream())
-    if rc == -3:
+    if rc == _lib.ERR_UNSUPPORTED:
         if f32:
             return dropout_add(resid, gemm(a, w, bias, out_dtype=F32), alpha, p, seed, stream_id)
         gemm(a, w, bias, out=out)

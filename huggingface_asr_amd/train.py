@@ -390,6 +390,7 @@ class EncoderCTCTrainer:
         self.map = _enc_map(c, self.head)
         self.hp = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm, grad_norm_skip=grad_norm_skip)
         self.sync = GradSync(self.store.flat_g, group, enabled=dp_sync)
+        self._ranges_waiting = []                 # gradient ranges whose weight-gradient GEMMs are still recorded (ops_train.TnBatch), see _range_done
         self._pos = {}
         self._scal = torch.zeros(4, dtype=F32, device=self.device)       # [sumsq, norm, coef, -]
         L = c["num_hidden_layers"]
@@ -495,7 +496,7 @@ class EncoderCTCTrainer:
         then waits, with any earlier ones, for the flush that does run; the backward's last range is `final`."""
         if getattr(self, "_lnred", None) is not None:
             self._lnred.flush()
-        pending = self.__dict__.setdefault("_ranges_waiting", [])
+        pending = self._ranges_waiting
         pending.append((lo, hi))
         tnb = getattr(self, "_tnb", None)
         if tnb is None or tnb.flush(final=final):
