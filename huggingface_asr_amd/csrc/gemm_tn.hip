@@ -77,8 +77,10 @@ __device__ __forceinline__ bf16x8 tr_frag_join(s16x4& lo, s16x4& hi) {
 // tile (128 x 128 with four waves, 256 x 128 with eight) — the 256 transposed reads per stage and CU and the 48 KiB of DMA writes keep the LDS busy ~1400 of those
 // ~2700 cycles, the MFMAs ~1000 — so the depth stays 2.
 // TNN = output tile rows (n): 128 (4 waves, 2 x 2 of 64 x 64) or 256 (8 waves, 4 x 2: the grouped launch — 85 FLOP per ingested byte instead of 64, two waves per SIMD).
-template <int TNN, int XW, int NS>
-__device__ __forceinline__ void tn_tile(const TnArgs& p, const int bid) {
+template <int TNN, int XW, int NS, bool CONVOK = true>       // CONVOK = false: the gathered-operand form (p.conv) is compiled out
+__device__ __forceinline__ void tn_tile(const TnArgs& pin, const int bid) {
+    TnArgs p = pin;
+    if constexpr (!CONVOK) p.conv = 0;
     constexpr int XB = XW * 2, XCH = XW / 8;                  // X tile row bytes, 16-B chunks per row
     constexpr int YB = TNN * 2, YCH = TNN / 8;                // dY tile row bytes / chunks
     constexpr int NW = (TNN / 64) * 2, NT = 64 * NW;          // waves (n x k = TNN/64 x 2), threads
@@ -115,18 +117,16 @@ __device__ __forceinline__ void tn_tile(const TnArgs& p, const int bid) {
         }
     }
     const int ctap = p.conv ? k0 / p.Cin : 0, ckh = p.conv ? ctap / p.KW : 0, ckw = p.conv ? ctap % p.KW : 0;       // block-uniform
-    // conv: (b, to, fo) of each X piece's row, decoded once and advanced by the stage's 64 rows with carries (no divisions between a barrier and the DMA it releases)
-    int cb_[PPW], cto[PPW], cfo[PPW];
+    // conv: (b, to, fo) of the wave's FIRST X row of the stage, decoded once and advanced by the stage's 64 rows with carries (no divisions between a barrier and the
+    // DMA it releases); a wave's pieces are consecutive rows, so piece q is that position + q * RPX with carries (three registers instead of three per piece)
+    int cb0 = 0, cto0 = 0, cfo0 = 0;
     const int adv_f = TN_KM % max(p.Fout, 1), adv_t = TN_KM / max(p.Fout, 1);
     if (p.conv) {
         const unsigned ctf = (unsigned)(p.Tout * p.Fout);
-#pragma unroll
-        for (int q = 0; q < PPW; ++q) {
-            const int g = wave * PPW + q;
-            const unsigned um = (unsigned)(m_lo + (g - YP) * RPX + rsubX);
-            const unsigned b = um / ctf, rem = um - b * ctf, to = rem / (unsigned)p.Fout;
-            cb_[q] = (int)b; cto[q] = (int)to; cfo[q] = (int)(rem - to * (unsigned)p.Fout);
-        }
+        const int g0 = max(wave * PPW - YP, 0);
+        const unsigned um = (unsigned)(m_lo + g0 * RPX + rsubX);
+        const unsigned bq = um / ctf, rem = um - bq * ctf, to = rem / (unsigned)p.Fout;
+        cb0 = (int)bq; cto0 = (int)to; cfo0 = (int)(rem - to * (unsigned)p.Fout);
     }
     auto issue = [&](int it, int stage) {
         char* sbase = smem + stage * STAGE + wave * PPW * 1024;
@@ -139,16 +139,20 @@ __device__ __forceinline__ void tn_tile(const TnArgs& p, const int bid) {
             const bf16_t* base = isY ? p.Y : p.X;
             const long ld = isY ? p.ldy : p.ldx;
             const bf16_t* sp = (m < m_hi && coloff[q] >= 0) ? base + (long)m * ld + coloff[q] : reinterpret_cast<const bf16_t*>(&g_zero16);
-            if (p.conv && !isY) {                            // gathered im2col row (wave-uniform branch); stages are issued in order, so the carried indices are this stage's
-                const int ti = cto[q] * p.cst - p.cpt + ckh, fi = cfo[q] * p.cst - p.cpf + ckw;
+            if (p.conv && !isY) {                            // gathered im2col row (wave-uniform branch); stages are issued in order, so the carried position is this stage's
+                int fo = cfo0 + (g - max(wave * PPW - YP, 0) - YP) * RPX, to = cto0, bb = cb0;
+                while (fo >= p.Fout) { fo -= p.Fout; ++to; }
+                while (to >= p.Tout) { to -= p.Tout; ++bb; }
+                const int ti = to * p.cst - p.cpt + ckh, fi = fo * p.cst - p.cpf + ckw;
                 const bool in = m < m_hi && coloff[q] >= 0 && ti >= 0 && ti < p.Tin && fi >= 0 && fi < p.Fin;
-                sp = in ? p.X + (((long)cb_[q] * p.Tin + ti) * p.Fin + fi) * p.Cin + coloff[q] : reinterpret_cast<const bf16_t*>(&g_zero16);
-                int fo = cfo[q] + adv_f, to = cto[q] + adv_t;
-                if (fo >= p.Fout) { fo -= p.Fout; ++to; }
-                while (to >= p.Tout) { to -= p.Tout; ++cb_[q]; }
-                cfo[q] = fo; cto[q] = to;
+                sp = in ? p.X + (((long)bb * p.Tin + ti) * p.Fin + fi) * p.Cin + coloff[q] : reinterpret_cast<const bf16_t*>(&g_zero16);
             }
             __builtin_amdgcn_global_load_lds((gptr_t)sp, (lptr_t)(sbase + q * 1024), 16, 0, 0);
+        }
+        if (p.conv) {
+            cfo0 += adv_f; cto0 += adv_t;
+            if (cfo0 >= p.Fout) { cfo0 -= p.Fout; ++cto0; }
+            while (cto0 >= p.Tout) { cto0 -= p.Tout; ++cb0; }
         }
     };
 
@@ -256,6 +260,9 @@ __device__ __forceinline__ void tn_tile(const TnArgs& p, const int bid) {
 
 template <int XW>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs p) { tn_tile<TN_T, XW, 2>(p, blockIdx.x); }
+// one long problem on the 256 x 256 tile of the grouped launch (8 waves, split over M)
+template <bool CONV>
+__global__ __launch_bounds__(512) void gemm_tn_big_kernel(TnArgs p) { tn_tile<256, 256, 2, CONV>(p, blockIdx.x); }
 
 // Grouped form: the weight-gradient GEMMs of one encoder layer (up to TN_GROUP problems: dY_i^T X_i -> dW_i) as ONE launch.  A layer's ten dW GEMMs together have
 // ~230 output tiles of 256 x 128 — enough to fill the chip WITHOUT splitting M: every block contracts over all rows of its problem and adds its tile into dW in place,
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g) {
     p.Y = q.Y; p.ldy = q.ldy; p.X = q.X; p.ldx = q.ldx; p.out = q.out; p.ldo = q.ldo; p.slab_stride = 0; p.db = q.db;
     p.M = q.M; p.N = q.N; p.K = q.K; p.n_store = q.n_store; p.splits = 1; p.rows_per_split = (q.M + TN_KM - 1) / TN_KM * TN_KM;
     p.conv = 0; p.Tin = p.Fin = p.Cin = p.Tout = p.Fout = p.KW = 1; p.cst = 1; p.cpt = p.cpf = 0;
-    tn_tile<TN_GROUP_N, XW, TN_GROUP_NS>(p, bid - __builtin_amdgcn_readfirstlane(g.tile0[iu]));
+    tn_tile<TN_GROUP_N, XW, TN_GROUP_NS, false>(p, bid - __builtin_amdgcn_readfirstlane(g.tile0[iu]));
 }
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ out, long ldo, const float* __restrict__ slabs, long slab_stride,
@@ -310,17 +317,20 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ ou
 }  // namespace
 
 // M splits: two (128-wide X tiles, 64 KiB of LDS) or three (64-wide, 48 KiB) blocks per CU on 256 CUs — 512 blocks per launch measured as the optimum (round 1)
+// variant 2: the grouped launch's 256 x 256 tile (one block per CU: 256 blocks) for a single long problem — the Conv2d #2 and CTC-head weight gradients
 static int tn_splits(int M, int N, int K, int variant) {
     const int xw = variant == 1 ? 64 : 128;
-    const int tiles = cdiv(N, TN_T) * cdiv(K, xw);
-    int s = (variant == 1 ? 768 : 512) / tiles;
+    const int tiles = variant == 2 ? cdiv(N, 256) * cdiv(K, 256) : cdiv(N, TN_T) * cdiv(K, xw);
+    int s = (variant == 2 ? 256 : variant == 1 ? 768 : 512) / tiles;
     const int max_s = cdiv(M, 4 * TN_KM);              // at least 4 K-iterations per block
     if (s > max_s) s = max_s;
     return s < 1 ? 1 : s;
 }
+// the long single problems: at least 32 Ki rows and a full 256 x 256 tile
+static bool tn_big(int M, int N, int K) { return M >= 32768 && N >= 256 && K >= 256; }
 extern "C" size_t mi_gemm_tn_workspace_bytes(int M, int N, int K) {       // enough for either variant
     size_t best = 0;
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < 3; ++v) {
         const int s = tn_splits(M, N, K, v);
         if (s > 1 && (size_t)s * N * K * sizeof(float) > best) best = (size_t)s * N * K * sizeof(float);
     }
@@ -335,7 +345,8 @@ extern "C" int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx
     MI_ENTER();
     if (M <= 0 || N <= 0 || K <= 0 || (N % 8) || (K % 8) || (ldy % 8) || (ldx % 8) || n_store > N || n_store <= 0 || variant < 0 || variant > 1) return MI_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(dY) & 15) || (reinterpret_cast<uintptr_t>(X) & 15)) return MI_ERR_ARG;
-    const int splits = tn_splits(M, N, K, variant);
+    const bool big = variant == 0 && tn_big(M, N, K);
+    const int splits = tn_splits(M, N, K, big ? 2 : variant);
     if (splits > 1 && workspace_bytes < (size_t)splits * N * K * sizeof(float)) return MI_ERR_ARG;
     TnArgs p{};
     p.Y = (const bf16_t*)dY; p.ldy = ldy; p.X = (const bf16_t*)X; p.ldx = ldx;
@@ -343,8 +354,13 @@ extern "C" int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx
     p.rows_per_split = cdiv(cdiv(M, splits), TN_KM) * TN_KM;
     if (splits > 1) { p.out = (float*)workspace; p.ldo = K; p.slab_stride = (long)N * K; }
     else { p.out = dW; p.ldo = ldo; p.slab_stride = 0; }
-    const int tiles = cdiv(N, TN_T) * cdiv(K, variant == 1 ? 64 : 128);
-    if (variant == 0) hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(tiles * splits), dim3(256), (size_t)2 * TN_KM * (TN_T * 2 + 256), st, p);
+    const int tiles = big ? cdiv(N, 256) * cdiv(K, 256) : cdiv(N, TN_T) * cdiv(K, variant == 1 ? 64 : 128);
+    if (big) {
+        const size_t lds = (size_t)2 * TN_KM * 1024;
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr != hipSuccess) return MI_ERR_LAUNCH;
+        hipLaunchKernelGGL(gemm_tn_big_kernel<false>, dim3(tiles * splits), dim3(512), lds, st, p);
+    } else if (variant == 0) hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(tiles * splits), dim3(256), (size_t)2 * TN_KM * (TN_T * 2 + 256), st, p);
     else hipLaunchKernelGGL(gemm_tn_kernel<64>, dim3(tiles * splits), dim3(256), (size_t)2 * TN_KM * (TN_T * 2 + 128), st, p);
     MI_CHECK_LAUNCH();
     if (splits > 1) {
@@ -369,7 +385,8 @@ extern "C" int mi_conv2d_wgrad_cl_bf16(const void* dY, long ldy, const void* x, 
     if ((Cin % 128) || Ml >= (1l << 31) || (long)B * Tin * Fin * Cin >= (1l << 40)) return MI_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(dY) & 15) || (reinterpret_cast<uintptr_t>(x) & 15) || !dW) return MI_ERR_ARG;
     const int M = (int)Ml;
-    const int splits = tn_splits(M, N, K, 0);
+    const bool big = tn_big(M, N, K) && (Cin % 256) == 0;
+    const int splits = tn_splits(M, N, K, big ? 2 : 0);
     if (splits > 1 && workspace_bytes < (size_t)splits * N * K * sizeof(float)) return MI_ERR_ARG;
     TnArgs p{};
     p.Y = (const bf16_t*)dY; p.ldy = ldy; p.X = (const bf16_t*)x; p.ldx = Cin;
@@ -378,8 +395,13 @@ extern "C" int mi_conv2d_wgrad_cl_bf16(const void* dY, long ldy, const void* x, 
     if (splits > 1) { p.out = (float*)workspace; p.ldo = K; p.slab_stride = (long)N * K; }
     else { p.out = dW; p.ldo = ldo; p.slab_stride = 0; }
     p.conv = 1; p.Tin = Tin; p.Fin = Fin; p.Cin = Cin; p.Tout = Tout; p.Fout = Fout; p.KW = KW; p.cst = stride; p.cpt = pad_t; p.cpf = pad_f;
-    const int tiles = cdiv(N, TN_T) * cdiv(K, 128);
-    hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(tiles * splits), dim3(256), (size_t)2 * TN_KM * (TN_T * 2 + 256), st, p);
+    const int tiles = big ? cdiv(N, 256) * cdiv(K, 256) : cdiv(N, TN_T) * cdiv(K, 128);
+    if (big) {
+        const size_t lds = (size_t)2 * TN_KM * 1024;
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr != hipSuccess) return MI_ERR_LAUNCH;
+        hipLaunchKernelGGL(gemm_tn_big_kernel<true>, dim3(tiles * splits), dim3(512), lds, st, p);
+    } else hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(tiles * splits), dim3(256), (size_t)2 * TN_KM * (TN_T * 2 + 256), st, p);
     MI_CHECK_LAUNCH();
     if (splits > 1) {
         const long total = (long)n_store * K;
