@@ -150,6 +150,9 @@ __global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ a, 
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm backward
+// Optional second output of the kernel: out (M, d) bf16 = alpha * dropout(dx) of the row it has just finished (dx after the accumulate) — the bf16 operand of the
+// linear backward that follows (what mi_dropout / the fp32 -> bf16 cast made in a pass of their own); p = 0: plain alpha * dx.  Mask of mi_dropout for element m * d + c.
+struct LnCast { bf16_t* out; long ld; float alpha, p; unsigned long long key; };
 // one wave per row, 4 consecutive columns per lane and step (16-B / 8-B accesses): c = 4 (lane + 64 j);
 //   dx (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;   dgamma += dy * xhat, dbeta += dy (block-reduced, then atomics)
 template <int NV>
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
                                                       float eps, const void* __restrict__ dy, long lddy, int dy_f32,
                                                       void* __restrict__ dx, long lddx, int dx_bf16, int accumulate,
                                                       float* __restrict__ partial, int M, int d,
-                                                      int rows_per_wave) {
+                                                      int rows_per_wave, LnCast cst) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const dgamma = partial;                       // non-null: this block's (2d) partial row goes to partial[blockIdx.x]
     float* sg = reinterpret_cast<float*>(smem);          // [4 waves][2d]: every wave's (dgamma | dbeta) partial, summed in wave order below (no atomics: deterministic,
@@ -225,6 +228,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
             const f32x4 v = (gv[j] - s1 - xv[j] * s2) * rstd + ov[j];            // ov = 0 unless accumulating
             if (dx_bf16) reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(dx) + r * lddx)[c] = bf16x4{f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
             else reinterpret_cast<f32x4*>(reinterpret_cast<float*>(dx) + r * lddx)[c] = v;
+            if (cst.out) {
+                f32x4 k4 = {1.f, 1.f, 1.f, 1.f};
+                if (cst.p > 0.f) {
+                    const unsigned long long pair0 = ((unsigned long long)r * (unsigned)d + 4u * (unsigned)c) >> 1;
+                    const unsigned long long h0 = mask_hash(cst.key, pair0), h1 = mask_hash(cst.key, pair0 + 1);
+                    const float ik = 1.f / (1.f - cst.p);
+                    k4 = f32x4{mask_u01(h0, 0) >= cst.p ? ik : 0.f, mask_u01(h0, 1) >= cst.p ? ik : 0.f, mask_u01(h1, 0) >= cst.p ? ik : 0.f, mask_u01(h1, 1) >= cst.p ? ik : 0.f};
+                }
+                reinterpret_cast<bf16x4*>(cst.out + r * cst.ld)[c] = bf16x4{f2bf(v.x * cst.alpha * k4.x), f2bf(v.y * cst.alpha * k4.y), f2bf(v.z * cst.alpha * k4.z), f2bf(v.w * cst.alpha * k4.w)};
+            }
         }
     };
     for (int i = 0; i < rows_per_wave; i += 2) {
@@ -628,7 +641,8 @@ extern "C" int mi_act_bwd_bf16(const void* dy, long lddy, const void* pre, long 
 // workspace: >= mi_layernorm_bwd_workspace_floats(d) floats when dgamma != NULL (per-block partial sums; no float atomics)
 extern "C" size_t mi_layernorm_bwd_workspace_floats(int d) { return (size_t)512 * 2 * d; }
 static int ln_bwd_launch(const void* x, long ldx, int x_bf16, const float* gamma, float eps, const void* dy, long lddy, int dy_f32,
-                         void* dx, long lddx, int dx_bf16, int accumulate, float* partial, int* nblk, int M, int d, hipStream_t st) {
+                         void* dx, long lddx, int dx_bf16, int accumulate, float* partial, int* nblk, int M, int d, hipStream_t st, LnCast cst = LnCast{nullptr, 0, 1.f, 0.f, 0ull}) {
+    if (cst.out && ((cst.ld % 4) || (reinterpret_cast<uintptr_t>(cst.out) & 7) || cst.p < 0.f || cst.p >= 1.f || (d % 2))) return MI_ERR_ARG;
     if (M <= 0 || d <= 0 || d > 2048 || (d % 4) || (ldx % 4) || (lddy % 4) || (lddx % 4) || !gamma) return MI_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(x) & (x_bf16 ? 7 : 15)) || (reinterpret_cast<uintptr_t>(dy) & (dy_f32 ? 15 : 7)) ||
         (reinterpret_cast<uintptr_t>(dx) & (dx_bf16 ? 7 : 15))) return MI_ERR_ARG;
@@ -637,7 +651,7 @@ static int ln_bwd_launch(const void* x, long ldx, int x_bf16, const float* gamma
     const int rpw = cdiv(M, (long)grid * 4);
     const size_t lds = (size_t)4 * 2 * d * sizeof(float);
     const int nv = cdiv(d, 256);
-#define LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(grid), dim3(256), lds, st, x, ldx, x_bf16, gamma, eps, dy, lddy, dy_f32, dx, lddx, dx_bf16, accumulate, partial, M, d, rpw)
+#define LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(grid), dim3(256), lds, st, x, ldx, x_bf16, gamma, eps, dy, lddy, dy_f32, dx, lddx, dx_bf16, accumulate, partial, M, d, rpw, cst)
     if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4); else LN_BWD(8);
 #undef LN_BWD
     if (nblk) *nblk = grid;
@@ -667,6 +681,20 @@ extern "C" int mi_layernorm_bwd_partial(const void* x, long ldx, int x_bf16, con
     MI_ENTER();
     if (!partial || !nblk) return MI_ERR_ARG;
     const int rc = ln_bwd_launch(x, ldx, x_bf16, gamma, eps, dy, lddy, dy_f32, dx, lddx, dx_bf16, accumulate, partial, nblk, M, d, st);
+    if (rc != MI_OK) return rc;
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// as mi_layernorm_bwd_partial, and in the same pass cast (M, d) bf16 = alpha * dropout(dx) of the finished rows: the operand of the linear backward that follows
+// (drop_p = 0: the plain scaled cast; mask of mi_dropout for (seed, stream_id), element m * d + c)
+extern "C" int mi_layernorm_bwd_partial_cast(const void* x, long ldx, int x_bf16, const float* gamma, float eps, const void* dy, long lddy, int dy_f32,
+                                             void* dx, long lddx, int dx_bf16, int accumulate, float* partial, int* nblk, void* cast, long ldcast, float alpha,
+                                             float drop_p, unsigned seed, unsigned stream_id, int M, int d, hipStream_t st) {
+    MI_ENTER();
+    if (!partial || !nblk || !cast) return MI_ERR_ARG;
+    const int rc = ln_bwd_launch(x, ldx, x_bf16, gamma, eps, dy, lddy, dy_f32, dx, lddx, dx_bf16, accumulate, partial, nblk, M, d, st,
+                                 LnCast{(bf16_t*)cast, ldcast, alpha, drop_p, ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed});
     if (rc != MI_OK) return rc;
     MI_CHECK_LAUNCH();
     return MI_OK;

@@ -149,10 +149,28 @@ class LnReduceBatch:
         self.items = []
 
 
-def layernorm_bwd(x, gamma, dy, dx, *, accumulate, dgamma=None, dbeta=None, eps=1e-5, defer=None):
+def layernorm_bwd(x, gamma, dy, dx, *, accumulate, dgamma=None, dbeta=None, eps=1e-5, defer=None, cast=None):
     """dx (+)= dLN(x)/dx · dy ; dgamma/dbeta += .  x f32|bf16, dy f32|bf16, dx f32|bf16 (all (M,d) row views).
-    defer: an LnReduceBatch — the dgamma / dbeta reduction is left to its next `flush()` (the trainer flushes once per layer)."""
+    defer: an LnReduceBatch — the dgamma / dbeta reduction is left to its next `flush()` (the trainer flushes once per layer).
+    cast = (alpha, drop): also returns bf16 (M,d) = alpha * dropout(dx) of the finished rows, written by the same pass (drop = (p, seed, stream_id) | None) —
+    what `dropout_(dx, ..., out=bf16, alpha=)` / `add_cast(dx, alpha=)` would make next; -> (dx, cast tensor)."""
     M, d = x.shape
+    if cast is not None:
+        alpha, drop = cast
+        pdrop, seed, sid = drop if drop is not None else (0.0, 0, 0)
+        if defer is not None and dgamma is not None:
+            import ctypes as C
+            part = defer.slot()
+            nblk = C.c_int(0)
+            out = torch.empty((M, d), device=x.device, dtype=BF16)
+            _lib.check(_L().mi_layernorm_bwd_partial_cast(x.data_ptr(), x.stride(0), int(x.dtype == BF16), gamma.data_ptr(), float(eps),
+                                                          dy.data_ptr(), dy.stride(0), int(dy.dtype == F32), dx.data_ptr(), dx.stride(0), int(dx.dtype == BF16),
+                                                          int(accumulate), part.data_ptr(), C.byref(nblk), out.data_ptr(), out.stride(0), float(alpha), float(pdrop),
+                                                          int(seed) & 0xFFFFFFFF, int(sid) & 0xFFFFFFFF, M, d, _stream()), "mi_layernorm_bwd_partial_cast")
+            defer.add(part, nblk.value, d, dgamma, dbeta)
+            return dx, out
+        layernorm_bwd(x, gamma, dy, dx, accumulate=accumulate, dgamma=dgamma, dbeta=dbeta, eps=eps, defer=defer)       # frozen affine pair / immediate form: two passes
+        return dx, (dropout_(dx, pdrop, seed, sid, out=torch.empty((M, d), device=x.device, dtype=BF16), alpha=alpha) if pdrop > 0 else add_cast(dx, alpha=alpha))
     if defer is not None and dgamma is not None:
         import ctypes as C
         part = defer.slot()

@@ -773,13 +773,18 @@ class EncoderCTCTrainer:
         def layer_bwd(dx, S, l):
             p, sl = f"l{l}.", l + int(l >= L)
             # final_layer_norm
+            # Every LayerNorm backward whose dx is next turned into a bf16 GEMM operand (scaled, dropped) writes that operand itself (`cast=`): no pass of its own
+            hdrop = lambda site: (pd["hidden"], seed, self._sid(sl, site)) if pd["hidden"] > 0 else None
+            mdrop = (pd["att"], seed, self._sid(sl, 5)) if pd["att"] > 0 else None
             d3 = e32(M, d)
-            T.layernorm_bwd(S["x3"], P(p + "fin_ln_g"), dx, d3, accumulate=False, **self._lng(p + "fin_ln_g", p + "fin_ln_b"))
-            dx = d3
             if macaron:
-                self._ffn_bwd(dx, S["x2"], S["ff2"], p + "ff2", pd, sl, (6, 7))
-            # merge:  x2 = x1 + dropout(merge_proj(m2))
-            dyb = T.dropout_(dx, pd["att"], seed, self._sid(sl, 5), out=e16(M, d)) if pd["att"] > 0 else T.add_cast(dx)
+                _, dyb = T.layernorm_bwd(S["x3"], P(p + "fin_ln_g"), dx, d3, accumulate=False, **self._lng(p + "fin_ln_g", p + "fin_ln_b"), cast=(0.5, hdrop(7)))
+                dx = d3
+                dyb = self._ffn_bwd(dx, S["x2"], S["ff2"], p + "ff2", pd, sl, (6, 7), dyb=dyb, cast_next=(1.0, mdrop))
+            else:
+                _, dyb = T.layernorm_bwd(S["x3"], P(p + "fin_ln_g"), dx, d3, accumulate=False, **self._lng(p + "fin_ln_g", p + "fin_ln_b"), cast=(1.0, mdrop))
+                dx = d3
+            # merge:  x2 = x1 + dropout(merge_proj(m2));  dyb = dropout(dx) as bf16
             dm2 = T.linear_bwd(dyb, S["m2"], WT(p + "mrg_w"), dw=GL(p + "mrg_w"), db=GL(p + "mrg_b"), defer=self._tnb)
             dcat = e16(M, 2 * d)
             T.dwconv_residual_bwd(S["cat"], P(p + "mrg_dw_w"), dm2, dcat, G(p + "mrg_dw_w"), G(p + "mrg_dw_b"), B, T2)
@@ -812,12 +817,15 @@ class EncoderCTCTrainer:
                 da1 = T.linear_bwd(dqkv[:, 2 * d:], S["a1"], wt[:, 2 * d:3 * d], dw=GL(p + "att_wqkv", slice(2 * d, None)), db=GL(p + "att_bqkv", slice(2 * d, None)), dx_dtype=F32, defer=self._tnb)
                 rot = ops.rotary(da1r, pos[0].reshape(-1), pos[2].reshape(-1), T2, H)             # R^T = rotation by -theta
                 T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), da1, dx, accumulate=True, **self._lng(p + "att_ln_g", p + "att_ln_b"))
-                T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), rot, dx, accumulate=True, **self._lng(p + "att_ln_g", p + "att_ln_b"))
+                last = dict(x=S["x1"], g=P(p + "att_ln_g"), dy=rot)
             else:
                 da1 = T.linear_bwd(dqkv, S["a1"], WT(p + "att_wqkv")[:, :3 * d], dw=GL(p + "att_wqkv"), db=GL(p + "att_bqkv"), defer=self._tnb)
-                T.layernorm_bwd(S["x1"], P(p + "att_ln_g"), da1, dx, accumulate=True, **self._lng(p + "att_ln_g", p + "att_ln_b"))
-            if macaron:
-                self._ffn_bwd(dx, S["x_in"], S["ff1"], p + "ff1", pd, sl, (0, 1))
+                last = dict(x=S["x1"], g=P(p + "att_ln_g"), dy=da1)
+            if macaron:             # the layer's last accumulation into dx also leaves the first FFN's bf16 operand
+                _, dyb = T.layernorm_bwd(last["x"], last["g"], last["dy"], dx, accumulate=True, **self._lng(p + "att_ln_g", p + "att_ln_b"), cast=(0.5, hdrop(1)))
+                self._ffn_bwd(dx, S["x_in"], S["ff1"], p + "ff1", pd, sl, (0, 1), dyb=dyb)
+            else:
+                T.layernorm_bwd(last["x"], last["g"], last["dy"], dx, accumulate=True, **self._lng(p + "att_ln_g", p + "att_ln_b"))
             return dx
 
         gs = float(loss_scale) / self.sync.world
@@ -965,19 +973,25 @@ class EncoderCTCTrainer:
             y = ops.gemm(h, W(pre + "_w2"), P(pre + "_b2"), out_dtype=F32, resid=x, alpha=0.5)
         return y, dict(a=a, hp=hp, h=h)
 
-    def _ffn_bwd(self, dx, x_in, S, pre, pd, l, sites):
-        """dx (f32, in place): gradient w.r.t. the block output -> gradient w.r.t. its input (residual + LN path)."""
+    def _ffn_bwd(self, dx, x_in, S, pre, pd, l, sites, dyb=None, cast_next=None):
+        """dx (f32, in place): gradient w.r.t. the block output -> gradient w.r.t. its input (residual + LN path).
+        dyb: bf16(0.5 * dropout(dx)) when the producer of dx already wrote it; cast_next = (alpha, drop): -> the same operand of the NEXT linear backward,
+        written by this block's LayerNorm backward."""
         P, G, WT = self.store.p, self.store.g, self.store.bfT
         GL = lambda n: None if n in self.frozen else self.store.g(n)
-        if pd["hidden"] > 0:
-            dyb = T.dropout_(dx, pd["hidden"], self.seed, self._sid(l, sites[1]), out=torch.empty(dx.shape, device=dx.device, dtype=BF16), alpha=0.5)
-        else:
-            dyb = T.add_cast(dx, alpha=0.5)
+        if dyb is None:
+            if pd["hidden"] > 0:
+                dyb = T.dropout_(dx, pd["hidden"], self.seed, self._sid(l, sites[1]), out=torch.empty(dx.shape, device=dx.device, dtype=BF16), alpha=0.5)
+            else:
+                dyb = T.add_cast(dx, alpha=0.5)
         # dh = dy W2 with the activation (+ dropout) backward in the GEMM's epilogue; the weight / bias gradients of W2 go to the layer's grouped launch
         dhp = T.gemm_act_bwd(dyb, WT(pre + "_w2")[:, :dyb.shape[1]], S["hp"], drop=(pd["act"], self.seed, self._sid(l, sites[0])) if pd["act"] > 0 else None)
         T.linear_bwd(dyb, S["h"], WT(pre + "_w2"), dw=GL(pre + "_w2"), db=GL(pre + "_b2"), need_dx=False, defer=self._tnb)
         da = T.linear_bwd(dhp, S["a"], WT(pre + "_w1"), dw=GL(pre + "_w1"), db=GL(pre + "_b1"), defer=self._tnb)
+        if cast_next is not None:
+            return T.layernorm_bwd(x_in, P(pre + "_ln_g"), da, dx, accumulate=True, **self._lng(pre + "_ln_g", pre + "_ln_b"), cast=cast_next)[1]
         T.layernorm_bwd(x_in, P(pre + "_ln_g"), da, dx, accumulate=True, **self._lng(pre + "_ln_g", pre + "_ln_b"))
+        return None
 
     def _attention_fwd(self, qkv, posp, u, v, lengths, B, Tt, H, S, drop=None):
         d = qkv.shape[1] // 3

@@ -250,6 +250,11 @@ int mi_layernorm_bwd(const void* x, long ldx, int x_bf16, const float* gamma, fl
 typedef struct { const float* partial; int nblk, d; float* dgamma; float* dbeta; } mi_lnred_desc;
 int mi_layernorm_bwd_partial(const void* x, long ldx, int x_bf16, const float* gamma, float eps, const void* dy, long lddy, int dy_f32,
                              void* dx, long lddx, int dx_bf16, int accumulate, float* partial, int* nblk, int M, int d, mi_stream_t stream);
+/* as mi_layernorm_bwd_partial, and in the same pass cast (M,d) bf16 = alpha * dropout(dx) of the finished rows — the bf16 operand of the linear backward that follows
+ * (drop_p = 0: the scaled cast; mask of mi_dropout for (seed, stream_id), element m*d + c) */
+int mi_layernorm_bwd_partial_cast(const void* x, long ldx, int x_bf16, const float* gamma, float eps, const void* dy, long lddy, int dy_f32,
+                                  void* dx, long lddx, int dx_bf16, int accumulate, float* partial, int* nblk, void* cast, long ldcast, float alpha,
+                                  float drop_p, unsigned seed, unsigned stream_id, int M, int d, mi_stream_t stream);
 int mi_ln_partial_reduce_many(const mi_lnred_desc* descs, int n, mi_stream_t stream);
 int mi_ln_apply_bf16(const void* x, long ldx, const float* stats, const float* gamma, const float* beta, void* y, long ldy,
                      int M, int N, mi_stream_t stream);

@@ -470,6 +470,33 @@ def test_layernorm_bwd_deferred_reductions_match_the_immediate_form():
         torch.testing.assert_close(f, c, rtol=1e-5, atol=1e-5 * float(c.abs().max()))
 
 
+@pytest.mark.parametrize("d,pdrop", [(512, 0.0), (512, 0.1), (256, 0.1), (1024, 0.0)])
+def test_layernorm_bwd_writes_the_next_operand_itself(d, pdrop):
+    """layernorm_bwd(..., cast=(alpha, drop)): the bf16 copy alpha * dropout(dx) from the same pass equals the separate dropout / cast kernel on the finished dx."""
+    ops, T = _o()
+    M = 777
+    x, dy = rnd(M, d, seed=1).to(DEV), dev16(rnd(M, d, seed=2))
+    g = (1 + 0.1 * rnd(d, seed=3)).to(DEV)
+    base = rnd(M, d, seed=4).to(DEV)
+    drop = (pdrop, 31, 977) if pdrop > 0 else None
+    red = T.LnReduceBatch(DEV)
+    dg, db = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    dx = base.clone()
+    _, cast = T.layernorm_bwd(x, g, dy, dx, accumulate=True, dgamma=dg, dbeta=db, defer=red, cast=(0.5, drop))
+    red.flush()
+    dx2 = base.clone()
+    dg2, db2 = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    T.layernorm_bwd(x, g, dy, dx2, accumulate=True, dgamma=dg2, dbeta=db2, defer=red)
+    red.flush()
+    want = T.dropout_(dx2, pdrop, drop[1], drop[2], out=torch.empty((M, d), device=DEV, dtype=BF), alpha=0.5) if drop else T.add_cast(dx2, alpha=0.5)
+    assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+    assert torch.equal(cast, want)
+    # frozen affine pair (no deferred reduction): the two-pass form behind the same call
+    dx3 = base.clone()
+    _, cast3 = T.layernorm_bwd(x, g, dy, dx3, accumulate=True, cast=(0.5, drop))
+    assert torch.equal(dx3, dx2) and torch.equal(cast3, want)
+
+
 def test_scale_by_device_scalar():
     """the autograd bridge's d(loss) factor: a device scalar, no host sync; exactly 1 leaves the buffer untouched, anything else scales it (odd length: the scalar tail)"""
     ops, T = _o()
