@@ -1095,7 +1095,8 @@ class EncoderCTCTrainer:
             T.colsum_(G(p + "att_v"), dqv)
         # d(posp) (P, d) = sum_b dBD^T · (q + v): K runs over the (b, t) rows of one head.  Partials per group of `cg` utterances (B / cg, P, d), then a column
         # sum over the groups: one long-K product per head would occupy 64 blocks only, per-utterance partials are 4x the fp32 traffic of groups of four
-        cg = 4 if B % 4 == 0 and B >= 16 else (2 if B % 2 == 0 and B >= 8 else 1)
+        # (the largest group that still leaves the 128 x 128 tile >= 256 blocks: with fewer the batched GEMM falls back to 64-wide tiles and reads dBD twice)
+        cg = next((c for c in (4, 2) if B % c == 0 and H * (B // c) * -(-Kp // 128) >= 256), 1)
         dpp = torch.empty((B // cg, Kp * d), device=dev, dtype=F32)
         T.bgemm(dbd, (B * Tt * Ps, cg * Tt * Ps, 1, Ps), qv, (hd, cg * Tt * d, 1, d), dpp, (hd, Kp * d, d), H, B // cg, Kp, hd, cg * Tt)
         dposp = torch.zeros((Kp, d), device=dev, dtype=F32)
