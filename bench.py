@@ -55,10 +55,11 @@ def pmc_traffic_bytes(kernel_prefix="gemm8p_kernel<false, 1"):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*per_launch*.txt")))
     if not files:
         return None, None
-    for line in open(files[-1]):
-        if line.startswith(kernel_prefix):
-            cols = [c.strip() for c in line.split("|")]
-            return (float(cols[3]) + float(cols[4])) * 1e6, os.path.relpath(files[-1], ROOT)
+    for f in reversed(files):                                  # the newest table that has the kernel (tables of other commands — the training step — live beside it)
+        for line in open(f):
+            if line.startswith(kernel_prefix) and ", true>" in line.split("|")[0]:        # the LayerNorm-folded consumer the forward step runs
+                cols = [c.strip() for c in line.split("|")]
+                return (float(cols[3]) + float(cols[4])) * 1e6, os.path.relpath(f, ROOT)
     return None, None
 
 
@@ -102,7 +103,7 @@ def rocprof_child_dense_us(args, B, per_step):
     steps = max(3, min(10, args.event_steps))
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
         cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", td, "--", sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", "2",
-               "--batch", str(B), "--pos", args.pos, "--no-cpu-baseline", "--no-kernel-events"]
+               "--batch", str(B), "--pos", args.pos, "--streams", "1", "--no-cpu-baseline", "--no-kernel-events"]
         try:
             r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
         except Exception as e:  # noqa: BLE001
@@ -169,6 +170,10 @@ def parse_args(argv=None):
     ap.add_argument("--event-steps", type=int, default=5, help="steps of the separate roofline pass (every dense launch timed, stride 1; never inside the timed region)")
     ap.add_argument("--keep-profile", default=None, help="directory that receives the kernel_stats.csv of the roofline leg's rocprofv3 child run")
     ap.add_argument("--pos", default="relative", choices=["relative", "rotary"])
+    ap.add_argument("--streams", type=int, default=2, choices=[1, 2, 3, 4],
+                    help="forward bench: steps in flight. Every step is one pass over its own batch of 32 clips; with k > 1 step j runs on HIP stream j %% k (k engines: own "
+                         "workspace, same weights), so the ramp / drain of one step's kernels is filled by the other's. 1 = strictly one step at a time (the mode every "
+                         "per-kernel figure — roofline, profiles/ — is taken in)")
     ap.add_argument("--train", action="store_true", help="BASELINE config 3 instead of the headline: data-parallel TRAINING step of the joint AED model "
                                                          "(small encoder + 6x256 GPT-2 decoder, per-GPU batch 96, 1-20 s clips), gradient all-reduce over RCCL")
     ap.add_argument("--overlap", type=int, default=0, choices=[0, 1], help="--train: gradient all-reduce schedule. 0 = ONE collective per parameter store after the backward "
@@ -332,23 +337,55 @@ def main():
     tables = FB.FbankTables(80)
     tables.device(dev)
 
-    def step():
-        feats, frames = FB.fbank_gpu(wave, tables, pad_frames_to=100)
-        out = eng.forward(feats, frames, want_hidden=False)
-        loss, _, _ = ops.ctc_loss(out["logits"], labels, out["outer_len"], reduction="mean", zero_infinity=True)
+    def step(e=eng, w=wave, lab=labels):
+        feats, frames = FB.fbank_gpu(w, tables, pad_frames_to=100)
+        out = e.forward(feats, frames, want_hidden=False)
+        loss, _, _ = ops.ctc_loss(out["logits"], lab, out["outer_len"], reduction="mean", zero_infinity=True)
         return loss
+
+    # Pipelined steps: step j runs on HIP stream j % k with its own engine (workspace) and its own resident batch.  A step is still one pass over one batch of B clips;
+    # what overlaps is the tail of one step's kernels with the ramp of the other's (one tile per CU leaves every launch with a fill and a drain nothing else covers).
+    nstr = max(1, args.streams)
+    lanes = [(eng, wave, labels, None)]
+    for i in range(1, nstr):
+        e_i = EBranchformerEngine(cfg, dev)
+        e_i.load_state_dict(sd)
+        lanes.append((e_i, torch.from_numpy(synth.waveforms(100 + rank + 1000 * i, B, SR * SECONDS)).to(dev),
+                      torch.from_numpy(synth.labels(rank + 1000 * i, B, U, cfg["vocab_size"])).to(dev), None))
+    if nstr > 1:
+        lanes = [(e_i, w_i, l_i, torch.cuda.Stream(device=dev)) for e_i, w_i, l_i, _ in lanes]
+    counter = {"j": 0}
+
+    def step_pipelined():
+        e_i, w_i, l_i, st = lanes[counter["j"] % nstr]
+        counter["j"] += 1
+        if st is None:
+            return step(e_i, w_i, l_i)
+        with torch.cuda.stream(st):
+            return step(e_i, w_i, l_i)
 
     L = _lib.lib()
     use_events = not args.no_kernel_events and rank == 0
     n_gemm_per_step = 4 + cfg["num_hidden_layers"] * 10 + 1
-    for _ in range(args.warmup):
-        loss = step()
+    for _ in range(max(args.warmup, nstr)):
+        loss = step_pipelined()
+    torch.cuda.synchronize()
+    counter["j"] = 0
     state = {}
 
     def one():
-        state["loss"] = step()
+        j = counter["j"] % nstr
+        v = step_pipelined()
+        if j == 0:
+            state["loss"] = v                # lane 0 is the batch every earlier round's line reports the loss of
     dt = PL.timed(one, args.steps, sync=torch.cuda.synchronize, device=dev)      # barrier + sync both sides, MAX over ranks
     loss_v = float(state["loss"])
+    single = None
+    if nstr > 1:                             # the same K steps strictly one at a time (outside the timed region): what the pipelining buys
+        for _ in range(2):
+            step()
+        dt1 = PL.timed(lambda: step(), args.steps, sync=torch.cuda.synchronize, device=dev)
+        single = dict(ms_per_step=round(dt1 / args.steps * 1e3, 3), value=round(world * B * SECONDS * args.steps / dt1, 1))
 
     # ---- roofline leg, AFTER the timed region: every dense contraction launch of `event_steps` further steps is bracketed by HIP events recorded on the
     # launch stream (mi_profile_*; the nn.Linear GEMMs and the implicit-GEMM conv), achieved = sum of their algorithmic FLOPs / sum of their durations
@@ -397,7 +434,8 @@ def main():
                         event_timed_tflops=round(tot_fl / (sum(iso_us.values()) * 1e-6) / 1e12, 1),
                         measured=(f"dispatch begin -> end timestamps of the dense kernels over {child_steps} back-to-back steps of a rocprofv3 --kernel-trace --stats child run of this script "
                                   "(= what `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-kernel-events` reports); `event_timed_*` = the same launches of this process, each "
-                                  "carrying a hipExtLaunchKernelGGL (start, stop) event pair, separate pass after the timed region, nothing subtracted") if pipe_us is not None else
+                                  "carrying a hipExtLaunchKernelGGL (start, stop) event pair, separate pass after the timed region, nothing subtracted.  Both legs run ONE step at a time "
+                                  "(the child with --streams 1): with steps pipelined over streams kernels of different steps share the chip and a dispatch's duration is no longer its own work") if pipe_us is not None else
                                  (f"FALL-BACK ({why}): every dense launch carries a hipExtLaunchKernelGGL (start, stop) event pair, separate pass after the timed region, nothing subtracted "
                                   "(reads within ~1 % of rocprofv3's kernel durations when no profiler is attached to this process, ~4 us per launch high under one)"))
 
@@ -414,6 +452,7 @@ def main():
                                    "fbank+CMVN -> conv2d sub -> 16 layers -> CTC head -> CTC loss"
                                    + (" (the batch-independent projection of the relative-position table, 0.2 % of the FLOPs, is cached across steps)" if args.pos == "relative" else ""),
                        "per_gpu_batch": B, "frames": 1000, "encoder_frames": T2, "parallelism": f"replicas x{world} (no exchange step)",
+                       "steps_in_flight": nstr, "one_step_at_a_time": single,
                        "algorithmic_gflop_per_audio_s": round(algorithmic_gflop_per_utt(cfg, T2) / SECONDS, 3),
                        "ctc_loss": round(loss_v, 4)},
             "roofline": roof,

@@ -212,6 +212,32 @@ def test_forward_is_bit_reproducible_at_the_bench_size(overlap):
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), i
 
 
+def test_pipelined_steps_on_two_streams_reproduce_the_single_stream_bits():
+    """bench.py's default: consecutive steps (each its own batch of 32 clips, its own engine / workspace) in flight together on two HIP streams.  Whatever shares
+    the chip with a step's kernels, its logits are the bits the same engine gives alone — 24 overlapped steps at the bench size against the two references."""
+    from huggingface_asr_amd import synth
+    from huggingface_asr_amd.engine import EBranchformerEngine
+    cfg = _cfg(shapes.BASE)
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()}
+    lens = torch.full((32,), 998, dtype=torch.int32, device=DEV)
+    lanes = []
+    for i in range(2):
+        eng = EBranchformerEngine(cfg, DEV)
+        eng.load_state_dict(sd)
+        feats = torch.from_numpy(synth.normal(11 + i, "feats", (32, 1000, 80), 1.0)).to(DEV)
+        ref = eng.forward(feats, lens)["logits"].clone()              # alone on the default stream
+        lanes.append((eng, feats, ref, torch.cuda.Stream()))
+    torch.cuda.synchronize()
+    outs = []
+    for j in range(24):
+        eng, feats, _, st = lanes[j % 2]
+        with torch.cuda.stream(st):
+            outs.append((j % 2, eng.forward(feats, lens)["logits"].clone()))        # the clone runs on the lane's stream, behind its forward
+    torch.cuda.synchronize()
+    for k, (lane, got) in enumerate(outs):
+        assert torch.equal(got, lanes[lane][2]), k
+
+
 @pytest.mark.parametrize("fold", [True, False])
 def test_full_size_batch_independence_and_loss_additivity(fold):
     """BASELINE configs[1] size (base, 32 x 10 s): size-independent properties instead of an oracle run — an utterance's logits do not depend on
