@@ -329,8 +329,12 @@ def main():
 
     cfg = dict(shapes.BASE, position_embeddings_type=args.pos, ctc_zero_infinity=True, ctc_loss_reduction="mean")
     sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()}
-    eng = EBranchformerEngine(cfg, dev)
-    eng.load_state_dict(sd)
+    # k engines (own workspace, same weights) on k HIP streams: step j runs on lane j % k (huggingface_asr_amd/pipeline.py).  A step is still one pass over one batch of B
+    # clips; what overlaps is the tail of one step's kernels with the ramp of the other's (one tile per CU leaves every launch with a fill and a drain nothing else covers).
+    from huggingface_asr_amd.pipeline import ForwardPipeline
+    nstr = max(1, args.streams)
+    pipe = ForwardPipeline(cfg, dev, sd, lanes=nstr)
+    eng = pipe.engines[0]
     B = args.batch or BATCH
     wave = torch.from_numpy(synth.waveforms(100 + rank, B, SR * SECONDS)).to(dev)       # resident in HBM
     labels = torch.from_numpy(synth.labels(rank, B, U, cfg["vocab_size"])).to(dev)
@@ -343,40 +347,24 @@ def main():
         loss, _, _ = ops.ctc_loss(out["logits"], lab, out["outer_len"], reduction="mean", zero_infinity=True)
         return loss
 
-    # Pipelined steps: step j runs on HIP stream j % k with its own engine (workspace) and its own resident batch.  A step is still one pass over one batch of B clips;
-    # what overlaps is the tail of one step's kernels with the ramp of the other's (one tile per CU leaves every launch with a fill and a drain nothing else covers).
-    nstr = max(1, args.streams)
-    lanes = [(eng, wave, labels, None)]
-    for i in range(1, nstr):
-        e_i = EBranchformerEngine(cfg, dev)
-        e_i.load_state_dict(sd)
-        lanes.append((e_i, torch.from_numpy(synth.waveforms(100 + rank + 1000 * i, B, SR * SECONDS)).to(dev),
-                      torch.from_numpy(synth.labels(rank + 1000 * i, B, U, cfg["vocab_size"])).to(dev), None))
-    if nstr > 1:
-        lanes = [(e_i, w_i, l_i, torch.cuda.Stream(device=dev)) for e_i, w_i, l_i, _ in lanes]
-    counter = {"j": 0}
+    batches = [(wave, labels)] + [(torch.from_numpy(synth.waveforms(100 + rank + 1000 * i, B, SR * SECONDS)).to(dev),
+                                   torch.from_numpy(synth.labels(rank + 1000 * i, B, U, cfg["vocab_size"])).to(dev)) for i in range(1, nstr)]
 
     def step_pipelined():
-        e_i, w_i, l_i, st = lanes[counter["j"] % nstr]
-        counter["j"] += 1
-        if st is None:
-            return step(e_i, w_i, l_i)
-        with torch.cuda.stream(st):
-            return step(e_i, w_i, l_i)
+        return pipe.submit(lambda e, lane: step(e, *batches[lane]))
 
     L = _lib.lib()
     use_events = not args.no_kernel_events and rank == 0
     n_gemm_per_step = 4 + cfg["num_hidden_layers"] * 10 + 1
     for _ in range(max(args.warmup, nstr)):
-        loss = step_pipelined()
+        step_pipelined()
     torch.cuda.synchronize()
-    counter["j"] = 0
+    pipe.reset()
     state = {}
 
     def one():
-        j = counter["j"] % nstr
-        v = step_pipelined()
-        if j == 0:
+        lane, v = step_pipelined()
+        if lane == 0:
             state["loss"] = v                # lane 0 is the batch every earlier round's line reports the loss of
     dt = PL.timed(one, args.steps, sync=torch.cuda.synchronize, device=dev)      # barrier + sync both sides, MAX over ranks
     loss_v = float(state["loss"])

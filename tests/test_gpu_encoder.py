@@ -219,23 +219,17 @@ def test_pipelined_steps_on_two_streams_reproduce_the_single_stream_bits():
     from huggingface_asr_amd.engine import EBranchformerEngine
     cfg = _cfg(shapes.BASE)
     sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()}
+    from huggingface_asr_amd.pipeline import ForwardPipeline
     lens = torch.full((32,), 998, dtype=torch.int32, device=DEV)
-    lanes = []
-    for i in range(2):
-        eng = EBranchformerEngine(cfg, DEV)
-        eng.load_state_dict(sd)
-        feats = torch.from_numpy(synth.normal(11 + i, "feats", (32, 1000, 80), 1.0)).to(DEV)
-        ref = eng.forward(feats, lens)["logits"].clone()              # alone on the default stream
-        lanes.append((eng, feats, ref, torch.cuda.Stream()))
+    pipe = ForwardPipeline(cfg, DEV, sd, lanes=2)
+    feats = [torch.from_numpy(synth.normal(11 + i, "feats", (32, 1000, 80), 1.0)).to(DEV) for i in range(2)]
+    refs = [pipe.engines[i].forward(feats[i], lens)["logits"].clone() for i in range(2)]          # each engine alone on the default stream
     torch.cuda.synchronize()
-    outs = []
-    for j in range(24):
-        eng, feats, _, st = lanes[j % 2]
-        with torch.cuda.stream(st):
-            outs.append((j % 2, eng.forward(feats, lens)["logits"].clone()))        # the clone runs on the lane's stream, behind its forward
+    outs = [pipe.submit(lambda e, lane: e.forward(feats[lane], lens)["logits"].clone()) for _ in range(24)]       # the clone runs on the lane's stream, behind its forward
     torch.cuda.synchronize()
+    assert [lane for lane, _ in outs] == [j % 2 for j in range(24)]
     for k, (lane, got) in enumerate(outs):
-        assert torch.equal(got, lanes[lane][2]), k
+        assert torch.equal(got, refs[lane]), k
 
 
 @pytest.mark.parametrize("fold", [True, False])
