@@ -373,7 +373,8 @@ def main():
         for _ in range(2):
             step()
         dt1 = PL.timed(lambda: step(), args.steps, sync=torch.cuda.synchronize, device=dev)
-        single = dict(ms_per_step=round(dt1 / args.steps * 1e3, 3), value=round(world * B * SECONDS * args.steps / dt1, 1))
+        single = dict(ms_per_step=round(dt1 / args.steps * 1e3, 3), value=round(world * B * SECONDS * args.steps / dt1, 1),
+                      same_loss_bits=bool(float(step()) == loss_v))        # lane 0's batch alone on the default stream against its last pipelined pass
 
     # ---- roofline leg, AFTER the timed region: every dense contraction launch of `event_steps` further steps is bracketed by HIP events recorded on the
     # launch stream (mi_profile_*; the nn.Linear GEMMs and the implicit-GEMM conv), achieved = sum of their algorithmic FLOPs / sum of their durations
