@@ -170,7 +170,10 @@ def parse_args(argv=None):
     ap.add_argument("--event-steps", type=int, default=5, help="steps of the separate roofline pass (every dense launch timed, stride 1; never inside the timed region)")
     ap.add_argument("--keep-profile", default=None, help="directory that receives the kernel_stats.csv of the roofline leg's rocprofv3 child run")
     ap.add_argument("--pos", default="relative", choices=["relative", "rotary"])
-    ap.add_argument("--streams", type=int, default=2, choices=[1, 2, 3, 4],
+    ap.add_argument("--wide-tiles", type=int, default=None, choices=[0, 1],
+                    help="forward bench, with --streams >= 3: the N = d GEMMs of a layer on 256 x 256 tiles (mi_ebf_config.wide_tiles) — a quarter of the blocks per launch, twice "
+                         "the FLOP per ingested byte; kernels of the steps in flight then share the chip by CU")
+    ap.add_argument("--streams", type=int, default=4, choices=[1, 2, 3, 4, 5, 6],
                     help="forward bench: steps in flight. Every step is one pass over its own batch of 32 clips; with k > 1 step j runs on HIP stream j %% k (k engines: own "
                          "workspace, same weights), so the ramp / drain of one step's kernels is filled by the other's. 1 = strictly one step at a time (the mode every "
                          "per-kernel figure — roofline, profiles/ — is taken in)")
@@ -184,7 +187,10 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo: tests with several ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (tests on a one-GPU box; needs --backend gloo)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check on a box without GPUs: gloo, no HIP work, value null")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.wide_tiles is None:
+        args.wide_tiles = int(args.streams >= 3)         # wide tiles leave one step alone with a quarter of the blocks per launch: they come with the lanes that fill the rest
+    return args
 
 
 def launch_ranks(args) -> int:
@@ -307,6 +313,8 @@ def train_bench(args, world, rank, dev, PL):
 def main():
     args = parse_args()
     from huggingface_asr_amd import parallel as PL
+    from huggingface_asr_amd.pipeline import reserve_hw_queues
+    hwq = 4 if args.train else reserve_hw_queues(args.streams)          # before the first HIP call of this process (and inherited by the ranks it starts)
     in_torchrun = "WORLD_SIZE" in os.environ
     if not in_torchrun and args.gpus > 1:
         sys.exit(launch_ranks(args))
@@ -333,8 +341,11 @@ def main():
     # clips; what overlaps is the tail of one step's kernels with the ramp of the other's (one tile per CU leaves every launch with a fill and a drain nothing else covers).
     from huggingface_asr_amd.pipeline import ForwardPipeline
     nstr = max(1, args.streams)
-    pipe = ForwardPipeline(cfg, dev, sd, lanes=nstr)
+    pipe = ForwardPipeline(cfg, dev, sd, lanes=nstr, wide_tiles=bool(args.wide_tiles))
     eng = pipe.engines[0]
+    if args.wide_tiles:                      # the one-step-at-a-time comparison and the per-kernel roofline leg run the product's own tiles (wide tiles are for steps in flight)
+        eng = EBranchformerEngine(cfg, dev)
+        eng.load_state_dict(sd)
     B = args.batch or BATCH
     wave = torch.from_numpy(synth.waveforms(100 + rank, B, SR * SECONDS)).to(dev)       # resident in HBM
     labels = torch.from_numpy(synth.labels(rank, B, U, cfg["vocab_size"])).to(dev)
@@ -374,7 +385,7 @@ def main():
             step()
         dt1 = PL.timed(lambda: step(), args.steps, sync=torch.cuda.synchronize, device=dev)
         single = dict(ms_per_step=round(dt1 / args.steps * 1e3, 3), value=round(world * B * SECONDS * args.steps / dt1, 1),
-                      same_loss_bits=bool(float(step()) == loss_v))        # lane 0's batch alone on the default stream against its last pipelined pass
+                      same_loss_bits=bool(float(step()) == loss_v), loss=float(step()))        # lane 0's batch alone on the default stream against its last pipelined pass
 
     # ---- roofline leg, AFTER the timed region: every dense contraction launch of `event_steps` further steps is bracketed by HIP events recorded on the
     # launch stream (mi_profile_*; the nn.Linear GEMMs and the implicit-GEMM conv), achieved = sum of their algorithmic FLOPs / sum of their durations
@@ -441,7 +452,7 @@ def main():
                                    "fbank+CMVN -> conv2d sub -> 16 layers -> CTC head -> CTC loss"
                                    + (" (the batch-independent projection of the relative-position table, 0.2 % of the FLOPs, is cached across steps)" if args.pos == "relative" else ""),
                        "per_gpu_batch": B, "frames": 1000, "encoder_frames": T2, "parallelism": f"replicas x{world} (no exchange step)",
-                       "steps_in_flight": nstr, "one_step_at_a_time": single,
+                       "steps_in_flight": nstr, "wide_tiles": bool(args.wide_tiles), "hw_queues": hwq, "one_step_at_a_time": single,
                        "algorithmic_gflop_per_audio_s": round(algorithmic_gflop_per_utt(cfg, T2) / SECONDS, 3),
                        "ctc_loss": round(loss_v, 4)},
             "roofline": roof,

@@ -19,7 +19,7 @@ class EbfConfig(C.Structure):
     _fields_ = [(n, i32) for n in ("B", "T", "F", "d", "H", "I", "L", "V", "C1", "C2", "K", "stride", "pad",
                                    "is_causal", "pos_type", "csgu_kernel", "merge_kernel", "csgu_act", "use_macaron")] + \
                [("ln_eps", f32), ("logits_f32", i32), ("logits_ld", i32), ("branch_overlap", i32), ("extra_layers", i32), ("layer_mixing", i32), ("csgu_linear", i32),
-                ("context_mode", i32), ("gate_blk", i32), ("ln_fold", i32)]
+                ("context_mode", i32), ("gate_blk", i32), ("ln_fold", i32), ("wide_tiles", i32)]
 
 
 class LnRedDesc(C.Structure):
@@ -112,6 +112,7 @@ SIGNATURES = {
     "mi_gemm_act_fwd_bf16": [vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, f32, C.c_uint, C.c_uint, i32, i32, i32, vp],
     "mi_gemm_act_bwd_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, i32, f32, C.c_uint, C.c_uint, i32, i32, i32, vp],
     "mi_conv2d_wgrad_cl_bf16": [vp, i64, vp, vp, i64, vp] + [i32] * 13 + [vp, C.c_size_t, vp],
+    "mi_gemm_resid_stats_f32_v": [vp, i64, vp, i64, vp, vp, i64, vp, i64, f32, vp, i64, vp, i32, i32, i32, i32, vp],
     "mi_gemm_tn_group_bf16": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
     "mi_bgemm_bf16": [vp, i64, i64, i64, i64, vp, i64, i64, i64, i64, vp, i64, i64, i64, i32, i32, f32, i32, i32, i32, i32, i32, vp],
     "mi_attn_softmax_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, f32, i32, f32, C.c_uint, C.c_uint, vp],

@@ -334,7 +334,8 @@ extern "C" int mi_ebf_forward_hs(const mi_ebf_config* cfg, const void* const* we
         // ---- LayerNorm-folded layers (header: mi_ebf_config.ln_fold).  a0 holds bf16(x) of the CURRENT residual stream, lnst its per-row partial statistics (np pairs):
         // written by the kernel that produced x (mi_layernorm_fold at layer entry and after final_layer_norm; the FFN-out / merge GEMMs' epilogues in between).
         if (c.pos_type == 2 || !c.use_macaron || c.extra_layers || c.layer_mixing || c.csgu_linear || (D.hd != 64 && D.hd != 128)) return MI_ERR_ARG;
-        const int npg = d / 32;                                   // pairs a producer GEMM writes (one per 32 columns)
+        const int gv = c.wide_tiles ? 40 : 0;                     // kernel of the N = d GEMMs: 0 the product's 128 x 128, 40 the 256 x 256 tile (throughput mode)
+        const int npg = c.wide_tiles ? d / 64 : d / 32;           // pairs a producer GEMM writes (one per 32 / 64 columns)
         // entry: zero padded frames once (tf:662-665); x, bf16(x), statistics
         RUN(mi_layernorm_fold(w.x, d, mask_len, T2, nullptr, nullptr, 0.f, w.x, d, w.a0, d, w.lnst, M, d, st));
         int np = 1;
@@ -343,7 +344,7 @@ extern "C" int mi_ebf_forward_hs(const mi_ebf_config* cfg, const void* const* we
                 return MI_ERR_LAUNCH;
             // x += 0.5 * FFN(LN(x))   e_branchformer.py:271-273
             RUN(mi_gemm_lnfold_bf16(w.a0, d, Lw(l, FF1_WF), d, Lf(l, FF1_SF), Lf(l, FF1_CF), w.lnst, np, leps, w.h, I, 1, M, I, d, st));
-            RUN(mi_gemm_resid_stats_f32(w.h, I, Lw(l, FF1_W2), I, Lf(l, FF1_B2), w.x, d, w.x, d, 0.5f, w.a0, d, w.lnst, M, d, I, st));
+            RUN(mi_gemm_resid_stats_f32_v(w.h, I, Lw(l, FF1_W2), I, Lf(l, FF1_B2), w.x, d, w.x, d, 0.5f, w.a0, d, w.lnst, M, d, I, gv, st));
             np = npg;
             // global branch: self_attn_layer_norm folded into [Q|K|V]   (e_branchformer.py:281-288)
             RUN(mi_gemm_lnfold_bf16(w.a0, d, Lw(l, QKV_WF), d, Lf(l, QKV_SF), Lf(l, QKV_CF), w.lnst, np, leps, w.qk, 3 * d, 0, M, 3 * d, d, st));
@@ -351,20 +352,20 @@ extern "C" int mi_ebf_forward_hs(const mi_ebf_config* cfg, const void* const* we
                                       c.pos_type == 1 ? (const bf16_t*)posp + (size_t)l * P * d : nullptr, d,
                                       c.pos_type == 1 ? Lf(l, ATT_U) : nullptr, c.pos_type == 1 ? Lf(l, ATT_V) : nullptr,
                                       mask_len, w.ctx, d, c.B, T2, 0, 0, c.H, D.hd, scale, c.is_causal, st));
-            RUN(mi_gemm_bf16(w.ctx, d, Lw(l, ATT_WO), d, Lf(l, ATT_BO), 1, w.cat, 2 * d, 0, nullptr, 0, 1.f, 0, M, d, d, 0, 0, st));
+            RUN(mi_gemm_bf16_v(w.ctx, d, Lw(l, ATT_WO), d, Lf(l, ATT_BO), 1, w.cat, 2 * d, 0, nullptr, 0, 1.f, 0, M, d, d, 0, 0, gv, st));
             // local branch: cgMLP_layer_norm folded into channel_proj1   (e_branchformer.py:291-292, 184-222)
             RUN(mi_gemm_lnfold_bf16(w.a0, d, Lw(l, MLP_WF), d, Lf(l, MLP_SF), Lf(l, MLP_CF), w.lnst, np, leps, w.h, I, 1, M, I, d, st));
             RUN(mi_row_stats_bf16(w.h + I / 2, I, I / 2, leps, w.stats, M, st));
             const int dil = c.is_causal ? (kc - 1) / 2 : 1;
             const int cpad = c.is_causal ? (kc - 1) * dil : (kc - 1) / 2;
             RUN(mi_csgu_bf16(w.h, I, w.stats, Lf(l, CSGU_LN_G), Lf(l, CSGU_LN_B), Lf(l, CSGU_W), Lf(l, CSGU_B), w.s, I / 2, c.B, T2, I / 2, kc, cpad, dil, c.csgu_act, st));
-            RUN(mi_gemm_bf16(w.s, I / 2, Lw(l, MLP_W2), I / 2, Lf(l, MLP_B2), 1, w.cat + d, 2 * d, 0, nullptr, 0, 1.f, 0, M, d, I / 2, 0, 0, st));
+            RUN(mi_gemm_bf16_v(w.s, I / 2, Lw(l, MLP_W2), I / 2, Lf(l, MLP_B2), 1, w.cat + d, 2 * d, 0, nullptr, 0, 1.f, 0, M, d, I / 2, 0, 0, gv, st));
             // merge (e_branchformer.py:296-304): x += merge_proj(m + dwconv(m)); the epilogue leaves bf16(x) and its statistics for ff2's folded LayerNorm
             RUN(mi_dwconv_residual_bf16(w.cat, 2 * d, Lf(l, MRG_DW_W), Lf(l, MRG_DW_B), w.m2, 2 * d, c.B, T2, 2 * d, km, (km - 1) / 2, st));
-            RUN(mi_gemm_resid_stats_f32(w.m2, 2 * d, Lw(l, MRG_W), 2 * d, Lf(l, MRG_B), w.x, d, w.x, d, 1.0f, w.a0, d, w.lnst, M, d, 2 * d, st));
+            RUN(mi_gemm_resid_stats_f32_v(w.m2, 2 * d, Lw(l, MRG_W), 2 * d, Lf(l, MRG_B), w.x, d, w.x, d, 1.0f, w.a0, d, w.lnst, M, d, 2 * d, gv, st));
             // x += 0.5 * FFN(LN(x))   e_branchformer.py:307-309
             RUN(mi_gemm_lnfold_bf16(w.a0, d, Lw(l, FF2_WF), d, Lf(l, FF2_SF), Lf(l, FF2_CF), w.lnst, np, leps, w.h, I, 1, M, I, d, st));
-            RUN(mi_gemm_bf16(w.h, I, Lw(l, FF2_W2), I, Lf(l, FF2_B2), 1, w.x, d, 1, w.x, d, 0.5f, 0, M, d, I, 0, 0, st));
+            RUN(mi_gemm_bf16_v(w.h, I, Lw(l, FF2_W2), I, Lf(l, FF2_B2), 1, w.x, d, 1, w.x, d, 0.5f, 0, M, d, I, 0, 0, gv, st));
             // final_layer_norm (:312): the new residual stream, its bf16 copy and statistics for the next layer — or, after the last layer, chained with encoder.layer_norm
             if (l + 1 == c.L) {
                 RUN(mi_layernorm_chain(w.x, d, nullptr, T2, Lf(l, FIN_LN_G), Lf(l, FIN_LN_B), leps, nullptr, 0,

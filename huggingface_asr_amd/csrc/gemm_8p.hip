@@ -292,13 +292,34 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
                     const int row = ii * 16 + fr;                                  // row within the half
                     *reinterpret_cast<f32x4*>(reg + row * 256 + (((j * 4 + fq) ^ (row & 15)) << 4)) = acc[half * 4 + ii][j];
                 }
+            // Residual form (the N = 512 GEMMs of the encoder on this tile: 64 blocks per launch — the throughput mode, where other steps' kernels own the rest of the
+            // chip): out = resid + alpha * (acc + bias), and the LayerNorm-fold producer's extras (bf16 copy, per-row partial statistics over the wave's 64 columns).
+            // The half's 16 residual vectors are requested once its accumulators have gone to LDS (their registers are free) and land under the LDS round trip.
+            f32x4 rr[16];
+            if (p.resid) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int m = min(m0 + wr * 128 + half * 64 + u * 4 + r16, p.M - 1);
+                    rr[u] = *reinterpret_cast<const f32x4*>(p.resid + (long)m * p.ldr + nb + c16 * 4);
+                }
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int row = u * 4 + r16;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * 256 + ((c16 ^ (row & 15)) << 4));
+                f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * 256 + ((c16 ^ (row & 15)) << 4));
                 const int m = m0 + wr * 128 + half * 64 + row, n = nb + c16 * 4;
+                if (p.resid) v = rr[u] + p.alpha * v;
                 if (m < p.M && n < n4) *reinterpret_cast<f32x4*>(C + (long)m * p.ldc + n) = v;
+                if (p.C2 && m < p.M) *reinterpret_cast<bf16x4*>(p.C2 + (long)m * p.ldc2 + n) = bf16x4{f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+                if (p.stats_out) {                          // 16 lanes hold a row's 64 columns: one (sum, sumsq) pair per row and wave column
+                    float sm = (v.x + v.y) + (v.z + v.w), sq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                    sm += dpp_f32<0xB1, 0xF>(0.f, sm); sq += dpp_f32<0xB1, 0xF>(0.f, sq);
+                    sm += dpp_f32<0x4E, 0xF>(0.f, sm); sq += dpp_f32<0x4E, 0xF>(0.f, sq);
+                    sm += dpp_f32<0x141, 0xF>(0.f, sm); sq += dpp_f32<0x141, 0xF>(0.f, sq);
+                    sm += dpp_f32<0x140, 0xF>(0.f, sm); sq += dpp_f32<0x140, 0xF>(0.f, sq);
+                    if (c16 == 0 && m < p.M) *reinterpret_cast<f32x2*>(p.stats_out + (long)m * LN_STATS_STRIDE + (((n0 >> 8) << 2) + wc) * 2) = f32x2{sm, sq};
+                }
                 if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four rows in flight at a time: all 128 accumulator registers are still live in the first half
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the second half overwrites the region
@@ -834,9 +855,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p128p_kernel(GemmArgs p) {
 
 bool gemm_8p_supported(const GemmArgs& a, bool conv) {
     if (a.M <= 0 || a.N <= 0 || (a.K % BK) != 0 || a.K < 2 * BK) return false;
-    if (a.resid || a.col_T || a.bias_mode == 2) return false;
+    if (a.col_T || a.bias_mode == 2) return false;
+    if (a.resid && (!a.out_f32 || (a.N % TB) != 0 || ((uintptr_t)a.resid & 15) || (a.ldr % 4) != 0)) return false;        // residual: the fp32 form only, whole tiles
     if (((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) || ((uintptr_t)a.C & 15) || (a.ldw % 8)) return false;
-    if (a.out_f32) {                 // fp32 output (CTC head): any N, no activation, 16-B stores may touch the row's padding up to the next multiple of 4
+    if (a.out_f32) {                 // fp32 output (CTC head; the residual GEMMs in throughput mode): no activation, 16-B stores may touch the row's padding up to the next multiple of 4
         if (conv || a.act != 0 || (a.ldc % 4) != 0 || a.ldc < ((a.N + 3) & ~3)) return false;
     } else {
         if ((a.N % TB) != 0 || (a.ldc % 8) != 0) return false;
@@ -851,8 +873,9 @@ bool gemm_8p_supported(const GemmArgs& a, bool conv) {
         if (conv || a.out_f32 || a.gated || a.ln_stats || a.resid || a.col_T || a.act > 4 || (a.aux_kind != 1 && a.aux_kind != 2) || a.drop_p < 0.f || a.drop_p >= 1.f) return false;
         if (a.act == 3 && (!a.aux || ((uintptr_t)a.aux & 15) || (a.ldaux % 8))) return false;
         if (a.act == 4 && (!a.C2 || ((uintptr_t)a.C2 & 15) || (a.ldc2 % 8))) return false;
-    } else if (a.C2) return false;
-    if (a.stats_out) return false;               // producer side lives in the 128x128 kernel
+    } else if (a.C2 || a.stats_out) {            // LayerNorm-fold producer on this tile: the fp32 residual form, at most 16 partial pairs per row (one per 64 columns)
+        if (!a.out_f32 || !a.resid || a.N > 1024 || (a.C2 && (((uintptr_t)a.C2 & 7) || (a.ldc2 % 4))) || ((uintptr_t)a.stats_out & 7)) return false;
+    }
     if ((long)a.N * a.ldw * 2 >= (1l << 32)) return false;                                             // 32-bit source offsets
     if (conv) {
         if ((a.Cin % BK) != 0 || a.Fout <= 0 || a.Tout <= 0) return false;

@@ -354,17 +354,24 @@ extern "C" int mi_gemm_dropout_bf16(const void* A, long lda, const void* W, long
 
 // Producer: C (M,N) fp32 = resid + alpha * (A W^T + b) (resid may be C), and in the same epilogue C2 (M,N) bf16 = the stored rows, stats_out = their per-row partial
 // (sum, sumsq) pairs (slot = 32-column block of the row, N / 32 <= 16 pairs, row stride 32 floats).  128x128 phase kernel only: N % 128 == 0, N <= 512, K % 128 == 0, K >= 320.
+extern "C" int mi_gemm_resid_stats_f32_v(const void* A, long lda, const void* W, long ldw, const float* bias, float* C, long ldc, const float* resid, long ldr, float alpha,
+                                         void* C2, long ldc2, float* stats_out, int M, int N, int K, int variant, hipStream_t stream);
 extern "C" int mi_gemm_resid_stats_f32(const void* A, long lda, const void* W, long ldw, const float* bias, float* C, long ldc, const float* resid, long ldr, float alpha,
                                        void* C2, long ldc2, float* stats_out, int M, int N, int K, hipStream_t stream) {
+    return mi_gemm_resid_stats_f32_v(A, lda, W, ldw, bias, C, ldc, resid, ldr, alpha, C2, ldc2, stats_out, M, N, K, 0, stream);
+}
+extern "C" int mi_gemm_resid_stats_f32_v(const void* A, long lda, const void* W, long ldw, const float* bias, float* C, long ldc, const float* resid, long ldr, float alpha,
+                                         void* C2, long ldc2, float* stats_out, int M, int N, int K, int variant, hipStream_t stream) {
     MI_ENTER();
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw; a.bias = bias; a.bias_mode = bias ? 1 : 0;
     a.C = C; a.ldc = ldc; a.out_f32 = 1; a.resid = resid; a.ldr = ldr; a.alpha = alpha; a.act = 0; a.M = M; a.N = N; a.K = K;
     a.C2 = (bf16_t*)C2; a.ldc2 = ldc2; a.stats_out = stats_out;
-    if (!A || !W || !C) return MI_ERR_ARG;
-    if (!gemm_8p128_supported(a)) return MI_ERR_UNSUPPORTED;
+    if (!A || !W || !C || !resid || (variant != 0 && variant != 40)) return MI_ERR_ARG;
+    const bool wide = variant == 40;
+    if (wide ? !gemm_8p_supported(a, false) : !gemm_8p128_supported(a)) return MI_ERR_UNSUPPORTED;
     const int slot = mi_profile_hook_begin(stream, 2.0 * M * N * K);
-    const int rc = gemm_8p128_launch(a, 0, stream);
+    const int rc = wide ? gemm_8p_launch(a, false, stream) : gemm_8p128_launch(a, 0, stream);
     if (slot >= 0) mi_profile_hook_end(slot, stream);
     if (rc != MI_OK) return rc;
     MI_CHECK_LAUNCH();

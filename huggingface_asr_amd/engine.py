@@ -86,6 +86,8 @@ class EBranchformerEngine:
         # True / False force it (tests; HFASR_LN_FOLD=0/1 sets the default)
         env = os.environ.get("HFASR_LN_FOLD")
         self.ln_fold = None if env is None else env == "1"
+        # throughput mode (mi_ebf_config.wide_tiles; pipeline.ForwardPipeline sets it): the N = d GEMMs on 256 x 256 tiles — for several steps in flight, not for one alone
+        self.wide_tiles = False
         self.weights = {}
         self._table = None
         self._ws = {}
@@ -252,7 +254,7 @@ class EBranchformerEngine:
     def _config_struct(self, B, T, F, slot=0):
         c = self.cfg
         fold = int(self._use_fold(B, self.out_frames(T)))
-        return _lib.EbfConfig(ln_fold=fold, B=B, T=T, F=F, d=c["hidden_size"], H=c["num_attention_heads"], I=c["intermediate_size"],
+        return _lib.EbfConfig(ln_fold=fold, wide_tiles=int(bool(self.wide_tiles) and bool(fold)), B=B, T=T, F=F, d=c["hidden_size"], H=c["num_attention_heads"], I=c["intermediate_size"],
                               L=c["num_hidden_layers"], V=c["vocab_size"], C1=c["conv_dim"][0], C2=c["conv_dim"][1],
                               K=c["conv_kernel"][0], stride=c["conv_stride"][0], pad=c["conv_padding"][0],
                               is_causal=int(c.get("is_causal", False)), pos_type=POS[c.get("position_embeddings_type", "relative")],
@@ -264,7 +266,7 @@ class EBranchformerEngine:
                               csgu_linear=int(bool(c.get("csgu_use_linear_after_conv", False))), context_mode=self.ctx_mode, gate_blk=self.gate_blk)
 
     def _workspace(self, cs, slot=0):
-        key = (cs.B, cs.T, cs.F, cs.ln_fold)
+        key = (cs.B, cs.T, cs.F, cs.ln_fold, cs.wide_tiles)
         if self._ws.get("key") != key:
             self._ws = {"key": key}                                                        # keep one shape resident
         if slot not in self._ws:

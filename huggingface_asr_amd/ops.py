@@ -160,15 +160,16 @@ def gemm_lnfold(xb, wf, colsum, cbias, stats, npart, eps=1e-5, act="none", out=N
     return out
 
 
-def gemm_resid_stats(a, w, bias, resid, alpha=1.0):
-    """-> (C fp32 = resid + alpha (a W^T + b), C2 = bf16(C), stats (M,32) fp32 with one (sum, sumsq) pair per 32 columns of C)"""
+def gemm_resid_stats(a, w, bias, resid, alpha=1.0, wide=False):
+    """-> (C fp32 = resid + alpha (a W^T + b), C2 = bf16(C), stats (M,32) fp32 with one (sum, sumsq) pair per 32 columns of C — per 64 columns with `wide`,
+    the 256 x 256 tile of the throughput mode (mi_ebf_config.wide_tiles))"""
     M, K = a.shape
     N = w.shape[0]
     c = torch.empty((M, N), device=a.device, dtype=torch.float32)
     c2 = torch.empty((M, N), device=a.device, dtype=BF16)
     st = torch.zeros((M, 32), device=a.device, dtype=torch.float32)
-    _lib.check(_lib.lib().mi_gemm_resid_stats_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _p(bias), c.data_ptr(), c.stride(0), _p(resid), resid.stride(0) if resid is not None else 0,
-                                                  float(alpha), c2.data_ptr(), c2.stride(0), st.data_ptr(), M, N, K, _stream()), "mi_gemm_resid_stats_f32")
+    _lib.check(_lib.lib().mi_gemm_resid_stats_f32_v(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _p(bias), c.data_ptr(), c.stride(0), _p(resid), resid.stride(0) if resid is not None else 0,
+                                                    float(alpha), c2.data_ptr(), c2.stride(0), st.data_ptr(), M, N, K, 40 if wide else 0, _stream()), "mi_gemm_resid_stats_f32_v")
     return c, c2, st
 
 

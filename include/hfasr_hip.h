@@ -109,6 +109,9 @@ int mi_gemm_lnfold_bf16(const void* xb, long lda, const void* Wf, long ldw, cons
                         void* C, long ldc, int act, int M, int N, int K, mi_stream_t stream);
 int mi_gemm_resid_stats_f32(const void* A, long lda, const void* W, long ldw, const float* bias, float* C, long ldc, const float* resid, long ldr, float alpha,
                             void* C2, long ldc2, float* stats_out, int M, int N, int K, mi_stream_t stream);
+/* the same with the kernel chosen by the caller: variant 40 = the 256 x 256 tile (N % 256 == 0; partial statistics then come one pair per 64 columns), 0 = as above */
+int mi_gemm_resid_stats_f32_v(const void* A, long lda, const void* W, long ldw, const float* bias, float* C, long ldc, const float* resid, long ldr, float alpha,
+                              void* C2, long ldc2, float* stats_out, int M, int N, int K, int variant, mi_stream_t stream);
 int mi_layernorm_fold(const float* x, long ldx, const int* lengths, int T, const float* g1, const float* b1, float eps1, float* y32, long ldy,
                       void* yb_bf16, long ldyb, float* stats, int M, int d, mi_stream_t stream);
 
@@ -419,6 +422,10 @@ typedef struct {
                                     the N = d GEMMs that produce the residual stream also emit its bf16 copy and per-row partial statistics, the consumers take those instead of
                                     a LayerNorm kernel's output — one LayerNorm launch per layer instead of three.  Needs the layer slots *_WF / *_SF / *_CF (engine.py LS), relative
                                     or no positions, macaron FFNs, d in {256, 512}, I % 256 == 0, no fine-tuning head.  0: LayerNorm kernels + plain GEMMs. */
+    int wide_tiles;              /* throughput mode (with ln_fold): the N = d GEMMs of a layer (FFN out x2, attention out, cgMLP out, merge) run on 256 x 256 tiles too — a quarter
+                                    of the blocks of the 128 x 128 kernel (64 per launch at M = 8000, d = 512), 2x the FLOP per ingested byte.  Alone such a launch leaves most
+                                    of the chip idle; it is meant for several independent steps in flight on their own streams (huggingface_asr_amd/pipeline.py), whose kernels
+                                    then share the chip by CU instead of taking turns on all of it.  Same results as 0 up to the summation order of the row statistics. */
 } mi_ebf_config;
 
 /* weight-table slot indices: see huggingface_asr_amd/engine.py (SLOTS) — the table is an array of device pointers. */

@@ -147,22 +147,28 @@ def test_layernorm_fold_path_vs_reference(name, cfg):
     g = load_golden(name)
     sd, x, am, lab = case_inputs(g, cfg)
     outs = {}
-    for fold in (True, False):
+    for mode in ("fold", "plain", "wide"):
+        fold = mode != "plain"
         eng = EBranchformerEngine(cfg, DEV)
         eng.ln_fold = fold
+        eng.wide_tiles = mode == "wide"                                                # throughput mode: the N = d GEMMs on the 256 x 256 tile (mi_ebf_config.wide_tiles)
         eng.load_state_dict(sd)
-        assert eng._config_struct(2, 1000, 80).ln_fold == int(fold)
+        cs = eng._config_struct(2, 1000, 80)
+        assert cs.ln_fold == int(fold) and cs.wide_tiles == int(mode == "wide")
         out = eng.forward(x.to(DEV), am.sum(-1).to(DEV, torch.int32))
         loss, _, _ = ops.ctc_loss(out["logits"], lab.to(DEV), out["outer_len"], reduction="mean", zero_infinity=True)
-        outs[fold] = (out["logits"].float().cpu().numpy(), float(loss), out["last_hidden"].cpu().numpy())
-    logits, loss, hid = outs[True]
-    d1 = np.abs(logits[:, ::25, :64] - g["logits_slice"])
-    d2 = np.abs(logits[:, :, -1] - g["logits_blank"])
-    assert max(d1.max(), d2.max()) < 0.06 and max(d1.mean(), d2.mean()) < 0.009, (d1.max(), d2.max(), d1.mean(), d2.mean())
-    assert abs(loss - float(g["loss"])) < 1e-3 * abs(float(g["loss"])), (loss, float(g["loss"]))
-    dd = np.abs(logits - outs[False][0])
-    assert dd.max() < 0.05 and dd.mean() < 0.006, (dd.max(), dd.mean())
-    assert np.abs(hid[1, 175:]).max() < 10 and np.isfinite(hid).all()                 # padded frames stay finite (their statistics are those of a zero row)
+        outs[mode] = (out["logits"].float().cpu().numpy(), float(loss), out["last_hidden"].cpu().numpy())
+    for mode in ("fold", "wide"):
+        logits, loss, hid = outs[mode]
+        d1 = np.abs(logits[:, ::25, :64] - g["logits_slice"])
+        d2 = np.abs(logits[:, :, -1] - g["logits_blank"])
+        assert max(d1.max(), d2.max()) < 0.06 and max(d1.mean(), d2.mean()) < 0.009, (mode, d1.max(), d2.max(), d1.mean(), d2.mean())
+        assert abs(loss - float(g["loss"])) < 1e-3 * abs(float(g["loss"])), (mode, loss, float(g["loss"]))
+        dd = np.abs(logits - outs["plain"][0])
+        assert dd.max() < 0.05 and dd.mean() < 0.006, (mode, dd.max(), dd.mean())
+        assert np.abs(hid[1, 175:]).max() < 10 and np.isfinite(hid).all()                 # padded frames stay finite (their statistics are those of a zero row)
+    dw = np.abs(outs["wide"][0] - outs["fold"][0])                                       # the two tiles differ by summation order only
+    assert dw.max() < 0.02 and dw.mean() < 0.002, (dw.max(), dw.mean())
 
 
 def test_no_attention_mask_and_batch_invariance():
@@ -212,22 +218,30 @@ def test_forward_is_bit_reproducible_at_the_bench_size(overlap):
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), i
 
 
-def test_pipelined_steps_on_two_streams_reproduce_the_single_stream_bits():
-    """bench.py's default: consecutive steps (each its own batch of 32 clips, its own engine / workspace) in flight together on two HIP streams.  Whatever shares
-    the chip with a step's kernels, its logits are the bits the same engine gives alone — 24 overlapped steps at the bench size against the two references."""
+@pytest.mark.parametrize("lanes,wide", [(2, False), (4, True)], ids=["two_lanes", "four_lanes_wide_tiles"])
+def test_pipelined_steps_on_two_streams_reproduce_the_single_stream_bits(lanes, wide):
+    """bench.py's default: consecutive steps (each its own batch of 32 clips, its own engine / workspace) in flight together on HIP streams of their own.  Whatever shares
+    the chip with a step's kernels, its logits are the bits the same engine gives alone — 24 overlapped steps at the bench size against the per-lane references.
+    Second case: the throughput mode (256 x 256 tiles for the N = d GEMMs, four steps in flight)."""
     from huggingface_asr_amd import synth
     from huggingface_asr_amd.engine import EBranchformerEngine
     cfg = _cfg(shapes.BASE)
     sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()}
     from huggingface_asr_amd.pipeline import ForwardPipeline
     lens = torch.full((32,), 998, dtype=torch.int32, device=DEV)
-    pipe = ForwardPipeline(cfg, DEV, sd, lanes=2)
-    feats = [torch.from_numpy(synth.normal(11 + i, "feats", (32, 1000, 80), 1.0)).to(DEV) for i in range(2)]
-    refs = [pipe.engines[i].forward(feats[i], lens)["logits"].clone() for i in range(2)]          # each engine alone on the default stream
+    pipe = ForwardPipeline(cfg, DEV, sd, lanes=lanes, wide_tiles=wide)
+    assert all(e._config_struct(32, 1000, 80).wide_tiles == int(wide) for e in pipe.engines)
+    feats = [torch.from_numpy(synth.normal(11 + i, "feats", (32, 1000, 80), 1.0)).to(DEV) for i in range(lanes)]
+    refs = [pipe.engines[i].forward(feats[i], lens)["logits"].clone() for i in range(lanes)]          # each engine alone on the default stream
     torch.cuda.synchronize()
+    if wide:                                                                                          # and the wide tiles compute the product tile's rows
+        plain = EBranchformerEngine(cfg, DEV)
+        plain.load_state_dict(sd)
+        dd = (plain.forward(feats[0], lens)["logits"].float() - refs[0].float()).abs()
+        assert float(dd.max()) < 0.05 and float(dd.mean()) < 0.003, (float(dd.max()), float(dd.mean()))
     outs = [pipe.submit(lambda e, lane: e.forward(feats[lane], lens)["logits"].clone()) for _ in range(24)]       # the clone runs on the lane's stream, behind its forward
     torch.cuda.synchronize()
-    assert [lane for lane, _ in outs] == [j % 2 for j in range(24)]
+    assert [lane for lane, _ in outs] == [j % lanes for j in range(24)]
     for k, (lane, got) in enumerate(outs):
         assert torch.equal(got, refs[lane]), k
 

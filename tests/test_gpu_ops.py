@@ -354,23 +354,42 @@ def test_context_aware_front_end_pieces():
     assert_close_bf16(got2, want2, what="shared gate conv2")
 
 
-@pytest.mark.parametrize("M,d,I", [(1000, 512, 2048), (700, 256, 1024)])
-def test_layernorm_folded_into_the_gemms(M, d, I):
+def _lib_call_inplace(ops, a_in, w_p, b_p, x, alpha):
+    from huggingface_asr_amd import _lib
+    a, w, b = a_in.to(DEV, torch.bfloat16), w_p.to(DEV, torch.bfloat16), b_p.to(DEV)
+    M, K = a.shape
+    N = w.shape[0]
+    c2 = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+    st = torch.zeros((M, 32), device=DEV, dtype=torch.float32)
+    _lib.check(_lib.lib().mi_gemm_resid_stats_f32_v(a.data_ptr(), K, w.data_ptr(), K, b.data_ptr(), x.data_ptr(), N, x.data_ptr(), N, float(alpha), c2.data_ptr(), N, st.data_ptr(),
+                                                    M, N, K, 40, torch.cuda.current_stream().cuda_stream), "mi_gemm_resid_stats_f32_v")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,d,I,wide", [(1000, 512, 2048, False), (700, 256, 1024, False), (1000, 512, 2048, True), (700, 256, 1024, True)])
+def test_layernorm_folded_into_the_gemms(M, d, I, wide):
     """LN(x) W^T + b evaluated as rstd (bf16(x) W'^T) - rstd mu colsum(W') + (W beta + b) (csrc/gemm_args.hpp): the producer GEMM's epilogue (fp32 rows + bf16 copy + per-row
-    partial statistics), the LayerNorm kernel's producer mode, and the consumer GEMM with both statistic forms (1 pair / one pair per 32 columns), against torch."""
+    partial statistics), the LayerNorm kernel's producer mode, and the consumer GEMM with both statistic forms (1 pair / one pair per 32 columns), against torch.
+    `wide`: the producer on the 256 x 256 tile of the throughput mode (one pair per 64 columns)."""
     ops = _ops()
     x0 = rnd(M, d, seed=41, scale=2.0) + 0.7                                        # a residual stream with a mean
     a_in, w_p, b_p = bfr(rnd(M, I, seed=42)), bfr(rnd(d, I, seed=43, scale=I ** -0.5)), rnd(d, seed=44, scale=0.1)
     gam, bet = 1.0 + 0.2 * rnd(d, seed=45), 0.1 * rnd(d, seed=46)
     W, b = rnd(I, d, seed=47, scale=d ** -0.5), rnd(I, seed=48, scale=0.1)
     # producer: x = x0 + 0.5 (a W_p^T + b_p)
-    c, c2, st = ops.gemm_resid_stats(a_in.to(DEV, torch.bfloat16), w_p.to(DEV, torch.bfloat16), b_p.to(DEV), x0.to(DEV), alpha=0.5)
+    c, c2, st = ops.gemm_resid_stats(a_in.to(DEV, torch.bfloat16), w_p.to(DEV, torch.bfloat16), b_p.to(DEV), x0.to(DEV), alpha=0.5, wide=wide)
     x = x0 + 0.5 * (a_in @ w_p.t() + b_p)
     torch.testing.assert_close(c.cpu(), x, atol=2e-3, rtol=1e-4)
     assert torch.equal(c2.cpu(), c.cpu().to(torch.bfloat16))                        # the bf16 copy IS the rounded stored row
-    npart = d // 32
+    npart = d // (64 if wide else 32)
     pairs = st.cpu().view(M, 16, 2)[:, :npart]
-    xs = c.cpu().view(M, npart, 32)
+    xs = c.cpu().view(M, npart, d // npart)
+    if wide:                                                                        # same rows as the product's tile, up to the summation order over K
+        c0 = ops.gemm_resid_stats(a_in.to(DEV, torch.bfloat16), w_p.to(DEV, torch.bfloat16), b_p.to(DEV), x0.to(DEV), alpha=0.5)[0]
+        torch.testing.assert_close(c, c0, atol=2e-5, rtol=1e-5)
+        xin = x0.to(DEV).clone()                                                    # in place over the residual, as the layer calls it
+        _lib_call_inplace(ops, a_in, w_p, b_p, xin, 0.5)
+        assert torch.equal(xin, c)
     torch.testing.assert_close(pairs[..., 0], xs.sum(-1), atol=1e-3, rtol=1e-5)
     torch.testing.assert_close(pairs[..., 1], (xs * xs).sum(-1), atol=1e-2, rtol=1e-5)
     # consumer on the producer's outputs
