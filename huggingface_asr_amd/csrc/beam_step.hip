@@ -1,0 +1,188 @@
+// One beam-search step of joint CTC / attention decoding, entirely on the device (BASELINE config 5: streaming bs = 1 latency).
+//
+// Replaces, per emitted token, what the reference runs on the host through transformers' GenerationMixin beam loop and BeamSearchScorer.process
+// (reference call site: src/models/ctc_encoder_plus_autoregressive_decoder.py:360-482, processors src/decoding/ctc_scorer.py:259-365):
+//     scores = log_softmax(decoder logits);  scores[:, pad] = logzero;  scores = (1 - w) scores + w ctc;  cand = scores + beam score
+//     top 2W of the W * V candidates of an utterance, best first
+//     walk them in order: EOS among the first W ranks closes a hypothesis (score / len ** length_penalty), the first W others continue as the next beams
+//     the utterance is done when W hypotheses are closed and the best running candidate cannot beat the worst of the best W (early_stopping = False)
+//     input ids follow their beams and get the new token appended
+// The host loop did this with two device -> host copies, a Python walk and three host -> device copies per token (~0.3 ms of a 0.8 ms token); here it is one
+// launch, nothing leaves the device until decoding ends, and the host only enqueues.  Arithmetic is the host loop's, operation for operation (fp32 subtract,
+// two multiplies and an add without contraction, fp32 beam add, double division for the closed hypotheses), so both produce the same hypotheses bit for bit.
+#include "common.hpp"
+#include "../../include/hfasr_hip.h"
+
+namespace {
+
+constexpr float LOGZERO = -10000000000.0f;
+constexpr int BS_THREADS = 1024, BS_WAVES = BS_THREADS / 64, BS_MAXW = 16;
+
+struct BeamArgs {
+    const float* logits; long ldl;        // (B * W, V) decoder logits of the last position
+    const float* lse;                     // (B * W) their row log-sum-exp (mi_row_lse)
+    const float* ctc;                     // (B * W, V) CTC prefix scores or null
+    float w_att, w_ctc;
+    int pad, eos, B, W, V, cur_len, Lmax, cap;
+    double denom;                         // cur_len ** length_penalty
+    long* ids;                            // (B * W, Lmax), updated in place
+    float* beam_scores;                   // (B * W), updated in place
+    long* new_tok;                        // (B * W)
+    long* beam_idx;                       // (B * W)
+    int* done; int* nfin; double* fin_score; int* fin_len; long* fin_tok;
+    float* top_s; int* top_i;             // optional (B, 2W): the candidates the step walked
+};
+
+// the host loop's arithmetic, one rounding per operation: no multiply-add contraction here (HIP's __fmul_rn / __fadd_rn are plain operators, so the pragma is what holds it)
+__device__ __forceinline__ float cand_value(const BeamArgs& p, int b, int e) {
+#pragma clang fp contract(off)
+    const int beam = e / p.V, tok = e - beam * p.V;
+    const long row = (long)b * p.W + beam;
+    float s = p.logits[row * p.ldl + tok] - p.lse[row];
+    if (tok == p.pad) s = LOGZERO;
+    if (p.ctc) {
+        const float a = p.w_att * s, c = p.w_ctc * p.ctc[row * p.V + tok];
+        s = a + c;
+    }
+    return s + p.beam_scores[row];
+}
+
+// candidates are ordered by (value descending, index ascending); `after` = the last one taken
+__device__ __forceinline__ bool comes_after(float v, int e, float pv, int pe) { return v < pv || (v == pv && e > pe); }
+__device__ __forceinline__ bool better(float v, int e, float bv, int be) { return v > bv || (v == bv && e < be); }
+
+__global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(BeamArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    long* stage = reinterpret_cast<long*>(smem);                       // [W][cur_len] the utterance's input ids before the step
+    __shared__ float wv[BS_WAVES];
+    __shared__ int we[BS_WAVES];
+    __shared__ float tops[2 * BS_MAXW];
+    __shared__ int topi[2 * BS_MAXW];
+    __shared__ float nbs[BS_MAXW];
+    __shared__ long nbt[BS_MAXW];
+    __shared__ int nbb[BS_MAXW];                                       // source beam (within the utterance) of every next beam
+    __shared__ int app_slot[BS_MAXW], app_beam[BS_MAXW], napp;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int W = p.W, N = W * p.V, R = 2 * W;
+    const bool was_done = p.done[b] != 0;
+
+    // ---- top 2W: every thread owns the candidates tid, tid + 1024, ... and offers its best one not yet taken; the owner of a round's winner re-scans
+    float mv = -INFINITY; int me = 0x7fffffff;
+    if (!was_done)
+        for (int e = tid; e < N; e += BS_THREADS) {
+            const float v = cand_value(p, b, e);
+            if (better(v, e, mv, me)) { mv = v; me = e; }
+        }
+    for (int r = 0; r < R && !was_done; ++r) {
+        const float wm = wave_max(mv);
+        const float ecand = (mv == wm && me != 0x7fffffff) ? -(float)me : -INFINITY;      // indices < 2^24: exact in fp32
+        const float em = wave_max(ecand);
+        if (lane == 0) { wv[wave] = wm; we[wave] = em == -INFINITY ? 0x7fffffff : (int)(-em); }
+        __syncthreads();
+        float bv = wv[0]; int be = we[0];
+#pragma unroll
+        for (int k = 1; k < BS_WAVES; ++k)
+            if (better(wv[k], we[k], bv, be)) { bv = wv[k]; be = we[k]; }
+        if (tid == 0) { tops[r] = bv; topi[r] = be; }
+        if (be != 0x7fffffff && (be % BS_THREADS) == tid) {            // my candidate was taken: next best of my subset
+            mv = -INFINITY; me = 0x7fffffff;
+            for (int e = tid; e < N; e += BS_THREADS) {
+                const float v = cand_value(p, b, e);
+                if (comes_after(v, e, bv, be) && better(v, e, mv, me)) { mv = v; me = e; }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- the utterance's ids before the step
+    for (int i = tid; i < W * p.cur_len; i += BS_THREADS) {
+        const int k = i / p.cur_len, j = i - k * p.cur_len;
+        stage[i] = p.ids[((long)b * W + k) * p.Lmax + j];
+    }
+
+    // ---- walk the candidates (one thread: at most 2W steps)
+    if (tid == 0) {
+        napp = 0;
+        for (int k = 0; k < W; ++k) { nbs[k] = 0.f; nbt[k] = was_done ? p.pad : 0; nbb[k] = 0; }
+        if (!was_done) {
+            int nf = p.nfin[b], k = 0;
+            for (int r = 0; r < R; ++r) {
+                const float s = tops[r];
+                const int idx = topi[r];
+                if (idx == 0x7fffffff) break;
+                const int beam = idx / p.V, tok = idx - beam * p.V;
+                if (tok == p.eos) {
+                    if (r >= W) continue;
+                    if (nf < p.cap) {
+                        p.fin_score[(long)b * p.cap + nf] = (double)s / p.denom;
+                        p.fin_len[(long)b * p.cap + nf] = p.cur_len + 1;
+                        app_slot[napp] = nf; app_beam[napp] = beam; ++napp;
+                    }
+                    ++nf;
+                } else {
+                    nbs[k] = s; nbt[k] = tok; nbb[k] = beam;
+                    ++k;
+                }
+                if (k == W) break;
+            }
+            if (nf > p.cap) nf = p.cap;
+            p.nfin[b] = nf;
+            if (nf >= W) {                                             // worst of the best W closed hypotheses
+                const double* fs = p.fin_score + (long)b * p.cap;
+                double worst = 0.0;
+                int taken[BS_MAXW];
+                for (int q = 0; q < W; ++q) {
+                    int bi = -1;
+                    for (int i = 0; i < nf; ++i) {
+                        bool used = false;
+                        for (int u = 0; u < q; ++u) used = used || taken[u] == i;
+                        if (!used && (bi < 0 || fs[i] > fs[bi])) bi = i;
+                    }
+                    taken[q] = bi; worst = fs[bi];
+                }
+                if ((double)tops[0] / p.denom <= worst) p.done[b] = 1;
+            }
+        }
+        if (p.top_s)
+            for (int r = 0; r < R; ++r) { p.top_s[(long)b * R + r] = was_done ? 0.f : tops[r]; p.top_i[(long)b * R + r] = was_done ? 0 : topi[r]; }
+    }
+    __syncthreads();
+
+    // ---- closed hypotheses keep their tokens; the ids follow their beams and take the new token
+    for (int a = 0; a < napp; ++a) {
+        long* dst = p.fin_tok + ((long)b * p.cap + app_slot[a]) * p.Lmax;
+        for (int j = tid; j < p.cur_len; j += BS_THREADS) dst[j] = stage[app_beam[a] * p.cur_len + j];
+        if (tid == 0) dst[p.cur_len] = p.eos;
+    }
+    for (int i = tid; i < W * p.cur_len; i += BS_THREADS) {
+        const int k = i / p.cur_len, j = i - k * p.cur_len;
+        p.ids[((long)b * W + k) * p.Lmax + j] = stage[nbb[k] * p.cur_len + j];
+    }
+    if (tid < W) {
+        const long row = (long)b * W + tid;
+        p.ids[row * p.Lmax + p.cur_len] = nbt[tid];
+        p.new_tok[row] = nbt[tid];
+        p.beam_idx[row] = (long)b * W + nbb[tid];
+        p.beam_scores[row] = nbs[tid];
+    }
+}
+
+}  // namespace
+
+extern "C" int mi_beam_step(const float* logits, long ldl, const float* lse, const float* ctc, float w_att, float w_ctc, int pad, int eos, int B, int W, int V,
+                            int cur_len, int Lmax, double denom, long* ids, float* beam_scores, long* new_tok, long* beam_idx, int* done, int* nfin,
+                            double* fin_score, int* fin_len, long* fin_tok, int cap, float* top_s, int* top_i, hipStream_t stream) {
+    MI_ENTER();
+    if (!logits || !lse || !ids || !beam_scores || !new_tok || !beam_idx || !done || !nfin || !fin_score || !fin_len || !fin_tok) return MI_ERR_ARG;
+    if (B <= 0 || W <= 0 || W > BS_MAXW || V <= 0 || (long)W * V >= (1l << 24) || cur_len <= 0 || cur_len >= Lmax || cap < W || pad < 0 || pad >= V || !(denom > 0.0))
+        return MI_ERR_ARG;
+    const size_t lds = (size_t)W * cur_len * sizeof(long);
+    if (lds > 96 * 1024) return MI_ERR_UNSUPPORTED;
+    BeamArgs a{logits, ldl, lse, ctc, w_att, w_ctc, pad, eos, B, W, V, cur_len, Lmax, cap, denom, ids, beam_scores, new_tok, beam_idx, done, nfin, fin_score, fin_len, fin_tok,
+               top_s, top_i};
+    static const bool attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(beam_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+    if (!attr_set) return MI_ERR_LAUNCH;
+    hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(BS_THREADS), lds, stream, a);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}

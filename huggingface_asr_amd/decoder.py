@@ -266,7 +266,114 @@ class JointAEDEngine:
 # scores = log_softmax(decoder logits) -> pad masked -> (1-w)*att + w*ctc -> + beam score -> top 2W over W*V ->
 # finished hypotheses scored sum_logprob / len**length_penalty (HF BeamSearchScorer semantics, early_stopping=False).
 def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_length=64, ctc_weight=0.3, length_penalty=1.0,
+             eos_token_id=1, pad_token_id=None, start_token_id=None, space_token_id=-1, run_ahead=2):
+    """Device-resident decoding loop: per token the decoder step (one C call), the row log-sum-exp and ONE launch that mixes the CTC prefix scores in, takes the top 2W
+    candidates, walks them with BeamSearchScorer's rules and moves ids / beam scores / closed hypotheses on the device (csrc/beam_step.hip).  The CTC prefix scorer of step t
+    depends on the prefixes only, not on the decoder's logits: it runs on a second stream beside the decoder step.  Nothing is copied to the host until decoding ends, except
+    the per-utterance `done` flags (pinned, asynchronous): the host stays at most `run_ahead` steps in front of the GPU and stops enqueuing once every utterance is done.
+    Same hypotheses, scores and order as `generate_stepwise` (same arithmetic, operation for operation)."""
+    from .decoding import CTCRescorerLogitsProcessor
+    dev = joint.device
+    c = joint.jcfg
+    pad = c["pad_token_id"] if pad_token_id is None else pad_token_id
+    start = c["decoder_start_token_id"] if start_token_id is None else start_token_id
+    W = num_beams
+    L_ = _lib.lib()
+    main = torch.cuda.current_stream()
+    enc_out, enc_bf, T2, key_len = joint.encode(feats, feat_len)
+    B = feats.shape[0]
+    d = enc_bf.shape[1]
+    V = joint.dec.w["lm_head"].shape[0]
+    if W > 16 or W * V >= (1 << 24):
+        raise NotImplementedError("generate: num_beams <= 16 and num_beams * vocabulary < 2^24 (use generate_stepwise)")
+    enc_rep = enc_bf.view(B, T2, d).repeat_interleave(W, 0).reshape(B * W * T2, d)
+    key_rep = key_len.repeat_interleave(W) if key_len is not None else None
+    kvs = joint.dec.cross_kv(enc_rep)
+    Lmax = max_length + 1
+    cache = joint.dec.init_cache(B * W, Lmax)
+    proc, side = None, None
+    if ctc_weight > 0:
+        lens = enc_out["outer_len"].clamp(max=T2)
+        proc = CTCRescorerLogitsProcessor(enc_out["logits"], lens, pad, eos_token_id, 0, ctc_weight, W, space_token_id, False, 1.0)
+        if proc.O != V:
+            raise ValueError(f"CTC head has {proc.O} classes, the decoder {V}: joint decoding needs one vocabulary")
+        side = torch.cuda.Stream(device=dev)
+    n_bh = B * W
+    ids = torch.full((n_bh, Lmax), pad, dtype=torch.long, device=dev)
+    ids[:, 0] = start
+    beam_scores = torch.zeros((B, W), device=dev)
+    beam_scores[:, 1:] = -1e9
+    beam_scores = beam_scores.view(-1).contiguous()
+    cap = W * max_length
+    done = torch.zeros((B,), dtype=torch.int32, device=dev)
+    nfin = torch.zeros((B,), dtype=torch.int32, device=dev)
+    fin_score = torch.zeros((B, cap), dtype=torch.float64, device=dev)
+    fin_len = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    fin_tok = torch.zeros((B, cap, Lmax), dtype=torch.long, device=dev)
+    done_host = torch.zeros((max_length, B), dtype=torch.int32).pin_memory()
+    new_tok = ids[:, :1].contiguous()
+    keep, flags = [], []                       # tensors another stream still reads stay referenced until the end; (event, step) of the done-flag copies
+    ev_ids = torch.cuda.Event()
+    ev_ids.record(main)
+    cur_len, steps = 1, 0
+    w_att, w_ctc = float(1 - ctc_weight), float(ctc_weight)
+    while cur_len < max_length:
+        if len(flags) >= run_ahead:            # bounded run-ahead: wait for the flags of step (now - run_ahead) and stop if everything is done
+            ev, t = flags[len(flags) - run_ahead]
+            ev.synchronize()
+            if bool(done_host[t].all()):
+                break
+        ctc = None
+        if proc is not None:                   # prefix scores of this step on the side stream (needs the ids the previous step left)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_ids)
+                ctc = proc.ctc_scores(ids[:, :cur_len])
+                ev_ctc = torch.cuda.Event()
+                ev_ctc.record(side)
+            keep.append((ctc, proc.state))
+        logits = joint.dec.step(new_tok, cache, kvs, T2, key_rep)                       # (B*W, V), row stride padded to 8
+        lse = ops.row_lse(logits)
+        if proc is not None:
+            main.wait_event(ev_ctc)
+        new_tok = torch.empty((n_bh, 1), dtype=torch.long, device=dev)
+        beam_idx = torch.empty((n_bh,), dtype=torch.long, device=dev)
+        _lib.check(L_.mi_beam_step(logits.data_ptr(), logits.stride(0), lse.data_ptr(), ctc.data_ptr() if ctc is not None else None, w_att, w_ctc, pad, eos_token_id,
+                                   B, W, V, cur_len, Lmax, float(cur_len ** length_penalty), ids.data_ptr(), beam_scores.data_ptr(), new_tok.data_ptr(), beam_idx.data_ptr(),
+                                   done.data_ptr(), nfin.data_ptr(), fin_score.data_ptr(), fin_len.data_ptr(), fin_tok.data_ptr(), cap, None, None, main.cuda_stream),
+                   "mi_beam_step")
+        ev_ids = torch.cuda.Event()
+        ev_ids.record(main)
+        if W > 1:
+            joint.dec.reorder_cache(cache, beam_idx)
+        done_host[steps].copy_(done, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        flags.append((ev, steps))
+        keep.append((logits, lse, new_tok, beam_idx))
+        cur_len += 1
+        steps += 1
+    if side is not None:
+        main.wait_stream(side)
+    ids_cpu, bs = ids[:, :cur_len].cpu(), beam_scores.cpu().view(B, W)                  # the first copy synchronises with everything enqueued
+    done_c, nfin_c, fs_c, fl_c, ft_c = done.cpu(), nfin.cpu(), fin_score.cpu(), fin_len.cpu(), fin_tok.cpu()
+    # steps enqueued after every utterance was done changed nothing but the ids' tail (pad tokens): drop them like the host loop, which never ran them
+    n_done = next((t + 1 for t in range(steps) if bool(done_host[t].all())), steps)
+    out_len = 1 + n_done
+    out = []
+    for b in range(B):
+        finished = [(float(fs_c[b, k]), ft_c[b, k, :int(fl_c[b, k])].tolist()) for k in range(int(nfin_c[b]))]
+        if not bool(done_c[b]):
+            for k in range(W):
+                finished.append((float(bs[b, k]) / (out_len ** length_penalty), ids_cpu[b * W + k, :out_len].tolist()))
+        best = max(finished, key=lambda t: t[0])
+        out.append(dict(tokens=best[1], score=best[0], hypotheses=sorted(finished, key=lambda t: -t[0])))      # hypotheses: every kept (score, tokens), best first
+    return out
+
+
+def generate_stepwise(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_length=64, ctc_weight=0.3, length_penalty=1.0,
              eos_token_id=1, pad_token_id=None, start_token_id=None, space_token_id=-1):
+    """The same decoding with the beam bookkeeping on the host, one token at a time (two device -> host copies and three host -> device copies per token): the form the
+    reference's generate() has, kept as the cross-check of `generate` (tests/test_gpu_config5.py, tests/test_gpu_aed.py compare the two hypothesis for hypothesis)."""
     from .decoding import CTCRescorerLogitsProcessor
     dev = joint.device
     c = joint.jcfg

@@ -385,6 +385,17 @@ int mi_gpt2_step(const mi_gpt2_config* cfg, const void* const* weights, const lo
 int mi_kv_cache_reorder(const void* const* src_k, const void* const* src_v, void* const* dst_k, void* const* dst_v, const long* beam_idx,
                         int L, int BW, int rows, int Lmax, int d, mi_stream_t stream);
 
+/* One beam-search step of joint CTC / attention decoding on the device (csrc/beam_step.hip): what the reference gets per token from transformers' beam loop +
+   BeamSearchScorer.process on the host (src/models/ctc_encoder_plus_autoregressive_decoder.py:360-482; processors src/decoding/ctc_scorer.py:259-365).
+   cand = ((1 - w)(logits - lse, pad -> logzero) + w ctc) + beam_scores  [ctc null: no mix];  top 2W per utterance, best first, ties by lower index;  EOS within the first W
+   ranks closes a hypothesis with score / denom (denom = cur_len ** length_penalty, computed by the caller in double) into fin_* (B, cap[, Lmax]); the first W other
+   candidates become the next beams: ids (B*W, Lmax) re-ordered in place + the new token at column cur_len, new_tok / beam_idx / beam_scores (B*W) written;
+   done[b] is set when >= W hypotheses are closed and top score / denom <= the W-th best closed score; a done utterance only emits pad tokens from beam b*W.
+   top_s / top_i (B, 2W) optional.  W <= 16, W * V < 2^24. */
+int mi_beam_step(const float* logits, long ldl, const float* lse, const float* ctc, float w_att, float w_ctc, int pad, int eos, int B, int W, int V,
+                 int cur_len, int Lmax, double denom, long* ids, float* beam_scores, long* new_tok, long* beam_idx, int* done, int* nfin,
+                 double* fin_score, int* fin_len, long* fin_tok, int cap, float* top_s, int* top_i, mi_stream_t stream);
+
 /* ---- Whisper-style front end + glue (BASELINE config 4).  replaces: transformers WhisperFeatureExtractor numpy path
  *      (selected by configs/default_data_preprocessing_whisper.json:20-29) and the conv/position prologue of WhisperEncoder. */
 /* scratch: B * frames * nmel + B floats (frames = n_samples / 160): the log-mel before the clamp, then the per-clip maxima. */

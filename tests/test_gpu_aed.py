@@ -143,3 +143,109 @@ def test_c_step_driver_matches_python_step_and_reorders_cache():
     # decoding continues on the re-ordered cache
     a = eng.dec.step(ids[:, 7:8], ca, kvs, T2, key_len)
     assert torch.isfinite(a).all()
+
+
+def _host_beam_step(logits, lse, ctc, w, pad, eos, B, W, V, cur_len, lp, ids, beam_scores, done, finished):
+    """the host loop's bookkeeping for one token (decoder.generate_stepwise), on CPU tensors"""
+    scores = logits - lse[:, None]
+    scores[:, pad] = -10000000000.0
+    if ctc is not None:
+        scores = (1 - w) * scores + w * ctc
+    cand = (scores + beam_scores[:, None]).view(B, W * V)
+    top = []
+    for b in range(B):                                      # (value descending, index ascending), as the kernel breaks ties
+        vals = cand[b].tolist()
+        order = sorted(range(W * V), key=lambda i: (-vals[i], i))[:2 * W]
+        top.append([(vals[i], i) for i in order])
+    nb_s, nb_t, nb_i = torch.zeros(B, W), torch.zeros(B, W, dtype=torch.long), torch.zeros(B, W, dtype=torch.long)
+    for b in range(B):
+        if done[b]:
+            nb_s[b] = 0; nb_t[b] = pad; nb_i[b] = b * W
+            continue
+        k = 0
+        for rank, (s, idx) in enumerate(top[b]):
+            s = float(np.float32(s))
+            beam, tok = idx // V, idx % V
+            if tok == eos:
+                if rank >= W:
+                    continue
+                finished[b].append((s / (cur_len ** lp), ids[b * W + beam].tolist() + [tok]))
+            else:
+                nb_s[b, k], nb_t[b, k], nb_i[b, k] = s, tok, b * W + beam
+                k += 1
+            if k == W:
+                break
+        if len(finished[b]) >= W:
+            worst = sorted(finished[b], key=lambda t: -t[0])[W - 1][0]
+            if float(np.float32(top[b][0][0])) / (cur_len ** lp) <= worst:
+                done[b] = True
+    bi = nb_i.view(-1)
+    return torch.cat([ids.index_select(0, bi), nb_t.view(-1, 1)], 1), nb_s.view(-1), nb_t.view(-1), bi
+
+
+@pytest.mark.parametrize("B,W,V,with_ctc", [(3, 4, 50, True), (2, 1, 37, True), (2, 5, 5001, False), (1, 16, 300, True)])
+def test_beam_step_kernel_follows_the_host_bookkeeping(B, W, V, with_ctc):
+    """csrc/beam_step.hip against the host loop's rules on random scores with a strong EOS (hypotheses close at most steps, utterances finish at different steps):
+    candidates, next beams, re-ordered ids, closed hypotheses and the done flags, bit for bit, over a whole decode."""
+    from huggingface_asr_amd import _lib, ops
+    gen = torch.Generator().manual_seed(B * 1000 + W * 10 + V)
+    pad, eos, lp, steps = V - 1, 1, 1.0, 9
+    Lmax, cap, w = steps + 2, W * (steps + 1), 0.3
+    n = B * W
+    ids = torch.full((n, Lmax), pad, dtype=torch.long); ids[:, 0] = 2
+    bs = torch.zeros(B, W); bs[:, 1:] = -1e9
+    d_ids, d_bs = ids.to(DEV), bs.view(-1).contiguous().to(DEV)
+    d_done, d_nfin = torch.zeros(B, dtype=torch.int32, device=DEV), torch.zeros(B, dtype=torch.int32, device=DEV)
+    d_fs, d_fl = torch.zeros(B, cap, dtype=torch.float64, device=DEV), torch.zeros(B, cap, dtype=torch.int32, device=DEV)
+    d_ft = torch.zeros(B, cap, Lmax, dtype=torch.long, device=DEV)
+    h_ids, h_bs, h_done, h_fin = ids[:, :1].clone(), bs.view(-1).clone(), [False] * B, [[] for _ in range(B)]
+    for t in range(steps):
+        cur = t + 1
+        Vp = (V + 7) // 8 * 8
+        buf = torch.randn(n, Vp, generator=gen) * 2.0
+        buf[:, eos] += 3.0 if t >= 1 else -5.0                     # EOS near the top from the second step on
+        logits = buf.to(DEV)[:, :V]
+        lse = ops.row_lse(logits)
+        ctc = (torch.randn(n, V, generator=gen) * 3.0 - 5.0) if with_ctc else None
+        d_ctc = ctc.to(DEV) if with_ctc else None
+        new_tok, beam_idx = torch.empty(n, dtype=torch.long, device=DEV), torch.empty(n, dtype=torch.long, device=DEV)
+        top_s, top_i = torch.empty(B, 2 * W, device=DEV), torch.empty(B, 2 * W, dtype=torch.int32, device=DEV)
+        _lib.check(_lib.lib().mi_beam_step(logits.data_ptr(), logits.stride(0), lse.data_ptr(), d_ctc.data_ptr() if with_ctc else None, float(1 - w), float(w), pad, eos,
+                                           B, W, V, cur, Lmax, float(cur ** lp), d_ids.data_ptr(), d_bs.data_ptr(), new_tok.data_ptr(), beam_idx.data_ptr(), d_done.data_ptr(),
+                                           d_nfin.data_ptr(), d_fs.data_ptr(), d_fl.data_ptr(), d_ft.data_ptr(), cap, top_s.data_ptr(), top_i.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream), "mi_beam_step")
+        was_done = list(h_done)
+        h_ids, h_bs, h_tok, h_bi = _host_beam_step(logits.cpu().clone(), lse.cpu(), ctc, w, pad, eos, B, W, V, cur, lp, h_ids, h_bs, h_done, h_fin)
+        assert torch.equal(d_ids.cpu()[:, :cur + 1], h_ids), t
+        assert torch.equal(d_bs.cpu(), h_bs) and torch.equal(new_tok.cpu(), h_tok) and torch.equal(beam_idx.cpu(), h_bi), t
+        assert d_done.cpu().bool().tolist() == h_done, t
+        assert d_nfin.cpu().tolist() == [len(f) for f in h_fin], t
+        ts = top_s.cpu()
+        for b in range(B):
+            if not was_done[b]:
+                assert bool((ts[b, :-1] >= ts[b, 1:]).all())
+    fs, fl, ft = d_fs.cpu(), d_fl.cpu(), d_ft.cpu()
+    assert sum(len(f) for f in h_fin) > 0 and (any(h_done) or V > 1000)  # the case exercises closing and (small vocabularies: EOS strong enough) finishing
+    for b in range(B):
+        for k, (s, toks) in enumerate(h_fin[b]):
+            assert float(fs[b, k]) == s and ft[b, k, :int(fl[b, k])].tolist() == toks, (b, k)
+
+
+@pytest.mark.parametrize("W,ctc_weight", [(1, 0.3), (3, 0.3), (5, 0.3), (3, 0.0)])
+def test_device_resident_decoding_equals_the_stepwise_loop(W, ctc_weight):
+    """decoder.generate (beam bookkeeping on the device, CTC prefix scorer on a second stream, no host copy per token) against decoder.generate_stepwise (the host loop)
+    on the reference-pinned tiny AED model: same hypotheses, same scores, same order — also when an EOS chosen from the greedy path closes hypotheses and ends decoding early."""
+    from huggingface_asr_amd.decoder import JointAEDEngine, generate, generate_stepwise
+    g = load_golden("aed_tiny")
+    sd, x, am, lab = aed_case_inputs(g)
+    eng = JointAEDEngine(_enc_cfg(), dict(TINY_DEC), AED_JCFG, DEV)
+    eng.load_state_dict(sd)
+    fl = am.sum(-1).to(DEV, torch.int32)
+    greedy = generate_stepwise(eng, x.to(DEV), fl, num_beams=1, max_length=12, ctc_weight=ctc_weight, eos_token_id=10 ** 6)
+    for eos in (10 ** 6, greedy[0]["tokens"][3], greedy[1]["tokens"][5]):                # never / early for utterance 0 / later
+        want = generate_stepwise(eng, x.to(DEV), fl, num_beams=W, max_length=12, ctc_weight=ctc_weight, eos_token_id=eos)
+        for ahead in (1, 2, 4):
+            got = generate(eng, x.to(DEV), fl, num_beams=W, max_length=12, ctc_weight=ctc_weight, eos_token_id=eos, run_ahead=ahead)
+            for b in range(2):
+                assert got[b]["tokens"] == want[b]["tokens"] and got[b]["score"] == want[b]["score"], (eos, ahead, b, got[b], want[b])
+                assert got[b]["hypotheses"] == want[b]["hypotheses"], (eos, ahead, b)

@@ -4,7 +4,7 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from huggingface_asr_amd import fbank as FB, shapes, synth
-from huggingface_asr_amd.decoder import JointAEDEngine, generate
+from huggingface_asr_amd.decoder import JointAEDEngine, generate, generate_stepwise
 
 dev = "cuda:0"
 enc_cfg = dict(shapes.BASE, vocab_size=5000, ctc_zero_infinity=True, ctc_loss_reduction="mean")
@@ -32,10 +32,14 @@ eng.load_state_dict(sd)
 wave = torch.from_numpy(synth.waveforms(1, 1, 160000)).to(dev)
 tb = FB.FbankTables(80)
 for W, maxlen in ((1, 40), (5, 40)):
-    for rep in range(3):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        feats, frames = FB.fbank_gpu(wave, tb, pad_frames_to=100)
-        out = generate(eng, feats, frames, num_beams=W, max_length=maxlen, ctc_weight=0.3, eos_token_id=1)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    n = len(out[0]["tokens"])
-    print(f"beams={W}: {dt*1e3:.1f} ms end-to-end (fbank+encoder+{n} tokens), {dt*1e3/max(n-1,1):.2f} ms/token incl. encoder")
+    res = {}
+    for name, fn in (("device-resident loop", generate), ("host loop", generate_stepwise)):
+        for rep in range(4):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            feats, frames = FB.fbank_gpu(wave, tb, pad_frames_to=100)
+            out = fn(eng, feats, frames, num_beams=W, max_length=maxlen, ctc_weight=0.3, eos_token_id=1)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        n = len(out[0]["tokens"])
+        res[name] = out
+        print(f"beams={W} {name}: {dt*1e3:.1f} ms end-to-end (fbank+encoder+{n} tokens), {dt*1e3/max(n-1,1):.2f} ms/token incl. encoder")
+    print(f"beams={W}: same hypotheses {res['device-resident loop'][0]['hypotheses'] == res['host loop'][0]['hypotheses']}")
