@@ -31,6 +31,7 @@ struct BeamArgs {
     long* beam_idx;                       // (B * W)
     int* done; int* nfin; double* fin_score; int* fin_len; long* fin_tok;
     float* top_s; int* top_i;             // optional (B, 2W): the candidates the step walked
+    int* done_out;                        // optional (B): copy of the done flags after the step (host-mapped pinned memory: the host polls it without a copy on the stream)
 };
 
 // the host loop's arithmetic, one rounding per operation: no multiply-add contraction here (HIP's __fmul_rn / __fadd_rn are plain operators, so the pragma is what holds it)
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(BeamArgs p) {
                 if ((double)tops[0] / p.denom <= worst) p.done[b] = 1;
             }
         }
+        if (p.done_out) p.done_out[b] = p.done[b];
         if (p.top_s)
             for (int r = 0; r < R; ++r) { p.top_s[(long)b * R + r] = was_done ? 0.f : tops[r]; p.top_i[(long)b * R + r] = was_done ? 0 : topi[r]; }
     }
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(BeamArgs p) {
 
 extern "C" int mi_beam_step(const float* logits, long ldl, const float* lse, const float* ctc, float w_att, float w_ctc, int pad, int eos, int B, int W, int V,
                             int cur_len, int Lmax, double denom, long* ids, float* beam_scores, long* new_tok, long* beam_idx, int* done, int* nfin,
-                            double* fin_score, int* fin_len, long* fin_tok, int cap, float* top_s, int* top_i, hipStream_t stream) {
+                            double* fin_score, int* fin_len, long* fin_tok, int cap, float* top_s, int* top_i, int* done_out, hipStream_t stream) {
     MI_ENTER();
     if (!logits || !lse || !ids || !beam_scores || !new_tok || !beam_idx || !done || !nfin || !fin_score || !fin_len || !fin_tok) return MI_ERR_ARG;
     if (B <= 0 || W <= 0 || W > BS_MAXW || V <= 0 || (long)W * V >= (1l << 24) || cur_len <= 0 || cur_len >= Lmax || cap < W || pad < 0 || pad >= V || !(denom > 0.0))
@@ -179,7 +181,7 @@ extern "C" int mi_beam_step(const float* logits, long ldl, const float* lse, con
     const size_t lds = (size_t)W * cur_len * sizeof(long);
     if (lds > 96 * 1024) return MI_ERR_UNSUPPORTED;
     BeamArgs a{logits, ldl, lse, ctc, w_att, w_ctc, pad, eos, B, W, V, cur_len, Lmax, cap, denom, ids, beam_scores, new_tok, beam_idx, done, nfin, fin_score, fin_len, fin_tok,
-               top_s, top_i};
+               top_s, top_i, done_out};
     static const bool attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(beam_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
     if (!attr_set) return MI_ERR_LAUNCH;
     hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(BS_THREADS), lds, stream, a);

@@ -60,15 +60,17 @@ struct ChainArgs {
     float* psi_out;                 // (K) / (n_bh, O) or null
     const float* s_prev;            // (n_bh) or null (= 0)
     float* scores_out;              // (n_bh, O) or null: psi - s_prev with blank / exact-zero -> logzero
+    int beam0;                      // chain selection without an index tensor: K chains, chain k = (hypothesis (k / W) W — beam 0 of k's utterance, the reference's quirk —, tok[k])
+    const float* psi_prev;          // s_prev gathered here instead: psi_prev[((i / W) W) O + last_i]   ((n_bh, O) of the previous call)
 };
 
 __global__ __launch_bounds__(256) void prefix_chain_kernel(ChainArgs p) {
     const int n_bh = p.B * p.W;
     long k = (long)blockIdx.x * 256 + threadIdx.x;
     int i, c;
-    if (p.hyp) {
+    if (p.hyp || p.beam0) {
         if (k >= p.K) return;
-        i = p.hyp[k];
+        i = p.hyp ? p.hyp[k] : (int)(k / p.W) * p.W;
         c = (int)p.tok[k * p.ld_tok];
     } else {
         const int cpb = (p.O + 255) / 256;                    // blocks per hypothesis
@@ -81,7 +83,8 @@ __global__ __launch_bounds__(256) void prefix_chain_kernel(ChainArgs p) {
     const float* xb = p.x + (long)b * p.T * p.O;
     const bool same = (long)c == p.last_ids[(long)i * p.ld_last];
     const int start = p.out_len > 1 ? p.out_len : 1;
-    const long Kt = p.hyp ? p.K : (long)n_bh * p.O;
+    const bool picked = p.hyp || p.beam0;
+    const long Kt = picked ? p.K : (long)n_bh * p.O;
     float r0 = LOGZERO, r1 = LOGZERO;
     if (p.out_len == 0) r0 = xb[c];
     if (p.r_out) {
@@ -125,10 +128,11 @@ __global__ __launch_bounds__(256) void prefix_chain_kernel(ChainArgs p) {
         }
     }
     float psi = pm + logf(ps);
-    if (p.scores_out || !p.hyp) { if (c == p.blank) psi = LOGZERO; }            // :173
+    if (p.scores_out || !picked) { if (c == p.blank) psi = LOGZERO; }           // :173
     if (p.psi_out) p.psi_out[k] = psi;
     if (p.scores_out) {
-        float s = psi - (p.s_prev ? p.s_prev[i] : 0.f);
+        const float sp = p.psi_prev ? p.psi_prev[(long)(i / p.W) * p.W * p.O + p.last_ids[(long)i * p.ld_last]] : (p.s_prev ? p.s_prev[i] : 0.f);
+        float s = psi - sp;
         if (s == 0.f) s = LOGZERO;                                              // :176
         p.scores_out[k] = s;
     }
@@ -162,7 +166,7 @@ extern "C" int mi_ctc_prefix_score(const float* x, int B, int T, int O, int blan
                                    long ld_last, int out_len, const float* s_prev, float* psi_out, float* scores_out, hipStream_t stream) {
     MI_ENTER();
     if (B <= 0 || T <= 0 || O <= 0 || W <= 0) return MI_ERR_ARG;
-    ChainArgs a{x, B, T, O, blank, W, r_prev, last_ids, ld_last, out_len, nullptr, nullptr, 0, 0, nullptr, psi_out, s_prev, scores_out};
+    ChainArgs a{x, B, T, O, blank, W, r_prev, last_ids, ld_last, out_len, nullptr, nullptr, 0, 0, nullptr, psi_out, s_prev, scores_out, 0, nullptr};
     hipLaunchKernelGGL(prefix_chain_kernel, dim3(B * W * cdiv(O, 256)), dim3(256), 0, stream, a);
     MI_CHECK_LAUNCH();
     return MI_OK;
@@ -174,8 +178,25 @@ extern "C" int mi_ctc_prefix_select(const float* x, int B, int T, int O, int bla
                                     hipStream_t stream) {
     MI_ENTER();
     if (B <= 0 || T <= 0 || O <= 0 || W <= 0 || K <= 0) return MI_ERR_ARG;
-    ChainArgs a{x, B, T, O, blank, W, r_prev, last_ids, ld_last, out_len, hyp, tok, ld_tok, K, r_out, nullptr, nullptr, nullptr};
+    ChainArgs a{x, B, T, O, blank, W, r_prev, last_ids, ld_last, out_len, hyp, tok, ld_tok, K, r_out, nullptr, nullptr, nullptr, 0, nullptr};
     hipLaunchKernelGGL(prefix_chain_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, a);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// One decoding step of the processor after the first (= mi_ctc_prefix_select along (beam 0 of every utterance, the token each hypothesis ended on) followed by
+// mi_ctc_prefix_score with s_prev gathered from the previous call's psi), without the index tensors in between: two launches from one call.
+//   previous call: r_old (T,2,n_bh), last_old (its prefixes' last tokens), out_len_old, psi_old (n_bh, O);  this call: last, out_len
+//   out: r_prev (T,2,n_bh) = the state this call's chains start from (kept for the next call), psi (n_bh, O), scores (n_bh, O)
+extern "C" int mi_ctc_prefix_advance(const float* x, int B, int T, int O, int blank, int W, const float* r_old, const long* last_old, long ld_last_old, int out_len_old,
+                                     const float* psi_old, const long* last, long ld_last, int out_len, float* r_prev, float* psi, float* scores, hipStream_t stream) {
+    MI_ENTER();
+    if (B <= 0 || T <= 0 || O <= 0 || W <= 0 || !r_old || !last_old || !psi_old || !last || !r_prev || !psi || !scores) return MI_ERR_ARG;
+    const int n_bh = B * W;
+    ChainArgs sel{x, B, T, O, blank, W, r_old, last_old, ld_last_old, out_len_old, nullptr, last, ld_last, n_bh, r_prev, nullptr, nullptr, nullptr, 1, nullptr};
+    hipLaunchKernelGGL(prefix_chain_kernel, dim3(cdiv(n_bh, 256)), dim3(256), 0, stream, sel);
+    ChainArgs sc{x, B, T, O, blank, W, r_prev, last, ld_last, out_len, nullptr, nullptr, 0, 0, nullptr, psi, nullptr, scores, 0, psi_old};
+    hipLaunchKernelGGL(prefix_chain_kernel, dim3(n_bh * cdiv(O, 256)), dim3(256), 0, stream, sc);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

@@ -13,6 +13,7 @@ Eval-mode semantics; the fp32 residual stream / bf16 GEMM operands precision mod
 from __future__ import annotations
 
 import ctypes as C
+import time
 
 import torch
 
@@ -266,11 +267,11 @@ class JointAEDEngine:
 # scores = log_softmax(decoder logits) -> pad masked -> (1-w)*att + w*ctc -> + beam score -> top 2W over W*V ->
 # finished hypotheses scored sum_logprob / len**length_penalty (HF BeamSearchScorer semantics, early_stopping=False).
 def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_length=64, ctc_weight=0.3, length_penalty=1.0,
-             eos_token_id=1, pad_token_id=None, start_token_id=None, space_token_id=-1, run_ahead=2):
+             eos_token_id=1, pad_token_id=None, start_token_id=None, space_token_id=-1, run_ahead=2, stats=None):
     """Device-resident decoding loop: per token the decoder step (one C call), the row log-sum-exp and ONE launch that mixes the CTC prefix scores in, takes the top 2W
     candidates, walks them with BeamSearchScorer's rules and moves ids / beam scores / closed hypotheses on the device (csrc/beam_step.hip).  The CTC prefix scorer of step t
     depends on the prefixes only, not on the decoder's logits: it runs on a second stream beside the decoder step.  Nothing is copied to the host until decoding ends, except
-    the per-utterance `done` flags (pinned, asynchronous): the host stays at most `run_ahead` steps in front of the GPU and stops enqueuing once every utterance is done.
+    the per-utterance `done` flags (the kernel writes them into pinned, device-mapped memory): the host stays at most `run_ahead` steps in front of the GPU and stops enqueuing once every utterance is done.
     Same hypotheses, scores and order as `generate_stepwise` (same arithmetic, operation for operation)."""
     from .decoding import CTCRescorerLogitsProcessor
     dev = joint.device
@@ -317,6 +318,7 @@ def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_lengt
     ev_ids.record(main)
     cur_len, steps = 1, 0
     w_att, w_ctc = float(1 - ctc_weight), float(ctc_weight)
+    t_loop = time.perf_counter()
     while cur_len < max_length:
         if len(flags) >= run_ahead:            # bounded run-ahead: wait for the flags of step (now - run_ahead) and stop if everything is done
             ev, t = flags[len(flags) - run_ahead]
@@ -339,19 +341,19 @@ def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_lengt
         beam_idx = torch.empty((n_bh,), dtype=torch.long, device=dev)
         _lib.check(L_.mi_beam_step(logits.data_ptr(), logits.stride(0), lse.data_ptr(), ctc.data_ptr() if ctc is not None else None, w_att, w_ctc, pad, eos_token_id,
                                    B, W, V, cur_len, Lmax, float(cur_len ** length_penalty), ids.data_ptr(), beam_scores.data_ptr(), new_tok.data_ptr(), beam_idx.data_ptr(),
-                                   done.data_ptr(), nfin.data_ptr(), fin_score.data_ptr(), fin_len.data_ptr(), fin_tok.data_ptr(), cap, None, None, main.cuda_stream),
+                                   done.data_ptr(), nfin.data_ptr(), fin_score.data_ptr(), fin_len.data_ptr(), fin_tok.data_ptr(), cap, None, None, done_host[steps].data_ptr(), main.cuda_stream),
                    "mi_beam_step")
         ev_ids = torch.cuda.Event()
         ev_ids.record(main)
         if W > 1:
             joint.dec.reorder_cache(cache, beam_idx)
-        done_host[steps].copy_(done, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(main)
-        flags.append((ev, steps))
+        flags.append((ev_ids, steps))          # the flags of this step are in pinned memory once the step's event has fired
         keep.append((logits, lse, new_tok, beam_idx))
         cur_len += 1
         steps += 1
+    if stats is not None:                      # host time spent enqueuing the token loop (the GPU may still be running it)
+        stats["host_loop_ms"] = (time.perf_counter() - t_loop) * 1e3
+        stats["steps"] = steps
     if side is not None:
         main.wait_stream(side)
     ids_cpu, bs = ids[:, :cur_len].cpu(), beam_scores.cpu().view(B, W)                  # the first copy synchronises with everything enqueued

@@ -73,22 +73,18 @@ class CTCRescorerLogitsProcessor(LogitsProcessor):
         dev = self.logits.device
         out_len = input_ids.shape[1] - 1
         last = input_ids[:, -1]
-        if self.state is None:
-            r_prev = self._prepare(W)
-            s_prev = None
-        else:
-            r_old, last_old, out_len_old, psi_old = self.state
-            src = (torch.arange(n_bh, device=dev, dtype=torch.int32) // W) * W        # beam 0 of every utterance (reference quirk)
-            r_prev = torch.empty((self.T, 2, n_bh), dtype=torch.float32, device=dev)
-            _lib.check(L.mi_ctc_prefix_select(self.x.data_ptr(), self.B, self.T, self.O, self.blank, W, r_old.data_ptr(),
-                                              last_old.data_ptr(), last_old.stride(0), out_len_old, src.data_ptr(), last.data_ptr(),
-                                              last.stride(0), n_bh, r_prev.data_ptr(), st), "mi_ctc_prefix_select")
-            s_prev = psi_old[src.long(), last].contiguous()
         psi = torch.empty((n_bh, self.O), dtype=torch.float32, device=dev)
         scores = torch.empty((n_bh, self.O), dtype=torch.float32, device=dev)
-        _lib.check(L.mi_ctc_prefix_score(self.x.data_ptr(), self.B, self.T, self.O, self.blank, W, r_prev.data_ptr(), last.data_ptr(),
-                                         last.stride(0), out_len, 0 if s_prev is None else s_prev.data_ptr(), psi.data_ptr(),
-                                         scores.data_ptr(), st), "mi_ctc_prefix_score")
+        if self.state is None:
+            r_prev = self._prepare(W)
+            _lib.check(L.mi_ctc_prefix_score(self.x.data_ptr(), self.B, self.T, self.O, self.blank, W, r_prev.data_ptr(), last.data_ptr(),
+                                             last.stride(0), out_len, 0, psi.data_ptr(), scores.data_ptr(), st), "mi_ctc_prefix_score")
+        else:                                      # state re-selected along (beam 0 of the utterance — reference quirk —, the token every hypothesis ended on), then scored
+            r_old, last_old, out_len_old, psi_old = self.state
+            r_prev = torch.empty((self.T, 2, n_bh), dtype=torch.float32, device=dev)
+            _lib.check(L.mi_ctc_prefix_advance(self.x.data_ptr(), self.B, self.T, self.O, self.blank, W, r_old.data_ptr(), last_old.data_ptr(), last_old.stride(0),
+                                               out_len_old, psi_old.data_ptr(), last.data_ptr(), last.stride(0), out_len, r_prev.data_ptr(), psi.data_ptr(),
+                                               scores.data_ptr(), st), "mi_ctc_prefix_advance")
         self.state = (r_prev, last.clone(), out_len, psi)
         return scores
 

@@ -219,6 +219,10 @@ int mi_ctc_prefix_score(const float* x, int B, int T, int O, int blank, int W, c
 int mi_ctc_prefix_select(const float* x, int B, int T, int O, int blank, int W, const float* r_prev, const long* last_ids,
                          long ld_last, int out_len, const int* hyp, const long* tok, long ld_tok, int K, float* r_out,
                          mi_stream_t stream);
+/* one processor call after the first = select along (beam 0 of every utterance, last token of every hypothesis) + score with s_prev = psi_old[beam 0 row, last token],
+   from one call (no index tensors in between; ctc_scorer.py:327-330 -> :58-207).  r_prev / psi are the state the next call passes as r_old / psi_old. */
+int mi_ctc_prefix_advance(const float* x, int B, int T, int O, int blank, int W, const float* r_old, const long* last_old, long ld_last_old, int out_len_old,
+                          const float* psi_old, const long* last, long ld_last, int out_len, float* r_prev, float* psi, float* scores, mi_stream_t stream);
 
 /* ---- GPT-2 cross-attention decoder helpers (the rest of the decoder runs on the shared LN / GEMM / attention entry points).
  * replaces: GPT2Model embeddings (wte + wpe) and the fixed-position variant src/models/embeddings.py:33-86;
@@ -391,10 +395,10 @@ int mi_kv_cache_reorder(const void* const* src_k, const void* const* src_v, void
    ranks closes a hypothesis with score / denom (denom = cur_len ** length_penalty, computed by the caller in double) into fin_* (B, cap[, Lmax]); the first W other
    candidates become the next beams: ids (B*W, Lmax) re-ordered in place + the new token at column cur_len, new_tok / beam_idx / beam_scores (B*W) written;
    done[b] is set when >= W hypotheses are closed and top score / denom <= the W-th best closed score; a done utterance only emits pad tokens from beam b*W.
-   top_s / top_i (B, 2W) optional.  W <= 16, W * V < 2^24. */
+   top_s / top_i (B, 2W) optional; done_out (B) optional: the flags after the step, written for the host (pinned, device-mapped memory).  W <= 16, W * V < 2^24. */
 int mi_beam_step(const float* logits, long ldl, const float* lse, const float* ctc, float w_att, float w_ctc, int pad, int eos, int B, int W, int V,
                  int cur_len, int Lmax, double denom, long* ids, float* beam_scores, long* new_tok, long* beam_idx, int* done, int* nfin,
-                 double* fin_score, int* fin_len, long* fin_tok, int cap, float* top_s, int* top_i, mi_stream_t stream);
+                 double* fin_score, int* fin_len, long* fin_tok, int cap, float* top_s, int* top_i, int* done_out, mi_stream_t stream);
 
 /* ---- Whisper-style front end + glue (BASELINE config 4).  replaces: transformers WhisperFeatureExtractor numpy path
  *      (selected by configs/default_data_preprocessing_whisper.json:20-29) and the conv/position prologue of WhisperEncoder. */
