@@ -1,4 +1,6 @@
-// Cost of an in-kernel grid barrier on gfx950, for pricing a persistent decoder token step:
+// Cost of an in-kernel grid barrier on gfx950, for pricing a persistent decoder token step.
+// build + run:  hipcc --offload-arch=gfx950 -O3 -o tools/bin/barrier_bench tools/barrier_bench.hip  (tools/bin/ is git-ignored; the binary travels with gpurun)
+//
 //   all: G blocks anywhere on the chip, agent-scope release / acquire around an atomic counter
 //   xcd: only the blocks that landed on XCC 0 take part (8 G launched)
 // Each barrier also hands one float per block to the next phase (written before, read after), like a real phase boundary.
