@@ -32,3 +32,16 @@ K = 10
 for _ in range(K): out = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
 print(f"whisper-small encoder + log-mel, B={B} x 30 s: {dt*1e3:.2f} ms/step -> {B*30/dt:.0f} audio-s/s; out {tuple(out.shape)}")
+# independent batches in flight on streams of their own (the engine holds only weights: the same engine serves every lane), as bench.py does for the headline config
+for lanes in (2, 3, 4):
+    streams = [torch.cuda.Stream() for _ in range(lanes)]
+    K = 12 * lanes
+    def run(n):
+        for j in range(n):
+            with torch.cuda.stream(streams[j % lanes]):
+                step()
+    run(2 * lanes)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    run(K)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
+    print(f"  {lanes} batches in flight: {dt*1e3:.2f} ms/step -> {B*30/dt:.0f} audio-s/s")
