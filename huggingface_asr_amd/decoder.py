@@ -272,7 +272,8 @@ def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_lengt
     candidates, walks them with BeamSearchScorer's rules and moves ids / beam scores / closed hypotheses on the device (csrc/beam_step.hip).  The CTC prefix scorer of step t
     depends on the prefixes only, not on the decoder's logits: it runs on a second stream beside the decoder step.  Nothing is copied to the host until decoding ends, except
     the per-utterance `done` flags (the kernel writes them into pinned, device-mapped memory): the host stays at most `run_ahead` steps in front of the GPU and stops enqueuing once every utterance is done.
-    Same hypotheses, scores and order as `generate_stepwise` (same arithmetic, operation for operation)."""
+    Same hypotheses, scores and order as `generate_stepwise` (same arithmetic, operation for operation).  `stats` (a dict) receives the host time spent enqueuing the
+    token loop and the number of steps enqueued."""
     from .decoding import CTCRescorerLogitsProcessor
     dev = joint.device
     c = joint.jcfg
@@ -281,12 +282,13 @@ def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_lengt
     W = num_beams
     L_ = _lib.lib()
     main = torch.cuda.current_stream()
+    V = joint.dec.w["lm_head"].shape[0]
+    if W > 16 or W * V >= (1 << 24):           # outside mi_beam_step's limits: the same decoding with the bookkeeping on the host (still the HIP kernels for everything else)
+        return generate_stepwise(joint, feats, feat_len, num_beams=num_beams, max_length=max_length, ctc_weight=ctc_weight, length_penalty=length_penalty,
+                                 eos_token_id=eos_token_id, pad_token_id=pad_token_id, start_token_id=start_token_id, space_token_id=space_token_id)
     enc_out, enc_bf, T2, key_len = joint.encode(feats, feat_len)
     B = feats.shape[0]
     d = enc_bf.shape[1]
-    V = joint.dec.w["lm_head"].shape[0]
-    if W > 16 or W * V >= (1 << 24):
-        raise NotImplementedError("generate: num_beams <= 16 and num_beams * vocabulary < 2^24 (use generate_stepwise)")
     enc_rep = enc_bf.view(B, T2, d).repeat_interleave(W, 0).reshape(B * W * T2, d)
     key_rep = key_len.repeat_interleave(W) if key_len is not None else None
     kvs = joint.dec.cross_kv(enc_rep)
