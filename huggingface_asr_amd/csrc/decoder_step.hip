@@ -150,6 +150,108 @@ int skinny(const SkArgs& a, hipStream_t st) {
     return MI_OK;
 }
 
+// ---- attention of at most 8 new rows over cached keys (token step): one block per (row, head).  The MFMA attention kernel pads these rows to a 128-query tile and walks the
+// keys in dependent steps (9-12 us over 250 encoder frames); here LPK = HD / 8 lanes share a key (16-B pieces of its K and V rows), the block's four waves split the keys, a wave
+// requests all 2 NB pieces of a batch before it uses the first, soft-max in fp32 with a running max across batches, key slots and waves merged through LDS.
+constexpr int DA_WAVES = 4;
+struct DecAttnArgs {
+    const bf16_t* q; long ldq; const bf16_t* K; const bf16_t* V; long ldkv, bstride;
+    const int* enc_len; bf16_t* ctx; long ldo;
+    int M, U, H, past, self, T_enc; float scale;
+};
+template <int HD>
+__global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnArgs p) {
+    constexpr int LPK = HD / 8, KPI = 64 / LPK, NB = 8, EPL = HD / 64;       // lanes per key, keys per wave and load round, rounds per batch, output dims per lane
+    __shared__ float red[DA_WAVES * 64 * 8];                                  // [wave][key slot][dim]: KPI HD = 512 floats per wave
+    __shared__ float rs[DA_WAVES * 8];
+    __shared__ float rm[DA_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane / LPK, c = lane % LPK;
+    const int t = blockIdx.x;
+    const int m = t / p.H, h = t - m * p.H, b = m / p.U, u = m - b * p.U;
+    const int nkeys = p.self ? p.past + u + 1 : (p.enc_len ? (p.enc_len[b] < p.T_enc ? p.enc_len[b] : p.T_enc) : p.T_enc);
+    const bf16_t* kb = p.K + (long)b * p.bstride + h * HD + c * 8;
+    const bf16_t* vb = p.V + (long)b * p.bstride + h * HD + c * 8;
+    const bf16x8 q8 = *reinterpret_cast<const bf16x8*>(p.q + (long)m * p.ldq + h * HD + c * 8);
+    float mrun = -INFINITY, lsum = 0.f, acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int key0 = wave * KPI; key0 < nkeys; key0 += DA_WAVES * KPI * NB) {           // wave-uniform
+        bf16x8 k8[NB], v8[NB];
+        float sv[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {                                 // unconditional, clamped: a load under a condition is its own basic block and costs a full wait at the join
+            const int key = key0 + i * DA_WAVES * KPI + g;
+            const long off = (long)(key < nkeys ? key : 0) * p.ldkv;
+            k8[i] = *reinterpret_cast<const bf16x8*>(kb + off);
+            v8[i] = *reinterpret_cast<const bf16x8*>(vb + off);
+        }
+        float bm = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            float sd = 0.f;
+            sd = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(k8[i], k8[i], 0, 1), __builtin_shufflevector(q8, q8, 0, 1), sd, false);
+            sd = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(k8[i], k8[i], 2, 3), __builtin_shufflevector(q8, q8, 2, 3), sd, false);
+            sd = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(k8[i], k8[i], 4, 5), __builtin_shufflevector(q8, q8, 4, 5), sd, false);
+            sd = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(k8[i], k8[i], 6, 7), __builtin_shufflevector(q8, q8, 6, 7), sd, false);
+            sd += dpp_f32<0xB1, 0xF>(0.f, sd);                         // the key's LPK lanes: quad, half row (8 lanes) [, row (16 lanes)]
+            sd += dpp_f32<0x4E, 0xF>(0.f, sd);
+            sd += dpp_f32<0x141, 0xF>(0.f, sd);
+            if (LPK == 16) sd += dpp_f32<0x140, 0xF>(0.f, sd);
+            sv[i] = (key0 + i * DA_WAVES * KPI + g) < nkeys ? sd * p.scale : -INFINITY;
+            bm = fmaxf(bm, sv[i]);
+        }
+        bm = wave_max(bm);                                             // finite: key slot 0 of the batch's first round is < nkeys
+        const float mnew = fmaxf(mrun, bm);
+        const float f = mrun == -INFINITY ? 0.f : __expf(mrun - mnew);
+        lsum *= f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] *= f;
+        mrun = mnew;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const float pr = sv[i] == -INFINITY ? 0.f : __expf(sv[i] - mnew);
+            lsum += pr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(pr, bf2f(v8[i][j]), acc[j]);
+        }
+    }
+    // key slots and waves -> LDS (a wave without keys has mrun = -inf and zeros)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[(wave * KPI + g) * HD + c * 8 + j] = acc[j];
+    if (c == 0) rs[wave * KPI + g] = lsum;
+    if (lane == 0) rm[wave] = mrun;
+    __syncthreads();
+    if (wave == 0) {
+        float gm = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < DA_WAVES; ++w) gm = fmaxf(gm, rm[w]);
+        float tot = 0.f, o[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int w = 0; w < DA_WAVES; ++w) {
+            const float f = rm[w] == -INFINITY ? 0.f : __expf(rm[w] - gm);
+#pragma unroll
+            for (int k = 0; k < KPI; ++k) {
+                tot = fmaf(rs[w * KPI + k], f, tot);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) o[e] = fmaf(red[(w * KPI + k) * HD + lane * EPL + e], f, o[e]);
+            }
+        }
+        const float inv = tot > 0.f ? 1.f / tot : 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) p.ctx[(long)m * p.ldo + h * HD + lane * EPL + e] = f2bf(o[e] * inv);
+    }
+}
+
+int decode_attn(const DecAttnArgs& a, int hd, hipStream_t st) {
+    if (hd == 64) hipLaunchKernelGGL(decode_attn_kernel<64>, dim3(a.M * a.H), dim3(256), 0, st, a);
+    else if (hd == 128) hipLaunchKernelGGL(decode_attn_kernel<128>, dim3(a.M * a.H), dim3(256), 0, st, a);
+    else return MI_ERR_UNSUPPORTED;
+    return MI_OK;
+}
+
 constexpr int MAX_LAYERS = 48;
 struct ReorderArgs { const bf16_t* src[2 * MAX_LAYERS]; bf16_t* dst[2 * MAX_LAYERS]; };
 
@@ -239,11 +341,10 @@ extern "C" int mi_gpt2_step(const mi_gpt2_config* cfg, const void* const* weight
                 a.kc = kc; a.vc = vc; a.U = U; a.past = past; a.Lmax = Lmax; a.dkv = d;
                 RUN(skinny(a, st));
             }
-            RUN(mi_attention_qkv_bf16(w.qkv, 3 * d, kc, d, vc, d, nullptr, 0, nullptr, nullptr, nullptr, w.ctx, d, B, U, past + U, (long)Lmax * d, c.H, hd,
-                                      scale, 1, st));
+            RUN(decode_attn(DecAttnArgs{w.qkv, 3 * d, kc, vc, d, (long)Lmax * d, nullptr, w.ctx, d, M, U, c.H, past, 1, 0, scale}, hd, st));
             RUN(lin_res(w.ctx, d, Lw(l, 4), Lf(l, 5)));
             RUN(lin_ln(Lf(l, 6), Lf(l, 7), Lw(l, 8), Lf(l, 9), d, w.qq, 0));
-            RUN(mi_attention_qkv_bf16(w.qq, d, ckv, 2 * d, ckv + d, 2 * d, nullptr, 0, nullptr, nullptr, enc_len, w.ctx, d, B, U, T_enc, 0, c.H, hd, scale, 0, st));
+            RUN(decode_attn(DecAttnArgs{w.qq, d, ckv, ckv + d, 2 * d, (long)T_enc * 2 * d, enc_len, w.ctx, d, M, U, c.H, 0, 0, T_enc, scale}, hd, st));
             RUN(lin_res(w.ctx, d, Lw(l, 10), Lf(l, 11)));
             RUN(lin_ln(Lf(l, 12), Lf(l, 13), Lw(l, 14), Lf(l, 15), 4 * d, w.m, 2));
             RUN(lin_res(w.m, 4 * d, Lw(l, 16), Lf(l, 17)));
