@@ -62,6 +62,7 @@ struct ChainArgs {
     float* scores_out;              // (n_bh, O) or null: psi - s_prev with blank / exact-zero -> logzero
     int beam0;                      // chain selection without an index tensor: K chains, chain k = (hypothesis (k / W) W — beam 0 of k's utterance, the reference's quirk —, tok[k])
     const float* psi_prev;          // s_prev gathered here instead: psi_prev[((i / W) W) O + last_i]   ((n_bh, O) of the previous call)
+    int rp_full;                    // r_prev is the previous call's (T, 2, n_bh, O) chains of EVERY (hypothesis, token): hypothesis i continues from [.., (i / W) W, last_i]
 };
 
 __global__ __launch_bounds__(256) void prefix_chain_kernel(ChainArgs p) {
@@ -83,6 +84,8 @@ __global__ __launch_bounds__(256) void prefix_chain_kernel(ChainArgs p) {
     const float* xb = p.x + (long)b * p.T * p.O;
     const bool same = (long)c == p.last_ids[(long)i * p.ld_last];
     const int start = p.out_len > 1 ? p.out_len : 1;
+    const long rp_plane = p.rp_full ? (long)n_bh * p.O : n_bh;                 // distance between the (t, n / b) planes of r_prev, and this chain's column in them
+    const long rp_col = p.rp_full ? (long)(i / p.W) * p.W * p.O + p.last_ids[(long)i * p.ld_last] : i;
     const bool picked = p.hyp || p.beam0;
     const long Kt = picked ? p.K : (long)n_bh * p.O;
     float r0 = LOGZERO, r1 = LOGZERO;
@@ -105,8 +108,8 @@ __global__ __launch_bounds__(256) void prefix_chain_kernel(ChainArgs p) {
         for (int u = 0; u < UNROLL; ++u) {
             const int t = t0 + u;
             const bool ok = t < p.T;
-            rp0[u] = ok ? p.r_prev[((long)(t - 1) * 2 + 0) * n_bh + i] : 0.f;
-            rp1[u] = ok ? p.r_prev[((long)(t - 1) * 2 + 1) * n_bh + i] : 0.f;
+            rp0[u] = ok ? p.r_prev[((long)(t - 1) * 2 + 0) * rp_plane + rp_col] : 0.f;
+            rp1[u] = ok ? p.r_prev[((long)(t - 1) * 2 + 1) * rp_plane + rp_col] : 0.f;
             xc[u] = ok ? xb[(long)t * p.O + c] : 0.f;
             xbl[u] = ok ? xb[(long)t * p.O + p.blank] : 0.f;
         }
@@ -166,7 +169,7 @@ extern "C" int mi_ctc_prefix_score(const float* x, int B, int T, int O, int blan
                                    long ld_last, int out_len, const float* s_prev, float* psi_out, float* scores_out, hipStream_t stream) {
     MI_ENTER();
     if (B <= 0 || T <= 0 || O <= 0 || W <= 0) return MI_ERR_ARG;
-    ChainArgs a{x, B, T, O, blank, W, r_prev, last_ids, ld_last, out_len, nullptr, nullptr, 0, 0, nullptr, psi_out, s_prev, scores_out, 0, nullptr};
+    ChainArgs a{x, B, T, O, blank, W, r_prev, last_ids, ld_last, out_len, nullptr, nullptr, 0, 0, nullptr, psi_out, s_prev, scores_out, 0, nullptr, 0};
     hipLaunchKernelGGL(prefix_chain_kernel, dim3(B * W * cdiv(O, 256)), dim3(256), 0, stream, a);
     MI_CHECK_LAUNCH();
     return MI_OK;
@@ -178,7 +181,7 @@ extern "C" int mi_ctc_prefix_select(const float* x, int B, int T, int O, int bla
                                     hipStream_t stream) {
     MI_ENTER();
     if (B <= 0 || T <= 0 || O <= 0 || W <= 0 || K <= 0) return MI_ERR_ARG;
-    ChainArgs a{x, B, T, O, blank, W, r_prev, last_ids, ld_last, out_len, hyp, tok, ld_tok, K, r_out, nullptr, nullptr, nullptr, 0, nullptr};
+    ChainArgs a{x, B, T, O, blank, W, r_prev, last_ids, ld_last, out_len, hyp, tok, ld_tok, K, r_out, nullptr, nullptr, nullptr, 0, nullptr, 0};
     hipLaunchKernelGGL(prefix_chain_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, a);
     MI_CHECK_LAUNCH();
     return MI_OK;
@@ -193,10 +196,24 @@ extern "C" int mi_ctc_prefix_advance(const float* x, int B, int T, int O, int bl
     MI_ENTER();
     if (B <= 0 || T <= 0 || O <= 0 || W <= 0 || !r_old || !last_old || !psi_old || !last || !r_prev || !psi || !scores) return MI_ERR_ARG;
     const int n_bh = B * W;
-    ChainArgs sel{x, B, T, O, blank, W, r_old, last_old, ld_last_old, out_len_old, nullptr, last, ld_last, n_bh, r_prev, nullptr, nullptr, nullptr, 1, nullptr};
+    ChainArgs sel{x, B, T, O, blank, W, r_old, last_old, ld_last_old, out_len_old, nullptr, last, ld_last, n_bh, r_prev, nullptr, nullptr, nullptr, 1, nullptr, 0};
     hipLaunchKernelGGL(prefix_chain_kernel, dim3(cdiv(n_bh, 256)), dim3(256), 0, stream, sel);
-    ChainArgs sc{x, B, T, O, blank, W, r_prev, last, ld_last, out_len, nullptr, nullptr, 0, 0, nullptr, psi, nullptr, scores, 0, psi_old};
+    ChainArgs sc{x, B, T, O, blank, W, r_prev, last, ld_last, out_len, nullptr, nullptr, 0, 0, nullptr, psi, nullptr, scores, 0, psi_old, 0};
     hipLaunchKernelGGL(prefix_chain_kernel, dim3(n_bh * cdiv(O, 256)), dim3(256), 0, stream, sc);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// The same step in ONE launch when the chains of every (hypothesis, token) may be kept (T x 2 x n_bh x O floats: 50 MB at T' = 250, W = 5, V = 5001 — what the reference
+// materialises per token, ctc_scorer.py:58-178; here it is written once, coalesced over the tokens, by the scan that computes it anyway): the state a hypothesis continues from
+// is then a column of the previous call's `r_all`, and the re-run of the selected chains (mi_ctc_prefix_select: a second dependent 250-frame scan per token) disappears.
+//   r_prev: rp_full = 0 -> (T, 2, n_bh) of mi_ctc_prefix_prepare (first token, psi_old null);  rp_full = 1 -> the previous call's r_all, psi_old its psi.
+extern "C" int mi_ctc_prefix_score_full(const float* x, int B, int T, int O, int blank, int W, const float* r_prev, int rp_full, const float* psi_old, const long* last,
+                                        long ld_last, int out_len, float* r_all, float* psi, float* scores, hipStream_t stream) {
+    MI_ENTER();
+    if (B <= 0 || T <= 0 || O <= 0 || W <= 0 || !r_prev || !last || !r_all || !psi || !scores || (rp_full && !psi_old) || (rp_full != 0 && rp_full != 1)) return MI_ERR_ARG;
+    ChainArgs a{x, B, T, O, blank, W, r_prev, last, ld_last, out_len, nullptr, nullptr, 0, 0, r_all, psi, nullptr, scores, 0, rp_full ? psi_old : nullptr, rp_full};
+    hipLaunchKernelGGL(prefix_chain_kernel, dim3(B * W * cdiv(O, 256)), dim3(256), 0, stream, a);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

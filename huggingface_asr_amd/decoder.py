@@ -300,7 +300,11 @@ def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_lengt
         proc = CTCRescorerLogitsProcessor(enc_out["logits"], lens, pad, eos_token_id, 0, ctc_weight, W, space_token_id, False, 1.0)
         if proc.O != V:
             raise ValueError(f"CTC head has {proc.O} classes, the decoder {V}: joint decoding needs one vocabulary")
-        side = torch.cuda.Stream(device=dev)
+        # beside the decoder step the scorer competes with it for the memory system (its step is a chain of latency-bound launches: 358 -> 409 us per token at W = 1 with the
+        # scorer running): the form that re-runs the selected chains moves a tenth of the bytes of the form that keeps every chain (425 us), so it is the one used here —
+        # for a processor called in sequence (HF generate, generate_stepwise) the single-scan form is the faster one (tools/decode_step_timing.py)
+        proc.FULL_STATE_BYTES = 0
+        side = torch.cuda.Stream(device=dev)                 # a higher stream priority for the scorer was measured: no better (21.4 -> 25 ms and erratic)
     n_bh = B * W
     ids = torch.full((n_bh, Lmax), pad, dtype=torch.long, device=dev)
     ids[:, 0] = start
@@ -334,7 +338,7 @@ def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_lengt
                 ctc = proc.ctc_scores(ids[:, :cur_len])
                 ev_ctc = torch.cuda.Event()
                 ev_ctc.record(side)
-            keep.append((ctc, proc.state))
+            keep.append(ctc)                   # read by the main stream below; the processor's own state stays on the side stream
         logits = joint.dec.step(new_tok, cache, kvs, T2, key_rep)                       # (B*W, V), row stride padded to 8
         lse = ops.row_lse(logits)
         if proc is not None:

@@ -31,6 +31,8 @@ class GenerationConfigCustom(GenerationConfig):
 
 
 class CTCRescorerLogitsProcessor(LogitsProcessor):
+    FULL_STATE_BYTES = 1 << 30      # keep every (hypothesis, token) chain between calls while that tensor stays below this (else: re-run the selected chains)
+
     def __init__(self, encoder_logits: torch.FloatTensor, encoder_output_lens: torch.LongTensor, pad_token_id: int,
                  eos_token_id: int, ctc_margin: int, ctc_weight: float, num_beams: int, space_token_id: int,
                  apply_eos_space_trick: bool, eos_space_trick_weight: float, debug: bool = False):
@@ -75,6 +77,21 @@ class CTCRescorerLogitsProcessor(LogitsProcessor):
         last = input_ids[:, -1]
         psi = torch.empty((n_bh, self.O), dtype=torch.float32, device=dev)
         scores = torch.empty((n_bh, self.O), dtype=torch.float32, device=dev)
+        full = self.T * 2 * n_bh * self.O * 4 <= self.FULL_STATE_BYTES
+        if full:
+            # the chains of EVERY (hypothesis, token) are kept (what the reference materialises, ctc_scorer.py:58-178): the state a hypothesis continues from — beam 0 of
+            # its utterance (reference quirk), the token it ended on — is a column of the previous call's tensor, and each token costs ONE 250-frame scan instead of two
+            if self.state is None:
+                r_prev, psi_old, rp_full = self._prepare(W), None, 0
+            else:
+                r_prev, _, _, psi_old = self.state
+                rp_full = 1
+            r_all = torch.empty((self.T, 2, n_bh, self.O), dtype=torch.float32, device=dev)
+            _lib.check(L.mi_ctc_prefix_score_full(self.x.data_ptr(), self.B, self.T, self.O, self.blank, W, r_prev.data_ptr(), rp_full,
+                                                  psi_old.data_ptr() if psi_old is not None else None, last.data_ptr(), last.stride(0), out_len,
+                                                  r_all.data_ptr(), psi.data_ptr(), scores.data_ptr(), st), "mi_ctc_prefix_score_full")
+            self.state = (r_all, None, out_len, psi)
+            return scores
         if self.state is None:
             r_prev = self._prepare(W)
             _lib.check(L.mi_ctc_prefix_score(self.x.data_ptr(), self.B, self.T, self.O, self.blank, W, r_prev.data_ptr(), last.data_ptr(),

@@ -223,6 +223,10 @@ int mi_ctc_prefix_select(const float* x, int B, int T, int O, int blank, int W, 
    from one call (no index tensors in between; ctc_scorer.py:327-330 -> :58-207).  r_prev / psi are the state the next call passes as r_old / psi_old. */
 int mi_ctc_prefix_advance(const float* x, int B, int T, int O, int blank, int W, const float* r_old, const long* last_old, long ld_last_old, int out_len_old,
                           const float* psi_old, const long* last, long ld_last, int out_len, float* r_prev, float* psi, float* scores, mi_stream_t stream);
+/* the same step in ONE scan when the chains of every (hypothesis, token) may be kept between calls: r_all (T, 2, B*W, O) is written by this call and passed as r_prev
+   (rp_full = 1, with psi_old) to the next; rp_full = 0: r_prev is mi_ctc_prefix_prepare's (T, 2, B*W) and psi_old is null (first token).  ctc_scorer.py:58-207. */
+int mi_ctc_prefix_score_full(const float* x, int B, int T, int O, int blank, int W, const float* r_prev, int rp_full, const float* psi_old, const long* last,
+                             long ld_last, int out_len, float* r_all, float* psi, float* scores, mi_stream_t stream);
 
 /* ---- GPT-2 cross-attention decoder helpers (the rest of the decoder runs on the shared LN / GEMM / attention entry points).
  * replaces: GPT2Model embeddings (wte + wpe) and the fixed-position variant src/models/embeddings.py:33-86;

@@ -10,8 +10,18 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(params=["all_chains_kept", "selected_chains_rerun"])
+def state_form(request, monkeypatch):
+    """both ways the processor carries its state between tokens: every (hypothesis, token) chain kept (one scan per token, mi_ctc_prefix_score_full) and — what it falls back to
+    when that tensor would pass FULL_STATE_BYTES — only the current prefixes' variables, the selected chains re-run (mi_ctc_prefix_advance)"""
+    from huggingface_asr_amd.decoding import CTCRescorerLogitsProcessor
+    if request.param == "selected_chains_rerun":
+        monkeypatch.setattr(CTCRescorerLogitsProcessor, "FULL_STATE_BYTES", 0)
+    return request.param
+
+
 @pytest.mark.parametrize("case", ["a", "b", "c", "m"])
-def test_ctc_rescorer_matches_reference(case):
+def test_ctc_rescorer_matches_reference(case, state_form):
     from huggingface_asr_amd.decoding import CTCRescorerLogitsProcessor, LogSoftmaxProcessor
     g = load_golden("ctc_prefix")
     B, W, T, O, blank, eos, space, trick, margin = [int(v) for v in g[f"{case}/meta"]]          # case "m": ctc_margin 6 (a no-op in the reference, and here)
@@ -21,7 +31,6 @@ def test_ctc_rescorer_matches_reference(case):
         ids = torch.from_numpy(g[f"{case}/step{step}/input_ids"]).to(DEV)
         att = torch.from_numpy(g[f"{case}/step{step}/att"]).to(DEV)
         out = proc(ids, att.clone())
-        ctc = proc.state[3] - 0  # psi of this step (state) — scores are checked through `out`
         want = g[f"{case}/step{step}/out"]
         got = out.cpu().numpy()
         live = want > -1e9
@@ -31,7 +40,7 @@ def test_ctc_rescorer_matches_reference(case):
     np.testing.assert_allclose(lsm.cpu().numpy(), g[f"{case}/logsoftmax"], atol=1e-5, rtol=0)
 
 
-def test_ctc_prefix_full_size_vs_oracle():
+def test_ctc_prefix_full_size_vs_oracle(state_form):
     """BASELINE config 5 shape: T'=250, V+1=5001, B=1, W=5 — three steps against the oracle."""
     from huggingface_asr_amd.decoding import CTCRescorerLogitsProcessor
     from oracle import ctc_prefix_ref as P
@@ -60,3 +69,25 @@ def test_processor_rejects_cpu_tensors():
     with pytest.raises(RuntimeError):
         CTCRescorerLogitsProcessor(enc, torch.tensor([10]), 6, 1, 0, 0.3, 2, 5, False, 1.0)
     assert CTCRescorerLogitsProcessor(enc.to(DEV), torch.tensor([10]), 6, 1, 3, 0.3, 2, 5, False, 1.0).ctc_margin == 3
+
+
+def test_both_state_forms_give_the_same_bits(monkeypatch):
+    """keeping every chain or re-running the selected ones is the same arithmetic: identical scores over a 6-token decode with beams that swap"""
+    from huggingface_asr_amd.decoding import CTCRescorerLogitsProcessor
+    B, W, T, O = 2, 3, 60, 301
+    g = torch.Generator().manual_seed(9)
+    enc = (torch.randn(B, T, O, generator=g) * 3.0).to(DEV)
+    lens = torch.tensor([60, 47]).to(DEV)
+    outs = []
+    for limit in (1 << 30, 0):
+        monkeypatch.setattr(CTCRescorerLogitsProcessor, "FULL_STATE_BYTES", limit)
+        proc = CTCRescorerLogitsProcessor(enc, lens, O - 1, 1, 0, 0.3, W, 5, False, 1.0)
+        gg = torch.Generator().manual_seed(10)
+        ids = torch.full((B * W, 1), 2, dtype=torch.long)
+        got = []
+        for step in range(6):
+            got.append(proc.ctc_scores(ids.to(DEV)).clone())
+            perm = torch.cat([torch.randperm(W, generator=gg) + b * W for b in range(B)])          # beams re-ordered, then extended
+            ids = torch.cat([ids[perm], torch.randint(3, O - 1, (B * W, 1), generator=gg)], 1)
+        outs.append(torch.stack(got))
+    assert torch.equal(outs[0], outs[1])

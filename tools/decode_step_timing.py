@@ -16,7 +16,7 @@ def timed_step(*a, **k):
     return r
 eng.dec.step = timed_step
 for w in (0.3, 0.0, 0.3, 0.0):
-    for rep in range(3):
+    for rep in range(4):
         evs.clear()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         feats, frames = FB.fbank_gpu(wave, tb, pad_frames_to=100)
