@@ -107,6 +107,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
     if (ty == 0 && n < N) atomic_add_f32(out + n, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
 }
 
+// out[n] = bf16(sum over the M rows of x[:, n]), rows added in order by one thread (a handful of partial-sum rows: deterministic, no zero-fill, no fp32 round trip)
+__global__ __launch_bounds__(256) void colsum_cast_kernel(const float* __restrict__ x, long ld, int M, int N4, bf16_t* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N4; i += (long)gridDim.x * 256) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 4);
+        for (int m = 1; m < M; ++m) a += *reinterpret_cast<const f32x4*>(x + (long)m * ld + i * 4);
+        const bf16x4 o = {f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w)};
+        *reinterpret_cast<bf16x4*>(out + i * 4) = o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ activations
 // MODE 0: out = act(a);  MODE 1: out = a * act'(b)   (a = dy, b = pre-activation);  kind 1 erf-GELU, 2 tanh-GELU
 // DROP: the activation dropout of the FFN (tf wav2vec2_conformer :353) applied in the same pass — forward out = dropout(act(a)), backward
@@ -381,6 +391,26 @@ __global__ __launch_bounds__(256) void add_rowvec_kernel(const bf16_t* __restric
         out[(long)m * ldo + c] = f2bf(bf2f(x[(long)m * ldx + c]) + vec[c]);
     }
 }
+// the same for TWO vectors from one read of x, 8 columns per thread: (q + pos_bias_u, q + pos_bias_v) of the attention backward
+__global__ __launch_bounds__(256) void add_rowvec2_vec8_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ u, const float* __restrict__ v,
+                                                                bf16_t* __restrict__ ou, bf16_t* __restrict__ ov, long ldo, int M, int N8) {
+    const long total = (long)M * N8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / N8), c = (int)(i % N8) * 8;
+        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + (long)m * ldx + c);
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(u + c), u1 = *reinterpret_cast<const f32x4*>(u + c + 4);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(v + c), v1 = *reinterpret_cast<const f32x4*>(v + c + 4);
+        bf16x8 a, b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xf = bf2f(xv[j]);
+            a[j] = f2bf(xf + (j < 4 ? u0[j & 3] : u1[j & 3]));
+            b[j] = f2bf(xf + (j < 4 ? v0[j & 3] : v1[j & 3]));
+        }
+        *reinterpret_cast<bf16x8*>(ou + (long)m * ldo + c) = a;
+        *reinterpret_cast<bf16x8*>(ov + (long)m * ldo + c) = b;
+    }
+}
 // gating backward of s = r * c:  dr = ds * c,  dc = ds * r
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* __restrict__ ds, long ldds, const bf16_t* __restrict__ c, long ldc,
                                                         const bf16_t* __restrict__ r, long ldr, bf16_t* __restrict__ dr, long lddr,
@@ -603,6 +633,15 @@ extern "C" int mi_colsum(const void* x, long ld, int dtype, int M, int N, float*
     return MI_OK;
 }
 
+// out (N) bf16 = column sums of x (M, N) f32, M small (partial sums of a batched product): N % 4 == 0, 16-byte aligned rows
+extern "C" int mi_colsum_cast_bf16(const float* x, long ld, int M, int N, void* out, hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || N <= 0 || (N % 4) || (ld % 4) || !x || !out || ((reinterpret_cast<uintptr_t>(x) & 15) != 0) || ((reinterpret_cast<uintptr_t>(out) & 7) != 0)) return MI_ERR_ARG;
+    hipLaunchKernelGGL(colsum_cast_kernel, dim3(grid_for((long)N / 4)), dim3(256), 0, st, x, ld, M, N / 4, (bf16_t*)out);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
 // kind 1 erf-GELU (ACT2FN["gelu"]), 2 tanh-GELU (gelu_new)
 extern "C" int mi_act_fwd_bf16(const void* pre, long ldp, void* out, long ldo, int M, int N, int kind, hipStream_t st) {
     MI_ENTER();
@@ -759,6 +798,20 @@ extern "C" int mi_add_rowvec_bf16(const void* x, long ldx, const float* vec, voi
     MI_ENTER();
     if (M <= 0 || N <= 0) return MI_ERR_ARG;
     hipLaunchKernelGGL(add_rowvec_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, st, (const bf16_t*)x, ldx, vec, (bf16_t*)out, ldo, M, N);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+// out_u = bf16(x + u), out_v = bf16(x + v): one pass over x (the element-wise form twice when the rows are not 16-byte aligned)
+extern "C" int mi_add_rowvec2_bf16(const void* x, long ldx, const float* u, const float* v, void* out_u, void* out_v, long ldo, int M, int N, hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || N <= 0 || !x || !u || !v || !out_u || !out_v) return MI_ERR_ARG;
+    const bool vec = (N % 8) == 0 && (ldx % 8) == 0 && (ldo % 8) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out_u) | reinterpret_cast<uintptr_t>(out_v)) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(add_rowvec2_vec8_kernel, dim3(grid_for((long)M * N / 8)), dim3(256), 0, st, (const bf16_t*)x, ldx, u, v, (bf16_t*)out_u, (bf16_t*)out_v, ldo, M, N / 8);
+    else {
+        hipLaunchKernelGGL(add_rowvec_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, st, (const bf16_t*)x, ldx, u, (bf16_t*)out_u, ldo, M, N);
+        hipLaunchKernelGGL(add_rowvec_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, st, (const bf16_t*)x, ldx, v, (bf16_t*)out_v, ldo, M, N);
+    }
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

@@ -51,6 +51,14 @@ def colsum_(out, x):
     _lib.check(_L().mi_colsum(x.data_ptr(), x.stride(0), 0 if x.dtype == F32 else 1, M, N, out.data_ptr(), _stream()), "mi_colsum")
 
 
+def colsum_cast(x):
+    """-> (N) bf16 = column sums of x (M, N) f32, rows added in order (M small)"""
+    M, N = x.shape
+    out = torch.empty((N,), device=x.device, dtype=BF16)
+    _lib.check(_L().mi_colsum_cast_bf16(x.data_ptr(), x.stride(0), M, N, out.data_ptr(), _stream()), "mi_colsum_cast_bf16")
+    return out
+
+
 KIND = {"gelu": 1, "gelu_new": 2}
 
 
@@ -220,6 +228,15 @@ def add_rowvec(x, vec, out=None):
         out = torch.empty((M, N), device=x.device, dtype=BF16)
     _lib.check(_L().mi_add_rowvec_bf16(x.data_ptr(), x.stride(0), vec.data_ptr(), out.data_ptr(), out.stride(0), M, N, _stream()), "mi_add_rowvec_bf16")
     return out
+
+
+def add_rowvec2(x, u, v):
+    """-> (bf16(x + u), bf16(x + v)) from one pass over x (bit-identical to two add_rowvec calls)"""
+    M, N = x.shape
+    ou = torch.empty((M, N), device=x.device, dtype=BF16)
+    ov = torch.empty((M, N), device=x.device, dtype=BF16)
+    _lib.check(_L().mi_add_rowvec2_bf16(x.data_ptr(), x.stride(0), u.data_ptr(), v.data_ptr(), ou.data_ptr(), ov.data_ptr(), N, M, N, _stream()), "mi_add_rowvec2_bf16")
+    return ou, ov
 
 
 def mask_rows_(x, lengths, T):

@@ -1018,7 +1018,7 @@ class EncoderCTCTrainer:
         dev = qkv.device
         q, k = qkv[:, :d], qkv[:, d:2 * d]
         if posp is not None:
-            qu, qv = T.add_rowvec(q, u), T.add_rowvec(q, v)
+            qu, qv = T.add_rowvec2(q, u, v)
             a_q, a_str = qu, (hd, Tt * d, d, 1)
         else:
             qu = qv = None
@@ -1055,7 +1055,7 @@ class EncoderCTCTrainer:
                                                      bias_v=P(p + "att_v") if rel else None, lengths=lengths, causal=self.causal, drop=drop)
             fused = True
             if rel:
-                qu, qv = T.add_rowvec(q, P(p + "att_u")), T.add_rowvec(q, P(p + "att_v"))
+                qu, qv = T.add_rowvec2(q, P(p + "att_u"), P(p + "att_v"))
                 off, Kp = T.band_geometry(Tt)                 # dbd's columns are relative positions + off
         else:
             fused = False
@@ -1099,10 +1099,8 @@ class EncoderCTCTrainer:
         cg = next((c for c in (4, 2) if B % c == 0 and H * (B // c) * -(-Kp // 128) >= 256), 1)
         dpp = torch.empty((B // cg, Kp * d), device=dev, dtype=F32)
         T.bgemm(dbd, (B * Tt * Ps, cg * Tt * Ps, 1, Ps), qv, (hd, cg * Tt * d, 1, d), dpp, (hd, Kp * d, d), H, B // cg, Kp, hd, cg * Tt)
-        dposp = torch.zeros((Kp, d), device=dev, dtype=F32)
-        T.colsum_(dposp.view(-1), dpp)
-        # linear_pos: posp = table · Wpos^T  ->  dWpos += dposp^T · table
-        dpb = T.add_cast(dposp[off:off + Pn])
+        # linear_pos: posp = table · Wpos^T  ->  dWpos += dposp^T · table.  dposp = the groups' partials summed in order, straight to the bf16 operand (rows off .. off + Pn)
+        dpb = T.colsum_cast(dpp[:, off * d:(off + Pn) * d]).view(Pn, d)
         T.gemm_tn_(G(p + "att_wpos"), dpb, pos[0], defer=self._tnb)
         return dqkv
 

@@ -243,6 +243,8 @@ int mi_ce_label_smoothing(const float* logits, long ld, const long* labels, int 
 int mi_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int M, int N, int Mp, mi_stream_t stream);
 int mi_transpose_many_bf16(const void* descs, int count, mi_stream_t stream);   /* descs: device array of {const void* in; void* out; int M, N, Mp, pad;} */
 int mi_colsum(const void* x, long ld, int dtype, int M, int N, float* out, mi_stream_t stream);
+/* out (N) bf16 = column sums of x (M, N) f32, rows added in order (M small: the per-group partials of d(posp), train.py `_attention_bwd`) */
+int mi_colsum_cast_bf16(const float* x, long ld, int M, int N, void* out, mi_stream_t stream);
 int mi_act_fwd_bf16(const void* pre, long ldp, void* out, long ldo, int M, int N, int kind, mi_stream_t stream);
 int mi_act_bwd_bf16(const void* dy, long lddy, const void* pre, long ldp, void* dx, long lddx, int M, int N, int kind,
                     mi_stream_t stream);
@@ -276,6 +278,8 @@ int mi_scale_dev_f32(float* a, long n, const float* alpha_dev, mi_stream_t strea
 int mi_add2_cast_bf16(const float* a, long lda, const float* b, long ldb, void* out, long ldo, int M, int N, float alpha,
                       mi_stream_t stream);
 int mi_add_rowvec_bf16(const void* x, long ldx, const float* vec, void* out, long ldo, int M, int N, mi_stream_t stream);
+/* out_u = bf16(x + u), out_v = bf16(x + v) from one read of x (q + pos_bias_u / q + pos_bias_v: e_branchformer's relative-position attention, tf wav2vec2_conformer :466-470) */
+int mi_add_rowvec2_bf16(const void* x, long ldx, const float* u, const float* v, void* out_u, void* out_v, long ldo, int M, int N, mi_stream_t stream);
 int mi_gate_bwd_bf16(const void* ds, long ldds, const void* c, long ldc, const void* r, long ldr, void* dr, long lddr,
                      void* dc, long lddc, int M, int N, mi_stream_t stream);
 int mi_mask_rows_f32(float* x, long ld, const int* lengths, int T, int M, int N, mi_stream_t stream);

@@ -758,3 +758,28 @@ def test_context_aware_front_end_backward_pieces(share):
     T.conv2d_first_wgrad(x.to(DEV), dev16(dy), dw, db, K, S, P)
     torch.testing.assert_close(dw.cpu(), w.grad.reshape(C, -1), atol=2e-3 * float(w.grad.abs().max()), rtol=1e-3)
     torch.testing.assert_close(db.cpu(), b.grad, atol=2e-3 * float(b.grad.abs().max()), rtol=1e-3)
+
+
+def test_small_fused_passes_of_the_attention_backward():
+    """(q + u, q + v) from one read of q == the element-wise op twice, bit for bit (also on a strided view and on an un-aligned width, which takes the element-wise form);
+    the in-order column sum of a few partial rows straight to bf16 == torch's sum rounded once."""
+    from huggingface_asr_amd import ops_train as T
+    g = torch.Generator().manual_seed(3)
+    for M, d, ld in ((777, 512, 1536), (50, 36, 36)):
+        qkv = (torch.randn(M, ld, generator=g)).to(DEV, torch.bfloat16)
+        u, v = torch.randn(d, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
+        q = qkv[:, :d]
+        qu, qv = T.add_rowvec2(q, u, v)
+        assert torch.equal(qu, T.add_rowvec(q, u)) and torch.equal(qv, T.add_rowvec(q, v))
+        assert torch.equal(qu, (q.float() + u).to(torch.bfloat16))
+    for M, N in ((8, 511 * 64), (24, 4096), (1, 64)):
+        x = torch.randn(M, N + 128, generator=g).to(DEV)
+        got = T.colsum_cast(x[:, 64:64 + N])
+        want = x[:, 64:64 + N].double().sum(0)
+        assert got.dtype == torch.bfloat16 and got.shape == (N,)
+        err = (got.double() - want).abs()
+        assert float((err / (want.abs() + 1.0)).max()) < 8e-3                       # one bf16 rounding of an fp32 sum
+        seq = x[0, 64:64 + N].clone()
+        for m in range(1, M):
+            seq = seq + x[m, 64:64 + N]
+        assert torch.equal(got, seq.to(torch.bfloat16))                             # rows added in order, rounded once
