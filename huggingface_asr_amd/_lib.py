@@ -95,6 +95,7 @@ SIGNATURES = {
     "mi_scale_dev_f32": [vp, i64, vp, vp],
     "mi_add2_cast_bf16": [vp, i64, vp, i64, vp, i64, i32, i32, f32, vp],
     "mi_add_rowvec_bf16": [vp, i64, vp, vp, i64, i32, i32, vp],
+    "mi_colsum2_acc_f32": [vp, vp, i64, i32, i32, vp, vp, vp],
     "mi_colsum_cast_bf16": [vp, i64, i32, i32, vp, vp],
     "mi_add_rowvec2_bf16": [vp, i64, vp, vp, vp, vp, i64, i32, i32, vp],
     "mi_gate_bwd_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, vp],

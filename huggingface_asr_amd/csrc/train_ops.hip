@@ -117,6 +117,23 @@ __global__ __launch_bounds__(256) void colsum_cast_kernel(const float* __restric
     }
 }
 
+// out_a[n] += sum_m a[m][n], out_b[n] += sum_m b[m][n]: two partial-sum matrices of the same shape (a few hundred rows), rows added in order by the column's thread —
+// the position-bias gradients from the attention backward's per-wave partials, without atomics (deterministic) and in one launch
+__global__ __launch_bounds__(256) void colsum2_acc_kernel(const float* __restrict__ a, const float* __restrict__ b, long ld, int M, int N,
+                                                           float* __restrict__ out_a, float* __restrict__ out_b) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float* src = blockIdx.y ? b : a;
+    float* dst = blockIdx.y ? out_b : out_a;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                      // four rows in flight; combined in a fixed order
+    int m = 0;
+    for (; m + 4 <= M; m += 4) {
+        s0 += src[(long)m * ld + n]; s1 += src[(long)(m + 1) * ld + n]; s2 += src[(long)(m + 2) * ld + n]; s3 += src[(long)(m + 3) * ld + n];
+    }
+    for (; m < M; ++m) s0 += src[(long)m * ld + n];
+    dst[n] += (s0 + s1) + (s2 + s3);
+}
+
 // ------------------------------------------------------------------------------------------------ activations
 // MODE 0: out = act(a);  MODE 1: out = a * act'(b)   (a = dy, b = pre-activation);  kind 1 erf-GELU, 2 tanh-GELU
 // DROP: the activation dropout of the FFN (tf wav2vec2_conformer :353) applied in the same pass — forward out = dropout(act(a)), backward
@@ -629,6 +646,15 @@ extern "C" int mi_colsum(const void* x, long ld, int dtype, int M, int N, float*
     if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ld, M, N, out, rpb);
     else if (dtype == 1) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ld, M, N, out, rpb);
     else return MI_ERR_ARG;
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// out_a (N) += column sums of a (M, N) f32, out_b (N) += column sums of b (M, N) f32 (same shape and row stride): deterministic, one launch
+extern "C" int mi_colsum2_acc_f32(const float* a, const float* b, long ld, int M, int N, float* out_a, float* out_b, hipStream_t st) {
+    MI_ENTER();
+    if (M <= 0 || N <= 0 || !a || !b || !out_a || !out_b) return MI_ERR_ARG;
+    hipLaunchKernelGGL(colsum2_acc_kernel, dim3(cdiv(N, 256), 2), dim3(256), 0, st, a, b, ld, M, N, out_a, out_b);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

@@ -51,6 +51,13 @@ def colsum_(out, x):
     _lib.check(_L().mi_colsum(x.data_ptr(), x.stride(0), 0 if x.dtype == F32 else 1, M, N, out.data_ptr(), _stream()), "mi_colsum")
 
 
+def colsum2_acc_(out_a, out_b, a, b):
+    """out_a (N) += column sums of a (M, N) f32, out_b (N) += column sums of b (same shape): rows added in a fixed order, one launch"""
+    M, N = a.shape
+    assert b.shape == a.shape and a.stride(0) == b.stride(0)
+    _lib.check(_L().mi_colsum2_acc_f32(a.data_ptr(), b.data_ptr(), a.stride(0), M, N, out_a.data_ptr(), out_b.data_ptr(), _stream()), "mi_colsum2_acc_f32")
+
+
 def colsum_cast(x):
     """-> (N) bf16 = column sums of x (M, N) f32, rows added in order (M small)"""
     M, N = x.shape

@@ -1083,8 +1083,7 @@ class EncoderCTCTrainer:
             return dqkv
         Ps = dbd.shape[-1]
         if fused:
-            T.colsum_(G(p + "att_u"), su)
-            T.colsum_(G(p + "att_v"), sv)
+            T.colsum2_acc_(G(p + "att_u"), G(p + "att_v"), su, sv)
         else:
             dqu = torch.empty((M, d), device=dev, dtype=F32)
             dqv = torch.empty((M, d), device=dev, dtype=F32)

@@ -245,6 +245,9 @@ int mi_transpose_many_bf16(const void* descs, int count, mi_stream_t stream);   
 int mi_colsum(const void* x, long ld, int dtype, int M, int N, float* out, mi_stream_t stream);
 /* out (N) bf16 = column sums of x (M, N) f32, rows added in order (M small: the per-group partials of d(posp), train.py `_attention_bwd`) */
 int mi_colsum_cast_bf16(const float* x, long ld, int M, int N, void* out, mi_stream_t stream);
+/* out_a (N) += column sums of a (M, N), out_b (N) += column sums of b (M, N): fp32, rows added in a fixed order (the pos_bias_u / pos_bias_v gradients from the attention
+   backward's per-wave partials; tf wav2vec2_conformer :466-470) */
+int mi_colsum2_acc_f32(const float* a, const float* b, long ld, int M, int N, float* out_a, float* out_b, mi_stream_t stream);
 int mi_act_fwd_bf16(const void* pre, long ldp, void* out, long ldo, int M, int N, int kind, mi_stream_t stream);
 int mi_act_bwd_bf16(const void* dy, long lddy, const void* pre, long ldp, void* dx, long lddx, int M, int N, int kind,
                     mi_stream_t stream);

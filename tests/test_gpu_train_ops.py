@@ -783,3 +783,12 @@ def test_small_fused_passes_of_the_attention_backward():
         for m in range(1, M):
             seq = seq + x[m, 64:64 + N]
         assert torch.equal(got, seq.to(torch.bfloat16))                             # rows added in order, rounded once
+    a, b = torch.randn(264, 512, generator=g).to(DEV), torch.randn(264, 512, generator=g).to(DEV)
+    oa, ob = torch.randn(512, generator=g).to(DEV), torch.randn(512, generator=g).to(DEV)
+    wa, wb = oa.double() + a.double().sum(0), ob.double() + b.double().sum(0)
+    oa2, ob2 = oa.clone(), ob.clone()
+    T.colsum2_acc_(oa, ob, a, b)
+    T.colsum2_acc_(oa2, ob2, a, b)
+    torch.testing.assert_close(oa.double(), wa, atol=2e-4, rtol=1e-5)
+    torch.testing.assert_close(ob.double(), wb, atol=2e-4, rtol=1e-5)
+    assert torch.equal(oa, oa2) and torch.equal(ob, ob2)                            # no atomics: the same bits every time
