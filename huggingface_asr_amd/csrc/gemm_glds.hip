@@ -303,12 +303,12 @@ bool gemm_glds_supported(const GemmArgs& a, bool conv) {
 }
 
 // Kernel selection.  a.variant (mi_gemm_bf16_v / mi_conv2d_cl_bf16_v; 0 from every product call site) exists for A/B runs and for tests that must reach a kernel
-// at a size its default dispatch would not pick:  40 = phase kernels wherever supported, 41 = never (this file's kernels only), 42 = 128x128 phase kernel wherever
+// at a size its default dispatch would not pick:  40 = phase kernels wherever supported, 41 = never (this file's kernels only), 32 = this file's 32x64 small-M tiles, 42 = 128x128 phase kernel wherever
 // supported, 47 = its two-segment form, 30 = this file's 128x128 tiles, 31 = the same, one block per tile.
 int gemm_glds_launch(const GemmArgs& a, bool conv, hipStream_t stream) {
     if (!gemm_glds_supported(a, conv)) return MI_ERR_UNSUPPORTED;
     const int v = a.variant;
-    const bool phase_ok = v != 41 && v != 30 && v != 31;
+    const bool phase_ok = v != 41 && v != 30 && v != 31 && v != 32;
     // wide-N bf16-out GEMMs (FFN in, cgMLP in, QKV) and the implicit-GEMM conv: 256x256 tiles on the phase-interleaved schedule (gemm_8p.hip) once the tiles fill half the chip
     const int t256 = cdiv(a.M, 256) * cdiv(a.N, 256);
     if (phase_ok && gemm_8p_supported(a, conv) && (t256 >= 128 || v == 40)) return gemm_8p_launch(a, conv, stream);
@@ -319,6 +319,14 @@ int gemm_glds_launch(const GemmArgs& a, bool conv, hipStream_t stream) {
     // 128 x 64 output tiles, 48 KiB of LDS -> THREE persistent blocks per CU (blocks in flight beat bytes per flop when operands arrive cold); longer ones
     // (the CTC head: 79) and the conv GEMM keep 128 x 128 tiles, two persistent blocks per CU, the next tile's first K tile prefetched under the epilogue.
     const long steps_per_cu = (long)cdiv(a.M, BM) * cdiv(a.N, BN) * (a.K / BK) / 256;
+    // A handful of rows (one utterance: M = 250 frames; the decoder's prompt): 128 x 64 tiles would give 16-64 blocks, each walking K with ONE tile in flight — the launch is
+    // a chain of L2 round trips on a sixth of the chip (16 us per GEMM of the bs = 1 encoder).  32 x 64 tiles on two waves, four stages (three K tiles in flight, 48 KiB):
+    // 4x the blocks, a third of the exposed round trips; same accumulation order, hence the same bits.  v == 32 forces it.
+    if (!conv && v != 30 && v != 31 && (v == 32 || (a.M <= 2048 && cdiv(a.M, 128) * cdiv(a.N, 64) < 128))) {
+        const int g = cdiv(a.M, 32) * cdiv(a.N, 64);
+        launch_dense(PF_GLDS, gemm_glds_kernel<32, 64, 1, 2, 4, false>, dim3(g), dim3(128), (size_t)4 * (32 + 64) * BK * 2, stream, a);
+        return MI_OK;
+    }
     if (!conv && v != 30 && v != 31 && steps_per_cu <= 48) {
         int g = cdiv(a.M, 128) * cdiv(a.N, 64);
         if (g > 768) g = 768;
