@@ -150,8 +150,10 @@ class GPT2DecoderEngine:
     def init_cache(self, B: int, Lmax: int):
         """KV cache: two sets of (B, Lmax, d) tensors per layer (beam re-ordering copies set A -> set B in one kernel and swaps)."""
         d, L = self.cfg["n_embd"], self.cfg["n_layer"]
-        z = lambda: torch.zeros((B, Lmax, d), device=self.device, dtype=BF16)
-        cache = dict(k=[z() for _ in range(L)], v=[z() for _ in range(L)], k2=[z() for _ in range(L)], v2=[z() for _ in range(L)], past=0, Lmax=Lmax)
+        # one allocation and one fill for all 4 L tensors.  Zero, not empty: the MFMA attention kernel stages whole 32-key tiles, and a V row past the last key meets a
+        # probability of exactly 0 — which only gives 0 if the row holds finite numbers
+        buf = torch.zeros((4, L, B, Lmax, d), device=self.device, dtype=BF16)
+        cache = dict(k=list(buf[0].unbind(0)), v=list(buf[1].unbind(0)), k2=list(buf[2].unbind(0)), v2=list(buf[3].unbind(0)), past=0, Lmax=Lmax)
         self._cache_tables(cache)
         return cache
 
