@@ -124,9 +124,16 @@ __device__ __forceinline__ void gemm_glds_tile(const GemmArgs& p, int bid, char*
         const int stage = kt % STAGES;
         // tile kt has landed for THIS wave's pieces once at most the younger in-flight tiles' pieces are outstanding
         const int younger = min(STAGES - 2, nk - 1 - kt);
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        static_assert(STAGES <= 8 && 6 * PPW <= 63, "vmcnt immediates below");
+        switch (younger) {                                  // the count is an immediate: one case per depth the ring can have
+            case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * PPW) : "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * PPW) : "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PPW) : "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         asm volatile("s_barrier" ::: "memory");    // every wave's pieces of tile kt landed; stage of tile kt-1 is free
         if (kt + STAGES - 1 < nk) issue(ktile(kt + STAGES - 1), (kt + STAGES - 1) % STAGES);
         const char* a = smem + stage * STG;
@@ -321,7 +328,8 @@ int gemm_glds_launch(const GemmArgs& a, bool conv, hipStream_t stream) {
     const long steps_per_cu = (long)cdiv(a.M, BM) * cdiv(a.N, BN) * (a.K / BK) / 256;
     // A handful of rows (one utterance: M = 250 frames; the decoder's prompt): 128 x 64 tiles would give 16-64 blocks, each walking K with ONE tile in flight — the launch is
     // a chain of L2 round trips on a sixth of the chip (16 us per GEMM of the bs = 1 encoder).  32 x 64 tiles on two waves, four stages (three K tiles in flight, 48 KiB):
-    // 4x the blocks, a third of the exposed round trips; same accumulation order, hence the same bits.  v == 32 forces it.
+    // 4x the blocks, a third of the exposed round trips; same accumulation order, hence the same bits.  v == 32 forces it.  (Eight stages for the K = 2048 ones measured
+    // slower, 13.6 vs 12.2 us: their K loop is bound by the issue of the LDS-DMA pieces — six per wave and tile — not by the tiles in flight.)
     if (!conv && v != 30 && v != 31 && (v == 32 || (a.M <= 2048 && cdiv(a.M, 128) * cdiv(a.N, 64) < 128))) {
         const int g = cdiv(a.M, 32) * cdiv(a.N, 64);
         launch_dense(PF_GLDS, gemm_glds_kernel<32, 64, 1, 2, 4, false>, dim3(g), dim3(128), (size_t)4 * (32 + 64) * BK * 2, stream, a);
