@@ -329,8 +329,8 @@ int gemm_glds_launch(const GemmArgs& a, bool conv, hipStream_t stream) {
     // A handful of rows (one utterance: M = 250 frames; the decoder's prompt): 128 x 64 tiles would give 16-64 blocks, each walking K with ONE tile in flight — the launch is
     // a chain of L2 round trips on a sixth of the chip (16 us per GEMM of the bs = 1 encoder).  32 x 64 tiles on two waves, four stages (three K tiles in flight, 48 KiB):
     // 4x the blocks, a third of the exposed round trips; same accumulation order, hence the same bits.  v == 32 forces it.  (Eight stages for the K = 2048 ones measured
-    // slower, 13.6 vs 12.2 us, and 64 x 64 tiles on four waves the same, 12.6: their K loop — 0.24 us per tile — is the chain of four dependent MFMAs into one accumulator plus
-    // the barrier, not the tiles in flight nor the LDS-DMA issue.)
+    // slower, 13.6 vs 12.2 us, and 64 x 64 tiles on four waves the same, 12.6: and one accumulator per k-step (no dependent MFMA chain)
+    // slower too, 12.9: the 0.24 us per K tile of that loop is none of tiles in flight, pieces per wave or MFMA latency — what is left is the barrier + wait per tile.)
     if (!conv && v != 30 && v != 31 && (v == 32 || (a.M <= 2048 && cdiv(a.M, 128) * cdiv(a.N, 64) < 128))) {
         const int g = cdiv(a.M, 32) * cdiv(a.N, 64);
         launch_dense(PF_GLDS, gemm_glds_kernel<32, 64, 1, 2, 4, false>, dim3(g), dim3(128), (size_t)4 * (32 + 64) * BK * 2, stream, a);
