@@ -15,6 +15,7 @@
 // One wave owns 32 queries; operands (K rows, P rows, V^T rows) are L2-resident and loaded straight
 // into MFMA fragments.  V^T (d, B*Tp) is produced key-contiguous by the V-projection GEMM.
 #include "common.hpp"
+#include <atomic>
 
 namespace {
 
@@ -39,6 +40,11 @@ struct AttnArgs {
     // attention-probability dropout (e_branchformer.py:132) in the LDS-staged kernel, training forward and backward: the counter-based mask of dropout.hip for the
     // logical element ((h * B + b) * T + i) * Tk + j of the (H, B, T, Tk) probabilities — the same mask the generic softmax kernels (attn_bwd.hip) and the host twin draw
     float drop_p; unsigned long long drop_key;
+#ifdef ATTN_STAMPS
+    unsigned long long* stamps;          // instrumented build only (tools/attn_stamps.py): per (block, wave) 32 shader-clock readings
+#endif
+    int gx; unsigned mgx, mgy;            // eight-wave form (1-D grid): query blocks per (batch, head) and ceil(2^32 / gx), ceil(2^32 / H) — exact quotients for block ids < 2^16
+    int variant;                         // 0: the product's choice; 1: the four-wave LDS-staged forward; 2: the eight-wave form (1, 2: A/B only, tools/attn_ab.py)
 };
 
 // 16-B chunk swizzle of the LDS-staged kernel's tiles (applied on the DMA source and on every read).  256-B rows (hd 128): the image that is conflict-free for ds_read_b128
@@ -810,8 +816,499 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
     }
 }
 
+
+// ======================================================================================================================
+// Eight-wave form of the LDS-staged forward (round 4; head size 64 / 128).  A block = 8 waves = 128 consecutive queries of one (batch, head), TWO waves per SIMD:
+// waves w and w + 4 own the SAME 32 queries (query group qi = w & 3) and split the keys by tile parity (s = w >> 2 takes the tiles t with t & 1 == s), each with its own
+// flash state (m, l, O); the pair is merged once at the end.  The two halves run HALF A TILE APART: a tile is two phases,
+//     P1(t): S^T = K_t (Q + u)^T, both G tiles of the band, the rel-shift's select + write               (24 MFMAs at head size 128, few VALU)
+//     P2(t): shifted band read back, scale, mask, online softmax, O^T += V_t^T P^T                        (8 MFMAs, the VALU work)
+// and in interval i (one s_barrier each) the half with s == (i & 1) runs P1(i) while the other runs P2(i - 1): on every SIMD one wave feeds the matrix pipe while
+// its partner does the soft-max — with one wave per SIMD (rounds 1-3) every segment ran at 1.5-3x its issue count because nothing else was there to issue.
+//  * Per interval ONE K tile, ONE V tile and ONE position block are requested (a 1-KiB LDS-DMA piece per wave and operand at head size 128), two intervals ahead of
+//    their first use: K / V rings of 3 tiles (4 without the position ring), position ring of 7 blocks; the wait at the top of an interval is a counted vmcnt that
+//    leaves the previous interval's requests in flight.
+//  * Relative positions: block k = rows RB0 + 32 k of the projected table; (qi, t) needs k = t - qi (lower G tile) and t - qi + 1 (upper): P1(t) reads blocks t - 3 .. t + 1.
+//    A wave computes BOTH G tiles (the carried tile of the four-wave form would belong to the partner: 32 instead of 24 MFMAs per tile).  The rel-shift no longer needs a
+//    64-column fp32 row per query: of the lower tile's element c and the upper tile's element c exactly one is inside the band's parallelogram (lower iff c >= 31 - r),
+//    and both land on key (c + r + 1) & 31 — one select (lane masks in SGPRs), ONE ds_write_b32 per register into a 32-column row, and the shifted tile comes back as
+//    four ds_read_b128: 4.5 KiB of scratch per wave instead of 8.5.
+//  * LDS map: [K ring][V ring][position ring][8 skew scratches, pair-adjacent][8 x 512 B].  Q is staged into the pair's two scratches (9 KiB >= one 32-row tile), the
+//    head's pos_bias_u / pos_bias_v into the 512-B areas (per-lane global loads of them cost 3 us of every launch in rounds 1-3); after the loop the ring area is the
+//    exchange region of the merge: each wave hands the partner the half of O^T (hd rows) it does not keep, so both combine, normalise and store one half of the head.
+//  * blockIdx -> (query block, head, batch) is XCD-aware: the hardware deals consecutive workgroups round-robin to the 8 XCDs, so consecutive LOGICAL blocks (the query
+//    blocks of one (batch, head), which read the same K / V / position rows) are given ids that are congruent mod 8: K and V reach one L2 once per (batch, head).
+#ifdef ATTN_STAMPS
+#define STAMP(i) do { if (lane == 0) sp[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+constexpr int SC8_LD = 36;                       // words per query row of a wave's skew scratch (32 + 4: rows stay 16-B aligned for ds_read_b128)
+constexpr int SC8_B = 32 * SC8_LD * 4;           // 4608 B per wave; re-used as the output staging (32 rows x (hd / 2 x 2 B + 16))
+template <int HD, bool REL, bool DROP>
+__global__ __launch_bounds__(512) void attn8_kernel(AttnArgs p) {
+    constexpr int KS = HD / 16, NTO = HD / 32, NH = NTO / 2;
+    constexpr int ROWB = HD * 2, NCH = ROWB / 16;
+    constexpr int TILEB = 32 * ROWB;
+    constexpr int RPP = 1024 / ROWB;                          // rows per 1-KiB DMA piece
+    constexpr int PIECES = TILEB / 1024;                      // per 32-row tile: 8 (hd 128: one per wave) / 4 (hd 64)
+    constexpr int KD = REL ? 3 : 4;                           // K / V ring depth
+    constexpr int FD = KS < 6 ? KS : 6;                      // P1: MFMA-fragment ds_read_b128 in flight per chain
+    constexpr int PRING = 7;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = sK + KD * TILEB;
+    char* sP = sV + KD * TILEB;
+    char* scr_all = sP + (REL ? PRING * TILEB : 0);
+    float* ml_all = reinterpret_cast<float*>(scr_all + 8 * SC8_B);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int qi = wave & 3, s = wave >> 2;
+    const int r = lane & 31, h2 = lane >> 5;
+    // XCD-aware block order (see above): hardware id L runs on XCD L % 8; logical id = (L % 8) * (N / 8) + L / 8.  Quotients by host-made reciprocals: no division, no
+    // dependent scalar load in front of the prologue's requests
+    int head, b, ib;
+    {
+        const unsigned N = gridDim.x;
+        unsigned L = blockIdx.x;
+        if ((N & 7) == 0) L = (L & 7) * (N >> 3) + (L >> 3);
+        const unsigned q1 = p.gx == 1 ? L : __umulhi(L, p.mgx);               // L / gx   (ceil(2^32 / 1) does not fit 32 bits)
+        const unsigned q2 = p.H == 1 ? q1 : __umulhi(q1, p.mgy);              // L / (gx H)
+        ib = (int)(L - q1 * (unsigned)p.gx) * 128;
+        head = (int)(q1 - q2 * (unsigned)p.H);
+        b = (int)q2;
+    }
+    const int i0 = ib + qi * 32;
+    char* scr = scr_all + (qi * 2 + s) * SC8_B;               // pair-adjacent: the pair's two scratches are one 9-KiB area (Q staging)
+#ifdef ATTN_STAMPS
+    unsigned long long* sp = p.stamps + ((long)blockIdx.x * 8 + wave) * 32;
+    STAMP(0);
+#endif
+    const int T = p.T;
+    const int Tk = p.Tk > 0 ? p.Tk : p.T;
+    const int coff = Tk - T;
+    const int RB0 = T - 1 - ib - 31;                          // first row of position block 0 (REL needs Tk == T)
+
+    // ---- DMA addressing: this wave's piece of a 32-row tile is the same for K, V and the position block
+    const int prow = lane / NCH, pc = lane % NCH;
+    const int piece = wave & (PIECES - 1);
+    const bool doK = PIECES == 8 || wave < 4, doV = PIECES == 8 || wave >= 4, doP = REL && (PIECES == 8 || wave < 4);
+    const int trow = piece * RPP + prow;                      // 0..31
+    const long kvoff = p.kv_bstride ? (long)b * p.kv_bstride : 0;
+    const int colb = (head * HD + (pc ^ tswz<NCH>(trow)) * 8) * 2;
+    const char* kB = reinterpret_cast<const char*>(p.k + (p.kv_bstride ? kvoff : (long)b * Tk * p.ldk)) + colb;
+    const char* vB = reinterpret_cast<const char*>(p.vt + (p.kv_bstride ? kvoff : (long)b * Tk * p.ldvt)) + colb;
+    const char* pB = reinterpret_cast<const char*>(p.pos) + colb;
+    const unsigned ldkB = (unsigned)p.ldk * 2u, ldvB = (unsigned)p.ldvt * 2u, ldpB = (unsigned)p.ldp * 2u;
+    auto issue_k = [&](int t, int slot) {
+        const unsigned gr = (unsigned)min(32 * t + trow, Tk - 1);
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(kB + (unsigned long)gr * ldkB),
+                                         (__attribute__((address_space(3))) void*)(sK + slot * TILEB + piece * 1024), 16, 0, 0);
+    };
+    auto issue_v = [&](int t, int slot) {
+        const unsigned gr = (unsigned)min(32 * t + trow, Tk - 1);
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(vB + (unsigned long)gr * ldvB),
+                                         (__attribute__((address_space(3))) void*)(sV + slot * TILEB + piece * 1024), 16, 0, 0);
+    };
+    auto issue_p = [&](int k, int slot) {
+        const unsigned gr = (unsigned)min(max(RB0 + 32 * k + trow, 0), 2 * T - 2);
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(pB + (unsigned long)gr * ldpB),
+                                         (__attribute__((address_space(3))) void*)(sP + slot * TILEB + piece * 1024), 16, 0, 0);
+    };
+
+    // ---- prologue: the pair's Q tile first (it is needed first), the head's position biases, then K tiles 0 .. KD - 2, V tiles 0 .. KD - 3, position blocks -3 .. 2
+    char* qst = scr_all + qi * 2 * SC8_B;
+    {
+        const char* qb = reinterpret_cast<const char*>(p.q + (long)b * T * p.ldq);
+        const unsigned ldqB = (unsigned)p.ldq * 2u;
+#pragma unroll
+        for (int pp = 0; pp < PIECES / 2; ++pp) {
+            const int pq = s * (PIECES / 2) + pp;
+            const int row = pq * RPP + prow;
+            const int cq = (head * HD + (pc ^ tswz<NCH>(row)) * 8) * 2;
+            const char* src = qb + (unsigned long)(unsigned)min(i0 + row, T - 1) * ldqB + cq;
+            __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)src,
+                                             (__attribute__((address_space(3))) void*)(qst + pq * 1024), 16, 0, 0);
+        }
+    }
+    if (REL && wave < 2) {                                    // wave 0: pos_bias_u[head], wave 1: pos_bias_v[head] -> ml_all[0 .. HD), ml_all[256 .. 256 + HD) (lanes past HD / 4 re-load the start)
+        const float* bsrc = (wave == 0 ? p.bias_u : p.bias_v) + head * HD + (lane % (HD / 4)) * 4;
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)bsrc,
+                                         (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(ml_all) + wave * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < KD - 1; ++t) if (doK) issue_k(t, t);
+#pragma unroll
+    for (int t = 0; t < KD - 2; ++t) if (doV) issue_v(t, t);
+    if (REL) {
+#pragma unroll
+        for (int k = -3; k <= 2; ++k) if (doP) issue_p(k, (k + PRING) % PRING);
+    }
+    STAMP(1);
+    asm volatile("" ::: "memory");
+    // the key length is a dependent load from HBM: asked for only now, behind the prologue's requests (it sat in front of them for 1 - 2 us of every launch)
+    const int len = p.lengths ? min(p.lengths[b], Tk) : Tk;
+    const int kend = p.causal ? min(len, ib + 128 + coff) : len;
+    const int nkt = (kend + 31) / 32;
+    // per-lane constants of the loop while the prologue's loads fly
+    int foff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) foff[ks] = r * ROWB + (((ks * 2 + h2) ^ tswz<NCH>(r)) << 4);
+    int voff[NTO][2];
+    {
+        const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+#pragma unroll
+        for (int t = 0; t < NTO; ++t)
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) {
+                const int col = t * 32 + (g & 1) * 16 + 4 * p4;
+                const int krow = 8 * hi + 4 * (g >> 1) + q4;
+                voff[t][hi] = krow * ROWB + (((col >> 3) ^ tswz<NCH>(krow)) << 4) + (col & 7) * 2;
+            }
+    }
+    // rel-shift: register e of a G tile is band column c = crow(e, h2) (lower tile) or 32 + c (upper); the lower one is inside the band iff c >= 31 - r; both belong to key (c + r + 1) & 31
+    bool low_in[REL ? 16 : 1];
+    unsigned wadr[REL ? 16 : 1];
+    if constexpr (REL) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = crow(e, h2);
+            low_in[e] = c >= 31 - r;
+            wadr[e] = (unsigned)(size_t)scr + (unsigned)((r * SC8_LD + ((c + r + 1) & 31)) * 4);
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(foff[ks]));        // computed under the prologue's loads, not behind them
+#pragma unroll
+    for (int t = 0; t < NTO; ++t) asm volatile("" : "+v"(voff[t][0]), "+v"(voff[t][1]));
+    if constexpr (REL) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) asm volatile("" : "+v"(wadr[e]));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(2);
+    asm volatile("s_barrier" ::: "memory");
+    STAMP(3);
+    bf16x8 qu[KS], qv[REL ? KS : 1];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 raw = *reinterpret_cast<const bf16x8*>(qst + foff[ks]);
+        if (REL) {
+            const int c = ks * 16 + h2 * 8;
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(ml_all + c), u1 = *reinterpret_cast<const f32x4*>(ml_all + c + 4);
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(ml_all + 256 + c), v1 = *reinterpret_cast<const f32x4*>(ml_all + 256 + c + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = bf2f(raw[j]);
+                qu[ks][j] = f2bf(f + (j < 4 ? u0[j & 3] : u1[j & 3]));
+                qv[ks][j] = f2bf(f + (j < 4 ? v0[j & 3] : v1[j & 3]));
+            }
+        } else {
+            qu[ks] = raw;
+        }
+    }
+
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // Q and the biases are in registers before the first interval's barrier lets the skew writes into the staging area
+    const unsigned long long drop_row0 = (unsigned long long)(((long)head * p.B + b) * T + min(i0 + r, T - 1)) * (unsigned long long)Tk;
+    f32x16 O[NTO];
+#pragma unroll
+    for (int t = 0; t < NTO; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) O[t][e] = 0.f;
+    float m = -1e30f, l = 0.f;
+    const float sc2 = p.scale * 1.4426950408889634f;
+    int pend = 0;                                             // LDS-DMA pieces this wave requested in the previous interval
+    int iv = 0;                                               // interval counter: every wave passes exactly nkt + 1 interval heads (barriers)
+    auto head_of_interval = [&]() {
+        if (iv < 4) STAMP(4 + 3 * iv);
+        // everything requested two or more intervals ago has landed.  No lgkmcnt wait: every read of a shared tile was consumed by an MFMA behind a counted wait, and what
+        // may still be queued are the wave's own skew writes, which its own reads of the next interval follow in order.
+        if (pend >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (pend == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (pend == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (iv < 4) STAMP(5 + 3 * iv);
+        asm volatile("s_barrier" ::: "memory");
+        if (iv < 4) STAMP(6 + 3 * iv);
+    };
+    // this interval's requests (K tile iv + KD - 1, V tile iv + KD - 2, position block iv + 3); called once per interval, BEHIND the phase's first LDS reads so that their
+    // round trip passes under the address arithmetic and the issue of the pieces (100 - 185 cycles each inside a busy phase)
+    auto issue_dma_part = [&](int part) {                   // part 0: K, 1: V, 2: position block; part 0 opens the interval's count, part 2 closes the interval
+        if (part == 0) { pend = 0; if (doK && iv + KD - 1 < nkt) { issue_k(iv + KD - 1, (iv + KD - 1) % KD); ++pend; } }
+        if (part == 1) { if (doV && iv + KD - 2 < nkt) { issue_v(iv + KD - 2, (iv + KD - 2) % KD); ++pend; } }
+        if (part == 2) { if (doP && iv + 3 <= nkt) { issue_p(iv + 3, (iv + 3) % PRING); ++pend; } ++iv; }
+    };
+    auto issue_dma = [&]() { issue_dma_part(0); issue_dma_part(1); issue_dma_part(2); };
+    if (s == 1) {
+        __builtin_amdgcn_s_setprio(1);                        // waves 4-7 are the younger ones on their SIMDs and lose every issue arbitration to their partners: one static raise, no per-phase flips
+        head_of_interval();                                   // the odd half starts half a tile late
+        issue_dma();
+    }
+    int kvslot = s;                                           // t % KD, advanced by 2 per tile
+    int slo = (s - qi + PRING) % PRING;                       // ring slot of position block t - qi, advanced by 2 per tile
+    for (int t = s; t < nkt; t += 2) {
+        const int j0 = 32 * t;
+        const bool live = i0 < T && !(p.causal && j0 > i0 + 31 + coff);      // wave-uniform
+        // ---- P1(t)
+        head_of_interval();
+        f32x16 S;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) S[e] = 0.f;
+        if (live) {
+            // ONE stream of MFMAs (REL: lower G tile, upper G tile, S; else S) whose A fragments (rows of [32][hd] LDS tiles) are requested FD deep by hand with counted
+            // waits: left to the compiler every use of a fragment is a full `s_waitcnt lgkmcnt(0)`, and a drain at the head of each chain exposes a loaded LDS round trip.
+            constexpr int NF = REL ? 3 * KS : KS;
+            const unsigned bK = (unsigned)(size_t)(sK + kvslot * TILEB);
+            const unsigned bPl = (unsigned)(size_t)(sP + slo * TILEB), bPu = (unsigned)(size_t)(sP + (slo + 1 == PRING ? 0 : slo + 1) * TILEB);
+            bf16x8 f[FD];
+            f32x16 Gl = S, Gu = S;                            // zeros
+#pragma unroll
+            for (int n = 0; n < FD; ++n) {
+                const unsigned base = !REL ? bK : (n / KS == 0 ? bPl : (n / KS == 1 ? bPu : bK));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(f[n]) : "v"(base + foff[n % KS]) : "memory");
+            }
+            if (t == s + 2) STAMP(16);
+            issue_dma_part(0);                                // one piece now, the others a third and two thirds into the stream: eight waves issuing three pieces each right behind the barrier queue up (~400 cycles)
+            if (t == s + 2) STAMP(17);
+#pragma unroll
+            for (int n = 0; n < NF; ++n) {
+                if (n == NF / 3) issue_dma_part(1);
+                if (n == 2 * NF / 3) issue_dma_part(2);
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f[n % FD]) : "n"(NF - 1 - n < FD - 1 ? NF - 1 - n : FD - 1) : "memory");
+                if (!REL || n / KS == 2) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[n % FD], qu[n % KS], S, 0, 0, 0);
+                else if (n / KS == 0) Gl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[n % FD], qv[REL ? n % KS : 0], Gl, 0, 0, 0);
+                else Gu = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[n % FD], qv[REL ? n % KS : 0], Gu, 0, 0, 0);
+                if (n + FD < NF) {
+                    const int n2 = n + FD;
+                    const unsigned base = !REL ? bK : (n2 / KS == 0 ? bPl : (n2 / KS == 1 ? bPu : bK));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(f[n % FD]) : "v"(base + foff[n2 % KS]) : "memory");
+                }
+            }
+            if (t == s + 2) STAMP(18);
+            if constexpr (REL) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = low_in[e] ? Gl[e] : Gu[e];
+                    asm volatile("ds_write_b32 %0, %1" :: "v"(wadr[e]), "v"(v) : "memory");
+                }
+            }
+        } else {
+            issue_dma();
+        }
+        if (t < 4) STAMP(22);
+        // ---- P2(t)
+        head_of_interval();
+        if (live) {
+            // the shifted band (four 16-B pieces of this lane's row) and the V^T fragments are requested first, then this interval's DMA pieces are issued under their round trip
+            f32x4 bd[REL ? 4 : 1];
+            if constexpr (REL) {
+                const unsigned sb = (unsigned)(size_t)scr + (unsigned)((r * SC8_LD + 4 * h2) * 4);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bd[a]) : "v"(sb), "n"(32 * a) : "memory");
+            }
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            s16x4 lo[NTO][2], hi[NTO][2];
+            {
+                const unsigned vb = (unsigned)(size_t)(sV + kvslot * TILEB);
+#pragma unroll
+                for (int tt = 0; tt < NTO; ++tt)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[tt][s2]) : "v"(vb + voff[tt][0]), "n"(s2 * 16 * ROWB) : "memory");
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[tt][s2]) : "v"(vb + voff[tt][1]), "n"(s2 * 16 * ROWB) : "memory");
+                    }
+            }
+            if (t == s + 2) STAMP(19);
+            issue_dma_part(0);
+            if (t == s + 2) STAMP(20);
+            if constexpr (REL) {
+                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bd[0]), "+v"(bd[1]), "+v"(bd[2]), "+v"(bd[3]) : "n"(4 * NTO > 15 ? 15 : 4 * NTO) : "memory");      // the band only: the V^T reads stay in flight
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) S[4 * a + k] += bd[a][k];
+            }
+            // soft-max in the exp2 domain with the scale folded into ONE fma per element: p = 2^(S sc2 - m); the row maximum is taken on the raw scores (sc2 > 0)
+            const bool edge = (j0 + 32 > len) || (p.causal && j0 + 31 > i0 + coff);
+            float mx = -1e30f;
+            if (edge) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int jj = j0 + crow(e, h2);
+                    const bool dead = (jj >= len) || (p.causal && jj > i0 + r + coff);
+                    S[e] = dead ? -INFINITY : S[e];
+                    mx = fmaxf(mx, S[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, S[e]);
+            }
+            mx = half_swap_max(mx) * sc2;
+            if (__builtin_amdgcn_ballot_w64(mx > m + 11.f) != 0) {       // lazy rescale (see the four-wave form)
+                const float mnew = fmaxf(m, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+                l *= alpha;
+                m = mnew;
+#pragma unroll
+                for (int tt = 0; tt < NTO; ++tt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) O[tt][e] *= alpha;
+            }
+            issue_dma_part(1);
+            float ls = 0.f;
+            const float negm = -m;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                S[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[e], sc2, negm));
+                ls += S[e];
+            }
+            l += half_swap_sum(ls);
+            issue_dma_part(2);
+            if constexpr (DROP) {
+                float ks[16];
+                keep16(p.drop_key, p.drop_p, drop_row0 + (unsigned long long)j0, h2, (Tk & 1) != 0, ks);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) S[e] *= ks[e];
+            }
+            bf16x8 pb[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[s2][j] = f2bf(S[8 * s2 + j]);
+#ifdef ATTN_STAMPS
+            asm volatile("" : "+v"(pb[0]), "+v"(pb[1]));
+            if (t == s + 2) STAMP(21);
+#endif
+#pragma unroll
+            for (int tt = 0; tt < NTO; ++tt) {
+                if (tt == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // requested a soft-max ago
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    asm volatile("" : "+v"(lo[tt][s2]), "+v"(hi[tt][s2]));
+                    const s16x8 v8 = {lo[tt][s2][0], lo[tt][s2][1], lo[tt][s2][2], lo[tt][s2][3], hi[tt][s2][0], hi[tt][s2][1], hi[tt][s2][2], hi[tt][s2][3]};
+                    O[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pb[s2], O[tt], 0, 0, 0);
+                }
+            }
+        } else {
+            issue_dma();
+        }
+        if (t < 4) STAMP(23);
+        kvslot = kvslot + 2 >= KD ? kvslot + 2 - KD : kvslot + 2;
+        slo = slo + 2 >= PRING ? slo + 2 - PRING : slo + 2;
+    }
+    while (iv <= nkt) { head_of_interval(); issue_dma(); }    // the half that finishes first keeps the barrier count
+
+    // ---- merge of the pair: the half of O^T this wave does not keep, and its (m, l), go to the partner through LDS (the ring area is free behind the barrier)
+    STAMP(24);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    STAMP(25);
+    {
+        f32x4* xo = reinterpret_cast<f32x4*>(smem) + wave * (NH * 4 * 64) + lane;         // [tile][register quad][lane] 16-B pieces: conflict-free ds_write_b128 / ds_read_b128
+        float* mlw = ml_all + wave * 128;
+        mlw[lane] = m;
+        mlw[64 + lane] = l;
+#pragma unroll
+        for (int tt = 0; tt < NH; ++tt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = s == 0 ? O[NH + tt][4 * g4 + k] : O[tt][4 * g4 + k];
+                xo[(tt * 4 + g4) * 64] = v;
+            }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    STAMP(26);
+    asm volatile("s_barrier" ::: "memory");
+    STAMP(27);
+    {
+        const int pw = wave ^ 4;
+        const f32x4* xi = reinterpret_cast<const f32x4*>(smem) + pw * (NH * 4 * 64) + lane;
+        const float pm = ml_all[pw * 128 + lane], pl = ml_all[pw * 128 + 64 + lane];
+        const float mn = fmaxf(m, pm);
+        const float a = __builtin_amdgcn_exp2f(m - mn), pa = __builtin_amdgcn_exp2f(pm - mn);
+        const float lt = l * a + pl * pa;
+        const float inv = 1.f / lt;
+        if (p.lse && s == 0 && h2 == 0 && i0 + r < T) p.lse[((long)b * p.H + head) * T + i0 + r] = mn + __builtin_amdgcn_logf(lt);      // log2 domain
+        constexpr int STG = HD + 16;                          // bytes per staged row: hd / 2 bf16 + 16
+        const float ca = a * inv, cp = pa * inv;
+#pragma unroll
+        for (int tt = 0; tt < NH; ++tt) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 X = xi[(tt * 4 + g4) * 64];
+                bf16x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float mine = s == 0 ? O[tt][4 * g4 + k] : O[NH + tt][4 * g4 + k];
+                    o[k] = f2bf(mine * ca + X[k] * cp);
+                }
+                *reinterpret_cast<bf16x4*>(scr + r * STG + (tt * 32 + 8 * g4 + 4 * h2) * 2) = o;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        constexpr int LPR = (HD / 2 * 2) / 16, RPI = 64 / LPR;       // lanes per half row, rows per store instruction
+        const int orow = lane / LPR, och = lane % LPR;
+#pragma unroll
+        for (int q = 0; q < 32 / RPI; ++q) {
+            const int row = q * RPI + orow;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(scr + row * STG + och * 16);
+            if (i0 + row < T) *reinterpret_cast<bf16x8*>(p.out + ((long)b * T + i0 + row) * p.ldo + head * HD + s * (HD / 2) + och * 8) = v;
+        }
+        STAMP(28);
+#ifdef ATTN_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(29);
+#endif
+    }
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (kernel, device) — a process-wide `static bool` would configure only
+// the device that happened to be current at the first call.
+template <int TAG>
+bool ensure_dynamic_lds(const void* kernel, size_t bytes) {
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if ((done.load(std::memory_order_acquire) >> dev) & 1ull) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+    done.fetch_or(1ull << dev, std::memory_order_release);
+    return true;
+}
+
+template <int HD, bool REL, bool DROP>
+int launch_attn8_inst(const AttnArgs& a_in, hipStream_t stream) {
+    AttnArgs a = a_in;
+    a.gx = cdiv(a.T, 128);
+    const long nblk = (long)a.gx * a.H * a.B;
+    if (nblk >= (1l << 16)) return MI_ERR_UNSUPPORTED;        // the reciprocal quotients are exact below 2^16 blocks (the caller falls back to the four-wave form)
+    a.mgx = (unsigned)(((1ull << 32) + (unsigned)a.gx - 1) / (unsigned)a.gx);
+    a.mgy = (unsigned)(((1ull << 32) + (unsigned)a.H - 1) / (unsigned)a.H);
+    dim3 grid((unsigned)nblk), block(512);
+    const size_t lds = (size_t)(REL ? 6 + 7 : 8) * 32 * HD * 2 + 8 * SC8_B + 8 * 512;      // K + V rings (3 + 3 | 4 + 4 tiles), position ring, skew scratches, (m, l) / bias area
+    if (!ensure_dynamic_lds<HD * 4 + REL * 2 + DROP>(reinterpret_cast<const void*>(attn8_kernel<HD, REL, DROP>), lds)) return MI_ERR_LAUNCH;
+    hipLaunchKernelGGL((attn8_kernel<HD, REL, DROP>), grid, block, lds, stream, a);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+template <int HD>
+int launch_attn8(const AttnArgs& a, bool rel, hipStream_t stream) {
+    const bool drop = a.drop_p > 0.f;
+    if (rel) return drop ? launch_attn8_inst<HD, true, true>(a, stream) : launch_attn8_inst<HD, true, false>(a, stream);
+    return drop ? launch_attn8_inst<HD, false, true>(a, stream) : launch_attn8_inst<HD, false, false>(a, stream);
+}
+
 template <int HD>
 int launch_lds(const AttnArgs& a, bool rel, hipStream_t stream) {
+    // The product's choice (variant 0): the eight-wave form, except with relative positions at head size 64 — there the four-wave form already runs two workgroups per CU
+    // (75 KiB of LDS each) on 24 instead of 32 MFMAs per tile and measures 10 % faster (tools/attn_ab.py: 89 vs 100 us at 96 x 500 frames, 20.4 vs 22.5 us at 32 x 250 x 8 heads).
+    if (a.variant == 2 || (a.variant == 0 && !(HD == 64 && rel))) {
+        const int rc = launch_attn8<HD>(a, rel, stream);
+        if (rc != MI_ERR_UNSUPPORTED) return rc;
+    }
     dim3 grid(cdiv(a.T, 128), a.H, a.B), block(256);
     const size_t lds = (size_t)(2 + 2 + 6) * 32 * HD * 2 + 4 * WSCR_B;
     if (rel) hipLaunchKernelGGL((attn_lds_kernel<HD, true, false>), grid, block, lds, stream, a);
@@ -824,12 +1321,8 @@ template <int HD>
 int launch_lds_bw(const AttnArgs& a, bool rel, hipStream_t stream) {
     dim3 grid(cdiv(a.T, 128), a.H, a.B), block(256);
     const size_t lds = (size_t)(2 + 2 + 6) * 32 * HD * 2 + 4 * WSCR_B + 4 * 32 * BAND_B;
-    static const bool attr_set = [&] {          // once per head size (function-local static initialiser: thread-safe)
-        const bool a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_lds_kernel<HD, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-        const bool a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_lds_kernel<HD, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-        return a1 && a2;
-    }();
-    (void)attr_set;
+    if (!ensure_dynamic_lds<1000 + HD * 2 + 1>(reinterpret_cast<const void*>(attn_lds_kernel<HD, true, true>), lds) ||
+        !ensure_dynamic_lds<1000 + HD * 2>(reinterpret_cast<const void*>(attn_lds_kernel<HD, false, true>), lds)) return MI_ERR_LAUNCH;
     if (rel) hipLaunchKernelGGL((attn_lds_kernel<HD, true, true>), grid, block, lds, stream, a);
     else hipLaunchKernelGGL((attn_lds_kernel<HD, false, true>), grid, block, lds, stream, a);
     MI_CHECK_LAUNCH();
@@ -892,6 +1385,40 @@ extern "C" int mi_attention_qkv_bf16(const void* q, long ldq, const void* k, lon
         default: return MI_ERR_UNSUPPORTED;
     }
 }
+
+// A/B form of the entry above: variant 0 = the product's kernel choice, 1 = the four-wave LDS-staged forward of rounds 1-3, 2 = the eight-wave form of round 4
+// (tools/attn_ab.py; no product call site passes a non-zero variant).
+extern "C" int mi_attention_qkv_bf16_v(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                       const void* pos, long ldp, const float* bias_u, const float* bias_v,
+                                       const int* lengths, void* out, long ldo, int B, int T, int Tk, long kv_bstride, int H, int hd,
+                                       float scale, int causal, int variant, hipStream_t stream) {
+    MI_ENTER();
+    if (B <= 0 || T <= 0 || H <= 0 || Tk < 0 || variant < 0 || variant > 2) return MI_ERR_ARG;
+    if (pos && Tk != 0 && Tk != T) return MI_ERR_ARG;
+    if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 8) || ((uintptr_t)out & 15)) return MI_ERR_ARG;
+    if (ldq >= (1l << 30)) return MI_ERR_ARG;
+    if (ldk <= 0 || ldv <= 0 || ldk >= (1l << 30) || ldv >= (1l << 30) || ldp >= (1l << 30)) return MI_ERR_ARG;
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) || (kv_bstride % 8)) return MI_ERR_ARG;
+    if (pos && ((ldp % 8) || ((uintptr_t)pos & 15) || !bias_u || !bias_v)) return MI_ERR_ARG;
+    AttnArgs a{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, 0, (const bf16_t*)pos, ldp,
+               bias_u, bias_v, lengths, (bf16_t*)out, ldo, B, T, H, scale, causal, Tk, kv_bstride};
+    a.variant = variant;
+    switch (hd) {
+        case 64: return launch_lds<64>(a, pos != nullptr, stream);
+        case 128: return launch_lds<128>(a, pos != nullptr, stream);
+        default: return MI_ERR_UNSUPPORTED;
+    }
+}
+
+#ifdef ATTN_STAMPS
+extern "C" int mi_attention_qkv_stamps(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* pos, long ldp, const float* bias_u, const float* bias_v,
+                                       const int* lengths, void* out, long ldo, int B, int T, int H, int hd, float scale, int causal, unsigned long long* stamps, hipStream_t stream) {
+    AttnArgs a{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, 0, (const bf16_t*)pos, ldp,
+               bias_u, bias_v, lengths, (bf16_t*)out, ldo, B, T, H, scale, causal, 0, 0};
+    a.stamps = stamps;
+    return hd == 64 ? launch_lds<64>(a, pos != nullptr, stream) : launch_lds<128>(a, pos != nullptr, stream);
+}
+#endif
 
 // The same kernel, also leaving the rows' log-sum-exp (log2 domain, of the scaled scores) in lse (B, H, T) fp32 for mi_attention_qkv_bwd_probs.
 extern "C" int mi_attention_qkv_lse_bf16(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,

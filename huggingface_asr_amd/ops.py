@@ -221,7 +221,7 @@ def attention(q, k, vt, Tp, B, T, H, *, pos=None, bias_u=None, bias_v=None, leng
     return out
 
 
-def attention_qkv(qkv, B, T, H, *, pos=None, bias_u=None, bias_v=None, lengths=None, causal=False, lse=None, drop=None):
+def attention_qkv(qkv, B, T, H, *, pos=None, bias_u=None, bias_v=None, lengths=None, causal=False, lse=None, drop=None, variant=0):
     """LDS-staged attention on a fused (B*T, 3d) bf16 projection [Q|K|V]; head size 64 or 128.
     lse: (B, H, T) fp32 that receives the rows' log-sum-exp (training forward; the backward's `ops_train.attn_bwd_probs` reads it).
     drop = (p, seed, stream_id): attention-probability dropout (with lse only)."""
@@ -236,6 +236,12 @@ def attention_qkv(qkv, B, T, H, *, pos=None, bias_u=None, bias_v=None, lengths=N
                                                   out.data_ptr(), out.stride(0), lse.data_ptr(), B, T, H, hd, 1.0 / math.sqrt(hd), int(causal),
                                                   float(dp), int(dseed) & 0xFFFFFFFF, int(dsid) & 0xFFFFFFFF, _stream())
         _lib.check(rc, "mi_attention_qkv_lse_bf16")
+        return out
+    if variant:      # measurement only (tools/attn_ab.py): the four-wave kernel of rounds 1-3
+        rc = _lib.lib().mi_attention_qkv_bf16_v(q.data_ptr(), qkv.stride(0), k.data_ptr(), qkv.stride(0), v.data_ptr(), qkv.stride(0),
+                                                _p(pos), pos.stride(0) if pos is not None else 0, _p(bias_u), _p(bias_v), _p(lengths),
+                                                out.data_ptr(), out.stride(0), B, T, 0, 0, H, hd, 1.0 / math.sqrt(hd), int(causal), int(variant), _stream())
+        _lib.check(rc, "mi_attention_qkv_bf16_v")
         return out
     rc = _lib.lib().mi_attention_qkv_bf16(q.data_ptr(), qkv.stride(0), k.data_ptr(), qkv.stride(0), v.data_ptr(), qkv.stride(0),
                                           _p(pos), pos.stride(0) if pos is not None else 0, _p(bias_u), _p(bias_v), _p(lengths),

@@ -146,6 +146,13 @@ int mi_attention_qkv_bf16(const void* q, long ldq, const void* k, long ldk, cons
                           const void* pos, long ldp, const float* bias_u, const float* bias_v,
                           const int* lengths, void* out, long ldo, int B, int T, int Tk, long kv_bstride, int H, int hd,
                           float scale, int causal, mi_stream_t stream);
+/* A/B form of mi_attention_qkv_bf16: variant 0 = the library's choice (the eight-wave kernel: two waves per SIMD, the wave pair of a query group splits the keys),
+ * except with relative positions at head size 64), 1 = the four-wave kernel of rounds 1-3, 2 = the eight-wave kernel.  Measurement only (tools/attn_ab.py); no product call
+ * site passes a non-zero variant. */
+int mi_attention_qkv_bf16_v(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                            const void* pos, long ldp, const float* bias_u, const float* bias_v,
+                            const int* lengths, void* out, long ldo, int B, int T, int Tk, long kv_bstride, int H, int hd,
+                            float scale, int causal, int variant, mi_stream_t stream);
 /* (kv_bstride = elements between batches of k/v, 0 = Tk*ld (KV caches are (B, Lmax, d)); T = queries per batch, Tk = keys per batch, 0 = T: cross-attention over encoder frames and KV-cache decoding use Tk != T;
  *  with causal != 0 query i sees keys <= i + (Tk - T).) */
 
