@@ -48,7 +48,7 @@ SIGNATURES = {
     "mi_im2col_cl_geo_bf16": [vp, vp] + [i32] * 12 + [vp],
     "mi_col2im_cl_bf16": [vp, vp] + [i32] * 13 + [vp],
     "mi_gated_act_bwd_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp],
-    "mi_conv2d_first_wgrad": [vp, vp, vp, vp] + [i32] * 12 + [vp],
+    "mi_conv2d_first_wgrad": [vp, vp, vp, vp] + [i32] * 12 + [vp, vp],
     "mi_gemm_lnfold_bf16": [vp, i64, vp, i64, vp, vp, vp, i32, f32, vp, i64, i32, i32, i32, i32, vp],
     "mi_gemm_resid_stats_f32": [vp, i64, vp, i64, vp, vp, i64, vp, i64, f32, vp, i64, vp, i32, i32, i32, vp],
     "mi_layernorm_fold": [vp, i64, vp, i32, vp, vp, f32, vp, i64, vp, i64, vp, i32, i32, vp],
@@ -74,13 +74,13 @@ SIGNATURES = {
     "mi_ctc_prefix_score": [vp, i32, i32, i32, i32, i32, vp, vp, i64, i32, vp, vp, vp, vp],
     "mi_ctc_prefix_select": [vp, i32, i32, i32, i32, i32, vp, vp, i64, i32, vp, vp, i64, i32, vp, vp],
     "mi_embed_tokens": [vp, vp, f32, vp, i32, i32, i32, i32, i32, vp, vp],
-    "mi_ce_label_smoothing": [vp, i64, vp, i32, i32, i32, i32, f32, vp, vp],
+    "mi_ce_label_smoothing": [vp, i64, vp, i32, i32, i32, i32, f32, vp, vp, vp],
     "mi_whisper_logmel": [vp, i64, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp],
     "mi_transpose_cast_bct_btc": [vp, vp, i32, i32, i32, vp],
     "mi_add_positions": [vp, vp, vp, i32, i32, i32, vp],
     "mi_transpose_bf16": [vp, i64, vp, i64, i32, i32, i32, vp],
     "mi_transpose_many_bf16": [vp, i32, vp],
-    "mi_colsum": [vp, i64, i32, i32, i32, vp, vp],
+    "mi_colsum": [vp, i64, i32, i32, i32, vp, vp, vp],
     "mi_act_fwd_bf16": [vp, i64, vp, i64, i32, i32, i32, vp],
     "mi_act_bwd_bf16": [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp],
     "mi_act_dropout_fwd_bf16": [vp, i64, vp, i64, i32, i32, i32, f32, C.c_uint, C.c_uint, vp],
@@ -102,7 +102,7 @@ SIGNATURES = {
     "mi_gate_bwd_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, vp],
     "mi_mask_rows_f32": [vp, i64, vp, i32, i32, i32, vp],
     "mi_spec_mask_apply": [vp, i64, vp, vp, vp, i32, i32, i32, vp],
-    "mi_spec_mask_bwd": [vp, i64, vp, vp, vp, i32, i32, i32, vp],
+    "mi_spec_mask_bwd": [vp, i64, vp, vp, vp, i32, i32, i32, vp, vp],
     "mi_softmax_vec_f32": [vp, i32, vp, vp],
     "mi_softmax_vec_bwd_f32": [vp, vp, i32, vp, vp],
     "mi_axpy_dev_f32": [vp, vp, i64, vp, i32, vp],
@@ -111,6 +111,9 @@ SIGNATURES = {
     "mi_clip_coef": [vp, f32, f32, vp, vp],
     "mi_adamw_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, vp, vp],
     "mi_gemm_tn_workspace_bytes": [i32, i32, i32],
+    "mi_colsum_workspace_floats": [i32, i32],
+    "mi_conv2d_first_bwd_workspace_floats": [i32, i32, i32, i32],
+    "mi_conv2d_first_wgrad_workspace_floats": [i32, i32, i32, i32, i32, i32],
     "mi_gemm_tn_bf16": [vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, i32, vp, sz, i32, vp],
     "mi_gemm_dropout_bf16": [vp, i64, vp, i64, vp, vp, i64, i32, vp, i64, f32, f32, C.c_uint, C.c_uint, i32, i32, i32, vp],
     "mi_gemm_act_fwd_bf16": [vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, f32, C.c_uint, C.c_uint, i32, i32, i32, vp],
@@ -129,11 +132,11 @@ SIGNATURES = {
     "mi_csgu_bwd_bf16": [vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
     "mi_dwconv_residual_bwd_bf16": [vp, i64, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
     "mi_im2col_cl_bf16": [vp, vp] + [i32] * 11 + [vp],
-    "mi_conv2d_first_bwd": [vp, vp, vp, vp, vp, vp] + [i32] * 16 + [vp],
+    "mi_conv2d_first_bwd": [vp, vp, vp, vp, vp, vp] + [i32] * 16 + [vp, vp],
     "mi_ctc_bwd_workspace_bytes": [i32, i32, i32],
     "mi_ctc_loss_bwd": [vp, i64, i64, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, f32, vp, sz, vp, i64, vp],
     "mi_ce_label_smoothing_bwd": [vp, i64, vp, i32, i32, i32, i32, f32, f32, vp, vp, i64, vp],
-    "mi_embed_tokens_bwd": [vp, vp, f32, i32, i32, i32, i32, i32, vp, vp, vp],
+    "mi_embed_tokens_bwd": [vp, vp, f32, i32, i32, i32, i32, i32, vp, vp, vp, vp],
     "mi_specaug_f32": [vp, vp, i32, i32, i32, vp, i32, i32, f32, vp],
     "mi_speed_resample_f32": [vp, i64, vp, i32, i32, i32, i32, vp, i32, vp, i64, i32, vp, vp],
     "mi_rpq_targets": [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp],
@@ -173,6 +176,7 @@ def lib():
             fn = getattr(h, name)          # AttributeError here = header/library mismatch: fail loudly
             fn.argtypes = args
             fn.restype = sz if name in ("mi_ebf_workspace_bytes", "mi_ctc_bwd_workspace_bytes", "mi_gemm_tn_workspace_bytes", "mi_layernorm_bwd_workspace_floats",
+                                          "mi_colsum_workspace_floats", "mi_conv2d_first_bwd_workspace_floats", "mi_conv2d_first_wgrad_workspace_floats",
                                           "mi_gpt2_step_workspace_bytes") else i32
         h.mi_profile_create.argtypes = [i32]; h.mi_profile_create.restype = i32
         h.mi_profile_enable.argtypes = [i32]; h.mi_profile_enable.restype = None

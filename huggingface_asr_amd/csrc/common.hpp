@@ -132,6 +132,41 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Fixed-order reduction of `rows` partial rows of n floats (the second stage of every parameter-gradient reduction of the training step: no float atomics anywhere, so the
+// backward is bit-reproducible run to run): a block owns 16 columns over ALL rows — thread (column, row group g) adds rows g, g + 16, ... with eight loads in flight, the 16
+// groups are combined in order through LDS — and hands (column, total) to `emit`.  A few dozen to a few thousand rows: all launch and memory latency, no bandwidth.
+struct EmitAdd { float* out; __device__ void operator()(int i, float v) const { out[i] += v; } };
+template <typename Emit>
+__global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ partial, int rows, int n, Emit emit) {
+    __shared__ float red[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + tx;
+    float s = 0.f;
+    if (i < n) {
+        const float* src = partial + i;
+        int r = ty;
+        for (; r + 7 * 16 < rows; r += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(long)(r + 16 * u) * n];
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; r < rows; r += 16) s += src[(long)r * n];
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][tx];
+        emit(i, t);
+    }
+}
+template <typename Emit>
+static inline void rows_reduce_launch(const float* partial, int rows, int n, Emit emit, hipStream_t st) {
+    hipLaunchKernelGGL(rows_reduce_kernel<Emit>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, partial, rows, n, emit);
+}
+
 // Counter-based uniform draws of the dropout masks (dropout.hip, attn_bwd.hip; host twin: huggingface_asr_amd/synth.py `dropout_keep`):
 // one splitmix64 round over (pair index ^ key) yields TWO 24-bit draws — element idx takes bits 63..40 when even, bits 39..16 when odd —
 // so a mask costs one 64-bit hash per two elements (the hash, quarter-rate integer multiplies, is what bounds the mask kernels).

@@ -7,9 +7,6 @@
 
 namespace {
 
-__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // ------------------------------------------------------------------------------------------------ depthwise conv backward
 constexpr int DB_TT = 64, DB_CT = 64, DB_KMAX = 31;
@@ -28,7 +25,7 @@ struct DwBwdArgs {
 
 // block = (64 channels, utterance b); walks the time tiles, keeps the K tap gradients of its channel in registers
 template <bool CSGU>
-__global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwBwdArgs p) {
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwBwdArgs p, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int halo = p.K - 1;
     const int rows = DB_TT + halo;
@@ -110,8 +107,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwBwdArgs p) {
         const int kk = (k == p.K) ? DB_KMAX : k;
         float s = 0.f;
         for (int q = 0; q < 4; ++q) s += red[(size_t)q * (DB_KMAX + 1) * DB_CT + kk * DB_CT + cc];
-        if (k == p.K) { if (p.db) atomic_add_f32(p.db + c0 + cc, s); }
-        else atomic_add_f32(p.dw + (long)(c0 + cc) * p.K + k, s);
+        partial[((long)b * p.C + c0 + cc) * 32 + kk] = s;                  // this utterance's partial (slot 31 = the bias); dw_partial_reduce_kernel adds the utterances in order
     }
 }
 
@@ -120,7 +116,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwBwdArgs p) {
 // pad of 450; also any causal / dilated merge conv).  A streaming model's training path, not a hot one: no LDS tiling (the halo would be 450 rows), every tap is read
 // from L2.  block = 64 channels x 64 time steps of utterance b; thread = (channel, 16 consecutive steps); tap gradients in registers, reduced like the kernel above.
 template <bool CSGU>
-__global__ __launch_bounds__(256) void dwconv_bwd_dilated_kernel(DwBwdArgs p) {
+__global__ __launch_bounds__(256) void dwconv_bwd_dilated_kernel(DwBwdArgs p, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);          // [4][K+1][64]
     const int c0 = blockIdx.x * DB_CT, t0 = blockIdx.y * DB_TT, b = blockIdx.z;
@@ -180,8 +176,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_dilated_kernel(DwBwdArgs p) {
         const int kk = (k == p.K) ? DB_KMAX : k;
         float s2 = 0.f;
         for (int q = 0; q < 4; ++q) s2 += red[(size_t)q * (DB_KMAX + 1) * DB_CT + kk * DB_CT + cc];
-        if (k == p.K) { if (p.db) atomic_add_f32(p.db + c0 + cc, s2); }
-        else atomic_add_f32(p.dw + (long)(c0 + cc) * p.K + k, s2);
+        partial[(((long)b * gridDim.y + blockIdx.y) * p.C + c0 + cc) * 32 + kk] = s2;     // one partial per (utterance, time tile)
     }
 }
 
@@ -329,14 +324,15 @@ __global__ __launch_bounds__(256) void dwconv31_bwd_kernel(DwBwdArgs p, float* _
     }
 }
 
-// dw[c][k] += sum_b partial[b][c][k] (k < 31),  db[c] += sum_b partial[b][c][31]
-__global__ __launch_bounds__(256) void dw_partial_reduce_kernel(const float* __restrict__ partial, int B, int C, float* __restrict__ dw, float* __restrict__ db) {
+// dw[c][k] += sum_b partial[b][c][k] (k < K <= 31),  db[c] += sum_b partial[b][c][31]; the B partials (utterances, or (utterance, time tile) pairs) are added in order
+__global__ __launch_bounds__(256) void dw_partial_reduce_kernel(const float* __restrict__ partial, int B, int C, int K, float* __restrict__ dw, float* __restrict__ db) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= C * 32) return;
     const int c = i >> 5, k = i & 31;
+    if (k >= K && k != 31) return;
     float s = 0.f;
     for (int b = 0; b < B; ++b) s += partial[((long)b * C + c) * 32 + k];
-    if (k < 31) dw[(long)c * 31 + k] += s;
+    if (k < K) dw[(long)c * K + k] += s;
     else if (db) db[c] += s;
 }
 
@@ -363,6 +359,24 @@ __global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ 
     }
 }
 
+// Fixed-order sum over the threads of a block that share a channel group: thread (g, pl) of cg x ppb contributes NV values; emit(g, v, sum over pl ascending).  Through an
+// LDS staging area of 256 x NV floats (in place of LDS float atomics, whose order is not reproducible).  Every thread of the block calls it.
+template <int NV, typename Emit>
+__device__ __forceinline__ void group_sum_ordered(float* stage, const float (&vals)[NV], int g, int pl, int cg, int ppb, Emit emit) {
+    __syncthreads();
+    if (pl < ppb) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) stage[((long)pl * cg + g) * NV + v] = vals[v];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cg * NV; i += 256) {
+        float sum = 0.f;
+        for (int q = 0; q < ppb; ++q) sum += stage[(long)q * cg * NV + i];
+        emit(i / NV, i % NV, sum);
+    }
+}
+struct EmitConv1 { float* dw; float* db; int NT; __device__ void operator()(int i, float v) const { const int ch = i / (NT + 1), k = i % (NT + 1); if (k == NT) db[ch] += v; else dw[ch * NT + k] += v; } };
+
 // ------------------------------------------------------------------------------------------------ conv1 backward (3x3)
 // Fused: dact1[b,t1,f1,c] = sum over the conv2 taps that read this position of dcol[(b,t2,f2), (kh,kw,c)]   (col2im gather)
 //        dpre1 = dact1 * gelu'(pre1), pre1 recomputed from the features;  dW1[c][tap] += dpre1 * x[tap];  db1[c] += dpre1.
@@ -371,16 +385,14 @@ __global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ 
 // divisions by the stride, 32-bit position arithmetic.
 template <bool FIX32>
 __global__ __launch_bounds__(256) void conv1_bwd3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                          const bf16_t* __restrict__ dcol, float* __restrict__ dw, float* __restrict__ db,
+                                                          const bf16_t* __restrict__ dcol, float* __restrict__ partial,
                                                           int B, int T, int F, int C, int stride, int pad_t, int pad_f, int T1, int F1,
                                                           int K2r, int stride2r, int pad2_t, int pad2_f, int T2, int F2) {
     const int K2 = FIX32 ? 3 : K2r, stride2 = FIX32 ? 2 : stride2r;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sacc = reinterpret_cast<float*>(smem);        // [C][10]
+    float* stage = reinterpret_cast<float*>(smem);       // [256][40]: the block's ordered reduction (below)
     const int cg = C >> 3, ppb = 256 / cg;
     const int g = threadIdx.x % cg, pl = threadIdx.x / cg;
-    for (int i = threadIdx.x; i < C * 10; i += 256) sacc[i] = 0.f;
-    __syncthreads();
     float wr[9][8], br[8], gwr[9][8], gbr[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -518,30 +530,32 @@ __global__ __launch_bounds__(256) void conv1_bwd3_kernel(const float* __restrict
             for (int tap = 0; tap < 9; ++tap) gwr[tap][j] = fmaf(dpre, xv[tap], gwr[tap][j]);
         }
     }
+    // the block's sums over its ppb position lanes, in lane order, as row blockIdx.x of `partial` ([channel][9 taps | bias]); a second kernel adds the rows in order
+    float* prow = partial + (long)blockIdx.x * C * 10;
+    float va[40], vb[40];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int ch = g * 8 + j;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) atomicAdd(sacc + ch * 10 + tap, gwr[tap][j]);
-        atomicAdd(sacc + ch * 10 + 9, gbr[j]);
+        for (int tap = 0; tap < 5; ++tap) va[tap * 8 + j] = gwr[tap][j];
+#pragma unroll
+        for (int tap = 5; tap < 9; ++tap) vb[(tap - 5) * 8 + j] = gwr[tap][j];
+        vb[32 + j] = gbr[j];
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < C * 10; i += 256) {
-        const int ch = i / 10, tap = i % 10;
-        if (tap == 9) atomic_add_f32(db + ch, sacc[i]);
-        else atomic_add_f32(dw + ch * 9 + tap, sacc[i]);
-    }
+    group_sum_ordered<40>(stage, va, g, pl, cg, ppb, [&](int gg, int v, float sum) { prow[(gg * 8 + (v & 7)) * 10 + (v >> 3)] = sum; });
+    group_sum_ordered<40>(stage, vb, g, pl, cg, ppb, [&](int gg, int v, float sum) { prow[(gg * 8 + (v & 7)) * 10 + 5 + (v >> 3)] = sum; });
 }
 
 int grid_for(long n, int cap) { const long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > cap ? cap : g)); }
 
 int dw_bwd_launch(const DwBwdArgs& a, bool csgu, float* workspace, hipStream_t st) {
-    if (a.B <= 0 || a.T <= 0 || a.C <= 0 || a.K <= 0 || a.K > DB_KMAX || a.dilation < 1 || a.pad_left < 0 || a.pad_left > (a.K - 1) * a.dilation) return MI_ERR_ARG;
+    if (a.B <= 0 || a.T <= 0 || a.C <= 0 || a.K <= 0 || a.K > DB_KMAX || a.dilation < 1 || a.pad_left < 0 || a.pad_left > (a.K - 1) * a.dilation || !workspace) return MI_ERR_ARG;
     if (a.dilation > 1) {                                   // the causal (dilated) CSGU / merge conv
         const size_t ldsd = (size_t)4 * (DB_KMAX + 1) * DB_CT * sizeof(float);
         dim3 gridd(cdiv(a.C, DB_CT), cdiv(a.T, DB_TT), a.B);
-        if (csgu) hipLaunchKernelGGL(dwconv_bwd_dilated_kernel<true>, gridd, dim3(256), ldsd, st, a);
-        else hipLaunchKernelGGL(dwconv_bwd_dilated_kernel<false>, gridd, dim3(256), ldsd, st, a);
+        if (csgu) hipLaunchKernelGGL(dwconv_bwd_dilated_kernel<true>, gridd, dim3(256), ldsd, st, a, workspace);
+        else hipLaunchKernelGGL(dwconv_bwd_dilated_kernel<false>, gridd, dim3(256), ldsd, st, a, workspace);
+        MI_CHECK_LAUNCH();
+        hipLaunchKernelGGL(dw_partial_reduce_kernel, dim3(cdiv((long)a.C * 32, 256)), dim3(256), 0, st, workspace, a.B * (int)gridd.y, a.C, a.K, a.dw, a.db);
         MI_CHECK_LAUNCH();
         return MI_OK;
     }
@@ -554,22 +568,25 @@ int dw_bwd_launch(const DwBwdArgs& a, bool csgu, float* workspace, hipStream_t s
         if (csgu) hipLaunchKernelGGL(dwconv31_bwd_kernel<true>, gridf, dim3(256), ldsf, st, a, workspace);
         else hipLaunchKernelGGL(dwconv31_bwd_kernel<false>, gridf, dim3(256), ldsf, st, a, workspace);
         MI_CHECK_LAUNCH();
-        hipLaunchKernelGGL(dw_partial_reduce_kernel, dim3(cdiv((long)a.C * 32, 256)), dim3(256), 0, st, workspace, a.B, a.C, a.dw, a.db);
+        hipLaunchKernelGGL(dw_partial_reduce_kernel, dim3(cdiv((long)a.C * 32, 256)), dim3(256), 0, st, workspace, a.B, a.C, a.K, a.dw, a.db);
         MI_CHECK_LAUNCH();
         return MI_OK;
     }
     const int rows = DB_TT + a.K - 1;
     const size_t lds = (size_t)(2 * rows * DB_CT + DB_KMAX * DB_CT + 4 * (DB_KMAX + 1) * DB_CT) * sizeof(float);
     dim3 grid(cdiv(a.C, DB_CT), a.B);
-    if (csgu) hipLaunchKernelGGL(dwconv_bwd_kernel<true>, grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(dwconv_bwd_kernel<false>, grid, dim3(256), lds, st, a);
+    if (csgu) hipLaunchKernelGGL(dwconv_bwd_kernel<true>, grid, dim3(256), lds, st, a, workspace);
+    else hipLaunchKernelGGL(dwconv_bwd_kernel<false>, grid, dim3(256), lds, st, a, workspace);
+    MI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dw_partial_reduce_kernel, dim3(cdiv((long)a.C * 32, 256)), dim3(256), 0, st, workspace, a.B, a.C, a.K, a.dw, a.db);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
 
 }  // namespace
 
-// `workspace`: B*C*32 floats (per-utterance tap-gradient partials of the K = 31 fast path) or NULL (generic kernel, atomics).
+// `workspace`: B*C*32 floats (per-utterance tap-gradient partials), B*ceil(T/64)*C*32 for the dilated form (a partial per time tile); the partials are added in a fixed
+// order by a second kernel: no float atomics, the gradients are bit-reproducible.
 // CSGU backward (identity activation; dilation > 1 = the causal form): u (B*T, 2C) = [x_r | x_g], ds = gradient of x_r * (dwconv(LN(x_g)) + b)
 //   -> dr (B*T, C) = ds * conv,  dgn (B*T, C) = gradient w.r.t. LN(x_g),  dw (C,K) +=, db (C) +=
 // dr == NULL: the split-gate form (mi_csgu_conv_bf16 forward) — `ds` is the gradient of the conv output itself, no gate operand is applied or produced.
@@ -739,15 +756,14 @@ __global__ __launch_bounds__(256) void gated_act_bwd_kernel(const bf16_t* __rest
 }
 
 // weight / bias gradient of a Conv2d(1 -> C) of general geometry from the gradient of its raw output: dw[c][tap] += sum_pos dy[pos][c] * x[window(pos)][tap], db[c] += sum_pos dy[pos][c].
-// A thread owns two channels and all NT taps (2 NT + 2 accumulators) and walks output positions; per-block LDS reduction, one global atomic per (channel, tap) and block.
+// A thread owns two channels and all NT taps (2 NT + 2 accumulators) and walks output positions; the block's sums (position lanes added in order) are row blockIdx.x of
+// `partial` ([channel][NT taps | bias]), added over the blocks in order by rows_reduce_kernel: no atomics.
 template <int KH, int KW>
-__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db,
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ partial,
                                                            int B, int T, int F, int C, int st_t, int st_f, int pad_t, int pad_f, int T1, int F1) {
     constexpr int NT = KH * KW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sacc = reinterpret_cast<float*>(smem);        // [C][NT + 1]
-    for (int i = threadIdx.x; i < C * (NT + 1); i += 256) sacc[i] = 0.f;
-    __syncthreads();
+    float* stage = reinterpret_cast<float*>(smem);       // [256][NT + 1]
     const int cp = C >> 1, ppb = 256 / cp;
     const int g = threadIdx.x % cp, pl = threadIdx.x / cp;
     float a0[NT], a1[NT], s0 = 0.f, s1 = 0.f;
@@ -775,17 +791,13 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
             }
         }
     }
-    if (pl < ppb) {
+    float* prow = partial + (long)blockIdx.x * C * (NT + 1);
+    float va[NT + 1], vb[NT + 1];
 #pragma unroll
-        for (int k = 0; k < NT; ++k) { atomicAdd(sacc + (g * 2) * (NT + 1) + k, a0[k]); atomicAdd(sacc + (g * 2 + 1) * (NT + 1) + k, a1[k]); }
-        atomicAdd(sacc + (g * 2) * (NT + 1) + NT, s0); atomicAdd(sacc + (g * 2 + 1) * (NT + 1) + NT, s1);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < C * (NT + 1); i += 256) {
-        const int ch = i / (NT + 1), k = i % (NT + 1);
-        if (k == NT) atomic_add_f32(db + ch, sacc[i]);
-        else atomic_add_f32(dw + ch * NT + k, sacc[i]);
-    }
+    for (int k = 0; k < NT; ++k) { va[k] = a0[k]; vb[k] = a1[k]; }
+    va[NT] = s0; vb[NT] = s1;
+    group_sum_ordered<NT + 1>(stage, va, g, pl, cp, ppb, [&](int gg, int v, float sum) { prow[(gg * 2) * (NT + 1) + v] = sum; });
+    group_sum_ordered<NT + 1>(stage, vb, g, pl, cp, ppb, [&](int gg, int v, float sum) { prow[(gg * 2 + 1) * (NT + 1) + v] = sum; });
 }
 }  // namespace
 
@@ -816,42 +828,66 @@ extern "C" int mi_gated_act_bwd_bf16(const void* dout, long lddo, const void* z,
 }
 
 // x (B,T,F) f32, dy (B,T1,F1,C) bf16 = gradient of the RAW output of a Conv2d(1 -> C, (KH,KW), strides, pads) -> dw (C, KH*KW) +=, db (C) +=.  (KH,KW) = (3,3) or (12,3).
+// workspace: mi_conv2d_first_wgrad_workspace_floats(...) floats (one partial row per block; the rows are added in a fixed order)
+static unsigned conv1_wgrad_grid(int B, int C, int T1, int F1) {
+    const int cp = C / 2, ppb = 256 / (cp > 0 ? cp : 1);
+    const long npos = (long)B * T1 * F1;
+    const long nb = (npos + (ppb > 0 ? ppb : 1) - 1) / (ppb > 0 ? ppb : 1);
+    return (unsigned)(nb < 1024 ? nb : 1024);
+}
+extern "C" size_t mi_conv2d_first_wgrad_workspace_floats(int B, int C, int KH, int KW, int T1, int F1) {
+    if (B <= 0 || C <= 0 || T1 <= 0 || F1 <= 0) return 0;
+    return (size_t)conv1_wgrad_grid(B, C, T1, F1) * (size_t)C * (size_t)(KH * KW + 1);
+}
 extern "C" int mi_conv2d_first_wgrad(const float* x, const void* dy, float* dw, float* db, int B, int T, int F, int C, int KH, int KW, int stride_t, int stride_f,
-                                     int pad_t, int pad_f, int T1, int F1, hipStream_t st) {
+                                     int pad_t, int pad_f, int T1, int F1, float* workspace, hipStream_t st) {
     MI_ENTER();
-    if (B <= 0 || C <= 0 || (C % 2) != 0 || C > 512 || T1 <= 0 || F1 <= 0 || stride_t <= 0 || stride_f <= 0) return MI_ERR_ARG;
+    if (B <= 0 || C <= 0 || (C % 2) != 0 || C > 512 || T1 <= 0 || F1 <= 0 || stride_t <= 0 || stride_f <= 0 || !workspace) return MI_ERR_ARG;
     const int cp = C / 2, ppb = 256 / cp;
     if (ppb < 1) return MI_ERR_UNSUPPORTED;
-    const long npos = (long)B * T1 * F1;
-    const long nb = (npos + ppb - 1) / ppb;
-    const unsigned grid = (unsigned)(nb < 1024 ? nb : 1024);
-    const size_t lds = (size_t)C * (KH * KW + 1) * sizeof(float);
+    const unsigned grid = conv1_wgrad_grid(B, C, T1, F1);
+    const size_t lds = (size_t)256 * (KH * KW + 1) * sizeof(float);
     if (KH == 3 && KW == 3)
-        hipLaunchKernelGGL((conv1_wgrad_kernel<3, 3>), dim3(grid), dim3(256), lds, st, x, (const bf16_t*)dy, dw, db, B, T, F, C, stride_t, stride_f, pad_t, pad_f, T1, F1);
+        hipLaunchKernelGGL((conv1_wgrad_kernel<3, 3>), dim3(grid), dim3(256), lds, st, x, (const bf16_t*)dy, workspace, B, T, F, C, stride_t, stride_f, pad_t, pad_f, T1, F1);
     else if (KH == 12 && KW == 3)
-        hipLaunchKernelGGL((conv1_wgrad_kernel<12, 3>), dim3(grid), dim3(256), lds, st, x, (const bf16_t*)dy, dw, db, B, T, F, C, stride_t, stride_f, pad_t, pad_f, T1, F1);
+        hipLaunchKernelGGL((conv1_wgrad_kernel<12, 3>), dim3(grid), dim3(256), lds, st, x, (const bf16_t*)dy, workspace, B, T, F, C, stride_t, stride_f, pad_t, pad_f, T1, F1);
     else return MI_ERR_UNSUPPORTED;
+    MI_CHECK_LAUNCH();
+    rows_reduce_launch(workspace, (int)grid, C * (KH * KW + 1), EmitConv1{dw, db, KH * KW}, st);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
 
 // x (B,T,F) f32, w (C,9), bias (C); dcol (B*T2*F2, K2*K2*C) bf16 = gradient of conv2's im2col operand -> dw (C,9) +=, db (C) +=
+// workspace: mi_conv2d_first_bwd_workspace_floats(B, C, T1, F1) floats (one partial row of 10 C floats per block; the rows are added in a fixed order)
+static unsigned conv1_bwd_grid(int B, int C, int T1, int F1) {
+    const int cgs = C / 8, ppb = 256 / (cgs > 0 ? cgs : 1);
+    const long npos = (long)B * T1 * F1;
+    const long nb = (npos + (ppb > 0 ? ppb : 1) - 1) / (ppb > 0 ? ppb : 1);
+    return (unsigned)(nb < 2048 ? nb : 2048);
+}
+extern "C" size_t mi_conv2d_first_bwd_workspace_floats(int B, int C, int T1, int F1) {
+    if (B <= 0 || C <= 0 || T1 <= 0 || F1 <= 0) return 0;
+    return (size_t)conv1_bwd_grid(B, C, T1, F1) * (size_t)C * 10;
+}
 extern "C" int mi_conv2d_first_bwd(const float* x, const float* w, const float* bias, const void* dcol, float* dw, float* db,
                                    int B, int T, int F, int C, int K, int stride, int pad_t, int pad_f, int T1, int F1,
-                                   int K2, int stride2, int pad2_t, int pad2_f, int T2, int F2, hipStream_t st) {
+                                   int K2, int stride2, int pad2_t, int pad2_f, int T2, int F2, float* workspace, hipStream_t st) {
     MI_ENTER();
     const int cgs = C / 8;
     if (B <= 0 || K != 3 || (C % 8) != 0 || cgs > 256 || stride2 <= 0) return MI_ERR_UNSUPPORTED;
+    if (!workspace) return MI_ERR_ARG;
     const long npos = (long)B * T1 * F1;
-    const int ppb = 256 / cgs;
-    const long nb = (npos + ppb - 1) / ppb;
-    const size_t lds = (size_t)C * 10 * sizeof(float);
+    const unsigned grid = conv1_bwd_grid(B, C, T1, F1);
+    const size_t lds = (size_t)256 * 40 * sizeof(float);
     if (K2 == 3 && stride2 == 2 && npos < (1L << 31))
-        hipLaunchKernelGGL(conv1_bwd3_kernel<true>, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), lds, st, x, w, bias, (const bf16_t*)dcol, dw, db,
+        hipLaunchKernelGGL(conv1_bwd3_kernel<true>, dim3(grid), dim3(256), lds, st, x, w, bias, (const bf16_t*)dcol, workspace,
                            B, T, F, C, stride, pad_t, pad_f, T1, F1, K2, stride2, pad2_t, pad2_f, T2, F2);
     else
-        hipLaunchKernelGGL(conv1_bwd3_kernel<false>, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), lds, st, x, w, bias, (const bf16_t*)dcol, dw, db,
+        hipLaunchKernelGGL(conv1_bwd3_kernel<false>, dim3(grid), dim3(256), lds, st, x, w, bias, (const bf16_t*)dcol, workspace,
                            B, T, F, C, stride, pad_t, pad_f, T1, F1, K2, stride2, pad2_t, pad2_f, T2, F2);
+    MI_CHECK_LAUNCH();
+    rows_reduce_launch(workspace, (int)grid, C * 10, EmitConv1{dw, db, 9}, st);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

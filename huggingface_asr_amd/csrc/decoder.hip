@@ -25,14 +25,14 @@ __global__ __launch_bounds__(256) void embed_kernel(const long* __restrict__ ids
 // one wave per (b, u) row, u < U - shift: loss_row = (1-eps) * (lse - z[target]) + eps * (lse - mean(z)), target = labels[b, u+shift]
 // (torch CrossEntropyLoss(label_smoothing=eps), ignore_index = -100); accumulates sum and valid count.
 __global__ __launch_bounds__(256) void ce_smooth_kernel(const float* __restrict__ logits, long ld, const long* __restrict__ labels,
-                                                         int B, int U, int shift, int V, float eps, float* __restrict__ acc) {
+                                                         int B, int U, int shift, int V, float eps, float* __restrict__ row_loss) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int rows_per_b = U - shift;
     if (row >= B * rows_per_b) return;
     const int b = row / rows_per_b, u = row - b * rows_per_b;
     const long tgt = labels[(long)b * U + u + shift];
-    if (tgt < 0) return;                                    // wave-uniform
+    if (tgt < 0) { if (lane == 0) row_loss[row] = __builtin_nanf(""); return; }       // wave-uniform; NaN marks an ignored row
     const float* z = logits + ((long)b * U + u) * ld;
     float mx = -INFINITY, sm = 0.f;
     for (int c = lane; c < V; c += 64) { const float v = z[c]; mx = fmaxf(mx, v); sm += v; }
@@ -44,9 +44,19 @@ __global__ __launch_bounds__(256) void ce_smooth_kernel(const float* __restrict_
     if (lane == 0) {
         const float lse = mx + logf(se);
         const float loss = (1.f - eps) * (lse - z[tgt]) + eps * (lse - sm / V);
-        atomicAdd(acc, loss);
-        atomicAdd(acc + 1, 1.f);
+        row_loss[row] = loss;
     }
+}
+// acc = [sum of the valid rows' losses, their count]: one block, rows strided over the threads, wave sums by DPP, the four waves in order (no float atomics: the loss and
+// everything derived from it are bit-reproducible)
+__global__ __launch_bounds__(256) void ce_sum_kernel(const float* __restrict__ row_loss, int n, float* __restrict__ acc) {
+    __shared__ float red[8];
+    float s = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { const float v = row_loss[i]; if (v == v) { s += v; c += 1.f; } }
+    s = wave_sum(s); c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; red[4 + (threadIdx.x >> 6)] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) { acc[0] += (red[0] + red[1]) + (red[2] + red[3]); acc[1] += (red[4] + red[5]) + (red[6] + red[7]); }
 }
 
 }  // namespace
@@ -64,10 +74,13 @@ extern "C" int mi_embed_tokens(const long* ids, const float* wte, float scale, c
 
 // acc[0] += sum of per-row losses, acc[1] += number of valid targets (caller zeroes acc and divides)
 extern "C" int mi_ce_label_smoothing(const float* logits, long ld, const long* labels, int B, int U, int shift, int V, float eps,
-                                     float* acc, hipStream_t stream) {
+                                     float* acc, float* row_loss, hipStream_t stream) {
     MI_ENTER();
-    if (B <= 0 || U <= shift || V <= 0 || shift < 0) return MI_ERR_ARG;
-    hipLaunchKernelGGL(ce_smooth_kernel, dim3(cdiv((long)B * (U - shift), 4)), dim3(256), 0, stream, logits, ld, labels, B, U, shift, V, eps, acc);
+    if (B <= 0 || U <= shift || V <= 0 || shift < 0 || !row_loss) return MI_ERR_ARG;          // row_loss: B * (U - shift) floats of workspace
+    const int rows = B * (U - shift);
+    hipLaunchKernelGGL(ce_smooth_kernel, dim3(cdiv((long)rows, 4)), dim3(256), 0, stream, logits, ld, labels, B, U, shift, V, eps, row_loss);
+    MI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ce_sum_kernel, dim3(1), dim3(256), 0, stream, row_loss, rows, acc);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

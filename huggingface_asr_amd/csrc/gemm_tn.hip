@@ -36,6 +36,8 @@ struct TnArgs {
     float* out; long ldo;          // splits == 1: dW (accumulated);  else: slab base, slab s at out + s * slab_stride
     long slab_stride;
     float* db;                     // optional: db[n] += sum_m dY[m][n] (bias gradient), taken from the dY tiles already staged in LDS
+    float* db_slab;                // splits > 1: split s leaves its column sums in db_slab[s * N + n] (plain stores; slab_reduce_kernel adds the splits in order).  splits == 1:
+                                   // exactly one block owns a column, which adds into db directly — no float atomics either way, the bias gradients are bit-reproducible
     int M, N, K, n_store, splits, rows_per_split;
     // conv != 0: X is not a matrix but a channels-last activation (B, Tin, Fin, Cin) and row m = (b, to, fo), column k = (kh * KW + kw) * Cin + c address
     // X[b][to * cst - cpt + kh][fo * cst - cpf + kw][c] (zero outside): the im2col operand of a Conv2d weight gradient, gathered by the LDS-DMA source addresses
@@ -236,7 +238,11 @@ __device__ __forceinline__ void tn_tile(const TnArgs& pin, const int bid) {
         float* red = reinterpret_cast<float*>(smem);
         red[tid] = bsum;
         __syncthreads();
-        if (tid < TNN && n0 + tid < p.n_store) __hip_atomic_fetch_add(p.db + n0 + tid, red[tid] + red[tid + TNN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < TNN && n0 + tid < p.n_store) {
+            const float v = red[tid] + red[tid + TNN];
+            if (p.db_slab) p.db_slab[(long)split * p.N + n0 + tid] = v;
+            else p.db[n0 + tid] += v;
+        }
     }
     // C layout: col (k) = lane & 31, row (n) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     const int lr = lane & 31, lh = lane >> 5;
@@ -297,14 +303,14 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g) {
     const int iu = __builtin_amdgcn_readfirstlane(lo);
     const TnDesc q = g.a[iu];
     TnArgs p;
-    p.Y = q.Y; p.ldy = q.ldy; p.X = q.X; p.ldx = q.ldx; p.out = q.out; p.ldo = q.ldo; p.slab_stride = 0; p.db = q.db;
+    p.Y = q.Y; p.ldy = q.ldy; p.X = q.X; p.ldx = q.ldx; p.out = q.out; p.ldo = q.ldo; p.slab_stride = 0; p.db = q.db; p.db_slab = nullptr;
     p.M = q.M; p.N = q.N; p.K = q.K; p.n_store = q.n_store; p.splits = 1; p.rows_per_split = (q.M + TN_KM - 1) / TN_KM * TN_KM;
     p.conv = 0; p.Tin = p.Fin = p.Cin = p.Tout = p.Fout = p.KW = 1; p.cst = 1; p.cpt = p.cpf = 0;
     tn_tile<TN_GROUP_N, XW, TN_GROUP_NS, false>(p, bid - __builtin_amdgcn_readfirstlane(g.tile0[iu]));
 }
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ out, long ldo, const float* __restrict__ slabs, long slab_stride,
-                                                           int splits, int rows, int cols) {
+                                                           int splits, int rows, int cols, float* __restrict__ db, const float* __restrict__ db_slab, int N) {
     const long total = (long)rows * cols;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int r = (int)(i / cols), c = (int)(i % cols);
@@ -312,6 +318,12 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ ou
         for (int q = 0; q < splits; ++q) s += slabs[q * slab_stride + i];
         out[(long)r * ldo + c] += s;
     }
+    if (db && blockIdx.x == 0)                                   // the bias gradient's per-split column sums, added in split order
+        for (int n = threadIdx.x; n < rows; n += 256) {
+            float s = 0.f;
+            for (int q = 0; q < splits; ++q) s += db_slab[(long)q * N + n];
+            db[n] += s;
+        }
 }
 
 }  // namespace
@@ -332,13 +344,13 @@ extern "C" size_t mi_gemm_tn_workspace_bytes(int M, int N, int K) {       // eno
     size_t best = 0;
     for (int v = 0; v < 3; ++v) {
         const int s = tn_splits(M, N, K, v);
-        if (s > 1 && (size_t)s * N * K * sizeof(float) > best) best = (size_t)s * N * K * sizeof(float);
+        if (s > 1 && (size_t)s * N * (K + 1) * sizeof(float) > best) best = (size_t)s * N * (K + 1) * sizeof(float);      // dW slabs + the bias gradient's column-sum slabs
     }
     return best;
 }
 
 // dW (n_store, K) fp32 (row stride ldo) += dY[:, :N]^T · X;  N, K % 8 == 0, rows of dY / X 16-B aligned; n_store <= N
-// db (optional, n_store floats): bias gradient db[n] += sum_m dY[m][n], fused (float atomics at block granularity)
+// db (optional, n_store floats): bias gradient db[n] += sum_m dY[m][n], fused (per-split column sums, added in split order by the slab reduce: no atomics)
 // variant: 0 = the product's tile (128 x 128), 1 = 128 (n) x 64 (k) for A/B.  Per call: the library keeps no kernel-selection state.
 extern "C" int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx, float* dW, long ldo, float* db, int M, int N, int K, int n_store,
                                void* workspace, size_t workspace_bytes, int variant, hipStream_t st) {
@@ -347,12 +359,12 @@ extern "C" int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx
     if ((reinterpret_cast<uintptr_t>(dY) & 15) || (reinterpret_cast<uintptr_t>(X) & 15)) return MI_ERR_ARG;
     const bool big = variant == 0 && tn_big(M, N, K);
     const int splits = tn_splits(M, N, K, big ? 2 : variant);
-    if (splits > 1 && workspace_bytes < (size_t)splits * N * K * sizeof(float)) return MI_ERR_ARG;
+    if (splits > 1 && workspace_bytes < (size_t)splits * N * (K + 1) * sizeof(float)) return MI_ERR_ARG;
     TnArgs p{};
     p.Y = (const bf16_t*)dY; p.ldy = ldy; p.X = (const bf16_t*)X; p.ldx = ldx;
     p.M = M; p.N = N; p.K = K; p.n_store = n_store; p.splits = splits; p.db = db;
     p.rows_per_split = cdiv(cdiv(M, splits), TN_KM) * TN_KM;
-    if (splits > 1) { p.out = (float*)workspace; p.ldo = K; p.slab_stride = (long)N * K; }
+    if (splits > 1) { p.out = (float*)workspace; p.ldo = K; p.slab_stride = (long)N * K; p.db_slab = db ? (float*)workspace + (size_t)splits * N * K : nullptr; }
     else { p.out = dW; p.ldo = ldo; p.slab_stride = 0; }
     const int tiles = big ? cdiv(N, 256) * cdiv(K, 256) : cdiv(N, TN_T) * cdiv(K, variant == 1 ? 64 : 128);
     if (big) {
@@ -367,7 +379,7 @@ extern "C" int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx
         const long total = (long)n_store * K;
         const long g = (total + 255) / 256;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, st, dW, ldo, (const float*)workspace, p.slab_stride,
-                           splits, n_store, K);
+                           splits, n_store, K, db, p.db_slab, N);
         MI_CHECK_LAUNCH();
     }
     return MI_OK;
@@ -387,12 +399,12 @@ extern "C" int mi_conv2d_wgrad_cl_bf16(const void* dY, long ldy, const void* x, 
     const int M = (int)Ml;
     const bool big = tn_big(M, N, K) && (Cin % 256) == 0;
     const int splits = tn_splits(M, N, K, big ? 2 : 0);
-    if (splits > 1 && workspace_bytes < (size_t)splits * N * K * sizeof(float)) return MI_ERR_ARG;
+    if (splits > 1 && workspace_bytes < (size_t)splits * N * (K + 1) * sizeof(float)) return MI_ERR_ARG;
     TnArgs p{};
     p.Y = (const bf16_t*)dY; p.ldy = ldy; p.X = (const bf16_t*)x; p.ldx = Cin;
     p.M = M; p.N = N; p.K = K; p.n_store = n_store; p.splits = splits; p.db = db;
     p.rows_per_split = cdiv(cdiv(M, splits), TN_KM) * TN_KM;
-    if (splits > 1) { p.out = (float*)workspace; p.ldo = K; p.slab_stride = (long)N * K; }
+    if (splits > 1) { p.out = (float*)workspace; p.ldo = K; p.slab_stride = (long)N * K; p.db_slab = db ? (float*)workspace + (size_t)splits * N * K : nullptr; }
     else { p.out = dW; p.ldo = ldo; p.slab_stride = 0; }
     p.conv = 1; p.Tin = Tin; p.Fin = Fin; p.Cin = Cin; p.Tout = Tout; p.Fout = Fout; p.KW = KW; p.cst = stride; p.cpt = pad_t; p.cpf = pad_f;
     const int tiles = big ? cdiv(N, 256) * cdiv(K, 256) : cdiv(N, TN_T) * cdiv(K, 128);
@@ -406,7 +418,7 @@ extern "C" int mi_conv2d_wgrad_cl_bf16(const void* dY, long ldy, const void* x, 
     if (splits > 1) {
         const long total = (long)n_store * K;
         const long g = (total + 255) / 256;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, st, dW, ldo, (const float*)workspace, p.slab_stride, splits, n_store, K);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, st, dW, ldo, (const float*)workspace, p.slab_stride, splits, n_store, K, db, p.db_slab, N);
         MI_CHECK_LAUNCH();
     }
     return MI_OK;

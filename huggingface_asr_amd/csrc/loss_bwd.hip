@@ -8,9 +8,6 @@
 
 namespace {
 
-__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ float lse3f(float a, float b, float c) {
     const float m = fmaxf(a, fmaxf(b, c));
     if (m == -INFINITY) return -INFINITY;
@@ -24,7 +21,7 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const T* __restrict
                                                               int Tmax, const long* __restrict__ labels, int U, const int* __restrict__ in_len,
                                                               int blank, const float* __restrict__ nll, int reduction, int B, float gscale,
                                                               float* __restrict__ alpha_ws, float* __restrict__ contrib,
-                                                              int* __restrict__ ext_ws, int* __restrict__ meta) {
+                                                              int* __restrict__ ext_ws, int* __restrict__ meta, int* __restrict__ chain_ws) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S_max = 2 * U + 1;
     int* hdr = reinterpret_cast<int*>(smem);          // [4]
@@ -47,6 +44,17 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(const T* __restrict
     float scale = (reduction == 1) ? gscale / ((float)max(tl, 1) * (float)B) : gscale;
     if (!isfinite(nl) || Tb <= 0) scale = 0.f;        // infeasible alignment: zero gradient (zero_infinity semantics)
     for (int s = tid; s < S; s += 256) ext_ws[(long)b * S_max + s] = ext[s];
+    // chain of the states that emit the same label (repeated labels in the target): chain[s] = next odd s' > s with ext[s'] == ext[s] (0: none), bit 30 set when an
+    // earlier state has the label — ctc_grad_rows_kernel lets the FIRST state of a label add the whole chain in order (no LDS float atomics: bit-reproducible rows)
+    for (int s = tid; s < S; s += 256) {
+        int code = 0;
+        if (s & 1) {
+            const int v = ext[s];
+            for (int q = s + 2; q < S; q += 2) if (ext[q] == v) { code = q; break; }
+            for (int q = 1; q < s; q += 2) if (ext[q] == v) { code |= 0x40000000; break; }
+        }
+        chain_ws[(long)b * S_max + s] = code;
+    }
     if (tid == 0) { meta[3 * b] = tl; meta[3 * b + 1] = Tb; meta[3 * b + 2] = __float_as_int(scale); }
     if (scale == 0.f) return;
     const T* lg = logits + (long)b * ld_b;
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_wave_kernel(const T* __res
                                                                    int Tmax, const long* __restrict__ labels, int U, const int* __restrict__ in_len,
                                                                    int blank, const float* __restrict__ nll, int reduction, int B, float gscale,
                                                                    float* __restrict__ alpha_ws, float* __restrict__ contrib,
-                                                                   int* __restrict__ ext_ws, int* __restrict__ meta) {
+                                                                   int* __restrict__ ext_ws, int* __restrict__ meta, int* __restrict__ chain_ws) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S_max = 2 * U + 1;
     int* hdr = reinterpret_cast<int*>(smem);          // [4]
@@ -143,6 +151,17 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_wave_kernel(const T* __res
     float scale = (reduction == 1) ? gscale / ((float)max(tl, 1) * (float)B) : gscale;
     if (!isfinite(nl) || Tb <= 0) scale = 0.f;        // infeasible alignment: zero gradient (zero_infinity semantics)
     for (int s = tid; s < S; s += 256) ext_ws[(long)b * S_max + s] = ext[s];
+    // chain of the states that emit the same label (repeated labels in the target): chain[s] = next odd s' > s with ext[s'] == ext[s] (0: none), bit 30 set when an
+    // earlier state has the label — ctc_grad_rows_kernel lets the FIRST state of a label add the whole chain in order (no LDS float atomics: bit-reproducible rows)
+    for (int s = tid; s < S; s += 256) {
+        int code = 0;
+        if (s & 1) {
+            const int v = ext[s];
+            for (int q = s + 2; q < S; q += 2) if (ext[q] == v) { code = q; break; }
+            for (int q = 1; q < s; q += 2) if (ext[q] == v) { code |= 0x40000000; break; }
+        }
+        chain_ws[(long)b * S_max + s] = code;
+    }
     if (tid == 0) { meta[3 * b] = tl; meta[3 * b + 1] = Tb; meta[3 * b + 2] = __float_as_int(scale); }
     if (scale == 0.f) return;
     const T* lg = logits + (long)b * ld_b;
@@ -232,7 +251,7 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_wave_kernel(const T* __res
 template <typename T>
 __global__ __launch_bounds__(256) void ctc_grad_rows_kernel(const T* __restrict__ logits, long ld_b, long ld_t, const float* __restrict__ lse,
                                                              int Tmax, int U, int V1, const float* __restrict__ contrib,
-                                                             const int* __restrict__ ext_ws, const int* __restrict__ meta,
+                                                             const int* __restrict__ ext_ws, const int* __restrict__ meta, const int* __restrict__ chain_ws,
                                                              bf16_t* __restrict__ out, long ldo) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* row = reinterpret_cast<float*>(smem);      // [V1]
@@ -252,7 +271,25 @@ __global__ __launch_bounds__(256) void ctc_grad_rows_kernel(const T* __restrict_
     const int S = 2 * tl + 1;
     const float* cw = contrib + ((long)b * Tmax + t) * S_max;
     const int* ext = ext_ws + (long)b * S_max;
-    for (int s = tid; s < S; s += 256) atomicAdd(row + ext[s], cw[s]);
+    const int* chain = chain_ws + (long)b * S_max;
+    // labels (odd states): the first state of each label adds its chain in state order — one writer per vocabulary entry
+    for (int s = 2 * tid + 1; s < S; s += 512) {
+        const int code = chain[s];
+        if (code & 0x40000000) continue;
+        float acc = cw[s];
+        for (int q = code; q != 0; q = chain[q] & 0x3FFFFFFF) acc += cw[q];
+        row[ext[s]] += acc;
+    }
+    // blanks (even states): strided partial sums, wave sums by DPP, the four waves in order
+    {
+        __shared__ float bred[4];
+        float bs = 0.f;
+        for (int s = 2 * tid; s < S; s += 512) bs += cw[s];
+        bs = wave_sum(bs);
+        if ((tid & 63) == 0) bred[tid >> 6] = bs;
+        __syncthreads();
+        if (tid == 0) row[ext[0]] += (bred[0] + bred[1]) + (bred[2] + bred[3]);
+    }
     __syncthreads();
     for (int c = tid; c < ldo; c += 256) o[c] = (c < V1) ? f2bf(row[c]) : (bf16_t)0.f;
 }
@@ -291,16 +328,52 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     }
 }
 
-// dwte[ids[m]] += scale * dx[m];  dwpe[pos_offset + m % U] += dx[m]  (learned positions only)
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const long* __restrict__ ids, const float* __restrict__ dx, float scale, int pos_offset,
-                                                         int U, int d, int M, int V, float* __restrict__ dwte, float* __restrict__ dwpe) {
-    const long total = (long)M * d;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int m = (int)(i / d), c = (int)(i % d);
-        const long id = ids[m];
-        const float g = dx[i];
-        if (id >= 0 && id < V) atomic_add_f32(dwte + id * d + c, scale * g);
-        if (dwpe) atomic_add_f32(dwpe + (long)(pos_offset + m % U) * d + c, g);
+// dwte[ids[m]] += scale * dx[m];  dwpe[pos_offset + m % U] += dx[m]  (learned positions only) — as GATHERS, so that no two threads ever add to one element (the scatter
+// with float atomics was the last unordered sum of the decoder's backward): block = one vocabulary entry (or one position); it scans the M token ids, and every thread
+// adds the matching rows of its columns in row order.
+__global__ __launch_bounds__(256) void embed_bwd_wte_kernel(const long* __restrict__ ids, const float* __restrict__ dx, float scale, int d, int M, int V,
+                                                             float* __restrict__ dwte, const unsigned char* __restrict__ used) {
+    const int id = blockIdx.x;
+    if (used && !used[id]) return;
+    __shared__ int hit[256];
+    __shared__ int nhit;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};                      // columns tid, tid + 256, ... (d <= 1024)
+    for (int m0 = 0; m0 < M; m0 += 256) {
+        __syncthreads();
+        if (threadIdx.x == 0) nhit = 0;
+        __syncthreads();
+        const int m = m0 + threadIdx.x;
+        const bool match = m < M && ids[m] == id;
+        // ordered compaction of this chunk's matching rows: ballot per wave, the four waves in order
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(match);
+        __shared__ int wcount[4];
+        if ((threadIdx.x & 63) == 0) wcount[threadIdx.x >> 6] = __builtin_popcountll(bal);
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wcount[w];
+        if (match) hit[base + __builtin_popcountll(bal & ((1ull << (threadIdx.x & 63)) - 1ull))] = m;
+        if (threadIdx.x == 0) nhit = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+        const int n = nhit;
+        for (int h = 0; h < n; ++h) {
+            const float* src = dx + (long)hit[h] * d;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int c = threadIdx.x + 256 * j; if (c < d) acc[j] += src[c]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int c = threadIdx.x + 256 * j; if (c < d) dwte[(long)id * d + c] += scale * acc[j]; }
+}
+__global__ __launch_bounds__(256) void embed_bwd_mark_kernel(const long* __restrict__ ids, int M, int V, unsigned char* __restrict__ used) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m < M) { const long id = ids[m]; if (id >= 0 && id < V) used[id] = 1; }      // same value from every writer: no race to lose
+}
+__global__ __launch_bounds__(256) void embed_bwd_wpe_kernel(const float* __restrict__ dx, int pos_offset, int U, int d, int M, float* __restrict__ dwpe) {
+    const int u = blockIdx.x;                                 // rows u, u + U, u + 2U, ... (one per utterance), added in order
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float acc = 0.f;
+        for (int m = u; m < M; m += U) acc += dx[(long)m * d + c];
+        dwpe[(long)(pos_offset + u) * d + c] += acc;
     }
 }
 
@@ -308,7 +381,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long* __restrict__
 
 extern "C" size_t mi_ctc_bwd_workspace_bytes(int B, int T, int U) {
     const size_t S = 2 * (size_t)U + 1;
-    return 2 * (size_t)B * T * S * sizeof(float) + (size_t)B * S * sizeof(int) + (size_t)3 * B * sizeof(int) + 1024;
+    return 2 * (size_t)B * T * S * sizeof(float) + 2 * (size_t)B * S * sizeof(int) + (size_t)3 * B * sizeof(int) + 1024;
 }
 
 // logits (B,T,V1) f32 (dtype 0) | bf16 (1) with strides; lse (B*T) and nll (B) from mi_row_lse / mi_ctc_loss_fwd;
@@ -325,6 +398,7 @@ extern "C" int mi_ctc_loss_bwd(const void* logits, long ld_b, long ld_t, int dty
     float* contrib = alpha_ws + (size_t)B * T * S;
     int* ext_ws = (int*)(contrib + (size_t)B * T * S);
     int* meta = ext_ws + (size_t)B * S;
+    int* chain_ws = meta + (size_t)3 * B;
     const size_t lds = (4 + S) * sizeof(int) + 2 * S * sizeof(float);
     const size_t lds_rows = (size_t)V1 * sizeof(float);
     if (lds > 150 * 1024 || lds_rows > 150 * 1024) return MI_ERR_UNSUPPORTED;
@@ -332,11 +406,11 @@ extern "C" int mi_ctc_loss_bwd(const void* logits, long ld_b, long ld_t, int dty
     const size_t ldsw = (4 + 132) * sizeof(int) + (size_t)T * 128 * sizeof(float);
 #define CTC_AB(TY) do { \
         if (wavef) hipLaunchKernelGGL(ctc_alpha_beta_wave_kernel<TY>, dim3(B), dim3(256), ldsw, st, (const TY*)logits, ld_b, ld_t, lse, T, labels, U, in_len, \
-                                      blank, nll, reduction, B, gscale, alpha_ws, contrib, ext_ws, meta); \
+                                      blank, nll, reduction, B, gscale, alpha_ws, contrib, ext_ws, meta, chain_ws); \
         else hipLaunchKernelGGL(ctc_alpha_beta_kernel<TY>, dim3(B), dim3(256), lds, st, (const TY*)logits, ld_b, ld_t, lse, T, labels, U, in_len, \
-                                blank, nll, reduction, B, gscale, alpha_ws, contrib, ext_ws, meta); \
+                                blank, nll, reduction, B, gscale, alpha_ws, contrib, ext_ws, meta, chain_ws); \
         hipLaunchKernelGGL(ctc_grad_rows_kernel<TY>, dim3(B * T), dim3(256), lds_rows, st, (const TY*)logits, ld_b, ld_t, lse, T, U, V1, \
-                           contrib, ext_ws, meta, (bf16_t*)dlogits, ldo); } while (0)
+                           contrib, ext_ws, meta, chain_ws, (bf16_t*)dlogits, ldo); } while (0)
     if (dtype == 0) CTC_AB(float); else CTC_AB(bf16_t);
 #undef CTC_AB
     MI_CHECK_LAUNCH();
@@ -353,13 +427,22 @@ extern "C" int mi_ce_label_smoothing_bwd(const float* logits, long ld, const lon
     return MI_OK;
 }
 
+// workspace: V bytes (which vocabulary entries occur: the others' blocks return at once), or NULL (every entry's block scans the ids)
 extern "C" int mi_embed_tokens_bwd(const long* ids, const float* dx, float scale, int pos_offset, int U, int d, int M, int V, float* dwte,
-                                   float* dwpe, hipStream_t st) {
+                                   float* dwpe, void* workspace, hipStream_t st) {
     MI_ENTER();
-    if (M <= 0 || d <= 0 || U <= 0) return MI_ERR_ARG;
-    const long total = (long)M * d;
-    const long g = (total + 255) / 256;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, st, ids, dx, scale, pos_offset, U, d, M, V, dwte, dwpe);
+    if (M <= 0 || d <= 0 || U <= 0 || V <= 0 || d > 1024) return MI_ERR_ARG;
+    unsigned char* used = (unsigned char*)workspace;
+    if (used) {
+        if (hipMemsetAsync(used, 0, (size_t)V, st) != hipSuccess) return MI_ERR_LAUNCH;
+        hipLaunchKernelGGL(embed_bwd_mark_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, ids, M, V, used);
+        MI_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(embed_bwd_wte_kernel, dim3((unsigned)V), dim3(256), 0, st, ids, dx, scale, d, M, V, dwte, used);
     MI_CHECK_LAUNCH();
+    if (dwpe) {
+        hipLaunchKernelGGL(embed_bwd_wpe_kernel, dim3((unsigned)(U < M ? U : M)), dim3(256), 0, st, dx, pos_offset, U, d, M, dwpe);
+        MI_CHECK_LAUNCH();
+    }
     return MI_OK;
 }

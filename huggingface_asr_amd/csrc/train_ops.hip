@@ -12,10 +12,6 @@
 
 namespace {
 
-__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // ------------------------------------------------------------------------------------------------ transpose
 // in (M,N) bf16 -> out (N, Mp) bf16 with columns M..Mp-1 zero (Mp = K extent of the GEMM that reads it, % 64 == 0).
 // 64 x 64 tiles through LDS, 16-B global accesses on both sides when rows are 16-B aligned (scalar edge path otherwise).
@@ -92,8 +88,9 @@ __global__ __launch_bounds__(256) void transpose_many_kernel(const TrDesc* __res
 }
 
 // ------------------------------------------------------------------------------------------------ column sums (bias grads)
+// stage 1: block (column block, row chunk) leaves its 64 column sums in partial[row chunk][N]; stage 2 (rows_reduce_kernel) adds the chunks in order
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long ld, int M, int N, float* __restrict__ out,
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long ld, int M, int N, float* __restrict__ partial,
                                                       int rows_per_block) {
     __shared__ float part[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -104,7 +101,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
         for (int m = m0 + ty; m < m1; m += 4) s += (float)x[(long)m * ld + n];
     part[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && n < N) atomic_add_f32(out + n, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+    if (ty == 0 && n < N) partial[(long)blockIdx.y * N + n] = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
 }
 
 // out[n] = bf16(sum over the M rows of x[:, n]), rows added in order by one thread (a handful of partial-sum rows: deterministic, no zero-fill, no fp32 round trip)
@@ -293,25 +290,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
     }
 }
 
-// dgamma[c] += sum_blk partial[blk][c],  dbeta[c] += sum_blk partial[blk][d + c];  grid (2d/64, row chunks): each block sums 64 partial rows
-__global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __restrict__ partial, int nblk, int d, float* __restrict__ dgamma,
-                                                                 float* __restrict__ dbeta) {
-    __shared__ float red[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
-    const int b0 = blockIdx.y * 64, b1 = min(nblk, b0 + 64);
-    float s = 0.f;
-    if (c < 2 * d)
-        for (int b = b0 + ty; b < b1; b += 4) s += partial[(long)b * 2 * d + c];
-    red[ty][tx] = s;
-    __syncthreads();
-    if (ty == 0 && c < 2 * d) {
-        const float t = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
-        atomic_add_f32(c < d ? dgamma + c : dbeta + (c - d), t);
-    }
-}
-
-// The same reduction for up to 16 LayerNorms in ONE launch (the trainer defers the reductions of a layer's LayerNorm backward passes and flushes them together: a
+// dgamma[c] += sum_blk partial[blk][c],  dbeta[c] += sum_blk partial[blk][d + c] for up to 16 LayerNorms in ONE launch (the trainer defers the reductions of a layer's LayerNorm backward passes and flushes them together: a
 // reduce of 2 MB is all launch latency).  grid (columns / 16, LayerNorm); a block owns its 16 columns over ALL partial rows (16 row groups x 32 rows), summed in a fixed order: no atomics.
 struct LnRedMany { mi_lnred_desc d[16]; };
 __global__ __launch_bounds__(256) void ln_partial_reduce_many_kernel(LnRedMany p) {
@@ -463,7 +442,7 @@ __global__ __launch_bounds__(256) void spec_mask_apply_kernel(float* __restrict_
         x[(long)m * ld + c] = v;
     }
 }
-__global__ __launch_bounds__(256) void spec_mask_bwd_kernel(float* __restrict__ dx, long ld, const unsigned char* __restrict__ tmask, float* __restrict__ dembed,
+__global__ __launch_bounds__(256) void spec_mask_bwd_kernel(float* __restrict__ dx, long ld, const unsigned char* __restrict__ tmask, float* __restrict__ partial,
                                                              const unsigned char* __restrict__ fmask, int T, int M, int N, int rows_per_block) {
     __shared__ float part[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -479,7 +458,7 @@ __global__ __launch_bounds__(256) void spec_mask_bwd_kernel(float* __restrict__ 
         }
     part[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && c < N && tmask && dembed) atomic_add_f32(dembed + c, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+    if (ty == 0 && c < N && tmask && partial) partial[(long)blockIdx.y * N + c] = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
 }
 
 // ------------------------------------------------------------------------------------------------ optimizer
@@ -637,15 +616,18 @@ extern "C" int mi_transpose_many_bf16(const void* descs, int count, hipStream_t 
     return MI_OK;
 }
 
-// out[n] += sum_m x[m,n];  dtype 0 f32, 1 bf16
-extern "C" int mi_colsum(const void* x, long ld, int dtype, int M, int N, float* out, hipStream_t st) {
+// out[n] += sum_m x[m,n];  dtype 0 f32, 1 bf16.  workspace: mi_colsum_workspace_floats(M, N) floats (per-chunk partial sums; the chunks are added in a fixed order)
+extern "C" size_t mi_colsum_workspace_floats(int M, int N) { return (size_t)cdiv(M, 128) * (size_t)N; }
+extern "C" int mi_colsum(const void* x, long ld, int dtype, int M, int N, float* out, float* workspace, hipStream_t st) {
     MI_ENTER();
-    if (M <= 0 || N <= 0) return MI_ERR_ARG;
+    if (M <= 0 || N <= 0 || !workspace) return MI_ERR_ARG;
     const int rpb = 128;
     dim3 grid(cdiv(N, 64), cdiv(M, rpb));
-    if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ld, M, N, out, rpb);
-    else if (dtype == 1) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ld, M, N, out, rpb);
+    if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ld, M, N, workspace, rpb);
+    else if (dtype == 1) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ld, M, N, workspace, rpb);
     else return MI_ERR_ARG;
+    MI_CHECK_LAUNCH();
+    rows_reduce_launch(workspace, (int)grid.y, N, EmitAdd{out}, st);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
@@ -733,7 +715,9 @@ extern "C" int mi_layernorm_bwd(const void* x, long ldx, int x_bf16, const float
     if (rc != MI_OK) return rc;
     MI_CHECK_LAUNCH();
     if (dgamma) {
-        hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(cdiv(2 * d, 64), cdiv(grid, 64)), dim3(256), 0, st, workspace, grid, d, dgamma, dbeta);
+        LnRedMany one{};
+        one.d[0] = mi_lnred_desc{workspace, grid, d, dgamma, dbeta};
+        hipLaunchKernelGGL(ln_partial_reduce_many_kernel, dim3(cdiv(2 * d, 16), 1), dim3(256), 0, st, one);
         MI_CHECK_LAUNCH();
     }
     return MI_OK;
@@ -866,13 +850,20 @@ extern "C" int mi_spec_mask_apply(float* x, long ld, const unsigned char* time_m
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
+// workspace: ceil(M / 128) * N floats when dembed is given (per-chunk partial sums of the masked rows' gradient, added in a fixed order)
 extern "C" int mi_spec_mask_bwd(float* dx, long ld, const unsigned char* time_mask, float* dembed, const unsigned char* feat_mask, int T, int M, int N,
-                                hipStream_t st) {
+                                float* workspace, hipStream_t st) {
     MI_ENTER();
     if (M <= 0 || N <= 0 || T <= 0) return MI_ERR_ARG;      // dembed == NULL: masked rows were replaced by a constant (noise): gradient dropped
+    const bool want = time_mask && dembed;
+    if (want && !workspace) return MI_ERR_ARG;
     const int rpb = 128;
-    hipLaunchKernelGGL(spec_mask_bwd_kernel, dim3(cdiv(N, 64), cdiv(M, rpb)), dim3(256), 0, st, dx, ld, time_mask, dembed, feat_mask, T, M, N, rpb);
+    hipLaunchKernelGGL(spec_mask_bwd_kernel, dim3(cdiv(N, 64), cdiv(M, rpb)), dim3(256), 0, st, dx, ld, time_mask, want ? workspace : nullptr, feat_mask, T, M, N, rpb);
     MI_CHECK_LAUNCH();
+    if (want) {
+        rows_reduce_launch(workspace, cdiv(M, rpb), N, EmitAdd{dembed}, st);
+        MI_CHECK_LAUNCH();
+    }
     return MI_OK;
 }
 

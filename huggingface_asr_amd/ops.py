@@ -365,7 +365,8 @@ def ce_label_smoothing(logits, labels, *, shift=1, eps=0.0):
     B, U, V = logits.shape
     labels = labels.contiguous()
     acc = torch.zeros((2,), device=logits.device, dtype=torch.float32)
-    rc = _lib.lib().mi_ce_label_smoothing(logits.data_ptr(), logits.stride(1), labels.data_ptr(), B, U, shift, V, float(eps), acc.data_ptr(), _stream())
+    rows = torch.empty((B * (U - shift),), device=logits.device, dtype=torch.float32)       # per-row losses; summed by one block in a fixed order
+    rc = _lib.lib().mi_ce_label_smoothing(logits.data_ptr(), logits.stride(1), labels.data_ptr(), B, U, shift, V, float(eps), acc.data_ptr(), rows.data_ptr(), _stream())
     _lib.check(rc, "mi_ce_label_smoothing")
     return acc[0] / acc[1]
 

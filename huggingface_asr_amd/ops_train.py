@@ -48,7 +48,8 @@ def transpose(x, Mp=None, out=None):
 def colsum_(out, x):
     """out (N) f32 += column sums of x (M,N) f32|bf16."""
     M, N = x.shape
-    _lib.check(_L().mi_colsum(x.data_ptr(), x.stride(0), 0 if x.dtype == F32 else 1, M, N, out.data_ptr(), _stream()), "mi_colsum")
+    ws = _dw_ws(x.device, int(_L().mi_colsum_workspace_floats(M, N)))      # per-chunk partial sums, added in chunk order (no atomics)
+    _lib.check(_L().mi_colsum(x.data_ptr(), x.stride(0), 0 if x.dtype == F32 else 1, M, N, out.data_ptr(), ws, _stream()), "mi_colsum")
 
 
 def colsum2_acc_(out_a, out_b, a, b):
@@ -258,7 +259,8 @@ def spec_mask_apply_(x, time_mask, embed, feat_mask, T):
 
 def spec_mask_bwd_(dx, time_mask, dembed, feat_mask, T):
     M, N = dx.shape
-    _lib.check(_L().mi_spec_mask_bwd(dx.data_ptr(), dx.stride(0), _p(time_mask), _p(dembed), _p(feat_mask), T, M, N, _stream()), "mi_spec_mask_bwd")
+    ws = _dw_ws(dx.device, ((M + 127) // 128) * N) if (dembed is not None and time_mask is not None) else 0
+    _lib.check(_L().mi_spec_mask_bwd(dx.data_ptr(), dx.stride(0), _p(time_mask), _p(dembed), _p(feat_mask), T, M, N, ws, _stream()), "mi_spec_mask_bwd")
 
 
 def bgemm(A, a_str, B, b_str, C, c_str, Z1, Z2, M, N, K, *, alpha=1.0, accumulate=False):
@@ -378,7 +380,7 @@ def csgu_bwd(u, stats, gamma, beta, w, bias, ds, dr, dgn, dw, db, B, T, pad_left
     pl = (K - 1) // 2 if pad_left is None else int(pad_left)
     _lib.check(_L().mi_csgu_bwd_bf16(u.data_ptr(), u.stride(0), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), _p(bias),
                                      ds.data_ptr(), ds.stride(0), _p(dr), dr.stride(0) if dr is not None else 0, dgn.data_ptr(), dgn.stride(0),
-                                     dw.data_ptr(), _p(db), B, T, Cc, K, pl, int(dilation), _dw_ws(u.device, B * Cc * 32), _stream()), "mi_csgu_bwd_bf16")
+                                     dw.data_ptr(), _p(db), B, T, Cc, K, pl, int(dilation), _dw_ws(u.device, B * Cc * 32 * (((T + 63) // 64) if dilation > 1 else 1)), _stream()), "mi_csgu_bwd_bf16")
 
 
 def gate_act_mul_bwd(r, g, ds, dr, act=0):
@@ -459,15 +461,17 @@ def conv2d_first_wgrad(x, dy, dw, db, K, stride, pad):
     B, T, F = x.shape
     _, T1, F1, Cc = dy.shape
     (KH, KW), (st, sf), (pt, pf) = K, stride, pad
-    _lib.check(_L().mi_conv2d_first_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), B, T, F, Cc, KH, KW, st, sf, pt, pf, T1, F1, _stream()),
+    ws = _dw_ws(x.device, int(_L().mi_conv2d_first_wgrad_workspace_floats(B, Cc, KH, KW, T1, F1)))
+    _lib.check(_L().mi_conv2d_first_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), B, T, F, Cc, KH, KW, st, sf, pt, pf, T1, F1, ws, _stream()),
                "mi_conv2d_first_wgrad")
 
 
 def conv2d_first_bwd(x, w, bias, dcol, dw, db, K, stride, pad, T1, F1, K2, stride2, pad2, T2, F2):
     B, T, F = x.shape
     Cc = w.shape[0]
+    ws = _dw_ws(x.device, int(_L().mi_conv2d_first_bwd_workspace_floats(B, Cc, T1, F1)))      # one partial row of 10 C floats per block, added in block order
     _lib.check(_L().mi_conv2d_first_bwd(x.data_ptr(), w.data_ptr(), bias.data_ptr(), dcol.data_ptr(), dw.data_ptr(), db.data_ptr(),
-                                        B, T, F, Cc, K, stride, pad, pad, T1, F1, K2, stride2, pad2, pad2, T2, F2, _stream()), "mi_conv2d_first_bwd")
+                                        B, T, F, Cc, K, stride, pad, pad, T1, F1, K2, stride2, pad2, pad2, T2, F2, ws, _stream()), "mi_conv2d_first_bwd")
 
 
 def ctc_loss_bwd(logits, lse, labels, in_len, nll, *, reduction="mean", gscale=1.0, ldo=None):
@@ -500,7 +504,8 @@ def embed_tokens_bwd(ids, dx, dwte, dwpe=None, *, scale=1.0, pos_offset=0):
     M = ids.numel()
     U = ids.shape[-1]
     V, d = dwte.shape
-    _lib.check(_L().mi_embed_tokens_bwd(ids.data_ptr(), dx.data_ptr(), float(scale), pos_offset, U, d, M, V, dwte.data_ptr(), _p(dwpe), _stream()),
+    ws = _dw_ws(dx.device, (V + 3) // 4)                      # V bytes: which vocabulary entries occur
+    _lib.check(_L().mi_embed_tokens_bwd(ids.data_ptr(), dx.data_ptr(), float(scale), pos_offset, U, d, M, V, dwte.data_ptr(), _p(dwpe), ws, _stream()),
                "mi_embed_tokens_bwd")
 
 

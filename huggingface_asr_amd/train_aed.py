@@ -303,7 +303,8 @@ class JointAEDTrainer:
             ops.gemm(hb16, W(wname), None, out=buf.view(M, Vp))
             lg = buf[..., :V]
             acc = torch.zeros((2,), device=dev, dtype=F32)
-            ops._lib.check(ops._lib.lib().mi_ce_label_smoothing(lg.data_ptr(), lg.stride(1), labels.data_ptr(), B, U, 1, V, lsm, acc.data_ptr(),
+            rows = torch.empty((B * (U - 1),), device=dev, dtype=F32)
+            ops._lib.check(ops._lib.lib().mi_ce_label_smoothing(lg.data_ptr(), lg.stride(1), labels.data_ptr(), B, U, 1, V, lsm, acc.data_ptr(), rows.data_ptr(),
                                                                  torch.cuda.current_stream().cuda_stream), "mi_ce_label_smoothing")
             dl = T.ce_label_smoothing_bwd(lg, labels, acc, shift=1, eps=lsm, weight=weight * gs, ldo=Vp)
             return lg, acc[0] / acc[1], dl

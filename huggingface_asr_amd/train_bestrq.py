@@ -103,7 +103,8 @@ class BestRQTrainer:
                 lg = buf[..., :self.C]
                 lab = tg[:, k].contiguous()
                 acc = torch.zeros((2,), device=dev, dtype=F32)
-                _lib.check(_lib.lib().mi_ce_label_smoothing(lg.data_ptr(), lg.stride(1), lab.data_ptr(), B, T2, 0, self.C, 0.0, acc.data_ptr(),
+                rows = torch.empty((B * T2,), device=dev, dtype=F32)
+                _lib.check(_lib.lib().mi_ce_label_smoothing(lg.data_ptr(), lg.stride(1), lab.data_ptr(), B, T2, 0, self.C, 0.0, acc.data_ptr(), rows.data_ptr(),
                                                             torch.cuda.current_stream().cuda_stream), "mi_ce_label_smoothing")
                 lk = acc[0] / self.nb                           # reduction="sum", then / num_books (bestrq.py:141-142)
                 loss = lk if loss is None else loss + lk

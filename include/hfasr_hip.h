@@ -240,8 +240,10 @@ int mi_ctc_prefix_score_full(const float* x, int B, int T, int O, int blank, int
  *           the shifted, label-smoothed CE of src/models/decoders/multi_head_gpt2.py:138-158. */
 int mi_embed_tokens(const long* ids, const float* wte, float scale, const float* pos, int pos_offset, int U, int d,
                     int M, int V, float* out, mi_stream_t stream);
+/* acc[0] += sum of the valid rows' losses, acc[1] += their count; row_loss: B * (U - shift) floats of workspace (the rows' losses, NaN where the target is ignored),
+ * summed by one block in a fixed order: no float atomics, the loss is bit-reproducible. */
 int mi_ce_label_smoothing(const float* logits, long ld, const long* labels, int B, int U, int shift, int V, float eps,
-                          float* acc, mi_stream_t stream);
+                          float* acc, float* row_loss, mi_stream_t stream);
 
 /* ---- training step: backward + optimizer building blocks.
  * replaces: torch autograd of the modules above under HF Trainer's bf16 autocast + torch.optim.AdamW + clip_grad_norm_
@@ -249,7 +251,11 @@ int mi_ce_label_smoothing(const float* logits, long ld, const long* labels, int 
  * Activations bf16, residual stream / parameter gradients fp32; parameter gradients ACCUMULATE (+=). */
 int mi_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int M, int N, int Mp, mi_stream_t stream);
 int mi_transpose_many_bf16(const void* descs, int count, mi_stream_t stream);   /* descs: device array of {const void* in; void* out; int M, N, Mp, pad;} */
-int mi_colsum(const void* x, long ld, int dtype, int M, int N, float* out, mi_stream_t stream);
+/* out[n] += sum_m x[m][n] (dtype 0 f32, 1 bf16).  workspace: mi_colsum_workspace_floats(M, N) floats — per-chunk column sums, added in chunk order by a second kernel.
+ * (Round 4: every parameter-gradient reduction of the training step is ordered — per-block partial rows + a fixed-order sum, csrc/common.hpp rows_reduce_kernel — so the
+ *  backward is bit-reproducible run to run; rounds 1-3 ended these sums in float atomics.) */
+size_t mi_colsum_workspace_floats(int M, int N);
+int mi_colsum(const void* x, long ld, int dtype, int M, int N, float* out, float* workspace, mi_stream_t stream);
 /* out (N) bf16 = column sums of x (M, N) f32, rows added in order (M small: the per-group partials of d(posp), train.py `_attention_bwd`) */
 int mi_colsum_cast_bf16(const float* x, long ld, int M, int N, void* out, mi_stream_t stream);
 /* out_a (N) += column sums of a (M, N), out_b (N) += column sums of b (M, N): fp32, rows added in a fixed order (the pos_bias_u / pos_bias_v gradients from the attention
@@ -297,7 +303,7 @@ int mi_mask_rows_f32(float* x, long ld, const int* lengths, int T, int M, int N,
 int mi_spec_mask_apply(float* x, long ld, const unsigned char* time_mask, const float* embed, const unsigned char* feat_mask, int T, int M, int N,
                        mi_stream_t stream);
 int mi_spec_mask_bwd(float* dx, long ld, const unsigned char* time_mask, float* dembed, const unsigned char* feat_mask, int T, int M, int N,
-                     mi_stream_t stream);
+                     float* workspace /* ceil(M / 128) * N floats when dembed is given */, mi_stream_t stream);
 /* ---- layer mixing of the CTC fine-tuning head — replaces src/models/bestrq.py:239-245
  *      (`(torch.stack(hidden_states) * softmax(per_layer_weights)[:, None, None, None]).sum(0)`) and its autograd backward.
  *  mi_softmax_vec_f32:      s = softmax(w), n <= 1024.        mi_softmax_vec_bwd_f32:  dw += s * (g - <s, g>)  (g_l = <d mixed, hidden_l>).
@@ -355,7 +361,8 @@ int mi_im2col_cl_bf16(const void* in, void* col, int B, int Tin, int Fin, int Ci
                       int pad_f, int Tout, int Fout, mi_stream_t stream);
 int mi_conv2d_first_bwd(const float* x, const float* w, const float* bias, const void* dcol, float* dw, float* db, int B, int T,
                         int F, int C, int K, int stride, int pad_t, int pad_f, int T1, int F1, int K2, int stride2, int pad2_t,
-                        int pad2_f, int T2, int F2, mi_stream_t stream);
+                        int pad2_f, int T2, int F2, float* workspace /* mi_conv2d_first_bwd_workspace_floats: one partial row per block */, mi_stream_t stream);
+size_t mi_conv2d_first_bwd_workspace_floats(int B, int C, int T1, int F1);
 /* backward pieces of the context-aware front ends (extractors.py:23-65), un-fused: im2col / col2im with separate strides, the backward of mi_gated_act_bf16
  * (dz = dout GELU'(y) sigmoid(g), dg = sum over the shared rows of dout GELU'(y) z sigmoid(g)(1 - sigmoid(g)), y = z sigmoid(g)), and the weight / bias gradient of a
  * Conv2d(1 -> C) of geometry (3,3) or (12,3) from the gradient of its raw output. */
@@ -366,7 +373,8 @@ int mi_col2im_cl_bf16(const void* dcol, void* din, int B, int Tin, int Fin, int 
 int mi_gated_act_bwd_bf16(const void* dout, long lddo, const void* z, long ldz, const void* g, long ldg, void* dz, long lddz, void* dg, long lddg,
                           int B, int T, int Fq, int C, int share, mi_stream_t stream);
 int mi_conv2d_first_wgrad(const float* x, const void* dy, float* dw, float* db, int B, int T, int F, int C, int KH, int KW, int stride_t, int stride_f,
-                          int pad_t, int pad_f, int T1, int F1, mi_stream_t stream);
+                          int pad_t, int pad_f, int T1, int F1, float* workspace /* mi_conv2d_first_wgrad_workspace_floats */, mi_stream_t stream);
+size_t mi_conv2d_first_wgrad_workspace_floats(int B, int C, int KH, int KW, int T1, int F1);
 /* loss gradients: F.ctc_loss backward composed with log_softmax (e_branchformer.py:472-488); label-smoothed CE of the decoder
  * heads (multi_head_gpt2.py:138-158); embedding scatter (embeddings.py:33-62) */
 size_t mi_ctc_bwd_workspace_bytes(int B, int T, int U);
@@ -375,8 +383,9 @@ int mi_ctc_loss_bwd(const void* logits, long ld_b, long ld_t, int dtype, const f
                     size_t workspace_bytes, void* dlogits, long ldo, mi_stream_t stream);
 int mi_ce_label_smoothing_bwd(const float* logits, long ld, const long* labels, int B, int U, int shift, int V, float eps,
                               float weight, const float* acc, void* dlogits, long ldo, mi_stream_t stream);
+/* as gathers (a block per vocabulary entry / position adds its rows in order: no atomics); workspace: V bytes (marks the entries that occur) or NULL; d <= 1024 */
 int mi_embed_tokens_bwd(const long* ids, const float* dx, float scale, int pos_offset, int U, int d, int M, int V, float* dwte,
-                        float* dwpe, mi_stream_t stream);
+                        float* dwpe, void* workspace, mi_stream_t stream);
 
 /* ---- feature-level SpecAugment on the device (src/augmentations/spec_aug.py:40-137: bicubic time warp + frequency / time masks) */
 int mi_specaug_f32(const float* x, float* out, int B, int T, int F, const int* params, int nf, int nt, float pad_value, mi_stream_t stream);

@@ -177,6 +177,72 @@ def test_config3_shape_joint_training_step_properties():
         assert abs(pad[k] - full[k]) < 2e-4 * abs(full[k]), (k, pad[k], full[k])
 
 
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_backward_is_bit_reproducible(dropout):
+    """VERDICT r3 item 4 / ADVICE r3 (medium): no parameter-gradient reduction of the training step ends in float atomics any more (bias, LayerNorm-affine, position-bias,
+    depthwise-conv, conv1, embedding and masked-embedding gradients, the CTC rows, the CE loss: per-block partial rows + a fixed-order sum), so the same state, batch and
+    dropout seed give the same gradient BITS twice — for the encoder + CTC step (small-encoder shapes: the grouped / 256-wide weight-gradient tiles, the K = 31 depthwise
+    kernels) and for the joint model (decoder store too: embedding gather, label-smoothed CE), and three AdamW steps later the weights are still equal."""
+    from huggingface_asr_amd import synth
+    from huggingface_asr_amd.train import EncoderCTCTrainer
+    from huggingface_asr_amd.train_aed import JointAEDTrainer
+    drops = dict(hidden_dropout=dropout, activation_dropout=dropout, attention_dropout=dropout, final_dropout=dropout, feat_proj_dropout=0.0,
+                 csgu_conv_dropout=dropout, layerdrop=0.0, apply_spec_augment=True, mask_time_prob=0.05, mask_time_length=4, mask_feature_prob=0.0)
+    cfg = dict(shapes.SMALL, position_embeddings_type="relative", ctc_zero_infinity=True, ctc_loss_reduction="mean", **drops)
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 0).items()}
+    B, T, U = 6, 420, 14
+    feats = torch.from_numpy(synth.normal(5, "feats", (B, T, 80), 1.0)).to(DEV)
+    lens = torch.tensor([420, 400, 333, 250, 411, 97], dtype=torch.int32, device=DEV)
+    labels = torch.from_numpy(synth.labels(5, B, U, cfg["vocab_size"])).to(DEV)
+    labels[:, 3] = labels[:, 1]                               # repeated labels: the CTC rows' chains
+    labels[2, 9:] = -100
+
+    def enc_run():
+        np.random.seed(11)                                    # the in-model SpecAugment masks are drawn on the host (numpy's global RNG, as the reference)
+        tr = EncoderCTCTrainer(cfg, DEV, lr=1e-3, seed=3)
+        tr.load_state_dict(sd)
+        tr.store.zero_grad()
+        o = tr.forward_backward(feats, lens, labels)
+        g = tr.store.flat_g.clone()
+        tr.optimizer_step()
+        for _ in range(2):
+            tr.store.zero_grad(); tr.forward_backward(feats, lens, labels); tr.optimizer_step()
+        torch.cuda.synchronize()
+        return float(o["loss"]), g, tr.store.flat_p.clone()
+    l0, g0, p0 = enc_run()
+    l1, g1, p1 = enc_run()
+    assert l0 == l1 and float(g0.abs().max()) > 0
+    assert torch.equal(g0, g1), f"{int((g0 != g1).sum())} of {g0.numel()} gradient elements differ between two runs (max {float((g0 - g1).abs().max()):.3e})"
+    assert torch.equal(p0, p1)
+
+    dcfg = dict(vocab_size=500, n_embd=256, n_layer=2, n_head=4, n_positions=64, head_locations=[], head_weights=[1.0], lsm_factor=0.1, layer_norm_epsilon=1e-5,
+                pos_emb_fixed=False, tie_word_embeddings=False, embd_pdrop=dropout, attn_pdrop=dropout, resid_pdrop=dropout)
+    jcfg = dict(ctc_weight=0.3, pad_token_id=3, decoder_start_token_id=1)
+    cfg2 = dict(cfg, vocab_size=500)
+    sd2 = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg2), 0).items()}
+    lab2 = torch.from_numpy(synth.labels(6, B, U, 500, lo=5)).to(DEV)
+    lab2[:, 5] = lab2[:, 2]
+    lab2[4, 7:] = -100
+
+    def aed_run():
+        np.random.seed(12)
+        tr = JointAEDTrainer(cfg2, dcfg, jcfg, DEV, lr=1e-3)
+        tr.enc.load_state_dict(sd2)
+        gen = torch.Generator().manual_seed(1)
+        for s_ in tr.store.specs.values():
+            tr.store.p(s_.name).copy_((torch.ones(s_.shape) if s_.name.endswith("_g") else torch.randn(s_.shape, generator=gen) * 0.02).to(DEV))
+        tr.store.refresh_mirrors(cast=True)
+        tr.enc.store.zero_grad(); tr.store.zero_grad()
+        o = tr.forward_backward(feats, lens, lab2)
+        torch.cuda.synchronize()
+        return float(o["loss"]), tr.enc.store.flat_g.clone(), tr.store.flat_g.clone()
+    a0, a1 = aed_run(), aed_run()
+    assert a0[0] == a1[0]
+    for x, y, what in ((a0[1], a1[1], "encoder"), (a0[2], a1[2], "decoder")):
+        assert float(x.abs().max()) > 0
+        assert torch.equal(x, y), f"{what} store: {int((x != y).sum())} of {x.numel()} gradient elements differ (max {float((x - y).abs().max()):.3e})"
+
+
 FINETUNE_CASES = ["finetune_tiny_mix_extra", "finetune_tiny_mix", "finetune_tiny_extra"]
 
 

@@ -570,7 +570,8 @@ def test_ce_and_embed_bwd():
     torch.testing.assert_close(rc_loss.cpu(), loss.detach(), atol=1e-4, rtol=1e-4)
     # the backward kernel reads the [sum, count] pair of the forward
     from huggingface_asr_amd import _lib
-    _lib.check(_lib.lib().mi_ce_label_smoothing(ld.data_ptr(), ld.stride(1), labels.to(DEV).data_ptr(), B, U, 1, V, 0.1, acc.data_ptr(),
+    rows = torch.empty(B * (U - 1), device=DEV)
+    _lib.check(_lib.lib().mi_ce_label_smoothing(ld.data_ptr(), ld.stride(1), labels.to(DEV).data_ptr(), B, U, 1, V, 0.1, acc.data_ptr(), rows.data_ptr(),
                                                 torch.cuda.current_stream().cuda_stream), "ce")
     dl = T.ce_label_smoothing_bwd(ld, labels.to(DEV), acc, shift=1, eps=0.1, weight=0.6)
     close(dl[:, :V].reshape(B, U, V), lg.grad, floor=5e-3, what="ce dlogits")
