@@ -10,7 +10,11 @@ The AED recipes do NOT only go through the registry, though: `src/utilities/mode
   * rebinds those names — in the defining modules (for importers that come later) and in every already-imported module of the reference tree
     that holds them (`utilities.model_utils`, `utilities.bind`, a trainer running as `__main__`, …) — to the HIP classes, and
   * registers the HIP decoder with the reference's `CustomModelForCausalLM`,
-so the reference's scripts run unchanged: `python -m huggingface_asr_amd.launch src/trainers/train_enc_dec_asr.py <recipe flags>`."""
+so the reference's scripts run unchanged: `python -m huggingface_asr_amd.launch src/trainers/train_enc_dec_asr.py <recipe flags>`.
+
+The Whisper branch (`model_utils.py:183` on a Whisper checkpoint, `decode_whisper_lumi.sh:60-66`) keeps HuggingFace's `WhisperForConditionalGeneration` — the trainer tests
+for that class (`train_enc_dec_asr.py:82-83`) — and gets the HIP encoder through `whisper.install_whisper()` (called by `bind_all()`): `WhisperEncoder.forward` is replaced,
+decoder / `generate` / checkpoints stay transformers' own."""
 import sys
 
 from transformers import AutoConfig, AutoFeatureExtractor, AutoModelForCTC, AutoModelForPreTraining, AutoModelForSpeechSeq2Seq
@@ -47,6 +51,8 @@ def bind_all():
     AutoModelForSpeechSeq2Seq.register(JointCTCAttentionEncoderDecoderConfig, JointCTCAttentionEncoderDecoder, exist_ok=True)
     AutoConfig.register("custom_feature_extractor", CustomFeatureExtractorConfig, exist_ok=True)
     AutoFeatureExtractor.register(CustomFeatureExtractorConfig, CustomFeatureExtractor, exist_ok=True)
+    from .whisper import install_whisper                          # the Whisper branch (model_utils.py:183 on a Whisper checkpoint): HF's classes, our encoder forward
+    install_whisper()
     ref_auto = sys.modules.get("models.auto_wrappers")          # the reference's own decoder registry (bind.py:48-49), when its tree is loaded
     if ref_auto is not None:
         ref_auto.CustomModelForCausalLM.register(GPT2MultiHeadConfig, GPT2LMMultiHeadModel, exist_ok=True)

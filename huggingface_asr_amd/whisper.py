@@ -132,3 +132,56 @@ class WhisperEncoderEngine:
         out = torch.empty((M, d), dtype=torch.float32, device=dev)
         ops.layernorm_chain(x, lna=w["lnf"], outa32=out)
         return out.view(B, T2, d)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# The Whisper branch of the reference (`src/utilities/model_utils.py:183`: `AutoModelForSpeechSeq2Seq.from_pretrained(...)` on a Whisper checkpoint, e.g.
+# `recipes_v0.0.1/decred/out_of_domain/decode_whisper_lumi.sh:60-66` `--from_pretrained=openai/whisper-medium --predict_with_generate`) runs HuggingFace's
+# `WhisperForConditionalGeneration` as it is, and `src/trainers/train_enc_dec_asr.py:82-83` tests `isinstance(model, WhisperForConditionalGeneration)` — so the class has
+# to stay HuggingFace's.  The drop-in is therefore a replacement of `WhisperEncoder.forward`: the encoder (the whole cost of config 4) runs on the HIP engine above, the
+# decoder, `generate`, the loss and the checkpoint format stay transformers' own.
+def _encoder_cfg(enc) -> dict:
+    c = enc.config
+    return dict(d_model=c.d_model, encoder_layers=c.encoder_layers, encoder_attention_heads=c.encoder_attention_heads, encoder_ffn_dim=c.encoder_ffn_dim)
+
+
+def _engine_for(enc) -> WhisperEncoderEngine:
+    """the HIP engine of a `WhisperEncoder` module: built at the first forward, rebuilt when a parameter was replaced, moved or written in place"""
+    params = list(enc.parameters())
+    key = (str(params[0].device), tuple((p.data_ptr(), p._version) for p in params))
+    cached = enc.__dict__.get("_hfasr_engine")
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    eng = WhisperEncoderEngine(_encoder_cfg(enc), params[0].device)
+    eng.load_state_dict(enc.state_dict())
+    enc.__dict__["_hfasr_engine"] = (key, eng)
+    return eng
+
+
+def hip_whisper_encoder_forward(self, input_features, attention_mask=None, **kwargs):
+    """`transformers.models.whisper.modeling_whisper.WhisperEncoder.forward` on the HIP engine (inference).  Everything the engine does not do RAISES — there is no PyTorch
+    path behind this function: training mode (dropout / LayerDrop / autograd through the encoder), attention or hidden-state outputs, head masks, CPU tensors."""
+    from transformers.modeling_outputs import BaseModelOutput
+    if self.training:
+        raise NotImplementedError("huggingface_asr_amd: the Whisper encoder is bound for inference (model.eval()); training through WhisperEncoder is not built on the HIP path")
+    cfg = self.config
+    want = {k: kwargs.get(k) for k in ("output_attentions", "output_hidden_states", "head_mask")}
+    if want["output_attentions"] or want["output_hidden_states"] or getattr(cfg, "output_attentions", False) or getattr(cfg, "output_hidden_states", False) \
+            or want["head_mask"] is not None:
+        raise NotImplementedError("huggingface_asr_amd: the HIP Whisper encoder returns last_hidden_state only (no attentions / hidden states / head masks)")
+    if not input_features.is_cuda:
+        raise RuntimeError("huggingface_asr_amd: the Whisper encoder runs on the HIP engine only — move the model and its inputs to a GPU (no CPU fallback)")
+    if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and input_features.requires_grad:
+        raise NotImplementedError("huggingface_asr_amd: no autograd through the HIP Whisper encoder")
+    out = _engine_for(self).forward(input_features=input_features)                       # (B, T/2, d) fp32; same length check / message as transformers
+    return BaseModelOutput(last_hidden_state=out.to(self.layer_norm.weight.dtype))
+
+
+def install_whisper():
+    """Give transformers' `WhisperEncoder` the HIP forward (idempotent).  The original stays reachable as `WhisperEncoder._hfasr_reference_forward` (tests compare against it)."""
+    from transformers.models.whisper import modeling_whisper as MW
+    if getattr(MW.WhisperEncoder.forward, "_hfasr_hip", False):
+        return
+    MW.WhisperEncoder._hfasr_reference_forward = MW.WhisperEncoder.forward
+    hip_whisper_encoder_forward._hfasr_hip = True
+    MW.WhisperEncoder.forward = hip_whisper_encoder_forward

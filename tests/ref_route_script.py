@@ -157,4 +157,33 @@ print("OK instantiate_ctc_model", type(mc).__module__)
 d = CustomModelForCausalLM.from_config(m1.config.decoder)
 assert isinstance(d, GPT2LMMultiHeadModel), type(d).__mro__
 print("OK CustomModelForCausalLM.from_config ->", type(d).__mro__[1].__module__)
+
+# the Whisper branch: model_utils.py:183 (`AutoModelForSpeechSeq2Seq.from_pretrained(model_path, config=config)`) on a Whisper checkpoint — what
+# recipes_v0.0.1/decred/out_of_domain/decode_whisper_lumi.sh:60-66 (`--from_pretrained=openai/whisper-medium`) reaches — keeps HuggingFace's class (the trainer tests
+# `isinstance(model, WhisperForConditionalGeneration)`, train_enc_dec_asr.py:82-83) and lands on the HIP encoder forward
+from transformers import WhisperConfig, WhisperForConditionalGeneration  # noqa: E402
+from transformers.models.whisper import modeling_whisper as MW  # noqa: E402
+wcfg = WhisperConfig(d_model=128, encoder_layers=2, decoder_layers=1, encoder_attention_heads=2, decoder_attention_heads=2, encoder_ffn_dim=256, decoder_ffn_dim=256,
+                     num_mel_bins=80, max_source_positions=50, max_target_positions=32, vocab_size=V, pad_token_id=3, bos_token_id=1, eos_token_id=2, decoder_start_token_id=1)
+wdir = os.path.join(WORK, "whisper")
+WhisperForConditionalGeneration(wcfg).save_pretrained(wdir)
+wconf = MU.AutoConfig.from_pretrained(wdir)                                   # :177, through the reference module's own names
+wm = MU.AutoModelForSpeechSeq2Seq.from_pretrained(wdir, config=wconf)         # :183
+assert type(wm) is WhisperForConditionalGeneration and isinstance(wm, MU.__dict__.get("WhisperForConditionalGeneration", WhisperForConditionalGeneration)), type(wm)
+fwd = type(wm.model.encoder).forward
+assert fwd.__module__ == "huggingface_asr_amd.whisper" and getattr(fwd, "_hfasr_hip", False), (fwd.__module__, fwd)
+assert MW.WhisperEncoder._hfasr_reference_forward.__module__.startswith("transformers")
+wm.eval()
+try:
+    wm.model.encoder(torch.zeros(1, 80, 100))
+    raise SystemExit("the HIP Whisper encoder accepted CPU tensors")
+except RuntimeError as e:
+    assert "no CPU fallback" in str(e), e
+wm.train()
+try:
+    wm.model.encoder(torch.zeros(1, 80, 100))
+    raise SystemExit("the HIP Whisper encoder accepted training mode")
+except NotImplementedError:
+    pass
+print("OK whisper branch (model_utils.py:183) ->", type(wm).__module__.split(".")[0], "class,", fwd.__module__, "encoder forward")
 print("ALL OK")

@@ -33,7 +33,8 @@ def test_reference_instantiate_functions_build_hip_models(tmp_path, order):
                  "instantiate_aed_model(from_encoder_decoder_pretrained) huggingface_asr_amd.modeling_joint.JointCTCAttentionEncoderDecoder",
                  "instantiate_aed_model(from_pretrained) huggingface_asr_amd.modeling_joint.JointCTCAttentionEncoderDecoder",
                  "instantiate_ctc_model huggingface_asr_amd.modeling_ebranchformer",
-                 "CustomModelForCausalLM.from_config -> huggingface_asr_amd.modeling_joint"):
+                 "CustomModelForCausalLM.from_config -> huggingface_asr_amd.modeling_joint",
+                 "whisper branch (model_utils.py:183) -> transformers class, huggingface_asr_amd.whisper encoder forward"):
         assert "OK " + what in out, out[-3000:]
 
 

@@ -149,3 +149,26 @@ def test_bestrq_classes_match_reference_parameter_list_and_registry():
     layer0 = {k[len("wav2vec2.encoder.layers.0."):]: tuple(v.shape) for k, v in plain.named_parameters() if k.startswith("wav2vec2.encoder.layers.0.")}
     assert added == {"per_layer_weights": (base["num_hidden_layers"] + 1,), **{"additional_layer." + k: v for k, v in layer0.items()}}
     assert ft.per_layer_weights.detach().tolist() == [0.0] * base["num_hidden_layers"] + [1.0]
+
+
+def test_whisper_branch_binding_without_a_gpu():
+    """`bind_all()` puts the HIP forward on transformers' WhisperEncoder (the class stays HuggingFace's: the reference's trainer tests for it, train_enc_dec_asr.py:82-83);
+    without device tensors, in training mode or with outputs the engine does not produce it raises instead of running PyTorch."""
+    import pytest
+    import torch
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+    from transformers.models.whisper import modeling_whisper as MW
+    from huggingface_asr_amd import bind
+    bind.bind_all(); bind.bind_all()                          # idempotent
+    assert MW.WhisperEncoder.forward.__module__ == "huggingface_asr_amd.whisper" and MW.WhisperEncoder._hfasr_reference_forward.__module__.startswith("transformers")
+    m = WhisperForConditionalGeneration(WhisperConfig(d_model=128, encoder_layers=1, decoder_layers=1, encoder_attention_heads=2, decoder_attention_heads=2,
+                                                      encoder_ffn_dim=128, decoder_ffn_dim=128, max_source_positions=20, max_target_positions=8, vocab_size=60,
+                                                      pad_token_id=0, bos_token_id=1, eos_token_id=2, decoder_start_token_id=1)).eval()
+    x = torch.zeros(1, 80, 40)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.model.encoder(x)
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m.model.encoder(x)
+    ref = MW.WhisperEncoder._hfasr_reference_forward(m.model.encoder.eval(), x)       # transformers' own forward is kept for comparisons
+    assert tuple(ref.last_hidden_state.shape) == (1, 20, 128)
