@@ -103,7 +103,7 @@ def rocprof_child_dense_us(args, B, per_step):
     steps = max(3, min(10, args.event_steps))
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
         cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", td, "--", sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", "2",
-               "--batch", str(B), "--pos", args.pos, "--streams", "1", "--no-cpu-baseline", "--no-kernel-events"]
+               "--batch", str(B), "--pos", args.pos, "--streams", "1", "--no-cpu-baseline", "--no-kernel-events", "--no-secondary"]
         try:
             r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
         except Exception as e:  # noqa: BLE001
@@ -187,6 +187,13 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo: tests with several ranks on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (tests on a one-GPU box; needs --backend gloo)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check on a box without GPUs: gloo, no HIP work, value null")
+    ap.add_argument("--secondary", default=None, choices=["whisper", "decode", "train"], help="run ONE bounded secondary measurement (config 4 / 5 / 3) on cuda:0 and print its "
+                                                                                                "JSON; the default run starts these as children after its timed region")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary records (configs 3, 4, 5) of the default single-GPU run")
+    ap.add_argument("--secondary-timeout", type=float, default=150.0, help="seconds allowed per secondary child")
+    ap.add_argument("--no-train-dp", action="store_true", help="more than one rank: skip the config-3 training step under both gradient all-reduce schedules")
+    ap.add_argument("--train-dp-batch", type=int, default=96, help="per-GPU batch of the `train_dp` record (config 3: 96)")
+    ap.add_argument("--train-dp-steps", type=int, default=5, help="timed steps per schedule of the `train_dp` record")
     args = ap.parse_args(argv)
     if args.wide_tiles is None:
         args.wide_tiles = int(args.streams >= 3)         # wide tiles leave one step alone with a quarter of the blocks per launch: they come with the lanes that fill the rest
@@ -221,10 +228,23 @@ def dry_run(args, world, rank):
         td.barrier(); td.destroy_process_group()
 
 
-def train_bench(args, world, rank, dev, PL):
-    """BASELINE config 3: one data-parallel training step of the joint CTC/attention model per rank shard (recipes_v0.0.1/librispeech_aed/train_small_baseline.sh:
-    small encoder + 6x256 GPT-2 decoder, ctc_weight 0.3, label smoothing 0.1, fixed positions, AdamW 2e-3 / wd 1e-6, per-GPU batch 96, clips 1-20 s sorted into the batch)."""
-    import torch.distributed as td
+def config3_gflop_per_step(cfg, dcfg, B, T2, U):
+    """algorithmic GFLOP of ONE training step at config 3's padded shape: 3 x (forward contractions) — forward, data gradient, weight gradient — of the Conv2d front end,
+    the encoder layers (as `algorithmic_gflop_per_utt`, at T' = T2), the CTC head and the decoder (self-attention over U tokens, cross-attention over T2 frames, MLP, lm_head)."""
+    d, I, L, V = cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"], cfg["vocab_size"]
+    C1, C2 = cfg["conv_dim"]
+    T1, F1, F2 = 2 * T2, 40, 20
+    mac = T1 * F1 * C1 * 9 + T2 * F2 * C2 * 9 * C1 + T2 * (F2 * C2) * d + T2 * d * d
+    mac += L * (2 * (2 * T2 * d * I) + 4 * T2 * d * d + (T2 * T2 * d) * 2 + T2 * (2 * T2 - 1) * d + T2 * d * I + T2 * (I // 2) * 31 + T2 * (I // 2) * d + T2 * 2 * d * 31
+                + T2 * 2 * d * d) + T2 * d * (V + 1)
+    dd, Ld, Vd = dcfg["n_embd"], dcfg["n_layer"], dcfg["vocab_size"]
+    mac += Ld * (U * dd * 3 * dd + 2 * U * U * dd + U * dd * dd + U * dd * dd + T2 * d * 2 * dd + 2 * U * T2 * dd + U * dd * dd + 8 * U * dd * dd) + U * dd * Vd
+    return 3.0 * 2.0 * mac * B / 1e9
+
+
+def build_config3(args, rank, dev, B, overlap):
+    """BASELINE config 3's trainer and one rank's shard (recipes_v0.0.1/librispeech_aed/train_small_baseline.sh: small encoder + 6x256 GPT-2 decoder, ctc_weight 0.3, label
+    smoothing 0.1, fixed positions, AdamW 2e-3 / wd 1e-6, per-GPU batch 96, clips 1-20 s sorted into the batch); seeded weights, the same on every rank."""
     from huggingface_asr_amd.train_aed import JointAEDTrainer
     pd = float(args.dropout)
     cfg = dict(shapes.SMALL, position_embeddings_type=args.pos, ctc_zero_infinity=True, ctc_loss_reduction="mean", hidden_dropout=pd, activation_dropout=pd,
@@ -233,10 +253,9 @@ def train_bench(args, world, rank, dev, PL):
     dcfg = dict(vocab_size=5000, n_embd=256, n_layer=6, n_head=4, n_positions=1024, head_locations=[], head_weights=[1.0], lsm_factor=0.1,
                 layer_norm_epsilon=1e-5, pos_emb_fixed=True, tie_word_embeddings=False, resid_pdrop=pd, embd_pdrop=pd, attn_pdrop=pd)
     jcfg = dict(ctc_weight=0.3, pad_token_id=3, decoder_start_token_id=1)
-    B = args.batch or 96
     tr = JointAEDTrainer(cfg, dcfg, jcfg, dev, lr=2e-3, weight_decay=1e-6)
     for sync in (tr.enc.sync, tr.sync):                     # the two parameter stores (encoder, decoder) each own their gradient all-reduce
-        sync.overlap = bool(args.overlap)
+        sync.overlap = bool(overlap)
     tr.enc.load_state_dict(sd)
     g = torch.Generator().manual_seed(1)
     for s_ in tr.store.specs.values():                      # seeded decoder weights straight into the packed store (same on every rank)
@@ -251,28 +270,22 @@ def train_bench(args, world, rank, dev, PL):
     labels = torch.from_numpy(synth.labels(rank, B, 60, cfg["vocab_size"], lo=5)).to(dev)
     for b in range(B):
         labels[b, max(2, int(fl[b] / 100 * 3)):] = -100
+    return tr, (feats, lens, labels), fl, cfg, dcfg
+
+
+def measure_config3(args, world, rank, dev, PL, B, overlap, steps, warmup):
+    """-> dict(ms_per_step, first_step_grad_norm, per_rank rows [ms, encoder checksum, decoder checksum], loss, audio seconds of this rank's shard, trainer, config dicts)"""
+    import torch.distributed as td
+    tr, (feats, lens, labels), fl, cfg, dcfg = build_config3(args, rank, dev, B, overlap)
     state = {}
 
     def one():
         state["o"] = tr.train_step(feats, lens, labels)
     one()                                                   # untimed first step from the seeded weights: its global gradient norm (deterministic reduction of the all-reduced
     first_norm = float(state["o"]["grad_norm"])             # gradients) identifies the step's gradients independently of the schedule
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         one()
-    dt = PL.timed(one, args.steps, sync=torch.cuda.synchronize, device=dev)
-    # the gradient all-reduce on its own: same buffers, same message sizes, timed on the compute stream (it runs after the backward by default)
-    ar_ms = None
-    if world > 1:
-        bufs = [tr.enc.store.flat_g, tr.store.flat_g]
-        for _ in range(3):
-            for b_ in bufs: td.all_reduce(b_)
-        torch.cuda.synchronize(); td.barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            for b_ in bufs: td.all_reduce(b_)
-        e1.record(); torch.cuda.synchronize()
-        ar_ms = round(e0.elapsed_time(e1) / 10, 3)
+    dt = PL.timed(one, steps, sync=torch.cuda.synchronize, device=dev)
     # per-rank view: every rank's own wall time per step and a checksum of its weights after the timed steps (replicas must stay bit-identical)
     t0 = time.perf_counter()
     for _ in range(3):
@@ -286,28 +299,193 @@ def train_bench(args, world, rank, dev, PL):
     else:
         per_rank = [buf]
     per_rank = [t.cpu() for t in per_rank]
+    return dict(dt=dt, ms_per_step=round(dt / steps * 1e3, 3), first_norm=first_norm, per_rank=per_rank, loss=float(state["o"]["loss"]), fl=fl, tr=tr, cfg=cfg, dcfg=dcfg)
+
+
+def all_reduce_alone_ms(tr, world):
+    """the step's gradient all-reduce on its own: same buffers, same message sizes, timed on the compute stream"""
+    import torch.distributed as td
+    if world <= 1:
+        return None
+    bufs = [tr.enc.store.flat_g, tr.store.flat_g]
+    for _ in range(3):
+        for b_ in bufs: td.all_reduce(b_)
+    torch.cuda.synchronize(); td.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        for b_ in bufs: td.all_reduce(b_)
+    e1.record(); torch.cuda.synchronize()
+    return round(e0.elapsed_time(e1) / 10, 3)
+
+
+def train_bench(args, world, rank, dev, PL):
+    """BASELINE config 3: one data-parallel training step of the joint CTC/attention model per rank shard."""
+    import torch.distributed as td
+    B = args.batch or 96
+    m = measure_config3(args, world, rank, dev, PL, B, args.overlap, args.steps, args.warmup)
+    tr, per_rank, fl, pd = m["tr"], m["per_rank"], m["fl"], float(args.dropout)
+    ar_ms = all_reduce_alone_ms(tr, world)
     if rank == 0:
         n_params = tr.store.n + tr.enc.store.n
         # every rank drew its own lengths; the job's audio = sum over ranks (same distribution): use this rank's sum x world
         sec = world * float(fl.sum()) / 100.0 * args.steps
-        print(json.dumps({"metric": "audio-seconds/sec, joint CTC/attention TRAINING step (fwd+bwd+AdamW), ED-small, DP", "value": round(sec / dt, 1),
+        gf = config3_gflop_per_step(m["cfg"], m["dcfg"], B, 500, 60)
+        print(json.dumps({"metric": "audio-seconds/sec, joint CTC/attention TRAINING step (fwd+bwd+AdamW), ED-small, DP", "value": round(sec / m["dt"], 1),
                           "unit": "audio-seconds/sec (un-padded audio)", "n_gpus": world, "rccl_ranks": td.get_world_size() if td.is_initialized() else 1,
                           "backend": td.get_backend() if td.is_initialized() else "none", "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                          "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                           "data": "synthetic",
                           "config": {"workload": "BASELINE config 3: small E-Branchformer encoder + 6x256 GPT-2 decoder, joint CTC/attention loss, AdamW; "
-                                                 f"{B} clips of 1-20 s per GPU padded to 2000 frames", "per_gpu_batch": B, "frames": T, "n_params": n_params, "dropout": pd,
+                                                 f"{B} clips of 1-20 s per GPU padded to 2000 frames", "per_gpu_batch": B, "frames": 2000, "n_params": n_params, "dropout": pd,
                                      "parallelism": f"dp{world}: SUM all-reduce of {n_params * 4 / 1e6:.0f} MB fp32 gradients after the backward",
-                                     "loss": round(float(state["o"]["loss"]), 4)},
+                                     "loss": round(m["loss"], 4)},
                           "schedule": "overlap: one async all-reduce per layer range, launched while the backward of the earlier layers runs" if args.overlap
                                       else "after-backward: one all-reduce per parameter store once the backward is done",
-                          "first_step_grad_norm": first_norm, "ms_per_step_by_rank": [round(float(t[0]), 3) for t in per_rank],
+                          "first_step_grad_norm": m["first_norm"], "ms_per_step_by_rank": [round(float(t[0]), 3) for t in per_rank],
                           "weights_checksum_by_rank": [[repr(float(t[1])), repr(float(t[2]))] for t in per_rank],
                           "replicas_identical": all(bool(torch.equal(t[1:], per_rank[0][1:])) for t in per_rank),
                           "all_reduce_ms": ar_ms, "all_reduce_note": "the step's gradient all-reduce timed on its own (same buffers), per step" if ar_ms else None,
+                          "model_gflop_per_step": round(gf, 1), "model_tflops_per_gpu": round(gf / (m["dt"] / args.steps) / 1e3, 1),
+                          "model_frac_of_bf16_peak": round(gf / (m["dt"] / args.steps) / 1e3 / PEAK_BF16_TFLOPS, 4),
                           "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)
     if world > 1:
         td.barrier(); td.destroy_process_group()
+
+
+def train_dp_record(args, world, rank, dev, PL):
+    """world > 1, inside the DEFAULT command: the config-3 training step under BOTH gradient all-reduce schedules of `GradSync` (0 = one collective per parameter store after
+    the backward; 1 = one async all-reduce per layer range, overlapped with the backward — what DDP's bucket hooks give the reference), each from the same seeded weights, so
+    that the run that measures the 1 -> N forward curve also exercises the 516-MB-class gradient all-reduce over RCCL.  Every rank takes part (collectives); rank 0 reports.
+    The backward has no float atomics (round 4): `first_step_grad_norm` and the weight checksums of the two schedules are comparable for EQUALITY."""
+    B = args.train_dp_batch
+    out = {"per_gpu_batch": B, "steps": args.train_dp_steps, "ms_per_step": [], "first_step_grad_norm": [], "replicas_identical": [], "weights_checksum_rank0": []}
+    ar = None
+    for ov in (0, 1):
+        m = measure_config3(args, world, rank, dev, PL, B, ov, args.train_dp_steps, 1)
+        out["ms_per_step"].append(m["ms_per_step"])
+        out["first_step_grad_norm"].append(m["first_norm"])
+        out["replicas_identical"].append(all(bool(torch.equal(t[1:], m["per_rank"][0][1:])) for t in m["per_rank"]))
+        out["weights_checksum_rank0"].append([repr(float(m["per_rank"][0][1])), repr(float(m["per_rank"][0][2]))])
+        if ov == 0:
+            ar = all_reduce_alone_ms(m["tr"], world)
+            out["n_params"] = m["tr"].store.n + m["tr"].enc.store.n
+        del m
+        torch.cuda.empty_cache()
+    out["all_reduce_ms"] = ar
+    out["schedules_agree"] = out["first_step_grad_norm"][0] == out["first_step_grad_norm"][1] and out["weights_checksum_rank0"][0] == out["weights_checksum_rank0"][1]
+    out["schedules"] = ["after-backward: one all-reduce per parameter store", "overlap: one async all-reduce per layer range during the backward"]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------ secondary records (configs 3, 4, 5)
+def secondary(name, args):
+    """One bounded measurement of another BASELINE.json config on cuda:0, as its own process (`bench.py --secondary NAME`, started by the default run after its timed region:
+    whatever happens here cannot take the headline line down).  Prints one JSON line."""
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from huggingface_asr_amd import parallel as PL
+    if name == "whisper":                                    # config 4: Whisper-small encoder, 16 x 30 s, log-mel on the device
+        from huggingface_asr_amd.whisper import WhisperEncoderEngine, WhisperFrontend
+        d, F, Bw = 768, 3072, 16
+        sd = {}
+        for n, shp in [("conv1.weight", (d, 80, 3)), ("conv1.bias", (d,)), ("conv2.weight", (d, d, 3)), ("conv2.bias", (d,)), ("embed_positions.weight", (1500, d)),
+                       ("layer_norm.weight", (d,)), ("layer_norm.bias", (d,))]:
+            sd[n] = torch.from_numpy(synth.init_param(0, n, shp))
+        for l in range(12):
+            for n, shp in [("self_attn_layer_norm.weight", (d,)), ("self_attn_layer_norm.bias", (d,)), ("self_attn.q_proj.weight", (d, d)), ("self_attn.q_proj.bias", (d,)),
+                           ("self_attn.k_proj.weight", (d, d)), ("self_attn.v_proj.weight", (d, d)), ("self_attn.v_proj.bias", (d,)), ("self_attn.out_proj.weight", (d, d)),
+                           ("self_attn.out_proj.bias", (d,)), ("final_layer_norm.weight", (d,)), ("final_layer_norm.bias", (d,)), ("fc1.weight", (F, d)), ("fc1.bias", (F,)),
+                           ("fc2.weight", (d, F)), ("fc2.bias", (d,))]:
+                sd[f"layers.{l}.{n}"] = torch.from_numpy(synth.init_param(0, f"layers.{l}.{n}", shp))
+        eng = WhisperEncoderEngine(dict(d_model=d, encoder_layers=12, encoder_attention_heads=12, encoder_ffn_dim=F), dev)
+        eng.load_state_dict(sd)
+        wave = torch.from_numpy(synth.waveforms(5, Bw, 480000)).to(dev)
+        fe = WhisperFrontend(80)
+
+        def step():
+            _, cl = fe(wave, want_features=False)
+            return eng.forward(features_cl=cl)
+        for _ in range(3): step()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(8): step()
+        torch.cuda.synchronize(); dt1 = (time.perf_counter() - t0) / 8
+        streams = [torch.cuda.Stream() for _ in range(3)]
+
+        def run(n):
+            for j in range(n):
+                with torch.cuda.stream(streams[j % 3]):
+                    step()
+        run(6); torch.cuda.synchronize(); t0 = time.perf_counter(); run(18); torch.cuda.synchronize(); dt3 = (time.perf_counter() - t0) / 18
+        gf = 2.0 * Bw * 1500 * (12 * (4 * d * d + 2 * d * F + 2 * 1500 * d) + 3 * d * d + 2 * 3 * 80 * d) / 1e9
+        return {"config": "BASELINE config 4: Whisper-small encoder (12 x 768, 12 heads, FFN 3072) + log-mel, 16 x 30 s per step, bf16, random weights", "ms_per_step": round(dt1 * 1e3, 3),
+                "value": round(Bw * 30 / dt1, 1), "unit": "audio-seconds/sec", "three_batches_in_flight_ms_per_step": round(dt3 * 1e3, 3),
+                "three_batches_in_flight_value": round(Bw * 30 / dt3, 1), "model_tflops": round(gf / dt1 / 1e3, 1), "model_frac_of_bf16_peak": round(gf / dt1 / 1e3 / PEAK_BF16_TFLOPS, 4)}
+    if name == "decode":                                     # config 5: DeCRED_base-shaped joint model, bs = 1, one 10 s clip, 40 tokens
+        from huggingface_asr_amd.decoder import JointAEDEngine, generate
+        enc_cfg = dict(shapes.BASE, vocab_size=5000, ctc_zero_infinity=True, ctc_loss_reduction="mean")
+        D, V = 512, 5001
+        dec_cfg = dict(vocab_size=V, n_embd=D, n_layer=8, n_head=8, n_positions=256, head_locations=[5], head_weights=[0.4, 0.6], lsm_factor=0.1, pos_emb_fixed=True)
+        jcfg = dict(ctc_weight=0.3, pad_token_id=5000, decoder_start_token_id=2)
+        sd = {"encoder." + k: torch.from_numpy(synth.init_param(0, "encoder." + k, shp)) for k, shp in shapes.param_shapes(enc_cfg).items()}
+
+        def P(n, shp):
+            sd[n] = torch.from_numpy(synth.init_param(0, n, shp))
+        P("decoder.transformer.wte.emb_layers.0.weight", (V, D))
+        for l in range(8):
+            for n, shp in [("ln_1.weight", (D,)), ("ln_1.bias", (D,)), ("attn.c_attn.weight", (D, 3 * D)), ("attn.c_attn.bias", (3 * D,)), ("attn.c_proj.weight", (D, D)),
+                           ("attn.c_proj.bias", (D,)), ("ln_cross_attn.weight", (D,)), ("ln_cross_attn.bias", (D,)), ("crossattention.q_attn.weight", (D, D)),
+                           ("crossattention.q_attn.bias", (D,)), ("crossattention.c_attn.weight", (D, 2 * D)), ("crossattention.c_attn.bias", (2 * D,)),
+                           ("crossattention.c_proj.weight", (D, D)), ("crossattention.c_proj.bias", (D,)), ("ln_2.weight", (D,)), ("ln_2.bias", (D,)),
+                           ("mlp.c_fc.weight", (D, 4 * D)), ("mlp.c_fc.bias", (4 * D,)), ("mlp.c_proj.weight", (4 * D, D)), ("mlp.c_proj.bias", (D,))]:
+                P(f"decoder.transformer.h.{l}.{n}", shp)
+        P("decoder.transformer.ln_f.weight", (D,)); P("decoder.transformer.ln_f.bias", (D,))
+        P("decoder.lm_head.weight", (V, D)); P("decoder.additional_lm_heads.0.weight", (V, D))
+        eng = JointAEDEngine(enc_cfg, dec_cfg, jcfg, dev)
+        eng.load_state_dict(sd)
+        wave = torch.from_numpy(synth.waveforms(1, 1, 160000)).to(dev)
+        tb = FB.FbankTables(80)
+        rec = {"config": "BASELINE config 5: DeCRED_base-shaped joint model (E-Branchformer-base + 8 x 512 GPT-2, auxiliary head), bs = 1, one 10 s clip, device-resident "
+                         "decoding loop, joint CTC / attention scoring (ctc_weight 0.3), 40 tokens (random weights: fixed-length decode)"}
+        feats, frames = FB.fbank_gpu(wave, tb, pad_frames_to=100)
+        for W, key in ((1, "greedy"), (5, "beam5")):
+            best, n = 1e9, 0
+            for _ in range(4):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                feats, frames = FB.fbank_gpu(wave, tb, pad_frames_to=100)
+                out = generate(eng, feats, frames, num_beams=W, max_length=40, ctc_weight=0.3, eos_token_id=1)
+                torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+                n = len(out[0]["tokens"])
+            rec[key + "_end_to_end_ms"] = round(best * 1e3, 2)
+            rec[key + "_tokens"] = n
+            rec[key + "_ms_per_token_incl_encoder"] = round(best * 1e3 / max(n - 1, 1), 3)
+        return rec
+    if name == "train":                                      # config 3 on one GPU (the data-parallel form is `bench.py --train --gpus N`)
+        m = measure_config3(args, 1, 0, dev, PL, 96, 0, 5, 2)
+        gf = config3_gflop_per_step(m["cfg"], m["dcfg"], 96, 500, 60)
+        sec = float(m["fl"].sum()) / 100.0
+        return {"config": "BASELINE config 3 on one GPU: small E-Branchformer encoder + 6x256 GPT-2 decoder, joint CTC/attention loss, fwd + bwd + AdamW, 96 clips of 1-20 s "
+                          f"padded to 2000 frames, dropout {args.dropout}", "ms_per_step": m["ms_per_step"], "value": round(sec / (m["dt"] / 5), 1),
+                "unit": "audio-seconds/sec (un-padded audio)", "model_gflop_per_step": round(gf, 1), "model_tflops": round(gf / (m["dt"] / 5) / 1e3, 1),
+                "model_frac_of_bf16_peak": round(gf / (m["dt"] / 5) / 1e3 / PEAK_BF16_TFLOPS, 4), "loss": round(m["loss"], 4)}
+    raise SystemExit(f"bench.py: unknown --secondary {name}")
+
+
+def run_secondaries(args):
+    """configs 4, 5 and 3 as child processes after the timed region (each bounded by a timeout; a failure becomes an `error` entry, never an exception here)"""
+    import subprocess
+    out = {}
+    for name in ("whisper", "decode", "train"):
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--secondary", name, "--pos", args.pos], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                               timeout=args.secondary_timeout, env=dict(os.environ))
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            out[name] = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": f"rc={r.returncode}: " + (r.stderr.strip().splitlines()[-1][:200] if r.stderr.strip() else "no output")}
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        out[name]["wall_s"] = round(time.perf_counter() - t0, 1)
+    return out
 
 
 def main():
@@ -316,6 +494,11 @@ def main():
     from huggingface_asr_amd.pipeline import reserve_hw_queues
     hwq = 4 if args.train else reserve_hw_queues(args.streams)          # before the first HIP call of this process (and inherited by the ranks it starts)
     in_torchrun = "WORLD_SIZE" in os.environ
+    if args.secondary:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py --secondary: no GPU visible (HIP-only path)")
+        print(json.dumps(secondary(args.secondary, args)), flush=True)
+        return
     if not in_torchrun and args.gpus > 1:
         sys.exit(launch_ranks(args))
     world, rank, local = PL.env_world()
@@ -458,9 +641,29 @@ def main():
             "roofline": roof,
         }
         rec["model_tflops_per_gpu"] = round(rec["config"]["algorithmic_gflop_per_audio_s"] * rec["value"] / world / 1e3, 2)
+        # flat copies of what `config` nests (a reader of the parsed line sees the headline's mode and the single-step latency beside it: ADVICE r3)
+        rec["mode"] = f"throughput: {nstr} independent steps in flight on {nstr} HIP streams" if nstr > 1 else "one step at a time"
+        rec["steps_in_flight"] = nstr
+        rec["one_step_ms"] = single["ms_per_step"] if single else rec["ms_per_step"]
+        rec["one_step_value"] = single["value"] if single else rec["value"]
         rec["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(cfg, sd)
+    train_dp = None
+    if world > 1 and not args.no_train_dp:                   # every rank: the config-3 training step under both GradSync schedules (collectives over the same process group)
+        del pipe, eng, batches
+        torch.cuda.empty_cache()
+        try:
+            train_dp = train_dp_record(args, world, rank, dev, PL)
+        except Exception as e:  # noqa: BLE001 — the headline line must come out
+            train_dp = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if rank == 0:
+        rec["train_dp"] = train_dp
+        rec["secondary"] = None
+        if world == 1 and not args.no_secondary:
+            del pipe
+            torch.cuda.empty_cache()
+            rec["secondary"] = run_secondaries(args)
         print(json.dumps(rec), flush=True)
     if dist:
         td.barrier()

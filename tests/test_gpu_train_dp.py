@@ -160,3 +160,26 @@ def test_bench_train_entry_point_both_schedules_identical_weights():
     # makes `--overlap 1` on real RCCL a yes / no question: any co-residency corruption of a gradient, however small, shows as an inequality here.
     assert recs[0]["first_step_grad_norm"] == recs[1]["first_step_grad_norm"], (recs[0]["first_step_grad_norm"], recs[1]["first_step_grad_norm"])
     assert recs[0]["weights_checksum_by_rank"] == recs[1]["weights_checksum_by_rank"], (recs[0]["weights_checksum_by_rank"], recs[1]["weights_checksum_by_rank"])
+
+
+def test_default_bench_command_carries_train_dp_when_it_runs_on_more_than_one_rank():
+    """the command the driver runs for the scaling curve (`bench.py --gpus N`, the forward replica bench) also runs, at N > 1, the config-3 training step
+    under BOTH gradient all-reduce schedules and reports it as `train_dp` — so the first multi-GPU run exercises the gradient all-reduce without a second invocation.  Here:
+    two ranks sharing the box's one GPU over gloo, small batches.  The schedules must agree bit for bit (no float atomics in the backward), replicas must be identical."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--streams", "1", "--train-dp-batch", "4", "--train-dp-steps", "2", "--no-kernel-events"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HFASR_DP_OVERLAP="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["value"] > 0
+    assert rec["one_step_ms"] > 0 and rec["one_step_value"] > 0 and rec["steps_in_flight"] == 1          # flat keys beside `value`
+    dp = rec["train_dp"]
+    assert dp is not None and "error" not in dp, dp
+    assert len(dp["ms_per_step"]) == 2 and all(v > 0 for v in dp["ms_per_step"]) and dp["all_reduce_ms"] is not None
+    assert dp["replicas_identical"] == [True, True] and dp["schedules_agree"] is True, dp
+    assert dp["first_step_grad_norm"][0] == dp["first_step_grad_norm"][1] > 0
+    assert rec["secondary"] is None                            # configs 3-5 ride the single-GPU line only
