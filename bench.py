@@ -410,13 +410,15 @@ def secondary(name, args):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(8): step()
         torch.cuda.synchronize(); dt1 = (time.perf_counter() - t0) / 8
-        streams = [torch.cuda.Stream() for _ in range(3)]
+        dt3 = dt1
+        if args.streams > 1:                                 # (`--secondary whisper --streams 1`: one batch at a time only — what a kernel trace of this command should show)
+            streams = [torch.cuda.Stream() for _ in range(3)]
 
-        def run(n):
-            for j in range(n):
-                with torch.cuda.stream(streams[j % 3]):
-                    step()
-        run(6); torch.cuda.synchronize(); t0 = time.perf_counter(); run(18); torch.cuda.synchronize(); dt3 = (time.perf_counter() - t0) / 18
+            def run(n):
+                for j in range(n):
+                    with torch.cuda.stream(streams[j % 3]):
+                        step()
+            run(6); torch.cuda.synchronize(); t0 = time.perf_counter(); run(18); torch.cuda.synchronize(); dt3 = (time.perf_counter() - t0) / 18
         gf = 2.0 * Bw * 1500 * (12 * (4 * d * d + 2 * d * F + 2 * 1500 * d) + 3 * d * d + 2 * 3 * 80 * d) / 1e9
         return {"config": "BASELINE config 4: Whisper-small encoder (12 x 768, 12 heads, FFN 3072) + log-mel, 16 x 30 s per step, bf16, random weights", "ms_per_step": round(dt1 * 1e3, 3),
                 "value": round(Bw * 30 / dt1, 1), "unit": "audio-seconds/sec", "three_batches_in_flight_ms_per_step": round(dt3 * 1e3, 3),
