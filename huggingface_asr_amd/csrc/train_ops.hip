@@ -114,21 +114,35 @@ __global__ __launch_bounds__(256) void colsum_cast_kernel(const float* __restric
     }
 }
 
-// out_a[n] += sum_m a[m][n], out_b[n] += sum_m b[m][n]: two partial-sum matrices of the same shape (a few hundred rows), rows added in order by the column's thread —
-// the position-bias gradients from the attention backward's per-wave partials, without atomics (deterministic) and in one launch
+// out_a[n] += sum_m a[m][n], out_b[n] += sum_m b[m][n]: two partial-sum matrices of the same shape (a few hundred to a few thousand rows of row stride ld) — the position-bias
+// gradients from the attention backward's per-wave partials, without atomics (deterministic) and in one launch.  Block = 16 columns x 16 row groups (round 4: a thread per
+// column walking ALL rows alone left 2 x N / 256 blocks on the chip — 169 us per call at config 3's 1536 rows x 256 columns, 4 % of that step).
 __global__ __launch_bounds__(256) void colsum2_acc_kernel(const float* __restrict__ a, const float* __restrict__ b, long ld, int M, int N,
                                                            float* __restrict__ out_a, float* __restrict__ out_b) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    const float* src = blockIdx.y ? b : a;
+    __shared__ float red[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int n = blockIdx.x * 16 + tx;
+    const float* src = (blockIdx.y ? b : a) + n;
     float* dst = blockIdx.y ? out_b : out_a;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                      // four rows in flight; combined in a fixed order
-    int m = 0;
-    for (; m + 4 <= M; m += 4) {
-        s0 += src[(long)m * ld + n]; s1 += src[(long)(m + 1) * ld + n]; s2 += src[(long)(m + 2) * ld + n]; s3 += src[(long)(m + 3) * ld + n];
+    float s = 0.f;
+    if (n < N) {
+        int m = ty;
+        for (; m + 7 * 16 < M; m += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(long)(m + 16 * u) * ld];
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; m < M; m += 16) s += src[(long)m * ld];
     }
-    for (; m < M; ++m) s0 += src[(long)m * ld + n];
-    dst[n] += (s0 + s1) + (s2 + s3);
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][tx];
+        dst[n] += t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ activations
@@ -636,7 +650,7 @@ extern "C" int mi_colsum(const void* x, long ld, int dtype, int M, int N, float*
 extern "C" int mi_colsum2_acc_f32(const float* a, const float* b, long ld, int M, int N, float* out_a, float* out_b, hipStream_t st) {
     MI_ENTER();
     if (M <= 0 || N <= 0 || !a || !b || !out_a || !out_b) return MI_ERR_ARG;
-    hipLaunchKernelGGL(colsum2_acc_kernel, dim3(cdiv(N, 256), 2), dim3(256), 0, st, a, b, ld, M, N, out_a, out_b);
+    hipLaunchKernelGGL(colsum2_acc_kernel, dim3(cdiv(N, 16), 2), dim3(256), 0, st, a, b, ld, M, N, out_a, out_b);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
