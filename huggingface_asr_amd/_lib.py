@@ -136,7 +136,8 @@ SIGNATURES = {
     "mi_ctc_bwd_workspace_bytes": [i32, i32, i32],
     "mi_ctc_loss_bwd": [vp, i64, i64, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, f32, vp, sz, vp, i64, vp],
     "mi_ce_label_smoothing_bwd": [vp, i64, vp, i32, i32, i32, i32, f32, f32, vp, vp, i64, vp],
-    "mi_embed_tokens_bwd": [vp, vp, f32, i32, i32, i32, i32, i32, vp, vp, vp, vp],
+    "mi_embed_tokens_bwd": [vp, vp, f32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp],
+    "mi_embed_tokens_bwd_workspace_bytes": [i32, i32, i32],
     "mi_specaug_f32": [vp, vp, i32, i32, i32, vp, i32, i32, f32, vp],
     "mi_speed_resample_f32": [vp, i64, vp, i32, i32, i32, i32, vp, i32, vp, i64, i32, vp, vp],
     "mi_rpq_targets": [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp],
@@ -176,7 +177,7 @@ def lib():
             fn = getattr(h, name)          # AttributeError here = header/library mismatch: fail loudly
             fn.argtypes = args
             fn.restype = sz if name in ("mi_ebf_workspace_bytes", "mi_ctc_bwd_workspace_bytes", "mi_gemm_tn_workspace_bytes", "mi_layernorm_bwd_workspace_floats",
-                                          "mi_colsum_workspace_floats", "mi_conv2d_first_bwd_workspace_floats", "mi_conv2d_first_wgrad_workspace_floats",
+                                          "mi_colsum_workspace_floats", "mi_conv2d_first_bwd_workspace_floats", "mi_conv2d_first_wgrad_workspace_floats", "mi_embed_tokens_bwd_workspace_bytes",
                                           "mi_gpt2_step_workspace_bytes") else i32
         h.mi_profile_create.argtypes = [i32]; h.mi_profile_create.restype = i32
         h.mi_profile_enable.argtypes = [i32]; h.mi_profile_enable.restype = None

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
 // thread t adds the matching rows' columns t, t + 256, ... to the entry's accumulator in row order.  (A block per entry scanning all ids itself: 0.79 ms at config 3.)
 constexpr int EW_IDS = 16;
 __global__ __launch_bounds__(256) void embed_bwd_wte_kernel(const long* __restrict__ ids, const float* __restrict__ dx, float scale, int d, int M, int V,
-                                                             float* __restrict__ dwte, const unsigned char* __restrict__ used) {
+                                                             float* __restrict__ dwte, const unsigned char* __restrict__ used, int heavy_id) {
     const int v0 = blockIdx.x * EW_IDS;
     __shared__ int hit_m[256];
     __shared__ unsigned char hit_v[256];
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void embed_bwd_wte_kernel(const long* __restri
     for (int m0 = 0; m0 < M; m0 += 256) {
         const int m = m0 + threadIdx.x;
         const long id = m < M ? ids[m] : -1;
-        const bool match = id >= v0 && id < v0 + EW_IDS && id < V;
+        const bool match = id >= v0 && id < v0 + EW_IDS && id < V && id != heavy_id;
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(match);
         __syncthreads();                                      // the previous chunk's hits have been consumed
         if ((threadIdx.x & 63) == 0) wcount[threadIdx.x >> 6] = __builtin_popcountll(bal);
@@ -390,6 +390,23 @@ __global__ __launch_bounds__(256) void embed_bwd_wte_kernel(const long* __restri
         for (int j = 0; j < 4; ++j) { const int c = threadIdx.x + 256 * j; if (c < d && acc[e][j] != 0.f) dwte[(long)(v0 + e) * d + c] += scale * acc[e][j]; }
     }
 }
+// The ONE entry that takes a large share of the rows — the padding token the shifted decoder input is filled with (thousands of rows at config 3) — is not gathered by one
+// block (a sequential walk over its rows: 1 ms) but summed as a masked column sum: block (64 columns, 128-row chunk) leaves a partial row, rows_reduce_kernel adds the chunks
+// in order.
+__global__ __launch_bounds__(256) void embed_bwd_heavy_kernel(const long* __restrict__ ids, const float* __restrict__ dx, int d, int M, long heavy_id, float* __restrict__ partial) {
+    __shared__ float part[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const int m0 = blockIdx.y * 128, m1 = min(M, m0 + 128);
+    float s = 0.f;
+    if (c < d)
+        for (int m = m0 + ty; m < m1; m += 4)
+            if (ids[m] == heavy_id) s += dx[(long)m * d + c];
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < d) partial[(long)blockIdx.y * d + c] = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
+}
+struct EmitScaled { float* out; float scale; __device__ void operator()(int i, float v) const { out[i] += scale * v; } };
 __global__ __launch_bounds__(256) void embed_bwd_mark_kernel(const long* __restrict__ ids, int M, int V, unsigned char* __restrict__ used) {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m < M) { const long id = ids[m]; if (id >= 0 && id < V) used[id] = 1; }      // same value from every writer: no race to lose
@@ -453,19 +470,26 @@ extern "C" int mi_ce_label_smoothing_bwd(const float* logits, long ld, const lon
     return MI_OK;
 }
 
-// workspace: V bytes (which vocabulary entries occur: the others' blocks return at once), or NULL (every entry's block scans the ids)
+// workspace: mi_embed_tokens_bwd_workspace_bytes(M, d, V) bytes (which vocabulary entries occur + the heavy entry's per-chunk partial rows).
+// heavy_id >= 0: a vocabulary entry expected on a large share of the rows (the decoder input's padding token); -1: none.
+extern "C" size_t mi_embed_tokens_bwd_workspace_bytes(int M, int d, int V) { return (((size_t)V + 255) / 256) * 256 + (size_t)cdiv(M, 128) * (size_t)d * sizeof(float); }
 extern "C" int mi_embed_tokens_bwd(const long* ids, const float* dx, float scale, int pos_offset, int U, int d, int M, int V, float* dwte,
-                                   float* dwpe, void* workspace, hipStream_t st) {
+                                   float* dwpe, int heavy_id, void* workspace, hipStream_t st) {
     MI_ENTER();
-    if (M <= 0 || d <= 0 || U <= 0 || V <= 0 || d > 1024) return MI_ERR_ARG;
+    if (M <= 0 || d <= 0 || U <= 0 || V <= 0 || d > 1024 || !workspace || heavy_id >= V) return MI_ERR_ARG;
     unsigned char* used = (unsigned char*)workspace;
-    if (used) {
-        if (hipMemsetAsync(used, 0, (size_t)V, st) != hipSuccess) return MI_ERR_LAUNCH;
-        hipLaunchKernelGGL(embed_bwd_mark_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, ids, M, V, used);
+    float* partial = reinterpret_cast<float*>(used + (((size_t)V + 255) / 256) * 256);
+    if (hipMemsetAsync(used, 0, (size_t)V, st) != hipSuccess) return MI_ERR_LAUNCH;
+    hipLaunchKernelGGL(embed_bwd_mark_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, ids, M, V, used);
+    MI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(embed_bwd_wte_kernel, dim3((unsigned)cdiv(V, EW_IDS)), dim3(256), 0, st, ids, dx, scale, d, M, V, dwte, used, heavy_id);
+    MI_CHECK_LAUNCH();
+    if (heavy_id >= 0) {
+        hipLaunchKernelGGL(embed_bwd_heavy_kernel, dim3(cdiv(d, 64), cdiv(M, 128)), dim3(256), 0, st, ids, dx, d, M, (long)heavy_id, partial);
+        MI_CHECK_LAUNCH();
+        rows_reduce_launch(partial, cdiv(M, 128), d, EmitScaled{dwte + (long)heavy_id * d, scale}, st);
         MI_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(embed_bwd_wte_kernel, dim3((unsigned)cdiv(V, EW_IDS)), dim3(256), 0, st, ids, dx, scale, d, M, V, dwte, used);
-    MI_CHECK_LAUNCH();
     if (dwpe) {
         hipLaunchKernelGGL(embed_bwd_wpe_kernel, dim3((unsigned)(U < M ? U : M)), dim3(256), 0, st, dx, pos_offset, U, d, M, dwpe);
         MI_CHECK_LAUNCH();

@@ -499,14 +499,16 @@ def ce_label_smoothing_bwd(logits, labels, acc, *, shift=1, eps=0.0, weight=1.0,
     return out
 
 
-def embed_tokens_bwd(ids, dx, dwte, dwpe=None, *, scale=1.0, pos_offset=0):
+def embed_tokens_bwd(ids, dx, dwte, dwpe=None, *, scale=1.0, pos_offset=0, heavy_id=None):
+    """dwte[ids[m]] += scale * dx[m]; dwpe[pos_offset + m % U] += dx[m].  heavy_id: a token expected on a large share of the rows (the padding token the shifted decoder
+    input is filled with): summed as a masked column sum instead of one block's walk over its rows."""
     ids = ids.contiguous()
     M = ids.numel()
     U = ids.shape[-1]
     V, d = dwte.shape
-    ws = _dw_ws(dx.device, (V + 3) // 4)                      # V bytes: which vocabulary entries occur
-    _lib.check(_L().mi_embed_tokens_bwd(ids.data_ptr(), dx.data_ptr(), float(scale), pos_offset, U, d, M, V, dwte.data_ptr(), _p(dwpe), ws, _stream()),
-               "mi_embed_tokens_bwd")
+    ws = _dw_ws(dx.device, (int(_L().mi_embed_tokens_bwd_workspace_bytes(M, d, V)) + 3) // 4)
+    _lib.check(_L().mi_embed_tokens_bwd(ids.data_ptr(), dx.data_ptr(), float(scale), pos_offset, U, d, M, V, dwte.data_ptr(), _p(dwpe),
+                                        int(heavy_id) if (heavy_id is not None and 0 <= int(heavy_id) < V) else -1, ws, _stream()), "mi_embed_tokens_bwd")
 
 
 def softmax_vec(w, out=None):

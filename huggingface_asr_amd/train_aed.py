@@ -366,7 +366,7 @@ class JointAEDTrainer:
             T.axpy_(dx, tap_grads[0])
         if pe > 0:
             T.dropout_(dx, pe, seed, sid(63, 0))
-        T.embed_tokens_bwd(ids, dx, G("wte"), None if self.pos_fixed is not None else G("wpe"), scale=self.emb_scale)
+        T.embed_tokens_bwd(ids, dx, G("wte"), None if self.pos_fixed is not None else G("wpe"), scale=self.emb_scale, heavy_id=self.jcfg.get("pad_token_id"))
         if self.with_proj:
             dh = T.linear_bwd(T.add_cast(denc), hb, WT("proj_w"), dw=G("proj_w"), db=G("proj_b"), dx_dtype=F32, defer=tnb)
         else:

@@ -383,9 +383,11 @@ int mi_ctc_loss_bwd(const void* logits, long ld_b, long ld_t, int dtype, const f
                     size_t workspace_bytes, void* dlogits, long ldo, mi_stream_t stream);
 int mi_ce_label_smoothing_bwd(const float* logits, long ld, const long* labels, int B, int U, int shift, int V, float eps,
                               float weight, const float* acc, void* dlogits, long ldo, mi_stream_t stream);
-/* as gathers (a block per vocabulary entry / position adds its rows in order: no atomics); workspace: V bytes (marks the entries that occur) or NULL; d <= 1024 */
+/* as gathers (a block per 16 vocabulary entries / per position adds its rows in order: no atomics).  heavy_id: an entry expected on a large share of the rows (the padding
+ * token of the shifted decoder input) is summed as a masked column sum instead, or -1; workspace: mi_embed_tokens_bwd_workspace_bytes(M, d, V) bytes; d <= 1024 */
+size_t mi_embed_tokens_bwd_workspace_bytes(int M, int d, int V);
 int mi_embed_tokens_bwd(const long* ids, const float* dx, float scale, int pos_offset, int U, int d, int M, int V, float* dwte,
-                        float* dwpe, void* workspace, mi_stream_t stream);
+                        float* dwpe, int heavy_id, void* workspace, mi_stream_t stream);
 
 /* ---- feature-level SpecAugment on the device (src/augmentations/spec_aug.py:40-137: bicubic time warp + frequency / time masks) */
 int mi_specaug_f32(const float* x, float* out, int B, int T, int F, const int* params, int nf, int nt, float pad_value, mi_stream_t stream);
