@@ -15,7 +15,6 @@
 // One wave owns 32 queries; operands (K rows, P rows, V^T rows) are L2-resident and loaded straight
 // into MFMA fragments.  V^T (d, B*Tp) is produced key-contiguous by the V-projection GEMM.
 #include "common.hpp"
-#include <atomic>
 
 namespace {
 
@@ -1264,19 +1263,6 @@ __global__ __launch_bounds__(512) void attn8_kernel(AttnArgs p) {
         STAMP(29);
 #endif
     }
-}
-
-// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (kernel, device) — a process-wide `static bool` would configure only
-// the device that happened to be current at the first call.
-template <int TAG>
-bool ensure_dynamic_lds(const void* kernel, size_t bytes) {
-    static std::atomic<unsigned long long> done{0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    if ((done.load(std::memory_order_acquire) >> dev) & 1ull) return true;
-    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
-    done.fetch_or(1ull << dev, std::memory_order_release);
-    return true;
 }
 
 template <int HD, bool REL, bool DROP>

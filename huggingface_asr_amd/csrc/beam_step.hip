@@ -182,8 +182,7 @@ extern "C" int mi_beam_step(const float* logits, long ldl, const float* lse, con
     if (lds > 96 * 1024) return MI_ERR_UNSUPPORTED;
     BeamArgs a{logits, ldl, lse, ctc, w_att, w_ctc, pad, eos, B, W, V, cur_len, Lmax, cap, denom, ids, beam_scores, new_tok, beam_idx, done, nfin, fin_score, fin_len, fin_tok,
                top_s, top_i, done_out};
-    static const bool attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(beam_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
-    if (!attr_set) return MI_ERR_LAUNCH;
+    if (!ensure_dynamic_lds<0>(reinterpret_cast<const void*>(beam_step_kernel), 96 * 1024)) return MI_ERR_LAUNCH;        // per device (a function-local static configured only the first one)
     hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(BS_THREADS), lds, stream, a);
     MI_CHECK_LAUNCH();
     return MI_OK;

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
+#include <unordered_map>
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -131,6 +133,23 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (kernel, device) — a function-local `static bool` configures only
+// the device that happened to be current at the first call.  One table per translation unit (kernel -> bit mask of configured devices).
+static inline bool ensure_dynamic_lds_ptr(const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, unsigned long long> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    unsigned long long& m = done[kernel];
+    if ((m >> dev) & 1ull) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+    m |= 1ull << dev;
+    return true;
+}
+template <int TAG>
+static inline bool ensure_dynamic_lds(const void* kernel, size_t bytes) { return ensure_dynamic_lds_ptr(kernel, bytes); }
 
 // Fixed-order reduction of `rows` partial rows of n floats (the second stage of every parameter-gradient reduction of the training step: no float atomics anywhere, so the
 // backward is bit-reproducible run to run): a block owns 16 columns over ALL rows — thread (column, row group g) adds rows g, g + 16, ... with eight loads in flight, the 16

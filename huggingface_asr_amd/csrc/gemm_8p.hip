@@ -884,45 +884,40 @@ bool gemm_8p_supported(const GemmArgs& a, bool conv) {
     return true;
 }
 
-// kernel attributes are set once per kernel behind C++11 function-local static initialisers (thread-safe; the library keeps no other process state for the GEMMs)
+// kernel attributes are set once per (kernel, device) through common.hpp's table (a function-local static configured only the device current at the first call)
 template <typename K>
-static bool set_lds_attr(K kernel, int bytes) { return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess; }
+static bool set_lds_attr(K kernel, int bytes) { return ensure_dynamic_lds_ptr(reinterpret_cast<const void*>(kernel), (size_t)bytes); }     // per (kernel, device)
 
 int gemm_8p_launch(const GemmArgs& a, bool conv, hipStream_t stream) {
     using kern_t = void (*)(GemmArgs);
     static const kern_t kerns[2][3] = {{gemm8p_kernel<false, 0>, gemm8p_kernel<false, 1>, gemm8p_kernel<false, 2>},
                                        {gemm8p_kernel<true, 0>, gemm8p_kernel<true, 1>, gemm8p_kernel<true, 2>}};
-    static const bool attr_set = [] {
-        bool ok = true;
-        for (int c = 0; c < 2; ++c)
-            for (int t = 0; t < 3; ++t) ok = set_lds_attr(kerns[c][t], 2 * BUF) && ok;
-        return ok;
-    }();
-    (void)attr_set;
+    // (the kernel actually launched below is one of these six; configuring only that one keeps the per-call cost at one table lookup)
+    if (a.act >= 0 && a.act <= 2 && !set_lds_attr(kerns[conv ? 1 : 0][a.act], 2 * BUF)) return MI_ERR_LAUNCH;
     if (a.act < 0 || a.act > 4) return MI_ERR_ARG;
     const int grid = cdiv(a.M, TB) * cdiv(a.N, TB);
     if (a.act >= 3) {
-        static const bool attr_t = set_lds_attr(gemm8p_kernel<false, 3>, 2 * BUF) && set_lds_attr(gemm8p_kernel<false, 4>, 2 * BUF);
+        const bool attr_t = set_lds_attr(gemm8p_kernel<false, 3>, 2 * BUF) && set_lds_attr(gemm8p_kernel<false, 4>, 2 * BUF);
         (void)attr_t;
         if (a.act == 3) launch_dense(PF_8P, gemm8p_kernel<false, 3>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
         else launch_dense(PF_8P_GELU, gemm8p_kernel<false, 4>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
         return MI_OK;
     }
     if (a.out_f32) {
-        static const bool attr32 = set_lds_attr(gemm8p_kernel<false, 0, true>, 2 * BUF);
+        const bool attr32 = set_lds_attr(gemm8p_kernel<false, 0, true>, 2 * BUF);
         (void)attr32;
         launch_dense(PF_8P_OUT32, gemm8p_kernel<false, 0, true>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
         return MI_OK;
     }
     if (a.ln_stats) {
-        static const bool attr_l = set_lds_attr(gemm8p_kernel<false, 0, false, false, true>, 2 * BUF + 2048) && set_lds_attr(gemm8p_kernel<false, 1, false, false, true>, 2 * BUF + 2048);
+        const bool attr_l = set_lds_attr(gemm8p_kernel<false, 0, false, false, true>, 2 * BUF + 2048) && set_lds_attr(gemm8p_kernel<false, 1, false, false, true>, 2 * BUF + 2048);
         (void)attr_l;
         if (a.act) launch_dense(PF_8P_GELU, gemm8p_kernel<false, 1, false, false, true>, dim3(grid), dim3(512), (size_t)2 * BUF + 2048, stream, a);
         else launch_dense(PF_8P, gemm8p_kernel<false, 0, false, false, true>, dim3(grid), dim3(512), (size_t)2 * BUF + 2048, stream, a);
         return MI_OK;
     }
     if (a.gated) {
-        static const bool attr_g = set_lds_attr(gemm8p_kernel<true, 1, false, true>, 2 * BUF);
+        const bool attr_g = set_lds_attr(gemm8p_kernel<true, 1, false, true>, 2 * BUF);
         (void)attr_g;
         launch_dense(PF_8P_CONV, gemm8p_kernel<true, 1, false, true>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
         return MI_OK;
@@ -946,11 +941,11 @@ bool gemm_8p128_supported(const GemmArgs& a) {
 }
 
 int gemm_8p128_launch(const GemmArgs& a, int ring, hipStream_t stream) {
-    static const bool attr_set = set_lds_attr(gemm8p128_kernel<4>, 4 * B128_BUF);
+    const bool attr_set = set_lds_attr(gemm8p128_kernel<4>, 4 * B128_BUF);
     (void)attr_set;
     const int grid = cdiv(a.M, 128) * (a.N / 128);
     if (ring == 0) {          // register-pipelined form (even number of K tiles)
-        static const bool attr_p = set_lds_attr(gemm8p128p_kernel, 4 * B128_BUF);
+        const bool attr_p = set_lds_attr(gemm8p128p_kernel, 4 * B128_BUF);
         (void)attr_p;
         launch_dense(PF_8P128, gemm8p128p_kernel, dim3(grid), dim3(512), (size_t)4 * B128_BUF, stream, a);
         return MI_OK;

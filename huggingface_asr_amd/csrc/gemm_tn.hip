@@ -369,8 +369,7 @@ extern "C" int mi_gemm_tn_bf16(const void* dY, long ldy, const void* X, long ldx
     const int tiles = big ? cdiv(N, 256) * cdiv(K, 256) : cdiv(N, TN_T) * cdiv(K, variant == 1 ? 64 : 128);
     if (big) {
         const size_t lds = (size_t)2 * TN_KM * 1024;
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (attr != hipSuccess) return MI_ERR_LAUNCH;
+        if (!ensure_dynamic_lds<1>(reinterpret_cast<const void*>(gemm_tn_big_kernel<false>), lds)) return MI_ERR_LAUNCH;
         hipLaunchKernelGGL(gemm_tn_big_kernel<false>, dim3(tiles * splits), dim3(512), lds, st, p);
     } else if (variant == 0) hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(tiles * splits), dim3(256), (size_t)2 * TN_KM * (TN_T * 2 + 256), st, p);
     else hipLaunchKernelGGL(gemm_tn_kernel<64>, dim3(tiles * splits), dim3(256), (size_t)2 * TN_KM * (TN_T * 2 + 128), st, p);
@@ -410,8 +409,7 @@ extern "C" int mi_conv2d_wgrad_cl_bf16(const void* dY, long ldy, const void* x, 
     const int tiles = big ? cdiv(N, 256) * cdiv(K, 256) : cdiv(N, TN_T) * cdiv(K, 128);
     if (big) {
         const size_t lds = (size_t)2 * TN_KM * 1024;
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (attr != hipSuccess) return MI_ERR_LAUNCH;
+        if (!ensure_dynamic_lds<2>(reinterpret_cast<const void*>(gemm_tn_big_kernel<true>), lds)) return MI_ERR_LAUNCH;
         hipLaunchKernelGGL(gemm_tn_big_kernel<true>, dim3(tiles * splits), dim3(512), lds, st, p);
     } else hipLaunchKernelGGL(gemm_tn_kernel<128>, dim3(tiles * splits), dim3(256), (size_t)2 * TN_KM * (TN_T * 2 + 256), st, p);
     MI_CHECK_LAUNCH();
@@ -454,12 +452,10 @@ extern "C" int mi_gemm_tn_group_bf16(int n, const void* const* dY, const long* l
     g.tile0[n] = tiles;
     const size_t lds = (size_t)TN_GROUP_NS * TN_KM * (TN_GROUP_N * 2 + xw * 2);          // 2 x 48 KiB / 2 x 64 KiB: one block per CU
     if (xw == 256) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_group_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (attr != hipSuccess) return MI_ERR_LAUNCH;
+        if (!ensure_dynamic_lds<3>(reinterpret_cast<const void*>(gemm_tn_group_kernel<256>), lds)) return MI_ERR_LAUNCH;
         hipLaunchKernelGGL(gemm_tn_group_kernel<256>, dim3(tiles), dim3(512), lds, st, g);
     } else {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_group_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (attr != hipSuccess) return MI_ERR_LAUNCH;
+        if (!ensure_dynamic_lds<4>(reinterpret_cast<const void*>(gemm_tn_group_kernel<128>), lds)) return MI_ERR_LAUNCH;
         hipLaunchKernelGGL(gemm_tn_group_kernel<128>, dim3(tiles), dim3(512), lds, st, g);
     }
     MI_CHECK_LAUNCH();

@@ -285,7 +285,8 @@ def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_lengt
     L_ = _lib.lib()
     main = torch.cuda.current_stream()
     V = joint.dec.w["lm_head"].shape[0]
-    if W > 16 or W * V >= (1 << 24):           # outside mi_beam_step's limits: the same decoding with the bookkeeping on the host (still the HIP kernels for everything else)
+    if W > 16 or W * V >= (1 << 24) or W * (max_length + 1) * 8 > 96 * 1024:      # outside mi_beam_step's limits (beams, candidates, the id buffer it stages in 96 KiB of LDS): the same
+        # decoding with the bookkeeping on the host (still the HIP kernels for everything else) — decided here, not by an error in the middle of a decode
         return generate_stepwise(joint, feats, feat_len, num_beams=num_beams, max_length=max_length, ctc_weight=ctc_weight, length_penalty=length_penalty,
                                  eos_token_id=eos_token_id, pad_token_id=pad_token_id, start_token_id=start_token_id, space_token_id=space_token_id)
     enc_out, enc_bf, T2, key_len = joint.encode(feats, feat_len)
@@ -321,7 +322,7 @@ def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_lengt
     fin_tok = torch.zeros((B, cap, Lmax), dtype=torch.long, device=dev)
     done_host = torch.zeros((max_length, B), dtype=torch.int32).pin_memory()
     new_tok = ids[:, :1].contiguous()
-    keep, flags = [], []                       # tensors another stream still reads stay referenced until the end; (event, step) of the done-flag copies
+    flags = []                                 # (event, step) of the done-flag copies
     ev_ids = torch.cuda.Event()
     ev_ids.record(main)
     cur_len, steps = 1, 0
@@ -340,7 +341,7 @@ def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_lengt
                 ctc = proc.ctc_scores(ids[:, :cur_len])
                 ev_ctc = torch.cuda.Event()
                 ev_ctc.record(side)
-            keep.append(ctc)                   # read by the main stream below; the processor's own state stays on the side stream
+            ctc.record_stream(main)            # allocated on the side stream, read by the main stream below: the only tensor of the loop that crosses streams
         logits = joint.dec.step(new_tok, cache, kvs, T2, key_rep)                       # (B*W, V), row stride padded to 8
         lse = ops.row_lse(logits)
         if proc is not None:
@@ -356,7 +357,6 @@ def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_lengt
         if W > 1:
             joint.dec.reorder_cache(cache, beam_idx)
         flags.append((ev_ids, steps))          # the flags of this step are in pinned memory once the step's event has fired
-        keep.append((logits, lse, new_tok, beam_idx))
         cur_len += 1
         steps += 1
     if stats is not None:                      # host time spent enqueuing the token loop (the GPU may still be running it)
