@@ -416,3 +416,34 @@ def test_layernorm_folded_into_the_gemms(M, d, I, wide):
     want2 = F.linear(F.layer_norm(want_y, (d,), gam, bet, 1e-5), W, b)
     e2 = (got2.float().cpu() - want2).abs()
     assert float(e2.max()) < 0.08 and float(e2.mean()) < 0.008, (float(e2.max()), float(e2.mean()))
+
+
+@pytest.mark.parametrize("ratio", [0.0, 3.0, 10.0, 30.0])
+def test_layernorm_fold_error_grows_with_the_row_mean_as_modelled(ratio):
+    """the folded form feeds the UN-normalised bf16(x) to the GEMM and subtracts rstd mu colsum(W') afterwards, so the bf16 rounding of x (relative 2^-9 of |x| ~ |mu|)
+    is amplified by |mu| / sigma against the un-folded bf16(LN(x)) — invisible on the parity fixtures (row means ~ 0), real for residual streams with a large common offset.
+    Rows with mean = ratio x sigma: the folded output's error against fp32 LayerNorm -> Linear must stay within the model  e_unfolded x sqrt(1 + (c ratio)^2)  (c ~ 1: both
+    errors are bf16 roundings of an operand of the same GEMM), i.e. ~ 3x at |mu| / sigma = 3, ~ 10x at 10, ~ 30x at 30 — the documented price; `HFASR_LN_FOLD=0`
+    forces the un-folded form for checkpoints whose streams carry such offsets.  (The E[x^2] - mu^2 variance from fp32 partials is NOT the problem: its relative error is
+    ~ 6e-8 (mu / sigma)^2, 5e-5 at ratio 30 — asserted through rstd below.)"""
+    ops = _ops()
+    M, d, I = 512, 512, 2048
+    z = rnd(M, d, seed=61, scale=1.0)
+    x = (z + ratio).contiguous()                                                    # sigma ~ 1, row mean ~ ratio
+    gam, bet = 1.0 + 0.2 * rnd(d, seed=62), 0.1 * rnd(d, seed=63)
+    W, b = rnd(I, d, seed=64, scale=d ** -0.5), rnd(I, seed=65, scale=0.1)
+    # statistics exactly as a producer would leave them: one (sum, sum of squares) pair per row over the stored fp32 row
+    st = torch.zeros(M, 32, device=DEV)
+    st[:, 0] = x.sum(-1).to(DEV); st[:, 1] = (x * x).sum(-1).to(DEV)
+    wf = (W * gam[None]).to(torch.bfloat16)
+    colsum, cbias = wf.float().sum(-1), W @ bet + b
+    want = F.linear(F.layer_norm(x, (d,), gam, bet, 1e-5), W, b)
+    got = ops.gemm_lnfold(x.to(DEV, torch.bfloat16), wf.to(DEV), colsum.to(DEV), cbias.to(DEV), st, 1, act="none").float().cpu()
+    unfolded = F.linear(bfr(F.layer_norm(x, (d,), gam, bet, 1e-5)), bfr(W * 1.0), b)                     # what LayerNorm kernel -> bf16 -> GEMM computes
+    e_fold, e_unf = float((got - want).abs().mean()), float((unfolded - want).abs().mean())
+    bound = 1.6 * e_unf * (1.0 + ratio * ratio) ** 0.5 + 2e-4
+    assert e_fold < bound, (ratio, e_fold, e_unf, bound)
+    if ratio >= 10.0:
+        assert e_fold > 2.0 * e_unf, (ratio, e_fold, e_unf)                         # the amplification is real: this test documents it, it does not hide it
+    var = (x * x).mean(-1) - x.mean(-1) ** 2
+    assert float(((var - x.var(-1, unbiased=False)).abs() / x.var(-1, unbiased=False)).max()) < 1e-3
