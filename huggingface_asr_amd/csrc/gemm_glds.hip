@@ -318,7 +318,7 @@ int gemm_glds_launch(const GemmArgs& a, bool conv, hipStream_t stream) {
     const bool phase_ok = v != 41 && v != 30 && v != 31 && v != 32;
     // wide-N bf16-out GEMMs (FFN in, cgMLP in, QKV) and the implicit-GEMM conv: 256x256 tiles on the phase-interleaved schedule (gemm_8p.hip) once the tiles fill half the chip
     const int t256 = cdiv(a.M, 256) * cdiv(a.N, 256);
-    if (phase_ok && gemm_8p_supported(a, conv) && (t256 >= 128 || v == 40)) return gemm_8p_launch(a, conv, stream);
+    if (phase_ok && v != 42 && v != 47 && gemm_8p_supported(a, conv) && (t256 >= 128 || v == 40)) return gemm_8p_launch(a, conv, stream);
     // N = 512-class GEMMs: 128x128 tiles (fp32 + residual or bf16 out); register-pipelined form for an even number of K tiles
     if (!conv && phase_ok && gemm_8p128_supported(a) && (cdiv(a.M, 128) * (a.N / 128) >= 128 || v == 40 || v == 42 || v == 47))
         return gemm_8p128_launch(a, (v != 47 && (a.K % 128) == 0) ? 0 : 4, stream);

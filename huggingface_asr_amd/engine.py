@@ -180,7 +180,7 @@ class EBranchformerEngine:
                 def fold(tag, w, b, g, be):          # LN(x) W^T + b = rstd (x W'^T) - rstd mu colsum(W') + (W beta + b)
                     w32, g32, be32 = w.detach().to(dev, torch.float32), g.detach().to(dev, torch.float32), be.detach().to(dev, torch.float32)
                     wf = (w32 * g32[None, :]).to(torch.bfloat16).contiguous()
-                    lp(tag + "_WF", wf); lp(tag + "_SF", wf.float().sum(-1).contiguous()); lp(tag + "_CF", (w32 @ be32 + b.detach().to(dev, torch.float32)).contiguous())
+                    lp(tag + "_WF", wf); lp(tag + "_SF", wf.float().sum(-1).contiguous()); lp(tag + "_CF", ((w32 * be32[None, :]).sum(-1) + b.detach().to(dev, torch.float32)).contiguous())      # (element-wise + row sum: no vendor BLAS call even at load time)
                 for ff, tag in (("ff1", "FF1"), ("ff2", "FF2")):
                     fold(tag, sd[p + ff + ".1.intermediate_dense.weight"], sd[p + ff + ".1.intermediate_dense.bias"], sd[p + ff + ".0.weight"], sd[p + ff + ".0.bias"])
                 fold("QKV", torch.cat([sd[a + f"linear_{n}.weight"].detach().to(dev) for n in "qkv"], 0), torch.cat([sd[a + f"linear_{n}.bias"].detach().to(dev) for n in "qkv"], 0),
