@@ -3,7 +3,16 @@
 import ctypes as C, math, os, sys
 import numpy as np, torch
 here = os.path.dirname(os.path.abspath(__file__))
-L = C.CDLL(os.path.join(here, "bin", "libattn_stamps.so"))
+so = os.path.join(here, "bin", "libattn_stamps.so")
+src = os.path.join(os.path.dirname(here), "huggingface_asr_amd", "csrc")
+if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(src, "attention.hip")):      # the instrumented build is not part of the library: made here, on demand
+    import subprocess, tempfile
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    with tempfile.NamedTemporaryFile("w", suffix=".cpp", delete=False) as f:
+        f.write('extern "C" void mi_record_hip_error(int, const char*, int) {}\n')
+    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-result", "-munsafe-fp-atomics", "-Xclang", "-target-feature", "-Xclang",
+                    "-packed-fp32-ops", "-DATTN_STAMPS", "-shared", os.path.join(src, "attention.hip"), f.name, "-o", so], check=True, stderr=subprocess.DEVNULL)
+L = C.CDLL(so)
 dev = "cuda:0"
 B, T, H, hd = (int(x) for x in (sys.argv[1:5] if len(sys.argv) > 4 else (32, 250, 4, 128)))
 rel = int(sys.argv[5]) if len(sys.argv) > 5 else 1
