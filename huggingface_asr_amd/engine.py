@@ -192,6 +192,16 @@ class EBranchformerEngine:
         self._posp_valid = {}
         self.weights_version += 1
 
+    def share_weights_from(self, other: "EBranchformerEngine") -> None:
+        """Adopt `other`'s packed weight table (the same device tensors: bf16 weights, fold tensors, biases) instead of packing a state dict again — the lane engines of a
+        `ForwardPipeline` differ in workspace and position cache only (four lanes held four copies of the weights and ran the load-time packing four times)."""
+        if other._table is None or other.device != self.device:
+            raise ValueError("share_weights_from: the source engine must have its weights loaded on the same device")
+        self._keep, self._slots, self._table = other._keep, other._slots, other._table
+        self.weights = other.weights
+        self._posp_valid = {}
+        self.weights_version += 1
+
     def _fold_shapes_ok(self) -> bool:
         """shapes the folded-LayerNorm GEMM kernels take (csrc/gemm_8p.hip: 256-wide consumer tiles, 128-wide producers with <= 16 statistics pairs per row) and the
         layer forms the folded driver covers (csrc/encoder.hip)"""

@@ -36,13 +36,21 @@ class ForwardPipeline:
         if lanes < 1:
             raise ValueError("lanes >= 1")
         self.device = torch.device(device)
+        if lanes > 3 and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
+            import warnings
+            warnings.warn("ForwardPipeline: more than 3 lanes on the HIP runtime's default 4 hardware queues — two lanes will take turns on one queue (measured: 4.6 instead of "
+                          "3.8 ms per step); call pipeline.reserve_hw_queues(lanes) before the first HIP call of the process, or export GPU_MAX_HW_QUEUES=8", RuntimeWarning)
         self.engines = []
-        for _ in range(lanes):
+        for i in range(lanes):
             e = EBranchformerEngine(cfg, self.device)
             e.wide_tiles = bool(wide_tiles)          # mi_ebf_config.wide_tiles: fewer, fatter GEMM blocks per launch — pays with >= 3 lanes
-            e.load_state_dict(state_dict)
+            if i == 0:
+                e.load_state_dict(state_dict)
+            else:
+                e.share_weights_from(self.engines[0])        # one packed weight table for every lane; a lane owns its workspace and position cache only
             self.engines.append(e)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(lanes)] if lanes > 1 else [None]
+        self.events = [None] * lanes                 # the event recorded behind each lane's latest submission (wait on it before reading that lane's results on another stream)
         self._next = 0
 
     @property
@@ -51,14 +59,18 @@ class ForwardPipeline:
 
     def submit(self, fn):
         """fn(engine, lane) is enqueued on the next lane's stream (behind that lane's earlier work only) -> (lane, fn's return value).
-        The caller synchronises (torch.cuda.synchronize(), or an event recorded on `self.streams[lane]`) before reading results on another stream."""
+        `self.events[lane]` is recorded behind it: wait on that event (or torch.cuda.synchronize()) before reading the results on another stream."""
         lane = self._next
         self._next = (lane + 1) % len(self.engines)
         st = self.streams[lane]
         if st is None:
             return lane, fn(self.engines[lane], lane)
         with torch.cuda.stream(st):
-            return lane, fn(self.engines[lane], lane)
+            out = fn(self.engines[lane], lane)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self.events[lane] = ev
+            return lane, out
 
     def reset(self):
         self._next = 0
