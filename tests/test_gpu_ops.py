@@ -207,6 +207,31 @@ def test_attention_lds_staged(T, H, hd, rel, causal):
     assert_close_bf16(got, want, atol=1.5e-2, rtol=2e-2, what="attention (lds)")
 
 
+@pytest.mark.parametrize("B,T,H,hd,rel,causal", [(3, 250, 4, 128, True, False), (2, 97, 4, 64, True, True), (8, 500, 2, 64, True, False), (3, 33, 2, 128, False, True),
+                                                 (5, 129, 1, 128, True, False), (4, 1500, 2, 64, False, False), (1, 1, 2, 64, False, False)])
+def test_attention_eight_wave_form_against_the_oracle_and_the_four_wave_kernel(B, T, H, hd, rel, causal):
+    """Round 4's eight-wave forward FORCED on every shape (variant 2: also head 64 with relative positions, which the product routes to the four-wave kernel; block counts with
+    and without the XCD-aware order: N % 8 == 0 or not; ragged key lengths; a lone query) against the oracle, and against the four-wave kernel of rounds 1-3 (variant 1) —
+    they differ by the summation order over the keys only (the wave pair of a query group splits them)."""
+    ops = _ops()
+    d = H * hd
+    q, k, v = (bfr(rnd(B * T, d, seed=250 + i, scale=0.8)) for i in range(3))
+    lengths = torch.tensor([max(1, T - 7 * b) if b % 2 == 0 else max(1, T // (b + 1)) for b in range(B)], dtype=torch.int32)
+    pos = bfr(rnd(2 * T - 1, d, seed=255, scale=0.8)) if rel else None
+    u, vb = (0.2 * rnd(H, hd, seed=256), 0.2 * rnd(H, hd, seed=257)) if rel else (None, None)
+    want = _attn_ref(q, k, v, B, T, H, pos, u, vb, lengths, causal)
+    qkv = torch.cat([q, k, v], 1).to(DEV, torch.bfloat16)
+    kw = dict(pos=None if pos is None else pos.to(DEV, torch.bfloat16), bias_u=None if u is None else u.to(DEV), bias_v=None if vb is None else vb.to(DEV),
+              lengths=lengths.to(DEV), causal=causal)
+    got8 = ops.attention_qkv(qkv, B, T, H, variant=2, **kw)
+    got4 = ops.attention_qkv(qkv, B, T, H, variant=1, **kw)
+    assert_close_bf16(got8, want, atol=1.5e-2, rtol=2e-2, what="attention (eight-wave)")
+    assert_close_bf16(got4, want, atol=1.5e-2, rtol=2e-2, what="attention (four-wave)")
+    dd = (got8.float() - got4.float()).abs()
+    assert float(dd.max()) < 1.6e-2 and float(dd.mean()) < 3e-4, (float(dd.max()), float(dd.mean()))
+    assert torch.equal(got8, ops.attention_qkv(qkv, B, T, H, variant=2, **kw))            # bit-reproducible launch to launch
+
+
 @pytest.mark.parametrize("causal", [False, True])
 def test_csgu_and_merge(causal):
     ops = _ops()
