@@ -133,6 +133,10 @@ SIGNATURES = {
     "mi_dwconv_residual_bwd_bf16": [vp, i64, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
     "mi_im2col_cl_bf16": [vp, vp] + [i32] * 11 + [vp],
     "mi_conv2d_first_bwd": [vp, vp, vp, vp, vp, vp] + [i32] * 16 + [vp, vp],
+    "mi_conv2d_s2k3_dgrad_elems": [i32] * 8,
+    "mi_conv2d_s2k3_dgrad_pack_bf16": [vp, i64, vp, i32, i32, vp],
+    "mi_conv2d_s2k3_dgrad_bf16": [vp, vp, vp] + [i32] * 9 + [vp],
+    "mi_conv2d_first_bwd_phases": [vp, vp, vp, vp, vp, vp] + [i32] * 14 + [vp, vp],
     "mi_ctc_bwd_workspace_bytes": [i32, i32, i32],
     "mi_ctc_loss_bwd": [vp, i64, i64, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, f32, vp, sz, vp, i64, vp],
     "mi_ce_label_smoothing_bwd": [vp, i64, vp, i32, i32, i32, i32, f32, f32, vp, vp, i64, vp],
@@ -177,7 +181,7 @@ def lib():
             fn = getattr(h, name)          # AttributeError here = header/library mismatch: fail loudly
             fn.argtypes = args
             fn.restype = sz if name in ("mi_ebf_workspace_bytes", "mi_ctc_bwd_workspace_bytes", "mi_gemm_tn_workspace_bytes", "mi_layernorm_bwd_workspace_floats",
-                                          "mi_colsum_workspace_floats", "mi_conv2d_first_bwd_workspace_floats", "mi_conv2d_first_wgrad_workspace_floats", "mi_embed_tokens_bwd_workspace_bytes",
+                                          "mi_colsum_workspace_floats", "mi_conv2d_first_bwd_workspace_floats", "mi_conv2d_s2k3_dgrad_elems", "mi_conv2d_first_wgrad_workspace_floats", "mi_embed_tokens_bwd_workspace_bytes",
                                           "mi_gpt2_step_workspace_bytes") else i32
         h.mi_profile_create.argtypes = [i32]; h.mi_profile_create.restype = i32
         h.mi_profile_enable.argtypes = [i32]; h.mi_profile_enable.restype = None

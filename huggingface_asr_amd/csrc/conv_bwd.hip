@@ -378,11 +378,14 @@ struct EmitConv1 { float* dw; float* db; int NT; __device__ void operator()(int 
 // Thread layout of conv2d_first3_kernel: a thread owns 8 channels and walks positions.
 // FIX32: conv2 is the usual 3x3 / stride 2 and there are fewer than 2^31 positions: tap loops unrolled over constants, shifts instead of
 // divisions by the stride, 32-bit position arithmetic.
-template <bool FIX32>
+// PH: the activation gradient arrives as the four PHASE buffers of mi_conv2d_s2k3_dgrad_bf16 (conv2's data gradient as four stride-1 convolutions, one per parity
+// of (t1 + pad2_t, f1 + pad2_f)) instead of the (B*T2*F2, 9 C) gradient of conv2's im2col operand: ONE 16-B load per position and channel group instead of up to four
+struct Conv1Ph { const bf16_t* buf[4]; int U[2], V[2], ulo[2], vlo[2]; };
+template <bool FIX32, bool PH = false>
 __global__ __launch_bounds__(256) void conv1_bwd3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                           const bf16_t* __restrict__ dcol, float* __restrict__ partial,
                                                           int B, int T, int F, int C, int stride, int pad_t, int pad_f, int T1, int F1,
-                                                          int K2r, int stride2r, int pad2_t, int pad2_f, int T2, int F2) {
+                                                          int K2r, int stride2r, int pad2_t, int pad2_f, int T2, int F2, Conv1Ph ph) {
     const int K2 = FIX32 ? 3 : K2r, stride2 = FIX32 ? 2 : stride2r;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* stage = reinterpret_cast<float*>(smem);       // [256][40]: the block's ordered reduction (below)
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(256) void conv1_bwd3_kernel(const float* __restrict
         // taps 0 and 2): ALWAYS four 16-B loads — a tap that does not exist re-reads the first one and is multiplied by zero — plus the nine features, all issued
         // for position n + 1 before position n's ~500 VALU instructions run.  Before, every position began with its own loads and nothing in flight: at two waves
         // per SIMD (200 VGPRs) the kernel ran at 0.9 TB/s on a 700-MB read.
-        struct Pos { bf16x8 v[4]; float x[9]; unsigned mask; };          // mask: bits 0-3 the taps that exist, bits 4-12 the features inside the input
+        struct Pos { bf16x8 v[PH ? 1 : 4]; float x[9]; unsigned mask; };          // mask: bits 0-3 the taps that exist, bits 4-12 the features inside the input
         auto fetch = [&](long pos, Pos& q) {
             const unsigned up = (unsigned)pos, qq = up / (unsigned)F1;
             const int f1 = (int)(up - qq * (unsigned)F1), b = (int)(qq / (unsigned)T1), t1 = (int)(qq - (unsigned)b * (unsigned)T1);
@@ -413,6 +416,12 @@ __global__ __launch_bounds__(256) void conv1_bwd3_kernel(const float* __restrict
             const bool vf[2] = {f2a < F2, kw0 == 0 && f2a >= 1 && f2a - 1 < F2};
             const bf16_t* base = dcol + g * 8;
             unsigned mask = 0;
+            if constexpr (PH) {
+                const int u = (at >> 1) - ph.ulo[kh0], v = (af >> 1) - ph.vlo[kw0];
+                const bf16_t* pb = kh0 ? (kw0 ? ph.buf[3] : ph.buf[2]) : (kw0 ? ph.buf[1] : ph.buf[0]);
+                q.v[0] = *reinterpret_cast<const bf16x8*>(pb + (((long)b * ph.U[kh0] + u) * ph.V[kw0] + v) * C + g * 8);
+                mask = 1u;
+            } else
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -453,7 +462,7 @@ __global__ __launch_bounds__(256) void conv1_bwd3_kernel(const float* __restrict
                 for (int j = 0; j < 8; ++j) {
                     da[j] = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) da[j] += (cur.mask >> i) & 1u ? bf2f(cur.v[i][j]) : 0.f;
+                    for (int i = 0; i < (PH ? 1 : 4); ++i) da[j] += (PH || ((cur.mask >> i) & 1u)) ? bf2f(cur.v[i][j]) : 0.f;
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -877,10 +886,122 @@ extern "C" int mi_conv2d_first_bwd(const float* x, const float* w, const float* 
     const size_t lds = (size_t)256 * 40 * sizeof(float);
     if (K2 == 3 && stride2 == 2 && npos < (1L << 31))
         hipLaunchKernelGGL(conv1_bwd3_kernel<true>, dim3(grid), dim3(256), lds, st, x, w, bias, (const bf16_t*)dcol, workspace,
-                           B, T, F, C, stride, pad_t, pad_f, T1, F1, K2, stride2, pad2_t, pad2_f, T2, F2);
+                           B, T, F, C, stride, pad_t, pad_f, T1, F1, K2, stride2, pad2_t, pad2_f, T2, F2, Conv1Ph{});
     else
         hipLaunchKernelGGL(conv1_bwd3_kernel<false>, dim3(grid), dim3(256), lds, st, x, w, bias, (const bf16_t*)dcol, workspace,
-                           B, T, F, C, stride, pad_t, pad_f, T1, F1, K2, stride2, pad2_t, pad2_f, T2, F2);
+                           B, T, F, C, stride, pad_t, pad_f, T1, F1, K2, stride2, pad2_t, pad2_f, T2, F2, Conv1Ph{});
+    MI_CHECK_LAUNCH();
+    rows_reduce_launch(workspace, (int)grid, C * 10, EmitConv1{dw, db, 9}, st);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ conv2's data gradient as four stride-1 convolutions
+// A 3x3 / stride-2 Conv2d reads input position t1 with tap kh iff (t1 + pad - kh) is even: along each axis the parity pt = (t1 + pad) & 1 decides WHICH taps (pt = 0:
+// kh in {0, 2}; pt = 1: kh = 1), and with t1 + pad = 2u + pt the contributing outputs are t2 = u - i for kh = pt + 2i.  So
+//     dact1[b, t1, f1, c] = sum_{i, j, co} dY2[b, u - i, v - j, co] * W2[co][pt + 2i][pf + 2j][c]
+// is, per parity class (pt, pf), a dense stride-1 convolution of dY2 (B, T2, F2, C2) with a (2 - pt) x (2 - pf) kernel: four implicit GEMMs on the forward conv kernel
+// (gemm_8p.hip, the operand gathered by the LDS-DMA addresses), M = B * U * V rows each, K = taps * C2 — the same 9 C1 C2 MACs per output position of conv2 in total.
+// What it replaces: dcol = dY2 · W2 as ONE GEMM into the (B*T2*F2, 9 C1) gradient of the im2col operand (4.4 GB at BASELINE config 3) which conv1's backward then
+// gathered back (col2im) — now 4 phase buffers of together B*T1*F1*C1 elements (2.0 GB), each element written once and read once.
+extern "C" int mi_conv2d_cl_geo_bf16(const void* in, const void* weight, const float* bias, void* out, int B, int Tin, int Fin, int Cin, int Cout, int KH, int KW,
+                                     int stride_t, int stride_f, int pad_t, int pad_f, int Tout, int Fout, int act, int gated, hipStream_t stream);      // gemm_bf16.hip
+namespace {
+struct S2Axis { int lo[2], n[2], pad[2]; bool ok; };
+S2Axis s2_axis(int L1, int p, int L2) {
+    S2Axis a{};
+    a.ok = L1 > 0 && L2 > 0 && p >= 0;
+    for (int pt = 0; pt < 2 && a.ok; ++pt) {
+        const int nt = pt == 0 ? 2 : 1;
+        const int lo = p - pt > 0 ? (p - pt + 1) / 2 : 0;             // first u with t1 = 2u + pt - p >= 0
+        const int hi = (L1 - 1 + p - pt) / 2;                          // last u with t1 <= L1 - 1   (L1 - 1 + p - pt >= 0 whenever lo <= hi)
+        a.lo[pt] = lo; a.n[pt] = hi - lo + 1; a.pad[pt] = nt - 1 - lo;
+        // the stride-1 conv reads input row u' - pad + i', i' in [0, nt): a non-negative leading pad, and the first tap of the last row inside the input
+        a.ok = a.n[pt] > 0 && a.pad[pt] >= 0 && (L1 - 1 + p - pt) >= 0 && (a.n[pt] - 1 - a.pad[pt]) < L2;
+    }
+    return a;
+}
+// packed[phase] (C1, taps * C2): row c, column (i' * ntf + j') * C2 + co = wT[((kh * 3 + kw) * C1 + c)][co], kh = pt + 2 (ntt - 1 - i'), kw = pf + 2 (ntf - 1 - j')
+__global__ __launch_bounds__(256) void s2k3_pack_kernel(const bf16_t* __restrict__ wT, long ldwt, bf16_t* __restrict__ packed, int C1, int C2) {
+    const int c8 = C2 >> 3;
+    const long total = (long)9 * C1 * c8;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int cc = (int)(e % c8);
+        long r = e / c8;
+        const int c = (int)(r % C1);
+        const int tap = (int)(r / C1), kh = tap / 3, kw = tap % 3;
+        const int pt = kh & 1, pf = kw & 1, ntt = 2 - pt, ntf = 2 - pf;
+        const int ip = ntt - 1 - (kh >> 1), jp = ntf - 1 - (kw >> 1);
+        const int phase = pt * 2 + pf;
+        const long base = phase == 0 ? 0 : phase == 1 ? (long)4 * C1 * C2 : phase == 2 ? (long)6 * C1 * C2 : (long)8 * C1 * C2;
+        const long K = (long)ntt * ntf * C2;
+        *reinterpret_cast<bf16x8*>(packed + base + c * K + (long)(ip * ntf + jp) * C2 + cc * 8) =
+            *reinterpret_cast<const bf16x8*>(wT + ((long)tap * C1 + c) * ldwt + cc * 8);
+    }
+}
+}  // namespace
+
+// elements of the phase-buffer allocation (bf16) for a (B, T1, F1, C1) activation gradient; 0 = this geometry is not supported (the caller keeps the im2col-gradient path)
+extern "C" size_t mi_conv2d_s2k3_dgrad_elems(int B, int T1, int F1, int C1, int T2, int F2, int pad_t, int pad_f) {
+    const S2Axis at = s2_axis(T1, pad_t, T2), af = s2_axis(F1, pad_f, F2);
+    if (!at.ok || !af.ok || B <= 0 || C1 <= 0) return 0;
+    size_t n = 0;
+    for (int pt = 0; pt < 2; ++pt)
+        for (int pf = 0; pf < 2; ++pf) n += (size_t)B * at.n[pt] * af.n[pf] * C1;
+    return n;
+}
+// wT (9 * C1 rows (kh, kw, c), >= C2 columns co; row stride ldwt) bf16 — the transposed copy of conv2's weight the trainer keeps for the data gradient — into the four
+// phase weight matrices, back to back: 9 * C1 * C2 elements
+extern "C" int mi_conv2d_s2k3_dgrad_pack_bf16(const void* wT, long ldwt, void* packed, int C1, int C2, hipStream_t st) {
+    MI_ENTER();
+    if (C1 <= 0 || C2 <= 0 || (C2 % 8) || (ldwt % 8) || ldwt < C2 || !wT || !packed) return MI_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(wT) & 15) || (reinterpret_cast<uintptr_t>(packed) & 15)) return MI_ERR_ARG;
+    hipLaunchKernelGGL(s2k3_pack_kernel, dim3(grid_for((long)9 * C1 * (C2 / 8), 1024)), dim3(256), 0, st, (const bf16_t*)wT, ldwt, (bf16_t*)packed, C1, C2);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+// dY2 (B, T2, F2, C2) bf16 contiguous, packed = mi_conv2d_s2k3_dgrad_pack_bf16's output -> phases (mi_conv2d_s2k3_dgrad_elems elements): the buffers of
+// (pt, pf) = (0,0), (0,1), (1,0), (1,1) back to back, each (B, U_pt, V_pf, C1) with U / V the number of positions of that parity.  replaces: the input gradient autograd
+// derives for the second Conv2d of extractors.py:82-89.
+extern "C" int mi_conv2d_s2k3_dgrad_bf16(const void* dY2, const void* packed, void* phases, int B, int T1, int F1, int C1, int T2, int F2, int C2,
+                                         int pad_t, int pad_f, hipStream_t st) {
+    MI_ENTER();
+    const S2Axis at = s2_axis(T1, pad_t, T2), af = s2_axis(F1, pad_f, F2);
+    if (!at.ok || !af.ok) return MI_ERR_UNSUPPORTED;
+    if (B <= 0 || C1 <= 0 || C2 <= 0 || !dY2 || !packed || !phases) return MI_ERR_ARG;
+    const bf16_t* wp = (const bf16_t*)packed;
+    bf16_t* op = (bf16_t*)phases;
+    for (int pt = 0; pt < 2; ++pt)
+        for (int pf = 0; pf < 2; ++pf) {
+            const int ntt = 2 - pt, ntf = 2 - pf;
+            const int rc = mi_conv2d_cl_geo_bf16(dY2, wp, nullptr, op, B, T2, F2, C2, C1, ntt, ntf, 1, 1, at.pad[pt], af.pad[pf], at.n[pt], af.n[pf], 0, 0, st);
+            if (rc != MI_OK) return rc;
+            wp += (long)C1 * ntt * ntf * C2;
+            op += (long)B * at.n[pt] * af.n[pf] * C1;
+        }
+    return MI_OK;
+}
+// mi_conv2d_first_bwd with the activation gradient in phase buffers (conv2: 3x3, stride 2, leading pads pad2_t / pad2_f)
+extern "C" int mi_conv2d_first_bwd_phases(const float* x, const float* w, const float* bias, const void* phases, float* dw, float* db,
+                                          int B, int T, int F, int C, int K, int stride, int pad_t, int pad_f, int T1, int F1,
+                                          int pad2_t, int pad2_f, int T2, int F2, float* workspace, hipStream_t st) {
+    MI_ENTER();
+    const int cgs = C / 8;
+    const long npos = (long)B * T1 * F1;
+    if (B <= 0 || K != 3 || (C % 8) != 0 || cgs > 256 || npos >= (1L << 31)) return MI_ERR_UNSUPPORTED;
+    const S2Axis at = s2_axis(T1, pad2_t, T2), af = s2_axis(F1, pad2_f, F2);
+    if (!at.ok || !af.ok) return MI_ERR_UNSUPPORTED;
+    if (!workspace || !phases || (reinterpret_cast<uintptr_t>(phases) & 15)) return MI_ERR_ARG;
+    Conv1Ph ph{};
+    const bf16_t* op = (const bf16_t*)phases;
+    for (int pt = 0; pt < 2; ++pt) {
+        ph.U[pt] = at.n[pt]; ph.ulo[pt] = at.lo[pt]; ph.V[pt] = af.n[pt]; ph.vlo[pt] = af.lo[pt];
+        for (int pf = 0; pf < 2; ++pf) { ph.buf[pt * 2 + pf] = op; op += (long)B * at.n[pt] * af.n[pf] * C; }
+    }
+    const unsigned grid = conv1_bwd_grid(B, C, T1, F1);
+    const size_t lds = (size_t)256 * 40 * sizeof(float);
+    hipLaunchKernelGGL((conv1_bwd3_kernel<true, true>), dim3(grid), dim3(256), lds, st, x, w, bias, (const bf16_t*)nullptr, workspace,
+                       B, T, F, C, stride, pad_t, pad_f, T1, F1, 3, 2, pad2_t, pad2_f, T2, F2, ph);
     MI_CHECK_LAUNCH();
     rows_reduce_launch(workspace, (int)grid, C * 10, EmitConv1{dw, db, 9}, st);
     MI_CHECK_LAUNCH();

@@ -18,6 +18,7 @@
 // not the limit); an eight-wave register-pipelined form was slower while the transposed reads were still 4-way bank-conflicted (fixed since: `swz`, -13 %).  The next
 // step is a 256 x 256 output tile (128 FLOP per byte, as the forward GEMM's gemm8p_kernel), at the price of twice the slab bytes.
 #include "common.hpp"
+#include <utility>
 
 namespace {
 
@@ -68,26 +69,44 @@ __device__ __forceinline__ void tr_frag_issue(const char* tile, int cb, int s, i
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0) : "memory");
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1) : "memory");
 }
+// The same read from a lane address computed ONCE per block (stage 0, k-step 0) plus an immediate: the swizzle of a row depends on (row & 15) only and a k-step moves
+// the rows by 16, so step s of a stage is the byte offset s * 16 * ROWB — the `offset:` field of the instruction, no VALU work between the MFMAs
+template <int OFF>
+__device__ __forceinline__ void tr_frag_issue_at(unsigned a0, unsigned a1, s16x4& lo, s16x4& hi) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "n"(OFF) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "n"(OFF) : "memory");
+}
+template <int ROWB>
+__device__ __forceinline__ void tr_frag_addr(unsigned tile_off, int cb, int lane, unsigned& a0, unsigned& a1) {
+    const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+    const int col = cb + (g & 1) * 16 + 4 * p4;
+    const int lc = col >> 3, within = (col & 7) * 2;
+    const int k0 = 4 * (g >> 1) + q4, k1 = k0 + 8;
+    a0 = tile_off + k0 * ROWB + ((lc ^ swz<ROWB / 16>(k0)) << 4) + within;
+    a1 = tile_off + k1 * ROWB + ((lc ^ swz<ROWB / 16>(k1)) << 4) + within;
+}
+template <int... I, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+
 __device__ __forceinline__ bf16x8 tr_frag_join(s16x4& lo, s16x4& hi) {
     asm volatile("" : "+v"(lo), "+v"(hi));                // the asm outputs are valid only behind the wait: keep the compiler from reading them earlier
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// NS = depth of the LDS ring.  Measured for the grouped launch (tools/tn_group_ab.py, 125 stages per block): once the compiler's vmcnt(0) waits were out of the way
-// (inline-asm transposed reads above; the group descriptor copied into SGPRs below) a stage costs a lone block 1.1-1.3 us whatever the depth (2, 3, 4) and whatever the
-// tile (128 x 128 with four waves, 256 x 128 with eight) — the 256 transposed reads per stage and CU and the 48 KiB of DMA writes keep the LDS busy ~1400 of those
-// ~2700 cycles, the MFMAs ~1000 — so the depth stays 2.
+// NS = depth of the LDS ring (see the grouped launch below for what it is worth per tile).
 // TNN = output tile rows (n): 128 (4 waves, 2 x 2 of 64 x 64) or 256 (8 waves, 4 x 2: the grouped launch — 85 FLOP per ingested byte instead of 64, two waves per SIMD).
-template <int TNN, int XW, int NS, bool CONVOK = true>       // CONVOK = false: the gathered-operand form (p.conv) is compiled out
+template <int TNN, int XW, int NS, bool CONVOK = true, int KM = TN_KM>       // KM = rows (m) per stage: 64, or 32 (finer stages: a deeper ring in the same LDS)
+//       // CONVOK = false: the gathered-operand form (p.conv) is compiled out
 __device__ __forceinline__ void tn_tile(const TnArgs& pin, const int bid) {
     TnArgs p = pin;
     if constexpr (!CONVOK) p.conv = 0;
     constexpr int XB = XW * 2, XCH = XW / 8;                  // X tile row bytes, 16-B chunks per row
     constexpr int YB = TNN * 2, YCH = TNN / 8;                // dY tile row bytes / chunks
     constexpr int NW = (TNN / 64) * 2, NT = 64 * NW;          // waves (n x k = TNN/64 x 2), threads
-    constexpr int YP = TN_KM * YB / 1024, XP = TN_KM * XB / 1024, PPW = (YP + XP) / NW;   // 1-KiB pieces per stage: dY, X, per wave
-    constexpr int STAGE = TN_KM * (YB + XB);
+    constexpr int YP = KM * YB / 1024, XP = KM * XB / 1024, PPW = (YP + XP) / NW;   // 1-KiB pieces per stage: dY, X, per wave
+    constexpr int STAGE = KM * (YB + XB);
     constexpr int NJ = XW / 64;                               // 32-column k blocks per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -97,32 +116,36 @@ __device__ __forceinline__ void tn_tile(const TnArgs& pin, const int bid) {
     const int split = bid / ntiles, tile = bid % ntiles;
     const int n0 = (tile / ntk) * TNN, k0 = (tile % ntk) * XW;
     const int m_lo = split * p.rows_per_split, m_hi = min(p.M, m_lo + p.rows_per_split);
-    const int nit = (m_hi - m_lo + TN_KM - 1) / TN_KM;
+    const int nit = (m_hi - m_lo + KM - 1) / KM;
 
     // piece g of the stage: 1 KiB of one operand tile — pieces [0, YP) dY, then X.  Per piece a lane keeps ONE register (its chunk's column within the operand's rows,
     // negative when outside the matrix); the row within the stage and the operand's base / row stride are recomputed from wave-uniform values at issue time
     // (eight 64-bit source pointers per lane pushed the 256 x 256 form over its 256-register budget: the pointers spilled and every reload waited for vmcnt(0)).
-    int coloff[PPW];
     constexpr int RPY = 1024 / YB, RPX = 1024 / XB;           // rows per piece
     const int rsubY = lane / YCH, rsubX = lane / XCH;
-#pragma unroll
-    for (int q = 0; q < PPW; ++q) {
+    auto coloff_of = [&](int q) {
         const int g = wave * PPW + q;
         if (g < YP) {
             const int row = g * RPY + rsubY, cs = lane % YCH;
             const int c = (cs ^ swz<YCH>(row)) * 8;          // source chunk for LDS slot cs
-            coloff[q] = n0 + c < p.N ? n0 + c : -1;
-        } else {
-            const int row = (g - YP) * RPX + rsubX, cs = lane % XCH;
-            const int c = (cs ^ swz<XCH>(row)) * 8;
-            coloff[q] = k0 + c < p.K ? (p.conv ? k0 % p.Cin + c : k0 + c) : -1;
+            return n0 + c < p.N ? n0 + c : -1;
         }
+        const int row = (g - YP) * RPX + rsubX, cs = lane % XCH;
+        const int c = (cs ^ swz<XCH>(row)) * 8;
+        return k0 + c < p.K ? (p.conv ? k0 % p.Cin + c : k0 + c) : -1;
+    };
+    // the gathered form addresses every stage through these; the plain-matrix kernels (CONVOK = false) need them for a ragged last stage only and recompute them
+    // there: eight registers that the second fragment set of the 64 x 128 wave tile takes instead
+    int coloff[CONVOK ? PPW : 1];
+    if constexpr (CONVOK) {
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) coloff[q] = coloff_of(q);
     }
     const int ctap = p.conv ? k0 / p.Cin : 0, ckh = p.conv ? ctap / p.KW : 0, ckw = p.conv ? ctap % p.KW : 0;       // block-uniform
     // conv: (b, to, fo) of the wave's FIRST X row of the stage, decoded once and advanced by the stage's 64 rows with carries (no divisions between a barrier and the
     // DMA it releases); a wave's pieces are consecutive rows, so piece q is that position + q * RPX with carries (three registers instead of three per piece)
     int cb0 = 0, cto0 = 0, cfo0 = 0;
-    const int adv_f = TN_KM % max(p.Fout, 1), adv_t = TN_KM / max(p.Fout, 1);
+    const int adv_f = KM % max(p.Fout, 1), adv_t = KM / max(p.Fout, 1);
     if (p.conv) {
         const unsigned ctf = (unsigned)(p.Tout * p.Fout);
         const int g0 = max(wave * PPW - YP, 0);
@@ -130,32 +153,68 @@ __device__ __forceinline__ void tn_tile(const TnArgs& pin, const int bid) {
         const unsigned bq = um / ctf, rem = um - bq * ctf, to = rem / (unsigned)p.Fout;
         cb0 = (int)bq; cto0 = (int)to; cfo0 = (int)(rem - to * (unsigned)p.Fout);
     }
-    auto issue = [&](int it, int stage) {
+    auto issue_part = [&](int it, int stage, int qlo, int qhi) {
         char* sbase = smem + stage * STAGE + wave * PPW * 1024;
-        const int mb = m_lo + it * TN_KM;
+        const int mb = m_lo + it * KM;
 #pragma unroll
         for (int q = 0; q < PPW; ++q) {
+            if (q < qlo || q >= qhi) continue;
+            const int colq = CONVOK ? coloff[CONVOK ? q : 0] : coloff_of(q);
             const int g = wave * PPW + q;                    // wave-uniform
             const bool isY = g < YP;
             const int m = mb + (isY ? g * RPY + rsubY : (g - YP) * RPX + rsubX);
             const bf16_t* base = isY ? p.Y : p.X;
             const long ld = isY ? p.ldy : p.ldx;
-            const bf16_t* sp = (m < m_hi && coloff[q] >= 0) ? base + (long)m * ld + coloff[q] : reinterpret_cast<const bf16_t*>(&g_zero16);
+            const bf16_t* sp = (m < m_hi && colq >= 0) ? base + (long)m * ld + colq : reinterpret_cast<const bf16_t*>(&g_zero16);
             if (p.conv && !isY) {                            // gathered im2col row (wave-uniform branch); stages are issued in order, so the carried position is this stage's
                 int fo = cfo0 + (g - max(wave * PPW - YP, 0) - YP) * RPX, to = cto0, bb = cb0;
                 while (fo >= p.Fout) { fo -= p.Fout; ++to; }
                 while (to >= p.Tout) { to -= p.Tout; ++bb; }
                 const int ti = to * p.cst - p.cpt + ckh, fi = fo * p.cst - p.cpf + ckw;
-                const bool in = m < m_hi && coloff[q] >= 0 && ti >= 0 && ti < p.Tin && fi >= 0 && fi < p.Fin;
-                sp = in ? p.X + (((long)bb * p.Tin + ti) * p.Fin + fi) * p.Cin + coloff[q] : reinterpret_cast<const bf16_t*>(&g_zero16);
+                const bool in = m < m_hi && colq >= 0 && ti >= 0 && ti < p.Tin && fi >= 0 && fi < p.Fin;
+                sp = in ? p.X + (((long)bb * p.Tin + ti) * p.Fin + fi) * p.Cin + colq : reinterpret_cast<const bf16_t*>(&g_zero16);
             }
             __builtin_amdgcn_global_load_lds((gptr_t)sp, (lptr_t)(sbase + q * 1024), 16, 0, 0);
         }
-        if (p.conv) {
+        if (p.conv && qhi == PPW) {
             cfo0 += adv_f; cto0 += adv_t;
             if (cfo0 >= p.Fout) { cfo0 -= p.Fout; ++cto0; }
             while (cto0 >= p.Tout) { cto0 -= p.Tout; ++cb0; }
         }
+    };
+    // A plain matrix operand goes through a BUFFER descriptor rebuilt per stage from scalars: base = operand + first row of the stage, records = the bytes up to the
+    // split's last row — rows past it read as zero (the hardware's range check is the ragged last stage), and the per-lane part of a piece's source is one 32-bit
+    // byte offset fixed for the whole block (row within the stage x row stride + column; a column outside the matrix is clamped to the tile's first one: what it
+    // brings in only reaches output rows / columns that are never stored).  The per-lane 64-bit pointer arithmetic of `issue_part` (~10 VALU operations per piece)
+    // was 40 % of the kernel's VALU instructions, which share the issue port with the MFMAs.
+    constexpr bool FAST = !(CONVOK && XW >= 256);             // (the gathered 256 x 256 form has no registers for the offsets and never takes this path)
+    unsigned poff[FAST ? PPW : 1];
+    const int wu = __builtin_amdgcn_readfirstlane(wave);
+    const bool fast_ok = FAST && !p.conv && (long)p.M * max(p.ldy, p.ldx) * 2 < (1l << 32) - 4096;
+    if constexpr (FAST) {
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            const int g = wu * PPW + q;
+            const bool isY = g < YP;
+            const int r = isY ? g * RPY + rsubY : (g - YP) * RPX + rsubX;
+            const int cq = coloff_of(q);
+            const int c = cq >= 0 ? cq : (isY ? n0 : k0);
+            poff[q] = (unsigned)(((long)r * (isY ? p.ldy : p.ldx) + c) * 2);
+        }
+    }
+    auto issue = [&](int it, int stage) {
+        const int mb = m_lo + it * KM;
+        if (FAST && fast_ok) {
+            char* sbase = smem + stage * STAGE + wu * PPW * 1024;
+            const long left = m_hi - mb;                                            // > 0: the stage exists
+            const auto ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.Y)) + (long)mb * p.ldy * 2, 0, (int)(unsigned)(left * p.ldy * 2), 0x00020000);
+            const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.X)) + (long)mb * p.ldx * 2, 0, (int)(unsigned)(left * p.ldx * 2), 0x00020000);
+#pragma unroll
+            for (int q = 0; q < PPW; ++q) {
+                if (wu * PPW + q < YP) __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lptr_t)(sbase + q * 1024), 16, (int)poff[FAST ? q : 0], 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(sbase + q * 1024), 16, (int)poff[FAST ? q : 0], 0, 0, 0);
+            }
+        } else issue_part(it, stage, 0, PPW);
     };
 
     f32x16 acc[2][NJ];
@@ -167,10 +226,21 @@ __device__ __forceinline__ void tn_tile(const TnArgs& pin, const int bid) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // bias gradient: the blocks of the first k-tile column also sum their dY tile over m (thread = column tid & 127, row half tid >> 7)
+    // (from the dY FRAGMENTS the MFMAs take anyway: a lane of an A operand holds eight m of one column n, `v_dot2_f32_bf16` against (1, 1) adds them two at a time into
+    // fp32 — 8 VALU instructions per k-step in the waves of the first k half, no LDS traffic.  Reading the column out of the LDS tile, 32 `ds_read_u16` per thread
+    // and stage, made these blocks the slowest of their launch: +14 ... +34 % on the whole grouped launch when every problem has a bias.)
     const bool do_db = p.db != nullptr && (tile % ntk) == 0;
-    const int bn = tid % TNN, bh = tid / TNN;
-    float bsum = 0.f;
+    const bool dbw = __builtin_amdgcn_readfirstlane((int)(do_db && wk == 0)) != 0;
+    float bsum[2] = {0.f, 0.f};
 
+    unsigned fya0[2], fya1[2], fxa0[NJ], fxa1[NJ];              // lane addresses of the fragment reads in stage 0, k-step 0 (LDS byte offsets)
+    {
+        const unsigned sm = (unsigned)(size_t)smem;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) tr_frag_addr<YB>(sm, wn * 64 + i * 32, lane, fya0[i], fya1[i]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) tr_frag_addr<XB>(sm + KM * YB, wk * (XW / 2) + j * 32, lane, fxa0[j], fxa1[j]);
+    }
 #pragma unroll
     for (int s0 = 0; s0 < NS - 1; ++s0)
         if (s0 < nit) issue(s0, s0);
@@ -182,43 +252,26 @@ __device__ __forceinline__ void tn_tile(const TnArgs& pin, const int bid) {
         asm volatile("s_barrier" ::: "memory");                        // every wave is done with stage it - 1: its buffer takes stage it + NS - 1
         if (it + NS - 1 < nit) issue(it + NS - 1, (it + NS - 1) % NS);
         const char* ty = smem + stage * STAGE;
-        const char* tx = ty + TN_KM * YB;
-        if (do_db) {
-            // (inline asm for the same reason as the transposed reads: a plain LDS load here would drag a vmcnt(0) in)
-            unsigned short hv[32];
-#pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                const int m = bh * 32 + r;
-                const unsigned a = (unsigned)(size_t)(ty + m * YB + (((bn >> 3) ^ swz<YCH>(m)) << 4) + (bn & 7) * 2);
-                unsigned v;
-                asm volatile("ds_read_u16 %0, %1" : "=v"(v) : "v"(a) : "memory");
-                hv[r] = (unsigned short)v;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                asm volatile("" : "+v"(hv[r]));
-                bsum += __builtin_bit_cast(float, (unsigned)hv[r] << 16);
-            }
-        }
+        const char* tx = ty + KM * YB;
         // 4 k-steps of 16 rows; the fragments of step s + 1 are requested before the MFMAs of step s issue (two register sets, counted lgkmcnt)
         constexpr int NR = 2 * (2 + NJ);                      // LDS reads per k-step and lane
-        constexpr int NB = XW >= 256 ? 1 : 2;                 // fragment register sets: the 64 x 128 wave tile (128 accumulators) has no room for a second one
+        constexpr int NB = (XW >= 256 && CONVOK) ? 1 : 2;    // fragment register sets: the gathered form on the 64 x 128 wave tile has no room for a second one
         s16x4 ylo[NB][2], yhi[NB][2], xlo[NB][NJ], xhi[NB][NJ];
-        auto rd = [&](int buf, int s) {
+        auto rd = [&](int buf, auto sc) {
+            constexpr int s = decltype(sc)::value;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) tr_frag_issue<YB>(ty, wn * 64 + i * 32, s, lane, ylo[buf][i], yhi[buf][i]);
+            for (int i = 0; i < 2; ++i) tr_frag_issue_at<s * 16 * YB>(fya0[i], fya1[i], ylo[buf][i], yhi[buf][i]);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) tr_frag_issue<XB>(tx, wk * (XW / 2) + j * 32, s, lane, xlo[buf][j], xhi[buf][j]);
+            for (int j = 0; j < NJ; ++j) tr_frag_issue_at<s * 16 * XB>(fxa0[j], fxa1[j], xlo[buf][j], xhi[buf][j]);
         };
-        if (NB == 2) rd(0, 0);
-#pragma unroll
-        for (int s = 0; s < TN_KM / 16; ++s) {
-            if (NB == 2 && s + 1 < TN_KM / 16) {
-                rd((s + 1) & 1, s + 1);
+        if constexpr (NB == 2) rd(0, std::integral_constant<int, 0>{});
+        static_for(std::make_integer_sequence<int, KM / 16>{}, [&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if constexpr (NB == 2 && s + 1 < KM / 16) {
+                rd((s + 1) & 1, std::integral_constant<int, s + 1>{});
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");      // step s's reads are the older NR
             } else {
-                if (NB == 1) rd(0, s);
+                if constexpr (NB == 1) rd(0, sc);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             bf16x8 fy[2], fx[NJ];
@@ -226,20 +279,44 @@ __device__ __forceinline__ void tn_tile(const TnArgs& pin, const int bid) {
             for (int i = 0; i < 2; ++i) fy[i] = tr_frag_join(ylo[s & (NB - 1)][i], yhi[s & (NB - 1)][i]);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) fx[j] = tr_frag_join(xlo[s & (NB - 1)][j], xhi[s & (NB - 1)][j]);
+            if (dbw) {
+                typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                const bf16x2_t one2 = __builtin_bit_cast(bf16x2_t, 0x3F803F80u);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(fy[i], fy[i], 0, 1), one2, bsum[i], false);
+                    bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(fy[i], fy[i], 2, 3), one2, bsum[i], false);
+                    bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(fy[i], fy[i], 4, 5), one2, bsum[i], false);
+                    bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(fy[i], fy[i], 6, 7), one2, bsum[i], false);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);   // rows n (regs), cols k (lanes)
+            // the MFMAs of a step stay between its wait and the next step's: left free, the scheduler sinks the third step's below the fourth's reads and
+            // lgkmcnt(0) (the asm statements keep their order, plain instructions float past them) — 16 MFMAs in a row behind a full LDS wait at the end of every stage
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        {                                                    // the read addresses follow the ring in place (no per-stage copies: registers)
+            const int step = stage == NS - 1 ? -(NS - 1) * STAGE : STAGE;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { fya0[i] += step; fya1[i] += step; }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { fxa0[j] += step; fxa1[j] += step; }
         }
     }
     if (do_db) {
         asm volatile("s_barrier" ::: "memory");                          // every wave is done with the LDS tiles
         float* red = reinterpret_cast<float*>(smem);
-        red[tid] = bsum;
+        if (dbw) {                                                       // column n of the tile: its two m halves (lane, lane + 32) side by side
+#pragma unroll
+            for (int i = 0; i < 2; ++i) red[(wn * 64 + i * 32 + (lane & 31)) * 2 + (lane >> 5)] = bsum[i];
+        }
         __syncthreads();
         if (tid < TNN && n0 + tid < p.n_store) {
-            const float v = red[tid] + red[tid + TNN];
+            const float v = red[2 * tid] + red[2 * tid + 1];
             if (p.db_slab) p.db_slab[(long)split * p.N + n0 + tid] = v;
             else p.db[n0 + tid] += v;
         }
@@ -280,11 +357,23 @@ constexpr int TN_GROUP = 48;
 struct TnDesc { const bf16_t* Y; const bf16_t* X; float* out; float* db; int ldy, ldx, ldo, M, N, K, n_store, pad_; };
 struct TnGroup { TnDesc a[TN_GROUP]; int tile0[TN_GROUP + 1]; int n; };
 
-constexpr int TN_GROUP_NS = 2, TN_GROUP_N = 256;           // 256 (n) x XW (k) tiles, 8 waves, two stages: one block per CU, two waves per SIMD
-// XW = 128: 48-KiB stages, wave tiles 64 x 64 (two LDS fragment reads per MFMA).  XW = 256: 64-KiB stages, wave tiles 64 x 128 (1.5 reads per MFMA) and 128 instead of 85 FLOP per
-// ingested byte — in situ the launch is bound by what the CUs pull out of L2 (a stage takes 1.9 us with 256 blocks running against 1.2 us for a lone block), so the
-// larger tile is used whenever the recorded problems still give (nearly) every CU a block: two base-size layers per launch.
-template <int XW>
+constexpr int TN_GROUP_N = 256;                            // 256 (n) x XW (k) tiles, 8 waves: one block per CU, two waves per SIMD
+// XW = 128: 48-KiB stages, wave tiles 64 x 64 (two LDS fragment reads per MFMA), THREE stages.  XW = 256: 64-KiB stages, wave tiles 64 x 128 (1.5 reads per MFMA), 128
+// instead of 85 FLOP per ingested byte, two stages (three would be 192 KiB) — used whenever the recorded problems still give (nearly) every CU a block: two base-size
+// layers per launch.
+// Round 4 (tools/tn_group_depth.py: whole launches, every problem with its bias gradient; profiles/r04_m): PMC on the round-3 kernel showed MFMA busy 36 % of its CUs,
+// LDS <= 27 %, waves 47 % of their time in s_waitcnt — and 5.9 VALU instructions per MFMA.  Three causes, fixed in this order:
+//  (1) the address of every transposed read and the 64-bit source pointer of every LDS-DMA piece were recomputed per use (the inline-asm reads hide their address
+//      pattern from the compiler): now 12 lane addresses per block + the instruction's offset field, and a buffer descriptor per stage built in SALU;
+//  (2) the scheduler sank the third k-step's MFMAs below the fourth's reads and its lgkmcnt(0) (sched_barrier per step), and the 64 x 128 wave tile had one fragment
+//      set (a second one fits once (1) freed the registers): each wave now covers its own LDS latency;
+//  (3) the bias gradient read its dY column out of LDS (32 ds_read_u16 per thread and stage): the blocks that own one — half of them at d = 256 — set the launch's length.
+// With those gone the ring depth shows (it did not before): 256 x 128, small encoder x 4 layers at config 3's 48 000 rows 1407 -> 1060 us (three stages; 1197 with
+// two), two base layers on 256 x 256 329 -> 292 us (832 TFLOP/s).  The 128-wide form now sits at the chip's L2 -> LDS ingest (232 CUs x 48 KiB / 1.41 us = 7.9 TB/s;
+// the forward GEMM at 8192^3 takes in 10.5); the 256-wide one at 6.4 TB/s is bound by its two-stage ring (a stage's DMA has one stage of compute to land).
+// Measured and not kept: 32-row stages (4 x 32 KiB / 6 x 24 KiB rings: 300 / 361 us, twice the barriers), spreading a stage's DMA instructions over its k-steps
+// (334 us / 467 us: the issue back-pressure round 2's stamps showed was the compiler's vmcnt(0), not the queue).
+template <int XW, int NS>
 __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g) {
     // XCD-aware tile order: the hardware deals consecutive block ids round-robin over the 8 XCDs (each with its own L2), so XCD x works through one contiguous run of
     // the tile list — the tiles of one or two problems, which share their dY / X stage tiles — instead of every XCD pulling every problem's operands (worth 1.6 %)
@@ -306,7 +395,7 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g) {
     p.Y = q.Y; p.ldy = q.ldy; p.X = q.X; p.ldx = q.ldx; p.out = q.out; p.ldo = q.ldo; p.slab_stride = 0; p.db = q.db; p.db_slab = nullptr;
     p.M = q.M; p.N = q.N; p.K = q.K; p.n_store = q.n_store; p.splits = 1; p.rows_per_split = (q.M + TN_KM - 1) / TN_KM * TN_KM;
     p.conv = 0; p.Tin = p.Fin = p.Cin = p.Tout = p.Fout = p.KW = 1; p.cst = 1; p.cpt = p.cpf = 0;
-    tn_tile<TN_GROUP_N, XW, TN_GROUP_NS, false>(p, bid - __builtin_amdgcn_readfirstlane(g.tile0[iu]));
+    tn_tile<TN_GROUP_N, XW, NS, false>(p, bid - __builtin_amdgcn_readfirstlane(g.tile0[iu]));
 }
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ out, long ldo, const float* __restrict__ slabs, long slab_stride,
@@ -450,13 +539,14 @@ extern "C" int mi_gemm_tn_group_bf16(int n, const void* const* dY, const long* l
         tiles += cdiv(N[i], TN_GROUP_N) * cdiv(K[i], xw);
     }
     g.tile0[n] = tiles;
-    const size_t lds = (size_t)TN_GROUP_NS * TN_KM * (TN_GROUP_N * 2 + xw * 2);          // 2 x 48 KiB / 2 x 64 KiB: one block per CU
+    const int ns = xw == 256 ? 2 : 3;
+    const size_t lds = (size_t)ns * TN_KM * (TN_GROUP_N * 2 + xw * 2);          // 2 x 64 KiB / 3 x 48 KiB: one block per CU
     if (xw == 256) {
-        if (!ensure_dynamic_lds<3>(reinterpret_cast<const void*>(gemm_tn_group_kernel<256>), lds)) return MI_ERR_LAUNCH;
-        hipLaunchKernelGGL(gemm_tn_group_kernel<256>, dim3(tiles), dim3(512), lds, st, g);
+        if (!ensure_dynamic_lds<3>(reinterpret_cast<const void*>(gemm_tn_group_kernel<256, 2>), lds)) return MI_ERR_LAUNCH;
+        hipLaunchKernelGGL((gemm_tn_group_kernel<256, 2>), dim3(tiles), dim3(512), lds, st, g);
     } else {
-        if (!ensure_dynamic_lds<4>(reinterpret_cast<const void*>(gemm_tn_group_kernel<128>), lds)) return MI_ERR_LAUNCH;
-        hipLaunchKernelGGL(gemm_tn_group_kernel<128>, dim3(tiles), dim3(512), lds, st, g);
+        if (!ensure_dynamic_lds<4>(reinterpret_cast<const void*>(gemm_tn_group_kernel<128, 3>), lds)) return MI_ERR_LAUNCH;
+        hipLaunchKernelGGL((gemm_tn_group_kernel<128, 3>), dim3(tiles), dim3(512), lds, st, g);
     }
     MI_CHECK_LAUNCH();
     return MI_OK;

@@ -474,6 +474,30 @@ def conv2d_first_bwd(x, w, bias, dcol, dw, db, K, stride, pad, T1, F1, K2, strid
                                         B, T, F, Cc, K, stride, pad, pad, T1, F1, K2, stride2, pad2, pad2, T2, F2, ws, _stream()), "mi_conv2d_first_bwd")
 
 
+def conv2d_s2k3_dgrad_supported(B, T1, F1, C1, T2, F2, pad):
+    """elements of the phase buffers of `conv2d_first_bwd_phases`, 0 when the geometry needs the im2col-gradient path"""
+    return int(_L().mi_conv2d_s2k3_dgrad_elems(B, T1, F1, C1, T2, F2, pad, pad))
+
+
+def conv2d_first_bwd_phases(x, w, bias, dy2, wT2, dw, db, K, stride, pad, T1, F1, pad2, T2, F2):
+    """Backward of the front end below conv2's pre-activation gradient `dy2` (B*T2*F2, C2) bf16, with conv2 = 3x3 / stride 2: conv2's input gradient as four stride-1
+    implicit-GEMM convolutions into phase buffers (mi_conv2d_s2k3_dgrad_bf16; wT2 (9*C1, >= C2) = the transposed weight copy, re-packed per call: the weights move every
+    step), then conv1's GELU', weight and bias gradient reading them (mi_conv2d_first_bwd_phases).  The (B*T2*F2, 9*C1) im2col gradient is never formed."""
+    B, T, F = x.shape
+    C1, C2 = w.shape[0], dy2.shape[1]
+    assert dy2.is_contiguous() and dy2.shape[0] == B * T2 * F2 and wT2.shape[0] == 9 * C1
+    n = conv2d_s2k3_dgrad_supported(B, T1, F1, C1, T2, F2, pad2)
+    assert n > 0
+    packed = torch.empty(9 * C1 * C2, device=x.device, dtype=BF16)
+    phases = torch.empty(n, device=x.device, dtype=BF16)
+    _lib.check(_L().mi_conv2d_s2k3_dgrad_pack_bf16(wT2.data_ptr(), wT2.stride(0), packed.data_ptr(), C1, C2, _stream()), "mi_conv2d_s2k3_dgrad_pack_bf16")
+    _lib.check(_L().mi_conv2d_s2k3_dgrad_bf16(dy2.data_ptr(), packed.data_ptr(), phases.data_ptr(), B, T1, F1, C1, T2, F2, C2, pad2, pad2, _stream()), "mi_conv2d_s2k3_dgrad_bf16")
+    ws = _dw_ws(x.device, int(_L().mi_conv2d_first_bwd_workspace_floats(B, C1, T1, F1)))
+    _lib.check(_L().mi_conv2d_first_bwd_phases(x.data_ptr(), w.data_ptr(), bias.data_ptr(), phases.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                               B, T, F, C1, K, stride, pad, pad, T1, F1, pad2, pad2, T2, F2, ws, _stream()), "mi_conv2d_first_bwd_phases")
+    return phases
+
+
 def ctc_loss_bwd(logits, lse, labels, in_len, nll, *, reduction="mean", gscale=1.0, ldo=None):
     """-> dlogits (B*T, ldo) bf16 of gscale * ctc_loss(reduction), pad columns zero."""
     B, T, V1 = logits.shape

@@ -887,8 +887,12 @@ class EncoderCTCTrainer:
         if cm == 0:
             dpre2 = T.act_bwd(dact2.view(B * T2 * F2, C2), pre2)
             T.conv2d_wgrad_(G("conv2_w"), dpre2, act1, K, s_, padl, T2, F2, db=G("conv2_b"))      # the im2col operand is gathered inside the GEMM, never written
-            dcol = ops.gemm(dpre2, WT("conv2_w")[:, :C2])
-            T.conv2d_first_bwd(feats, P("conv1_w"), P("conv1_b"), dcol, G("conv1_w"), G("conv1_b"), K, s_, padl, T1, F1, K, s_, padl, T2, F2)
+            if K == 3 and s_ == 2 and T.conv2d_s2k3_dgrad_supported(B, T1, F1, C1, T2, F2, padl):
+                # conv2's input gradient as four stride-1 convolutions (one per parity of the position) into phase buffers that conv1's backward reads directly
+                T.conv2d_first_bwd_phases(feats, P("conv1_w"), P("conv1_b"), dpre2, WT("conv2_w"), G("conv1_w"), G("conv1_b"), K, s_, padl, T1, F1, padl, T2, F2)
+            else:
+                dcol = ops.gemm(dpre2, WT("conv2_w")[:, :C2])
+                T.conv2d_first_bwd(feats, P("conv1_w"), P("conv1_b"), dcol, G("conv1_w"), G("conv1_b"), K, s_, padl, T1, F1, K, s_, padl, T2, F2)
         else:
             # y = z * sigmoid(g), out = GELU(y): dz = dout GELU'(y) sigmoid(g), dg = sum over the rows sharing g of dout GELU'(y) z sigmoid(g)(1 - sigmoid(g));
             # then conv and gate are two plain convs (ONE for "gated": conv and gate rows stacked) — dW = dY^T col, dX = col2im(dY W)

@@ -363,6 +363,19 @@ int mi_conv2d_first_bwd(const float* x, const float* w, const float* bias, const
                         int F, int C, int K, int stride, int pad_t, int pad_f, int T1, int F1, int K2, int stride2, int pad2_t,
                         int pad2_f, int T2, int F2, float* workspace /* mi_conv2d_first_bwd_workspace_floats: one partial row per block */, mi_stream_t stream);
 size_t mi_conv2d_first_bwd_workspace_floats(int B, int C, int T1, int F1);
+/* The second Conv2d's INPUT gradient (3x3, stride 2; what autograd derives for extractors.py:82-89's second layer) as four stride-1 implicit-GEMM convolutions, one per
+ * parity class of (t1 + pad_t, f1 + pad_f), instead of one GEMM into the gradient of the im2col operand (9 C1 columns per output position of conv2) and a col2im gather:
+ *   mi_conv2d_s2k3_dgrad_elems      bf16 elements of the four phase buffers, back to back; 0 = geometry not supported (keep mi_gemm_bf16 + mi_conv2d_first_bwd)
+ *   mi_conv2d_s2k3_dgrad_pack_bf16  wT (9*C1 rows (kh,kw,c), C2 columns, row stride ldwt) -> the four phase weight matrices (9*C1*C2 elements), once per weight update
+ *   mi_conv2d_s2k3_dgrad_bf16       dY2 (B,T2,F2,C2) contiguous -> phases
+ *   mi_conv2d_first_bwd_phases      mi_conv2d_first_bwd reading the phase buffers (one 16-B load per position and 8 channels instead of up to four) */
+size_t mi_conv2d_s2k3_dgrad_elems(int B, int T1, int F1, int C1, int T2, int F2, int pad_t, int pad_f);
+int mi_conv2d_s2k3_dgrad_pack_bf16(const void* wT, long ldwt, void* packed, int C1, int C2, mi_stream_t stream);
+int mi_conv2d_s2k3_dgrad_bf16(const void* dY2, const void* packed, void* phases, int B, int T1, int F1, int C1, int T2, int F2, int C2, int pad_t, int pad_f,
+                              mi_stream_t stream);
+int mi_conv2d_first_bwd_phases(const float* x, const float* w, const float* bias, const void* phases, float* dw, float* db, int B, int T, int F, int C, int K,
+                               int stride, int pad_t, int pad_f, int T1, int F1, int pad2_t, int pad2_f, int T2, int F2,
+                               float* workspace /* mi_conv2d_first_bwd_workspace_floats */, mi_stream_t stream);
 /* backward pieces of the context-aware front ends (extractors.py:23-65), un-fused: im2col / col2im with separate strides, the backward of mi_gated_act_bf16
  * (dz = dout GELU'(y) sigmoid(g), dg = sum over the shared rows of dout GELU'(y) z sigmoid(g)(1 - sigmoid(g)), y = z sigmoid(g)), and the weight / bias gradient of a
  * Conv2d(1 -> C) of geometry (3,3) or (12,3) from the gradient of its raw output. */

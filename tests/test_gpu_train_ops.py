@@ -531,6 +531,46 @@ def test_conv_frontend_bwd():
     torch.testing.assert_close(db.cpu(), b1r.grad, atol=5e-3 * float(b1r.grad.abs().max()), rtol=5e-3)
 
 
+@pytest.mark.parametrize("B,Tt,Fq", [(2, 61, 40), (3, 64, 80), (1, 37, 23)])
+def test_conv_frontend_bwd_by_phases(B, Tt, Fq):
+    """conv2's input gradient as four stride-1 implicit-GEMM convolutions (mi_conv2d_s2k3_dgrad_bf16: one per parity of the position) + conv1's backward reading the
+    phase buffers, against autograd through gelu(conv1) -> conv2 (the reference's front end, extractors.py:82-89): the phase buffers hold d(act1) position for position
+    (odd and even T1 / F1: the last row / column of a parity class reads past conv2's output and must see zeros), and dW1 / db1 follow."""
+    ops, T = _o()
+    C1 = C2 = 256
+    K, s, pad = 3, 2, 1
+    T1, F1 = (Tt + 2 * pad - K) // s + 1, (Fq + 2 * pad - K) // s + 1
+    T2, F2 = (T1 + 2 * pad - K) // s + 1, (F1 + 2 * pad - K) // s + 1
+    x = rnd(B, Tt, Fq, seed=1)
+    w1, b1 = rnd(C1, 1, K, K, seed=2, scale=0.3), 0.1 * rnd(C1, seed=3)
+    w2 = bfr(rnd(C2, C1, K, K, seed=5, scale=0.05))
+    dy2 = bfr(rnd(B, T2, F2, C2, seed=4))
+    w1r, b1r = w1.clone().requires_grad_(True), b1.clone().requires_grad_(True)
+    act1 = F.gelu(F.conv2d(x[:, None], w1r, b1r, stride=s, padding=pad))                  # (B,C1,T1,F1)
+    act1.retain_grad()
+    F.conv2d(act1, w2, None, stride=s, padding=pad).backward(dy2.permute(0, 3, 1, 2))
+    want_dact1 = act1.grad.permute(0, 2, 3, 1)                                              # (B,T1,F1,C1)
+    wT2 = dev16(w2.permute(2, 3, 1, 0).reshape(K * K * C1, C2))                             # row (kh, kw, c), column co
+    assert T.conv2d_s2k3_dgrad_supported(B, T1, F1, C1, T2, F2, pad) == B * T1 * F1 * C1
+    assert T.conv2d_s2k3_dgrad_supported(B, T1, F1, C1, T2, F2, 2) == 0                     # the causal front end's leading pad: stays on the im2col-gradient path
+    dw = torch.zeros(C1, K * K, device=DEV); db = torch.zeros(C1, device=DEV)
+    phases = T.conv2d_first_bwd_phases(x.to(DEV), w1.reshape(C1, K * K).to(DEV), b1.to(DEV), dev16(dy2.reshape(B * T2 * F2, C2)), wT2, dw, db,
+                                       K, s, pad, T1, F1, pad, T2, F2).float().cpu()
+    got = torch.zeros(B, T1, F1, C1)
+    off = 0
+    for pt in (0, 1):
+        t1s = [t for t in range(T1) if (t + pad) % 2 == pt]
+        for pf in (0, 1):
+            f1s = [f for f in range(F1) if (f + pad) % 2 == pf]
+            n = B * len(t1s) * len(f1s) * C1
+            blk = got[:, t1s]; blk[:, :, f1s] = phases[off:off + n].view(B, len(t1s), len(f1s), C1); got[:, t1s] = blk
+            off += n
+    assert off == phases.numel()
+    close(got, want_dact1, floor=4e-3, what="d(act1) from the phase buffers")
+    torch.testing.assert_close(dw.cpu(), w1r.grad.reshape(C1, K * K), atol=5e-3 * float(w1r.grad.abs().max()), rtol=5e-3)
+    torch.testing.assert_close(db.cpu(), b1r.grad, atol=5e-3 * float(b1r.grad.abs().max()), rtol=5e-3)
+
+
 @pytest.mark.parametrize("reduction", ["mean", "sum"])
 def test_ctc_loss_bwd(reduction):
     ops, T = _o()

@@ -1,11 +1,14 @@
 """Per-kernel totals of a rocprofv3 --kernel-trace CSV over the last `frac` of the run (default: the second half = steady state): microseconds per `n_steps`.
 
-    python tools/trace_breakdown.py <kernel_trace.csv> <n_steps_in_window> [start_frac]
+    python tools/trace_breakdown.py <kernel_trace.csv> <n_steps_in_window> [marker] [--grid]      (--grid: one row per (kernel, grid size): tells a kernel's call sites apart)
 """
 import collections
 import csv
 import sys
 
+by_grid = "--grid" in sys.argv
+if by_grid:
+    sys.argv.remove("--grid")
 rows = list(csv.DictReader(open(sys.argv[1])))
 n = int(sys.argv[2])
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -15,6 +18,8 @@ lo, hi = idx[-n - 1] + 1, idx[-1] + 1          # the last n steps, each ending w
 agg = collections.defaultdict(lambda: [0, 0])
 for r in rows[lo:hi]:
     k = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:70]
+    if by_grid:
+        k = f"{k[:52]} grid {r.get('Grid_Size_X', r.get('Grid_Size', '?'))}x{r.get('Grid_Size_Y', '')}x{r.get('Grid_Size_Z', '')} wg {r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?'))}"
     agg[k][0] += 1
     agg[k][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 tot = sum(v[1] for v in agg.values())
