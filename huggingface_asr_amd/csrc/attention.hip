@@ -60,22 +60,20 @@ constexpr int WSCR_B = 32 * OST_B;   // per-wave scratch of the LDS-staged kerne
 __device__ __forceinline__ int crow(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
 // keep factors (0 or 1 / (1 - p)) of a lane's 16 score registers of one 32-key step: register e is key j0 + crow(e, half); idx0 = logical index of key j0 of the
-// lane's query row.  One hash per PAIR of logical indices (common.hpp): a run of four consecutive keys takes two hashes, three when it starts odd (Tk odd only).
-__device__ __forceinline__ void keep16(unsigned long long key, float p, unsigned long long idx0, int half, bool tk_odd, float (&ks)[16]) {
+// lane's query row.  One hash per QUAD of logical indices (common.hpp): a run of four consecutive keys takes one hash, two when it does not start on a quad
+// (`unaligned`, wave-uniform: Tk not a multiple of 4 — then a row's first key sits anywhere in its quad).
+__device__ __forceinline__ void keep16(unsigned long long key, float p, unsigned long long idx0, int half, bool unaligned, float (&ks)[16]) {
     const float inv = 1.f / (1.f - p);
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
-        const unsigned long long s = idx0 + 8 * g4 + 4 * half, p0 = s >> 1;
-        const unsigned long long h0 = mask_hash(key, p0), h1 = mask_hash(key, p0 + 1);
-        unsigned long long h2 = h1;
-        if (tk_odd) h2 = mask_hash(key, p0 + 2);           // wave-uniform
-        const bool odd = (s & 1) != 0;
+        const unsigned long long s = idx0 + 8 * g4 + 4 * half, q0 = s >> 2;
+        if (!unaligned) { mask_keep4(key, q0, p, inv, &ks[4 * g4]); continue; }
+        const unsigned long long h0 = mask_hash(key, q0), h1 = mask_hash(key, q0 + 1);
+        const int o = (int)(s & 3);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            // even start: (h0 e, h0 o, h1 e, h1 o); odd start: (h0 o, h1 e, h1 o, h2 e)
-            const unsigned long long he = k < 2 ? h0 : h1, ho = k == 0 ? h0 : (k == 3 ? h2 : h1);
-            const float u = odd ? mask_u01(ho, (k & 1) == 0 ? 1 : 0) : mask_u01(he, k & 1);
-            ks[4 * g4 + k] = u >= p ? inv : 0.f;
+            const int j = o + k;
+            ks[4 * g4 + k] = mask_u01(j < 4 ? h0 : h1, j & 3) >= p ? inv : 0.f;
         }
     }
 }
@@ -571,7 +569,7 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
                 // the forward multiplied V by P keep / (1 - p): dctx V^T is the gradient of THAT, delta = dctx · ctx already is sum_j P_j keep_j dP_j, and the P that
                 // leaves for dV = P^T dctx is the dropped one
                 float ks[16];
-                keep16(p.drop_key, p.drop_p, drop_row0 + (unsigned long long)j0, h2, (Tk & 1) != 0, ks);
+                keep16(p.drop_key, p.drop_p, drop_row0 + (unsigned long long)j0, h2, (Tk & 3) != 0, ks);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const float pr = __builtin_amdgcn_exp2f(S[e] - lse2);
@@ -654,7 +652,7 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
             l += half_swap_sum(ls);
             if (p.drop_p > 0.f) {                            // probability dropout (training forward): the normaliser keeps every key, the PV product the survivors / (1 - p)
                 float ks[16];
-                keep16(p.drop_key, p.drop_p, drop_row0 + (unsigned long long)j0, h2, (Tk & 1) != 0, ks);
+                keep16(p.drop_key, p.drop_p, drop_row0 + (unsigned long long)j0, h2, (Tk & 3) != 0, ks);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) S[e] *= ks[e];
             }
@@ -1165,7 +1163,7 @@ __global__ __launch_bounds__(512) void attn8_kernel(AttnArgs p) {
             issue_dma_part(2);
             if constexpr (DROP) {
                 float ks[16];
-                keep16(p.drop_key, p.drop_p, drop_row0 + (unsigned long long)j0, h2, (Tk & 1) != 0, ks);
+                keep16(p.drop_key, p.drop_p, drop_row0 + (unsigned long long)j0, h2, (Tk & 3) != 0, ks);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) S[e] *= ks[e];
             }

@@ -38,27 +38,14 @@ __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
 
 // erf-GELU, the reference's "gelu" activation (ACT2FN["gelu"] / nn.GELU()):  0.5 x (1 + erf(x / sqrt 2)).
-// erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7, far below the bf16 / fp32-accumulate noise of the path):
-// libm's erff costs ~50 VALU instructions and the path evaluates it 0.8 G times per step, this form ~14.
-__device__ __forceinline__ float fast_erf(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float poly = fmaf(t, 1.061405429f, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    const float r = 1.0f - poly * __expf(-ax * ax);
-    return copysignf(r, x);
-}
 // Every forward GELU of the path is rounded to bf16 (8 significant bits) right after it, and in the GEMM epilogues it is the critical path: 128 values
-// per lane, VALU-bound (17 instructions per value with the erf form above, two of them quarter-rate).  So the forward uses
+// per lane, VALU-bound (17 instructions per value with an Abramowitz-Stegun erf, two of them quarter-rate).  So the forward uses
 //     x * Phi(x),  Phi(x) ~= 1 / (1 + 2^(xc * (c1 + c3 xc^2 + c5 xc^4))),  xc = clamp(x, -10, 10)      (c* = -log2(e) * minimax fit of logit(Phi), odd in x)
 // 9 instructions (med3, mul, 2 fma, mul, exp2, add, rcp, mul); |error| <= 2.6e-5 absolute for |x| <= 10 (the usual tanh form: 4.7e-4), relative error <= 5e-4 for
 // x > -2 — below a quarter of a bf16 half-ulp wherever |GELU| > 0.02 — and values in the negative tail (|GELU| < 0.016) within 2.6e-5 of exact.
 // The clamp is what makes it total: the quintic's x^5 coefficient has the opposite sign of the others, so the un-clamped exponent turns around at |x| ~ 11.1
 // (GELU(12) came out as 9e-12, GELU(-12) as -12).  At |xc| = 10 the exponent is -+28.5, i.e. Phi = 1 - 3e-9 / 3e-9: beyond it the result is x * Phi(+-10)
-// = x resp. -0 to fp32 precision, +-inf included (x = -inf: -inf * 2.6e-9 = -inf is avoided by the select below).  The backward keeps the exact derivative (fast_erf).
+// = x resp. -0 to fp32 precision, +-inf included (x = -inf: -inf * 2.6e-9 = -inf is avoided by the select below).  The backward (gelu_erf_grad below) uses the same fit for Phi.
 __device__ __forceinline__ float gelu_erf(float x) {
     const float xc = __builtin_amdgcn_fmed3f(x, -10.0f, 10.0f);
     const float x2 = xc * xc;
@@ -79,10 +66,17 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 }
 
 // derivatives of the two GELUs (training: element-wise kernels, the conv front end's backward, the dX GEMM's training epilogue)
+// GELU'(x) = Phi(x) + x phi(x), with the forward's logistic fit for Phi and phi from one exp2 (|error| <= 5e-5 absolute over the whole line): 12 instructions, three of them quarter-rate — the
+// erf form (fast_erf + a separate exp: 22) made every epilogue and element-wise kernel that applies the derivative VALU-bound (the dX GEMM's training epilogue, conv1's
+// backward, mi_act_bwd); every consumer rounds the product to bf16 (relative 2e-3).  The clamp keeps +-inf finite: Phi(+-10) = 1 / 0 to fp32, x phi(x) -> 0.
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.f + fast_erf(x * 0.70710678118654752440f));
-    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    const float xc = __builtin_amdgcn_fmed3f(x, -10.0f, 10.0f);
+    const float x2 = xc * xc;
+    float p = fmaf(x2, 1.01426783e-3f, -1.06775756e-1f);
+    p = fmaf(p, x2, -2.30112135f);
+    const float cdf = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(p * xc));
+    const float pdf = __builtin_amdgcn_exp2f(-0.72134752044f * x2);                    // exp(-x^2 / 2)
+    return fmaf(xc * 0.3989422804014327f, pdf, cdf);
 }
 __device__ __forceinline__ float gelu_tanh_grad(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
@@ -187,16 +181,25 @@ static inline void rows_reduce_launch(const float* partial, int rows, int n, Emi
 }
 
 // Counter-based uniform draws of the dropout masks (dropout.hip, attn_bwd.hip; host twin: huggingface_asr_amd/synth.py `dropout_keep`):
-// one splitmix64 round over (pair index ^ key) yields TWO 24-bit draws — element idx takes bits 63..40 when even, bits 39..16 when odd —
-// so a mask costs one 64-bit hash per two elements (the hash, quarter-rate integer multiplies, is what bounds the mask kernels).
-__device__ __forceinline__ unsigned long long mask_hash(unsigned long long key, unsigned long long pair) {
-    unsigned long long z = (pair ^ key) + 0x9E3779B97F4A7C15ull;
+// one splitmix64 round over (quad index ^ key) yields FOUR 16-bit draws — element idx takes bits 63..48, 47..32, 31..16, 15..0 for idx & 3 = 0, 1, 2, 3 —
+// so a mask costs one 64-bit hash per four elements.  The hash (two 64-bit multiplies = eight quarter-rate 32-bit ones, ~200 issue cycles) is what bounds the mask
+// kernels and was, at one hash per PAIR with 24-bit draws (rounds 2-3), the largest VALU item of the training GEMM epilogues — more than the GELU next to it;
+// 16 bits resolve p to 1.5e-5 (keep probability at p = 0.1: 0.899994).
+__device__ __forceinline__ unsigned long long mask_hash(unsigned long long key, unsigned long long quad) {
+    unsigned long long z = (quad ^ key) + 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-__device__ __forceinline__ float mask_u01(unsigned long long h, int odd) {
-    return (float)(odd ? (unsigned)(h >> 16) & 0xFFFFFFu : (unsigned)(h >> 40)) * (1.0f / 16777216.0f);
+__device__ __forceinline__ float mask_u01(unsigned long long h, int j) {        // j = idx & 3
+    const unsigned w = j < 2 ? (unsigned)(h >> 32) : (unsigned)h;
+    return (float)((j & 1) ? (w & 0xFFFFu) : (w >> 16)) * (1.0f / 65536.0f);
 }
-__device__ __forceinline__ float mask_u01_at(unsigned long long key, unsigned long long idx) { return mask_u01(mask_hash(key, idx >> 1), (int)(idx & 1)); }
+__device__ __forceinline__ float mask_u01_at(unsigned long long key, unsigned long long idx) { return mask_u01(mask_hash(key, idx >> 2), (int)(idx & 3)); }
+// keep factors of the four elements of one (aligned) quad
+__device__ __forceinline__ void mask_keep4(unsigned long long key, unsigned long long quad, float p, float inv_keep, float* ks) {
+    const unsigned long long h = mask_hash(key, quad);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ks[j] = mask_u01(h, j) >= p ? inv_keep : 0.f;
+}
 

@@ -3,7 +3,7 @@
 // Reference: torch.nn.Dropout at the points the reference applies it in train() mode (e_branchformer.py:132,203,288,301,451;
 // tf wav2vec2_conformer FFN :353,356, encoder input :674; GPT-2 embd / attn / resid dropouts).  torch's Philox stream cannot be
 // reproduced, so the mask is DEFINED here as a pure function of (seed, stream, logical element index):
-//     keep(idx) = u24(idx) * 2^-24 >= p,   u24 = bits 63..40 (idx even) or 39..16 (idx odd) of splitmix64((idx >> 1) ^ key),   key = (stream << 32) ^ seed
+//     keep(idx) = u16(idx) * 2^-16 >= p,   u16 = 16-bit field (idx & 3) — from the top — of splitmix64((idx >> 2) ^ key),   key = (stream << 32) ^ seed
 // the same hash as huggingface_asr_amd/synth.py (`dropout_keep`), so the CPU oracle is run with the identical masks in the parity
 // tests and the backward pass regenerates the mask instead of storing it.   out = x * keep / (1 - p).
 #include "common.hpp"
@@ -47,13 +47,11 @@ __global__ __launch_bounds__(256) void dropout_vec8_kernel(const TI* __restrict_
             const f32x4 a = *reinterpret_cast<const f32x4*>(x + (long)m * ldx + c), b = *reinterpret_cast<const f32x4*>(x + (long)m * ldx + c + 4);
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
         }
-        const unsigned long long pair0 = (unsigned long long)i << 2;              // 8 elements = 4 hashes
+        float ks[8];                                                              // 8 elements = 2 hashes
+        mask_keep4(key, (unsigned long long)i << 1, p, inv_keep, ks);
+        mask_keep4(key, ((unsigned long long)i << 1) + 1, p, inv_keep, ks + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const unsigned long long h = mask_hash(key, pair0 + e);
-            v[2 * e] = v[2 * e] * alpha * (mask_u01(h, 0) >= p ? inv_keep : 0.f);
-            v[2 * e + 1] = v[2 * e + 1] * alpha * (mask_u01(h, 1) >= p ? inv_keep : 0.f);
-        }
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * alpha * ks[e];
         if constexpr (sizeof(TO) == 2) {
             bf16x8 o;
 #pragma unroll
@@ -74,12 +72,13 @@ __global__ __launch_bounds__(256) void dropout_add_vec4_kernel(float* __restrict
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total4; i += gridDim.x * 256u) {
         const unsigned m = i / n4, c = (i - m * n4) << 2;
         const f32x4 r = *reinterpret_cast<const f32x4*>(resid + (long)m * ldr + c), tv = *reinterpret_cast<const f32x4*>(t + (long)m * ldt + c);
-        const unsigned long long h0 = mask_hash(key, (unsigned long long)i << 1), h1 = mask_hash(key, ((unsigned long long)i << 1) + 1);
+        float ks[4];
+        mask_keep4(key, (unsigned long long)i, p, inv_keep, ks);
         f32x4 o;
-        o.x = r.x + alpha * tv.x * (mask_u01(h0, 0) >= p ? inv_keep : 0.f);
-        o.y = r.y + alpha * tv.y * (mask_u01(h0, 1) >= p ? inv_keep : 0.f);
-        o.z = r.z + alpha * tv.z * (mask_u01(h1, 0) >= p ? inv_keep : 0.f);
-        o.w = r.w + alpha * tv.w * (mask_u01(h1, 1) >= p ? inv_keep : 0.f);
+        o.x = r.x + alpha * tv.x * ks[0];
+        o.y = r.y + alpha * tv.y * ks[1];
+        o.z = r.z + alpha * tv.z * ks[2];
+        o.w = r.w + alpha * tv.w * ks[3];
         *reinterpret_cast<f32x4*>(y + (long)m * ldy + c) = o;
     }
 }

@@ -413,13 +413,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
                 const int m = m0 + wr * 128 + row;
                 float ks[8];
                 if (drop) {
-                    const unsigned long long pair0 = ((unsigned long long)m * n8 + ((nb >> 3) + pc)) << 2;      // logical index m * N + n of the first element, halved
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const unsigned long long h = mask_hash(p.drop_key, pair0 + e);
-                        ks[2 * e] = mask_u01(h, 0) >= p.drop_p ? inv_keep : 0.f;
-                        ks[2 * e + 1] = mask_u01(h, 1) >= p.drop_p ? inv_keep : 0.f;
-                    }
+                    const unsigned long long quad0 = ((unsigned long long)m * n8 + ((nb >> 3) + pc)) << 1;      // logical index m * N + n of the first element, over 4
+                    mask_keep4(p.drop_key, quad0, p.drop_p, inv_keep, ks);
+                    mask_keep4(p.drop_key, quad0 + 1, p.drop_p, inv_keep, ks + 4);
                 }
                 bf16x8 o;
                 if constexpr (ACT == 3) {
@@ -796,11 +792,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p128p_kernel(GemmArgs p) {
             f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * 128 + ((pc ^ ((row >> 1) & 7)) << 4));
             const int m = m0 + wr * 64 + row;
             if (p.drop_p > 0.f) {            // dropout of the linear's output before the residual add (training: hidden / final dropout): mask of mi_dropout_add_f32 for (m, n)
-                const unsigned long long pair0 = ((unsigned long long)m * (unsigned)(p.N >> 2) + (unsigned)((nb >> 2) + pc)) << 1;
-                const unsigned long long h0 = mask_hash(p.drop_key, pair0), h1 = mask_hash(p.drop_key, pair0 + 1);
-                const float ik = 1.f / (1.f - p.drop_p);
-                v = f32x4{v.x * (mask_u01(h0, 0) >= p.drop_p ? ik : 0.f), v.y * (mask_u01(h0, 1) >= p.drop_p ? ik : 0.f),
-                          v.z * (mask_u01(h1, 0) >= p.drop_p ? ik : 0.f), v.w * (mask_u01(h1, 1) >= p.drop_p ? ik : 0.f)};
+                float k4[4];
+                mask_keep4(p.drop_key, (unsigned long long)m * (unsigned)(p.N >> 2) + (unsigned)((nb >> 2) + pc), p.drop_p, 1.f / (1.f - p.drop_p), k4);
+                v = f32x4{v.x * k4[0], v.y * k4[1], v.z * k4[2], v.w * k4[3]};
             }
             if (use_res) v = rres[u] + p.alpha * v;
             if (m < p.M) *reinterpret_cast<f32x4*>(C + (long)m * p.ldc + nb + pc * 4) = v;
@@ -836,14 +830,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p128p_kernel(GemmArgs p) {
             const int m = m0 + wr * 64 + row;
             if (p.drop_p > 0.f) {            // dropout on the bf16 rows (mask and rounding of mi_dropout's bf16 form for element m * N + n)
                 bf16x8 e = __builtin_bit_cast(bf16x8, v);
-                const unsigned long long pair0 = ((unsigned long long)m * (unsigned)(p.N >> 3) + (unsigned)((nb >> 3) + c4)) << 2;
-                const float ik = 1.f / (1.f - p.drop_p);
+                const unsigned long long quad0 = ((unsigned long long)m * (unsigned)(p.N >> 3) + (unsigned)((nb >> 3) + c4)) << 1;
+                float k8[8];
+                mask_keep4(p.drop_key, quad0, p.drop_p, 1.f / (1.f - p.drop_p), k8);
+                mask_keep4(p.drop_key, quad0 + 1, p.drop_p, 1.f / (1.f - p.drop_p), k8 + 4);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned long long h = mask_hash(p.drop_key, pair0 + q);
-                    e[2 * q] = f2bf(bf2f(e[2 * q]) * (mask_u01(h, 0) >= p.drop_p ? ik : 0.f));
-                    e[2 * q + 1] = f2bf(bf2f(e[2 * q + 1]) * (mask_u01(h, 1) >= p.drop_p ? ik : 0.f));
-                }
+                for (int q = 0; q < 8; ++q) e[q] = f2bf(bf2f(e[q]) * k8[q]);
                 v = __builtin_bit_cast(uint4, e);
             }
             if (m < p.M) *reinterpret_cast<uint4*>(C + (long)m * p.ldc + nb + c4 * 8) = v;

@@ -162,13 +162,9 @@ __global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ a, 
         if (MODE == 1) vb = *reinterpret_cast<const bf16x8*>(b + (long)m * ldb + c);
         float ks[8];
         if (DROP) {
-            const unsigned long long pair0 = (unsigned long long)i << 2;          // logical index of the first element = 8 i (rows are N = 8 N8 long)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned long long h = mask_hash(key, pair0 + e);
-                ks[2 * e] = mask_u01(h, 0) >= p ? inv_keep : 0.f;
-                ks[2 * e + 1] = mask_u01(h, 1) >= p ? inv_keep : 0.f;
-            }
+            const unsigned long long quad0 = (unsigned long long)i << 1;          // logical index of the first element = 8 i (rows are N = 8 N8 long)
+            mask_keep4(key, quad0, p, inv_keep, ks);
+            mask_keep4(key, quad0 + 1, p, inv_keep, ks + 4);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -269,10 +265,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
             if (cst.out) {
                 f32x4 k4 = {1.f, 1.f, 1.f, 1.f};
                 if (cst.p > 0.f) {
-                    const unsigned long long pair0 = ((unsigned long long)r * (unsigned)d + 4u * (unsigned)c) >> 1;
-                    const unsigned long long h0 = mask_hash(cst.key, pair0), h1 = mask_hash(cst.key, pair0 + 1);
-                    const float ik = 1.f / (1.f - cst.p);
-                    k4 = f32x4{mask_u01(h0, 0) >= cst.p ? ik : 0.f, mask_u01(h0, 1) >= cst.p ? ik : 0.f, mask_u01(h1, 0) >= cst.p ? ik : 0.f, mask_u01(h1, 1) >= cst.p ? ik : 0.f};
+                    float kk[4];
+                    mask_keep4(cst.key, ((unsigned long long)r * (unsigned)d + 4u * (unsigned)c) >> 2, cst.p, 1.f / (1.f - cst.p), kk);      // d % 4 == 0: the four columns are one quad
+                    k4 = f32x4{kk[0], kk[1], kk[2], kk[3]};
                 }
                 reinterpret_cast<bf16x4*>(cst.out + r * cst.ld)[c] = bf16x4{f2bf(v.x * cst.alpha * k4.x), f2bf(v.y * cst.alpha * k4.y), f2bf(v.z * cst.alpha * k4.z), f2bf(v.w * cst.alpha * k4.w)};
             }

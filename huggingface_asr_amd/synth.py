@@ -90,9 +90,9 @@ def dropout_keep(seed: int, stream_id: int, n: int, p: float) -> np.ndarray:
     key = np.uint64(((stream_id & 0xFFFFFFFF) << 32) ^ (seed & 0xFFFFFFFF))
     with np.errstate(over="ignore"):
         idx = np.arange(n, dtype=np.uint64)
-        h = _splitmix64((idx >> np.uint64(1)) ^ key)                # one hash per PAIR of elements: two 24-bit draws (csrc/common.hpp mask_hash / mask_u01)
-    u24 = np.where((idx & np.uint64(1)) == 0, h >> np.uint64(40), (h >> np.uint64(16)) & np.uint64(0xFFFFFF))
-    u = u24.astype(np.float32) * np.float32(1.0 / (1 << 24))
+        h = _splitmix64((idx >> np.uint64(2)) ^ key)                # one hash per QUAD of elements: four 16-bit draws, from the top (csrc/common.hpp mask_hash / mask_u01)
+    u16 = (h >> (np.uint64(48) - np.uint64(16) * (idx & np.uint64(3)))) & np.uint64(0xFFFF)
+    u = u16.astype(np.float32) * np.float32(1.0 / (1 << 16))
     return u >= np.float32(p)
 
 
