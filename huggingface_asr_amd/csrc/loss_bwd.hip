@@ -122,18 +122,22 @@ __device__ __forceinline__ float w_shl1(float v, float fill) {   // lane i <- la
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, false));
 }
 
-template <typename T>
+// LPG (T > 256: the emissions of 500 frames x 128 states are 256 KB, more than the LDS): the table lives in a global scratch (`lp_ws`, L2-resident: the block that wrote it reads
+// it) and the two recursions keep the emissions of the next PF steps in registers — the loads do not depend on the recursion, so eight steps (~2 us) ahead covers the L2
+// round trip.  The block form above, the only one for such inputs until round 4, pays a dependent gather and a barrier per step, alpha THEN beta: 653 us at config 3.
+template <typename T, bool LPG>
 __global__ __launch_bounds__(256) void ctc_alpha_beta_wave_kernel(const T* __restrict__ logits, long ld_b, long ld_t, const float* __restrict__ lse,
                                                                    int Tmax, const long* __restrict__ labels, int U, const int* __restrict__ in_len,
                                                                    int blank, const float* __restrict__ nll, int reduction, int B, float gscale,
                                                                    float* __restrict__ alpha_ws, float* __restrict__ contrib,
-                                                                   int* __restrict__ ext_ws, int* __restrict__ meta, int* __restrict__ chain_ws) {
+                                                                   int* __restrict__ ext_ws, int* __restrict__ meta, int* __restrict__ chain_ws, float* __restrict__ lp_ws) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S_max = 2 * U + 1;
     int* hdr = reinterpret_cast<int*>(smem);          // [4]
     int* ext = hdr + 4;                               // [132]: blank sentinels behind the last state
-    float* lp = reinterpret_cast<float*>(ext + 132);  // [Tmax][128]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* lp = LPG ? lp_ws + (long)b * Tmax * 128 : reinterpret_cast<float*>(ext + 132);  // [Tmax][128]
+    constexpr int PF = LPG ? 8 : 1;                   // steps of emissions held ahead of the recursion
     if (tid == 0) {
         int n = 0;
         for (int u = 0; u < U; ++u) {
@@ -193,26 +197,32 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_wave_kernel(const T* __res
     if (wave == 0) {                                   // ---- alpha, t = 0 .. Tb-1
         const bool skip0 = s0 >= 2 && s0 < S && ext[s0] != blank && ext[s0] != ext[s0 - 2];
         const bool skip1 = s1 < S && ext[s1] != blank && ext[s1] != ext[s1 - 2];
-        float l0n = lp[s0], l1n = lp[s1];
-        float a0 = (s0 < 2 && s0 < S) ? l0n : -INFINITY, a1 = -INFINITY;
+        float a0 = (s0 < 2 && s0 < S) ? lp[s0] : -INFINITY, a1 = -INFINITY;
         if (s0 < S) aw[s0] = a0;
         if (s1 < S) aw[s1] = a1;
-        l0n = lp[min(1, Tb - 1) * 128 + s0]; l1n = lp[min(1, Tb - 1) * 128 + s1];
-        for (int t = 1; t < Tb; ++t) {
-            const float l0 = l0n, l1 = l1n;
-            const int tn = min(t + 1, Tb - 1);
-            l0n = lp[tn * 128 + s0]; l1n = lp[tn * 128 + s1];
-            const float top = __shfl(a0, 63, 64), top2 = __shfl(a0, 62, 64);
-            const float p0 = w_shr1(a0, -INFINITY), q0 = w_shr1(p0, -INFINITY);
-            const float p1 = w_shr1(a1, top);
-            float q1 = w_shr1(p1, top2);
-            if (lane == 1) q1 = top;
-            const float n0 = lse3f(a0, p0, skip0 ? q0 : -INFINITY) + l0;
-            const float n1 = lse3f(a1, p1, skip1 ? q1 : -INFINITY) + l1;
-            a0 = (s0 < S) ? n0 : -INFINITY;
-            a1 = (s1 < S) ? n1 : -INFINITY;
-            if (s0 < S) aw[(long)t * S_max + s0] = a0;
-            if (s1 < S) aw[(long)t * S_max + s1] = a1;
+        float r0[PF], r1[PF];                          // emissions of steps tb .. tb + PF - 1 (slot k = step tb + k), refilled for step + PF as they are used
+#pragma unroll
+        for (int k = 0; k < PF; ++k) { const int tt = min(1 + k, Tb - 1); r0[k] = lp[tt * 128 + s0]; r1[k] = lp[tt * 128 + s1]; }
+        for (int tb = 1; tb < Tb; tb += PF) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int t = tb + k;
+                if (t >= Tb) break;
+                const float l0 = r0[k], l1 = r1[k];
+                const int tn = min(t + PF, Tb - 1);
+                r0[k] = lp[tn * 128 + s0]; r1[k] = lp[tn * 128 + s1];
+                const float top = __shfl(a0, 63, 64), top2 = __shfl(a0, 62, 64);
+                const float p0 = w_shr1(a0, -INFINITY), q0 = w_shr1(p0, -INFINITY);
+                const float p1 = w_shr1(a1, top);
+                float q1 = w_shr1(p1, top2);
+                if (lane == 1) q1 = top;
+                const float n0 = lse3f(a0, p0, skip0 ? q0 : -INFINITY) + l0;
+                const float n1 = lse3f(a1, p1, skip1 ? q1 : -INFINITY) + l1;
+                a0 = (s0 < S) ? n0 : -INFINITY;
+                a1 = (s1 < S) ? n1 : -INFINITY;
+                if (s0 < S) aw[(long)t * S_max + s0] = a0;
+                if (s1 < S) aw[(long)t * S_max + s1] = a1;
+            }
         }
     } else if (wave == 1) {                            // ---- beta, t = Tb-1 .. 0 (stored in contrib)
         const bool sk0 = s0 + 2 < S && ext[s0 + 2] != blank && ext[s0 + 2] != ext[s0];
@@ -221,20 +231,27 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_wave_kernel(const T* __res
         float b0 = (s0 < S && s0 >= S - 2) ? l0 : -INFINITY, b1 = (s1 < S && s1 >= S - 2) ? l1 : -INFINITY;
         if (s0 < S) cw[(long)(Tb - 1) * S_max + s0] = b0;
         if (s1 < S) cw[(long)(Tb - 1) * S_max + s1] = b1;
-        float l0n = lp[max(Tb - 2, 0) * 128 + s0], l1n = lp[max(Tb - 2, 0) * 128 + s1];
-        for (int t = Tb - 2; t >= 0; --t) {
-            l0 = l0n; l1 = l1n;
-            const int tn = max(t - 1, 0);
-            l0n = lp[tn * 128 + s0]; l1n = lp[tn * 128 + s1];
-            const float bot = __shfl(b1, 0, 64), bot2 = __shfl(b1, 1, 64);
-            const float p0 = w_shl1(b0, bot), q0 = w_shl1(p0, bot2);
-            const float p1 = w_shl1(b1, -INFINITY), q1 = w_shl1(p1, -INFINITY);
-            const float n0 = lse3f(b0, p0, sk0 ? q0 : -INFINITY) + l0;
-            const float n1 = lse3f(b1, p1, sk1 ? q1 : -INFINITY) + l1;
-            b0 = (s0 < S) ? n0 : -INFINITY;
-            b1 = (s1 < S) ? n1 : -INFINITY;
-            if (s0 < S) cw[(long)t * S_max + s0] = b0;
-            if (s1 < S) cw[(long)t * S_max + s1] = b1;
+        float r0[PF], r1[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) { const int tt = max(Tb - 2 - k, 0); r0[k] = lp[tt * 128 + s0]; r1[k] = lp[tt * 128 + s1]; }
+        for (int tb = Tb - 2; tb >= 0; tb -= PF) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int t = tb - k;
+                if (t < 0) break;
+                l0 = r0[k]; l1 = r1[k];
+                const int tn = max(t - PF, 0);
+                r0[k] = lp[tn * 128 + s0]; r1[k] = lp[tn * 128 + s1];
+                const float bot = __shfl(b1, 0, 64), bot2 = __shfl(b1, 1, 64);
+                const float p0 = w_shl1(b0, bot), q0 = w_shl1(p0, bot2);
+                const float p1 = w_shl1(b1, -INFINITY), q1 = w_shl1(p1, -INFINITY);
+                const float n0 = lse3f(b0, p0, sk0 ? q0 : -INFINITY) + l0;
+                const float n1 = lse3f(b1, p1, sk1 ? q1 : -INFINITY) + l1;
+                b0 = (s0 < S) ? n0 : -INFINITY;
+                b1 = (s1 < S) ? n1 : -INFINITY;
+                if (s0 < S) cw[(long)t * S_max + s0] = b0;
+                if (s1 < S) cw[(long)t * S_max + s1] = b1;
+            }
         }
     }
     __threadfence_block();
@@ -424,7 +441,8 @@ __global__ __launch_bounds__(256) void embed_bwd_wpe_kernel(const float* __restr
 
 extern "C" size_t mi_ctc_bwd_workspace_bytes(int B, int T, int U) {
     const size_t S = 2 * (size_t)U + 1;
-    return 2 * (size_t)B * T * S * sizeof(float) + 2 * (size_t)B * S * sizeof(int) + (size_t)3 * B * sizeof(int) + 1024;
+    const size_t lpg = (S <= 128 && T > 256) ? (size_t)B * T * 128 * sizeof(float) : 0;        // the long-input wave form's emission table
+    return 2 * (size_t)B * T * S * sizeof(float) + 2 * (size_t)B * S * sizeof(int) + (size_t)3 * B * sizeof(int) + 1024 + lpg;
 }
 
 // logits (B,T,V1) f32 (dtype 0) | bf16 (1) with strides; lse (B*T) and nll (B) from mi_row_lse / mi_ctc_loss_fwd;
@@ -446,10 +464,14 @@ extern "C" int mi_ctc_loss_bwd(const void* logits, long ld_b, long ld_t, int dty
     const size_t lds_rows = (size_t)V1 * sizeof(float);
     if (lds > 150 * 1024 || lds_rows > 150 * 1024) return MI_ERR_UNSUPPORTED;
     const bool wavef = S <= 128 && T <= 256;          // the wave form: states in one wave's registers, all emissions in LDS
+    const bool wavel = S <= 128 && T > 256;           // ... and in an L2-resident global table for longer inputs
     const size_t ldsw = (4 + 132) * sizeof(int) + (size_t)T * 128 * sizeof(float);
+    float* lp_ws = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(chain_ws + (size_t)B * S) + 255) & ~(uintptr_t)255);      // inside the 1024 bytes of slack
 #define CTC_AB(TY) do { \
-        if (wavef) hipLaunchKernelGGL(ctc_alpha_beta_wave_kernel<TY>, dim3(B), dim3(256), ldsw, st, (const TY*)logits, ld_b, ld_t, lse, T, labels, U, in_len, \
-                                      blank, nll, reduction, B, gscale, alpha_ws, contrib, ext_ws, meta, chain_ws); \
+        if (wavef) hipLaunchKernelGGL((ctc_alpha_beta_wave_kernel<TY, false>), dim3(B), dim3(256), ldsw, st, (const TY*)logits, ld_b, ld_t, lse, T, labels, U, in_len, \
+                                      blank, nll, reduction, B, gscale, alpha_ws, contrib, ext_ws, meta, chain_ws, (float*)nullptr); \
+        else if (wavel) hipLaunchKernelGGL((ctc_alpha_beta_wave_kernel<TY, true>), dim3(B), dim3(256), (4 + 132) * sizeof(int), st, (const TY*)logits, ld_b, ld_t, lse, T, labels, U, in_len, \
+                                      blank, nll, reduction, B, gscale, alpha_ws, contrib, ext_ws, meta, chain_ws, lp_ws); \
         else hipLaunchKernelGGL(ctc_alpha_beta_kernel<TY>, dim3(B), dim3(256), lds, st, (const TY*)logits, ld_b, ld_t, lse, T, labels, U, in_len, \
                                 blank, nll, reduction, B, gscale, alpha_ws, contrib, ext_ws, meta, chain_ws); \
         hipLaunchKernelGGL(ctc_grad_rows_kernel<TY>, dim3(B * T), dim3(256), lds_rows, st, (const TY*)logits, ld_b, ld_t, lse, T, U, V1, \

@@ -595,6 +595,33 @@ def test_ctc_loss_bwd(reduction):
     close(dl[:, :V1].reshape(B, Tt, V1), lg.grad, floor=5e-3, what="ctc dlogits")
 
 
+@pytest.mark.parametrize("Tt,U", [(500, 60), (300, 20), (257, 63)])
+def test_ctc_loss_bwd_long_inputs(Tt, U):
+    """more than 256 frames with <= 128 states (BASELINE config 3: 20 s clips = 500 encoder frames, 60 labels): the wave form with the emissions in an L2-resident global
+    table (round 4; before: the block form, alpha then beta with a barrier per frame) against torch's ctc_loss backward — ragged input lengths down to 1 frame past the
+    256 boundary, repeated labels, a padded target, an infeasible utterance."""
+    ops, T = _o()
+    B, V1 = 5, 71
+    logits = rnd(B, Tt, V1, seed=11, scale=1.5)
+    labels = torch.randint(0, V1 - 1, (B, U), generator=torch.Generator().manual_seed(12))
+    labels[1, U // 2:] = -100; labels[2, 1] = labels[2, 0]; labels[2, 5] = labels[2, 4]; labels[3, :] = labels[3, 0]
+    in_len = torch.tensor([Tt, Tt - 37, 257, min(Tt, 2 * U - 2), 1], dtype=torch.int32)        # utterance 3: U repeats need 2U - 1 frames: infeasible; utterance 4: one frame
+    labels[4, 1:] = -100
+    lg = logits.clone().requires_grad_(True)
+    lp = torch.log_softmax(lg, -1).transpose(0, 1)
+    tl = (labels >= 0).sum(-1)
+    flat = labels[labels >= 0]
+    loss = F.ctc_loss(lp, flat, in_len.long(), tl, blank=V1 - 1, reduction="mean", zero_infinity=True)
+    (0.3 * loss).backward()
+    ld = logits.to(DEV)
+    lse = ops.row_lse(ld.reshape(B * Tt, V1))
+    got_loss, nll, _ = ops.ctc_loss(ld, labels.to(DEV), in_len.to(DEV), reduction="mean", zero_infinity=True, lse=lse)
+    torch.testing.assert_close(got_loss.cpu(), loss.detach(), atol=1e-3, rtol=1e-4)
+    dl = T.ctc_loss_bwd(ld, lse, labels.to(DEV), in_len.to(DEV), nll, reduction="mean", gscale=0.3)
+    close(dl[:, :V1].reshape(B, Tt, V1), lg.grad, floor=5e-3, what="ctc dlogits, long inputs")
+    assert torch.equal(dl, T.ctc_loss_bwd(ld, lse, labels.to(DEV), in_len.to(DEV), nll, reduction="mean", gscale=0.3))          # bit-reproducible
+
+
 def test_ce_and_embed_bwd():
     ops, T = _o()
     B, U, V, d = 3, 11, 50, 64
