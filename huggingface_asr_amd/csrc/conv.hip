@@ -102,6 +102,107 @@ __global__ __launch_bounds__(256) void conv2d_first3_kernel(const float* __restr
     }
 }
 
+// The same layer on the matrix cores (round 4; C = 256).  pre[ch][pos] = sum_tap w[ch][tap] x[pos][tap] + b[ch] is a GEMM with K = 9: one 32-position tile x 32 channels is
+// ONE v_mfma_f32_32x32x16_bf16 — but x, w and b are fp32 here (the un-fused kernel above multiplies them in fp32), so each factor is split into two bf16 parts
+// (hi = bf16(v), lo = bf16(v - hi)) and the K = 32 slots of TWO MFMAs carry   x_hi w_hi (9) | x_lo w_hi (9) | x_hi w_lo (9) | 1 b_hi | 1 b_lo | 0 0 0:
+// the result differs from the fp32 FMA chain by the dropped x_lo w_lo terms (2^-16 relative) — far inside the bf16 rounding of the output.
+// A wave owns 32 consecutive output positions x all 256 channels (16 MFMAs, 128 accumulators: rows = channels, so four consecutive registers are four consecutive
+// channels), applies GELU, packs to bf16 and passes the 16-KiB tile through a wave-private, XOR-swizzled LDS region so that it leaves as whole 512-B rows (1 KiB per
+// store instruction).  Why: the VALU form spends 38 lane-instructions per output (72 FMAs + 72 for the GELU + address arithmetic per 8 channels; PMC: 97 M wave
+// instructions per launch, 181 us at BASELINE config 2 for a 328-MB write that takes 70 us); here the GELU and the pack are all that is left on the VALU (13 per output).
+__device__ __forceinline__ bf16_t c1_slot(const bf16_t (&hi)[9], const bf16_t (&lo_)[9], bf16_t one_hi, bf16_t one_lo, int s, bool lo_in_middle) {
+    // slots 0-8: hi | 9-17: (x operand: lo, w operand: hi) | 18-26: (x: hi, w: lo) | 27, 28: (x: 1, 1; w: b_hi, b_lo) | 29-31: 0
+    if (s < 9) return hi[s];
+    if (s < 18) return lo_in_middle ? lo_[s - 9] : hi[s - 9];
+    if (s < 27) return lo_in_middle ? hi[s - 18] : lo_[s - 18];
+    if (s == 27) return one_hi;
+    if (s == 28) return one_lo;
+    return (bf16_t)0.f;
+}
+__global__ __launch_bounds__(256) void conv2d_first3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                                  int B, int T, int F, int stride, int pad_t, int pad_f, int T1, int F1) {
+    constexpr int C = 256, NG = C / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    char* stage = smem + wave * (32 * C * 2);              // [32 positions][512 B], 16-B chunk c of row p at chunk c ^ p
+    // ---- the weight operand: row = channel 32 g + l31, k = slots 16 j + 8 h + i
+    bf16x8 wa[NG][2];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int ch = 32 * g + l31;
+        bf16_t whi[9], wlo[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { const float v = w[ch * 9 + t]; whi[t] = f2bf(v); wlo[t] = f2bf(v - bf2f(whi[t])); }
+        const float bv = bias[ch];
+        const bf16_t bhi = f2bf(bv), blo = f2bf(bv - bf2f(bhi));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bf16_t s0 = c1_slot(whi, wlo, bhi, blo, 16 * j + i, false), s1 = c1_slot(whi, wlo, bhi, blo, 16 * j + 8 + i, false);
+                wa[g][j][i] = h ? s1 : s0;
+            }
+    }
+    const int total = B * T1 * F1;                          // < 2^31 - 2^20 (launcher)
+    const int ntiles = (total + 31) >> 5;
+    const bf16_t one = f2bf(1.f), zero = f2bf(0.f);
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const int m0 = tile << 5;
+        const int pos = min(m0 + l31, total - 1);
+        const int bt = pos / F1, f1 = pos - bt * F1, b = bt / T1, t1 = bt - b * T1;
+        const float* xb = x + (long)b * T * F;
+        bf16_t xhi[9], xlo[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int t = t1 * stride - pad_t + kh;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int f = f1 * stride - pad_f + kw;
+                const float v = (t >= 0 && t < T && f >= 0 && f < F) ? xb[(long)t * F + f] : 0.f;
+                xhi[kh * 3 + kw] = f2bf(v); xlo[kh * 3 + kw] = f2bf(v - bf2f(xhi[kh * 3 + kw]));
+            }
+        }
+        bf16x8 xb_[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bf16_t s0 = c1_slot(xhi, xlo, one, one, 16 * j + i, true), s1 = c1_slot(xhi, xlo, one, one, 16 * j + 8 + i, true);
+                xb_[j][i] = h ? s1 : s0;
+            }
+        // two halves of four channel groups: 64 accumulators live at a time (all eight at once put the kernel at 300 registers = one wave per SIMD)
+#pragma unroll
+        for (int gh = 0; gh < NG; gh += 4) {
+            f32x16 acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[gh + g][0], xb_[0], acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[gh + g][1], xb_[1], acc[g], 0, 0, 0);
+            }
+            // lane = position l31; registers 4 q .. 4 q + 3 of group g = channels 32 g + 8 q + 4 h .. + 3  ->  8 B of chunk (4 g + q) of row l31
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bf16x4 o = {f2bf(gelu_erf(acc[g][4 * q])), f2bf(gelu_erf(acc[g][4 * q + 1])), f2bf(gelu_erf(acc[g][4 * q + 2])), f2bf(gelu_erf(acc[g][4 * q + 3]))};
+                    *reinterpret_cast<bf16x4*>(stage + l31 * 512 + (((4 * (gh + g) + q) ^ l31) << 4) + h * 8) = o;
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int p = 2 * i + h;
+            const uint4 v = *reinterpret_cast<const uint4*>(stage + p * 512 + ((l31 ^ p) << 4));
+            if (m0 + p < total) *reinterpret_cast<uint4*>(out + (long)(m0 + p) * C + l31 * 8) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the next tile overwrites the region
+    }
+}
+
 // GatedConv2d (extractors.py:23-32) as the first layer, 3x3: out = GELU((conv(x) + b) * sigmoid(gate(x) + bg)) — two filter banks over the same nine
 // input samples.  A thread owns 4 output channels (2 x 36 taps + 8 biases in registers) and walks output positions.
 __global__ __launch_bounds__(256) void conv2d_first3_gated_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
@@ -388,6 +489,14 @@ extern "C" int mi_conv2d_first_gelu(const float* x, const float* w, const float*
     MI_ENTER();
     if (B <= 0 || T <= 0 || F <= 0 || C <= 0 || (C % 8) != 0 || K <= 0 || K > 7) return MI_ERR_ARG;
     const int cgs = C / 8;
+    if (K == 3 && C == 256 && (long)B * T1 * F1 < (1L << 31) - (1L << 20) && (reinterpret_cast<uintptr_t>(out_cl_bf16) & 15) == 0) {      // the matrix-core form
+        const long ntiles = ((long)B * T1 * F1 + 31) / 32;
+        const long nb = (ntiles + 3) / 4;
+        hipLaunchKernelGGL(conv2d_first3_mfma_kernel, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), 4 * 32 * 256 * 2, stream, x, w, bias, (bf16_t*)out_cl_bf16,
+                           B, T, F, stride, pad_t, pad_f, T1, F1);
+        MI_CHECK_LAUNCH();
+        return MI_OK;
+    }
     if (K == 3 && cgs <= 256 && (256 % cgs) == 0 && (long)B * T1 * F1 < (1L << 31) - 256L * 8192) {
         const long npos = (long)B * T1 * F1;
         const int ppb = 256 / cgs;

@@ -114,6 +114,30 @@ def test_conv_subsampling(causal):
     assert_close_bf16(g2.permute(0, 3, 1, 2), h2, what="conv2")
 
 
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("B,T,Fd", [(2, 61, 80), (3, 130, 23)])
+def test_conv2d_first_on_the_matrix_cores(B, T, Fd, causal):
+    """C = 256 (every model of the recipes): Conv2d(1 -> 256, 3x3, stride 2) + GELU as two K = 16 MFMAs per 32 positions x 32 channels with x, w, b each split into two
+    bf16 parts (conv.hip conv2d_first3_mfma_kernel) — against fp32 torch: the result before its bf16 rounding must agree to ~2^-15 (a plain bf16 product would be 2^-8 off),
+    checked as: the bf16 outputs equal torch's GELU(conv) rounded to bf16 except for last-bit ties; position count not a multiple of the 32-row tile; causal (leading) padding."""
+    ops = _ops()
+    C1 = 256
+    x = rnd(B, T, Fd, seed=41) * 3.0 + 0.7                      # log-mel-like magnitudes
+    w1, b1 = rnd(C1, 1, 3, 3, seed=42, scale=0.3), rnd(C1, seed=43, scale=0.2)
+    xin = x[:, None]
+    h1 = F.gelu(F.conv2d(F.pad(xin, (2, 0, 2, 0)), w1, b1, stride=2)) if causal else F.gelu(F.conv2d(xin, w1, b1, stride=2, padding=1))
+    g1 = ops.conv2d_first_gelu(x.to(DEV), w1.reshape(C1, 9).to(DEV), b1.to(DEV), causal=causal)
+    got = g1.permute(0, 3, 1, 2).float().cpu()
+    assert got.shape == h1.shape and (B * h1.shape[2] * h1.shape[3]) % 32 != 0
+    want = h1.to(torch.bfloat16).float()
+    ulp = torch.maximum(want.abs(), torch.tensor(2.0 ** -126)) * 2.0 ** -7            # one bf16 step at |want|
+    d = (got - want).abs()
+    assert bool((d <= ulp * 1.01 + 1e-4).all()), float((d / ulp).max())              # never more than one step (GELU fit: 2.6e-5 absolute) ...
+    big = want.abs() > 0.05                                                         # (below it the GELU fit's 2.6e-5 is comparable to a bf16 step: last-bit flips)
+    assert float((d[big] > 0).float().mean()) < 0.03 and int(big.sum()) > 1000      # ... and almost always the same bf16 value: the split-precision product is fp32-like
+    assert torch.equal(g1, ops.conv2d_first_gelu(x.to(DEV), w1.reshape(C1, 9).to(DEV), b1.to(DEV), causal=causal))
+
+
 @pytest.mark.parametrize("d", [64, 512, 1024])
 def test_layernorm_chain(d):
     ops = _ops()
