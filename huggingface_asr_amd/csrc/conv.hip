@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void conv2d_first3_kernel(const float* __restr
 // the result differs from the fp32 FMA chain by the dropped x_lo w_lo terms (2^-16 relative) — far inside the bf16 rounding of the output.
 // A wave owns 32 consecutive output positions x all 256 channels (16 MFMAs, 128 accumulators: rows = channels, so four consecutive registers are four consecutive
 // channels), applies GELU, packs to bf16 and passes the 16-KiB tile through a wave-private, XOR-swizzled LDS region so that it leaves as whole 512-B rows (1 KiB per
-// store instruction).  Why: the VALU form spends 38 lane-instructions per output (72 FMAs + 72 for the GELU + address arithmetic per 8 channels; PMC: 97 M wave
+// store instruction).  Measured and not kept: the next tile's nine features requested one tile ahead (114.5 vs 100.7 us: the loads are L2 hits; the extra live registers
+// and the waits the compiler places cost more than the round trip two waves per SIMD leave exposed).  Why the matrix cores: the VALU form spends 38 lane-instructions per output (72 FMAs + 72 for the GELU + address arithmetic per 8 channels; PMC: 97 M wave
 // instructions per launch, 181 us at BASELINE config 2 for a 328-MB write that takes 70 us); here the GELU and the pack are all that is left on the VALU (13 per output).
 __device__ __forceinline__ bf16_t c1_slot(const bf16_t (&hi)[9], const bf16_t (&lo_)[9], bf16_t one_hi, bf16_t one_lo, int s, bool lo_in_middle) {
     // slots 0-8: hi | 9-17: (x operand: lo, w operand: hi) | 18-26: (x: hi, w: lo) | 27, 28: (x: 1, 1; w: b_hi, b_lo) | 29-31: 0
