@@ -549,6 +549,221 @@ __global__ __launch_bounds__(256) void conv1_bwd3_kernel(const float* __restrict
     group_sum_ordered<40>(stage, vb, g, pl, cg, ppb, [&](int gg, int v, float sum) { prow[(gg * 8 + (v & 7)) * 10 + 5 + (v >> 3)] = sum; });
 }
 
+// ------------------------------------------------------------------------------------------------ conv1 backward on the matrix cores (round 4; C = 256, phase buffers)
+// Per 32-position tile and 128 channels (a wave; the two waves of a pair split the channels):
+//   pre[ch][pos]  = two K = 16 MFMAs on hi / lo split operands, exactly the forward (conv.hip conv2d_first3_mfma_kernel: slots x_hi w_hi | x_lo w_hi | x_hi w_lo | b_hi | b_lo)
+//   dpre          = dact1 * GELU'(pre)                      (dact1: the tile's rows come in as 16-B chunks, pass through LDS and are read back in the accumulator layout)
+//   dW[ch][tap]  += sum_pos dpre[pos][ch] x[pos][tap]       = a GEMM over the tile's 32 positions: dpre (hi / lo bf16 images [pos][ch]) and the tile's features
+//                                                             ([pos][x_hi 0-8 | 1 | x_lo 0-8 | 0]) both go through LDS and come back by `ds_read_b64_tr_b16` as the A / B
+//                                                             operands (same k-permutation on both sides, as in gemm_tn.hip); column 9 (the ones) is db.
+// The accumulators (128 channels x 32 columns per wave) live in registers for the whole kernel; per block they are summed in wave order into one partial row.
+// The VALU form above spends ~300 instructions per position and 8 channels (72 FMAs for pre, 72 for dW, GELU', gather): 1.51 ms at BASELINE config 3 against 0.45 ms of reads.
+__device__ __forceinline__ int c1b_swz16(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }       // 256-B rows: the transposed read's four rows x 64 B land on disjoint banks
+typedef short c1b_s16x4 __attribute__((ext_vector_type(4)));
+typedef short c1b_s16x8 __attribute__((ext_vector_type(8)));
+template <int OFF>
+__device__ __forceinline__ void c1b_tr_issue(unsigned a0, unsigned a1, c1b_s16x4& lo, c1b_s16x4& hi) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "n"(OFF) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "n"(OFF + 0) : "memory");
+}
+__device__ __forceinline__ bf16x8 c1b_tr_join(c1b_s16x4& lo, c1b_s16x4& hi) {
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    const c1b_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+// lane addresses of the two transposed reads of a 32-column fragment starting at column cb of a [row][ROWB bytes] image (k-block 0); SWZ16: the 256-B rows' chunk swizzle, else row & 3
+template <int ROWB, bool SWZ16>
+__device__ __forceinline__ void c1b_tr_addr(unsigned base, int cb, int lane, unsigned& a0, unsigned& a1) {
+    const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+    const int col = cb + (g & 1) * 16 + 4 * p4;
+    const int lc = col >> 3, within = (col & 7) * 2;
+    const int k0 = 4 * (g >> 1) + q4, k1 = k0 + 8;
+    a0 = base + k0 * ROWB + ((lc ^ (SWZ16 ? c1b_swz16(k0) : (k0 & 3))) << 4) + within;
+    a1 = base + k1 * ROWB + ((lc ^ (SWZ16 ? c1b_swz16(k1) : (k1 & 3))) << 4) + within;
+}
+__device__ __forceinline__ bf16_t c1b_slot(const bf16_t (&hi)[9], const bf16_t (&lo_)[9], bf16_t one_hi, bf16_t one_lo, int s, bool lo_in_middle) {
+    if (s < 9) return hi[s];
+    if (s < 18) return lo_in_middle ? lo_[s - 9] : hi[s - 9];
+    if (s < 27) return lo_in_middle ? hi[s - 18] : lo_[s - 18];
+    if (s == 27) return one_hi;
+    if (s == 28) return one_lo;
+    return (bf16_t)0.f;
+}
+constexpr int C1B_WAVE_LDS = 2 * 8192 + 2048;          // per wave: dact staging / dpre hi image | dpre lo image | feature image   (the final 128 x 32 fp32 accumulators reuse the first 16 KiB)
+__global__ __launch_bounds__(256, 2) void conv1_bwd3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ partial,
+                                                               int B, int T, int F, int stride, int pad_t, int pad_f, int T1, int F1, int pad2_t, int pad2_f, Conv1Ph ph) {
+    constexpr int C = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int pair = wave >> 1, cb0 = (wave & 1) * 128;
+    char* reg = smem + wave * C1B_WAVE_LDS;
+    char* DH = reg;                                     // [32][256 B]: first the dact tile, then — in place — dpre's hi image (both in the transposed read's layout: chunk c of row p at c ^ swz16(p))
+    char* DL = reg + 8192;
+    char* XI = reg + 16384;                             // [32][64 B]
+    // weight operand of the forward product: rows = channels cb0 + 32 g + l31
+    bf16x8 wa[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int ch = cb0 + 32 * g + l31;
+        bf16_t whi[9], wlo[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { const float v = w[ch * 9 + t]; whi[t] = f2bf(v); wlo[t] = f2bf(v - bf2f(whi[t])); }
+        const float bv = bias[ch];
+        const bf16_t bhi = f2bf(bv), blo = f2bf(bv - bf2f(bhi));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bf16_t s0 = c1b_slot(whi, wlo, bhi, blo, 16 * j + i, false), s1 = c1b_slot(whi, wlo, bhi, blo, 16 * j + 8 + i, false);
+                wa[g][j][i] = h ? s1 : s0;
+            }
+    }
+    unsigned xa0, xa1, da0[4], da1[4];
+    c1b_tr_addr<64, false>((unsigned)(size_t)XI, 0, lane, xa0, xa1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) c1b_tr_addr<256, true>((unsigned)(size_t)DH, 32 * g, lane, da0[g], da1[g]);
+    f32x16 dacc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dacc[g][r] = 0.f;
+    const int total = B * T1 * F1;
+    const int ntiles = (total + 31) >> 5;
+    const bf16_t one = f2bf(1.f), zero = f2bf(0.f);
+    for (int tile = blockIdx.x * 2 + pair; tile < ntiles; tile += gridDim.x * 2) {
+        const int m0 = tile << 5;
+        const int pos = min(m0 + l31, total - 1);
+        const int bt = pos / F1, f1 = pos - bt * F1, b = bt / T1, t1 = bt - b * T1;
+        const float* xb = x + (long)b * T * F;
+        bf16_t xhi[9], xlo[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int t = t1 * stride - pad_t + kh;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int f = f1 * stride - pad_f + kw;
+                const float v = (t >= 0 && t < T && f >= 0 && f < F) ? xb[(long)t * F + f] : 0.f;
+                xhi[kh * 3 + kw] = f2bf(v); xlo[kh * 3 + kw] = f2bf(v - bf2f(xhi[kh * 3 + kw]));
+            }
+        }
+        // this lane's position in its phase buffer (conv1_bwd3_kernel<.., PH>'s fetch)
+        const int at = t1 + pad2_t, af = f1 + pad2_f, kh0 = at & 1, kw0 = af & 1;
+        const bf16_t* pbuf = kh0 ? (kw0 ? ph.buf[3] : ph.buf[2]) : (kw0 ? ph.buf[1] : ph.buf[0]);
+        const bf16_t* rowp = pbuf + (((long)b * ph.U[kh0] + ((at >> 1) - ph.ulo[kh0])) * ph.V[kw0] + ((af >> 1) - ph.vlo[kw0])) * C + cb0;
+        const unsigned long long rp = reinterpret_cast<unsigned long long>(rowp);
+        // (1) the tile's dact rows, 16-B chunks: row p = 4 i + (lane >> 4), chunk c = lane & 15
+        uint4 dv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = 4 * i + (lane >> 4), c = lane & 15;
+            const unsigned lo32 = (unsigned)__shfl((int)(unsigned)rp, p, 64), hi32 = (unsigned)__shfl((int)(unsigned)(rp >> 32), p, 64);
+            const bf16_t* src = reinterpret_cast<const bf16_t*>(((unsigned long long)hi32 << 32) | lo32);
+            dv[i] = (m0 + p < total) ? *reinterpret_cast<const uint4*>(src + c * 8) : uint4{0u, 0u, 0u, 0u};
+        }
+        // (2) pre = W x (+ b), rows = channels, lane = position
+        bf16x8 xb_[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bf16_t s0 = c1b_slot(xhi, xlo, one, one, 16 * j + i, true), s1 = c1b_slot(xhi, xlo, one, one, 16 * j + 8 + i, true);
+                xb_[j][i] = h ? s1 : s0;
+            }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = 4 * i + (lane >> 4), c = lane & 15;
+            *reinterpret_cast<uint4*>(DH + p * 256 + ((c ^ c1b_swz16(p)) << 4)) = dv[i];
+        }
+        // the feature image: row = position, columns x_hi 0-8 | 1 | x_lo 0-8 | 0 (32 bf16 = four 16-B chunks, chunk c at c ^ (row & 3)); the two lanes of a position write two chunks each
+        {
+            bf16x8 c0, c1;
+            if (h == 0) { c0 = bf16x8{xhi[0], xhi[1], xhi[2], xhi[3], xhi[4], xhi[5], xhi[6], xhi[7]}; c1 = bf16x8{xhi[8], one, xlo[0], xlo[1], xlo[2], xlo[3], xlo[4], xlo[5]}; }
+            else { c0 = bf16x8{xlo[6], xlo[7], xlo[8], zero, zero, zero, zero, zero}; c1 = bf16x8{zero, zero, zero, zero, zero, zero, zero, zero}; }
+            *reinterpret_cast<bf16x8*>(XI + l31 * 64 + (((2 * h) ^ (l31 & 3)) << 4)) = c0;
+            *reinterpret_cast<bf16x8*>(XI + l31 * 64 + (((2 * h + 1) ^ (l31 & 3)) << 4)) = c1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // (2) + (4), two channel groups at a time (32 accumulators live): pre = W x (+ b) with rows = channels, lane = position; dpre = dact * GELU'(pre), split into
+        // bf16 hi / lo and written as [position][channel] images in the transposed read's layout
+        // (dact comes back from the staging rows in the accumulator layout — registers 4 q .. 4 q + 3 of group g = channels 32 g + 8 q + 4 h .. + 3 of position l31 — and
+        // the staging rows use the transposed read's chunk swizzle, so a lane's 8-B piece of dpre's hi image lands exactly where its dact piece was: in place, group by group)
+        const int sw = c1b_swz16(l31);
+#pragma unroll
+        for (int gh = 0; gh < 4; gh += 2) {
+            bf16x4 da[2][4];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) da[g][q] = *reinterpret_cast<const bf16x4*>(DH + l31 * 256 + (((4 * (gh + g) + q) ^ sw) << 4) + h * 8);
+            f32x16 acc[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[gh + g][0], xb_[0], acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[gh + g][1], xb_[1], acc[g], 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bf16x4 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = bf2f(da[g][q][e]) * gelu_erf_grad(acc[g][4 * q + e]);
+                        vh[e] = f2bf(d); vl[e] = f2bf(d - bf2f(vh[e]));
+                    }
+                    const int off = l31 * 256 + (((4 * (gh + g) + q) ^ sw) << 4) + h * 8;
+                    *reinterpret_cast<bf16x4*>(DH + off) = vh;
+                    *reinterpret_cast<bf16x4*>(DL + off) = vl;
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // (5) dW += dpre^T x over the tile's 32 positions: two k-blocks of 16, hi and lo images
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            c1b_s16x4 xl, xh, dl_[4][2], dh_[4][2];                      // [group][hi / lo image]
+            if (kb == 0) {
+                c1b_tr_issue<0>(xa0, xa1, xl, xh);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { c1b_tr_issue<0>(da0[g], da1[g], dl_[g][0], dh_[g][0]); c1b_tr_issue<8192>(da0[g], da1[g], dl_[g][1], dh_[g][1]); }
+            } else {
+                c1b_tr_issue<16 * 64>(xa0, xa1, xl, xh);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { c1b_tr_issue<16 * 256>(da0[g], da1[g], dl_[g][0], dh_[g][0]); c1b_tr_issue<8192 + 16 * 256>(da0[g], da1[g], dl_[g][1], dh_[g][1]); }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const bf16x8 xf = c1b_tr_join(xl, xh);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                dacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1b_tr_join(dl_[g][0], dh_[g][0]), xf, dacc[g], 0, 0, 0);
+                dacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1b_tr_join(dl_[g][1], dh_[g][1]), xf, dacc[g], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- the block's partial row [channel][9 taps | bias]: every wave's 128 x 32 accumulators through LDS, pairs added in order
+    float* fin = reinterpret_cast<float*>(reg);          // [128 channels][32 columns]
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fin[(32 * g + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = dacc[g][r];
+    __syncthreads();
+    float* prow = partial + (long)blockIdx.x * C * 10;
+    for (int i = threadIdx.x; i < C * 10; i += 256) {
+        const int ch = i / 10, k = i - ch * 10;
+        float sum = 0.f;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const float* fw = reinterpret_cast<const float*>(smem + (pr * 2 + (ch >> 7)) * C1B_WAVE_LDS) + (ch & 127) * 32;
+            sum += k < 9 ? fw[k] + fw[10 + k] : fw[9];
+        }
+        prow[i] = sum;
+    }
+}
+
 int grid_for(long n, int cap) { const long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > cap ? cap : g)); }
 
 int dw_bwd_launch(const DwBwdArgs& a, bool csgu, float* workspace, hipStream_t st) {
@@ -998,7 +1213,18 @@ extern "C" int mi_conv2d_first_bwd_phases(const float* x, const float* w, const 
         ph.U[pt] = at.n[pt]; ph.ulo[pt] = at.lo[pt]; ph.V[pt] = af.n[pt]; ph.vlo[pt] = af.lo[pt];
         for (int pf = 0; pf < 2; ++pf) { ph.buf[pt * 2 + pf] = op; op += (long)B * at.n[pt] * af.n[pf] * C; }
     }
-    const unsigned grid = conv1_bwd_grid(B, C, T1, F1);
+    unsigned grid = conv1_bwd_grid(B, C, T1, F1);
+    if (C == 256) {                                        // the matrix-core form (two position tiles per block at a time, 128 channels per wave)
+        const long ntiles = (npos + 31) / 32;
+        const unsigned g2 = (unsigned)((ntiles + 1) / 2 < 512 ? (ntiles + 1) / 2 : 512);
+        if (g2 < grid) grid = g2;                          // never more partial rows than the workspace holds
+        hipLaunchKernelGGL(conv1_bwd3_mfma_kernel, dim3(grid), dim3(256), (size_t)4 * C1B_WAVE_LDS, st, x, w, bias, workspace,
+                           B, T, F, stride, pad_t, pad_f, T1, F1, pad2_t, pad2_f, ph);
+        MI_CHECK_LAUNCH();
+        rows_reduce_launch(workspace, (int)grid, C * 10, EmitConv1{dw, db, 9}, st);
+        MI_CHECK_LAUNCH();
+        return MI_OK;
+    }
     const size_t lds = (size_t)256 * 40 * sizeof(float);
     hipLaunchKernelGGL((conv1_bwd3_kernel<true, true>), dim3(grid), dim3(256), lds, st, x, w, bias, (const bf16_t*)nullptr, workspace,
                        B, T, F, C, stride, pad_t, pad_f, T1, F1, 3, 2, pad2_t, pad2_f, T2, F2, ph);
