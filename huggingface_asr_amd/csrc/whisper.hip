@@ -71,16 +71,25 @@ __global__ __launch_bounds__(256) void whisper_logmel_kernel(WhArgs p, float* __
         if (valid && lane <= 50) {
             const int k = lane;
             double re[4] = {0.0, 0.0, 0.0, 0.0}, im[4] = {0.0, 0.0, 0.0, 0.0};      // S_j = re[j] + i im[j]
-            int idx = 0;
+            // The twiddle of sample n = 4 m + j is e^{2 pi i (4 m + j) k / 400}: four independent rotators c_j, started from the table at j k and advanced by the table's
+            // entry at 4 k (float64 complex multiply: 100 steps grow the error to ~1e-14, the test's tolerance on log10 is 3e-5).  Gathering tw[n k mod 400] per lane
+            // and step, as rounds 1-3 did, is a 51-lane LDS access whose bank is (n k) mod 16: up to 51-way conflicts — the kernel took 704 us per 16 x 30 s batch,
+            // 7.5 % of config 4's step, most of it LDS replays.  The samples stay a broadcast read.
+            double2 c[4];
+            {
+                int idx = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { c[j] = tw[idx]; idx += k; if (idx >= WN) idx -= WN; }
+            }
+            const double2 w4 = tw[(4 * k) % WN];
             for (int n = 0; n < WN; n += 4) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const double2 c = tw[idx];
                     const double x = xs[wave][n + j];
-                    re[j] = fma(x, c.x, re[j]);
-                    im[j] = fma(-x, c.y, im[j]);
-                    idx += k;
-                    if (idx >= WN) idx -= WN;
+                    re[j] = fma(x, c[j].x, re[j]);
+                    im[j] = fma(-x, c[j].y, im[j]);
+                    const double nx = fma(c[j].x, w4.x, -(c[j].y * w4.y)), ny = fma(c[j].x, w4.y, c[j].y * w4.x);
+                    c[j] = double2{nx, ny};
                 }
             }
             auto put = [&](int bin, double r, double i_) {
