@@ -15,6 +15,7 @@
 namespace {
 
 constexpr int FRAME = 400, HOP = 160, NFFT = 512, NBINS = 257;
+constexpr int MEL_W = 640;                                              // LDS slots for the packed mel weights (>= 2 * NBINS + a triangle's slack)
 
 struct FbankArgs {
     const float* wave; long ldw;         // (B, ldw) samples
@@ -42,6 +43,27 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs p) {
     double2* buf1 = buf0 + NZ;
     double2* twl = reinterpret_cast<double2*>(smem) + 4 * 2 * NZ;         // [NFFT/2] twiddles, shared by the four waves (an LDS read instead of a global load per butterfly)
     for (int i = threadIdx.x; i < NFFT / 2; i += 256) twl[i] = double2{p.twiddle[2 * i], p.twiddle[2 * i + 1]};
+    // the mel triangles' non-zero spans, packed back to back in LDS (every bin lies under at most two triangles: <= 2 * 257 weights): the filter loop of step 5 read its
+    // weights from global memory, one dependent L2 round trip per bin of the longest span (~40) and frame — most of the kernel's time
+    double* mwt = reinterpret_cast<double*>(twl + NFFT / 2);             // [MEL_W]
+    int* moff = reinterpret_cast<int*>(mwt + MEL_W);                     // [nmel + 1] (nmel <= 127)
+    int* mlo_s = moff + 128;                                            // [nmel]: the spans' first bins
+    if ((int)threadIdx.x < p.nmel) { mlo_s[threadIdx.x] = p.mel_lo[threadIdx.x]; moff[threadIdx.x + 1] = max(p.mel_hi[threadIdx.x] - p.mel_lo[threadIdx.x], 0); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int o = 0;
+        for (int f = 0; f < p.nmel; ++f) { const int n = moff[f + 1]; moff[f] = o; o += n; }
+        moff[p.nmel] = o;
+    }
+    __syncthreads();
+    const int mtot = moff[p.nmel];
+    const bool mel_lds = mtot <= MEL_W;
+    if (mel_lds)
+        for (int i = threadIdx.x; i < mtot; i += 256) {                  // one load per thread: the filter of slot i by bisection of the offsets
+            int lo = 0, hi = p.nmel - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (moff[mid] <= i) lo = mid; else hi = mid - 1; }
+            mwt[i] = p.mel_t[(long)lo * NBINS + mlo_s[lo] + (i - moff[lo])];
+        }
     __syncthreads();
     const long total = (long)p.B * p.T_out;
     for (long fidx = (long)blockIdx.x * 4 + wave; fidx < total; fidx += (long)gridDim.x * 4) {
@@ -124,9 +146,15 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs p) {
         // 5. mel filters, floor, log
         float* o = p.out + (long)b * p.ld_out_b + (long)t * p.nmel;
         for (int f = lane; f < p.nmel; f += 64) {
-            const double* mt = p.mel_t + (long)f * NBINS;
+            const int lo = mlo_s[f], hi = lo + (moff[f + 1] - moff[f]);
             double acc = 0.0;
-            for (int k = p.mel_lo[f]; k < p.mel_hi[f]; ++k) acc += pw[k] * mt[k];
+            if (mel_lds) {
+                const double* mw = mwt + moff[f] - lo;
+                for (int k = lo; k < hi; ++k) acc += pw[k] * mw[k];       // same products in the same order as the global-memory form
+            } else {
+                const double* mt = p.mel_t + (long)f * NBINS;
+                for (int k = lo; k < hi; ++k) acc += pw[k] * mt[k];
+            }
             o[f] = (float)log(fmax(acc, p.mel_floor));
         }
         wave_lds_sync();
@@ -173,9 +201,17 @@ __global__ __launch_bounds__(256) void cmvn_lds_kernel(float* x, long ld_b, cons
     const int b = blockIdx.x, f0 = blockIdx.y * G, tid = threadIdx.x;
     float* xb = x + (long)b * ld_b;
     const int n = frames ? min(frames[b], T) : T;
-    for (int i = tid; i < T * G; i += 256) {
-        const int t = i / G, g = i % G;
-        slab[i] = (f0 + g < nmel) ? xb[(long)t * nmel + f0 + g] : 0.f;
+    const bool vec4 = (G % 4) == 0 && (nmel % 4) == 0 && f0 + G <= nmel && (reinterpret_cast<uintptr_t>(xb) & 15) == 0;       // 16-B accesses: a quarter of the load / store instructions
+    if (vec4) {
+        for (int i = tid; i < T * (G / 4); i += 256) {
+            const int t = i / (G / 4), g4 = i % (G / 4);
+            reinterpret_cast<f32x4*>(slab)[i] = *reinterpret_cast<const f32x4*>(xb + (long)t * nmel + f0 + 4 * g4);
+        }
+    } else {
+        for (int i = tid; i < T * G; i += 256) {
+            const int t = i / G, g = i % G;
+            slab[i] = (f0 + g < nmel) ? xb[(long)t * nmel + f0 + g] : 0.f;
+        }
     }
     __syncthreads();
     if (tid < G) {
@@ -225,6 +261,19 @@ __global__ __launch_bounds__(256) void cmvn_lds_kernel(float* x, long ld_b, cons
         red[tid] = mean; red[G + tid] = sd;
     }
     __syncthreads();
+    if (vec4) {
+        for (int i = tid; i < T * (G / 4); i += 256) {
+            const int t = i / (G / 4), g4 = i % (G / 4);
+            f32x4 v = {pad, pad, pad, pad};
+            if (t < n) {
+                v = reinterpret_cast<const f32x4*>(slab)[i];
+                if (norm_means) v = f32x4{v.x - red[4 * g4], v.y - red[4 * g4 + 1], v.z - red[4 * g4 + 2], v.w - red[4 * g4 + 3]};
+                if (norm_vars) v = f32x4{v.x / red[G + 4 * g4], v.y / red[G + 4 * g4 + 1], v.z / red[G + 4 * g4 + 2], v.w / red[G + 4 * g4 + 3]};
+            }
+            *reinterpret_cast<f32x4*>(xb + (long)t * nmel + f0 + 4 * g4) = v;
+        }
+        return;
+    }
     for (int i = tid; i < T * G; i += 256) {
         const int t = i / G, g = i % G;
         if (f0 + g >= nmel) continue;
@@ -288,8 +337,9 @@ extern "C" int mi_fbank_f64(const float* wave, long ldw, const int* num_samples,
     FbankArgs a{wave, ldw, num_samples, N, window, twiddle, mel_t, mel_lo, mel_hi, out, (long)T_out * nmel, T_out,
                 B, nmel, mel_floor, preemph};
     const long total = (long)B * T_out;
-    const int grid = (int)((total + 3) / 4 < 4096 ? (total + 3) / 4 : 4096);
-    const size_t lds = (4 * 2 * (NFFT / 2) + NFFT / 2) * sizeof(double2);
+    const int grid = (int)((total + 3) / 4 < 768 ? (total + 3) / 4 : 768);       // three blocks per CU: a block's set-up (twiddles, packed mel weights) serves ~10 frames per wave
+    if (nmel > 127) return MI_ERR_ARG;
+    const size_t lds = (4 * 2 * (NFFT / 2) + NFFT / 2) * sizeof(double2) + MEL_W * sizeof(double) + 256 * sizeof(int);
     hipLaunchKernelGGL(fbank_kernel, dim3(grid), dim3(256), lds, stream, a);
     MI_CHECK_LAUNCH();
     return MI_OK;
