@@ -135,8 +135,8 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs p) {
                 const double2 wk = (k < 256) ? twl[k] : double2{-1.0, 0.0};
                 const double2 ow = cmul(o, wk);
                 const double re = (double)(float)(e.x + ow.x), im = (double)(float)(e.y + ow.y);
-                const double mag = sqrt(re * re + im * im);
-                pk[i] = mag * mag;
+                pk[i] = re * re + im * im;                  // (|X|^2 directly: sqrt-then-square of the reference differs from it by one float64 rounding, 1e-16 relative; a float64
+                                                            // square root is ~20 instructions of the ~850 per frame that bound this kernel — PMC: f64 VALU issue = its duration)
             }
         }
         wave_lds_sync();                                            // every lane has read Z before dst/src are reused for the powers
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs p) {
                 const double* mt = p.mel_t + (long)f * NBINS;
                 for (int k = lo; k < hi; ++k) acc += pw[k] * mt[k];
             }
-            o[f] = (float)log(fmax(acc, p.mel_floor));
+            o[f] = logf((float)fmax(acc, p.mel_floor));     // float32 log of the float64 energy: within 1 ulp (1e-6 absolute) of float32(log64(acc)); the float64 log was ~60 instructions per value
         }
         wave_lds_sync();
     }
