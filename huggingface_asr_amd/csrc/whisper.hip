@@ -48,12 +48,18 @@ __global__ __launch_bounds__(256) void whisper_logmel_kernel(WhArgs p, float* __
     __shared__ float smax[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i < WN; i += 256) tw[i] = double2{p.twiddle[2 * i], p.twiddle[2 * i + 1]};
-    if (tid < p.nmel) {                                    // non-zero span of this mel filter (triangles: contiguous)
-        const double* mt = p.mel_t + (long)tid * WBINS;
-        int lo = WBINS, hi = 0;
-        for (int k = 0; k < WBINS; ++k)
-            if (mt[k] != 0.0) { lo = min(lo, k); hi = k + 1; }
-        mlo[tid] = lo; mhi[tid] = hi;
+    // non-zero span of every mel filter (triangles: contiguous).  Thread = bin, loop over the filters: one coalesced load per filter and thread, the span's ends from
+    // wave ballots.  (Rounds 1-3: thread = filter walking its 201 bins — 201 DEPENDENT L2 round trips at the start of every block, ~150 us x 3 block rounds: most of
+    // the kernel's 704 us.)
+    for (int i = tid; i < 256; i += 256) { mlo[i] = WBINS; mhi[i] = 0; }
+    __syncthreads();
+    for (int m = 0; m < p.nmel; ++m) {
+        const bool nz = tid < WBINS && p.mel_t[(long)m * WBINS + tid] != 0.0;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(nz);
+        if (lane == 0 && bal != 0ull) {
+            atomicMin(&mlo[m], wave * 64 + (int)__builtin_ctzll(bal));
+            atomicMax(&mhi[m], wave * 64 + 64 - (int)__builtin_clzll(bal));
+        }
     }
     const long total = (long)p.B * p.frames;
     for (long f0 = (long)blockIdx.x * 4; f0 < total; f0 += (long)gridDim.x * 4) {
@@ -94,8 +100,7 @@ __global__ __launch_bounds__(256) void whisper_logmel_kernel(WhArgs p, float* __
             }
             auto put = [&](int bin, double r, double i_) {
                 const double r32 = (double)(float)r, i32 = (double)(float)i_;          // the reference stores the STFT as complex64
-                const double mag = sqrt(r32 * r32 + i32 * i32);
-                pw[wave][bin] = mag * mag;
+                pw[wave][bin] = r32 * r32 + i32 * i32;           // |X|^2 directly (the reference's abs-then-square differs by one float64 rounding)
             };
             put(k, (re[0] + re[2]) + (re[1] + re[3]), (im[0] + im[2]) + (im[1] + im[3]));
             put(200 - k, (re[0] + re[2]) - (re[1] + re[3]), -((im[0] + im[2]) - (im[1] + im[3])));
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(256) void whisper_logmel_kernel(WhArgs p, float* __
             const double* mt = p.mel_t + (long)m * WBINS;
             double acc = 0.0;
             for (int kk = mlo[m]; kk < mhi[m]; ++kk) acc = fma(pw[fr][kk], mt[kk], acc);
-            const float v = (float)log10(fmax(acc, 1e-10));
+            const float v = log10f((float)fmax(acc, 1e-10));           // float32 log10 of the float64 energy: 1 ulp (< 1e-6) from float32(log10_64(acc))
             p.out[ff * p.nmel + m] = v;
             atomic_max_f32(&smax[fr], v);
         }
