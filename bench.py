@@ -413,6 +413,7 @@ def secondary(name, args):
         dt3 = dt1
         if args.streams > 1:                                 # (`--secondary whisper --streams 1`: one batch at a time only — what a kernel trace of this command should show)
             streams = [torch.cuda.Stream() for _ in range(3)]
+            eng.tail_split = False                            # the other batches' blocks fill an under-filled last round of tiles: no split of the GEMMs (gemm_glds.hip)
 
             def run(n):
                 for j in range(n):

@@ -314,10 +314,38 @@ bool gemm_glds_supported(const GemmArgs& a, bool conv) {
 // supported, 47 = its two-segment form, 30 = this file's 128x128 tiles, 31 = the same, one block per tile.
 int gemm_glds_launch(const GemmArgs& a, bool conv, hipStream_t stream) {
     if (!gemm_glds_supported(a, conv)) return MI_ERR_UNSUPPORTED;
-    const int v = a.variant;
+    const bool tail_split = a.variant != 48;                  // 48 = the product's dispatch without the tail-round split below (callers that keep several batches in flight)
+    const int v = a.variant == 48 ? 0 : a.variant;
     const bool phase_ok = v != 41 && v != 30 && v != 31 && v != 32;
     // wide-N bf16-out GEMMs (FFN in, cgMLP in, QKV) and the implicit-GEMM conv: 256x256 tiles on the phase-interleaved schedule (gemm_8p.hip) once the tiles fill half the chip
     const int t256 = cdiv(a.M, 256) * cdiv(a.N, 256);
+    // Wave quantization (round 4): t256 tiles run in ceil(t256 / 256) rounds of one tile per CU; when the last round would be less than half full its rows go to the
+    // 128 x 128 phase kernel instead — quarter-size tiles, so the tail costs a quarter of a round or less.  Whisper-small at 16 x 30 s (M = 24 000): N = 768 is 282
+    // tiles = TWO rounds for 1.1 rounds of work, N = 2304 / 3072 are 3.3 / 4.4 rounds.  Same K order and MFMA shape in both kernels: the same bits as one launch.
+    // Same-box A/B on config 4 (tools/tail_split_ab.sh): one batch at a time 8.94 -> 8.72 ms (dense kernel time 5.53 -> 5.05 ms per step); with three batches in
+    // flight the other batches' blocks already fill the tail and the extra launches cost 3 % (7.53 -> 7.77 ms): such callers pass variant 48.
+#ifndef HFASR_NO_TAIL_SPLIT                                   // (A/B builds of tools/tail_split_ab.sh only)
+    if (tail_split && !conv && v == 0 && t256 > 256 && (t256 % 256) > 0 && (t256 % 256) < 128 && a.act <= 2 && a.drop_p == 0.f && !a.ln_stats && !a.gated && gemm_8p_supported(a, false)) {
+        const int ntn = cdiv(a.N, 256);
+        const int mt_main = (t256 / 256) * 256 / ntn;                     // M tiles that fill whole rounds
+        const int m_main = mt_main * 256;
+        if (mt_main > 0 && m_main < a.M) {
+            GemmArgs a1 = a, a2 = a;
+            a1.M = m_main;
+            a2.M = a.M - m_main;
+            a2.A = a.A + (long)m_main * a.lda;
+            a2.C = reinterpret_cast<char*>(a.C) + (long)m_main * a.ldc * (a.out_f32 ? 4 : 2);
+            if (a.resid) a2.resid = a.resid + (long)m_main * a.ldr;
+            if (a.C2) a2.C2 = a.C2 + (long)m_main * a.ldc2;
+            if (a.stats_out) a2.stats_out = a.stats_out + (long)m_main * LN_STATS_STRIDE;
+            if (gemm_8p128_supported(a2) && gemm_8p_supported(a1, false)) {
+                const int rc = gemm_8p_launch(a1, false, stream);
+                if (rc != MI_OK) return rc;
+                return gemm_8p128_launch(a2, (a2.K % 128) == 0 ? 0 : 4, stream);
+            }
+        }
+    }
+#endif
     if (phase_ok && v != 42 && v != 47 && gemm_8p_supported(a, conv) && (t256 >= 128 || v == 40)) return gemm_8p_launch(a, conv, stream);
     // N = 512-class GEMMs: 128x128 tiles (fp32 + residual or bf16 out); register-pipelined form for an even number of K tiles
     if (!conv && phase_ok && gemm_8p128_supported(a) && (cdiv(a.M, 128) * (a.N / 128) >= 128 || v == 40 || v == 42 || v == 47))

@@ -74,6 +74,7 @@ class WhisperEncoderEngine:
         if cfg["d_model"] // cfg["encoder_attention_heads"] not in (64, 128):
             raise NotImplementedError("head size must be 64 or 128")
         self.w = None
+        self.tail_split = True          # GEMM dispatch: give an under-filled last round of 256 x 256 tiles to the 128 x 128 kernel (gemm_glds.hip); set False when several batches are in flight on streams
 
     def load_state_dict(self, sd: dict, prefix: str = ""):
         dev, c = self.device, self.cfg
@@ -121,14 +122,15 @@ class WhisperEncoderEngine:
         x = torch.empty((M, d), dtype=torch.float32, device=dev)
         _lib.check(L.mi_add_positions(h2.data_ptr(), w["pos"].data_ptr(), x.data_ptr(), M, T2, d, st), "mi_add_positions")
         a = torch.empty((M, d), dtype=BF16, device=dev)
+        gv = 0 if self.tail_split else 48
         for lw in w["layers"]:
             ops.layernorm_chain(x, lna=lw["ln1"], outa=a)
-            qkv = ops.gemm(a, lw["wqkv"], lw["bqkv"])
+            qkv = ops.gemm(a, lw["wqkv"], lw["bqkv"], variant=gv)
             ctx = ops.attention_qkv(qkv, B, T2, H)
-            ops.gemm(ctx, lw["wo"], lw["bo"], out=x, resid=x, alpha=1.0)
+            ops.gemm(ctx, lw["wo"], lw["bo"], out=x, resid=x, alpha=1.0, variant=gv)
             ops.layernorm_chain(x, lna=lw["ln2"], outa=a)
-            m = ops.gemm(a, lw["w1"], lw["b1"], act="gelu")
-            ops.gemm(m, lw["w2"], lw["b2"], out=x, resid=x, alpha=1.0)
+            m = ops.gemm(a, lw["w1"], lw["b1"], act="gelu", variant=gv)
+            ops.gemm(m, lw["w2"], lw["b2"], out=x, resid=x, alpha=1.0, variant=gv)
         out = torch.empty((M, d), dtype=torch.float32, device=dev)
         ops.layernorm_chain(x, lna=w["lnf"], outa32=out)
         return out.view(B, T2, d)

@@ -47,7 +47,9 @@ int mi_gemm_bf16(const void* A, long lda, const void* W, long ldw, const float* 
                  int M, int N, int K, int col_T, int col_Tp, mi_stream_t stream);
 /* the same with an explicit kernel selection (A/B runs, tests that must reach a kernel below the size its default dispatch picks it at): 0 = the product's
  * dispatch (= mi_gemm_bf16), 40 / 41 = phase-interleaved kernels wherever supported / never, 42 / 47 = the 128x128 phase kernel (pipelined / two-segment form),
- * 30 / 31 = the older 128x128 LDS-DMA tiles (persistent / one block per tile).  Per call — the library keeps no kernel-selection state. */
+ * 30 / 31 = the older 128x128 LDS-DMA tiles (persistent / one block per tile); 48 = the product's dispatch (as 0) without the tail-round split: with variant 0 a GEMM
+ * whose 256x256 tiles leave a last round of the 256 CUs less than half full runs that round's rows on 128x128 tiles (same bits; callers with several batches in flight pass 48).
+ * Per call — the library keeps no kernel-selection state. */
 int mi_gemm_bf16_v(const void* A, long lda, const void* W, long ldw, const float* bias, int bias_mode,
                    void* C, long ldc, int out_f32, const float* resid, long ldr, float alpha, int act,
                    int M, int N, int K, int col_T, int col_Tp, int variant, mi_stream_t stream);

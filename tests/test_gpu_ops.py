@@ -90,6 +90,30 @@ def test_gemm_epilogues():
     assert bool((got[:, :, T:] == 0).all())
 
 
+@pytest.mark.parametrize("M,N,K,f32", [(24000, 768, 768, True), (24000, 768, 3072, True), (23987, 2304, 768, False), (24000, 3072, 768, False)])
+def test_gemm_tail_round_on_quarter_tiles_same_bits(M, N, K, f32):
+    """Wave quantization (gemm_glds.hip, round 4): when the 256 x 256 tiles of a GEMM leave a last round less than half full (Whisper-small's shapes at 16 x 30 s: 282 /
+    846 / 1128 tiles on 256 CUs), the product dispatch gives that round's rows to the 128 x 128 phase kernel.  Same K order and MFMA shape: the result must equal, bit
+    for bit, the one launch on 256 x 256 tiles (variant 40) — fp32 out with residual (attention / FFN out) and bf16 out with GELU (FFN in), a ragged last tile included."""
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    a = (torch.randn(M, K, device=DEV, generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(N, device=DEV, generator=g)
+    if f32:
+        res = torch.randn(M, N, device=DEV, generator=g)
+        got = ops.gemm(a, w, b, out=res.clone(), resid=res, alpha=1.0)
+        one = ops.gemm(a, w, b, out=res.clone(), resid=res, alpha=1.0, variant=40)
+    else:
+        got = ops.gemm(a, w, b, act="gelu")
+        one = ops.gemm(a, w, b, act="gelu", variant=40)
+    assert torch.equal(got, one)
+    rows = torch.tensor([0, 255, 21759, 21760, 21761, M - 1])               # both sides of the split (85 M tiles x 256 rows) against fp32 torch
+    want = a[rows].float() @ w.float().t() + b
+    want = (res[rows] + want) if f32 else F.gelu(want)
+    torch.testing.assert_close(got[rows].float().cpu(), want.cpu(), atol=3e-2, rtol=2e-2)
+
+
 @pytest.mark.parametrize("causal", [False, True])
 def test_conv_subsampling(causal):
     ops = _ops()
