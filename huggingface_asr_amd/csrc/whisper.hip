@@ -12,6 +12,7 @@
 namespace {
 
 constexpr int WN = 400, WHOP = 160, WBINS = 201;
+constexpr int MELW = 640;                                  // LDS slots for the packed mel weights (>= 2 * WBINS + a triangle's slack)
 
 struct WhArgs {
     const float* wave; long ldw; const int* num_samples; int n_samples;    // clips are zero-padded / cut to n_samples
@@ -35,95 +36,147 @@ __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
     else atomicMin(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
 }
 
-// A wave per frame, four frames per block.  400 = 4 x 100, so the bins k, 100-k, 100+k and 200-k (k = 0..50) share their twiddles up to
-// factors (-i)^n and a conjugation: lane k accumulates S_j = sum over n = j (mod 4) of x[n] e^{-2 pi i nk/400} (two FMAs per sample) and
-//   X[k] = S0 + S1 + S2 + S3,  X[200-k] = S0* - S1* + S2* - S3*,  X[100+k] = S0 - i S1 - S2 + i S3,  X[100-k] = S0* - i S1* - S2* + i S3*
-// — a quarter of the multiply-adds and of the twiddle gathers of one-lane-per-bin.  The mel filters are applied over their non-zero span only,
-// and the per-clip maximum the normalisation needs is taken here (one global atomic per frame).
+// Two frames per wave, eight per block.  400 = 8 x 50: with S_j(k) = sum over n = j (mod 8) of x[n] e^{-2 pi i n k / 400} (k = 0..25, one lane each; lanes 0-25 the wave's
+// first frame, 32-57 its second) the bins are 8-point transforms of the eight partial sums,
+//     X[k + 50 m] = sum_j S_j(k) w8^{j m},      X[50 m - k] = sum_j conj(S_j(k)) w8^{j m},      w8 = e^{-2 pi i / 8}
+// (x is real: S_j(-k) = conj S_j(k)), m = 0..3 of the first and 1..4 of the second cover 0..200.  A sample costs two FMAs and one rotation of its residue class's twiddle
+// (eight rotators per lane, each advanced by e^{-2 pi i 8 k / 400}; float64: 50 steps grow the error to ~1e-14).  The four-fold form of rounds 1-3 ran ONE frame per
+// wave on 51 lanes: the same 2 400 float64 instructions per wave for half the frames (PMC: the kernel is bound by their issue: 146 M per 16 x 30 s batch).
+// The mel filters are applied over their non-zero span only, and the per-clip maximum the normalisation needs is taken here (one global atomic per frame).
 __global__ __launch_bounds__(256) void whisper_logmel_kernel(WhArgs p, float* __restrict__ clipmax) {
-    __shared__ double xs[4][WN];
+    constexpr int FB = 8;                                   // frames per block
+    __shared__ double xs[FB][WN];
     __shared__ double2 tw[WN];
-    __shared__ double pw[4][WBINS + 3];
+    __shared__ double pw[FB][WBINS + 3];
     __shared__ int mlo[256], mhi[256];
-    __shared__ float smax[4];
+    __shared__ float smax[FB];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i < WN; i += 256) tw[i] = double2{p.twiddle[2 * i], p.twiddle[2 * i + 1]};
     // non-zero span of every mel filter (triangles: contiguous).  Thread = bin, loop over the filters: one coalesced load per filter and thread, the span's ends from
-    // wave ballots.  (Rounds 1-3: thread = filter walking its 201 bins — 201 DEPENDENT L2 round trips at the start of every block, ~150 us x 3 block rounds: most of
-    // the kernel's 704 us.)
+    // wave ballots (a thread per filter walking its 201 bins was 201 dependent L2 round trips at the start of every block).
     for (int i = tid; i < 256; i += 256) { mlo[i] = WBINS; mhi[i] = 0; }
     __syncthreads();
-    for (int m = 0; m < p.nmel; ++m) {
-        const bool nz = tid < WBINS && p.mel_t[(long)m * WBINS + tid] != 0.0;
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(nz);
-        if (lane == 0 && bal != 0ull) {
-            atomicMin(&mlo[m], wave * 64 + (int)__builtin_ctzll(bal));
-            atomicMax(&mhi[m], wave * 64 + 64 - (int)__builtin_clzll(bal));
+    for (int m0 = 0; m0 < p.nmel; m0 += 8) {                 // eight filters' loads in flight at a time (one at a time the loop is 80 L2 round trips per block)
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (tid < WBINS && m0 + j < p.nmel) ? p.mel_t[(long)(m0 + j) * WBINS + tid] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(v[j] != 0.0);
+            if (lane == 0 && bal != 0ull) {
+                atomicMin(&mlo[m0 + j], wave * 64 + (int)__builtin_ctzll(bal));
+                atomicMax(&mhi[m0 + j], wave * 64 + 64 - (int)__builtin_clzll(bal));
+            }
         }
     }
+    // the filters' non-zero weights packed back to back in LDS (every bin lies under at most two triangles): the filter loop below read them from global memory — a chain
+    // of L2 round trips per (frame, filter) task, three tasks per thread and block iteration — which, not the transform, was most of the kernel's time
+    __shared__ double mw[MELW];
+    __shared__ int moff[257];
+    __syncthreads();
+    if (tid == 0) {
+        int o = 0;
+        for (int m = 0; m < p.nmel; ++m) { moff[m] = o; o += max(mhi[m] - mlo[m], 0); }
+        moff[p.nmel] = o;
+    }
+    __syncthreads();
+    const int mtot = moff[p.nmel];
+    const bool mel_lds = mtot <= MELW;
+    if (mel_lds)
+        for (int i = tid; i < mtot; i += 256) {
+            int lo = 0, hi = p.nmel - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (moff[mid] <= i) lo = mid; else hi = mid - 1; }
+            mw[i] = p.mel_t[(long)lo * WBINS + mlo[lo] + (i - moff[lo])];
+        }
     const long total = (long)p.B * p.frames;
-    for (long f0 = (long)blockIdx.x * 4; f0 < total; f0 += (long)gridDim.x * 4) {
-        const long f = f0 + wave;
-        const bool valid = f < total;
-        const int b = valid ? (int)(f / p.frames) : 0, t = valid ? (int)(f % p.frames) : 0;
+    // A block owns a CONTIGUOUS run of frames — one clip, rarely two — and keeps that clip's maximum to itself until the clip changes or the block ends: ~800 global
+    // atomics per launch.  One `atomic max` per frame on the clip's single word (rounds 1-3; 48 000 per batch on 16 addresses, 3 000 serialised L2 round trips each) was
+    // what the kernel's 650-700 us actually were: halving its arithmetic, its set-up or its mel loads changed nothing.
+    const long per = ((total + gridDim.x - 1) / gridDim.x + FB - 1) / FB * FB;
+    const long fbeg = (long)blockIdx.x * per, fend = fbeg + per < total ? fbeg + per : total;
+    int cur_clip = -1;                                      // (thread 0)
+    float cur_max = -INFINITY;
+    for (long f0 = fbeg; f0 < fend; f0 += FB) {
         __syncthreads();
-        if (tid < 4) smax[tid] = -INFINITY;
-        if (valid) {
-            const float* w = p.wave + (long)b * p.ldw;
-            const int ns = p.num_samples ? min(p.num_samples[b], p.n_samples) : p.n_samples;
-            for (int i = lane; i < WN; i += 64) xs[wave][i] = (double)sample_reflect(w, ns, p.n_samples, t * WHOP + i) * p.window[i];
+        if (tid < FB) smax[tid] = -INFINITY;
+        // the eight windowed frames: 32 threads per frame
+        {
+            const int fr = tid >> 5, l32 = tid & 31;
+            const long f = f0 + fr;
+            if (f < fend) {
+                const int b = (int)(f / p.frames), t = (int)(f % p.frames);
+                const float* w = p.wave + (long)b * p.ldw;
+                const int ns = p.num_samples ? min(p.num_samples[b], p.n_samples) : p.n_samples;
+                for (int i = l32; i < WN; i += 32) xs[fr][i] = (double)sample_reflect(w, ns, p.n_samples, t * WHOP + i) * p.window[i];
+            }
         }
         __syncthreads();
-        if (valid && lane <= 50) {
-            const int k = lane;
-            double re[4] = {0.0, 0.0, 0.0, 0.0}, im[4] = {0.0, 0.0, 0.0, 0.0};      // S_j = re[j] + i im[j]
-            // The twiddle of sample n = 4 m + j is e^{2 pi i (4 m + j) k / 400}: four independent rotators c_j, started from the table at j k and advanced by the table's
-            // entry at 4 k (float64 complex multiply: 100 steps grow the error to ~1e-14, the test's tolerance on log10 is 3e-5).  Gathering tw[n k mod 400] per lane
-            // and step, as rounds 1-3 did, is a 51-lane LDS access whose bank is (n k) mod 16: up to 51-way conflicts — the kernel took 704 us per 16 x 30 s batch,
-            // 7.5 % of config 4's step, most of it LDS replays.  The samples stay a broadcast read.
-            double2 c[4];
+        const int half = lane >> 5, k = lane & 31, fr = 2 * wave + half;
+        if (f0 + fr < fend && k <= 25) {
+            double sr[8], si[8];                              // S_j = sr[j] + i si[j]
+            double2 c[8];
             {
                 int idx = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { c[j] = tw[idx]; idx += k; if (idx >= WN) idx -= WN; }
+                for (int j = 0; j < 8; ++j) { sr[j] = 0.0; si[j] = 0.0; c[j] = tw[idx]; idx += k; }       // e^{+2 pi i j k / 400}: j k <= 175
             }
-            const double2 w4 = tw[(4 * k) % WN];
-            for (int n = 0; n < WN; n += 4) {
+            const double2 w8k = tw[8 * k];                    // 8 k <= 200
+            const double* xf = xs[fr];
+            for (int n = 0; n < WN; n += 8) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const double x = xs[wave][n + j];
-                    re[j] = fma(x, c[j].x, re[j]);
-                    im[j] = fma(-x, c[j].y, im[j]);
-                    const double nx = fma(c[j].x, w4.x, -(c[j].y * w4.y)), ny = fma(c[j].x, w4.y, c[j].y * w4.x);
+                for (int j = 0; j < 8; ++j) {
+                    const double x = xf[n + j];
+                    sr[j] = fma(x, c[j].x, sr[j]);
+                    si[j] = fma(-x, c[j].y, si[j]);
+                    const double nx = fma(c[j].x, w8k.x, -(c[j].y * w8k.y)), ny = fma(c[j].x, w8k.y, c[j].y * w8k.x);
                     c[j] = double2{nx, ny};
                 }
             }
+            // 8-point transforms of (S_j) and (conj S_j):  w8^q = (cr[q], ci[q]), q = j m mod 8
+            const double h = 0.70710678118654752440;
+            const double cr[8] = {1.0, h, 0.0, -h, -1.0, -h, 0.0, h}, ci[8] = {0.0, -h, -1.0, -h, 0.0, h, 1.0, h};
             auto put = [&](int bin, double r, double i_) {
                 const double r32 = (double)(float)r, i32 = (double)(float)i_;          // the reference stores the STFT as complex64
-                pw[wave][bin] = r32 * r32 + i32 * i32;           // |X|^2 directly (the reference's abs-then-square differs by one float64 rounding)
+                pw[fr][bin] = r32 * r32 + i32 * i32;           // |X|^2 directly (the reference's abs-then-square differs by one float64 rounding)
             };
-            put(k, (re[0] + re[2]) + (re[1] + re[3]), (im[0] + im[2]) + (im[1] + im[3]));
-            put(200 - k, (re[0] + re[2]) - (re[1] + re[3]), -((im[0] + im[2]) - (im[1] + im[3])));
-            // -i S1 = (im1, -re1),  +i S3 = (-im3, re3)
-            put(100 + k, (re[0] - re[2]) + (im[1] - im[3]), (im[0] - im[2]) - (re[1] - re[3]));
-            // S* terms: S0* - i S1* - S2* + i S3*;  -i (re1 - i im1) = (-im1, -re1),  +i (re3 - i im3) = (im3, re3)
-            put(100 - k, (re[0] - re[2]) - (im[1] - im[3]), -(im[0] - im[2]) - (re[1] - re[3]));
+#pragma unroll
+            for (int m = 0; m <= 4; ++m) {
+                double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;  // a = sum S_j w^{jm}, b = sum conj(S_j) w^{jm}
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int q = (j * m) & 7;
+                    ar += sr[j] * cr[q] - si[j] * ci[q];  ai += sr[j] * ci[q] + si[j] * cr[q];
+                    br += sr[j] * cr[q] + si[j] * ci[q];  bi += sr[j] * ci[q] - si[j] * cr[q];
+                }
+                if (m <= 3) put(k + 50 * m, ar, ai);
+                if (m >= 1 && k >= 1) put(50 * m - k, br, bi);
+                if (m == 4 && k == 0) put(200, ar, ai);
+            }
         }
         __syncthreads();
-        for (int q = tid; q < 4 * p.nmel; q += 256) {
-            const int fr = q / p.nmel, m = q - fr * p.nmel;
-            const long ff = f0 + fr;
-            if (ff >= total) continue;
-            const double* mt = p.mel_t + (long)m * WBINS;
+        for (int q = tid; q < FB * p.nmel; q += 256) {
+            const int fq = q / p.nmel, m = q - fq * p.nmel;
+            const long ff = f0 + fq;
+            if (ff >= fend) continue;
+            const double* mt = mel_lds ? mw + moff[m] - mlo[m] : p.mel_t + (long)m * WBINS;
             double acc = 0.0;
-            for (int kk = mlo[m]; kk < mhi[m]; ++kk) acc = fma(pw[fr][kk], mt[kk], acc);
+            for (int kk = mlo[m]; kk < mhi[m]; ++kk) acc = fma(pw[fq][kk], mt[kk], acc);
             const float v = log10f((float)fmax(acc, 1e-10));           // float32 log10 of the float64 energy: 1 ulp (< 1e-6) from float32(log10_64(acc))
             p.out[ff * p.nmel + m] = v;
-            atomic_max_f32(&smax[fr], v);
+            atomic_max_f32(&smax[fq], v);
         }
         __syncthreads();
-        if (tid < 4 && f0 + tid < total) atomic_max_f32(clipmax + (int)((f0 + tid) / p.frames), smax[tid]);
+        if (tid == 0)
+            for (int i = 0; i < FB && f0 + i < fend; ++i) {
+                const int b = (int)((f0 + i) / p.frames);
+                if (b != cur_clip) {
+                    if (cur_clip >= 0) atomic_max_f32(clipmax + cur_clip, cur_max);
+                    cur_clip = b; cur_max = -INFINITY;
+                }
+                cur_max = fmaxf(cur_max, smax[i]);
+            }
     }
+    if (tid == 0 && cur_clip >= 0) atomic_max_f32(clipmax + cur_clip, cur_max);
 }
 
 // out = (max(x, m - 8) + 4) / 4 with m = the clip's maximum (taken by the log-mel kernel), written both as (B, nmel, frames) fp32 (the HF
@@ -182,8 +235,8 @@ extern "C" int mi_whisper_logmel(const float* wave, long ldw, const int* num_sam
     const long total = (long)B * frames;
     float* clipmax = scratch + total * nmel;                   // B floats behind the (B, frames, nmel) scratch
     if (hipMemsetD32Async((hipDeviceptr_t)clipmax, 0xFF800000u /* -inf */, B, stream) != hipSuccess) return MI_ERR_LAUNCH;
-    const long nblk = (total + 3) / 4;
-    hipLaunchKernelGGL(whisper_logmel_kernel, dim3((unsigned)(nblk < 4096 ? nblk : 4096)), dim3(256), 0, stream, a, clipmax);
+    const long nblk = (total + 7) / 8;
+    hipLaunchKernelGGL(whisper_logmel_kernel, dim3((unsigned)(nblk < 768 ? nblk : 768)), dim3(256), 0, stream, a, clipmax);      // three blocks per CU, resident for the whole launch: a block's set-up (twiddles, mel spans, packed weights) runs once per CU slot, not once per 8 frames
     const long nel = total * nmel;
     hipLaunchKernelGGL(whisper_norm_kernel, dim3((unsigned)((nel + 255) / 256 < 8192 ? (nel + 255) / 256 : 8192)), dim3(256), 0, stream, scratch, clipmax, frames, nmel, B,
                        out_features, (bf16_t*)out_cl_bf16);
