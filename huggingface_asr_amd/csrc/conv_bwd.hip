@@ -564,7 +564,7 @@ typedef short c1b_s16x8 __attribute__((ext_vector_type(8)));
 template <int OFF>
 __device__ __forceinline__ void c1b_tr_issue(unsigned a0, unsigned a1, c1b_s16x4& lo, c1b_s16x4& hi) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "n"(OFF) : "memory");
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "n"(OFF + 0) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ bf16x8 c1b_tr_join(c1b_s16x4& lo, c1b_s16x4& hi) {
     asm volatile("" : "+v"(lo), "+v"(hi));

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void whisper_logmel_kernel(WhArgs p, float* __
     for (int i = tid; i < WN; i += 256) tw[i] = double2{p.twiddle[2 * i], p.twiddle[2 * i + 1]};
     // non-zero span of every mel filter (triangles: contiguous).  Thread = bin, loop over the filters: one coalesced load per filter and thread, the span's ends from
     // wave ballots (a thread per filter walking its 201 bins was 201 dependent L2 round trips at the start of every block).
-    for (int i = tid; i < 256; i += 256) { mlo[i] = WBINS; mhi[i] = 0; }
+    mlo[tid] = WBINS; mhi[tid] = 0;
     __syncthreads();
     for (int m0 = 0; m0 < p.nmel; m0 += 8) {                 // eight filters' loads in flight at a time (one at a time the loop is 80 L2 round trips per block)
         double v[8];
