@@ -371,7 +371,7 @@ constexpr int TN_GROUP_N = 256;                            // 256 (n) x XW (k) t
 // With those gone the ring depth shows (it did not before): 256 x 128, small encoder x 4 layers at config 3's 48 000 rows 1407 -> 1060 us (three stages; 1197 with
 // two), two base layers on 256 x 256 329 -> 292 us (832 TFLOP/s).  The 128-wide form now sits at the chip's L2 -> LDS ingest (232 CUs x 48 KiB / 1.41 us = 7.9 TB/s;
 // the forward GEMM at 8192^3 takes in 10.5); the 256-wide one at 6.4 TB/s is bound by its two-stage ring (a stage's DMA has one stage of compute to land).
-// Measured and not kept: 32-row stages (4 x 32 KiB / 6 x 24 KiB rings: 300 / 361 us, twice the barriers), spreading a stage's DMA instructions over its k-steps
+// Measured and not kept: 32-row stages (4 x 32 KiB / 6 x 24 KiB rings: 300 / 361 us, twice the barriers), three 48-row stages for the 256 x 256 tile (144 KiB: 318 vs 307 us), spreading a stage's DMA instructions over its k-steps
 // (334 us / 467 us: the issue back-pressure round 2's stamps showed was the compiler's vmcnt(0), not the queue).
 template <int XW, int NS>
 __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g) {
