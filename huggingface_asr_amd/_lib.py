@@ -58,6 +58,8 @@ SIGNATURES = {
     "mi_attention_bf16": [vp, i64, vp, i64, vp, i64, i32, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, i32, vp],
     "mi_attention_qkv_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i64, i32, i32, f32, i32, vp],
     "mi_attention_qkv_bf16_v": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i64, i32, i32, f32, i32, i32, vp],
+    "mi_attention_x_lse_bf16": [vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, i32, f32, i32, f32, C.c_uint, C.c_uint, vp],
+    "mi_attention_x_bwd_probs": [vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, i32, f32, C.c_uint, C.c_uint, vp],
     "mi_attention_qkv_lse_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, f32, i32, f32, C.c_uint, C.c_uint, vp],
     "mi_attention_qkv_bwd_probs": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, i32,
                                    vp, i64, vp, vp, i32, i32, i32, i32, f32, i32, f32, C.c_uint, C.c_uint, vp],

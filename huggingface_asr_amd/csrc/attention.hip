@@ -1457,3 +1457,41 @@ extern "C" int mi_attention_qkv_bwd_probs(const void* q, long ldq, const void* k
         default: return MI_ERR_UNSUPPORTED;
     }
 }
+
+// The two training entries above for Tq != Tk and separate q / k / v operands (no relative positions): the GPT-2 decoder's causal self-attention (Tq = Tk = U) and its
+// cross-attention over the encoder frames (Tq = U, Tk = T', `lengths` = valid keys), multi_head_gpt2.py:80-170 — which rounds 2-3 trained through materialised scores
+// (batched GEMM, soft-max, batched GEMM: three launches forward, seven backward).  lse (B, H, Tq); prob / ds (H, B, Tq, ldsr), ldsr a multiple of 32 >= Tk rounded up to 32.
+extern "C" int mi_attention_x_lse_bf16(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const int* lengths, void* out, long ldo, float* lse,
+                                       int B, int Tq, int Tk, int H, int hd, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, hipStream_t stream) {
+    MI_ENTER();
+    if (B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0 || !lse || drop_p < 0.f || drop_p >= 1.f) return MI_ERR_ARG;
+    if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 8) || ((uintptr_t)out & 15)) return MI_ERR_ARG;
+    if (ldq >= (1l << 30) || ldk <= 0 || ldv <= 0 || ldk >= (1l << 30) || ldv >= (1l << 30)) return MI_ERR_ARG;
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15)) return MI_ERR_ARG;
+    AttnArgs a{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, 0, nullptr, 0, nullptr, nullptr, lengths, (bf16_t*)out, ldo, B, Tq, H, scale, causal, Tk, 0, lse};
+    a.drop_p = drop_p; a.drop_key = ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed;
+    switch (hd) {
+        case 64: return launch_lds<64>(a, false, stream);
+        case 128: return launch_lds<128>(a, false, stream);
+        default: return MI_ERR_UNSUPPORTED;
+    }
+}
+extern "C" int mi_attention_x_bwd_probs(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const int* lengths,
+                                        const void* ctx, long ldo, const void* dctx, long ldd, const float* lse, void* prob, void* ds, long ldsr, void* dq, long lddq,
+                                        int B, int Tq, int Tk, int H, int hd, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, hipStream_t stream) {
+    MI_ENTER();
+    if (B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0 || !lse || !ctx || !dctx || !prob || !ds || !dq || drop_p < 0.f || drop_p >= 1.f) return MI_ERR_ARG;
+    if ((lddq % 8) || lddq >= (1l << 30) || ((uintptr_t)dq & 15)) return MI_ERR_ARG;
+    if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 8) || (ldd % 8)) return MI_ERR_ARG;
+    if (ldq >= (1l << 30) || ldk <= 0 || ldv <= 0 || ldk >= (1l << 30) || ldv >= (1l << 30) || ldo >= (1l << 30) || ldd >= (1l << 30)) return MI_ERR_ARG;
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)ctx | (uintptr_t)dctx | (uintptr_t)prob | (uintptr_t)ds) & 15)) return MI_ERR_ARG;
+    if ((ldsr % 32) || ldsr < (Tk + 31) / 32 * 32) return MI_ERR_ARG;
+    AttnArgs a{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, 0, nullptr, 0, nullptr, nullptr, lengths, (bf16_t*)const_cast<void*>(ctx), ldo, B, Tq, H, scale, causal,
+               Tk, 0, const_cast<float*>(lse), (const bf16_t*)dctx, ldd, (bf16_t*)prob, (bf16_t*)ds, ldsr, nullptr, 0, 0, (bf16_t*)dq, lddq, nullptr, nullptr, drop_p,
+               ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed};
+    switch (hd) {
+        case 64: return launch_lds_bw<64>(a, false, stream);
+        case 128: return launch_lds_bw<128>(a, false, stream);
+        default: return MI_ERR_UNSUPPORTED;
+    }
+}

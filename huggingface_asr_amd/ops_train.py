@@ -278,6 +278,36 @@ def band_geometry(T: int):
     return pad, (pad + 2 * T - 1 + 31) // 32 * 32
 
 
+def attention_x_lse(q, k, v, B, Tq, Tk, H, *, lengths=None, causal=False, drop=None):
+    """Fused training forward for separate q (B*Tq, .) / k, v (B*Tk, .) bf16 row views (head size 64 / 128, no relative positions): -> (ctx (B*Tq, d) bf16,
+    lse (B, H, Tq) fp32).  drop = (p, seed, stream_id): probability dropout with the mask of the generic softmax kernels for element ((h B + b) Tq + i) Tk + j."""
+    d = q.shape[1]
+    hd = d // H
+    out = torch.empty((B * Tq, d), device=q.device, dtype=BF16)
+    lse = torch.empty((B, H, Tq), device=q.device, dtype=F32)
+    dp, dseed, dsid = drop if drop is not None else (0.0, 0, 0)
+    _lib.check(_L().mi_attention_x_lse_bf16(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(lengths), out.data_ptr(), out.stride(0),
+                                            lse.data_ptr(), B, Tq, Tk, H, hd, 1.0 / math.sqrt(hd), int(causal), float(dp), int(dseed) & 0xFFFFFFFF, int(dsid) & 0xFFFFFFFF,
+                                            _stream()), "mi_attention_x_lse_bf16")
+    return out, lse
+
+
+def attn_x_bwd_probs(q, k, v, B, Tq, Tk, H, ctx, dctx, lse, dq, *, lengths=None, causal=False, drop=None):
+    """First half of the fused backward for `attention_x_lse`: -> prob (the dropped probabilities when drop is given), ds (H, B, Tq, Ts) bf16, Ts = Tk rounded up to 32;
+    dq (B*Tq, .) bf16 row view receives dS K."""
+    d = ctx.shape[1]
+    hd = d // H
+    Ts = (Tk + 31) // 32 * 32
+    prob = torch.empty((H, B, Tq, Ts), device=q.device, dtype=BF16)
+    ds = torch.empty((H, B, Tq, Ts), device=q.device, dtype=BF16)
+    dp, dseed, dsid = drop if drop is not None else (0.0, 0, 0)
+    _lib.check(_L().mi_attention_x_bwd_probs(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(lengths), ctx.data_ptr(), ctx.stride(0),
+                                             dctx.data_ptr(), dctx.stride(0), lse.data_ptr(), prob.data_ptr(), ds.data_ptr(), Ts, dq.data_ptr(), dq.stride(0),
+                                             B, Tq, Tk, H, hd, 1.0 / math.sqrt(hd), int(causal), float(dp), int(dseed) & 0xFFFFFFFF, int(dsid) & 0xFFFFFFFF, _stream()),
+               "mi_attention_x_bwd_probs")
+    return prob, ds
+
+
 def attn_bwd_probs(qkv, B, T, H, ctx, dctx, lse, dq, *, pos=None, bias_u=None, bias_v=None, lengths=None, causal=False, drop=None):
     """First half of the fused attention backward (head size 64 / 128, no probability dropout): -> prob, ds (H, B, T, Ts) bf16 and, with relative positions,
     dbd (H, B, T, Ps) bf16 with dbd[i][T-1-i+j + pad] = ds[i][j] (else None).  Ts = T rounded up to 32; (pad, Ps) = band_geometry(T).  Everything is written.

@@ -91,7 +91,8 @@ def attention_fwd_plain(q, k, v, B, Tq, Tk, H, *, lengths=None, causal=False, dr
     d = q.shape[1]
     hd = d // H
     ac, Ts = _scores(q, k, B, Tq, Tk, H, hd)
-    prob, pdrop = T.attn_softmax_fwd(ac, None, lengths, H, B, Tq, Tk, 1.0 / math.sqrt(hd), causal, drop=drop)
+    r = T.attn_softmax_fwd(ac, None, lengths, H, B, Tq, Tk, 1.0 / math.sqrt(hd), causal, drop=drop)
+    prob, pdrop = r if drop else (r, r)                    # (without dropout the op returns the probabilities alone)
     ctx = torch.empty((B * Tq, d), device=q.device, dtype=BF16)
     T.bgemm(pdrop, (B * Tq * Ts, Tq * Ts, Ts, 1), v, (hd, Tk * v.stride(0), 1, v.stride(0)), ctx, (hd, Tq * d, d), H, B, Tq, hd, Tk)
     return ctx, prob, pdrop
@@ -118,6 +119,19 @@ def attention_bwd_plain(q, k, v, dctx, dq, dk, dv, B, Tq, Tk, H, *, lengths=None
     T.bgemm(pdrop, (*sS, 1, Ts), dctx, (hd, Tq * sd_, 1, sd_), dv, (hd, Tk * dv.stride(0), dv.stride(0)), H, B, Tk, hd, Tq)
     T.bgemm(ds, (*sS, 1, Ts), q, (hd, Tq * sq, 1, sq), dk, (hd, Tk * dk.stride(0), dk.stride(0)), H, B, Tk, hd, Tq)
     T.bgemm(ds, (*sS, Ts, 1), k, (hd, Tk * sk, 1, sk), dq, (hd, Tq * dq.stride(0), dq.stride(0)), H, B, Tq, hd, Tk)
+
+
+def attention_bwd_fused(q, k, v, ctx, dctx, lse, dq, dk, dv, B, Tq, Tk, H, *, lengths=None, causal=False, drop=None):
+    """Backward of `ops_train.attention_x_lse` (head size 64 / 128): ONE walk recomputes the probabilities, leaves P (dropped) and dS in bf16 and accumulates dQ = dS K on the
+    way (mi_attention_x_bwd_probs); dV = P^T dctx and dK = dS^T q stay batched GEMMs over them.  Three launches where attention_bwd_plain has seven."""
+    d = dctx.shape[1]
+    hd = d // H
+    prob, ds = T.attn_x_bwd_probs(q, k, v, B, Tq, Tk, H, ctx, dctx, lse, dq, lengths=lengths, causal=causal, drop=drop)
+    Ts = prob.shape[-1]
+    sS = (B * Tq * Ts, Tq * Ts)
+    sd_, sq = dctx.stride(0), q.stride(0)
+    T.bgemm(prob, (*sS, 1, Ts), dctx, (hd, Tq * sd_, 1, sd_), dv, (hd, Tk * dv.stride(0), dv.stride(0)), H, B, Tk, hd, Tq)
+    T.bgemm(ds, (*sS, 1, Ts), q, (hd, Tq * sq, 1, sq), dk, (hd, Tk * dk.stride(0), dk.stride(0)), H, B, Tk, hd, Tq)
 
 
 class JointAEDTrainer:
@@ -247,6 +261,7 @@ class JointAEDTrainer:
         pos = self.pos_fixed if self.pos_fixed is not None else P("wpe")
         x = ops.embed_tokens(ids, P("wte"), pos, scale=self.emb_scale)
         pe, pa, pr = self.pdrop["embd_pdrop"], self.pdrop["attn_pdrop"], self.pdrop["resid_pdrop"]
+        fused_att = (self.dcfg["n_embd"] // self.dcfg["n_head"]) in (64, 128)          # the LDS-staged attention kernels' head sizes
         seed, sid = self.enc.seed, self.enc._sid
         if pe > 0:
             T.dropout_(x, pe, seed, sid(63, 0))
@@ -268,7 +283,10 @@ class JointAEDTrainer:
             a1 = e16(M, d)
             LN(x, lna=(P(p + "ln1_g"), P(p + "ln1_b")), eps2=eps, outa=a1)
             qkv = ops.gemm(a1, W(p + "wqkv"), P(p + "bqkv"))
-            if pa > 0:
+            if fused_att:                                       # head size 64 / 128: fused forward with the row log-sum-exp (and the dropout mask) for the fused backward
+                ctx1, lse1 = T.attention_x_lse(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, U, U, H, causal=True, drop=(pa, seed, sid(32 + l, 0)) if pa > 0 else None)
+                S["p1"] = ("lse", lse1)
+            elif pa > 0:
                 ctx1, *S["p1"] = attention_fwd_plain(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, U, U, H, causal=True, drop=(pa, seed, sid(32 + l, 0)))
             else:
                 ctx1 = ops.attention_general(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, U, U, H, causal=True)
@@ -277,7 +295,10 @@ class JointAEDTrainer:
             LN(x1, lna=(P(p + "lnc_g"), P(p + "lnc_b")), eps2=eps, outa=a2)
             qq = ops.gemm(a2, W(p + "wq"), P(p + "bq"))
             kv = ops.gemm(enc_bf, W(p + "wkv"), P(p + "bkv"))
-            if pa > 0:
+            if fused_att:
+                ctx2, lse2 = T.attention_x_lse(qq, kv[:, :d], kv[:, d:], B, U, T2, H, lengths=key_len, drop=(pa, seed, sid(32 + l, 2)) if pa > 0 else None)
+                S["p2"] = ("lse", lse2)
+            elif pa > 0:
                 ctx2, *S["p2"] = attention_fwd_plain(qq, kv[:, :d], kv[:, d:], B, U, T2, H, lengths=key_len, drop=(pa, seed, sid(32 + l, 2)))
             else:
                 ctx2 = ops.attention_general(qq, kv[:, :d], kv[:, d:], B, U, T2, H, lengths=key_len)
@@ -347,8 +368,12 @@ class JointAEDTrainer:
             dctx2 = T.linear_bwd(dyb, S["ctx2"], WT(p + "wco"), dw=G(p + "wco"), db=G(p + "bco"), defer=tnb)
             dqq, dkv = e16(M, d), e16(Me, 2 * d)
             kv = S["kv"]
-            attention_bwd_plain(S["qq"], kv[:, :d], kv[:, d:], dctx2, dqq, dkv[:, :d], dkv[:, d:], B, U, T2, H, lengths=key_len,
-                                drop=(pa, seed, sid(32 + l, 2)) if pa > 0 else None, saved=S["p2"])
+            if isinstance(S["p2"], tuple) and S["p2"][0] == "lse":
+                attention_bwd_fused(S["qq"], kv[:, :d], kv[:, d:], S["ctx2"], dctx2, S["p2"][1], dqq, dkv[:, :d], dkv[:, d:], B, U, T2, H, lengths=key_len,
+                                    drop=(pa, seed, sid(32 + l, 2)) if pa > 0 else None)
+            else:
+                attention_bwd_plain(S["qq"], kv[:, :d], kv[:, d:], dctx2, dqq, dkv[:, :d], dkv[:, d:], B, U, T2, H, lengths=key_len,
+                                    drop=(pa, seed, sid(32 + l, 2)) if pa > 0 else None, saved=S["p2"])
             da2 = T.linear_bwd(dqq, S["a2"], WT(p + "wq"), dw=G(p + "wq"), db=G(p + "bq"), defer=tnb)
             T.linear_bwd(dkv, enc_bf, WT(p + "wkv"), dw=G(p + "wkv"), db=G(p + "bkv"), need_dx=False, defer=tnb)
             ops.gemm(dkv, WT(p + "wkv")[:, :2 * d], out=denc, resid=denc, alpha=1.0)
@@ -358,8 +383,12 @@ class JointAEDTrainer:
             dctx1 = T.linear_bwd(dyb, S["ctx1"], WT(p + "wo"), dw=G(p + "wo"), db=G(p + "bo"), defer=tnb)
             qkv = S["qkv"]
             dqkv = e16(M, 3 * d)
-            attention_bwd_plain(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], dctx1, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, U, U, H, causal=True,
-                                drop=(pa, seed, sid(32 + l, 0)) if pa > 0 else None, saved=S["p1"])
+            if isinstance(S["p1"], tuple) and S["p1"][0] == "lse":
+                attention_bwd_fused(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], S["ctx1"], dctx1, S["p1"][1], dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, U, U, H,
+                                    causal=True, drop=(pa, seed, sid(32 + l, 0)) if pa > 0 else None)
+            else:
+                attention_bwd_plain(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], dctx1, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, U, U, H, causal=True,
+                                    drop=(pa, seed, sid(32 + l, 0)) if pa > 0 else None, saved=S["p1"])
             da1 = T.linear_bwd(dqkv, S["a1"], WT(p + "wqkv"), dw=G(p + "wqkv"), db=G(p + "bqkv"), defer=tnb)
             T.layernorm_bwd(S["x"], P(p + "ln1_g"), da1, dx, accumulate=True, dgamma=G(p + "ln1_g"), dbeta=G(p + "ln1_b"), eps=eps)
         if 0 in tap_grads:

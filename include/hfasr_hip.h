@@ -178,6 +178,13 @@ int mi_attention_qkv_bwd_probs(const void* q, long ldq, const void* k, long ldk,
                                void* prob, void* ds, long ldsr, void* dbd, long ldbd, int pad,
                                void* dq, long lddq, float* dsum_u, float* dsum_v,
                                int B, int T, int H, int hd, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, mi_stream_t stream);
+/* the two entries above for Tq != Tk and separate q / k / v operands, no relative positions: the GPT-2 decoder's causal self-attention and its cross-attention over the
+ * encoder frames in training (multi_head_gpt2.py:80-170).  lse (B, H, Tq); prob / ds (H, B, Tq, ldsr) bf16, ldsr % 32 == 0, ldsr >= Tk rounded up to 32; dq = dS K. */
+int mi_attention_x_lse_bf16(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const int* lengths, void* out, long ldo, float* lse,
+                            int B, int Tq, int Tk, int H, int hd, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, mi_stream_t stream);
+int mi_attention_x_bwd_probs(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const int* lengths, const void* ctx, long ldo,
+                             const void* dctx, long ldd, const float* lse, void* prob, void* ds, long ldsr, void* dq, long lddq,
+                             int B, int Tq, int Tk, int H, int hd, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, mi_stream_t stream);
 /* (drop_p / seed / stream_id as given to the forward: prob then holds the DROPPED probabilities, ds the gradient through the un-dropped softmax) */
 
 /* ---- cgMLP gate: per-row LN statistics + fused LN -> depthwise conv(time) -> gate.

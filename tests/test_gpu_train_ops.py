@@ -595,6 +595,35 @@ def test_ctc_loss_bwd(reduction):
     close(dl[:, :V1].reshape(B, Tt, V1), lg.grad, floor=5e-3, what="ctc dlogits")
 
 
+@pytest.mark.parametrize("B,Tq,Tk,H,hd,causal,p", [(3, 60, 500, 4, 64, False, 0.1), (3, 60, 60, 4, 64, True, 0.1), (2, 37, 250, 2, 128, False, 0.0), (2, 33, 33, 2, 64, True, 0.0),
+                                                    (2, 150, 97, 4, 64, False, 0.1)])
+def test_fused_attention_for_separate_operands_against_the_materialised_path(B, Tq, Tk, H, hd, causal, p):
+    """mi_attention_x_lse_bf16 / mi_attention_x_bwd_probs (round 4: the GPT-2 decoder's self- and cross-attention in training, Tq != Tk, ragged key lengths, probability dropout)
+    against the path they replace — batched GEMM, generic soft-max (same counter-based mask), batched GEMM (train_aed.attention_fwd_plain / attention_bwd_plain): context,
+    probabilities, score gradients and dq / dk / dv."""
+    ops, T = _o()
+    from huggingface_asr_amd import train_aed as TA
+    d = H * hd
+    q = dev16(rnd(B * Tq, d, seed=1, scale=0.7)); k = dev16(rnd(B * Tk, d, seed=2, scale=0.7)); v = dev16(rnd(B * Tk, d, seed=3, scale=0.7))
+    dctx = dev16(rnd(B * Tq, d, seed=4, scale=0.5))
+    lengths = None if causal else torch.tensor([max(1, Tk - 41 * b) for b in range(B)], dtype=torch.int32, device=DEV)
+    drop = (p, 77, 5) if p > 0 else None
+    ctx0, prob0, pdrop0 = TA.attention_fwd_plain(q, k, v, B, Tq, Tk, H, lengths=lengths, causal=causal, drop=drop)
+    dq0, dk0, dv0 = (torch.zeros_like(t) for t in (q, k, v))
+    TA.attention_bwd_plain(q, k, v, dctx, dq0, dk0, dv0, B, Tq, Tk, H, lengths=lengths, causal=causal, drop=drop, saved=(prob0, pdrop0))
+    ctx1, lse = T.attention_x_lse(q, k, v, B, Tq, Tk, H, lengths=lengths, causal=causal, drop=drop)
+    close(ctx1, ctx0.float().cpu(), floor=6e-3, what="context")
+    dq1, dk1, dv1 = (torch.zeros_like(t) for t in (q, k, v))
+    TA.attention_bwd_fused(q, k, v, ctx1, dctx, lse, dq1, dk1, dv1, B, Tq, Tk, H, lengths=lengths, causal=causal, drop=drop)
+    close(dv1, dv0.float().cpu(), floor=8e-3, what="dv")
+    close(dk1, dk0.float().cpu(), floor=8e-3, what="dk")
+    close(dq1, dq0.float().cpu(), floor=8e-3, what="dq")
+    # bit-reproducible
+    dq2, dk2, dv2 = (torch.zeros_like(t) for t in (q, k, v))
+    TA.attention_bwd_fused(q, k, v, ctx1, dctx, lse, dq2, dk2, dv2, B, Tq, Tk, H, lengths=lengths, causal=causal, drop=drop)
+    assert torch.equal(dq1, dq2) and torch.equal(dk1, dk2) and torch.equal(dv1, dv2)
+
+
 @pytest.mark.parametrize("Tt,U", [(500, 60), (300, 20), (257, 63)])
 def test_ctc_loss_bwd_long_inputs(Tt, U):
     """more than 256 frames with <= 128 states (BASELINE config 3: 20 s clips = 500 encoder frames, 60 labels): the wave form with the emissions in an L2-resident global
