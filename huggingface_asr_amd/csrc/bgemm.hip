@@ -22,6 +22,10 @@ struct BgArgs {
     int out_f32, accumulate;
     float alpha;
     int Z2, M, N, K;
+    // band (mi_bgemm_band_bf16; 0 = off): A is the un-shifted relative-position gradient dBD — K runs over `band_cg` utterances of band_T query rows each, and row i of an
+    // utterance is non-zero only in columns m in [band_a - i, band_a - i + band_T) — so an M tile [m0, m0 + TMB) meets only the rows i in
+    // [band_a - (m0 + TMB - 1), band_a + band_T - 1 - m0] of every utterance: the K loop walks those (rounded out to k tiles) and skips the all-zero rest, about half.
+    int band_T, band_a, band_cg;
 };
 
 // Block tile TMB x TMB x TKB (64 x 64 x 32: one 32 x 32 MFMA tile per wave — round 1; 128 x 128 x 64: 2 x 2 tiles per wave, sixteen MFMAs per barrier pair and eight
@@ -165,6 +169,17 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgArgs p) {
         // give it none, and it reorders the prologue's loads so that the loop header drains the queue.  Every stage's loads are therefore unconditional (k tiles
         // past K re-read k = 0 and are masked to zero on their way to LDS), NS per operand, and a stage waits with vmcnt(2 NS): exactly the younger stage.
         bf16x8 ra[2][NS], rb[2][NS];
+        // with a band (BgArgs) only the k tiles that hold a row this M tile's columns can meet are walked, in order, each once: the sums are those of the full walk
+        // minus tiles of zeros — the same bits
+        const int ilo = p.band_T > 0 ? max(p.band_a - (m0 + TMB - 1), 0) : 0, ihi = p.band_T > 0 ? min(p.band_a + p.band_T - 1 - m0, p.band_T - 1) : 0;
+        auto needed = [&](int t) -> bool {                   // block-uniform
+            if (p.band_T <= 0) return true;
+            const int a = t * TK, b = min(a + TK, p.K) - 1;
+            for (int u = a / p.band_T; u <= b / p.band_T; ++u)
+                if (max(a, u * p.band_T + ilo) <= min(b, u * p.band_T + ihi)) return true;
+            return false;
+        };
+        auto next_needed = [&](int t) { while (t < nk && !needed(t)) ++t; return t < nk ? t : nk; };
         auto issue = [&](int s, int k0) {
 #pragma unroll
             for (int ps = 0; ps < NS; ++ps) {
@@ -172,12 +187,15 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgArgs p) {
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[s][ps]) : "v"(stage_addr<MB, TMB, TK>(B, p.b_n, p.b_k, n0, p.N, k0, p.K, tid, ps)) : "memory");
             }
         };
-        issue(0, 0);
-        issue(1, TK);
-        for (int kt0 = 0; kt0 < nk; kt0 += 2) {
+        int tq[2];
+        tq[0] = next_needed(0);
+        tq[1] = tq[0] < nk ? next_needed(tq[0] + 1) : nk;
+        issue(0, tq[0] * TK);
+        issue(1, tq[1] * TK);
+        while (tq[0] < nk || tq[1] < nk) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const int kt = kt0 + s;
+                const int kt = tq[s];
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NS) : "memory");
 #pragma unroll
                 for (int ps = 0; ps < NS; ++ps) {
@@ -186,8 +204,10 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgArgs p) {
                     stage_store<MB, TMB, TK>(sB, stage_mask<MB, TMB, TK>(rb[s][ps], kt * TK, p.K, tid, ps), tid, ps);
                 }
                 __syncthreads();
-                issue(s, (kt + 2) * TK);
-                if (kt < nk) mma_tile();         // block-uniform (an odd tile count leaves one all-zero stage)
+                const int last = max(tq[0], tq[1]);
+                tq[s] = last < nk ? next_needed(last + 1) : nk;
+                issue(s, tq[s] * TK);                  // (a tile index of nk: k past K — the loads re-read k = 0 and are masked to zero, nothing is multiplied)
+                if (kt < nk) mma_tile();               // block-uniform
                 __syncthreads();
             }
         }
@@ -265,6 +285,9 @@ bool bg_operand_fast(const void* base, long z1, long z2, long s_row, long s_k, i
 
 }  // namespace
 
+extern "C" int mi_bgemm_band_bf16(const void* A, long a_z1, long a_z2, long a_m, long a_k, const void* B, long b_z1, long b_z2, long b_n, long b_k,
+                                  void* C, long c_z1, long c_z2, long c_m, int out_f32, int accumulate, float alpha,
+                                  int Z1, int Z2, int M, int N, int K, int band_T, int band_a, int band_cg, hipStream_t st);
 extern "C" int mi_bgemm_bf16(const void* A, long a_z1, long a_z2, long a_m, long a_k,
                              const void* B, long b_z1, long b_z2, long b_n, long b_k,
                              void* C, long c_z1, long c_z2, long c_m, int out_f32, int accumulate, float alpha,
@@ -272,7 +295,20 @@ extern "C" int mi_bgemm_bf16(const void* A, long a_z1, long a_z2, long a_m, long
     MI_ENTER();
     if (Z1 <= 0 || Z2 <= 0 || M <= 0 || N <= 0 || K <= 0 || (long)Z1 * Z2 > 65535) return MI_ERR_ARG;
     if ((a_k != 1 && a_m != 1) || (b_k != 1 && b_n != 1)) return MI_ERR_UNSUPPORTED;
-    BgArgs p{(const bf16_t*)A, a_z1, a_z2, a_m, a_k, (const bf16_t*)B, b_z1, b_z2, b_n, b_k, C, c_z1, c_z2, c_m, out_f32, accumulate, alpha, Z2, M, N, K};
+    return mi_bgemm_band_bf16(A, a_z1, a_z2, a_m, a_k, B, b_z1, b_z2, b_n, b_k, C, c_z1, c_z2, c_m, out_f32, accumulate, alpha, Z1, Z2, M, N, K, 0, 0, 0, st);
+}
+
+// mi_bgemm_bf16 for an A operand that is banded along K (BgArgs): K = band_cg * band_T rows, row (u, i) non-zero only in columns [band_a - i, band_a - i + band_T).  The
+// all-zero k tiles are skipped when the operands qualify for the branch-free loads (otherwise the whole K range is walked: same result).  band_T = 0: no band.
+extern "C" int mi_bgemm_band_bf16(const void* A, long a_z1, long a_z2, long a_m, long a_k,
+                                  const void* B, long b_z1, long b_z2, long b_n, long b_k,
+                                  void* C, long c_z1, long c_z2, long c_m, int out_f32, int accumulate, float alpha,
+                                  int Z1, int Z2, int M, int N, int K, int band_T, int band_a, int band_cg, hipStream_t st) {
+    MI_ENTER();
+    if (Z1 <= 0 || Z2 <= 0 || M <= 0 || N <= 0 || K <= 0 || (long)Z1 * Z2 > 65535) return MI_ERR_ARG;
+    if ((a_k != 1 && a_m != 1) || (b_k != 1 && b_n != 1)) return MI_ERR_UNSUPPORTED;
+    if (band_T < 0 || (band_T > 0 && (band_cg <= 0 || (long)band_cg * band_T != K))) return MI_ERR_ARG;
+    BgArgs p{(const bf16_t*)A, a_z1, a_z2, a_m, a_k, (const bf16_t*)B, b_z1, b_z2, b_n, b_k, C, c_z1, c_z2, c_m, out_f32, accumulate, alpha, Z2, M, N, K, band_T, band_a, band_cg};
     const int ma = a_k == 1 ? 0 : 1, mb = b_k == 1 ? 0 : 1;
     const bool fast = bg_operand_fast(A, a_z1, a_z2, a_m, a_k, M, K) && bg_operand_fast(B, b_z1, b_z2, b_n, b_k, N, K);
     const long blocks128 = (long)cdiv(M, 128) * cdiv(N, 128) * Z1 * Z2;

@@ -1101,7 +1101,8 @@ class EncoderCTCTrainer:
         # (the largest group that still leaves the 128 x 128 tile >= 256 blocks: with fewer the batched GEMM falls back to 64-wide tiles and reads dBD twice)
         cg = next((c for c in (4, 2) if B % c == 0 and H * (B // c) * -(-Kp // 128) >= 256), 1)
         dpp = torch.empty((B // cg, Kp * d), device=dev, dtype=F32)
-        T.bgemm(dbd, (B * Tt * Ps, cg * Tt * Ps, 1, Ps), qv, (hd, cg * Tt * d, 1, d), dpp, (hd, Kp * d, d), H, B // cg, Kp, hd, cg * Tt)
+        T.bgemm(dbd, (B * Tt * Ps, cg * Tt * Ps, 1, Ps), qv, (hd, cg * Tt * d, 1, d), dpp, (hd, Kp * d, d), H, B // cg, Kp, hd, cg * Tt,
+                band=(Tt, Tt - 1 + off, cg))               # row i of dBD is non-zero in columns [T - 1 - i + off, 2T - 1 - i + off) only: half of the k tiles are skipped
         # linear_pos: posp = table · Wpos^T  ->  dWpos += dposp^T · table.  dposp = the groups' partials summed in order, straight to the bf16 operand (rows off .. off + Pn)
         dpb = T.colsum_cast(dpp[:, off * d:(off + Pn) * d]).view(Pn, d)
         T.gemm_tn_(G(p + "att_wpos"), dpb, pos[0], defer=self._tnb)

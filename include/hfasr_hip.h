@@ -348,6 +348,11 @@ int mi_gemm_tn_group_bf16(int n, const void* const* dY, const long* ldy, const v
 int mi_bgemm_bf16(const void* A, long a_z1, long a_z2, long a_m, long a_k, const void* B, long b_z1, long b_z2, long b_n, long b_k,
                   void* C, long c_z1, long c_z2, long c_m, int out_f32, int accumulate, float alpha, int Z1, int Z2, int M, int N,
                   int K, mi_stream_t stream);
+/* mi_bgemm_bf16 for an A operand banded along K: K = band_cg * band_T rows, row (u, i) of A non-zero only in columns [band_a - i, band_a - i + band_T) — the
+ * un-shifted relative-position gradient dBD of mi_attention_qkv_bwd_probs in the d(positions) product.  All-zero k tiles are skipped (same result); band_T = 0: no band. */
+int mi_bgemm_band_bf16(const void* A, long a_z1, long a_z2, long a_m, long a_k, const void* B, long b_z1, long b_z2, long b_n, long b_k,
+                       void* C, long c_z1, long c_z2, long c_m, int out_f32, int accumulate, float alpha, int Z1, int Z2, int M, int N, int K,
+                       int band_T, int band_a, int band_cg, mi_stream_t stream);
 /* softmax stage of attention (e_branchformer.py:100-135, tf wav2vec2_conformer:528-565 relative shift), head-major (H,B,Tq,Tk) */
 int mi_attn_softmax_fwd(const float* ac, const float* bd, const int* lengths, void* prob, void* prob_drop, int H, int B, int Tq, int Tk,
                         long ld_s, long ld_p, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, mi_stream_t stream);

@@ -624,6 +624,33 @@ def test_fused_attention_for_separate_operands_against_the_materialised_path(B, 
     assert torch.equal(dq1, dq2) and torch.equal(dk1, dk2) and torch.equal(dv1, dv2)
 
 
+@pytest.mark.parametrize("Tt,cg,hd", [(500, 4, 64), (250, 4, 128), (97, 2, 64), (33, 1, 64)])
+def test_bgemm_band_skips_only_zero_tiles(Tt, cg, hd):
+    """mi_bgemm_band_bf16 (round 4): the d(positions) product dBD^T (q + v) with the K loop limited, per tile of relative positions, to the query rows whose band of dBD
+    can reach it — against the same product over the whole K range: identical bits (the skipped tiles are all zero), on a dBD with the real band geometry."""
+    ops, T = _o()
+    H, G = 2, 3                                                  # heads, utterance groups
+    off, Kp = T.band_geometry(Tt)
+    Ps = (off + 2 * Tt - 1 + 31) // 32 * 32
+    d = H * hd
+    g = torch.Generator().manual_seed(3)
+    ds = (torch.randn(H, G * cg, Tt, Tt, generator=g) * 0.3).to(torch.bfloat16)
+    dbd = torch.zeros(H, G * cg, Tt, Ps, dtype=torch.bfloat16)
+    for i in range(Tt):
+        dbd[:, :, i, Tt - 1 - i + off: 2 * Tt - 1 - i + off] = ds[:, :, i, :]
+    qv = (torch.randn(G * cg * Tt, d, generator=g) * 0.5).to(torch.bfloat16)
+    dbd_d, qv_d = dbd.to(DEV), qv.to(DEV)
+    B = G * cg
+    outs = []
+    for band in (None, (Tt, Tt - 1 + off, cg)):
+        dpp = torch.zeros((G, Kp * d), device=DEV, dtype=torch.float32)
+        T.bgemm(dbd_d, (B * Tt * Ps, cg * Tt * Ps, 1, Ps), qv_d, (hd, cg * Tt * d, 1, d), dpp, (hd, Kp * d, d), H, G, Kp, hd, cg * Tt, band=band)
+        outs.append(dpp)
+    assert torch.equal(outs[0], outs[1])
+    want = torch.einsum("hbip,bihc->bphc", dbd.float().view(H, G, cg * Tt, Ps)[..., :Kp].reshape(H, G, cg * Tt, Kp), qv.float().view(G, cg * Tt, H, hd)).reshape(G, Kp * d)
+    close(outs[1], want, floor=4e-3, what="d(positions) partials")
+
+
 @pytest.mark.parametrize("Tt,U", [(500, 60), (300, 20), (257, 63)])
 def test_ctc_loss_bwd_long_inputs(Tt, U):
     """more than 256 frames with <= 128 states (BASELINE config 3: 20 s clips = 500 encoder frames, 60 labels): the wave form with the emissions in an L2-resident global
