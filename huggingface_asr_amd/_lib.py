@@ -124,6 +124,7 @@ SIGNATURES = {
     "mi_gemm_resid_stats_f32_v": [vp, i64, vp, i64, vp, vp, i64, vp, i64, f32, vp, i64, vp, i32, i32, i32, i32, vp],
     "mi_gemm_tn_group_bf16": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
     "mi_bgemm_bf16": [vp, i64, i64, i64, i64, vp, i64, i64, i64, i64, vp, i64, i64, i64, i32, i32, f32, i32, i32, i32, i32, i32, vp],
+    "mi_bgemm_sparse_bf16": [vp, i64, i64, i64, i64, vp, i64, i64, i64, i64, vp, i64, i64, i64, i32, i32, f32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "mi_bgemm_band_bf16": [vp, i64, i64, i64, i64, vp, i64, i64, i64, i64, vp, i64, i64, i64, i32, i32, f32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "mi_attn_softmax_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, f32, i32, f32, C.c_uint, C.c_uint, vp],
     "mi_attn_softmax_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, f32, f32, C.c_uint, C.c_uint, vp],

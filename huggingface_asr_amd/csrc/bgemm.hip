@@ -26,6 +26,9 @@ struct BgArgs {
     // utterance is non-zero only in columns m in [band_a - i, band_a - i + band_T) — so an M tile [m0, m0 + TMB) meets only the rows i in
     // [band_a - (m0 + TMB - 1), band_a + band_T - 1 - m0] of every utterance: the K loop walks those (rounded out to k tiles) and skips the all-zero rest, about half.
     int band_T, band_a, band_cg;
+    // m_valid (Z2 ints or null): rows m >= m_valid[z2] of A are zero for this batch entry (keys beyond an utterance's length in P^T / dS^T): their M tiles are not
+    // multiplied — the block stores zeros (or leaves C alone when accumulating)
+    const int* m_valid;
 };
 
 // Block tile TMB x TMB x TKB (64 x 64 x 32: one 32 x 32 MFMA tile per wave — round 1; 128 x 128 x 64: 2 x 2 tiles per wave, sixteen MFMAs per barrier pair and eight
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgArgs p) {
     const int m0 = blockIdx.y * TMB, n0 = blockIdx.x * TMB;
     const bf16_t* A = p.A + z1 * p.a_z1 + z2 * p.a_z2;
     const bf16_t* B = p.B + z1 * p.b_z1 + z2 * p.b_z2;
+    const bool dead = p.m_valid != nullptr && m0 >= p.m_valid[z2];        // block-uniform: an all-zero M tile
     f32x16 acc[NP][NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i)
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgArgs p) {
         for (int j = 0; j < NP; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int nk = (p.K + TK - 1) / TK;
+    const int nk = dead ? 0 : (p.K + TK - 1) / TK;
     // Register staging NST k-tiles deep: a block's k-tiles are a chain of dependent HBM round trips (load -> LDS -> MFMA), and with one tile in flight the chain
     // — not bandwidth or the MFMAs — set the time (19-22 us for a 2-GFLOP launch whatever the tile).  The LDS image stays single; the stores into it wait only for
     // the oldest stage's loads (the compiler counts vmcnt over the plain loads).
@@ -190,8 +194,10 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgArgs p) {
         int tq[2];
         tq[0] = next_needed(0);
         tq[1] = tq[0] < nk ? next_needed(tq[0] + 1) : nk;
-        issue(0, tq[0] * TK);
-        issue(1, tq[1] * TK);
+        if (nk > 0) {                                          // (a dead M tile loads nothing)
+            issue(0, tq[0] * TK);
+            issue(1, tq[1] * TK);
+        }
         while (tq[0] < nk || tq[1] < nk) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -214,10 +220,12 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         bf16x8 ra[NS], rb[NS];
+        if (nk > 0) {
 #pragma unroll
-        for (int ps = 0; ps < NS; ++ps) {
-            ra[ps] = stage_load<MA, TMB, TK>(A, p.a_m, p.a_k, m0, p.M, 0, p.K, tid, ps);
-            rb[ps] = stage_load<MB, TMB, TK>(B, p.b_n, p.b_k, n0, p.N, 0, p.K, tid, ps);
+            for (int ps = 0; ps < NS; ++ps) {
+                ra[ps] = stage_load<MA, TMB, TK>(A, p.a_m, p.a_k, m0, p.M, 0, p.K, tid, ps);
+                rb[ps] = stage_load<MB, TMB, TK>(B, p.b_n, p.b_k, n0, p.N, 0, p.K, tid, ps);
+            }
         }
         for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
@@ -288,6 +296,9 @@ bool bg_operand_fast(const void* base, long z1, long z2, long s_row, long s_k, i
 extern "C" int mi_bgemm_band_bf16(const void* A, long a_z1, long a_z2, long a_m, long a_k, const void* B, long b_z1, long b_z2, long b_n, long b_k,
                                   void* C, long c_z1, long c_z2, long c_m, int out_f32, int accumulate, float alpha,
                                   int Z1, int Z2, int M, int N, int K, int band_T, int band_a, int band_cg, hipStream_t st);
+extern "C" int mi_bgemm_sparse_bf16(const void* A, long a_z1, long a_z2, long a_m, long a_k, const void* B, long b_z1, long b_z2, long b_n, long b_k,
+                                    void* C, long c_z1, long c_z2, long c_m, int out_f32, int accumulate, float alpha,
+                                    int Z1, int Z2, int M, int N, int K, int band_T, int band_a, int band_cg, const int* m_valid, hipStream_t st);
 extern "C" int mi_bgemm_bf16(const void* A, long a_z1, long a_z2, long a_m, long a_k,
                              const void* B, long b_z1, long b_z2, long b_n, long b_k,
                              void* C, long c_z1, long c_z2, long c_m, int out_f32, int accumulate, float alpha,
@@ -304,11 +315,18 @@ extern "C" int mi_bgemm_band_bf16(const void* A, long a_z1, long a_z2, long a_m,
                                   const void* B, long b_z1, long b_z2, long b_n, long b_k,
                                   void* C, long c_z1, long c_z2, long c_m, int out_f32, int accumulate, float alpha,
                                   int Z1, int Z2, int M, int N, int K, int band_T, int band_a, int band_cg, hipStream_t st) {
+    return mi_bgemm_sparse_bf16(A, a_z1, a_z2, a_m, a_k, B, b_z1, b_z2, b_n, b_k, C, c_z1, c_z2, c_m, out_f32, accumulate, alpha, Z1, Z2, M, N, K, band_T, band_a, band_cg, nullptr, st);
+}
+// ... and with m_valid (Z2 ints, device, or NULL): rows m >= m_valid[z2] of A are zero for batch entry z2 — their M tiles are stored as zeros without being multiplied
+extern "C" int mi_bgemm_sparse_bf16(const void* A, long a_z1, long a_z2, long a_m, long a_k,
+                                    const void* B, long b_z1, long b_z2, long b_n, long b_k,
+                                    void* C, long c_z1, long c_z2, long c_m, int out_f32, int accumulate, float alpha,
+                                    int Z1, int Z2, int M, int N, int K, int band_T, int band_a, int band_cg, const int* m_valid, hipStream_t st) {
     MI_ENTER();
     if (Z1 <= 0 || Z2 <= 0 || M <= 0 || N <= 0 || K <= 0 || (long)Z1 * Z2 > 65535) return MI_ERR_ARG;
     if ((a_k != 1 && a_m != 1) || (b_k != 1 && b_n != 1)) return MI_ERR_UNSUPPORTED;
     if (band_T < 0 || (band_T > 0 && (band_cg <= 0 || (long)band_cg * band_T != K))) return MI_ERR_ARG;
-    BgArgs p{(const bf16_t*)A, a_z1, a_z2, a_m, a_k, (const bf16_t*)B, b_z1, b_z2, b_n, b_k, C, c_z1, c_z2, c_m, out_f32, accumulate, alpha, Z2, M, N, K, band_T, band_a, band_cg};
+    BgArgs p{(const bf16_t*)A, a_z1, a_z2, a_m, a_k, (const bf16_t*)B, b_z1, b_z2, b_n, b_k, C, c_z1, c_z2, c_m, out_f32, accumulate, alpha, Z2, M, N, K, band_T, band_a, band_cg, m_valid};
     const int ma = a_k == 1 ? 0 : 1, mb = b_k == 1 ? 0 : 1;
     const bool fast = bg_operand_fast(A, a_z1, a_z2, a_m, a_k, M, K) && bg_operand_fast(B, b_z1, b_z2, b_n, b_k, N, K);
     const long blocks128 = (long)cdiv(M, 128) * cdiv(N, 128) * Z1 * Z2;

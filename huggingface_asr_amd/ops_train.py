@@ -263,15 +263,16 @@ def spec_mask_bwd_(dx, time_mask, dembed, feat_mask, T):
     _lib.check(_L().mi_spec_mask_bwd(dx.data_ptr(), dx.stride(0), _p(time_mask), _p(dembed), _p(feat_mask), T, M, N, ws, _stream()), "mi_spec_mask_bwd")
 
 
-def bgemm(A, a_str, B, b_str, C, c_str, Z1, Z2, M, N, K, *, alpha=1.0, accumulate=False, band=None):
+def bgemm(A, a_str, B, b_str, C, c_str, Z1, Z2, M, N, K, *, alpha=1.0, accumulate=False, band=None, m_valid=None):
     """C[z1,z2][m][n] = alpha * sum_k A[..][m][k] B[..][n][k] (+C). a_str = (z1, z2, m, k) element strides, b_str = (z1, z2, n, k),
     c_str = (z1, z2, m); A/B bf16 storage, C f32|bf16 with unit column stride.
     band = (T, a, cg): A is banded along K — K = cg * T rows and row (u, i) is zero outside columns [a - i, a - i + T) (the un-shifted relative-position gradient):
-    the kernel skips the all-zero k tiles (mi_bgemm_band_bf16)."""
+    the kernel skips the all-zero k tiles.  m_valid (Z2) int32: rows m >= m_valid[z2] of A are zero for batch entry z2 (keys beyond an utterance's length in
+    P^T / dS^T): those M tiles are stored as zeros without being read or multiplied (mi_bgemm_sparse_bf16)."""
     bt, ba, bc = band if band is not None else (0, 0, 0)
-    _lib.check(_L().mi_bgemm_band_bf16(A.data_ptr(), *[int(s) for s in a_str], B.data_ptr(), *[int(s) for s in b_str],
-                                       C.data_ptr(), *[int(s) for s in c_str], int(C.dtype == F32), int(accumulate), float(alpha),
-                                       Z1, Z2, M, N, K, int(bt), int(ba), int(bc), _stream()), "mi_bgemm_band_bf16")
+    _lib.check(_L().mi_bgemm_sparse_bf16(A.data_ptr(), *[int(s) for s in a_str], B.data_ptr(), *[int(s) for s in b_str],
+                                         C.data_ptr(), *[int(s) for s in c_str], int(C.dtype == F32), int(accumulate), float(alpha),
+                                         Z1, Z2, M, N, K, int(bt), int(ba), int(bc), _p(m_valid), _stream()), "mi_bgemm_sparse_bf16")
     return C
 
 

@@ -1077,10 +1077,12 @@ class EncoderCTCTrainer:
         Ts = prob.shape[-1]
         sTT = (B * Tt * Ts, Tt * Ts)
         # dV = P^T · dctx
-        T.bgemm(prob, (*sTT, 1, Ts), dctx, (hd, Tt * d, 1, d), dqkv[:, 2 * d:], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt)
+        # (keys beyond an utterance's length have all-zero rows in P^T and dS^T: their tiles are stored as zeros without being read — `m_valid`; at BASELINE config 3,
+        # clips of 1-20 s padded to 20 s, that is half of both products)
+        T.bgemm(prob, (*sTT, 1, Ts), dctx, (hd, Tt * d, 1, d), dqkv[:, 2 * d:], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt, m_valid=lengths)
         # dK = dS^T · (q + u)
         aq, aq_str = (qu, (hd, Tt * d, 1, d)) if rel else (q, (hd, Tt * 3 * d, 1, 3 * d))
-        T.bgemm(ds, (*sTT, 1, Ts), aq, aq_str, dqkv[:, d:2 * d], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt)
+        T.bgemm(ds, (*sTT, 1, Ts), aq, aq_str, dqkv[:, d:2 * d], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt, m_valid=lengths)
         if not rel:
             if not fused:      # dQ = dS · K
                 T.bgemm(ds, (*sTT, Ts, 1), k, (hd, Tt * 3 * d, 1, 3 * d), dqkv[:, :d], (hd, Tt * 3 * d, 3 * d), H, B, Tt, hd, Tt)

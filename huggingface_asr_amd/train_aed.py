@@ -130,8 +130,8 @@ def attention_bwd_fused(q, k, v, ctx, dctx, lse, dq, dk, dv, B, Tq, Tk, H, *, le
     Ts = prob.shape[-1]
     sS = (B * Tq * Ts, Tq * Ts)
     sd_, sq = dctx.stride(0), q.stride(0)
-    T.bgemm(prob, (*sS, 1, Ts), dctx, (hd, Tq * sd_, 1, sd_), dv, (hd, Tk * dv.stride(0), dv.stride(0)), H, B, Tk, hd, Tq)
-    T.bgemm(ds, (*sS, 1, Ts), q, (hd, Tq * sq, 1, sq), dk, (hd, Tk * dk.stride(0), dk.stride(0)), H, B, Tk, hd, Tq)
+    T.bgemm(prob, (*sS, 1, Ts), dctx, (hd, Tq * sd_, 1, sd_), dv, (hd, Tk * dv.stride(0), dv.stride(0)), H, B, Tk, hd, Tq, m_valid=lengths)
+    T.bgemm(ds, (*sS, 1, Ts), q, (hd, Tq * sq, 1, sq), dk, (hd, Tk * dk.stride(0), dk.stride(0)), H, B, Tk, hd, Tq, m_valid=lengths)
 
 
 class JointAEDTrainer:

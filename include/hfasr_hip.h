@@ -353,6 +353,11 @@ int mi_bgemm_bf16(const void* A, long a_z1, long a_z2, long a_m, long a_k, const
 int mi_bgemm_band_bf16(const void* A, long a_z1, long a_z2, long a_m, long a_k, const void* B, long b_z1, long b_z2, long b_n, long b_k,
                        void* C, long c_z1, long c_z2, long c_m, int out_f32, int accumulate, float alpha, int Z1, int Z2, int M, int N, int K,
                        int band_T, int band_a, int band_cg, mi_stream_t stream);
+/* ... and with m_valid (Z2 ints on the device, or NULL): rows m >= m_valid[z2] of A are zero for batch entry z2 (keys beyond an utterance's length in the dV = P^T dctx and
+ * dK = dS^T q products): those M tiles of C are stored as zeros (left alone when accumulating) without being read or multiplied. */
+int mi_bgemm_sparse_bf16(const void* A, long a_z1, long a_z2, long a_m, long a_k, const void* B, long b_z1, long b_z2, long b_n, long b_k,
+                         void* C, long c_z1, long c_z2, long c_m, int out_f32, int accumulate, float alpha, int Z1, int Z2, int M, int N, int K,
+                         int band_T, int band_a, int band_cg, const int* m_valid, mi_stream_t stream);
 /* softmax stage of attention (e_branchformer.py:100-135, tf wav2vec2_conformer:528-565 relative shift), head-major (H,B,Tq,Tk) */
 int mi_attn_softmax_fwd(const float* ac, const float* bd, const int* lengths, void* prob, void* prob_drop, int H, int B, int Tq, int Tk,
                         long ld_s, long ld_p, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, mi_stream_t stream);

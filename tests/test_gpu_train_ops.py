@@ -624,6 +624,32 @@ def test_fused_attention_for_separate_operands_against_the_materialised_path(B, 
     assert torch.equal(dq1, dq2) and torch.equal(dk1, dk2) and torch.equal(dv1, dv2)
 
 
+def test_bgemm_dead_row_tiles_are_stored_as_zeros():
+    """mi_bgemm_sparse_bf16's m_valid: the tiles of rows at or beyond an entry's count are written as zeros without reading A (filled with NaN there: a multiplied tile
+    would show it) — the dV / dK products at ragged key lengths; everything else equals the plain call bit for bit."""
+    ops, T = _o()
+    H, B, Tk, Tq, hd = 2, 3, 300, 70, 64
+    d = H * hd
+    Ts = (Tk + 31) // 32 * 32
+    g = torch.Generator().manual_seed(9)
+    lens = torch.tensor([300, 129, 64], dtype=torch.int32)
+    prob = (torch.rand(H, B, Tq, Ts, generator=g)).to(torch.bfloat16)
+    for b in range(B):
+        prob[:, b, :, int(lens[b]):] = 0
+    dctx = (torch.randn(B * Tq, d, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    sS = (B * Tq * Ts, Tq * Ts)
+    pz = prob.to(DEV)
+    want = torch.empty((B * Tk, d), device=DEV, dtype=torch.bfloat16)
+    T.bgemm(pz, (*sS, 1, Ts), dctx, (hd, Tq * d, 1, d), want, (hd, Tk * d, d), H, B, Tk, hd, Tq)
+    pn = prob.clone()
+    for b in range(B):
+        dead0 = (int(lens[b]) + 63) // 64 * 64                # first row of the first dead 64-row tile
+        pn[:, b, :, dead0:] = float("nan")
+    got = torch.full((B * Tk, d), 7.0, device=DEV, dtype=torch.bfloat16)
+    T.bgemm(pn.to(DEV), (*sS, 1, Ts), dctx, (hd, Tq * d, 1, d), got, (hd, Tk * d, d), H, B, Tk, hd, Tq, m_valid=lens.to(DEV))
+    assert torch.equal(got, want) and not bool(torch.isnan(got.float()).any())
+
+
 @pytest.mark.parametrize("Tt,cg,hd", [(500, 4, 64), (250, 4, 128), (97, 2, 64), (33, 1, 64)])
 def test_bgemm_band_skips_only_zero_tiles(Tt, cg, hd):
     """mi_bgemm_band_bf16 (round 4): the d(positions) product dBD^T (q + v) with the K loop limited, per tile of relative positions, to the query rows whose band of dBD
