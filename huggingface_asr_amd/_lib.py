@@ -90,6 +90,7 @@ SIGNATURES = {
     "mi_layernorm_bwd_workspace_floats": [i32],
     "mi_layernorm_bwd": [vp, i64, i32, vp, f32, vp, i64, i32, vp, i64, i32, i32, vp, vp, vp, i32, i32, vp],
     "mi_layernorm_bwd_partial": [vp, i64, i32, vp, f32, vp, i64, i32, vp, i64, i32, i32, vp, vp, i32, i32, vp],
+    "mi_layernorm_bwd_dual_partial": [vp, i64, i32, f32, vp, vp, i64, i32, vp, vp, i64, i32, vp, i64, i32, i32, vp, vp, vp, vp, i64, f32, f32, C.c_uint, C.c_uint, i32, i32, vp],
     "mi_layernorm_bwd_partial_cast": [vp, i64, i32, vp, f32, vp, i64, i32, vp, i64, i32, i32, vp, vp, vp, i64, f32, f32, C.c_uint, C.c_uint, i32, i32, vp],
     "mi_ln_partial_reduce_many": [vp, i32, vp],
     "mi_ln_apply_bf16": [vp, i64, vp, vp, vp, vp, i64, i32, i32, vp],

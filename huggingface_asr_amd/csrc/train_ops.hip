@@ -189,35 +189,48 @@ __global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ a, 
 struct LnCast { bf16_t* out; long ld; float alpha, p; unsigned long long key; };
 // one wave per row, 4 consecutive columns per lane and step (16-B / 8-B accesses): c = 4 (lane + 64 j);
 //   dx (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;   dgamma += dy * xhat, dbeta += dy (block-reduced, then atomics)
-template <int NV>
+// DUAL: a second LayerNorm of the SAME rows (the layer's two branch norms both read x1, e_branchformer.py:273,292) in the same pass: dx is linear in g = dy * gamma, so the
+// pass runs once on g = dy * gamma + dy2 * gamma2 (x, the statistics and the old dx are read once instead of twice); only the affine gradients keep two accumulator sets.
+struct LnDual { const float* gamma2; const void* dy2; long lddy2; int dy2_f32; float* partial2; };
+template <int NV, bool DUAL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x, long ldx, int x_bf16, const float* __restrict__ gamma,
                                                       float eps, const void* __restrict__ dy, long lddy, int dy_f32,
                                                       void* __restrict__ dx, long lddx, int dx_bf16, int accumulate,
                                                       float* __restrict__ partial, int M, int d,
-                                                      int rows_per_wave, LnCast cst) {
+                                                      int rows_per_wave, LnCast cst, LnDual du) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const dgamma = partial;                       // non-null: this block's (2d) partial row goes to partial[blockIdx.x]
     float* sg = reinterpret_cast<float*>(smem);          // [4 waves][2d]: every wave's (dgamma | dbeta) partial, summed in wave order below (no atomics: deterministic,
                                                          // and a float atomic add on LDS is a compare-and-swap loop in this build)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int d4 = d >> 2;
-    f32x4 gm[NV], ag[NV], ab[NV];
+    constexpr int NV2 = DUAL ? NV : 1;
+    f32x4 gm[NV], ag[NV], ab[NV], gm2[NV2], ag2[NV2], ab2[NV2];
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int c = lane + 64 * j;
         gm[j] = (c < d4) ? reinterpret_cast<const f32x4*>(gamma)[c] : z4;
         ag[j] = z4; ab[j] = z4;
+        if constexpr (DUAL) { gm2[j] = (c < d4) ? reinterpret_cast<const f32x4*>(du.gamma2)[c] : z4; ag2[j] = z4; ab2[j] = z4; }
     }
     const float inv_d = 1.f / d;
     const long wave_id = (long)blockIdx.x * 4 + wave, nwaves = (long)gridDim.x * 4;
     // A wave walks its rows (wave_id, wave_id + nwaves, ...) two at a time: the reads of both rows — x, dy and, when accumulating, the old dx —
     // are issued before either row is reduced, so the second row's memory round trip hides behind the first row's arithmetic.
-    auto load_row = [&](long r, f32x4 (&xv)[NV], f32x4 (&gv)[NV], f32x4 (&ov)[NV]) {
+    auto load_row = [&](long r, f32x4 (&xv)[NV], f32x4 (&gv)[NV], f32x4 (&ov)[NV], f32x4 (&hv)[NV2]) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int c = lane + 64 * j;
             f32x4 v = z4, g = z4, o = z4;
+            if constexpr (DUAL) {
+                f32x4 h = z4;
+                if (c < d4) {
+                    if (du.dy2_f32) h = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(du.dy2) + r * du.lddy2)[c];
+                    else { const bf16x4 t = reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(du.dy2) + r * du.lddy2)[c]; h = f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])}; }
+                }
+                hv[j] = h;
+            }
             if (c < d4) {
                 if (x_bf16) { const bf16x4 t = reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(x) + r * ldx)[c]; v = f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])}; }
                 else v = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + r * ldx)[c];
@@ -231,7 +244,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
             xv[j] = v; gv[j] = g; ov[j] = o;
         }
     };
-    auto do_row = [&](long r, f32x4 (&xv)[NV], f32x4 (&gv)[NV], f32x4 (&ov)[NV]) {
+    auto do_row = [&](long r, f32x4 (&xv)[NV], f32x4 (&gv)[NV], f32x4 (&ov)[NV], f32x4 (&hv)[NV2]) {
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) s += xv[j].x + xv[j].y + xv[j].z + xv[j].w;
@@ -251,6 +264,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
             ag[j] += gv[j] * xv[j];
             ab[j] += gv[j];
             gv[j] *= gm[j];                       // g = dy * gamma
+            if constexpr (DUAL) { ag2[j] += hv[j] * xv[j]; ab2[j] += hv[j]; gv[j] += hv[j] * gm2[j]; }
             const f32x4 t = gv[j] * xv[j];
             s1 += gv[j].x + gv[j].y + gv[j].z + gv[j].w; s2 += t.x + t.y + t.z + t.w;
         }
@@ -277,11 +291,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
         const long r0 = wave_id + (long)i * nwaves, r1 = r0 + nwaves;          // interleaved rows: neighbouring waves touch neighbouring rows
         if (r0 >= M) break;
         const bool two = (i + 1 < rows_per_wave) && r1 < M;
-        f32x4 xa[NV], ga[NV], oa[NV], xb[NV], gb[NV], ob[NV];
-        load_row(r0, xa, ga, oa);
-        if (two) load_row(r1, xb, gb, ob);
-        do_row(r0, xa, ga, oa);
-        if (two) do_row(r1, xb, gb, ob);
+        f32x4 xa[NV], ga[NV], oa[NV], xb[NV], gb[NV], ob[NV], ha[NV2], hb[NV2];
+        load_row(r0, xa, ga, oa, ha);
+        if (two) load_row(r1, xb, gb, ob, hb);
+        do_row(r0, xa, ga, oa, ha);
+        if (two) do_row(r1, xb, gb, ob, hb);
     }
     if (dgamma) {
         float* mine = sg + (size_t)wave * 2 * d;
@@ -296,6 +310,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
         __syncthreads();
         float* prow = partial + (long)blockIdx.x * 2 * d;
         for (int c = threadIdx.x; c < 2 * d; c += 256) prow[c] = (sg[c] + sg[2 * d + c]) + (sg[4 * d + c] + sg[6 * d + c]);
+        if constexpr (DUAL) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int c = lane + 64 * j;
+                if (c < d4) {
+                    reinterpret_cast<f32x4*>(mine)[c] = ag2[j];
+                    reinterpret_cast<f32x4*>(mine + d)[c] = ab2[j];
+                }
+            }
+            __syncthreads();
+            float* prow2 = du.partial2 + (long)blockIdx.x * 2 * d;
+            for (int c = threadIdx.x; c < 2 * d; c += 256) prow2[c] = (sg[c] + sg[2 * d + c]) + (sg[4 * d + c] + sg[6 * d + c]);
+        }
     }
 }
 
@@ -697,7 +725,9 @@ extern "C" int mi_act_bwd_bf16(const void* dy, long lddy, const void* pre, long 
 // workspace: >= mi_layernorm_bwd_workspace_floats(d) floats when dgamma != NULL (per-block partial sums; no float atomics)
 extern "C" size_t mi_layernorm_bwd_workspace_floats(int d) { return (size_t)512 * 2 * d; }
 static int ln_bwd_launch(const void* x, long ldx, int x_bf16, const float* gamma, float eps, const void* dy, long lddy, int dy_f32,
-                         void* dx, long lddx, int dx_bf16, int accumulate, float* partial, int* nblk, int M, int d, hipStream_t st, LnCast cst = LnCast{nullptr, 0, 1.f, 0.f, 0ull}) {
+                         void* dx, long lddx, int dx_bf16, int accumulate, float* partial, int* nblk, int M, int d, hipStream_t st, LnCast cst = LnCast{nullptr, 0, 1.f, 0.f, 0ull},
+                         LnDual du = LnDual{nullptr, nullptr, 0, 0, nullptr}) {
+    if (du.dy2 && (!du.gamma2 || !du.partial2 || !partial || d > 512 || (du.lddy2 % 4) || (reinterpret_cast<uintptr_t>(du.dy2) & (du.dy2_f32 ? 15 : 7)))) return MI_ERR_ARG;
     if (cst.out && ((cst.ld % 4) || (reinterpret_cast<uintptr_t>(cst.out) & 7) || cst.p < 0.f || cst.p >= 1.f || (d % 2))) return MI_ERR_ARG;
     if (M <= 0 || d <= 0 || d > 2048 || (d % 4) || (ldx % 4) || (lddy % 4) || (lddx % 4) || !gamma) return MI_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(x) & (x_bf16 ? 7 : 15)) || (reinterpret_cast<uintptr_t>(dy) & (dy_f32 ? 15 : 7)) ||
@@ -707,8 +737,9 @@ static int ln_bwd_launch(const void* x, long ldx, int x_bf16, const float* gamma
     const int rpw = cdiv(M, (long)grid * 4);
     const size_t lds = (size_t)4 * 2 * d * sizeof(float);
     const int nv = cdiv(d, 256);
-#define LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(grid), dim3(256), lds, st, x, ldx, x_bf16, gamma, eps, dy, lddy, dy_f32, dx, lddx, dx_bf16, accumulate, partial, M, d, rpw, cst)
-    if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4); else LN_BWD(8);
+#define LN_BWD(NV, DU) hipLaunchKernelGGL((ln_bwd_kernel<NV, DU>), dim3(grid), dim3(256), lds, st, x, ldx, x_bf16, gamma, eps, dy, lddy, dy_f32, dx, lddx, dx_bf16, accumulate, partial, M, d, rpw, cst, du)
+    if (du.dy2) { if (nv <= 1) LN_BWD(1, true); else LN_BWD(2, true); }
+    else if (nv <= 1) LN_BWD(1, false); else if (nv <= 2) LN_BWD(2, false); else if (nv <= 3) LN_BWD(3, false); else if (nv <= 4) LN_BWD(4, false); else LN_BWD(8, false);
 #undef LN_BWD
     if (nblk) *nblk = grid;
     return MI_OK;
@@ -753,6 +784,22 @@ extern "C" int mi_layernorm_bwd_partial_cast(const void* x, long ldx, int x_bf16
     if (!partial || !nblk || !cast) return MI_ERR_ARG;
     const int rc = ln_bwd_launch(x, ldx, x_bf16, gamma, eps, dy, lddy, dy_f32, dx, lddx, dx_bf16, accumulate, partial, nblk, M, d, st,
                                  LnCast{(bf16_t*)cast, ldcast, alpha, drop_p, ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed});
+    if (rc != MI_OK) return rc;
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// Two LayerNorms of the same rows x (same eps) in one pass: dx (+)= dLN1/dx · dy + dLN2/dx · dy2; their (dgamma | dbeta) partial rows go to `partial` and `partial2`
+// (*nblk rows each).  d <= 512.  cast (may be NULL): the bf16 alpha * dropout(dx) operand of mi_layernorm_bwd_partial_cast.
+extern "C" int mi_layernorm_bwd_dual_partial(const void* x, long ldx, int x_bf16, float eps, const float* gamma, const void* dy, long lddy, int dy_f32,
+                                             const float* gamma2, const void* dy2, long lddy2, int dy2_f32, void* dx, long lddx, int dx_bf16, int accumulate,
+                                             float* partial, float* partial2, int* nblk, void* cast, long ldcast, float alpha, float drop_p, unsigned seed,
+                                             unsigned stream_id, int M, int d, hipStream_t st) {
+    MI_ENTER();
+    if (!partial || !partial2 || !nblk || !dy2 || !gamma2) return MI_ERR_ARG;
+    const int rc = ln_bwd_launch(x, ldx, x_bf16, gamma, eps, dy, lddy, dy_f32, dx, lddx, dx_bf16, accumulate, partial, nblk, M, d, st,
+                                 LnCast{(bf16_t*)cast, ldcast, alpha, drop_p, ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed},
+                                 LnDual{gamma2, dy2, lddy2, dy2_f32, partial2});
     if (rc != MI_OK) return rc;
     MI_CHECK_LAUNCH();
     return MI_OK;

@@ -272,12 +272,12 @@ def row_stats(x, eps=1e-5):
     return st
 
 
-def csgu(u, gamma, beta, w, bias, B, T, *, pad_left=None, dilation=1, act=0, eps=1e-5):
-    """u (B*T, 2C) bf16 = [x_r | x_g] -> x_r * act(dwconv(LN(x_g)) + b)  (B*T, C) bf16."""
+def csgu(u, gamma, beta, w, bias, B, T, *, pad_left=None, dilation=1, act=0, eps=1e-5, stats=None):
+    """u (B*T, 2C) bf16 = [x_r | x_g] -> x_r * act(dwconv(LN(x_g)) + b)  (B*T, C) bf16.  stats: row_stats(u[:, C:], eps) when the caller already holds it."""
     M, C2 = u.shape
     Cc = C2 // 2
     K = w.shape[-1]
-    st = row_stats(u[:, Cc:], eps)
+    st = row_stats(u[:, Cc:], eps) if stats is None else stats
     out = torch.empty((M, Cc), device=u.device, dtype=BF16)
     rc = _lib.lib().mi_csgu_bf16(u.data_ptr(), u.stride(0), st.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(),
                                  _p(bias), out.data_ptr(), out.stride(0), B, T, Cc, K,

@@ -203,6 +203,30 @@ def layernorm_bwd(x, gamma, dy, dx, *, accumulate, dgamma=None, dbeta=None, eps=
     return dx
 
 
+def layernorm_bwd_dual(x, gamma, dy, gamma2, dy2, dx, *, accumulate, dgamma, dbeta, dgamma2, dbeta2, defer, eps=1e-5, cast=None):
+    """two LayerNorms of the same rows x (same eps) in ONE pass: dx (+)= dLN(x; gamma)/dx · dy + dLN(x; gamma2)/dx · dy2, both affine gradients deferred to `defer`
+    (an LnReduceBatch).  d <= 512.  cast as in layernorm_bwd; -> dx | (dx, cast tensor)."""
+    import ctypes as C
+    M, d = x.shape
+    out = None
+    alpha, pdrop, seed, sid = 1.0, 0.0, 0, 0
+    if cast is not None:
+        alpha, drop = cast
+        pdrop, seed, sid = drop if drop is not None else (0.0, 0, 0)
+        out = torch.empty((M, d), device=x.device, dtype=BF16)
+    if len(defer.items) + 2 > defer.SLOTS:          # both partial sets must stay pending together
+        defer.flush()
+    p1, p2 = defer.slot(), defer.slot()
+    nblk = C.c_int(0)
+    _lib.check(_L().mi_layernorm_bwd_dual_partial(x.data_ptr(), x.stride(0), int(x.dtype == BF16), float(eps), gamma.data_ptr(), dy.data_ptr(), dy.stride(0), int(dy.dtype == F32),
+                                                  gamma2.data_ptr(), dy2.data_ptr(), dy2.stride(0), int(dy2.dtype == F32), dx.data_ptr(), dx.stride(0), int(dx.dtype == BF16),
+                                                  int(accumulate), p1.data_ptr(), p2.data_ptr(), C.byref(nblk), _p(out), out.stride(0) if out is not None else 0, float(alpha),
+                                                  float(pdrop), int(seed) & 0xFFFFFFFF, int(sid) & 0xFFFFFFFF, M, d, _stream()), "mi_layernorm_bwd_dual_partial")
+    defer.add(p1, nblk.value, d, dgamma, dbeta)
+    defer.add(p2, nblk.value, d, dgamma2, dbeta2)
+    return dx if cast is None else (dx, out)
+
+
 def axpy_(a, b, alpha=1.0):
     """a += alpha * b (contiguous f32)."""
     assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()

@@ -494,12 +494,12 @@ class EncoderCTCTrainer:
         """the gradients of [lo, hi) are final once the deferred LayerNorm reductions and weight-gradient GEMMs have run: flush them, then hand the range to the
         data-parallel all-reduce.  The weight-gradient batch may decline a non-final flush (too few output tiles to fill the chip: ops_train.TnBatch) — the range
         then waits, with any earlier ones, for the flush that does run; the backward's last range is `final`."""
-        if getattr(self, "_lnred", None) is not None:
-            self._lnred.flush()
         pending = self._ranges_waiting
         pending.append((lo, hi))
         tnb = getattr(self, "_tnb", None)
         if tnb is None or tnb.flush(final=final):
+            if getattr(self, "_lnred", None) is not None:       # the LayerNorm reductions ride the same cadence (a full batch flushes itself): fewer, fuller launches
+                self._lnred.flush()
             for r in pending:
                 self.sync.launch(*r)
             pending.clear()
@@ -699,7 +699,7 @@ class EncoderCTCTrainer:
                     lin = ops.gemm(cv, W(p + "csgu_lin_w"), P(p + "csgu_lin_b"))
                 sg = ops.gate_act_mul(h[:, :I // 2], lin, self.csgu_act)
             else:
-                sg = ops.csgu(h, P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), B, T2, pad_left=cs_pad, dilation=cs_dil)
+                sg = ops.csgu(h, P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), B, T2, pad_left=cs_pad, dilation=cs_dil, stats=stats)
             if pd["csgu"] > 0:
                 T.dropout_(sg, pd["csgu"], seed, self._sid(sl, 4))
             ops.gemm(sg, W(p + "mlp_w2"), P(p + "mlp_b2"), out=cat[:, d:])
@@ -803,9 +803,13 @@ class EncoderCTCTrainer:
                 T.csgu_bwd(S["h"], S["stats"], P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), dsg, dh[:, :I // 2], dgn,
                            G(p + "csgu_w"), G(p + "csgu_b"), B, T2, pad_left=cs_pad, dilation=cs_dil)
             T.layernorm_bwd(S["h"][:, I // 2:], P(p + "csgu_ln_g"), dgn, dh[:, I // 2:], accumulate=False, **self._lng(p + "csgu_ln_g", p + "csgu_ln_b"))
-            dhp = T.act_bwd(dh, S["hp"])
+            dhp = T.act_bwd(dh, S["hp"])       # (folding this pass into the two kernels above was built and measured: each slows by what its share of this one costs — DESIGN §7)
             da2 = T.linear_bwd(dhp, S["a2"], WT(p + "mlp_w1"), dw=GL(p + "mlp_w1"), db=GL(p + "mlp_b1"), defer=self._tnb)
-            T.layernorm_bwd(S["x1"], P(p + "mlp_ln_g"), da2, dx, accumulate=True, **self._lng(p + "mlp_ln_g", p + "mlp_ln_b"))
+            # the two branch norms read the same x1: one pass for both when their affine pairs train (the gradient w.r.t. x1 is linear in dy * gamma)
+            lng_m, lng_a = self._lng(p + "mlp_ln_g", p + "mlp_ln_b"), self._lng(p + "att_ln_g", p + "att_ln_b")
+            dual = ptype != "rotary" and d <= 512 and lng_m["dgamma"] is not None and lng_a["dgamma"] is not None
+            if not dual:
+                T.layernorm_bwd(S["x1"], P(p + "mlp_ln_g"), da2, dx, accumulate=True, **lng_m)
             # global branch
             if pd["att"] > 0:
                 T.dropout_(dcat[:, :d], pd["att"], seed, self._sid(sl, 3))
@@ -821,6 +825,12 @@ class EncoderCTCTrainer:
             else:
                 da1 = T.linear_bwd(dqkv, S["a1"], WT(p + "att_wqkv")[:, :3 * d], dw=GL(p + "att_wqkv"), db=GL(p + "att_bqkv"), defer=self._tnb)
                 last = dict(x=S["x1"], g=P(p + "att_ln_g"), dy=da1)
+                if dual:
+                    r = T.layernorm_bwd_dual(S["x1"], P(p + "att_ln_g"), da1, P(p + "mlp_ln_g"), da2, dx, accumulate=True, dgamma=lng_a["dgamma"], dbeta=lng_a["dbeta"],
+                                             dgamma2=lng_m["dgamma"], dbeta2=lng_m["dbeta"], defer=lng_a["defer"], cast=(0.5, hdrop(1)) if macaron else None)
+                    if macaron:
+                        self._ffn_bwd(dx, S["x_in"], S["ff1"], p + "ff1", pd, sl, (0, 1), dyb=r[1])
+                    return dx
             if macaron:             # the layer's last accumulation into dx also leaves the first FFN's bf16 operand
                 _, dyb = T.layernorm_bwd(last["x"], last["g"], last["dy"], dx, accumulate=True, **self._lng(p + "att_ln_g", p + "att_ln_b"), cast=(0.5, hdrop(1)))
                 self._ffn_bwd(dx, S["x_in"], S["ff1"], p + "ff1", pd, sl, (0, 1), dyb=dyb)

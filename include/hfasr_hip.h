@@ -293,6 +293,13 @@ int mi_layernorm_bwd_partial(const void* x, long ldx, int x_bf16, const float* g
 int mi_layernorm_bwd_partial_cast(const void* x, long ldx, int x_bf16, const float* gamma, float eps, const void* dy, long lddy, int dy_f32,
                                   void* dx, long lddx, int dx_bf16, int accumulate, float* partial, int* nblk, void* cast, long ldcast, float alpha,
                                   float drop_p, unsigned seed, unsigned stream_id, int M, int d, mi_stream_t stream);
+/* two LayerNorms of the SAME rows x with the same eps (the layer's two branch norms on x1, reference e_branchformer.py:273,292) in one pass:
+ * dx (+)= dLN1/dx . dy + dLN2/dx . dy2 (linear in dy * gamma: x, its statistics and the old dx are read once); the two (dgamma | dbeta) partial sets go to
+ * `partial` / `partial2` (*nblk rows each) for mi_ln_partial_reduce_many.  d <= 512.  cast may be NULL; otherwise as in mi_layernorm_bwd_partial_cast. */
+int mi_layernorm_bwd_dual_partial(const void* x, long ldx, int x_bf16, float eps, const float* gamma, const void* dy, long lddy, int dy_f32,
+                                  const float* gamma2, const void* dy2, long lddy2, int dy2_f32, void* dx, long lddx, int dx_bf16, int accumulate,
+                                  float* partial, float* partial2, int* nblk, void* cast, long ldcast, float alpha, float drop_p, unsigned seed,
+                                  unsigned stream_id, int M, int d, mi_stream_t stream);
 int mi_ln_partial_reduce_many(const mi_lnred_desc* descs, int n, mi_stream_t stream);
 int mi_ln_apply_bf16(const void* x, long ldx, const float* stats, const float* gamma, const float* beta, void* y, long ldy,
                      int M, int N, mi_stream_t stream);

@@ -497,6 +497,50 @@ def test_layernorm_bwd_writes_the_next_operand_itself(d, pdrop):
     assert torch.equal(dx3, dx2) and torch.equal(cast3, want)
 
 
+@pytest.mark.parametrize("d,pdrop,dy2f32", [(256, 0.0, False), (512, 0.1, False), (320, 0.0, True), (64, 0.1, True)])
+def test_layernorm_bwd_of_two_norms_on_the_same_rows_in_one_pass(d, pdrop, dy2f32):
+    """layernorm_bwd_dual (the layer's two branch norms read the same x1, e_branchformer.py:273,292): dx against torch autograd of both norms in fp64 and against the
+    two single passes; each affine gradient equal to its single pass's bit for bit (same rows per block, same order); the cast operand from the finished dx."""
+    ops, T = _o()
+    M = 1003
+    x = rnd(M, d, seed=1)
+    dy1, dy2 = rnd(M, d, seed=2).to(BF), rnd(M, d, seed=3)
+    dy2 = dy2 if dy2f32 else dy2.to(BF).float()
+    g1, g2 = 1 + 0.1 * rnd(d, seed=4), 1 + 0.1 * rnd(d, seed=5)
+    base = rnd(M, d, seed=6)
+    xr = x.double().requires_grad_(True)
+    ga, gb = g1.double().requires_grad_(True), g2.double().requires_grad_(True)
+    za, zb = torch.zeros(d, dtype=torch.float64, requires_grad=True), torch.zeros(d, dtype=torch.float64, requires_grad=True)
+    y = (torch.nn.functional.layer_norm(xr, (d,), ga, za) * dy1.double()).sum() + (torch.nn.functional.layer_norm(xr, (d,), gb, zb) * dy2.double()).sum()
+    y.backward()
+    drop = (pdrop, 17, 4242) if pdrop > 0 else None
+    red = T.LnReduceBatch(DEV)
+    G = lambda: torch.zeros(d, device=DEV)
+    dga, dba, dgb, dbb = G(), G(), G(), G()
+    dx = base.to(DEV)
+    xd, d1, d2 = x.to(DEV), dy1.to(DEV), (dy2.to(DEV) if dy2f32 else dy2.to(DEV, BF))
+    _, cast = T.layernorm_bwd_dual(xd, g1.to(DEV), d1, g2.to(DEV), d2, dx, accumulate=True, dgamma=dga, dbeta=dba, dgamma2=dgb, dbeta2=dbb, defer=red, cast=(0.5, drop))
+    red.flush()
+    torch.testing.assert_close(dx.cpu().double(), base.double() + xr.grad, rtol=1e-4, atol=2e-5)
+    # the two single passes
+    dx2 = base.to(DEV)
+    sga, sba, sgb, sbb = G(), G(), G(), G()
+    T.layernorm_bwd(xd, g1.to(DEV), d1, dx2, accumulate=True, dgamma=sga, dbeta=sba, defer=red)
+    T.layernorm_bwd(xd, g2.to(DEV), d2, dx2, accumulate=True, dgamma=sgb, dbeta=sbb, defer=red)
+    red.flush()
+    torch.testing.assert_close(dx, dx2, rtol=1e-5, atol=2e-6)
+    assert torch.equal(dga, sga) and torch.equal(dba, sba) and torch.equal(dgb, sgb) and torch.equal(dbb, sbb)
+    torch.testing.assert_close(dga.cpu().double(), ga.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dbb.cpu().double(), zb.grad, rtol=1e-4, atol=1e-4)
+    want = T.dropout_(dx.clone(), pdrop, drop[1], drop[2], out=torch.empty((M, d), device=DEV, dtype=BF), alpha=0.5) if drop else T.add_cast(dx, alpha=0.5)
+    assert torch.equal(cast, want)
+    # without the cast operand, and overwriting
+    dx3 = torch.full((M, d), 7.0, device=DEV)
+    T.layernorm_bwd_dual(xd, g1.to(DEV), d1, g2.to(DEV), d2, dx3, accumulate=False, dgamma=G(), dbeta=G(), dgamma2=G(), dbeta2=G(), defer=red)
+    red.flush()
+    torch.testing.assert_close(dx3.cpu().double(), xr.grad, rtol=1e-4, atol=2e-5)
+
+
 def test_scale_by_device_scalar():
     """the autograd bridge's d(loss) factor: a device scalar, no host sync; exactly 1 leaves the buffer untouched, anything else scales it (odd length: the scalar tail)"""
     ops, T = _o()
