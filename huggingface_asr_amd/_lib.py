@@ -24,7 +24,7 @@ class EbfConfig(C.Structure):
 
 class LnRedDesc(C.Structure):
     """mirror of mi_lnred_desc (include/hfasr_hip.h)"""
-    _fields_ = [("partial", vp), ("nblk", i32), ("d", i32), ("dgamma", vp), ("dbeta", vp)]
+    _fields_ = [("partial", vp), ("nblk", i32), ("d", i32), ("dgamma", vp), ("dbeta", vp), ("kind", i32)]
 
 
 class Gpt2Config(C.Structure):
@@ -103,6 +103,7 @@ SIGNATURES = {
     "mi_colsum_cast_bf16": [vp, i64, i32, i32, vp, vp],
     "mi_add_rowvec2_bf16": [vp, i64, vp, vp, vp, vp, i64, i32, i32, vp],
     "mi_gate_bwd_bf16": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, vp],
+    "mi_subsampled_lengths_i32": [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     "mi_mask_rows_f32": [vp, i64, vp, i32, i32, i32, vp],
     "mi_spec_mask_apply": [vp, i64, vp, vp, vp, i32, i32, i32, vp],
     "mi_spec_mask_bwd": [vp, i64, vp, vp, vp, i32, i32, i32, vp, vp],

@@ -774,7 +774,7 @@ int dw_bwd_launch(const DwBwdArgs& a, bool csgu, float* workspace, hipStream_t s
         if (csgu) hipLaunchKernelGGL(dwconv_bwd_dilated_kernel<true>, gridd, dim3(256), ldsd, st, a, workspace);
         else hipLaunchKernelGGL(dwconv_bwd_dilated_kernel<false>, gridd, dim3(256), ldsd, st, a, workspace);
         MI_CHECK_LAUNCH();
-        dw_partial_reduce_launch(workspace, a.B * (int)gridd.y, a.C, a.K, a.dw, a.db, st);
+        if (a.dw) dw_partial_reduce_launch(workspace, a.B * (int)gridd.y, a.C, a.K, a.dw, a.db, st);
         MI_CHECK_LAUNCH();
         return MI_OK;
     }
@@ -787,7 +787,7 @@ int dw_bwd_launch(const DwBwdArgs& a, bool csgu, float* workspace, hipStream_t s
         if (csgu) hipLaunchKernelGGL(dwconv31_bwd_kernel<true>, gridf, dim3(256), ldsf, st, a, workspace);
         else hipLaunchKernelGGL(dwconv31_bwd_kernel<false>, gridf, dim3(256), ldsf, st, a, workspace);
         MI_CHECK_LAUNCH();
-        dw_partial_reduce_launch(workspace, a.B, a.C, a.K, a.dw, a.db, st);
+        if (a.dw) dw_partial_reduce_launch(workspace, a.B, a.C, a.K, a.dw, a.db, st);
         MI_CHECK_LAUNCH();
         return MI_OK;
     }
@@ -797,7 +797,7 @@ int dw_bwd_launch(const DwBwdArgs& a, bool csgu, float* workspace, hipStream_t s
     if (csgu) hipLaunchKernelGGL(dwconv_bwd_kernel<true>, grid, dim3(256), lds, st, a, workspace);
     else hipLaunchKernelGGL(dwconv_bwd_kernel<false>, grid, dim3(256), lds, st, a, workspace);
     MI_CHECK_LAUNCH();
-    dw_partial_reduce_launch(workspace, a.B, a.C, a.K, a.dw, a.db, st);
+    if (a.dw) dw_partial_reduce_launch(workspace, a.B, a.C, a.K, a.dw, a.db, st);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

@@ -335,11 +335,12 @@ __global__ __launch_bounds__(256) void ln_partial_reduce_many_kernel(LnRedMany p
     const mi_lnred_desc q = p.d[blockIdx.y];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;           // 16 columns x 16 row groups
     const int c = blockIdx.x * 16 + tx;
-    if ((int)blockIdx.x * 16 >= 2 * q.d) return;
+    const int ncol = q.kind ? q.d * 32 : 2 * q.d;                      // kind = K > 0: a depthwise conv's (channel, 32) tap-gradient partials (include/hfasr_hip.h)
+    if ((int)blockIdx.x * 16 >= ncol) return;
     float s = 0.f;
-    if (c < 2 * q.d) {
+    if (c < ncol) {
         const float* src = q.partial + c;
-        const long ld = 2 * q.d;
+        const long ld = ncol;
         int b = ty;
         for (; b + 7 * 16 < q.nblk; b += 8 * 16) {                    // eight loads in flight per thread; the sum order is fixed (row group, then rows ascending)
             float v[8];
@@ -352,12 +353,18 @@ __global__ __launch_bounds__(256) void ln_partial_reduce_many_kernel(LnRedMany p
     }
     red[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && c < 2 * q.d) {
+    if (ty == 0 && c < ncol) {
         float t = 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) t += red[j][tx];
-        float* o = c < q.d ? q.dgamma + c : q.dbeta + (c - q.d);
-        *o += t;
+        if (q.kind) {
+            const int ch = c >> 5, k = c & 31;
+            if (k < q.kind) q.dgamma[(long)ch * q.kind + k] += t;
+            else if (k == 31 && q.dbeta) q.dbeta[ch] += t;
+        } else {
+            float* o = c < q.d ? q.dgamma + c : q.dbeta + (c - q.d);
+            *o += t;
+        }
     }
 }
 
@@ -756,7 +763,7 @@ extern "C" int mi_layernorm_bwd(const void* x, long ldx, int x_bf16, const float
     MI_CHECK_LAUNCH();
     if (dgamma) {
         LnRedMany one{};
-        one.d[0] = mi_lnred_desc{workspace, grid, d, dgamma, dbeta};
+        one.d[0] = mi_lnred_desc{workspace, grid, d, dgamma, dbeta, 0};
         hipLaunchKernelGGL(ln_partial_reduce_many_kernel, dim3(cdiv(2 * d, 16), 1), dim3(256), 0, st, one);
         MI_CHECK_LAUNCH();
     }
@@ -811,11 +818,12 @@ extern "C" int mi_ln_partial_reduce_many(const mi_lnred_desc* descs, int n, hipS
     LnRedMany p{};
     int dmax = 0;
     for (int i = 0; i < n; ++i) {
-        if (!descs[i].partial || !descs[i].dgamma || !descs[i].dbeta || descs[i].nblk <= 0 || descs[i].d <= 0) return MI_ERR_ARG;
+        if (!descs[i].partial || !descs[i].dgamma || (!descs[i].dbeta && !descs[i].kind) || descs[i].nblk <= 0 || descs[i].d <= 0 || descs[i].kind < 0 || descs[i].kind > 31) return MI_ERR_ARG;
         p.d[i] = descs[i];
-        dmax = descs[i].d > dmax ? descs[i].d : dmax;
+        const int ncol = descs[i].kind ? descs[i].d * 32 : 2 * descs[i].d;
+        dmax = ncol > dmax ? ncol : dmax;
     }
-    hipLaunchKernelGGL(ln_partial_reduce_many_kernel, dim3(cdiv(2 * dmax, 16), n), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(ln_partial_reduce_many_kernel, dim3(cdiv(dmax, 16), n), dim3(256), 0, st, p);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
@@ -887,6 +895,25 @@ extern "C" int mi_gate_bwd_bf16(const void* ds, long ldds, const void* c, long l
     if (M <= 0 || N <= 0) return MI_ERR_ARG;
     hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, st, (const bf16_t*)ds, ldds, (const bf16_t*)c, ldc,
                        (const bf16_t*)r, ldr, (bf16_t*)dr, lddr, (bf16_t*)dc, lddc, M, N);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+// frame counts behind the two-layer Conv2d sub-sampling for every utterance in one launch (the dozen one-block torch kernels of the length arithmetic were 70 us of a step):
+// inner = min(the count with the convs' padding, tmax) — what the encoder's masks use —, outer = the count without padding — what the CTC loss is given
+// (reference: _get_feat_extract_output_lengths with / without padding).  Floor division as torch.div(rounding_mode="floor").
+__global__ void subsampled_lengths_kernel(const int* __restrict__ in, int B, int k, int s, int p, int layers, int tmax, int* __restrict__ inner, int* __restrict__ outer) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    auto fdiv = [](int a, int d) { int q = a / d; if ((a % d) != 0 && ((a < 0) != (d < 0))) --q; return q; };
+    int li = in[b], lo = li;
+    for (int i = 0; i < layers; ++i) { li = fdiv(li + 2 * p - k, s) + 1; lo = fdiv(lo - k, s) + 1; }
+    inner[b] = li < tmax ? li : tmax;
+    outer[b] = lo;
+}
+extern "C" int mi_subsampled_lengths_i32(const int* lengths, int B, int kernel, int stride, int pad, int layers, int tmax, int* inner, int* outer, hipStream_t st) {
+    MI_ENTER();
+    if (!lengths || !inner || !outer || B <= 0 || kernel <= 0 || stride <= 0 || pad < 0 || layers < 0) return MI_ERR_ARG;
+    hipLaunchKernelGGL(subsampled_lengths_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, lengths, B, kernel, stride, pad, layers, tmax, inner, outer);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

@@ -136,7 +136,7 @@ class LnReduceBatch:
     `flush()` reduces up to 16 of them in ONE launch (mi_ln_partial_reduce_many).  A 2-MB reduce is all launch latency: the training step has ~100 of them."""
     SLOTS = 16
 
-    def __init__(self, device, floats_per_slot=512 * 2 * 2048):
+    def __init__(self, device, floats_per_slot=4 * 512 * 2 * 2048):          # 32 MiB: a depthwise conv's partials (B x C x 32 floats) of up to B * C = 128 Ki fit a slot
         self.device, self.per = device, floats_per_slot
         self.arena = None
         self.items = []
@@ -154,7 +154,13 @@ class LnReduceBatch:
     def add(self, partial, nblk, d, dgamma, dbeta):
         if any(it.dgamma == dgamma.data_ptr() for it in self.items):      # two LayerNorm passes into the same target: their `+=` must not run in one launch
             self.flush()
-        self.items.append(_lib.LnRedDesc(partial=partial.data_ptr(), nblk=int(nblk), d=int(d), dgamma=dgamma.data_ptr(), dbeta=dbeta.data_ptr()))
+        self.items.append(_lib.LnRedDesc(partial=partial.data_ptr(), nblk=int(nblk), d=int(d), dgamma=dgamma.data_ptr(), dbeta=dbeta.data_ptr(), kind=0))
+
+    def add_dw(self, partial, rows, C, K, dw, db):
+        """the tap-gradient partials a depthwise-conv backward left in `partial` (rows x C x 32; csgu_bwd / dwconv_residual_bwd with defer=): reduced by the same launch"""
+        if any(it.dgamma == dw.data_ptr() for it in self.items):
+            self.flush()
+        self.items.append(_lib.LnRedDesc(partial=partial.data_ptr(), nblk=int(rows), d=int(C), dgamma=dw.data_ptr(), dbeta=db.data_ptr() if db is not None else None, kind=int(K)))
 
     def flush(self):
         if not self.items:
@@ -430,12 +436,21 @@ def dropout_add(resid, t, alpha, p, seed, stream_id):
     return y
 
 
-def csgu_bwd(u, stats, gamma, beta, w, bias, ds, dr, dgn, dw, db, B, T, pad_left=None, dilation=1):
-    """dr None: `ds` is the gradient of the conv output itself (split form, ops.csgu_conv).  pad_left / dilation: None / 1 = the symmetric conv; the causal encoder passes ((K-1)*dil, dil = (K-1)//2), as ops.csgu does."""
+def csgu_bwd(u, stats, gamma, beta, w, bias, ds, dr, dgn, dw, db, B, T, pad_left=None, dilation=1, defer=None):
+    """dr None: `ds` is the gradient of the conv output itself (split form, ops.csgu_conv).  pad_left / dilation: None / 1 = the symmetric conv; the causal encoder passes ((K-1)*dil, dil = (K-1)//2), as ops.csgu does.
+    defer: an LnReduceBatch — the tap / bias gradients' cross-utterance sum is left to its next flush (one launch for several layers' reductions)."""
     M, C2 = u.shape
     Cc = C2 // 2
     K = w.shape[-1]
     pl = (K - 1) // 2 if pad_left is None else int(pad_left)
+    rows = B * (((T + 63) // 64) if dilation > 1 else 1)
+    if defer is not None and rows * Cc * 32 <= defer.per:
+        ws = defer.slot()
+        _lib.check(_L().mi_csgu_bwd_bf16(u.data_ptr(), u.stride(0), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), _p(bias),
+                                         ds.data_ptr(), ds.stride(0), _p(dr), dr.stride(0) if dr is not None else 0, dgn.data_ptr(), dgn.stride(0),
+                                         None, None, B, T, Cc, K, pl, int(dilation), ws.data_ptr(), _stream()), "mi_csgu_bwd_bf16")
+        defer.add_dw(ws, rows, Cc, K, dw, db)
+        return
     _lib.check(_L().mi_csgu_bwd_bf16(u.data_ptr(), u.stride(0), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), _p(bias),
                                      ds.data_ptr(), ds.stride(0), _p(dr), dr.stride(0) if dr is not None else 0, dgn.data_ptr(), dgn.stride(0),
                                      dw.data_ptr(), _p(db), B, T, Cc, K, pl, int(dilation), _dw_ws(u.device, B * Cc * 32 * (((T + 63) // 64) if dilation > 1 else 1)), _stream()), "mi_csgu_bwd_bf16")
@@ -450,10 +465,17 @@ def gate_act_mul_bwd(r, g, ds, dr, act=0):
     return dg
 
 
-def dwconv_residual_bwd(m, w, dy, dm, dw, db, B, T, pad_left=None):
+def dwconv_residual_bwd(m, w, dy, dm, dw, db, B, T, pad_left=None, defer=None):
+    """defer: as in csgu_bwd"""
     M, Cc = m.shape
     K = w.shape[-1]
     pl = (K - 1) // 2 if pad_left is None else int(pad_left)
+    if defer is not None and B * Cc * 32 <= defer.per:
+        ws = defer.slot()
+        _lib.check(_L().mi_dwconv_residual_bwd_bf16(m.data_ptr(), m.stride(0), w.data_ptr(), dy.data_ptr(), dy.stride(0), dm.data_ptr(), dm.stride(0),
+                                                    None, None, B, T, Cc, K, pl, 1, ws.data_ptr(), _stream()), "mi_dwconv_residual_bwd_bf16")
+        defer.add_dw(ws, B, Cc, K, dw, db)
+        return
     _lib.check(_L().mi_dwconv_residual_bwd_bf16(m.data_ptr(), m.stride(0), w.data_ptr(), dy.data_ptr(), dy.stride(0), dm.data_ptr(), dm.stride(0),
                                                 dw.data_ptr(), _p(db), B, T, Cc, K, pl, 1, _dw_ws(m.device, B * Cc * 32), _stream()), "mi_dwconv_residual_bwd_bf16")
 

@@ -374,6 +374,7 @@ class EncoderCTCTrainer:
         self.csgu_lin = bool(c.get("csgu_use_linear_after_conv", False))
         # fused CSGU kernels cover the reference recipes' form (identity activation, no Linear); anything else runs split: conv -> [Linear] -> act * gate
         self.csgu_split = self.csgu_lin or self.csgu_act != 0
+        self.dual_ln = True                       # the two branch norms' backward in one pass (tools/train_bench.py --no-dual-ln measures the two-pass form beside it)
         self.frozen = set()
         self.layerdrop = float(c.get("layerdrop", 0.0) or 0.0)      # tf:models/wav2vec2_conformer/modeling_wav2vec2_conformer.py:686-690
         g = lambda k: float(c.get(k, 0.0) or 0.0)
@@ -503,6 +504,12 @@ class EncoderCTCTrainer:
             for r in pending:
                 self.sync.launch(*r)
             pending.clear()
+
+    def _dwred(self):
+        """the batch the depthwise-conv backward passes defer their tap-gradient reductions to (the LayerNorm one: flushed in _range_done, before a range is handed on)"""
+        if getattr(self, "_lnred", None) is None:
+            self._lnred = T.LnReduceBatch(self.device)
+        return self._lnred
 
     def _lng(self, gname, bname):
         """gradient targets of a LayerNorm's affine pair: none when both are frozen (the cross-row reduction is then skipped)"""
@@ -787,7 +794,8 @@ class EncoderCTCTrainer:
             # merge:  x2 = x1 + dropout(merge_proj(m2));  dyb = dropout(dx) as bf16
             dm2 = T.linear_bwd(dyb, S["m2"], WT(p + "mrg_w"), dw=GL(p + "mrg_w"), db=GL(p + "mrg_b"), defer=self._tnb)
             dcat = e16(M, 2 * d)
-            T.dwconv_residual_bwd(S["cat"], P(p + "mrg_dw_w"), dm2, dcat, G(p + "mrg_dw_w"), G(p + "mrg_dw_b"), B, T2)
+            dwred = self._dwred()                       # the depthwise convs' cross-utterance tap-gradient sums ride the deferred LayerNorm reductions' launches
+            T.dwconv_residual_bwd(S["cat"], P(p + "mrg_dw_w"), dm2, dcat, G(p + "mrg_dw_w"), G(p + "mrg_dw_b"), B, T2, defer=dwred)
             # local branch
             dsg = T.linear_bwd(dcat[:, d:], S["sg"], WT(p + "mlp_w2"), dw=GL(p + "mlp_w2"), db=GL(p + "mlp_b2"), defer=self._tnb)
             if pd["csgu"] > 0:
@@ -798,16 +806,16 @@ class EncoderCTCTrainer:
                 dlin = T.gate_act_mul_bwd(S["h"][:, :I // 2], S["lin"], dsg, dh[:, :I // 2], self.csgu_act)
                 dcv = T.linear_bwd(dlin, S["cv"], WT(p + "csgu_lin_w"), dw=GL(p + "csgu_lin_w"), db=GL(p + "csgu_lin_b"), defer=self._tnb) if self.csgu_lin else dlin
                 T.csgu_bwd(S["h"], S["stats"], P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), dcv, None, dgn,
-                           G(p + "csgu_w"), G(p + "csgu_b"), B, T2, pad_left=cs_pad, dilation=cs_dil)
+                           G(p + "csgu_w"), G(p + "csgu_b"), B, T2, pad_left=cs_pad, dilation=cs_dil, defer=dwred)
             else:
                 T.csgu_bwd(S["h"], S["stats"], P(p + "csgu_ln_g"), P(p + "csgu_ln_b"), P(p + "csgu_w"), P(p + "csgu_b"), dsg, dh[:, :I // 2], dgn,
-                           G(p + "csgu_w"), G(p + "csgu_b"), B, T2, pad_left=cs_pad, dilation=cs_dil)
+                           G(p + "csgu_w"), G(p + "csgu_b"), B, T2, pad_left=cs_pad, dilation=cs_dil, defer=dwred)
             T.layernorm_bwd(S["h"][:, I // 2:], P(p + "csgu_ln_g"), dgn, dh[:, I // 2:], accumulate=False, **self._lng(p + "csgu_ln_g", p + "csgu_ln_b"))
             dhp = T.act_bwd(dh, S["hp"])       # (folding this pass into the two kernels above was built and measured: each slows by what its share of this one costs — DESIGN §7)
             da2 = T.linear_bwd(dhp, S["a2"], WT(p + "mlp_w1"), dw=GL(p + "mlp_w1"), db=GL(p + "mlp_b1"), defer=self._tnb)
             # the two branch norms read the same x1: one pass for both when their affine pairs train (the gradient w.r.t. x1 is linear in dy * gamma)
             lng_m, lng_a = self._lng(p + "mlp_ln_g", p + "mlp_ln_b"), self._lng(p + "att_ln_g", p + "att_ln_b")
-            dual = ptype != "rotary" and d <= 512 and lng_m["dgamma"] is not None and lng_a["dgamma"] is not None
+            dual = self.dual_ln and ptype != "rotary" and d <= 512 and lng_m["dgamma"] is not None and lng_a["dgamma"] is not None
             if not dual:
                 T.layernorm_bwd(S["x1"], P(p + "mlp_ln_g"), da2, dx, accumulate=True, **lng_m)
             # global branch
@@ -967,6 +975,12 @@ class EncoderCTCTrainer:
     def _lengths(self, feat_lengths, T2):
         c = self.cfg
         k, s, p = c["conv_kernel"][0], c["conv_stride"][0], c["conv_padding"][0]
+        if feat_lengths.is_cuda and feat_lengths.dtype == torch.int32:                 # one launch instead of fifteen one-block torch kernels
+            from . import _lib
+            inner, outer = torch.empty_like(feat_lengths), torch.empty_like(feat_lengths)
+            _lib.check(_lib.lib().mi_subsampled_lengths_i32(feat_lengths.data_ptr(), feat_lengths.numel(), int(k), int(s), int(p), 2, int(T2), inner.data_ptr(), outer.data_ptr(),
+                                                            torch.cuda.current_stream().cuda_stream), "mi_subsampled_lengths_i32")
+            return inner, outer
         li, lo = feat_lengths.clone(), feat_lengths.clone()
         for _ in range(2):
             li = torch.div(li + 2 * p - k, s, rounding_mode="floor") + 1

@@ -285,7 +285,10 @@ int mi_layernorm_bwd(const void* x, long ldx, int x_bf16, const float* gamma, fl
                      mi_stream_t stream);
 /* deferred form: the per-block (dgamma | dbeta) partial rows stay in `partial` (*nblk rows of 2 d floats; size as mi_layernorm_bwd_workspace_floats) and are reduced
    later, up to 16 LayerNorms per launch, by mi_ln_partial_reduce_many (dgamma[c] += sum, dbeta[c] += sum; fixed summation order, no atomics) */
-typedef struct { const float* partial; int nblk, d; float* dgamma; float* dbeta; } mi_lnred_desc;
+typedef struct { const float* partial; int nblk, d; float* dgamma; float* dbeta; int kind; } mi_lnred_desc;
+/* kind 0: a LayerNorm's rows as above.  kind = K (1..31): the tap-gradient partials a depthwise-conv backward left in its workspace (mi_csgu_bwd_bf16 /
+ * mi_dwconv_residual_bwd_bf16 called with dw == NULL): nblk rows of d * 32 floats, d = channels; dgamma = the (d, K) tap gradient, dbeta = the (d) bias gradient or NULL;
+ * dgamma[c * K + k] += sum_rows partial[row][c * 32 + k] (k < K), dbeta[c] += sum_rows partial[row][c * 32 + 31] */
 int mi_layernorm_bwd_partial(const void* x, long ldx, int x_bf16, const float* gamma, float eps, const void* dy, long lddy, int dy_f32,
                              void* dx, long lddx, int dx_bf16, int accumulate, float* partial, int* nblk, int M, int d, mi_stream_t stream);
 /* as mi_layernorm_bwd_partial, and in the same pass cast (M,d) bf16 = alpha * dropout(dx) of the finished rows — the bf16 operand of the linear backward that follows
@@ -314,6 +317,9 @@ int mi_add_rowvec_bf16(const void* x, long ldx, const float* vec, void* out, lon
 int mi_add_rowvec2_bf16(const void* x, long ldx, const float* u, const float* v, void* out_u, void* out_v, long ldo, int M, int N, mi_stream_t stream);
 int mi_gate_bwd_bf16(const void* ds, long ldds, const void* c, long ldc, const void* r, long ldr, void* dr, long lddr,
                      void* dc, long lddc, int M, int N, mi_stream_t stream);
+/* valid frame counts behind `layers` Conv2d sub-sampling layers (kernel, stride, pad on the time axis) for B utterances: inner[b] = min(count with padding, tmax) — the
+ * encoder's masks —, outer[b] = count without padding — the CTC loss's input lengths (reference: e_branchformer.py _get_feat_extract_output_lengths; floor division) */
+int mi_subsampled_lengths_i32(const int* lengths, int B, int kernel, int stride, int pad, int layers, int tmax, int* inner, int* outer, mi_stream_t stream);
 int mi_mask_rows_f32(float* x, long ld, const int* lengths, int T, int M, int N, mi_stream_t stream);
 /* in-model SpecAugment of the encoder input (tf wav2vec2_conformer _mask_hidden_states :1086-1130): time_mask (M) / feat_mask (B, N) bytes */
 int mi_spec_mask_apply(float* x, long ld, const unsigned char* time_mask, const float* embed, const unsigned char* feat_mask, int T, int M, int N,
@@ -377,6 +383,8 @@ int mi_dropout(const void* x, long ldx, int in_dtype, void* out, long ldo, int o
 int mi_dropout_add_f32(float* y, long ldy, const float* resid, long ldr, const float* t, long ldt, int M, int N, float alpha, float p,
                        unsigned seed, unsigned stream_id, mi_stream_t stream);
 /* depthwise-conv / conv front-end gradients (e_branchformer.py:184-204,296-304; extractors.py:71-113) */
+/* the two depthwise-conv backward entries below: dw == NULL leaves the per-utterance tap-gradient partials in `workspace` un-reduced (rows = B, or B * ceil(T / 64) for the
+ * dilated form) for a later mi_ln_partial_reduce_many (desc kind = K) — several layers' reductions in one launch */
 int mi_csgu_bwd_bf16(const void* u, long ldu, const float* stats, const float* gamma, const float* beta, const float* w,
                      const float* bias, const void* ds, long ldds, void* dr, long lddr, void* dgn, long lddgn, float* dw,
                      float* db, int B, int T, int C, int K, int pad_left, int dilation /* 1, or the causal form's (K-1)/2 */,

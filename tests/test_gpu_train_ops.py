@@ -413,6 +413,49 @@ def test_csgu_and_merge_dwconv_bwd():
     torch.testing.assert_close(db2.cpu(), br2.grad, atol=1e-2 * float(br2.grad.abs().max()), rtol=1e-2)
 
 
+@pytest.mark.parametrize("B,Tt,Cc,K,dil", [(5, 150, 128, 31, 1), (40, 70, 64, 31, 1), (3, 90, 96, 15, 1), (2, 130, 64, 31, 15)])
+def test_depthwise_conv_tap_gradient_sums_deferred_with_the_layernorm_reductions(B, Tt, Cc, K, dil):
+    """csgu_bwd / dwconv_residual_bwd(..., defer=LnReduceBatch): the cross-utterance sums of the tap / bias gradients leave with the batch's next launch (together with
+    LayerNorm entries); same data gradients bit for bit, same tap gradients up to the order of the B-term sums; twice into the same target = accumulated twice."""
+    ops, T = _o()
+    M = B * Tt
+    u = dev16(rnd(M, 2 * Cc, seed=1))
+    g, be = (1 + 0.1 * rnd(Cc, seed=2)).to(DEV), (0.1 * rnd(Cc, seed=3)).to(DEV)
+    w, bias = rnd(Cc, K, seed=4, scale=0.2).to(DEV), (0.1 * rnd(Cc, seed=5)).to(DEV)
+    ds, dy = dev16(rnd(M, Cc, seed=6)), dev16(rnd(M, Cc, seed=8))
+    st = ops.row_stats(u[:, Cc:])
+    pl = (K - 1) * dil if dil > 1 else None
+    Z = lambda *s: torch.zeros(*s, device=DEV)
+    E = lambda: torch.empty(M, Cc, device=DEV, dtype=BF)
+    red = T.LnReduceBatch(DEV)
+    # immediate
+    dr0, dgn0, dm0 = E(), E(), E()
+    dw0, db0, dw0m, db0m = Z(Cc, K), Z(Cc), Z(Cc, K), Z(Cc)
+    for _ in range(2):
+        T.csgu_bwd(u, st, g, be, w, bias, ds, dr0, dgn0, dw0, db0, B, Tt, pad_left=pl, dilation=dil)
+    if dil == 1:
+        T.dwconv_residual_bwd(u[:, :Cc], w, dy, dm0, dw0m, db0m, B, Tt)
+    # deferred, with a LayerNorm entry in the same batch
+    dr1, dgn1, dm1 = E(), E(), E()
+    dw1, db1, dw1m, db1m = Z(Cc, K), Z(Cc), Z(Cc, K), Z(Cc)
+    dgl, dbl, dgl0, dbl0 = Z(Cc), Z(Cc), Z(Cc), Z(Cc)
+    x = rnd(M, Cc, seed=9).to(DEV)
+    T.csgu_bwd(u, st, g, be, w, bias, ds, dr1, dgn1, dw1, db1, B, Tt, pad_left=pl, dilation=dil, defer=red)
+    T.layernorm_bwd(x, g, dy, torch.empty(M, Cc, device=DEV), accumulate=False, dgamma=dgl, dbeta=dbl, defer=red)
+    if dil == 1:
+        T.dwconv_residual_bwd(u[:, :Cc], w, dy, dm1, dw1m, db1m, B, Tt, defer=red)
+    T.csgu_bwd(u, st, g, be, w, bias, ds, dr1, dgn1, dw1, db1, B, Tt, pad_left=pl, dilation=dil, defer=red)      # same target again: flushes the pending entry first
+    red.flush()
+    T.layernorm_bwd(x, g, dy, torch.empty(M, Cc, device=DEV), accumulate=False, dgamma=dgl0, dbeta=dbl0)
+    assert torch.equal(dr1, dr0) and torch.equal(dgn1, dgn0)
+    tol = lambda t: dict(rtol=1e-5, atol=2e-6 * float(t.abs().max()))
+    torch.testing.assert_close(dw1, dw0, **tol(dw0)); torch.testing.assert_close(db1, db0, **tol(db0))
+    torch.testing.assert_close(dgl, dgl0, **tol(dgl0)); torch.testing.assert_close(dbl, dbl0, **tol(dbl0))
+    if dil == 1:
+        assert torch.equal(dm1, dm0)
+        torch.testing.assert_close(dw1m, dw0m, **tol(dw0m)); torch.testing.assert_close(db1m, db0m, **tol(db0m))
+
+
 @pytest.mark.parametrize("B,Tt,Cc", [(2, 100, 128), (3, 77, 96), (1, 520, 64)])
 def test_causal_dilated_csgu_bwd(B, Tt, Cc):
     """the streaming encoder's CSGU: CausalConv1d with (K-1)//2 = 15 in its dilation slot (e_branchformer.py:153-160; left pad 450) — conv_bwd.hip's dilated kernel
@@ -539,6 +582,23 @@ def test_layernorm_bwd_of_two_norms_on_the_same_rows_in_one_pass(d, pdrop, dy2f3
     T.layernorm_bwd_dual(xd, g1.to(DEV), d1, g2.to(DEV), d2, dx3, accumulate=False, dgamma=G(), dbeta=G(), dgamma2=G(), dbeta2=G(), defer=red)
     red.flush()
     torch.testing.assert_close(dx3.cpu().double(), xr.grad, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("k,s,p", [(3, 2, 1), (3, 2, 0), (5, 3, 2)])
+def test_subsampled_lengths_in_one_launch(k, s, p):
+    """mi_subsampled_lengths_i32 against the reference's length arithmetic (_get_feat_extract_output_lengths: floor division, two conv layers), including inputs shorter
+    than the kernel (negative numerators) and the clamp of the padded count to the batch's frame axis"""
+    from huggingface_asr_amd import _lib
+    fl = torch.tensor([1, 2, 3, 4, 7, 8, 9, 100, 999, 1000, 1001, 1998, 2000, 0], dtype=torch.int32)
+    li, lo = fl.clone(), fl.clone()
+    for _ in range(2):
+        li = torch.div(li + 2 * p - k, s, rounding_mode="floor") + 1
+        lo = torch.div(lo - k, s, rounding_mode="floor") + 1
+    T2 = 250
+    d = fl.to(DEV)
+    inner, outer = torch.empty_like(d), torch.empty_like(d)
+    _lib.check(_lib.lib().mi_subsampled_lengths_i32(d.data_ptr(), d.numel(), k, s, p, 2, T2, inner.data_ptr(), outer.data_ptr(), torch.cuda.current_stream().cuda_stream), "lengths")
+    assert torch.equal(inner.cpu(), torch.clamp(li, max=T2).to(torch.int32)) and torch.equal(outer.cpu(), lo.to(torch.int32))
 
 
 def test_scale_by_device_scalar():

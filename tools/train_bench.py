@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", default="base"); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3); ap.add_argument("--pos", default="relative"); ap.add_argument("--frames", type=int, default=1000)
 ap.add_argument("--fwd-only", action="store_true")
+ap.add_argument("--no-dual-ln", action="store_true", help="the layer's two branch LayerNorm backward passes as two launches (the form before round 4's last change), for a same-box A/B")
 ap.add_argument("--specaug", action="store_true", help="in-model SpecAugment as in the recipes (mask_time_prob 0.05, length 10, min 2 masks)")
 ap.add_argument("--dropout", type=float, default=0.0, help="the recipes train with 0.1 at every dropout site (hidden, activation, attention, CSGU, final)")
 ap.add_argument("--finetune", action="store_true", help="the frozen fine-tuning recipes' setting (recipes/librispeech/ssl/*/lumi/finetune_frozen*.sh): layer mixing + "
@@ -60,6 +61,8 @@ labels = torch.from_numpy(synth.labels(rank, B, U, cfg["vocab_size"], lo=5)).to(
 if a.model == "aed":                                        # label lengths follow the audio lengths (about 3 tokens / s)
     for b in range(B):
         labels[b, max(2, int(fl[b] / 100 * 3)):] = -100
+if a.no_dual_ln:
+    (tr.enc if a.model == "aed" else tr).dual_ln = False
 state = {}
 def step():
     if a.fwd_only:
