@@ -39,6 +39,7 @@ struct AttnArgs {
     // attention-probability dropout (e_branchformer.py:132) in the LDS-staged kernel, training forward and backward: the counter-based mask of dropout.hip for the
     // logical element ((h * B + b) * T + i) * Tk + j of the (H, B, T, Tk) probabilities — the same mask the generic softmax kernels (attn_bwd.hip) and the host twin draw
     float drop_p; unsigned long long drop_key;
+    long ldsum;                          // row stride of dsum_u / dsum_v in floats (0 = H*HD); 2 H*HD when the caller interleaves them as rows of [u | v] (one deferred reduction for both)
 #ifdef ATTN_STAMPS
     unsigned long long* stamps;          // instrumented build only (tools/attn_stamps.py): per (block, wave) 32 shader-clock readings
 #endif
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
         }
         // ---- column sums of dQu / dQv over this wave's valid queries (the bias gradients' partials): 64 channels at a time through the scratch as fp32 rows
         const int rows_valid = min(32, T - i0);
-        const long psum0 = (((long)b * (gridDim.x * 4) + blockIdx.x * 4 + wave) * p.H + head) * HD;
+        const long psum0 = ((long)b * (gridDim.x * 4) + blockIdx.x * 4 + wave) * (p.ldsum ? p.ldsum : (long)p.H * HD) + (long)head * HD;
         auto colsum_out = [&](const f32x16* acc, float* dst) {
 #pragma unroll
             for (int hh = 0; hh < HD / 64; ++hh) {
@@ -1451,6 +1452,7 @@ extern "C" int mi_attention_qkv_bwd_probs(const void* q, long ldq, const void* k
                bias_u, bias_v, lengths, (bf16_t*)const_cast<void*>(ctx), ldo, B, T, H, scale, causal, 0, 0, const_cast<float*>(lse),
                (const bf16_t*)dctx, ldd, (bf16_t*)prob, (bf16_t*)ds, ldsr, (bf16_t*)dbd, pos ? ldbd : 0, pos ? pad : 0,
                (bf16_t*)dq, lddq, dsum_u, dsum_v, drop_p, ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed};
+    a.ldsum = (dsum_u && dsum_v == dsum_u + (long)H * hd) ? 2l * H * hd : 0;      // [u | v] rows of one (rows, 2 H hd) buffer: see the header
     switch (hd) {
         case 64: return launch_lds_bw<64>(a, pos != nullptr, stream);
         case 128: return launch_lds_bw<128>(a, pos != nullptr, stream);

@@ -140,6 +140,7 @@ class LnReduceBatch:
         self.device, self.per = device, floats_per_slot
         self.arena = None
         self.items = []
+        self.keep = []                                      # caller-owned partial buffers of pending entries
         self.cursor = 0                                     # slots are handed out round-robin: the pending entries always sit in the len(items) most recent ones
 
     def slot(self):
@@ -162,13 +163,21 @@ class LnReduceBatch:
             self.flush()
         self.items.append(_lib.LnRedDesc(partial=partial.data_ptr(), nblk=int(rows), d=int(C), dgamma=dw.data_ptr(), dbeta=db.data_ptr() if db is not None else None, kind=int(K)))
 
+    def add_rows2(self, su, dgu, dgv):
+        """su = the [:, :d] view of a (rows, 2d) fp32 buffer of [u | v] rows (attn_bwd_probs): dgu += column sums of the u half, dgv += those of the v half, with the next
+        flush.  The buffer is kept alive until then (the caching allocator would otherwise hand it to a later kernel of the same stream before the reduction has read it)."""
+        rows, d = su.shape
+        assert su.stride(0) == 2 * d and su.dtype == F32
+        if len(self.items) == self.SLOTS or any(it.dgamma == dgu.data_ptr() for it in self.items):
+            self.flush()
+        self.keep.append(su)
+        self.items.append(_lib.LnRedDesc(partial=su.data_ptr(), nblk=int(rows), d=int(d), dgamma=dgu.data_ptr(), dbeta=dgv.data_ptr(), kind=0))
+
     def flush(self):
-        if not self.items:
-            return
-        import ctypes as C
-        arr = (_lib.LnRedDesc * len(self.items))(*self.items)
-        _lib.check(_L().mi_ln_partial_reduce_many(arr, len(self.items), _stream()), "mi_ln_partial_reduce_many")
-        self.items = []
+        if self.items:
+            arr = (_lib.LnRedDesc * len(self.items))(*self.items)
+            _lib.check(_L().mi_ln_partial_reduce_many(arr, len(self.items), _stream()), "mi_ln_partial_reduce_many")
+        self.items, self.keep = [], []
 
 
 def layernorm_bwd(x, gamma, dy, dx, *, accumulate, dgamma=None, dbeta=None, eps=1e-5, defer=None, cast=None):
@@ -358,8 +367,8 @@ def attn_bwd_probs(qkv, B, T, H, ctx, dctx, lse, dq, *, pos=None, bias_u=None, b
     rel = pos is not None
     dbd = torch.empty((H, B, T, Ps), device=dev, dtype=BF16) if rel else None
     nw = 4 * ((T + 127) // 128)
-    su = torch.empty((B * nw, d), device=dev, dtype=F32) if rel else None
-    sv = torch.empty((B * nw, d), device=dev, dtype=F32) if rel else None
+    suv = torch.empty((B * nw, 2 * d), device=dev, dtype=F32) if rel else None         # rows of [u | v]: `LnReduceBatch.add_rows2(su, ...)` can defer their column sums
+    su, sv = (suv[:, :d], suv[:, d:]) if rel else (None, None)
     q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
     _lib.check(_L().mi_attention_qkv_bwd_probs(q.data_ptr(), qkv.stride(0), k.data_ptr(), qkv.stride(0), v.data_ptr(), qkv.stride(0),
                                                _p(pos), pos.stride(0) if rel else 0, _p(bias_u), _p(bias_v), _p(lengths),

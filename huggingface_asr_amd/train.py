@@ -575,7 +575,7 @@ class EncoderCTCTrainer:
         is below `config.layerdrop` (every rank draws its own, from its dropout seed) — in training mode; nothing is skipped in eval."""
         c, st = self.cfg, self.store
         if getattr(self, "_lnred", None) is not None:
-            self._lnred.items = []              # a step that raised part-way leaves deferred LayerNorm reductions behind: they must not land in this step's gradients
+            self._lnred.items, self._lnred.keep = [], []              # a step that raised part-way leaves deferred LayerNorm reductions behind: they must not land in this step's gradients
         if getattr(self, "_tnb", None) is None:
             self._tnb = T.TnBatch()
         self._tnb.items = []
@@ -1113,7 +1113,7 @@ class EncoderCTCTrainer:
             return dqkv
         Ps = dbd.shape[-1]
         if fused:
-            T.colsum2_acc_(G(p + "att_u"), G(p + "att_v"), su, sv)
+            self._dwred().add_rows2(su, G(p + "att_u"), G(p + "att_v"))       # the per-wave rows' column sums leave with the deferred LayerNorm reductions' next launch
         else:
             dqu = torch.empty((M, d), device=dev, dtype=F32)
             dqv = torch.empty((M, d), device=dev, dtype=F32)

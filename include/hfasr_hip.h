@@ -171,6 +171,8 @@ int mi_attention_qkv_lse_bf16(const void* q, long ldq, const void* k, long ldk, 
  *   prob, ds (H, B, T, ldsr)   and   dbd (H, B, T, ldbd), dbd[i][T-1-i+j + pad] = ds[i][j]  (the gradient of the un-shifted position scores; null without pos).
  * It also accumulates the query gradient over the walk: dq (B*T, lddq) bf16 = dS K + dBD P, and the per-wave column sums of the two terms in
  * dsum_u / dsum_v (B, 4 ceil(T/128), H*hd) fp32 (summed over their first two axes: the pos_bias_u / pos_bias_v gradients; unused without pos).
+ * dsum_v == dsum_u + H*hd selects the interleaved layout: ONE (B * 4 ceil(T/128), 2 H*hd) buffer whose rows are [u | v] — the shape mi_ln_partial_reduce_many sums
+ * (desc kind 0 with d = H*hd, dgamma = the pos_bias_u gradient, dbeta = the pos_bias_v gradient), so the reduction can leave with a later launch.
  * ldsr, ldbd multiples of 32 with ldsr >= T rounded up to 32 and ldbd >= pad + 2T - 1; 0 <= pad < 32 with (T - 32 + pad) % 32 == 0.  Every element is written. */
 int mi_attention_qkv_bwd_probs(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                                const void* pos, long ldp, const float* bias_u, const float* bias_v, const int* lengths,

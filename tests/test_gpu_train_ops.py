@@ -601,6 +601,38 @@ def test_subsampled_lengths_in_one_launch(k, s, p):
     assert torch.equal(inner.cpu(), torch.clamp(li, max=T2).to(torch.int32)) and torch.equal(outer.cpu(), lo.to(torch.int32))
 
 
+def test_position_bias_gradient_sums_deferred_with_the_layernorm_reductions():
+    """attn_bwd_probs leaves the per-wave column sums of dS K / dBD P as rows of [u | v]; LnReduceBatch.add_rows2 sums them into the pos_bias_u / pos_bias_v gradients with
+    its next launch — against colsum2_acc_ on the same rows (same values up to the order of the row sums), the buffer kept alive until the flush"""
+    ops, T = _o()
+    B, Tq, H, hd = 3, 200, 4, 64
+    d = H * hd
+    qkv = dev16(rnd(B * Tq, 3 * d, seed=1, scale=0.5))
+    Pn = 2 * Tq - 1
+    pos = dev16(rnd(Pn, d, seed=2, scale=0.5))
+    bu, bv = (0.1 * rnd(H, hd, seed=3)).to(DEV), (0.1 * rnd(H, hd, seed=4)).to(DEV)
+    lens = torch.tensor([200, 150, 77], dtype=torch.int32, device=DEV)
+    lse = torch.empty((B, H, Tq), device=DEV)
+    ctx = ops.attention_qkv(qkv, B, Tq, H, pos=pos, bias_u=bu, bias_v=bv, lengths=lens, lse=lse)
+    dctx = dev16(rnd(B * Tq, d, seed=5))
+    dq = torch.empty(B * Tq, d, device=DEV, dtype=BF)
+    _, _, _, su, sv = T.attn_bwd_probs(qkv, B, Tq, H, ctx, dctx, lse, dq, pos=pos, bias_u=bu, bias_v=bv, lengths=lens)
+    assert su.stride(0) == 2 * d and sv.data_ptr() == su.data_ptr() + 4 * d
+    gu0, gv0 = torch.zeros(H, hd, device=DEV), torch.zeros(H, hd, device=DEV)
+    T.colsum2_acc_(gu0, gv0, su, sv)
+    gu1, gv1 = torch.zeros(H, hd, device=DEV), torch.zeros(H, hd, device=DEV)
+    red = T.LnReduceBatch(DEV)
+    red.add_rows2(su, gu1, gv1)
+    keep_ptr = su.data_ptr()
+    del su, sv
+    junk = [torch.full((B * 8, 2 * d), 1e9, device=DEV) for _ in range(4)]          # would land in the freed buffer
+    assert all(j.data_ptr() != keep_ptr for j in junk)
+    red.flush()
+    torch.testing.assert_close(gu1, gu0, rtol=1e-5, atol=2e-6 * float(gu0.abs().max()))
+    torch.testing.assert_close(gv1, gv0, rtol=1e-5, atol=2e-6 * float(gv0.abs().max()))
+    assert float(gu0.abs().max()) > 0 and float(gv0.abs().max()) > 0
+
+
 def test_scale_by_device_scalar():
     """the autograd bridge's d(loss) factor: a device scalar, no host sync; exactly 1 leaves the buffer untouched, anything else scales it (odd length: the scalar tail)"""
     ops, T = _o()
