@@ -39,6 +39,8 @@ struct AttnArgs {
     // attention-probability dropout (e_branchformer.py:132) in the LDS-staged kernel, training forward and backward: the counter-based mask of dropout.hip for the
     // logical element ((h * B + b) * T + i) * Tk + j of the (H, B, T, Tk) probabilities — the same mask the generic softmax kernels (attn_bwd.hip) and the host twin draw
     float drop_p; unsigned long long drop_key;
+    bf16_t* qu_out; bf16_t* qv_out; long ldqb;   // BW + REL, optional: (B*T, ldqb) bf16 rows q + pos_bias_u / q + pos_bias_v of this head's columns, as the walk's A fragments hold them
+                                         // (the operands of the dK and d(positions) products that follow: no pass of their own)
     long ldsum;                          // row stride of dsum_u / dsum_v in floats (0 = H*HD); 2 H*HD when the caller interleaves them as rows of [u | v] (one deferred reduction for both)
 #ifdef ATTN_STAMPS
     unsigned long long* stamps;          // instrumented build only (tools/attn_stamps.py): per (block, wave) 32 shader-clock readings
@@ -339,6 +341,13 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
             }
         } else {
             qu[ks] = raw;
+        }
+        if constexpr (BW && REL) {
+            if (p.qu_out && i0 + r < T) {
+                const long o = ((long)b * T + i0 + r) * p.ldqb + c;
+                *reinterpret_cast<bf16x8*>(p.qu_out + o) = qu[ks];
+                *reinterpret_cast<bf16x8*>(p.qv_out + o) = qv[ks];
+            }
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the fragments are in registers before the scratch is reused as the skew rows
@@ -1431,13 +1440,15 @@ extern "C" int mi_attention_qkv_lse_bf16(const void* q, long ldq, const void* k,
 // dq (B*T, lddq) bf16 = dS K + dBD P, with the per-wave column sums of its two terms in dsum_u / dsum_v (B, 4 ceil(T/128), H*hd) fp32.  ldsr, ldbd multiples of 32,
 // ldsr >= T rounded up to 32, ldbd >= pad + 2T - 1, (T - 32 + pad) % 32 == 0: a wave's band of relative positions then starts on a 64-B boundary of its rows.
 // Every element of the three outputs is written (zeros where no key / relative position contributes).
-extern "C" int mi_attention_qkv_bwd_probs(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
-                                          const void* pos, long ldp, const float* bias_u, const float* bias_v, const int* lengths,
-                                          const void* ctx, long ldo, const void* dctx, long ldd, const float* lse,
-                                          void* prob, void* ds, long ldsr, void* dbd, long ldbd, int pad,
-                                          void* dq, long lddq, float* dsum_u, float* dsum_v,
-                                          int B, int T, int H, int hd, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, hipStream_t stream) {
+// qu_out / qv_out (both or neither; with pos only): (B*T, ldqb) bf16 = q + pos_bias_u / q + pos_bias_v, written by the walk's prologue from its A fragments.
+extern "C" int mi_attention_qkv_bwd_probs_qb(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                             const void* pos, long ldp, const float* bias_u, const float* bias_v, const int* lengths,
+                                             const void* ctx, long ldo, const void* dctx, long ldd, const float* lse,
+                                             void* prob, void* ds, long ldsr, void* dbd, long ldbd, int pad,
+                                             void* dq, long lddq, float* dsum_u, float* dsum_v, void* qu_out, void* qv_out, long ldqb,
+                                             int B, int T, int H, int hd, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, hipStream_t stream) {
     MI_ENTER();
+    if ((qu_out != nullptr) != (qv_out != nullptr) || (qu_out && (!pos || (ldqb % 8) || ldqb < (long)H * hd || (((uintptr_t)qu_out | (uintptr_t)qv_out) & 15)))) return MI_ERR_ARG;
     if (B <= 0 || T <= 0 || H <= 0 || !lse || !ctx || !dctx || !prob || !ds || !dq || drop_p < 0.f || drop_p >= 1.f) return MI_ERR_ARG;
     if ((lddq % 8) || lddq >= (1l << 30) || ((uintptr_t)dq & 15) || (pos && (!dsum_u || !dsum_v))) return MI_ERR_ARG;
     if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 8) || (ldd % 8)) return MI_ERR_ARG;
@@ -1453,11 +1464,21 @@ extern "C" int mi_attention_qkv_bwd_probs(const void* q, long ldq, const void* k
                (const bf16_t*)dctx, ldd, (bf16_t*)prob, (bf16_t*)ds, ldsr, (bf16_t*)dbd, pos ? ldbd : 0, pos ? pad : 0,
                (bf16_t*)dq, lddq, dsum_u, dsum_v, drop_p, ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed};
     a.ldsum = (dsum_u && dsum_v == dsum_u + (long)H * hd) ? 2l * H * hd : 0;      // [u | v] rows of one (rows, 2 H hd) buffer: see the header
+    a.qu_out = (bf16_t*)qu_out; a.qv_out = (bf16_t*)qv_out; a.ldqb = ldqb;
     switch (hd) {
         case 64: return launch_lds_bw<64>(a, pos != nullptr, stream);
         case 128: return launch_lds_bw<128>(a, pos != nullptr, stream);
         default: return MI_ERR_UNSUPPORTED;
     }
+}
+extern "C" int mi_attention_qkv_bwd_probs(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                          const void* pos, long ldp, const float* bias_u, const float* bias_v, const int* lengths,
+                                          const void* ctx, long ldo, const void* dctx, long ldd, const float* lse,
+                                          void* prob, void* ds, long ldsr, void* dbd, long ldbd, int pad,
+                                          void* dq, long lddq, float* dsum_u, float* dsum_v,
+                                          int B, int T, int H, int hd, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, hipStream_t stream) {
+    return mi_attention_qkv_bwd_probs_qb(q, ldq, k, ldk, v, ldv, pos, ldp, bias_u, bias_v, lengths, ctx, ldo, dctx, ldd, lse, prob, ds, ldsr, dbd, ldbd, pad, dq, lddq,
+                                         dsum_u, dsum_v, nullptr, nullptr, 0, B, T, H, hd, scale, causal, drop_p, seed, stream_id, stream);
 }
 
 // The two training entries above for Tq != Tk and separate q / k / v operands (no relative positions): the GPT-2 decoder's causal self-attention (Tq = Tk = U) and its

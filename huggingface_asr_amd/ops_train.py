@@ -351,11 +351,12 @@ def attn_x_bwd_probs(q, k, v, B, Tq, Tk, H, ctx, dctx, lse, dq, *, lengths=None,
     return prob, ds
 
 
-def attn_bwd_probs(qkv, B, T, H, ctx, dctx, lse, dq, *, pos=None, bias_u=None, bias_v=None, lengths=None, causal=False, drop=None):
+def attn_bwd_probs(qkv, B, T, H, ctx, dctx, lse, dq, *, pos=None, bias_u=None, bias_v=None, lengths=None, causal=False, drop=None, qb=False):
     """First half of the fused attention backward (head size 64 / 128, no probability dropout): -> prob, ds (H, B, T, Ts) bf16 and, with relative positions,
     dbd (H, B, T, Ps) bf16 with dbd[i][T-1-i+j + pad] = ds[i][j] (else None).  Ts = T rounded up to 32; (pad, Ps) = band_geometry(T).  Everything is written.
     dq (B*T, d) bf16 row view receives the query gradient dS K + dBD P; with positions also -> (su, sv): (rows, d) fp32 whose column sums are the gradients
-    of pos_bias_u / pos_bias_v.  drop = the (p, seed, stream_id) the forward used: prob is then the DROPPED probabilities (what multiplied V)."""
+    of pos_bias_u / pos_bias_v.  drop = the (p, seed, stream_id) the forward used: prob is then the DROPPED probabilities (what multiplied V).
+    qb (with positions): also -> (qu, qv) (B*T, d) bf16 = q + pos_bias_u, q + pos_bias_v as the kernel's own operands (what `add_rowvec2(q, u, v)` makes), appended to the result."""
     d = qkv.shape[1] // 3
     dp, dseed, dsid = drop if drop is not None else (0.0, 0, 0)
     hd = d // H
@@ -370,13 +371,15 @@ def attn_bwd_probs(qkv, B, T, H, ctx, dctx, lse, dq, *, pos=None, bias_u=None, b
     suv = torch.empty((B * nw, 2 * d), device=dev, dtype=F32) if rel else None         # rows of [u | v]: `LnReduceBatch.add_rows2(su, ...)` can defer their column sums
     su, sv = (suv[:, :d], suv[:, d:]) if rel else (None, None)
     q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-    _lib.check(_L().mi_attention_qkv_bwd_probs(q.data_ptr(), qkv.stride(0), k.data_ptr(), qkv.stride(0), v.data_ptr(), qkv.stride(0),
-                                               _p(pos), pos.stride(0) if rel else 0, _p(bias_u), _p(bias_v), _p(lengths),
-                                               ctx.data_ptr(), ctx.stride(0), dctx.data_ptr(), dctx.stride(0), lse.data_ptr(),
-                                               prob.data_ptr(), ds.data_ptr(), Ts, _p(dbd), Ps, pad, dq.data_ptr(), dq.stride(0), _p(su), _p(sv),
-                                               B, T, H, hd, 1.0 / math.sqrt(hd), int(causal), float(dp), int(dseed) & 0xFFFFFFFF, int(dsid) & 0xFFFFFFFF, _stream()),
-               "mi_attention_qkv_bwd_probs")
-    return prob, ds, dbd, su, sv
+    qu = torch.empty((B * T, d), device=dev, dtype=BF16) if (qb and rel) else None
+    qv = torch.empty((B * T, d), device=dev, dtype=BF16) if (qb and rel) else None
+    _lib.check(_L().mi_attention_qkv_bwd_probs_qb(q.data_ptr(), qkv.stride(0), k.data_ptr(), qkv.stride(0), v.data_ptr(), qkv.stride(0),
+                                                  _p(pos), pos.stride(0) if rel else 0, _p(bias_u), _p(bias_v), _p(lengths),
+                                                  ctx.data_ptr(), ctx.stride(0), dctx.data_ptr(), dctx.stride(0), lse.data_ptr(),
+                                                  prob.data_ptr(), ds.data_ptr(), Ts, _p(dbd), Ps, pad, dq.data_ptr(), dq.stride(0), _p(su), _p(sv), _p(qu), _p(qv), d,
+                                                  B, T, H, hd, 1.0 / math.sqrt(hd), int(causal), float(dp), int(dseed) & 0xFFFFFFFF, int(dsid) & 0xFFFFFFFF, _stream()),
+               "mi_attention_qkv_bwd_probs_qb")
+    return (prob, ds, dbd, su, sv, qu, qv) if qb else (prob, ds, dbd, su, sv)
 
 
 def pad8(n: int) -> int:

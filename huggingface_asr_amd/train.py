@@ -375,6 +375,7 @@ class EncoderCTCTrainer:
         # fused CSGU kernels cover the reference recipes' form (identity activation, no Linear); anything else runs split: conv -> [Linear] -> act * gate
         self.csgu_split = self.csgu_lin or self.csgu_act != 0
         self.dual_ln = True                       # the two branch norms' backward in one pass (tools/train_bench.py --no-dual-ln measures the two-pass form beside it)
+        self.walk_qb = True                       # q + u / q + v of the attention backward from the fused walk's prologue (--no-walk-qb: the pass of their own)
         self.frozen = set()
         self.layerdrop = float(c.get("layerdrop", 0.0) or 0.0)      # tf:models/wav2vec2_conformer/modeling_wav2vec2_conformer.py:686-690
         g = lambda k: float(c.get(k, 0.0) or 0.0)
@@ -1079,11 +1080,13 @@ class EncoderCTCTrainer:
         if "lse" in S:
             # fused forward: ONE walk over the keys recomputes the scores and leaves P, dS and the un-shifted dBD (bf16) — no fp32 score-sized tensors — and
             # accumulates dQ = dS K + dBD P on the way (its two terms' column sums are the position-bias gradients)
-            prob, ds, dbd, su, sv = T.attn_bwd_probs(qkv, B, Tt, H, S["ctx"], dctx, S["lse"], dqkv[:, :d], pos=posp, bias_u=P(p + "att_u") if rel else None,
-                                                     bias_v=P(p + "att_v") if rel else None, lengths=lengths, causal=self.causal, drop=drop)
+            # (with positions the walk also leaves q + u and q + v, its own A operands, for the dK and d(positions) products below)
+            prob, ds, dbd, su, sv, qu, qv = T.attn_bwd_probs(qkv, B, Tt, H, S["ctx"], dctx, S["lse"], dqkv[:, :d], pos=posp, bias_u=P(p + "att_u") if rel else None,
+                                                             bias_v=P(p + "att_v") if rel else None, lengths=lengths, causal=self.causal, drop=drop, qb=self.walk_qb)[:7] + ((None, None) if not self.walk_qb else ())
             fused = True
             if rel:
-                qu, qv = T.add_rowvec2(q, P(p + "att_u"), P(p + "att_v"))
+                if qu is None:
+                    qu, qv = T.add_rowvec2(q, P(p + "att_u"), P(p + "att_v"))
                 off, Kp = T.band_geometry(Tt)                 # dbd's columns are relative positions + off
         else:
             fused = False

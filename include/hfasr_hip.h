@@ -180,6 +180,14 @@ int mi_attention_qkv_bwd_probs(const void* q, long ldq, const void* k, long ldk,
                                void* prob, void* ds, long ldsr, void* dbd, long ldbd, int pad,
                                void* dq, long lddq, float* dsum_u, float* dsum_v,
                                int B, int T, int H, int hd, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, mi_stream_t stream);
+/* the same, also leaving qu_out / qv_out (B*T, ldqb) bf16 = q + pos_bias_u / q + pos_bias_v (both or neither, with pos only): the walk's own A fragments — the operands
+ * of the dK = dS^T (q + u) and d(positions) = dBD^T (q + v) products that follow, which a pass of their own used to make */
+int mi_attention_qkv_bwd_probs_qb(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                  const void* pos, long ldp, const float* bias_u, const float* bias_v, const int* lengths,
+                                  const void* ctx, long ldo, const void* dctx, long ldd, const float* lse,
+                                  void* prob, void* ds, long ldsr, void* dbd, long ldbd, int pad,
+                                  void* dq, long lddq, float* dsum_u, float* dsum_v, void* qu_out, void* qv_out, long ldqb,
+                                  int B, int T, int H, int hd, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, mi_stream_t stream);
 /* the two entries above for Tq != Tk and separate q / k / v operands, no relative positions: the GPT-2 decoder's causal self-attention and its cross-attention over the
  * encoder frames in training (multi_head_gpt2.py:80-170).  lse (B, H, Tq); prob / ds (H, B, Tq, ldsr) bf16, ldsr % 32 == 0, ldsr >= Tk rounded up to 32; dq = dS K. */
 int mi_attention_x_lse_bf16(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const int* lengths, void* out, long ldo, float* lse,

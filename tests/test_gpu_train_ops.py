@@ -618,6 +618,11 @@ def test_position_bias_gradient_sums_deferred_with_the_layernorm_reductions():
     dq = torch.empty(B * Tq, d, device=DEV, dtype=BF)
     _, _, _, su, sv = T.attn_bwd_probs(qkv, B, Tq, H, ctx, dctx, lse, dq, pos=pos, bias_u=bu, bias_v=bv, lengths=lens)
     assert su.stride(0) == 2 * d and sv.data_ptr() == su.data_ptr() + 4 * d
+    # the walk's own (q + u) / (q + v) operands against the pass that used to make them
+    dq2 = torch.empty_like(dq)
+    *_, qu, qv = T.attn_bwd_probs(qkv, B, Tq, H, ctx, dctx, lse, dq2, pos=pos, bias_u=bu, bias_v=bv, lengths=lens, qb=True)
+    wu, wv = T.add_rowvec2(qkv[:, :d], bu, bv)
+    assert torch.equal(qu, wu) and torch.equal(qv, wv) and torch.equal(dq2, dq)
     gu0, gv0 = torch.zeros(H, hd, device=DEV), torch.zeros(H, hd, device=DEV)
     T.colsum2_acc_(gu0, gv0, su, sv)
     gu1, gv1 = torch.zeros(H, hd, device=DEV), torch.zeros(H, hd, device=DEV)
