@@ -73,6 +73,8 @@ SIGNATURES = {
     "mi_cmvn_utterance": [vp, vp, i32, i32, i32, i32, i32, f32, vp],
     "mi_cmvn_global": [vp, i64, i32, vp, vp, vp],
     "mi_row_lse": [vp, i64, i32, i32, vp, i32, vp],
+    "mi_gemm_lse_f32": [vp, i64, vp, i64, vp, vp, i64, vp, vp, i32, i32, i32, vp],
+    "mi_gemm_lse_workspace_floats": [i32, i32],
     "mi_ctc_loss_fwd": [vp, i64, i64, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp],
     "mi_ctc_prefix_prepare": [vp, i64, i64, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp],
     "mi_ctc_prefix_score": [vp, i32, i32, i32, i32, i32, vp, vp, i64, i32, vp, vp, vp, vp],
@@ -163,6 +165,7 @@ SIGNATURES = {
     "mi_ebf_workspace_bytes": [C.POINTER(EbfConfig)],
     "mi_ebf_forward": [C.POINTER(EbfConfig), vp, vp, vp, vp, vp, i32, vp, sz, vp, vp, vp, vp, vp],
     "mi_ebf_forward_hs": [C.POINTER(EbfConfig), vp, vp, vp, vp, vp, i32, vp, sz, vp, vp, vp, vp, vp, vp],
+    "mi_ebf_forward_lse": [C.POINTER(EbfConfig), vp, vp, vp, vp, vp, i32, vp, sz, vp, vp, vp, vp, vp, vp, vp, vp],
 }
 
 _lib = None
@@ -190,7 +193,7 @@ def lib():
             fn.argtypes = args
             fn.restype = sz if name in ("mi_ebf_workspace_bytes", "mi_ctc_bwd_workspace_bytes", "mi_gemm_tn_workspace_bytes", "mi_layernorm_bwd_workspace_floats",
                                           "mi_colsum_workspace_floats", "mi_conv2d_first_bwd_workspace_floats", "mi_conv2d_s2k3_dgrad_elems", "mi_conv2d_first_wgrad_workspace_floats", "mi_embed_tokens_bwd_workspace_bytes",
-                                          "mi_gpt2_step_workspace_bytes") else i32
+                                          "mi_gpt2_step_workspace_bytes", "mi_gemm_lse_workspace_floats") else i32
         h.mi_profile_create.argtypes = [i32]; h.mi_profile_create.restype = i32
         h.mi_profile_enable.argtypes = [i32]; h.mi_profile_enable.restype = None
         h.mi_profile_reset.argtypes = []; h.mi_profile_reset.restype = None

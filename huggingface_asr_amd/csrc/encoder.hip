@@ -239,11 +239,17 @@ extern "C" size_t mi_ebf_workspace_bytes(const mi_ebf_config* cfg) { return carv
 // posp: (L, 2*T2-1, d) bf16 projected relative positions, (re)computed from pos_table when compute_posp != 0
 // hidden_states (nullable): (L+1, B*T2, d) fp32 = the tuple HF returns for output_hidden_states (tf:685-713): the input of every encoder layer, then the
 // encoder's last hidden state (after encoder.layer_norm); needs last_hidden.  Device-to-device copies on the same stream, only when asked for.
-extern "C" int mi_ebf_forward_hs(const mi_ebf_config* cfg, const void* const* weights, const float* feats,
-                                 const int* feat_lengths, const void* pos_table, void* posp, int compute_posp,
-                                 void* workspace, size_t workspace_bytes, float* last_hidden, void* logits,
-                                 int* inner_len, int* outer_len, float* hidden_states, hipStream_t st) {
+// lse / lse_workspace (both or neither; fp32 logits only): lse (B*T2) fp32 = the row log-sum-exp of the logits out of the head GEMM's epilogue (mi_gemm_lse_f32;
+// lse_workspace >= mi_gemm_lse_workspace_floats(B*T2, V+1) floats) — what the CTC loss needs beside the logits, without a second pass over them.
+extern "C" int mi_gemm_lse_f32(const void* A, long lda, const void* W, long ldw, const float* bias, float* C, long ldc, float* lse, float* workspace,
+                               int M, int N, int K, hipStream_t stream);
+extern "C" int mi_row_lse(const void* x, long ld, int dtype, int V, float* lse, int M, hipStream_t stream);
+extern "C" int mi_ebf_forward_lse(const mi_ebf_config* cfg, const void* const* weights, const float* feats,
+                                  const int* feat_lengths, const void* pos_table, void* posp, int compute_posp,
+                                  void* workspace, size_t workspace_bytes, float* last_hidden, void* logits,
+                                  int* inner_len, int* outer_len, float* hidden_states, float* lse, float* lse_workspace, hipStream_t st) {
     MI_ENTER();
+    if ((lse != nullptr) != (lse_workspace != nullptr) || (lse && (!logits || !cfg->logits_f32))) return MI_ERR_ARG;
     const mi_ebf_config& c = *cfg;
     if (hidden_states && !last_hidden) return MI_ERR_ARG;
     if (c.B <= 0 || c.T <= 0 || c.L <= 0 || c.d % c.H || c.I % 2) return MI_ERR_ARG;
@@ -472,13 +478,30 @@ extern "C" int mi_ebf_forward_hs(const mi_ebf_config* cfg, const void* const* we
                                    Lf(l + 1, MLP_LN_G), Lf(l + 1, MLP_LN_B), w.a2, d, M, d, st));
     }
     // CTC head: lm_head ⊕ blank_projection, blank LAST (e_branchformer.py:456-457)
-    if (logits)
-        RUN(mi_gemm_bf16(w.hid, d, Gw(G_HEAD_W), d, Gf(G_HEAD_B), 1, logits, c.logits_ld > 0 ? c.logits_ld : c.V + 1, c.logits_f32, nullptr, 0, 1.f, 0,
-                         M, c.V + 1, d, 0, 0, st));
+    if (logits) {
+        const long ldl = c.logits_ld > 0 ? c.logits_ld : c.V + 1;
+        int rc_l = MI_ERR_UNSUPPORTED;
+        if (lse) {
+            rc_l = mi_gemm_lse_f32(w.hid, d, Gw(G_HEAD_W), d, Gf(G_HEAD_B), (float*)logits, ldl, lse, lse_workspace, M, c.V + 1, d, st);
+            if (rc_l != MI_OK && rc_l != MI_ERR_UNSUPPORTED) return rc_l;
+        }
+        if (rc_l == MI_ERR_UNSUPPORTED) {
+            RUN(mi_gemm_bf16(w.hid, d, Gw(G_HEAD_W), d, Gf(G_HEAD_B), 1, logits, ldl, c.logits_f32, nullptr, 0, 1.f, 0, M, c.V + 1, d, 0, 0, st));
+            if (lse) RUN(mi_row_lse(logits, ldl, 0, c.V + 1, lse, M, st));
+        }
+    }
     if (hidden_states && hipMemcpyAsync(hidden_states + (size_t)c.L * M * d, last_hidden, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return MI_ERR_LAUNCH;
     MI_CHECK_LAUNCH();
     return MI_OK;
+}
+
+extern "C" int mi_ebf_forward_hs(const mi_ebf_config* cfg, const void* const* weights, const float* feats,
+                                 const int* feat_lengths, const void* pos_table, void* posp, int compute_posp,
+                                 void* workspace, size_t workspace_bytes, float* last_hidden, void* logits,
+                                 int* inner_len, int* outer_len, float* hidden_states, hipStream_t st) {
+    return mi_ebf_forward_lse(cfg, weights, feats, feat_lengths, pos_table, posp, compute_posp, workspace, workspace_bytes, last_hidden, logits, inner_len, outer_len,
+                              hidden_states, nullptr, nullptr, st);
 }
 
 extern "C" int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weights, const float* feats,

@@ -69,7 +69,7 @@ struct Ctx {
 // LNF (LayerNorm folded into the GEMM, gemm_args.hpp): the prologue reduces the per-row partial (sum, sumsq) pairs of the tile's 256 rows to (rstd, rstd * mean) in a 2-KiB LDS
 // table behind the ring — issued before the first K tile is consumed, so its memory round trip hides under the ring's fill — and the epilogue computes
 // rstd * acc - rstd * mean * s_n + bias_n instead of acc + bias_n.
-template <bool CONV, int ACT, bool OUT32 = false, bool GATED = false, bool LNF = false>     // ACT: 0 none, 1 erf-GELU, 2 tanh-GELU — compile-time, so the epilogue is straight-line code with many independent chains in flight
+template <bool CONV, int ACT, bool OUT32 = false, bool GATED = false, bool LNF = false, bool LSE = false>     // ACT: 0 none, 1 erf-GELU, 2 tanh-GELU — compile-time, so the epilogue is straight-line code with many independent chains in flight
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -319,6 +319,19 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
                     sm += dpp_f32<0x141, 0xF>(0.f, sm); sq += dpp_f32<0x141, 0xF>(0.f, sq);
                     sm += dpp_f32<0x140, 0xF>(0.f, sm); sq += dpp_f32<0x140, 0xF>(0.f, sq);
                     if (c16 == 0 && m < p.M) *reinterpret_cast<f32x2*>(p.stats_out + (long)m * LN_STATS_STRIDE + (((n0 >> 8) << 2) + wc) * 2) = f32x2{sm, sq};
+                }
+                if constexpr (LSE) {                        // the row's 64 columns of this wave block -> (max, sum exp(x - max)); columns >= N do not count
+                    float xe[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xe[e] = (n + e < p.N) ? xe[e] : -INFINITY;
+                    float mx = fmaxf(fmaxf(xe[0], xe[1]), fmaxf(xe[2], xe[3]));
+                    mx = fmaxf(mx, dpp_f32<0xB1, 0xF>(mx, mx)); mx = fmaxf(mx, dpp_f32<0x4E, 0xF>(mx, mx));
+                    mx = fmaxf(mx, dpp_f32<0x141, 0xF>(mx, mx)); mx = fmaxf(mx, dpp_f32<0x140, 0xF>(mx, mx));
+                    float se = 0.f;
+                    if (mx > -INFINITY) se = (__expf(xe[0] - mx) + __expf(xe[1] - mx)) + (__expf(xe[2] - mx) + __expf(xe[3] - mx));
+                    se += dpp_f32<0xB1, 0xF>(0.f, se); se += dpp_f32<0x4E, 0xF>(0.f, se);
+                    se += dpp_f32<0x141, 0xF>(0.f, se); se += dpp_f32<0x140, 0xF>(0.f, se);
+                    if (c16 == 0 && m < p.M) *reinterpret_cast<f32x2*>(p.lse_part + (long)m * p.lse_ld + ((n0 >> 6) + wc) * 2) = f32x2{mx, se};
                 }
                 if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four rows in flight at a time: all 128 accumulator registers are still live in the first half
             }
@@ -868,6 +881,7 @@ bool gemm_8p_supported(const GemmArgs& a, bool conv) {
     } else if (a.C2 || a.stats_out) {            // LayerNorm-fold producer on this tile: the fp32 residual form, at most 16 partial pairs per row (one per 64 columns)
         if (!a.out_f32 || !a.resid || a.N > 1024 || (a.C2 && (((uintptr_t)a.C2 & 7) || (a.ldc2 % 4))) || ((uintptr_t)a.stats_out & 7)) return false;
     }
+    if (a.lse_part && (conv || !a.out_f32 || a.resid || a.C2 || a.stats_out || a.act != 0 || ((uintptr_t)a.lse_part & 7) || (a.lse_ld % 2) || a.lse_ld < 8 * cdiv(a.N, TB))) return false;
     if ((long)a.N * a.ldw * 2 >= (1l << 32)) return false;                                             // 32-bit source offsets
     if (conv) {
         if ((a.Cin % BK) != 0 || a.Fout <= 0 || a.Tout <= 0) return false;
@@ -893,6 +907,12 @@ int gemm_8p_launch(const GemmArgs& a, bool conv, hipStream_t stream) {
         (void)attr_t;
         if (a.act == 3) launch_dense(PF_8P, gemm8p_kernel<false, 3>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
         else launch_dense(PF_8P_GELU, gemm8p_kernel<false, 4>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
+        return MI_OK;
+    }
+    if (a.out_f32 && a.lse_part) {
+        const bool attr_e = set_lds_attr(gemm8p_kernel<false, 0, true, false, false, true>, 2 * BUF);
+        (void)attr_e;
+        launch_dense(PF_8P_OUT32, gemm8p_kernel<false, 0, true, false, false, true>, dim3(grid), dim3(512), (size_t)2 * BUF, stream, a);
         return MI_OK;
     }
     if (a.out_f32) {

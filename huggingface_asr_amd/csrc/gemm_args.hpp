@@ -35,6 +35,10 @@ struct GemmArgs {
     //  act 3 (backward): C = dropout(bf16(acc)) * act'(aux), aux (M, N) bf16 = the saved pre-activation — the dX GEMM dh = dy W2 and mi_act_bwd in one launch
     //  act 4 (forward):  C = bf16(acc + bias) (the pre-activation, kept for the backward), C2 = dropout(act(C)) — the FFN-in GEMM and mi_act_fwd in one launch
     const bf16_t* aux; long ldaux; int aux_kind; float drop_p; unsigned long long drop_key;
+    // CTC-head form of the 256x256 kernel's fp32 epilogue (mi_gemm_lse_f32): per row and 64-column wave block one (max, sum of exp(x - max)) pair over the columns < N
+    // at lse_part[m * lse_ld + 2 * (n0 / 64 + wave column)] — the row log-sum-exp without a second pass over the (M, N) logits.  lse_ld >= 8 * ceil(N / 256); every pair
+    // of a row is written ((-inf, 0) for blocks entirely beyond N).
+    float* lse_part; int lse_ld;
 };
 constexpr int LN_STATS_STRIDE = 32;       // floats per row of a partial-statistics buffer (16 (sum, sumsq) pairs)
 

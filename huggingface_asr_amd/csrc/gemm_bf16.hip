@@ -377,3 +377,48 @@ extern "C" int mi_gemm_resid_stats_f32_v(const void* A, long lda, const void* W,
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
+
+// ---- CTC head with the row log-sum-exp out of the GEMM's epilogue: C (M,N) fp32 = A W^T + b on the 256x256 kernel, whose epilogue also leaves one
+// (max, sum exp(x - max)) pair per row and 64-column block in `workspace`; a second, small launch merges a row's pairs into lse[m] = log sum_n exp(C[m][n]) — what
+// mi_row_lse computes with a pass over the (M, N) logits (160 MB at 8000 x 5001).  The natural-log value; differs from mi_row_lse's in the order of the sums (<= 2 ulp).
+namespace {
+__global__ __launch_bounds__(256) void lse_merge_kernel(const float* __restrict__ part, int ld, int npair, float* __restrict__ lse, int M) {
+    const int g = threadIdx.x & 15;                                   // 16 lanes per row (one DPP row), 16 rows per block
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const float* pr = part + (long)min(row, M - 1) * ld;
+    float mx = -INFINITY;
+    for (int t = g; t < npair; t += 16) mx = fmaxf(mx, pr[2 * t]);
+    mx = fmaxf(mx, dpp_f32<0xB1, 0xF>(mx, mx)); mx = fmaxf(mx, dpp_f32<0x4E, 0xF>(mx, mx));
+    mx = fmaxf(mx, dpp_f32<0x141, 0xF>(mx, mx)); mx = fmaxf(mx, dpp_f32<0x140, 0xF>(mx, mx));
+    float s = 0.f;
+    for (int t = g; t < npair; t += 16) {
+        const f32x2 q = *reinterpret_cast<const f32x2*>(pr + 2 * t);
+        if (q.x > -INFINITY) s += q.y * __expf(q.x - mx);
+    }
+    s += dpp_f32<0xB1, 0xF>(0.f, s); s += dpp_f32<0x4E, 0xF>(0.f, s);
+    s += dpp_f32<0x141, 0xF>(0.f, s); s += dpp_f32<0x140, 0xF>(0.f, s);
+    if (g == 0 && row < M) lse[row] = mx + __logf(s);
+}
+}  // namespace
+
+extern "C" size_t mi_gemm_lse_workspace_floats(int M, int N) { return (size_t)(M > 0 ? M : 0) * 8 * (size_t)((N + 255) / 256); }
+
+// MI_ERR_UNSUPPORTED: the shape is outside the 256x256 kernel (the caller runs mi_gemm_bf16 + mi_row_lse).
+extern "C" int mi_gemm_lse_f32(const void* A, long lda, const void* W, long ldw, const float* bias, float* C, long ldc, float* lse, float* workspace,
+                               int M, int N, int K, hipStream_t stream) {
+    MI_ENTER();
+    if (!A || !W || !C || !lse || !workspace) return MI_ERR_ARG;
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw; a.bias = bias; a.bias_mode = bias ? 1 : 0;
+    a.C = C; a.ldc = ldc; a.out_f32 = 1; a.alpha = 1.f; a.act = 0; a.M = M; a.N = N; a.K = K;
+    a.lse_part = workspace; a.lse_ld = 8 * ((N + 255) / 256);
+    if (!gemm_8p_supported(a, false)) return MI_ERR_UNSUPPORTED;
+    const int slot = mi_profile_hook_begin(stream, 2.0 * M * N * K);
+    const int rc = gemm_8p_launch(a, false, stream);
+    if (slot >= 0) mi_profile_hook_end(slot, stream);
+    if (rc != MI_OK) return rc;
+    MI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(lse_merge_kernel, dim3((M + 15) / 16), dim3(256), 0, stream, workspace, a.lse_ld, a.lse_ld / 2, lse, M);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}

@@ -254,7 +254,7 @@ class JointAEDEngine:
         enc_out, enc_bf, T2, key_len = self.encode(feats, feat_len)
         enc_loss, _, _ = ops.ctc_loss(enc_out["logits"], labels, enc_out["outer_len"],
                                       reduction=self.enc.cfg.get("ctc_loss_reduction", "mean"),
-                                      zero_infinity=self.enc.cfg.get("ctc_zero_infinity", False))
+                                      zero_infinity=self.enc.cfg.get("ctc_zero_infinity", False), lse=enc_out.get("lse"))
         dec_ids = shift_tokens_right(labels, c["pad_token_id"], c["decoder_start_token_id"])
         d = self.dec.forward(dec_ids, enc_bf, T2, key_len, labels)
         w = c["ctc_weight"]

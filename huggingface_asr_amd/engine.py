@@ -88,6 +88,7 @@ class EBranchformerEngine:
         self.ln_fold = None if env is None else env == "1"
         # throughput mode (mi_ebf_config.wide_tiles; pipeline.ForwardPipeline sets it): the N = d GEMMs on 256 x 256 tiles — for several steps in flight, not for one alone
         self.wide_tiles = False
+        self.head_lse = True                      # fp32 logits come with their row log-sum-exp out of the head GEMM's epilogue (bench.py --no-head-lse: the pass of its own)
         self.weights = {}
         self._table = None
         self._ws = {}
@@ -325,11 +326,16 @@ class EBranchformerEngine:
         if feat_lengths is not None:
             feat_lengths = feat_lengths.to(device=self.device, dtype=torch.int32).contiguous()
         p = lambda t: None if t is None else t.data_ptr()
-        rc = _lib.lib().mi_ebf_forward_hs(C.byref(cs), self._table, feats.data_ptr(), p(feat_lengths), p(pos), p(posp), compute,
-                                          ws.data_ptr(), ws.numel(), p(hidden), p(lbuf), lens[0].data_ptr(), lens[1].data_ptr(), p(hs),
-                                          torch.cuda.current_stream().cuda_stream)
+        # fp32 logits come with their rows' log-sum-exp (B*T2) out of the head GEMM's epilogue: `ops.ctc_loss(..., lse=out["lse"])` then needs no pass of its own over them
+        lse = lse_ws = None
+        if want_logits and self.logits_dtype == torch.float32 and self.head_lse:
+            lse = torch.empty((B * T2,), dtype=torch.float32, device=self.device)
+            lse_ws = torch.empty((int(_lib.lib().mi_gemm_lse_workspace_floats(B * T2, V1)),), dtype=torch.float32, device=self.device)
+        rc = _lib.lib().mi_ebf_forward_lse(C.byref(cs), self._table, feats.data_ptr(), p(feat_lengths), p(pos), p(posp), compute,
+                                           ws.data_ptr(), ws.numel(), p(hidden), p(lbuf), lens[0].data_ptr(), lens[1].data_ptr(), p(hs), p(lse), p(lse_ws),
+                                           torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "mi_ebf_forward")
-        out = dict(logits=logits, last_hidden=hidden, inner_len=lens[0], outer_len=lens[1])
+        out = dict(logits=logits, last_hidden=hidden, inner_len=lens[0], outer_len=lens[1], lse=lse)
         if hs is not None:
             out["hidden_states"] = tuple(hs[i] for i in range(hs.shape[0]))
         return out

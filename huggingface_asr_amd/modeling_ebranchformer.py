@@ -288,7 +288,7 @@ class Wav2Vec2EBranchformerForCTC(PreTrainedModel):
             if labels.max() >= self.config.vocab_size:      # same check / same sync point as e_branchformer.py:461-462
                 raise ValueError(f"Label values must be <= vocab_size: {self.config.vocab_size}")
             loss, _, _ = ops.ctc_loss(logits, labels.to(logits.device), out["outer_len"],
-                                      reduction=self.config.ctc_loss_reduction, zero_infinity=self.config.ctc_zero_infinity)
+                                      reduction=self.config.ctc_loss_reduction, zero_infinity=self.config.ctc_zero_infinity, lse=out.get("lse"))
         hidden_states = out["hidden_states"] if output_hidden_states else None          # L + 1 tensors, as HF (tf:685-713)
         if not return_dict:
             output = (logits,) + ((hidden_states,) if hidden_states is not None else ())

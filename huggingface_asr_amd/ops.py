@@ -318,6 +318,23 @@ def dwconv_residual(m, w, bias, B, T, pad_left=None):
     return out
 
 
+def gemm_lse(a, w, bias, out):
+    """the CTC head in one pass over its logits: out (M, ld >= N) fp32 [:, :N] = a W^T + b, N = w.shape[0], and -> lse (M) fp32 = the rows' log-sum-exp over those N
+    columns, out of the GEMM's epilogue (mi_gemm_lse_f32); shapes outside that kernel: the GEMM followed by row_lse."""
+    _req(a, BF16); _req(w, BF16)
+    M, K = a.shape
+    N = w.shape[0]
+    L = _lib.lib()
+    lse = torch.empty((M,), device=a.device, dtype=torch.float32)
+    ws = torch.empty((int(L.mi_gemm_lse_workspace_floats(M, N)),), device=a.device, dtype=torch.float32)
+    rc = L.mi_gemm_lse_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _p(bias), out.data_ptr(), out.stride(0), lse.data_ptr(), ws.data_ptr(), M, N, K, _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        gemm(a, w, bias, out=out)
+        return row_lse(out[:, :N])
+    _lib.check(rc, "mi_gemm_lse_f32")
+    return lse
+
+
 def row_lse(x):
     M, V = x.shape
     out = torch.empty((M,), device=x.device, dtype=torch.float32)

@@ -765,9 +765,8 @@ class EncoderCTCTrainer:
             if pd["final"] > 0:
                 T.dropout_(hid, pd["final"], seed, self._sid(L, 2))
             lbuf = e32(B, T2, ldl)
-            ops.gemm(hid, W("head_w"), P("head_b"), out=lbuf.view(M, ldl))
+            lse = ops.gemm_lse(hid, W("head_w"), P("head_b"), lbuf.view(M, ldl))       # logits and their row log-sum-exp from one pass (the GEMM's epilogue)
             logits = lbuf[..., :V1]
-            lse = ops.row_lse(lbuf.view(M, ldl)[:, :V1])
             if labels is not None:
                 loss, nll, _ = ops.ctc_loss(logits, labels, outer, reduction=red, zero_infinity=bool(c.get("ctc_zero_infinity", False)), lse=lse)
             elif backward:

@@ -231,6 +231,13 @@ int mi_cmvn_global(float* x, long total, int nmel, const float* means, const flo
 
 /* ---- CTC tail. replaces: log_softmax + F.ctc_loss at e_branchformer.py:472-488. */
 int mi_row_lse(const void* x, long ld, int dtype, int V, float* lse, int M, mi_stream_t stream);
+/* the CTC head (reference e_branchformer.py:456-457, 472-488: lm_head + blank projection, then log_softmax) as ONE pass over the logits: C (M,N) fp32 = A W^T + b with
+ * the rows' log-sum-exp lse (M) — the GEMM's epilogue leaves a (max, sum exp) pair per row and 64 columns in `workspace` (mi_gemm_lse_workspace_floats(M, N) floats), a small
+ * second launch merges them.  lse equals mi_row_lse's up to the order of the sums.  MI_ERR_UNSUPPORTED outside the 256 x 256 kernel's shapes (K % 64, K >= 128, 16-B aligned
+ * operands, ldc % 4 == 0): the caller runs mi_gemm_bf16 + mi_row_lse. */
+size_t mi_gemm_lse_workspace_floats(int M, int N);
+int mi_gemm_lse_f32(const void* A, long lda, const void* W, long ldw, const float* bias, float* C, long ldc, float* lse, float* workspace,
+                    int M, int N, int K, mi_stream_t stream);
 int mi_ctc_loss_fwd(const void* logits, long ld_b, long ld_t, int dtype, const float* lse, int T,
                     const long* labels, int U, const int* in_len, int blank, int B,
                     int reduction, int zero_infinity, float* nll, int* tgt_len, float* loss, mi_stream_t stream);
@@ -550,6 +557,13 @@ int mi_ebf_forward(const mi_ebf_config* cfg, const void* const* weights, const f
 int mi_ebf_forward_hs(const mi_ebf_config* cfg, const void* const* weights, const float* feats, const int* feat_lengths,
                       const void* pos_table, void* posp, int compute_posp, void* workspace, size_t workspace_bytes,
                       float* last_hidden, void* logits, int* inner_len, int* outer_len, float* hidden_states, mi_stream_t stream);
+/* the same, additionally leaving lse (B*T2) fp32 = the row log-sum-exp of the fp32 logits (the log_softmax of reference e_branchformer.py:472-488 is never materialised: the
+ * CTC loss takes the logits and this vector) out of the head GEMM's epilogue — mi_gemm_lse_f32; lse_workspace: mi_gemm_lse_workspace_floats(B*T2, V+1) floats.
+ * lse and lse_workspace both or neither; needs fp32 logits. */
+int mi_ebf_forward_lse(const mi_ebf_config* cfg, const void* const* weights, const float* feats, const int* feat_lengths,
+                       const void* pos_table, void* posp, int compute_posp, void* workspace, size_t workspace_bytes,
+                       float* last_hidden, void* logits, int* inner_len, int* outer_len, float* hidden_states,
+                       float* lse, float* lse_workspace, mi_stream_t stream);
 
 #ifdef __cplusplus
 }

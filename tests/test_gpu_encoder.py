@@ -187,6 +187,37 @@ def test_no_attention_mask_and_batch_invariance():
     torch.testing.assert_close(one[0], a[0], atol=0, rtol=0)
 
 
+@pytest.mark.parametrize("size", ["tiny", "base"])
+def test_forward_returns_the_logits_row_log_sum_exp(size):
+    """engine.forward(...)["lse"] (the head GEMM's epilogue, mi_ebf_forward_lse; the tiny config's head is outside that kernel and takes the GEMM + mi_row_lse route
+    behind the same entry): equal to the log-sum-exp of the returned logits, and the CTC loss computed with it equals the loss computed from the logits alone"""
+    from huggingface_asr_amd import ops, synth
+    from huggingface_asr_amd.engine import EBranchformerEngine
+    if size == "tiny":
+        cfg = _cfg(shapes.TINY)
+        g = load_golden("tiny_rel")
+        sd, x, am, lab = case_inputs(g, cfg)
+        lens = am.sum(-1).to(DEV, torch.int32)
+        x, lab = x.to(DEV), lab.to(DEV)
+    else:
+        cfg = _cfg(shapes.BASE)
+        sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(shapes.param_shapes(cfg), 3).items()}
+        B, T = 8, 1000
+        x = torch.from_numpy(synth.normal(5, "feats", (B, T, 80), 1.0)).to(DEV)
+        lens = torch.tensor([1000, 998, 900, 777, 640, 512, 300, 120], dtype=torch.int32, device=DEV)
+        lab = torch.from_numpy(synth.labels(1, B, 12, cfg["vocab_size"], lo=5)).to(DEV)
+    eng = EBranchformerEngine(cfg, DEV)
+    eng.load_state_dict(sd)
+    out = eng.forward(x, lens, want_hidden=False)
+    lg = out["logits"]
+    Bz, T2, V1 = lg.shape
+    want = torch.logsumexp(lg.double(), dim=-1).reshape(-1)
+    torch.testing.assert_close(out["lse"].double(), want, rtol=2e-6, atol=2e-6)
+    l1 = ops.ctc_loss(lg, lab, out["outer_len"], reduction="mean", zero_infinity=True, lse=out["lse"])[0]
+    l0 = ops.ctc_loss(lg, lab, out["outer_len"], reduction="mean", zero_infinity=True)[0]
+    torch.testing.assert_close(l1, l0, rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("overlap", [False, True])
 def test_forward_is_bit_reproducible_at_the_bench_size(overlap):
     """The whole forward gives identical bits run after run, also when issued from a non-default stream: every reduction in it has a

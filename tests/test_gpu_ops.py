@@ -52,6 +52,26 @@ def test_gemm_plain(M, N, K):
     assert_close_bf16(got16, want, what="gemm bf16")
 
 
+@pytest.mark.parametrize("M,N,K,ld", [(777, 5001, 512, 5056), (8000, 5001, 512, 5004), (300, 300, 256, 304), (256, 256, 128, 256), (100, 5001, 64, 5004), (513, 1030, 192, 1032)])
+def test_ctc_head_gemm_leaves_the_row_log_sum_exp(M, N, K, ld):
+    """mi_gemm_lse_f32 (the CTC head, e_branchformer.py:456-457 + the log_softmax of :472-488): the logits are bit-identical to the plain fp32-out GEMM's, the row
+    log-sum-exp from the epilogue's per-64-column (max, sum exp) pairs agrees with fp64 log-sum-exp of those logits to 2e-6 relative and with mi_row_lse to the order of the
+    sums — ragged N (5001 = 19 tiles + 137 columns), ragged M, large logits (no overflow: the pairs carry their own maximum), a K outside the kernel (falls back)."""
+    ops = _ops()
+    a = rnd(M, K, seed=1, scale=3.0).to(DEV, torch.bfloat16)
+    w = rnd(N, K, seed=2, scale=2.0 / math.sqrt(K)).to(DEV, torch.bfloat16)
+    b = (5.0 * rnd(N, seed=3)).to(DEV)
+    out = torch.full((M, ld), float("nan"), device=DEV)
+    lse = ops.gemm_lse(a, w, b, out)
+    ref = torch.empty((M, ld), device=DEV)
+    ops.gemm(a, w, b, out=ref)
+    assert torch.equal(out[:, :N], ref[:, :N])
+    want = torch.logsumexp(ref[:, :N].double(), dim=1)
+    torch.testing.assert_close(lse.double(), want, rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(lse, ops.row_lse(ref[:, :N]), rtol=2e-6, atol=2e-6)
+    assert float(ref[:, :N].abs().max()) > 20.0                    # the logits are large enough that a sum of exp without the running maximum would lose digits
+
+
 def test_gemm_identity_asymmetric():
     """A = I with an asymmetric W catches a transposed C write (guide §3)."""
     ops = _ops()
