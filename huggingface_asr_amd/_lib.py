@@ -129,6 +129,7 @@ SIGNATURES = {
     "mi_conv2d_wgrad_cl_bf16": [vp, i64, vp, vp, i64, vp] + [i32] * 13 + [vp, C.c_size_t, vp],
     "mi_gemm_resid_stats_f32_v": [vp, i64, vp, i64, vp, vp, i64, vp, i64, f32, vp, i64, vp, i32, i32, i32, i32, vp],
     "mi_gemm_tn_group_bf16": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
+    "mi_gemm_tn_group_ow_bf16": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "mi_bgemm_bf16": [vp, i64, i64, i64, i64, vp, i64, i64, i64, i64, vp, i64, i64, i64, i32, i32, f32, i32, i32, i32, i32, i32, vp],
     "mi_bgemm_sparse_bf16": [vp, i64, i64, i64, i64, vp, i64, i64, i64, i64, vp, i64, i64, i64, i32, i32, f32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "mi_bgemm_band_bf16": [vp, i64, i64, i64, i64, vp, i64, i64, i64, i64, vp, i64, i64, i64, i32, i32, f32, i32, i32, i32, i32, i32, i32, i32, i32, vp],

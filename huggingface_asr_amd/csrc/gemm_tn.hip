@@ -44,6 +44,8 @@ struct TnArgs {
     // X[b][to * cst - cpt + kh][fo * cst - cpf + kw][c] (zero outside): the im2col operand of a Conv2d weight gradient, gathered by the LDS-DMA source addresses
     // instead of being written to HBM first (Cin a multiple of the k tile: a tile's columns stay inside one tap)
     int conv, Tin, Fin, Cin, Tout, Fout, KW, cst, cpt, cpf;
+    int overwrite;                 // splits == 1: dW = / db = instead of += (the caller knows the targets hold zeros: a training step's first backward after zero_grad) — the
+                                   // epilogue then only stores; it otherwise ends with a dependent load -> add -> store of the whole output tile
 };
 
 // 16-B chunk swizzle of a tile row.  256-B rows (16 chunks): chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)) — the transposed read's 32-lane half takes 4 consecutive rows x
@@ -318,6 +320,7 @@ __device__ __forceinline__ void tn_tile(const TnArgs& pin, const int bid) {
         if (tid < TNN && n0 + tid < p.n_store) {
             const float v = red[2 * tid] + red[2 * tid + 1];
             if (p.db_slab) p.db_slab[(long)split * p.N + n0 + tid] = v;
+            else if (p.overwrite) p.db[n0 + tid] = v;
             else p.db[n0 + tid] += v;
         }
     }
@@ -335,7 +338,7 @@ __device__ __forceinline__ void tn_tile(const TnArgs& pin, const int bid) {
                 const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (n >= p.n_store) continue;
                 float* o = outp + (long)n * p.ldo + k;
-                if (p.splits > 1) *o = acc[i][j][r];
+                if (p.splits > 1 || p.overwrite) *o = acc[i][j][r];
                 else *o += acc[i][j][r];
             }
         }
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(TnArgs p) { tn_tile<25
 constexpr int TN_GROUP = 48;
 // 64-B problem descriptors: 48 of them + the tile prefix table stay under the 4-KiB kernel-argument segment (the small encoder's layers have ~50 tiles each: its
 // problems are gathered over several layers, and the attention decoder's 46 over its whole backward, before a launch fills the chip)
-struct TnDesc { const bf16_t* Y; const bf16_t* X; float* out; float* db; int ldy, ldx, ldo, M, N, K, n_store, pad_; };
+struct TnDesc { const bf16_t* Y; const bf16_t* X; float* out; float* db; int ldy, ldx, ldo, M, N, K, n_store, overwrite; };
 struct TnGroup { TnDesc a[TN_GROUP]; int tile0[TN_GROUP + 1]; int n; };
 
 constexpr int TN_GROUP_N = 256;                            // 256 (n) x XW (k) tiles, 8 waves: one block per CU, two waves per SIMD
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroup g) {
     TnArgs p;
     p.Y = q.Y; p.ldy = q.ldy; p.X = q.X; p.ldx = q.ldx; p.out = q.out; p.ldo = q.ldo; p.slab_stride = 0; p.db = q.db; p.db_slab = nullptr;
     p.M = q.M; p.N = q.N; p.K = q.K; p.n_store = q.n_store; p.splits = 1; p.rows_per_split = (q.M + TN_KM - 1) / TN_KM * TN_KM;
-    p.conv = 0; p.Tin = p.Fin = p.Cin = p.Tout = p.Fout = p.KW = 1; p.cst = 1; p.cpt = p.cpf = 0;
+    p.conv = 0; p.Tin = p.Fin = p.Cin = p.Tout = p.Fout = p.KW = 1; p.cst = 1; p.cpt = p.cpf = 0; p.overwrite = q.overwrite;
     tn_tile<TN_GROUP_N, XW, NS, false>(p, bid - __builtin_amdgcn_readfirstlane(g.tile0[iu]));
 }
 
@@ -514,8 +517,10 @@ extern "C" int mi_conv2d_wgrad_cl_bf16(const void* dY, long ldy, const void* x, 
 // The grouped form (see gemm_tn_group_kernel): n <= 48 problems, each dW_i (n_store_i, K_i) fp32 (row stride ldo_i) += dY_i[:, :N_i]^T X_i with optional bias gradient db_i,
 // ONE launch, no M-split, no workspace.  tile_k: k extent of the 256-row output tiles — 128, 256, or 0 = 256 when that still gives >= 200 tiles, else 128.  Arrays of length n on the HOST.  Same operand constraints as mi_gemm_tn_bf16.  Meant for >= ~256 output tiles in total
 // (sum of ceil(N_i / 128) * ceil(K_i / 128)); with fewer the chip is under-filled: use mi_gemm_tn_bf16 per problem.
-extern "C" int mi_gemm_tn_group_bf16(int n, const void* const* dY, const long* ldy, const void* const* X, const long* ldx, float* const* dW, const long* ldo,
-                                     float* const* db, const int* M, const int* N, const int* K, const int* n_store, int tile_k, hipStream_t st) {
+// overwrite != 0: every dW_i / db_i is WRITTEN (= instead of +=): for targets the caller knows to hold zeros — the first backward after the gradients were cleared, each
+// target the output of exactly one problem; the kernel's epilogue then has no read of the output tile in it.
+extern "C" int mi_gemm_tn_group_ow_bf16(int n, const void* const* dY, const long* ldy, const void* const* X, const long* ldx, float* const* dW, const long* ldo,
+                                        float* const* db, const int* M, const int* N, const int* K, const int* n_store, int tile_k, int overwrite, hipStream_t st) {
     MI_ENTER();
     if (n <= 0 || n > TN_GROUP) return MI_ERR_ARG;
     TnGroup g{};
@@ -533,7 +538,7 @@ extern "C" int mi_gemm_tn_group_bf16(int n, const void* const* dY, const long* l
     for (int i = 0; i < n; ++i) {
         TnDesc& p = g.a[i];
         p.Y = (const bf16_t*)dY[i]; p.ldy = (int)ldy[i]; p.X = (const bf16_t*)X[i]; p.ldx = (int)ldx[i];
-        p.M = M[i]; p.N = N[i]; p.K = K[i]; p.n_store = n_store[i]; p.db = db ? db[i] : nullptr;
+        p.M = M[i]; p.N = N[i]; p.K = K[i]; p.n_store = n_store[i]; p.db = db ? db[i] : nullptr; p.overwrite = overwrite ? 1 : 0;
         p.out = dW[i]; p.ldo = (int)ldo[i];
         g.tile0[i] = tiles;
         tiles += cdiv(N[i], TN_GROUP_N) * cdiv(K[i], xw);
@@ -550,4 +555,8 @@ extern "C" int mi_gemm_tn_group_bf16(int n, const void* const* dY, const long* l
     }
     MI_CHECK_LAUNCH();
     return MI_OK;
+}
+extern "C" int mi_gemm_tn_group_bf16(int n, const void* const* dY, const long* ldy, const void* const* X, const long* ldx, float* const* dW, const long* ldo,
+                                     float* const* db, const int* M, const int* N, const int* K, const int* n_store, int tile_k, hipStream_t st) {
+    return mi_gemm_tn_group_ow_bf16(n, dY, ldy, X, ldx, dW, ldo, db, M, N, K, n_store, tile_k, 0, st);
 }

@@ -679,6 +679,7 @@ class TnBatch:
 
     def __init__(self):
         self.items = []
+        self.overwrite = False          # set by the trainer for the first backward after zero_grad: the grouped launch writes its targets instead of adding into them
 
     def add(self, dw, dy, x, n_store, db):
         self.items.append((dw, dy, x, n_store, db))
@@ -705,13 +706,16 @@ class TnBatch:
         import ctypes as C
         n = len(items)
         vp, lg, it = (C.c_void_p * n), (C.c_long * n), (C.c_int * n)
-        _lib.check(_L().mi_gemm_tn_group_bf16(
+        # overwrite: only when every target of this launch is named once in it (a weight hit twice — tied, or two slices of one matrix are fine, two problems into the
+        # SAME rows are not — must accumulate)
+        ow = bool(self.overwrite) and len({dw.data_ptr() for dw, _, _, _, _ in items}) == n and len({db.data_ptr() for _, _, _, _, db in items if db is not None}) == sum(db is not None for _, _, _, _, db in items)
+        _lib.check(_L().mi_gemm_tn_group_ow_bf16(
             n, vp(*[dy.data_ptr() for _, dy, _, _, _ in items]), lg(*[dy.stride(0) for _, dy, _, _, _ in items]),
             vp(*[x.data_ptr() for _, _, x, _, _ in items]), lg(*[x.stride(0) for _, _, x, _, _ in items]),
             vp(*[dw.data_ptr() for dw, _, _, _, _ in items]), lg(*[dw.stride(0) for dw, _, _, _, _ in items]),
             vp(*[(db.data_ptr() if db is not None else None) for _, _, _, _, db in items]),
             it(*[dy.shape[0] for _, dy, _, _, _ in items]), it(*[dy.shape[1] for _, dy, _, _, _ in items]), it(*[x.shape[1] for _, _, x, _, _ in items]),
-            it(*[ns for _, _, _, ns, _ in items]), int(tile_k), _stream()), "mi_gemm_tn_group_bf16")
+            it(*[ns for _, _, _, ns, _ in items]), int(tile_k), int(ow), _stream()), "mi_gemm_tn_group_bf16")
         return True
 
 

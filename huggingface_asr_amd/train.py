@@ -143,6 +143,7 @@ class ParamStore:
 
     def zero_grad(self):
         self.flat_g.zero_()
+        self.fresh = True               # every gradient is exactly zero: the next backward's grouped weight-gradient launches may WRITE their targets (EncoderCTCTrainer.dw_overwrite)
 
 
 def ops_cast_flat(src_f32, dst_bf16):
@@ -375,6 +376,7 @@ class EncoderCTCTrainer:
         # fused CSGU kernels cover the reference recipes' form (identity activation, no Linear); anything else runs split: conv -> [Linear] -> act * gate
         self.csgu_split = self.csgu_lin or self.csgu_act != 0
         self.dual_ln = True                       # the two branch norms' backward in one pass (tools/train_bench.py --no-dual-ln measures the two-pass form beside it)
+        self.dw_overwrite = os.environ.get("HFASR_DW_OVERWRITE", "1") != "0"      # see _forward_backward (HFASR_DW_OVERWRITE=0 / tools/train_bench.py --no-dw-overwrite: always accumulate)
         self.walk_qb = True                       # q + u / q + v of the attention backward from the fused walk's prologue (--no-walk-qb: the pass of their own)
         self.frozen = set()
         self.layerdrop = float(c.get("layerdrop", 0.0) or 0.0)      # tf:models/wav2vec2_conformer/modeling_wav2vec2_conformer.py:686-690
@@ -580,6 +582,11 @@ class EncoderCTCTrainer:
         if getattr(self, "_tnb", None) is None:
             self._tnb = T.TnBatch()
         self._tnb.items = []
+        # first backward after zero_grad: every layer matrix is the target of exactly one weight-gradient problem, so the grouped launches write dW / db instead of adding
+        # into the zeros (their epilogue otherwise ends with a dependent read of the output tile: 516 MB per step at the base size); any later backward accumulates
+        self._tnb.overwrite = bool(backward and self.dw_overwrite and getattr(self.store, "fresh", False))
+        if backward:
+            self.store.fresh = False
         self._ranges_waiting = []
         P, G, W, WT = st.p, st.g, st.bf, st.bfT
         GL = lambda n, sl=None: None if n in self.frozen else (st.g(n) if sl is None else st.g(n)[sl])      # gradient of a linear's weight / bias, None when frozen

@@ -336,6 +336,10 @@ class JointAEDTrainer:
         # ---- backward of the last head
         dhid = ops.gemm(dl, WT(lm_name))
         tnb = T.TnBatch()            # every weight gradient of the decoder's backward: one grouped launch at the end (46 problems, ~150 output tiles at 6 x 256)
+        # first backward after zero_grad: the launch writes its targets instead of adding into the zeros (train.EncoderCTCTrainer._forward_backward); the embedding
+        # gradient — the one other contribution to a matrix of this store (wte, tied to the lm head) — is therefore added AFTER the flush below
+        tnb.overwrite = bool(self.enc.dw_overwrite and getattr(st, "fresh", False))
+        st.fresh = False
         T.gemm_tn_(G(lm_name), dl, hid, n_store=V, defer=tnb)
         tap_grads, final_dys = {}, [dhid]
         for k, loc in enumerate(locs):
@@ -395,12 +399,12 @@ class JointAEDTrainer:
             T.axpy_(dx, tap_grads[0])
         if pe > 0:
             T.dropout_(dx, pe, seed, sid(63, 0))
-        T.embed_tokens_bwd(ids, dx, G("wte"), None if self.pos_fixed is not None else G("wpe"), scale=self.emb_scale, heavy_id=self.jcfg.get("pad_token_id"))
         if self.with_proj:
             dh = T.linear_bwd(T.add_cast(denc), hb, WT("proj_w"), dw=G("proj_w"), db=G("proj_b"), dx_dtype=F32, defer=tnb)
         else:
             dh = denc
         tnb.flush()
+        T.embed_tokens_bwd(ids, dx, G("wte"), None if self.pos_fixed is not None else G("wpe"), scale=self.emb_scale, heavy_id=self.jcfg.get("pad_token_id"))
         self.sync.launch(0, st.n)
         out.update(dec_loss=dec_loss, logits=logits, encoder_hidden=enc_bf)
         return dh

@@ -373,6 +373,10 @@ int mi_conv2d_wgrad_cl_bf16(const void* dY, long ldy, const void* x, float* dW, 
  * chip without splitting M, so every block adds its tile into dW in place: no slabs, no reduce pass, no workspace.  Use it for >= ~256 tiles in total. */
 int mi_gemm_tn_group_bf16(int n, const void* const* dY, const long* ldy, const void* const* X, const long* ldx, float* const* dW, const long* ldo,
                           float* const* db, const int* M, const int* N, const int* K, const int* n_store, int tile_k, mi_stream_t stream);
+/* the same with overwrite != 0: every dW_i / db_i is written (= instead of +=) — for targets known to hold zeros (a training step's first backward after the gradients
+ * were cleared; each target the output of exactly one problem): the kernel's epilogue then has no dependent read of its output tile */
+int mi_gemm_tn_group_ow_bf16(int n, const void* const* dY, const long* ldy, const void* const* X, const long* ldx, float* const* dW, const long* ldo,
+                             float* const* db, const int* M, const int* N, const int* K, const int* n_store, int tile_k, int overwrite, mi_stream_t stream);
 /* (tile_k: k extent of the 256-row output tiles: 128, 256, or 0 = 256 when the problems then still have >= 200 tiles between them, else 128) */
 /* strided batched GEMM C[z1,z2] = alpha * A[z1,z2] · B[z1,z2]^T (+ C): the per-(utterance, head) products of attention backward */
 int mi_bgemm_bf16(const void* A, long a_z1, long a_z2, long a_m, long a_k, const void* B, long b_z1, long b_z2, long b_n, long b_k,
