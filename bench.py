@@ -166,7 +166,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 32 forward / 96 --train)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-head-lse", action="store_true", help="the CTC loss's row log-sum-exp by a pass of its own over the logits (the form before round 4's last change), for a same-box A/B")
+    ap.add_argument("--head-lse", action="store_true", help="the CTC loss's row log-sum-exp out of the head GEMM's epilogue (mi_ebf_forward_lse) instead of a pass of its own over the logits: same-box A/B (tools/head_lse_ab.sh)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the separate HIP-event pass over the dense GEMM launches (roofline leg)")
     ap.add_argument("--event-steps", type=int, default=5, help="steps of the separate roofline pass (every dense launch timed, stride 1; never inside the timed region)")
     ap.add_argument("--keep-profile", default=None, help="directory that receives the kernel_stats.csv of the roofline leg's rocprofv3 child run")
@@ -533,9 +533,9 @@ def main():
     if args.wide_tiles:                      # the one-step-at-a-time comparison and the per-kernel roofline leg run the product's own tiles (wide tiles are for steps in flight)
         eng = EBranchformerEngine(cfg, dev)
         eng.load_state_dict(sd)
-    if args.no_head_lse:
+    if args.head_lse:
         for e_ in list(pipe.engines) + [eng]:
-            e_.head_lse = False
+            e_.head_lse = True
     B = args.batch or BATCH
     wave = torch.from_numpy(synth.waveforms(100 + rank, B, SR * SECONDS)).to(dev)       # resident in HBM
     labels = torch.from_numpy(synth.labels(rank, B, U, cfg["vocab_size"])).to(dev)
@@ -545,7 +545,7 @@ def main():
     def step(e=eng, w=wave, lab=labels):
         feats, frames = FB.fbank_gpu(w, tables, pad_frames_to=100)
         out = e.forward(feats, frames, want_hidden=False)
-        loss, _, _ = ops.ctc_loss(out["logits"], lab, out["outer_len"], reduction="mean", zero_infinity=True, lse=out["lse"])     # lse: out of the head GEMM's epilogue
+        loss, _, _ = ops.ctc_loss(out["logits"], lab, out["outer_len"], reduction="mean", zero_infinity=True, lse=out["lse"])     # lse: None (a pass over the logits inside ctc_loss) unless --head-lse
         return loss
 
     batches = [(wave, labels)] + [(torch.from_numpy(synth.waveforms(100 + rank + 1000 * i, B, SR * SECONDS)).to(dev),

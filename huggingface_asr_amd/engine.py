@@ -88,7 +88,8 @@ class EBranchformerEngine:
         self.ln_fold = None if env is None else env == "1"
         # throughput mode (mi_ebf_config.wide_tiles; pipeline.ForwardPipeline sets it): the N = d GEMMs on 256 x 256 tiles — for several steps in flight, not for one alone
         self.wide_tiles = False
-        self.head_lse = True                      # fp32 logits come with their row log-sum-exp out of the head GEMM's epilogue (bench.py --no-head-lse: the pass of its own)
+        self.head_lse = False                     # True: fp32 logits come with their row log-sum-exp out of the head GEMM's epilogue (`out["lse"]`, mi_ebf_forward_lse). Built for VERDICT r3
+                                                  # item 7 and measured to buy nothing (the epilogue costs what the separate pass does): off by default, bench.py --head-lse
         self.weights = {}
         self._table = None
         self._ws = {}

@@ -208,6 +208,8 @@ def test_forward_returns_the_logits_row_log_sum_exp(size):
         lab = torch.from_numpy(synth.labels(1, B, 12, cfg["vocab_size"], lo=5)).to(DEV)
     eng = EBranchformerEngine(cfg, DEV)
     eng.load_state_dict(sd)
+    assert eng.forward(x, lens, want_hidden=False)["lse"] is None            # off by default (measured: no gain)
+    eng.head_lse = True
     out = eng.forward(x, lens, want_hidden=False)
     lg = out["logits"]
     Bz, T2, V1 = lg.shape
