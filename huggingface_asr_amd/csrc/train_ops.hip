@@ -327,9 +327,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
     }
 }
 
-// dgamma[c] += sum_blk partial[blk][c],  dbeta[c] += sum_blk partial[blk][d + c] for up to 16 LayerNorms in ONE launch (the trainer defers the reductions of a layer's LayerNorm backward passes and flushes them together: a
+// dgamma[c] += sum_blk partial[blk][c],  dbeta[c] += sum_blk partial[blk][d + c] for up to 24 LayerNorms (or other row sets, `kind`) in ONE launch (the trainer defers the reductions of a layer's LayerNorm backward passes and flushes them together: a
 // reduce of 2 MB is all launch latency).  grid (columns / 16, LayerNorm); a block owns its 16 columns over ALL partial rows (16 row groups x 32 rows), summed in a fixed order: no atomics.
-struct LnRedMany { mi_lnred_desc d[16]; };
+constexpr int LNRED_MAX = 24;            // a pair of layers defers 18 reductions (12 LayerNorm, 4 depthwise, 2 position-bias): one launch per pair
+struct LnRedMany { mi_lnred_desc d[LNRED_MAX]; };
 __global__ __launch_bounds__(256) void ln_partial_reduce_many_kernel(LnRedMany p) {
     __shared__ float red[16][17];
     const mi_lnred_desc q = p.d[blockIdx.y];
@@ -814,7 +815,7 @@ extern "C" int mi_layernorm_bwd_dual_partial(const void* x, long ldx, int x_bf16
 
 extern "C" int mi_ln_partial_reduce_many(const mi_lnred_desc* descs, int n, hipStream_t st) {
     MI_ENTER();
-    if (!descs || n <= 0 || n > 16) return MI_ERR_ARG;
+    if (!descs || n <= 0 || n > LNRED_MAX) return MI_ERR_ARG;
     LnRedMany p{};
     int dmax = 0;
     for (int i = 0; i < n; ++i) {

@@ -133,10 +133,10 @@ def act_bwd(dy, pre, kind="gelu", out=None, drop=None):
 
 class LnReduceBatch:
     """Deferred (dgamma | dbeta) reductions of LayerNorm backward passes: `layernorm_bwd(..., defer=batch)` leaves its per-block partial rows in this object's arena;
-    `flush()` reduces up to 16 of them in ONE launch (mi_ln_partial_reduce_many).  A 2-MB reduce is all launch latency: the training step has ~100 of them."""
-    SLOTS = 16
+    `flush()` reduces up to 24 entries in ONE launch (mi_ln_partial_reduce_many).  A 2-MB reduce is all launch latency: the training step has ~100 of them."""
+    SLOTS = 24                      # a pair of base-size layers defers 18 reductions: one launch per weight-gradient flush
 
-    def __init__(self, device, floats_per_slot=4 * 512 * 2 * 2048):          # 32 MiB: a depthwise conv's partials (B x C x 32 floats) of up to B * C = 128 Ki fit a slot
+    def __init__(self, device, floats_per_slot=2 * 512 * 2 * 2048):          # 16 MiB: a depthwise conv's partials (B x C x 32 floats) of up to B * C = 128 Ki fit a slot
         self.device, self.per = device, floats_per_slot
         self.arena = None
         self.items = []

@@ -772,7 +772,11 @@ class EncoderCTCTrainer:
             if pd["final"] > 0:
                 T.dropout_(hid, pd["final"], seed, self._sid(L, 2))
             lbuf = e32(B, T2, ldl)
-            lse = ops.gemm_lse(hid, W("head_w"), P("head_b"), lbuf.view(M, ldl))       # logits and their row log-sum-exp from one pass (the GEMM's epilogue)
+            if os.environ.get("HFASR_TRAIN_HEAD_LSE", "1") != "0":
+                lse = ops.gemm_lse(hid, W("head_w"), P("head_b"), lbuf.view(M, ldl))       # logits and their row log-sum-exp from one pass (the GEMM's epilogue)
+            else:                                                                          # (the two passes: A/B and trajectory comparisons)
+                ops.gemm(hid, W("head_w"), P("head_b"), out=lbuf.view(M, ldl))
+                lse = ops.row_lse(lbuf.view(M, ldl)[:, :V1])
             logits = lbuf[..., :V1]
             if labels is not None:
                 loss, nll, _ = ops.ctc_loss(logits, labels, outer, reduction=red, zero_infinity=bool(c.get("ctc_zero_infinity", False)), lse=lse)

@@ -301,7 +301,7 @@ int mi_layernorm_bwd(const void* x, long ldx, int x_bf16, const float* gamma, fl
                      void* dx, long lddx, int dx_bf16, int accumulate, float* dgamma, float* dbeta, float* workspace, int M, int d,
                      mi_stream_t stream);
 /* deferred form: the per-block (dgamma | dbeta) partial rows stay in `partial` (*nblk rows of 2 d floats; size as mi_layernorm_bwd_workspace_floats) and are reduced
-   later, up to 16 LayerNorms per launch, by mi_ln_partial_reduce_many (dgamma[c] += sum, dbeta[c] += sum; fixed summation order, no atomics) */
+   later, up to 24 entries per launch, by mi_ln_partial_reduce_many (dgamma[c] += sum, dbeta[c] += sum; fixed summation order, no atomics) */
 typedef struct { const float* partial; int nblk, d; float* dgamma; float* dbeta; int kind; } mi_lnred_desc;
 /* kind 0: a LayerNorm's rows as above.  kind = K (1..31): the tap-gradient partials a depthwise-conv backward left in its workspace (mi_csgu_bwd_bf16 /
  * mi_dwconv_residual_bwd_bf16 called with dw == NULL): nblk rows of d * 32 floats, d = channels; dgamma = the (d, K) tap gradient, dbeta = the (d) bias gradient or NULL;

@@ -495,7 +495,7 @@ def test_layernorm_bwd_deferred_reductions_match_the_immediate_form():
     M = 1000
     batch = T.LnReduceBatch(DEV)
     want, got = [], []
-    cases = [(512, 1), (1024, 2), (512, 3), (64, 4)] * 5                       # 20 entries > 16 slots: an automatic flush in between
+    cases = [(512, 1), (1024, 2), (512, 3), (64, 4)] * 7                       # 28 entries > 24 slots: an automatic flush in between
     for d, seed in cases:
         x = rnd(M, d, seed=seed).to(DEV); dy = dev16(rnd(M, d, seed=seed + 50)); g = (1 + 0.1 * rnd(d, seed=seed + 90)).to(DEV)
         dg1, db1 = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
