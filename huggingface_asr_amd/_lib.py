@@ -150,6 +150,8 @@ SIGNATURES = {
     "mi_conv2d_first_bwd_phases": [vp, vp, vp, vp, vp, vp] + [i32] * 14 + [vp, vp],
     "mi_ctc_bwd_workspace_bytes": [i32, i32, i32],
     "mi_ctc_loss_bwd": [vp, i64, i64, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, f32, vp, sz, vp, i64, vp],
+    "mi_ctc_loss_bwd_nll": [vp, i64, i64, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, f32, vp, sz, vp, i64, vp, vp, vp, vp],
+    "mi_ctc_reduce": [vp, vp, i32, i32, i32, vp, vp],
     "mi_ce_label_smoothing_bwd": [vp, i64, vp, i32, i32, i32, i32, f32, f32, vp, vp, i64, vp],
     "mi_embed_tokens_bwd": [vp, vp, f32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp],
     "mi_embed_tokens_bwd_workspace_bytes": [i32, i32, i32],

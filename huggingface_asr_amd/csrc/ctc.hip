@@ -268,6 +268,15 @@ __global__ void ctc_reduce_kernel(const float* nll, const int* tl, int B, int re
 
 }  // namespace
 
+// the reduction of mi_ctc_loss_fwd alone: loss = mean_b(nll_b / max(tl_b, 1)) (reduction 1) or sum_b nll_b (0), infinite entries zeroed with zero_infinity
+extern "C" int mi_ctc_reduce(const float* nll, const int* tgt_len, int B, int reduction, int zero_infinity, float* loss, hipStream_t stream) {
+    MI_ENTER();
+    if (!nll || !tgt_len || !loss || B <= 0) return MI_ERR_ARG;
+    hipLaunchKernelGGL(ctc_reduce_kernel, dim3(1), dim3(64), 0, stream, nll, tgt_len, B, reduction, zero_infinity, loss);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
 // logits (M, ld) f32 (dtype 0) or bf16 (dtype 1) -> lse (M) f32
 extern "C" int mi_row_lse(const void* x, long ld, int dtype, int V, float* lse, int M, hipStream_t stream) {
     MI_ENTER();

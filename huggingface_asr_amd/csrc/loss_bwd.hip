@@ -130,7 +130,10 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_wave_kernel(const T* __res
                                                                    int Tmax, const long* __restrict__ labels, int U, const int* __restrict__ in_len,
                                                                    int blank, const float* __restrict__ nll, int reduction, int B, float gscale,
                                                                    float* __restrict__ alpha_ws, float* __restrict__ contrib,
-                                                                   int* __restrict__ ext_ws, int* __restrict__ meta, int* __restrict__ chain_ws, float* __restrict__ lp_ws) {
+                                                                   int* __restrict__ ext_ws, int* __restrict__ meta, int* __restrict__ chain_ws, float* __restrict__ lp_ws,
+                                                                   float* __restrict__ nll_out, int* __restrict__ tl_out) {
+    // nll == NULL (own-nll form, mi_ctc_loss_bwd_nll): the utterance's negative log-likelihood is taken from THIS kernel's alpha recursion (-logsumexp of the two final
+    // states at Tb - 1) and written to nll_out / tl_out — the training step then needs no forward alpha kernel at all (it ran the same recursion a second time)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S_max = 2 * U + 1;
     int* hdr = reinterpret_cast<int*>(smem);          // [4]
@@ -151,9 +154,11 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_wave_kernel(const T* __res
     __syncthreads();
     const int tl = hdr[0], S = 2 * tl + 1;
     const int Tb = min(in_len[b], Tmax);
-    const float nl = nll[b];
+    const bool own = nll == nullptr;
+    float nl = own ? 0.f : nll[b];
     float scale = (reduction == 1) ? gscale / ((float)max(tl, 1) * (float)B) : gscale;
     if (!isfinite(nl) || Tb <= 0) scale = 0.f;        // infeasible alignment: zero gradient (zero_infinity semantics)
+    if (own && tid == 0) { tl_out[b] = tl; if (Tb <= 0) nll_out[b] = (tl == 0) ? 0.f : INFINITY; }      // (as mi_ctc_loss_fwd for an empty input)
     for (int s = tid; s < S; s += 256) ext_ws[(long)b * S_max + s] = ext[s];
     // chain of the states that emit the same label (repeated labels in the target): chain[s] = next odd s' > s with ext[s'] == ext[s] (0: none), bit 30 set when an
     // earlier state has the label — ctc_grad_rows_kernel lets the FIRST state of a label add the whole chain in order (no LDS float atomics: bit-reproducible rows)
@@ -166,8 +171,8 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_wave_kernel(const T* __res
         }
         chain_ws[(long)b * S_max + s] = code;
     }
-    if (tid == 0) { meta[3 * b] = tl; meta[3 * b + 1] = Tb; meta[3 * b + 2] = __float_as_int(scale); }
-    if (scale == 0.f) return;
+    if (tid == 0) { meta[3 * b] = tl; meta[3 * b + 1] = Tb; meta[3 * b + 2] = __float_as_int(scale); }      // (own-nll form: the scale is confirmed after the recursion)
+    if (scale == 0.f && (!own || Tb <= 0)) return;    // (own-nll form with a zero upstream gradient: the recursion still runs, for the loss)
     const T* lg = logits + (long)b * ld_b;
     const float* ls = lse + (long)b * Tmax;
     float* aw = alpha_ws + (long)b * Tmax * S_max;
@@ -256,6 +261,16 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_wave_kernel(const T* __res
     }
     __threadfence_block();
     __syncthreads();
+    if (own) {                                         // log-likelihood = logsumexp(alpha_{Tb-1}[S-1], alpha_{Tb-1}[S-2]) from the rows wave 0 has just stored
+        const float va = aw[(long)(Tb - 1) * S_max + S - 1];
+        const float vb = S >= 2 ? aw[(long)(Tb - 1) * S_max + S - 2] : -INFINITY;
+        nl = -lse3f(va, vb, -INFINITY);
+        if (tid == 0) nll_out[b] = nl;
+        if (!isfinite(nl)) {                           // infeasible alignment: zero gradient (ctc_grad_rows_kernel does not read `contrib` for a zero scale)
+            if (tid == 0) meta[3 * b + 2] = __float_as_int(0.f);
+            return;
+        }
+    }
     // ---- contributions: every (t, s) of this utterance, whole block
     for (int i = tid; i < Tb * S; i += 256) {
         const int t = i / S, s2 = i - t * S;
@@ -447,10 +462,9 @@ extern "C" size_t mi_ctc_bwd_workspace_bytes(int B, int T, int U) {
 
 // logits (B,T,V1) f32 (dtype 0) | bf16 (1) with strides; lse (B*T) and nll (B) from mi_row_lse / mi_ctc_loss_fwd;
 // dlogits (B*T, ldo) bf16, ldo >= V1 (pad columns zeroed); gscale = upstream gradient of the reduced loss (e.g. ctc_weight)
-extern "C" int mi_ctc_loss_bwd(const void* logits, long ld_b, long ld_t, int dtype, const float* lse, int T, const long* labels, int U,
-                               const int* in_len, int blank, int B, int reduction, const float* nll, float gscale, void* workspace,
-                               size_t workspace_bytes, void* dlogits, long ldo, hipStream_t st) {
-    MI_ENTER();
+static int ctc_loss_bwd_impl(const void* logits, long ld_b, long ld_t, int dtype, const float* lse, int T, const long* labels, int U,
+                             const int* in_len, int blank, int B, int reduction, const float* nll, float gscale, void* workspace,
+                             size_t workspace_bytes, void* dlogits, long ldo, float* nll_out, int* tl_out, hipStream_t st) {
     const int V1 = blank + 1;
     if (B <= 0 || T <= 0 || U < 0 || ldo < V1 || dtype < 0 || dtype > 1) return MI_ERR_ARG;
     if (workspace_bytes < mi_ctc_bwd_workspace_bytes(B, T, U)) return MI_ERR_ARG;
@@ -465,13 +479,14 @@ extern "C" int mi_ctc_loss_bwd(const void* logits, long ld_b, long ld_t, int dty
     if (lds > 150 * 1024 || lds_rows > 150 * 1024) return MI_ERR_UNSUPPORTED;
     const bool wavef = S <= 128 && T <= 256;          // the wave form: states in one wave's registers, all emissions in LDS
     const bool wavel = S <= 128 && T > 256;           // ... and in an L2-resident global table for longer inputs
+    if (!nll && !(wavef || wavel)) return MI_ERR_UNSUPPORTED;        // the own-nll form exists in the wave kernels only
     const size_t ldsw = (4 + 132) * sizeof(int) + (size_t)T * 128 * sizeof(float);
     float* lp_ws = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(chain_ws + (size_t)B * S) + 255) & ~(uintptr_t)255);      // inside the 1024 bytes of slack
 #define CTC_AB(TY) do { \
         if (wavef) hipLaunchKernelGGL((ctc_alpha_beta_wave_kernel<TY, false>), dim3(B), dim3(256), ldsw, st, (const TY*)logits, ld_b, ld_t, lse, T, labels, U, in_len, \
-                                      blank, nll, reduction, B, gscale, alpha_ws, contrib, ext_ws, meta, chain_ws, (float*)nullptr); \
+                                      blank, nll, reduction, B, gscale, alpha_ws, contrib, ext_ws, meta, chain_ws, (float*)nullptr, nll_out, tl_out); \
         else if (wavel) hipLaunchKernelGGL((ctc_alpha_beta_wave_kernel<TY, true>), dim3(B), dim3(256), (4 + 132) * sizeof(int), st, (const TY*)logits, ld_b, ld_t, lse, T, labels, U, in_len, \
-                                      blank, nll, reduction, B, gscale, alpha_ws, contrib, ext_ws, meta, chain_ws, lp_ws); \
+                                      blank, nll, reduction, B, gscale, alpha_ws, contrib, ext_ws, meta, chain_ws, lp_ws, nll_out, tl_out); \
         else hipLaunchKernelGGL(ctc_alpha_beta_kernel<TY>, dim3(B), dim3(256), lds, st, (const TY*)logits, ld_b, ld_t, lse, T, labels, U, in_len, \
                                 blank, nll, reduction, B, gscale, alpha_ws, contrib, ext_ws, meta, chain_ws); \
         hipLaunchKernelGGL(ctc_grad_rows_kernel<TY>, dim3(B * T), dim3(256), lds_rows, st, (const TY*)logits, ld_b, ld_t, lse, T, U, V1, \
@@ -480,6 +495,30 @@ extern "C" int mi_ctc_loss_bwd(const void* logits, long ld_b, long ld_t, int dty
 #undef CTC_AB
     MI_CHECK_LAUNCH();
     return MI_OK;
+}
+
+extern "C" int mi_ctc_loss_bwd(const void* logits, long ld_b, long ld_t, int dtype, const float* lse, int T, const long* labels, int U,
+                               const int* in_len, int blank, int B, int reduction, const float* nll, float gscale, void* workspace,
+                               size_t workspace_bytes, void* dlogits, long ldo, hipStream_t st) {
+    MI_ENTER();
+    if (!nll) return MI_ERR_ARG;
+    return ctc_loss_bwd_impl(logits, ld_b, ld_t, dtype, lse, T, labels, U, in_len, blank, B, reduction, nll, gscale, workspace, workspace_bytes, dlogits, ldo, nullptr, nullptr, st);
+}
+
+// Loss AND gradient from one pair of recursions (the training step): as mi_ctc_loss_bwd, but the per-utterance negative log-likelihood comes out of this call's own alpha
+// recursion — nll_out (B), tgt_len_out (B), loss_out (1: the reduced loss of mi_ctc_loss_fwd, same reduction / zero_infinity semantics) — instead of going in: the forward
+// loss kernel (a second run of the alpha recursion) is not needed.  MI_ERR_UNSUPPORTED when the target has more than 63 labels (the wave kernels hold 128 states): the
+// caller runs mi_ctc_loss_fwd + mi_ctc_loss_bwd.
+extern "C" int mi_ctc_reduce(const float* nll, const int* tgt_len, int B, int reduction, int zero_infinity, float* loss, hipStream_t stream);
+extern "C" int mi_ctc_loss_bwd_nll(const void* logits, long ld_b, long ld_t, int dtype, const float* lse, int T, const long* labels, int U,
+                                   const int* in_len, int blank, int B, int reduction, int zero_infinity, float gscale, void* workspace,
+                                   size_t workspace_bytes, void* dlogits, long ldo, float* nll_out, int* tgt_len_out, float* loss_out, hipStream_t st) {
+    MI_ENTER();
+    if (!nll_out || !tgt_len_out) return MI_ERR_ARG;
+    const int rc = ctc_loss_bwd_impl(logits, ld_b, ld_t, dtype, lse, T, labels, U, in_len, blank, B, reduction, nullptr, gscale, workspace, workspace_bytes, dlogits, ldo,
+                                     nll_out, tgt_len_out, st);
+    if (rc != MI_OK) return rc;
+    return loss_out ? mi_ctc_reduce(nll_out, tgt_len_out, B, reduction, zero_infinity, loss_out, st) : MI_OK;
 }
 
 // logits (B,U,V) f32 rows of stride ld; acc = [sum, count] written by mi_ce_label_smoothing; dlogits (B*U, ldo) bf16

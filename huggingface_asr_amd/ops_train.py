@@ -605,6 +605,28 @@ def ctc_loss_bwd(logits, lse, labels, in_len, nll, *, reduction="mean", gscale=1
     return out
 
 
+def ctc_loss_bwd_nll(logits, lse, labels, in_len, *, reduction="mean", zero_infinity=False, gscale=1.0, ldo=None):
+    """loss and gradient from ONE pair of recursions: -> (dlogits (B*T, ldo) bf16, loss scalar tensor, nll (B)) as `ops.ctc_loss` + `ctc_loss_bwd` give them, the
+    per-utterance nll taken from the backward's own alpha recursion (no forward loss kernel); None when the target is too long for that kernel (callers run the two)."""
+    B, T, V1 = logits.shape
+    labels = labels.contiguous()
+    U = labels.shape[1]
+    ldo = (V1 + 7) // 8 * 8 if ldo is None else ldo
+    nbytes = _L().mi_ctc_bwd_workspace_bytes(B, T, U)
+    ws = torch.empty(nbytes, device=logits.device, dtype=torch.uint8)
+    out = torch.empty((B * T, ldo), device=logits.device, dtype=BF16)
+    nll = torch.empty((B,), device=logits.device, dtype=F32)
+    tl = torch.empty((B,), device=logits.device, dtype=torch.int32)
+    loss = torch.empty((1,), device=logits.device, dtype=F32)
+    rc = _L().mi_ctc_loss_bwd_nll(logits.data_ptr(), logits.stride(0), logits.stride(1), 0 if logits.dtype == F32 else 1, lse.data_ptr(), T,
+                                  labels.data_ptr(), U, in_len.data_ptr(), V1 - 1, B, 1 if reduction == "mean" else 0, int(zero_infinity), float(gscale),
+                                  ws.data_ptr(), nbytes, out.data_ptr(), ldo, nll.data_ptr(), tl.data_ptr(), loss.data_ptr(), _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "mi_ctc_loss_bwd_nll")
+    return out, loss[0], nll
+
+
 def ce_label_smoothing_bwd(logits, labels, acc, *, shift=1, eps=0.0, weight=1.0, ldo=None):
     B, U, V = logits.shape
     labels = labels.contiguous()

@@ -377,6 +377,7 @@ class EncoderCTCTrainer:
         self.csgu_split = self.csgu_lin or self.csgu_act != 0
         self.dual_ln = True                       # the two branch norms' backward in one pass (tools/train_bench.py --no-dual-ln measures the two-pass form beside it)
         self.dw_overwrite = os.environ.get("HFASR_DW_OVERWRITE", "1") != "0"      # see _forward_backward (HFASR_DW_OVERWRITE=0 / tools/train_bench.py --no-dw-overwrite: always accumulate)
+        self.ctc_from_bwd = True                  # the CTC loss out of the backward's own alpha recursion (tools/train_bench.py --no-ctc-from-bwd: forward loss kernel + backward)
         self.walk_qb = True                       # q + u / q + v of the attention backward from the fused walk's prologue (--no-walk-qb: the pass of their own)
         self.frozen = set()
         self.layerdrop = float(c.get("layerdrop", 0.0) or 0.0)      # tf:models/wav2vec2_conformer/modeling_wav2vec2_conformer.py:686-690
@@ -779,7 +780,8 @@ class EncoderCTCTrainer:
                 lse = ops.row_lse(lbuf.view(M, ldl)[:, :V1])
             logits = lbuf[..., :V1]
             if labels is not None:
-                loss, nll, _ = ops.ctc_loss(logits, labels, outer, reduction=red, zero_infinity=bool(c.get("ctc_zero_infinity", False)), lse=lse)
+                if not (backward and self.ctc_from_bwd and red in ("mean", "sum")):       # with a backward pass the loss comes out of ITS alpha recursion (below): no forward loss kernel
+                    loss, nll, _ = ops.ctc_loss(logits, labels, outer, reduction=red, zero_infinity=bool(c.get("ctc_zero_infinity", False)), lse=lse)
             elif backward:
                 raise ValueError("forward_backward: the backward pass of the CTC head needs `labels`")
         out = dict(loss=loss, logits=logits, outer_len=outer, inner_len=inner,
@@ -860,7 +862,17 @@ class EncoderCTCTrainer:
         gs = float(loss_scale) / self.sync.world
         dhid = None
         if self.head:
-            dlog = T.ctc_loss_bwd(logits, lse, labels, outer, nll, reduction=red, gscale=gs, ldo=ldl)         # (M, ldl) bf16
+            dlog = None
+            if nll is None:         # loss, per-utterance nll and the gradient from one pair of recursions; a target too long for that kernel takes the two calls
+                zi = bool(c.get("ctc_zero_infinity", False))
+                r = T.ctc_loss_bwd_nll(logits, lse, labels, outer, reduction=red, zero_infinity=zi, gscale=gs, ldo=ldl)
+                if r is not None:
+                    dlog, loss, nll = r
+                else:
+                    loss, nll, _ = ops.ctc_loss(logits, labels, outer, reduction=red, zero_infinity=zi, lse=lse)
+                out["loss"] = loss
+            if dlog is None:
+                dlog = T.ctc_loss_bwd(logits, lse, labels, outer, nll, reduction=red, gscale=gs, ldo=ldl)         # (M, ldl) bf16
             dhid = T.gemm(dlog, WT("head_w"), out_dtype=F32 if (self.mix or self.extra) else BF16)           # (M, d)
             if pd["final"] > 0:
                 T.dropout_(dhid, pd["final"], seed, self._sid(L, 2))

@@ -449,6 +449,14 @@ size_t mi_ctc_bwd_workspace_bytes(int B, int T, int U);
 int mi_ctc_loss_bwd(const void* logits, long ld_b, long ld_t, int dtype, const float* lse, int T, const long* labels, int U,
                     const int* in_len, int blank, int B, int reduction, const float* nll, float gscale, void* workspace,
                     size_t workspace_bytes, void* dlogits, long ldo, mi_stream_t stream);
+/* loss AND gradient from one pair of recursions (the training step): as mi_ctc_loss_bwd, but the per-utterance negative log-likelihood comes OUT of the call (its own alpha
+ * recursion: nll_out (B), tgt_len_out (B), loss_out (1, nullable) = the reduced loss of mi_ctc_loss_fwd with the same reduction / zero_infinity semantics) instead of
+ * going in — no forward loss kernel.  MI_ERR_UNSUPPORTED for targets of more than 63 labels (the caller runs mi_ctc_loss_fwd + mi_ctc_loss_bwd). */
+int mi_ctc_loss_bwd_nll(const void* logits, long ld_b, long ld_t, int dtype, const float* lse, int T, const long* labels, int U,
+                        const int* in_len, int blank, int B, int reduction, int zero_infinity, float gscale, void* workspace,
+                        size_t workspace_bytes, void* dlogits, long ldo, float* nll_out, int* tgt_len_out, float* loss_out, mi_stream_t stream);
+/* the reduction of mi_ctc_loss_fwd alone */
+int mi_ctc_reduce(const float* nll, const int* tgt_len, int B, int reduction, int zero_infinity, float* loss, mi_stream_t stream);
 int mi_ce_label_smoothing_bwd(const float* logits, long ld, const long* labels, int B, int U, int shift, int V, float eps,
                               float weight, const float* acc, void* dlogits, long ldo, mi_stream_t stream);
 /* as gathers (a block per 16 vocabulary entries / per position adds its rows in order: no atomics).  heavy_id: an entry expected on a large share of the rows (the padding

@@ -845,6 +845,42 @@ def test_ctc_loss_bwd_long_inputs(Tt, U):
     assert torch.equal(dl, T.ctc_loss_bwd(ld, lse, labels.to(DEV), in_len.to(DEV), nll, reduction="mean", gscale=0.3))          # bit-reproducible
 
 
+@pytest.mark.parametrize("Tt,U,red", [(120, 20, "mean"), (250, 40, "mean"), (500, 60, "sum"), (300, 33, "mean")])
+def test_ctc_loss_and_gradient_from_one_pair_of_recursions(Tt, U, red):
+    """mi_ctc_loss_bwd_nll (the training step: no forward loss kernel): loss, per-utterance nll and dlogits against torch's ctc_loss + backward, and against the two-call
+    form (the forward kernel's nll comes from its bidirectional recursion: equal to 1e-5) — ragged lengths, repeats, a padded target, an infeasible utterance
+    (nll = inf, zero gradient, counted as 0 with zero_infinity), a one-frame utterance; a target of more than 63 labels is refused (None: callers run the two calls)."""
+    ops, T = _o()
+    B, V1 = 5, 71
+    logits = rnd(B, Tt, V1, seed=21, scale=1.5)
+    labels = torch.randint(0, V1 - 1, (B, U), generator=torch.Generator().manual_seed(22))
+    labels[1, U // 2:] = -100; labels[2, 1] = labels[2, 0]; labels[2, 5] = labels[2, 4]; labels[3, :] = labels[3, 0]
+    in_len = torch.tensor([Tt, Tt - 37, max(Tt // 2, 2 * U + 1), min(Tt, 2 * U - 2), 1], dtype=torch.int32)
+    labels[4, 1:] = -100
+    lg = logits.clone().requires_grad_(True)
+    lp = torch.log_softmax(lg, -1).transpose(0, 1)
+    tl = (labels >= 0).sum(-1)
+    loss = F.ctc_loss(lp, labels[labels >= 0], in_len.long(), tl, blank=V1 - 1, reduction=red, zero_infinity=True)
+    (0.3 * loss).backward()
+    ld, lab, il = logits.to(DEV), labels.to(DEV), in_len.to(DEV)
+    lse = ops.row_lse(ld.reshape(B * Tt, V1))
+    dl, got_loss, nll = T.ctc_loss_bwd_nll(ld, lse, lab, il, reduction=red, zero_infinity=True, gscale=0.3)
+    torch.testing.assert_close(got_loss.cpu(), loss.detach(), atol=1e-3, rtol=1e-4)
+    close(dl[:, :V1].reshape(B, Tt, V1), lg.grad, floor=5e-3, what="ctc dlogits, own nll")
+    l2, nll2, _ = ops.ctc_loss(ld, lab, il, reduction=red, zero_infinity=True, lse=lse)
+    assert torch.isinf(nll[3]) and torch.isinf(nll2[3])
+    fin = torch.isfinite(nll2)
+    torch.testing.assert_close(nll[fin], nll2[fin], rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(got_loss, l2, rtol=1e-5, atol=1e-5)
+    dl2 = T.ctc_loss_bwd(ld, lse, lab, il, nll2, reduction=red, gscale=0.3)
+    close(dl[:, :V1].float(), dl2[:, :V1].float(), floor=5e-3, what="own nll vs given nll")
+    assert float(dl[3 * Tt:4 * Tt].abs().max()) == 0.0                       # the infeasible utterance
+    r = T.ctc_loss_bwd_nll(ld, lse, lab, il, reduction=red, zero_infinity=True, gscale=0.3)
+    assert torch.equal(r[0], dl) and torch.equal(r[2], nll)                   # bit-reproducible
+    long_lab = torch.randint(0, V1 - 1, (B, 70), generator=torch.Generator().manual_seed(3)).to(DEV)
+    assert T.ctc_loss_bwd_nll(ld, lse, long_lab, il, reduction=red, zero_infinity=True) is None
+
+
 def test_ce_and_embed_bwd():
     ops, T = _o()
     B, U, V, d = 3, 11, 50, 64

@@ -15,6 +15,7 @@ ap.add_argument("--size", default="base"); ap.add_argument("--batch", type=int, 
 ap.add_argument("--warmup", type=int, default=3); ap.add_argument("--pos", default="relative"); ap.add_argument("--frames", type=int, default=1000)
 ap.add_argument("--fwd-only", action="store_true")
 ap.add_argument("--no-dw-overwrite", action="store_true", help="the grouped weight-gradient launches always add into their targets (the form before), for a same-box A/B")
+ap.add_argument("--no-ctc-from-bwd", action="store_true", help="the CTC loss by its forward kernel (the form before), for a same-box A/B")
 ap.add_argument("--no-walk-qb", action="store_true", help="q + pos_bias_u / q + pos_bias_v of the attention backward by a pass of their own (the form before), for a same-box A/B")
 ap.add_argument("--no-dual-ln", action="store_true", help="the layer's two branch LayerNorm backward passes as two launches (the form before round 4's last change), for a same-box A/B")
 ap.add_argument("--specaug", action="store_true", help="in-model SpecAugment as in the recipes (mask_time_prob 0.05, length 10, min 2 masks)")
@@ -67,6 +68,8 @@ if a.no_dual_ln:
     (tr.enc if a.model == "aed" else tr).dual_ln = False
 if a.no_dw_overwrite:
     (tr.enc if a.model == "aed" else tr).dw_overwrite = False
+if a.no_ctc_from_bwd:
+    (tr.enc if a.model == "aed" else tr).ctc_from_bwd = False
 if a.no_walk_qb:
     (tr.enc if a.model == "aed" else tr).walk_qb = False
 state = {}
