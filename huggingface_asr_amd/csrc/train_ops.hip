@@ -330,34 +330,37 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ x,
 // dgamma[c] += sum_blk partial[blk][c],  dbeta[c] += sum_blk partial[blk][d + c] for up to 24 LayerNorms (or other row sets, `kind`) in ONE launch (the trainer defers the reductions of a layer's LayerNorm backward passes and flushes them together: a
 // reduce of 2 MB is all launch latency).  grid (columns / 16, LayerNorm); a block owns its 16 columns over ALL partial rows (16 row groups x 32 rows), summed in a fixed order: no atomics.
 constexpr int LNRED_MAX = 24;            // a pair of layers defers 18 reductions (12 LayerNorm, 4 depthwise, 2 position-bias): one launch per pair
-struct LnRedMany { mi_lnred_desc d[LNRED_MAX]; };
+struct LnRedMany { mi_lnred_desc d[LNRED_MAX]; int blk0[LNRED_MAX + 1]; int n; };      // blk0: first block of every entry (64 columns per block): the grid has no empty blocks
 __global__ __launch_bounds__(256) void ln_partial_reduce_many_kernel(LnRedMany p) {
-    __shared__ float red[16][17];
-    const mi_lnred_desc q = p.d[blockIdx.y];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;           // 16 columns x 16 row groups
-    const int c = blockIdx.x * 16 + tx;
+    // a block owns 64 columns of ONE entry (a wave reads 256 consecutive bytes of a partial row) over all its partial rows: 4 row groups (one per wave), each walking its
+    // rows in order with eight loads in flight.  The grid is the exact block count (prefix table blk0): as (widest entry / 16 columns) x entries it was ~37 000 blocks, most
+    // of which found nothing to do — dispatching them, not the 40 MB, was the launch's 16-18 us (64-column blocks alone, and 16 row groups alone, changed nothing).
+    __shared__ float red[4][64];
+    int e = 0;
+    while (e + 1 < p.n && (int)blockIdx.x >= p.blk0[e + 1]) ++e;
+    e = __builtin_amdgcn_readfirstlane(e);
+    const mi_lnred_desc q = p.d[e];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;           // 64 columns x 4 row groups
+    const int c = ((int)blockIdx.x - p.blk0[e]) * 64 + tx;
     const int ncol = q.kind ? q.d * 32 : 2 * q.d;                      // kind = K > 0: a depthwise conv's (channel, 32) tap-gradient partials (include/hfasr_hip.h)
-    if ((int)blockIdx.x * 16 >= ncol) return;
     float s = 0.f;
     if (c < ncol) {
         const float* src = q.partial + c;
         const long ld = ncol;
         int b = ty;
-        for (; b + 7 * 16 < q.nblk; b += 8 * 16) {                    // eight loads in flight per thread; the sum order is fixed (row group, then rows ascending)
+        for (; b + 7 * 4 < q.nblk; b += 8 * 4) {                      // the sum order is fixed (row group, then rows ascending)
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = src[(long)(b + j * 16) * ld];
+            for (int j = 0; j < 8; ++j) v[j] = src[(long)(b + j * 4) * ld];
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += v[j];
         }
-        for (; b < q.nblk; b += 16) s += src[(long)b * ld];
+        for (; b < q.nblk; b += 4) s += src[(long)b * ld];
     }
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && c < ncol) {
-        float t = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) t += red[j][tx];
+        const float t = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
         if (q.kind) {
             const int ch = c >> 5, k = c & 31;
             if (k < q.kind) q.dgamma[(long)ch * q.kind + k] += t;
@@ -765,7 +768,8 @@ extern "C" int mi_layernorm_bwd(const void* x, long ldx, int x_bf16, const float
     if (dgamma) {
         LnRedMany one{};
         one.d[0] = mi_lnred_desc{workspace, grid, d, dgamma, dbeta, 0};
-        hipLaunchKernelGGL(ln_partial_reduce_many_kernel, dim3(cdiv(2 * d, 16), 1), dim3(256), 0, st, one);
+        one.n = 1; one.blk0[0] = 0; one.blk0[1] = cdiv(2 * d, 64);
+        hipLaunchKernelGGL(ln_partial_reduce_many_kernel, dim3(one.blk0[1]), dim3(256), 0, st, one);
         MI_CHECK_LAUNCH();
     }
     return MI_OK;
@@ -817,14 +821,16 @@ extern "C" int mi_ln_partial_reduce_many(const mi_lnred_desc* descs, int n, hipS
     MI_ENTER();
     if (!descs || n <= 0 || n > LNRED_MAX) return MI_ERR_ARG;
     LnRedMany p{};
-    int dmax = 0;
+    p.n = n;
+    int blocks = 0;
     for (int i = 0; i < n; ++i) {
         if (!descs[i].partial || !descs[i].dgamma || (!descs[i].dbeta && !descs[i].kind) || descs[i].nblk <= 0 || descs[i].d <= 0 || descs[i].kind < 0 || descs[i].kind > 31) return MI_ERR_ARG;
         p.d[i] = descs[i];
-        const int ncol = descs[i].kind ? descs[i].d * 32 : 2 * descs[i].d;
-        dmax = ncol > dmax ? ncol : dmax;
+        p.blk0[i] = blocks;
+        blocks += cdiv(descs[i].kind ? descs[i].d * 32 : 2 * descs[i].d, 64);
     }
-    hipLaunchKernelGGL(ln_partial_reduce_many_kernel, dim3(cdiv(dmax, 16), n), dim3(256), 0, st, p);
+    p.blk0[n] = blocks;
+    hipLaunchKernelGGL(ln_partial_reduce_many_kernel, dim3(blocks), dim3(256), 0, st, p);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
