@@ -164,7 +164,7 @@ SIGNATURES = {
     "mi_kv_cache_reorder": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "mi_ctc_prefix_advance": [vp, i32, i32, i32, i32, i32, vp, vp, i64, i32, vp, vp, i64, i32, vp, vp, vp, vp],
     "mi_ctc_prefix_score_full": [vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, i64, i32, vp, vp, vp, vp],
-    "mi_beam_step": [vp, i64, vp, vp, f32, f32, i32, i32, i32, i32, i32, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp],
+    "mi_beam_step": [vp, i64, vp, vp, f32, f32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "mi_ebf_workspace_bytes": [C.POINTER(EbfConfig)],
     "mi_ebf_forward": [C.POINTER(EbfConfig), vp, vp, vp, vp, vp, i32, vp, sz, vp, vp, vp, vp, vp],
     "mi_ebf_forward_hs": [C.POINTER(EbfConfig), vp, vp, vp, vp, vp, i32, vp, sz, vp, vp, vp, vp, vp, vp],

@@ -1,15 +1,18 @@
 // One beam-search step of joint CTC / attention decoding, entirely on the device (BASELINE config 5: streaming bs = 1 latency).
 //
-// Replaces, per emitted token, what the reference runs on the host through transformers' GenerationMixin beam loop and BeamSearchScorer.process
-// (reference call site: src/models/ctc_encoder_plus_autoregressive_decoder.py:360-482, processors src/decoding/ctc_scorer.py:259-365):
-//     scores = log_softmax(decoder logits);  scores[:, pad] = logzero;  scores = (1 - w) scores + w ctc;  cand = scores + beam score
-//     top 2W of the W * V candidates of an utterance, best first
-//     walk them in order: EOS among the first W ranks closes a hypothesis (score / len ** length_penalty), the first W others continue as the next beams
-//     the utterance is done when W hypotheses are closed and the best running candidate cannot beat the worst of the best W (early_stopping = False)
+// Replaces, per emitted token, what the reference runs on the host through transformers' GenerationMixin beam loop
+// (reference call site: src/models/ctc_encoder_plus_autoregressive_decoder.py:360-482, processors src/decoding/ctc_scorer.py:259-365; the loop is third-party code:
+// transformers/generation/utils.py `_beam_search` of the installed 5.x — the rules the fixtures tests/golden/gen_*.npz pin, restated on the CPU in oracle/generate_ref.py):
+//     scores = log_softmax(decoder logits);  [CTC processor: scores[:, pad] = logzero;  scores = (1 - w) scores + w ctc];  cand = scores + running beam score
+//     top 2W of the W * V candidates of an utterance, best first;  a candidate STOPS when its token is EOS or its length reaches max_length
+//     the first W candidates that did not stop run on as the next beams (at max_length: stopped ones, lowered by 1e9 — the loop ends there)
+//     stopped candidates among the first W ranks join the kept hypotheses with score / (generated tokens) ** length_penalty; the best W are kept, best first
+//     early-stop rule: the utterance is finished when W hypotheses are kept and best running score / (hypothetical length) ** length_penalty cannot beat the worst of them
+//     (early_stopping False / True: the current length; "never" with a positive penalty: max_length), or — early_stopping True — as soon as W hypotheses are kept
 //     input ids follow their beams and get the new token appended
 // The host loop did this with two device -> host copies, a Python walk and three host -> device copies per token (~0.3 ms of a 0.8 ms token); here it is one
 // launch, nothing leaves the device until decoding ends, and the host only enqueues.  Arithmetic is the host loop's, operation for operation (fp32 subtract,
-// two multiplies and an add without contraction, fp32 beam add, double division for the closed hypotheses), so both produce the same hypotheses bit for bit.
+// two multiplies and an add without contraction, fp32 beam add, fp32 division for the kept hypotheses), so both produce the same hypotheses bit for bit.
 #include "common.hpp"
 #include "../../include/hfasr_hip.h"
 
@@ -23,13 +26,15 @@ struct BeamArgs {
     const float* lse;                     // (B * W) their row log-sum-exp (mi_row_lse)
     const float* ctc;                     // (B * W, V) CTC prefix scores or null
     float w_att, w_ctc;
-    int pad, eos, B, W, V, cur_len, Lmax, cap;
-    double denom;                         // cur_len ** length_penalty
+    int mask_pad;                         // the CTC processor masks the pad token (ctc_scorer.py:325); without it nothing does
+    int pad, eos, B, W, V, cur_len, max_length, Lmax;
+    float denom, heur_denom;              // (generated tokens of a hypothesis closed in this step) ** length_penalty; (hypothetical length of the early-stop rule) ** length_penalty
+    int early_stopping;                   // 0 False, 1 True, 2 "never"
     long* ids;                            // (B * W, Lmax), updated in place
     float* beam_scores;                   // (B * W), updated in place
     long* new_tok;                        // (B * W)
     long* beam_idx;                       // (B * W)
-    int* done; int* nfin; double* fin_score; int* fin_len; long* fin_tok;
+    int* done; int* nfin; float* fin_score; int* fin_len; long* fin_tok;      // (B), (B), (B, W), (B, W), (B, W, Lmax): the kept hypotheses, best first
     float* top_s; int* top_i;             // optional (B, 2W): the candidates the step walked
     int* done_out;                        // optional (B): copy of the done flags after the step (host-mapped pinned memory: the host polls it without a copy on the stream)
 };
@@ -40,7 +45,7 @@ __device__ __forceinline__ float cand_value(const BeamArgs& p, int b, int e) {
     const int beam = e / p.V, tok = e - beam * p.V;
     const long row = (long)b * p.W + beam;
     float s = p.logits[row * p.ldl + tok] - p.lse[row];
-    if (tok == p.pad) s = LOGZERO;
+    if (p.mask_pad && tok == p.pad) s = LOGZERO;
     if (p.ctc) {
         const float a = p.w_att * s, c = p.w_ctc * p.ctc[row * p.V + tok];
         s = a + c;
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(BeamArgs p) {
     __shared__ float nbs[BS_MAXW];
     __shared__ long nbt[BS_MAXW];
     __shared__ int nbb[BS_MAXW];                                       // source beam (within the utterance) of every next beam
-    __shared__ int app_slot[BS_MAXW], app_beam[BS_MAXW], napp;
+    __shared__ int fsrc[BS_MAXW], nf_new;                              // new rank -> old rank (>= 0) or ~(candidate rank) of every kept hypothesis
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int W = p.W, N = W * p.V, R = 2 * W;
     const bool was_done = p.done[b] != 0;
@@ -116,54 +121,58 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(BeamArgs p) {
         __syncthreads();
     }
 
-    // ---- the utterance's ids before the step
+    // ---- the utterance's ids before the step, and its kept hypotheses
+    long* fstage = stage + W * p.cur_len;                              // [W][Lmax]
     for (int i = tid; i < W * p.cur_len; i += BS_THREADS) {
         const int k = i / p.cur_len, j = i - k * p.cur_len;
         stage[i] = p.ids[((long)b * W + k) * p.Lmax + j];
     }
+    if (!was_done)
+        for (int i = tid; i < W * p.Lmax; i += BS_THREADS) fstage[i] = p.fin_tok[(long)b * W * p.Lmax + i];
 
     // ---- walk the candidates (one thread: at most 2W steps)
     if (tid == 0) {
-        napp = 0;
-        for (int k = 0; k < W; ++k) { nbs[k] = 0.f; nbt[k] = was_done ? p.pad : 0; nbb[k] = 0; }
+        for (int k = 0; k < W; ++k) { nbs[k] = 0.f; nbt[k] = was_done ? p.pad : 0; nbb[k] = 0; fsrc[k] = k; }
+        nf_new = p.nfin[b];
         if (!was_done) {
-            int nf = p.nfin[b], k = 0;
+            const bool at_max = p.cur_len + 1 >= p.max_length;
+            bool hit[2 * BS_MAXW];
+            int nr = 0;
             for (int r = 0; r < R; ++r) {
-                const float s = tops[r];
-                const int idx = topi[r];
-                if (idx == 0x7fffffff) break;
-                const int beam = idx / p.V, tok = idx - beam * p.V;
-                if (tok == p.eos) {
-                    if (r >= W) continue;
-                    if (nf < p.cap) {
-                        p.fin_score[(long)b * p.cap + nf] = (double)s / p.denom;
-                        p.fin_len[(long)b * p.cap + nf] = p.cur_len + 1;
-                        app_slot[napp] = nf; app_beam[napp] = beam; ++napp;
-                    }
-                    ++nf;
-                } else {
-                    nbs[k] = s; nbt[k] = tok; nbb[k] = beam;
-                    ++k;
-                }
-                if (k == W) break;
+                if (topi[r] == 0x7fffffff) break;
+                const int tok = topi[r] % p.V;
+                hit[r] = tok == p.eos || at_max;
+                ++nr;
             }
-            if (nf > p.cap) nf = p.cap;
+            // the W best candidates that did not stop run on; when fewer are left (max_length) the stopped ones follow, lowered by 1e9
+            int k = 0;
+            for (int r = 0; r < nr && k < W; ++r)
+                if (!hit[r]) { nbs[k] = tops[r]; nbt[k] = topi[r] % p.V; nbb[k] = topi[r] / p.V; ++k; }
+            for (int r = 0; r < nr && k < W; ++r)
+                if (hit[r]) { nbs[k] = tops[r] + -1.0e9f; nbt[k] = topi[r] % p.V; nbb[k] = topi[r] / p.V; ++k; }
+            // stopped candidates among the first W ranks compete with the kept hypotheses: best W, best first, an equal score behind the older one
+            int nf = nf_new;
+            float fs[BS_MAXW];
+            int fl[BS_MAXW];
+            for (int i = 0; i < nf; ++i) { fs[i] = p.fin_score[(long)b * W + i]; fl[i] = p.fin_len[(long)b * W + i]; }
+            for (int r = 0; r < nr && r < W; ++r) {
+                if (!hit[r]) continue;
+                const float sc = tops[r] / p.denom;
+                int pos = nf;
+                while (pos > 0 && sc > fs[pos - 1]) --pos;
+                if (pos >= W) continue;
+                const int last = nf < W ? nf : W - 1;
+                for (int i = last; i > pos; --i) { fs[i] = fs[i - 1]; fl[i] = fl[i - 1]; fsrc[i] = fsrc[i - 1]; }
+                fs[pos] = sc; fl[pos] = p.cur_len + 1; fsrc[pos] = ~r;
+                if (nf < W) ++nf;
+            }
+            for (int i = 0; i < nf; ++i) { p.fin_score[(long)b * W + i] = fs[i]; p.fin_len[(long)b * W + i] = fl[i]; }
+            nf_new = nf;
             p.nfin[b] = nf;
-            if (nf >= W) {                                             // worst of the best W closed hypotheses
-                const double* fs = p.fin_score + (long)b * p.cap;
-                double worst = 0.0;
-                int taken[BS_MAXW];
-                for (int q = 0; q < W; ++q) {
-                    int bi = -1;
-                    for (int i = 0; i < nf; ++i) {
-                        bool used = false;
-                        for (int u = 0; u < q; ++u) used = used || taken[u] == i;
-                        if (!used && (bi < 0 || fs[i] > fs[bi])) bi = i;
-                    }
-                    taken[q] = bi; worst = fs[bi];
-                }
-                if ((double)tops[0] / p.denom <= worst) p.done[b] = 1;
-            }
+            // early-stop rule on the state after the step
+            const float best = nbs[0] / p.heur_denom;
+            const bool unsat = best > (nf == W ? fs[W - 1] : -1.0e9f);
+            if (!unsat || (p.early_stopping == 1 && nf == W) || at_max) p.done[b] = 1;
         }
         if (p.done_out) p.done_out[b] = p.done[b];
         if (p.top_s)
@@ -171,12 +180,19 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(BeamArgs p) {
     }
     __syncthreads();
 
-    // ---- closed hypotheses keep their tokens; the ids follow their beams and take the new token
-    for (int a = 0; a < napp; ++a) {
-        long* dst = p.fin_tok + ((long)b * p.cap + app_slot[a]) * p.Lmax;
-        for (int j = tid; j < p.cur_len; j += BS_THREADS) dst[j] = stage[app_beam[a] * p.cur_len + j];
-        if (tid == 0) dst[p.cur_len] = p.eos;
-    }
+    // ---- the kept hypotheses move to their new ranks (old rows from the LDS copy, new ones = their beam's ids + the closing token)
+    if (!was_done)
+        for (int i = 0; i < nf_new; ++i) {
+            const int src = fsrc[i];
+            if (src == i) continue;
+            long* dst = p.fin_tok + ((long)b * W + i) * p.Lmax;
+            if (src >= 0) {
+                for (int j = tid; j < p.Lmax; j += BS_THREADS) dst[j] = fstage[src * p.Lmax + j];
+            } else {
+                const int r = ~src, beam = topi[r] / p.V;
+                for (int j = tid; j < p.Lmax; j += BS_THREADS) dst[j] = j < p.cur_len ? stage[beam * p.cur_len + j] : (j == p.cur_len ? (long)(topi[r] % p.V) : (long)p.pad);
+            }
+        }
     for (int i = tid; i < W * p.cur_len; i += BS_THREADS) {
         const int k = i / p.cur_len, j = i - k * p.cur_len;
         p.ids[((long)b * W + k) * p.Lmax + j] = stage[nbb[k] * p.cur_len + j];
@@ -192,17 +208,18 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(BeamArgs p) {
 
 }  // namespace
 
-extern "C" int mi_beam_step(const float* logits, long ldl, const float* lse, const float* ctc, float w_att, float w_ctc, int pad, int eos, int B, int W, int V,
-                            int cur_len, int Lmax, double denom, long* ids, float* beam_scores, long* new_tok, long* beam_idx, int* done, int* nfin,
-                            double* fin_score, int* fin_len, long* fin_tok, int cap, float* top_s, int* top_i, int* done_out, hipStream_t stream) {
+extern "C" int mi_beam_step(const float* logits, long ldl, const float* lse, const float* ctc, float w_att, float w_ctc, int mask_pad, int pad, int eos, int B, int W,
+                            int V, int cur_len, int max_length, int Lmax, float denom, float heur_denom, int early_stopping, long* ids, float* beam_scores, long* new_tok,
+                            long* beam_idx, int* done, int* nfin, float* fin_score, int* fin_len, long* fin_tok, float* top_s, int* top_i, int* done_out, hipStream_t stream) {
     MI_ENTER();
     if (!logits || !lse || !ids || !beam_scores || !new_tok || !beam_idx || !done || !nfin || !fin_score || !fin_len || !fin_tok) return MI_ERR_ARG;
-    if (B <= 0 || W <= 0 || W > BS_MAXW || V <= 0 || (long)W * V >= (1l << 24) || cur_len <= 0 || cur_len >= Lmax || cap < W || pad < 0 || pad >= V || !(denom > 0.0))
+    if (B <= 0 || W <= 0 || W > BS_MAXW || V <= 1 || (long)W * V >= (1l << 24) || cur_len <= 0 || cur_len >= Lmax || cur_len >= max_length || max_length > Lmax || pad < 0 ||
+        pad >= V || !(denom > 0.f) || !(heur_denom > 0.f) || early_stopping < 0 || early_stopping > 2)
         return MI_ERR_ARG;
-    const size_t lds = (size_t)W * cur_len * sizeof(long);
+    const size_t lds = (size_t)W * (cur_len + Lmax) * sizeof(long);
     if (lds > 96 * 1024) return MI_ERR_UNSUPPORTED;
-    BeamArgs a{logits, ldl, lse, ctc, w_att, w_ctc, pad, eos, B, W, V, cur_len, Lmax, cap, denom, ids, beam_scores, new_tok, beam_idx, done, nfin, fin_score, fin_len, fin_tok,
-               top_s, top_i, done_out};
+    BeamArgs a{logits, ldl, lse, ctc, w_att, w_ctc, mask_pad, pad, eos, B, W, V, cur_len, max_length, Lmax, denom, heur_denom, early_stopping, ids, beam_scores, new_tok, beam_idx,
+               done, nfin, fin_score, fin_len, fin_tok, top_s, top_i, done_out};
     if (!ensure_dynamic_lds<0>(reinterpret_cast<const void*>(beam_step_kernel), 96 * 1024)) return MI_ERR_LAUNCH;        // per device (a function-local static configured only the first one)
     hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(BS_THREADS), lds, stream, a);
     MI_CHECK_LAUNCH();

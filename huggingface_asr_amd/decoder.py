@@ -266,17 +266,41 @@ class JointAEDEngine:
 # Joint CTC/attention decoding (config 5 of BASELINE.json): greedy (W = 1) and beam search with the device-side CTC
 # prefix scorer.  Mirrors what the reference obtains from GenerationMixin.generate + its logits processors
 # (ctc_encoder_plus_autoregressive_decoder.py:360-482, hf_shared_models/ED_small.py:20-22: ctc_weight 0.3, num_beams 5):
-# scores = log_softmax(decoder logits) -> pad masked -> (1-w)*att + w*ctc -> + beam score -> top 2W over W*V ->
-# finished hypotheses scored sum_logprob / len**length_penalty (HF BeamSearchScorer semantics, early_stopping=False).
-def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_length=64, ctc_weight=0.3, length_penalty=1.0,
-             eos_token_id=1, pad_token_id=None, start_token_id=None, space_token_id=-1, run_ahead=2, stats=None):
+# scores = log_softmax(decoder logits) -> [CTC processor: pad masked, (1-w)*att + w*ctc] -> + running beam score -> top 2W over W*V ->
+# candidates that stop (EOS, or max_length reached) among the first W ranks join the kept hypotheses with sum_logprob / generated_tokens**length_penalty,
+# the best W are kept; the first W that did not stop run on; the early-stop rule compares the best running beam with the worst kept hypothesis
+# (transformers/generation/utils.py `_beam_search` of the installed 5.x — the loop the reference's generate() runs here; pinned by tests/golden/gen_*.npz,
+# restated in oracle/generate_ref.py).
+_ES_MODE = {False: 0, True: 1, "never": 2}
+
+
+def _step_denoms(cur_len, max_length, length_penalty, early_stopping):
+    """(closing denominator, early-stop denominator) of the step that extends prefixes of `cur_len` tokens (one of them the start token), as fp32 values:
+    generated tokens of a hypothesis closed now = cur_len; hypothetical length of the early-stop rule = cur_len, or max_length - 1 for "never" with a positive penalty."""
+    import numpy as np
+    hyp = (max_length - 1) if (early_stopping == "never" and length_penalty > 0.0) else cur_len
+    return float(np.float32(cur_len ** length_penalty)), float(np.float32(hyp ** length_penalty))
+
+
+def _check_generate_args(num_beams, max_length, early_stopping):
+    if early_stopping not in _ES_MODE:
+        raise ValueError(f"early_stopping must be False, True or 'never', got {early_stopping!r}")
+    if num_beams < 1 or max_length < 2:
+        raise ValueError(f"num_beams >= 1 and max_length >= 2 required, got {num_beams}, {max_length}")
+
+
+def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_length=64, ctc_weight=0.3, length_penalty=1.0, early_stopping=False,
+             eos_token_id=1, pad_token_id=None, start_token_id=None, space_token_id=-1, apply_eos_space_trick=False, eos_space_trick_weight=1.0,
+             run_ahead=2, stats=None, trace=None):
     """Device-resident decoding loop: per token the decoder step (one C call), the row log-sum-exp and ONE launch that mixes the CTC prefix scores in, takes the top 2W
-    candidates, walks them with BeamSearchScorer's rules and moves ids / beam scores / closed hypotheses on the device (csrc/beam_step.hip).  The CTC prefix scorer of step t
+    candidates, applies the beam loop's rules and moves ids / beam scores / kept hypotheses on the device (csrc/beam_step.hip).  The CTC prefix scorer of step t
     depends on the prefixes only, not on the decoder's logits: it runs on a second stream beside the decoder step.  Nothing is copied to the host until decoding ends, except
     the per-utterance `done` flags (the kernel writes them into pinned, device-mapped memory): the host stays at most `run_ahead` steps in front of the GPU and stops enqueuing once every utterance is done.
-    Same hypotheses, scores and order as `generate_stepwise` (same arithmetic, operation for operation).  `stats` (a dict) receives the host time spent enqueuing the
-    token loop and the number of steps enqueued."""
+    Returns per utterance dict(tokens, score, hypotheses = the kept (score, tokens), best first, at most W).  Same hypotheses, scores and order as `generate_stepwise`
+    (same arithmetic, operation for operation).  `stats` (a dict) receives the host time spent enqueuing the token loop and the number of steps enqueued; `trace` (a list)
+    receives per step the (B, 2W) candidate values and indices the kernel walked and the (B) done flags before the step (device tensors)."""
     from .decoding import CTCRescorerLogitsProcessor
+    _check_generate_args(num_beams, max_length, early_stopping)
     dev = joint.device
     c = joint.jcfg
     pad = c["pad_token_id"] if pad_token_id is None else pad_token_id
@@ -285,17 +309,19 @@ def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_lengt
     L_ = _lib.lib()
     main = torch.cuda.current_stream()
     V = joint.dec.w["lm_head"].shape[0]
-    if W > 16 or W * V >= (1 << 24) or W * (max_length + 1) * 8 > 96 * 1024:      # outside mi_beam_step's limits (beams, candidates, the id buffer it stages in 96 KiB of LDS): the same
-        # decoding with the bookkeeping on the host (still the HIP kernels for everything else) — decided here, not by an error in the middle of a decode
+    Lmax = max_length + 1
+    if apply_eos_space_trick or W > 16 or W * V >= (1 << 24) or W * (max_length + Lmax) * 8 > 96 * 1024:
+        # the eos / space trick (ctc_scorer.py:333-349) lives in the processor the host loop calls; beyond mi_beam_step's limits (beams, candidates, the two id buffers it
+        # stages in 96 KiB of LDS) the bookkeeping runs on the host as well (still the HIP kernels for everything else) — decided here, not by an error in the middle of a decode
         return generate_stepwise(joint, feats, feat_len, num_beams=num_beams, max_length=max_length, ctc_weight=ctc_weight, length_penalty=length_penalty,
-                                 eos_token_id=eos_token_id, pad_token_id=pad_token_id, start_token_id=start_token_id, space_token_id=space_token_id)
+                                 early_stopping=early_stopping, eos_token_id=eos_token_id, pad_token_id=pad_token_id, start_token_id=start_token_id,
+                                 space_token_id=space_token_id, apply_eos_space_trick=apply_eos_space_trick, eos_space_trick_weight=eos_space_trick_weight)
     enc_out, enc_bf, T2, key_len = joint.encode(feats, feat_len)
     B = feats.shape[0]
     d = enc_bf.shape[1]
     enc_rep = enc_bf.view(B, T2, d).repeat_interleave(W, 0).reshape(B * W * T2, d)
     key_rep = key_len.repeat_interleave(W) if key_len is not None else None
     kvs = joint.dec.cross_kv(enc_rep)
-    Lmax = max_length + 1
     cache = joint.dec.init_cache(B * W, Lmax)
     proc, side = None, None
     if ctc_weight > 0:
@@ -314,12 +340,11 @@ def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_lengt
     beam_scores = torch.zeros((B, W), device=dev)
     beam_scores[:, 1:] = -1e9
     beam_scores = beam_scores.view(-1).contiguous()
-    cap = W * max_length
     done = torch.zeros((B,), dtype=torch.int32, device=dev)
     nfin = torch.zeros((B,), dtype=torch.int32, device=dev)
-    fin_score = torch.zeros((B, cap), dtype=torch.float64, device=dev)
-    fin_len = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-    fin_tok = torch.zeros((B, cap, Lmax), dtype=torch.long, device=dev)
+    fin_score = torch.zeros((B, W), dtype=torch.float32, device=dev)
+    fin_len = torch.zeros((B, W), dtype=torch.int32, device=dev)
+    fin_tok = torch.full((B, W, Lmax), pad, dtype=torch.long, device=dev)
     done_host = torch.zeros((max_length, B), dtype=torch.int32).pin_memory()
     new_tok = ids[:, :1].contiguous()
     flags = []                                 # (event, step) of the done-flag copies
@@ -327,6 +352,7 @@ def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_lengt
     ev_ids.record(main)
     cur_len, steps = 1, 0
     w_att, w_ctc = float(1 - ctc_weight), float(ctc_weight)
+    es_mode = _ES_MODE[early_stopping]
     t_loop = time.perf_counter()
     while cur_len < max_length:
         if len(flags) >= run_ahead:            # bounded run-ahead: wait for the flags of step (now - run_ahead) and stop if everything is done
@@ -348,10 +374,16 @@ def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_lengt
             main.wait_event(ev_ctc)
         new_tok = torch.empty((n_bh, 1), dtype=torch.long, device=dev)
         beam_idx = torch.empty((n_bh,), dtype=torch.long, device=dev)
-        _lib.check(L_.mi_beam_step(logits.data_ptr(), logits.stride(0), lse.data_ptr(), ctc.data_ptr() if ctc is not None else None, w_att, w_ctc, pad, eos_token_id,
-                                   B, W, V, cur_len, Lmax, float(cur_len ** length_penalty), ids.data_ptr(), beam_scores.data_ptr(), new_tok.data_ptr(), beam_idx.data_ptr(),
-                                   done.data_ptr(), nfin.data_ptr(), fin_score.data_ptr(), fin_len.data_ptr(), fin_tok.data_ptr(), cap, None, None, done_host[steps].data_ptr(), main.cuda_stream),
-                   "mi_beam_step")
+        top_s = top_i = None
+        if trace is not None:
+            top_s, top_i = torch.empty((B, 2 * W), device=dev), torch.empty((B, 2 * W), dtype=torch.int32, device=dev)
+            trace.append((top_s, top_i, done.clone()))          # the done flags BEFORE the step
+        denom, heur = _step_denoms(cur_len, max_length, length_penalty, early_stopping)
+        _lib.check(L_.mi_beam_step(logits.data_ptr(), logits.stride(0), lse.data_ptr(), ctc.data_ptr() if ctc is not None else None, w_att, w_ctc, int(proc is not None), pad,
+                                   eos_token_id, B, W, V, cur_len, max_length, Lmax, denom, heur, es_mode, ids.data_ptr(), beam_scores.data_ptr(), new_tok.data_ptr(),
+                                   beam_idx.data_ptr(), done.data_ptr(), nfin.data_ptr(), fin_score.data_ptr(), fin_len.data_ptr(), fin_tok.data_ptr(),
+                                   top_s.data_ptr() if top_s is not None else None, top_i.data_ptr() if top_i is not None else None, done_host[steps].data_ptr(),
+                                   main.cuda_stream), "mi_beam_step")
         ev_ids = torch.cuda.Event()
         ev_ids.record(main)
         if W > 1:
@@ -364,27 +396,22 @@ def generate(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_lengt
         stats["steps"] = steps
     if side is not None:
         main.wait_stream(side)
-    ids_cpu, bs = ids[:, :cur_len].cpu(), beam_scores.cpu().view(B, W)                  # the first copy synchronises with everything enqueued
-    done_c, nfin_c, fs_c, fl_c, ft_c = done.cpu(), nfin.cpu(), fin_score.cpu(), fin_len.cpu(), fin_tok.cpu()
-    # steps enqueued after every utterance was done changed nothing but the ids' tail (pad tokens): drop them like the host loop, which never ran them
-    n_done = next((t + 1 for t in range(steps) if bool(done_host[t].all())), steps)
-    out_len = 1 + n_done
+    nfin_c, fs_c, fl_c, ft_c = nfin.cpu(), fin_score.cpu(), fin_len.cpu(), fin_tok.cpu()             # the first copy synchronises with everything enqueued
     out = []
-    for b in range(B):
-        finished = [(float(fs_c[b, k]), ft_c[b, k, :int(fl_c[b, k])].tolist()) for k in range(int(nfin_c[b]))]
-        if not bool(done_c[b]):
-            for k in range(W):
-                finished.append((float(bs[b, k]) / (out_len ** length_penalty), ids_cpu[b * W + k, :out_len].tolist()))
-        best = max(finished, key=lambda t: t[0])
-        out.append(dict(tokens=best[1], score=best[0], hypotheses=sorted(finished, key=lambda t: -t[0])))      # hypotheses: every kept (score, tokens), best first
+    for b in range(B):                         # every utterance ends with kept hypotheses: at max_length the step's first W candidates all stop
+        hyps = [(float(fs_c[b, k]), ft_c[b, k, :int(fl_c[b, k])].tolist()) for k in range(int(nfin_c[b]))]
+        out.append(dict(tokens=hyps[0][1], score=hyps[0][0], hypotheses=hyps))
     return out
 
 
-def generate_stepwise(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_length=64, ctc_weight=0.3, length_penalty=1.0,
-             eos_token_id=1, pad_token_id=None, start_token_id=None, space_token_id=-1):
+def generate_stepwise(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, max_length=64, ctc_weight=0.3, length_penalty=1.0, early_stopping=False,
+                      eos_token_id=1, pad_token_id=None, start_token_id=None, space_token_id=-1, apply_eos_space_trick=False, eos_space_trick_weight=1.0):
     """The same decoding with the beam bookkeeping on the host, one token at a time (two device -> host copies and three host -> device copies per token): the form the
-    reference's generate() has, kept as the cross-check of `generate` (tests/test_gpu_config5.py, tests/test_gpu_aed.py compare the two hypothesis for hypothesis)."""
+    reference's generate() has, kept as the cross-check of `generate` (tests/test_gpu_config5.py, tests/test_gpu_aed.py compare the two hypothesis for hypothesis) and as
+    the route of the eos / space trick (the processor applies it, ctc_scorer.py:333-349)."""
+    import numpy as np
     from .decoding import CTCRescorerLogitsProcessor
+    _check_generate_args(num_beams, max_length, early_stopping)
     dev = joint.device
     c = joint.jcfg
     pad = c["pad_token_id"] if pad_token_id is None else pad_token_id
@@ -401,61 +428,56 @@ def generate_stepwise(joint: "JointAEDEngine", feats, feat_len, *, num_beams=1, 
     proc = None
     if ctc_weight > 0:
         lens = enc_out["outer_len"].clamp(max=T2)
-        proc = CTCRescorerLogitsProcessor(enc_out["logits"], lens, pad, eos_token_id, 0, ctc_weight, W, space_token_id, False, 1.0)
+        proc = CTCRescorerLogitsProcessor(enc_out["logits"], lens, pad, eos_token_id, 0, ctc_weight, W, space_token_id, bool(apply_eos_space_trick), eos_space_trick_weight)
     ids = torch.full((B * W, 1), start, dtype=torch.long, device=dev)
     beam_scores = torch.zeros((B, W), device=dev)
     beam_scores[:, 1:] = -1e9
     beam_scores = beam_scores.view(-1)
-    finished = [[] for _ in range(B)]          # (score, tokens)
+    kept = [[] for _ in range(B)]              # (score fp32, tokens), best first, at most W
     done = [False] * B
     new_tok = ids
     V = joint.dec.w["lm_head"].shape[0]
+    NEG = np.float32(-1.0e9)
     while ids.shape[1] < max_length and not all(done):
         logits = joint.dec.step(new_tok, cache, kvs, T2, key_rep)                       # (B*W, V)
-        from . import ops as _ops
-        scores = logits - _ops.row_lse(logits.contiguous())[:, None]                     # log_softmax
+        scores = logits - ops.row_lse(logits.contiguous())[:, None]                      # log_softmax
         if proc is not None:
             scores = proc(ids, scores.clone())
-        else:
-            scores = scores.clone(); scores[:, pad] = -10000000000.0
         cand = (scores + beam_scores[:, None]).view(B, W * V)
         top_s, top_i = cand.topk(2 * W, dim=1)
-        top_s, top_i = top_s.cpu(), top_i.cpu()
+        top_s, top_i = top_s.cpu().numpy(), top_i.cpu().numpy()
         cur_len = ids.shape[1]
+        at_max = cur_len + 1 >= max_length
+        denom, heur = (np.float32(v) for v in _step_denoms(cur_len, max_length, length_penalty, early_stopping))
         nb_scores = torch.zeros((B, W)); nb_tok = torch.zeros((B, W), dtype=torch.long); nb_idx = torch.zeros((B, W), dtype=torch.long)
         ids_cpu = ids.cpu()
         for b in range(B):
             if done[b]:
                 nb_scores[b] = 0; nb_tok[b] = pad; nb_idx[b] = b * W
                 continue
-            k = 0
-            for rank in range(2 * W):
-                s, idx = float(top_s[b, rank]), int(top_i[b, rank])
-                beam, tok = idx // V, idx % V
-                if tok == eos_token_id:
-                    if rank >= W:
-                        continue
-                    finished[b].append((s / (cur_len ** length_penalty), ids_cpu[b * W + beam].tolist() + [tok]))
-                else:
-                    nb_scores[b, k], nb_tok[b, k], nb_idx[b, k] = s, tok, b * W + beam
-                    k += 1
-                if k == W:
-                    break
-            if len(finished[b]) >= W:            # HF early_stopping=False heuristic: best running beam cannot beat the worst kept
-                worst = sorted(finished[b], key=lambda t: -t[0])[W - 1][0]
-                if float(top_s[b].max()) / (cur_len ** length_penalty) <= worst:
-                    done[b] = True
+            rows = [(np.float32(top_s[b, r]), int(top_i[b, r]) // V, int(top_i[b, r]) % V) for r in range(2 * W)]
+            hit = [tok == eos_token_id or at_max for _, _, tok in rows]
+            nxt = [(s, beam, tok) for (s, beam, tok), h in zip(rows, hit) if not h][:W]
+            nxt += [(np.float32(s + NEG), beam, tok) for (s, beam, tok), h in zip(rows, hit) if h][:W - len(nxt)]
+            for k, (s, beam, tok) in enumerate(nxt):
+                nb_scores[b, k], nb_tok[b, k], nb_idx[b, k] = float(s), tok, b * W + beam
+            for r in range(W):
+                if hit[r]:
+                    s, beam, tok = rows[r]
+                    sc = np.float32(s / denom)
+                    pos = len(kept[b])
+                    while pos > 0 and sc > kept[b][pos - 1][0]:
+                        pos -= 1
+                    if pos < W:
+                        kept[b].insert(pos, (sc, ids_cpu[b * W + beam].tolist() + [tok]))
+                        del kept[b][W:]
+            best = np.float32(nxt[0][0] / heur)
+            unsat = best > (kept[b][W - 1][0] if len(kept[b]) == W else NEG)
+            if (not unsat) or (early_stopping is True and len(kept[b]) == W) or at_max:
+                done[b] = True
         beam_idx = nb_idx.view(-1).to(dev)
         new_tok = nb_tok.view(-1, 1).to(dev)
         beam_scores = nb_scores.view(-1).to(dev)
         ids = torch.cat([ids.index_select(0, beam_idx), new_tok], 1)
         joint.dec.reorder_cache(cache, beam_idx)
-    ids_cpu, bs = ids.cpu(), beam_scores.cpu().view(B, W)
-    out = []
-    for b in range(B):
-        if not done[b]:
-            for k in range(W):
-                finished[b].append((float(bs[b, k]) / (ids_cpu.shape[1] ** length_penalty), ids_cpu[b * W + k].tolist()))
-        best = max(finished[b], key=lambda t: t[0])
-        out.append(dict(tokens=best[1], score=best[0], hypotheses=sorted(finished[b], key=lambda t: -t[0])))      # hypotheses: every kept (score, tokens), best first
-    return out
+    return [dict(tokens=kept[b][0][1], score=float(kept[b][0][0]), hypotheses=[(float(s), t) for s, t in kept[b]]) for b in range(B)]

@@ -343,21 +343,114 @@ class JointCTCAttentionEncoderDecoder(PreTrainedModel):
         return Seq2SeqLMOutputLosses(loss=out["loss"], enc_loss=out["enc_loss"], dec_loss=out["dec_loss"], logits=out["logits"],
                                      encoder_last_hidden_state=out["encoder_hidden"].view(B, T2, -1), encoder_logits=out["encoder_logits"])
 
+    # generation options that change the decoding and that the HIP loop does not implement: name -> the values that leave them off
+    _GENERATION_OFF = {"do_sample": (None, False), "num_beam_groups": (None, 1), "penalty_alpha": (None,), "dola_layers": (None,), "min_length": (None, 0),
+                       "min_new_tokens": (None, 0), "repetition_penalty": (None, 1.0), "no_repeat_ngram_size": (None, 0), "encoder_no_repeat_ngram_size": (None, 0),
+                       "bad_words_ids": (None,), "force_words_ids": (None,), "constraints": (None,), "forced_bos_token_id": (None,), "forced_eos_token_id": (None,),
+                       "remove_invalid_values": (None, False), "exponential_decay_length_penalty": (None,), "suppress_tokens": (None,), "begin_suppress_tokens": (None,),
+                       "sequence_bias": (None,), "guidance_scale": (None, 1.0), "renormalize_logits": (None, False), "diversity_penalty": (None, 0.0),
+                       "lm_weight": (None, 0, 0.0), "output_logits": (None, False), "low_memory": (None, False), "token_healing": (None, False),
+                       "max_time": (None,), "stop_strings": (None,), "prompt_lookup_num_tokens": (None,), "watermarking_config": (None,)}
+    _MODEL_KWARGS = ("attention_mask", "labels", "use_cache", "output_attentions", "output_hidden_states", "return_dict")
+
     @torch.no_grad()
-    def generate(self, inputs=None, generation_config=None, attention_mask=None, input_values=None, input_features=None, **kwargs):
-        """Joint CTC/attention decoding (reference :450-482 + :360-404): returns (B, L) token ids padded with pad_token_id."""
+    def generate(self, inputs=None, generation_config=None, logits_processor=None, stopping_criteria=None, prefix_allowed_tokens_fn=None, synced_gpus=None,
+                 assistant_model=None, streamer=None, input_values=None, input_features=None, **kwargs):
+        """Joint CTC / attention decoding with the reference's call contract (`generate`, ctc_encoder_plus_autoregressive_decoder.py:450-482, its processors :360-404;
+        call sites: `do_generate`, src/utilities/general_utils.py:198-218 — `generation_config=..., **batch` incl. `labels`, `num_return_sequences`,
+        `return_dict_in_generate`, `output_scores`, reads `.sequences` / `.sequences_scores`; `Seq2SeqTrainer.prediction_step` through `do_evaluate` :148-158 —
+        `**batch, max_length=, num_beams=, output_hidden_states=True`; the configuration the trainer assigns, src/trainers/train_enc_dec_asr.py:61-85).
+        Returns what transformers' generate returns for the same request: a (B * num_return_sequences, L) LongTensor padded with `pad_token_id`, or — with
+        `return_dict_in_generate` — `GenerateBeamEncoderDecoderOutput(sequences, sequences_scores)` (beam search; best first per utterance) /
+        `GenerateEncoderDecoderOutput(sequences)` (greedy: no sequence scores, as in transformers).  Per-step `scores` are not collected (None).
+        As in the reference, the CTC processor's parameters come from the MODEL's `generation_config` (:385-396) while the passed configuration only gates it (:382).
+        Every other option that would change the decoding raises instead of being ignored."""
+        import copy
+
+        from transformers.generation.utils import GenerateBeamEncoderDecoderOutput, GenerateEncoderDecoderOutput
+        for name, v in (("logits_processor", logits_processor), ("stopping_criteria", stopping_criteria), ("prefix_allowed_tokens_fn", prefix_allowed_tokens_fn),
+                        ("assistant_model", assistant_model), ("streamer", streamer)):
+            if v is not None and not (hasattr(v, "__len__") and len(v) == 0):
+                raise NotImplementedError(f"JointCTCAttentionEncoderDecoder.generate (HIP): `{name}` is not supported")
+        if synced_gpus:
+            raise NotImplementedError("JointCTCAttentionEncoderDecoder.generate (HIP): synced_gpus=True is not supported (every rank decodes its own batch to the end)")
+        g = copy.deepcopy(generation_config if generation_config is not None else self.generation_config)
+        model_kwargs = {}
+        for k, v in kwargs.items():                       # transformers: generation attributes passed as keyword arguments override the configuration, the rest is for the model
+            if hasattr(g, k):
+                setattr(g, k, v)
+            else:
+                model_kwargs[k] = v
+        for k in ("decoder_input_ids", "decoder_attention_mask", "encoder_outputs", "decoder_inputs_embeds", "past_key_values"):
+            if model_kwargs.get(k) is not None:
+                raise NotImplementedError(f"JointCTCAttentionEncoderDecoder.generate (HIP): `{k}` is not supported (decoding starts from `decoder_start_token_id`)")
+        unused = [k for k, v in model_kwargs.items() if k not in self._MODEL_KWARGS and v is not None]
+        if unused:                                        # transformers `_validate_model_kwargs`
+            raise ValueError(f"The following `model_kwargs` are not used by the model: {unused} (note: typos in the generate arguments will also show up in this list)")
+        for name, off in self._GENERATION_OFF.items():
+            v = getattr(g, name, None)
+            if v not in off:
+                raise NotImplementedError(f"JointCTCAttentionEncoderDecoder.generate (HIP): generation option `{name}={v!r}` is not implemented "
+                                          f"(implemented: num_beams, max_length / max_new_tokens, length_penalty, early_stopping, num_return_sequences, ctc_weight, "
+                                          f"ctc_margin, space_token_id, apply_eos_space_trick, eos_space_trick_weight, return_dict_in_generate, output_scores)")
         inputs = self._pick_inputs(inputs, input_values, input_features)
-        g = generation_config if generation_config is not None else self.generation_config
-        gv = lambda k, d: kwargs.get(k, getattr(g, k, None)) if kwargs.get(k, getattr(g, k, None)) is not None else d
+        attention_mask = model_kwargs.get("attention_mask")
+        W = int(getattr(g, "num_beams", None) or 1)
+        nret = int(getattr(g, "num_return_sequences", None) or 1)
+        if W == 1 and nret != 1:
+            raise ValueError(f"Greedy methods without beam search do not support `num_return_sequences` different than 1 (got {nret}).")
+        if nret > W:
+            raise ValueError(f"`num_return_sequences` ({nret}) has to be smaller or equal to `num_beams` ({W}).")
+        ret_dict = bool(getattr(g, "return_dict_in_generate", False))
+        if ret_dict and (getattr(g, "output_attentions", False) or getattr(g, "output_hidden_states", False)):
+            raise NotImplementedError("JointCTCAttentionEncoderDecoder.generate (HIP): attention / hidden-state outputs are not collected")
+        if getattr(g, "max_new_tokens", None) is not None:
+            max_length = int(g.max_new_tokens) + 1         # the decoder prompt is the start token
+        else:
+            max_length = int(getattr(g, "max_length", None) or 20)
+        lp = getattr(g, "length_penalty", None)
+        lp = 1.0 if lp is None else float(lp)
+        es = getattr(g, "early_stopping", None)
+        es = False if es is None else es
+        eos = getattr(g, "eos_token_id", None)
+        if isinstance(eos, (list, tuple)):
+            if len(eos) != 1:
+                raise NotImplementedError("JointCTCAttentionEncoderDecoder.generate (HIP): one eos_token_id")
+            eos = eos[0]
+        eos = self.config.decoder.eos_token_id if eos is None else int(eos)
+        pad = getattr(g, "pad_token_id", None)
+        pad = self.config.pad_token_id if pad is None else int(pad)
+        start = getattr(g, "decoder_start_token_id", None)
+        start = self.config.decoder_start_token_id if start is None else int(start)
+        ctc = dict(ctc_weight=0.0, space_token_id=-1, apply_eos_space_trick=False, eos_space_trick_weight=1.0)
+        if getattr(g, "ctc_weight", None) is not None and g.ctc_weight > 0:            # reference :382 gates on the PASSED configuration ...
+            mg = self.generation_config                                                # ... and reads the processor's parameters from the MODEL's (:385-396)
+            missing = [k for k in ("ctc_weight", "ctc_margin", "space_token_id", "apply_eos_space_trick", "eos_space_trick_weight") if not hasattr(mg, k)]
+            if missing:
+                raise AttributeError(f"model.generation_config has no {missing}: assign a GenerationConfigCustom to the model (train_enc_dec_asr.py:61-85); "
+                                     f"the CTC processor reads its parameters from there (ctc_encoder_plus_autoregressive_decoder.py:385-396)")
+            if int(mg.num_beams or 1) != W:
+                raise ValueError(f"model.generation_config.num_beams = {mg.num_beams} but decoding runs {W} beams: the reference builds its CTC prefix scorer for the "
+                                 f"model configuration's beam count (:392) and cannot decode another one (do_generate's eval_beam_factor must be 1)")
+            if (mg.pad_token_id is not None and int(mg.pad_token_id) != pad) or (mg.eos_token_id is not None and int(mg.eos_token_id) != eos):
+                raise ValueError("model.generation_config and the passed generation configuration disagree on pad_token_id / eos_token_id")
+            ctc = dict(ctc_weight=float(mg.ctc_weight), space_token_id=int(mg.space_token_id), apply_eos_space_trick=bool(mg.apply_eos_space_trick),
+                       eos_space_trick_weight=float(mg.eos_space_trick_weight))
+        if not inputs.is_cuda:
+            raise RuntimeError("JointCTCAttentionEncoderDecoder (HIP): inputs must be on the GPU; there is no CPU fallback")
         eng = self._get_engine(inputs.device)
         fl = attention_mask.sum(-1).to(torch.int32) if attention_mask is not None else None
-        pad = gv("pad_token_id", self.config.pad_token_id)
-        hyps = _generate(eng, inputs, fl, num_beams=gv("num_beams", 1), max_length=gv("max_length", 64), ctc_weight=gv("ctc_weight", 0.0),
-                         length_penalty=gv("length_penalty", 1.0), eos_token_id=gv("eos_token_id", self.config.decoder.eos_token_id),
-                         pad_token_id=pad, start_token_id=gv("decoder_start_token_id", self.config.decoder_start_token_id),
-                         space_token_id=gv("space_token_id", -1))
-        L = max(len(h["tokens"]) for h in hyps)
-        out = torch.full((len(hyps), L), pad, dtype=torch.long, device=inputs.device)
-        for b, h in enumerate(hyps):
-            out[b, : len(h["tokens"])] = torch.tensor(h["tokens"], device=inputs.device)
-        return out
+        hyps = _generate(eng, inputs, fl, num_beams=W, max_length=max_length, length_penalty=lp, early_stopping=es, eos_token_id=eos, pad_token_id=pad,
+                         start_token_id=start, **ctc)
+        rows = [h["hypotheses"][k] for h in hyps for k in range(nret)]
+        L = max(len(t) for _, t in rows)                  # (greedy: transformers runs every row until all have stopped and closed rows take pad tokens — the same layout)
+        seq = torch.full((len(rows), L), pad, dtype=torch.long)
+        for i, (_, t) in enumerate(rows):
+            seq[i, : len(t)] = torch.tensor(t)
+        seq = seq.to(inputs.device)
+        if not ret_dict:
+            return seq
+        if W == 1:
+            return GenerateEncoderDecoderOutput(sequences=seq)
+        scores = torch.tensor([s for s, _ in rows], dtype=torch.float32, device=inputs.device) if getattr(g, "output_scores", False) else None
+        return GenerateBeamEncoderDecoderOutput(sequences=seq, sequences_scores=scores)

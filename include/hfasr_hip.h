@@ -494,16 +494,20 @@ int mi_gpt2_step(const mi_gpt2_config* cfg, const void* const* weights, const lo
 int mi_kv_cache_reorder(const void* const* src_k, const void* const* src_v, void* const* dst_k, void* const* dst_v, const long* beam_idx,
                         int L, int BW, int rows, int Lmax, int d, mi_stream_t stream);
 
-/* One beam-search step of joint CTC / attention decoding on the device (csrc/beam_step.hip): what the reference gets per token from transformers' beam loop +
-   BeamSearchScorer.process on the host (src/models/ctc_encoder_plus_autoregressive_decoder.py:360-482; processors src/decoding/ctc_scorer.py:259-365).
-   cand = ((1 - w)(logits - lse, pad -> logzero) + w ctc) + beam_scores  [ctc null: no mix];  top 2W per utterance, best first, ties by lower index;  EOS within the first W
-   ranks closes a hypothesis with score / denom (denom = cur_len ** length_penalty, computed by the caller in double) into fin_* (B, cap[, Lmax]); the first W other
-   candidates become the next beams: ids (B*W, Lmax) re-ordered in place + the new token at column cur_len, new_tok / beam_idx / beam_scores (B*W) written;
-   done[b] is set when >= W hypotheses are closed and top score / denom <= the W-th best closed score; a done utterance only emits pad tokens from beam b*W.
+/* One beam-search step of joint CTC / attention decoding on the device (csrc/beam_step.hip): what the reference gets per token from transformers' beam loop on the host
+   (src/models/ctc_encoder_plus_autoregressive_decoder.py:360-482; processors src/decoding/ctc_scorer.py:259-365; the loop itself: transformers/generation/utils.py
+   `_beam_search` of the installed 5.x, the rules tests/golden/gen_*.npz pin from the reference's own generate()).
+   cand = ((1 - w)(logits - lse, pad -> logzero when mask_pad) + w ctc) + beam_scores  [ctc null: no mix];  top 2W per utterance, best first, ties by lower index;
+   a candidate stops when its token is EOS or cur_len + 1 >= max_length; the first W that did not stop become the next beams: ids (B*W, Lmax) re-ordered in place + the
+   new token at column cur_len, new_tok / beam_idx / beam_scores (B*W) written; stopped candidates among the first W ranks enter the kept hypotheses with
+   score / denom (denom = (cur_len + 1 - prompt) ** length_penalty as fp32, computed by the caller): fin_score / fin_len (B, W), fin_tok (B, W, Lmax), nfin (B) hold the
+   best W, best first.  done[b] is set when W are kept and beam_scores[b, 0] / heur_denom cannot beat the worst of them (heur_denom = (hypothetical length) **
+   length_penalty: cur_len, or max_length - prompt for early_stopping 2 = "never" with a positive penalty), when early_stopping is 1 (True) and W are kept, or at
+   max_length; a done utterance only emits pad tokens from beam b*W.
    top_s / top_i (B, 2W) optional; done_out (B) optional: the flags after the step, written for the host (pinned, device-mapped memory).  W <= 16, W * V < 2^24. */
-int mi_beam_step(const float* logits, long ldl, const float* lse, const float* ctc, float w_att, float w_ctc, int pad, int eos, int B, int W, int V,
-                 int cur_len, int Lmax, double denom, long* ids, float* beam_scores, long* new_tok, long* beam_idx, int* done, int* nfin,
-                 double* fin_score, int* fin_len, long* fin_tok, int cap, float* top_s, int* top_i, int* done_out, mi_stream_t stream);
+int mi_beam_step(const float* logits, long ldl, const float* lse, const float* ctc, float w_att, float w_ctc, int mask_pad, int pad, int eos, int B, int W, int V,
+                 int cur_len, int max_length, int Lmax, float denom, float heur_denom, int early_stopping, long* ids, float* beam_scores, long* new_tok, long* beam_idx,
+                 int* done, int* nfin, float* fin_score, int* fin_len, long* fin_tok, float* top_s, int* top_i, int* done_out, mi_stream_t stream);
 
 /* ---- Whisper-style front end + glue (BASELINE config 4).  replaces: transformers WhisperFeatureExtractor numpy path
  *      (selected by configs/default_data_preprocessing_whisper.json:20-29) and the conv/position prologue of WhisperEncoder. */

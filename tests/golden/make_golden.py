@@ -699,8 +699,121 @@ def run_ctc_prefix_cases():
     print("ctc_prefix cases written")
 
 
+def _install_generate_adapters():
+    """Harness-side adapters for the `generate()` call chain (transformers 4.39 -> 5.15): the reference's overrides keep the 4.39 signatures —
+    `_prepare_encoder_decoder_kwargs_for_generation(self, inputs_tensor, model_kwargs, model_input_name)` calls its parent without the `generation_config`
+    argument 5.15 added (ctc_encoder_plus_autoregressive_decoder.py:406-418), `_get_logits_processor` (:360-404) has no `device` parameter and hands its
+    parent `model_kwargs, negative_prompt_ids, negative_prompt_attention_mask` positionally where 5.15 expects `device` first.  The adapters restore the
+    missing argument on the parent's side from a stash a thin subclass fills on the way in; the reference's own bodies run unchanged.  Returns the class
+    factory `adapt(model)` and the recorder of the loop's decisions (instrumentation only: it reads the tensors transformers' beam loop computes)."""
+    from transformers.generation.utils import GenerationMixin
+    if getattr(GenerationMixin, "_hfasr_gen_adapters", None) is not None:
+        return GenerationMixin._hfasr_gen_adapters
+    stash, rec = {}, {"margin": [], "stop_gap": []}
+    orig_prep = GenerationMixin._prepare_encoder_decoder_kwargs_for_generation
+    orig_glp = GenerationMixin._get_logits_processor
+    orig_topk = GenerationMixin._get_top_k_continuations
+    orig_heur = GenerationMixin._check_early_stop_heuristic
+
+    def prep(self, inputs_tensor, model_kwargs, model_input_name=None, generation_config=None):
+        return orig_prep(self, inputs_tensor, model_kwargs, model_input_name, generation_config if generation_config is not None else stash["generation_config"])
+
+    def glp(self, generation_config, input_ids_seq_length=None, encoder_input_ids=None, prefix_allowed_tokens_fn=None, logits_processor=None, *rest, **kw):
+        if rest:                                   # the 4.39 positional order
+            kw.update(dict(zip(("model_kwargs", "negative_prompt_ids", "negative_prompt_attention_mask"), rest)))
+            kw.setdefault("device", stash.get("device"))
+        return orig_glp(self, generation_config, input_ids_seq_length, encoder_input_ids, prefix_allowed_tokens_fn, logits_processor, **kw)
+
+    def topk(self, accumulated_log_probs, *a, num_beams, **k):
+        v = accumulated_log_probs.topk(num_beams + 1, dim=1).values
+        rec["margin"].append((v[:, :-1] - v[:, 1:]).min(1).values.tolist())      # per utterance: the smallest gap among the top W + 1 candidates of this step
+        return orig_topk(self, accumulated_log_probs, *a, num_beams=num_beams, **k)
+
+    def heur(is_early_stop_heuristic_unsatisfied, running_beam_scores, beam_scores, is_sent_finished, cur_len, max_length, decoder_prompt_len, early_stopping, length_penalty):
+        hl = (max_length if (early_stopping == "never" and length_penalty > 0.0) else cur_len) - decoder_prompt_len
+        full = is_sent_finished.all(1)
+        gap = (running_beam_scores[:, 0] / (hl ** length_penalty) - beam_scores.min(1).values).abs()
+        rec["stop_gap"].append([float(g) if bool(f) and bool(u) else float("inf") for g, f, u in zip(gap, full, is_early_stop_heuristic_unsatisfied[:, 0])])
+        return orig_heur(is_early_stop_heuristic_unsatisfied, running_beam_scores, beam_scores, is_sent_finished, cur_len, max_length, decoder_prompt_len,
+                         early_stopping, length_penalty)
+    GenerationMixin._prepare_encoder_decoder_kwargs_for_generation = prep
+    GenerationMixin._get_logits_processor = glp
+    GenerationMixin._get_top_k_continuations = topk
+    GenerationMixin._check_early_stop_heuristic = staticmethod(heur)
+
+    def adapt(model):
+        ref = type(model)
+
+        class Adapted(ref):
+            def _prepare_encoder_decoder_kwargs_for_generation(self, inputs_tensor, model_kwargs, model_input_name=None, generation_config=None):
+                stash["generation_config"] = generation_config
+                return ref._prepare_encoder_decoder_kwargs_for_generation(self, inputs_tensor, model_kwargs, model_input_name)
+
+            def _get_logits_processor(self, generation_config, input_ids_seq_length=None, encoder_input_ids=None, prefix_allowed_tokens_fn=None,
+                                      logits_processor=None, device=None, model_kwargs=None, negative_prompt_ids=None, negative_prompt_attention_mask=None):
+                stash["device"] = device
+                return ref._get_logits_processor(self, generation_config, input_ids_seq_length, encoder_input_ids, prefix_allowed_tokens_fn, logits_processor,
+                                                 model_kwargs, negative_prompt_ids, negative_prompt_attention_mask)
+        model.__class__ = Adapted
+        return model
+    GenerationMixin._hfasr_gen_adapters = (adapt, rec)
+    return adapt, rec
+
+
+def run_generate_cases():
+    """the reference joint model's OWN `generate()` (ctc_encoder_plus_autoregressive_decoder.py:450-482 -> transformers' GenerationMixin with the
+    reference's processors, :360-404) on the tiny AED configuration with the structured decoder of tests/gen_model.py, decoded the way `do_generate` asks
+    (general_utils.py:198-218: `num_return_sequences = num_beams`, `return_dict_in_generate`, `output_scores`; the generation configuration assigned to the model as
+    train_enc_dec_asr.py:61-85 does): greedy and beams of 3 / 5, three length penalties, `early_stopping` False / True / "never", a `max_length` at which some beams close on
+    the end-of-sequence token and the rest when the length runs out, and one short enough that nothing closes before it.  Stored per setting: sequences, sequence scores, and
+    the smallest decision margins of the loop (candidate gaps, stopping-rule gaps) so that the tests can assert the fixture is decided far above bf16 noise."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import gen_model as GM
+    from decoding.config import GenerationConfigCustom
+    adapt, rec = _install_generate_adapters()
+    for name, (seed, fixed, lengths) in GM.CASES.items():
+        model = adapt(build_reference_aed(fixed))
+        wsum = load_seeded(model, seed)
+        ov = GM.overrides(seed, fixed)
+        missing, unexpected = model.load_state_dict(ov, strict=False)
+        assert not unexpected, unexpected
+        B, T = len(lengths), 200
+        x, am = synth_feats(seed, B, T, lengths)
+        out = dict(seed=seed, weight_sum=wsum, lengths=np.array(lengths), shape=np.array([B, T]), fixed_pos=np.array(int(fixed)),
+                   override_sum=np.float64(sum(float(v.double().sum()) for v in ov.values())),
+                   param_names=np.array([k for k, _ in model.named_parameters()]), param_shapes=np.array([str(tuple(v.shape)) for _, v in model.named_parameters()]))
+        for W, lp, es, ml in GM.SETTINGS:
+            g = GenerationConfigCustom(bos_token_id=GM.START, pad_token_id=GM.PAD, decoder_start_token_id=GM.START, length_penalty=lp, early_stopping=es, eos_token_id=GM.EOS,
+                                       max_length=ml, num_beams=W, ctc_weight=0.3, ctc_margin=0, lm_weight=0, lm_model=None, space_token_id=-1, apply_eos_space_trick=False,
+                                       eos_space_trick_weight=1.0)
+            model.generation_config = g                                           # train_enc_dec_asr.py:85
+            g.num_return_sequences, g.return_dict_in_generate, g.output_scores = W, True, True     # general_utils.py:198-201
+            rec["margin"].clear(); rec["stop_gap"].clear()
+            o = model.generate(generation_config=g, input_values=torch.from_numpy(x), attention_mask=torch.from_numpy(am))
+            key = GM.setting_key(W, lp, es, ml)
+            out[key + "/sequences"] = o.sequences.numpy()
+            if W > 1:
+                out[key + "/sequences_scores"] = o.sequences_scores.numpy()
+                out[key + "/min_margin"] = np.float32(min(min(m) for m in rec["margin"]))
+                sg = [v for row in rec["stop_gap"] for v in row if np.isfinite(v)]
+                out[key + "/min_stop_gap"] = np.float32(min(sg) if sg else np.inf)
+            else:                                     # greedy: the gap between the two best tokens of every step before the utterance closed
+                gaps = []
+                seqs = o.sequences.numpy()
+                for t, sc in enumerate(o.scores):
+                    top2 = sc.topk(2, dim=1).values
+                    for b in range(B):
+                        if t == 0 or (seqs[b, t] != GM.EOS and seqs[b, t] != GM.PAD):
+                            gaps.append(float(top2[b, 0] - top2[b, 1]))
+                out[key + "/min_margin"] = np.float32(min(gaps))
+            print(name, key, "margin", float(out[key + "/min_margin"]), "stop gap", float(out.get(key + "/min_stop_gap", np.inf)))
+            for i, s in enumerate(o.sequences.tolist()):
+                print("    ", s, float(o.sequences_scores[i]) if W > 1 else "")
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "grads", "base", "basegrads", "fbank", "harness", "ckptavg", "lengths", "ctc", "prefix", "aed", "aedgrads", "bestrq", "finetune", "specaug", "whisper", "whispersmall"]
+    which = sys.argv[1:] or ["tiny", "grads", "base", "basegrads", "fbank", "harness", "ckptavg", "lengths", "ctc", "prefix", "aed", "aedgrads", "gen", "bestrq", "finetune", "specaug", "whisper", "whispersmall"]
     if "tiny" in which:
         run_encoder_case("tiny_rel", TINY, seed=11, B=2, T=200, lengths=[198, 150], U=7, tgt_lens=[7, 5])
         run_encoder_case("tiny_rotary", TINY, seed=12, B=2, T=200, lengths=[200, 131], U=6, tgt_lens=[6, 4],
@@ -762,6 +875,8 @@ if __name__ == "__main__":
         run_aed_cases()
     if "aedgrads" in which:
         run_aed_grad_cases()
+    if "gen" in which:
+        run_generate_cases()
     if "bestrq" in which:
         run_bestrq_case()
     if "finetune" in which:

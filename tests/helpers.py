@@ -79,66 +79,49 @@ def bestrq_case_inputs(g):
     return sd, x, am, torch.from_numpy(g["mask"])
 
 
-def oracle_generate(sd, enc_cfg, dec_cfg, jcfg, x, am, W, max_length, ctc_weight, eos=1, margins=None):
-    """The same joint decoding loop on the CPU oracle (teacher-forced recomputation each step, oracle prefix scorer).
-    margins: a list that receives, per step and utterance, the smallest gap between consecutive candidates among the top W + 1 (the decisions beam search takes)."""
+def oracle_generate(sd, enc_cfg, dec_cfg, jcfg, x, am, W, max_length, ctc_weight, eos=1, margins=None, length_penalty=1.0, early_stopping=False, q="bf16", stop_gaps=None):
+    """Joint decoding on the CPU oracle: the loop of oracle/generate_ref.py (pinned by tests/golden/gen_*.npz against the reference's own generate()) over the oracle models
+    with the kernels' bf16 storage model (`q="bf16"`; `q=None`: plain fp32, what the fixtures were made with).  Returns per utterance (score, tokens, kept hypotheses
+    [(score, tokens)] best first); W = 1 runs the beam loop with one beam (the same tokens as transformers' greedy loop, plus a score).
+    margins / stop_gaps: lists that receive, per step, the smallest gap among the top W + 1 candidates of every utterance / the early-stop rule's gap."""
     from oracle import aed_ref as A
-    from oracle import ctc_prefix_ref as P
-    q = A.E.bf16_round
-    esd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
-    with torch.no_grad():
-        hidden = A.E.encoder_forward(esd, enc_cfg, x, am, q)
-        enc_logits = A.E.ctc_head(esd, hidden, q)
-        outer = A.E.conv_out_lengths_outer(am.sum(-1), enc_cfg).long()
-        enc_h = torch.nn.functional.linear(q(hidden), q(sd["enc_to_dec_proj.weight"]), sd["enc_to_dec_proj.bias"]) if "enc_to_dec_proj.weight" in sd else hidden
-    B, T2 = hidden.shape[:2]
-    mask = torch.arange(T2)[None] < outer[:, None]
-    pad, start, V = jcfg["pad_token_id"], jcfg["decoder_start_token_id"], dec_cfg["vocab_size"]
-    sc = P.PrefixScorer(torch.log_softmax(enc_logits, -1).numpy(), outer.numpy(), pad, W)
-    ids = torch.full((B * W, 1), start, dtype=torch.long)
-    beam_scores = torch.zeros(B, W); beam_scores[:, 1:] = -1e9; beam_scores = beam_scores.view(-1)
-    finished, done = [[] for _ in range(B)], [False] * B
-    enc_rep, mask_rep = enc_h.repeat_interleave(W, 0), mask.repeat_interleave(W, 0)
-    while ids.shape[1] < max_length and not all(done):
-        with torch.no_grad():
-            _, logits = A.decoder_forward(sd, "decoder.", dec_cfg, ids, enc_rep, mask_rep, None, q)
-        att = torch.log_softmax(logits[:, -1].float(), -1).numpy()
-        ctc = sc.step(ids.numpy())
-        scores = torch.from_numpy(P.rescore(att, ctc, pad, ctc_weight))
-        cand = (scores + beam_scores[:, None]).view(B, W * V)
-        top_s, top_i = cand.topk(2 * W, dim=1)
-        if margins is not None:
-            margins.append([float((top_s[b, :W] - top_s[b, 1:W + 1]).min()) for b in range(B)])
-        cur_len = ids.shape[1]
-        nb = []
-        for b in range(B):
-            row = []
-            if done[b]:
-                nb.append([(0.0, pad, b * W)] * W); continue
-            for rank in range(2 * W):
-                s, idx = float(top_s[b, rank]), int(top_i[b, rank])
-                beam, tok = idx // V, idx % V
-                if tok == eos:
-                    if rank < W:
-                        finished[b].append((s / cur_len, ids[b * W + beam].tolist() + [tok]))
-                else:
-                    row.append((s, tok, b * W + beam))
-                if len(row) == W:
-                    break
-            nb.append(row)
-            if len(finished[b]) >= W and float(top_s[b].max()) / cur_len <= sorted(finished[b], key=lambda t: -t[0])[W - 1][0]:
-                done[b] = True
-        beam_idx = torch.tensor([r[2] for row in nb for r in row])
-        new_tok = torch.tensor([r[1] for row in nb for r in row])[:, None]
-        beam_scores = torch.tensor([r[0] for row in nb for r in row])
-        ids = torch.cat([ids[beam_idx], new_tok], 1)
+    from oracle import generate_ref as G
+    fn, B = G.joint_score_fn(sd, enc_cfg, dec_cfg, jcfg, x, am, W, ctc_weight, q=A.E.bf16_round if q == "bf16" else q)
+    V, pad, start = dec_cfg["vocab_size"], jcfg["pad_token_id"], jcfg["decoder_start_token_id"]
+    tr = {}
+    seq, sc = G.beam_search(fn, B, W, V, max_length=max_length, eos=eos, pad=pad, start=start, length_penalty=length_penalty, early_stopping=early_stopping, trace=tr)
+    if margins is not None:
+        margins.extend([[float(v) for v in row] for row in tr["margin"]])
+    if stop_gaps is not None:
+        stop_gaps.extend([[float(v) for v in row] for row in tr["stop_gap"]])
     out = []
-    bs = beam_scores.view(B, W)
     for b in range(B):
-        if not done[b]:
-            for k in range(W):
-                finished[b].append((float(bs[b, k]) / ids.shape[1], ids[b * W + k].tolist()))
-        out.append(max(finished[b], key=lambda t: t[0]) + (sorted(finished[b], key=lambda t: -t[0]),))      # (score, tokens, every kept hypothesis best first)
+        hyps = []
+        for k in range(W):
+            t = seq[b * W + k].tolist()
+            n = len(t)
+            while n > 1 and t[n - 1] == pad:
+                n -= 1
+            hyps.append((float(sc[b * W + k]), t[:n]))
+        out.append((hyps[0][0], hyps[0][1], hyps))
     return out
 
 
+def gen_case_inputs(name):
+    """(fixture, state_dict, feats, attention_mask, decoder config) of a `gen_*` fixture: seeded weights + the structured overrides of tests/gen_model.py."""
+    import ast
+
+    import gen_model as GM
+    g = load_golden(name)
+    seed, fixed, lengths = GM.CASES[name]
+    assert seed == int(g["seed"]) and fixed == bool(int(g["fixed_pos"])) and lengths == [int(v) for v in g["lengths"]]
+    sd = {str(n): torch.from_numpy(synth.init_param(seed, str(n), ast.literal_eval(str(s)))) for n, s in zip(g["param_names"], g["param_shapes"])}
+    wsum = float(sum(v.double().sum() for v in sd.values()))
+    assert abs(wsum - float(g["weight_sum"])) < 1e-6 * max(1.0, abs(wsum))
+    ov = GM.overrides(seed, fixed)
+    osum = float(sum(float(v.double().sum()) for v in ov.values()))
+    assert abs(osum - float(g["override_sum"])) < 1e-6 * max(1.0, abs(osum)), "the structured weights drifted from the fixture"
+    sd.update(ov)
+    B, T = [int(v) for v in g["shape"]]
+    x, am = synth_feats(seed, B, T, lengths)
+    return g, sd, x, am, dict(TINY_DEC, pos_emb_fixed=fixed)

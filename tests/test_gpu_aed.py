@@ -80,6 +80,7 @@ def test_joint_decoding_matches_oracle(W):
         assert abs(got[b]["score"] - want[b][0]) < 0.05 * max(1.0, abs(want[b][0])), (got[b], want[b])
         if W == 1 or got[b]["tokens"] == want[b][1]:
             assert got[b]["tokens"] == want[b][1], (got[b], want[b])
+            assert len(got[b]["hypotheses"]) == W
         else:
             # beam search on a random-weight model is a sequence of near-ties: a bf16-level difference in one logit changes which beams survive a pruning
             # step, and the fp32 oracle and the bf16 engine may then end on different hypotheses of (almost) equal score.  A different hypothesis is accepted
@@ -105,10 +106,14 @@ def test_hf_joint_model_surface():
         assert abs(float(getattr(out, k)) - float(g[k])) < 2e-3 * abs(float(g[k])), k
     assert np.abs(out.logits.cpu().numpy() - g["logits"]).max() < 0.08
     assert out.encoder_logits.shape == (2, 50, 51) and out.encoder_last_hidden_state.shape == (2, 50, 128)
-    toks = model.generate(input_values=x.to(DEV), attention_mask=am.to(DEV), num_beams=3, max_length=8, ctc_weight=0.3)
+    from huggingface_asr_amd.decoding import GenerationConfigCustom
+    model.generation_config = GenerationConfigCustom(pad_token_id=50, eos_token_id=1, decoder_start_token_id=2, bos_token_id=2, num_beams=3, max_length=8, ctc_weight=0.3,
+                                                     length_penalty=1.0, early_stopping=False)           # what train_enc_dec_asr.py:61-85 assigns
+    toks = model.generate(input_values=x.to(DEV), attention_mask=am.to(DEV))
     ref = generate(model._get_engine(DEV), x.to(DEV), am.sum(-1).to(DEV, torch.int32), num_beams=3, max_length=8, ctc_weight=0.3)
+    assert toks.shape[0] == 2
     for b in range(2):
-        assert toks[b, : len(ref[b]["tokens"])].tolist() == ref[b]["tokens"]
+        assert toks[b, : len(ref[b]["tokens"])].tolist() == ref[b]["tokens"] and (toks[b, len(ref[b]["tokens"]):] == 50).all()
 
 
 def test_c_step_driver_matches_python_step_and_reorders_cache():
@@ -145,60 +150,26 @@ def test_c_step_driver_matches_python_step_and_reorders_cache():
     assert torch.isfinite(a).all()
 
 
-def _host_beam_step(logits, lse, ctc, w, pad, eos, B, W, V, cur_len, lp, ids, beam_scores, done, finished):
-    """the host loop's bookkeeping for one token (decoder.generate_stepwise), on CPU tensors"""
-    scores = logits - lse[:, None]
-    scores[:, pad] = -10000000000.0
-    if ctc is not None:
-        scores = (1 - w) * scores + w * ctc
-    cand = (scores + beam_scores[:, None]).view(B, W * V)
-    top = []
-    for b in range(B):                                      # (value descending, index ascending), as the kernel breaks ties
-        vals = cand[b].tolist()
-        order = sorted(range(W * V), key=lambda i: (-vals[i], i))[:2 * W]
-        top.append([(vals[i], i) for i in order])
-    nb_s, nb_t, nb_i = torch.zeros(B, W), torch.zeros(B, W, dtype=torch.long), torch.zeros(B, W, dtype=torch.long)
-    for b in range(B):
-        if done[b]:
-            nb_s[b] = 0; nb_t[b] = pad; nb_i[b] = b * W
-            continue
-        k = 0
-        for rank, (s, idx) in enumerate(top[b]):
-            s = float(np.float32(s))
-            beam, tok = idx // V, idx % V
-            if tok == eos:
-                if rank >= W:
-                    continue
-                finished[b].append((s / (cur_len ** lp), ids[b * W + beam].tolist() + [tok]))
-            else:
-                nb_s[b, k], nb_t[b, k], nb_i[b, k] = s, tok, b * W + beam
-                k += 1
-            if k == W:
-                break
-        if len(finished[b]) >= W:
-            worst = sorted(finished[b], key=lambda t: -t[0])[W - 1][0]
-            if float(np.float32(top[b][0][0])) / (cur_len ** lp) <= worst:
-                done[b] = True
-    bi = nb_i.view(-1)
-    return torch.cat([ids.index_select(0, bi), nb_t.view(-1, 1)], 1), nb_s.view(-1), nb_t.view(-1), bi
-
-
-@pytest.mark.parametrize("B,W,V,with_ctc", [(3, 4, 50, True), (2, 1, 37, True), (2, 5, 5001, False), (1, 16, 300, True)])
-def test_beam_step_kernel_follows_the_host_bookkeeping(B, W, V, with_ctc):
-    """csrc/beam_step.hip against the host loop's rules on random scores with a strong EOS (hypotheses close at most steps, utterances finish at different steps):
-    candidates, next beams, re-ordered ids, closed hypotheses and the done flags, bit for bit, over a whole decode."""
+@pytest.mark.parametrize("B,W,V,with_ctc,lp,es", [(3, 4, 50, True, 1.0, False), (2, 1, 37, True, 1.0, False), (2, 5, 5001, False, 0.7, False), (1, 16, 300, True, 1.3, "never"),
+                                                    (3, 3, 50, True, 1.0, True), (2, 5, 64, True, 1.5, False)])
+def test_beam_step_kernel_follows_the_pinned_loop(B, W, V, with_ctc, lp, es):
+    """csrc/beam_step.hip against oracle/generate_ref.py `beam_search` (the loop pinned by tests/golden/gen_*.npz against the reference's own generate()) on random
+    scores with a strong EOS from the second step on (hypotheses close at most steps, utterances finish at different steps, the rest closes at max_length): both are fed
+    the same per-step scores; candidates, kept hypotheses, their scores and order must agree exactly over a whole decode."""
     from huggingface_asr_amd import _lib, ops
+    from huggingface_asr_amd.decoder import _ES_MODE, _step_denoms
+    from oracle import generate_ref as G
     gen = torch.Generator().manual_seed(B * 1000 + W * 10 + V)
-    pad, eos, lp, steps = V - 1, 1, 1.0, 9
-    Lmax, cap, w = steps + 2, W * (steps + 1), 0.3
+    pad, eos, max_length = V - 1, 1, 11
+    steps, Lmax, w = max_length - 1, max_length + 1, 0.3
     n = B * W
     ids = torch.full((n, Lmax), pad, dtype=torch.long); ids[:, 0] = 2
     bs = torch.zeros(B, W); bs[:, 1:] = -1e9
     d_ids, d_bs = ids.to(DEV), bs.view(-1).contiguous().to(DEV)
     d_done, d_nfin = torch.zeros(B, dtype=torch.int32, device=DEV), torch.zeros(B, dtype=torch.int32, device=DEV)
-    d_fs, d_fl = torch.zeros(B, cap, dtype=torch.float64, device=DEV), torch.zeros(B, cap, dtype=torch.int32, device=DEV)
-    d_ft = torch.zeros(B, cap, Lmax, dtype=torch.long, device=DEV)
-    h_ids, h_bs, h_done, h_fin = ids[:, :1].clone(), bs.view(-1).clone(), [False] * B, [[] for _ in range(B)]
+    d_fs, d_fl = torch.zeros(B, W, dtype=torch.float32, device=DEV), torch.zeros(B, W, dtype=torch.int32, device=DEV)
+    d_ft = torch.full((B, W, Lmax), pad, dtype=torch.long, device=DEV)
+    processed, tops = [], []
     for t in range(steps):
         cur = t + 1
         Vp = (V + 7) // 8 * 8
@@ -208,27 +179,42 @@ def test_beam_step_kernel_follows_the_host_bookkeeping(B, W, V, with_ctc):
         lse = ops.row_lse(logits)
         ctc = (torch.randn(n, V, generator=gen) * 3.0 - 5.0) if with_ctc else None
         d_ctc = ctc.to(DEV) if with_ctc else None
+        sc = (logits.cpu() - lse.cpu()[:, None]).numpy()           # the kernel's arithmetic on the host, one rounding per operation
+        if with_ctc:
+            sc[:, pad] = np.float32(-10000000000.0)
+            sc = np.float32(1 - w) * sc + np.float32(w) * ctc.numpy()
+        processed.append(sc.astype(np.float32))
         new_tok, beam_idx = torch.empty(n, dtype=torch.long, device=DEV), torch.empty(n, dtype=torch.long, device=DEV)
         top_s, top_i = torch.empty(B, 2 * W, device=DEV), torch.empty(B, 2 * W, dtype=torch.int32, device=DEV)
-        _lib.check(_lib.lib().mi_beam_step(logits.data_ptr(), logits.stride(0), lse.data_ptr(), d_ctc.data_ptr() if with_ctc else None, float(1 - w), float(w), pad, eos,
-                                           B, W, V, cur, Lmax, float(cur ** lp), d_ids.data_ptr(), d_bs.data_ptr(), new_tok.data_ptr(), beam_idx.data_ptr(), d_done.data_ptr(),
-                                           d_nfin.data_ptr(), d_fs.data_ptr(), d_fl.data_ptr(), d_ft.data_ptr(), cap, top_s.data_ptr(), top_i.data_ptr(), None,
+        denom, heur = _step_denoms(cur, max_length, lp, es)
+        was_done = d_done.cpu().bool().tolist()
+        _lib.check(_lib.lib().mi_beam_step(logits.data_ptr(), logits.stride(0), lse.data_ptr(), d_ctc.data_ptr() if with_ctc else None, float(1 - w), float(w), int(with_ctc), pad, eos,
+                                           B, W, V, cur, max_length, Lmax, denom, heur, _ES_MODE[es], d_ids.data_ptr(), d_bs.data_ptr(), new_tok.data_ptr(), beam_idx.data_ptr(),
+                                           d_done.data_ptr(), d_nfin.data_ptr(), d_fs.data_ptr(), d_fl.data_ptr(), d_ft.data_ptr(), top_s.data_ptr(), top_i.data_ptr(), None,
                                            torch.cuda.current_stream().cuda_stream), "mi_beam_step")
-        was_done = list(h_done)
-        h_ids, h_bs, h_tok, h_bi = _host_beam_step(logits.cpu().clone(), lse.cpu(), ctc, w, pad, eos, B, W, V, cur, lp, h_ids, h_bs, h_done, h_fin)
-        assert torch.equal(d_ids.cpu()[:, :cur + 1], h_ids), t
-        assert torch.equal(d_bs.cpu(), h_bs) and torch.equal(new_tok.cpu(), h_tok) and torch.equal(beam_idx.cpu(), h_bi), t
-        assert d_done.cpu().bool().tolist() == h_done, t
-        assert d_nfin.cpu().tolist() == [len(f) for f in h_fin], t
-        ts = top_s.cpu()
+        tops.append((top_s.cpu().numpy(), top_i.cpu().numpy(), was_done))
+    calls = []
+
+    def score_fn(rows):                                            # the oracle loop sees the same processed scores, step by step
+        calls.append(rows.copy())
+        return processed[len(calls) - 1]
+    tr = {}
+    seq, scores = G.beam_search(score_fn, B, W, V, max_length=max_length, eos=eos, pad=pad, start=2, length_penalty=lp, early_stopping=es, trace=tr)
+    fs, fl, ft, nf = d_fs.cpu().numpy(), d_fl.cpu().numpy(), d_ft.cpu().numpy(), d_nfin.cpu().numpy()
+    assert (nf == W).all() and bool(d_done.cpu().all())            # every utterance ends with W kept hypotheses (max_length closes the rest)
+    for b in range(B):
+        for k in range(W):
+            want = seq[b * W + k]
+            n_tok = int(fl[b, k])
+            assert ft[b, k, :n_tok].tolist() == want[:n_tok].tolist() and (want[n_tok:] == pad).all(), (b, k, ft[b, k], want)
+            assert fs[b, k] == scores[b * W + k], (b, k, fs[b, k], scores[b * W + k])
+    for ts, ti, was_done in tops:                                  # candidates come best first
         for b in range(B):
             if not was_done[b]:
                 assert bool((ts[b, :-1] >= ts[b, 1:]).all())
-    fs, fl, ft = d_fs.cpu(), d_fl.cpu(), d_ft.cpu()
-    assert sum(len(f) for f in h_fin) > 0 and (any(h_done) or V > 1000 or W > 8)  # the case exercises closing and (small vocabularies, few beams) finishing
-    for b in range(B):
-        for k, (s, toks) in enumerate(h_fin[b]):
-            assert float(fs[b, k]) == s and ft[b, k, :int(fl[b, k])].tolist() == toks, (b, k)
+    ends = [int(ft[b, k, int(fl[b, k]) - 1]) for b in range(B) for k in range(W)]
+    assert eos in ends                                             # the case closes hypotheses on the end-of-sequence token ...
+    assert len(calls) >= 3                                         # ... and not all of them at once
 
 
 @pytest.mark.parametrize("W,ctc_weight", [(1, 0.3), (3, 0.3), (5, 0.3), (3, 0.0)])

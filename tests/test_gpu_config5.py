@@ -105,3 +105,25 @@ def test_beam5_hypotheses_token_for_token_at_the_reference_default_width():
         assert len(got["hypotheses"]) == len(want[2]) == W
         for (gs, gt), (ws, wt) in zip(got["hypotheses"], want[2]):
             assert gt == wt and abs(gs - ws) < 0.03, (gt, wt, gs, ws)
+
+
+def test_beam5_over_forty_tokens_at_decred_base_size():
+    """the reference's defaults are `max_length=200`, `num_beams=5` (hf_shared_models/DeCRED_base.py:20-22) and the bench decodes 40 tokens; the cases
+    above stop at 6-8.  Here: W = 5, max_length 44 (43 token steps: the KV cache is re-ordered 43 times, the CTC prefix scorer walks 43 prefixes of every beam), with an
+    end-of-sequence id chosen among the structured decoder's second-best successors so that hypotheses close along the way and the rest closes at max_length.  Held by
+    the certification of tests/test_gpu_generate.py against the oracle with the kernels' bf16 storage model: the kernel's bookkeeping exact over all 43 steps, every
+    candidate value within tolerance of the oracle's for the same prefixes, token-for-token equality of all five kept hypotheses up to a certified near tie."""
+    from test_gpu_generate import certified_decode
+    from huggingface_asr_amd.decoder import generate
+    torch.set_num_threads(8)
+    sd = M.state_dict(8, structured=True)
+    x, am = _inputs()
+    eng = _engine(sd)
+    fl = am.sum(-1).to(DEV, torch.int32)
+    greedy = generate(eng, x.to(DEV), fl, num_beams=1, max_length=44, ctc_weight=0.3, eos_token_id=10 ** 6)[0]["tokens"]
+    assert len(greedy) == 44
+    eos = M.successors(greedy[18])[1]                      # the second-best continuation after the 18th token ends a hypothesis
+    got, (ref_seq, ref_sc), diverged, worst = certified_decode(eng, sd, M.ENC_CFG, M.DEC_CFG, M.JCFG, x, am, 5, 1.0, False, 44, eos, ref_q=A.E.bf16_round, tol=0.06)
+    lens = [len(t) for _, t in got[0]["hypotheses"]]
+    print("config 5, W = 5, 43 steps: kept lengths", lens, "worst candidate-value gap", worst, "diverged at a near tie:", diverged)
+    assert len(lens) == 5 and max(lens) >= 40
