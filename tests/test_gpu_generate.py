@@ -66,7 +66,7 @@ def certified_decode(eng, sd, enc_cfg, dec_cfg, jcfg, x, am, W, lp, es, ml, eos,
             assert toks == want[: len(toks)].tolist() and (want[len(toks):] == pad).all(), ("bookkeeping", b, k, toks, want)
             assert abs(s - float(rep_sc[b * W + k])) < 1e-6 * max(1.0, abs(s)), ("bookkeeping score", b, k, s, rep_sc[b * W + k])
     worst = 0.0
-    for t, (s, i, was_done) in enumerate(dev):
+    for t, (s, i, was_done) in enumerate(dev[: len(rep["acc"])]):        # (run-ahead: the device may have enqueued steps after every utterance was closed)
         acc = rep["acc"][t]                                     # oracle values of EVERY candidate of the device's prefixes (its running scores are the device's)
         for b in range(B):
             if was_done[b] or not rep["open"][t][b]:
@@ -101,7 +101,7 @@ def certified_decode(eng, sd, enc_cfg, dec_cfg, jcfg, x, am, W, lp, es, ml, eos,
                 want = ref_seq[b * W + k]
                 toks = dev_h[k][1]
                 assert toks == want[: len(toks)].tolist() and (want[len(toks):] == pad).all(), ("tokens", b, k, toks, want)
-                assert abs(dev_h[k][0] - float(ref_sc[b * W + k])) < tol / 2, ("score", b, k, dev_h[k][0], ref_sc[b * W + k])
+                assert abs(dev_h[k][0] - float(ref_sc[b * W + k])) < tol, ("score", b, k, dev_h[k][0], ref_sc[b * W + k])
         else:
             assert dev_h[0][0] >= float(ref_sc[b * W]) - tol, ("after a near tie the best hypothesis is worse than the reference's", b, dev_h[0], ref_sc[b * W])
     return got, (ref_seq, ref_sc), diverged, worst
