@@ -656,16 +656,30 @@ def main():
         rec["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(cfg, sd)
-    train_dp = None
-    if world > 1 and not args.no_train_dp:                   # every rank: the config-3 training step under both GradSync schedules (collectives over the same process group)
-        del pipe, eng, batches
+    if world > 1 and not args.no_train_dp:
+        # The forward curve is what a multi-GPU run of this command is for: its line goes to stdout BEFORE any training collective starts, and the line with `train_dp`
+        # merged in follows as the LAST line.  A rank that fails inside `train_dp` leaves at once with a non-zero code — it never waits in a collective, and the launcher
+        # (torch.distributed.run) takes the other ranks down with it; stdout keeps the forward line.  Collectives time out after PL.COLLECTIVE_TIMEOUT_S.
+        if rank == 0:
+            print(json.dumps(dict(rec, train_dp=None, secondary=None, note="forward headline; the line with `train_dp` follows as the last line")), flush=True)
+        import gc
+        pipe = eng = batches = step = step_pipelined = one = wave = labels = state = None      # the closures above held the forward engines and their batches alive
+        gc.collect()
         torch.cuda.empty_cache()
         try:
+            if os.environ.get("HFASR_BENCH_FAIL_RANK") == str(rank):                              # test knob: a rank-local failure at the worst moment
+                raise RuntimeError("injected failure (HFASR_BENCH_FAIL_RANK)")
             train_dp = train_dp_record(args, world, rank, dev, PL)
-        except Exception as e:  # noqa: BLE001 — the headline line must come out
-            train_dp = {"error": f"{type(e).__name__}: {e}"[:300]}
-    if rank == 0:
-        rec["train_dp"] = train_dp
+        except BaseException as e:  # noqa: BLE001
+            print(f"bench.py: rank {rank}: train_dp failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            sys.stdout.flush()
+            os._exit(3)
+        if rank == 0:
+            rec["train_dp"] = train_dp
+            rec["secondary"] = None
+            print(json.dumps(rec), flush=True)
+    elif rank == 0:
+        rec["train_dp"] = None
         rec["secondary"] = None
         if world == 1 and not args.no_secondary:
             del pipe

@@ -53,6 +53,11 @@ def bind_all():
     AutoFeatureExtractor.register(CustomFeatureExtractorConfig, CustomFeatureExtractor, exist_ok=True)
     from .whisper import install_whisper                          # the Whisper branch (model_utils.py:183 on a Whisper checkpoint): HF's classes, our encoder forward
     install_whisper()
+    ref_enc = sys.modules.get("models.encoders.e_branchformer")  # wav2vec2-style contrastive pre-training is not built on the HIP path: when the reference's
+    ref_pt = getattr(ref_enc, "Wav2Vec2EBranchformerForPreTraining", None) if ref_enc is not None else None      # tree is loaded its own PyTorch class stays reachable
+    if isinstance(ref_pt, type):                                 # through AutoModelForPreTraining, as its bind_all registers it (reference bind.py:42)
+        ref_pt.config_class = Wav2Vec2EBranchformerConfig
+        AutoModelForPreTraining.register(Wav2Vec2EBranchformerConfig, ref_pt, exist_ok=True)
     ref_auto = sys.modules.get("models.auto_wrappers")          # the reference's own decoder registry (bind.py:48-49), when its tree is loaded
     if ref_auto is not None:
         ref_auto.CustomModelForCausalLM.register(GPT2MultiHeadConfig, GPT2LMMultiHeadModel, exist_ok=True)

@@ -136,16 +136,27 @@ class LnReduceBatch:
     `flush()` reduces up to 24 entries in ONE launch (mi_ln_partial_reduce_many).  A 2-MB reduce is all launch latency: the training step has ~100 of them."""
     SLOTS = 24                      # a pair of base-size layers defers 18 reductions: one launch per weight-gradient flush
 
-    def __init__(self, device, floats_per_slot=2 * 512 * 2 * 2048):          # 16 MiB: a depthwise conv's partials (B x C x 32 floats) of up to B * C = 128 Ki fit a slot
-        self.device, self.per = device, floats_per_slot
+    MAX_PER = 2 * 512 * 2 * 2048                            # 16 MiB: the largest slot (a depthwise conv's partials, B x C x 32 floats, of up to B * C = 128 Ki)
+
+    def __init__(self, device, floats_per_slot=512 * 2 * 64):
+        self.device, self.per = device, floats_per_slot     # slots grow to the largest partial actually asked for (ADVICE r4: 24 x 16 MiB whatever the model was 384 MiB per trainer)
         self.arena = None
         self.items = []
         self.keep = []                                      # caller-owned partial buffers of pending entries
         self.cursor = 0                                     # slots are handed out round-robin: the pending entries always sit in the len(items) most recent ones
 
-    def slot(self):
-        if self.arena is None:
+    def reserve(self, need):
+        """slots of at least `need` floats (<= MAX_PER) from here on.  A larger need than any before re-allocates the arena: pending entries are reduced first."""
+        if need > self.MAX_PER:
+            raise ValueError(f"LnReduceBatch: {need} floats asked for, a slot holds at most {self.MAX_PER}")
+        if need > self.per or self.arena is None:
+            self.flush()
+            self.per = max(self.per, -(-int(need) // 1024) * 1024)
             self.arena = torch.empty(self.SLOTS * self.per, device=self.device, dtype=F32)
+            self.cursor = 0
+
+    def slot(self, need):
+        self.reserve(need)
         if len(self.items) == self.SLOTS:                   # every slot holds partial rows that are not reduced yet
             self.flush()
         i = self.cursor
@@ -191,7 +202,7 @@ def layernorm_bwd(x, gamma, dy, dx, *, accumulate, dgamma=None, dbeta=None, eps=
         pdrop, seed, sid = drop if drop is not None else (0.0, 0, 0)
         if defer is not None and dgamma is not None:
             import ctypes as C
-            part = defer.slot()
+            part = defer.slot(512 * 2 * d)
             nblk = C.c_int(0)
             out = torch.empty((M, d), device=x.device, dtype=BF16)
             _lib.check(_L().mi_layernorm_bwd_partial_cast(x.data_ptr(), x.stride(0), int(x.dtype == BF16), gamma.data_ptr(), float(eps),
@@ -204,7 +215,7 @@ def layernorm_bwd(x, gamma, dy, dx, *, accumulate, dgamma=None, dbeta=None, eps=
         return dx, (dropout_(dx, pdrop, seed, sid, out=torch.empty((M, d), device=x.device, dtype=BF16), alpha=alpha) if pdrop > 0 else add_cast(dx, alpha=alpha))
     if defer is not None and dgamma is not None:
         import ctypes as C
-        part = defer.slot()
+        part = defer.slot(512 * 2 * d)
         nblk = C.c_int(0)
         _lib.check(_L().mi_layernorm_bwd_partial(x.data_ptr(), x.stride(0), int(x.dtype == BF16), gamma.data_ptr(), float(eps),
                                                  dy.data_ptr(), dy.stride(0), int(dy.dtype == F32), dx.data_ptr(), dx.stride(0), int(dx.dtype == BF16),
@@ -229,9 +240,10 @@ def layernorm_bwd_dual(x, gamma, dy, gamma2, dy2, dx, *, accumulate, dgamma, dbe
         alpha, drop = cast
         pdrop, seed, sid = drop if drop is not None else (0.0, 0, 0)
         out = torch.empty((M, d), device=x.device, dtype=BF16)
+    defer.reserve(512 * 2 * d)                       # (a growing arena flushes: size it before the pair is taken)
     if len(defer.items) + 2 > defer.SLOTS:          # both partial sets must stay pending together
         defer.flush()
-    p1, p2 = defer.slot(), defer.slot()
+    p1, p2 = defer.slot(512 * 2 * d), defer.slot(512 * 2 * d)
     nblk = C.c_int(0)
     _lib.check(_L().mi_layernorm_bwd_dual_partial(x.data_ptr(), x.stride(0), int(x.dtype == BF16), float(eps), gamma.data_ptr(), dy.data_ptr(), dy.stride(0), int(dy.dtype == F32),
                                                   gamma2.data_ptr(), dy2.data_ptr(), dy2.stride(0), int(dy2.dtype == F32), dx.data_ptr(), dx.stride(0), int(dx.dtype == BF16),
@@ -456,8 +468,8 @@ def csgu_bwd(u, stats, gamma, beta, w, bias, ds, dr, dgn, dw, db, B, T, pad_left
     K = w.shape[-1]
     pl = (K - 1) // 2 if pad_left is None else int(pad_left)
     rows = B * (((T + 63) // 64) if dilation > 1 else 1)
-    if defer is not None and rows * Cc * 32 <= defer.per:
-        ws = defer.slot()
+    if defer is not None and rows * Cc * 32 <= defer.MAX_PER:
+        ws = defer.slot(rows * Cc * 32)
         _lib.check(_L().mi_csgu_bwd_bf16(u.data_ptr(), u.stride(0), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), _p(bias),
                                          ds.data_ptr(), ds.stride(0), _p(dr), dr.stride(0) if dr is not None else 0, dgn.data_ptr(), dgn.stride(0),
                                          None, None, B, T, Cc, K, pl, int(dilation), ws.data_ptr(), _stream()), "mi_csgu_bwd_bf16")
@@ -482,8 +494,8 @@ def dwconv_residual_bwd(m, w, dy, dm, dw, db, B, T, pad_left=None, defer=None):
     M, Cc = m.shape
     K = w.shape[-1]
     pl = (K - 1) // 2 if pad_left is None else int(pad_left)
-    if defer is not None and B * Cc * 32 <= defer.per:
-        ws = defer.slot()
+    if defer is not None and B * Cc * 32 <= defer.MAX_PER:
+        ws = defer.slot(B * Cc * 32)
         _lib.check(_L().mi_dwconv_residual_bwd_bf16(m.data_ptr(), m.stride(0), w.data_ptr(), dy.data_ptr(), dy.stride(0), dm.data_ptr(), dm.stride(0),
                                                     None, None, B, T, Cc, K, pl, 1, ws.data_ptr(), _stream()), "mi_dwconv_residual_bwd_bf16")
         defer.add_dw(ws, B, Cc, K, dw, db)
@@ -701,7 +713,17 @@ class TnBatch:
 
     def __init__(self):
         self.items = []
-        self.overwrite = False          # set by the trainer for the first backward after zero_grad: the grouped launch writes its targets instead of adding into them
+        self._overwrite = False
+        self._written = set()           # targets (dW / db pointers) written since `overwrite` was armed: a later launch of the same backward that names one of them must ADD
+
+    @property
+    def overwrite(self):
+        return self._overwrite
+
+    @overwrite.setter
+    def overwrite(self, v):             # set by the trainer for the first backward after zero_grad: the grouped launches write their targets instead of adding into them
+        self._overwrite = bool(v)
+        self._written = set()
 
     def add(self, dw, dy, x, n_store, db):
         self.items.append((dw, dy, x, n_store, db))
@@ -722,15 +744,21 @@ class TnBatch:
         tiles = self.tiles()
         items, self.items = self.items, []
         if tiles < self.MIN_TILES // 2:
-            for dw, dy, x, n_store, db in items:
+            for dw, dy, x, n_store, db in items:          # (the one-by-one path always adds: its targets count as written from here on)
                 gemm_tn_(dw, dy, x, n_store=n_store, db=db)
+                self._written.update([dw.data_ptr()] + ([db.data_ptr()] if db is not None else []))
             return True
         import ctypes as C
         n = len(items)
         vp, lg, it = (C.c_void_p * n), (C.c_long * n), (C.c_int * n)
         # overwrite: only when every target of this launch is named once in it (a weight hit twice — tied, or two slices of one matrix are fine, two problems into the
         # SAME rows are not — must accumulate)
-        ow = bool(self.overwrite) and len({dw.data_ptr() for dw, _, _, _, _ in items}) == n and len({db.data_ptr() for _, _, _, _, db in items if db is not None}) == sum(db is not None for _, _, _, _, db in items)
+        # SAME rows are not — must accumulate), and none of them was written by an earlier launch of this backward (the auto-flush at MAX and the per-layer-pair flushes split a
+        # backward over several launches: a weight shared across them — tied, or a head reused by an intermediate loss — would otherwise lose its first contribution)
+        tg = [dw.data_ptr() for dw, _, _, _, _ in items] + [db.data_ptr() for _, _, _, _, db in items if db is not None]
+        ow = bool(self._overwrite) and len(set(tg)) == len(tg) and not (self._written & set(tg))
+        if self._overwrite:
+            self._written.update(tg)
         _lib.check(_L().mi_gemm_tn_group_ow_bf16(
             n, vp(*[dy.data_ptr() for _, dy, _, _, _ in items]), lg(*[dy.stride(0) for _, dy, _, _, _ in items]),
             vp(*[x.data_ptr() for _, _, x, _, _ in items]), lg(*[x.stride(0) for _, _, x, _, _ in items]),

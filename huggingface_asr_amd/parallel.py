@@ -11,6 +11,9 @@ import torch
 import torch.distributed as dist
 
 
+COLLECTIVE_TIMEOUT_S = 120          # a rank that never arrives fails the others after two minutes (torch's default is ten: longer than the driver waits for a bench)
+
+
 def env_world():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -23,7 +26,8 @@ def init(backend: str | None = None, device: torch.device | None = None):
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
-        dist.init_process_group(backend, **kw)
+        import datetime
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S), **kw)
     return world, rank, local
 
 

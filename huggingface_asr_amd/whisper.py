@@ -160,21 +160,41 @@ def _engine_for(enc) -> WhisperEncoderEngine:
     return eng
 
 
+def _stock_forward(self, why, input_features, attention_mask, kwargs):
+    """What the HIP engine does not cover runs transformers' OWN `WhisperEncoder.forward` — the code the reference runs for its Whisper branch anyway (the class is
+    transformers', not ours: replacing its forward process-wide must not take away what worked before).  Said once per reason; `HFASR_WHISPER_STRICT=1` raises
+    instead (what the GPU parity tests run under, so that a silent PyTorch pass cannot stand in for the HIP encoder)."""
+    import os
+    import warnings
+    if os.environ.get("HFASR_WHISPER_STRICT") == "1":
+        raise NotImplementedError(f"huggingface_asr_amd: the HIP Whisper encoder does not cover this call ({why}) and HFASR_WHISPER_STRICT=1 forbids transformers' own forward")
+    if why not in _stock_forward.said:
+        _stock_forward.said.add(why)
+        warnings.warn(f"huggingface_asr_amd: WhisperEncoder.forward runs transformers' own PyTorch implementation for this call ({why}); the HIP engine covers "
+                      "inference on GPU tensors returning last_hidden_state", stacklevel=3)
+    from transformers.models.whisper import modeling_whisper as MW
+    return MW.WhisperEncoder._hfasr_reference_forward(self, input_features, attention_mask=attention_mask, **kwargs)
+
+
+_stock_forward.said = set()
+
+
 def hip_whisper_encoder_forward(self, input_features, attention_mask=None, **kwargs):
-    """`transformers.models.whisper.modeling_whisper.WhisperEncoder.forward` on the HIP engine (inference).  Everything the engine does not do RAISES — there is no PyTorch
-    path behind this function: training mode (dropout / LayerDrop / autograd through the encoder), attention or hidden-state outputs, head masks, CPU tensors."""
+    """`transformers.models.whisper.modeling_whisper.WhisperEncoder.forward` on the HIP engine: inference (`eval()`, or no gradient wanted) on GPU tensors returning
+    `last_hidden_state`.  Every other call — training mode (dropout / LayerDrop / autograd through the encoder: `train_enc_dec_asr.py --do_train` on a Whisper checkpoint,
+    `recipes_v0.0.1/librispeech_whisper_ctc`), attention or hidden-state outputs, head masks, CPU tensors — is handed to transformers' own forward (`_stock_forward`)."""
     from transformers.modeling_outputs import BaseModelOutput
-    if self.training:
-        raise NotImplementedError("huggingface_asr_amd: the Whisper encoder is bound for inference (model.eval()); training through WhisperEncoder is not built on the HIP path")
     cfg = self.config
     want = {k: kwargs.get(k) for k in ("output_attentions", "output_hidden_states", "head_mask")}
     if want["output_attentions"] or want["output_hidden_states"] or getattr(cfg, "output_attentions", False) or getattr(cfg, "output_hidden_states", False) \
             or want["head_mask"] is not None:
-        raise NotImplementedError("huggingface_asr_amd: the HIP Whisper encoder returns last_hidden_state only (no attentions / hidden states / head masks)")
+        return _stock_forward(self, "attentions / hidden states / head mask requested", input_features, attention_mask, kwargs)
     if not input_features.is_cuda:
-        raise RuntimeError("huggingface_asr_amd: the Whisper encoder runs on the HIP engine only — move the model and its inputs to a GPU (no CPU fallback)")
-    if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and input_features.requires_grad:
-        raise NotImplementedError("huggingface_asr_amd: no autograd through the HIP Whisper encoder")
+        return _stock_forward(self, "CPU tensors", input_features, attention_mask, kwargs)
+    if self.training:
+        return _stock_forward(self, "training mode", input_features, attention_mask, kwargs)
+    if torch.is_grad_enabled() and (input_features.requires_grad or any(p.requires_grad for p in self.parameters())):
+        return _stock_forward(self, "a gradient through the encoder is wanted (wrap inference in torch.no_grad())", input_features, attention_mask, kwargs)
     out = _engine_for(self).forward(input_features=input_features)                       # (B, T/2, d) fp32; same length check / message as transformers
     return BaseModelOutput(last_hidden_state=out.to(self.layer_norm.weight.dtype))
 

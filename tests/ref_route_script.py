@@ -174,16 +174,22 @@ fwd = type(wm.model.encoder).forward
 assert fwd.__module__ == "huggingface_asr_amd.whisper" and getattr(fwd, "_hfasr_hip", False), (fwd.__module__, fwd)
 assert MW.WhisperEncoder._hfasr_reference_forward.__module__.startswith("transformers")
 wm.eval()
+os.environ["HFASR_WHISPER_STRICT"] = "1"                                       # strict: what the engine does not cover raises ...
 try:
     wm.model.encoder(torch.zeros(1, 80, 100))
-    raise SystemExit("the HIP Whisper encoder accepted CPU tensors")
-except RuntimeError as e:
-    assert "no CPU fallback" in str(e), e
-wm.train()
-try:
-    wm.model.encoder(torch.zeros(1, 80, 100))
-    raise SystemExit("the HIP Whisper encoder accepted training mode")
+    raise SystemExit("HFASR_WHISPER_STRICT=1: the HIP Whisper encoder accepted CPU tensors")
 except NotImplementedError:
     pass
+del os.environ["HFASR_WHISPER_STRICT"]                                         # ... by default it runs transformers' own forward: a Whisper fine-tune (--do_train) keeps working
+wm.train()
+out = wm.model.encoder(torch.zeros(1, 80, 100))
+assert tuple(out.last_hidden_state.shape) == (1, 50, 128)
 print("OK whisper branch (model_utils.py:183) ->", type(wm).__module__.split(".")[0], "class,", fwd.__module__, "encoder forward")
+# the reference's bind_all registers Wav2Vec2EBranchformerForPreTraining with AutoModelForPreTraining (bind.py:42); the HIP path does not build it and
+# keeps the reference's own PyTorch class reachable there
+from transformers import AutoModelForPreTraining  # noqa: E402
+import models.encoders.e_branchformer as REB  # noqa: E402
+pt = AutoModelForPreTraining._model_mapping[type(mc.config)]        # (resolved, not constructed: transformers 5.15's Wav2Vec2ForPreTraining reads config fields 4.39's conformer config had)
+assert pt is REB.Wav2Vec2EBranchformerForPreTraining and pt.__module__ == "models.encoders.e_branchformer", pt
+print("OK AutoModelForPreTraining(wav2vec2-ebranchformer) ->", pt.__module__)
 print("ALL OK")

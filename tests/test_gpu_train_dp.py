@@ -183,3 +183,25 @@ def test_default_bench_command_carries_train_dp_when_it_runs_on_more_than_one_ra
     assert dp["replicas_identical"] == [True, True] and dp["schedules_agree"] is True, dp
     assert dp["first_step_grad_norm"][0] == dp["first_step_grad_norm"][1] > 0
     assert rec["secondary"] is None                            # configs 3-5 ride the single-GPU line only
+
+
+def test_a_rank_failing_in_train_dp_cannot_take_the_forward_line_down():
+    """VERDICT r4 item 5 / ADVICE r4: at more than one rank the forward headline is printed before the training collectives start; a rank that fails inside `train_dp`
+    (here: injected on rank 1 while rank 0 is already inside the first schedule's collectives) exits non-zero at once, the launcher ends the run, and stdout still carries a
+    parseable forward line — the run neither hangs until the driver's limit nor loses its headline."""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--streams", "1", "--train-dp-batch", "4", "--train-dp-steps", "2", "--no-kernel-events"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HFASR_DP_OVERLAP="0", HFASR_BENCH_FAIL_RANK="1"))
+    assert r.returncode != 0
+    assert time.time() - t0 < 400
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, r.stderr[-2000:]
+    rec = json.loads(lines[-1])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["train_dp"] is None and rec["roofline"] is None or rec["value"] > 0
+    assert "injected failure" in r.stderr

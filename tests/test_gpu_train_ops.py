@@ -158,6 +158,42 @@ def test_grouped_weight_gradients_one_launch(tile_k):
     assert b2.flush() is True and float(dw.abs().max()) > 0.0
 
 
+def test_overwriting_weight_gradient_launches_add_into_a_target_an_earlier_launch_wrote():
+    """in overwrite mode (the first backward after zero_grad) a grouped launch STORES its targets; a backward is split over several launches (auto-flush at 48
+    problems, one flush per layer pair), so a target named by two of them — a tied weight, a head reused by an intermediate loss — must be written by the first and ADDED
+    to by the second.  Ten 512 x 512 problems per launch (the grouped kernel, not the one-by-one path); targets start as garbage."""
+    ops, T = _o()
+    b = T.TnBatch()
+    b.overwrite = True
+    shared = torch.full((512, 512), 7.0, device=DEV)
+    sb = torch.full((512,), -3.0, device=DEV)
+    want_shared, want_sb = torch.zeros(512, 512), torch.zeros(512)
+    others = []
+    for launch in range(2):
+        for i in range(10):
+            dy, x = bfr(rnd(700, 512, seed=100 * launch + i)), bfr(rnd(700, 512, seed=100 * launch + 50 + i))
+            if i == 4:
+                dw, db = shared, sb
+                want_shared += dy.t() @ x
+                want_sb += dy.sum(0)
+            else:
+                dw, db = torch.full((512, 512), 5.0, device=DEV), torch.full((512,), 2.0, device=DEV)
+                others.append((dw, db, dy.t() @ x, dy.sum(0)))
+            T.gemm_tn_(dw, dev16(dy), dev16(x), db=db, defer=b)
+        assert b.tiles() >= b.MIN_TILES // 2 and b.flush() is True
+    torch.testing.assert_close(shared.cpu(), want_shared, atol=3e-3 * float(want_shared.abs().max()), rtol=1e-3)
+    torch.testing.assert_close(sb.cpu(), want_sb, atol=3e-3 * float(want_sb.abs().max()), rtol=1e-3)
+    for dw, db, w, wb in others:                      # written once: the garbage is gone
+        torch.testing.assert_close(dw.cpu(), w, atol=3e-3 * float(w.abs().max()), rtol=1e-3)
+        torch.testing.assert_close(db.cpu(), wb, atol=3e-3 * float(wb.abs().max()), rtol=1e-3)
+    b.overwrite = True                                 # the next zero_grad re-arms it: the same target is stored again
+    dy, x = bfr(rnd(700, 512, seed=900)), bfr(rnd(700, 512, seed=901))
+    for i in range(10):
+        T.gemm_tn_(shared if i == 0 else torch.empty(512, 512, device=DEV), dev16(dy), dev16(x), defer=b)
+    b.flush()
+    torch.testing.assert_close(shared.cpu(), dy.t() @ x, atol=3e-3 * float((dy.t() @ x).abs().max()), rtol=1e-3)
+
+
 @pytest.mark.parametrize("kind", ["gelu", "gelu_new"])
 @pytest.mark.parametrize("M,N,K,p", [(1000, 512, 256, 0.0), (777, 1024, 512, 0.1), (300, 136, 72, 0.1)])       # the last shape is outside the fused kernel: two launches
 def test_ffn_activation_passes_in_the_gemm_epilogues(M, N, K, p, kind):

@@ -2,6 +2,8 @@
 outputs, HIP encoder against transformers' WhisperEncoder outputs (tests/golden/whisper.npz) and the bf16-modelled oracle."""
 import ast
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -95,6 +97,7 @@ def test_bound_whisper_model_runs_the_hip_encoder_and_generates_transformers_tok
     from huggingface_asr_amd import bind
     bind.bind_all()
     assert getattr(MW.WhisperEncoder.forward, "_hfasr_hip", False) and MW.WhisperEncoder.forward.__module__ == "huggingface_asr_amd.whisper"
+    os.environ["HFASR_WHISPER_STRICT"] = "1"                  # a call the HIP engine does not cover raises instead of running transformers' forward
     g = load_golden("whisper")
     seed = int(g["seed"])
     sd = {str(n): torch.from_numpy(synth.init_param(seed, str(n), ast.literal_eval(str(s)))) for n, s in zip(g["param_names"], g["param_shapes"])}
@@ -137,11 +140,16 @@ def test_bound_whisper_model_runs_the_hip_encoder_and_generates_transformers_tok
             from huggingface_asr_amd.whisper import hip_whisper_encoder_forward
             MW.WhisperEncoder.forward = hip_whisper_encoder_forward
     assert gen_hip.shape == gen_ref.shape and torch.equal(gen_hip, gen_ref), (gen_hip.tolist(), gen_ref.tolist())
-    # what the engine does not do raises (never a silent PyTorch path)
-    with pytest.raises(RuntimeError):
+    # what the engine does not do goes to transformers' own forward — and under HFASR_WHISPER_STRICT=1, which this test ran under so far, it raises: no
+    # PyTorch pass stood in for the HIP encoder above
+    with pytest.raises(NotImplementedError):
         model.model.encoder(x.cpu())
     with pytest.raises(NotImplementedError):
         model.model.encoder(x, output_hidden_states=True)
+    os.environ.pop("HFASR_WHISPER_STRICT")
+    hs = model.model.encoder(x, output_hidden_states=True)
+    assert len(hs.hidden_states) == 3 and float((hs.last_hidden_state - ref_enc).abs().max()) < 1e-5
     model.train()
-    with pytest.raises(NotImplementedError):
-        model.model.encoder(x)
+    out = model(input_features=x, decoder_input_ids=dec_in, labels=dec_in)
+    out.loss.backward()
+    assert float(model.model.encoder.conv1.weight.grad.abs().sum()) > 0
