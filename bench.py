@@ -130,6 +130,38 @@ def rocprof_child_dense_us(args, B, per_step):
     return out, steps, "ok"
 
 
+def rocprof_child_in_flight(args, B):
+    """The headline's OWN mode (steps in flight, wide tiles) as a kernel trace: a rocprofv3 --kernel-trace child run of this script with the default lanes and no one-step
+    comparison, summarised by tools/lanes_trace.py — the share of the wall in which a dense kernel / only other kernels / nothing runs, and the non-GEMM share of the busy
+    time.  Tracing serialises dispatch bookkeeping, so the traced wall is longer than the timed region's (both are reported); the shares are what the trace is for."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return {"error": "rocprofv3 not found"}
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD")):
+        return {"error": "this process already runs under a profiler (no nested rocprofv3)"}
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lanes_trace
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", td, "--", sys.executable, os.path.abspath(__file__), "--steps", "24", "--warmup", "8", "--batch", str(B),
+               "--pos", args.pos, "--streams", str(args.streams), "--wide-tiles", str(int(args.wide_tiles)), "--no-cpu-baseline", "--no-kernel-events", "--no-secondary", "--no-one-step"]
+        try:
+            r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        except Exception as e:  # noqa: BLE001
+            return {"error": f"rocprofv3 child failed: {type(e).__name__}"}
+        files = glob.glob(os.path.join(td, "**", "*kernel_trace.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return {"error": f"rocprofv3 child rc={r.returncode}, trace files: {len(files)}"}
+        rec = lanes_trace.summarise(files, 0.4)
+        if args.keep_profile:
+            os.makedirs(args.keep_profile, exist_ok=True)
+            json.dump(rec, open(os.path.join(args.keep_profile, "in_flight_trace.json"), "w"), indent=1)
+    return rec
+
+
 def cpu_baseline(cfg, sd, seconds_budget=25.0):
     """Time the ORACLE (CPU restatement; checker only, never the product path) on the host cores:
     feature extraction + encoder forward + CTC head, fp32, bounded sample."""
@@ -190,6 +222,9 @@ def parse_args(argv=None):
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check on a box without GPUs: gloo, no HIP work, value null")
     ap.add_argument("--secondary", default=None, choices=["whisper", "decode", "train"], help="run ONE bounded secondary measurement (config 4 / 5 / 3) on cuda:0 and print its "
                                                                                                 "JSON; the default run starts these as children after its timed region")
+    ap.add_argument("--no-one-step", action="store_true", help="skip the one-step-at-a-time comparison after the timed region (a kernel trace of this command then shows the "
+                                                                "headline's own mode only: tools/lanes_trace.py)")
+    ap.add_argument("--no-in-flight-trace", action="store_true", help="skip the kernel trace of the headline's own mode (`roofline.in_flight.trace`)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary records (configs 3, 4, 5) of the default single-GPU run")
     ap.add_argument("--secondary-timeout", type=float, default=150.0, help="seconds allowed per secondary child")
     ap.add_argument("--no-train-dp", action="store_true", help="more than one rank: skip the config-3 training step under both gradient all-reduce schedules")
@@ -243,6 +278,26 @@ def config3_gflop_per_step(cfg, dcfg, B, T2, U):
     return 3.0 * 2.0 * mac * B / 1e9
 
 
+def config3_gflop_per_step_unpadded(cfg, dcfg, frame_lengths, label_lengths):
+    """the same accounting on the work the clips actually hold: every clip with its OWN frame count (T1 = ceil(frames / 2), T' = ceil(T1 / 2): the Conv2d front end with k 3 /
+    s 2 / p 1) and its own number of decoder tokens instead of the padded (2000 frames, U tokens) shape.  Several kernels skip padded tiles (key lengths, `m_valid`), so the
+    padded figure credits the step with FLOPs nobody asked for — `model_frac_of_bf16_peak` keeps that figure (comparable across rounds), this one is reported beside it."""
+    d, I, L, V = cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"], cfg["vocab_size"]
+    C1, C2 = cfg["conv_dim"]
+    F1, F2 = 40, 20
+    dd, Ld, Vd = dcfg["n_embd"], dcfg["n_layer"], dcfg["vocab_size"]
+    mac = 0.0
+    for fr, U in zip(frame_lengths, label_lengths):
+        T1 = (int(fr) + 1) // 2
+        T2 = (T1 + 1) // 2
+        mac += T1 * F1 * C1 * 9 + T2 * F2 * C2 * 9 * C1 + T2 * (F2 * C2) * d + T2 * d * d
+        mac += L * (2 * (2 * T2 * d * I) + 4 * T2 * d * d + (T2 * T2 * d) * 2 + T2 * (2 * T2 - 1) * d + T2 * d * I + T2 * (I // 2) * 31 + T2 * (I // 2) * d + T2 * 2 * d * 31
+                    + T2 * 2 * d * d) + T2 * d * (V + 1)
+        U = int(U)
+        mac += Ld * (U * dd * 3 * dd + 2 * U * U * dd + U * dd * dd + U * dd * dd + T2 * d * 2 * dd + 2 * U * T2 * dd + U * dd * dd + 8 * U * dd * dd) + U * dd * Vd
+    return 3.0 * 2.0 * mac / 1e9
+
+
 def build_config3(args, rank, dev, B, overlap):
     """BASELINE config 3's trainer and one rank's shard (recipes_v0.0.1/librispeech_aed/train_small_baseline.sh: small encoder + 6x256 GPT-2 decoder, ctc_weight 0.3, label
     smoothing 0.1, fixed positions, AdamW 2e-3 / wd 1e-6, per-GPU batch 96, clips 1-20 s sorted into the batch); seeded weights, the same on every rank."""
@@ -271,13 +326,14 @@ def build_config3(args, rank, dev, B, overlap):
     labels = torch.from_numpy(synth.labels(rank, B, 60, cfg["vocab_size"], lo=5)).to(dev)
     for b in range(B):
         labels[b, max(2, int(fl[b] / 100 * 3)):] = -100
-    return tr, (feats, lens, labels), fl, cfg, dcfg
+    ul = (labels != -100).sum(1).cpu().numpy()
+    return tr, (feats, lens, labels), fl, cfg, dcfg, ul
 
 
 def measure_config3(args, world, rank, dev, PL, B, overlap, steps, warmup):
     """-> dict(ms_per_step, first_step_grad_norm, per_rank rows [ms, encoder checksum, decoder checksum], loss, audio seconds of this rank's shard, trainer, config dicts)"""
     import torch.distributed as td
-    tr, (feats, lens, labels), fl, cfg, dcfg = build_config3(args, rank, dev, B, overlap)
+    tr, (feats, lens, labels), fl, cfg, dcfg, ul = build_config3(args, rank, dev, B, overlap)
     state = {}
 
     def one():
@@ -300,7 +356,7 @@ def measure_config3(args, world, rank, dev, PL, B, overlap, steps, warmup):
     else:
         per_rank = [buf]
     per_rank = [t.cpu() for t in per_rank]
-    return dict(dt=dt, ms_per_step=round(dt / steps * 1e3, 3), first_norm=first_norm, per_rank=per_rank, loss=float(state["o"]["loss"]), fl=fl, tr=tr, cfg=cfg, dcfg=dcfg)
+    return dict(dt=dt, ms_per_step=round(dt / steps * 1e3, 3), first_norm=first_norm, per_rank=per_rank, loss=float(state["o"]["loss"]), fl=fl, ul=ul, tr=tr, cfg=cfg, dcfg=dcfg)
 
 
 def all_reduce_alone_ms(tr, world):
@@ -332,6 +388,7 @@ def train_bench(args, world, rank, dev, PL):
         # every rank drew its own lengths; the job's audio = sum over ranks (same distribution): use this rank's sum x world
         sec = world * float(fl.sum()) / 100.0 * args.steps
         gf = config3_gflop_per_step(m["cfg"], m["dcfg"], B, 500, 60)
+        gfu = config3_gflop_per_step_unpadded(m["cfg"], m["dcfg"], fl, m["ul"])
         print(json.dumps({"metric": "audio-seconds/sec, joint CTC/attention TRAINING step (fwd+bwd+AdamW), ED-small, DP", "value": round(sec / m["dt"], 1),
                           "unit": "audio-seconds/sec (un-padded audio)", "n_gpus": world, "rccl_ranks": td.get_world_size() if td.is_initialized() else 1,
                           "backend": td.get_backend() if td.is_initialized() else "none", "steps": args.steps, "warmup": args.warmup,
@@ -349,6 +406,8 @@ def train_bench(args, world, rank, dev, PL):
                           "all_reduce_ms": ar_ms, "all_reduce_note": "the step's gradient all-reduce timed on its own (same buffers), per step" if ar_ms else None,
                           "model_gflop_per_step": round(gf, 1), "model_tflops_per_gpu": round(gf / (m["dt"] / args.steps) / 1e3, 1),
                           "model_frac_of_bf16_peak": round(gf / (m["dt"] / args.steps) / 1e3 / PEAK_BF16_TFLOPS, 4),
+                          "model_gflop_per_step_unpadded": round(gfu, 1), "model_frac_of_bf16_peak_unpadded": round(gfu / (m["dt"] / args.steps) / 1e3 / PEAK_BF16_TFLOPS, 4),
+                          "flop_note": "padded = every clip counted at the 2000-frame / 60-token bucket it is padded to; unpadded = every clip at its own length",
                           "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)
     if world > 1:
         td.barrier(); td.destroy_process_group()
@@ -467,11 +526,15 @@ def secondary(name, args):
     if name == "train":                                      # config 3 on one GPU (the data-parallel form is `bench.py --train --gpus N`)
         m = measure_config3(args, 1, 0, dev, PL, 96, 0, 5, 2)
         gf = config3_gflop_per_step(m["cfg"], m["dcfg"], 96, 500, 60)
+        gfu = config3_gflop_per_step_unpadded(m["cfg"], m["dcfg"], m["fl"], m["ul"])
         sec = float(m["fl"].sum()) / 100.0
         return {"config": "BASELINE config 3 on one GPU: small E-Branchformer encoder + 6x256 GPT-2 decoder, joint CTC/attention loss, fwd + bwd + AdamW, 96 clips of 1-20 s "
                           f"padded to 2000 frames, dropout {args.dropout}", "ms_per_step": m["ms_per_step"], "value": round(sec / (m["dt"] / 5), 1),
                 "unit": "audio-seconds/sec (un-padded audio)", "model_gflop_per_step": round(gf, 1), "model_tflops": round(gf / (m["dt"] / 5) / 1e3, 1),
-                "model_frac_of_bf16_peak": round(gf / (m["dt"] / 5) / 1e3 / PEAK_BF16_TFLOPS, 4), "loss": round(m["loss"], 4)}
+                "model_frac_of_bf16_peak": round(gf / (m["dt"] / 5) / 1e3 / PEAK_BF16_TFLOPS, 4),
+                "model_gflop_per_step_unpadded": round(gfu, 1), "model_frac_of_bf16_peak_unpadded": round(gfu / (m["dt"] / 5) / 1e3 / PEAK_BF16_TFLOPS, 4),
+                "flop_note": "padded = every clip counted at the 2000-frame / 60-token bucket it is padded to; unpadded = every clip at its own length (several kernels skip padded tiles)",
+                "loss": round(m["loss"], 4)}
     raise SystemExit(f"bench.py: unknown --secondary {name}")
 
 
@@ -570,7 +633,7 @@ def main():
     dt = PL.timed(one, args.steps, sync=torch.cuda.synchronize, device=dev)      # barrier + sync both sides, MAX over ranks
     loss_v = float(state["loss"])
     single = None
-    if nstr > 1:                             # the same K steps strictly one at a time (outside the timed region): what the pipelining buys
+    if nstr > 1 and not args.no_one_step:    # the same K steps strictly one at a time (outside the timed region): what the pipelining buys
         for _ in range(2):
             step()
         dt1 = PL.timed(lambda: step(), args.steps, sync=torch.cuda.synchronize, device=dev)
@@ -647,6 +710,28 @@ def main():
                        "ctc_loss": round(loss_v, 4)},
             "roofline": roof,
         }
+        if roof is not None:
+            # the headline's own mode: dense GFLOP of a step / the timed region's wall per step (every non-GEMM kernel, gap and ramp included), and — from a kernel trace of the
+            # same mode — how the wall divides between dense kernels, other kernels and nothing
+            dense_tf = roof["gflop_per_step"] / (dt / args.steps) / 1e3
+            inf = dict(steps_in_flight=nstr, wide_tiles=bool(args.wide_tiles), dense_gflop_per_step=roof["gflop_per_step"], wall_ms_per_step=round(dt / args.steps * 1e3, 3),
+                       dense_tflops_over_wall=round(dense_tf, 1), frac_of_bf16_peak=round(dense_tf / PEAK_BF16_TFLOPS, 4))
+            if world == 1 and not args.no_in_flight_trace:
+                try:
+                    tr_ = rocprof_child_in_flight(args, B)
+                except Exception as e:  # noqa: BLE001 — never take the line down
+                    tr_ = {"error": f"{type(e).__name__}: {e}"[:200]}
+                if "error" in tr_:
+                    inf["trace"] = tr_
+                else:
+                    inf["trace"] = dict(traced_wall_ms_per_step=tr_["wall_ms_per_step"], wall_share_dense_running=tr_["wall_share_dense_running"],
+                                        wall_share_only_other_kernels=tr_["wall_share_only_other_kernels"], wall_share_idle=tr_["wall_share_idle"],
+                                        non_gemm_share_of_busy=tr_["non_gemm_share_of_busy"], dense_busy_us_per_wall_ms=tr_["dense_busy_us_per_wall_ms"],
+                                        other_busy_us_per_wall_ms=tr_["other_busy_us_per_wall_ms"],
+                                        busy_us_per_step_by_family={k: v["busy_us_per_step"] for k, v in tr_["families"].items()},
+                                        note="rocprofv3 --kernel-trace child of this command in the headline's mode (tools/lanes_trace.py); busy = sum of dispatch durations, which "
+                                             "overlap across lanes; tracing lengthens the wall, the shares are what it is for")
+            roof["in_flight"] = inf
         rec["model_tflops_per_gpu"] = round(rec["config"]["algorithmic_gflop_per_audio_s"] * rec["value"] / world / 1e3, 2)
         # flat copies of what `config` nests (a reader of the parsed line sees the headline's mode and the single-step latency beside it: ADVICE r3)
         rec["mode"] = f"throughput: {nstr} independent steps in flight on {nstr} HIP streams" if nstr > 1 else "one step at a time"

@@ -741,32 +741,41 @@ class TnBatch:
             return True
         if not final and self.tiles(256) < self.FULL_TILES and len(self.items) + room <= self.MAX:
             return False
-        tiles = self.tiles()
         items, self.items = self.items, []
-        if tiles < self.MIN_TILES // 2:
-            for dw, dy, x, n_store, db in items:          # (the one-by-one path always adds: its targets count as written from here on)
+        # overwrite (the first backward after zero_grad): a launch STORES its targets, so every target may be named once per launch and must not have been written by an
+        # earlier launch of this backward (the auto-flush at MAX and the per-layer-pair flushes split a backward over several launches: a weight shared across them — tied,
+        # or a head reused by an intermediate loss — would otherwise lose its first contribution).  Problems whose dW or db was already written — by an earlier launch or by
+        # an earlier problem of this one — leave the grouped launch and ADD afterwards, one by one, in recording order; the rest of the launch still stores.
+        again = []
+        if self._overwrite:
+            fresh = []
+            for it in items:
+                t = [it[0].data_ptr()] + ([it[4].data_ptr()] if it[4] is not None else [])
+                (again if any(q in self._written for q in t) else fresh).append(it)
+                self._written.update(t)
+            items = fresh
+        self._launch(items, tile_k, ow=self._overwrite)
+        for dw, dy, x, n_store, db in again:
+            gemm_tn_(dw, dy, x, n_store=n_store, db=db)
+        return True
+
+    def _launch(self, items, tile_k, ow):
+        if not items:
+            return
+        if sum(-(-dy.shape[1] // 256) * -(-x.shape[1] // 128) for _, dy, x, _, _ in items) < self.MIN_TILES // 2:
+            for dw, dy, x, n_store, db in items:          # the one-by-one path always adds (the trainer's targets are zero after zero_grad: adding is storing)
                 gemm_tn_(dw, dy, x, n_store=n_store, db=db)
-                self._written.update([dw.data_ptr()] + ([db.data_ptr()] if db is not None else []))
-            return True
+            return
         import ctypes as C
         n = len(items)
         vp, lg, it = (C.c_void_p * n), (C.c_long * n), (C.c_int * n)
-        # overwrite: only when every target of this launch is named once in it (a weight hit twice — tied, or two slices of one matrix are fine, two problems into the
-        # SAME rows are not — must accumulate)
-        # SAME rows are not — must accumulate), and none of them was written by an earlier launch of this backward (the auto-flush at MAX and the per-layer-pair flushes split a
-        # backward over several launches: a weight shared across them — tied, or a head reused by an intermediate loss — would otherwise lose its first contribution)
-        tg = [dw.data_ptr() for dw, _, _, _, _ in items] + [db.data_ptr() for _, _, _, _, db in items if db is not None]
-        ow = bool(self._overwrite) and len(set(tg)) == len(tg) and not (self._written & set(tg))
-        if self._overwrite:
-            self._written.update(tg)
         _lib.check(_L().mi_gemm_tn_group_ow_bf16(
             n, vp(*[dy.data_ptr() for _, dy, _, _, _ in items]), lg(*[dy.stride(0) for _, dy, _, _, _ in items]),
             vp(*[x.data_ptr() for _, _, x, _, _ in items]), lg(*[x.stride(0) for _, _, x, _, _ in items]),
             vp(*[dw.data_ptr() for dw, _, _, _, _ in items]), lg(*[dw.stride(0) for dw, _, _, _, _ in items]),
             vp(*[(db.data_ptr() if db is not None else None) for _, _, _, _, db in items]),
             it(*[dy.shape[0] for _, dy, _, _, _ in items]), it(*[dy.shape[1] for _, dy, _, _, _ in items]), it(*[x.shape[1] for _, _, x, _, _ in items]),
-            it(*[ns for _, _, _, ns, _ in items]), int(tile_k), int(ow), _stream()), "mi_gemm_tn_group_bf16")
-        return True
+            it(*[ns for _, _, _, ns, _ in items]), int(tile_k), int(bool(ow)), _stream()), "mi_gemm_tn_group_bf16")
 
 
 def gemm_tn_(dw, dy, x, n_store=None, db=None, variant=0, defer=None):
