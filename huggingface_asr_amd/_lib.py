@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhfasr_hip.so")
+# HFASR_HIP_LIB: an A/B build of the SAME C ABI at another path (tools/*_ab.sh build their variants beside the product library instead of over it: ADVICE r4); unset = the product build
+LIB_PATH = os.environ.get("HFASR_HIP_LIB") or os.path.join(_HERE, "libhfasr_hip.so")
 
 vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_size_t
 

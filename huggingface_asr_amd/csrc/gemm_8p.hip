@@ -29,6 +29,17 @@
 #include "gemm_args.hpp"
 #include <type_traits>
 
+// A/B switch of tools/gemm_floor_ab.sh only (never set in the product build): 1 = the kernels' K loops WITHOUT their LDS fragment reads and MFMAs (what the
+// LDS-DMA staging alone costs: the ingest floor of the schedule), 2 = WITHOUT the staging (what the reads + MFMAs alone cost), 3 = staging + MFMAs without the fragment
+// reads, 4 = staging + fragment reads without the MFMAs (which of the two the staging does not overlap with).  Results are garbage in every mode but 0.
+#ifndef GEMM_FLOOR
+#define GEMM_FLOOR 0
+#endif
+// which 128 x 128 form `ring = 0` (every product call site) means: 0 = by K (see gemm_8p128_launch), 1 = always the loader / consumer form, 2 = always the register-pipelined one (A/B builds)
+#ifndef GEMM128_LOADER
+#define GEMM128_LOADER 0
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -118,6 +129,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
         c.bRd[1] = c.bRd[0] ^ 64;
     }
     auto stageA = [&](int kt, unsigned buf, int mq) {
+        if (GEMM_FLOOR == 2) return;
         if constexpr (CONV) {
             const int ntap = p.K / p.Cin;
             const int chunk = kt / ntap, tap = kt - chunk * ntap, c0 = chunk * BK;      // K tiles in channel-slice-major order (see conv_k)
@@ -140,6 +152,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
     // consecutive K tiles keep it in L2.  Tap-major order re-read the whole 540-KB patch of every tile 2.2x from beyond L2 (PMC: 690 MB fetched per launch for a 320-MB input).
     auto conv_k = [&](int kt) { const int ntap = p.K / p.Cin; const int chunk = kt / ntap; return (kt - chunk * ntap) * p.Cin + chunk * BK; };
     auto stageB = [&](int kt, unsigned buf, int nq) {
+        if (GEMM_FLOOR == 2) return;
         const unsigned kb = CONV ? (unsigned)conv_k(kt) * 2u : (unsigned)kt * 128u;
 #pragma unroll
         for (int e = 0; e < 2; ++e)
@@ -154,6 +167,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
     bf16x8 fa[4][2], fb[2][2][2];        // A fragments of the current 64-row half; W fragments of both 32-column halves
 
     auto readA = [&](unsigned cb, int mq) {
+        if (GEMM_FLOOR == 1 || GEMM_FLOOR == 3) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -161,6 +175,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
                 fa[i][s] = *reinterpret_cast<const bf16x8*>(smem + (cb + c.aRd[s]) + (mq * 64 + i * 16) * 128);
     };
     auto readB = [&](unsigned cb, int nq) {
+        if (GEMM_FLOOR == 1 || GEMM_FLOOR == 3) return;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -168,6 +183,16 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs p) {
                 fb[nq][j][s] = *reinterpret_cast<const bf16x8*>(smem + (cb + c.bRd[s]) + (nq * 32 + j * 16) * 128);
     };
     auto quad = [&](int mq, int nq) {
+        if (GEMM_FLOOR == 4) {               // keep the fragment reads alive without the MFMAs
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[i][s]));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(fb[nq][j][s]));
+            }
+        }
+        if (GEMM_FLOOR == 1 || GEMM_FLOOR == 4) return;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -701,6 +726,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p128p_kernel(GemmArgs p) {
         dst[e] = (wave < 4 ? 0 : B128_BOFF) + r0 * 128;
     }
     auto stage = [&](int kt) {
+        if (GEMM_FLOOR == 2) return;
         const unsigned buf = (unsigned)(kt & 3) * B128_BUF;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -717,6 +743,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p128p_kernel(GemmArgs p) {
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 fa[2][4][2], fb[2][2][2];
     auto read_frags = [&](int kt, auto SET) {
+        if (GEMM_FLOOR == 1 || GEMM_FLOOR == 3) return;
         constexpr int S = decltype(SET)::value;
         const unsigned cb = (unsigned)(kt & 3) * B128_BUF;
 #pragma unroll
@@ -730,6 +757,16 @@ __global__ __launch_bounds__(512, 2) void gemm8p128p_kernel(GemmArgs p) {
     };
     auto mfmas = [&](auto SET) {
         constexpr int S = decltype(SET)::value;
+        if (GEMM_FLOOR == 4) {               // keep the fragment reads alive without the MFMAs
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[S][i][s]));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(fb[S][j][s]));
+            }
+        }
+        if (GEMM_FLOOR == 1 || GEMM_FLOOR == 4) return;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -856,6 +893,252 @@ __global__ __launch_bounds__(512, 2) void gemm8p128p_kernel(GemmArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// 128 x 128 x 64, loader / consumer form (round 5).  tools/gemm_floor_ab.sh on the pipelined form above: its K loop costs 0.44 us per K tile, its staging alone 0.28, its
+// fragment reads + MFMAs alone 0.22 (the matrix pipe's own time) — and ANY TWO of {staging, reads, MFMAs} overlap perfectly (0.26 - 0.29) while all three together do not:
+// a wave that has a phase's LDS-DMA pieces to issue sits in their issue (100 - 185 cycles per piece inside a phase that also reads LDS, MI355X_MICROARCH.md) instead of
+// feeding the matrix pipe, and with all eight waves symmetric both waves of a SIMD do so at the same time.  Here the roles are split: waves 0-3 (one per SIMD) own a
+// 64 x 64 quarter of the tile each — fragment sets of K tiles t and t+1 in registers, 16 ds_read_b128 under 32 MFMAs, never a vector-memory instruction in the loop —
+// and waves 4-7 (their SIMD partners) issue the ring's LDS-DMA pieces (waves 4, 5 the A rows, 6, 7 the W rows: 8 pieces per wave and K tile) behind a counted vmcnt.
+// Same ring (four 32-KiB K tiles), same one barrier per K tile, same K order and MFMA shape as the pipelined form: the same bits.
+//   loader, phase t:   stage K tile t+4 into buffer t & 3 (its reads were retired before the barrier that ended phase t-1); vmcnt(16): tile t+2 has landed; s_barrier
+//   consumer, phase t: read K tile t+1 -> fragment set (t+1) & 1  ||  MFMAs of K tile t from set t & 1;  lgkmcnt(0);  s_barrier
+// Epilogue by all eight waves: the consumers leave acc + bias as an fp32 tile in LDS (the ring is dead; 16-B chunk ^ (row & 31): conflict-free both ways), then every wave
+// finishes 16 rows — residual rows requested at kernel start (the loaders' registers are free, the consumers stay under 256), whole 512-B / 256-B row segments out.
+__global__ __launch_bounds__(512, 2) void gemm8p128l_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntm = (p.M + 127) / 128, ntn = p.N / 128;
+    const int nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / ntn) * 128, n0 = (bid % ntn) * 128;
+    const int nk = p.K / BK;
+#ifdef GEMM128_STAMPS
+    const unsigned long long t_kernel0 = __builtin_readcyclecounter();
+#endif
+
+    // final pass: wave w finishes rows [16 w, 16 w + 16) of the tile, two rows per instruction (32 lanes x 16 B = one 512-B fp32 row)
+    const int er = lane >> 5, ec = lane & 31;
+    f32x4 rres[8];
+    const bool use_res = p.out_f32 && p.resid != nullptr;
+    if (use_res) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int m = min(m0 + wave * 16 + u * 2 + er, p.M - 1);
+            rres[u] = *reinterpret_cast<const f32x4*>(p.resid + (long)m * p.ldr + n0 + ec * 4);
+        }
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int wr = (wave >> 1) & 1, wc = wave & 1;          // consumers: 64-row / 64-column half of the tile
+    const int fr = lane & 15, fq = lane >> 4;
+
+    if (wave >= 4) {
+        // ---------------- loader
+        const int prow = lane >> 3, pc = lane & 7;
+        const bool isA = wave < 6;
+        const char* src_base = reinterpret_cast<const char*>(isA ? (const void*)p.A : (const void*)p.W);
+        unsigned off[8], dst[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int r0 = (8 * (wave & 1) + e) * 8;
+            const int lc = pc ^ (((r0 + prow) >> 1) & 7);
+            if (isA) off[e] = (unsigned)min(m0 + r0 + prow, p.M - 1) * (unsigned)(p.lda * 2) + lc * 16;
+            else off[e] = (unsigned)min(n0 + r0 + prow, p.N - 1) * (unsigned)(p.ldw * 2) + lc * 16;
+            dst[e] = (isA ? 0 : B128_BOFF) + r0 * 128;
+        }
+        auto stage = [&](int kt) {
+            if (GEMM_FLOOR == 2) return;
+            const unsigned buf = (unsigned)(kt & 3) * B128_BUF;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src_base + off[e] + (unsigned)kt * 128u), (lptr_t)(smem + buf + dst[e]), 16, 0, 0);
+        };
+        stage(0); stage(1); stage(2); stage(3);
+        wait_vm<24>();                      // tile 0 (and the residual rows, older still) has landed
+        barrier();
+        wait_vm<16>();                      // tile 1
+        barrier();
+        int kt = 0;
+#ifdef GEMM128_STAMPS                       // instrumented build (tools/gemm128l_stamps.py): where a loader wave's K loop goes — issuing, waiting for its pieces to land, waiting at the barrier
+        unsigned long long t_iss = 0, t_vm = 0, t_bar = 0;
+        const unsigned long long t_begin = __builtin_readcyclecounter();
+        for (; kt < nk - 4; ++kt) {
+            const unsigned long long a0 = __builtin_readcyclecounter();
+            stage(kt + 4);
+            const unsigned long long a1 = __builtin_readcyclecounter();
+            wait_vm<16>();
+            const unsigned long long a2 = __builtin_readcyclecounter();
+            barrier();
+            const unsigned long long a3 = __builtin_readcyclecounter();
+            t_iss += a1 - a0; t_vm += a2 - a1; t_bar += a3 - a2;
+        }
+        if (wave == 4 && lane == 0) {
+            float* dbg = reinterpret_cast<float*>(p.C) + (long)p.M * p.ldc * (p.out_f32 ? 1 : 0) + blockIdx.x * 8;       // fp32 output only: row M.. of the (padded) output buffer
+            if (p.out_f32) { dbg[0] = (float)t_iss; dbg[1] = (float)t_vm; dbg[2] = (float)t_bar; dbg[3] = (float)(__builtin_readcyclecounter() - t_begin); }
+        }
+#else
+        for (; kt < nk - 4; ++kt) {
+            stage(kt + 4);
+            wait_vm<16>();                  // tiles kt+3, kt+4 stay in flight: kt+2 has landed
+            barrier();
+        }
+#endif
+        wait_vm<8>();  barrier();           // phase nk-4: tile nk-2
+        wait_vm<0>();  barrier();           // phase nk-3: tile nk-1
+        barrier();                          // phase nk-2
+        barrier();                          // phase nk-1
+    } else {
+        // ---------------- consumer
+        const int swz = (fr >> 1) & 7;
+        const unsigned low = fr * 128 + ((fq ^ swz) << 4);
+        const unsigned aRd0 = wr * 64 * 128 + low, bRd0 = B128_BOFF + wc * 64 * 128 + low;
+        bf16x8 fa[2][4][2], fb[2][4][2];
+        auto read_frags = [&](int kt, auto SET) {
+            if (GEMM_FLOOR == 1 || GEMM_FLOOR == 3) return;
+            constexpr int S = decltype(SET)::value;
+            const unsigned cb = (unsigned)(kt & 3) * B128_BUF;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) fb[S][j][s] = *reinterpret_cast<const bf16x8*>(smem + ((cb + bRd0) ^ (s * 64)) + j * 16 * 128);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) fa[S][i][s] = *reinterpret_cast<const bf16x8*>(smem + ((cb + aRd0) ^ (s * 64)) + i * 16 * 128);
+        };
+        auto mfmas = [&](auto SET) {
+            constexpr int S = decltype(SET)::value;
+            if (GEMM_FLOOR == 1) return;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[S][j][s], fa[S][i][s], acc[i][j], 0, 0, 0);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+#ifdef GEMM128_STAMPS
+        unsigned long long s_lds = 0, s_bar = 0;
+#endif
+        auto phase = [&](int kt, auto CUR, auto DO_READ) {
+            constexpr int C = decltype(CUR)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (decltype(DO_READ)::value) read_frags(kt + 1, std::integral_constant<int, 1 - C>{});
+            mfmas(CUR);
+            if constexpr (decltype(DO_READ)::value) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one DS read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef GEMM128_STAMPS
+            const unsigned long long c0 = __builtin_readcyclecounter();       // (s_memtime + lgkmcnt(0): behind the phase's last MFMA issue, so c1 - c0 is the wait for the LDS reads)
+            if constexpr (decltype(DO_READ)::value) wait_lds();
+            const unsigned long long c1 = __builtin_readcyclecounter();
+            barrier();
+            const unsigned long long c2 = __builtin_readcyclecounter();
+            s_lds += c1 - c0; s_bar += c2 - c1;
+#else
+            if constexpr (decltype(DO_READ)::value) wait_lds();
+            barrier();
+#endif
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        barrier();
+        read_frags(0, I0{});
+        wait_lds();
+        barrier();
+        int kt = 0;
+        for (; kt < nk - 2; kt += 2) {
+            phase(kt, I0{}, T{});
+            phase(kt + 1, I1{}, T{});
+        }
+        phase(kt, I0{}, T{});
+        phase(kt + 1, I1{}, F{});
+#ifdef GEMM128_STAMPS
+        if (wave == 0 && lane == 0 && p.out_f32) {
+            float* dbg = reinterpret_cast<float*>(p.C) + (long)p.M * p.ldc + blockIdx.x * 8;
+            dbg[4] = (float)s_lds; dbg[5] = (float)s_bar; dbg[6] = (float)(__builtin_readcyclecounter() - t_kernel0);      // kernel start -> end of the K loop
+        }
+#endif
+    }
+
+    // ---- epilogue: consumers -> fp32 tile [128][512 B] in LDS, 16-B chunk c of row r at chunk c ^ (r & 31)
+    if (wave < 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nb = n0 + wc * 64 + j * 16 + fq * 4;
+            const f32x4 b4 = (p.bias_mode == 1) ? *reinterpret_cast<const f32x4*>(p.bias + nb) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v = acc[i][j] + b4;
+                if (p.act == 1) v = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+                else if (p.act == 2) v = f32x4{gelu_tanh(v.x), gelu_tanh(v.y), gelu_tanh(v.z), gelu_tanh(v.w)};
+                const int row = wr * 64 + i * 16 + fr;
+                const int ch = wc * 16 + j * 4 + fq;
+                *reinterpret_cast<f32x4*>(smem + row * 512 + ((ch ^ (row & 31)) << 4)) = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (p.out_f32) {
+        float* C = reinterpret_cast<float*>(p.C);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = wave * 16 + u * 2 + er;
+            f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * 512 + ((ec ^ (row & 31)) << 4));
+            const int m = m0 + row, n = n0 + ec * 4;
+            if (p.drop_p > 0.f) {            // dropout of the linear's output before the residual add (training: hidden / final dropout): mask of mi_dropout_add_f32 for (m, n)
+                float k4[4];
+                mask_keep4(p.drop_key, (unsigned long long)m * (unsigned)(p.N >> 2) + (unsigned)(n >> 2), p.drop_p, 1.f / (1.f - p.drop_p), k4);
+                v = f32x4{v.x * k4[0], v.y * k4[1], v.z * k4[2], v.w * k4[3]};
+            }
+            if (use_res) v = rres[u] + p.alpha * v;
+            if (m < p.M) *reinterpret_cast<f32x4*>(C + (long)m * p.ldc + n) = v;
+            if (p.C2 && m < p.M) *reinterpret_cast<bf16x4*>(p.C2 + (long)m * p.ldc2 + n) = bf16x4{f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+            if (p.stats_out) {               // LayerNorm-fold producer: per-row partial (sum, sumsq) per 32 columns — 8 lanes hold them, same order as the pipelined form
+                float sm = (v.x + v.y) + (v.z + v.w), sq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                sm += dpp_f32<0xB1, 0xF>(0.f, sm); sq += dpp_f32<0xB1, 0xF>(0.f, sq);
+                sm += dpp_f32<0x4E, 0xF>(0.f, sm); sq += dpp_f32<0x4E, 0xF>(0.f, sq);
+                sm += dpp_f32<0x141, 0xF>(0.f, sm); sq += dpp_f32<0x141, 0xF>(0.f, sq);
+                if ((ec & 7) == 0 && m < p.M) *reinterpret_cast<f32x2*>(p.stats_out + (long)m * LN_STATS_STRIDE + (((n0 >> 7) << 2) + (ec >> 3)) * 2) = f32x2{sm, sq};
+            }
+        }
+    } else {
+        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = wave * 16 + u * 2 + er;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * 512 + ((ec ^ (row & 31)) << 4));
+            const int m = m0 + row, n = n0 + ec * 4;
+            bf16x4 o = {f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+            if (p.drop_p > 0.f) {            // dropout on the bf16 rows (mask and rounding of mi_dropout's bf16 form for element m * N + n)
+                float k4[4];
+                mask_keep4(p.drop_key, ((unsigned long long)m * (unsigned)p.N + (unsigned)n) >> 2, p.drop_p, 1.f / (1.f - p.drop_p), k4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = f2bf(bf2f(o[q]) * k4[q]);
+            }
+            if (m < p.M) *reinterpret_cast<bf16x4*>(C + (long)m * p.ldc + n) = o;
+        }
+    }
+}
+
 }  // namespace
 
 bool gemm_8p_supported(const GemmArgs& a, bool conv) {
@@ -956,7 +1239,17 @@ int gemm_8p128_launch(const GemmArgs& a, int ring, hipStream_t stream) {
     const bool attr_set = set_lds_attr(gemm8p128_kernel<4>, 4 * B128_BUF);
     (void)attr_set;
     const int grid = cdiv(a.M, 128) * (a.N / 128);
-    if (ring == 0) {          // register-pipelined form (even number of K tiles)
+    // the product's form for an even number of K tiles: the loader / consumer form from K = 2048 on (its K loop runs at the staging floor, 0.41 vs 0.47 us per K tile, its
+    // epilogue through the block-wide LDS tile costs ~1 us more: 8000 x 512 x K fp32 + residual 17.4 -> 18.3 us at K = 1024, 24.8 -> 24.1 at 2048, 47.4 -> 43.6 at 5120,
+    // tools/gemm128l_floor.py; same bits either way), the register-pipelined form below that.  GEMM128_LOADER = 1 / 2 force one form for every K (A/B builds).
+    if (ring == 0) ring = (GEMM128_LOADER == 1 || (GEMM128_LOADER == 0 && a.K >= 2048)) ? 2 : 3;
+    if (ring == 2) {          // loader / consumer form (even number of K tiles, at least four)
+        const bool attr_l = set_lds_attr(gemm8p128l_kernel, 4 * B128_BUF);
+        (void)attr_l;
+        launch_dense(PF_8P128, gemm8p128l_kernel, dim3(grid), dim3(512), (size_t)4 * B128_BUF, stream, a);
+        return MI_OK;
+    }
+    if (ring == 3) {          // register-pipelined form (even number of K tiles)
         const bool attr_p = set_lds_attr(gemm8p128p_kernel, 4 * B128_BUF);
         (void)attr_p;
         launch_dense(PF_8P128, gemm8p128p_kernel, dim3(grid), dim3(512), (size_t)4 * B128_BUF, stream, a);

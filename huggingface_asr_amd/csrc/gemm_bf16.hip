@@ -367,11 +367,11 @@ extern "C" int mi_gemm_resid_stats_f32_v(const void* A, long lda, const void* W,
     a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw; a.bias = bias; a.bias_mode = bias ? 1 : 0;
     a.C = C; a.ldc = ldc; a.out_f32 = 1; a.resid = resid; a.ldr = ldr; a.alpha = alpha; a.act = 0; a.M = M; a.N = N; a.K = K;
     a.C2 = (bf16_t*)C2; a.ldc2 = ldc2; a.stats_out = stats_out;
-    if (!A || !W || !C || !resid || (variant != 0 && variant != 40)) return MI_ERR_ARG;
+    if (!A || !W || !C || !resid || (variant != 0 && variant != 40 && variant != 42 && variant != 43)) return MI_ERR_ARG;       // 42 / 43: the 128 x 128 kernel's pipelined / loader-consumer form (A/B, tests)
     const bool wide = variant == 40;
     if (wide ? !gemm_8p_supported(a, false) : !gemm_8p128_supported(a)) return MI_ERR_UNSUPPORTED;
     const int slot = mi_profile_hook_begin(stream, 2.0 * M * N * K);
-    const int rc = wide ? gemm_8p_launch(a, false, stream) : gemm_8p128_launch(a, 0, stream);
+    const int rc = wide ? gemm_8p_launch(a, false, stream) : gemm_8p128_launch(a, variant == 42 ? 3 : (variant == 43 ? 2 : 0), stream);
     if (slot >= 0) mi_profile_hook_end(slot, stream);
     if (rc != MI_OK) return rc;
     MI_CHECK_LAUNCH();

@@ -346,10 +346,10 @@ int gemm_glds_launch(const GemmArgs& a, bool conv, hipStream_t stream) {
         }
     }
 #endif
-    if (phase_ok && v != 42 && v != 47 && gemm_8p_supported(a, conv) && (t256 >= 128 || v == 40)) return gemm_8p_launch(a, conv, stream);
+    if (phase_ok && v != 42 && v != 43 && v != 47 && gemm_8p_supported(a, conv) && (t256 >= 128 || v == 40)) return gemm_8p_launch(a, conv, stream);
     // N = 512-class GEMMs: 128x128 tiles (fp32 + residual or bf16 out); register-pipelined form for an even number of K tiles
-    if (!conv && phase_ok && gemm_8p128_supported(a) && (cdiv(a.M, 128) * (a.N / 128) >= 128 || v == 40 || v == 42 || v == 47))
-        return gemm_8p128_launch(a, (v != 47 && (a.K % 128) == 0) ? 0 : 4, stream);
+    if (!conv && phase_ok && gemm_8p128_supported(a) && (cdiv(a.M, 128) * (a.N / 128) >= 128 || v == 40 || v == 42 || v == 43 || v == 47))
+        return gemm_8p128_launch(a, (v != 47 && (a.K % 128) == 0) ? (v == 43 ? 2 : (v == 42 ? 3 : 0)) : 4, stream);       // 43 / 42 = the loader-consumer / the pipelined form whatever the default (A/B)
     // Everything else (small problems, the CTC head's odd N, K < 320): this file's LDS-DMA kernel.  Short launches — up to ~48 K steps of 128 x 128 work per CU — run
     // 128 x 64 output tiles, 48 KiB of LDS -> THREE persistent blocks per CU (blocks in flight beat bytes per flop when operands arrive cold); longer ones
     // (the CTC head: 79) and the conv GEMM keep 128 x 128 tiles, two persistent blocks per CU, the next tile's first K tile prefetched under the epilogue.

@@ -160,7 +160,7 @@ def gemm_lnfold(xb, wf, colsum, cbias, stats, npart, eps=1e-5, act="none", out=N
     return out
 
 
-def gemm_resid_stats(a, w, bias, resid, alpha=1.0, wide=False):
+def gemm_resid_stats(a, w, bias, resid, alpha=1.0, wide=False, variant=None):
     """-> (C fp32 = resid + alpha (a W^T + b), C2 = bf16(C), stats (M,32) fp32 with one (sum, sumsq) pair per 32 columns of C — per 64 columns with `wide`,
     the 256 x 256 tile of the throughput mode (mi_ebf_config.wide_tiles))"""
     M, K = a.shape
@@ -169,7 +169,7 @@ def gemm_resid_stats(a, w, bias, resid, alpha=1.0, wide=False):
     c2 = torch.empty((M, N), device=a.device, dtype=BF16)
     st = torch.zeros((M, 32), device=a.device, dtype=torch.float32)
     _lib.check(_lib.lib().mi_gemm_resid_stats_f32_v(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _p(bias), c.data_ptr(), c.stride(0), _p(resid), resid.stride(0) if resid is not None else 0,
-                                                    float(alpha), c2.data_ptr(), c2.stride(0), st.data_ptr(), M, N, K, 40 if wide else 0, _stream()), "mi_gemm_resid_stats_f32_v")
+                                                    float(alpha), c2.data_ptr(), c2.stride(0), st.data_ptr(), M, N, K, (40 if wide else 0) if variant is None else int(variant), _stream()), "mi_gemm_resid_stats_f32_v")
     return c, c2, st
 
 

@@ -540,3 +540,29 @@ def test_layernorm_fold_error_grows_with_the_row_mean_as_modelled(ratio):
         assert e_fold > 2.0 * e_unf, (ratio, e_fold, e_unf)                         # the amplification is real: this test documents it, it does not hide it
     var = (x * x).mean(-1) - x.mean(-1) ** 2
     assert float(((var - x.var(-1, unbiased=False)).abs() / x.var(-1, unbiased=False)).max()) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(8000, 512, 2048), (777, 256, 384), (130, 128, 768), (1000, 512, 4096)])
+def test_gemm_128_loader_consumer_form_same_bits_as_the_pipelined_form(M, N, K):
+    """gemm8p128l_kernel (round 5: four MFMA waves + four LDS-DMA waves; the dispatch takes it from K = 2048 on) against gemm8p128p_kernel: same ring, K order and MFMA shape, so every
+    output must be bit-identical — fp32 + residual, bf16, the LayerNorm-fold producer's bf16 copy and partial statistics, ragged last row tile — and right against fp32 torch."""
+    from huggingface_asr_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(DEV)
+    b, r = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    outs = {}
+    for v in (42, 43):
+        o32 = torch.full((M, N), float("nan"), device=DEV)
+        ops.gemm(a, w, b, out=o32, resid=r, alpha=0.5, variant=v)
+        o16 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+        ops.gemm(a, w, b, out=o16, variant=v)
+        outs[v] = (o32, o16) + tuple(ops.gemm_resid_stats(a, w, b, r, alpha=0.5, variant=v))
+    for x, y in zip(outs[42], outs[43]):
+        assert torch.equal(x, y)
+    ref = r + 0.5 * (a.float() @ w.float().t() + b)
+    torch.testing.assert_close(outs[43][0], ref, atol=2e-3, rtol=1e-3)
+    c, c2, st = outs[43][2:]
+    assert torch.equal(c2, c.to(torch.bfloat16))
+    torch.testing.assert_close(st[:, 0:2 * (N // 32):2].sum(1), c.sum(1), atol=1e-2, rtol=1e-4)
