@@ -30,7 +30,7 @@ class LnRedDesc(C.Structure):
 
 class Gpt2Config(C.Structure):
     """mirror of mi_gpt2_config (include/hfasr_hip.h)"""
-    _fields_ = [("d", i32), ("H", i32), ("L", i32), ("V", i32), ("eps", f32)]
+    _fields_ = [("d", i32), ("H", i32), ("L", i32), ("V", i32), ("eps", f32), ("step_form", i32)]
 
 
 GLOBAL_SLOTS, LAYER_SLOTS = 24, 64

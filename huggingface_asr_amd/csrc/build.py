@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libhfasr_hip.so")
 OBJ = os.path.join(HERE, "build")
-SOURCES = ["gemm_bf16.hip", "gemm_glds.hip", "gemm_8p.hip", "norm.hip", "conv.hip", "attention.hip", "fbank.hip", "ctc.hip", "ctc_prefix.hip", "decoder.hip", "decoder_step.hip", "beam_step.hip", "whisper.hip", "encoder.hip",
+SOURCES = ["gemm_bf16.hip", "gemm_glds.hip", "gemm_8p.hip", "norm.hip", "conv.hip", "attention.hip", "fbank.hip", "ctc.hip", "ctc_prefix.hip", "decoder.hip", "decoder_step.hip", "decoder_fused.hip", "beam_step.hip", "whisper.hip", "encoder.hip",
            "train_ops.hip", "gemm_tn.hip", "bgemm.hip", "attn_bwd.hip", "conv_bwd.hip", "loss_bwd.hip", "dropout.hip", "bestrq.hip", "specaug.hip", "speed.hip"]
 # -packed-fp32-ops (device side only): no v_pk_{add,mul,fma}_f32 in any kernel.  A wave executing packed-f32 VALU ops next to the LDS-DMA GEMM's
 # waves on one CU (kernels from two streams) lost the low-half product on 16 lanes in ~3 % of launches (tools/dbg/README.md); without packed

@@ -275,8 +275,15 @@ struct Carver {
     char* base; size_t off;
     void* take(size_t bytes) { void* p = base ? base + off : nullptr; off += (bytes + 255) / 256 * 256; return p; }
 };
-struct StepWs { float* x; bf16_t *a, *qkv, *ctx, *qq, *m, *hid; size_t bytes; };
-StepWs carve(const mi_gpt2_config& c, int M, int B, void* base) {
+}  // namespace
+// decoder_fused.hip: the three-launches-per-layer form of the token step
+bool gpt2_step_fused_ok(const mi_gpt2_config& c, int B, int U);
+size_t gpt2_step_fused_floats(const mi_gpt2_config& c, int M);
+int gpt2_step_fused(const mi_gpt2_config& c, const void* const* weights, const float* x0, int M, int past, int Lmax, void* const* kcache, void* const* vcache,
+                    const void* const* cross_kv, int T_enc, const int* enc_len, float* fws, bf16_t* hid, hipStream_t st);
+namespace {
+struct StepWs { float* x; bf16_t *a, *qkv, *ctx, *qq, *m, *hid; float* fws; size_t bytes; };
+StepWs carve(const mi_gpt2_config& c, int M, int B, int U, void* base) {
     Carver k{(char*)base, 0};
     StepWs w;
     w.x = (float*)k.take((size_t)M * c.d * 4);
@@ -286,6 +293,7 @@ StepWs carve(const mi_gpt2_config& c, int M, int B, void* base) {
     w.qq = (bf16_t*)k.take((size_t)M * c.d * 2);
     w.m = (bf16_t*)k.take((size_t)M * 4 * c.d * 2);
     w.hid = (bf16_t*)k.take((size_t)B * c.d * 2);
+    w.fws = gpt2_step_fused_ok(c, B, U) ? (float*)k.take(gpt2_step_fused_floats(c, M) * sizeof(float)) : nullptr;
     w.bytes = k.off;
     return w;
 }
@@ -294,7 +302,7 @@ StepWs carve(const mi_gpt2_config& c, int M, int B, void* base) {
 
 }  // namespace
 
-extern "C" size_t mi_gpt2_step_workspace_bytes(const mi_gpt2_config* cfg, int B, int U) { return carve(*cfg, B * U, B, nullptr).bytes; }
+extern "C" size_t mi_gpt2_step_workspace_bytes(const mi_gpt2_config* cfg, int B, int U) { return carve(*cfg, B * U, B, U, nullptr).bytes; }
 
 // weights: [wte f32 (V,d), pos f32 (n_pos,d), lnf_g, lnf_b, lm_head bf16 (V,d)] then per layer 18 pointers in the order
 //   ln1_g, ln1_b, wqkv, bqkv, wo, bo, lnc_g, lnc_b, wq, bq, wco, bco, ln2_g, ln2_b, wfc, bfc, wpr, bpr     (matrices bf16 (out,in), vectors f32)
@@ -309,7 +317,7 @@ extern "C" int mi_gpt2_step(const mi_gpt2_config* cfg, const void* const* weight
     const int hd = c.d / c.H;
     if (hd != 64 && hd != 128) return MI_ERR_UNSUPPORTED;
     const int M = B * U, d = c.d;
-    StepWs w = carve(c, M, B, workspace);
+    StepWs w = carve(c, M, B, U, workspace);
     if (w.bytes > workspace_bytes) return MI_ERR_ARG;
     const float scale = 1.0f / sqrtf((float)hd);
     auto Gf = [&](int i) { return (const float*)weights[i]; };
@@ -319,6 +327,14 @@ extern "C" int mi_gpt2_step(const mi_gpt2_config* cfg, const void* const* weight
         return mi_layernorm_chain(x, ldx, nullptr, 1, nullptr, nullptr, 0.f, nullptr, 0, g, b, c.eps, out, d, nullptr, 0, nullptr, nullptr, nullptr, 0, rows, d, st);
     };
     RUN(mi_embed_tokens(ids_new, Gf(0), emb_scale, Gf(1), past, U, d, M, c.V, w.x, st));
+    if (c.step_form != 1 && w.fws) {
+        // ---- fused token step (decoder_fused.hip): three launches per layer, every cross-workgroup reduction folded into the next launch's prologue
+        RUN(gpt2_step_fused(c, weights, w.x, M, past, Lmax, kcache, vcache, cross_kv, T_enc, enc_len, w.fws, w.hid, st));
+        SkArgs a{}; a.x16 = w.hid; a.ldx16 = d; a.W = (const bf16_t*)weights[4]; a.ldw = d; a.out32 = logits; a.ldo32 = ld_logits; a.M = B; a.N = c.V; a.K = d; a.act = 0;
+        RUN(skinny(a, st));
+        MI_CHECK_LAUNCH();
+        return MI_OK;
+    }
     if (M <= SK_MAXM && (d % 8) == 0 && 4 * d <= 2048) {
         // ---- skinny token step: LayerNorms, biases, activations and residual adds fused into GEMV-style linears (8 launches per layer)
         auto lin_ln = [&](const float* g, const float* b, const void* W, const float* bias, int N, bf16_t* out, int act) {

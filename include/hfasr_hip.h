@@ -486,6 +486,8 @@ int mi_mask_noise_f32(float* x, long ld, const unsigned char* time_mask, int M, 
 typedef struct {
     int d, H, L, V;
     float eps;
+    int step_form;      /* token step with one new token per row and <= 8 rows: 0 = the fused form (three launches per layer, csrc/decoder_fused.hip) where it applies
+                           (head size 64, d <= 512), 1 = always one launch per op (the cross-check; what every other shape runs) */
 } mi_gpt2_config;
 size_t mi_gpt2_step_workspace_bytes(const mi_gpt2_config* cfg, int B, int U);
 int mi_gpt2_step(const mi_gpt2_config* cfg, const void* const* weights, const long* ids_new, int B, int U, int past, int Lmax,

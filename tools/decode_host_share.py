@@ -1,7 +1,7 @@
 import os, sys, time
 import torch
-sys.path.insert(0, "/root/repo")
-exec(open("/root/repo/tools/decode_bench.py").read().split("wave = torch.from_numpy")[0])
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+exec(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "decode_bench.py")).read().split("wave = torch.from_numpy")[0])
 wave = torch.from_numpy(synth.waveforms(1, 1, 160000)).to(dev)
 tb = FB.FbankTables(80)
 for W in (1, 5):

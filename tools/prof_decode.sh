@@ -2,7 +2,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r4dec
+O=$GRAFT_REPO_ROOT/gpurun_out/${1:-r5dec}
 rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/d -o d -- python3 bench.py --secondary decode > $O/dec.log 2>&1
 cp $(find $O/d -name "*kernel_stats.csv" | head -1) $O/decode_kernel_stats.csv
