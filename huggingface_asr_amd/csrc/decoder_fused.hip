@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void fused_mlp_kernel(FusedArgs p) {
     __shared__ float hs[FD_HD];
     __shared__ __attribute__((aligned(16))) float po[FD_MAXD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = blockIdx.x / p.M, m = blockIdx.x - j * p.M, d = p.d;
+    const int J = p.d >> 4, m = blockIdx.x / J, j = blockIdx.x - m * J, d = p.d;      // (m, j) with j fastest: the blocks that stream the same weight slice share blockIdx % 8, i.e. an XCD's L2
     RowLoads rl;
     row_issue(p.pd, m, p.M, d, lane, wave, rl);
     bf16x8 wf[16];
