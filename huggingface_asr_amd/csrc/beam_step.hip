@@ -81,11 +81,53 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(BeamArgs p) {
     float mv = -INFINITY; int me = 0x7fffffff;
     if (!was_done) {
         if (cached) {
+            // Round 5: every load of the pass is requested before the first is used.  Written as `e < N ? cand_value(...) : -inf` each candidate's four loads sat under
+            // a condition — a basic block of their own, a full wait at every join: 25 dependent round trips to logits another kernel had just written (27 of the
+            // kernel's 40 us at W = 5).  Now the indices are clamped, (beam, token) advance by (1024 / V, 1024 % V) without a division per candidate, the per-row
+            // scalars come from LDS, and the arithmetic — cand_value's, operation for operation — runs on registers.
+            __shared__ float row_lse[BS_MAXW], row_bs[BS_MAXW];
+            if (tid < W) { row_lse[tid] = p.lse[(long)b * W + tid]; row_bs[tid] = p.beam_scores[(long)b * W + tid]; }
+            const int qstep = BS_THREADS / p.V, rstep = BS_THREADS - qstep * p.V;
+            float lg[CPT], ct[CPT];
+            {
+                int beam = tid / p.V, tok = tid - beam * p.V;
 #pragma unroll
-            for (int i = 0; i < CPT; ++i) {
-                const int e = tid + i * BS_THREADS;
-                cv[i] = e < N ? cand_value(p, b, e) : -INFINITY;
-                if (e < N && better(cv[i], e, mv, me)) { mv = cv[i]; me = e; }
+                for (int g8 = 0; g8 < CPT / 8; ++g8) {
+                    if (g8 * 8 * BS_THREADS < N) {                     // block-uniform: groups of eight candidates per thread that hold any at all
+#pragma unroll
+                        for (int i = g8 * 8; i < g8 * 8 + 8; ++i) {
+                            const int bc = beam < W ? beam : W - 1;    // past the last candidate: any valid address (the value is dropped below)
+                            const long row = (long)b * W + bc;
+                            lg[i] = p.logits[row * p.ldl + tok];
+                            ct[i] = p.ctc ? p.ctc[row * p.V + tok] : 0.f;
+                            beam += qstep; tok += rstep;
+                            if (tok >= p.V) { tok -= p.V; ++beam; }
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = g8 * 8; i < g8 * 8 + 8; ++i) { lg[i] = 0.f; ct[i] = 0.f; }
+                    }
+                }
+            }
+            __syncthreads();
+            {
+#pragma clang fp contract(off)
+                int beam = tid / p.V, tok = tid - beam * p.V;
+#pragma unroll
+                for (int i = 0; i < CPT; ++i) {
+                    const int e = tid + i * BS_THREADS;
+                    float sc = lg[i] - row_lse[beam < W ? beam : 0];
+                    if (p.mask_pad && tok == p.pad) sc = LOGZERO;
+                    if (p.ctc) {
+                        const float a = p.w_att * sc, c = p.w_ctc * ct[i];
+                        sc = a + c;
+                    }
+                    sc = sc + row_bs[beam < W ? beam : 0];
+                    cv[i] = e < N ? sc : -INFINITY;
+                    if (cv[i] > mv) { mv = cv[i]; me = e; }           // ascending e: the first of equal values stays (= better())
+                    beam += qstep; tok += rstep;
+                    if (tok >= p.V) { tok -= p.V; ++beam; }
+                }
             }
         } else
             for (int e = tid; e < N; e += BS_THREADS) {
@@ -93,24 +135,28 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(BeamArgs p) {
                 if (better(v, e, mv, me)) { mv = v; me = e; }
             }
     }
+    unsigned alive = 0xffffffffu;                                      // cached form: bit i = candidate tid + 1024 i not yet taken
     for (int r = 0; r < R && !was_done; ++r) {
         const float wm = wave_max(mv);
         const float ecand = (mv == wm && me != 0x7fffffff) ? -(float)me : -INFINITY;      // indices < 2^24: exact in fp32
         const float em = wave_max(ecand);
         if (lane == 0) { wv[wave] = wm; we[wave] = em == -INFINITY ? 0x7fffffff : (int)(-em); }
         __syncthreads();
-        float bv = wv[0]; int be = we[0];
-#pragma unroll
-        for (int k = 1; k < BS_WAVES; ++k)
-            if (better(wv[k], we[k], bv, be)) { bv = wv[k]; be = we[k]; }
+        // the 16 wave winners -> the block's: one DPP reduction per wave (lane k holds wave k's), not a 16-entry scan per thread
+        const float xv = lane < BS_WAVES ? wv[lane] : -INFINITY;
+        const int xe = lane < BS_WAVES ? we[lane] : 0x7fffffff;
+        const float bv = wave_max(xv);
+        const float bem = wave_max((xv == bv && xe != 0x7fffffff) ? -(float)xe : -INFINITY);
+        const int be = bem == -INFINITY ? 0x7fffffff : (int)(-bem);
         if (tid == 0) { tops[r] = bv; topi[r] = be; }
         if (be != 0x7fffffff && (be % BS_THREADS) == tid) {            // my candidate was taken: next best of my subset
             mv = -INFINITY; me = 0x7fffffff;
             if (cached) {
+                alive &= ~(1u << (be / BS_THREADS));
 #pragma unroll
                 for (int i = 0; i < CPT; ++i) {
-                    const int e = tid + i * BS_THREADS;
-                    if (e < N && comes_after(cv[i], e, bv, be) && better(cv[i], e, mv, me)) { mv = cv[i]; me = e; }
+                    const float v = ((alive >> i) & 1u) ? cv[i] : -INFINITY;
+                    if (v > mv) { mv = v; me = tid + i * BS_THREADS; }
                 }
             } else
                 for (int e = tid; e < N; e += BS_THREADS) {
