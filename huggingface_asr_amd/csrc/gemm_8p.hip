@@ -35,7 +35,7 @@
 #ifndef GEMM_FLOOR
 #define GEMM_FLOOR 0
 #endif
-// which 128 x 128 form `ring = 0` (every product call site) means: 0 = by K (see gemm_8p128_launch), 1 = always the loader / consumer form, 2 = always the register-pipelined one (A/B builds)
+// which 128 x 128 form `ring = 0` (every product call site) means: 0 = the register-pipelined one, 1 = the loader / consumer form from K = 2048 on (A/B builds: tools/gemm128l_step_ab.sh)
 #ifndef GEMM128_LOADER
 #define GEMM128_LOADER 0
 #endif
@@ -900,6 +900,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p128p_kernel(GemmArgs p) {
 // feeding the matrix pipe, and with all eight waves symmetric both waves of a SIMD do so at the same time.  Here the roles are split: waves 0-3 (one per SIMD) own a
 // 64 x 64 quarter of the tile each — fragment sets of K tiles t and t+1 in registers, 16 ds_read_b128 under 32 MFMAs, never a vector-memory instruction in the loop —
 // and waves 4-7 (their SIMD partners) issue the ring's LDS-DMA pieces (waves 4, 5 the A rows, 6, 7 the W rows: 8 pieces per wave and K tile) behind a counted vmcnt.
+// NOT the product's choice (see gemm_8p128_launch: it loses inside the step); kept as variant 43 — the measured answer to "would dedicated loader waves lift the K loop".
 // Same ring (four 32-KiB K tiles), same one barrier per K tile, same K order and MFMA shape as the pipelined form: the same bits.
 //   loader, phase t:   stage K tile t+4 into buffer t & 3 (its reads were retired before the barrier that ended phase t-1); vmcnt(16): tile t+2 has landed; s_barrier
 //   consumer, phase t: read K tile t+1 -> fragment set (t+1) & 1  ||  MFMAs of K tile t from set t & 1;  lgkmcnt(0);  s_barrier
@@ -1239,10 +1240,11 @@ int gemm_8p128_launch(const GemmArgs& a, int ring, hipStream_t stream) {
     const bool attr_set = set_lds_attr(gemm8p128_kernel<4>, 4 * B128_BUF);
     (void)attr_set;
     const int grid = cdiv(a.M, 128) * (a.N / 128);
-    // the product's form for an even number of K tiles: the loader / consumer form from K = 2048 on (its K loop runs at the staging floor, 0.41 vs 0.47 us per K tile, its
-    // epilogue through the block-wide LDS tile costs ~1 us more: 8000 x 512 x K fp32 + residual 17.4 -> 18.3 us at K = 1024, 24.8 -> 24.1 at 2048, 47.4 -> 43.6 at 5120,
-    // tools/gemm128l_floor.py; same bits either way), the register-pipelined form below that.  GEMM128_LOADER = 1 / 2 force one form for every K (A/B builds).
-    if (ring == 0) ring = (GEMM128_LOADER == 1 || (GEMM128_LOADER == 0 && a.K >= 2048)) ? 2 : 3;
+    // the product's form for an even number of K tiles is the register-pipelined one.  The loader / consumer form wins the isolated replay from K = 2048 on (24.8 -> 24.1 us,
+    // 47.4 -> 43.6 at K = 5120: its K loop runs at the staging floor) but LOSES inside the step, where its launches meet cold caches and its block-wide epilogue is exposed:
+    // same-box A/B of the dispatch rule "loader form from K = 2048 on" (tools/gemm128l_step_ab.sh, three alternations): forward one step at a time 5.01 -> 5.08 ms, base
+    // training step 18.05 -> 18.37 ms.  It stays reachable as variant 43 (tests, A/B); GEMM128_LOADER = 1 builds a library that takes it from K = 2048 on.
+    if (ring == 0) ring = (GEMM128_LOADER == 1 && a.K >= 2048) ? 2 : 3;
     if (ring == 2) {          // loader / consumer form (even number of K tiles, at least four)
         const bool attr_l = set_lds_attr(gemm8p128l_kernel, 4 * B128_BUF);
         (void)attr_l;

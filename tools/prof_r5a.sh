@@ -11,7 +11,7 @@ fi
 python3 bench.py --keep-profile $O/roof > $O/bench.log 2>&1
 tail -1 $O/bench.log > $O/bench_default.json
 python3 -c "import json;d=json.load(open('$O/bench_default.json'));print(d['value'],d['ms_per_step'],d['roofline']['frac'],{k:v for k,v in d.items() if k.startswith('one_step')})"
-rocprofv3 --kernel-trace --output-format csv -d $O/lt -o lt -- python3 bench.py --steps 40 --warmup 8 --no-kernel-events --no-secondary --no-cpu-baseline > $O/lanes_bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/lt -o lt -- python3 bench.py --steps 40 --warmup 8 --no-kernel-events --no-secondary --no-cpu-baseline --no-one-step > $O/lanes_bench.log 2>&1
 python3 tools/lanes_trace.py $(find $O/lt -name "*kernel_trace.csv" | head -1) --json $O/lanes_trace.json > $O/lanes_trace.txt 2>&1 || true
 rm -rf $O/lt
 cat $O/lanes_trace.txt
