@@ -545,7 +545,7 @@ def test_layernorm_fold_error_grows_with_the_row_mean_as_modelled(ratio):
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(8000, 512, 2048), (777, 256, 384), (130, 128, 768), (1000, 512, 4096)])
 def test_gemm_128_loader_consumer_form_same_bits_as_the_pipelined_form(M, N, K):
-    """gemm8p128l_kernel (round 5: four MFMA waves + four LDS-DMA waves; the dispatch takes it from K = 2048 on) against gemm8p128p_kernel: same ring, K order and MFMA shape, so every
+    """gemm8p128l_kernel (round 5: four MFMA waves + four LDS-DMA waves; variant 43 — measured faster in isolation, slower inside the step, so not the product's choice) against gemm8p128p_kernel: same ring, K order and MFMA shape, so every
     output must be bit-identical — fp32 + residual, bf16, the LayerNorm-fold producer's bf16 copy and partial statistics, ragged last row tile — and right against fp32 torch."""
     from huggingface_asr_amd import ops
     g = torch.Generator().manual_seed(M + N + K)
