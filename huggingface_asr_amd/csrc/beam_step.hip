@@ -18,6 +18,11 @@
 
 namespace {
 
+// BEAM_STOP = 1 / 2 / 3 (tools/beam_step_phases.sh only; never in the product build): the kernel returns after its candidate pass / its 2W selection rounds / the one-thread
+// walk — where its time goes (results are garbage in every mode but 0)
+#ifndef BEAM_STOP
+#define BEAM_STOP 0
+#endif
 constexpr float LOGZERO = -10000000000.0f;
 constexpr int BS_THREADS = 1024, BS_WAVES = BS_THREADS / 64, BS_MAXW = 16;
 
@@ -57,11 +62,28 @@ __device__ __forceinline__ float cand_value(const BeamArgs& p, int b, int e) {
 __device__ __forceinline__ bool comes_after(float v, int e, float pv, int pe) { return v < pv || (v == pv && e > pe); }
 __device__ __forceinline__ bool better(float v, int e, float bv, int be) { return v > bv || (v == bv && e < be); }
 
+// logits / CTC scores of the candidates tid, tid + 1024, ... of the first NG groups of eight (clamped addresses past the last candidate; the rest zero)
+template <int NG>
+__device__ __forceinline__ void load_pass(const BeamArgs& p, int b, int W, int tid, int qstep, int rstep, float (&lg)[32], float (&ct)[32]) {
+    int beam = tid / p.V, tok = tid - beam * p.V;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if (i < NG * 8) {
+            const int bc = beam < W ? beam : W - 1;
+            const long row = (long)b * W + bc;
+            lg[i] = p.logits[row * p.ldl + tok];
+            ct[i] = p.ctc ? p.ctc[row * p.V + tok] : 0.f;
+            beam += qstep; tok += rstep;
+            if (tok >= p.V) { tok -= p.V; ++beam; }
+        } else { lg[i] = 0.f; ct[i] = 0.f; }
+    }
+}
+
 __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(BeamArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long* stage = reinterpret_cast<long*>(smem);                       // [W][cur_len] the utterance's input ids before the step
-    __shared__ float wv[BS_WAVES];
-    __shared__ int we[BS_WAVES];
+    __shared__ float wv[2 * BS_WAVES];
+    __shared__ int we[2 * BS_WAVES];
     __shared__ float tops[2 * BS_MAXW];
     __shared__ int topi[2 * BS_MAXW];
     __shared__ float nbs[BS_MAXW];
@@ -71,6 +93,12 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(BeamArgs p) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int W = p.W, N = W * p.V, R = 2 * W;
     const bool was_done = p.done[b] != 0;
+    // the kept hypotheses' scores / lengths / count: requested here by W threads, read by the one-thread walk below from LDS (it used to fetch them itself, one dependent
+    // global round trip after another at the end of the kernel)
+    __shared__ float pf_fs[BS_MAXW];
+    __shared__ int pf_fl[BS_MAXW], pf_nf;
+    if (tid < W) { pf_fs[tid] = p.fin_score[(long)b * W + tid]; pf_fl[tid] = p.fin_len[(long)b * W + tid]; }
+    if (tid == 0) pf_nf = p.nfin[b];
 
     // ---- top 2W: every thread owns the candidates tid, tid + 1024, ... and offers its best one not yet taken; the owner of a round's winner re-scans
     // (a thread keeps its candidates' values in registers when they fit — W * V <= 32 Ki: the owner of a round's winner then re-scans 25 registers instead of
@@ -79,6 +107,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(BeamArgs p) {
     const bool cached = N <= CPT * BS_THREADS;
     float cv[CPT];
     float mv = -INFINITY; int me = 0x7fffffff;
+    float mv2 = -INFINITY; int me2 = 0x7fffffff;                       // cached form: the thread's second best (valid while have2), so that a taken best needs no rescan
+    bool have2 = true;
     if (!was_done) {
         if (cached) {
             // Round 5: every load of the pass is requested before the first is used.  Written as `e < N ? cand_value(...) : -inf` each candidate's four loads sat under
@@ -89,26 +119,11 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(BeamArgs p) {
             if (tid < W) { row_lse[tid] = p.lse[(long)b * W + tid]; row_bs[tid] = p.beam_scores[(long)b * W + tid]; }
             const int qstep = BS_THREADS / p.V, rstep = BS_THREADS - qstep * p.V;
             float lg[CPT], ct[CPT];
-            {
-                int beam = tid / p.V, tok = tid - beam * p.V;
-#pragma unroll
-                for (int g8 = 0; g8 < CPT / 8; ++g8) {
-                    if (g8 * 8 * BS_THREADS < N) {                     // block-uniform: groups of eight candidates per thread that hold any at all
-#pragma unroll
-                        for (int i = g8 * 8; i < g8 * 8 + 8; ++i) {
-                            const int bc = beam < W ? beam : W - 1;    // past the last candidate: any valid address (the value is dropped below)
-                            const long row = (long)b * W + bc;
-                            lg[i] = p.logits[row * p.ldl + tok];
-                            ct[i] = p.ctc ? p.ctc[row * p.V + tok] : 0.f;
-                            beam += qstep; tok += rstep;
-                            if (tok >= p.V) { tok -= p.V; ++beam; }
-                        }
-                    } else {
-#pragma unroll
-                        for (int i = g8 * 8; i < g8 * 8 + 8; ++i) { lg[i] = 0.f; ct[i] = 0.f; }
-                    }
-                }
-            }
+            const int ng = (N + 8 * BS_THREADS - 1) / (8 * BS_THREADS);      // groups of eight candidates per thread that hold any at all (block-uniform)
+            if (ng >= 4) load_pass<4>(p, b, W, tid, qstep, rstep, lg, ct);     // one straight-line block per count: every load of the pass is in flight together
+            else if (ng == 3) load_pass<3>(p, b, W, tid, qstep, rstep, lg, ct);
+            else if (ng == 2) load_pass<2>(p, b, W, tid, qstep, rstep, lg, ct);
+            else load_pass<1>(p, b, W, tid, qstep, rstep, lg, ct);
             __syncthreads();
             {
 #pragma clang fp contract(off)
@@ -124,7 +139,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(BeamArgs p) {
                     }
                     sc = sc + row_bs[beam < W ? beam : 0];
                     cv[i] = e < N ? sc : -INFINITY;
-                    if (cv[i] > mv) { mv = cv[i]; me = e; }           // ascending e: the first of equal values stays (= better())
+                    if (cv[i] > mv) { mv2 = mv; me2 = me; mv = cv[i]; me = e; }           // ascending e: the first of equal values stays (= better())
+                    else if (cv[i] > mv2) { mv2 = cv[i]; me2 = e; }
                     beam += qstep; tok += rstep;
                     if (tok >= p.V) { tok -= p.V; ++beam; }
                 }
@@ -135,38 +151,47 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(BeamArgs p) {
                 if (better(v, e, mv, me)) { mv = v; me = e; }
             }
     }
+    if (BEAM_STOP == 1) { if (mv == 12345.f) p.new_tok[0] = me; return; }
     unsigned alive = 0xffffffffu;                                      // cached form: bit i = candidate tid + 1024 i not yet taken
     for (int r = 0; r < R && !was_done; ++r) {
         const float wm = wave_max(mv);
         const float ecand = (mv == wm && me != 0x7fffffff) ? -(float)me : -INFINITY;      // indices < 2^24: exact in fp32
         const float em = wave_max(ecand);
-        if (lane == 0) { wv[wave] = wm; we[wave] = em == -INFINITY ? 0x7fffffff : (int)(-em); }
+        float* wvr = wv + (r & 1) * BS_WAVES;                          // winners of odd and even rounds in separate slots: ONE barrier per round (a wave cannot run two rounds ahead)
+        int* wer = we + (r & 1) * BS_WAVES;
+        if (lane == 0) { wvr[wave] = wm; wer[wave] = em == -INFINITY ? 0x7fffffff : (int)(-em); }
         __syncthreads();
         // the 16 wave winners -> the block's: one DPP reduction per wave (lane k holds wave k's), not a 16-entry scan per thread
-        const float xv = lane < BS_WAVES ? wv[lane] : -INFINITY;
-        const int xe = lane < BS_WAVES ? we[lane] : 0x7fffffff;
+        const float xv = lane < BS_WAVES ? wvr[lane] : -INFINITY;
+        const int xe = lane < BS_WAVES ? wer[lane] : 0x7fffffff;
         const float bv = wave_max(xv);
         const float bem = wave_max((xv == bv && xe != 0x7fffffff) ? -(float)xe : -INFINITY);
         const int be = bem == -INFINITY ? 0x7fffffff : (int)(-bem);
         if (tid == 0) { tops[r] = bv; topi[r] = be; }
         if (be != 0x7fffffff && (be % BS_THREADS) == tid) {            // my candidate was taken: next best of my subset
-            mv = -INFINITY; me = 0x7fffffff;
             if (cached) {
                 alive &= ~(1u << (be / BS_THREADS));
+                if (have2) { mv = mv2; me = me2; have2 = false; }      // the second best of the pass (no rescan: a thread is rarely taken from twice)
+                else {
+                    mv = -INFINITY; me = 0x7fffffff;
 #pragma unroll
-                for (int i = 0; i < CPT; ++i) {
-                    const float v = ((alive >> i) & 1u) ? cv[i] : -INFINITY;
-                    if (v > mv) { mv = v; me = tid + i * BS_THREADS; }
+                    for (int i = 0; i < CPT; ++i) {
+                        const float v = ((alive >> i) & 1u) ? cv[i] : -INFINITY;
+                        if (v > mv) { mv = v; me = tid + i * BS_THREADS; }
+                    }
                 }
-            } else
+            } else {
+                mv = -INFINITY; me = 0x7fffffff;
                 for (int e = tid; e < N; e += BS_THREADS) {
                     const float v = cand_value(p, b, e);
                     if (comes_after(v, e, bv, be) && better(v, e, mv, me)) { mv = v; me = e; }
                 }
+            }
         }
-        __syncthreads();
     }
+    __syncthreads();
 
+    if (BEAM_STOP == 2) { if (tid == 0 && tops[0] == 12345.f) p.new_tok[0] = topi[0]; return; }
     // ---- the utterance's ids before the step, and its kept hypotheses
     long* fstage = stage + W * p.cur_len;                              // [W][Lmax]
     for (int i = tid; i < W * p.cur_len; i += BS_THREADS) {
@@ -179,7 +204,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(BeamArgs p) {
     // ---- walk the candidates (one thread: at most 2W steps)
     if (tid == 0) {
         for (int k = 0; k < W; ++k) { nbs[k] = 0.f; nbt[k] = was_done ? p.pad : 0; nbb[k] = 0; fsrc[k] = k; }
-        nf_new = p.nfin[b];
+        nf_new = pf_nf;
         if (!was_done) {
             const bool at_max = p.cur_len + 1 >= p.max_length;
             bool hit[2 * BS_MAXW];
@@ -200,7 +225,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(BeamArgs p) {
             int nf = nf_new;
             float fs[BS_MAXW];
             int fl[BS_MAXW];
-            for (int i = 0; i < nf; ++i) { fs[i] = p.fin_score[(long)b * W + i]; fl[i] = p.fin_len[(long)b * W + i]; }
+            for (int i = 0; i < nf; ++i) { fs[i] = pf_fs[i]; fl[i] = pf_fl[i]; }
             for (int r = 0; r < nr && r < W; ++r) {
                 if (!hit[r]) continue;
                 const float sc = tops[r] / p.denom;
@@ -225,6 +250,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(BeamArgs p) {
             for (int r = 0; r < R; ++r) { p.top_s[(long)b * R + r] = was_done ? 0.f : tops[r]; p.top_i[(long)b * R + r] = was_done ? 0 : topi[r]; }
     }
     __syncthreads();
+    if (BEAM_STOP == 3) return;
 
     // ---- the kept hypotheses move to their new ranks (old rows from the LDS copy, new ones = their beam's ids + the closing token)
     if (!was_done)
