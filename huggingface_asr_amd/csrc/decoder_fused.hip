@@ -25,6 +25,9 @@ constexpr int FD_MAXM = 8, FD_MAXD = 512, FD_HD = 64;
 
 struct Pending {                 // x_cur[m] = base[m] + pbias + sum_{p < P} part[p][m]      (P = 0: x_cur = base, nothing stored)
     const float* base; const float* part; const float* pbias; int P; float* next;      // part: (P, M, d) fp32; next: (M, d) — the designated block stores x_cur there
+    // the first launch of a token step embeds the tokens itself (ids != null; base unused): x_cur[m] = wte[ids[m]] * emb_scale + pos_row — mi_embed_tokens' arithmetic —
+    // and the designated block stores it (the cross-attention launch of layer 0 reads it back as its base)
+    const long* ids; const float* wte; const float* pos_row; float emb_scale; int V;
 };
 
 // 8 consecutive elements k0 = 8 * lane of row m, for every wave of the block (all four take part: the partials are split over the waves, wave sums go through `wsum`).
@@ -34,6 +37,14 @@ struct RowLoads { f32x4 b0, b1, c0, c1, v0[8], v1[8]; };
 __device__ __forceinline__ void row_issue(const Pending& pd, int m, int M, int d, int lane, int wave, RowLoads& r) {
     const int k0 = lane * 8;
     const int ko = k0 < d ? k0 : 0;
+    if (pd.ids) {
+        long id = pd.ids[m];
+        id = id < 0 ? 0 : (id >= pd.V ? pd.V - 1 : id);
+        const float* er = pd.wte + id * d + ko;
+        r.b0 = *reinterpret_cast<const f32x4*>(er); r.b1 = *reinterpret_cast<const f32x4*>(er + 4);
+        r.c0 = *reinterpret_cast<const f32x4*>(pd.pos_row + ko); r.c1 = *reinterpret_cast<const f32x4*>(pd.pos_row + ko + 4);
+        return;
+    }
     const float* br = pd.base + (long)m * d + ko;
     r.b0 = *reinterpret_cast<const f32x4*>(br); r.b1 = *reinterpret_cast<const f32x4*>(br + 4);
     if (pd.P > 0) {
@@ -53,7 +64,11 @@ __device__ __forceinline__ void row_finish(const Pending& pd, const RowLoads& r,
     const bool on = k0 < d;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     f32x4 b0 = on ? r.b0 : z, b1 = on ? r.b1 : z;
-    if (pd.P > 0) {
+    if (pd.ids) {
+        b0 = b0 * pd.emb_scale + r.c0; b1 = b1 * pd.emb_scale + r.c1;
+        if (!on) { b0 = z; b1 = z; }
+        if (store && wave == 0 && on) { *reinterpret_cast<f32x4*>(pd.next + (long)m * d + k0) = b0; *reinterpret_cast<f32x4*>(pd.next + (long)m * d + k0 + 4) = b1; }
+    } else if (pd.P > 0) {
         const int per = (pd.P + 3) >> 2;
         const int p0 = wave * per, p1 = min(pd.P, p0 + per);
         f32x4 a0 = z, a1 = z;
@@ -374,8 +389,9 @@ size_t gpt2_step_fused_floats(const mi_gpt2_config& c, int M) {
     return 2 * (size_t)M * c.d + 2 * pmax * M * c.d;
 }
 
-// x0: (M, d) fp32 embedded tokens (read only); fws: gpt2_step_fused_floats(c, M) floats; hid: (M, d) bf16 out = ln_f(stream) for the lm head.  Weight table as mi_gpt2_step.
-int gpt2_step_fused(const mi_gpt2_config& c, const void* const* weights, const float* x0, int M, int past, int Lmax, void* const* kcache, void* const* vcache,
+// ids: (M) int64 new tokens, embedded by the first launch (wte = weights[0] scaled by emb_scale, + position row `past` of weights[1]); fws: gpt2_step_fused_floats(c, M)
+// floats; hid: (M, d) bf16 out = ln_f(stream) for the lm head.  Weight table as mi_gpt2_step.
+int gpt2_step_fused(const mi_gpt2_config& c, const void* const* weights, const long* ids, float emb_scale, int M, int past, int Lmax, void* const* kcache, void* const* vcache,
                     const void* const* cross_kv, int T_enc, const int* enc_len, float* fws, bf16_t* hid, hipStream_t st) {
     const int d = c.d, H = c.H, J = d / 16;
     const size_t pmax = (size_t)(H > J ? H : J);
@@ -383,10 +399,11 @@ int gpt2_step_fused(const mi_gpt2_config& c, const void* const* weights, const f
     float* pb[2] = {fws + 2 * (size_t)M * d, fws + 2 * (size_t)M * d + pmax * M * d};
     auto Lw = [&](int l, int i) { return weights[5 + l * 18 + i]; };
     auto Lf = [&](int l, int i) { return (const float*)weights[5 + l * 18 + i]; };
-    Pending pd{x0, nullptr, nullptr, 0, nullptr};
+    Pending pd{nullptr, nullptr, nullptr, 0, nullptr, ids, (const float*)weights[0], (const float*)weights[1] + (long)past * d, emb_scale, c.V};
     int xi = 0, pi = 0;
-    auto advance = [&](float* part_written, const float* bias, int P) {           // the launch just enqueued wrote `part_written`; if it had partials to fold in, it also stored pd.next
-        if (pd.P > 0) pd.base = pd.next;
+    auto advance = [&](float* part_written, const float* bias, int P) {           // the launch just enqueued wrote `part_written`; if it had something to fold in (partials, or the embedding), it also stored pd.next
+        if (pd.P > 0 || pd.ids) pd.base = pd.next;
+        pd.ids = nullptr;
         pd.part = part_written; pd.pbias = bias; pd.P = P;
         pd.next = xb[xi]; xi ^= 1;
     };

@@ -279,7 +279,7 @@ struct Carver {
 // decoder_fused.hip: the three-launches-per-layer form of the token step
 bool gpt2_step_fused_ok(const mi_gpt2_config& c, int B, int U);
 size_t gpt2_step_fused_floats(const mi_gpt2_config& c, int M);
-int gpt2_step_fused(const mi_gpt2_config& c, const void* const* weights, const float* x0, int M, int past, int Lmax, void* const* kcache, void* const* vcache,
+int gpt2_step_fused(const mi_gpt2_config& c, const void* const* weights, const long* ids, float emb_scale, int M, int past, int Lmax, void* const* kcache, void* const* vcache,
                     const void* const* cross_kv, int T_enc, const int* enc_len, float* fws, bf16_t* hid, hipStream_t st);
 namespace {
 struct StepWs { float* x; bf16_t *a, *qkv, *ctx, *qq, *m, *hid; float* fws; size_t bytes; };
@@ -326,15 +326,15 @@ extern "C" int mi_gpt2_step(const mi_gpt2_config* cfg, const void* const* weight
     auto ln = [&](const float* x, long ldx, const float* g, const float* b, bf16_t* out, int rows) {
         return mi_layernorm_chain(x, ldx, nullptr, 1, nullptr, nullptr, 0.f, nullptr, 0, g, b, c.eps, out, d, nullptr, 0, nullptr, nullptr, nullptr, 0, rows, d, st);
     };
-    RUN(mi_embed_tokens(ids_new, Gf(0), emb_scale, Gf(1), past, U, d, M, c.V, w.x, st));
     if (c.step_form != 1 && w.fws) {
-        // ---- fused token step (decoder_fused.hip): three launches per layer, every cross-workgroup reduction folded into the next launch's prologue
-        RUN(gpt2_step_fused(c, weights, w.x, M, past, Lmax, kcache, vcache, cross_kv, T_enc, enc_len, w.fws, w.hid, st));
+        // ---- fused token step (decoder_fused.hip): three launches per layer, every cross-workgroup reduction folded into the next launch's prologue (the embedding too)
+        RUN(gpt2_step_fused(c, weights, ids_new, emb_scale, M, past, Lmax, kcache, vcache, cross_kv, T_enc, enc_len, w.fws, w.hid, st));
         SkArgs a{}; a.x16 = w.hid; a.ldx16 = d; a.W = (const bf16_t*)weights[4]; a.ldw = d; a.out32 = logits; a.ldo32 = ld_logits; a.M = B; a.N = c.V; a.K = d; a.act = 0;
         RUN(skinny(a, st));
         MI_CHECK_LAUNCH();
         return MI_OK;
     }
+    RUN(mi_embed_tokens(ids_new, Gf(0), emb_scale, Gf(1), past, U, d, M, c.V, w.x, st));
     if (M <= SK_MAXM && (d % 8) == 0 && 4 * d <= 2048) {
         // ---- skinny token step: LayerNorms, biases, activations and residual adds fused into GEMV-style linears (8 launches per layer)
         auto lin_ln = [&](const float* g, const float* b, const void* W, const float* bias, int N, bf16_t* out, int act) {
