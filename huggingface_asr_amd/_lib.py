@@ -66,6 +66,8 @@ SIGNATURES = {
                                    vp, i64, vp, vp, i32, i32, i32, i32, f32, i32, f32, C.c_uint, C.c_uint, vp],
     "mi_attention_qkv_bwd_probs_qb": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, i32,
                                       vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, i32, f32, C.c_uint, C.c_uint, vp],
+    "mi_attention_qkv_bwd_probs_f": [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, i32,
+                                     vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, i32, f32, C.c_uint, C.c_uint, i32, vp],
     "mi_row_stats_bf16": [vp, i64, i32, f32, vp, i32, vp],
     "mi_csgu_bf16": [vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp],
     "mi_dwconv_residual_bf16": [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp],

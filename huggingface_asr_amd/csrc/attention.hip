@@ -47,6 +47,11 @@ struct AttnArgs {
 #endif
     int gx; unsigned mgx, mgy;            // eight-wave form (1-D grid): query blocks per (batch, head) and ceil(2^32 / gx), ceil(2^32 / H) — exact quotients for block ids < 2^16
     int variant;                         // 0: the product's choice; 1: the four-wave LDS-staged forward; 2: the eight-wave form (1, 2: A/B only, tools/attn_ab.py)
+    // BW, round 5: the zeros nobody reads are not written.  The caller guarantees that (a) dbd is a buffer it zero-filled ONCE and that only this entry writes — a row's
+    // relative positions outside its wave's MAXIMAL band (every key valid) are the same for every launch, so they stay zero —, and (b) columns of P / dS from the key
+    // length rounded up to 128 on are never read (mi_bgemm_sparse_bf16's m_valid skips those M tiles).  The walk then zeroes only what an earlier launch with longer
+    // utterances may have written: the rest of the maximal band in dbd, the rest of the last 128-key tile in P / dS.
+    int sparse;
 };
 
 // 16-B chunk swizzle of the LDS-staged kernel's tiles (applied on the DMA source and on every read).  256-B rows (hd 128): the image that is conflict-free for ds_read_b128
@@ -723,9 +728,10 @@ __global__ __launch_bounds__(256, 1) void attn_lds_kernel(AttnArgs p) {
                 const bf16x8 bv = *reinterpret_cast<const bf16x8*>(band + row * BAND_B + (nkt & 1) * 64 + sch * 16);
                 if (cb >= 0 && cb < (int)p.ldbd) *reinterpret_cast<bf16x8*>(p.dbd + (orow0 + row) * p.ldbd + cb + sch * 8) = bv;
             }
-            for (int blk = 0; REL && blk < nbd; ++blk)
+            const int bmax = blo + ((T + 31) >> 5);                    // last block of this wave's band when every key is valid
+            for (int blk = p.sparse ? max(blo, 0) : 0; REL && blk < (p.sparse ? min(nbd, bmax + 1) : nbd); ++blk)
                 if (blk < blo || blk > bhi) *reinterpret_cast<bf16x8*>(p.dbd + (orow0 + row) * p.ldbd + blk * 32 + sch * 8) = z8;
-            for (int blk = nkt; blk < nbs; ++blk) {
+            for (int blk = nkt; blk < ((p.sparse && !p.causal) ? min(nbs, (nkt + 3) & ~3) : nbs); ++blk) {      // (causal: a query block's future keys are zeros the dV / dK products DO read)
                 *reinterpret_cast<bf16x8*>(p.prob + (orow0 + row) * p.ldsr + blk * 32 + sch * 8) = z8;
                 *reinterpret_cast<bf16x8*>(p.ds + (orow0 + row) * p.ldsr + blk * 32 + sch * 8) = z8;
             }
@@ -1441,13 +1447,32 @@ extern "C" int mi_attention_qkv_lse_bf16(const void* q, long ldq, const void* k,
 // ldsr >= T rounded up to 32, ldbd >= pad + 2T - 1, (T - 32 + pad) % 32 == 0: a wave's band of relative positions then starts on a 64-B boundary of its rows.
 // Every element of the three outputs is written (zeros where no key / relative position contributes).
 // qu_out / qv_out (both or neither; with pos only): (B*T, ldqb) bf16 = q + pos_bias_u / q + pos_bias_v, written by the walk's prologue from its A fragments.
+// ... _f: the same with `flags`.  bit 0 (sparse writes): zeros nobody reads are not written — dbd must be a buffer the caller zero-filled once and that only this entry
+// writes (relative positions outside a row's maximal band stay zero from launch to launch), and columns of prob / ds from the key length rounded up to 128 on must never be
+// read (mi_bgemm_sparse_bf16 with m_valid = lengths does not).  At BASELINE config 3 (clips of 1-20 s padded to 20 s) that is 42 % of the walk's 800 MB of writes per launch.
+extern "C" int mi_attention_qkv_bwd_probs_f(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                            const void* pos, long ldp, const float* bias_u, const float* bias_v, const int* lengths,
+                                            const void* ctx, long ldo, const void* dctx, long ldd, const float* lse,
+                                            void* prob, void* ds, long ldsr, void* dbd, long ldbd, int pad,
+                                            void* dq, long lddq, float* dsum_u, float* dsum_v, void* qu_out, void* qv_out, long ldqb,
+                                            int B, int T, int H, int hd, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, int flags, hipStream_t stream);
 extern "C" int mi_attention_qkv_bwd_probs_qb(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                                              const void* pos, long ldp, const float* bias_u, const float* bias_v, const int* lengths,
                                              const void* ctx, long ldo, const void* dctx, long ldd, const float* lse,
                                              void* prob, void* ds, long ldsr, void* dbd, long ldbd, int pad,
                                              void* dq, long lddq, float* dsum_u, float* dsum_v, void* qu_out, void* qv_out, long ldqb,
                                              int B, int T, int H, int hd, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, hipStream_t stream) {
+    return mi_attention_qkv_bwd_probs_f(q, ldq, k, ldk, v, ldv, pos, ldp, bias_u, bias_v, lengths, ctx, ldo, dctx, ldd, lse, prob, ds, ldsr, dbd, ldbd, pad, dq, lddq,
+                                        dsum_u, dsum_v, qu_out, qv_out, ldqb, B, T, H, hd, scale, causal, drop_p, seed, stream_id, 0, stream);
+}
+extern "C" int mi_attention_qkv_bwd_probs_f(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                            const void* pos, long ldp, const float* bias_u, const float* bias_v, const int* lengths,
+                                            const void* ctx, long ldo, const void* dctx, long ldd, const float* lse,
+                                            void* prob, void* ds, long ldsr, void* dbd, long ldbd, int pad,
+                                            void* dq, long lddq, float* dsum_u, float* dsum_v, void* qu_out, void* qv_out, long ldqb,
+                                            int B, int T, int H, int hd, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, int flags, hipStream_t stream) {
     MI_ENTER();
+    if (flags & ~1) return MI_ERR_ARG;
     if ((qu_out != nullptr) != (qv_out != nullptr) || (qu_out && (!pos || (ldqb % 8) || ldqb < (long)H * hd || (((uintptr_t)qu_out | (uintptr_t)qv_out) & 15)))) return MI_ERR_ARG;
     if (B <= 0 || T <= 0 || H <= 0 || !lse || !ctx || !dctx || !prob || !ds || !dq || drop_p < 0.f || drop_p >= 1.f) return MI_ERR_ARG;
     if ((lddq % 8) || lddq >= (1l << 30) || ((uintptr_t)dq & 15) || (pos && (!dsum_u || !dsum_v))) return MI_ERR_ARG;
@@ -1465,6 +1490,7 @@ extern "C" int mi_attention_qkv_bwd_probs_qb(const void* q, long ldq, const void
                (bf16_t*)dq, lddq, dsum_u, dsum_v, drop_p, ((unsigned long long)stream_id << 32) ^ (unsigned long long)seed};
     a.ldsum = (dsum_u && dsum_v == dsum_u + (long)H * hd) ? 2l * H * hd : 0;      // [u | v] rows of one (rows, 2 H hd) buffer: see the header
     a.qu_out = (bf16_t*)qu_out; a.qv_out = (bf16_t*)qv_out; a.ldqb = ldqb;
+    a.sparse = flags & 1;
     switch (hd) {
         case 64: return launch_lds_bw<64>(a, pos != nullptr, stream);
         case 128: return launch_lds_bw<128>(a, pos != nullptr, stream);

@@ -363,12 +363,27 @@ def attn_x_bwd_probs(q, k, v, B, Tq, Tk, H, ctx, dctx, lse, dq, *, lengths=None,
     return prob, ds
 
 
-def attn_bwd_probs(qkv, B, T, H, ctx, dctx, lse, dq, *, pos=None, bias_u=None, bias_v=None, lengths=None, causal=False, drop=None, qb=False):
+_DBD_CACHE = {}          # device -> (key, zero-filled dbd buffer of the sparse-writes walk)
+
+
+def _dbd_static(dev, H, B, T, Ps):
+    """the sparse-writes walk's dbd: zero-filled ONCE per shape and then only ever written by that walk (relative positions outside a row's maximal band stay zero from
+    launch to launch); one buffer per device — a new shape replaces it"""
+    key = (H, B, T, Ps)
+    got = _DBD_CACHE.get(dev)
+    if got is None or got[0] != key:
+        _DBD_CACHE[dev] = got = (key, torch.zeros((H, B, T, Ps), device=dev, dtype=BF16))
+    return got[1]
+
+
+def attn_bwd_probs(qkv, B, T, H, ctx, dctx, lse, dq, *, pos=None, bias_u=None, bias_v=None, lengths=None, causal=False, drop=None, qb=False, sparse=False):
     """First half of the fused attention backward (head size 64 / 128, no probability dropout): -> prob, ds (H, B, T, Ts) bf16 and, with relative positions,
     dbd (H, B, T, Ps) bf16 with dbd[i][T-1-i+j + pad] = ds[i][j] (else None).  Ts = T rounded up to 32; (pad, Ps) = band_geometry(T).  Everything is written.
     dq (B*T, d) bf16 row view receives the query gradient dS K + dBD P; with positions also -> (su, sv): (rows, d) fp32 whose column sums are the gradients
     of pos_bias_u / pos_bias_v.  drop = the (p, seed, stream_id) the forward used: prob is then the DROPPED probabilities (what multiplied V).
-    qb (with positions): also -> (qu, qv) (B*T, d) bf16 = q + pos_bias_u, q + pos_bias_v as the kernel's own operands (what `add_rowvec2(q, u, v)` makes), appended to the result."""
+    qb (with positions): also -> (qu, qv) (B*T, d) bf16 = q + pos_bias_u, q + pos_bias_v as the kernel's own operands (what `add_rowvec2(q, u, v)` makes), appended to the result.
+    sparse: the zeros nobody reads are not written (mi_attention_qkv_bwd_probs_f, flag 1): dbd is then ONE zero-filled buffer per shape that every call re-uses (the caller
+    consumes it before the next call on the same stream), and prob / ds hold garbage from the key length rounded up to 128 on — read them only through `bgemm(..., m_valid=lengths)`."""
     d = qkv.shape[1] // 3
     dp, dseed, dsid = drop if drop is not None else (0.0, 0, 0)
     hd = d // H
@@ -378,19 +393,19 @@ def attn_bwd_probs(qkv, B, T, H, ctx, dctx, lse, dq, *, pos=None, bias_u=None, b
     prob = torch.empty((H, B, T, Ts), device=dev, dtype=BF16)
     ds = torch.empty((H, B, T, Ts), device=dev, dtype=BF16)
     rel = pos is not None
-    dbd = torch.empty((H, B, T, Ps), device=dev, dtype=BF16) if rel else None
+    dbd = (_dbd_static(dev, H, B, T, Ps) if sparse else torch.empty((H, B, T, Ps), device=dev, dtype=BF16)) if rel else None
     nw = 4 * ((T + 127) // 128)
     suv = torch.empty((B * nw, 2 * d), device=dev, dtype=F32) if rel else None         # rows of [u | v]: `LnReduceBatch.add_rows2(su, ...)` can defer their column sums
     su, sv = (suv[:, :d], suv[:, d:]) if rel else (None, None)
     q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
     qu = torch.empty((B * T, d), device=dev, dtype=BF16) if (qb and rel) else None
     qv = torch.empty((B * T, d), device=dev, dtype=BF16) if (qb and rel) else None
-    _lib.check(_L().mi_attention_qkv_bwd_probs_qb(q.data_ptr(), qkv.stride(0), k.data_ptr(), qkv.stride(0), v.data_ptr(), qkv.stride(0),
+    _lib.check(_L().mi_attention_qkv_bwd_probs_f(q.data_ptr(), qkv.stride(0), k.data_ptr(), qkv.stride(0), v.data_ptr(), qkv.stride(0),
                                                   _p(pos), pos.stride(0) if rel else 0, _p(bias_u), _p(bias_v), _p(lengths),
                                                   ctx.data_ptr(), ctx.stride(0), dctx.data_ptr(), dctx.stride(0), lse.data_ptr(),
                                                   prob.data_ptr(), ds.data_ptr(), Ts, _p(dbd), Ps, pad, dq.data_ptr(), dq.stride(0), _p(su), _p(sv), _p(qu), _p(qv), d,
-                                                  B, T, H, hd, 1.0 / math.sqrt(hd), int(causal), float(dp), int(dseed) & 0xFFFFFFFF, int(dsid) & 0xFFFFFFFF, _stream()),
-               "mi_attention_qkv_bwd_probs_qb")
+                                                  B, T, H, hd, 1.0 / math.sqrt(hd), int(causal), float(dp), int(dseed) & 0xFFFFFFFF, int(dsid) & 0xFFFFFFFF, int(bool(sparse)), _stream()),
+               "mi_attention_qkv_bwd_probs_f")
     return (prob, ds, dbd, su, sv, qu, qv) if qb else (prob, ds, dbd, su, sv)
 
 

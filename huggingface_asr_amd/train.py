@@ -379,6 +379,7 @@ class EncoderCTCTrainer:
         self.dw_overwrite = os.environ.get("HFASR_DW_OVERWRITE", "1") != "0"      # see _forward_backward (HFASR_DW_OVERWRITE=0 / tools/train_bench.py --no-dw-overwrite: always accumulate)
         self.ctc_from_bwd = True                  # the CTC loss out of the backward's own alpha recursion (tools/train_bench.py --no-ctc-from-bwd: forward loss kernel + backward)
         self.walk_qb = True                       # q + u / q + v of the attention backward from the fused walk's prologue (--no-walk-qb: the pass of their own)
+        self.sparse_attn_bwd = os.environ.get("HFASR_ATTN_BWD_SPARSE", "1") != "0"       # round 5: the fused walk does not write the zeros nobody reads (ops_train.attn_bwd_probs)
         self.frozen = set()
         self.layerdrop = float(c.get("layerdrop", 0.0) or 0.0)      # tf:models/wav2vec2_conformer/modeling_wav2vec2_conformer.py:686-690
         g = lambda k: float(c.get(k, 0.0) or 0.0)
@@ -1104,7 +1105,7 @@ class EncoderCTCTrainer:
             # accumulates dQ = dS K + dBD P on the way (its two terms' column sums are the position-bias gradients)
             # (with positions the walk also leaves q + u and q + v, its own A operands, for the dK and d(positions) products below)
             prob, ds, dbd, su, sv, qu, qv = T.attn_bwd_probs(qkv, B, Tt, H, S["ctx"], dctx, S["lse"], dqkv[:, :d], pos=posp, bias_u=P(p + "att_u") if rel else None,
-                                                             bias_v=P(p + "att_v") if rel else None, lengths=lengths, causal=self.causal, drop=drop, qb=self.walk_qb)[:7] + ((None, None) if not self.walk_qb else ())
+                                                             bias_v=P(p + "att_v") if rel else None, lengths=lengths, causal=self.causal, drop=drop, qb=self.walk_qb, sparse=self.sparse_attn_bwd)[:7] + ((None, None) if not self.walk_qb else ())
             fused = True
             if rel:
                 if qu is None:

@@ -188,6 +188,15 @@ int mi_attention_qkv_bwd_probs_qb(const void* q, long ldq, const void* k, long l
                                   void* prob, void* ds, long ldsr, void* dbd, long ldbd, int pad,
                                   void* dq, long lddq, float* dsum_u, float* dsum_v, void* qu_out, void* qv_out, long ldqb,
                                   int B, int T, int H, int hd, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, mi_stream_t stream);
+/* ... with flags.  bit 0, sparse writes: the zeros nobody reads are not written — `dbd` must be a buffer the caller zero-filled ONCE and that only this entry writes (a row's
+ * relative positions outside its maximal band are the same for every launch), and columns of prob / ds from the key length rounded up to 128 on must never be read
+ * (mi_bgemm_sparse_bf16 with m_valid = lengths does not read them). */
+int mi_attention_qkv_bwd_probs_f(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                  const void* pos, long ldp, const float* bias_u, const float* bias_v, const int* lengths,
+                                  const void* ctx, long ldo, const void* dctx, long ldd, const float* lse,
+                                  void* prob, void* ds, long ldsr, void* dbd, long ldbd, int pad,
+                                  void* dq, long lddq, float* dsum_u, float* dsum_v, void* qu_out, void* qv_out, long ldqb,
+                                  int B, int T, int H, int hd, float scale, int causal, float drop_p, unsigned seed, unsigned stream_id, int flags, mi_stream_t stream);
 /* the two entries above for Tq != Tk and separate q / k / v operands, no relative positions: the GPT-2 decoder's causal self-attention and its cross-attention over the
  * encoder frames in training (multi_head_gpt2.py:80-170).  lse (B, H, Tq); prob / ds (H, B, Tq, ldsr) bf16, ldsr % 32 == 0, ldsr >= Tk rounded up to 32; dq = dS K. */
 int mi_attention_x_lse_bf16(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const int* lengths, void* out, long ldo, float* lse,
