@@ -1,7 +1,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r4pmc
+O=$GRAFT_REPO_ROOT/gpurun_out/${1:-r5pmc}
 rm -rf $O; mkdir -p $O
 CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary --streams 1"
 i=0
