@@ -1155,3 +1155,46 @@ def test_small_fused_passes_of_the_attention_backward():
     torch.testing.assert_close(oa.double(), wa, atol=2e-4, rtol=1e-5)
     torch.testing.assert_close(ob.double(), wb, atol=2e-4, rtol=1e-5)
     assert torch.equal(oa, oa2) and torch.equal(ob, ob2)                            # no atomics: the same bits every time
+
+
+@pytest.mark.parametrize("T_,H,hd", [(250, 4, 128), (500, 2, 64), (97, 2, 64)])
+def test_attention_backward_sparse_writes_leave_the_products_unchanged(T_, H, hd):
+    """Round 5: with `sparse=True` the fused walk does not write the zeros nobody reads — its dBD buffer is zero-filled once per shape and re-used by every call, P / dS hold
+    garbage from the key length rounded up to 128 on.  What the trainer computes from them — dV = P^T dctx and dK = dS^T (q + u) through `bgemm(..., m_valid=lengths)`, the
+    position gradient dBD^T (q + v) through the banded product — must be the bits of the dense-write walk, also when the SAME buffer was written by an earlier call with LONGER
+    utterances (whatever that call left beyond the new lengths must have been zeroed again), and dQ / the bias sums come from the same walk either way."""
+    ops, T = _o()
+    B, d, Tq = 4, H * hd, T_
+    qkv = torch.cat([bfr(rnd(B * Tq, d, seed=700 + i, scale=0.8)) for i in range(3)], 1).to(DEV, BF)
+    pos = dev16(bfr(rnd(2 * Tq - 1, d, seed=705, scale=0.8)))
+    u, vb = (0.2 * rnd(H, hd, seed=706)).to(DEV), (0.2 * rnd(H, hd, seed=707)).to(DEV)
+    dctx = dev16(bfr(rnd(B * Tq, d, seed=708)))
+    pad, Ps = T.band_geometry(Tq)
+    off = pad
+    long_len = torch.tensor([Tq, Tq - 3, Tq, Tq - 1], dtype=torch.int32, device=DEV)
+    short_len = torch.tensor([max(1, Tq // 3), max(1, Tq // 2 + 5), 7, max(1, Tq - 40)], dtype=torch.int32, device=DEV)
+
+    def run(lengths, sparse):
+        lse = torch.empty((B, H, Tq), device=DEV, dtype=torch.float32)
+        ctx = ops.attention_qkv(qkv, B, Tq, H, lse=lse, pos=pos, bias_u=u, bias_v=vb, lengths=lengths)
+        dq = torch.full((B * Tq, d), float("nan"), device=DEV, dtype=BF)
+        prob, ds, dbd, su, sv, qu, qv = T.attn_bwd_probs(qkv, B, Tq, H, ctx, dctx, lse, dq, pos=pos, bias_u=u, bias_v=vb, lengths=lengths, qb=True, sparse=sparse)
+        Ts = prob.shape[-1]
+        sTT = (B * Tq * Ts, Tq * Ts)
+        dv = torch.full((B * Tq, d), float("nan"), device=DEV, dtype=BF)
+        dk = torch.full((B * Tq, d), float("nan"), device=DEV, dtype=BF)
+        T.bgemm(prob, (*sTT, 1, Ts), dctx, (hd, Tq * d, 1, d), dv, (hd, Tq * d, d), H, B, Tq, hd, Tq, m_valid=lengths)
+        T.bgemm(ds, (*sTT, 1, Ts), qu, (hd, Tq * d, 1, d), dk, (hd, Tq * d, d), H, B, Tq, hd, Tq, m_valid=lengths)
+        Kp = Ps
+        dpp = torch.full((B, Kp * d), float("nan"), device=DEV, dtype=torch.float32)
+        T.bgemm(dbd, (B * Tq * Ps, Tq * Ps, 1, Ps), qv, (hd, Tq * d, 1, d), dpp, (hd, Kp * d, d), H, B, Kp, hd, Tq, band=(Tq, Tq - 1 + off, 1))
+        torch.cuda.synchronize()
+        return dq.clone(), su.clone(), sv.clone(), dv, dk, dpp
+
+    want_long, want_short = run(long_len, False), run(short_len, False)
+    got_long = run(long_len, True)                       # fills the static buffer's maximal band
+    got_short = run(short_len, True)                     # ... and must clear what the long call left beyond the short lengths
+    got_long2 = run(long_len, True)
+    for name, want, got in (("long", want_long, got_long), ("short after long", want_short, got_short), ("long again", want_long, got_long2)):
+        for w, g_, what in zip(want, got, ("dQ", "su", "sv", "dV", "dK", "d(posp) partials")):
+            assert torch.equal(w, g_), (name, what, float((w.float() - g_.float()).abs().max()))

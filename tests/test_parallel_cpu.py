@@ -86,3 +86,43 @@ def test_bench_roofline_traffic_comes_from_the_committed_pmc_table():
         sys.argv = argv
     traffic, src = mod.pmc_traffic_bytes()
     assert traffic is not None and 30e6 < traffic < 120e6 and src.startswith("profiles/"), (traffic, src)
+
+
+def test_unpadded_flop_accounting_equals_the_padded_one_on_full_length_clips():
+    """bench.py's config-3 FLOP accounting: counting every clip at its own length must reproduce the padded figure when every clip fills the bucket,
+    and must be smaller — by about half for uniform 1-20 s clips — otherwise."""
+    import importlib.util
+    import os
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from huggingface_asr_amd import shapes
+    cfg, dcfg = dict(shapes.SMALL), dict(vocab_size=5000, n_embd=256, n_layer=6)
+    full = bench.config3_gflop_per_step(cfg, dcfg, 96, 500, 60)
+    assert abs(bench.config3_gflop_per_step_unpadded(cfg, dcfg, [2000] * 96, [60] * 96) - full) < 1e-6 * full
+    fl = np.sort(np.random.default_rng(0).integers(100, 2001, size=96))[::-1]
+    part = bench.config3_gflop_per_step_unpadded(cfg, dcfg, fl, [max(2, int(f / 100 * 3)) for f in fl])
+    assert 0.4 * full < part < 0.65 * full
+
+
+def test_lanes_trace_summary_on_a_synthetic_trace(tmp_path):
+    """tools/lanes_trace.py (the `roofline.in_flight.trace` block): wall shares by interval union, busy time by family, on a hand-made two-lane trace."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import lanes_trace
+    rows = ["Kernel_Name,Start_Timestamp,End_Timestamp,Grid_Size_X,Workgroup_Size_X"]
+    t = 0
+    for step in range(6):                                  # per step: fbank 10 us, a GEMM 100 us overlapping a dwconv (from the other lane) for 50 us, 20 us of nothing
+        rows.append(f"fbank_kernel,{t},{t + 10000},1024,256")
+        rows.append(f"\"void gemm8p_kernel<false, 1, false>(GemmArgs)\",{t + 10000},{t + 110000},131072,512")
+        rows.append(f"\"void dwconv31_kernel<true>(DwArgs)\",{t + 60000},{t + 130000},2048,256")
+        t += 150000
+    p = tmp_path / "kernel_trace.csv"
+    p.write_text("\n".join(rows) + "\n")
+    rec = lanes_trace.summarise([str(p)], skip=0.0)
+    assert rec["steps"] == 5                                # from the first fbank launch to the last one
+    assert abs(rec["wall_share_dense_running"] - 100 / 150) < 1e-3 and abs(rec["wall_share_only_other_kernels"] - 30 / 150) < 1e-3 and abs(rec["wall_share_idle"] - 20 / 150) < 1e-3
+    assert abs(rec["non_gemm_share_of_busy"] - 80 / 180) < 1e-3
+    assert rec["families"]["dense: 256x256 GEMMs (FFN in, cgMLP in, QKV)"]["launches_per_step"] == 1.0
