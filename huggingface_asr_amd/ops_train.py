@@ -363,17 +363,25 @@ def attn_x_bwd_probs(q, k, v, B, Tq, Tk, H, ctx, dctx, lse, dq, *, lengths=None,
     return prob, ds
 
 
-_DBD_CACHE = {}          # device -> (key, zero-filled dbd buffer of the sparse-writes walk)
+_DBD_CACHE = {}          # (device, H, B, T, Ps) -> zero-filled dbd buffer of the sparse-writes walk; at most three shapes per process (least recently used goes first)
 
 
 def _dbd_static(dev, H, B, T, Ps):
     """the sparse-writes walk's dbd: zero-filled ONCE per shape and then only ever written by that walk (relative positions outside a row's maximal band stay zero from
-    launch to launch); one buffer per device — a new shape replaces it"""
-    key = (H, B, T, Ps)
-    got = _DBD_CACHE.get(dev)
-    if got is None or got[0] != key:
-        _DBD_CACHE[dev] = got = (key, torch.zeros((H, B, T, Ps), device=dev, dtype=BF16))
-    return got[1]
+    launch to launch).  Length-bucketed training alternates between a few shapes: three buffers are kept, so that a shape coming back does not pay its 400-MB fill again."""
+    key = (str(dev), H, B, T, Ps)
+    buf = _DBD_CACHE.pop(key, None)
+    if buf is None:
+        while len(_DBD_CACHE) >= 3:
+            _DBD_CACHE.pop(next(iter(_DBD_CACHE)))
+        buf = torch.zeros((H, B, T, Ps), device=dev, dtype=BF16)
+    _DBD_CACHE[key] = buf                                   # (re-)inserted last: most recently used
+    return buf
+
+
+def release_static_buffers():
+    """frees the buffers `_dbd_static` keeps between steps (call when a trainer is done with the device)"""
+    _DBD_CACHE.clear()
 
 
 def attn_bwd_probs(qkv, B, T, H, ctx, dctx, lse, dq, *, pos=None, bias_u=None, bias_v=None, lengths=None, causal=False, drop=None, qb=False, sparse=False):
