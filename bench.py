@@ -105,7 +105,7 @@ def rocprof_child_dense_us(args, B, per_step):
         cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", td, "--", sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", "2",
                "--batch", str(B), "--pos", args.pos, "--streams", "1", "--no-cpu-baseline", "--no-kernel-events", "--no-secondary"]
         try:
-            r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+            r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)      # ~20 s when all is well
         except Exception as e:  # noqa: BLE001
             return None, 0, f"rocprofv3 child failed: {type(e).__name__}"
         files = glob.glob(os.path.join(td, "**", "*kernel_trace.csv"), recursive=True)
@@ -149,7 +149,7 @@ def rocprof_child_in_flight(args, B):
         cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", td, "--", sys.executable, os.path.abspath(__file__), "--steps", "24", "--warmup", "8", "--batch", str(B),
                "--pos", args.pos, "--streams", str(args.streams), "--wide-tiles", str(int(args.wide_tiles)), "--no-cpu-baseline", "--no-kernel-events", "--no-secondary", "--no-one-step"]
         try:
-            r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150)      # ~20 s when all is well
         except Exception as e:  # noqa: BLE001
             return {"error": f"rocprofv3 child failed: {type(e).__name__}"}
         files = glob.glob(os.path.join(td, "**", "*kernel_trace.csv"), recursive=True)
