@@ -57,7 +57,8 @@ def pmc_traffic_bytes(kernel_prefix="gemm8p_kernel<false, 1"):
         return None, None
     for f in reversed(files):                                  # the newest table that has the kernel (tables of other commands — the training step — live beside it)
         for line in open(f):
-            if line.startswith(kernel_prefix) and ", true>" in line.split("|")[0]:        # the LayerNorm-folded consumer the forward step runs
+            targs = line.split("|")[0].split("<", 1)[-1].rsplit(">", 1)[0].split(", ")
+            if line.startswith(kernel_prefix) and len(targs) >= 5 and targs[4].strip() == "true":      # the LayerNorm-folded consumer the forward step runs (template argument LNF)
                 cols = [c.strip() for c in line.split("|")]
                 return (float(cols[3]) + float(cols[4])) * 1e6, os.path.relpath(f, ROOT)
     return None, None
